@@ -1,0 +1,75 @@
+"""Seeded synthetic detection streams; shared by tests, bench.py and the CPU baseline.
+
+World 1920x1080, P persistent objects on a jittered grid, constant velocity U(-3,3) px/frame plus
+N(0, 0.5^2) jitter, w ~ U(30,90), h = w * U(1.8,2.6), reflected at the borders. Every frame emits M of
+the P objects (seeded permutation) with N(0,1 px) box noise; 90 % of the emitted detections get
+conf ~ U(0.5,1.0), 10 % get U(0.12,0.44) (so ByteTrack's low-score stage runs); cls = 0.
+Optional D-dim appearance: one unit vector per object + N(0, 0.05^2) noise, renormalised.
+"""
+import numpy as np
+
+W, H = 1920.0, 1080.0
+
+
+class SynthStream:
+    def __init__(self, P, M, seed=1234, emb_dim=0):
+        self.P, self.M, self.D = int(P), int(M), int(emb_dim)
+        self.rng = np.random.Generator(np.random.MT19937(int(seed)))
+        r = self.rng
+        gx = int(np.ceil(np.sqrt(P * W / H)))
+        gy = int(np.ceil(P / gx))
+        idx = np.arange(P)
+        cx = (idx % gx + 0.5) * (W / gx) + r.uniform(-0.3, 0.3, P) * (W / gx)
+        cy = (idx // gx + 0.5) * (H / gy) + r.uniform(-0.3, 0.3, P) * (H / gy)
+        self.c = np.stack([cx, cy], 1)
+        self.v = r.uniform(-3.0, 3.0, (P, 2))
+        self.w = r.uniform(30.0, 90.0, P)
+        self.h = self.w * r.uniform(1.8, 2.6, P)
+        if self.D:
+            e = r.standard_normal((P, self.D))
+            self.e = e / np.linalg.norm(e, axis=1, keepdims=True)
+        self.frame = 0
+
+    def next_frame(self):
+        r = self.rng
+        self.c = self.c + self.v + r.normal(0.0, 0.5, (self.P, 2))
+        for k, lim in ((0, W), (1, H)):
+            lo = self.c[:, k] < 0
+            hi = self.c[:, k] > lim
+            self.c[lo, k] = -self.c[lo, k]
+            self.c[hi, k] = 2 * lim - self.c[hi, k]
+            self.v[lo | hi, k] = -self.v[lo | hi, k]
+        sel = r.permutation(self.P)[: self.M]
+        n = r.normal(0.0, 1.0, (self.M, 4))
+        x1 = self.c[sel, 0] - self.w[sel] / 2 + n[:, 0]
+        y1 = self.c[sel, 1] - self.h[sel] / 2 + n[:, 1]
+        x2 = self.c[sel, 0] + self.w[sel] / 2 + n[:, 2]
+        y2 = self.c[sel, 1] + self.h[sel] / 2 + n[:, 3]
+        low = r.uniform(0, 1, self.M) < 0.10
+        conf = np.where(low, r.uniform(0.12, 0.44, self.M), r.uniform(0.5, 1.0, self.M))
+        dets = np.stack([x1, y1, x2, y2, conf, np.zeros(self.M)], 1).astype(np.float32)
+        embs = None
+        if self.D:
+            e = self.e[sel] + r.normal(0.0, 0.05, (self.M, self.D))
+            embs = (e / np.linalg.norm(e, axis=1, keepdims=True)).astype(np.float32)
+        self.frame += 1
+        return dets, embs
+
+    def frames(self, n):
+        """n frames as arrays: dets [n, M, 6] (and embs [n, M, D] or None)."""
+        ds, es = [], []
+        for _ in range(n):
+            d, e = self.next_frame()
+            ds.append(d)
+            es.append(e)
+        return np.stack(ds), (np.stack(es) if self.D else None)
+
+
+CONFIGS = {
+    # name: (tracker, P, M, emb_dim)
+    "C2": ("bytetrack", 256, 128, 0),
+    "C3": ("botsort", 1024, 512, 256),
+    "C4": ("ocsort", 4096, 2048, 0),
+    "C5": ("bytetrack", 1000, 512, 0),
+    "NS": ("bytetrack", 1000, 500, 0),
+}

@@ -1,0 +1,278 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.hpp header).
+// Flat C entry points over the CPU restatement so tests/ and bench.py's cpu_baseline leg can
+// drive it through ctypes. Nothing in the product links or loads this library.
+#include <cstring>
+#include <memory>
+#include <variant>
+
+#include "orc_trackers.hpp"
+
+using namespace orc;
+
+namespace {
+struct Handle {
+  int kind;
+  std::unique_ptr<Sort> sort;
+  std::unique_ptr<ByteTrack> byte;
+  std::unique_ptr<OCSort> oc;
+  std::unique_ptr<BotSort> bot;
+  const std::vector<LapResult>* laps() const {
+    switch (kind) {
+      case 1: return &byte->laps;
+      case 2: return &oc->laps;
+      case 3: return &bot->laps;
+      default: return nullptr;
+    }
+  }
+  std::vector<LapResult> sort_laps;
+};
+float P(const float* p, int n, int i, float dflt) { return (p && i < n) ? p[i] : dflt; }
+Mat as_mat(const float* a, int r, int c) {
+  Mat m(r, c);
+  if (r * c > 0) std::memcpy(m.a.data(), a, sizeof(float) * static_cast<size_t>(r) * c);
+  return m;
+}
+}  // namespace
+
+extern "C" {
+
+// kind: 0 SORT, 1 ByteTrack, 2 OC-SORT, 3 BoT-SORT. Parameter vectors (missing tail = defaults):
+//  SORT     [det_thresh, max_age, max_obs, min_hits, iou_threshold]
+//  ByteTrack[min_conf, track_thresh, match_thresh, track_buffer, frame_rate, max_age, max_obs]
+//  OC-SORT  [det_thresh, max_age, max_obs, min_hits, iou_threshold, min_conf, delta_t, inertia, use_byte, Q_xy, Q_s]
+//  BoT-SORT [track_high, track_low, new_track, track_buffer, match_thresh, proximity, appearance,
+//            frame_rate, fuse_first_associate, with_reid, max_age, max_obs]
+void* orc_tracker_create(int kind, const float* p, int np) {
+  auto* h = new Handle();
+  h->kind = kind;
+  switch (kind) {
+    case 0:
+      h->sort = std::make_unique<Sort>(P(p, np, 0, 0.3f), (int)P(p, np, 1, 1), (int)P(p, np, 2, 50),
+                                       (int)P(p, np, 3, 3), P(p, np, 4, 0.3f));
+      break;
+    case 1:
+      h->byte = std::make_unique<ByteTrack>(P(p, np, 0, 0.1f), P(p, np, 1, 0.45f), P(p, np, 2, 0.8f),
+                                            (int)P(p, np, 3, 25), (int)P(p, np, 4, 30),
+                                            (int)P(p, np, 5, 30), (int)P(p, np, 6, 50));
+      break;
+    case 2:
+      h->oc = std::make_unique<OCSort>(P(p, np, 0, 0.2f), (int)P(p, np, 1, 30), (int)P(p, np, 2, 50),
+                                       (int)P(p, np, 3, 3), P(p, np, 4, 0.3f), P(p, np, 5, 0.1f),
+                                       (int)P(p, np, 6, 3), P(p, np, 7, 0.2f), P(p, np, 8, 0.f) != 0.f,
+                                       P(p, np, 9, 0.01f), P(p, np, 10, 0.0001f));
+      break;
+    case 3:
+      h->bot = std::make_unique<BotSort>(P(p, np, 0, 0.5f), P(p, np, 1, 0.1f), P(p, np, 2, 0.6f),
+                                         (int)P(p, np, 3, 30), P(p, np, 4, 0.8f), P(p, np, 5, 0.5f),
+                                         P(p, np, 6, 0.25f), (int)P(p, np, 7, 30), P(p, np, 8, 0.f) != 0.f,
+                                         P(p, np, 9, 1.f) != 0.f, (int)P(p, np, 10, 30), (int)P(p, np, 11, 50));
+      break;
+    default:
+      delete h;
+      return nullptr;
+  }
+  return h;
+}
+void orc_tracker_destroy(void* hv) { delete static_cast<Handle*>(hv); }
+void orc_tracker_reset(void* hv) {
+  auto* h = static_cast<Handle*>(hv);
+  if (h->sort) h->sort->reset();
+  if (h->byte) h->byte->reset();
+  if (h->oc) h->oc->reset();
+  if (h->bot) h->bot->reset();
+}
+
+// dets: row-major n x 6. embs: row-major n x d or null. out: row-major cap x 8. Returns rows (or -needed).
+int orc_tracker_update(void* hv, const float* dets, int n, const float* embs, int d, float* out, int cap) {
+  auto* h = static_cast<Handle*>(hv);
+  OutTable t;
+  switch (h->kind) {
+    case 0:
+      t = h->sort->update(dets, n);
+      h->sort_laps.clear();
+      if (!h->sort->last_lap.x.empty() || !h->sort->last_lap.y.empty()) h->sort_laps.push_back(h->sort->last_lap);
+      h->sort->last_lap = LapResult();
+      break;
+    case 1: t = h->byte->update(dets, n); break;
+    case 2: t = h->oc->update(dets, n); break;
+    case 3: t = h->bot->update(dets, n, embs, d); break;
+  }
+  const int rows = static_cast<int>(t.size());
+  if (rows > cap) return -rows;
+  for (int i = 0; i < rows; ++i) std::memcpy(out + static_cast<size_t>(i) * 8, t[i].data(), 8 * sizeof(float));
+  return rows;
+}
+int orc_tracker_lap_count(void* hv) {
+  auto* h = static_cast<Handle*>(hv);
+  if (h->kind == 0) return static_cast<int>(h->sort_laps.size());
+  return static_cast<int>(h->laps()->size());
+}
+// copies x (n) and y (m) of the k-th assignment solved during the last update
+int orc_tracker_lap_get(void* hv, int k, int* n, int* m, int* x, int* y, int cap) {
+  auto* h = static_cast<Handle*>(hv);
+  const std::vector<LapResult>& v = (h->kind == 0) ? h->sort_laps : *h->laps();
+  if (k < 0 || k >= static_cast<int>(v.size())) return -1;
+  *n = static_cast<int>(v[k].x.size());
+  *m = static_cast<int>(v[k].y.size());
+  if (*n > cap || *m > cap) return -2;
+  std::memcpy(x, v[k].x.data(), sizeof(int) * *n);
+  std::memcpy(y, v[k].y.data(), sizeof(int) * *m);
+  return 0;
+}
+// state dump: rows of [id, mean(d), cov(d*d)] — returns number of rows, row width in *w
+int orc_tracker_dump_states(void* hv, float* out, int cap_floats, int* w) {
+  auto* h = static_cast<Handle*>(hv);
+  std::vector<std::vector<float>> s;
+  switch (h->kind) {
+    case 0: s = h->sort->dump_states(); break;
+    case 1: s = h->byte->dump_states(); break;
+    case 2: s = h->oc->dump_states(); break;
+    case 3: s = h->bot->dump_states(); break;
+  }
+  *w = s.empty() ? 0 : static_cast<int>(s[0].size());
+  size_t need = s.size() * static_cast<size_t>(*w);
+  if (need > static_cast<size_t>(cap_floats)) return -static_cast<int>(s.size());
+  for (size_t i = 0; i < s.size(); ++i) std::memcpy(out + i * *w, s[i].data(), sizeof(float) * *w);
+  return static_cast<int>(s.size());
+}
+
+// ---- primitives (row-major everywhere) -------------------------------------------------
+void orc_iou_batch(const float* a, int n, int ca, const float* b, int m, int cb, float* out) {
+  Mat r = iou_batch(as_mat(a, n, ca), as_mat(b, m, cb));
+  if (r.size()) std::memcpy(out, r.a.data(), sizeof(float) * r.size());
+}
+void orc_iou_distance(const float* a, int n, const float* b, int m, float* out) {
+  Mat r = iou_distance(as_mat(a, n, 4), as_mat(b, m, 4));
+  if (r.size()) std::memcpy(out, r.a.data(), sizeof(float) * r.size());
+}
+void orc_fuse_score(const float* cost, int n, int m, const float* conf, float* out) {
+  Mat r = fuse_score(as_mat(cost, n, m), std::vector<float>(conf, conf + m));
+  if (r.size()) std::memcpy(out, r.a.data(), sizeof(float) * r.size());
+}
+void orc_cosine_distance(const float* t, int n, const float* dd, int m, int d, float* out) {
+  Mat r = embedding_distance_cosine(as_mat(t, n, d), as_mat(dd, m, d));
+  if (r.size()) std::memcpy(out, r.a.data(), sizeof(float) * r.size());
+}
+// x: n ints, y: m ints (-1 = unmatched)
+void orc_linear_assignment(const float* cost, int n, int m, float thresh, int* x, int* y) {
+  LapResult r = linear_assignment(as_mat(cost, n, m), thresh);
+  if (n) std::memcpy(x, r.x.data(), sizeof(int) * n);
+  if (m) std::memcpy(y, r.y.data(), sizeof(int) * m);
+}
+// OC-SORT first-stage association (ocsort.cpp:610-738). dets nd x 5, trks nt x 5, vel nt x 2, prev nt x 5.
+// Writes matches as (det,trk) pairs; um lists may contain duplicates (Q4). Returns match count.
+int orc_ocsort_associate(const float* dets, int nd, const float* trks, int nt, const float* vel,
+                         const float* prev, float thr, float vdc, int* matches, int* um_d, int* n_umd,
+                         int* um_t, int* n_umt, int* used_lap) {
+  OCSort o;
+  OCSort::Assoc a = o.associate(as_mat(dets, nd, 5), as_mat(trks, nt, 5), thr, as_mat(vel, nt, 2),
+                                as_mat(prev, nt, 5), vdc);
+  for (size_t i = 0; i < a.matches.size(); ++i) { matches[2 * i] = a.matches[i][0]; matches[2 * i + 1] = a.matches[i][1]; }
+  *n_umd = static_cast<int>(a.um_dets.size());
+  *n_umt = static_cast<int>(a.um_trks.size());
+  std::memcpy(um_d, a.um_dets.data(), sizeof(int) * a.um_dets.size());
+  std::memcpy(um_t, a.um_trks.data(), sizeof(int) * a.um_trks.size());
+  *used_lap = o.laps.empty() ? 0 : 1;
+  return static_cast<int>(a.matches.size());
+}
+// OC-SORT final cost matrix -(iou + angle) and the iou matrix, both nd x nt (for kernel parity)
+void orc_ocsort_cost(const float* dets, int nd, const float* trks, int nt, const float* vel,
+                     const float* prev, float vdc, float* cost, float* iou) {
+  Mat D = as_mat(dets, nd, 5), T = as_mat(trks, nt, 5), V = as_mat(vel, nt, 2), Pv = as_mat(prev, nt, 5);
+  Mat I = iou_batch(D, T);
+  for (int i = 0; i < nt; ++i)
+    for (int j = 0; j < nd; ++j) {
+      float cx1 = (D(j, 0) + D(j, 2)) / 2.0f, cy1 = (D(j, 1) + D(j, 3)) / 2.0f;
+      float cx2 = (Pv(i, 0) + Pv(i, 2)) / 2.0f, cy2 = (Pv(i, 1) + Pv(i, 3)) / 2.0f;
+      float dx = cx1 - cx2, dy = cy1 - cy2;
+      float norm = std::sqrt(dx * dx + dy * dy) + 1e-6f;
+      float Y = dy / norm, X = dx / norm;
+      float c = V(i, 1) * X + V(i, 0) * Y;
+      c = std::min(std::max(c, -1.0f), 1.0f);
+      const float PI = 3.14159265358979323846f;
+      float da = (PI / 2.0f - std::fabs(OCSort::acos_f32(c))) / PI;
+      float valid = (Pv(i, 4) >= 0.0f) ? 1.0f : 0.0f;
+      float a = ((valid * da) * vdc) * D(j, 4);
+      cost[static_cast<size_t>(j) * nt + i] = -(I(j, i) + a);
+      iou[static_cast<size_t>(j) * nt + i] = I(j, i);
+    }
+}
+
+// ---- Kalman primitives on arrays of states ---------------------------------------------
+// kind 0 XYSR (d=7), 1 XYAH (d=8), 2 XYWH (d=8). mean: n x d, cov: n x d x d, row-major.
+// XYSR extra: q = [Q44, Q55, Q66] process-noise diagonal entries (others 1), may be null.
+static void load_xysr(KfXYSR& k, const float* mean, const float* cov, const float* q) {
+  for (int i = 0; i < 7; ++i) k.x[i] = mean[i];
+  for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) k.P[i][j] = cov[i * 7 + j];
+  if (q) { k.Q[4][4] = q[0]; k.Q[5][5] = q[1]; k.Q[6][6] = q[2]; }
+}
+static void store_xysr(const KfXYSR& k, float* mean, float* cov) {
+  for (int i = 0; i < 7; ++i) mean[i] = k.x[i];
+  for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) cov[i * 7 + j] = k.P[i][j];
+}
+static void load8(State8& s, const float* mean, const float* cov) {
+  for (int i = 0; i < 8; ++i) s.mean[i] = mean[i];
+  for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) s.cov[i][j] = cov[i * 8 + j];
+}
+static void store8(const State8& s, float* mean, float* cov) {
+  for (int i = 0; i < 8; ++i) mean[i] = s.mean[i];
+  for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) cov[i * 8 + j] = s.cov[i][j];
+}
+void orc_kf_initiate(int kind, int n, const float* meas, const float* q, float* mean, float* cov) {
+  (void)q;
+  for (int t = 0; t < n; ++t) {
+    const float* z = meas + 4 * t;
+    if (kind == 0) {
+      KfXYSR k;
+      for (int i = 0; i < 4; ++i) k.x[i] = z[i];
+      store_xysr(k, mean + 7 * t, cov + 49 * t);
+    } else {
+      State8 s = (kind == 1) ? KfXYAH::initiate(z) : KfXYWH::initiate(z);
+      store8(s, mean + 8 * t, cov + 64 * t);
+    }
+  }
+}
+void orc_kf_predict(int kind, int n, const float* q, float* mean, float* cov) {
+  for (int t = 0; t < n; ++t) {
+    if (kind == 0) {
+      KfXYSR k; load_xysr(k, mean + 7 * t, cov + 49 * t, q);
+      k.predict(); store_xysr(k, mean + 7 * t, cov + 49 * t);
+    } else {
+      State8 s; load8(s, mean + 8 * t, cov + 64 * t);
+      if (kind == 1) KfXYAH::predict(s); else KfXYWH::predict(s);
+      store8(s, mean + 8 * t, cov + 64 * t);
+    }
+  }
+}
+void orc_kf_update(int kind, int n, const float* meas, const float* q, float* mean, float* cov) {
+  for (int t = 0; t < n; ++t) {
+    const float* z = meas + 4 * t;
+    if (kind == 0) {
+      KfXYSR k; load_xysr(k, mean + 7 * t, cov + 49 * t, q);
+      k.update(z); store_xysr(k, mean + 7 * t, cov + 49 * t);
+    } else {
+      State8 s; load8(s, mean + 8 * t, cov + 64 * t);
+      if (kind == 1) KfXYAH::update(s, z); else KfXYWH::update(s, z);
+      store8(s, mean + 8 * t, cov + 64 * t);
+    }
+  }
+}
+// box conversions exposed for known-answer tests: op 0 xyxy2xysr, 1 xysr2xyxy, 2 xyxy2xywh, 3 xywh2xyxy,
+// 4 xywh2tlwh, 5 tlwh2xyah, 6 xyah2xywh
+void orc_box_convert(int op, int n, const float* in, float* out) {
+  for (int i = 0; i < n; ++i) {
+    Box b{in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3]}, r{};
+    switch (op) {
+      case 0: r = xyxy2xysr(b); break;
+      case 1: r = xysr2xyxy(b); break;
+      case 2: r = xyxy2xywh(b); break;
+      case 3: r = xywh2xyxy(b); break;
+      case 4: r = xywh2tlwh(b); break;
+      case 5: r = tlwh2xyah(b); break;
+      case 6: r = xyah2xywh(b); break;
+    }
+    for (int k = 0; k < 4; ++k) out[4 * i + k] = r[k];
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,349 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.hpp header).
+//
+// CPU restatement of motcpp's three Kalman filters, fp32, dense small-matrix loops in the
+// same expression order as the reference's Eigen expressions, every inner product summed
+// in k order, no FMA contraction:
+//   KalmanFilterXYSR            src/motion/kalman_filters/xysr_kf.cpp:10-112
+//   BaseKalmanFilter + XYAH     src/motion/kalman_filter.cpp:29-112, kalman_filters/xyah_kf.cpp:14-62
+//   KalmanFilterXYWH            include/motcpp/motion/kalman_filters/xywh_kf.hpp:41-135
+// Parity status: the reference's tests pin only XYSR, loosely (tests/test_kalman_filter.cpp).
+// Eigen (un-vendored dependency, any 3.3+) is absent here, so the rounding order inside its
+// GEMM / LLT / PartialPivLU kernels is restated from its documented algorithms
+// (unblocked Cholesky, column-axpy forward / row-dot backward substitution, partial-pivot
+// Doolittle LU) — "parity unpinned" at the last-bit level, 1e-4 relative by contract.
+#pragma once
+#include <cmath>
+#include <utility>
+
+namespace orc {
+
+template <int R, int C>
+struct SMat {
+  float a[R][C];
+  float* operator[](int i) { return a[i]; }
+  const float* operator[](int i) const { return a[i]; }
+  static SMat zero() {
+    SMat m;
+    for (int i = 0; i < R; ++i)
+      for (int j = 0; j < C; ++j) m.a[i][j] = 0.0f;
+    return m;
+  }
+  static SMat identity() {
+    SMat m = zero();
+    for (int i = 0; i < (R < C ? R : C); ++i) m.a[i][i] = 1.0f;
+    return m;
+  }
+};
+
+template <int R, int K, int C>
+inline SMat<R, C> mul(const SMat<R, K>& A, const SMat<K, C>& B) {
+  SMat<R, C> o;
+  for (int i = 0; i < R; ++i)
+    for (int j = 0; j < C; ++j) {
+      float s = A[i][0] * B[0][j];
+      for (int k = 1; k < K; ++k) s += A[i][k] * B[k][j];
+      o[i][j] = s;
+    }
+  return o;
+}
+template <int R, int C>
+inline SMat<C, R> transpose(const SMat<R, C>& A) {
+  SMat<C, R> o;
+  for (int i = 0; i < R; ++i)
+    for (int j = 0; j < C; ++j) o[j][i] = A[i][j];
+  return o;
+}
+template <int R, int C>
+inline SMat<R, C> add(const SMat<R, C>& A, const SMat<R, C>& B) {
+  SMat<R, C> o;
+  for (int i = 0; i < R; ++i)
+    for (int j = 0; j < C; ++j) o[i][j] = A[i][j] + B[i][j];
+  return o;
+}
+template <int R, int C>
+inline SMat<R, C> sub(const SMat<R, C>& A, const SMat<R, C>& B) {
+  SMat<R, C> o;
+  for (int i = 0; i < R; ++i)
+    for (int j = 0; j < C; ++j) o[i][j] = A[i][j] - B[i][j];
+  return o;
+}
+
+// Unblocked lower Cholesky (Eigen llt_inplace<Lower>::unblocked): diagonal first, then the
+// column below it; inner sums are formed first and subtracted once.
+template <int N>
+inline bool cholesky(SMat<N, N>& A) {
+  for (int k = 0; k < N; ++k) {
+    float x = A[k][k];
+    if (k > 0) {
+      float s = A[k][0] * A[k][0];
+      for (int j = 1; j < k; ++j) s += A[k][j] * A[k][j];
+      x -= s;
+    }
+    if (!(x > 0.0f)) return false;
+    x = std::sqrt(x);
+    A[k][k] = x;
+    for (int i = k + 1; i < N; ++i) {
+      float t = A[i][k];
+      if (k > 0) {
+        float s = A[i][0] * A[k][0];
+        for (int j = 1; j < k; ++j) s += A[i][j] * A[k][j];
+        t -= s;
+      }
+      A[i][k] = t / x;
+    }
+  }
+  return true;
+}
+// Solve (L L^T) z = b in place: forward substitution column-axpy style, backward row-dot style.
+template <int N>
+inline void chol_solve(const SMat<N, N>& L, float* b) {
+  for (int i = 0; i < N; ++i) {
+    b[i] /= L[i][i];
+    for (int r = i + 1; r < N; ++r) b[r] -= b[i] * L[r][i];
+  }
+  for (int i = N - 1; i >= 0; --i) {
+    if (i < N - 1) {
+      float s = L[i + 1][i] * b[i + 1];
+      for (int j = i + 2; j < N; ++j) s += L[j][i] * b[j];
+      b[i] -= s;
+    }
+    b[i] /= L[i][i];
+  }
+}
+
+// Partial-pivot LU inverse of a 4x4 (Eigen's dynamic-size inverse() = partialPivLu().inverse()).
+inline SMat<4, 4> inverse_lu4(const SMat<4, 4>& S) {
+  SMat<4, 4> lu = S;
+  int perm[4] = {0, 1, 2, 3};
+  for (int k = 0; k < 4; ++k) {
+    int p = k;
+    float best = std::fabs(lu[k][k]);
+    for (int i = k + 1; i < 4; ++i) {
+      float v = std::fabs(lu[i][k]);
+      if (v > best) { best = v; p = i; }
+    }
+    if (p != k) {
+      for (int j = 0; j < 4; ++j) std::swap(lu[k][j], lu[p][j]);
+      std::swap(perm[k], perm[p]);
+    }
+    for (int i = k + 1; i < 4; ++i) lu[i][k] /= lu[k][k];
+    for (int i = k + 1; i < 4; ++i)
+      for (int j = k + 1; j < 4; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+  }
+  SMat<4, 4> inv;
+  for (int c = 0; c < 4; ++c) {
+    float b[4];
+    for (int i = 0; i < 4; ++i) b[i] = (perm[i] == c) ? 1.0f : 0.0f;
+    for (int i = 0; i < 4; ++i)  // unit-lower forward, column-axpy
+      for (int r = i + 1; r < 4; ++r) b[r] -= b[i] * lu[r][i];
+    for (int i = 3; i >= 0; --i) {  // upper backward, column-axpy
+      b[i] /= lu[i][i];
+      for (int r = 0; r < i; ++r) b[r] -= b[i] * lu[r][i];
+    }
+    for (int i = 0; i < 4; ++i) inv[i][c] = b[i];
+  }
+  return inv;
+}
+
+// ---------------------------------------------------------------------------------------
+// KalmanFilterXYSR — xysr_kf.cpp:10-112. State [x,y,s,r,vx,vy,vs], observation [x,y,s,r].
+struct KfXYSR {
+  SMat<7, 7> F, P, Q;
+  SMat<4, 7> H;
+  SMat<4, 4> R;
+  float x[7];
+  KfXYSR() {  // :10-69
+    F = SMat<7, 7>::identity();
+    F[0][4] = 1.0f; F[1][5] = 1.0f; F[2][6] = 1.0f;
+    H = SMat<4, 7>::zero();
+    for (int i = 0; i < 4; ++i) H[i][i] = 1.0f;
+    for (float& v : x) v = 0.0f;
+    P = SMat<7, 7>::identity();
+    for (int i = 0; i < 7; ++i) P[i][i] *= 10.0f;
+    for (int i = 4; i < 7; ++i)
+      for (int j = 4; j < 7; ++j) P[i][j] *= 100.0f;
+    Q = SMat<7, 7>::identity();
+    Q[4][4] = 0.01f; Q[5][5] = 0.01f; Q[6][6] = 0.0001f;
+    R = SMat<4, 4>::identity();
+    for (int i = 2; i < 4; ++i)
+      for (int j = 2; j < 4; ++j) R[i][j] *= 10.0f;
+  }
+  void predict() {  // :71-77
+    float nx[7];
+    for (int i = 0; i < 7; ++i) {
+      float s = F[i][0] * x[0];
+      for (int k = 1; k < 7; ++k) s += F[i][k] * x[k];
+      nx[i] = s;
+    }
+    for (int i = 0; i < 7; ++i) x[i] = nx[i];
+    P = add(mul(mul(F, P), transpose(F)), Q);
+  }
+  void update(const float z[4]) {  // :79-112 (a size-0 z is the caller's no-op, :80-82)
+    float y[4];
+    for (int i = 0; i < 4; ++i) {
+      float s = H[i][0] * x[0];
+      for (int k = 1; k < 7; ++k) s += H[i][k] * x[k];
+      y[i] = z[i] - s;
+    }
+    SMat<7, 4> Ht = transpose(H);
+    SMat<4, 4> S = add(mul(mul(H, P), Ht), R);
+    SMat<4, 4> L = S;
+    SMat<4, 4> Sinv;
+    if (cholesky(L)) {
+      for (int c = 0; c < 4; ++c) {
+        float b[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        b[c] = 1.0f;
+        chol_solve(L, b);
+        for (int i = 0; i < 4; ++i) Sinv[i][c] = b[i];
+      }
+    } else {
+      Sinv = inverse_lu4(S);  // stand-in for the pseudo-inverse fallback (:98-104); never hit for SPD S
+    }
+    SMat<7, 4> K = mul(mul(P, Ht), Sinv);
+    for (int i = 0; i < 7; ++i) {
+      float s = K[i][0] * y[0];
+      for (int k = 1; k < 4; ++k) s += K[i][k] * y[k];
+      x[i] = x[i] + s;
+    }
+    SMat<7, 7> IKH = sub(SMat<7, 7>::identity(), mul(K, H));
+    SMat<7, 7> first = mul(mul(IKH, P), transpose(IKH));
+    SMat<7, 7> second = mul(mul(K, R), transpose(K));
+    P = add(first, second);
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// 8-state filters share this shape: mean[8], cov[8][8], F = I + shift(4), H = [I 0].
+struct State8 {
+  float mean[8];
+  SMat<8, 8> cov;
+};
+
+inline SMat<8, 8> motion8() {
+  SMat<8, 8> F = SMat<8, 8>::identity();
+  for (int i = 0; i < 4; ++i) F[i][4 + i] = 1.0f;  // dt = 1
+  return F;
+}
+inline SMat<4, 8> obs8() {
+  SMat<4, 8> H = SMat<4, 8>::zero();
+  for (int i = 0; i < 4; ++i) H[i][i] = 1.0f;
+  return H;
+}
+inline void predict8(State8& s, const float std8[8]) {
+  const SMat<8, 8> F = motion8();
+  float nm[8];
+  for (int i = 0; i < 8; ++i) {
+    float acc = F[i][0] * s.mean[0];
+    for (int k = 1; k < 8; ++k) acc += F[i][k] * s.mean[k];
+    nm[i] = acc;
+  }
+  SMat<8, 8> Q = SMat<8, 8>::zero();
+  for (int i = 0; i < 8; ++i) Q[i][i] = std8[i] * std8[i];
+  s.cov = add(mul(mul(F, s.cov), transpose(F)), Q);
+  for (int i = 0; i < 8; ++i) s.mean[i] = nm[i];
+}
+
+// KalmanFilterXYAH (ByteTrack) — kalman_filter.cpp + xyah_kf.cpp
+struct KfXYAH {
+  static constexpr float wp = 1.0f / 20.0f;   // kalman_filter.cpp:13
+  static constexpr float wv = 1.0f / 160.0f;  // kalman_filter.cpp:14
+  static State8 initiate(const float m[4]) {  // kalman_filter.cpp:29-42, xyah_kf.cpp:14-30
+    State8 s;
+    for (int i = 0; i < 4; ++i) { s.mean[i] = m[i]; s.mean[4 + i] = 0.0f; }
+    const float h = m[3];
+    const float sd[8] = {2.0f * wp * h, 2.0f * wp * h, 1e-2f, 2.0f * wp * h,
+                         10.0f * wv * h, 10.0f * wv * h, 1e-5f, 10.0f * wv * h};
+    s.cov = SMat<8, 8>::zero();
+    for (int i = 0; i < 8; ++i) s.cov[i][i] = sd[i] * sd[i];
+    return s;
+  }
+  static void predict(State8& s) {  // kalman_filter.cpp:44-58, xyah_kf.cpp:32-49
+    const float h = s.mean[3];
+    const float sd[8] = {wp * h, wp * h, 1e-2f, wp * h, wv * h, wv * h, 1e-5f, wv * h};
+    predict8(s, sd);
+  }
+  static void update(State8& s, const float z[4], float confidence = 0.0f) {  // kalman_filter.cpp:60-112
+    const float h = s.mean[3];
+    float sd[4] = {wp * h, wp * h, 1e-1f, wp * h};  // xyah_kf.cpp:51-62
+    for (float& v : sd) v = v * (1.0f - confidence);  // NSA, kalman_filter.cpp:67
+    const SMat<4, 8> H = obs8();
+    const SMat<8, 4> Ht = transpose(H);
+    float pm[4];
+    for (int i = 0; i < 4; ++i) {
+      float acc = H[i][0] * s.mean[0];
+      for (int k = 1; k < 8; ++k) acc += H[i][k] * s.mean[k];
+      pm[i] = acc;
+    }
+    SMat<4, 4> Rn = SMat<4, 4>::zero();
+    for (int i = 0; i < 4; ++i) Rn[i][i] = sd[i] * sd[i];
+    SMat<4, 4> S = add(mul(mul(H, s.cov), Ht), Rn);
+    SMat<4, 4> L = S;
+    SMat<8, 4> PHt = mul(s.cov, Ht);
+    SMat<8, 4> K;
+    if (cholesky(L)) {  // row-wise solves, :103-105
+      for (int i = 0; i < 8; ++i) {
+        float b[4] = {PHt[i][0], PHt[i][1], PHt[i][2], PHt[i][3]};
+        chol_solve(L, b);
+        for (int c = 0; c < 4; ++c) K[i][c] = b[c];
+      }
+    } else {  // :86-94 fallback (pseudo-inverse); LU inverse stands in, unreachable for SPD S
+      K = mul(PHt, inverse_lu4(S));
+    }
+    float inn[4];
+    for (int i = 0; i < 4; ++i) inn[i] = z[i] - pm[i];
+    for (int i = 0; i < 8; ++i) {
+      float acc = K[i][0] * inn[0];
+      for (int k = 1; k < 4; ++k) acc += K[i][k] * inn[k];
+      s.mean[i] = s.mean[i] + acc;
+    }
+    s.cov = sub(s.cov, mul(mul(K, S), transpose(K)));
+  }
+};
+
+// KalmanFilterXYWH (BoT-SORT) — xywh_kf.hpp:41-135
+struct KfXYWH {
+  static constexpr float wp = 1.0f / 20.0f;
+  static constexpr float wv = 1.0f / 160.0f;
+  static State8 initiate(const float m[4]) {  // :41-62
+    State8 s;
+    for (int i = 0; i < 4; ++i) { s.mean[i] = m[i]; s.mean[4 + i] = 0.0f; }
+    const float h = m[3];
+    s.cov = SMat<8, 8>::zero();
+    for (int i = 0; i < 8; ++i) {
+      const float sd = (i < 4) ? 2.0f * wp * h : 10.0f * wv * h;
+      s.cov[i][i] = sd * sd;
+    }
+    return s;
+  }
+  static void predict(State8& s) {  // :70-94
+    const float h = s.mean[3];
+    float sd[8];
+    for (int i = 0; i < 8; ++i) sd[i] = (i < 4) ? wp * h : wv * h;
+    predict8(s, sd);
+  }
+  static void update(State8& s, const float z[4]) {  // :103-135
+    const float h = s.mean[3];
+    const SMat<4, 8> H = obs8();
+    const SMat<8, 4> Ht = transpose(H);
+    SMat<4, 4> Rn = SMat<4, 4>::zero();
+    for (int i = 0; i < 4; ++i) { const float sd = wp * h; Rn[i][i] = sd * sd; }
+    float pm[4];
+    for (int i = 0; i < 4; ++i) {
+      float acc = H[i][0] * s.mean[0];
+      for (int k = 1; k < 8; ++k) acc += H[i][k] * s.mean[k];
+      pm[i] = acc;
+    }
+    SMat<4, 4> S = add(mul(mul(H, s.cov), Ht), Rn);
+    SMat<8, 4> K = mul(mul(s.cov, Ht), inverse_lu4(S));
+    float inn[4];
+    for (int i = 0; i < 4; ++i) inn[i] = z[i] - pm[i];
+    for (int i = 0; i < 8; ++i) {
+      float acc = K[i][0] * inn[0];
+      for (int k = 1; k < 4; ++k) acc += K[i][k] * inn[k];
+      s.mean[i] = s.mean[i] + acc;
+    }
+    s.cov = sub(s.cov, mul(mul(K, S), transpose(K)));
+  }
+};
+
+}  // namespace orc

@@ -1,0 +1,969 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.hpp header).
+//
+// CPU restatement of the four in-scope trackers' update() orchestration, including the
+// reference's lifecycle quirks:
+//   Sort      src/trackers/sort.cpp:16-255
+//   ByteTrack src/trackers/bytetrack.cpp:15-706
+//   OCSort    src/trackers/ocsort.cpp:24-738
+//   BotSort   src/trackers/botsort.cpp:16-764   (cmc_method != "ecc": no CMC; embeddings passed in)
+// Id counters are per tracker instance (the reference's process-global statics, Q6, make
+// ids depend on every other instance in the process; parity is defined per stream).
+// Detections come in as a row-major N x 6 array [x1,y1,x2,y2,conf,cls]; output rows are
+// [x1,y1,x2,y2,id,conf,cls,det_ind] like the reference's M x 8 matrix.
+#pragma once
+#include <cstdio>
+#include <deque>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "orc_kf.hpp"
+#include "orc_math.hpp"
+
+namespace orc {
+
+using OutRow = std::array<float, 8>;
+using OutTable = std::vector<OutRow>;
+
+struct Det7 {  // one detection row with its index in the caller's matrix appended
+  float x1, y1, x2, y2, conf, cls;
+  int ind;
+  Box box() const { return {x1, y1, x2, y2}; }
+};
+inline std::vector<Det7> wrap_dets(const float* dets, int n) {
+  std::vector<Det7> v(n);
+  for (int i = 0; i < n; ++i) {
+    const float* r = dets + static_cast<size_t>(i) * 6;
+    v[i] = {r[0], r[1], r[2], r[3], r[4], r[5], i};
+  }
+  return v;
+}
+inline Mat boxes_to_mat(const std::vector<Box>& b) {
+  Mat m(static_cast<int>(b.size()), 4);
+  for (int i = 0; i < m.r; ++i)
+    for (int k = 0; k < 4; ++k) m(i, k) = b[i][k];
+  return m;
+}
+
+// tracker.cpp:17-46 — shared parameter block (max_obs forced to max_age+5 when max_age>=max_obs)
+struct BaseParams {
+  float det_thresh = 0.3f;
+  int max_age = 30, max_obs = 50, min_hits = 3;
+  float iou_threshold = 0.3f;
+  void normalise() {
+    if (max_age >= max_obs) max_obs = max_age + 5;
+  }
+};
+
+// =======================================================================================
+// SORT — sort.cpp
+// =======================================================================================
+class Sort {
+ public:
+  explicit Sort(float det_thresh = 0.3f, int max_age = 1, int max_obs = 50, int min_hits = 3,
+                float iou_threshold = 0.3f) {
+    p_.det_thresh = det_thresh; p_.max_age = max_age; p_.max_obs = max_obs;
+    p_.min_hits = min_hits; p_.iou_threshold = iou_threshold;
+    p_.normalise();
+  }
+  void reset() { trk_.clear(); frame_count_ = 0; }  // sort.cpp:97-100 (id counter is NOT reset)
+
+  OutTable update(const float* dets, int n) {  // sort.cpp:102-255
+    ++frame_count_;
+    std::vector<Det7> all = wrap_dets(dets, n), fd;
+    for (const Det7& d : all)
+      if (d.conf >= p_.det_thresh) fd.push_back(d);
+
+    std::vector<Box> trks(trk_.size());
+    std::vector<int> to_del;
+    for (size_t t = 0; t < trk_.size(); ++t) {
+      predict(trk_[t]);
+      Box pos = state_box(trk_[t]);
+      if (std::isnan(pos[0] + pos[1] + pos[2] + pos[3])) to_del.push_back(static_cast<int>(t));
+      trks[t] = pos;
+    }
+    for (auto it = to_del.rbegin(); it != to_del.rend(); ++it) trk_.erase(trk_.begin() + *it);
+    if (!to_del.empty()) {
+      trks.resize(trk_.size());
+      for (size_t t = 0; t < trk_.size(); ++t) trks[t] = state_box(trk_[t]);
+    }
+
+    std::vector<std::array<int, 2>> matched;
+    std::vector<int> um_dets, um_trks;
+    if (trk_.empty()) {
+      for (int i = 0; i < static_cast<int>(fd.size()); ++i) um_dets.push_back(i);
+    } else if (fd.empty()) {
+      for (int t = 0; t < static_cast<int>(trk_.size()); ++t) um_trks.push_back(t);
+    } else {
+      std::vector<Box> db;
+      for (const Det7& d : fd) db.push_back(d.box());
+      Mat cost = iou_distance(boxes_to_mat(trks), boxes_to_mat(db));
+      LapResult r = linear_assignment(cost, 1.0f - p_.iou_threshold);
+      matched = r.matches; um_dets = r.unmatched_b; um_trks = r.unmatched_a;
+      last_lap = r;
+    }
+    for (const auto& m : matched) apply(trk_[m[0]], fd[m[1]]);
+    for (int di : um_dets) trk_.push_back(spawn(fd[di]));
+
+    std::vector<Track> keep;
+    for (const Track& t : trk_)
+      if (t.tsu <= p_.max_age) keep.push_back(t);
+    trk_ = std::move(keep);
+
+    OutTable out;
+    for (const Track& t : trk_) {
+      if (t.tsu == 0 && (t.hits >= p_.min_hits || frame_count_ <= p_.min_hits)) {
+        Box b = state_box(t);
+        out.push_back({b[0], b[1], b[2], b[3], static_cast<float>(t.id), t.conf,
+                       static_cast<float>(t.cls), static_cast<float>(t.det_ind)});
+      }
+    }
+    return out;
+  }
+  LapResult last_lap;  // exposed for assignment-index parity checks
+  int num_tracks() const { return static_cast<int>(trk_.size()); }
+  // state dump for float parity: rows of [id, x(7), P(49)]
+  std::vector<std::vector<float>> dump_states() const {
+    std::vector<std::vector<float>> v;
+    for (const Track& t : trk_) {
+      std::vector<float> r;
+      r.push_back(static_cast<float>(t.id));
+      for (int i = 0; i < 7; ++i) r.push_back(t.kf.x[i]);
+      for (int i = 0; i < 7; ++i)
+        for (int j = 0; j < 7; ++j) r.push_back(t.kf.P[i][j]);
+      v.push_back(r);
+    }
+    return v;
+  }
+
+ private:
+  struct Track {  // SortTrack, sort.cpp:21-76
+    int id, cls, det_ind, hits, tsu, age;
+    float conf;
+    KfXYSR kf;
+  };
+  Track spawn(const Det7& d) {
+    Track t;
+    t.id = ++next_id_;
+    t.conf = d.conf; t.cls = static_cast<int>(d.cls); t.det_ind = d.ind;
+    t.hits = 1; t.tsu = 0; t.age = 1;
+    Box z = xyxy2xysr(d.box());
+    for (int i = 0; i < 4; ++i) t.kf.x[i] = z[i];
+    return t;
+  }
+  static void predict(Track& t) { t.kf.predict(); ++t.age; ++t.tsu; }
+  static void apply(Track& t, const Det7& d) {
+    t.conf = d.conf; t.cls = static_cast<int>(d.cls); t.det_ind = d.ind;
+    Box z = xyxy2xysr(d.box());
+    t.kf.update(z.data());
+    ++t.hits; t.tsu = 0;
+  }
+  static Box state_box(const Track& t) { return xysr2xyxy({t.kf.x[0], t.kf.x[1], t.kf.x[2], t.kf.x[3]}); }
+
+  BaseParams p_;
+  int frame_count_ = 0, next_id_ = 0;
+  std::vector<Track> trk_;
+};
+
+// =======================================================================================
+// ByteTrack — bytetrack.cpp
+// =======================================================================================
+class ByteTrack {
+ public:
+  explicit ByteTrack(float min_conf = 0.1f, float track_thresh = 0.45f, float match_thresh = 0.8f,
+                     int track_buffer = 25, int frame_rate = 30, int max_age = 30, int max_obs = 50)
+      : min_conf_(min_conf), track_thresh_(track_thresh), match_thresh_(match_thresh) {
+    p_.max_age = max_age; p_.max_obs = max_obs; p_.normalise();
+    buffer_size_ = static_cast<int>(frame_rate / 30.0f * track_buffer);  // bytetrack.cpp:141
+    max_time_lost_ = buffer_size_;
+    p_.det_thresh = track_thresh_;  // :145
+  }
+  void reset() { frame_count_ = 0; frame_id_ = 0; active_.clear(); lost_.clear(); }
+
+  enum State { New = 0, Tracked = 1, Lost = 2, Removed = 3 };
+  struct STrack {
+    bool has_state = false;
+    State8 kf;
+    Box xywh, tlwh, xyah;
+    float conf = 0.f;
+    int cls = 0, det_ind = 0, id = 0;
+    State state = New;
+    bool activated = false;
+    int tracklet_len = 0, frame_id = 0, start_frame = 0;
+    Box xyxy() const {  // bytetrack.cpp:117-127
+      if (!has_state) return xywh2xyxy(xywh);
+      return xywh2xyxy(xyah2xywh({kf.mean[0], kf.mean[1], kf.mean[2], kf.mean[3]}));
+    }
+  };
+
+  OutTable update(const float* dets, int n) {  // bytetrack.cpp:166-621
+    std::vector<Det7> all = wrap_dets(dets, n);
+    ++frame_count_; ++frame_id_;
+    std::vector<STrack> activated, refind, lost_new, removed_new;
+    laps.clear();
+
+    std::vector<STrack> detections, detections_second;
+    for (const Det7& d : all) {
+      if (d.conf > track_thresh_) detections.push_back(make_det(d));
+    }
+    for (const Det7& d : all) {
+      if (d.conf > min_conf_ && d.conf < track_thresh_) detections_second.push_back(make_det(d));
+    }
+
+    std::vector<int> unconf_idx, tracked_idx;
+    for (size_t i = 0; i < active_.size(); ++i)
+      (active_[i].activated ? tracked_idx : unconf_idx).push_back(static_cast<int>(i));
+    std::vector<STrack> unconfirmed, tracked;
+    for (int i : unconf_idx) unconfirmed.push_back(active_[i]);
+    for (int i : tracked_idx) tracked.push_back(active_[i]);
+
+    // pool = copies of tracked ∪ lost, with a map back to the originals (:251-262)
+    std::vector<STrack> pool = joint(tracked, lost_);
+    std::vector<std::pair<int, bool>> origin;
+    for (size_t i = 0; i < tracked.size(); ++i) origin.emplace_back(tracked_idx[i], true);
+    for (size_t i = 0; i < lost_.size(); ++i) origin.emplace_back(static_cast<int>(i), false);
+    // NB: joint() drops lost tracks whose id already exists in tracked; the reference builds
+    // `origin` without that filter (:259-262). Ids are unique across the two lists in practice.
+
+    for (STrack& st : pool) {  // multi_predict :97-115
+      if (st.state != Tracked) st.kf.mean[7] = 0.0f;
+      KfXYAH::predict(st.kf);
+    }
+
+    const int nt = static_cast<int>(pool.size()), nd = static_cast<int>(detections.size());
+    std::vector<Box> tb(nt), db(nd);
+    std::vector<float> dconf(nd);
+    for (int i = 0; i < nt; ++i) tb[i] = pool[i].xyxy();
+    for (int j = 0; j < nd; ++j) { db[j] = detections[j].xyxy(); dconf[j] = detections[j].conf; }
+    Mat dists = iou_distance(boxes_to_mat(tb), boxes_to_mat(db));
+    dists = fuse_score(dists, dconf);
+    LapResult a1 = linear_assignment(dists, match_thresh_);
+    laps.push_back(a1);
+
+    std::vector<int> u_track = a1.unmatched_a, u_det = a1.unmatched_b;
+    for (const auto& m : a1.matches) {  // :337-365
+      auto [oi, is_tracked] = origin[m[0]];
+      STrack& orig = is_tracked ? active_[oi] : lost_[oi];
+      orig.kf = pool[m[0]].kf; orig.has_state = true;
+      if (orig.state == Tracked) { apply_update(orig, detections[m[1]]); activated.push_back(orig); }
+      else { reactivate(orig, detections[m[1]]); refind.push_back(orig); }
+    }
+
+    // second association (:367-442): un-predicted originals of the still-Tracked pool members
+    std::vector<STrack*> r_tracked;
+    std::vector<int> r_pool_idx;
+    for (int idx : u_track) {
+      if (pool[idx].state == Tracked) {
+        auto [oi, is_tracked] = origin[idx];
+        if (is_tracked) { r_tracked.push_back(&active_[oi]); r_pool_idx.push_back(idx); }
+      }
+    }
+    if (!detections_second.empty() && !r_tracked.empty()) {
+      std::vector<Box> rb, d2;
+      for (STrack* t : r_tracked) rb.push_back(t->xyxy());
+      for (const STrack& d : detections_second) d2.push_back(d.xyxy());
+      Mat dists2 = iou_distance(boxes_to_mat(rb), boxes_to_mat(d2));
+      LapResult a2 = linear_assignment(dists2, 0.5f);
+      laps.push_back(a2);
+      for (const auto& m : a2.matches) {
+        STrack* t = r_tracked[m[0]];
+        t->kf = pool[r_pool_idx[m[0]]].kf;
+        if (t->state == Tracked) { apply_update(*t, detections_second[m[1]]); activated.push_back(*t); }
+        else { reactivate(*t, detections_second[m[1]]); refind.push_back(*t); }
+      }
+      for (int i : a2.unmatched_a) {
+        STrack* t = r_tracked[i];
+        if (t->state != Lost) { t->state = Lost; lost_new.push_back(*t); }
+      }
+    }
+
+    // unconfirmed tracks vs. leftover high detections (:455-542)
+    std::vector<STrack> remaining;
+    for (int idx : u_det) remaining.push_back(detections[idx]);
+    std::vector<int> u_det_final;
+    if (!unconfirmed.empty() && !remaining.empty()) {
+      std::vector<Box> ub, rb;
+      std::vector<float> rc;
+      for (const STrack& t : unconfirmed) ub.push_back(t.xyxy());
+      for (const STrack& d : remaining) { rb.push_back(d.xyxy()); rc.push_back(d.conf); }
+      Mat dists3 = fuse_score(iou_distance(boxes_to_mat(ub), boxes_to_mat(rb)), rc);
+      LapResult a3 = linear_assignment(dists3, 0.7f);
+      laps.push_back(a3);
+      for (int j : a3.unmatched_b) u_det_final.push_back(u_det[j]);
+      for (const auto& m : a3.matches) {
+        STrack& t = active_[unconf_idx[m[0]]];
+        apply_update(t, remaining[m[1]]);
+        activated.push_back(t);
+      }
+      for (int i : a3.unmatched_a) {
+        STrack& t = active_[unconf_idx[i]];
+        t.state = Removed;
+        removed_new.push_back(t);
+      }
+    } else {
+      u_det_final = u_det;
+    }
+
+    for (int idx : u_det_final) {  // :546-554
+      STrack& t = detections[idx];
+      if (t.conf >= p_.det_thresh) { activate(t); activated.push_back(t); }
+    }
+    for (STrack& t : lost_) {  // :557-562
+      if (frame_count_ - t.frame_id > max_time_lost_) { t.state = Removed; removed_new.push_back(t); }
+    }
+
+    std::vector<STrack> na;
+    for (const STrack& t : active_)
+      if (t.state == Tracked) na.push_back(t);
+    active_ = joint(joint(na, activated), refind);
+    lost_ = sub(lost_, active_);
+    lost_.insert(lost_.end(), lost_new.begin(), lost_new.end());
+    lost_ = sub(lost_, removed_new);
+    remove_duplicates();
+
+    OutTable out;
+    for (const STrack& t : active_) {
+      if (!t.activated) continue;
+      Box b = t.xyxy();
+      out.push_back({b[0], b[1], b[2], b[3], static_cast<float>(t.id), t.conf,
+                     static_cast<float>(t.cls), static_cast<float>(t.det_ind)});
+    }
+    return out;
+  }
+
+  std::vector<LapResult> laps;
+  int num_active() const { return static_cast<int>(active_.size()); }
+  int num_lost() const { return static_cast<int>(lost_.size()); }
+  // rows of [id, mean(8), cov(64)] over active_ then lost_
+  std::vector<std::vector<float>> dump_states() const {
+    std::vector<std::vector<float>> v;
+    auto push = [&](const STrack& t) {
+      std::vector<float> r;
+      r.push_back(static_cast<float>(t.id));
+      for (int i = 0; i < 8; ++i) r.push_back(t.kf.mean[i]);
+      for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) r.push_back(t.kf.cov[i][j]);
+      v.push_back(r);
+    };
+    for (const STrack& t : active_) push(t);
+    for (const STrack& t : lost_) push(t);
+    return v;
+  }
+
+ private:
+  STrack make_det(const Det7& d) const {  // STrack ctor :18-37
+    STrack s;
+    s.xywh = xyxy2xywh(d.box());
+    s.tlwh = xywh2tlwh(s.xywh);
+    s.xyah = tlwh2xyah(s.tlwh);
+    s.conf = d.conf; s.cls = static_cast<int>(d.cls); s.det_ind = d.ind;
+    return s;
+  }
+  void activate(STrack& t) {  // :39-53
+    t.id = ++next_id_;
+    t.kf = KfXYAH::initiate(t.xyah.data());
+    t.has_state = true;
+    t.tracklet_len = 0; t.state = Tracked;
+    if (frame_id_ == 1) t.activated = true;
+    t.frame_id = frame_id_; t.start_frame = frame_id_;
+  }
+  void reactivate(STrack& t, const STrack& d) {  // :55-69
+    KfXYAH::update(t.kf, d.xyah.data());
+    t.tracklet_len = 0; t.state = Tracked; t.activated = true; t.frame_id = frame_id_;
+    t.conf = d.conf; t.cls = d.cls; t.det_ind = d.det_ind;
+  }
+  void apply_update(STrack& t, const STrack& d) {  // :71-89
+    t.frame_id = frame_id_; ++t.tracklet_len;
+    KfXYAH::update(t.kf, d.xyah.data());
+    t.state = Tracked; t.activated = true;
+    t.conf = d.conf; t.cls = d.cls; t.det_ind = d.det_ind;
+  }
+  static std::vector<STrack> joint(const std::vector<STrack>& a, const std::vector<STrack>& b) {  // :623-640
+    std::unordered_set<int> seen;
+    std::vector<STrack> r = a;
+    for (const STrack& t : a) seen.insert(t.id);
+    for (const STrack& t : b)
+      if (seen.insert(t.id).second) r.push_back(t);
+    return r;
+  }
+  static std::vector<STrack> sub(const std::vector<STrack>& a, const std::vector<STrack>& b) {  // :642-657
+    std::unordered_set<int> rm;
+    for (const STrack& t : b) rm.insert(t.id);
+    std::vector<STrack> r;
+    for (const STrack& t : a)
+      if (!rm.count(t.id)) r.push_back(t);
+    return r;
+  }
+  void remove_duplicates() {  // :659-706
+    if (active_.empty() || lost_.empty()) return;
+    std::vector<Box> ab, lb;
+    for (const STrack& t : active_) ab.push_back(t.xyxy());
+    for (const STrack& t : lost_) lb.push_back(t.xyxy());
+    Mat pd = iou_distance(boxes_to_mat(ab), boxes_to_mat(lb));
+    std::vector<char> dupa(active_.size(), 0), dupb(lost_.size(), 0);
+    for (int i = 0; i < pd.r; ++i)
+      for (int j = 0; j < pd.c; ++j)
+        if (pd(i, j) < 0.15f) {
+          int tp = active_[i].frame_id - active_[i].start_frame;
+          int tq = lost_[j].frame_id - lost_[j].start_frame;
+          if (tp > tq) dupb[j] = 1; else dupa[i] = 1;
+        }
+    std::vector<STrack> ra, rb;
+    for (size_t i = 0; i < active_.size(); ++i) if (!dupa[i]) ra.push_back(active_[i]);
+    for (size_t j = 0; j < lost_.size(); ++j) if (!dupb[j]) rb.push_back(lost_[j]);
+    active_ = std::move(ra); lost_ = std::move(rb);
+  }
+
+  BaseParams p_;
+  float min_conf_, track_thresh_, match_thresh_;
+  int buffer_size_, max_time_lost_;
+  int frame_count_ = 0, frame_id_ = 0, next_id_ = 0;
+  std::vector<STrack> active_, lost_;
+};
+
+// =======================================================================================
+// OC-SORT — ocsort.cpp
+// =======================================================================================
+class OCSort {
+ public:
+  explicit OCSort(float det_thresh = 0.2f, int max_age = 30, int max_obs = 50, int min_hits = 3,
+                  float iou_threshold = 0.3f, float min_conf = 0.1f, int delta_t = 3,
+                  float inertia = 0.2f, bool use_byte = false, float q_xy = 0.01f, float q_s = 0.0001f)
+      : min_conf_(min_conf), asso_thr_(iou_threshold), delta_t_(delta_t), inertia_(inertia),
+        use_byte_(use_byte), q_xy_(q_xy), q_s_(q_s) {
+    p_.det_thresh = det_thresh; p_.max_age = max_age; p_.max_obs = max_obs;
+    p_.min_hits = min_hits; p_.iou_threshold = iou_threshold; p_.normalise();
+  }
+  void reset() { frame_count_ = 0; trk_.clear(); }
+
+  struct Obs5 { float v[5]; };
+  struct Track {  // KalmanBoxTracker, ocsort.cpp:53-156
+    KfXYSR kf;
+    int id, age = 0, hits = 0, hit_streak = 0, tsu = 0, cls = 0, det_ind = 0;
+    float conf = 0.f;
+    Obs5 last_obs{{-1, -1, -1, -1, -1}};
+    std::map<int, Obs5> observations;  // age -> box (+conf)
+    float vel[2] = {0.f, 0.f};         // (dy, dx)
+  };
+
+  OutTable update(const float* dets, int n) {  // ocsort.cpp:285-606
+    std::vector<Det7> all = wrap_dets(dets, n);
+    ++frame_count_;
+    laps.clear();
+    std::vector<Det7> high, second;
+    for (const Det7& d : all) {
+      if (d.conf > min_conf_ && d.conf < p_.det_thresh) second.push_back(d);
+      if (d.conf > p_.det_thresh) high.push_back(d);
+    }
+
+    size_t nt = trk_.size();
+    std::vector<std::array<float, 5>> trks(nt);
+    std::vector<int> to_del;
+    for (size_t t = 0; t < nt; ++t) {
+      Box pos = predict(trk_[t]);
+      trks[t] = {pos[0], pos[1], pos[2], pos[3], 0.0f};
+      if (std::isnan(pos[0]) || std::isnan(pos[1]) || std::isnan(pos[2]) || std::isnan(pos[3]))
+        to_del.push_back(static_cast<int>(t));
+    }
+    for (auto it = to_del.rbegin(); it != to_del.rend(); ++it) { trk_.erase(trk_.begin() + *it); --nt; }
+    trks.resize(nt);  // conservativeResize keeps the FIRST nt rows (:363-364), NaN rows included
+
+    if (nt == 0) {  // :366-383
+      for (const Det7& d : high) trk_.push_back(spawn(d));
+      return {};
+    }
+
+    Mat vel(static_cast<int>(nt), 2), kobs(static_cast<int>(nt), 5);
+    for (size_t t = 0; t < nt; ++t) {
+      vel(t, 0) = trk_[t].vel[0]; vel(t, 1) = trk_[t].vel[1];
+      Obs5 k = k_previous_obs(trk_[t], delta_t_);
+      for (int c = 0; c < 5; ++c) kobs(t, c) = k.v[c];
+    }
+    Mat dm(static_cast<int>(high.size()), 5), tm(static_cast<int>(nt), 5);
+    for (int i = 0; i < dm.r; ++i) { dm(i,0)=high[i].x1; dm(i,1)=high[i].y1; dm(i,2)=high[i].x2; dm(i,3)=high[i].y2; dm(i,4)=high[i].conf; }
+    for (int i = 0; i < tm.r; ++i) for (int c = 0; c < 5; ++c) tm(i, c) = trks[i][c];
+
+    Assoc as = associate(dm, tm, asso_thr_, vel, kobs, inertia_);
+    for (const auto& m : as.matches) apply(trk_[m[1]], high[m[0]]);
+
+    if (use_byte_ && !second.empty() && !as.um_trks.empty()) {  // :430-472
+      Mat ut(static_cast<int>(as.um_trks.size()), 5), sd(static_cast<int>(second.size()), 5);
+      for (int i = 0; i < ut.r; ++i) for (int c = 0; c < 5; ++c) ut(i, c) = trks[as.um_trks[i]][c];
+      for (int i = 0; i < sd.r; ++i) { sd(i,0)=second[i].x1; sd(i,1)=second[i].y1; sd(i,2)=second[i].x2; sd(i,3)=second[i].y2; sd(i,4)=second[i].conf; }
+      Mat iou = iou_batch(sd, ut);
+      float mx = -std::numeric_limits<float>::infinity();
+      for (float v : iou.a) mx = std::max(mx, v);
+      if (mx > asso_thr_) {
+        Mat cost = iou; for (float& v : cost.a) v = -v;
+        LapResult r = linear_assignment(cost, -asso_thr_);
+        laps.push_back(r);
+        std::unordered_set<int> rm;
+        for (const auto& m : r.matches) {
+          int ti = as.um_trks[m[1]];
+          if (iou(m[0], m[1]) < asso_thr_) continue;
+          apply(trk_[ti], second[m[0]]);
+          rm.insert(ti);
+        }
+        std::vector<int> keep;
+        for (int t : as.um_trks) if (!rm.count(t)) keep.push_back(t);
+        as.um_trks = keep;
+      }
+    }
+
+    if (!as.um_dets.empty() && !as.um_trks.empty()) {  // OCR rematch :475-540
+      Mat ld(static_cast<int>(as.um_dets.size()), 4), lt(static_cast<int>(as.um_trks.size()), 4);
+      for (int i = 0; i < ld.r; ++i) { const Det7& d = high[as.um_dets[i]]; ld(i,0)=d.x1; ld(i,1)=d.y1; ld(i,2)=d.x2; ld(i,3)=d.y2; }
+      for (int i = 0; i < lt.r; ++i) for (int c = 0; c < 4; ++c) lt(i, c) = trk_[as.um_trks[i]].last_obs.v[c];
+      Mat iou = iou_batch(ld, lt);
+      float mx = -std::numeric_limits<float>::infinity();
+      for (float v : iou.a) mx = std::max(mx, v);
+      if (mx > asso_thr_) {
+        Mat cost = iou; for (float& v : cost.a) v = -v;
+        LapResult r = linear_assignment(cost, -asso_thr_);
+        laps.push_back(r);
+        std::unordered_set<int> rmd, rmt;
+        for (const auto& m : r.matches) {
+          int di = as.um_dets[m[0]], ti = as.um_trks[m[1]];
+          if (iou(m[0], m[1]) < asso_thr_) continue;
+          apply(trk_[ti], high[di]);
+          rmd.insert(di); rmt.insert(ti);
+        }
+        std::vector<int> kd, kt;
+        for (int d : as.um_dets) if (!rmd.count(d)) kd.push_back(d);
+        for (int t : as.um_trks) if (!rmt.count(t)) kt.push_back(t);
+        as.um_dets = kd; as.um_trks = kt;
+      }
+    }
+    // unmatched tracks get a "None" update: det_ind = 0 and a KF no-op (:543-545, :89-124, xysr_kf.cpp:80-82)
+    for (int t : as.um_trks) trk_[t].det_ind = 0;
+    for (int d : as.um_dets) trk_.push_back(spawn(high[d]));
+
+    OutTable out;
+    for (int i = static_cast<int>(trk_.size()) - 1; i >= 0; --i) {  // :562-587
+      Track& t = trk_[i];
+      Box d;
+      float ls = t.last_obs.v[0] + t.last_obs.v[1] + t.last_obs.v[2] + t.last_obs.v[3];
+      if (ls < 0) d = state_box(t);
+      else d = {t.last_obs.v[0], t.last_obs.v[1], t.last_obs.v[2], t.last_obs.v[3]};
+      if (t.tsu < 1 && (t.hit_streak >= p_.min_hits || frame_count_ <= p_.min_hits))
+        out.push_back({d[0], d[1], d[2], d[3], static_cast<float>(t.id + 1), t.conf,
+                       static_cast<float>(t.cls), static_cast<float>(t.det_ind)});
+      if (t.tsu > p_.max_age) trk_.erase(trk_.begin() + i);
+    }
+    return out;
+  }
+
+  std::vector<LapResult> laps;
+  int num_tracks() const { return static_cast<int>(trk_.size()); }
+  std::vector<std::vector<float>> dump_states() const {
+    std::vector<std::vector<float>> v;
+    for (const Track& t : trk_) {
+      std::vector<float> r;
+      r.push_back(static_cast<float>(t.id));
+      for (int i = 0; i < 7; ++i) r.push_back(t.kf.x[i]);
+      for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) r.push_back(t.kf.P[i][j]);
+      v.push_back(r);
+    }
+    return v;
+  }
+
+  struct Assoc {
+    std::vector<std::array<int, 2>> matches;  // (det, trk)
+    std::vector<int> um_dets, um_trks;
+  };
+  // ocsort_assoc::associate, ocsort.cpp:610-738. Public so primitive-level parity tests can call it.
+  Assoc associate(const Mat& dets, const Mat& trks, float thr, const Mat& vel, const Mat& prev, float vdc) {
+    Assoc R;
+    const int nd = dets.r, ntk = trks.r;
+    if (ntk == 0) {
+      for (int i = 0; i < nd; ++i) R.um_dets.push_back(i);
+      return R;
+    }
+    Mat angle(nd, ntk);  // already transposed to (dets x trks) and score-weighted
+    for (int i = 0; i < ntk; ++i) {
+      for (int j = 0; j < nd; ++j) {
+        float cx1 = (dets(j, 0) + dets(j, 2)) / 2.0f, cy1 = (dets(j, 1) + dets(j, 3)) / 2.0f;
+        float cx2 = (prev(i, 0) + prev(i, 2)) / 2.0f, cy2 = (prev(i, 1) + prev(i, 3)) / 2.0f;
+        float dx = cx1 - cx2, dy = cy1 - cy2;
+        float norm = std::sqrt(dx * dx + dy * dy) + 1e-6f;
+        float Y = dy / norm, X = dx / norm;
+        float c = vel(i, 1) * X + vel(i, 0) * Y;
+        c = std::min(std::max(c, -1.0f), 1.0f);
+        const float PI = 3.14159265358979323846f;
+        float da = (PI / 2.0f - std::fabs(acos_f32(c))) / PI;
+        float valid = (prev(i, 4) >= 0.0f) ? 1.0f : 0.0f;
+        float a = (valid * da) * vdc;
+        angle(j, i) = a * dets(j, 4);
+      }
+    }
+    Mat iou = iou_batch(dets, trks);
+    last_iou = iou;
+    if (nd > 0) {
+      int max_row = 0, max_col = 0;
+      std::vector<int> colsum(ntk, 0);
+      for (int i = 0; i < nd; ++i) {
+        int rs = 0;
+        for (int j = 0; j < ntk; ++j)
+          if (iou(i, j) > thr) { ++rs; ++colsum[j]; }
+        max_row = std::max(max_row, rs);
+      }
+      for (int j = 0; j < ntk; ++j) max_col = std::max(max_col, colsum[j]);
+      if (max_row == 1 && max_col == 1) {
+        for (int i = 0; i < nd; ++i)
+          for (int j = 0; j < ntk; ++j)
+            if (iou(i, j) > thr) R.matches.push_back({i, j});
+      } else {
+        Mat fc(nd, ntk);
+        for (int i = 0; i < nd; ++i)
+          for (int j = 0; j < ntk; ++j) fc(i, j) = -(iou(i, j) + angle(i, j));
+        LapResult r = linear_assignment(fc, -thr);
+        laps.push_back(r);
+        for (const auto& m : r.matches) {
+          if (iou(m[0], m[1]) >= thr) R.matches.push_back({m[0], m[1]});
+          else { R.um_dets.push_back(m[0]); R.um_trks.push_back(m[1]); }  // Q4: pushed again by the sweep below
+        }
+      }
+    }
+    std::unordered_set<int> md, mt;
+    for (const auto& m : R.matches) { md.insert(m[0]); mt.insert(m[1]); }
+    for (int i = 0; i < nd; ++i) if (!md.count(i)) R.um_dets.push_back(i);
+    for (int i = 0; i < ntk; ++i) if (!mt.count(i)) R.um_trks.push_back(i);
+    return R;
+  }
+  Mat last_iou;
+
+  // acos in fp32. The reference calls std::acos(float) (glibc acosf, <1 ulp but not correctly
+  // rounded, libm-version dependent). The oracle fixes a canonical value: the correctly
+  // rounded fp32 result obtained through double precision, which any platform can reproduce.
+  static float acos_f32(float c) { return static_cast<float>(std::acos(static_cast<double>(c))); }
+
+ private:
+  Track spawn(const Det7& d) {  // ctor :53-87
+    Track t;
+    t.id = ++next_id_;
+    t.conf = d.conf; t.cls = static_cast<int>(d.cls); t.det_ind = d.ind;
+    t.kf.Q[4][4] *= q_xy_; t.kf.Q[5][5] *= q_xy_; t.kf.Q[6][6] *= q_s_;  // Q5: scaling applied on top of the ctor values
+    Box z = xyxy2xysr(d.box());
+    for (int i = 0; i < 4; ++i) t.kf.x[i] = z[i];
+    return t;
+  }
+  static Box state_box(const Track& t) {  // convert_x_to_bbox_impl :177-186 (no clamping)
+    return xysr2xyxy({t.kf.x[0], t.kf.x[1], t.kf.x[2], t.kf.x[3]});
+  }
+  static Box predict(Track& t) {  // :132-148
+    if ((t.kf.x[6] + t.kf.x[2]) <= 0) t.kf.x[6] = 0.0f;
+    t.kf.predict();
+    ++t.age;
+    if (t.tsu > 0) t.hit_streak = 0;
+    ++t.tsu;
+    return state_box(t);
+  }
+  static Obs5 k_previous_obs(const Track& t, int k) {  // :24-51
+    if (t.observations.empty()) return Obs5{{-1, -1, -1, -1, -1}};
+    for (int i = 0; i < k; ++i) {
+      auto it = t.observations.find(t.age - (k - i));
+      if (it != t.observations.end()) return it->second;
+    }
+    return t.observations.rbegin()->second;  // max age key
+  }
+  static void speed_direction(const float* b1, const float* b2, float out[2]) {  // :160-172
+    float cx1 = (b1[0] + b1[2]) / 2.0f, cy1 = (b1[1] + b1[3]) / 2.0f;
+    float cx2 = (b2[0] + b2[2]) / 2.0f, cy2 = (b2[1] + b2[3]) / 2.0f;
+    float dy = cy2 - cy1, dx = cx2 - cx1;
+    float norm = std::sqrt(dy * dy + dx * dx) + 1e-6f;
+    out[0] = dy / norm; out[1] = dx / norm;
+  }
+  void apply(Track& t, const Det7& d) {  // update :89-130
+    t.det_ind = d.ind;
+    t.conf = d.conf; t.cls = static_cast<int>(d.cls);
+    const float box[4] = {d.x1, d.y1, d.x2, d.y2};
+    float ls = t.last_obs.v[0] + t.last_obs.v[1] + t.last_obs.v[2] + t.last_obs.v[3];
+    if (ls >= 0) {
+      Obs5 pb = k_previous_obs(t, delta_t_);
+      if (pb.v[0] + pb.v[1] + pb.v[2] + pb.v[3] >= 0) speed_direction(pb.v, box, t.vel);
+      else speed_direction(t.last_obs.v, box, t.vel);
+    }
+    for (int i = 0; i < 4; ++i) t.last_obs.v[i] = box[i];
+    t.last_obs.v[4] = t.conf;
+    t.observations[t.age] = t.last_obs;
+    t.tsu = 0; ++t.hits; ++t.hit_streak;
+    Box z = xyxy2xysr(d.box());
+    t.kf.update(z.data());
+  }
+
+  BaseParams p_;
+  float min_conf_, asso_thr_;
+  int delta_t_;
+  float inertia_;
+  bool use_byte_;
+  float q_xy_, q_s_;
+  int frame_count_ = 0, next_id_ = 0;
+  std::vector<Track> trk_;
+};
+
+// =======================================================================================
+// BoT-SORT — botsort.cpp (no CMC, no ReID model: embeddings are passed in, N x D row-major)
+// =======================================================================================
+class BotSort {
+ public:
+  explicit BotSort(float track_high = 0.5f, float track_low = 0.1f, float new_track = 0.6f,
+                   int track_buffer = 30, float match_thresh = 0.8f, float proximity = 0.5f,
+                   float appearance = 0.25f, int frame_rate = 30, bool fuse_first = false,
+                   bool with_reid = true, int max_age = 30, int max_obs = 50)
+      : hi_(track_high), lo_(track_low), newt_(new_track), match_(match_thresh), prox_(proximity),
+        app_(appearance), fuse_first_(fuse_first), with_reid_(with_reid) {
+    p_.max_age = max_age; p_.max_obs = max_obs; p_.normalise();
+    max_time_lost_ = static_cast<int>(frame_rate / 30.0f * track_buffer);  // botsort.cpp:236-237
+  }
+  void reset() { frame_count_ = 0; active_.clear(); lost_.clear(); next_id_ = 0; }  // :252-258
+
+  enum State { New = 0, Tracked = 1, Lost = 2, Removed = 3 };
+  struct BTrack {  // BotSTrack :23-193
+    Box xywh;
+    float conf = 0.f;
+    int cls = 0, det_ind = -1, id = 0, frame_id = 0, start_frame = 0, end_frame = 0, tracklet_len = 0;
+    bool has_state = false;
+    State8 kf;
+    State state = New;
+    bool activated = false;
+    std::vector<float> curr_feat, smooth_feat;
+    Box xyxy() const {  // :171-181
+      float cx, cy, w, h;
+      if (has_state) { cx = kf.mean[0]; cy = kf.mean[1]; w = kf.mean[2]; h = kf.mean[3]; }
+      else { cx = xywh[0]; cy = xywh[1]; w = xywh[2]; h = xywh[3]; }
+      return {cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2};
+    }
+  };
+
+  OutTable update(const float* dets, int n, const float* embs, int emb_dim) {  // :260-359
+    if (n == 0) return {};  // :267-269 (no predict, no frame_count++)
+    ++frame_count_;
+    laps.clear();
+    std::vector<Det7> all = wrap_dets(dets, n);
+    std::vector<BTrack> detections, detections_second;
+    for (const Det7& d : all) {  // split_detections :361-403 + create_detections :405-423
+      if (d.conf > hi_) {
+        BTrack b = make_det(d);
+        if (with_reid_ && embs != nullptr && emb_dim > 0) set_feat(b, embs + static_cast<size_t>(d.ind) * emb_dim, emb_dim);
+        detections.push_back(std::move(b));
+      } else if (d.conf > lo_) {
+        detections_second.push_back(make_det(d));
+      }
+    }
+    active_.reserve(active_.size() + detections.size() + 10);
+    lost_.reserve(lost_.size() + active_.size() + 10);
+    std::vector<BTrack*> unconfirmed, act_ptrs, lost_ptrs;
+    for (BTrack& t : active_) (t.activated ? act_ptrs : unconfirmed).push_back(&t);
+    for (BTrack& t : lost_) lost_ptrs.push_back(&t);
+    std::vector<BTrack*> pool = joint(act_ptrs, lost_ptrs);
+    for (BTrack* t : pool) KfXYWH::predict(t->kf);  // multi_predict :54-58 (in place)
+
+    std::vector<BTrack*> activated, refind, lost_new, removed_new;
+
+    // first association :425-495
+    std::vector<int> u_track, u_det;
+    {
+      Mat iou_d = iou_dist_ptrs(pool, detections);
+      Mat dists = assoc_cost(iou_d, pool, detections, fuse_first_);
+      LapResult r = linear_assignment(dists, match_);
+      laps.push_back(r);
+      u_track = r.unmatched_a; u_det = r.unmatched_b;
+      for (const auto& m : r.matches) {
+        BTrack* t = pool[m[0]];
+        if (t->state == Tracked) { apply_update(*t, detections[m[1]]); activated.push_back(t); }
+        else { reactivate(*t, detections[m[1]]); refind.push_back(t); }
+      }
+    }
+    // second association :497-563
+    {
+      std::vector<BTrack*> r_tracked;
+      for (int i : u_track)
+        if (pool[i]->state == Tracked) r_tracked.push_back(pool[i]);
+      if (!r_tracked.empty() && !detections_second.empty()) {
+        Mat d2 = iou_dist_ptrs(r_tracked, detections_second);
+        LapResult r = linear_assignment(d2, 0.5f);
+        laps.push_back(r);
+        for (const auto& m : r.matches) {
+          BTrack* t = r_tracked[m[0]];
+          if (t->state == Tracked) { apply_update(*t, detections_second[m[1]]); activated.push_back(t); }
+          else { reactivate(*t, detections_second[m[1]]); refind.push_back(t); }
+        }
+        for (int i : r.unmatched_a) {
+          BTrack* t = r_tracked[i];
+          if (t->state != Lost) { t->state = Lost; lost_new.push_back(t); }
+        }
+      }
+    }
+    // unconfirmed :565-647
+    std::vector<BTrack> filtered;
+    for (int i : u_det) filtered.push_back(detections[i]);
+    std::vector<int> u_det_unc;
+    if (unconfirmed.empty() || u_det.empty()) {
+      for (size_t i = 0; i < u_det.size(); ++i) u_det_unc.push_back(static_cast<int>(i));
+    } else {
+      Mat iou_d = iou_dist_ptrs(unconfirmed, filtered);
+      Mat dists = assoc_cost(iou_d, unconfirmed, filtered, true);
+      LapResult r = linear_assignment(dists, 0.7f);
+      laps.push_back(r);
+      for (const auto& m : r.matches) { apply_update(*unconfirmed[m[0]], filtered[m[1]]); activated.push_back(unconfirmed[m[0]]); }
+      for (int i : r.unmatched_a) { unconfirmed[i]->state = Removed; removed_new.push_back(unconfirmed[i]); }
+      u_det_unc = r.unmatched_b;
+    }
+    // new tracks :649-667
+    for (int idx : u_det_unc) {
+      BTrack& d = filtered[idx];
+      if (d.conf < newt_) continue;
+      active_.push_back(d);
+      activate(active_.back());
+      activated.push_back(&active_.back());
+    }
+    for (BTrack& t : lost_)  // :669-676
+      if (frame_count_ - t.end_frame > max_time_lost_) { t.state = Removed; removed_new.push_back(&t); }
+
+    // prepare_output :678-764 — NB re-found lost tracks are dropped from lost_ but never
+    // appended to active_ (reference behaviour, kept).
+    std::unordered_set<int> active_ids;
+    for (BTrack* t : activated) if (t->state == Tracked) active_ids.insert(t->id);
+    for (BTrack* t : refind) if (t->state == Tracked) active_ids.insert(t->id);
+    std::vector<BTrack> new_lost;
+    std::unordered_set<int> lost_ids;
+    for (BTrack& t : lost_)
+      if (!active_ids.count(t.id) && t.state != Removed) { new_lost.push_back(t); lost_ids.insert(t.id); }
+    for (BTrack* t : lost_new)
+      if (!active_ids.count(t->id) && !lost_ids.count(t->id)) { new_lost.push_back(*t); lost_ids.insert(t->id); }
+    std::vector<BTrack> new_active;
+    for (BTrack& t : active_) if (t.state == Tracked) new_active.push_back(t);
+    active_ = std::move(new_active);
+    lost_ = std::move(new_lost);
+
+    OutTable out;
+    for (const BTrack& t : active_) {
+      if (!t.activated) continue;
+      Box b = t.xyxy();
+      out.push_back({b[0], b[1], b[2], b[3], static_cast<float>(t.id), t.conf,
+                     static_cast<float>(t.cls), static_cast<float>(t.det_ind)});
+    }
+    return out;
+  }
+
+  std::vector<LapResult> laps;
+  int num_active() const { return static_cast<int>(active_.size()); }
+  int num_lost() const { return static_cast<int>(lost_.size()); }
+  std::vector<std::vector<float>> dump_states() const {
+    std::vector<std::vector<float>> v;
+    auto push = [&](const BTrack& t) {
+      std::vector<float> r;
+      r.push_back(static_cast<float>(t.id));
+      for (int i = 0; i < 8; ++i) r.push_back(t.kf.mean[i]);
+      for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) r.push_back(t.kf.cov[i][j]);
+      v.push_back(r);
+    };
+    for (const BTrack& t : active_) push(t);
+    for (const BTrack& t : lost_) push(t);
+    return v;
+  }
+
+ private:
+  static BTrack make_det(const Det7& d) {  // :23-36
+    BTrack b;
+    float w = d.x2 - d.x1, h = d.y2 - d.y1;
+    b.xywh = {d.x1 + w / 2.0f, d.y1 + h / 2.0f, w, h};
+    b.conf = d.conf; b.cls = static_cast<int>(d.cls); b.det_ind = d.ind;
+    return b;
+  }
+  static float norm(const std::vector<float>& v) {
+    return std::sqrt(dot_chain(v.data(), v.data(), static_cast<int>(v.size())));
+  }
+  static void set_feat(BTrack& b, const float* f, int d) {  // :38-46
+    b.curr_feat.assign(f, f + d);
+    b.smooth_feat = b.curr_feat;
+    float nn = norm(b.smooth_feat);
+    if (nn > 0) for (float& v : b.smooth_feat) v /= nn;
+  }
+  static void update_features(BTrack& t, const std::vector<float>& feat) {  // :158-169
+    t.curr_feat = feat;
+    if (t.smooth_feat.empty()) t.smooth_feat = feat;
+    else for (size_t k = 0; k < feat.size(); ++k) t.smooth_feat[k] = 0.9f * t.smooth_feat[k] + (1.0f - 0.9f) * feat[k];
+    float nn = norm(t.smooth_feat);
+    if (nn > 0) for (float& v : t.smooth_feat) v /= nn;
+  }
+  void activate(BTrack& t) {  // :93-109
+    t.id = ++next_id_;
+    t.kf = KfXYWH::initiate(t.xywh.data());
+    t.has_state = true;
+    t.tracklet_len = 0; t.state = Tracked;
+    if (frame_count_ == 1) t.activated = true;
+    t.frame_id = frame_count_; t.end_frame = frame_count_; t.start_frame = frame_count_;
+  }
+  void reactivate(BTrack& t, const BTrack& d) {  // :111-131
+    KfXYWH::update(t.kf, d.xywh.data());
+    if (!d.curr_feat.empty()) update_features(t, d.curr_feat);
+    t.tracklet_len = 0; t.state = Tracked; t.activated = true;
+    t.frame_id = frame_count_; t.end_frame = frame_count_;
+    t.conf = d.conf; t.cls = d.cls; t.det_ind = d.det_ind;
+  }
+  void apply_update(BTrack& t, const BTrack& d) {  // :133-156
+    t.frame_id = frame_count_; t.end_frame = frame_count_; ++t.tracklet_len;
+    KfXYWH::update(t.kf, d.xywh.data());
+    if (!d.curr_feat.empty()) update_features(t, d.curr_feat);
+    t.state = Tracked; t.activated = true;
+    t.conf = d.conf; t.cls = d.cls; t.det_ind = d.det_ind;
+  }
+  static std::vector<BTrack*> joint(const std::vector<BTrack*>& a, const std::vector<BTrack*>& b) {  // :767-786
+    std::unordered_set<int> seen;
+    std::vector<BTrack*> r;
+    for (BTrack* t : a) { seen.insert(t->id); r.push_back(t); }
+    for (BTrack* t : b) if (seen.insert(t->id).second) r.push_back(t);
+    return r;
+  }
+  // matching.hpp:157-182 — Ones(m,n) when either side is empty
+  static Mat iou_dist_ptrs(const std::vector<BTrack*>& a, const std::vector<BTrack>& b) {
+    if (a.empty() || b.empty()) return Mat(static_cast<int>(a.size()), static_cast<int>(b.size()), 1.0f);
+    std::vector<Box> ab, bb;
+    for (BTrack* t : a) ab.push_back(t->xyxy());
+    for (const BTrack& t : b) bb.push_back(t.xyxy());
+    return iou_distance(boxes_to_mat(ab), boxes_to_mat(bb));
+  }
+  // :433-466 / :591-623 — IoU distance (optionally score-fused) min'ed with the gated cosine distance
+  Mat assoc_cost(const Mat& iou_d, const std::vector<BTrack*>& trks, const std::vector<BTrack>& dets, bool fuse) const {
+    Mat d = iou_d;
+    if (fuse) {
+      std::vector<float> c;
+      for (const BTrack& t : dets) c.push_back(t.conf);
+      d = fuse_score(d, c);
+    }
+    if (!with_reid_) return d;
+    const int m = static_cast<int>(trks.size()), n = static_cast<int>(dets.size());
+    Mat emb(m, n, 1.0f);  // matching.hpp:194-196 — Ones when either side is empty
+    if (m > 0 && n > 0) {
+      const int dt = static_cast<int>(trks[0]->smooth_feat.size());
+      const int dd = static_cast<int>(dets[0].smooth_feat.size());
+      Mat tf(m, dt, 0.0f), df(n, dd, 0.0f);
+      for (int i = 0; i < m; ++i)
+        if (!trks[i]->smooth_feat.empty()) for (int k = 0; k < dt; ++k) tf(i, k) = trks[i]->smooth_feat[k];
+      for (int j = 0; j < n; ++j)
+        if (!dets[j].smooth_feat.empty()) for (int k = 0; k < dd; ++k) df(j, k) = dets[j].smooth_feat[k];
+      if (dt != dd) throw std::runtime_error("orc::BotSort: track/detection feature dims differ");
+      emb = embedding_distance_cosine(tf, df);
+    }
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < n; ++j) {
+        float e = emb(i, j) / 2.0f;
+        if (e > app_) e = 1.0f;
+        if (iou_d(i, j) > prox_) e = 1.0f;
+        d(i, j) = std::min(d(i, j), e);
+      }
+    return d;
+  }
+
+  BaseParams p_;
+  float hi_, lo_, newt_, match_, prox_, app_;
+  bool fuse_first_, with_reid_;
+  int max_time_lost_;
+  int frame_count_ = 0, next_id_ = 0;
+  std::vector<BTrack> active_, lost_;
+};
+
+}  // namespace orc

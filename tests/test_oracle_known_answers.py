@@ -1,0 +1,289 @@
+"""Pins the CPU oracle against every known answer the reference's own tests hold for the hot path
+(SURVEY.md §8c): tests/test_matching.cpp:15-110, tests/test_iou.cpp:29-75,101-108,
+tests/test_kalman_filter.cpp:19-83, tests/test_sort.cpp:36-148, tests/test_trackers.cpp /
+test_bytetrack.cpp shape checks — plus an independent optimum check of the assignment with
+scipy.optimize.linear_sum_assignment on the explicitly extended (n+m)^2 matrix."""
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment
+
+from tests import orclib
+
+
+def matches(x):
+    return {(i, int(j)) for i, j in enumerate(x) if j >= 0}
+
+
+# ---- tests/test_matching.cpp ------------------------------------------------------------
+def test_lap_empty(orc):
+    x, y = orc.linear_assignment(np.zeros((0, 0), np.float32), 0.5)
+    assert len(x) == 0 and len(y) == 0
+
+
+def test_lap_single_match(orc):  # :24-35
+    x, y = orc.linear_assignment([[0.1]], 0.5)
+    assert list(x) == [0] and list(y) == [0]
+
+
+def test_lap_above_threshold(orc):  # :37-46
+    x, y = orc.linear_assignment([[0.9]], 0.5)
+    assert list(x) == [-1] and list(y) == [-1]
+
+
+def test_lap_diag3(orc):  # :48-70
+    c = np.full((3, 3), 0.9, np.float32)
+    np.fill_diagonal(c, 0.1)
+    x, y = orc.linear_assignment(c, 0.5)
+    assert matches(x) == {(0, 0), (1, 1), (2, 2)}
+
+
+def test_lap_more_tracks(orc):  # :72-83
+    x, y = orc.linear_assignment([[0.1, 0.9], [0.9, 0.1], [0.9, 0.9]], 0.5)
+    assert matches(x) == {(0, 0), (1, 1)} and list(np.where(x < 0)[0]) == [2] and (y >= 0).all()
+
+
+def test_lap_more_dets(orc):  # :85-96
+    x, y = orc.linear_assignment([[0.1, 0.9, 0.9], [0.9, 0.1, 0.9]], 0.5)
+    assert matches(x) == {(0, 0), (1, 1)} and list(np.where(y < 0)[0]) == [2]
+
+
+def test_lap_optimal_2x2(orc):  # :98-110
+    x, _ = orc.linear_assignment([[0.1, 0.2], [0.3, 0.1]], 0.5)
+    assert matches(x) == {(0, 0), (1, 1)}
+
+
+# ---- independent optimum check (scipy on the explicit extension, lap_solver.hpp:299-315) ----
+def extended(cost, thresh):
+    n, m = cost.shape
+    e = np.full((n + m, n + m), thresh / 2.0, np.float64)
+    e[:n, :m] = cost.astype(np.float64)
+    e[n:, m:] = 0.0
+    return e
+
+
+@pytest.mark.parametrize("n,m,kind,seed", [(7, 5, "dense", 0), (40, 60, "dense", 1), (64, 64, "sparse", 2),
+                                           (130, 90, "sparse", 3), (33, 33, "neg", 4), (1, 9, "dense", 5),
+                                           (200, 120, "sparse", 6)])
+def test_lap_total_cost_is_optimal(orc, n, m, kind, seed):
+    r = np.random.default_rng(seed)
+    if kind == "dense":
+        c, th = r.uniform(0, 1, (n, m)).astype(np.float32), 0.8
+    elif kind == "neg":  # OC-SORT style negative costs / threshold (ocsort.cpp:700-701)
+        c, th = (-r.uniform(0, 1, (n, m))).astype(np.float32), -0.3
+    else:  # IoU-like: one good candidate per row, few extra overlaps, rest exactly 1
+        c = np.ones((n, m), np.float32)
+        for i in range(n):
+            if r.uniform() < 0.8:
+                c[i, r.integers(m)] = r.uniform(0.05, 0.6)
+        extra = r.uniform(0, 1, (n, m)) < 0.02
+        c[extra] = r.uniform(0.2, 0.95, extra.sum()).astype(np.float32)
+        th = 0.8
+    x, y = orc.linear_assignment(c, th)
+    # consistency of x and y
+    for i, j in enumerate(x):
+        if j >= 0:
+            assert y[j] == i
+    assert (x >= 0).sum() == (y >= 0).sum()
+    e = extended(c, th)
+    ri, ci = linear_sum_assignment(e)
+    best = e[ri, ci].sum()
+    k = int((x >= 0).sum())
+    mine = sum(float(c[i, j]) for i, j in enumerate(x) if j >= 0) + (th / 2.0) * ((n - k) + (m - k))
+    assert mine == pytest.approx(best, rel=1e-12, abs=1e-9)
+
+
+# ---- tests/test_iou.cpp -------------------------------------------------------------------
+B1, B2, B3 = [[0, 0, 100, 100]], [[50, 50, 150, 150]], [[200, 200, 300, 300]]
+
+
+def test_iou_identical_and_disjoint(orc):  # :29-37
+    assert orc.iou_batch(B1, B1)[0, 0] == 1.0
+    assert orc.iou_batch(B1, B3)[0, 0] == 0.0
+
+
+def test_iou_overlap(orc):  # :39-46
+    v = orc.iou_batch(B1, B2)[0, 0]
+    assert abs(v - 0.143) < 0.01 and v == np.float32(2500.0) / np.float32(17500.0)
+
+
+def test_iou_batch_2x2(orc):  # :48-67
+    m = orc.iou_batch([[0, 0, 100, 100], [50, 50, 150, 150]], [[0, 0, 100, 100], [200, 200, 300, 300]])
+    assert m.shape == (2, 2) and m[0, 0] == 1.0 and m[0, 1] == 0.0
+
+
+def test_iou_empty(orc):  # :69-75
+    assert orc.iou_batch(np.zeros((0, 4), np.float32), B1).shape == (0, 1)
+
+
+def test_iou_distance_and_fuse(orc):  # matching.cpp:62-65,130-143
+    d = orc.iou_distance(B1 + B2, B1 + B3)
+    assert d[0, 0] == 0.0 and d[0, 1] == 1.0
+    f = orc.fuse_score(d, [0.5, 0.9])
+    assert f[0, 0] == np.float32(1.0) - np.float32(1.0) * np.float32(0.5) and f[0, 1] == 1.0
+
+
+# ---- tests/test_kalman_filter.cpp (XYSR) ----------------------------------------------------
+def xysr_default():
+    mean = np.zeros((1, 7), np.float32)
+    cov = np.diag([10, 10, 10, 10, 1000, 1000, 1000]).astype(np.float32)[None]
+    return mean, cov
+
+
+def test_xysr_predict_adds_velocity(orc):  # :35-45
+    mean, cov = xysr_default()
+    mean[0] = [100, 100, 1000, 0.5, 10, 10, 0]
+    m2, _ = orc.kf_predict(orclib.KF_XYSR, mean, cov)
+    assert m2[0, 0] == 110.0 and m2[0, 1] == 110.0
+
+
+def test_xysr_initial_matrices(orc):  # :19-33 and xysr_kf.cpp:52-65 via one predict from x = 0
+    mean, cov = xysr_default()
+    _, c2 = orc.kf_predict(orclib.KF_XYSR, mean, cov)
+    # P' = F P F^T + Q with P = diag(10,10,10,10,1000,1000,1000), Q = diag(1,1,1,1,.01,.01,.0001)
+    assert c2[0, 0, 0] == np.float32(10 + 1000 + 1)
+    assert c2[0, 0, 4] == 1000.0 and c2[0, 4, 0] == 1000.0
+    assert c2[0, 3, 3] == 11.0
+    assert c2[0, 4, 4] == np.float32(1000.0) + np.float32(0.01)
+    assert c2[0, 6, 6] == np.float32(1000.0) + np.float32(0.0001)
+
+
+def test_xysr_update_moves_towards_measurement(orc):  # :47-58
+    mean, cov = xysr_default()
+    mean[0] = [100, 100, 1000, 0.5, 0, 0, 0]
+    m2, c2 = orc.kf_update(orclib.KF_XYSR, mean, cov, [[110, 110, 1100, 0.5]])
+    assert 100 < m2[0, 0] < 110
+    # closed form for the decoupled x channel: K = P/(P+R) = 10/11
+    assert m2[0, 0] == pytest.approx(100 + 10 * 10 / 11, rel=1e-6)
+    assert c2[0, 0, 0] == pytest.approx(10 / 11, rel=1e-5)
+    assert np.allclose(c2[0], c2[0].T, rtol=0, atol=1e-4)
+
+
+# ---- 8-state filters: closed forms (the reference has no tests for them, §4) ----------------
+@pytest.mark.parametrize("kind", [orclib.KF_XYAH, orclib.KF_XYWH])
+def test_kf8_initiate_predict_update(orc, kind):
+    z = np.array([[320.0, 240.0, 0.5 if kind == orclib.KF_XYAH else 60.0, 120.0]], np.float32)
+    mean, cov = orc.kf_initiate(kind, z)
+    h = np.float32(120.0)
+    wp, wv = np.float32(1.0) / np.float32(20.0), np.float32(1.0) / np.float32(160.0)
+    assert (mean[0, :4] == z[0]).all() and (mean[0, 4:] == 0).all()
+    sd0 = np.float32(2.0) * wp * h
+    assert cov[0, 0, 0] == sd0 * sd0
+    assert cov[0, 4, 4] == (np.float32(10.0) * wv * h) ** 2
+    if kind == orclib.KF_XYAH:
+        assert cov[0, 2, 2] == np.float32(1e-2) ** 2 and cov[0, 6, 6] == np.float32(1e-5) ** 2
+    m2, c2 = orc.kf_predict(kind, mean, cov)
+    assert (m2[0] == mean[0]).all()  # zero velocity
+    assert c2[0, 0, 0] == cov[0, 0, 0] + cov[0, 4, 4] + (wp * h) ** 2
+    assert c2[0, 0, 4] == cov[0, 4, 4]
+    m3, c3 = orc.kf_update(kind, m2, c2, z + np.float32(1.0))
+    assert (m3[0, :2] > z[0, :2]).all() and (m3[0, :2] < z[0, :2] + 1).all()
+    assert np.allclose(c3[0], c3[0].T, atol=1e-3)
+    assert (np.diag(c3[0]) > 0).all() and c3[0, 0, 0] < c2[0, 0, 0]
+    # float64 textbook Kalman update as an independent numerical check (1e-4 relative)
+    P = c2[0].astype(np.float64)
+    Hm = np.eye(4, 8)
+    if kind == orclib.KF_XYAH:
+        R = np.diag([(0.05 * 120) ** 2, (0.05 * 120) ** 2, 1e-2, (0.05 * 120) ** 2])
+    else:
+        R = np.eye(4) * (0.05 * 120) ** 2
+    S = Hm @ P @ Hm.T + R
+    K = P @ Hm.T @ np.linalg.inv(S)
+    mref = m2[0].astype(np.float64) + K @ ((z[0] + 1).astype(np.float64) - m2[0, :4])
+    Pref = P - K @ S @ K.T
+    assert np.allclose(m3[0], mref, rtol=1e-5, atol=1e-5)
+    assert np.allclose(c3[0], Pref, rtol=1e-4, atol=1e-4)
+
+
+def test_xysr_update_vs_float64(orc):
+    r = np.random.default_rng(0)
+    mean, cov = xysr_default()
+    mean[0] = [500, 300, 6000, 0.45, 2, -1, 10]
+    for _ in range(5):
+        mean, cov = orc.kf_predict(orclib.KF_XYSR, mean, cov)
+        z = mean[:, :4] + r.normal(0, 1, (1, 4)).astype(np.float32) * [1, 1, 50, 0.01]
+        P = cov[0].astype(np.float64)
+        Hm, R = np.eye(4, 7), np.diag([1.0, 1, 10, 10])
+        S = Hm @ P @ Hm.T + R
+        K = P @ Hm.T @ np.linalg.inv(S)
+        mref = mean[0] + K @ (z[0].astype(np.float64) - mean[0, :4])
+        IKH = np.eye(7) - K @ Hm
+        Pref = IKH @ P @ IKH.T + K @ R @ K.T
+        mean, cov = orc.kf_update(orclib.KF_XYSR, mean, cov, z)
+        assert np.allclose(mean[0], mref, rtol=1e-5, atol=1e-4)
+        assert np.allclose(cov[0], Pref, rtol=1e-4, atol=1e-3)
+
+
+# ---- ops.hpp edge semantics -------------------------------------------------------------------
+def test_box_conversions(orc):
+    out = orc.box_convert(0, [[10, 20, 50, 100]])  # xyxy2xysr
+    assert list(out[0]) == [30.0, 60.0, 3200.0, 0.5]
+    back = orc.box_convert(1, out)  # xysr2xyxy
+    assert np.allclose(back[0], [10, 20, 50, 100])
+    assert orc.box_convert(0, [[0, 0, 10, 0]])[0, 3] == 0.0  # r = 0 when h <= 1e-6 (ops.hpp:195)
+    assert np.isnan(orc.box_convert(1, [[0, 0, -5, 1]])).any()  # sqrt(s*r<0) -> NaN (ops.hpp:204)
+    assert orc.box_convert(5, [[0, 0, 10, 0]])[0, 2] == 0.0  # a = 0 when h <= 0 (ops.hpp:83)
+
+
+# ---- tests/test_sort.cpp -----------------------------------------------------------------------
+SINGLE = np.array([[100, 100, 200, 200, 0.9, 0]], np.float32)
+EMPTY = np.zeros((0, 6), np.float32)
+
+
+def test_sort_single_detection(orc):  # :36-47
+    t = orc.tracker(orclib.SORT, [0.3, 1, 50, 1])
+    out = t.update(SINGLE)
+    assert out.shape == (1, 8) and out[0, 2] > out[0, 0] and out[0, 3] > out[0, 1]
+
+
+def test_sort_multi_frame_id(orc):  # :49-67
+    t = orc.tracker(orclib.SORT, [0.3, 3, 50, 1])
+    t.update(SINGLE)
+    t.update(SINGLE)
+    out = t.update(np.array([[110, 110, 210, 210, 0.9, 0]], np.float32))
+    assert out.shape[0] == 1 and int(out[0, 4]) == 1
+
+
+def test_sort_track_deletion(orc):  # :69-84
+    t = orc.tracker(orclib.SORT, [0.3, 2, 50, 1])
+    t.update(SINGLE)
+    t.update(EMPTY)
+    assert t.update(EMPTY).shape[0] == 0
+
+
+def test_sort_confidence_filter(orc):  # :108-122
+    t = orc.tracker(orclib.SORT, [0.5, 3, 50, 1])
+    out = t.update(np.array([[100, 100, 200, 200, 0.3, 0], [300, 300, 400, 400, 0.7, 0]], np.float32))
+    assert out.shape[0] <= 1
+
+
+def test_sort_id_survives_missed_frame(orc):  # :128-148
+    t = orc.tracker(orclib.SORT, [0.3, 5, 50, 1])
+    for i in range(5):
+        t.update(np.array([[100 + i * 10, 100 + i * 10, 200 + i * 10, 200 + i * 10, 0.9, 0]], np.float32))
+    t.update(EMPTY)
+    out = t.update(np.array([[160, 160, 260, 260, 0.9, 0]], np.float32))
+    assert out.shape[0] == 1 and int(out[0, 4]) == 1
+
+
+# ---- tests/test_bytetrack.cpp / test_trackers.cpp shape and persistence checks -------------------
+MULTI = np.array([[100, 100, 200, 200, 0.9, 0], [300, 300, 400, 400, 0.8, 0], [500, 100, 600, 200, 0.7, 1]],
+                 np.float32)
+
+
+@pytest.mark.parametrize("kind", [orclib.BYTETRACK, orclib.OCSORT, orclib.BOTSORT])
+def test_tracker_output_validity(orc, kind):  # test_bytetrack.cpp:125-149, test_trackers.cpp:39-107
+    t = orc.tracker(kind)
+    ids = []
+    for _ in range(3):
+        out = t.update(MULTI)
+        assert out.shape[1] == 8 if out.size else True
+        for row in out:
+            assert row[0] < row[2] and row[1] < row[3] and row[4] > 0 and 0 <= row[5] <= 1
+        ids.append(set(out[:, 4].astype(int)))
+    assert ids[1] & ids[2]  # some ids persist over identical frames
+    assert t.update(EMPTY).shape[0] == 0 or kind != orclib.BOTSORT
+
+
+def test_empty_dets_give_no_rows(orc):  # test_trackers.cpp:100-107
+    for kind in (orclib.BYTETRACK, orclib.OCSORT, orclib.BOTSORT, orclib.SORT):
+        assert orc.tracker(kind).update(EMPTY).shape[0] == 0

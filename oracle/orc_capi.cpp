@@ -159,6 +159,12 @@ void orc_linear_assignment(const float* cost, int n, int m, float thresh, int* x
   if (n) std::memcpy(x, r.x.data(), sizeof(int) * n);
   if (m) std::memcpy(y, r.y.data(), sizeof(int) * m);
 }
+// work counters of the last assignment solved on this thread (instrumentation)
+void orc_lap_stats(long* out) {
+  const LapStats& s = lap_stats();
+  long v[9] = {s.n, s.free_after_colred, s.unique_rows, s.carr_iters, s.paths, s.finds, s.find_records, s.scan_rows, s.scan_ties};
+  for (int i = 0; i < 9; ++i) out[i] = v[i];
+}
 // OC-SORT first-stage association (ocsort.cpp:610-738). dets nd x 5, trks nt x 5, vel nt x 2, prev nt x 5.
 // Writes matches as (det,trk) pairs; um lists may contain duplicates (Q4). Returns match count.
 int orc_ocsort_associate(const float* dets, int nd, const float* trks, int nt, const float* vel,

@@ -162,6 +162,13 @@ struct LapResult {
   std::vector<int> x, y;  // row->col / col->row over the real block, -1 when unmatched
 };
 
+// Work counters of the last lapjv_rect() call (instrumentation only; results are unaffected).
+struct LapStats {
+  long n = 0, free_after_colred = 0, unique_rows = 0, carr_iters = 0, paths = 0, finds = 0,
+       find_records = 0, scan_rows = 0, scan_ties = 0;
+};
+inline LapStats& lap_stats() { static thread_local LapStats s; return s; }
+
 namespace lapdetail {
 constexpr double kLarge = 1000000.0;  // lap_solver.hpp:24
 
@@ -197,6 +204,7 @@ inline int column_reduce(const Ext& E, std::vector<int>& free_rows, std::vector<
   for (int i = 0; i < n; ++i) {
     if (x[i] < 0) { free_rows[nfree++] = i; continue; }
     if (!uniq[i]) continue;
+    ++lap_stats().unique_rows;
     const int j = x[i];
     double mn = kLarge;
     for (int j2 = 0; j2 < n; ++j2) {
@@ -217,6 +225,7 @@ inline int augmenting_row_reduce(const Ext& E, int nfree, std::vector<int>& free
   int new_free = 0;
   while (current < static_cast<unsigned>(nfree)) {
     ++rr_cnt;
+    ++lap_stats().carr_iters;
     const int fi = free_rows[current++];
     int j1 = 0, j2 = -1;
     double v1 = E.at(fi, 0) - v[0], v2 = kLarge;
@@ -260,7 +269,10 @@ inline void lapjv_rect(const float* cost, int nr, int nc, int ld, double thresh,
   const int n = E.n();
   std::vector<int> x(n), y(n), free_rows(n);
   std::vector<double> v(n);
+  lap_stats() = LapStats();
+  lap_stats().n = n;
   int nfree = column_reduce(E, free_rows, x, y, v);
+  lap_stats().free_after_colred = nfree;
   for (int pass = 0; nfree > 0 && pass < 2; ++pass)  // lap_solver.hpp:220-224
     nfree = augmenting_row_reduce(E, nfree, free_rows, x, y, v);
   if (nfree > 0) {  // _ca_dense :195-211
@@ -268,6 +280,7 @@ inline void lapjv_rect(const float* cost, int nr, int nc, int ld, double thresh,
     std::vector<double> d(n);
     for (int f = 0; f < nfree; ++f) {
       const int start = free_rows[f];
+      ++lap_stats().paths;
       // shortest path with exact lo/hi write-back semantics of find_path_dense
       const unsigned un = static_cast<unsigned>(n);
       unsigned lo = 0, hi = 0, n_ready = 0;
@@ -280,11 +293,13 @@ inline void lapjv_rect(const float* cost, int nr, int nc, int ld, double thresh,
       while (final_j == -1) {
         if (lo == hi) {
           n_ready = lo;
+          ++lap_stats().finds;
           hi = lo + 1;
           double mind = d[cols[lo]];
           for (unsigned k = hi; k < un; ++k) {
             const int j = cols[k];
             if (d[j] <= mind) {
+              ++lap_stats().find_records;
               if (d[j] < mind) { hi = lo; mind = d[j]; }
               cols[k] = cols[hi];
               cols[hi++] = j;
@@ -300,6 +315,7 @@ inline void lapjv_rect(const float* cost, int nr, int nc, int ld, double thresh,
           bool returned = false;
           while (slo != shi) {
             int j = cols[slo++];
+            ++lap_stats().scan_rows;
             const int i = y[j];
             const double mind = d[j];
             const double h = E.at(i, j) - v[j] - mind;
@@ -311,6 +327,7 @@ inline void lapjv_rect(const float* cost, int nr, int nc, int ld, double thresh,
                 pred[j] = i;
                 if (cred == mind) {
                   if (y[j] < 0) { final_j = j; returned = true; break; }
+                  ++lap_stats().scan_ties;
                   cols[k] = cols[shi];
                   cols[shi++] = j;
                 }

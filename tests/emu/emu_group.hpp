@@ -1,0 +1,77 @@
+// TEST HARNESS ONLY — host thread emulation of the device workgroup interface (grp.hpp) so the
+// kernels' algorithmic cores (lap_core.hpp) can be exercised against the oracle on a machine
+// without a GPU. One OS thread per emulated lane, pthread barrier for __syncthreads(), reductions
+// through a shared scratch in a fixed lane order. Never linked into the product libraries.
+#pragma once
+#include <pthread.h>
+
+#include <atomic>
+#include <vector>
+
+#include "../../motcpp_amd/csrc/grp.hpp"
+
+namespace mot {
+
+struct EmuShared {
+  pthread_barrier_t bar;
+  int T;
+  std::vector<Top2> s_top2[2];
+  std::vector<double> s_f64[2];
+  std::vector<int> s_int[2];
+  explicit EmuShared(int t) : T(t) {
+    pthread_barrier_init(&bar, nullptr, t);
+    for (int k = 0; k < 2; ++k) { s_top2[k].resize(t); s_f64[k].resize(t); s_int[k].resize(t); }
+  }
+  ~EmuShared() { pthread_barrier_destroy(&bar); }
+};
+
+struct EmuGroup {
+  EmuShared* sh;
+  int tid_;
+  int phase = 0;
+  EmuGroup(EmuShared* s, int t) : sh(s), tid_(t) {}
+  int tid() const { return tid_; }
+  int size() const { return sh->T; }
+  void sync() { pthread_barrier_wait(&sh->bar); }
+  double reduce_min(double v) {
+    auto& s = sh->s_f64[phase++ & 1];
+    s[tid_] = v;
+    sync();
+    double r = s[0];
+    for (int t = 1; t < sh->T; ++t) r = (s[t] < r) ? s[t] : r;
+    return r;
+  }
+  int reduce_max(int v) {
+    auto& s = sh->s_int[phase++ & 1];
+    s[tid_] = v;
+    sync();
+    int r = s[0];
+    for (int t = 1; t < sh->T; ++t) r = (s[t] > r) ? s[t] : r;
+    return r;
+  }
+  int reduce_min_int(int v) { return -reduce_max(-v); }
+  Top2 reduce_top2(Top2 v) {
+    auto& s = sh->s_top2[phase++ & 1];
+    s[tid_] = v;
+    sync();
+    Top2 r = s[0];
+    for (int t = 1; t < sh->T; ++t) r = top2_merge(r, s[t]);
+    return r;
+  }
+  int exclusive_scan(int v, int* total) {
+    auto& s = sh->s_int[phase++ & 1];
+    s[tid_] = v;
+    sync();
+    int base = 0, tot = 0;
+    for (int t = 0; t < sh->T; ++t) { if (t < tid_) base += s[t]; tot += s[t]; }
+    *total = tot;
+    return base;
+  }
+  static void atomic_max(int* p, int v) {
+    int cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  }
+  static int atomic_add(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+};
+
+}  // namespace mot

@@ -1,0 +1,203 @@
+/* motcpp_amd.h — C ABI of the MI355X-native association hot path of motcpp.
+ *
+ * Drop-in boundary: these entry points are what a binding of the reference's
+ * internal primitive seam would call instead of the Eigen/CPU code. Each one cites the reference
+ * interface it replaces (paths relative to the motcpp repository):
+ *
+ *   mot_det_prepare     STrack/BotSTrack/SortTrack ctors' box chains  src/trackers/bytetrack.cpp:18-37,
+ *                       botsort.cpp:23-36, sort.cpp:21-41; include/motcpp/utils/ops.hpp:15-211
+ *   mot_kf_initiate     BaseKalmanFilter::initiate src/motion/kalman_filter.cpp:29-42,
+ *                       KalmanFilterXYWH::initiate include/motcpp/motion/kalman_filters/xywh_kf.hpp:41-62,
+ *                       KalmanFilterXYSR ctor src/motion/kalman_filters/xysr_kf.cpp:10-69
+ *   mot_kf_predict      ::predict kalman_filter.cpp:44-58, xysr_kf.cpp:71-77, xywh_kf.hpp:70-94 (+ the
+ *                       per-track glue STrack::multi_predict bytetrack.cpp:97-115, KalmanBoxTracker::predict
+ *                       ocsort.cpp:132-148)
+ *   mot_kf_update       ::update kalman_filter.cpp:77-112, xysr_kf.cpp:79-112, xywh_kf.hpp:103-135
+ *   mot_kf_boxes        STrack::xyxy bytetrack.cpp:117-127, BotSTrack::xyxy botsort.cpp:171-181,
+ *                       utils::xysr2xyxy ops.hpp:202-211
+ *   mot_iou_cost        utils::iou_batch include/motcpp/utils/iou.hpp:63-100, utils::iou_distance
+ *                       src/utils/matching.cpp:62-65, utils::fuse_score matching.cpp:130-143, BoT-SORT's
+ *                       gate/min botsort.cpp:433-466, ByteTrack::remove_duplicate_stracks bytetrack.cpp:659-706
+ *   mot_cosine_cost     utils::embedding_distance src/utils/matching.cpp:67-92
+ *   mot_feat_update     BotSTrack ctor / update_features botsort.cpp:38-46,158-169
+ *   mot_ocsort_cost     ocsort_assoc::associate cost construction src/trackers/ocsort.cpp:624-679,699
+ *   mot_lap_solve       utils::linear_assignment src/utils/matching.cpp:14-60 →
+ *                       LAPSolver::linearAssignment include/motcpp/association/lap_solver.hpp:251-332
+ *                       (+ OC-SORT's trivial-case shortcut and max-IoU gates ocsort.cpp:681-714,443,499)
+ *
+ * Conventions: every pointer inside a *_task is a DEVICE pointer; task arrays are device arrays;
+ * all calls are asynchronous on the context's HIP stream unless suffixed _host (those take host
+ * pointers, copy, run and synchronise — convenience for bindings and tests). Functions return
+ * MOT_OK (0) or a negative mot_status and never throw. One mot_ctx per host thread / stream.
+ * There is no CPU fallback: without a usable gfx950 device mot_ctx_create fails.
+ */
+#ifndef MOTCPP_AMD_H_
+#define MOTCPP_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mot_ctx mot_ctx;
+
+typedef enum mot_status {
+  MOT_OK = 0,
+  MOT_ERR_INVALID = -1,   /* bad argument */
+  MOT_ERR_HIP = -2,       /* a HIP runtime call failed; see mot_ctx_last_error */
+  MOT_ERR_NOMEM = -3,
+  MOT_ERR_NODEVICE = -4   /* no gfx950 device visible */
+} mot_status;
+
+/* ---- context, stream, memory --------------------------------------------------------- */
+const char* mot_version(void);
+int mot_device_count(void);
+int mot_ctx_create(int device, void* hip_stream /* hipStream_t or NULL: own stream */, mot_ctx** out);
+int mot_ctx_destroy(mot_ctx* ctx);
+int mot_ctx_sync(mot_ctx* ctx);
+void* mot_ctx_stream(mot_ctx* ctx);
+const char* mot_ctx_last_error(mot_ctx* ctx);
+
+int mot_malloc(mot_ctx* ctx, size_t bytes, void** dptr);
+int mot_free(mot_ctx* ctx, void* dptr);
+int mot_host_alloc(mot_ctx* ctx, size_t bytes, void** hptr); /* pinned */
+int mot_host_free(mot_ctx* ctx, void* hptr);
+int mot_memcpy_h2d(mot_ctx* ctx, void* d, const void* h, size_t bytes); /* async on the stream */
+int mot_memcpy_d2h(mot_ctx* ctx, void* h, const void* d, size_t bytes); /* async on the stream */
+int mot_memcpy_d2d(mot_ctx* ctx, void* dst, const void* src, size_t bytes);
+int mot_memset(mot_ctx* ctx, void* d, int value, size_t bytes);
+/* stream-ordered timing (hipEvent pair): returns elapsed milliseconds between two marks */
+int mot_timer_start(mot_ctx* ctx);
+int mot_timer_stop(mot_ctx* ctx, float* ms); /* synchronises */
+
+/* ---- detections ---------------------------------------------------------------------- */
+typedef enum mot_det_kind {
+  MOT_DET_XYSR = 0, /* SORT / OC-SORT: box = raw xyxy, meas = xyxy2xysr                     */
+  MOT_DET_XYAH = 1, /* ByteTrack: xywh -> tlwh -> xyah chain, box = xywh2xyxy(xywh)          */
+  MOT_DET_XYWH = 2  /* BoT-SORT: xywh = (x1+w/2, y1+h/2, w, h), box = (cx-w/2, ...)          */
+} mot_det_kind;
+
+typedef struct mot_det_task {
+  const float* dets; /* SoA planes [6][ld]: x1,y1,x2,y2,conf,cls (= a column-major N x 6 matrix) */
+  int32_t ld, n;
+  float* box;  int32_t ldb; /* out [4][ldb] association boxes                                  */
+  float* meas; int32_t ldm; /* out [4][ldm] Kalman measurements                                */
+} mot_det_task;
+int mot_det_prepare(mot_ctx* ctx, int det_kind, const mot_det_task* tasks, int ntasks, int max_n);
+
+/* ---- Kalman filters ------------------------------------------------------------------ */
+typedef enum mot_kf_kind { MOT_KF_XYSR = 0 /* d=7 */, MOT_KF_XYAH = 1 /* d=8 */, MOT_KF_XYWH = 2 /* d=8 */ } mot_kf_kind;
+enum {
+  MOT_KF_ZERO_V7 = 1,     /* predict: mean[7] = 0 first (ByteTrack, non-Tracked: bytetrack.cpp:108-110) */
+  MOT_KF_OCSORT_CLAMP = 2 /* predict: if x6 + x2 <= 0 then x6 = 0 (ocsort.cpp:134-136)                  */
+};
+/* Track-state slab, SoA: mean plane k at mean + k*cap, covariance element (r,c) at cov + (r*d+c)*cap. */
+typedef struct mot_kf_task {
+  float* mean; float* cov; int32_t cap;
+  int32_t n;                 /* items                                                         */
+  const int32_t* src;        /* [n] slot read  (NULL: item index)                             */
+  const int32_t* dst;        /* [n] slot written (NULL: same as src)                          */
+  const uint8_t* flags;      /* [n] MOT_KF_* bits or NULL                                     */
+  const float* meas; int32_t ldm; /* [4][ldm] measurements (initiate / update)               */
+  const int32_t* midx;       /* [n] measurement column per item (NULL: item index)            */
+  float* boxes; int32_t ldb; /* optional out [4][ldb]: xyxy of the written state, column = item */
+  float q[3];                /* XYSR only: Q(4,4), Q(5,5), Q(6,6)                             */
+  int32_t reserved;
+} mot_kf_task;
+int mot_kf_dim(int kf_kind);
+int mot_kf_initiate(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
+int mot_kf_predict(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
+int mot_kf_update(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
+int mot_kf_boxes(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
+
+/* ---- N x M box costs ----------------------------------------------------------------- */
+typedef enum mot_cost_mode {
+  MOT_COST_IOU = 0,           /* iou                                                          */
+  MOT_COST_IOU_DIST = 1,      /* 1 - iou                                                      */
+  MOT_COST_IOU_DIST_FUSE = 2, /* 1 - (1 - (1 - iou)) * conf_j                                 */
+  MOT_COST_NEG_IOU = 3,       /* -iou (OC-SORT rematch)                                       */
+  MOT_COST_BOTSORT = 4        /* min(fuse?(1-iou), gate(emb/2)) — botsort.cpp:433-466          */
+} mot_cost_mode;
+typedef struct mot_iou_task {
+  int32_t n, m;
+  const float* a; int32_t lda; const int32_t* aidx; /* row boxes [4][lda], optional gather       */
+  const float* b; int32_t ldb; const int32_t* bidx; /* column boxes                              */
+  const float* bconf;                               /* column confidences, indexed like b        */
+  float* cost; int32_t ldc;                         /* out n x m row-major (may be NULL)         */
+  int32_t mode;
+  const float* emb; int32_t lde;                    /* BOTSORT: cosine distances n x m           */
+  float prox_thresh, app_thresh; int32_t fuse;      /* BOTSORT                                   */
+  int32_t* pairs; int32_t* npairs; int32_t pairs_cap; float pair_thresh; /* optional: (i,j) with value < thresh */
+} mot_iou_task;
+int mot_iou_cost(mot_ctx* ctx, const mot_iou_task* tasks, int ntasks, int max_n, int max_m);
+
+typedef struct mot_ocsort_task {
+  int32_t nd, nt;
+  const float* dbox; int32_t ldd; const int32_t* didx; const float* dconf; /* detections (gathered)   */
+  const float* tbox; int32_t ldt;  /* predicted track boxes [4][ldt]                                   */
+  const float* vel;  int32_t ldv;  /* [2][ldv] velocity direction (dy, dx)                             */
+  const float* prev; int32_t ldp;  /* [5][ldp] k-previous observation x1,y1,x2,y2,score (-1: none)     */
+  float vdc_weight;
+  float* cost; float* iou; int32_t ldc; /* out nd x nt row-major: -(iou + angle) and iou               */
+} mot_ocsort_task;
+int mot_ocsort_cost(mot_ctx* ctx, const mot_ocsort_task* tasks, int ntasks, int max_nd, int max_nt);
+
+/* ---- appearance ---------------------------------------------------------------------- */
+typedef struct mot_cos_task {
+  int32_t n, m, d;
+  const float* a; int32_t lda; const int32_t* aidx; /* track features, rows of length d (gathered) */
+  const float* b; int32_t ldb; const int32_t* bidx; /* detection features                          */
+  float* out; int32_t ldo;                          /* n x m: max(0, 1 - a.b / (|a||b| + 1e-10))   */
+  float* norm_a; float* norm_b;                     /* scratch [n], [m]                            */
+} mot_cos_task;
+int mot_cosine_cost(mot_ctx* ctx, const mot_cos_task* tasks, int ntasks, int max_n, int max_m);
+
+typedef struct mot_feat_task {
+  int32_t n, d;
+  float* feat; int32_t ldf; const int32_t* slot;          /* destination rows feat[slot[i]*ldf ..]   */
+  const float* src; int32_t lds; const int32_t* sidx;     /* raw detection feature rows              */
+  int32_t mode;                                           /* 0: set = src/|src|, 1: EMA then renormalise */
+  float alpha;                                            /* EMA weight of the old feature (0.9)     */
+} mot_feat_task;
+int mot_feat_update(mot_ctx* ctx, const mot_feat_task* tasks, int ntasks, int max_n);
+
+/* ---- linear assignment ---------------------------------------------------------------- */
+typedef enum mot_lap_mode {
+  MOT_LAP_PLAIN = 0,
+  MOT_LAP_GATE_MIN = 1, /* solve only if min(cost) < gate, else leave everything unmatched (ocsort.cpp:443,499) */
+  MOT_LAP_OCSORT = 2    /* if every row/col of (iou > gate) has <= 1 hit and one exists: take those pairs (ocsort.cpp:684-696) */
+} mot_lap_mode;
+typedef struct mot_lap_task {
+  int32_t n, m;
+  const float* cost; int32_t ldc;
+  float thresh;
+  int32_t* x;   /* out [n]: column matched to row i or -1                       */
+  int32_t* y;   /* out [m]: row matched to column j or -1                       */
+  int32_t mode;
+  const float* iou; int32_t ldi; float gate;
+  float* xval;  /* optional out [n]: iou (if given, else cost) at (i, x[i])     */
+  int32_t* info;/* optional out [1]: 0 lapjv, 1 trivial shortcut, 2 gated off   */
+  void* work;   /* scratch of mot_lap_work_bytes(n, m) bytes; only needed when the problem does not fit LDS */
+} mot_lap_task;
+size_t mot_lap_work_bytes(int n, int m);
+int mot_lap_lds_limit(void); /* largest n+m solved entirely out of LDS */
+int mot_lap_solve(mot_ctx* ctx, const mot_lap_task* tasks, int ntasks, int max_n_plus_m);
+
+/* ---- host-pointer conveniences (synchronous; row-major matrices) ---------------------- */
+int mot_iou_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_xyxy, int m,
+                      const float* bconf_or_null, int mode, float* cost);
+int mot_cosine_cost_host(mot_ctx* ctx, const float* a, int n, const float* b, int m, int d, float* out);
+int mot_ocsort_cost_host(mot_ctx* ctx, const float* dets5, int nd, const float* trks4, int nt,
+                         const float* vel2, const float* prev5, float vdc_weight, float* cost, float* iou);
+int mot_lap_solve_host(mot_ctx* ctx, const float* cost, int n, int m, float thresh, int mode,
+                       const float* iou_or_null, float gate, int* x, int* y, int* info_or_null);
+/* mean: n x d, cov: n x d x d row-major (AoS); op: 0 initiate (mean/cov out), 1 predict, 2 update */
+int mot_kf_apply_host(mot_ctx* ctx, int kf_kind, int op, int n, const float* meas4, const float* q3_or_null,
+                      const unsigned char* flags_or_null, float* mean, float* cov, float* boxes4_or_null);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOTCPP_AMD_H_ */

@@ -1,0 +1,271 @@
+// C ABI implementation (include/motcpp_amd.h): context/stream/memory plumbing, launch wrappers
+// for the gfx950 kernels and the synchronous host-pointer conveniences. No CPU compute path
+// exists in this library: every entry point either launches a HIP kernel or fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/motcpp_amd.h"
+#include "lap_core.hpp"
+
+namespace mot {
+hipError_t launch_kf_op(int op, int kind, const mot_kf_task*, int, int, hipStream_t);
+hipError_t launch_det(int kind, const mot_det_task*, int, int, hipStream_t);
+hipError_t launch_iou(const mot_iou_task*, int, int, int, hipStream_t);
+hipError_t launch_ocsort(const mot_ocsort_task*, int, int, int, hipStream_t);
+hipError_t launch_feat(const mot_feat_task*, int, int, hipStream_t);
+hipError_t launch_cosine(const mot_cos_task*, int, int, int, hipStream_t);
+hipError_t launch_lap(const mot_lap_task*, int, int, hipStream_t);
+int lap_lds_limit();
+}  // namespace mot
+
+struct mot_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+};
+
+namespace {
+int fail(mot_ctx* c, hipError_t e, const char* what) {
+  if (c) c->err = std::string(what) + ": " + hipGetErrorString(e);
+  return MOT_ERR_HIP;
+}
+#define MOT_HIP(c, call)                                    \
+  do {                                                      \
+    hipError_t e__ = (call);                                \
+    if (e__ != hipSuccess) return fail((c), e__, #call);    \
+  } while (0)
+
+// RAII device buffer for the _host conveniences
+struct DBuf {
+  void* p = nullptr;
+  ~DBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <class T> T* as() { return static_cast<T*>(p); }
+};
+}  // namespace
+
+extern "C" {
+
+const char* mot_version(void) { return "motcpp_amd 0.1 (gfx950)"; }
+
+int mot_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mot_ctx_create(int device, void* hip_stream, mot_ctx** out) {
+  if (!out) return MOT_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return MOT_ERR_NODEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MOT_ERR_NODEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MOT_ERR_NODEVICE;  // kernels are built for gfx950 only
+  if (hipSetDevice(device) != hipSuccess) return MOT_ERR_HIP;
+  mot_ctx* c = new mot_ctx();
+  c->device = device;
+  if (hip_stream) c->stream = static_cast<hipStream_t>(hip_stream);
+  else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MOT_ERR_HIP; }
+    c->own_stream = true;
+  }
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return MOT_ERR_HIP; }
+  *out = c;
+  return MOT_OK;
+}
+int mot_ctx_destroy(mot_ctx* c) {
+  if (!c) return MOT_OK;
+  (void)hipStreamSynchronize(c->stream);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return MOT_OK;
+}
+int mot_ctx_sync(mot_ctx* c) { MOT_HIP(c, hipStreamSynchronize(c->stream)); return MOT_OK; }
+void* mot_ctx_stream(mot_ctx* c) { return c ? c->stream : nullptr; }
+const char* mot_ctx_last_error(mot_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int mot_malloc(mot_ctx* c, size_t bytes, void** d) { MOT_HIP(c, hipSetDevice(c->device)); MOT_HIP(c, hipMalloc(d, bytes ? bytes : 16)); return MOT_OK; }
+int mot_free(mot_ctx* c, void* d) { if (d) MOT_HIP(c, hipFree(d)); return MOT_OK; }
+int mot_host_alloc(mot_ctx* c, size_t bytes, void** h) { MOT_HIP(c, hipHostMalloc(h, bytes ? bytes : 16, hipHostMallocDefault)); return MOT_OK; }
+int mot_host_free(mot_ctx* c, void* h) { if (h) MOT_HIP(c, hipHostFree(h)); return MOT_OK; }
+int mot_memcpy_h2d(mot_ctx* c, void* d, const void* h, size_t b) { if (b) MOT_HIP(c, hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, c->stream)); return MOT_OK; }
+int mot_memcpy_d2h(mot_ctx* c, void* h, const void* d, size_t b) { if (b) MOT_HIP(c, hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, c->stream)); return MOT_OK; }
+int mot_memcpy_d2d(mot_ctx* c, void* dst, const void* src, size_t b) { if (b) MOT_HIP(c, hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToDevice, c->stream)); return MOT_OK; }
+int mot_memset(mot_ctx* c, void* d, int v, size_t b) { if (b) MOT_HIP(c, hipMemsetAsync(d, v, b, c->stream)); return MOT_OK; }
+int mot_timer_start(mot_ctx* c) { MOT_HIP(c, hipEventRecord(c->ev0, c->stream)); return MOT_OK; }
+int mot_timer_stop(mot_ctx* c, float* ms) {
+  MOT_HIP(c, hipEventRecord(c->ev1, c->stream));
+  MOT_HIP(c, hipEventSynchronize(c->ev1));
+  MOT_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return MOT_OK;
+}
+
+int mot_kf_dim(int kind) { return kind == MOT_KF_XYSR ? 7 : 8; }
+
+int mot_det_prepare(mot_ctx* c, int kind, const mot_det_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_det(kind, t, nt, max_n, c->stream)); return MOT_OK; }
+int mot_kf_initiate(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_kf_op(0, kind, t, nt, max_n, c->stream)); return MOT_OK; }
+int mot_kf_predict(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_kf_op(1, kind, t, nt, max_n, c->stream)); return MOT_OK; }
+int mot_kf_update(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_kf_op(2, kind, t, nt, max_n, c->stream)); return MOT_OK; }
+int mot_kf_boxes(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_kf_op(3, kind, t, nt, max_n, c->stream)); return MOT_OK; }
+int mot_iou_cost(mot_ctx* c, const mot_iou_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_iou(t, nt, max_n, max_m, c->stream)); return MOT_OK; }
+int mot_ocsort_cost(mot_ctx* c, const mot_ocsort_task* t, int nt, int max_nd, int max_nt) { MOT_HIP(c, mot::launch_ocsort(t, nt, max_nd, max_nt, c->stream)); return MOT_OK; }
+int mot_cosine_cost(mot_ctx* c, const mot_cos_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_cosine(t, nt, max_n, max_m, c->stream)); return MOT_OK; }
+int mot_feat_update(mot_ctx* c, const mot_feat_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_feat(t, nt, max_n, c->stream)); return MOT_OK; }
+size_t mot_lap_work_bytes(int n, int m) { return (mot::lap_work_bytes(n + m) + 255) & ~size_t(255); }
+int mot_lap_lds_limit(void) { return mot::lap_lds_limit(); }
+int mot_lap_solve(mot_ctx* c, const mot_lap_task* t, int nt, int max_nm) { MOT_HIP(c, mot::launch_lap(t, nt, max_nm, c->stream)); return MOT_OK; }
+
+// ---- host-pointer conveniences ------------------------------------------------------------------
+static void to_soa4(const float* aos, int n, int cols, int stride, std::vector<float>& soa) {
+  soa.assign(static_cast<size_t>(cols) * (n ? n : 1), 0.f);
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < cols; ++k) soa[static_cast<size_t>(k) * n + i] = aos[static_cast<size_t>(i) * stride + k];
+}
+
+int mot_iou_cost_host(mot_ctx* c, const float* a, int n, const float* b, int m, const float* bconf, int mode, float* cost) {
+  if (n <= 0 || m <= 0) return MOT_OK;
+  std::vector<float> sa, sb;
+  to_soa4(a, n, 4, 4, sa);
+  to_soa4(b, m, 4, 4, sb);
+  DBuf da, db, dc, dcost, dt;
+  MOT_HIP(c, da.alloc(sa.size() * 4)); MOT_HIP(c, db.alloc(sb.size() * 4)); MOT_HIP(c, dc.alloc(m * 4));
+  MOT_HIP(c, dcost.alloc(static_cast<size_t>(n) * m * 4)); MOT_HIP(c, dt.alloc(sizeof(mot_iou_task)));
+  MOT_HIP(c, hipMemcpyAsync(da.p, sa.data(), sa.size() * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(db.p, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, c->stream));
+  if (bconf) MOT_HIP(c, hipMemcpyAsync(dc.p, bconf, m * 4, hipMemcpyHostToDevice, c->stream));
+  mot_iou_task t{};
+  t.n = n; t.m = m; t.a = da.as<float>(); t.lda = n; t.b = db.as<float>(); t.ldb = m;
+  t.bconf = bconf ? dc.as<float>() : nullptr; t.cost = dcost.as<float>(); t.ldc = m; t.mode = mode;
+  MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, mot::launch_iou(dt.as<mot_iou_task>(), 1, n, m, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(cost, dcost.p, static_cast<size_t>(n) * m * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+
+int mot_cosine_cost_host(mot_ctx* c, const float* a, int n, const float* b, int m, int d, float* out) {
+  if (n <= 0 || m <= 0) return MOT_OK;
+  DBuf da, db, dout, dna, dnb, dt;
+  MOT_HIP(c, da.alloc(static_cast<size_t>(n) * d * 4)); MOT_HIP(c, db.alloc(static_cast<size_t>(m) * d * 4));
+  MOT_HIP(c, dout.alloc(static_cast<size_t>(n) * m * 4)); MOT_HIP(c, dna.alloc(n * 4)); MOT_HIP(c, dnb.alloc(m * 4));
+  MOT_HIP(c, dt.alloc(sizeof(mot_cos_task)));
+  MOT_HIP(c, hipMemcpyAsync(da.p, a, static_cast<size_t>(n) * d * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(db.p, b, static_cast<size_t>(m) * d * 4, hipMemcpyHostToDevice, c->stream));
+  mot_cos_task t{};
+  t.n = n; t.m = m; t.d = d; t.a = da.as<float>(); t.lda = d; t.b = db.as<float>(); t.ldb = d;
+  t.out = dout.as<float>(); t.ldo = m; t.norm_a = dna.as<float>(); t.norm_b = dnb.as<float>();
+  MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, mot::launch_cosine(dt.as<mot_cos_task>(), 1, n, m, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(out, dout.p, static_cast<size_t>(n) * m * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+
+int mot_ocsort_cost_host(mot_ctx* c, const float* dets5, int nd, const float* trks4, int nt, const float* vel2,
+                         const float* prev5, float vdc, float* cost, float* iou) {
+  if (nd <= 0 || nt <= 0) return MOT_OK;
+  std::vector<float> sd, st, sv, sp;
+  to_soa4(dets5, nd, 5, 5, sd);
+  to_soa4(trks4, nt, 4, 4, st);
+  to_soa4(vel2, nt, 2, 2, sv);
+  to_soa4(prev5, nt, 5, 5, sp);
+  DBuf dd, dtb, dv, dp, dc, di, dtask;
+  MOT_HIP(c, dd.alloc(sd.size() * 4)); MOT_HIP(c, dtb.alloc(st.size() * 4)); MOT_HIP(c, dv.alloc(sv.size() * 4));
+  MOT_HIP(c, dp.alloc(sp.size() * 4)); MOT_HIP(c, dc.alloc(static_cast<size_t>(nd) * nt * 4));
+  MOT_HIP(c, di.alloc(static_cast<size_t>(nd) * nt * 4)); MOT_HIP(c, dtask.alloc(sizeof(mot_ocsort_task)));
+  MOT_HIP(c, hipMemcpyAsync(dd.p, sd.data(), sd.size() * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(dtb.p, st.data(), st.size() * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(dv.p, sv.data(), sv.size() * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(dp.p, sp.data(), sp.size() * 4, hipMemcpyHostToDevice, c->stream));
+  mot_ocsort_task t{};
+  t.nd = nd; t.nt = nt; t.dbox = dd.as<float>(); t.ldd = nd; t.dconf = dd.as<float>() + static_cast<size_t>(4) * nd;
+  t.tbox = dtb.as<float>(); t.ldt = nt; t.vel = dv.as<float>(); t.ldv = nt; t.prev = dp.as<float>(); t.ldp = nt;
+  t.vdc_weight = vdc; t.cost = dc.as<float>(); t.iou = di.as<float>(); t.ldc = nt;
+  MOT_HIP(c, hipMemcpyAsync(dtask.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, mot::launch_ocsort(dtask.as<mot_ocsort_task>(), 1, nd, nt, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(cost, dc.p, static_cast<size_t>(nd) * nt * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(iou, di.p, static_cast<size_t>(nd) * nt * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+
+int mot_lap_solve_host(mot_ctx* c, const float* cost, int n, int m, float thresh, int mode, const float* iou, float gate,
+                       int* x, int* y, int* info) {
+  if (n <= 0 || m <= 0) {
+    for (int i = 0; i < n; ++i) x[i] = -1;
+    for (int j = 0; j < m; ++j) y[j] = -1;
+    if (info) *info = 2;
+    return MOT_OK;
+  }
+  DBuf dc, di, dx, dy, dinfo, dwork, dt;
+  MOT_HIP(c, dc.alloc(static_cast<size_t>(n) * m * 4)); MOT_HIP(c, dx.alloc(n * 4)); MOT_HIP(c, dy.alloc(m * 4));
+  MOT_HIP(c, dinfo.alloc(16)); MOT_HIP(c, dwork.alloc(mot_lap_work_bytes(n, m))); MOT_HIP(c, dt.alloc(sizeof(mot_lap_task)));
+  MOT_HIP(c, hipMemcpyAsync(dc.p, cost, static_cast<size_t>(n) * m * 4, hipMemcpyHostToDevice, c->stream));
+  if (iou) {
+    MOT_HIP(c, di.alloc(static_cast<size_t>(n) * m * 4));
+    MOT_HIP(c, hipMemcpyAsync(di.p, iou, static_cast<size_t>(n) * m * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  mot_lap_task t{};
+  t.n = n; t.m = m; t.cost = dc.as<float>(); t.ldc = m; t.thresh = thresh; t.x = dx.as<int>(); t.y = dy.as<int>();
+  t.mode = mode; t.iou = iou ? di.as<float>() : nullptr; t.ldi = m; t.gate = gate; t.info = dinfo.as<int>();
+  t.work = dwork.p;
+  MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n + m, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(x, dx.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(y, dy.p, m * 4, hipMemcpyDeviceToHost, c->stream));
+  int inf = 0;
+  MOT_HIP(c, hipMemcpyAsync(&inf, dinfo.p, 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  if (info) *info = inf;
+  return MOT_OK;
+}
+
+int mot_kf_apply_host(mot_ctx* c, int kind, int op, int n, const float* meas4, const float* q3, const unsigned char* flags,
+                      float* mean, float* cov, float* boxes4) {
+  if (n <= 0) return MOT_OK;
+  const int D = mot_kf_dim(kind);
+  std::vector<float> sm(static_cast<size_t>(D) * n), sc(static_cast<size_t>(D) * D * n), sz;
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < D; ++k) sm[static_cast<size_t>(k) * n + i] = mean[static_cast<size_t>(i) * D + k];
+    for (int k = 0; k < D * D; ++k) sc[static_cast<size_t>(k) * n + i] = cov[static_cast<size_t>(i) * D * D + k];
+  }
+  DBuf dm, dcv, dz, df, db, dt;
+  MOT_HIP(c, dm.alloc(sm.size() * 4)); MOT_HIP(c, dcv.alloc(sc.size() * 4)); MOT_HIP(c, dz.alloc(static_cast<size_t>(4) * n * 4));
+  MOT_HIP(c, df.alloc(n)); MOT_HIP(c, db.alloc(static_cast<size_t>(4) * n * 4)); MOT_HIP(c, dt.alloc(sizeof(mot_kf_task)));
+  MOT_HIP(c, hipMemcpyAsync(dm.p, sm.data(), sm.size() * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(dcv.p, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, c->stream));
+  if (meas4) {
+    to_soa4(meas4, n, 4, 4, sz);
+    MOT_HIP(c, hipMemcpyAsync(dz.p, sz.data(), sz.size() * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  if (flags) MOT_HIP(c, hipMemcpyAsync(df.p, flags, n, hipMemcpyHostToDevice, c->stream));
+  mot_kf_task t{};
+  t.mean = dm.as<float>(); t.cov = dcv.as<float>(); t.cap = n; t.n = n; t.flags = flags ? df.as<uint8_t>() : nullptr;
+  t.meas = dz.as<float>(); t.ldm = n; t.boxes = boxes4 ? db.as<float>() : nullptr; t.ldb = n;
+  t.q[0] = q3 ? q3[0] : 0.01f; t.q[1] = q3 ? q3[1] : 0.01f; t.q[2] = q3 ? q3[2] : 0.0001f;
+  MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+  if (op < 0 || op > 2) return MOT_ERR_INVALID;
+  MOT_HIP(c, mot::launch_kf_op(op, kind, dt.as<mot_kf_task>(), 1, n, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(sm.data(), dm.p, sm.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(sc.data(), dcv.p, sc.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  std::vector<float> sb(static_cast<size_t>(4) * n);
+  if (boxes4) MOT_HIP(c, hipMemcpyAsync(sb.data(), db.p, sb.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < D; ++k) mean[static_cast<size_t>(i) * D + k] = sm[static_cast<size_t>(k) * n + i];
+    for (int k = 0; k < D * D; ++k) cov[static_cast<size_t>(i) * D * D + k] = sc[static_cast<size_t>(k) * n + i];
+    if (boxes4) for (int k = 0; k < 4; ++k) boxes4[static_cast<size_t>(i) * 4 + k] = sb[static_cast<size_t>(k) * n + i];
+  }
+  return MOT_OK;
+}
+
+}  // extern "C"

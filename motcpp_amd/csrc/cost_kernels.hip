@@ -1,0 +1,264 @@
+// N x M box-cost matrices for gfx950: IoU family (iou.hpp:63-100, matching.cpp:62-65,130-143,
+// botsort.cpp:433-466), OC-SORT's IoU + velocity-direction cost (ocsort.cpp:624-679,699) and the
+// BoT-SORT feature maintenance (botsort.cpp:38-46,158-169).
+//
+// Tiling: a 256-thread workgroup (4 wavefronts) owns a 64 x 64 output tile. The 64 row boxes and
+// 64 column boxes (+ area, + per-column confidence) are staged once in LDS (2.8 KB) and every
+// thread produces a 4(rows, stride 16) x 4(consecutive columns) micro-tile, so each output row
+// segment is written as one float4 per lane = 256 contiguous bytes per 16 lanes. The matrix is
+// written exactly once and never re-read here: algorithmic traffic = 4*n*m + 16*(n+m) bytes.
+// Grid: x = column tiles, y = row tiles, z = task (one association problem per stream/stage).
+//
+// Arithmetic is the reference's order verbatim (+,-,*,/,min,max with std::min/std::max NaN
+// behaviour), -ffp-contract=off, so costs are bit-identical to the CPU restatement.
+#include <hip/hip_runtime.h>
+
+#include "../../include/motcpp_amd.h"
+
+namespace {
+
+constexpr int kTile = 64;
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a; }  // std::max(a,b)
+__device__ __forceinline__ float smin(float a, float b) { return (b < a) ? b : a; }  // std::min(a,b)
+
+__device__ __forceinline__ float iou_pair(const float a[4], float area_a, const float b[4], float area_b) {
+  const float xx1 = smax(a[0], b[0]);
+  const float yy1 = smax(a[1], b[1]);
+  const float xx2 = smin(a[2], b[2]);
+  const float yy2 = smin(a[3], b[3]);
+  const float w = smax(0.0f, xx2 - xx1);
+  const float h = smax(0.0f, yy2 - yy1);
+  const float inter = w * h;
+  const float uni = area_a + area_b - inter;
+  return (uni > 0.0f) ? (inter / uni) : 0.0f;
+}
+
+struct BoxTile {
+  float c[4][kTile];
+  float area[kTile];
+};
+
+// loads up to 64 boxes (optionally gathered) of a SoA [4][ld] array into LDS; lanes 0..63 of the block do it
+__device__ __forceinline__ void stage_boxes(BoxTile& t, const float* base, int ld, const int* idx, int first, int count,
+                                            int lane) {
+  if (lane >= 0 && lane < kTile) {
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (lane < count) {
+      const int g = idx ? idx[first + lane] : first + lane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) b[k] = base[static_cast<size_t>(k) * ld + g];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t.c[k][lane] = b[k];
+    t.area[lane] = (b[2] - b[0]) * (b[3] - b[1]);
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) iou_kernel(const mot_iou_task* __restrict__ tasks) {
+  const mot_iou_task T = tasks[blockIdx.z];
+  const int row0 = blockIdx.y * kTile, col0 = blockIdx.x * kTile;
+  if (row0 >= T.n || col0 >= T.m) return;
+  __shared__ BoxTile A, B;
+  __shared__ float conf[kTile];
+  const int tid = threadIdx.x;
+  const int nrow = min(kTile, T.n - row0), ncol = min(kTile, T.m - col0);
+  stage_boxes(A, T.a, T.lda, T.aidx, row0, nrow, tid);
+  stage_boxes(B, T.b, T.ldb, T.bidx, col0, ncol, tid - 64);
+  if (tid >= 128 && tid < 128 + kTile) {
+    const int l = tid - 128;
+    float c = 0.f;
+    if (T.bconf && l < ncol) c = T.bconf[T.bidx ? T.bidx[col0 + l] : col0 + l];
+    conf[l] = c;
+  }
+  __syncthreads();
+  const int tx = tid & 15, ty = tid >> 4;
+  const int mode = T.mode;
+  float bb[4][4], barea[4], bc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = tx * 4 + q;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bb[q][k] = B.c[k][c];
+    barea[q] = B.area[c];
+    bc[q] = conf[c];
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = ty + 16 * p;
+    if (r >= nrow) continue;
+    const float aa[4] = {A.c[0][r], A.c[1][r], A.c[2][r], A.c[3][r]};
+    const float aarea = A.area[r];
+    float out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float iou = iou_pair(aa, aarea, bb[q], barea[q]);
+      float v;
+      if (mode == MOT_COST_IOU) v = iou;
+      else if (mode == MOT_COST_NEG_IOU) v = -iou;
+      else {
+        float d = 1.0f - iou;  // iou_distance
+        if (mode == MOT_COST_IOU_DIST_FUSE) {  // fuse_score: 1 - (1 - d) * conf
+          const float sim = 1.0f - d;
+          d = 1.0f - sim * bc[q];
+        } else if (mode == MOT_COST_BOTSORT) {
+          const bool far = d > T.prox_thresh;  // mask from the un-fused distance (botsort.cpp:439)
+          if (T.fuse) { const float sim = 1.0f - d; d = 1.0f - sim * bc[q]; }
+          if (T.emb) {
+            const int c = tx * 4 + q;
+            float e = (c < ncol) ? T.emb[static_cast<size_t>(row0 + r) * T.lde + col0 + c] : 0.f;
+            e = e / 2.0f;
+            if (e > T.app_thresh) e = 1.0f;
+            if (far) e = 1.0f;
+            d = smin(d, e);
+          }
+        }
+        v = d;
+      }
+      out[q] = v;
+    }
+    const int gr = row0 + r;
+    const int gc = col0 + tx * 4;
+    if (T.cost) {
+      float* dst = T.cost + static_cast<size_t>(gr) * T.ldc + gc;
+      if (tx * 4 + 3 < ncol && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+        *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (tx * 4 + q < ncol) dst[q] = out[q];
+      }
+    }
+    if (T.pairs) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (tx * 4 + q < ncol && out[q] < T.pair_thresh) {
+          const int k = atomicAdd(T.npairs, 1);
+          if (k < T.pairs_cap) { T.pairs[2 * k] = gr; T.pairs[2 * k + 1] = gc + q; }
+        }
+    }
+  }
+}
+
+// ---- OC-SORT: rows = detections, columns = tracks --------------------------------------------
+struct TrkTile {
+  float c[4][kTile];
+  float area[kTile];
+  float vy[kTile], vx[kTile];
+  float pcx[kTile], pcy[kTile], valid[kTile];
+};
+
+__global__ void __launch_bounds__(kThreads) ocsort_kernel(const mot_ocsort_task* __restrict__ tasks) {
+  const mot_ocsort_task T = tasks[blockIdx.z];
+  const int row0 = blockIdx.y * kTile, col0 = blockIdx.x * kTile;
+  if (row0 >= T.nd || col0 >= T.nt) return;
+  __shared__ BoxTile D;
+  __shared__ float dcx[kTile], dcy[kTile], dscore[kTile];
+  __shared__ TrkTile K;
+  const int tid = threadIdx.x;
+  const int nrow = min(kTile, T.nd - row0), ncol = min(kTile, T.nt - col0);
+  stage_boxes(D, T.dbox, T.ldd, T.didx, row0, nrow, tid);
+  if (tid < kTile) {
+    float s = 0.f;
+    if (tid < nrow) s = T.dconf[T.didx ? T.didx[row0 + tid] : row0 + tid];
+    dscore[tid] = s;
+  }
+  if (tid >= 64 && tid < 128) {
+    const int l = tid - 64;
+    float b[4] = {0.f, 0.f, 0.f, 0.f}, vy = 0.f, vx = 0.f, p[5] = {0.f, 0.f, 0.f, 0.f, -1.f};
+    if (l < ncol) {
+      const int g = col0 + l;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) b[k] = T.tbox[static_cast<size_t>(k) * T.ldt + g];
+      vy = T.vel[g]; vx = T.vel[static_cast<size_t>(T.ldv) + g];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) p[k] = T.prev[static_cast<size_t>(k) * T.ldp + g];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) K.c[k][l] = b[k];
+    K.area[l] = (b[2] - b[0]) * (b[3] - b[1]);
+    K.vy[l] = vy; K.vx[l] = vx;
+    K.pcx[l] = (p[0] + p[2]) / 2.0f;  // ocsort.cpp:639-640
+    K.pcy[l] = (p[1] + p[3]) / 2.0f;
+    K.valid[l] = (p[4] >= 0.0f) ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  if (tid < kTile) {  // detection centres, ocsort.cpp:637-638
+    dcx[tid] = (D.c[0][tid] + D.c[2][tid]) / 2.0f;
+    dcy[tid] = (D.c[1][tid] + D.c[3][tid]) / 2.0f;
+  }
+  __syncthreads();
+  const int tx = tid & 15, ty = tid >> 4;
+  const float PI = 3.14159265358979323846f;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = ty + 16 * p;
+    if (r >= nrow) continue;
+    const float da[4] = {D.c[0][r], D.c[1][r], D.c[2][r], D.c[3][r]};
+    const float darea = D.area[r];
+    float oc[4], oi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = tx * 4 + q;
+      const float tb[4] = {K.c[0][c], K.c[1][c], K.c[2][c], K.c[3][c]};
+      const float iou = iou_pair(da, darea, tb, K.area[c]);
+      const float dx = dcx[r] - K.pcx[c], dy = dcy[r] - K.pcy[c];
+      const float norm = sqrtf(dx * dx + dy * dy) + 1e-6f;
+      const float Y = dy / norm, X = dx / norm;
+      float cs = K.vx[c] * X + K.vy[c] * Y;
+      cs = smin(smax(cs, -1.0f), 1.0f);
+      const float ac = static_cast<float>(acos(static_cast<double>(cs)));  // canonical fp32 acos
+      const float diff = (PI / 2.0f - fabsf(ac)) / PI;
+      const float ang = ((K.valid[c] * diff) * T.vdc_weight) * dscore[r];
+      oc[q] = -(iou + ang);
+      oi[q] = iou;
+    }
+    const size_t off = static_cast<size_t>(row0 + r) * T.ldc + col0 + tx * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (tx * 4 + q < ncol) { T.cost[off + q] = oc[q]; T.iou[off + q] = oi[q]; }
+  }
+}
+
+// ---- BoT-SORT appearance features: one lane per track, k-ordered fmaf chains -------------------
+__global__ void __launch_bounds__(kThreads) feat_kernel(const mot_feat_task* __restrict__ tasks) {
+  const mot_feat_task T = tasks[blockIdx.y];
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= T.n) return;
+  float* f = T.feat + static_cast<size_t>(T.slot ? T.slot[i] : i) * T.ldf;
+  const float* s = T.src + static_cast<size_t>(T.sidx ? T.sidx[i] : i) * T.lds;
+  float nn = 0.0f;
+  for (int k = 0; k < T.d; ++k) {
+    float v = s[k];
+    if (T.mode == 1) v = T.alpha * f[k] + (1.0f - T.alpha) * v;  // botsort.cpp:163
+    f[k] = v;
+    nn = __builtin_fmaf(v, v, nn);
+  }
+  nn = sqrtf(nn);
+  if (nn > 0.0f)
+    for (int k = 0; k < T.d; ++k) f[k] = f[k] / nn;
+}
+
+}  // namespace
+
+namespace mot {
+hipError_t launch_iou(const mot_iou_task* tasks, int ntasks, int max_n, int max_m, hipStream_t st) {
+  if (ntasks <= 0 || max_n <= 0 || max_m <= 0) return hipSuccess;
+  dim3 grid((max_m + kTile - 1) / kTile, (max_n + kTile - 1) / kTile, ntasks);
+  hipLaunchKernelGGL(iou_kernel, grid, dim3(kThreads), 0, st, tasks);
+  return hipGetLastError();
+}
+hipError_t launch_ocsort(const mot_ocsort_task* tasks, int ntasks, int max_nd, int max_nt, hipStream_t st) {
+  if (ntasks <= 0 || max_nd <= 0 || max_nt <= 0) return hipSuccess;
+  dim3 grid((max_nt + kTile - 1) / kTile, (max_nd + kTile - 1) / kTile, ntasks);
+  hipLaunchKernelGGL(ocsort_kernel, grid, dim3(kThreads), 0, st, tasks);
+  return hipGetLastError();
+}
+hipError_t launch_feat(const mot_feat_task* tasks, int ntasks, int max_n, hipStream_t st) {
+  if (ntasks <= 0 || max_n <= 0) return hipSuccess;
+  dim3 grid((max_n + kThreads - 1) / kThreads, ntasks);
+  hipLaunchKernelGGL(feat_kernel, grid, dim3(kThreads), 0, st, tasks);
+  return hipGetLastError();
+}
+}  // namespace mot

@@ -10,8 +10,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define MOT_DEV __device__ __forceinline__
+#define MOT_HD __host__ __device__ __forceinline__
 #else
 #define MOT_DEV inline
+#define MOT_HD inline
 #endif
 
 namespace mot {

@@ -1,0 +1,467 @@
+// Batched Kalman filters and detection preparation for gfx950 (wave64).
+//
+// Layout: track state lives in HBM as a struct-of-arrays slab — mean plane k at mean + k*cap,
+// covariance element (r,c) at cov + (r*D+c)*cap — so lane l of a wavefront touching slot s+l
+// makes every one of the D + D*D loads/stores a single coalesced 256-byte transaction.
+// One lane owns one track: its 7x7 / 8x8 covariance tile sits in VGPRs (<= 64 floats, fully
+// unrolled constant indexing, no scratch); LDS is deliberately not used — there is no reuse
+// between lanes and the SoA loads are already coalesced, so an LDS round trip would only add
+// traffic. The kernels are HBM-streaming: 2*(D+D*D)*4 bytes per track, a few hundred flops.
+//
+// Arithmetic: fp32, built with -ffp-contract=off, correctly rounded / and sqrt; every inner
+// product is accumulated in k order exactly like the CPU restatement so states are bit-identical
+// to it (F = I + shift and H = [I 0] are applied structurally: the skipped terms are exact zeros).
+#include <hip/hip_runtime.h>
+
+#include "../../include/motcpp_amd.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <int D>
+struct St {
+  float m[D];
+  float P[D][D];
+};
+
+template <int D>
+__device__ __forceinline__ void load_state(St<D>& s, const float* mean, const float* cov, int cap, int slot) {
+#pragma unroll
+  for (int k = 0; k < D; ++k) s.m[k] = mean[static_cast<size_t>(k) * cap + slot];
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) s.P[r][c] = cov[static_cast<size_t>(r * D + c) * cap + slot];
+}
+template <int D>
+__device__ __forceinline__ void store_state(const St<D>& s, float* mean, float* cov, int cap, int slot) {
+#pragma unroll
+  for (int k = 0; k < D; ++k) mean[static_cast<size_t>(k) * cap + slot] = s.m[k];
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) cov[static_cast<size_t>(r * D + c) * cap + slot] = s.P[r][c];
+}
+
+// x' = F x, P' = F P F^T (+Q by the caller). NV = number of position components that carry a velocity.
+template <int D, int NV>
+__device__ __forceinline__ void motion(St<D>& s) {
+  constexpr int O = D - NV;  // velocity of component i sits at i + O (7-state: 4, 8-state: 4)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s.m[i] = s.m[i] + s.m[i + O];
+  float A[D][D];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) A[i][j] = (i < NV) ? (s.P[i][j] + s.P[i + O][j]) : s.P[i][j];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) s.P[i][j] = (j < NV) ? (A[i][j] + A[i][j + O]) : A[i][j];
+}
+
+// Unblocked lower Cholesky of a 4x4 (diagonal, then the column below it; sums first, one subtraction).
+__device__ __forceinline__ bool chol4(float A[4][4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float x = A[k][k];
+    if (k > 0) {
+      float s = A[k][0] * A[k][0];
+#pragma unroll
+      for (int j = 1; j < k; ++j) s += A[k][j] * A[k][j];
+      x -= s;
+    }
+    if (!(x > 0.0f)) return false;
+    x = sqrtf(x);
+    A[k][k] = x;
+#pragma unroll
+    for (int i = k + 1; i < 4; ++i) {
+      float t = A[i][k];
+      if (k > 0) {
+        float s = A[i][0] * A[k][0];
+#pragma unroll
+        for (int j = 1; j < k; ++j) s += A[i][j] * A[k][j];
+        t -= s;
+      }
+      A[i][k] = t / x;
+    }
+  }
+  return true;
+}
+// (L L^T) z = b in place: forward column-axpy, backward row-dot.
+__device__ __forceinline__ void chol4_solve(const float L[4][4], float b[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    b[i] /= L[i][i];
+#pragma unroll
+    for (int r = i + 1; r < 4; ++r) b[r] -= b[i] * L[r][i];
+  }
+#pragma unroll
+  for (int i = 3; i >= 0; --i) {
+    if (i < 3) {
+      float s = L[i + 1][i] * b[i + 1];
+#pragma unroll
+      for (int j = i + 2; j < 4; ++j) s += L[j][i] * b[j];
+      b[i] -= s;
+    }
+    b[i] /= L[i][i];
+  }
+}
+// Partial-pivot LU inverse of a 4x4 (XYWH's S.inverse(), xywh_kf.hpp:124).
+__device__ __forceinline__ void inv_lu4(const float S[4][4], float inv[4][4]) {
+  float lu[4][4];
+  int perm[4] = {0, 1, 2, 3};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lu[i][j] = S[i][j];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int p = k;
+    float best = fabsf(lu[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 4; ++i) {
+      float v = fabsf(lu[i][k]);
+      if (v > best) { best = v; p = i; }
+    }
+    // row swap with a data-dependent index done as selects to keep everything in registers
+#pragma unroll
+    for (int i = k + 1; i < 4; ++i) {
+      if (p == i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float t = lu[k][j]; lu[k][j] = lu[i][j]; lu[i][j] = t; }
+        int tp = perm[k]; perm[k] = perm[i]; perm[i] = tp;
+      }
+    }
+#pragma unroll
+    for (int i = k + 1; i < 4; ++i) lu[i][k] /= lu[k][k];
+#pragma unroll
+    for (int i = k + 1; i < 4; ++i)
+#pragma unroll
+      for (int j = k + 1; j < 4; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = (perm[i] == c) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = i + 1; r < 4; ++r) b[r] -= b[i] * lu[r][i];
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+      b[i] /= lu[i][i];
+#pragma unroll
+      for (int r = 0; r < i; ++r) b[r] -= b[i] * lu[r][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) inv[i][c] = b[i];
+  }
+}
+
+__device__ __forceinline__ float dot4(const float a[4], const float b0, const float b1, const float b2, const float b3) {
+  float s = a[0] * b0;
+  s += a[1] * b1;
+  s += a[2] * b2;
+  s += a[3] * b3;
+  return s;
+}
+
+// ---- XYSR (xysr_kf.cpp) ------------------------------------------------------------------
+__device__ __forceinline__ void xysr_init(St<7>& s, const float z[4]) {
+#pragma unroll
+  for (int i = 0; i < 7; ++i) s.m[i] = (i < 4) ? z[i] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) s.P[i][j] = (i == j) ? ((i < 4) ? 10.0f : 10.0f * 100.0f) : 0.0f;
+}
+__device__ __forceinline__ void xysr_predict(St<7>& s, const float q[3]) {
+  motion<7, 3>(s);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) s.P[i][i] = s.P[i][i] + ((i < 4) ? 1.0f : q[i - 4]);
+}
+__device__ __forceinline__ void xysr_update(St<7>& s, const float z[4]) {
+  const float Rd[4] = {1.0f, 1.0f, 10.0f, 10.0f};
+  float y[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) y[i] = z[i] - s.m[i];
+  float S[4][4], L[4][4], Sinv[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { S[i][j] = s.P[i][j] + ((i == j) ? Rd[i] : 0.0f); L[i][j] = S[i][j]; }
+  if (chol4(L)) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float b[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      b[c] = 1.0f;
+      chol4_solve(L, b);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Sinv[i][c] = b[i];
+    }
+  } else {
+    inv_lu4(S, Sinv);
+  }
+  float K[7][4];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const float pr[4] = {s.P[i][0], s.P[i][1], s.P[i][2], s.P[i][3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) K[i][j] = dot4(pr, Sinv[0][j], Sinv[1][j], Sinv[2][j], Sinv[3][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) s.m[i] = s.m[i] + dot4(K[i], y[0], y[1], y[2], y[3]);
+  // Joseph form P = (I-KH) P (I-KH)^T + K R K^T (xysr_kf.cpp:110-111)
+  float G[7][4];  // first four columns of I - K H (the remaining columns are those of I)
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) G[i][j] = ((i == j) ? 1.0f : 0.0f) - K[i][j];
+  float M1[7][7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      float v = dot4(G[i], s.P[0][j], s.P[1][j], s.P[2][j], s.P[3][j]);
+      if (i >= 4) v += s.P[i][j];
+      M1[i][j] = v;
+    }
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      float first = dot4(M1[i], G[j][0], G[j][1], G[j][2], G[j][3]);
+      if (j >= 4) first += M1[i][j];
+      const float kr[4] = {K[i][0] * Rd[0], K[i][1] * Rd[1], K[i][2] * Rd[2], K[i][3] * Rd[3]};
+      const float second = dot4(kr, K[j][0], K[j][1], K[j][2], K[j][3]);
+      s.P[i][j] = first + second;
+    }
+}
+__device__ __forceinline__ void xysr_box(const St<7>& s, float b[4]) {  // ops.hpp:202-211
+  const float w = sqrtf(s.m[2] * s.m[3]);
+  const float h = s.m[2] / w;
+  b[0] = s.m[0] - w * 0.5f; b[1] = s.m[1] - h * 0.5f; b[2] = s.m[0] + w * 0.5f; b[3] = s.m[1] + h * 0.5f;
+}
+
+// ---- XYAH / XYWH (kalman_filter.cpp, xyah_kf.cpp, xywh_kf.hpp) ------------------------------
+constexpr float kWp = 1.0f / 20.0f;
+constexpr float kWv = 1.0f / 160.0f;
+
+template <int KIND>
+__device__ __forceinline__ void s8_init(St<8>& s, const float z[4]) {
+  const float h = z[3];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s.m[i] = (i < 4) ? z[i] : 0.0f;
+  float sd[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sd[i] = (i < 4) ? 2.0f * kWp * h : 10.0f * kWv * h;
+  if (KIND == MOT_KF_XYAH) { sd[2] = 1e-2f; sd[6] = 1e-5f; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.P[i][j] = (i == j) ? sd[i] * sd[i] : 0.0f;
+}
+template <int KIND>
+__device__ __forceinline__ void s8_predict(St<8>& s) {
+  const float h = s.m[3];
+  float sd[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sd[i] = (i < 4) ? kWp * h : kWv * h;
+  if (KIND == MOT_KF_XYAH) { sd[2] = 1e-2f; sd[6] = 1e-5f; }
+  motion<8, 4>(s);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s.P[i][i] = s.P[i][i] + sd[i] * sd[i];
+}
+template <int KIND>
+__device__ __forceinline__ void s8_update(St<8>& s, const float z[4]) {
+  const float h = s.m[3];
+  float sd[4] = {kWp * h, kWp * h, kWp * h, kWp * h};
+  if (KIND == MOT_KF_XYAH) {
+    sd[2] = 1e-1f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sd[i] = sd[i] * (1.0f - 0.0f);  // NSA factor with confidence 0 (kalman_filter.cpp:67)
+  }
+  float S[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) S[i][j] = s.P[i][j] + ((i == j) ? sd[i] * sd[i] : 0.0f);
+  float K[8][4];
+  if (KIND == MOT_KF_XYAH) {
+    float L[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) L[i][j] = S[i][j];
+    if (chol4(L)) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float b[4] = {s.P[i][0], s.P[i][1], s.P[i][2], s.P[i][3]};
+        chol4_solve(L, b);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) K[i][c] = b[c];
+      }
+    } else {
+      float Sinv[4][4];
+      inv_lu4(S, Sinv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float pr[4] = {s.P[i][0], s.P[i][1], s.P[i][2], s.P[i][3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) K[i][j] = dot4(pr, Sinv[0][j], Sinv[1][j], Sinv[2][j], Sinv[3][j]);
+      }
+    }
+  } else {
+    float Sinv[4][4];
+    inv_lu4(S, Sinv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float pr[4] = {s.P[i][0], s.P[i][1], s.P[i][2], s.P[i][3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) K[i][j] = dot4(pr, Sinv[0][j], Sinv[1][j], Sinv[2][j], Sinv[3][j]);
+    }
+  }
+  float inn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) inn[i] = z[i] - s.m[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s.m[i] = s.m[i] + dot4(K[i], inn[0], inn[1], inn[2], inn[3]);
+  float KS[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) KS[i][j] = dot4(K[i], S[0][j], S[1][j], S[2][j], S[3][j]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.P[i][j] = s.P[i][j] - dot4(KS[i], K[j][0], K[j][1], K[j][2], K[j][3]);
+}
+template <int KIND>
+__device__ __forceinline__ void s8_box(const St<8>& s, float b[4]) {
+  float w = s.m[2];
+  const float h = s.m[3];
+  if (KIND == MOT_KF_XYAH) w = s.m[2] * s.m[3];  // xyah2xywh, ops.hpp:110-114
+  b[0] = s.m[0] - w * 0.5f; b[1] = s.m[1] - h * 0.5f; b[2] = s.m[0] + w * 0.5f; b[3] = s.m[1] + h * 0.5f;
+}
+
+template <int KIND> struct Dim { static constexpr int D = 8; };
+template <> struct Dim<MOT_KF_XYSR> { static constexpr int D = 7; };
+
+enum { OP_INIT = 0, OP_PREDICT = 1, OP_UPDATE = 2, OP_BOXES = 3 };
+
+template <int KIND, int OP>
+__global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restrict__ tasks) {
+  constexpr int D = Dim<KIND>::D;
+  const mot_kf_task T = tasks[blockIdx.y];
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= T.n) return;
+  const int src = T.src ? T.src[i] : i;
+  const int dst = T.dst ? T.dst[i] : src;
+  St<D> s;
+  float z[4] = {0.f, 0.f, 0.f, 0.f};
+  if (OP == OP_INIT || OP == OP_UPDATE) {
+    const int c = T.midx ? T.midx[i] : i;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = T.meas[static_cast<size_t>(k) * T.ldm + c];
+  }
+  if (OP == OP_INIT) {
+    if constexpr (KIND == MOT_KF_XYSR) xysr_init(s, z); else s8_init<KIND>(s, z);
+  } else if (OP == OP_BOXES) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.m[k] = T.mean[static_cast<size_t>(k) * T.cap + src];
+  } else {
+    load_state<D>(s, T.mean, T.cov, T.cap, src);
+    const unsigned f = T.flags ? T.flags[i] : 0u;
+    if (OP == OP_PREDICT) {
+      if constexpr (KIND == MOT_KF_XYSR) {
+        if ((f & MOT_KF_OCSORT_CLAMP) && (s.m[6] + s.m[2]) <= 0.0f) s.m[6] = 0.0f;
+        xysr_predict(s, T.q);
+      } else {
+        if (f & MOT_KF_ZERO_V7) s.m[7] = 0.0f;
+        s8_predict<KIND>(s);
+      }
+    } else {
+      if constexpr (KIND == MOT_KF_XYSR) xysr_update(s, z); else s8_update<KIND>(s, z);
+    }
+  }
+  if (OP != OP_BOXES) store_state<D>(s, T.mean, T.cov, T.cap, dst);
+  if (T.boxes) {
+    float b[4];
+    if constexpr (KIND == MOT_KF_XYSR) xysr_box(s, b); else s8_box<KIND>(s, b);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) T.boxes[static_cast<size_t>(k) * T.ldb + i] = b[k];
+  }
+}
+
+// ---- detections ------------------------------------------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(kThreads) det_kernel(const mot_det_task* __restrict__ tasks) {
+  const mot_det_task T = tasks[blockIdx.y];
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= T.n) return;
+  const float x1 = T.dets[i], y1 = T.dets[static_cast<size_t>(T.ld) + i];
+  const float x2 = T.dets[static_cast<size_t>(2) * T.ld + i], y2 = T.dets[static_cast<size_t>(3) * T.ld + i];
+  float box[4], z[4];
+  if (KIND == MOT_DET_XYSR) {  // ops.hpp:188-197
+    const float w = x2 - x1, h = y2 - y1;
+    z[0] = x1 + w * 0.5f; z[1] = y1 + h * 0.5f; z[2] = w * h; z[3] = (h > 1e-6f) ? (w / h) : 0.0f;
+    box[0] = x1; box[1] = y1; box[2] = x2; box[3] = y2;
+  } else if (KIND == MOT_DET_XYAH) {  // bytetrack.cpp:29-33: xyxy2xywh -> xywh2tlwh -> tlwh2xyah
+    const float w = x2 - x1, h = y2 - y1;
+    const float xc = x1 + w * 0.5f, yc = y1 + h * 0.5f;
+    const float tl = xc - w * 0.5f, tt = yc - h * 0.5f;
+    z[0] = tl + w * 0.5f; z[1] = tt + h * 0.5f; z[2] = (h > 0.0f) ? (w / h) : 0.0f; z[3] = h;
+    box[0] = xc - w * 0.5f; box[1] = yc - h * 0.5f; box[2] = xc + w * 0.5f; box[3] = yc + h * 0.5f;  // xywh2xyxy
+  } else {  // botsort.cpp:23-36, 171-181
+    const float w = x2 - x1, h = y2 - y1;
+    const float cx = x1 + w / 2.0f, cy = y1 + h / 2.0f;
+    z[0] = cx; z[1] = cy; z[2] = w; z[3] = h;
+    box[0] = cx - w / 2; box[1] = cy - h / 2; box[2] = cx + w / 2; box[3] = cy + h / 2;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (T.box) T.box[static_cast<size_t>(k) * T.ldb + i] = box[k];
+    if (T.meas) T.meas[static_cast<size_t>(k) * T.ldm + i] = z[k];
+  }
+}
+
+template <int OP>
+hipError_t launch_kf(int kind, const mot_kf_task* tasks, int ntasks, int max_n, hipStream_t st) {
+  if (ntasks <= 0 || max_n <= 0) return hipSuccess;
+  dim3 grid((max_n + kThreads - 1) / kThreads, ntasks), block(kThreads);
+  switch (kind) {
+    case MOT_KF_XYSR: hipLaunchKernelGGL((kf_kernel<MOT_KF_XYSR, OP>), grid, block, 0, st, tasks); break;
+    case MOT_KF_XYAH: hipLaunchKernelGGL((kf_kernel<MOT_KF_XYAH, OP>), grid, block, 0, st, tasks); break;
+    case MOT_KF_XYWH: hipLaunchKernelGGL((kf_kernel<MOT_KF_XYWH, OP>), grid, block, 0, st, tasks); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+namespace mot {
+hipError_t launch_kf_op(int op, int kind, const mot_kf_task* tasks, int ntasks, int max_n, hipStream_t st) {
+  switch (op) {
+    case OP_INIT: return launch_kf<OP_INIT>(kind, tasks, ntasks, max_n, st);
+    case OP_PREDICT: return launch_kf<OP_PREDICT>(kind, tasks, ntasks, max_n, st);
+    case OP_UPDATE: return launch_kf<OP_UPDATE>(kind, tasks, ntasks, max_n, st);
+    case OP_BOXES: return launch_kf<OP_BOXES>(kind, tasks, ntasks, max_n, st);
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_det(int kind, const mot_det_task* tasks, int ntasks, int max_n, hipStream_t st) {
+  if (ntasks <= 0 || max_n <= 0) return hipSuccess;
+  dim3 grid((max_n + kThreads - 1) / kThreads, ntasks), block(kThreads);
+  switch (kind) {
+    case MOT_DET_XYSR: hipLaunchKernelGGL((det_kernel<MOT_DET_XYSR>), grid, block, 0, st, tasks); break;
+    case MOT_DET_XYAH: hipLaunchKernelGGL((det_kernel<MOT_DET_XYAH>), grid, block, 0, st, tasks); break;
+    case MOT_DET_XYWH: hipLaunchKernelGGL((det_kernel<MOT_DET_XYWH>), grid, block, 0, st, tasks); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+}  // namespace mot

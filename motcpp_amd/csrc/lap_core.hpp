@@ -37,8 +37,8 @@ struct LapWork {
   int* tmp;    // tie flags (slow path)
   int* lst;    // compacted tie positions (slow path)
 };
-MOT_DEV size_t lap_work_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 7 * sizeof(int)); }
-MOT_DEV LapWork lap_carve(void* base, int n) {
+MOT_HD size_t lap_work_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 7 * sizeof(int)); }
+MOT_HD LapWork lap_carve(void* base, int n) {
   LapWork w;
   char* p = static_cast<char*>(base);
   w.v = reinterpret_cast<double*>(p); p += sizeof(double) * n;

@@ -1,0 +1,201 @@
+"""GPU parity tests of the C-ABI primitives (through the _host entry points of include/motcpp_amd.h) against
+the CPU oracle on the same seeded inputs. Integer results (assignment indices) must be identical; floats are
+required to be bit-identical where the kernel follows the oracle's operation order (IoU family, Kalman,
+cosine via the fp32 MFMA fmaf chain) and within 1e-4 relative otherwise (OC-SORT's acos term)."""
+import numpy as np
+import pytest
+
+from motcpp_amd import _lib as L
+from tests import orclib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def boxes(r, n, world=(1920, 1080)):
+    cx, cy = r.uniform(0, world[0], n), r.uniform(0, world[1], n)
+    w = r.uniform(30, 90, n)
+    h = w * r.uniform(1.8, 2.6, n)
+    return np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (3, 130), (64, 64), (65, 63), (256, 128), (1000, 500), (777, 1231)])
+def test_iou_family_bit_exact(ctx, orc, n, m):
+    r = np.random.default_rng(n * 1000 + m)
+    a, b = boxes(r, n, (600, 400)), boxes(r, m, (600, 400))
+    b[: min(n, m) // 2] = a[: min(n, m) // 2] + r.normal(0, 2, (min(n, m) // 2, 4)).astype(np.float32)
+    conf = r.uniform(0.1, 1, m).astype(np.float32)
+    iou = orc.iou_batch(a, b)
+    assert (iou > 0).sum() > 0 or min(n, m) < 2
+    assert np.array_equal(ctx.iou_cost(a, b, L.COST_IOU), iou)
+    dist = orc.iou_distance(a, b)
+    assert np.array_equal(ctx.iou_cost(a, b, L.COST_IOU_DIST), dist)
+    assert np.array_equal(ctx.iou_cost(a, b, L.COST_IOU_DIST_FUSE, conf), orc.fuse_score(dist, conf))
+    assert np.array_equal(ctx.iou_cost(a, b, L.COST_NEG_IOU), -iou)
+
+
+def test_iou_degenerate_boxes(ctx, orc):
+    a = np.array([[0, 0, 0, 0], [10, 10, 5, 5], [0, 0, 100, 100], [np.nan, 0, 1, 1]], np.float32)
+    b = np.array([[0, 0, 100, 100], [0, 0, 0, 0], [50, 50, 60, 60]], np.float32)
+    assert np.array_equal(ctx.iou_cost(a, b, L.COST_IOU), orc.iou_batch(a, b), equal_nan=True)
+
+
+@pytest.mark.parametrize("n,m,d", [(5, 7, 16), (64, 64, 256), (100, 33, 255), (1024, 512, 256)])
+def test_cosine_mfma_matches_fmaf_chain(ctx, orc, n, m, d):
+    r = np.random.default_rng(d + n)
+    a = r.standard_normal((n, d)).astype(np.float32)
+    b = r.standard_normal((m, d)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    k = min(n, m) // 2
+    b[:k] = a[:k] + 0.05 * r.standard_normal((k, d)).astype(np.float32)
+    ref = orc.cosine_distance(a, b)
+    got = ctx.cosine_cost(a, b)
+    assert np.allclose(got, ref, rtol=1e-4, atol=1e-6)
+    assert np.array_equal(got, ref), f"max abs diff {np.abs(got - ref).max()}"
+
+
+@pytest.mark.parametrize("nd,nt", [(9, 5), (64, 64), (200, 333), (512, 1024)])
+def test_ocsort_cost(ctx, orc, nd, nt):
+    r = np.random.default_rng(nd + nt)
+    trks = boxes(r, nt, (800, 600))
+    dets = np.concatenate([boxes(r, nd, (800, 600)), r.uniform(0.3, 1, (nd, 1)).astype(np.float32)], 1)
+    k = min(nd, nt) // 2
+    dets[:k, :4] = trks[:k] + r.normal(0, 3, (k, 4)).astype(np.float32)
+    vel = r.standard_normal((nt, 2)).astype(np.float32)
+    vel /= np.linalg.norm(vel, axis=1, keepdims=True) + 1e-6
+    prev = np.concatenate([trks + r.normal(0, 5, (nt, 4)).astype(np.float32), r.uniform(0.3, 1, (nt, 1)).astype(np.float32)], 1)
+    prev[::7] = -1
+    cost_o, iou_o = orc.ocsort_cost(dets, np.concatenate([trks, np.zeros((nt, 1), np.float32)], 1), vel, prev, 0.2)
+    cost_g, iou_g = ctx.ocsort_cost(dets, trks, vel, prev, 0.2)
+    assert np.array_equal(iou_g, iou_o)
+    assert np.allclose(cost_g, cost_o, rtol=1e-4, atol=1e-7)
+    frac_exact = (cost_g == cost_o).mean()
+    assert frac_exact > 0.999, frac_exact
+
+
+def lap_case(r, kind, n, m):
+    if kind == "dense":
+        return r.uniform(0, 1, (n, m)).astype(np.float32), 0.8
+    if kind == "dense_forced":
+        return r.uniform(0, 1, (n, m)).astype(np.float32), 10.0
+    if kind == "neg":
+        return (-r.uniform(0, 1, (n, m))).astype(np.float32), -0.3
+    if kind == "quant":
+        return (r.integers(0, 6, (n, m)) / 5.0).astype(np.float32), 0.7
+    if kind == "quant_forced":
+        return (r.integers(0, 4, (n, m)) / 3.0).astype(np.float32), 5.0
+    c = np.ones((n, m), np.float32)
+    for i in range(n):
+        if r.uniform() < 0.8:
+            c[i, r.integers(m)] = r.uniform(0.05, 0.6)
+    e = r.uniform(0, 1, (n, m)) < 0.03
+    c[e] = r.uniform(0.2, 0.95, e.sum()).astype(np.float32)
+    return c, 0.8
+
+
+@pytest.mark.parametrize("kind", ["sparse", "dense", "dense_forced", "neg", "quant", "quant_forced"])
+def test_lap_indices_identical(ctx, orc, kind):
+    r = np.random.default_rng(abs(hash(kind)) % 997)
+    for n, m in [(1, 1), (2, 3), (17, 9), (9, 17), (64, 64), (100, 130), (256, 128), (300, 300)]:
+        c, th = lap_case(r, kind, n, m)
+        xo, yo = orc.linear_assignment(c, th)
+        xg, yg, info = ctx.lap(c, th)
+        assert info == 0
+        assert np.array_equal(xg, xo) and np.array_equal(yg, yo), (kind, n, m)
+
+
+def test_lap_north_star_and_global_workspace(ctx, orc):
+    r = np.random.default_rng(5)
+    for n, m in [(1000, 500), (2600, 1400)]:  # second one exceeds the LDS limit -> global-scratch variant
+        c, th = lap_case(r, "sparse", n, m)
+        xo, yo = orc.linear_assignment(c, th)
+        xg, yg, _ = ctx.lap(c, th)
+        assert np.array_equal(xg, xo) and np.array_equal(yg, yo), (n, m)
+
+
+def test_lap_ocsort_modes(ctx, orc):
+    r = np.random.default_rng(11)
+    # trivial one-to-one case (ocsort.cpp:684-696)
+    iou = np.zeros((6, 5), np.float32)
+    iou[0, 1], iou[2, 0], iou[5, 4] = 0.7, 0.5, 0.9
+    x, y, info = ctx.lap(-iou, -0.3, L.LAP_OCSORT, iou=iou, gate=0.3)
+    assert info == 1 and list(x) == [1, -1, 0, -1, -1, 4] and list(y) == [2, 0, -1, -1, 5]
+    # two hits in one row -> falls through to lapjv
+    iou[0, 2] = 0.6
+    x, y, info = ctx.lap(-iou, -0.3, L.LAP_OCSORT, iou=iou, gate=0.3)
+    xo, yo = orc.linear_assignment(-iou, -0.3)
+    assert info == 0 and np.array_equal(x, xo) and np.array_equal(y, yo)
+    # gate: nothing above the threshold -> untouched (ocsort.cpp:499)
+    low = r.uniform(0, 0.25, (7, 9)).astype(np.float32)
+    x, y, info = ctx.lap(-low, -0.3, L.LAP_GATE_MIN, gate=-0.3)
+    assert info == 2 and (x == -1).all() and (y == -1).all()
+    low[3, 3] = 0.8
+    x, y, info = ctx.lap(-low, -0.3, L.LAP_GATE_MIN, gate=-0.3)
+    xo, yo = orc.linear_assignment(-low, -0.3)
+    assert info == 0 and np.array_equal(x, xo) and np.array_equal(y, yo)
+
+
+@pytest.mark.parametrize("kind", [L.KF_XYSR, L.KF_XYAH, L.KF_XYWH])
+def test_kalman_bit_exact(ctx, orc, kind):
+    r = np.random.default_rng(kind)
+    n = 700
+    b = boxes(r, n)
+    w, h = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    cx, cy = b[:, 0] + w / 2, b[:, 1] + h / 2
+    if kind == L.KF_XYSR:
+        z = np.stack([cx, cy, w * h, w / h], 1)
+    elif kind == L.KF_XYAH:
+        z = np.stack([cx, cy, w / h, h], 1)
+    else:
+        z = np.stack([cx, cy, w, h], 1)
+    z = z.astype(np.float32)
+    q = np.array([1e-4, 1e-4, 1e-8], np.float32) if kind == L.KF_XYSR else None
+    mo, co = orc.kf_initiate(kind, z)
+    mg, cg = ctx.kf_apply(kind, 0, None, None, meas=z)
+    assert np.array_equal(mg, mo) and np.array_equal(cg, co)
+    scale = np.array([2, 2, 60 if kind == L.KF_XYSR else (0.01 if kind == L.KF_XYAH else 2), 0.01 if kind == L.KF_XYSR else 2],
+                     np.float32)
+    for step in range(6):
+        mo, co = orc.kf_predict(kind, mo, co, q)
+        mg, cg, bx = ctx.kf_apply(kind, 1, mg, cg, q=q, want_boxes=True)
+        assert np.array_equal(mg, mo) and np.array_equal(cg, co), f"predict step {step}"
+        zz = (mo[:, :4] + r.normal(0, 1, (n, 4)).astype(np.float32) * scale).astype(np.float32)
+        mo, co = orc.kf_update(kind, mo, co, zz, q)
+        mg, cg = ctx.kf_apply(kind, 2, mg, cg, meas=zz, q=q)
+        assert np.allclose(mg, mo, rtol=1e-4, atol=1e-5) and np.allclose(cg, co, rtol=1e-4, atol=1e-4), f"update step {step}"
+        assert np.array_equal(mg, mo) and np.array_equal(cg, co), f"update step {step}: max diff {np.abs(cg - co).max()}"
+    # state -> box conversion
+    if kind == L.KF_XYSR:
+        ref = orc.box_convert(1, mo[:, :4])
+    elif kind == L.KF_XYAH:
+        ref = orc.box_convert(3, orc.box_convert(6, mo[:, :4]))
+    else:
+        ref = orc.box_convert(3, mo[:, :4])
+    _, _, bx = ctx.kf_apply(kind, 1, mg, cg, q=q, want_boxes=True)
+    mo2, _ = orc.kf_predict(kind, mo, co, q)
+    if kind == L.KF_XYSR:
+        ref = orc.box_convert(1, mo2[:, :4])
+    elif kind == L.KF_XYAH:
+        ref = orc.box_convert(3, orc.box_convert(6, mo2[:, :4]))
+    else:
+        ref = orc.box_convert(3, mo2[:, :4])
+    assert np.array_equal(bx, ref)
+
+
+def test_kalman_predict_flags(ctx, orc):
+    r = np.random.default_rng(3)
+    z = np.stack([r.uniform(0, 1000, 50), r.uniform(0, 1000, 50), r.uniform(0.3, 0.6, 50), r.uniform(50, 200, 50)], 1).astype(np.float32)
+    m, c = orc.kf_initiate(L.KF_XYAH, z)
+    m[:, 4:] = r.normal(0, 1, (50, 4)).astype(np.float32)
+    flags = (np.arange(50) % 2).astype(np.uint8)  # MOT_KF_ZERO_V7 on odd items
+    mref = m.copy()
+    mref[flags == 1, 7] = 0
+    mo, co = orc.kf_predict(L.KF_XYAH, mref, c)
+    mg, cg = ctx.kf_apply(L.KF_XYAH, 1, m, c, flags=flags)
+    assert np.array_equal(mg, mo) and np.array_equal(cg, co)

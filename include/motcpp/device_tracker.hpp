@@ -1,0 +1,50 @@
+// Common base of the MI355X-backed tracker classes: BaseTracker's contract on top of a stage machine
+// (motcpp::rt::Staged) whose numeric work runs in HIP kernels behind the C ABI of motcpp_amd.h.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "tracker.hpp"
+
+namespace motcpp {
+namespace rt {
+class Staged;
+class Device;
+}  // namespace rt
+
+class DeviceTracker : public BaseTracker {
+ public:
+  ~DeviceTracker() override;
+  Eigen::MatrixXf update(const Eigen::MatrixXf& dets, const cv::Mat& img,
+                         const Eigen::MatrixXf& embs = Eigen::MatrixXf()) override;
+  void reset() override;
+  rt::Staged* staged() const { return impl_.get(); }
+  const std::shared_ptr<rt::Device>& device() const { return dev_; }
+
+ protected:
+  DeviceTracker(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class,
+                int nr_classes, const std::string& asso_func, bool is_obb, int device_index);
+  void adopt(rt::Staged* impl);
+  bool validate_inputs_ = true;  // SORT does not call check_inputs (sort.cpp:102-110)
+  bool skip_empty_ = false;      // BoT-SORT returns before touching any state when dets is empty (botsort.cpp:267-269)
+  std::shared_ptr<rt::Device> dev_;
+
+ private:
+  std::unique_ptr<rt::Staged> impl_;
+};
+
+// Lock-step driver for many independent streams on one GPU: every stage of every tracker is batched into
+// one kernel launch per kernel family (the data-parallel axis of the hot path).
+class StreamBatch {
+ public:
+  explicit StreamBatch(std::vector<DeviceTracker*> trackers);
+  // dets[s]: N_s x 6 column-major; returns per-stream M_s x 8 tables
+  std::vector<Eigen::MatrixXf> update(const std::vector<Eigen::MatrixXf>& dets, const cv::Mat& img,
+                                      const std::vector<Eigen::MatrixXf>& embs = {});
+  size_t size() const { return trackers_.size(); }
+
+ private:
+  std::vector<DeviceTracker*> trackers_;
+};
+
+}  // namespace motcpp

@@ -1,0 +1,9 @@
+// Umbrella header (reference: include/motcpp/motcpp.hpp:28-37) for the MI355X-native hot path.
+#pragma once
+#include "tracker.hpp"
+#include "device_tracker.hpp"
+#include "trackers/sort.hpp"
+#include "trackers/bytetrack.hpp"
+#include "trackers/ocsort.hpp"
+#include "trackers/botsort.hpp"
+#include "utils/matching.hpp"

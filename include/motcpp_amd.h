@@ -127,7 +127,7 @@ typedef struct mot_iou_task {
   const float* bconf;                               /* column confidences, indexed like b        */
   float* cost; int32_t ldc;                         /* out n x m row-major (may be NULL)         */
   int32_t mode;
-  const float* emb; int32_t lde;                    /* BOTSORT: cosine distances n x m           */
+  const float* emb; int32_t lde;                    /* BOTSORT: cosine distances n x m (emb NULL and lde < 0: constant 1) */
   float prox_thresh, app_thresh; int32_t fuse;      /* BOTSORT                                   */
   int32_t* pairs; int32_t* npairs; int32_t pairs_cap; float pair_thresh; /* optional: (i,j) with value < thresh */
 } mot_iou_task;

@@ -1,0 +1,49 @@
+/* motcpp_c.h — flat C handles over the C++ tracker classes of libmotcpp.so (for ctypes / cgo / JNI style
+ * bindings and for this repository's tests and bench.py). Matrices are ROW-major here.
+ *
+ * kind: 0 SORT, 1 ByteTrack, 2 OC-SORT, 3 BoT-SORT. Parameter vectors (missing tail = reference defaults):
+ *  SORT      [det_thresh, max_age, max_obs, min_hits, iou_threshold]
+ *  ByteTrack [min_conf, track_thresh, match_thresh, track_buffer, frame_rate, max_age, max_obs]
+ *  OC-SORT   [det_thresh, max_age, max_obs, min_hits, iou_threshold, min_conf, delta_t, inertia, use_byte, Q_xy, Q_s]
+ *  BoT-SORT  [track_high, track_low, new_track, track_buffer, match_thresh, proximity, appearance,
+ *             frame_rate, fuse_first_associate, with_reid, max_age, max_obs]
+ * Functions return >= 0 on success and a negative value on error (motcpp_last_error() has the message).
+ */
+#ifndef MOTCPP_C_H_
+#define MOTCPP_C_H_
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct motcpp_tracker motcpp_tracker;
+typedef struct motcpp_batch motcpp_batch;
+
+const char* motcpp_last_error(void);
+
+motcpp_tracker* motcpp_tracker_create(int kind, const float* params, int nparams, int device);
+void motcpp_tracker_destroy(motcpp_tracker* t);
+int motcpp_tracker_reset(motcpp_tracker* t);
+/* dets: n x 6 [x1,y1,x2,y2,conf,cls]; embs: n x d or NULL; out: cap x 8. Returns rows, or -(rows needed) - 1000000 if cap is too small. */
+int motcpp_tracker_update(motcpp_tracker* t, const float* dets, int n, const float* embs, int d, float* out, int cap);
+/* parity hooks: assignments solved during the last update, and the Kalman states of the live tracks */
+int motcpp_tracker_lap_count(motcpp_tracker* t);
+int motcpp_tracker_lap_get(motcpp_tracker* t, int k, int* n, int* m, int* x, int* y, int cap);
+int motcpp_tracker_dump_states(motcpp_tracker* t, float* out, int cap_floats, int* width); /* rows [id, mean(d), cov(d*d)] */
+
+/* S independent streams stepped in lockstep on one GPU (one kernel launch per kernel family per stage). */
+motcpp_batch* motcpp_batch_create(int kind, const float* params, int nparams, int nstreams, int device);
+void motcpp_batch_destroy(motcpp_batch* b);
+/* dets: [S][max_n][6] with counts[s] valid rows; embs: [S][max_n][d] or NULL; out: [S][cap][8]; out_counts: [S].
+ * threads: host threads used for the per-stream lifecycle work (<= 1: caller thread only). */
+int motcpp_batch_step(motcpp_batch* b, const float* dets, const int* counts, int max_n, const float* embs, int d,
+                      float* out, int* out_counts, int cap);
+int motcpp_batch_set_threads(motcpp_batch* b, int threads);
+/* counters since creation: [0] frames stepped, [1] flushes, [2] kernel launches */
+int motcpp_batch_counters(motcpp_batch* b, long* out3);
+int motcpp_batch_tracker_count(motcpp_batch* b);
+motcpp_tracker* motcpp_batch_tracker(motcpp_batch* b, int s); /* borrowed handle (for the parity hooks) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -130,3 +130,163 @@ class Context:
                                              _p(qq) if qq is not None else None, _p(fl) if fl is not None else None,
                                              _p(mean), _p(cov), _p(boxes) if boxes is not None else None))
         return (mean, cov, boxes) if want_boxes else (mean, cov)
+
+
+# ---- tracker handles (libmotcpp.so: C++17 host library over the C ABI) ------------------------------------
+SORT, BYTETRACK, OCSORT, BOTSORT = 0, 1, 2, 3
+KIND = {"sort": SORT, "bytetrack": BYTETRACK, "ocsort": OCSORT, "botsort": BOTSORT}
+_host = None
+
+
+def host():
+    global _host
+    if _host is None:
+        hip()
+        if not os.path.exists(HOST_LIB):
+            raise MotError(f"{HOST_LIB} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+        H = C.CDLL(HOST_LIB)
+        H.motcpp_last_error.restype = C.c_char_p
+        H.motcpp_tracker_create.restype = C.c_void_p
+        H.motcpp_tracker_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
+        H.motcpp_tracker_destroy.argtypes = [C.c_void_p]
+        H.motcpp_tracker_reset.argtypes = [C.c_void_p]
+        H.motcpp_tracker_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        H.motcpp_tracker_lap_count.argtypes = [C.c_void_p]
+        H.motcpp_tracker_lap_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int]
+        H.motcpp_tracker_dump_states.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        H.motcpp_batch_create.restype = C.c_void_p
+        H.motcpp_batch_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        H.motcpp_batch_destroy.argtypes = [C.c_void_p]
+        H.motcpp_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        H.motcpp_batch_set_threads.argtypes = [C.c_void_p, C.c_int]
+        H.motcpp_batch_counters.argtypes = [C.c_void_p, C.c_void_p]
+        H.motcpp_batch_tracker.restype = C.c_void_p
+        H.motcpp_batch_tracker.argtypes = [C.c_void_p, C.c_int]
+        _host = H
+    return _host
+
+
+def _err():
+    return host().motcpp_last_error().decode()
+
+
+class _Hooks:
+    """parity hooks shared by Tracker and the borrowed per-stream handles of a Batch"""
+
+    def laps(self):
+        H, out, cap = host(), [], 1 << 15
+        x, y = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        for k in range(H.motcpp_tracker_lap_count(self.h)):
+            n, m = C.c_int(), C.c_int()
+            if H.motcpp_tracker_lap_get(self.h, k, C.byref(n), C.byref(m), _p(x), _p(y), cap) != 0:
+                raise MotError("lap_get failed")
+            out.append((x[:n.value].copy(), y[:m.value].copy()))
+        return out
+
+    def dump_states(self):
+        H, w = host(), C.c_int()
+        buf = np.zeros(1 << 20, np.float32)
+        while True:
+            r = H.motcpp_tracker_dump_states(self.h, _p(buf), buf.size, C.byref(w))
+            if r >= 0:
+                return buf[:r * w.value].reshape(r, w.value).copy() if r else np.zeros((0, 0), np.float32)
+            if r > -1000000:
+                raise MotError(_err())
+            buf = np.zeros((-r - 1000000 + 8) * max(w.value, 1), np.float32)
+
+
+class Tracker(_Hooks):
+    """One tracker instance on one GPU. update() mirrors motcpp::BaseTracker::update (row-major numpy in/out)."""
+
+    def __init__(self, kind, params=None, device=0):
+        kind = KIND.get(kind, kind)
+        p = f32(params if params is not None else [])
+        self.h = host().motcpp_tracker_create(int(kind), _p(p) if p.size else None, int(p.size), int(device))
+        if not self.h:
+            raise MotError("tracker create failed: " + _err())
+        self._out = np.zeros((8192, 8), np.float32)
+
+    def close(self):
+        if getattr(self, "h", None):
+            host().motcpp_tracker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        host().motcpp_tracker_reset(self.h)
+
+    def update(self, dets, embs=None):
+        dets = f32(dets).reshape(-1, 6)
+        e, d = None, 0
+        if embs is not None and np.size(embs):
+            embs = f32(embs)
+            e, d = _p(embs), embs.shape[1]
+        while True:
+            r = host().motcpp_tracker_update(self.h, _p(dets), dets.shape[0], e, d, _p(self._out), self._out.shape[0])
+            if r >= 0:
+                return self._out[:r].copy()
+            if r > -1000000:
+                raise MotError(_err())
+            self._out = np.zeros((-r - 1000000 + 64, 8), np.float32)
+
+
+class _Borrowed(_Hooks):
+    def __init__(self, h):
+        self.h = h
+
+
+class Batch:
+    """S independent streams stepped in lockstep on one GPU (motcpp::StreamBatch)."""
+
+    def __init__(self, kind, nstreams, params=None, device=0, threads=1):
+        kind = KIND.get(kind, kind)
+        p = f32(params if params is not None else [])
+        self.S = int(nstreams)
+        self.h = host().motcpp_batch_create(int(kind), _p(p) if p.size else None, int(p.size), self.S, int(device))
+        if not self.h:
+            raise MotError("batch create failed: " + _err())
+        host().motcpp_batch_set_threads(self.h, int(threads))
+        self._out = None
+        self._cnt = np.zeros(self.S, np.int32)
+
+    def close(self):
+        if getattr(self, "h", None):
+            host().motcpp_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stream(self, s):
+        return _Borrowed(host().motcpp_batch_tracker(self.h, int(s)))
+
+    def counters(self):
+        a = (C.c_long * 3)()
+        host().motcpp_batch_counters(self.h, a)
+        return {"frames": a[0], "flushes": a[1], "launches": a[2]}
+
+    def step(self, dets, counts=None, embs=None, cap=None):
+        """dets [S, N, 6] (counts[s] valid rows each); returns (out [S, cap, 8], out_counts [S])."""
+        dets = f32(dets)
+        S, N = dets.shape[0], dets.shape[1]
+        assert S == self.S
+        counts = np.full(S, N, np.int32) if counts is None else np.ascontiguousarray(counts, np.int32)
+        cap = cap or max(2 * N, 64)
+        if self._out is None or self._out.shape[1] < cap:
+            self._out = np.zeros((S, cap, 8), np.float32)
+        e, d = None, 0
+        if embs is not None:
+            embs = f32(embs)
+            e, d = _p(embs), embs.shape[2]
+        r = host().motcpp_batch_step(self.h, _p(dets), _p(counts), N, e, d, _p(self._out), _p(self._cnt), self._out.shape[1])
+        if r < 0:
+            raise MotError("batch step failed: " + _err())
+        return self._out, self._cnt

@@ -105,9 +105,10 @@ __global__ void __launch_bounds__(kThreads) iou_kernel(const mot_iou_task* __res
         } else if (mode == MOT_COST_BOTSORT) {
           const bool far = d > T.prox_thresh;  // mask from the un-fused distance (botsort.cpp:439)
           if (T.fuse) { const float sim = 1.0f - d; d = 1.0f - sim * bc[q]; }
-          if (T.emb) {
+          if (T.emb || T.lde < 0) {  // lde < 0: no features anywhere -> cosine distance is the constant 1 (matching.cpp:79-92, D = 0)
             const int c = tx * 4 + q;
-            float e = (c < ncol) ? T.emb[static_cast<size_t>(row0 + r) * T.lde + col0 + c] : 0.f;
+            float e = 1.0f;
+            if (T.emb) e = (c < ncol) ? T.emb[static_cast<size_t>(row0 + r) * T.lde + col0 + c] : 0.f;
             e = e / 2.0f;
             if (e > T.app_thresh) e = 1.0f;
             if (far) e = 1.0f;

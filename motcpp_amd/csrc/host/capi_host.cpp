@@ -1,0 +1,169 @@
+// C handles over the stage machines (include/motcpp_c.h).
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "motcpp_c.h"
+#include "staged.hpp"
+
+using namespace motcpp::rt;
+
+namespace {
+thread_local std::string g_err;
+float P(const float* p, int n, int i, float dflt) { return (p && i < n) ? p[i] : dflt; }
+
+Staged* make(std::shared_ptr<Device> dev, int kind, const float* p, int np) {
+  switch (kind) {
+    case 0: return make_sort(dev, P(p, np, 0, 0.3f), (int)P(p, np, 1, 1), (int)P(p, np, 2, 50), (int)P(p, np, 3, 3), P(p, np, 4, 0.3f));
+    case 1: return make_bytetrack(dev, P(p, np, 0, 0.1f), P(p, np, 1, 0.45f), P(p, np, 2, 0.8f), (int)P(p, np, 3, 25),
+                                  (int)P(p, np, 4, 30), (int)P(p, np, 5, 30), (int)P(p, np, 6, 50));
+    case 2: return make_ocsort(dev, P(p, np, 0, 0.2f), (int)P(p, np, 1, 30), (int)P(p, np, 2, 50), (int)P(p, np, 3, 3), P(p, np, 4, 0.3f),
+                               P(p, np, 5, 0.1f), (int)P(p, np, 6, 3), P(p, np, 7, 0.2f), P(p, np, 8, 0.f) != 0.f, P(p, np, 9, 0.01f),
+                               P(p, np, 10, 0.0001f));
+    case 3: return make_botsort(dev, P(p, np, 0, 0.5f), P(p, np, 1, 0.1f), P(p, np, 2, 0.6f), (int)P(p, np, 3, 30), P(p, np, 4, 0.8f),
+                                P(p, np, 5, 0.5f), P(p, np, 6, 0.25f), (int)P(p, np, 7, 30), P(p, np, 8, 0.f) != 0.f,
+                                P(p, np, 9, 1.f) != 0.f, (int)P(p, np, 10, 30), (int)P(p, np, 11, 50));
+  }
+  throw Error("unknown tracker kind");
+}
+}  // namespace
+
+struct motcpp_tracker {
+  std::shared_ptr<Device> dev;
+  std::unique_ptr<Staged> impl;
+  std::vector<float> colmajor;
+};
+struct motcpp_batch {
+  std::shared_ptr<Device> dev;
+  std::vector<std::unique_ptr<motcpp_tracker>> trk;
+  std::vector<std::vector<float>> colmajor;
+  long frames = 0;
+  int threads = 1;
+};
+
+namespace {
+void to_colmajor(const float* rows, int n, std::vector<float>& out) {
+  out.resize(static_cast<size_t>(6) * (n > 0 ? n : 1));
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 6; ++k) out[static_cast<size_t>(k) * n + i] = rows[static_cast<size_t>(i) * 6 + k];
+}
+FrameIn frame_in(const std::vector<float>& cm, int n, const float* embs, int d) {
+  FrameIn in;
+  in.dets = cm.data(); in.n = n; in.ld = n;
+  if (embs && d > 0 && n > 0) { in.embs = embs; in.emb_dim = d; in.emb_ld = d; in.embs_rowmajor = true; }
+  in.img_w = 1920; in.img_h = 1080;
+  return in;
+}
+int copy_rows(const std::vector<float>& rows, float* out, int cap) {
+  const int m = static_cast<int>(rows.size() / 8);
+  if (m > cap) return -m - 1000000;
+  if (m) std::memcpy(out, rows.data(), sizeof(float) * rows.size());
+  return m;
+}
+}  // namespace
+
+extern "C" {
+
+const char* motcpp_last_error(void) { return g_err.c_str(); }
+
+motcpp_tracker* motcpp_tracker_create(int kind, const float* params, int nparams, int device) {
+  try {
+    auto t = std::make_unique<motcpp_tracker>();
+    t->dev = Device::shared(device);
+    t->impl.reset(make(t->dev, kind, params, nparams));
+    return t.release();
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void motcpp_tracker_destroy(motcpp_tracker* t) { delete t; }
+int motcpp_tracker_reset(motcpp_tracker* t) {
+  try { t->impl->reset(); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int motcpp_tracker_update(motcpp_tracker* t, const float* dets, int n, const float* embs, int d, float* out, int cap) {
+  try {
+    to_colmajor(dets, n, t->colmajor);
+    FrameIn in = frame_in(t->colmajor, n, embs, d);
+    Staged* s = t->impl.get();
+    run_frame(*t->dev, &s, &in, 1);
+    return copy_rows(s->rows(), out, cap);
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int motcpp_tracker_lap_count(motcpp_tracker* t) { return static_cast<int>(t->impl->laps().size()); }
+int motcpp_tracker_lap_get(motcpp_tracker* t, int k, int* n, int* m, int* x, int* y, int cap) {
+  const auto& v = t->impl->laps();
+  if (k < 0 || k >= static_cast<int>(v.size())) return -1;
+  *n = static_cast<int>(v[k].x.size()); *m = static_cast<int>(v[k].y.size());
+  if (*n > cap || *m > cap) return -2;
+  if (*n) std::memcpy(x, v[k].x.data(), sizeof(int) * *n);
+  if (*m) std::memcpy(y, v[k].y.data(), sizeof(int) * *m);
+  return 0;
+}
+int motcpp_tracker_dump_states(motcpp_tracker* t, float* out, int cap_floats, int* width) {
+  try {
+    std::vector<int> ids, slots;
+    t->impl->live_tracks(&ids, &slots);
+    Core& c = t->impl->core();
+    const int D = mot_kf_dim(c.kf_kind()), w = 1 + D + D * D, cap = c.cap();
+    *width = w;
+    const int rows = static_cast<int>(ids.size());
+    if (static_cast<size_t>(rows) * w > static_cast<size_t>(cap_floats)) return -rows - 1000000;
+    if (rows == 0) return 0;
+    std::vector<float> mean(static_cast<size_t>(D) * cap), cov(static_cast<size_t>(D) * D * cap);
+    c.dev().check(mot_memcpy_d2h(c.dev().ctx, mean.data(), c.d_mean(), mean.size() * sizeof(float)), "state readback");
+    c.dev().check(mot_memcpy_d2h(c.dev().ctx, cov.data(), c.d_cov(), cov.size() * sizeof(float)), "state readback");
+    c.dev().check(mot_ctx_sync(c.dev().ctx), "state readback");
+    for (int r = 0; r < rows; ++r) {
+      float* o = out + static_cast<size_t>(r) * w;
+      o[0] = static_cast<float>(ids[r]);
+      for (int k = 0; k < D; ++k) o[1 + k] = mean[static_cast<size_t>(k) * cap + slots[r]];
+      for (int k = 0; k < D * D; ++k) o[1 + D + k] = cov[static_cast<size_t>(k) * cap + slots[r]];
+    }
+    return rows;
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+motcpp_batch* motcpp_batch_create(int kind, const float* params, int nparams, int nstreams, int device) {
+  try {
+    auto b = std::make_unique<motcpp_batch>();
+    b->dev = Device::shared(device);
+    for (int s = 0; s < nstreams; ++s) {
+      auto t = std::make_unique<motcpp_tracker>();
+      t->dev = b->dev;
+      t->impl.reset(make(b->dev, kind, params, nparams));
+      b->trk.push_back(std::move(t));
+    }
+    b->colmajor.resize(nstreams);
+    return b.release();
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void motcpp_batch_destroy(motcpp_batch* b) { delete b; }
+int motcpp_batch_set_threads(motcpp_batch* b, int threads) { b->threads = threads < 1 ? 1 : threads; return 0; }
+int motcpp_batch_tracker_count(motcpp_batch* b) { return static_cast<int>(b->trk.size()); }
+motcpp_tracker* motcpp_batch_tracker(motcpp_batch* b, int s) { return b->trk[s].get(); }
+int motcpp_batch_counters(motcpp_batch* b, long* out3) {
+  out3[0] = b->frames; out3[1] = b->dev->counters.flushes; out3[2] = b->dev->counters.launches;
+  return 0;
+}
+int motcpp_batch_step(motcpp_batch* b, const float* dets, const int* counts, int max_n, const float* embs, int d, float* out,
+                      int* out_counts, int cap) {
+  try {
+    const int S = static_cast<int>(b->trk.size());
+    std::vector<FrameIn> in(S);
+    std::vector<Staged*> st(S);
+    for (int s = 0; s < S; ++s) {
+      to_colmajor(dets + static_cast<size_t>(s) * max_n * 6, counts[s], b->colmajor[s]);
+      in[s] = frame_in(b->colmajor[s], counts[s], embs ? embs + static_cast<size_t>(s) * max_n * d : nullptr, d);
+      st[s] = b->trk[s]->impl.get();
+    }
+    run_frame(*b->dev, st.data(), in.data(), S);
+    b->frames += S;
+    for (int s = 0; s < S; ++s) {
+      const int m = copy_rows(st[s]->rows(), out + static_cast<size_t>(s) * cap * 8, cap);
+      if (m < 0) { g_err = "output capacity too small"; return m; }
+      out_counts[s] = m;
+    }
+    return S;
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+}  // extern "C"

@@ -1,0 +1,327 @@
+#include "runtime.hpp"
+
+#include <algorithm>
+#include <map>
+
+namespace motcpp::rt {
+
+// ---- Arena ---------------------------------------------------------------------------------
+Arena::Arena(mot_ctx* ctx, size_t chunk_bytes, bool host_mirror) : ctx_(ctx), chunk_bytes_(chunk_bytes), host_(host_mirror) {}
+Arena::~Arena() {
+  for (Chunk& c : chunks_) {
+    if (c.d) mot_free(ctx_, c.d);
+    if (c.h) mot_host_free(ctx_, c.h);
+  }
+}
+void Arena::raw_alloc(size_t bytes, void** h, void** d) {
+  bytes = (bytes + 255) & ~size_t(255);
+  if (bytes == 0) bytes = 256;
+  while (true) {
+    if (cur_ < chunks_.size()) {
+      Chunk& c = chunks_[cur_];
+      if (c.top + bytes <= c.cap) {
+        *h = c.h ? c.h + c.top : nullptr;
+        *d = c.d + c.top;
+        c.top += bytes;
+        return;
+      }
+      ++cur_;
+      continue;
+    }
+    Chunk c{};
+    c.cap = std::max(chunk_bytes_, bytes);
+    void* dp = nullptr;
+    if (mot_malloc(ctx_, c.cap, &dp) != MOT_OK) throw Error(std::string("arena: device allocation failed: ") + mot_ctx_last_error(ctx_));
+    c.d = static_cast<char*>(dp);
+    if (host_) {
+      void* hp = nullptr;
+      if (mot_host_alloc(ctx_, c.cap, &hp) != MOT_OK) throw Error("arena: pinned host allocation failed");
+      c.h = static_cast<char*>(hp);
+    }
+    chunks_.push_back(c);
+  }
+}
+void Arena::reset() {
+  for (Chunk& c : chunks_) c.top = c.mark = 0;
+  cur_ = 0;
+}
+void Arena::mark() {
+  for (Chunk& c : chunks_) c.mark = c.top;
+}
+void Arena::upload() {
+  for (Chunk& c : chunks_)
+    if (c.top > c.mark) {
+      if (mot_memcpy_h2d(ctx_, c.d + c.mark, c.h + c.mark, c.top - c.mark) != MOT_OK) throw Error("arena upload failed");
+      c.mark = c.top;
+    }
+}
+void Arena::download() {
+  for (Chunk& c : chunks_)
+    if (c.top > c.mark) {
+      if (mot_memcpy_d2h(ctx_, c.h + c.mark, c.d + c.mark, c.top - c.mark) != MOT_OK) throw Error("arena download failed");
+      c.mark = c.top;
+    }
+}
+size_t Arena::bytes_in_flight() const {
+  size_t s = 0;
+  for (const Chunk& c : chunks_) s += c.top - c.mark;
+  return s;
+}
+
+// ---- Device --------------------------------------------------------------------------------
+Device::Device(int device_index) : index(device_index) {
+  int rc = mot_ctx_create(device_index, nullptr, &ctx);
+  if (rc != MOT_OK)
+    throw Error("motcpp_amd: no usable gfx950 (MI355X) device " + std::to_string(device_index) +
+                " (mot_ctx_create=" + std::to_string(rc) + "); there is no CPU fallback");
+  up = std::make_unique<Arena>(ctx, size_t(8) << 20, true);
+  down = std::make_unique<Arena>(ctx, size_t(4) << 20, true);
+  tmp = std::make_unique<Arena>(ctx, size_t(64) << 20, false);
+}
+Device::~Device() {
+  up.reset();
+  down.reset();
+  tmp.reset();
+  if (ctx) mot_ctx_destroy(ctx);
+}
+std::shared_ptr<Device> Device::shared(int device_index) {
+  static std::mutex m;
+  static std::map<int, std::weak_ptr<Device>> cache;
+  std::lock_guard<std::mutex> g(m);
+  auto sp = cache[device_index].lock();
+  if (!sp) {
+    sp = std::make_shared<Device>(device_index);
+    cache[device_index] = sp;
+  }
+  return sp;
+}
+void Device::check(int rc, const char* what) {
+  if (rc != MOT_OK) throw Error(std::string(what) + " failed: " + mot_ctx_last_error(ctx));
+}
+void Device::begin_frame() {
+  up->reset();
+  down->reset();
+  tmp->reset();
+}
+bool Device::pending() const {
+  for (int k = 0; k < 3; ++k)
+    if (!det[k].empty() || !kf_init[k].empty() || !kf_upd[k].empty() || !kf_pred[k].empty() || !kf_box[k].empty()) return true;
+  return !feat_set.empty() || !feat_ema.empty() || !cos.empty() || !iou.empty() || !oc.empty() || !lap.empty() ||
+         up->bytes_in_flight() > 0 || down->bytes_in_flight() > 0;
+}
+
+namespace {
+template <class T>
+const T* stage_tasks(Arena& up, const std::vector<T>& v) {
+  if (v.empty()) return nullptr;
+  Span<T> s = up.alloc<T>(v.size());
+  std::memcpy(s.h, v.data(), sizeof(T) * v.size());
+  return s.d;
+}
+}  // namespace
+
+void Device::flush() {
+  const mot_det_task* d_det[3];
+  const mot_kf_task *d_init[3], *d_upd[3], *d_pred[3], *d_box[3];
+  for (int k = 0; k < 3; ++k) {
+    d_det[k] = stage_tasks(*up, det[k]);
+    d_init[k] = stage_tasks(*up, kf_init[k]);
+    d_upd[k] = stage_tasks(*up, kf_upd[k]);
+    d_pred[k] = stage_tasks(*up, kf_pred[k]);
+    d_box[k] = stage_tasks(*up, kf_box[k]);
+  }
+  const mot_feat_task* d_fset = stage_tasks(*up, feat_set);
+  const mot_feat_task* d_fema = stage_tasks(*up, feat_ema);
+  const mot_cos_task* d_cos = stage_tasks(*up, cos);
+  const mot_iou_task* d_iou = stage_tasks(*up, iou);
+  const mot_ocsort_task* d_oc = stage_tasks(*up, oc);
+  const mot_lap_task* d_lap = stage_tasks(*up, lap);
+  up->upload();
+
+  auto maxn = [](const auto& v, auto get) { int m = 0; for (const auto& t : v) m = std::max(m, get(t)); return m; };
+  for (int k = 0; k < 3; ++k)
+    if (!det[k].empty()) { check(mot_det_prepare(ctx, k, d_det[k], (int)det[k].size(), maxn(det[k], [](const mot_det_task& t) { return t.n; })), "mot_det_prepare"); ++counters.launches; }
+  if (!feat_set.empty()) { check(mot_feat_update(ctx, d_fset, (int)feat_set.size(), maxn(feat_set, [](const mot_feat_task& t) { return t.n; })), "mot_feat_update"); ++counters.launches; }
+  for (int k = 0; k < 3; ++k)
+    if (!kf_init[k].empty()) { check(mot_kf_initiate(ctx, k, d_init[k], (int)kf_init[k].size(), maxn(kf_init[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_initiate"); ++counters.launches; }
+  for (int k = 0; k < 3; ++k)
+    if (!kf_upd[k].empty()) { check(mot_kf_update(ctx, k, d_upd[k], (int)kf_upd[k].size(), maxn(kf_upd[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_update"); ++counters.launches; }
+  if (!feat_ema.empty()) { check(mot_feat_update(ctx, d_fema, (int)feat_ema.size(), maxn(feat_ema, [](const mot_feat_task& t) { return t.n; })), "mot_feat_update"); ++counters.launches; }
+  for (int k = 0; k < 3; ++k)
+    if (!kf_pred[k].empty()) { check(mot_kf_predict(ctx, k, d_pred[k], (int)kf_pred[k].size(), maxn(kf_pred[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_predict"); ++counters.launches; }
+  for (int k = 0; k < 3; ++k)
+    if (!kf_box[k].empty()) { check(mot_kf_boxes(ctx, k, d_box[k], (int)kf_box[k].size(), maxn(kf_box[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_boxes"); ++counters.launches; }
+  if (!cos.empty()) {
+    check(mot_cosine_cost(ctx, d_cos, (int)cos.size(), maxn(cos, [](const mot_cos_task& t) { return t.n; }), maxn(cos, [](const mot_cos_task& t) { return t.m; })), "mot_cosine_cost");
+    counters.launches += 2;
+  }
+  if (!iou.empty()) {
+    check(mot_iou_cost(ctx, d_iou, (int)iou.size(), maxn(iou, [](const mot_iou_task& t) { return t.n; }), maxn(iou, [](const mot_iou_task& t) { return t.m; })), "mot_iou_cost");
+    ++counters.launches;
+  }
+  if (!oc.empty()) {
+    check(mot_ocsort_cost(ctx, d_oc, (int)oc.size(), maxn(oc, [](const mot_ocsort_task& t) { return t.nd; }), maxn(oc, [](const mot_ocsort_task& t) { return t.nt; })), "mot_ocsort_cost");
+    ++counters.launches;
+  }
+  if (!lap.empty()) {
+    check(mot_lap_solve(ctx, d_lap, (int)lap.size(), maxn(lap, [](const mot_lap_task& t) { return t.n + t.m; })), "mot_lap_solve");
+    ++counters.launches;
+  }
+  down->download();
+  check(mot_ctx_sync(ctx), "mot_ctx_sync");
+  ++counters.flushes;
+  for (int k = 0; k < 3; ++k) { det[k].clear(); kf_init[k].clear(); kf_upd[k].clear(); kf_pred[k].clear(); kf_box[k].clear(); }
+  feat_set.clear(); feat_ema.clear(); cos.clear(); iou.clear(); oc.clear(); lap.clear();
+}
+
+// ---- Core ----------------------------------------------------------------------------------
+Core::Core(std::shared_ptr<Device> dev, int kf_kind) : dev_(std::move(dev)), kind_(kf_kind), D_(mot_kf_dim(kf_kind)) {}
+Core::~Core() {
+  if (mean_) mot_free(dev_->ctx, mean_);
+  if (cov_) mot_free(dev_->ctx, cov_);
+}
+void Core::grow(int pcap, int scap) {
+  const int ncap = pcap + scap;
+  void *nm = nullptr, *nc = nullptr;
+  dev_->check(mot_malloc(dev_->ctx, sizeof(float) * D_ * ncap, &nm), "slab alloc");
+  dev_->check(mot_malloc(dev_->ctx, sizeof(float) * D_ * D_ * ncap, &nc), "slab alloc");
+  if (mean_ && next_ > 0) {
+    for (int k = 0; k < D_; ++k)
+      dev_->check(mot_memcpy_d2d(dev_->ctx, static_cast<float*>(nm) + static_cast<size_t>(k) * ncap, mean_ + static_cast<size_t>(k) * cap_, sizeof(float) * next_), "slab copy");
+    for (int k = 0; k < D_ * D_; ++k)
+      dev_->check(mot_memcpy_d2d(dev_->ctx, static_cast<float*>(nc) + static_cast<size_t>(k) * ncap, cov_ + static_cast<size_t>(k) * cap_, sizeof(float) * next_), "slab copy");
+    dev_->check(mot_ctx_sync(dev_->ctx), "slab copy sync");
+  }
+  if (mean_) mot_free(dev_->ctx, mean_);
+  if (cov_) mot_free(dev_->ctx, cov_);
+  mean_ = static_cast<float*>(nm);
+  cov_ = static_cast<float*>(nc);
+  pcap_ = pcap; scap_ = scap; cap_ = ncap;
+}
+void Core::reserve(int extra_persistent, int scratch) {
+  const int avail = (pcap_ - next_) + static_cast<int>(free_.size());
+  int pcap = pcap_, scap = scap_;
+  if (avail < extra_persistent) pcap = std::max(pcap_ * 2, round_up(next_ + extra_persistent + 64, 64));
+  if (scap_ < scratch) scap = std::max(scap_ * 2, round_up(scratch + 64, 64));
+  if (pcap != pcap_ || scap != scap_ || !mean_) grow(std::max(pcap, 64), std::max(scap, 64));
+}
+int Core::new_slot() {
+  if (!free_.empty()) { int s = free_.back(); free_.pop_back(); return s; }
+  if (next_ >= pcap_) throw Error("Core::new_slot: slab exhausted (reserve() not called with enough headroom)");
+  return next_++;
+}
+void Core::release_slot(int s) { free_.push_back(s); }
+void Core::clear_slots() { free_.clear(); next_ = 0; }
+
+Core::Dets Core::upload_dets(const float* colmajor, int n, int ld, int det_kind) {
+  Dets d;
+  d.n = n;
+  if (n <= 0) return d;
+  std::lock_guard<std::mutex> g(dev_->mu);
+  Span<float> raw = dev_->up->alloc<float>(static_cast<size_t>(6) * n);
+  for (int k = 0; k < 6; ++k) std::memcpy(raw.h + static_cast<size_t>(k) * n, colmajor + static_cast<size_t>(k) * ld, sizeof(float) * n);
+  d.d_raw = raw.d;
+  d.d_box = dev_->tmp->alloc<float>(static_cast<size_t>(4) * n).d;
+  d.d_meas = dev_->tmp->alloc<float>(static_cast<size_t>(4) * n).d;
+  mot_det_task t{};
+  t.dets = raw.d; t.ld = n; t.n = n; t.box = d.d_box; t.ldb = n; t.meas = d.d_meas; t.ldm = n;
+  dev_->det[det_kind].push_back(t);
+  return d;
+}
+Span<int32_t> Core::ints(const std::vector<int>& v) {
+  std::lock_guard<std::mutex> g(dev_->mu);
+  Span<int32_t> s = dev_->up->alloc<int32_t>(v.size());
+  if (!v.empty()) std::memcpy(s.h, v.data(), sizeof(int32_t) * v.size());
+  return s;
+}
+Span<uint8_t> Core::bytes(const std::vector<uint8_t>& v) {
+  std::lock_guard<std::mutex> g(dev_->mu);
+  Span<uint8_t> s = dev_->up->alloc<uint8_t>(v.size());
+  if (!v.empty()) std::memcpy(s.h, v.data(), v.size());
+  return s;
+}
+Span<float> Core::floats(const std::vector<float>& v) {
+  std::lock_guard<std::mutex> g(dev_->mu);
+  Span<float> s = dev_->up->alloc<float>(v.size());
+  if (!v.empty()) std::memcpy(s.h, v.data(), sizeof(float) * v.size());
+  return s;
+}
+
+float* Core::predict(const std::vector<int>& src, const std::vector<int>* dst, const std::vector<uint8_t>* flags, Span<float>* boxes_dl) {
+  const int n = static_cast<int>(src.size());
+  if (n == 0) return nullptr;
+  Span<int32_t> s = ints(src), d;
+  if (dst) d = ints(*dst);
+  Span<uint8_t> f;
+  if (flags) f = bytes(*flags);
+  std::lock_guard<std::mutex> g(dev_->mu);
+  float* bx;
+  if (boxes_dl) { *boxes_dl = dev_->down->alloc<float>(static_cast<size_t>(4) * n); bx = boxes_dl->d; }
+  else bx = dev_->tmp->alloc<float>(static_cast<size_t>(4) * n).d;
+  mot_kf_task t{};
+  t.mean = mean_; t.cov = cov_; t.cap = cap_; t.n = n; t.src = s.d; t.dst = dst ? d.d : nullptr; t.flags = flags ? f.d : nullptr;
+  t.boxes = bx; t.ldb = n; t.q[0] = q[0]; t.q[1] = q[1]; t.q[2] = q[2];
+  dev_->kf_pred[kind_].push_back(t);
+  return bx;
+}
+float* Core::boxes(const std::vector<int>& slots, Span<float>* boxes_dl) {
+  const int n = static_cast<int>(slots.size());
+  if (n == 0) return nullptr;
+  Span<int32_t> s = ints(slots);
+  std::lock_guard<std::mutex> g(dev_->mu);
+  float* bx;
+  if (boxes_dl) { *boxes_dl = dev_->down->alloc<float>(static_cast<size_t>(4) * n); bx = boxes_dl->d; }
+  else bx = dev_->tmp->alloc<float>(static_cast<size_t>(4) * n).d;
+  mot_kf_task t{};
+  t.mean = mean_; t.cov = cov_; t.cap = cap_; t.n = n; t.src = s.d; t.boxes = bx; t.ldb = n;
+  dev_->kf_box[kind_].push_back(t);
+  return bx;
+}
+void Core::update(const std::vector<int>& src, const std::vector<int>& dst, const std::vector<int>& midx, const Dets& dets) {
+  const int n = static_cast<int>(src.size());
+  if (n == 0) return;
+  Span<int32_t> s = ints(src), d = ints(dst), m = ints(midx);
+  std::lock_guard<std::mutex> g(dev_->mu);
+  mot_kf_task t{};
+  t.mean = mean_; t.cov = cov_; t.cap = cap_; t.n = n; t.src = s.d; t.dst = d.d; t.meas = dets.d_meas; t.ldm = dets.n; t.midx = m.d;
+  t.q[0] = q[0]; t.q[1] = q[1]; t.q[2] = q[2];
+  dev_->kf_upd[kind_].push_back(t);
+}
+void Core::initiate(const std::vector<int>& dst, const std::vector<int>& midx, const Dets& dets) {
+  const int n = static_cast<int>(dst.size());
+  if (n == 0) return;
+  Span<int32_t> d = ints(dst), m = ints(midx);
+  std::lock_guard<std::mutex> g(dev_->mu);
+  mot_kf_task t{};
+  t.mean = mean_; t.cov = cov_; t.cap = cap_; t.n = n; t.src = d.d; t.dst = d.d; t.meas = dets.d_meas; t.ldm = dets.n; t.midx = m.d;
+  dev_->kf_init[kind_].push_back(t);
+}
+float* Core::iou_cost(const IouArgs& a, int* ldc) {
+  std::lock_guard<std::mutex> g(dev_->mu);
+  const int ld = round_up(std::max(a.m, 1), 4);
+  float* cost = dev_->tmp->alloc<float>(static_cast<size_t>(std::max(a.n, 1)) * ld).d;
+  mot_iou_task t{};
+  t.n = a.n; t.m = a.m; t.a = a.a; t.lda = a.lda; t.aidx = a.aidx; t.b = a.b; t.ldb = a.ldb; t.bidx = a.bidx; t.bconf = a.bconf;
+  t.cost = cost; t.ldc = ld; t.mode = a.mode; t.emb = a.emb; t.lde = a.lde; t.prox_thresh = a.prox; t.app_thresh = a.app; t.fuse = a.fuse;
+  dev_->iou.push_back(t);
+  *ldc = ld;
+  return cost;
+}
+Core::Lap Core::lap(const float* cost, int ldc, int n, int m, float thresh, int mode, const float* iou, int ldi, float gate, bool want_xval) {
+  Lap r;
+  r.n = n; r.m = m;
+  std::lock_guard<std::mutex> g(dev_->mu);
+  r.x = dev_->down->alloc<int32_t>(std::max(n, 1));
+  r.y = dev_->down->alloc<int32_t>(std::max(m, 1));
+  r.info = dev_->down->alloc<int32_t>(4);
+  if (want_xval) r.xval = dev_->down->alloc<float>(std::max(n, 1));
+  mot_lap_task t{};
+  t.n = n; t.m = m; t.cost = cost; t.ldc = ldc; t.thresh = thresh; t.x = r.x.d; t.y = r.y.d; t.mode = mode; t.iou = iou; t.ldi = ldi; t.gate = gate;
+  t.xval = want_xval ? r.xval.d : nullptr; t.info = r.info.d;
+  t.work = (n + m > mot_lap_lds_limit()) ? dev_->tmp->alloc<char>(mot_lap_work_bytes(n, m)).d : nullptr;
+  dev_->lap.push_back(t);
+  r.queued = true;
+  return r;
+}
+
+}  // namespace motcpp::rt

@@ -1,0 +1,164 @@
+// Host runtime under the tracker classes: owns one mot_ctx per GPU, mirrored bump arenas for
+// per-frame uploads/downloads, and the per-stage task lists that turn "every tracker of a batch
+// wants an IoU matrix now" into ONE kernel launch. Plain C++17 — the only thing it knows about the
+// GPU is the C ABI in motcpp_amd.h (no HIP headers, no device code here).
+//
+// A frame is processed as a few stages. In each stage every tracker of the batch appends tasks
+// (detections to prepare, track slots to predict/update, cost matrices, assignments) and
+// Device::flush() uploads the stage's inputs in one copy, launches each non-empty kernel family
+// once over all tasks (grid dimension = task), downloads the results in one copy and syncs.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "motcpp_amd.h"
+
+namespace motcpp::rt {
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+template <class T>
+struct Span {
+  T* h = nullptr;  // host mirror (pinned) or nullptr for device-only memory
+  T* d = nullptr;  // device address
+  size_t n = 0;
+};
+
+// Chunked bump arena. Device addresses stay valid for the whole frame (chunks are never moved).
+class Arena {
+ public:
+  Arena(mot_ctx* ctx, size_t chunk_bytes, bool host_mirror);
+  ~Arena();
+  Arena(const Arena&) = delete;
+  Arena& operator=(const Arena&) = delete;
+  template <class T>
+  Span<T> alloc(size_t n) {
+    void *h, *d;
+    raw_alloc(n * sizeof(T), &h, &d);
+    return Span<T>{static_cast<T*>(h), static_cast<T*>(d), n};
+  }
+  void reset();       // frame boundary
+  void mark();        // stage boundary: [mark, top) is what the next transfer moves
+  void upload();      // host -> device for [mark, top) of every chunk, then mark()
+  void download();    // device -> host for [mark, top) of every chunk, then mark()
+  size_t bytes_in_flight() const;
+ private:
+  struct Chunk { char* h; char* d; size_t cap, top, mark; };
+  void raw_alloc(size_t bytes, void** h, void** d);
+  mot_ctx* ctx_;
+  size_t chunk_bytes_;
+  bool host_;
+  std::vector<Chunk> chunks_;
+  size_t cur_ = 0;
+};
+
+struct StageCounters {
+  long flushes = 0, launches = 0;
+};
+
+class Device {
+ public:
+  explicit Device(int device_index);
+  ~Device();
+  static std::shared_ptr<Device> shared(int device_index);  // process-wide default per GPU
+
+  mot_ctx* ctx = nullptr;
+  int index = 0;
+  std::unique_ptr<Arena> up, down, tmp;
+  std::mutex mu;  // guards arenas + task lists when trackers of a batch are stepped from several threads
+
+  // task lists of the current stage (host copies; flush() moves them to the device)
+  std::vector<mot_det_task> det[3];
+  std::vector<mot_kf_task> kf_init[3], kf_upd[3], kf_pred[3], kf_box[3];
+  std::vector<mot_feat_task> feat_set, feat_ema;
+  std::vector<mot_cos_task> cos;
+  std::vector<mot_iou_task> iou;
+  std::vector<mot_ocsort_task> oc;
+  std::vector<mot_lap_task> lap;
+
+  void begin_frame();
+  bool pending() const;
+  void flush();
+  void check(int rc, const char* what);
+  StageCounters counters;
+};
+
+// Per-tracker device state + task-building helpers.
+class Core {
+ public:
+  Core(std::shared_ptr<Device> dev, int kf_kind);
+  ~Core();
+  Device& dev() { return *dev_; }
+  int kf_kind() const { return kind_; }
+
+  // ---- Kalman slab (persistent slots + per-frame scratch slots) ----
+  int new_slot();
+  void release_slot(int s);
+  void reserve(int extra_persistent, int scratch);  // call at frame start, before any task is queued
+  int scratch_slot(int i) const { return pcap_ + i; }
+  void clear_slots();
+  float q[3] = {0.01f, 0.01f, 0.0001f};  // XYSR process noise tail
+
+  // ---- detections of the current frame ----
+  struct Dets {
+    int n = 0;
+    const float* d_raw = nullptr;  // SoA [6][n]
+    float* d_box = nullptr;        // [4][n]
+    float* d_meas = nullptr;       // [4][n]
+    const float* d_conf() const { return d_raw + static_cast<size_t>(4) * n; }
+  };
+  Dets upload_dets(const float* colmajor, int n, int ld, int det_kind);
+
+  Span<int32_t> ints(const std::vector<int>& v);
+  Span<uint8_t> bytes(const std::vector<uint8_t>& v);
+  Span<float> floats(const std::vector<float>& v);
+
+  // predict src slots into dst slots (nullptr: in place); returns device boxes [4][n] (ld = n)
+  float* predict(const std::vector<int>& src, const std::vector<int>* dst, const std::vector<uint8_t>* flags, Span<float>* boxes_dl);
+  float* boxes(const std::vector<int>& slots, Span<float>* boxes_dl);  // state -> xyxy, [4][n]
+  void update(const std::vector<int>& src, const std::vector<int>& dst, const std::vector<int>& midx, const Dets& dets);
+  void initiate(const std::vector<int>& dst, const std::vector<int>& midx, const Dets& dets);
+
+  struct Lap {
+    int n = 0, m = 0;
+    Span<int32_t> x, y, info;
+    Span<float> xval;
+    bool queued = false;
+  };
+  // rows: boxes [4][lda] (+ optional gather), cols: boxes [4][ldb] (+ optional gather) -> cost -> assignment
+  struct IouArgs {
+    const float* a = nullptr; int lda = 0; const int32_t* aidx = nullptr; int n = 0;
+    const float* b = nullptr; int ldb = 0; const int32_t* bidx = nullptr; int m = 0;
+    const float* bconf = nullptr;
+    int mode = MOT_COST_IOU_DIST;
+    const float* emb = nullptr; int lde = 0; float prox = 0.f, app = 0.f; int fuse = 0;
+  };
+  float* iou_cost(const IouArgs& a, int* ldc);  // returns device cost matrix (tmp arena)
+  Lap lap(const float* cost, int ldc, int n, int m, float thresh, int mode = MOT_LAP_PLAIN, const float* iou = nullptr,
+          int ldi = 0, float gate = 0.f, bool want_xval = false);
+
+  float* d_mean() const { return mean_; }
+  float* d_cov() const { return cov_; }
+  int cap() const { return cap_; }
+
+ private:
+  void grow(int pcap, int scap);
+  std::shared_ptr<Device> dev_;
+  int kind_, D_;
+  float* mean_ = nullptr;
+  float* cov_ = nullptr;
+  int cap_ = 0, pcap_ = 0, scap_ = 0;
+  std::vector<int> free_;
+  int next_ = 0;
+};
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+}  // namespace motcpp::rt

@@ -1,0 +1,69 @@
+// Stage-machine interface shared by the four tracker implementations and the frame drivers.
+#pragma once
+#include <utility>
+#include <vector>
+
+#include "runtime.hpp"
+
+namespace motcpp::rt {
+
+struct FrameIn {
+  const float* dets = nullptr;  // column-major n x 6 (ld = leading dimension)
+  int n = 0, ld = 0;
+  const float* embs = nullptr;  // column-major n x emb_dim (ld = emb_ld) or nullptr
+  int emb_ld = 0, emb_dim = 0;
+  bool embs_rowmajor = false;   // true: n x emb_dim row-major (ld = emb_dim)
+  int img_w = 0, img_h = 0;
+};
+
+struct LapRecord {
+  std::vector<int> x, y;
+};
+
+class Staged {
+ public:
+  virtual ~Staged() = default;
+  virtual void begin(const FrameIn& in) = 0;  // queue the first stage of a frame
+  virtual bool advance() = 0;                 // consume the flushed stage, queue the next; false = frame finished
+  virtual void reset() = 0;
+  virtual Core& core() = 0;
+  const std::vector<float>& rows() const { return rows_; }  // output rows [x1,y1,x2,y2,id,conf,cls,det_ind]
+  const std::vector<LapRecord>& laps() const { return laps_; }
+  // parity hook: slots of the live tracks in list order with their ids (states are read back by the caller)
+  virtual void live_tracks(std::vector<int>* ids, std::vector<int>* slots) const = 0;
+
+ protected:
+  void record(const Core::Lap& l) {
+    LapRecord r;
+    r.x.assign(l.x.h, l.x.h + l.n);
+    r.y.assign(l.y.h, l.y.h + l.m);
+    laps_.push_back(std::move(r));
+  }
+  void push_row(const float* box4, int ld, int col, int id, float conf, int cls, int det_ind) {
+    rows_.push_back(box4[col]);
+    rows_.push_back(box4[static_cast<size_t>(ld) + col]);
+    rows_.push_back(box4[static_cast<size_t>(2) * ld + col]);
+    rows_.push_back(box4[static_cast<size_t>(3) * ld + col]);
+    rows_.push_back(static_cast<float>(id));
+    rows_.push_back(conf);
+    rows_.push_back(static_cast<float>(cls));
+    rows_.push_back(static_cast<float>(det_ind));
+  }
+  std::vector<float> rows_;
+  std::vector<LapRecord> laps_;
+};
+
+// Runs one frame for a set of trackers sharing a Device in lockstep: one kernel launch per kernel family per stage.
+void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count);
+
+// factories (parameter vectors: same layout as documented in include/motcpp_c.h)
+Staged* make_sort(std::shared_ptr<Device>, float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold);
+Staged* make_bytetrack(std::shared_ptr<Device>, float min_conf, float track_thresh, float match_thresh, int track_buffer,
+                       int frame_rate, int max_age, int max_obs);
+Staged* make_ocsort(std::shared_ptr<Device>, float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold,
+                    float min_conf, int delta_t, float inertia, bool use_byte, float q_xy, float q_s);
+Staged* make_botsort(std::shared_ptr<Device>, float track_high, float track_low, float new_track, int track_buffer,
+                     float match_thresh, float proximity, float appearance, int frame_rate, bool fuse_first, bool with_reid,
+                     int max_age, int max_obs);
+
+}  // namespace motcpp::rt

@@ -1,0 +1,222 @@
+// BaseTracker / DeviceTracker / StreamBatch and the four public tracker classes (constructor signatures of
+// the reference's include/motcpp/trackers/*.hpp), plus the frame driver that steps stage machines in lockstep.
+#include <stdexcept>
+
+#include "motcpp/motcpp.hpp"
+#include "staged.hpp"
+
+namespace motcpp {
+
+// ---- BaseTracker (src/tracker.cpp:17-56,108-125,166-183) -------------------------------------
+BaseTracker::BaseTracker(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class,
+                         int nr_classes, const std::string& asso_func, bool is_obb)
+    : det_thresh_(det_thresh), max_age_(max_age), max_obs_(max_obs), min_hits_(min_hits), iou_threshold_(iou_threshold),
+      per_class_(per_class), nr_classes_(nr_classes), asso_func_name_(asso_func), is_obb_(is_obb) {
+  if (max_age_ >= max_obs_) max_obs_ = max_age_ + 5;
+}
+void BaseTracker::reset() {
+  frame_count_ = 0;
+  first_frame_processed_ = false;
+  first_dets_processed_ = false;
+}
+void BaseTracker::check_inputs(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) const {
+  if (dets.rows() > 0 && dets.cols() != 6 && dets.cols() != 7)
+    throw std::invalid_argument("Detections must have 6 (AABB) or 7 (OBB) columns");
+  if (img.empty()) throw std::invalid_argument("Image cannot be empty");
+  if (embs.rows() > 0 && dets.rows() != embs.rows())
+    throw std::invalid_argument("Detections and embeddings must have same number of rows");
+  if (is_obb_ && dets.rows() > 0 && dets.cols() != 7)
+    throw std::invalid_argument("OBB mode requires 7 columns in detections");
+}
+void BaseTracker::setup_association_function(const cv::Mat& img) {
+  if (!first_frame_processed_ && !img.empty()) {
+    frame_height_ = img.rows; frame_width_ = img.cols;
+    first_frame_processed_ = true;
+  }
+}
+void BaseTracker::setup_detection_format(const Eigen::MatrixXf& dets) {
+  if (!first_dets_processed_ && dets.rows() > 0) {
+    if (dets.cols() == 6) is_obb_ = false;
+    else if (dets.cols() == 7) is_obb_ = true;
+    first_dets_processed_ = true;
+  }
+}
+
+namespace rt {
+void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count) {
+  dev.begin_frame();
+  std::vector<char> done(count, 0);
+  for (int i = 0; i < count; ++i) trackers[i]->begin(inputs[i]);
+  while (true) {
+    if (dev.pending()) dev.flush();
+    bool any = false;
+    for (int i = 0; i < count; ++i) {
+      if (done[i]) continue;
+      if (trackers[i]->advance()) any = true;
+      else done[i] = 1;
+    }
+    if (!any) break;
+  }
+}
+}  // namespace rt
+
+// ---- DeviceTracker ---------------------------------------------------------------------------
+DeviceTracker::DeviceTracker(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class,
+                             int nr_classes, const std::string& asso_func, bool is_obb, int device_index)
+    : BaseTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb),
+      dev_(rt::Device::shared(device_index)) {
+  if (asso_func != "iou")
+    throw std::invalid_argument("motcpp_amd: association function '" + asso_func + "' is not built yet (only \"iou\")");
+}
+DeviceTracker::~DeviceTracker() = default;
+void DeviceTracker::adopt(rt::Staged* impl) { impl_.reset(impl); }
+void DeviceTracker::reset() {
+  BaseTracker::reset();
+  impl_->reset();
+}
+
+namespace {
+rt::FrameIn make_input(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) {
+  rt::FrameIn in;
+  if (dets.rows() > 0 && dets.cols() == 7) throw std::invalid_argument("motcpp_amd: oriented boxes (7 columns) are out of scope");
+  in.dets = dets.data(); in.n = static_cast<int>(dets.rows()); in.ld = static_cast<int>(dets.rows());
+  if (embs.rows() > 0 && embs.cols() > 0) {
+    in.embs = embs.data(); in.emb_ld = static_cast<int>(embs.rows()); in.emb_dim = static_cast<int>(embs.cols());
+  }
+  in.img_w = img.cols; in.img_h = img.rows;
+  return in;
+}
+Eigen::MatrixXf to_matrix(const std::vector<float>& rows) {
+  const int m = static_cast<int>(rows.size() / 8);
+  Eigen::MatrixXf out(m, 8);
+  for (int i = 0; i < m; ++i)
+    for (int k = 0; k < 8; ++k) out(i, k) = rows[static_cast<size_t>(i) * 8 + k];
+  return out;
+}
+}  // namespace
+
+Eigen::MatrixXf DeviceTracker::update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) {
+  if (validate_inputs_) check_inputs(dets, img, skip_empty_ ? Eigen::MatrixXf() : embs);
+  if (skip_empty_ && dets.rows() == 0) return Eigen::MatrixXf(0, 8);
+  setup_detection_format(dets);
+  setup_association_function(img);
+  ++frame_count_;
+  rt::FrameIn in = make_input(dets, img, embs);
+  rt::Staged* s = impl_.get();
+  rt::run_frame(*dev_, &s, &in, 1);
+  return to_matrix(impl_->rows());
+}
+
+StreamBatch::StreamBatch(std::vector<DeviceTracker*> trackers) : trackers_(std::move(trackers)) {
+  for (DeviceTracker* t : trackers_)
+    if (t->device().get() != trackers_[0]->device().get()) throw std::invalid_argument("StreamBatch: trackers must share one device");
+}
+std::vector<Eigen::MatrixXf> StreamBatch::update(const std::vector<Eigen::MatrixXf>& dets, const cv::Mat& img,
+                                                 const std::vector<Eigen::MatrixXf>& embs) {
+  if (dets.size() != trackers_.size()) throw std::invalid_argument("StreamBatch: one detection matrix per stream");
+  std::vector<rt::FrameIn> in(trackers_.size());
+  std::vector<rt::Staged*> st(trackers_.size());
+  static const Eigen::MatrixXf kNone;
+  for (size_t i = 0; i < trackers_.size(); ++i) {
+    in[i] = make_input(dets[i], img, i < embs.size() ? embs[i] : kNone);
+    st[i] = trackers_[i]->staged();
+  }
+  if (!trackers_.empty()) rt::run_frame(*trackers_[0]->device(), st.data(), in.data(), static_cast<int>(st.size()));
+  std::vector<Eigen::MatrixXf> out;
+  for (rt::Staged* s : st) out.push_back(to_matrix(s->rows()));
+  return out;
+}
+
+// ---- public tracker classes --------------------------------------------------------------------
+namespace trackers {
+Sort::Sort(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class, int nr_classes,
+           const std::string& asso_func, bool is_obb, int device_index)
+    : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
+  validate_inputs_ = false;
+  adopt(rt::make_sort(dev_, det_thresh_, max_age_, max_obs_, min_hits_, iou_threshold_));
+}
+ByteTrack::ByteTrack(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class,
+                     int nr_classes, const std::string& asso_func, bool is_obb, float min_conf, float track_thresh,
+                     float match_thresh, int track_buffer, int frame_rate, int device_index)
+    : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
+  det_thresh_ = track_thresh;
+  adopt(rt::make_bytetrack(dev_, min_conf, track_thresh, match_thresh, track_buffer, frame_rate, max_age_, max_obs_));
+}
+OCSort::OCSort(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class, int nr_classes,
+               const std::string& asso_func, bool is_obb, float min_conf, int delta_t, float inertia, bool use_byte,
+               float Q_xy_scaling, float Q_s_scaling, int device_index)
+    : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
+  adopt(rt::make_ocsort(dev_, det_thresh_, max_age_, max_obs_, min_hits_, iou_threshold_, min_conf, delta_t, inertia, use_byte,
+                        Q_xy_scaling, Q_s_scaling));
+}
+BotSort::BotSort(const std::string& reid_weights, bool /*use_half*/, bool /*use_gpu*/, float det_thresh, int max_age, int max_obs,
+                 int min_hits, float iou_threshold, bool per_class, int nr_classes, const std::string& asso_func, bool is_obb,
+                 float track_high_thresh, float track_low_thresh, float new_track_thresh, int track_buffer, float match_thresh,
+                 float proximity_thresh, float appearance_thresh, const std::string& /*cmc_method*/, int frame_rate,
+                 bool fuse_first_associate, bool with_reid, int device_index)
+    : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
+  if (!reid_weights.empty())
+    throw std::invalid_argument("motcpp_amd: ReID model inference is outside the hot path; pass embeddings to update()");
+  skip_empty_ = true;
+  adopt(rt::make_botsort(dev_, track_high_thresh, track_low_thresh, new_track_thresh, track_buffer, match_thresh,
+                         proximity_thresh, appearance_thresh, frame_rate, fuse_first_associate, with_reid, max_age_, max_obs_));
+}
+}  // namespace trackers
+
+// ---- utils:: primitive seam ----------------------------------------------------------------------
+namespace utils {
+namespace {
+std::vector<float> row_major(const Eigen::MatrixXf& m, int cols) {
+  std::vector<float> v(static_cast<size_t>(m.rows()) * cols);
+  for (Eigen::Index i = 0; i < m.rows(); ++i)
+    for (int k = 0; k < cols; ++k) v[static_cast<size_t>(i) * cols + k] = m(i, k);
+  return v;
+}
+void chk(rt::Device& d, int rc, const char* what) { d.check(rc, what); }
+}  // namespace
+
+LinearAssignmentResult linear_assignment(const Eigen::MatrixXf& cost, float thresh, int device_index) {
+  LinearAssignmentResult r;
+  const int n = static_cast<int>(cost.rows()), m = static_cast<int>(cost.cols());
+  if (n == 0 || m == 0) {
+    for (int i = 0; i < n; ++i) r.unmatched_a.push_back(i);
+    for (int j = 0; j < m; ++j) r.unmatched_b.push_back(j);
+    return r;
+  }
+  auto dev = rt::Device::shared(device_index);
+  std::vector<float> c = row_major(cost, m);
+  std::vector<int> x(n), y(m);
+  chk(*dev, mot_lap_solve_host(dev->ctx, c.data(), n, m, thresh, MOT_LAP_PLAIN, nullptr, 0.f, x.data(), y.data(), nullptr), "mot_lap_solve_host");
+  for (int i = 0; i < n; ++i) {
+    if (x[i] < 0) r.unmatched_a.push_back(i);
+    else r.matches.push_back({i, x[i]});
+  }
+  for (int j = 0; j < m; ++j) if (y[j] < 0) r.unmatched_b.push_back(j);
+  return r;
+}
+static Eigen::MatrixXf iou_mode(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, int mode, int device_index) {
+  const int n = static_cast<int>(a.rows()), m = static_cast<int>(b.rows());
+  Eigen::MatrixXf out(n, m);
+  if (n == 0 || m == 0) return out;
+  auto dev = rt::Device::shared(device_index);
+  std::vector<float> ra = row_major(a, 4), rb = row_major(b, 4), c(static_cast<size_t>(n) * m);
+  chk(*dev, mot_iou_cost_host(dev->ctx, ra.data(), n, rb.data(), m, nullptr, mode, c.data()), "mot_iou_cost_host");
+  for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) out(i, j) = c[static_cast<size_t>(i) * m + j];
+  return out;
+}
+Eigen::MatrixXf iou_batch(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, int device_index) { return iou_mode(a, b, MOT_COST_IOU, device_index); }
+Eigen::MatrixXf iou_distance(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, int device_index) { return iou_mode(a, b, MOT_COST_IOU_DIST, device_index); }
+Eigen::MatrixXf embedding_distance(const Eigen::MatrixXf& t, const Eigen::MatrixXf& d, const std::string& metric, int device_index) {
+  if (metric != "cosine") throw std::invalid_argument("Unknown metric: " + metric);
+  const int n = static_cast<int>(t.rows()), m = static_cast<int>(d.rows()), dim = static_cast<int>(t.cols());
+  Eigen::MatrixXf out(n, m);
+  if (n == 0 || m == 0) return out;
+  auto dev = rt::Device::shared(device_index);
+  std::vector<float> ra = row_major(t, dim), rb = row_major(d, dim), c(static_cast<size_t>(n) * m);
+  chk(*dev, mot_cosine_cost_host(dev->ctx, ra.data(), n, rb.data(), m, dim, c.data()), "mot_cosine_cost_host");
+  for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) out(i, j) = c[static_cast<size_t>(i) * m + j];
+  return out;
+}
+}  // namespace utils
+
+}  // namespace motcpp

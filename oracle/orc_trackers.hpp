@@ -738,9 +738,9 @@ class BotSort {
   };
 
   OutTable update(const float* dets, int n, const float* embs, int emb_dim) {  // :260-359
+    laps.clear();
     if (n == 0) return {};  // :267-269 (no predict, no frame_count++)
     ++frame_count_;
-    laps.clear();
     std::vector<Det7> all = wrap_dets(dets, n);
     std::vector<BTrack> detections, detections_second;
     for (const Det7& d : all) {  // split_detections :361-403 + create_detections :405-423

@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Benchmark of the association hot path behind tracker.update() (BASELINE.json metric: frames/s at
+N_tracks x M_dets with assignment indices identical to the reference path).
+
+A "step" = one frame for every one of the S independent streams a rank owns, stepped in lockstep through
+motcpp::StreamBatch (one kernel launch per kernel family per stage, whatever S is). value = frames processed by
+all ranks / wall time of the timed region. The detection payload is resident in HBM before the timed region starts
+(the host keeps its own copy for the lifecycle decisions); only per-stage index lists / task descriptors and the
+result tables cross PCIe inside it. Streams are sharded over GPUs with no data-path collective; the final track
+tables are gathered over RCCL every --gather-every steps (weak scaling: S streams per GPU).
+
+Prints ONE JSON line on rank 0 (contract in the task brief) with the extra objects `roofline` (dominant kernel by
+summed HIP-event time inside the timed region) and `cpu_baseline` (the CPU oracle = restatement of the reference,
+timed on one host core on a bounded sample of stream 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # fp32 MFMA = fp32 vector peak
+
+WORKLOADS = {
+    # name: (tracker, P persistent objects, M dets/frame, emb_dim, description)
+    "C2": ("bytetrack", 256, 128, 0, "ByteTrack, synthetic 256 tracks x 128 dets/frame, IoU-only cost (BASELINE configs[1])"),
+    "NS": ("bytetrack", 1000, 500, 0, "ByteTrack, synthetic 1000 tracks x 500 dets/frame (north-star shape)"),
+    "C5": ("bytetrack", 1000, 512, 0, "ByteTrack, 1000 x 512 per stream (BASELINE configs[4] per-GPU shape)"),
+    "C3": ("botsort", 1024, 512, 256, "BoT-SORT, 1024 x 512 with 256-d embeddings (BASELINE configs[2])"),
+    "C4": ("ocsort", 4096, 2048, 0, "OC-SORT, 4096 x 2048 (BASELINE configs[3])"),
+    "SORT": ("sort", 256, 128, 0, "SORT, 256 x 128"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (0: workload default)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads for the per-stream lifecycle (0: all cores, max 16)")
+    ap.add_argument("--gather-every", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from motcpp_amd import _lib as L
+    from motcpp_amd.synth import SynthStream
+
+    if not (os.path.exists(L.HIP_LIB) and os.path.exists(L.HOST_LIB)):
+        L.build()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    tracker, P, M, D, desc = WORKLOADS[args.workload]
+    S = args.streams or {"C2": 512, "SORT": 512, "NS": 128, "C5": 128, "C3": 32, "C4": 8}[args.workload]
+    threads = args.threads or min(16, os.cpu_count() or 1)
+    K, W = args.steps, args.warmup
+    F = K + W
+
+    # ---- synthetic streams (seed 1234 + global stream id), generated before anything is timed ----
+    host = np.zeros((F, S, M, 6), np.float32)
+    embs = np.zeros((F, S, M, D), np.float32) if D else None
+    for s in range(S):
+        st = SynthStream(P, M, 1234 + rank * S + s, D)
+        for f in range(F):
+            d, e = st.next_frame()
+            host[f, s] = d
+            if D:
+                embs[f, s] = e
+    # detection payload resident in HBM as SoA [F, S, 6, M] before the timed region
+    dev_dets = torch.from_numpy(np.ascontiguousarray(host.transpose(0, 1, 3, 2))).cuda(local)
+    torch.cuda.synchronize()
+    frame_bytes = S * 6 * M * 4
+
+    batch = L.Batch(tracker, S, device=local, threads=threads)
+    cap = max(2 * M, 64)
+    gathered = None
+
+    def step(f):
+        out, cnt = batch.step(host[f], embs=embs[f] if D else None, cap=cap, resident_ptr=dev_dets.data_ptr() + f * frame_bytes)
+        return out, cnt
+
+    def gather(out, cnt):
+        # final track tables of this rank's streams -> every rank (RCCL all_gather over xGMI), padded [S, cap, 8] + counts
+        nonlocal gathered
+        t = torch.from_numpy(out[:, :cap]).cuda(local, non_blocking=True)
+        c = torch.from_numpy(cnt.astype(np.int32)).cuda(local, non_blocking=True)
+        if gathered is None:
+            gathered = (torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device),
+                        torch.empty((world, S), dtype=torch.int32, device=t.device))
+        dist.all_gather_into_tensor(gathered[0], t)
+        dist.all_gather_into_tensor(gathered[1], c)
+
+    kept = []  # stream 0 outputs of rank 0 for the parity spot check
+    for f in range(W):
+        out, cnt = step(f)
+        if rank == 0:
+            kept.append(out[0, :cnt[0]].copy())
+    if world > 1:
+        gather(out, cnt)
+        dist.barrier()
+    torch.cuda.synchronize()
+    L.profile(True, local)
+    c0 = batch.counters()
+    t0 = time.perf_counter()
+    for k in range(K):
+        out, cnt = step(W + k)
+        if world > 1 and ((k + 1) % args.gather_every == 0 or k == K - 1):
+            gather(out, cnt)
+        if rank == 0 and k < 24:
+            kept.append(out[0, :cnt[0]].copy())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    stats = L.profile_stats(local)
+    L.profile(False, local)
+    c1 = batch.counters()
+    elapsed = t1 - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    frames = world * S * K
+    value = frames / elapsed
+    # ---- roofline of the dominant kernel family (largest summed event time in the timed region) ----
+    fam = max(stats, key=lambda k: stats[k]["ms"])
+    st = stats[fam]
+    launches = max(st["launches"], 1)
+    avg_ms = st["ms"] / launches
+    bytes_per_launch = st["bytes"] / launches
+    if fam == "cosine" and st["flops"] > 0:
+        achieved = st["flops"] / launches / (avg_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_F32_PEAK_TFLOPS}
+    else:
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+    roof.update({"kernel": fam, "avg_launch_ms": avg_ms, "launches": st["launches"], "problems_per_launch": st["tasks"] / launches,
+                 "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": None,
+                 "note": "lap is one workgroup per problem and latency/dependency-bound (sequential rows of lapjv); "
+                         "its HBM fraction is reported as measured, see DESIGN.md"})
+    prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+    if os.path.exists(prof):
+        try:
+            roof["traffic"] = json.load(open(prof)).get(fam, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["launches"],
+                   "GB/s": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 2) if v["ms"] > 0 else 0.0}
+               for k, v in stats.items() if v["launches"]}
+    gpu_busy_ms = sum(v["ms"] for v in stats.values())
+
+    # ---- CPU baseline: the oracle (CPU restatement of the reference path) on one core, stream 0 ----
+    cpu = None
+    parity = None
+    if not args.no_cpu_baseline and world == 1:
+        from tests import orclib
+        orc = orclib.load()
+        kind = {"sort": orclib.SORT, "bytetrack": orclib.BYTETRACK, "ocsort": orclib.OCSORT, "botsort": orclib.BOTSORT}[tracker]
+        to = orc.tracker(kind)
+        mism = 0
+        for f in range(len(kept)):  # parity spot check on the frames the GPU path just processed
+            fi = f if f < W else W + (f - W)
+            oo = to.update(host[fi, 0], embs[fi, 0] if D else None)
+            if oo.shape != kept[f].shape or not np.array_equal(oo, kept[f]):
+                mism += 1
+        parity = {"stream0_frames_checked": len(kept), "mismatching_frames": mism}
+        to2 = orc.tracker(kind)
+        st0 = SynthStream(P, M, 1234, D)
+        for _ in range(W):
+            d, e = st0.next_frame()
+            to2.update(d, e)
+        n, tc = 0, 0.0
+        while tc < args.cpu_seconds and n < 200000:
+            d, e = st0.next_frame()
+            ta = time.perf_counter()
+            to2.update(d, e)
+            tc += time.perf_counter() - ta
+            n += 1
+        cpu = {"value": n / tc, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"{n} consecutive frames of stream 0 after {W} warm-up frames ({tc:.1f} s), oracle/ (scalar C++17, -O2)",
+               "host_cores_available": os.cpu_count()}
+
+    line = {
+        "metric": "tracker.update() frames/sec at N_tracks x M_dets (assignment indices identical to the reference path)",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {desc}", "tracker": tracker, "tracks": P, "dets_per_frame": M, "emb_dim": D,
+                   "streams_per_gpu": S, "frames_per_step": world * S, "host_threads": threads,
+                   "parallelism": f"{world} GPU(s) x {S} independent streams, lockstep stages",
+                   "inputs": "detections resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},
+        "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+        "kernels": kernels,
+        "gpu_busy_frac": gpu_busy_ms / (elapsed * 1e3) if elapsed > 0 else None,
+        "flushes_per_step": (c1["flushes"] - c0["flushes"]) / K, "launches_per_step": (c1["launches"] - c0["launches"]) / K,
+        "single_stream_equivalent_latency_ms": elapsed / K * 1e3,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

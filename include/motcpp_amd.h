@@ -71,6 +71,11 @@ int mot_memset(mot_ctx* ctx, void* d, int value, size_t bytes);
 /* stream-ordered timing (hipEvent pair): returns elapsed milliseconds between two marks */
 int mot_timer_start(mot_ctx* ctx);
 int mot_timer_stop(mot_ctx* ctx, float* ms); /* synchronises */
+/* HIP events on the context's stream (used to time individual kernel launches for the roofline report) */
+int mot_event_create(mot_ctx* ctx, void** ev);
+int mot_event_destroy(mot_ctx* ctx, void* ev);
+int mot_event_record(mot_ctx* ctx, void* ev);
+int mot_event_elapsed(mot_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* both events must have completed */
 
 /* ---- detections ---------------------------------------------------------------------- */
 typedef enum mot_det_kind {

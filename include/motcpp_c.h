@@ -37,7 +37,16 @@ void motcpp_batch_destroy(motcpp_batch* b);
  * threads: host threads used for the per-stream lifecycle work (<= 1: caller thread only). */
 int motcpp_batch_step(motcpp_batch* b, const float* dets, const int* counts, int max_n, const float* embs, int d,
                       float* out, int* out_counts, int cap);
+/* same, with the detections ALSO already resident in HBM as SoA [S][6][max_n] (device pointer): nothing but the small
+ * per-stage index lists crosses PCIe inside the call. The host copy is still needed for the lifecycle decisions. */
+int motcpp_batch_step_resident(motcpp_batch* b, const float* dets, const int* counts, int max_n, const void* d_dets_soa,
+                               const float* embs, int d, float* out, int* out_counts, int cap);
 int motcpp_batch_set_threads(motcpp_batch* b, int threads);
+/* per-kernel-family HIP-event timing on the device's stream. enable=1 resets the counters. Families (rows):
+ * 0 det_prepare 1 feat 2 kf_initiate 3 kf_update 4 kf_predict 5 kf_boxes 6 cosine 7 iou 8 ocsort_cost 9 lap.
+ * stats row = [summed ms, launches, tasks, algorithmic bytes, flops]. */
+int motcpp_profile(int device, int enable);
+int motcpp_profile_stats(int device, double* out_rows5, int cap_rows);
 /* counters since creation: [0] frames stepped, [1] flushes, [2] kernel launches */
 int motcpp_batch_counters(motcpp_batch* b, long* out3);
 int motcpp_batch_tracker_count(motcpp_batch* b);

@@ -158,7 +158,11 @@ def host():
         H.motcpp_batch_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
         H.motcpp_batch_destroy.argtypes = [C.c_void_p]
         H.motcpp_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        H.motcpp_batch_step_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_int]
         H.motcpp_batch_set_threads.argtypes = [C.c_void_p, C.c_int]
+        H.motcpp_profile.argtypes = [C.c_int, C.c_int]
+        H.motcpp_profile_stats.argtypes = [C.c_int, C.c_void_p, C.c_int]
         H.motcpp_batch_counters.argtypes = [C.c_void_p, C.c_void_p]
         H.motcpp_batch_tracker.restype = C.c_void_p
         H.motcpp_batch_tracker.argtypes = [C.c_void_p, C.c_int]
@@ -273,8 +277,9 @@ class Batch:
         host().motcpp_batch_counters(self.h, a)
         return {"frames": a[0], "flushes": a[1], "launches": a[2]}
 
-    def step(self, dets, counts=None, embs=None, cap=None):
-        """dets [S, N, 6] (counts[s] valid rows each); returns (out [S, cap, 8], out_counts [S])."""
+    def step(self, dets, counts=None, embs=None, cap=None, resident_ptr=None):
+        """dets [S, N, 6] (counts[s] valid rows each); returns (out [S, cap, 8], out_counts [S]).
+        resident_ptr: device address of the same detections as SoA [S, 6, N] already in HBM (no payload upload)."""
         dets = f32(dets)
         S, N = dets.shape[0], dets.shape[1]
         assert S == self.S
@@ -286,7 +291,28 @@ class Batch:
         if embs is not None:
             embs = f32(embs)
             e, d = _p(embs), embs.shape[2]
-        r = host().motcpp_batch_step(self.h, _p(dets), _p(counts), N, e, d, _p(self._out), _p(self._cnt), self._out.shape[1])
+        if resident_ptr:
+            r = host().motcpp_batch_step_resident(self.h, _p(dets), _p(counts), N, C.c_void_p(int(resident_ptr)), e, d,
+                                                  _p(self._out), _p(self._cnt), self._out.shape[1])
+        else:
+            r = host().motcpp_batch_step(self.h, _p(dets), _p(counts), N, e, d, _p(self._out), _p(self._cnt), self._out.shape[1])
         if r < 0:
             raise MotError("batch step failed: " + _err())
         return self._out, self._cnt
+
+
+FAMILIES = ["det_prepare", "feat", "kf_initiate", "kf_update", "kf_predict", "kf_boxes", "cosine", "iou_cost", "ocsort_cost", "lap"]
+
+
+def profile(enable, device=0):
+    """Turn per-kernel-family HIP-event timing on (resets the counters) or off."""
+    if host().motcpp_profile(int(device), 1 if enable else 0) != 0:
+        raise MotError(_err())
+
+
+def profile_stats(device=0):
+    a = np.zeros((len(FAMILIES), 5), np.float64)
+    if host().motcpp_profile_stats(int(device), _p(a), len(FAMILIES)) < 0:
+        raise MotError(_err())
+    return {FAMILIES[i]: {"ms": a[i, 0], "launches": int(a[i, 1]), "tasks": int(a[i, 2]), "bytes": a[i, 3], "flops": a[i, 4]}
+            for i in range(len(FAMILIES))}

@@ -109,6 +109,14 @@ int mot_timer_stop(mot_ctx* c, float* ms) {
   return MOT_OK;
 }
 
+int mot_event_create(mot_ctx* c, void** ev) { hipEvent_t e; MOT_HIP(c, hipEventCreate(&e)); *ev = e; return MOT_OK; }
+int mot_event_destroy(mot_ctx* c, void* ev) { if (ev) MOT_HIP(c, hipEventDestroy(static_cast<hipEvent_t>(ev))); return MOT_OK; }
+int mot_event_record(mot_ctx* c, void* ev) { MOT_HIP(c, hipEventRecord(static_cast<hipEvent_t>(ev), c->stream)); return MOT_OK; }
+int mot_event_elapsed(mot_ctx* c, void* a, void* b, float* ms) {
+  MOT_HIP(c, hipEventElapsedTime(ms, static_cast<hipEvent_t>(a), static_cast<hipEvent_t>(b)));
+  return MOT_OK;
+}
+
 int mot_kf_dim(int kind) { return kind == MOT_KF_XYSR ? 7 : 8; }
 
 int mot_det_prepare(mot_ctx* c, int kind, const mot_det_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_det(kind, t, nt, max_n, c->stream)); return MOT_OK; }

@@ -62,7 +62,7 @@ class BotSortGpu final : public Staged {
       if (seen.insert(lost_[i].id).second) pool_.push_back({static_cast<int>(i), false});
 
     core_.reserve(static_cast<int>(first_.size()) + 8, 8);
-    dets_ = core_.upload_dets(in.dets, in.n, in.ld, MOT_DET_XYWH);
+    dets_ = core_.upload_dets(in.dets, in.n, in.ld, MOT_DET_XYWH, in.d_dets, in.d_ld);
     // appearance: raw rows for every detection, L2-normalised copies for the association (:38-46)
     have_emb_ = with_reid_ && in.embs != nullptr && in.emb_dim > 0;
     if (have_emb_) {

@@ -73,7 +73,7 @@ class ByteTrackGpu final : public Staged {
       if (seen.insert(lost_[i].id).second) pool_.push_back({static_cast<int>(i), false});
     const int np = static_cast<int>(pool_.size());
     core_.reserve(static_cast<int>(high_.size()) + 8, np + 8);
-    dets_ = core_.upload_dets(in.dets, in.n, in.ld, MOT_DET_XYAH);
+    dets_ = core_.upload_dets(in.dets, in.n, in.ld, MOT_DET_XYAH, in.d_dets, in.d_ld);
 
     lap1_ = Core::Lap();
     if (np > 0) {

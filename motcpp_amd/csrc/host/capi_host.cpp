@@ -144,8 +144,8 @@ int motcpp_batch_counters(motcpp_batch* b, long* out3) {
   out3[0] = b->frames; out3[1] = b->dev->counters.flushes; out3[2] = b->dev->counters.launches;
   return 0;
 }
-int motcpp_batch_step(motcpp_batch* b, const float* dets, const int* counts, int max_n, const float* embs, int d, float* out,
-                      int* out_counts, int cap) {
+static int batch_step_impl(motcpp_batch* b, const float* dets, const int* counts, int max_n, const float* d_dets,
+                           const float* embs, int d, float* out, int* out_counts, int cap) {
   try {
     const int S = static_cast<int>(b->trk.size());
     std::vector<FrameIn> in(S);
@@ -153,9 +153,10 @@ int motcpp_batch_step(motcpp_batch* b, const float* dets, const int* counts, int
     for (int s = 0; s < S; ++s) {
       to_colmajor(dets + static_cast<size_t>(s) * max_n * 6, counts[s], b->colmajor[s]);
       in[s] = frame_in(b->colmajor[s], counts[s], embs ? embs + static_cast<size_t>(s) * max_n * d : nullptr, d);
+      if (d_dets) { in[s].d_dets = d_dets + static_cast<size_t>(s) * 6 * max_n; in[s].d_ld = max_n; }
       st[s] = b->trk[s]->impl.get();
     }
-    run_frame(*b->dev, st.data(), in.data(), S);
+    run_frame(*b->dev, st.data(), in.data(), S, b->threads);
     b->frames += S;
     for (int s = 0; s < S; ++s) {
       const int m = copy_rows(st[s]->rows(), out + static_cast<size_t>(s) * cap * 8, cap);
@@ -163,6 +164,34 @@ int motcpp_batch_step(motcpp_batch* b, const float* dets, const int* counts, int
       out_counts[s] = m;
     }
     return S;
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int motcpp_batch_step(motcpp_batch* b, const float* dets, const int* counts, int max_n, const float* embs, int d, float* out,
+                      int* out_counts, int cap) {
+  return batch_step_impl(b, dets, counts, max_n, nullptr, embs, d, out, out_counts, cap);
+}
+int motcpp_batch_step_resident(motcpp_batch* b, const float* dets, const int* counts, int max_n, const void* d_dets_soa,
+                               const float* embs, int d, float* out, int* out_counts, int cap) {
+  return batch_step_impl(b, dets, counts, max_n, static_cast<const float*>(d_dets_soa), embs, d, out, out_counts, cap);
+}
+int motcpp_profile(int device, int enable) {
+  try {
+    auto dev = Device::shared(device);
+    dev->profile = enable != 0;
+    if (enable) dev->reset_stats();
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int motcpp_profile_stats(int device, double* out, int cap_rows) {
+  try {
+    auto dev = Device::shared(device);
+    const int n = F_COUNT < cap_rows ? F_COUNT : cap_rows;
+    for (int f = 0; f < n; ++f) {
+      const FamilyStat& s = dev->stats[f];
+      out[f * 5 + 0] = s.ms; out[f * 5 + 1] = static_cast<double>(s.launches); out[f * 5 + 2] = static_cast<double>(s.tasks);
+      out[f * 5 + 3] = s.bytes; out[f * 5 + 4] = s.flops;
+    }
+    return n;
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 

@@ -55,7 +55,7 @@ class OCSortGpu final : public Staged {
     }
     const int nt = static_cast<int>(trk_.size());
     core_.reserve(2 * static_cast<int>(high_.size()) + 8, 8);
-    dets_ = core_.upload_dets(in.dets, in.n, in.ld, MOT_DET_XYSR);
+    dets_ = core_.upload_dets(in.dets, in.n, in.ld, MOT_DET_XYSR, in.d_dets, in.d_ld);
     pbox_ = Span<float>();
     nt0_ = nt;
     assoc_ = Core::Lap();

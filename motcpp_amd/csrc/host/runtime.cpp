@@ -120,6 +120,26 @@ const T* stage_tasks(Arena& up, const std::vector<T>& v) {
 }
 }  // namespace
 
+void Device::reset_stats() {
+  for (FamilyStat& f : stats) f = FamilyStat();
+}
+void* Device::get_event() {
+  if (!event_pool_.empty()) { void* e = event_pool_.back(); event_pool_.pop_back(); return e; }
+  void* e = nullptr;
+  check(mot_event_create(ctx, &e), "mot_event_create");
+  return e;
+}
+void Device::time_begin(int family) {
+  if (!profile) return;
+  Timed t{family, get_event(), get_event()};
+  check(mot_event_record(ctx, t.e0), "mot_event_record");
+  timed_.push_back(t);
+}
+void Device::time_end() {
+  if (!profile) return;
+  check(mot_event_record(ctx, timed_.back().e1), "mot_event_record");
+}
+
 void Device::flush() {
   const mot_det_task* d_det[3];
   const mot_kf_task *d_init[3], *d_upd[3], *d_pred[3], *d_box[3];
@@ -139,36 +159,82 @@ void Device::flush() {
   up->upload();
 
   auto maxn = [](const auto& v, auto get) { int m = 0; for (const auto& t : v) m = std::max(m, get(t)); return m; };
-  for (int k = 0; k < 3; ++k)
-    if (!det[k].empty()) { check(mot_det_prepare(ctx, k, d_det[k], (int)det[k].size(), maxn(det[k], [](const mot_det_task& t) { return t.n; })), "mot_det_prepare"); ++counters.launches; }
-  if (!feat_set.empty()) { check(mot_feat_update(ctx, d_fset, (int)feat_set.size(), maxn(feat_set, [](const mot_feat_task& t) { return t.n; })), "mot_feat_update"); ++counters.launches; }
-  for (int k = 0; k < 3; ++k)
-    if (!kf_init[k].empty()) { check(mot_kf_initiate(ctx, k, d_init[k], (int)kf_init[k].size(), maxn(kf_init[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_initiate"); ++counters.launches; }
-  for (int k = 0; k < 3; ++k)
-    if (!kf_upd[k].empty()) { check(mot_kf_update(ctx, k, d_upd[k], (int)kf_upd[k].size(), maxn(kf_upd[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_update"); ++counters.launches; }
-  if (!feat_ema.empty()) { check(mot_feat_update(ctx, d_fema, (int)feat_ema.size(), maxn(feat_ema, [](const mot_feat_task& t) { return t.n; })), "mot_feat_update"); ++counters.launches; }
-  for (int k = 0; k < 3; ++k)
-    if (!kf_pred[k].empty()) { check(mot_kf_predict(ctx, k, d_pred[k], (int)kf_pred[k].size(), maxn(kf_pred[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_predict"); ++counters.launches; }
-  for (int k = 0; k < 3; ++k)
-    if (!kf_box[k].empty()) { check(mot_kf_boxes(ctx, k, d_box[k], (int)kf_box[k].size(), maxn(kf_box[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_boxes"); ++counters.launches; }
-  if (!cos.empty()) {
-    check(mot_cosine_cost(ctx, d_cos, (int)cos.size(), maxn(cos, [](const mot_cos_task& t) { return t.n; }), maxn(cos, [](const mot_cos_task& t) { return t.m; })), "mot_cosine_cost");
-    counters.launches += 2;
-  }
-  if (!iou.empty()) {
-    check(mot_iou_cost(ctx, d_iou, (int)iou.size(), maxn(iou, [](const mot_iou_task& t) { return t.n; }), maxn(iou, [](const mot_iou_task& t) { return t.m; })), "mot_iou_cost");
+  // One launch per non-empty kernel family; with profile on, each launch is bracketed by an event pair and its
+  // algorithmic bytes (DESIGN.md "Kernels") are accumulated for the roofline report.
+  auto run = [&](int family, size_t ntasks, double bytes, double flops, auto&& launch) {
+    if (ntasks == 0) return;
+    time_begin(family);
+    launch();
+    time_end();
     ++counters.launches;
+    FamilyStat& f = stats[family];
+    ++f.launches; f.tasks += static_cast<long>(ntasks); f.bytes += bytes; f.flops += flops;
+  };
+  auto kf_bytes = [](const std::vector<mot_kf_task>& v, int kind, double per_state_rw) {
+    const double D = mot_kf_dim(kind);
+    double b = 0;
+    for (const mot_kf_task& t : v) b += t.n * (4.0 * (D + D * D) * per_state_rw + 16.0 + 8.0);
+    return b;
+  };
+  for (int k = 0; k < 3; ++k) {
+    double b = 0;
+    for (const mot_det_task& t : det[k]) b += t.n * (16.0 + 32.0);
+    run(F_DET, det[k].size(), b, 0, [&] { check(mot_det_prepare(ctx, k, d_det[k], (int)det[k].size(), maxn(det[k], [](const mot_det_task& t) { return t.n; })), "mot_det_prepare"); });
   }
-  if (!oc.empty()) {
-    check(mot_ocsort_cost(ctx, d_oc, (int)oc.size(), maxn(oc, [](const mot_ocsort_task& t) { return t.nd; }), maxn(oc, [](const mot_ocsort_task& t) { return t.nt; })), "mot_ocsort_cost");
-    ++counters.launches;
+  {
+    double b = 0;
+    for (const mot_feat_task& t : feat_set) b += 4.0 * t.n * t.d * 2;
+    run(F_FEAT, feat_set.size(), b, 0, [&] { check(mot_feat_update(ctx, d_fset, (int)feat_set.size(), maxn(feat_set, [](const mot_feat_task& t) { return t.n; })), "mot_feat_update"); });
   }
-  if (!lap.empty()) {
-    check(mot_lap_solve(ctx, d_lap, (int)lap.size(), maxn(lap, [](const mot_lap_task& t) { return t.n + t.m; })), "mot_lap_solve");
-    ++counters.launches;
+  for (int k = 0; k < 3; ++k)
+    run(F_KF_INIT, kf_init[k].size(), kf_bytes(kf_init[k], k, 1.0), 0, [&] { check(mot_kf_initiate(ctx, k, d_init[k], (int)kf_init[k].size(), maxn(kf_init[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_initiate"); });
+  for (int k = 0; k < 3; ++k)
+    run(F_KF_UPDATE, kf_upd[k].size(), kf_bytes(kf_upd[k], k, 2.0), 0, [&] { check(mot_kf_update(ctx, k, d_upd[k], (int)kf_upd[k].size(), maxn(kf_upd[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_update"); });
+  {
+    double b = 0;
+    for (const mot_feat_task& t : feat_ema) b += 4.0 * t.n * t.d * 3;
+    run(F_FEAT, feat_ema.size(), b, 0, [&] { check(mot_feat_update(ctx, d_fema, (int)feat_ema.size(), maxn(feat_ema, [](const mot_feat_task& t) { return t.n; })), "mot_feat_update"); });
+  }
+  for (int k = 0; k < 3; ++k)
+    run(F_KF_PREDICT, kf_pred[k].size(), kf_bytes(kf_pred[k], k, 2.0), 0, [&] { check(mot_kf_predict(ctx, k, d_pred[k], (int)kf_pred[k].size(), maxn(kf_pred[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_predict"); });
+  for (int k = 0; k < 3; ++k) {
+    double b = 0;
+    for (const mot_kf_task& t : kf_box[k]) b += t.n * (16.0 + 16.0 + 4.0);
+    run(F_KF_BOXES, kf_box[k].size(), b, 0, [&] { check(mot_kf_boxes(ctx, k, d_box[k], (int)kf_box[k].size(), maxn(kf_box[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_boxes"); });
+  }
+  {
+    double b = 0, fl = 0;
+    for (const mot_cos_task& t : cos) { b += 4.0 * ((double)(t.n + t.m) * t.d + (double)t.n * t.m); fl += 2.0 * t.n * (double)t.m * t.d; }
+    run(F_COSINE, cos.size(), b, fl, [&] {
+      check(mot_cosine_cost(ctx, d_cos, (int)cos.size(), maxn(cos, [](const mot_cos_task& t) { return t.n; }), maxn(cos, [](const mot_cos_task& t) { return t.m; })), "mot_cosine_cost");
+      ++counters.launches;
+    });
+  }
+  {
+    double b = 0;
+    for (const mot_iou_task& t : iou) b += 16.0 * (t.n + t.m) + (t.cost ? 4.0 * t.n * (double)t.m : 0.0) + (t.emb ? 4.0 * t.n * (double)t.m : 0.0);
+    run(F_IOU, iou.size(), b, 0, [&] { check(mot_iou_cost(ctx, d_iou, (int)iou.size(), maxn(iou, [](const mot_iou_task& t) { return t.n; }), maxn(iou, [](const mot_iou_task& t) { return t.m; })), "mot_iou_cost"); });
+  }
+  {
+    double b = 0;
+    for (const mot_ocsort_task& t : oc) b += 20.0 * t.nd + 44.0 * t.nt + 8.0 * t.nd * (double)t.nt;
+    run(F_OCSORT, oc.size(), b, 0, [&] { check(mot_ocsort_cost(ctx, d_oc, (int)oc.size(), maxn(oc, [](const mot_ocsort_task& t) { return t.nd; }), maxn(oc, [](const mot_ocsort_task& t) { return t.nt; })), "mot_ocsort_cost"); });
+  }
+  {
+    double b = 0;
+    for (const mot_lap_task& t : lap) b += 4.0 * t.n * (double)t.m * (t.iou ? 2.0 : 1.0) + 4.0 * (t.n + t.m);
+    run(F_LAP, lap.size(), b, 0, [&] { check(mot_lap_solve(ctx, d_lap, (int)lap.size(), maxn(lap, [](const mot_lap_task& t) { return t.n + t.m; })), "mot_lap_solve"); });
   }
   down->download();
   check(mot_ctx_sync(ctx), "mot_ctx_sync");
+  for (const Timed& t : timed_) {
+    float ms = 0.f;
+    check(mot_event_elapsed(ctx, t.e0, t.e1, &ms), "mot_event_elapsed");
+    stats[t.family].ms += ms;
+    event_pool_.push_back(t.e0);
+    event_pool_.push_back(t.e1);
+  }
+  timed_.clear();
   ++counters.flushes;
   for (int k = 0; k < 3; ++k) { det[k].clear(); kf_init[k].clear(); kf_upd[k].clear(); kf_pred[k].clear(); kf_box[k].clear(); }
   feat_set.clear(); feat_ema.clear(); cos.clear(); iou.clear(); oc.clear(); lap.clear();
@@ -213,18 +279,24 @@ int Core::new_slot() {
 void Core::release_slot(int s) { free_.push_back(s); }
 void Core::clear_slots() { free_.clear(); next_ = 0; }
 
-Core::Dets Core::upload_dets(const float* colmajor, int n, int ld, int det_kind) {
+Core::Dets Core::upload_dets(const float* colmajor, int n, int ld, int det_kind, const float* resident, int resident_ld) {
   Dets d;
   d.n = n;
   if (n <= 0) return d;
   std::lock_guard<std::mutex> g(dev_->mu);
-  Span<float> raw = dev_->up->alloc<float>(static_cast<size_t>(6) * n);
-  for (int k = 0; k < 6; ++k) std::memcpy(raw.h + static_cast<size_t>(k) * n, colmajor + static_cast<size_t>(k) * ld, sizeof(float) * n);
-  d.d_raw = raw.d;
+  if (resident) {
+    d.d_raw = resident;
+    d.ld_raw = resident_ld;
+  } else {
+    Span<float> raw = dev_->up->alloc<float>(static_cast<size_t>(6) * n);
+    for (int k = 0; k < 6; ++k) std::memcpy(raw.h + static_cast<size_t>(k) * n, colmajor + static_cast<size_t>(k) * ld, sizeof(float) * n);
+    d.d_raw = raw.d;
+    d.ld_raw = n;
+  }
   d.d_box = dev_->tmp->alloc<float>(static_cast<size_t>(4) * n).d;
   d.d_meas = dev_->tmp->alloc<float>(static_cast<size_t>(4) * n).d;
   mot_det_task t{};
-  t.dets = raw.d; t.ld = n; t.n = n; t.box = d.d_box; t.ldb = n; t.meas = d.d_meas; t.ldm = n;
+  t.dets = d.d_raw; t.ld = d.ld_raw; t.n = n; t.box = d.d_box; t.ldb = n; t.meas = d.d_meas; t.ldm = n;
   dev_->det[det_kind].push_back(t);
   return d;
 }

@@ -63,6 +63,16 @@ struct StageCounters {
   long flushes = 0, launches = 0;
 };
 
+// Kernel families timed with HIP events when Device::profile is on (bench.py's roofline leg).
+enum Family { F_DET = 0, F_FEAT, F_KF_INIT, F_KF_UPDATE, F_KF_PREDICT, F_KF_BOXES, F_COSINE, F_IOU, F_OCSORT, F_LAP, F_COUNT };
+struct FamilyStat {
+  double ms = 0.0;      // summed launch durations (event pairs on the stream)
+  long launches = 0;
+  long tasks = 0;
+  double bytes = 0.0;   // algorithmic bytes (DESIGN.md "kernels")
+  double flops = 0.0;   // cosine only
+};
+
 class Device {
  public:
   explicit Device(int device_index);
@@ -88,6 +98,16 @@ class Device {
   void flush();
   void check(int rc, const char* what);
   StageCounters counters;
+  bool profile = false;
+  FamilyStat stats[F_COUNT];
+  void reset_stats();
+ private:
+  struct Timed { int family; void* e0; void* e1; };
+  std::vector<void*> event_pool_;
+  std::vector<Timed> timed_;
+  void* get_event();
+  void time_begin(int family);
+  void time_end();
 };
 
 // Per-tracker device state + task-building helpers.
@@ -109,12 +129,14 @@ class Core {
   // ---- detections of the current frame ----
   struct Dets {
     int n = 0;
-    const float* d_raw = nullptr;  // SoA [6][n]
+    const float* d_raw = nullptr;  // SoA [6][ld_raw]
+    int ld_raw = 0;
     float* d_box = nullptr;        // [4][n]
     float* d_meas = nullptr;       // [4][n]
-    const float* d_conf() const { return d_raw + static_cast<size_t>(4) * n; }
+    const float* d_conf() const { return d_raw + static_cast<size_t>(4) * ld_raw; }
   };
-  Dets upload_dets(const float* colmajor, int n, int ld, int det_kind);
+  // resident != nullptr: the detections already sit in HBM as SoA [6][resident_ld]; nothing is uploaded
+  Dets upload_dets(const float* colmajor, int n, int ld, int det_kind, const float* resident = nullptr, int resident_ld = 0);
 
   Span<int32_t> ints(const std::vector<int>& v);
   Span<uint8_t> bytes(const std::vector<uint8_t>& v);

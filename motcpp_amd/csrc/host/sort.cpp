@@ -39,7 +39,7 @@ class SortGpu final : public Staged {
       cls_[i] = static_cast<int>(in.dets[static_cast<size_t>(5) * in.ld + i]);
     }
     core_.reserve(static_cast<int>(valid_.size()) + 8, 8);
-    dets_ = core_.upload_dets(in.dets, in.n, in.ld, MOT_DET_XYSR);
+    dets_ = core_.upload_dets(in.dets, in.n, in.ld, MOT_DET_XYSR, in.d_dets, in.d_ld);
     const int nt = static_cast<int>(trk_.size());
     lap_ = Core::Lap();
     pbox_ = Span<float>();

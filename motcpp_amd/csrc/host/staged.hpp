@@ -14,6 +14,8 @@ struct FrameIn {
   int emb_ld = 0, emb_dim = 0;
   bool embs_rowmajor = false;   // true: n x emb_dim row-major (ld = emb_dim)
   int img_w = 0, img_h = 0;
+  const float* d_dets = nullptr;  // optional: the same detections already resident in HBM, SoA [6][d_ld]
+  int d_ld = 0;
 };
 
 struct LapRecord {
@@ -54,7 +56,7 @@ class Staged {
 };
 
 // Runs one frame for a set of trackers sharing a Device in lockstep: one kernel launch per kernel family per stage.
-void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count);
+void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, int threads = 1);
 
 // factories (parameter vectors: same layout as documented in include/motcpp_c.h)
 Staged* make_sort(std::shared_ptr<Device>, float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold);

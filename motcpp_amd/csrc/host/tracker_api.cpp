@@ -43,18 +43,38 @@ void BaseTracker::setup_detection_format(const Eigen::MatrixXf& dets) {
 }
 
 namespace rt {
-void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count) {
+void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, int threads) {
   dev.begin_frame();
   std::vector<char> done(count, 0);
-  for (int i = 0; i < count; ++i) trackers[i]->begin(inputs[i]);
+  std::string err;
+  const bool par = threads > 1 && count > 1;
+  // Host lifecycle of different streams is independent: step the stage machines from several host threads
+  // (arena allocation and task-list appends are serialised by Device::mu; kernels are launched once per stage).
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4) if (par)
+  for (int i = 0; i < count; ++i) {
+    try { trackers[i]->begin(inputs[i]); }
+    catch (const std::exception& e) {
+#pragma omp critical
+      err = e.what();
+    }
+  }
+  if (!err.empty()) throw Error(err);
   while (true) {
     if (dev.pending()) dev.flush();
-    bool any = false;
+    int any = 0;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4) reduction(| : any) if (par)
     for (int i = 0; i < count; ++i) {
       if (done[i]) continue;
-      if (trackers[i]->advance()) any = true;
-      else done[i] = 1;
+      try {
+        if (trackers[i]->advance()) any |= 1;
+        else done[i] = 1;
+      } catch (const std::exception& e) {
+        done[i] = 1;
+#pragma omp critical
+        err = e.what();
+      }
     }
+    if (!err.empty()) throw Error(err);
     if (!any) break;
   }
 }

@@ -184,11 +184,16 @@ typedef struct mot_lap_task {
   const float* iou; int32_t ldi; float gate;
   float* xval;  /* optional out [n]: iou (if given, else cost) at (i, x[i])     */
   int32_t* info;/* optional out [1]: 0 lapjv, 1 trivial shortcut, 2 gated off   */
-  void* work;   /* scratch of mot_lap_work_bytes(n, m) bytes; only needed when the problem does not fit LDS */
+  void* work;   /* REQUIRED scratch of mot_lap_work_bytes(n, m) bytes (cold path arrays, staged boxes, overflow of the LDS state) */
+  /* on-the-fly cost: when geom.a != NULL the cost of pair (i,j) is recomputed inside the solver from geom's row /
+   * column boxes with mot_iou_cost's arithmetic for geom.mode (cost, ldc are ignored; geom.cost/pairs unused): the
+   * N x M matrix is never materialised. geom.emb (BOTSORT) is still read from memory, for overlapping pairs only. */
+  mot_iou_task geom;
+  long long* prof; /* optional out [8]: shader cycles per solver phase + pass counts (diagnostics) */
 } mot_lap_task;
+enum { MOT_LAP_F_GEOM = 1 /* some task carries geom: reserve LDS for the staged boxes */ };
 size_t mot_lap_work_bytes(int n, int m);
-int mot_lap_lds_limit(void); /* largest n+m solved entirely out of LDS */
-int mot_lap_solve(mot_ctx* ctx, const mot_lap_task* tasks, int ntasks, int max_n_plus_m);
+int mot_lap_solve(mot_ctx* ctx, const mot_lap_task* tasks, int ntasks, int max_n, int max_m, int flags);
 
 /* ---- host-pointer conveniences (synchronous; row-major matrices) ---------------------- */
 int mot_iou_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_xyxy, int m,
@@ -198,6 +203,10 @@ int mot_ocsort_cost_host(mot_ctx* ctx, const float* dets5, int nd, const float* 
                          const float* vel2, const float* prev5, float vdc_weight, float* cost, float* iou);
 int mot_lap_solve_host(mot_ctx* ctx, const float* cost, int n, int m, float thresh, int mode,
                        const float* iou_or_null, float gate, int* x, int* y, int* info_or_null);
+/* assignment straight from boxes (on-the-fly cost, no matrix): cost_mode is a mot_cost_mode */
+int mot_lap_geom_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_xyxy, int m, const float* bconf_or_null,
+                      int cost_mode, float thresh, int lap_mode, float gate, int* x, int* y, float* xval_or_null,
+                      int* info_or_null, long long* prof8_or_null);
 /* mean: n x d, cov: n x d x d row-major (AoS); op: 0 initiate (mean/cov out), 1 predict, 2 update */
 int mot_kf_apply_host(mot_ctx* ctx, int kf_kind, int op, int n, const float* meas4, const float* q3_or_null,
                       const unsigned char* flags_or_null, float* mean, float* cov, float* boxes4_or_null);

@@ -49,6 +49,8 @@ int motcpp_profile(int device, int enable);
 int motcpp_profile_stats(int device, double* out_rows5, int cap_rows);
 /* counters since creation: [0] frames stepped, [1] flushes, [2] kernel launches */
 int motcpp_batch_counters(motcpp_batch* b, long* out3);
+/* host wall time since creation, ms: [0] begin() of all trackers, [1] flush (upload+launch+download+sync), [2] advance(), [3] the sync wait inside flush */
+int motcpp_batch_host_ms(motcpp_batch* b, double* out4);
 int motcpp_batch_tracker_count(motcpp_batch* b);
 motcpp_tracker* motcpp_batch_tracker(motcpp_batch* b, int s); /* borrowed handle (for the parity hooks) */
 

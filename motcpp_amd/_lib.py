@@ -112,6 +112,20 @@ class Context:
                                               _p(i) if i is not None else None, C.c_float(gate), _p(x), _p(y), C.byref(info)))
         return x[:n], y[:m], info.value
 
+    def lap_geom(self, a, b, thresh, cost_mode=COST_IOU_DIST, conf=None, lap_mode=LAP_PLAIN, gate=0.0):
+        """Assignment straight from boxes (on-the-fly IoU-family cost inside the solver; no matrix in memory)."""
+        a, b = f32(a).reshape(-1, 4), f32(b).reshape(-1, 4)
+        n, m = a.shape[0], b.shape[0]
+        x, y = np.full(max(n, 1), -1, np.int32), np.full(max(m, 1), -1, np.int32)
+        xv = np.zeros(max(n, 1), np.float32)
+        info = C.c_int(0)
+        self._prof = np.zeros(8, np.int64)
+        c = f32(conf) if conf is not None else None
+        self._chk(self.lib.mot_lap_geom_host(self.h, _p(a), n, _p(b), m, _p(c) if c is not None else None, int(cost_mode),
+                                             C.c_float(thresh), int(lap_mode), C.c_float(gate), _p(x), _p(y), _p(xv), C.byref(info),
+                                             _p(self._prof)))
+        return x[:n], y[:m], xv[:n], info.value
+
     def kf_apply(self, kind, op, mean, cov, meas=None, q=None, flags=None, want_boxes=False):
         """op: 0 initiate, 1 predict, 2 update. mean [n,d], cov [n,d,d]; returns (mean, cov[, boxes])."""
         d = 7 if kind == KF_XYSR else 8
@@ -164,6 +178,7 @@ def host():
         H.motcpp_profile.argtypes = [C.c_int, C.c_int]
         H.motcpp_profile_stats.argtypes = [C.c_int, C.c_void_p, C.c_int]
         H.motcpp_batch_counters.argtypes = [C.c_void_p, C.c_void_p]
+        H.motcpp_batch_host_ms.argtypes = [C.c_void_p, C.c_void_p]
         H.motcpp_batch_tracker.restype = C.c_void_p
         H.motcpp_batch_tracker.argtypes = [C.c_void_p, C.c_int]
         _host = H
@@ -275,7 +290,10 @@ class Batch:
     def counters(self):
         a = (C.c_long * 3)()
         host().motcpp_batch_counters(self.h, a)
-        return {"frames": a[0], "flushes": a[1], "launches": a[2]}
+        h = (C.c_double * 4)()
+        host().motcpp_batch_host_ms(self.h, h)
+        return {"frames": a[0], "flushes": a[1], "launches": a[2], "ms_begin": h[0], "ms_flush": h[1], "ms_advance": h[2],
+                "ms_sync_wait": h[3]}
 
     def step(self, dets, counts=None, embs=None, cap=None, resident_ptr=None):
         """dets [S, N, 6] (counts[s] valid rows each); returns (out [S, cap, 8], out_counts [S]).

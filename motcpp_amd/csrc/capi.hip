@@ -18,8 +18,8 @@ hipError_t launch_iou(const mot_iou_task*, int, int, int, hipStream_t);
 hipError_t launch_ocsort(const mot_ocsort_task*, int, int, int, hipStream_t);
 hipError_t launch_feat(const mot_feat_task*, int, int, hipStream_t);
 hipError_t launch_cosine(const mot_cos_task*, int, int, int, hipStream_t);
-hipError_t launch_lap(const mot_lap_task*, int, int, hipStream_t);
-int lap_lds_limit();
+hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, hipStream_t);
+size_t lap_scratch_bytes(int n, int m);
 }  // namespace mot
 
 struct mot_ctx {
@@ -128,9 +128,8 @@ int mot_iou_cost(mot_ctx* c, const mot_iou_task* t, int nt, int max_n, int max_m
 int mot_ocsort_cost(mot_ctx* c, const mot_ocsort_task* t, int nt, int max_nd, int max_nt) { MOT_HIP(c, mot::launch_ocsort(t, nt, max_nd, max_nt, c->stream)); return MOT_OK; }
 int mot_cosine_cost(mot_ctx* c, const mot_cos_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_cosine(t, nt, max_n, max_m, c->stream)); return MOT_OK; }
 int mot_feat_update(mot_ctx* c, const mot_feat_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_feat(t, nt, max_n, c->stream)); return MOT_OK; }
-size_t mot_lap_work_bytes(int n, int m) { return (mot::lap_work_bytes(n + m) + 255) & ~size_t(255); }
-int mot_lap_lds_limit(void) { return mot::lap_lds_limit(); }
-int mot_lap_solve(mot_ctx* c, const mot_lap_task* t, int nt, int max_nm) { MOT_HIP(c, mot::launch_lap(t, nt, max_nm, c->stream)); return MOT_OK; }
+size_t mot_lap_work_bytes(int n, int m) { return (mot::lap_scratch_bytes(n, m) + 255) & ~size_t(255); }
+int mot_lap_solve(mot_ctx* c, const mot_lap_task* t, int nt, int max_n, int max_m, int flags) { MOT_HIP(c, mot::launch_lap(t, nt, max_n, max_m, (flags & MOT_LAP_F_GEOM) != 0, c->stream)); return MOT_OK; }
 
 // ---- host-pointer conveniences ------------------------------------------------------------------
 static void to_soa4(const float* aos, int n, int cols, int stride, std::vector<float>& soa) {
@@ -227,12 +226,54 @@ int mot_lap_solve_host(mot_ctx* c, const float* cost, int n, int m, float thresh
   t.mode = mode; t.iou = iou ? di.as<float>() : nullptr; t.ldi = m; t.gate = gate; t.info = dinfo.as<int>();
   t.work = dwork.p;
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
-  MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n + m, c->stream));
+  MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n, m, false, c->stream));
   MOT_HIP(c, hipMemcpyAsync(x, dx.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(y, dy.p, m * 4, hipMemcpyDeviceToHost, c->stream));
   int inf = 0;
   MOT_HIP(c, hipMemcpyAsync(&inf, dinfo.p, 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
+  if (info) *info = inf;
+  return MOT_OK;
+}
+
+int mot_lap_geom_host(mot_ctx* c, const float* a, int n, const float* b, int m, const float* bconf, int cost_mode, float thresh,
+                      int lap_mode, float gate, int* x, int* y, float* xval, int* info, long long* prof8) {
+  if (n <= 0 || m <= 0) {
+    for (int i = 0; i < n; ++i) { x[i] = -1; if (xval) xval[i] = 0.f; }
+    for (int j = 0; j < m; ++j) y[j] = -1;
+    if (info) *info = 2;
+    return MOT_OK;
+  }
+  std::vector<float> sa, sb;
+  to_soa4(a, n, 4, 4, sa);
+  to_soa4(b, m, 4, 4, sb);
+  DBuf da, db, dc, dx, dy, dv, dinfo, dwork, dt;
+  MOT_HIP(c, da.alloc(sa.size() * 4)); MOT_HIP(c, db.alloc(sb.size() * 4)); MOT_HIP(c, dc.alloc(m * 4));
+  MOT_HIP(c, dx.alloc(n * 4)); MOT_HIP(c, dy.alloc(m * 4)); MOT_HIP(c, dv.alloc(n * 4)); MOT_HIP(c, dinfo.alloc(16));
+  MOT_HIP(c, dwork.alloc(mot_lap_work_bytes(n, m))); MOT_HIP(c, dt.alloc(sizeof(mot_lap_task)));
+  MOT_HIP(c, hipMemcpyAsync(da.p, sa.data(), sa.size() * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(db.p, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, c->stream));
+  if (bconf) MOT_HIP(c, hipMemcpyAsync(dc.p, bconf, m * 4, hipMemcpyHostToDevice, c->stream));
+  mot_lap_task t{};
+  t.n = n; t.m = m; t.thresh = thresh; t.x = dx.as<int>(); t.y = dy.as<int>(); t.mode = lap_mode; t.gate = gate;
+  t.xval = dv.as<float>(); t.info = dinfo.as<int>(); t.work = dwork.p;
+  DBuf dprof;
+  MOT_HIP(c, dprof.alloc(64));
+  MOT_HIP(c, hipMemsetAsync(dprof.p, 0, 64, c->stream));
+  t.prof = prof8 ? dprof.as<long long>() : nullptr;
+  t.geom.n = n; t.geom.m = m; t.geom.a = da.as<float>(); t.geom.lda = n; t.geom.b = db.as<float>(); t.geom.ldb = m;
+  t.geom.bconf = bconf ? dc.as<float>() : nullptr; t.geom.mode = cost_mode;
+  MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n, m, true, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(x, dx.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(y, dy.p, m * 4, hipMemcpyDeviceToHost, c->stream));
+  std::vector<float> hv(n);
+  int inf = 0;
+  MOT_HIP(c, hipMemcpyAsync(hv.data(), dv.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(&inf, dinfo.p, 4, hipMemcpyDeviceToHost, c->stream));
+  if (prof8) MOT_HIP(c, hipMemcpyAsync(prof8, dprof.p, 64, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  if (xval) for (int i = 0; i < n; ++i) xval[i] = hv[i];
   if (info) *info = inf;
   return MOT_OK;
 }

@@ -14,26 +14,16 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/motcpp_amd.h"
+#include "cost_math.hpp"
 
 namespace {
 
 constexpr int kTile = 64;
 constexpr int kThreads = 256;
 
-__device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a; }  // std::max(a,b)
-__device__ __forceinline__ float smin(float a, float b) { return (b < a) ? b : a; }  // std::min(a,b)
-
-__device__ __forceinline__ float iou_pair(const float a[4], float area_a, const float b[4], float area_b) {
-  const float xx1 = smax(a[0], b[0]);
-  const float yy1 = smax(a[1], b[1]);
-  const float xx2 = smin(a[2], b[2]);
-  const float yy2 = smin(a[3], b[3]);
-  const float w = smax(0.0f, xx2 - xx1);
-  const float h = smax(0.0f, yy2 - yy1);
-  const float inter = w * h;
-  const float uni = area_a + area_b - inter;
-  return (uni > 0.0f) ? (inter / uni) : 0.0f;
-}
+using mot::iou_pair;
+using mot::smax;
+using mot::smin;
 
 struct BoxTile {
   float c[4][kTile];
@@ -74,7 +64,7 @@ __global__ void __launch_bounds__(kThreads) iou_kernel(const mot_iou_task* __res
   }
   __syncthreads();
   const int tx = tid & 15, ty = tid >> 4;
-  const int mode = T.mode;
+  const mot::CostParams cp{T.mode, T.prox_thresh, T.app_thresh, T.fuse, T.emb != nullptr, T.emb == nullptr && T.lde < 0};
   float bb[4][4], barea[4], bc[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -94,29 +84,10 @@ __global__ void __launch_bounds__(kThreads) iou_kernel(const mot_iou_task* __res
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float iou = iou_pair(aa, aarea, bb[q], barea[q]);
-      float v;
-      if (mode == MOT_COST_IOU) v = iou;
-      else if (mode == MOT_COST_NEG_IOU) v = -iou;
-      else {
-        float d = 1.0f - iou;  // iou_distance
-        if (mode == MOT_COST_IOU_DIST_FUSE) {  // fuse_score: 1 - (1 - d) * conf
-          const float sim = 1.0f - d;
-          d = 1.0f - sim * bc[q];
-        } else if (mode == MOT_COST_BOTSORT) {
-          const bool far = d > T.prox_thresh;  // mask from the un-fused distance (botsort.cpp:439)
-          if (T.fuse) { const float sim = 1.0f - d; d = 1.0f - sim * bc[q]; }
-          if (T.emb || T.lde < 0) {  // lde < 0: no features anywhere -> cosine distance is the constant 1 (matching.cpp:79-92, D = 0)
-            const int c = tx * 4 + q;
-            float e = 1.0f;
-            if (T.emb) e = (c < ncol) ? T.emb[static_cast<size_t>(row0 + r) * T.lde + col0 + c] : 0.f;
-            e = e / 2.0f;
-            if (e > T.app_thresh) e = 1.0f;
-            if (far) e = 1.0f;
-            d = smin(d, e);
-          }
-        }
-        v = d;
-      }
+      const int cq = tx * 4 + q;
+      const float v = mot::cost_from_iou(cp, iou, bc[q], [&]() {
+        return (cq < ncol) ? T.emb[static_cast<size_t>(row0 + r) * T.lde + col0 + cq] : 0.f;
+      });
       out[q] = v;
     }
     const int gr = row0 + r;

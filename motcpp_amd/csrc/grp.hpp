@@ -52,11 +52,47 @@ struct DevGroup {
   __device__ __forceinline__ int size() const { return size_; }
   __device__ __forceinline__ void sync() { __syncthreads(); }
 
-  static __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl_xor(lo, m, 64);
-    hi = __shfl_xor(hi, m, 64);
+  // ---- wavefront reductions on DPP (row_shr 1,2,4,8 then row_bcast 15/31): VALU-only, no LDS crossbar round trips.
+  // After the sequence lane 63 holds the reduction of all 64 lanes; v_readlane broadcasts it.
+  template <int CTRL, int ROW_MASK = 0xf>
+  static __device__ __forceinline__ int dpp(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);  // lanes without a source keep their own value
+  }
+  template <int CTRL, int ROW_MASK = 0xf>
+  static __device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = dpp<CTRL, ROW_MASK>(__double2loint(v)), hi = dpp<CTRL, ROW_MASK>(__double2hiint(v));
     return __hiloint2double(hi, lo);
+  }
+  static __device__ __forceinline__ double bcast63_f64(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+  }
+#define MOT_DPP_STEPS(OP)            \
+  OP(0x111, 0xf) /* row_shr:1 */     \
+  OP(0x112, 0xf) /* row_shr:2 */     \
+  OP(0x114, 0xf) /* row_shr:4 */     \
+  OP(0x118, 0xf) /* row_shr:8 */     \
+  OP(0x142, 0xa) /* row_bcast:15 */  \
+  OP(0x143, 0xc) /* row_bcast:31 */
+  static __device__ __forceinline__ double wave_min_f64(double v) {
+#define MOT_STEP(C, M) { const double o = dpp_f64<C, M>(v); v = (o < v) ? o : v; }
+    MOT_DPP_STEPS(MOT_STEP)
+#undef MOT_STEP
+    return bcast63_f64(v);
+  }
+  static __device__ __forceinline__ int wave_max_i32(int v) {
+#define MOT_STEP(C, M) { const int o = dpp<C, M>(v); v = (o > v) ? o : v; }
+    MOT_DPP_STEPS(MOT_STEP)
+#undef MOT_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+  }
+  // lexicographic (value, index) minimum
+  static __device__ __forceinline__ void wave_lexmin(double& v, int& j) {
+#define MOT_STEP(C, M) { const double ov = dpp_f64<C, M>(v); const int oj = dpp<C, M>(j); if (lex_less(ov, oj, v, j)) { v = ov; j = oj; } }
+    MOT_DPP_STEPS(MOT_STEP)
+#undef MOT_STEP
+    v = bcast63_f64(v);
+    j = __builtin_amdgcn_readlane(j, 63);
   }
   template <class T>
   __device__ __forceinline__ T* slot() {
@@ -65,8 +101,7 @@ struct DevGroup {
     return p;
   }
   __device__ __forceinline__ double reduce_min(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { double o = shfl_xor_f64(v, m); v = (o < v) ? o : v; }
+    v = wave_min_f64(v);
     const int nw = (size_ + 63) >> 6;
     if (nw == 1) return v;
     double* s = slot<double>();
@@ -77,8 +112,7 @@ struct DevGroup {
     return r;
   }
   __device__ __forceinline__ int reduce_max(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m, 64); v = (o > v) ? o : v; }
+    v = wave_max_i32(v);
     const int nw = (size_ + 63) >> 6;
     if (nw == 1) return v;
     int* s = slot<int>();
@@ -89,14 +123,15 @@ struct DevGroup {
     return r;
   }
   __device__ __forceinline__ int reduce_min_int(int v) { return -reduce_max(-v); }
+  // two lexicographically smallest (value,index) pairs of the group: wave-level in two DPP passes (the winner,
+  // then the best of everything else), wavefront partials merged through LDS
   __device__ __forceinline__ Top2 reduce_top2(Top2 t) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      Top2 o;
-      o.v1 = shfl_xor_f64(t.v1, m); o.v2 = shfl_xor_f64(t.v2, m);
-      o.j1 = __shfl_xor(t.j1, m, 64); o.j2 = __shfl_xor(t.j2, m, 64);
-      t = top2_merge(t, o);
-    }
+    double v1 = t.v1; int j1 = t.j1;
+    wave_lexmin(v1, j1);
+    double v2 = (t.j1 == j1) ? t.v2 : t.v1;
+    int j2 = (t.j1 == j1) ? t.j2 : t.j1;
+    wave_lexmin(v2, j2);
+    t.v1 = v1; t.j1 = j1; t.v2 = v2; t.j2 = j2;
     const int nw = (size_ + 63) >> 6;
     if (nw == 1) return t;
     Top2* s = slot<Top2>();

@@ -145,9 +145,7 @@ class BotSortGpu final : public Staged {
     a.a = boxes; a.lda = ld; a.aidx = aidx; a.n = n;
     a.b = dets_.d_box; a.ldb = dets_.n; a.bidx = didx.d; a.m = m; a.bconf = dets_.d_conf();
     a.mode = MOT_COST_BOTSORT; a.emb = emb; a.lde = lde; a.prox = prox_; a.app = app_; a.fuse = fuse;
-    int ldc;
-    float* cost = core_.iou_cost(a, &ldc);
-    return core_.lap(cost, ldc, n, m, thresh);
+    return core_.lap_geom(a, thresh);
   }
 
   void apply_match(Trk& t, int det, bool first_stage_det) {  // BotSTrack::update :133-156 / re_activate :111-131
@@ -191,9 +189,7 @@ class BotSortGpu final : public Staged {
       a.a = pool_box_; a.lda = np; a.aidx = r_tracked_d_.d; a.n = static_cast<int>(r_tracked_.size());
       a.b = dets_.d_box; a.ldb = dets_.n; a.bidx = second_d_.d; a.m = static_cast<int>(second_.size());
       a.mode = MOT_COST_IOU_DIST;
-      int ldc;
-      float* cost = core_.iou_cost(a, &ldc);
-      lap2_ = core_.lap(cost, ldc, a.n, a.m, 0.5f);
+      lap2_ = core_.lap_geom(a, 0.5f);
     }
     // unconfirmed :565-647
     if (!unconf_.empty() && !u_det_.empty()) {

@@ -91,9 +91,7 @@ class ByteTrackGpu final : public Staged {
         a.a = pool_box_; a.lda = np; a.n = np;
         a.b = dets_.d_box; a.ldb = dets_.n; a.bidx = high_d_.d; a.m = static_cast<int>(high_.size());
         a.bconf = dets_.d_conf(); a.mode = MOT_COST_IOU_DIST_FUSE;
-        int ldc;
-        float* cost = core_.iou_cost(a, &ldc);
-        lap1_ = core_.lap(cost, ldc, a.n, a.m, match_thresh_);
+        lap1_ = core_.lap_geom(a, match_thresh_);
       }
     }
   }
@@ -157,9 +155,7 @@ class ByteTrackGpu final : public Staged {
       a.a = rb; a.lda = static_cast<int>(slots.size()); a.n = a.lda;
       a.b = dets_.d_box; a.ldb = dets_.n; a.bidx = second_d_.d; a.m = static_cast<int>(second_.size());
       a.mode = MOT_COST_IOU_DIST;
-      int ldc;
-      float* cost = core_.iou_cost(a, &ldc);
-      lap2_ = core_.lap(cost, ldc, a.n, a.m, 0.5f);
+      lap2_ = core_.lap_geom(a, 0.5f);
       queued_ = true;
     }
     // unconfirmed tracks (stored, un-predicted state) vs. leftover high detections (:455-542)
@@ -173,9 +169,7 @@ class ByteTrackGpu final : public Staged {
       a.a = ub; a.lda = static_cast<int>(slots.size()); a.n = a.lda;
       a.b = dets_.d_box; a.ldb = dets_.n; a.bidx = rem_d_.d; a.m = static_cast<int>(rem.size());
       a.bconf = dets_.d_conf(); a.mode = MOT_COST_IOU_DIST_FUSE;
-      int ldc;
-      float* cost = core_.iou_cost(a, &ldc);
-      lap3_ = core_.lap(cost, ldc, a.n, a.m, 0.7f);
+      lap3_ = core_.lap_geom(a, 0.7f);
       queued_ = true;
     }
   }

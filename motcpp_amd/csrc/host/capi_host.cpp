@@ -144,6 +144,11 @@ int motcpp_batch_counters(motcpp_batch* b, long* out3) {
   out3[0] = b->frames; out3[1] = b->dev->counters.flushes; out3[2] = b->dev->counters.launches;
   return 0;
 }
+int motcpp_batch_host_ms(motcpp_batch* b, double* out4) {
+  out4[0] = b->dev->counters.ms_begin; out4[1] = b->dev->counters.ms_flush; out4[2] = b->dev->counters.ms_advance;
+  out4[3] = b->dev->counters.ms_sync_wait;
+  return 0;
+}
 static int batch_step_impl(motcpp_batch* b, const float* dets, const int* counts, int max_n, const float* d_dets,
                            const float* embs, int d, float* out, int* out_counts, int cap) {
   try {

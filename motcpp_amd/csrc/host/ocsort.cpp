@@ -233,9 +233,7 @@ class OCSortGpu final : public Staged {
     a.a = dets_.d_box; a.lda = dets_.n; a.aidx = second_d_.d; a.n = static_cast<int>(second_.size());
     a.b = pbox_d_; a.ldb = nt0_; a.bidx = um_trks_d_.d; a.m = static_cast<int>(um_trks_.size());
     a.mode = MOT_COST_NEG_IOU;
-    int ldc;
-    float* cost = core_.iou_cost(a, &ldc);
-    byte_ = core_.lap(cost, ldc, a.n, a.m, -thr_, MOT_LAP_GATE_MIN, nullptr, 0, -thr_, true);
+    byte_ = core_.lap_geom(a, -thr_, MOT_LAP_GATE_MIN, -thr_, true);
   }
   void after_byte() {
     if (byte_.info.h[0] == 2) return;
@@ -266,9 +264,7 @@ class OCSortGpu final : public Staged {
     a.a = dets_.d_box; a.lda = dets_.n; a.aidx = left_d_.d; a.n = static_cast<int>(didx.size());
     a.b = dlt.d; a.ldb = nl; a.m = nl;
     a.mode = MOT_COST_NEG_IOU;
-    int ldc;
-    float* cost = core_.iou_cost(a, &ldc);
-    rematch_ = core_.lap(cost, ldc, a.n, a.m, -thr_, MOT_LAP_GATE_MIN, nullptr, 0, -thr_, true);
+    rematch_ = core_.lap_geom(a, -thr_, MOT_LAP_GATE_MIN, -thr_, true);
   }
   void after_rematch() {
     if (rematch_.info.h[0] == 2) return;

@@ -1,6 +1,7 @@
 #include "runtime.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 
 namespace motcpp::rt {
@@ -222,11 +223,16 @@ void Device::flush() {
   }
   {
     double b = 0;
-    for (const mot_lap_task& t : lap) b += 4.0 * t.n * (double)t.m * (t.iou ? 2.0 : 1.0) + 4.0 * (t.n + t.m);
-    run(F_LAP, lap.size(), b, 0, [&] { check(mot_lap_solve(ctx, d_lap, (int)lap.size(), maxn(lap, [](const mot_lap_task& t) { return t.n + t.m; })), "mot_lap_solve"); });
+    for (const mot_lap_task& t : lap)
+      b += (t.geom.a ? 20.0 * (t.n + t.m) : 4.0 * t.n * (double)t.m) + (t.iou ? 4.0 * t.n * (double)t.m : 0.0) + 4.0 * (t.n + t.m);
+    run(F_LAP, lap.size(), b, 0, [&] { check(mot_lap_solve(ctx, d_lap, (int)lap.size(), maxn(lap, [](const mot_lap_task& t) { return t.n; }), maxn(lap, [](const mot_lap_task& t) { return t.m; }), lap_geom ? MOT_LAP_F_GEOM : 0), "mot_lap_solve"); });
   }
   down->download();
-  check(mot_ctx_sync(ctx), "mot_ctx_sync");
+  {
+    const auto w0 = std::chrono::steady_clock::now();
+    check(mot_ctx_sync(ctx), "mot_ctx_sync");
+    counters.ms_sync_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+  }
   for (const Timed& t : timed_) {
     float ms = 0.f;
     check(mot_event_elapsed(ctx, t.e0, t.e1, &ms), "mot_event_elapsed");
@@ -237,7 +243,7 @@ void Device::flush() {
   timed_.clear();
   ++counters.flushes;
   for (int k = 0; k < 3; ++k) { det[k].clear(); kf_init[k].clear(); kf_upd[k].clear(); kf_pred[k].clear(); kf_box[k].clear(); }
-  feat_set.clear(); feat_ema.clear(); cos.clear(); iou.clear(); oc.clear(); lap.clear();
+  feat_set.clear(); feat_ema.clear(); cos.clear(); iou.clear(); oc.clear(); lap.clear(); lap_geom = false;
 }
 
 // ---- Core ----------------------------------------------------------------------------------
@@ -390,8 +396,29 @@ Core::Lap Core::lap(const float* cost, int ldc, int n, int m, float thresh, int 
   mot_lap_task t{};
   t.n = n; t.m = m; t.cost = cost; t.ldc = ldc; t.thresh = thresh; t.x = r.x.d; t.y = r.y.d; t.mode = mode; t.iou = iou; t.ldi = ldi; t.gate = gate;
   t.xval = want_xval ? r.xval.d : nullptr; t.info = r.info.d;
-  t.work = (n + m > mot_lap_lds_limit()) ? dev_->tmp->alloc<char>(mot_lap_work_bytes(n, m)).d : nullptr;
+  t.work = dev_->tmp->alloc<char>(mot_lap_work_bytes(n, m)).d;
   dev_->lap.push_back(t);
+  r.queued = true;
+  return r;
+}
+
+Core::Lap Core::lap_geom(const IouArgs& a, float thresh, int mode, float gate, bool want_xval) {
+  Lap r;
+  r.n = a.n; r.m = a.m;
+  std::lock_guard<std::mutex> g(dev_->mu);
+  r.x = dev_->down->alloc<int32_t>(std::max(a.n, 1));
+  r.y = dev_->down->alloc<int32_t>(std::max(a.m, 1));
+  r.info = dev_->down->alloc<int32_t>(4);
+  if (want_xval) r.xval = dev_->down->alloc<float>(std::max(a.n, 1));
+  mot_lap_task t{};
+  t.n = a.n; t.m = a.m; t.thresh = thresh; t.x = r.x.d; t.y = r.y.d; t.mode = mode; t.gate = gate;
+  t.xval = want_xval ? r.xval.d : nullptr; t.info = r.info.d;
+  t.work = dev_->tmp->alloc<char>(mot_lap_work_bytes(a.n, a.m)).d;
+  t.geom.n = a.n; t.geom.m = a.m; t.geom.a = a.a; t.geom.lda = a.lda; t.geom.aidx = a.aidx; t.geom.b = a.b; t.geom.ldb = a.ldb;
+  t.geom.bidx = a.bidx; t.geom.bconf = a.bconf; t.geom.mode = a.mode; t.geom.emb = a.emb; t.geom.lde = a.lde;
+  t.geom.prox_thresh = a.prox; t.geom.app_thresh = a.app; t.geom.fuse = a.fuse;
+  dev_->lap.push_back(t);
+  dev_->lap_geom = true;
   r.queued = true;
   return r;
 }

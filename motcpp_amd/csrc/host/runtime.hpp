@@ -61,6 +61,7 @@ class Arena {
 
 struct StageCounters {
   long flushes = 0, launches = 0;
+  double ms_begin = 0, ms_flush = 0, ms_advance = 0, ms_sync_wait = 0;  // host wall time by phase (run_frame)
 };
 
 // Kernel families timed with HIP events when Device::profile is on (bench.py's roofline leg).
@@ -92,6 +93,7 @@ class Device {
   std::vector<mot_iou_task> iou;
   std::vector<mot_ocsort_task> oc;
   std::vector<mot_lap_task> lap;
+  bool lap_geom = false;  // some queued LAP task carries on-the-fly geometry
 
   void begin_frame();
   bool pending() const;
@@ -165,6 +167,9 @@ class Core {
   float* iou_cost(const IouArgs& a, int* ldc);  // returns device cost matrix (tmp arena)
   Lap lap(const float* cost, int ldc, int n, int m, float thresh, int mode = MOT_LAP_PLAIN, const float* iou = nullptr,
           int ldi = 0, float gate = 0.f, bool want_xval = false);
+
+  // assignment straight from boxes: the solver recomputes the IoU-family cost on the fly (no N x M matrix in memory)
+  Lap lap_geom(const IouArgs& a, float thresh, int mode = MOT_LAP_PLAIN, float gate = 0.f, bool want_xval = false);
 
   float* d_mean() const { return mean_; }
   float* d_cov() const { return cov_; }

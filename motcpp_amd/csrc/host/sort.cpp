@@ -90,9 +90,7 @@ class SortGpu final : public Staged {
     a.a = boxes; a.lda = ld; a.aidx = aidx; a.n = n;
     a.b = dets_.d_box; a.ldb = dets_.n; a.bidx = valid_d_.d; a.m = static_cast<int>(valid_.size());
     a.mode = MOT_COST_IOU_DIST;
-    int ldc;
-    float* cost = core_.iou_cost(a, &ldc);
-    lap_ = core_.lap(cost, ldc, a.n, a.m, 1.0f - iou_thr_);
+    lap_ = core_.lap_geom(a, 1.0f - iou_thr_);
   }
   void apply() {
     const int nt = static_cast<int>(trk_.size()), nd = static_cast<int>(valid_.size());

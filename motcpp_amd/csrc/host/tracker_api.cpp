@@ -1,5 +1,6 @@
 // BaseTracker / DeviceTracker / StreamBatch and the four public tracker classes (constructor signatures of
 // the reference's include/motcpp/trackers/*.hpp), plus the frame driver that steps stage machines in lockstep.
+#include <chrono>
 #include <stdexcept>
 
 #include "motcpp/motcpp.hpp"
@@ -44,9 +45,12 @@ void BaseTracker::setup_detection_format(const Eigen::MatrixXf& dets) {
 
 namespace rt {
 void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, int threads) {
+  using clk = std::chrono::steady_clock;
+  auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   dev.begin_frame();
   std::vector<char> done(count, 0);
   std::string err;
+  auto t0 = clk::now();
   const bool par = threads > 1 && count > 1;
   // Host lifecycle of different streams is independent: step the stage machines from several host threads
   // (arena allocation and task-list appends are serialised by Device::mu; kernels are launched once per stage).
@@ -59,8 +63,12 @@ void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int 
     }
   }
   if (!err.empty()) throw Error(err);
+  dev.counters.ms_begin += ms(t0, clk::now());
   while (true) {
+    auto t1 = clk::now();
     if (dev.pending()) dev.flush();
+    auto t2 = clk::now();
+    dev.counters.ms_flush += ms(t1, t2);
     int any = 0;
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 4) reduction(| : any) if (par)
     for (int i = 0; i < count; ++i) {
@@ -74,6 +82,7 @@ void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int 
         err = e.what();
       }
     }
+    dev.counters.ms_advance += ms(t2, clk::now());
     if (!err.empty()) throw Error(err);
     if (!any) break;
   }

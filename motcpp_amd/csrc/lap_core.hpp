@@ -18,58 +18,98 @@
 #pragma once
 #include "grp.hpp"
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MOT_CLOCK() static_cast<long long>(__builtin_readcyclecounter())
+#else
+#define MOT_CLOCK() 0LL
+#endif
+
 namespace mot {
 
-struct LapProblem {
+// Cost functors. A functor exposes the real nr x nc block of the problem:
+//   Row row(i)        row-invariant context (pointer to the matrix row, or the row's box in registers)
+//   Row::at(j)        element (i, j) as double
+//   at(i, j)          same, without a row context (column scans)
+// MatrixCost reads a materialised float matrix; IouCost (lap_cost.hpp) recomputes IoU-family costs from boxes
+// staged in LDS, so the N x M matrix never exists in memory.
+struct MatrixCost {
   const float* cost;  // nr x nc, row-major, leading dimension ld
-  int ld, nr, nc;
-  double half;        // thresh / 2 (lap_solver.hpp:300)
+  int ld;
+  struct Row {
+    const float* p;
+    MOT_DEV double at(int j) const { return static_cast<double>(p[j]); }
+  };
+  MOT_DEV Row row(int i) const { return Row{cost + static_cast<size_t>(i) * ld}; }
+  MOT_DEV double at(int i, int j) const { return static_cast<double>(cost[static_cast<size_t>(i) * ld + j]); }
 };
-// Workspace, each array n = nr + nc long. May live in LDS or in global memory.
+struct LapDims {
+  int nr, nc;
+  double half;  // thresh / 2 (lap_solver.hpp:300)
+};
+// Workspace, each array n = nr + nc long. The HOT arrays are touched by every row pass and live in LDS when
+// the problem fits; the COLD arrays are only used by the general shortest-path search (rare on tracking costs)
+// and the phase-1 row list, and always live in global scratch.
 struct LapWork {
+  // hot
   double* v;   // column duals
-  double* d;   // shortest-path distances
   int* x;      // row -> col (extended)
   int* y;      // col -> row (extended)
-  int* fr;     // free-row list
-  int* pred;   // path predecessors / column-hit counters in phase 1
-  int* cols;   // lapjv's column permutation / scratch list
+  int* fr;     // free-row list (doubles as the column-hit counter in phase 1)
+  // cold
+  double* d;   // shortest-path distances
+  int* pred;   // path predecessors
+  int* cols;   // lapjv's column permutation / phase-1 unique-row list
   int* tmp;    // tie flags (slow path)
   int* lst;    // compacted tie positions (slow path)
+  long long* cyc = nullptr;  // optional profiling: [0..3] cycles in phase 1a (column minima), 1b (transfer), 2, 3; [4..7] pass counts
 };
-MOT_HD size_t lap_work_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 7 * sizeof(int)); }
-MOT_HD LapWork lap_carve(void* base, int n) {
-  LapWork w;
+MOT_HD size_t lap_hot_bytes(int n) { return static_cast<size_t>(n) * (sizeof(double) + 3 * sizeof(int)); }
+MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (sizeof(double) + 4 * sizeof(int)); }
+MOT_HD size_t lap_work_bytes(int n) { return lap_hot_bytes(n) + lap_cold_bytes(n); }
+MOT_HD void lap_carve_hot(LapWork& w, void* base, int n) {
   char* p = static_cast<char*>(base);
   w.v = reinterpret_cast<double*>(p); p += sizeof(double) * n;
-  w.d = reinterpret_cast<double*>(p); p += sizeof(double) * n;
   w.x = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.y = reinterpret_cast<int*>(p); p += sizeof(int) * n;
-  w.fr = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.fr = reinterpret_cast<int*>(p);
+}
+MOT_HD void lap_carve_cold(LapWork& w, void* base, int n) {
+  char* p = static_cast<char*>(base);
+  w.d = reinterpret_cast<double*>(p); p += sizeof(double) * n;
   w.pred = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.cols = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.tmp = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.lst = reinterpret_cast<int*>(p);
+}
+MOT_HD LapWork lap_carve(void* base, int n) {  // hot then cold, contiguous
+  LapWork w;
+  lap_carve_hot(w, base, n);
+  lap_carve_cold(w, static_cast<char*>(base) + ((lap_hot_bytes(n) + 7) & ~size_t(7)), n);
   return w;
 }
 
 // Row view of the extended matrix (lap_solver.hpp:303-315): real rows are [cost | half...],
 // dummy rows are [half... | 0...].
+template <class Cost>
 struct ExtRow {
-  const float* p;
-  double left, right;  // constants used when p == nullptr (left: j < nc) / for j >= nc
+  typename Cost::Row r;
+  bool real;
+  double left, right;  // dummy row: value for j < nc; any row: value for j >= nc
   int nc;
   MOT_DEV double at(int j) const {
-    if (j < nc) return p ? static_cast<double>(p[j]) : left;
+    if (j < nc) return real ? r.at(j) : left;
     return right;
   }
 };
-MOT_DEV ExtRow ext_row(const LapProblem& P, int i) {
-  ExtRow r;
-  r.nc = P.nc;
-  if (i < P.nr) { r.p = P.cost + static_cast<size_t>(i) * P.ld; r.left = 0.0; r.right = P.half; }
-  else { r.p = nullptr; r.left = P.half; r.right = 0.0; }
-  return r;
+template <class Cost>
+MOT_DEV ExtRow<Cost> ext_row(const Cost& C, const LapDims& P, int i) {
+  ExtRow<Cost> e;
+  e.nc = P.nc;
+  e.real = i < P.nr;
+  e.r = C.row(e.real ? i : 0);
+  if (e.real) { e.left = 0.0; e.right = P.half; }
+  else { e.left = P.half; e.right = 0.0; }
+  return e;
 }
 
 // Compacts {i in [0,n) : flag(i)} in ascending order into out[]; returns the count (uniform).
@@ -90,22 +130,23 @@ MOT_DEV int compact_ascending(G& g, int n, F flag, int* out) {
 
 // Solves one problem. On return W.x[0..nr) / W.y[0..nc) hold extended assignments; callers map
 // x >= nc / y >= nr to -1 (lap_solver.hpp:326-331). All threads of the group must call this.
-template <class G>
-MOT_DEV void lap_solve(G& g, const LapProblem& P, const LapWork& W) {
+template <class G, class Cost>
+MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) {
   const int T = g.size(), t = g.tid();
   const int nr = P.nr, nc = P.nc, n = nr + nc;
   const double half = P.half;
 
+  long long c0 = MOT_CLOCK();
+  long long n_carr = 0, n_paths = 0;
   // ---- phase 1: column reduction + reduction transfer (_ccrrt_dense, :36-72) ----
-  for (int i = t; i < n; i += T) { W.x[i] = -1; W.pred[i] = 0; }
+  for (int i = t; i < n; i += T) { W.x[i] = -1; W.fr[i] = 0; }
   g.sync();
   for (int j = t; j < n; j += T) {
     double vm = kLapLarge;
     int im = 0;
     if (j < nc) {
-      const float* cp = P.cost + j;
       for (int i = 0; i < nr; ++i) {
-        const double c = static_cast<double>(cp[static_cast<size_t>(i) * P.ld]);
+        const double c = C.at(i, j);
         if (c < vm) { vm = c; im = i; }
       }
       if (half < vm) { vm = half; im = nr; }  // rows nr.. are all `half`: only the first can win
@@ -116,19 +157,20 @@ MOT_DEV void lap_solve(G& g, const LapProblem& P, const LapWork& W) {
     W.v[j] = vm;
     W.y[j] = im;
     G::atomic_max(&W.x[im], j);   // x[i] = largest column whose minimum sits in row i (:47-55)
-    G::atomic_add(&W.pred[im], 1);
+    G::atomic_add(&W.fr[im], 1);
   }
   g.sync();
+  long long c1 = MOT_CLOCK();
   for (int j = t; j < n; j += T)
     if (W.x[W.y[j]] != j) W.y[j] = -1;
   g.sync();
   // rows that own exactly one column get their dual tightened, in ascending row order (:57-69)
-  const int n_uniq = compact_ascending(g, n, [&](int i) { return W.x[i] >= 0 && W.pred[i] == 1; }, W.cols);
+  const int n_uniq = compact_ascending(g, n, [&](int i) { return W.x[i] >= 0 && W.fr[i] == 1; }, W.cols);
   int nfree = compact_ascending(g, n, [&](int i) { return W.x[i] < 0; }, W.fr);
   for (int u = 0; u < n_uniq; ++u) {
     const int i = W.cols[u];
     const int j = W.x[i];
-    const ExtRow R = ext_row(P, i);
+    const ExtRow<Cost> R = ext_row(C, P, i);
     double mn = kLapLarge;
     for (int j2 = t; j2 < n; j2 += T) {
       if (j2 == j) continue;
@@ -140,6 +182,7 @@ MOT_DEV void lap_solve(G& g, const LapProblem& P, const LapWork& W) {
   }
   g.sync();
 
+  long long c2 = MOT_CLOCK();
   // ---- phase 2: augmenting row reduction, twice (_carr_dense, :74-113, :221-224) ----
   for (int pass = 0; pass < 2 && nfree > 0; ++pass) {
     unsigned current = 0, rr_cnt = 0;
@@ -147,12 +190,19 @@ MOT_DEV void lap_solve(G& g, const LapProblem& P, const LapWork& W) {
     int forwarded = -1;  // row re-queued by free_rows[--current] = i0, consumed next iteration
     while (current < static_cast<unsigned>(nfree)) {
       ++rr_cnt;
+      ++n_carr;
       const int fi = (forwarded >= 0) ? forwarded : W.fr[current];
       forwarded = -1;
       ++current;
-      const ExtRow R = ext_row(P, fi);
+      const ExtRow<Cost> R = ext_row(C, P, fi);
       Top2 tt = top2_empty();
-      for (int j = t; j < n; j += T) top2_push(tt, R.at(j) - W.v[j], j);
+      for (int j = t; j < n; j += T) {
+        const double c = R.at(j) - W.v[j];
+        if (c < tt.v2) {  // a lane visits its columns in ascending order: strict < keeps the lowest index on ties
+          if (c < tt.v1) { tt.v2 = tt.v1; tt.j2 = tt.j1; tt.v1 = c; tt.j1 = j; }
+          else { tt.v2 = c; tt.j2 = j; }
+        }
+      }
       tt = g.reduce_top2(tt);
       int j1 = tt.j1, j2 = tt.j2;
       double v1 = tt.v1, v2 = tt.v2;
@@ -182,10 +232,12 @@ MOT_DEV void lap_solve(G& g, const LapProblem& P, const LapWork& W) {
     nfree = new_free;
   }
 
+  long long c3 = MOT_CLOCK();
   // ---- phase 3: augmentation (_ca_dense, :195-211) ----
   for (int f = 0; f < nfree; ++f) {
     const int start = W.fr[f];
-    const ExtRow R0 = ext_row(P, start);
+    ++n_paths;
+    const ExtRow<Cost> R0 = ext_row(C, P, start);
     double mn = 1e300;
     for (int j = t; j < n; j += T) {
       const double dj = R0.at(j) - W.v[j];
@@ -239,7 +291,7 @@ MOT_DEV void lap_solve(G& g, const LapProblem& P, const LapWork& W) {
             const int jq = W.cols[slo++];
             const int i = W.y[jq];
             const double mind = W.d[jq];
-            const ExtRow R = ext_row(P, i);
+            const ExtRow<Cost> R = ext_row(C, P, i);
             const double h = R.at(jq) - W.v[jq] - mind;
             g.sync();
             int first_sink = kNoIdx;
@@ -306,6 +358,11 @@ MOT_DEV void lap_solve(G& g, const LapProblem& P, const LapWork& W) {
       // a barrier); x[] is only read again by lane 0 behind the general path's barriers.
       if ((final_j % T) == t) { W.y[final_j] = start; W.x[start] = final_j; }
     }
+  }
+  if (W.cyc && t == 0) {
+    const long long c4 = MOT_CLOCK();
+    W.cyc[0] = c1 - c0; W.cyc[1] = c2 - c1; W.cyc[2] = c3 - c2; W.cyc[3] = c4 - c3;
+    W.cyc[4] = n_uniq; W.cyc[5] = n_carr; W.cyc[6] = n_paths; W.cyc[7] = n;
   }
 }
 

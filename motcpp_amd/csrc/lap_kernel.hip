@@ -1,42 +1,40 @@
-// Linear-assignment kernel for gfx950: one 256-lane workgroup (4 wavefronts) per problem runs the
-// exact lapjv restatement of lap_core.hpp. All solver state (duals, assignments, free list, path
-// arrays: 44 bytes per extended row) lives in LDS when n+m <= mot_lap_lds_limit() — the cost matrix
-// is the only thing read from HBM/L2, rows by coalesced loads — otherwise in a caller-provided
-// global scratch. Throughput comes from many problems in flight (grid = problems: streams x stages),
-// not from one problem; a problem is latency/dependency-bound by construction (sequential rows).
+// Linear-assignment kernel for gfx950: the exact lapjv restatement of lap_core.hpp, ONE WAVEFRONT per problem
+// by default. Measured on MI355X a row pass of lapjv costs ~4.5k cycles of serial overhead when a problem is spread
+// over 4 wavefronts (cross-wavefront merges through LDS + two barriers + dependent scalar chains) almost regardless
+// of its size; with one wavefront per problem there are no barriers and no LDS merges (reductions are DPP-only),
+// and — because only the HOT solver state (duals, assignments, free list: 20 bytes per extended row) plus the
+// staged boxes sit in LDS — 4 to 8 problems are resident per CU, one or two per SIMD, hiding each other's
+// latencies. The COLD arrays of the general shortest-path search live in global scratch. Large problems with too
+// few instances to fill the chip anyway (n+m > 3072 and < 512 problems) use 4 wavefronts per problem instead.
+//
+// Two cost sources:
+//  * geometry (task.geom.a != NULL): IoU-family costs are recomputed on the fly from the row/column boxes staged
+//    once (lap_cost.hpp) — the N x M matrix is never written or read; a problem's HBM traffic is its boxes + results;
+//  * matrix (task.cost): a materialised float matrix, rows read by coalesced loads (OC-SORT's IoU+direction cost,
+//    or any caller-supplied cost).
+// Throughput comes from many problems in flight (grid = problems: streams x stages); one problem is
+// dependency-bound by construction (lapjv's sequential rows), so this kernel is reported against the HBM roofline
+// only because the brief asks for it — its real bound is issue latency of the serial row passes.
 #include <hip/hip_runtime.h>
 
 #include "../../include/motcpp_amd.h"
 #include "lap_core.hpp"
+#include "lap_cost.hpp"
 
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kScratch = 1024;
+constexpr int kScratch = 1024;  // DevGroup reduction scratch: 2 halves x 16 wavefronts x 32 bytes
 constexpr int kLdsBudget = 160 * 1024;
 
-template <bool kLds>
-__global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __restrict__ tasks) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const mot_lap_task T = tasks[blockIdx.x];
-  const int nr = T.n, nc = T.m, n = nr + nc;
-  const int t = threadIdx.x;
-  if (nr <= 0 || nc <= 0) {
-    for (int i = t; i < nr; i += kThreads) { T.x[i] = -1; if (T.xval) T.xval[i] = 0.f; }
-    for (int j = t; j < nc; j += kThreads) T.y[j] = -1;
-    if (T.info && t == 0) T.info[0] = 2;
-    return;
-  }
-  mot::DevGroup g(smem);
-  void* base = kLds ? static_cast<void*>(smem + kScratch) : T.work;
-  const mot::LapWork W = mot::lap_carve(base, n);
+template <int kThreads, class Cost>
+__device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, const mot_lap_task& T, const mot::LapWork& W) {
+  const int nr = T.n, nc = T.m, t = threadIdx.x;
   int path = 0;
-
   if (T.mode == MOT_LAP_GATE_MIN) {
     double mn = 1e300;
-    for (int e = t; e < nr * nc; e += kThreads) {
-      const double c = static_cast<double>(T.cost[static_cast<size_t>(e / nc) * T.ldc + (e % nc)]);
-      if (c < mn) mn = c;
+    for (int i = 0; i < nr; ++i) {
+      const typename Cost::Row R = C.row(i);
+      for (int j = t; j < nc; j += kThreads) { const double c = R.at(j); if (c < mn) mn = c; }
     }
     mn = g.reduce_min(mn);
     if (!(mn < static_cast<double>(T.gate))) path = 2;
@@ -63,10 +61,9 @@ __global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __res
     g.sync();
     if (max_row == 1 && max_col == 1) path = 1;
   }
-
   if (path == 0) {
-    mot::LapProblem P{T.cost, T.ldc, nr, nc, static_cast<double>(T.thresh) / 2.0};
-    mot::lap_solve(g, P, W);
+    const mot::LapDims P{nr, nc, static_cast<double>(T.thresh) / 2.0};
+    mot::lap_solve(g, C, P, W);
     g.sync();
     for (int i = t; i < nr; i += kThreads) { const int v = W.x[i]; W.x[i] = (v >= nc) ? -1 : v; }
     for (int j = t; j < nc; j += kThreads) { const int v = W.y[j]; W.y[j] = (v >= nr) ? -1 : v; }
@@ -80,34 +77,115 @@ __global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __res
     T.x[i] = xi;
     if (T.xval) {
       float v = 0.f;
-      if (xi >= 0) v = T.iou ? T.iou[static_cast<size_t>(i) * T.ldi + xi] : T.cost[static_cast<size_t>(i) * T.ldc + xi];
+      if (xi >= 0) v = T.iou ? T.iou[static_cast<size_t>(i) * T.ldi + xi] : static_cast<float>(C.at(i, xi));
       T.xval[i] = v;
     }
   }
   for (int j = t; j < nc; j += kThreads) T.y[j] = W.y[j];
+  return path;
+}
+
+// lds_mode (compile-time, so every pointer has a static address space — a run-time choice makes the compiler fall back
+// to flat_* instructions for the LDS state, which costs hundreds of cycles per dependent access): 0 = solver state in global scratch, 1 = hot state + column boxes in LDS (row boxes
+// in global scratch), 2 = hot state + column boxes + row boxes in LDS.
+template <int kThreads, int lds_mode>
+__global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __restrict__ tasks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const mot_lap_task T = tasks[blockIdx.x];
+  const int nr = T.n, nc = T.m, n = nr + nc;
+  const int t = threadIdx.x;
+  if (nr <= 0 || nc <= 0) {
+    for (int i = t; i < nr; i += kThreads) { T.x[i] = -1; if (T.xval) T.xval[i] = 0.f; }
+    for (int j = t; j < nc; j += kThreads) T.y[j] = -1;
+    if (T.info && t == 0) T.info[0] = 2;
+    return;
+  }
+  mot::DevGroup g(smem);
+  // global scratch layout: [hot (mode 0 only)] [cold] [row boxes 5*nr floats] [col boxes 6*nc floats]
+  char* gw = static_cast<char*>(T.work);
+  const size_t hot_b = (mot::lap_hot_bytes(n) + 15) & ~size_t(15), cold_b = (mot::lap_cold_bytes(n) + 15) & ~size_t(15);
+  mot::LapWork W;
+  char* lds = smem + kScratch;
+  if constexpr (lds_mode >= 1) { mot::lap_carve_hot(W, lds, n); lds += hot_b; }
+  else mot::lap_carve_hot(W, gw, n);
+  mot::lap_carve_cold(W, gw + hot_b, n);
+  W.cyc = T.prof;
+  int path;
+  if (T.geom.a != nullptr) {
+    float* gbox = reinterpret_cast<float*>(gw + hot_b + cold_b);
+    float* cp;
+    if constexpr (lds_mode >= 1) cp = reinterpret_cast<float*>(lds); else cp = gbox + 5 * nr;
+    float* cf = cp + 5 * nc;
+    float* rp;
+    if constexpr (lds_mode >= 2) rp = cf + nc; else rp = gbox;
+    const mot_iou_task& G = T.geom;
+    for (int i = t; i < nr; i += kThreads) {
+      const int gi = G.aidx ? G.aidx[i] : i;
+      float b[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { b[k] = G.a[static_cast<size_t>(k) * G.lda + gi]; rp[k * nr + i] = b[k]; }
+      rp[4 * nr + i] = (b[2] - b[0]) * (b[3] - b[1]);
+    }
+    for (int j = t; j < nc; j += kThreads) {
+      const int gj = G.bidx ? G.bidx[j] : j;
+      float b[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { b[k] = G.b[static_cast<size_t>(k) * G.ldb + gj]; cp[k * nc + j] = b[k]; }
+      cp[4 * nc + j] = (b[2] - b[0]) * (b[3] - b[1]);
+      cf[j] = G.bconf ? G.bconf[gj] : 0.0f;
+    }
+    g.sync();
+    mot::IouCost C;
+    C.rows = mot::BoxPlanes{rp, nr};
+    C.cols = mot::BoxPlanes{cp, nc};
+    C.conf = G.bconf ? cf : nullptr;
+    C.prm = mot::CostParams{G.mode, G.prox_thresh, G.app_thresh, G.fuse, G.emb != nullptr, G.emb == nullptr && G.lde < 0};
+    C.emb = G.emb;
+    C.lde = G.lde;
+    path = gate_and_solve<kThreads>(g, C, T, W);
+  } else {
+    const mot::MatrixCost C{T.cost, T.ldc};
+    path = gate_and_solve<kThreads>(g, C, T, W);
+  }
   if (T.info && t == 0) T.info[0] = path;
 }
 
 }  // namespace
 
 namespace mot {
-int lap_lds_limit() { return static_cast<int>((kLdsBudget - kScratch - 64) / lap_work_bytes(1)); }
+size_t lap_scratch_bytes(int n, int m) {
+  const size_t nm = static_cast<size_t>(n) + m;
+  return ((lap_hot_bytes(nm) + 15) & ~size_t(15)) + ((lap_cold_bytes(nm) + 15) & ~size_t(15)) + 4 * (5 * static_cast<size_t>(n) + 6 * static_cast<size_t>(m)) + 256;
+}
 
-hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_nm, hipStream_t st) {
+// Threads per problem: one wavefront (no barriers, no LDS merges; 4-8 problems co-resident per CU) unless the problem is
+// large AND there are too few problems to fill the chip anyway, where 4 wavefronts cut the latency of a row pass.
+hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool geom, hipStream_t st) {
   if (ntasks <= 0) return hipSuccess;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
-    if (e != hipSuccess) return e;
+    const void* fns[] = {reinterpret_cast<const void*>(&lap_kernel<64, 1>), reinterpret_cast<const void*>(&lap_kernel<64, 2>),
+                         reinterpret_cast<const void*>(&lap_kernel<256, 1>), reinterpret_cast<const void*>(&lap_kernel<256, 2>)};
+    for (const void* f : fns) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+      if (e != hipSuccess) return e;
+    }
     attr_set = true;
   }
-  if (max_nm <= lap_lds_limit()) {
-    const size_t lds = kScratch + ((lap_work_bytes(max_nm > 0 ? max_nm : 1) + 15) & ~size_t(15));
-    hipLaunchKernelGGL(lap_kernel<true>, dim3(ntasks), dim3(kThreads), lds, st, tasks);
-  } else {
-    hipLaunchKernelGGL(lap_kernel<false>, dim3(ntasks), dim3(kThreads), kScratch, st, tasks);
-  }
+  const size_t n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1, nm = n + m;
+  const size_t hot = (lap_hot_bytes(nm) + 15) & ~size_t(15);
+  const size_t b1 = kScratch + hot + (geom ? 24 * m + 16 : 0);
+  const size_t b2 = b1 + (geom ? 20 * n + 16 : 0);
+  int mode;
+  size_t lds;
+  if (b2 <= 40 * 1024) { mode = 2; lds = b2; }           // >= 4 problems per CU with everything in LDS
+  else if (b1 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 1; lds = b1; }
+  else { mode = 0; lds = kScratch; }
+  const bool wide = (nm > 3072) && (ntasks < 512);
+#define MOT_LAUNCH(T, M) hipLaunchKernelGGL((lap_kernel<T, M>), dim3(ntasks), dim3(T), lds, st, tasks)
+  if (wide) { if (mode == 2) MOT_LAUNCH(256, 2); else if (mode == 1) MOT_LAUNCH(256, 1); else MOT_LAUNCH(256, 0); }
+  else { if (mode == 2) MOT_LAUNCH(64, 2); else if (mode == 1) MOT_LAUNCH(64, 1); else MOT_LAUNCH(64, 0); }
+#undef MOT_LAUNCH
   return hipGetLastError();
 }
 }  // namespace mot

@@ -7,17 +7,46 @@
 
 #include "emu_group.hpp"
 #include "../../motcpp_amd/csrc/lap_core.hpp"
+#include "../../motcpp_amd/csrc/lap_cost.hpp"
 
 extern "C" int emu_lap(const float* cost, int nr, int nc, int ld, float thresh, int T, int* x, int* y) {
   using namespace mot;
   const int n = nr + nc;
   std::vector<char> mem(lap_work_bytes(n) + 64);
   LapWork W = lap_carve(mem.data(), n);
-  LapProblem P{cost, ld, nr, nc, static_cast<double>(thresh) / 2.0};
+  const MatrixCost C{cost, ld};
+  const LapDims P{nr, nc, static_cast<double>(thresh) / 2.0};
   EmuShared sh(T);
   std::vector<std::thread> th;
   for (int t = 0; t < T; ++t)
-    th.emplace_back([&, t]() { EmuGroup g(&sh, t); lap_solve(g, P, W); });
+    th.emplace_back([&, t]() { EmuGroup g(&sh, t); lap_solve(g, C, P, W); });
+  for (auto& t : th) t.join();
+  for (int i = 0; i < nr; ++i) x[i] = (W.x[i] >= nc) ? -1 : W.x[i];
+  for (int j = 0; j < nc; ++j) y[j] = (W.y[j] >= nr) ? -1 : W.y[j];
+  return 0;
+}
+
+// same solver with the on-the-fly IoU-family cost functor (row boxes a: nr x 4, column boxes b: nc x 4, row-major)
+extern "C" int emu_lap_iou(const float* a, int nr, const float* b, int nc, const float* conf, int mode, float thresh, int T,
+                           int* x, int* y) {
+  using namespace mot;
+  const int n = nr + nc;
+  std::vector<char> mem(lap_work_bytes(n) + 64);
+  LapWork W = lap_carve(mem.data(), n);
+  std::vector<float> rp(5 * nr), cp(5 * nc);
+  for (int i = 0; i < nr; ++i) { for (int k = 0; k < 4; ++k) rp[k * nr + i] = a[i * 4 + k]; rp[4 * nr + i] = (a[i * 4 + 2] - a[i * 4]) * (a[i * 4 + 3] - a[i * 4 + 1]); }
+  for (int j = 0; j < nc; ++j) { for (int k = 0; k < 4; ++k) cp[k * nc + j] = b[j * 4 + k]; cp[4 * nc + j] = (b[j * 4 + 2] - b[j * 4]) * (b[j * 4 + 3] - b[j * 4 + 1]); }
+  IouCost C;
+  C.rows = BoxPlanes{rp.data(), nr};
+  C.cols = BoxPlanes{cp.data(), nc};
+  C.conf = conf;
+  C.prm = CostParams{mode, 0.f, 0.f, 0, false, false};
+  C.emb = nullptr; C.lde = 0;
+  const LapDims P{nr, nc, static_cast<double>(thresh) / 2.0};
+  EmuShared sh(T);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t]() { EmuGroup g(&sh, t); lap_solve(g, C, P, W); });
   for (auto& t : th) t.join();
   for (int i = 0; i < nr; ++i) x[i] = (W.x[i] >= nc) ? -1 : W.x[i];
   for (int j = 0; j < nc; ++j) y[j] = (W.y[j] >= nr) ? -1 : W.y[j];

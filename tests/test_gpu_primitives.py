@@ -119,6 +119,31 @@ def test_lap_north_star_and_global_workspace(ctx, orc):
         assert np.array_equal(xg, xo) and np.array_equal(yg, yo), (n, m)
 
 
+@pytest.mark.parametrize("n,m", [(1, 1), (40, 64), (256, 128), (1000, 500), (2600, 1400)])
+def test_lap_on_the_fly_geometry(ctx, orc, n, m):
+    # mot_lap_task.geom: the solver recomputes the IoU-family cost from boxes; decisions must equal the oracle's on the matrix
+    r = np.random.default_rng(n + m)
+    a = boxes(r, n, (1920, 1080))
+    k = min(n, m)
+    b = boxes(r, m, (1920, 1080))
+    b[:k] = a[r.permutation(n)[:k]] + r.normal(0, 2, (k, 4)).astype(np.float32)
+    if k > 8:
+        b[1] = b[0]  # duplicate detection: exact ties
+    conf = r.uniform(0.3, 1, m).astype(np.float32)
+    dist = orc.iou_distance(a, b)
+    for mode, cost, th in ((L.COST_IOU_DIST, dist, 0.7), (L.COST_IOU_DIST_FUSE, orc.fuse_score(dist, conf), 0.8),
+                           (L.COST_NEG_IOU, -orc.iou_batch(a, b), -0.3)):
+        xo, yo = orc.linear_assignment(cost, th)
+        xg, yg, xv, info = ctx.lap_geom(a, b, th, mode, conf)
+        assert info == 0 and np.array_equal(xg, xo) and np.array_equal(yg, yo), (n, m, mode)
+        hit = xg >= 0
+        assert np.array_equal(xv[hit], cost[np.arange(n)[hit], xg[hit]])
+    # gate (OC-SORT rematch): nothing overlaps enough -> untouched
+    far = boxes(r, m, (1920, 1080)) + 5000
+    xg, yg, _, info = ctx.lap_geom(a, far, -0.3, L.COST_NEG_IOU, None, L.LAP_GATE_MIN, -0.3)
+    assert info == 2 and (xg == -1).all() and (yg == -1).all()
+
+
 def test_lap_ocsort_modes(ctx, orc):
     r = np.random.default_rng(11)
     # trivial one-to-one case (ocsort.cpp:684-696)

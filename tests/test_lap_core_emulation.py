@@ -24,6 +24,38 @@ def emu():
     return run
 
 
+@pytest.fixture(scope="module")
+def emu_iou():
+    lib = C.CDLL(build_lap_emu())
+
+    def run(a, b, conf, mode, th, T):
+        a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+        conf = np.ascontiguousarray(conf, np.float32)
+        x, y = np.zeros(a.shape[0], np.int32), np.zeros(b.shape[0], np.int32)
+        lib.emu_lap_iou(a.ctypes.data_as(C.c_void_p), a.shape[0], b.ctypes.data_as(C.c_void_p), b.shape[0],
+                        conf.ctypes.data_as(C.c_void_p), mode, C.c_float(th), T, x.ctypes.data_as(C.c_void_p),
+                        y.ctypes.data_as(C.c_void_p))
+        return x, y
+    return run
+
+
+def test_on_the_fly_cost_functor_matches_materialised_matrix(orc, emu_iou):
+    # the solver recomputing fuse(1 - IoU) from boxes must make the same decisions as the oracle on the matrix
+    r = np.random.default_rng(2)
+    for n, m in [(30, 20), (120, 70), (64, 64)]:
+        cx, cy = r.uniform(0, 500, n), r.uniform(0, 300, n)
+        w = r.uniform(30, 90, n)
+        a = np.stack([cx - w / 2, cy - w, cx + w / 2, cy + w], 1).astype(np.float32)
+        b = a[r.permutation(n)[:m] if m <= n else r.integers(0, n, m)] + r.normal(0, 3, (m, 4)).astype(np.float32)
+        b[::5] = a[: len(b[::5])]  # exact duplicates -> exact cost ties
+        conf = r.uniform(0.3, 1, m).astype(np.float32)
+        for mode, th in ((1, 0.7), (2, 0.8), (3, -0.3)):
+            cost = {1: orc.iou_distance(a, b), 2: orc.fuse_score(orc.iou_distance(a, b), conf), 3: -orc.iou_batch(a, b)}[mode]
+            xo, yo = orc.linear_assignment(cost, th)
+            xe, ye = emu_iou(a, b, conf, mode, th, 8)
+            assert (xo == xe).all() and (yo == ye).all(), (n, m, mode)
+
+
 def gen(r, kind, n, m):
     if kind == "dense":
         return r.uniform(0, 1, (n, m)).astype(np.float32), 0.8

@@ -71,7 +71,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     tracker, P, M, D, desc = WORKLOADS[args.workload]
-    S = args.streams or {"C2": 512, "SORT": 512, "NS": 128, "C5": 128, "C3": 32, "C4": 8}[args.workload]
+    S = args.streams or {"C2": 4096, "SORT": 4096, "NS": 512, "C5": 512, "C3": 64, "C4": 8}[args.workload]
     threads = args.threads or min(16, os.cpu_count() or 1)
     K, W = args.steps, args.warmup
     F = K + W
@@ -91,7 +91,7 @@ def main():
     torch.cuda.synchronize()
     frame_bytes = S * 6 * M * 4
 
-    batch = L.Batch(tracker, S, device=local, threads=threads)
+    batch = L.Batch(tracker, S, device=local, threads=threads, record_laps=False)
     cap = max(2 * M, 64)
     gathered = None
 

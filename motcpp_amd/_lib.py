@@ -175,6 +175,7 @@ def host():
         H.motcpp_batch_step_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_int]
         H.motcpp_batch_set_threads.argtypes = [C.c_void_p, C.c_int]
+        H.motcpp_batch_record_laps.argtypes = [C.c_void_p, C.c_int]
         H.motcpp_profile.argtypes = [C.c_int, C.c_int]
         H.motcpp_profile_stats.argtypes = [C.c_int, C.c_void_p, C.c_int]
         H.motcpp_batch_counters.argtypes = [C.c_void_p, C.c_void_p]
@@ -262,7 +263,7 @@ class _Borrowed(_Hooks):
 class Batch:
     """S independent streams stepped in lockstep on one GPU (motcpp::StreamBatch)."""
 
-    def __init__(self, kind, nstreams, params=None, device=0, threads=1):
+    def __init__(self, kind, nstreams, params=None, device=0, threads=1, record_laps=True):
         kind = KIND.get(kind, kind)
         p = f32(params if params is not None else [])
         self.S = int(nstreams)
@@ -270,6 +271,7 @@ class Batch:
         if not self.h:
             raise MotError("batch create failed: " + _err())
         host().motcpp_batch_set_threads(self.h, int(threads))
+        host().motcpp_batch_record_laps(self.h, 1 if record_laps else 0)
         self._out = None
         self._cnt = np.zeros(self.S, np.int32)
 

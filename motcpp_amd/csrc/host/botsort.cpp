@@ -5,7 +5,6 @@
 //
 // Stages: 0 det/feature prepare, predict pool, cosine + gated cost, LAP#1 | 1 LAP#2 (0.5) and the
 // unconfirmed association LAP#3 (0.7) | 2 Kalman/feature updates, new tracks, boxes of the rows to emit.
-#include <unordered_set>
 
 #include "staged.hpp"
 
@@ -53,13 +52,14 @@ class BotSortGpu final : public Staged {
       else if (conf_[i] > lo_) second_.push_back(i);
     }
     unconf_.clear(); pool_.clear();
-    std::unordered_set<int> seen;
+    IdSet& seen = set_a_;
+    seen.clear();
     for (size_t i = 0; i < active_.size(); ++i) {
       if (!active_[i].activated) unconf_.push_back(static_cast<int>(i));
       else { pool_.push_back({static_cast<int>(i), true}); seen.insert(active_[i].id); }
     }
     for (size_t i = 0; i < lost_.size(); ++i)
-      if (seen.insert(lost_[i].id).second) pool_.push_back({static_cast<int>(i), false});
+      if (seen.insert(lost_[i].id)) pool_.push_back({static_cast<int>(i), false});
 
     core_.reserve(static_cast<int>(first_.size()) + 8, 8);
     dets_ = core_.upload_dets(in.dets, in.n, in.ld, MOT_DET_XYWH, in.d_dets, in.d_ld);
@@ -69,7 +69,6 @@ class BotSortGpu final : public Staged {
       if (D_ == 0) D_ = in.emb_dim;
       if (D_ != in.emb_dim) throw Error("BotSort: embedding dimension changed between frames");
       ensure_feat_slab();
-      std::lock_guard<std::mutex> g(core_.dev().mu);
       Span<float> raw = core_.dev().up->alloc<float>(static_cast<size_t>(in.n) * D_);
       if (in.embs_rowmajor) std::memcpy(raw.h, in.embs, sizeof(float) * static_cast<size_t>(in.n) * D_);
       else
@@ -79,7 +78,7 @@ class BotSortGpu final : public Staged {
       emb_norm_ = core_.dev().tmp->alloc<float>(static_cast<size_t>(in.n) * D_).d;
       mot_feat_task t{};
       t.n = in.n; t.d = D_; t.feat = emb_norm_; t.ldf = D_; t.src = emb_raw_; t.lds = D_; t.mode = 0; t.alpha = 0.9f;
-      core_.dev().feat_set.push_back(t);
+      core_.dev().q().feat_set.push_back(t);
     }
     const int np = static_cast<int>(pool_.size());
     lap1_ = Core::Lap();
@@ -130,14 +129,13 @@ class BotSortGpu final : public Staged {
     int lde = 0;
     if (with_reid_ && have_emb_) {
       Span<int32_t> sl = core_.ints(slots);
-      std::lock_guard<std::mutex> g(core_.dev().mu);
       lde = round_up(m, 4);
       float* out = core_.dev().tmp->alloc<float>(static_cast<size_t>(n) * lde).d;
       mot_cos_task t{};
       t.n = n; t.m = m; t.d = D_; t.a = feat_; t.lda = D_; t.aidx = sl.d; t.b = emb_norm_; t.ldb = D_; t.bidx = didx.d;
       t.out = out; t.ldo = lde;
       t.norm_a = core_.dev().tmp->alloc<float>(n).d; t.norm_b = core_.dev().tmp->alloc<float>(m).d;
-      core_.dev().cos.push_back(t);
+      core_.dev().q().cos.push_back(t);
       emb = out;
     }
     else if (with_reid_) lde = -1;  // no features this frame: the reference's cosine term is the constant 1 (matching.cpp:79-92, D = 0)
@@ -165,7 +163,7 @@ class BotSortGpu final : public Staged {
     const int np = static_cast<int>(pool_.size()), nd = static_cast<int>(first_.size());
     std::vector<int> x(np, -1), y(nd, -1);
     if (lap1_.queued) { record(lap1_); x.assign(lap1_.x.h, lap1_.x.h + np); y.assign(lap1_.y.h, lap1_.y.h + nd); }
-    else laps_.push_back(LapRecord{x, y});
+    else if (record_laps) laps_.push_back(LapRecord{x, y});
     upd_slot_.clear(); upd_meas_.clear(); ema_slot_.clear(); ema_det_.clear(); set_slot_.clear(); set_det_.clear();
     act_ids_.clear(); lost_new_.clear();
     std::vector<int> u_track;
@@ -247,19 +245,21 @@ class BotSortGpu final : public Staged {
       if (frame_count_ - t.end_frame > max_time_lost_) t.state = Removed;
 
     // prepare_output :678-764. Re-found lost tracks are dropped from lost_ and never re-enter active_.
-    std::unordered_set<int> active_ids;
+    IdSet& active_ids = set_a_;
+    active_ids.clear();
     for (const Trk& t : active_) if (act_ids_.count(t.id) && t.state == Tracked) active_ids.insert(t.id);
     for (const Trk& t : lost_) if (act_ids_.count(t.id) && t.state == Tracked) active_ids.insert(t.id);
     for (const Trk& t : fresh) active_ids.insert(t.id);
     std::vector<Trk> new_lost;
-    std::unordered_set<int> lost_ids;
+    IdSet& lost_ids = set_b_;
+    lost_ids.clear();
     for (const Trk& t : lost_) {
       if (!active_ids.count(t.id) && t.state != Removed) { new_lost.push_back(t); lost_ids.insert(t.id); }
       else dead_.push_back(t.slot);
     }
     for (int id : lost_new_)
       for (const Trk& t : active_)
-        if (t.id == id && !active_ids.count(id) && lost_ids.insert(id).second) new_lost.push_back(t);
+        if (t.id == id && !active_ids.count(id) && lost_ids.insert(id)) new_lost.push_back(t);
     std::vector<Trk> new_active;
     for (const Trk& t : active_) {
       if (t.state == Tracked) new_active.push_back(t);
@@ -286,11 +286,10 @@ class BotSortGpu final : public Staged {
   void queue_feat(const std::vector<int>& slots, const std::vector<int>& dets, int mode) {
     if (slots.empty()) return;
     Span<int32_t> s = core_.ints(slots), d = core_.ints(dets);
-    std::lock_guard<std::mutex> g(core_.dev().mu);
     mot_feat_task t{};
     t.n = static_cast<int>(slots.size()); t.d = D_; t.feat = feat_; t.ldf = D_; t.slot = s.d; t.src = emb_raw_; t.lds = D_; t.sidx = d.d;
     t.mode = mode; t.alpha = 0.9f;
-    (mode ? core_.dev().feat_ema : core_.dev().feat_set).push_back(t);
+    (mode ? core_.dev().q().feat_ema : core_.dev().q().feat_set).push_back(t);
   }
   void emit() {
     const int n = static_cast<int>(out_idx_.size());
@@ -316,7 +315,7 @@ class BotSortGpu final : public Staged {
   std::vector<int> first_, second_, unconf_, u_det_, r_tracked_, cls_, out_idx_, lost_new_, dead_;
   std::vector<int> upd_slot_, upd_meas_, ema_slot_, ema_det_, set_slot_, set_det_;
   std::vector<float> conf_;
-  std::unordered_set<int> act_ids_;
+  IdSet act_ids_, set_a_, set_b_;
   Core::Dets dets_;
   float* pool_box_ = nullptr;
   Span<int32_t> first_d_, second_d_, rem_d_, r_tracked_d_;

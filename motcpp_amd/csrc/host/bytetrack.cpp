@@ -8,7 +8,6 @@
 //   1  boxes of the un-predicted remaining/unconfirmed originals, IoU costs, LAP#2 (0.5), LAP#3 (0.7)
 //   2  Kalman updates / initiations, boxes of active+lost, duplicate pairs (iou_dist < 0.15)
 #include <algorithm>
-#include <unordered_set>
 
 #include "staged.hpp"
 
@@ -67,10 +66,11 @@ class ByteTrackGpu final : public Staged {
     for (size_t i = 0; i < active_.size(); ++i) (active_[i].activated ? tracked_idx_ : unconf_idx_).push_back(static_cast<int>(i));
     // pool = tracked ∪ lost (by id), as copies predicted into scratch slots (:251-265)
     pool_.clear();
-    std::unordered_set<int> seen;
+    IdSet& seen = set_a_;
+    seen.clear();
     for (int i : tracked_idx_) { pool_.push_back({i, true}); seen.insert(active_[i].id); }
     for (size_t i = 0; i < lost_.size(); ++i)
-      if (seen.insert(lost_[i].id).second) pool_.push_back({static_cast<int>(i), false});
+      if (seen.insert(lost_[i].id)) pool_.push_back({static_cast<int>(i), false});
     const int np = static_cast<int>(pool_.size());
     core_.reserve(static_cast<int>(high_.size()) + 8, np + 8);
     dets_ = core_.upload_dets(in.dets, in.n, in.ld, MOT_DET_XYAH, in.d_dets, in.d_ld);
@@ -125,7 +125,7 @@ class ByteTrackGpu final : public Staged {
       x.assign(lap1_.x.h, lap1_.x.h + np);
       y.assign(lap1_.y.h, lap1_.y.h + nd);
     } else {
-      laps_.push_back(LapRecord{x, y});  // utils::linear_assignment's empty-side early return (matching.cpp:20-27)
+      if (record_laps) laps_.push_back(LapRecord{x, y});  // utils::linear_assignment's empty-side early return (matching.cpp:20-27)
     }
     upd_src_.clear(); upd_dst_.clear(); upd_meas_.clear();
     refind_.clear();
@@ -232,16 +232,19 @@ class ByteTrackGpu final : public Staged {
 
     // list algebra (:565-580). Copies in the reference == moves here: one slot per id.
     std::vector<Trk> na;
-    std::unordered_set<int> active_ids;
+    IdSet& active_ids = set_a_;
+    active_ids.clear();
     for (const Trk& t : active_)
       if (t.state == Tracked) { na.push_back(t); active_ids.insert(t.id); }
       else if (t.state == Removed) dead_slots_.push_back(t.slot);
     for (const Trk& t : fresh) { na.push_back(t); active_ids.insert(t.id); }
     for (int id : refind_)
       for (const Trk& t : lost_)
-        if (t.id == id && active_ids.insert(id).second) na.push_back(t);
+        if (t.id == id && active_ids.insert(id)) na.push_back(t);
     std::vector<Trk> nl;
-    std::unordered_set<int> rm(removed_ids.begin(), removed_ids.end());
+    IdSet& rm = set_b_;
+    rm.clear();
+    for (int id : removed_ids) rm.insert(id);
     for (const Trk& t : lost_) {
       if (active_ids.count(t.id)) continue;
       if (rm.count(t.id)) { dead_slots_.push_back(t.slot); continue; }
@@ -266,17 +269,14 @@ class ByteTrackGpu final : public Staged {
     pairs_cap_ = 0;
     if (!sa.empty() && !sl.empty()) {
       float* dl = core_.boxes(sl, nullptr);
-      std::lock_guard<std::mutex> g(core_.dev().mu);
       pairs_ = core_.dev().down->alloc<int32_t>(static_cast<size_t>(2) * cap);
-      npairs_ = core_.dev().down->alloc<int32_t>(4);
+      npairs_ = core_.dev().zdown->alloc<int32_t>(4);  // zeroed on the device ahead of this stage's kernels
       pairs_cap_ = cap;
-      // npairs_ lives in the download arena (device side); cleared on the stream ahead of this stage's kernels
-      mot_memset(core_.dev().ctx, npairs_.d, 0, sizeof(int32_t) * 4);
       mot_iou_task t{};
       t.n = static_cast<int>(sa.size()); t.m = static_cast<int>(sl.size());
       t.a = da; t.lda = t.n; t.b = dl; t.ldb = t.m; t.mode = MOT_COST_IOU_DIST;
       t.pairs = pairs_.d; t.npairs = npairs_.d; t.pairs_cap = cap; t.pair_thresh = 0.15f;
-      core_.dev().iou.push_back(t);
+      core_.dev().q().iou.push_back(t);
     }
   }
 
@@ -322,6 +322,7 @@ class ByteTrackGpu final : public Staged {
   }
 
   Core core_;
+  IdSet set_a_, set_b_;
   float min_conf_, track_thresh_, match_thresh_, det_thresh_;
   int max_time_lost_;
   int frame_count_ = 0, next_id_ = 0;

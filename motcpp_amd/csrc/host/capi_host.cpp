@@ -138,6 +138,7 @@ motcpp_batch* motcpp_batch_create(int kind, const float* params, int nparams, in
 }
 void motcpp_batch_destroy(motcpp_batch* b) { delete b; }
 int motcpp_batch_set_threads(motcpp_batch* b, int threads) { b->threads = threads < 1 ? 1 : threads; return 0; }
+int motcpp_batch_record_laps(motcpp_batch* b, int on) { for (auto& t : b->trk) t->impl->record_laps = on != 0; return 0; }
 int motcpp_batch_tracker_count(motcpp_batch* b) { return static_cast<int>(b->trk.size()); }
 motcpp_tracker* motcpp_batch_tracker(motcpp_batch* b, int s) { return b->trk[s].get(); }
 int motcpp_batch_counters(motcpp_batch* b, long* out3) {

@@ -19,7 +19,9 @@ struct Trk {
   int id = 0, slot = -1, age = 0, hits = 0, hit_streak = 0, tsu = 0, cls = 0, det_ind = 0;
   float conf = 0.f;
   Obs5 last_obs{{-1, -1, -1, -1, -1}};
-  std::map<int, Obs5> observations;
+  // age -> observation. The reference keeps every entry (ocsort.cpp:118); only the last delta_t+1 ages and the newest
+  // entry are ever looked up (:24-51), so a short age-ordered tail is equivalent.
+  std::vector<std::pair<int, Obs5>> observations;
   float vel[2] = {0.f, 0.f};
 };
 
@@ -148,10 +150,11 @@ class OCSortGpu final : public Staged {
   static Obs5 k_previous_obs(const Trk& t, int k) {  // :24-51
     if (t.observations.empty()) return Obs5{{-1, -1, -1, -1, -1}};
     for (int i = 0; i < k; ++i) {
-      auto it = t.observations.find(t.age - (k - i));
-      if (it != t.observations.end()) return it->second;
+      const int key = t.age - (k - i);
+      for (const auto& o : t.observations)
+        if (o.first == key) return o.second;
     }
-    return t.observations.rbegin()->second;
+    return t.observations.back().second;
   }
   static void speed_direction(const float* b1, const float* b2, float out[2]) {  // :160-172
     const float cx1 = (b1[0] + b1[2]) / 2.0f, cy1 = (b1[1] + b1[3]) / 2.0f;
@@ -173,7 +176,9 @@ class OCSortGpu final : public Staged {
     }
     for (int k = 0; k < 4; ++k) t.last_obs.v[k] = b[k];
     t.last_obs.v[4] = t.conf;
-    t.observations[t.age] = t.last_obs;
+    if (!t.observations.empty() && t.observations.back().first == t.age) t.observations.back().second = t.last_obs;
+    else t.observations.push_back({t.age, t.last_obs});
+    if (static_cast<int>(t.observations.size()) > delta_t_ + 2) t.observations.erase(t.observations.begin());
     t.tsu = 0; ++t.hits; ++t.hit_streak;
     upd_.push_back({t.slot, det});
   }
@@ -193,14 +198,13 @@ class OCSortGpu final : public Staged {
     const int ld = round_up(nt, 4);
     float* cost;
     {
-      std::lock_guard<std::mutex> g(core_.dev().mu);
       cost = core_.dev().tmp->alloc<float>(static_cast<size_t>(nd) * ld).d;
       iou_d_ = core_.dev().tmp->alloc<float>(static_cast<size_t>(nd) * ld).d;
       mot_ocsort_task t{};
       t.nd = nd; t.nt = nt; t.dbox = dets_.d_box; t.ldd = dets_.n; t.didx = high_d_.d; t.dconf = dets_.d_conf();
       t.tbox = pbox_d_; t.ldt = nt0_; t.vel = dv.d; t.ldv = nt; t.prev = dp.d; t.ldp = nt; t.vdc_weight = inertia_;
       t.cost = cost; t.iou = iou_d_; t.ldc = ld;
-      core_.dev().oc.push_back(t);
+      core_.dev().q().oc.push_back(t);
     }
     assoc_nt_ = nt;
     assoc_ = core_.lap(cost, ld, nd, nt, -thr_, MOT_LAP_OCSORT, iou_d_, ld, thr_, true);

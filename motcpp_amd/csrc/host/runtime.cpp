@@ -4,68 +4,92 @@
 #include <chrono>
 #include <map>
 
+#include <omp.h>
+
 namespace motcpp::rt {
 
 // ---- Arena ---------------------------------------------------------------------------------
-Arena::Arena(mot_ctx* ctx, size_t chunk_bytes, bool host_mirror) : ctx_(ctx), chunk_bytes_(chunk_bytes), host_(host_mirror) {}
+Arena::Arena(mot_ctx* ctx, size_t chunk_bytes, bool host_mirror) : ctx_(ctx), chunk_bytes_(chunk_bytes), host_(host_mirror) {
+  chunks_.reserve(1024);  // the vector never reallocates while other threads index it
+}
 Arena::~Arena() {
-  for (Chunk& c : chunks_) {
-    if (c.d) mot_free(ctx_, c.d);
-    if (c.h) mot_host_free(ctx_, c.h);
+  for (auto& c : chunks_) {
+    if (c->d) mot_free(ctx_, c->d);
+    if (c->h) mot_host_free(ctx_, c->h);
   }
 }
 void Arena::raw_alloc(size_t bytes, void** h, void** d) {
   bytes = (bytes + 255) & ~size_t(255);
   if (bytes == 0) bytes = 256;
   while (true) {
-    if (cur_ < chunks_.size()) {
-      Chunk& c = chunks_[cur_];
-      if (c.top + bytes <= c.cap) {
-        *h = c.h ? c.h + c.top : nullptr;
-        *d = c.d + c.top;
-        c.top += bytes;
-        return;
+    const size_t ci = cur_.load(std::memory_order_acquire);
+    if (ci < n_chunks_.load(std::memory_order_acquire)) {
+      Chunk& c = *chunks_[ci];
+      if (bytes <= c.cap) {
+        const size_t off = c.top.fetch_add(bytes, std::memory_order_relaxed);
+        if (off + bytes <= c.cap) {
+          *h = c.h ? c.h + off : nullptr;
+          *d = c.d + off;
+          return;
+        }
       }
-      ++cur_;
-      continue;
     }
-    Chunk c{};
-    c.cap = std::max(chunk_bytes_, bytes);
-    void* dp = nullptr;
-    if (mot_malloc(ctx_, c.cap, &dp) != MOT_OK) throw Error(std::string("arena: device allocation failed: ") + mot_ctx_last_error(ctx_));
-    c.d = static_cast<char*>(dp);
-    if (host_) {
-      void* hp = nullptr;
-      if (mot_host_alloc(ctx_, c.cap, &hp) != MOT_OK) throw Error("arena: pinned host allocation failed");
-      c.h = static_cast<char*>(hp);
+    // slow path: this chunk is exhausted (or none exists yet) -> move on / grow, one thread at a time
+    std::lock_guard<std::mutex> g(grow_mu_);
+    if (cur_.load(std::memory_order_relaxed) != ci) continue;  // somebody else already advanced
+    const size_t next = (ci < n_chunks_.load(std::memory_order_relaxed)) ? ci + 1 : ci;
+    if (next >= n_chunks_.load(std::memory_order_relaxed)) {  // append a chunk (an existing but too-small next chunk is simply skipped)
+      if (chunks_.size() >= 1024) throw Error("arena: too many chunks");
+      auto c = std::make_unique<Chunk>();
+      c->cap = std::max(chunk_bytes_, bytes);
+      void* dp = nullptr;
+      if (mot_malloc(ctx_, c->cap, &dp) != MOT_OK) throw Error(std::string("arena: device allocation failed: ") + mot_ctx_last_error(ctx_));
+      c->d = static_cast<char*>(dp);
+      if (host_) {
+        void* hp = nullptr;
+        if (mot_host_alloc(ctx_, c->cap, &hp) != MOT_OK) throw Error("arena: pinned host allocation failed");
+        c->h = static_cast<char*>(hp);
+      }
+      chunks_.push_back(std::move(c));
+      n_chunks_.store(chunks_.size(), std::memory_order_release);
     }
-    chunks_.push_back(c);
+    cur_.store(next, std::memory_order_release);
   }
 }
 void Arena::reset() {
-  for (Chunk& c : chunks_) c.top = c.mark = 0;
-  cur_ = 0;
-}
-void Arena::mark() {
-  for (Chunk& c : chunks_) c.mark = c.top;
+  for (auto& c : chunks_) { c->top.store(0, std::memory_order_relaxed); c->mark = 0; }
+  cur_.store(0, std::memory_order_release);
 }
 void Arena::upload() {
-  for (Chunk& c : chunks_)
-    if (c.top > c.mark) {
-      if (mot_memcpy_h2d(ctx_, c.d + c.mark, c.h + c.mark, c.top - c.mark) != MOT_OK) throw Error("arena upload failed");
-      c.mark = c.top;
+  for (auto& c : chunks_) {
+    const size_t top = std::min(c->top.load(std::memory_order_relaxed), c->cap);
+    if (top > c->mark) {
+      if (mot_memcpy_h2d(ctx_, c->d + c->mark, c->h + c->mark, top - c->mark) != MOT_OK) throw Error("arena upload failed");
+      c->mark = top;
     }
+  }
 }
 void Arena::download() {
-  for (Chunk& c : chunks_)
-    if (c.top > c.mark) {
-      if (mot_memcpy_d2h(ctx_, c.h + c.mark, c.d + c.mark, c.top - c.mark) != MOT_OK) throw Error("arena download failed");
-      c.mark = c.top;
+  for (auto& c : chunks_) {
+    const size_t top = std::min(c->top.load(std::memory_order_relaxed), c->cap);
+    if (top > c->mark) {
+      if (mot_memcpy_d2h(ctx_, c->h + c->mark, c->d + c->mark, top - c->mark) != MOT_OK) throw Error("arena download failed");
+      c->mark = top;
     }
+  }
+}
+void Arena::clear_pending() {
+  for (auto& c : chunks_) {
+    const size_t top = std::min(c->top.load(std::memory_order_relaxed), c->cap);
+    if (top > c->mark && mot_memset(ctx_, c->d + c->mark, 0, top - c->mark) != MOT_OK) throw Error("arena clear failed");
+  }
 }
 size_t Arena::bytes_in_flight() const {
   size_t s = 0;
-  for (const Chunk& c : chunks_) s += c.top - c.mark;
+  for (const auto& c : chunks_) {
+    const size_t top = std::min(c->top.load(std::memory_order_relaxed), c->cap);
+    if (top > c->mark) s += top - c->mark;
+  }
   return s;
 }
 
@@ -78,11 +102,14 @@ Device::Device(int device_index) : index(device_index) {
   up = std::make_unique<Arena>(ctx, size_t(8) << 20, true);
   down = std::make_unique<Arena>(ctx, size_t(4) << 20, true);
   tmp = std::make_unique<Arena>(ctx, size_t(64) << 20, false);
+  zdown = std::make_unique<Arena>(ctx, size_t(1) << 20, true);
+  lists.resize(kMaxHostThreads);
 }
 Device::~Device() {
   up.reset();
   down.reset();
   tmp.reset();
+  zdown.reset();
   if (ctx) mot_ctx_destroy(ctx);
 }
 std::shared_ptr<Device> Device::shared(int device_index) {
@@ -103,12 +130,43 @@ void Device::begin_frame() {
   up->reset();
   down->reset();
   tmp->reset();
+  zdown->reset();
+}
+bool Device::TaskLists::empty() const {
+  for (int k = 0; k < 3; ++k)
+    if (!det[k].empty() || !kf_init[k].empty() || !kf_upd[k].empty() || !kf_pred[k].empty() || !kf_box[k].empty()) return false;
+  return feat_set.empty() && feat_ema.empty() && cos.empty() && iou.empty() && oc.empty() && lap.empty();
+}
+void Device::TaskLists::clear() {
+  for (int k = 0; k < 3; ++k) { det[k].clear(); kf_init[k].clear(); kf_upd[k].clear(); kf_pred[k].clear(); kf_box[k].clear(); }
+  feat_set.clear(); feat_ema.clear(); cos.clear(); iou.clear(); oc.clear(); lap.clear();
+  lap_geom = false;
+}
+namespace {
+template <class T>
+void move_back(std::vector<T>& dst, std::vector<T>& src) {
+  dst.insert(dst.end(), src.begin(), src.end());
+  src.clear();
+}
+}  // namespace
+void Device::TaskLists::append(TaskLists& o) {
+  for (int k = 0; k < 3; ++k) {
+    move_back(det[k], o.det[k]); move_back(kf_init[k], o.kf_init[k]); move_back(kf_upd[k], o.kf_upd[k]);
+    move_back(kf_pred[k], o.kf_pred[k]); move_back(kf_box[k], o.kf_box[k]);
+  }
+  move_back(feat_set, o.feat_set); move_back(feat_ema, o.feat_ema); move_back(cos, o.cos); move_back(iou, o.iou);
+  move_back(oc, o.oc); move_back(lap, o.lap);
+  lap_geom = lap_geom || o.lap_geom;
+  o.lap_geom = false;
+}
+Device::TaskLists& Device::q() {
+  const int t = omp_get_thread_num();
+  return lists[t < kMaxHostThreads ? t : 0];
 }
 bool Device::pending() const {
-  for (int k = 0; k < 3; ++k)
-    if (!det[k].empty() || !kf_init[k].empty() || !kf_upd[k].empty() || !kf_pred[k].empty() || !kf_box[k].empty()) return true;
-  return !feat_set.empty() || !feat_ema.empty() || !cos.empty() || !iou.empty() || !oc.empty() || !lap.empty() ||
-         up->bytes_in_flight() > 0 || down->bytes_in_flight() > 0;
+  for (const TaskLists& l : lists)
+    if (!l.empty()) return true;
+  return up->bytes_in_flight() > 0 || down->bytes_in_flight() > 0 || zdown->bytes_in_flight() > 0;
 }
 
 namespace {
@@ -142,6 +200,21 @@ void Device::time_end() {
 }
 
 void Device::flush() {
+  TaskLists& L = lists[0];
+  for (size_t i = 1; i < lists.size(); ++i)
+    if (!lists[i].empty()) L.append(lists[i]);
+  auto& det = L.det;
+  auto& kf_init = L.kf_init;
+  auto& kf_upd = L.kf_upd;
+  auto& kf_pred = L.kf_pred;
+  auto& kf_box = L.kf_box;
+  auto& feat_set = L.feat_set;
+  auto& feat_ema = L.feat_ema;
+  auto &cos = L.cos;
+  auto &iou = L.iou;
+  auto &oc = L.oc;
+  auto &lap = L.lap;
+  const bool lap_geom = L.lap_geom;
   const mot_det_task* d_det[3];
   const mot_kf_task *d_init[3], *d_upd[3], *d_pred[3], *d_box[3];
   for (int k = 0; k < 3; ++k) {
@@ -158,6 +231,7 @@ void Device::flush() {
   const mot_ocsort_task* d_oc = stage_tasks(*up, oc);
   const mot_lap_task* d_lap = stage_tasks(*up, lap);
   up->upload();
+  zdown->clear_pending();
 
   auto maxn = [](const auto& v, auto get) { int m = 0; for (const auto& t : v) m = std::max(m, get(t)); return m; };
   // One launch per non-empty kernel family; with profile on, each launch is bracketed by an event pair and its
@@ -228,6 +302,7 @@ void Device::flush() {
     run(F_LAP, lap.size(), b, 0, [&] { check(mot_lap_solve(ctx, d_lap, (int)lap.size(), maxn(lap, [](const mot_lap_task& t) { return t.n; }), maxn(lap, [](const mot_lap_task& t) { return t.m; }), lap_geom ? MOT_LAP_F_GEOM : 0), "mot_lap_solve"); });
   }
   down->download();
+  zdown->download();
   {
     const auto w0 = std::chrono::steady_clock::now();
     check(mot_ctx_sync(ctx), "mot_ctx_sync");
@@ -242,8 +317,7 @@ void Device::flush() {
   }
   timed_.clear();
   ++counters.flushes;
-  for (int k = 0; k < 3; ++k) { det[k].clear(); kf_init[k].clear(); kf_upd[k].clear(); kf_pred[k].clear(); kf_box[k].clear(); }
-  feat_set.clear(); feat_ema.clear(); cos.clear(); iou.clear(); oc.clear(); lap.clear(); lap_geom = false;
+  L.clear();
 }
 
 // ---- Core ----------------------------------------------------------------------------------
@@ -273,9 +347,10 @@ void Core::grow(int pcap, int scap) {
 void Core::reserve(int extra_persistent, int scratch) {
   const int avail = (pcap_ - next_) + static_cast<int>(free_.size());
   int pcap = pcap_, scap = scap_;
-  if (avail < extra_persistent) pcap = std::max(pcap_ * 2, round_up(next_ + extra_persistent + 64, 64));
-  if (scap_ < scratch) scap = std::max(scap_ * 2, round_up(scratch + 64, 64));
-  if (pcap != pcap_ || scap != scap_ || !mean_) grow(std::max(pcap, 64), std::max(scap, 64));
+  // growth is a slab re-allocation + plane copies + a sync: start generous and double, so it happens O(1) times per stream
+  if (avail < extra_persistent) pcap = std::max(pcap_ * 2, round_up(2 * (next_ + extra_persistent) + 64, 64));
+  if (scap_ < scratch) scap = std::max(scap_ * 2, round_up(2 * scratch + 64, 64));
+  if (pcap != pcap_ || scap != scap_ || !mean_) grow(std::max(pcap, 512), std::max(scap, 512));
 }
 int Core::new_slot() {
   if (!free_.empty()) { int s = free_.back(); free_.pop_back(); return s; }
@@ -289,7 +364,6 @@ Core::Dets Core::upload_dets(const float* colmajor, int n, int ld, int det_kind,
   Dets d;
   d.n = n;
   if (n <= 0) return d;
-  std::lock_guard<std::mutex> g(dev_->mu);
   if (resident) {
     d.d_raw = resident;
     d.ld_raw = resident_ld;
@@ -303,23 +377,20 @@ Core::Dets Core::upload_dets(const float* colmajor, int n, int ld, int det_kind,
   d.d_meas = dev_->tmp->alloc<float>(static_cast<size_t>(4) * n).d;
   mot_det_task t{};
   t.dets = d.d_raw; t.ld = d.ld_raw; t.n = n; t.box = d.d_box; t.ldb = n; t.meas = d.d_meas; t.ldm = n;
-  dev_->det[det_kind].push_back(t);
+  dev_->q().det[det_kind].push_back(t);
   return d;
 }
 Span<int32_t> Core::ints(const std::vector<int>& v) {
-  std::lock_guard<std::mutex> g(dev_->mu);
   Span<int32_t> s = dev_->up->alloc<int32_t>(v.size());
   if (!v.empty()) std::memcpy(s.h, v.data(), sizeof(int32_t) * v.size());
   return s;
 }
 Span<uint8_t> Core::bytes(const std::vector<uint8_t>& v) {
-  std::lock_guard<std::mutex> g(dev_->mu);
   Span<uint8_t> s = dev_->up->alloc<uint8_t>(v.size());
   if (!v.empty()) std::memcpy(s.h, v.data(), v.size());
   return s;
 }
 Span<float> Core::floats(const std::vector<float>& v) {
-  std::lock_guard<std::mutex> g(dev_->mu);
   Span<float> s = dev_->up->alloc<float>(v.size());
   if (!v.empty()) std::memcpy(s.h, v.data(), sizeof(float) * v.size());
   return s;
@@ -332,63 +403,57 @@ float* Core::predict(const std::vector<int>& src, const std::vector<int>* dst, c
   if (dst) d = ints(*dst);
   Span<uint8_t> f;
   if (flags) f = bytes(*flags);
-  std::lock_guard<std::mutex> g(dev_->mu);
   float* bx;
   if (boxes_dl) { *boxes_dl = dev_->down->alloc<float>(static_cast<size_t>(4) * n); bx = boxes_dl->d; }
   else bx = dev_->tmp->alloc<float>(static_cast<size_t>(4) * n).d;
   mot_kf_task t{};
   t.mean = mean_; t.cov = cov_; t.cap = cap_; t.n = n; t.src = s.d; t.dst = dst ? d.d : nullptr; t.flags = flags ? f.d : nullptr;
   t.boxes = bx; t.ldb = n; t.q[0] = q[0]; t.q[1] = q[1]; t.q[2] = q[2];
-  dev_->kf_pred[kind_].push_back(t);
+  dev_->q().kf_pred[kind_].push_back(t);
   return bx;
 }
 float* Core::boxes(const std::vector<int>& slots, Span<float>* boxes_dl) {
   const int n = static_cast<int>(slots.size());
   if (n == 0) return nullptr;
   Span<int32_t> s = ints(slots);
-  std::lock_guard<std::mutex> g(dev_->mu);
   float* bx;
   if (boxes_dl) { *boxes_dl = dev_->down->alloc<float>(static_cast<size_t>(4) * n); bx = boxes_dl->d; }
   else bx = dev_->tmp->alloc<float>(static_cast<size_t>(4) * n).d;
   mot_kf_task t{};
   t.mean = mean_; t.cov = cov_; t.cap = cap_; t.n = n; t.src = s.d; t.boxes = bx; t.ldb = n;
-  dev_->kf_box[kind_].push_back(t);
+  dev_->q().kf_box[kind_].push_back(t);
   return bx;
 }
 void Core::update(const std::vector<int>& src, const std::vector<int>& dst, const std::vector<int>& midx, const Dets& dets) {
   const int n = static_cast<int>(src.size());
   if (n == 0) return;
   Span<int32_t> s = ints(src), d = ints(dst), m = ints(midx);
-  std::lock_guard<std::mutex> g(dev_->mu);
   mot_kf_task t{};
   t.mean = mean_; t.cov = cov_; t.cap = cap_; t.n = n; t.src = s.d; t.dst = d.d; t.meas = dets.d_meas; t.ldm = dets.n; t.midx = m.d;
   t.q[0] = q[0]; t.q[1] = q[1]; t.q[2] = q[2];
-  dev_->kf_upd[kind_].push_back(t);
+  dev_->q().kf_upd[kind_].push_back(t);
 }
 void Core::initiate(const std::vector<int>& dst, const std::vector<int>& midx, const Dets& dets) {
   const int n = static_cast<int>(dst.size());
   if (n == 0) return;
   Span<int32_t> d = ints(dst), m = ints(midx);
-  std::lock_guard<std::mutex> g(dev_->mu);
   mot_kf_task t{};
   t.mean = mean_; t.cov = cov_; t.cap = cap_; t.n = n; t.src = d.d; t.dst = d.d; t.meas = dets.d_meas; t.ldm = dets.n; t.midx = m.d;
-  dev_->kf_init[kind_].push_back(t);
+  dev_->q().kf_init[kind_].push_back(t);
 }
 float* Core::iou_cost(const IouArgs& a, int* ldc) {
-  std::lock_guard<std::mutex> g(dev_->mu);
   const int ld = round_up(std::max(a.m, 1), 4);
   float* cost = dev_->tmp->alloc<float>(static_cast<size_t>(std::max(a.n, 1)) * ld).d;
   mot_iou_task t{};
   t.n = a.n; t.m = a.m; t.a = a.a; t.lda = a.lda; t.aidx = a.aidx; t.b = a.b; t.ldb = a.ldb; t.bidx = a.bidx; t.bconf = a.bconf;
   t.cost = cost; t.ldc = ld; t.mode = a.mode; t.emb = a.emb; t.lde = a.lde; t.prox_thresh = a.prox; t.app_thresh = a.app; t.fuse = a.fuse;
-  dev_->iou.push_back(t);
+  dev_->q().iou.push_back(t);
   *ldc = ld;
   return cost;
 }
 Core::Lap Core::lap(const float* cost, int ldc, int n, int m, float thresh, int mode, const float* iou, int ldi, float gate, bool want_xval) {
   Lap r;
   r.n = n; r.m = m;
-  std::lock_guard<std::mutex> g(dev_->mu);
   r.x = dev_->down->alloc<int32_t>(std::max(n, 1));
   r.y = dev_->down->alloc<int32_t>(std::max(m, 1));
   r.info = dev_->down->alloc<int32_t>(4);
@@ -397,7 +462,7 @@ Core::Lap Core::lap(const float* cost, int ldc, int n, int m, float thresh, int 
   t.n = n; t.m = m; t.cost = cost; t.ldc = ldc; t.thresh = thresh; t.x = r.x.d; t.y = r.y.d; t.mode = mode; t.iou = iou; t.ldi = ldi; t.gate = gate;
   t.xval = want_xval ? r.xval.d : nullptr; t.info = r.info.d;
   t.work = dev_->tmp->alloc<char>(mot_lap_work_bytes(n, m)).d;
-  dev_->lap.push_back(t);
+  dev_->q().lap.push_back(t);
   r.queued = true;
   return r;
 }
@@ -405,7 +470,6 @@ Core::Lap Core::lap(const float* cost, int ldc, int n, int m, float thresh, int 
 Core::Lap Core::lap_geom(const IouArgs& a, float thresh, int mode, float gate, bool want_xval) {
   Lap r;
   r.n = a.n; r.m = a.m;
-  std::lock_guard<std::mutex> g(dev_->mu);
   r.x = dev_->down->alloc<int32_t>(std::max(a.n, 1));
   r.y = dev_->down->alloc<int32_t>(std::max(a.m, 1));
   r.info = dev_->down->alloc<int32_t>(4);
@@ -417,8 +481,8 @@ Core::Lap Core::lap_geom(const IouArgs& a, float thresh, int mode, float gate, b
   t.geom.n = a.n; t.geom.m = a.m; t.geom.a = a.a; t.geom.lda = a.lda; t.geom.aidx = a.aidx; t.geom.b = a.b; t.geom.ldb = a.ldb;
   t.geom.bidx = a.bidx; t.geom.bconf = a.bconf; t.geom.mode = a.mode; t.geom.emb = a.emb; t.geom.lde = a.lde;
   t.geom.prox_thresh = a.prox; t.geom.app_thresh = a.app; t.geom.fuse = a.fuse;
-  dev_->lap.push_back(t);
-  dev_->lap_geom = true;
+  dev_->q().lap.push_back(t);
+  dev_->q().lap_geom = true;
   r.queued = true;
   return r;
 }

@@ -8,6 +8,7 @@
 // Device::flush() uploads the stage's inputs in one copy, launches each non-empty kernel family
 // once over all tasks (grid dimension = task), downloads the results in one copy and syncs.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -31,7 +32,8 @@ struct Span {
   size_t n = 0;
 };
 
-// Chunked bump arena. Device addresses stay valid for the whole frame (chunks are never moved).
+// Chunked bump arena. Device addresses stay valid for the whole frame (chunks are never moved). alloc() is lock-free
+// on its fast path (one atomic add), so the stage machines of a batch can run on many host threads.
 class Arena {
  public:
   Arena(mot_ctx* ctx, size_t chunk_bytes, bool host_mirror);
@@ -44,19 +46,25 @@ class Arena {
     raw_alloc(n * sizeof(T), &h, &d);
     return Span<T>{static_cast<T*>(h), static_cast<T*>(d), n};
   }
-  void reset();       // frame boundary
-  void mark();        // stage boundary: [mark, top) is what the next transfer moves
-  void upload();      // host -> device for [mark, top) of every chunk, then mark()
-  void download();    // device -> host for [mark, top) of every chunk, then mark()
+  void reset();       // frame boundary (single-threaded)
+  void upload();      // host -> device for everything allocated since the last transfer (single-threaded)
+  void download();    // device -> host for everything allocated since the last transfer (single-threaded)
+  void clear_pending(); // memset(0) on the device for everything allocated since the last transfer (no mark change)
   size_t bytes_in_flight() const;
  private:
-  struct Chunk { char* h; char* d; size_t cap, top, mark; };
+  struct Chunk {
+    char* h = nullptr; char* d = nullptr; size_t cap = 0;
+    std::atomic<size_t> top{0};
+    size_t mark = 0;
+  };
   void raw_alloc(size_t bytes, void** h, void** d);
   mot_ctx* ctx_;
   size_t chunk_bytes_;
   bool host_;
-  std::vector<Chunk> chunks_;
-  size_t cur_ = 0;
+  std::vector<std::unique_ptr<Chunk>> chunks_;  // grows under grow_mu_ only; readers index below n_chunks_
+  std::atomic<size_t> cur_{0};
+  std::atomic<size_t> n_chunks_{0};
+  std::mutex grow_mu_;
 };
 
 struct StageCounters {
@@ -83,17 +91,26 @@ class Device {
   mot_ctx* ctx = nullptr;
   int index = 0;
   std::unique_ptr<Arena> up, down, tmp;
-  std::mutex mu;  // guards arenas + task lists when trackers of a batch are stepped from several threads
+  std::unique_ptr<Arena> zdown;  // like `down`, but the device side is zeroed before the stage's kernels run (atomic counters)
 
-  // task lists of the current stage (host copies; flush() moves them to the device)
-  std::vector<mot_det_task> det[3];
-  std::vector<mot_kf_task> kf_init[3], kf_upd[3], kf_pred[3], kf_box[3];
-  std::vector<mot_feat_task> feat_set, feat_ema;
-  std::vector<mot_cos_task> cos;
-  std::vector<mot_iou_task> iou;
-  std::vector<mot_ocsort_task> oc;
-  std::vector<mot_lap_task> lap;
-  bool lap_geom = false;  // some queued LAP task carries on-the-fly geometry
+  // Task lists of the current stage (host copies; flush() concatenates them and moves them to the device). One set
+  // per host thread: a stage machine appends to the set of the thread it runs on, without locking.
+  struct TaskLists {
+    std::vector<mot_det_task> det[3];
+    std::vector<mot_kf_task> kf_init[3], kf_upd[3], kf_pred[3], kf_box[3];
+    std::vector<mot_feat_task> feat_set, feat_ema;
+    std::vector<mot_cos_task> cos;
+    std::vector<mot_iou_task> iou;
+    std::vector<mot_ocsort_task> oc;
+    std::vector<mot_lap_task> lap;
+    bool lap_geom = false;  // some queued LAP task carries on-the-fly geometry
+    bool empty() const;
+    void clear();
+    void append(TaskLists& o);  // moves o's tasks behind this one's
+  };
+  static constexpr int kMaxHostThreads = 256;
+  std::vector<TaskLists> lists;  // [kMaxHostThreads]
+  TaskLists& q();                // the calling host thread's lists
 
   void begin_frame();
   bool pending() const;

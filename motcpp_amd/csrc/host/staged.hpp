@@ -18,6 +18,23 @@ struct FrameIn {
   int d_ld = 0;
 };
 
+// Set of small non-negative ints (track ids) with O(1) clear: a generation stamp per id, no hashing, no allocation
+// in steady state. The tracker lifecycles build several id sets per frame; std::unordered_set dominated host time.
+class IdSet {
+ public:
+  void clear() { ++gen_; }
+  bool insert(int id) {  // true if newly inserted
+    if (id >= static_cast<int>(stamp_.size())) stamp_.resize(static_cast<size_t>(id) * 2 + 64, 0);
+    if (stamp_[id] == gen_) return false;
+    stamp_[id] = gen_;
+    return true;
+  }
+  bool count(int id) const { return id < static_cast<int>(stamp_.size()) && stamp_[id] == gen_; }
+ private:
+  std::vector<int> stamp_;
+  int gen_ = 1;
+};
+
 struct LapRecord {
   std::vector<int> x, y;
 };
@@ -31,11 +48,13 @@ class Staged {
   virtual Core& core() = 0;
   const std::vector<float>& rows() const { return rows_; }  // output rows [x1,y1,x2,y2,id,conf,cls,det_ind]
   const std::vector<LapRecord>& laps() const { return laps_; }
+  bool record_laps = true;  // parity hook; switched off for throughput runs
   // parity hook: slots of the live tracks in list order with their ids (states are read back by the caller)
   virtual void live_tracks(std::vector<int>* ids, std::vector<int>* slots) const = 0;
 
  protected:
   void record(const Core::Lap& l) {
+    if (!record_laps) return;
     LapRecord r;
     r.x.assign(l.x.h, l.x.h + l.n);
     r.y.assign(l.y.h, l.y.h + l.m);

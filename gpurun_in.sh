@@ -1,6 +1,9 @@
-mkdir -p gpurun_out
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-for cfg in "C2 1024 1" "C2 1024 8" "C2 4096 16" "C2 4096 32"; do set -- $cfg
-  python bench.py --workload $1 --steps 30 --warmup 40 --streams $2 --threads $3 --no-cpu-baseline > gpurun_out/b.json 2> gpurun_out/b.err; python -c "
-import json;d=json.load(open('gpurun_out/b.json'));print('$1 S=$2 thr=$3 fps',round(d['value']),'ms/step',round(d['ms_per_step'],2),'busy',round(d['gpu_busy_frac'],3),'host',{k:round(v,2) for k,v in d['host_ms_per_step'].items()},'lap ms/launch',round(d['kernels']['lap']['ms_total']/d['kernels']['lap']['launches'],2))" || tail -5 gpurun_out/b.err
-done
+export TMPDIR=/tmp
+mkdir -p gpurun_out/prof_C2 gpurun_out/prof_NS
+R=$PWD
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_C2 -o c2 -- python $R/bench.py --workload C2 --steps 30 --warmup 40 --streams 2048 --no-cpu-baseline > $R/gpurun_out/prof_C2/bench.json 2> $R/gpurun_out/prof_C2/bench.err
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_NS -o ns -- python $R/bench.py --workload NS --steps 15 --warmup 30 --streams 256 --no-cpu-baseline > $R/gpurun_out/prof_NS/bench.json 2> $R/gpurun_out/prof_NS/bench.err
+cd $R
+find gpurun_out/prof_C2 gpurun_out/prof_NS -type f | head -30
+ls -la gpurun_out/prof_C2/* | head

@@ -60,6 +60,7 @@ def main():
     import torch
     import torch.distributed as dist
     from motcpp_amd import _lib as L
+    from motcpp_amd import dist as mdist
     from motcpp_amd.synth import SynthStream
 
     if not (os.path.exists(L.HIP_LIB) and os.path.exists(L.HOST_LIB)):
@@ -80,7 +81,7 @@ def main():
     host = np.zeros((F, S, M, 6), np.float32)
     embs = np.zeros((F, S, M, D), np.float32) if D else None
     for s in range(S):
-        st = SynthStream(P, M, 1234 + rank * S + s, D)
+        st = SynthStream(P, M, mdist.stream_seed(mdist.stream_ids(rank, S)[s]), D)
         for f in range(F):
             d, e = st.next_frame()
             host[f, s] = d
@@ -102,13 +103,7 @@ def main():
     def gather(out, cnt):
         # final track tables of this rank's streams -> every rank (RCCL all_gather over xGMI), padded [S, cap, 8] + counts
         nonlocal gathered
-        t = torch.from_numpy(out[:, :cap]).cuda(local, non_blocking=True)
-        c = torch.from_numpy(cnt.astype(np.int32)).cuda(local, non_blocking=True)
-        if gathered is None:
-            gathered = (torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device),
-                        torch.empty((world, S), dtype=torch.int32, device=t.device))
-        dist.all_gather_into_tensor(gathered[0], t)
-        dist.all_gather_into_tensor(gathered[1], c)
+        gathered = mdist.gather_tables(out[:, :cap], cnt.astype(np.int32), device=torch.device("cuda", local))
 
     kept = []  # stream 0 outputs of rank 0 for the parity spot check
     for f in range(W):

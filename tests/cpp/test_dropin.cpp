@@ -1,0 +1,139 @@
+// Drop-in check of the C++ surface: user code written against the reference's headers (motcpp::BaseTracker,
+// trackers::Sort/ByteTrack/OCSort/BotSort, utils::linear_assignment/iou_batch) compiles against include/motcpp/ and
+// behaves as the reference's own gtest files expect (tests/test_sort.cpp, test_bytetrack.cpp, test_trackers.cpp,
+// test_matching.cpp, test_iou.cpp, plus BaseTracker::check_inputs' exception rules, src/tracker.cpp:108-125).
+// Needs an MI355X at run time (the classes have no CPU path); compiling it needs none.
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <set>
+#include <stdexcept>
+
+#include <motcpp/motcpp.hpp>
+
+static int g_fail = 0;
+#define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #c); ++g_fail; } } while (0)
+
+using motcpp::trackers::BotSort;
+using motcpp::trackers::ByteTrack;
+using motcpp::trackers::OCSort;
+using motcpp::trackers::Sort;
+
+static Eigen::MatrixXf dets1(float x1, float y1, float x2, float y2, float c, float cls) {
+  Eigen::MatrixXf d(1, 6);
+  d << x1, y1, x2, y2, c, cls;
+  return d;
+}
+
+int main() {
+  cv::Mat img = cv::Mat::zeros(480, 640, CV_8UC3);
+  Eigen::MatrixXf single = dets1(100, 100, 200, 200, 0.9f, 0);
+  Eigen::MatrixXf multi(3, 6);
+  multi << 100, 100, 200, 200, 0.9f, 0, 300, 300, 400, 400, 0.8f, 0, 500, 100, 600, 200, 0.7f, 1;
+  Eigen::MatrixXf empty(0, 6);
+
+  {  // test_sort.cpp:36-47
+    Sort t(0.3f, 1, 50, 1);
+    auto tr = t.update(single, img);
+    CHECK(tr.cols() == 8 && tr.rows() == 1);
+    CHECK(tr(0, 2) > tr(0, 0) && tr(0, 3) > tr(0, 1));
+  }
+  {  // test_sort.cpp:49-67 (ids are per instance here: the first id of any tracker is 1)
+    Sort t(0.3f, 3, 50, 1);
+    t.update(single, img);
+    t.update(single, img);
+    auto tr = t.update(dets1(110, 110, 210, 210, 0.9f, 0), img);
+    CHECK(tr.rows() == 1 && static_cast<int>(tr(0, 4)) == 1);
+  }
+  {  // test_sort.cpp:69-84
+    Sort t(0.3f, 2, 50, 1);
+    t.update(single, img);
+    t.update(empty, img);
+    CHECK(t.update(empty, img).rows() == 0);
+  }
+  {  // test_sort.cpp:128-148
+    Sort t(0.3f, 5, 50, 1);
+    for (int i = 0; i < 5; ++i) t.update(dets1(100 + i * 10, 100 + i * 10, 200 + i * 10, 200 + i * 10, 0.9f, 0), img);
+    t.update(empty, img);
+    auto tr = t.update(dets1(160, 160, 260, 260, 0.9f, 0), img);
+    CHECK(tr.rows() == 1 && static_cast<int>(tr(0, 4)) == 1);
+  }
+  {  // test_bytetrack.cpp:125-149 / test_trackers.cpp:39-107 through the base-class pointer
+    std::unique_ptr<motcpp::BaseTracker> ts[3] = {std::make_unique<ByteTrack>(), std::make_unique<OCSort>(), std::make_unique<BotSort>()};
+    for (auto& t : ts) {
+      std::set<int> a, b;
+      for (int f = 0; f < 3; ++f) {
+        auto tr = t->update(multi, img);
+        for (int i = 0; i < tr.rows(); ++i) {
+          CHECK(tr.cols() == 8 && tr(i, 0) < tr(i, 2) && tr(i, 1) < tr(i, 3) && tr(i, 4) > 0 && tr(i, 5) >= 0 && tr(i, 5) <= 1);
+          (f == 1 ? a : b).insert(static_cast<int>(tr(i, 4)));
+        }
+      }
+      bool persisted = false;
+      for (int id : a) persisted = persisted || b.count(id);
+      CHECK(persisted);
+      t->reset();
+      CHECK(t->update(empty, img).rows() == 0);  // test_trackers.cpp:100-107 (fresh state)
+      CHECK(t->update(multi, img).cols() == 8);
+    }
+  }
+  {  // src/tracker.cpp:108-125
+    ByteTrack t;
+    bool threw = false;
+    try { t.update(Eigen::MatrixXf(2, 5), img); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    try { t.update(single, cv::Mat()); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    try { t.update(single, img, Eigen::MatrixXf(3, 8)); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    Sort s;  // SORT never calls check_inputs (sort.cpp:102-110)
+    CHECK(s.update(single, cv::Mat()).cols() == 8);
+  }
+  {  // test_matching.cpp:24-110
+    using motcpp::utils::linear_assignment;
+    Eigen::MatrixXf c1(1, 1);
+    c1 << 0.1f;
+    auto r = linear_assignment(c1, 0.5f);
+    CHECK(r.matches.size() == 1 && r.matches[0][0] == 0 && r.matches[0][1] == 0 && r.unmatched_a.empty() && r.unmatched_b.empty());
+    c1 << 0.9f;
+    r = linear_assignment(c1, 0.5f);
+    CHECK(r.matches.empty() && r.unmatched_a.size() == 1 && r.unmatched_b.size() == 1);
+    Eigen::MatrixXf c32(3, 2);
+    c32 << 0.1f, 0.9f, 0.9f, 0.1f, 0.9f, 0.9f;
+    r = linear_assignment(c32, 0.5f);
+    CHECK(r.matches.size() == 2 && r.unmatched_a.size() == 1 && r.unmatched_a[0] == 2 && r.unmatched_b.empty());
+    Eigen::MatrixXf c22(2, 2);
+    c22 << 0.1f, 0.2f, 0.3f, 0.1f;
+    r = linear_assignment(c22, 0.5f);
+    CHECK(r.matches.size() == 2 && r.matches[0][1] == 0 && r.matches[1][1] == 1);
+    r = linear_assignment(Eigen::MatrixXf(0, 0), 0.5f);
+    CHECK(r.matches.empty() && r.unmatched_a.empty() && r.unmatched_b.empty());
+  }
+  {  // test_iou.cpp:29-75
+    Eigen::MatrixXf b1(1, 4), b2(1, 4), b3(1, 4);
+    b1 << 0, 0, 100, 100;
+    b2 << 50, 50, 150, 150;
+    b3 << 200, 200, 300, 300;
+    CHECK(motcpp::utils::iou_batch(b1, b1)(0, 0) == 1.0f);
+    CHECK(motcpp::utils::iou_batch(b1, b3)(0, 0) == 0.0f);
+    CHECK(std::fabs(motcpp::utils::iou_batch(b1, b2)(0, 0) - 0.143f) < 0.01f);
+    auto e = motcpp::utils::iou_batch(Eigen::MatrixXf(0, 4), b1);
+    CHECK(e.rows() == 0 && e.cols() == 1);
+  }
+  {  // StreamBatch == the same trackers stepped one by one
+    ByteTrack a1, a2, b1, b2;
+    motcpp::StreamBatch batch({&a1, &a2});
+    for (int f = 0; f < 5; ++f) {
+      Eigen::MatrixXf d1 = multi, d2 = single;
+      d1(0, 0) += f; d1(0, 2) += f;
+      auto out = batch.update({d1, d2}, img);
+      auto r1 = b1.update(d1, img), r2 = b2.update(d2, img);
+      CHECK(out.size() == 2 && out[0].rows() == r1.rows() && out[1].rows() == r2.rows());
+      for (int i = 0; i < r1.rows(); ++i) for (int k = 0; k < 8; ++k) CHECK(out[0](i, k) == r1(i, k));
+    }
+  }
+  std::printf(g_fail ? "%d check(s) failed\n" : "drop-in ok\n", g_fail);
+  return g_fail ? 1 : 0;
+}

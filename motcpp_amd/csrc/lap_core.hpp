@@ -112,6 +112,18 @@ MOT_DEV ExtRow<Cost> ext_row(const Cost& C, const LapDims& P, int i) {
   return e;
 }
 
+// Visits the calling lane's columns (j = t, t+T, ...) of extended row view R in ascending order and hands each reduced
+// cost c = R(j) - v[j] to f(c, j). The real block (j < nc) and the dummy block (j >= nc) are separate loops so that
+// neither carries the other's branches; within a lane the order stays ascending, which the callers' tie rules rely on.
+template <class Cost, class F>
+MOT_DEV void for_lane_columns(const ExtRow<Cost>& R, const double* v, int t, int T, int nc, int n, F f) {
+  int j = t;
+  if (R.real) { for (; j < nc; j += T) f(R.r.at(j) - v[j], j); }
+  else { const double l = R.left; for (; j < nc; j += T) f(l - v[j], j); }
+  const double rr = R.right;
+  for (; j < n; j += T) f(rr - v[j], j);
+}
+
 // Compacts {i in [0,n) : flag(i)} in ascending order into out[]; returns the count (uniform).
 template <class G, class F>
 MOT_DEV int compact_ascending(G& g, int n, F flag, int* out) {
@@ -172,11 +184,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
     const int j = W.x[i];
     const ExtRow<Cost> R = ext_row(C, P, i);
     double mn = kLapLarge;
-    for (int j2 = t; j2 < n; j2 += T) {
-      if (j2 == j) continue;
-      const double c = R.at(j2) - W.v[j2];
-      if (c < mn) mn = c;
-    }
+    for_lane_columns(R, W.v, t, T, nc, n, [&](double c, int j2) { if (j2 != j && c < mn) mn = c; });
     mn = g.reduce_min(mn);
     if ((j % T) == t) W.v[j] -= mn;  // owner lane: next reader of v[j] is this same lane
   }
@@ -188,22 +196,33 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
     unsigned current = 0, rr_cnt = 0;
     int new_free = 0;
     int forwarded = -1;  // row re-queued by free_rows[--current] = i0, consumed next iteration
+    bool dc_valid = false;
+    Top2 dc = top2_empty();
     while (current < static_cast<unsigned>(nfree)) {
       ++rr_cnt;
       ++n_carr;
       const int fi = (forwarded >= 0) ? forwarded : W.fr[current];
       forwarded = -1;
       ++current;
-      const ExtRow<Cost> R = ext_row(C, P, fi);
-      Top2 tt = top2_empty();
-      for (int j = t; j < n; j += T) {
-        const double c = R.at(j) - W.v[j];
-        if (c < tt.v2) {  // a lane visits its columns in ascending order: strict < keeps the lowest index on ties
-          if (c < tt.v1) { tt.v2 = tt.v1; tt.j2 = tt.j1; tt.v1 = c; tt.j1 = j; }
-          else { tt.v2 = c; tt.j2 = j; }
-        }
+      // Dummy rows (fi >= nr) all have the same cost row, so while no dual changes their top-2 is the same tuple:
+      // it is reduced once and reused until some v[j] is written (the extension makes these rounds a large share).
+      const bool dummy_row = fi >= nr;
+      Top2 tt;
+      if (dummy_row && dc_valid) {
+        tt = dc;
+        g.sync();  // stands in for the reduction's barrier: last round's owner writes are visible before y/v are read
+      } else {
+        const ExtRow<Cost> R = ext_row(C, P, fi);
+        tt = top2_empty();
+        for_lane_columns(R, W.v, t, T, nc, n, [&](double c, int j) {
+          if (c < tt.v2) {  // a lane visits its columns in ascending order: strict < keeps the lowest index on ties
+            if (c < tt.v1) { tt.v2 = tt.v1; tt.j2 = tt.j1; tt.v1 = c; tt.j1 = j; }
+            else { tt.v2 = c; tt.j2 = j; }
+          }
+        });
+        tt = g.reduce_top2(tt);
+        if (dummy_row) { dc = tt; dc_valid = true; }
       }
-      tt = g.reduce_top2(tt);
       int j1 = tt.j1, j2 = tt.j2;
       double v1 = tt.v1, v2 = tt.v2;
       if (!(v2 < kLapLarge)) { v2 = kLapLarge; j2 = -1; }
@@ -214,7 +233,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
       const double v1_new = vj1 - (v2 - v1);
       const bool lowers = v1_new < vj1;
       if (rr_cnt < current * static_cast<unsigned>(n)) {
-        if (lowers) { if ((j1 % T) == t) W.v[j1] = v1_new; }
+        if (lowers) { if ((j1 % T) == t) W.v[j1] = v1_new; dc_valid = false; }
         else if (i0 >= 0 && j2 >= 0) { j1 = j2; i0 = yj2; }
         if (i0 >= 0) {
           if (lowers) { --current; if (t == 0) W.fr[current] = i0; forwarded = i0; }
@@ -234,24 +253,35 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
 
   long long c3 = MOT_CLOCK();
   // ---- phase 3: augmentation (_ca_dense, :195-211) ----
+  bool da_valid = false;  // dummy-start cache: valid while no dual has changed (single-step paths never change duals)
+  double da_g0 = 0.0;
+  int da_ptr = -1;        // this lane's largest column that may still be a free member of the tied-minimum set
   for (int f = 0; f < nfree; ++f) {
     const int start = W.fr[f];
     ++n_paths;
     const ExtRow<Cost> R0 = ext_row(C, P, start);
-    double mn = 1e300;
-    for (int j = t; j < n; j += T) {
-      const double dj = R0.at(j) - W.v[j];
-      if (dj < mn) mn = dj;
+    const bool dummy_row = start >= nr;
+    int final_j;
+    if (dummy_row && da_valid) {
+      // Same cost row and same duals as the last dummy start: the tied-minimum set is unchanged and only shrinks as
+      // columns get assigned, so each lane just walks its own candidate pointer down to its next free tied column.
+      while (da_ptr >= 0 && !((((da_ptr < nc) ? R0.left : R0.right) - W.v[da_ptr]) == da_g0 && W.y[da_ptr] < 0)) da_ptr -= T;
+      if (da_ptr < 0) da_ptr = -1;
+      final_j = g.reduce_max(da_ptr);
+    } else {
+      double mn = 1e300;
+      for_lane_columns(R0, W.v, t, T, nc, n, [&](double dj, int) { if (dj < mn) mn = dj; });
+      const double g0 = g.reduce_min(mn);
+      // First _find_dense from cols = identity leaves the tied-minimum columns in ascending
+      // order in [0,hi) and the sink test (:174-177) keeps the LAST free one.
+      int cand = -1;
+      for_lane_columns(R0, W.v, t, T, nc, n, [&](double dj, int j) { if (dj == g0 && W.y[j] < 0) cand = j; });
+      final_j = g.reduce_max(cand);
+      if (dummy_row) { da_valid = true; da_g0 = g0; da_ptr = cand; }
     }
-    const double g0 = g.reduce_min(mn);
-    // First _find_dense from cols = identity leaves the tied-minimum columns in ascending
-    // order in [0,hi) and the sink test (:174-177) keeps the LAST free one.
-    int cand = -1;
-    for (int j = t; j < n; j += T)
-      if ((R0.at(j) - W.v[j]) == g0 && W.y[j] < 0 && j > cand) cand = j;
-    int final_j = g.reduce_max(cand);
     if (final_j < 0) {
       // ---- general path: exact emulation of find_path_dense (:157-193) ----
+      da_valid = false;  // the dual update below changes v
       for (int j = t; j < n; j += T) { W.cols[j] = j; W.pred[j] = start; W.d[j] = R0.at(j) - W.v[j]; }
       g.sync();
       unsigned lo = 0, hi = 0, n_ready = 0;

@@ -85,6 +85,8 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
   return path;
 }
 
+// lds_mode 3 = lean: duals v[] and y[] in LDS, everything else (x, free list, boxes) in global scratch / L2 —
+// 12 B of LDS per extended row, so ~8 north-star-sized problems stay resident per CU.
 // lds_mode (compile-time, so every pointer has a static address space — a run-time choice makes the compiler fall back
 // to flat_* instructions for the LDS state, which costs hundreds of cycles per dependent access): 0 = solver state in global scratch, 1 = hot state + column boxes in LDS (row boxes
 // in global scratch), 2 = hot state + column boxes + row boxes in LDS.
@@ -106,18 +108,22 @@ __global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __res
   const size_t hot_b = (mot::lap_hot_bytes(n) + 15) & ~size_t(15), cold_b = (mot::lap_cold_bytes(n) + 15) & ~size_t(15);
   mot::LapWork W;
   char* lds = smem + kScratch;
-  if constexpr (lds_mode >= 1) { mot::lap_carve_hot(W, lds, n); lds += hot_b; }
+  if constexpr (lds_mode == 1 || lds_mode == 2) { mot::lap_carve_hot(W, lds, n); lds += hot_b; }
   else mot::lap_carve_hot(W, gw, n);
+  if constexpr (lds_mode == 3) {  // lean: only the per-column duals and column->row map in LDS (12 B per extended row)
+    W.v = reinterpret_cast<double*>(lds);
+    W.y = reinterpret_cast<int*>(lds + sizeof(double) * static_cast<size_t>(n));
+  }
   mot::lap_carve_cold(W, gw + hot_b, n);
   W.cyc = T.prof;
   int path;
   if (T.geom.a != nullptr) {
     float* gbox = reinterpret_cast<float*>(gw + hot_b + cold_b);
     float* cp;
-    if constexpr (lds_mode >= 1) cp = reinterpret_cast<float*>(lds); else cp = gbox + 5 * nr;
+    if constexpr (lds_mode == 1 || lds_mode == 2) cp = reinterpret_cast<float*>(lds); else cp = gbox + 5 * nr;
     float* cf = cp + 5 * nc;
     float* rp;
-    if constexpr (lds_mode >= 2) rp = cf + nc; else rp = gbox;
+    if constexpr (lds_mode == 2) rp = cf + nc; else rp = gbox;
     const mot_iou_task& G = T.geom;
     for (int i = t; i < nr; i += kThreads) {
       const int gi = G.aidx ? G.aidx[i] : i;
@@ -165,7 +171,8 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   static bool attr_set = false;
   if (!attr_set) {
     const void* fns[] = {reinterpret_cast<const void*>(&lap_kernel<64, 1>), reinterpret_cast<const void*>(&lap_kernel<64, 2>),
-                         reinterpret_cast<const void*>(&lap_kernel<256, 1>), reinterpret_cast<const void*>(&lap_kernel<256, 2>)};
+                         reinterpret_cast<const void*>(&lap_kernel<64, 3>), reinterpret_cast<const void*>(&lap_kernel<256, 1>),
+                         reinterpret_cast<const void*>(&lap_kernel<256, 2>), reinterpret_cast<const void*>(&lap_kernel<256, 3>)};
     for (const void* f : fns) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
       if (e != hipSuccess) return e;
@@ -176,15 +183,17 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   const size_t hot = (lap_hot_bytes(nm) + 15) & ~size_t(15);
   const size_t b1 = kScratch + hot + (geom ? 24 * m + 16 : 0);
   const size_t b2 = b1 + (geom ? 20 * n + 16 : 0);
+  const size_t b3 = kScratch + 12 * nm + 16;
   int mode;
   size_t lds;
-  if (b2 <= 40 * 1024) { mode = 2; lds = b2; }           // >= 4 problems per CU with everything in LDS
+  if (b2 <= 18 * 1024) { mode = 2; lds = b2; }            // everything in LDS and still >= 8 problems per CU
+  else if (b3 <= 40 * 1024) { mode = 3; lds = b3; }       // lean: duals + y in LDS, >= 4 (typically 8) problems per CU
   else if (b1 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 1; lds = b1; }
   else { mode = 0; lds = kScratch; }
   const bool wide = (nm > 3072) && (ntasks < 512);
 #define MOT_LAUNCH(T, M) hipLaunchKernelGGL((lap_kernel<T, M>), dim3(ntasks), dim3(T), lds, st, tasks)
-  if (wide) { if (mode == 2) MOT_LAUNCH(256, 2); else if (mode == 1) MOT_LAUNCH(256, 1); else MOT_LAUNCH(256, 0); }
-  else { if (mode == 2) MOT_LAUNCH(64, 2); else if (mode == 1) MOT_LAUNCH(64, 1); else MOT_LAUNCH(64, 0); }
+  if (wide) { if (mode == 2) MOT_LAUNCH(256, 2); else if (mode == 3) MOT_LAUNCH(256, 3); else if (mode == 1) MOT_LAUNCH(256, 1); else MOT_LAUNCH(256, 0); }
+  else { if (mode == 2) MOT_LAUNCH(64, 2); else if (mode == 3) MOT_LAUNCH(64, 3); else if (mode == 1) MOT_LAUNCH(64, 1); else MOT_LAUNCH(64, 0); }
 #undef MOT_LAUNCH
   return hipGetLastError();
 }

@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (0: workload default)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for the per-stream lifecycle (0: all cores, max 16)")
     ap.add_argument("--gather-every", type=int, default=8)
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="split a rank's streams into this many sub-batches with their own HIP stream, stepped concurrently so one's host lifecycle overlaps another's kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -92,13 +94,39 @@ def main():
     torch.cuda.synchronize()
     frame_bytes = S * 6 * M * 4
 
-    batch = L.Batch(tracker, S, device=local, threads=threads, record_laps=False)
+    if args.pipeline <= 0:
+        args.pipeline = 1 if args.workload in ("C2", "SORT") else 2  # C2 is host-bound (more host threads per batch win), the rest GPU-bound
+    PIPE = max(1, min(args.pipeline, S))
+    bounds = [S * p // PIPE for p in range(PIPE + 1)]
+    batches = [L.Batch(tracker, bounds[p + 1] - bounds[p], device=local, threads=max(1, threads // PIPE), record_laps=False,
+                       private_device=PIPE > 1) for p in range(PIPE)]
     cap = max(2 * M, 64)
     gathered = None
+    out_all = np.zeros((S, cap, 8), np.float32)
+    cnt_all = np.zeros(S, np.int32)
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(PIPE) if PIPE > 1 else None
+
+    def sub_step(p, f):
+        s0, s1 = bounds[p], bounds[p + 1]
+        o, c = batches[p].step(host[f, s0:s1], embs=embs[f, s0:s1] if D else None, cap=cap,
+                               resident_ptr=dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4)
+        out_all[s0:s1] = o[:, :cap]
+        cnt_all[s0:s1] = c
 
     def step(f):
-        out, cnt = batch.step(host[f], embs=embs[f] if D else None, cap=cap, resident_ptr=dev_dets.data_ptr() + f * frame_bytes)
-        return out, cnt
+        if pool is None:
+            sub_step(0, f)
+        else:
+            list(pool.map(lambda p: sub_step(p, f), range(PIPE)))
+        return out_all, cnt_all
+
+    def counters():
+        tot = {}
+        for b in batches:
+            for k, v in b.counters().items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
 
     def gather(out, cnt):
         # final track tables of this rank's streams -> every rank (RCCL all_gather over xGMI), padded [S, cap, 8] + counts
@@ -114,8 +142,9 @@ def main():
         gather(out, cnt)
         dist.barrier()
     torch.cuda.synchronize()
-    L.profile(True, local)
-    c0 = batch.counters()
+    for b in batches:
+        b.profile(True)
+    c0 = counters()
     t0 = time.perf_counter()
     for k in range(K):
         out, cnt = step(W + k)
@@ -127,9 +156,14 @@ def main():
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    stats = L.profile_stats(local)
-    L.profile(False, local)
-    c1 = batch.counters()
+    stats = {}
+    for b in batches:
+        for k, v in b.profile_stats().items():
+            a = stats.setdefault(k, {"ms": 0.0, "launches": 0, "tasks": 0, "bytes": 0.0, "flops": 0.0})
+            for kk in a:
+                a[kk] += v[kk]
+        b.profile(False)
+    c1 = counters()
     elapsed = t1 - t0
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
@@ -208,7 +242,7 @@ def main():
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "tracker": tracker, "tracks": P, "dets_per_frame": M, "emb_dim": D,
-                   "streams_per_gpu": S, "frames_per_step": world * S, "host_threads": threads,
+                   "streams_per_gpu": S, "frames_per_step": world * S, "host_threads": threads, "sub_batches": PIPE,
                    "parallelism": f"{world} GPU(s) x {S} independent streams, lockstep stages",
                    "inputs": "detections resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity,

@@ -32,6 +32,11 @@ int motcpp_tracker_dump_states(motcpp_tracker* t, float* out, int cap_floats, in
 
 /* S independent streams stepped in lockstep on one GPU (one kernel launch per kernel family per stage). */
 motcpp_batch* motcpp_batch_create(int kind, const float* params, int nparams, int nstreams, int device);
+/* same, but with its own device context (HIP stream + arenas): several batches can then be stepped concurrently from
+ * different host threads, overlapping one batch's host lifecycle with another's kernels */
+motcpp_batch* motcpp_batch_create_private(int kind, const float* params, int nparams, int nstreams, int device);
+int motcpp_batch_profile(motcpp_batch* b, int enable);
+int motcpp_batch_profile_stats(motcpp_batch* b, double* out_rows5, int cap_rows);
 void motcpp_batch_destroy(motcpp_batch* b);
 /* dets: [S][max_n][6] with counts[s] valid rows; embs: [S][max_n][d] or NULL; out: [S][cap][8]; out_counts: [S].
  * threads: host threads used for the per-stream lifecycle work (<= 1: caller thread only). */

@@ -170,6 +170,10 @@ def host():
         H.motcpp_tracker_dump_states.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         H.motcpp_batch_create.restype = C.c_void_p
         H.motcpp_batch_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        H.motcpp_batch_create_private.restype = C.c_void_p
+        H.motcpp_batch_create_private.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        H.motcpp_batch_profile.argtypes = [C.c_void_p, C.c_int]
+        H.motcpp_batch_profile_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         H.motcpp_batch_destroy.argtypes = [C.c_void_p]
         H.motcpp_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         H.motcpp_batch_step_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
@@ -263,11 +267,12 @@ class _Borrowed(_Hooks):
 class Batch:
     """S independent streams stepped in lockstep on one GPU (motcpp::StreamBatch)."""
 
-    def __init__(self, kind, nstreams, params=None, device=0, threads=1, record_laps=True):
+    def __init__(self, kind, nstreams, params=None, device=0, threads=1, record_laps=True, private_device=False):
         kind = KIND.get(kind, kind)
         p = f32(params if params is not None else [])
         self.S = int(nstreams)
-        self.h = host().motcpp_batch_create(int(kind), _p(p) if p.size else None, int(p.size), self.S, int(device))
+        create = host().motcpp_batch_create_private if private_device else host().motcpp_batch_create
+        self.h = create(int(kind), _p(p) if p.size else None, int(p.size), self.S, int(device))
         if not self.h:
             raise MotError("batch create failed: " + _err())
         host().motcpp_batch_set_threads(self.h, int(threads))
@@ -285,6 +290,15 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+    def profile(self, enable):
+        host().motcpp_batch_profile(self.h, 1 if enable else 0)
+
+    def profile_stats(self):
+        a = np.zeros((len(FAMILIES), 5), np.float64)
+        host().motcpp_batch_profile_stats(self.h, _p(a), len(FAMILIES))
+        return {FAMILIES[i]: {"ms": a[i, 0], "launches": int(a[i, 1]), "tasks": int(a[i, 2]), "bytes": a[i, 3], "flops": a[i, 4]}
+                for i in range(len(FAMILIES))}
 
     def stream(self, s):
         return _Borrowed(host().motcpp_batch_tracker(self.h, int(s)))

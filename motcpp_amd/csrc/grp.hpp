@@ -141,6 +141,30 @@ struct DevGroup {
     for (int w = 1; w < nw; ++w) r = top2_merge(r, s[w]);
     return r;
   }
+  // exclusive prefix minimum over thread ids (threads with no predecessor get +inf); general-path helper
+  __device__ __forceinline__ double exclusive_scan_min(double v) {
+    const int lane = tid_ & 63;
+    double inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int lo = __double2loint(inc), hi = __double2hiint(inc);
+      lo = __shfl_up(lo, d, 64); hi = __shfl_up(hi, d, 64);
+      const double o = __hiloint2double(hi, lo);
+      if (lane >= d && o < inc) inc = o;
+    }
+    // exclusive within the wavefront: value of the previous lane's inclusive scan
+    int lo = __double2loint(inc), hi = __double2hiint(inc);
+    lo = __shfl_up(lo, 1, 64); hi = __shfl_up(hi, 1, 64);
+    double ex = (lane == 0) ? 1e300 : __hiloint2double(hi, lo);
+    const int nw = (size_ + 63) >> 6;
+    if (nw > 1) {
+      double* s = slot<double>();
+      if (lane == 63) s[tid_ >> 6] = inc;
+      __syncthreads();
+      for (int w = 0; w < (tid_ >> 6); ++w) { const double o = s[w]; if (o < ex) ex = o; }
+    }
+    return ex;
+  }
   // exclusive prefix sum of one int per thread; *total gets the group sum
   __device__ __forceinline__ int exclusive_scan(int v, int* total) {
     const int lane = tid_ & 63;

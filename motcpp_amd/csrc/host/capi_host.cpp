@@ -122,10 +122,10 @@ int motcpp_tracker_dump_states(motcpp_tracker* t, float* out, int cap_floats, in
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 
-motcpp_batch* motcpp_batch_create(int kind, const float* params, int nparams, int nstreams, int device) {
+static motcpp_batch* batch_create(int kind, const float* params, int nparams, int nstreams, int device, bool private_dev) {
   try {
     auto b = std::make_unique<motcpp_batch>();
-    b->dev = Device::shared(device);
+    b->dev = private_dev ? std::make_shared<Device>(device) : Device::shared(device);
     for (int s = 0; s < nstreams; ++s) {
       auto t = std::make_unique<motcpp_tracker>();
       t->dev = b->dev;
@@ -135,6 +135,22 @@ motcpp_batch* motcpp_batch_create(int kind, const float* params, int nparams, in
     b->colmajor.resize(nstreams);
     return b.release();
   } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+motcpp_batch* motcpp_batch_create(int kind, const float* params, int nparams, int nstreams, int device) {
+  return batch_create(kind, params, nparams, nstreams, device, false);
+}
+motcpp_batch* motcpp_batch_create_private(int kind, const float* params, int nparams, int nstreams, int device) {
+  return batch_create(kind, params, nparams, nstreams, device, true);
+}
+int motcpp_batch_profile(motcpp_batch* b, int enable) { b->dev->profile = enable != 0; if (enable) b->dev->reset_stats(); return 0; }
+int motcpp_batch_profile_stats(motcpp_batch* b, double* out, int cap_rows) {
+  const int n = F_COUNT < cap_rows ? F_COUNT : cap_rows;
+  for (int f = 0; f < n; ++f) {
+    const FamilyStat& s = b->dev->stats[f];
+    out[f * 5 + 0] = s.ms; out[f * 5 + 1] = static_cast<double>(s.launches); out[f * 5 + 2] = static_cast<double>(s.tasks);
+    out[f * 5 + 3] = s.bytes; out[f * 5 + 4] = s.flops;
+  }
+  return n;
 }
 void motcpp_batch_destroy(motcpp_batch* b) { delete b; }
 int motcpp_batch_set_threads(motcpp_batch* b, int threads) { b->threads = threads < 1 ? 1 : threads; return 0; }
@@ -156,6 +172,8 @@ static int batch_step_impl(motcpp_batch* b, const float* dets, const int* counts
     const int S = static_cast<int>(b->trk.size());
     std::vector<FrameIn> in(S);
     std::vector<Staged*> st(S);
+    const int thr = b->threads;
+#pragma omp parallel for num_threads(thr) schedule(static) if (thr > 1 && S > 8)
     for (int s = 0; s < S; ++s) {
       to_colmajor(dets + static_cast<size_t>(s) * max_n * 6, counts[s], b->colmajor[s]);
       in[s] = frame_in(b->colmajor[s], counts[s], embs ? embs + static_cast<size_t>(s) * max_n * d : nullptr, d);
@@ -164,11 +182,14 @@ static int batch_step_impl(motcpp_batch* b, const float* dets, const int* counts
     }
     run_frame(*b->dev, st.data(), in.data(), S, b->threads);
     b->frames += S;
+    int bad = 0;
+#pragma omp parallel for num_threads(thr) schedule(static) reduction(| : bad) if (thr > 1 && S > 8)
     for (int s = 0; s < S; ++s) {
       const int m = copy_rows(st[s]->rows(), out + static_cast<size_t>(s) * cap * 8, cap);
-      if (m < 0) { g_err = "output capacity too small"; return m; }
-      out_counts[s] = m;
+      if (m < 0) bad |= 1;
+      else out_counts[s] = m;
     }
+    if (bad) { g_err = "output capacity too small"; return -1; }
     return S;
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }

@@ -33,11 +33,13 @@ namespace mot {
 // MatrixCost reads a materialised float matrix; IouCost (lap_cost.hpp) recomputes IoU-family costs from boxes
 // staged in LDS, so the N x M matrix never exists in memory.
 struct MatrixCost {
+  static constexpr int kRPL = 0;  // no lane-owned column cache
   const float* cost;  // nr x nc, row-major, leading dimension ld
   int ld;
   struct Row {
     const float* p;
     MOT_DEV double at(int j) const { return static_cast<double>(p[j]); }
+    MOT_DEV double at_owned(int, int j) const { return at(j); }
   };
   MOT_DEV Row row(int i) const { return Row{cost + static_cast<size_t>(i) * ld}; }
   MOT_DEV double at(int i, int j) const { return static_cast<double>(cost[static_cast<size_t>(i) * ld + j]); }
@@ -118,8 +120,19 @@ MOT_DEV ExtRow<Cost> ext_row(const Cost& C, const LapDims& P, int i) {
 template <class Cost, class F>
 MOT_DEV void for_lane_columns(const ExtRow<Cost>& R, const double* v, int t, int T, int nc, int n, F f) {
   int j = t;
-  if (R.real) { for (; j < nc; j += T) f(R.r.at(j) - v[j], j); }
-  else { const double l = R.left; for (; j < nc; j += T) f(l - v[j], j); }
+  if (R.real) {
+    if constexpr (Cost::kRPL > 0) {  // lane-owned column boxes in registers: fully unrolled, no box loads
+#pragma unroll
+      for (int k = 0; k < Cost::kRPL; ++k) {
+        const int jj = t + k * T;
+        if (jj < nc) f(R.r.at_owned(k, jj) - v[jj], jj);
+      }
+      for (int jj = t + Cost::kRPL * T; jj < nc; jj += T) f(R.r.at(jj) - v[jj], jj);  // columns beyond the register cache
+      j = t + ((nc > t) ? ((nc - t + T - 1) / T) * T : 0);
+    } else {
+      for (; j < nc; j += T) f(R.r.at(j) - v[j], j);
+    }
+  } else { const double l = R.left; for (; j < nc; j += T) f(l - v[j], j); }
   const double rr = R.right;
   for (; j < n; j += T) f(rr - v[j], j);
 }
@@ -153,23 +166,58 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
   // ---- phase 1: column reduction + reduction transfer (_ccrrt_dense, :36-72) ----
   for (int i = t; i < n; i += T) { W.x[i] = -1; W.fr[i] = 0; }
   g.sync();
-  for (int j = t; j < n; j += T) {
-    double vm = kLapLarge;
-    int im = 0;
-    if (j < nc) {
-      for (int i = 0; i < nr; ++i) {
-        const double c = C.at(i, j);
-        if (c < vm) { vm = c; im = i; }
-      }
-      if (half < vm) { vm = half; im = nr; }  // rows nr.. are all `half`: only the first can win
-    } else {
-      if (half < vm) { vm = half; im = 0; }   // rows 0..nr-1 are all `half`
-      if (0.0 < vm) { vm = 0.0; im = nr; }    // rows nr.. are all 0
-    }
+  auto publish_column = [&](int j, double vm, int im) {
     W.v[j] = vm;
     W.y[j] = im;
     G::atomic_max(&W.x[im], j);   // x[i] = largest column whose minimum sits in row i (:47-55)
     G::atomic_add(&W.fr[im], 1);
+  };
+  int j_first = t;  // first column of this lane not handled by the register-cached sweep below
+  if constexpr (Cost::kRPL > 0) {
+    // all of the lane's cached real columns advance together down the rows: one row-box fetch per row, no column loads
+    double vmk[Cost::kRPL];
+    int imk[Cost::kRPL];
+#pragma unroll
+    for (int k = 0; k < Cost::kRPL; ++k) { vmk[k] = kLapLarge; imk[k] = 0; }
+    for (int i = 0; i < nr; ++i) {
+      const typename Cost::Row R = C.row(i);
+#pragma unroll
+      for (int k = 0; k < Cost::kRPL; ++k) {
+        const int jj = t + k * T;
+        if (jj < nc) {
+          const double c = R.at_owned(k, jj);
+          if (c < vmk[k]) { vmk[k] = c; imk[k] = i; }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < Cost::kRPL; ++k) {
+      const int jj = t + k * T;
+      if (jj < nc) {
+        double vm = vmk[k];
+        int im = imk[k];
+        if (half < vm) { vm = half; im = nr; }  // rows nr.. are all `half`: only the first can win
+        publish_column(jj, vm, im);
+      }
+    }
+    j_first = t + Cost::kRPL * T;
+  }
+  for (int j = j_first; j < nc; j += T) {  // real columns outside the register cache (or all of them without one)
+    double vm = kLapLarge;
+    int im = 0;
+    for (int i = 0; i < nr; ++i) {
+      const double c = C.at(i, j);
+      if (c < vm) { vm = c; im = i; }
+    }
+    if (half < vm) { vm = half; im = nr; }
+    publish_column(j, vm, im);
+  }
+  for (int j = t + ((nc > t) ? ((nc - t + T - 1) / T) * T : 0); j < n; j += T) {  // dummy columns
+    double vm = kLapLarge;
+    int im = 0;
+    if (half < vm) { vm = half; im = 0; }   // rows 0..nr-1 are all `half`
+    if (0.0 < vm) { vm = 0.0; im = nr; }    // rows nr.. are all 0
+    publish_column(j, vm, im);
   }
   g.sync();
   long long c1 = MOT_CLOCK();
@@ -288,25 +336,46 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
       while (final_j == -1) {
         if (lo == hi) {
           n_ready = lo;
-          if (t == 0) {  // _find_dense (:115-127), sequential: order of cols[] matters
-            unsigned h2 = lo + 1;
-            double mind = W.d[W.cols[lo]];
-            for (unsigned k = h2; k < static_cast<unsigned>(n); ++k) {
-              const int j = W.cols[k];
-              const double dj = W.d[j];
-              if (dj <= mind) {
+          // _find_dense (:115-127). Its outcome depends on the ORDER of cols[], which only changes at positions whose
+          // value is <= the running minimum ("weak records") — and the values it reads are those of the cols[] order
+          // at entry (a swap never touches a position still to be read). So: find the records in parallel (chunk
+          // minima -> exclusive prefix-min -> re-scan), compact them in order, and let one lane replay only those.
+          {
+            const int first = static_cast<int>(lo) + 1, cnt = n - first;
+            const double m0 = W.d[W.cols[lo]];
+            const int L = (cnt + T - 1) / T;
+            const int b = first + t * L, e = (b + L < n) ? b + L : n;
+            double cm = 1e300;
+            for (int k = b; k < e; ++k) { const double dj = W.d[W.cols[k]]; if (dj < cm) cm = dj; }
+            double run = g.exclusive_scan_min(cm);
+            if (m0 < run) run = m0;
+            for (int k = b; k < e; ++k) {
+              const double dj = W.d[W.cols[k]];
+              int rec = 0;
+              if (dj <= run) { rec = 1; if (dj < run) run = dj; }
+              W.tmp[k] = rec;
+            }
+            g.sync();
+            const int nrec = compact_ascending(g, cnt, [&](int q) { return W.tmp[first + q] != 0; }, W.lst);
+            if (t == 0) {
+              unsigned h2 = lo + 1;
+              double mind = m0;
+              for (int r = 0; r < nrec; ++r) {
+                const int k = first + W.lst[r];
+                const int j = W.cols[k];
+                const double dj = W.d[j];
                 if (dj < mind) { h2 = lo; mind = dj; }
                 W.cols[k] = W.cols[h2];
                 W.cols[h2++] = j;
               }
+              int fj = -1;
+              for (unsigned k = lo; k < h2; ++k) {
+                const int j = W.cols[k];
+                if (W.y[j] < 0) fj = j;
+              }
+              W.tmp[0] = static_cast<int>(h2);
+              W.tmp[1] = fj;
             }
-            int fj = -1;
-            for (unsigned k = lo; k < h2; ++k) {
-              const int j = W.cols[k];
-              if (W.y[j] < 0) fj = j;
-            }
-            W.tmp[0] = static_cast<int>(h2);
-            W.tmp[1] = fj;
           }
           g.sync();
           hi = static_cast<unsigned>(W.tmp[0]);
@@ -324,7 +393,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
             const ExtRow<Cost> R = ext_row(C, P, i);
             const double h = R.at(jq) - W.v[jq] - mind;
             g.sync();
-            int first_sink = kNoIdx;
+            int first_sink = kNoIdx, any_tie = 0;
             for (int k = static_cast<int>(shi) + t; k < n; k += T) {
               const int j = W.cols[k];
               const double cred = R.at(j) - W.v[j] - h;
@@ -334,6 +403,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
                 W.pred[j] = i;
                 if (cred == mind) {
                   flag = 1;
+                  any_tie = 1;
                   if (W.y[j] < 0 && k < first_sink) first_sink = k;
                 }
               }
@@ -347,13 +417,16 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
               break;
             }
             const int base = static_cast<int>(shi);
-            const int nt = compact_ascending(g, n - base, [&](int q) { return W.tmp[base + q] != 0; }, W.lst);
-            if (t == 0) {
-              for (int q = 0; q < nt; ++q) {  // ties join the SCAN set in ascending k (:146-147)
-                const int k = base + W.lst[q];
-                const int j = W.cols[k];
-                W.cols[k] = W.cols[shi + q];
-                W.cols[shi + q] = j;
+            int nt = 0;
+            if (g.reduce_max(any_tie) > 0) {  // ties are rare on real-valued costs: skip the ordered compaction without them
+              nt = compact_ascending(g, n - base, [&](int q) { return W.tmp[base + q] != 0; }, W.lst);
+              if (t == 0) {
+                for (int q = 0; q < nt; ++q) {  // ties join the SCAN set in ascending k (:146-147)
+                  const int k = base + W.lst[q];
+                  const int j = W.cols[k];
+                  W.cols[k] = W.cols[shi + q];
+                  W.cols[shi + q] = j;
+                }
               }
             }
             shi += static_cast<unsigned>(nt);

@@ -18,24 +18,47 @@ struct BoxPlanes {
   }
 };
 
-struct IouCost {
+// RPL = lane-owned real columns kept in registers (column j = t + k*T belongs to lane t, k < RPL); 0 = none.
+// The solver's row passes only ever touch a lane's own columns, so with RPL > 0 a pass reads no box from memory at
+// all: the row box sits in registers for the pass, the column boxes for the whole solve. `cols` (memory) still backs the
+// rare arbitrary-column accesses (general path search, result read-out).
+template <int RPL>
+struct IouCostT {
+  static constexpr int kRPL = RPL;
   BoxPlanes rows, cols;
   const float* conf;  // [nc] or nullptr
   CostParams prm;
   const float* emb;   // nr x nc cosine distances (global memory) or nullptr
   int lde;
+  struct Owned { float b[4], area, conf; };
+  Owned own[RPL > 0 ? RPL : 1];
+  MOT_DEV void load_owned(int t, int T, int nc) {
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+      const int j = t + k * T;
+      Owned o{{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f};
+      if (j < nc) { cols.load(j, o.b, &o.area); o.conf = conf ? conf[j] : 0.0f; }
+      own[k] = o;
+    }
+  }
   struct Row {
-    const IouCost* c;
+    const IouCostT* c;
     int i;
     float a[4], area;
-    MOT_DEV double at(int j) const {
-      float b[4], barea;
-      c->cols.load(j, b, &barea);
+    MOT_DEV double eval(const float b[4], float barea, float cf, int j) const {
       const float iou = iou_pair(a, area, b, barea);
-      const float cf = c->conf ? c->conf[j] : 0.0f;
       const float* e = c->emb;
       const size_t off = static_cast<size_t>(i) * c->lde + j;
       return static_cast<double>(cost_from_iou(c->prm, iou, cf, [&]() { return e[off]; }));
+    }
+    MOT_DEV double at(int j) const {
+      float b[4], barea;
+      c->cols.load(j, b, &barea);
+      return eval(b, barea, c->conf ? c->conf[j] : 0.0f, j);
+    }
+    MOT_DEV double at_owned(int k, int j) const {  // k must be a compile-time constant after unrolling
+      const Owned& o = c->own[k];
+      return eval(o.b, o.area, o.conf, j);
     }
   };
   MOT_DEV Row row(int i) const {
@@ -46,5 +69,6 @@ struct IouCost {
   }
   MOT_DEV double at(int i, int j) const { return row(i).at(j); }
 };
+using IouCost = IouCostT<0>;
 
 }  // namespace mot

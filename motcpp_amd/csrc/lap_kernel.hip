@@ -40,21 +40,26 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
     if (!(mn < static_cast<double>(T.gate))) path = 2;
   } else if (T.mode == MOT_LAP_OCSORT) {
     // a = (iou > gate); trivial one-to-one case iff max row sum == 1 and max col sum == 1 (ocsort.cpp:684-696)
+    // one coalesced sweep: lane t owns columns t, t+T, ... and walks them down the rows; row hits go through atomics
     int max_row = 0, max_col = 0;
-    for (int i = t; i < nr; i += kThreads) {
-      int c = 0, last = -1;
-      const float* r = T.iou + static_cast<size_t>(i) * T.ldi;
-      for (int j = 0; j < nc; ++j)
-        if (r[j] > T.gate) { ++c; last = j; }
-      W.x[i] = (c == 1) ? last : -1;
-      if (c > max_row) max_row = c;
-    }
+    for (int i = t; i < nr; i += kThreads) { W.x[i] = -1; W.fr[i] = 0; }
+    g.sync();
     for (int j = t; j < nc; j += kThreads) {
       int c = 0, last = -1;
       for (int i = 0; i < nr; ++i)
-        if (T.iou[static_cast<size_t>(i) * T.ldi + j] > T.gate) { ++c; last = i; }
+        if (T.iou[static_cast<size_t>(i) * T.ldi + j] > T.gate) {
+          ++c; last = i;
+          mot::DevGroup::atomic_add(&W.fr[i], 1);
+          mot::DevGroup::atomic_max(&W.x[i], j);
+        }
       W.y[j] = (c == 1) ? last : -1;
       if (c > max_col) max_col = c;
+    }
+    g.sync();
+    for (int i = t; i < nr; i += kThreads) {
+      const int c = W.fr[i];
+      if (c != 1) W.x[i] = -1;
+      if (c > max_row) max_row = c;
     }
     max_row = g.reduce_max(max_row);
     max_col = g.reduce_max(max_col);
@@ -90,7 +95,7 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
 // lds_mode (compile-time, so every pointer has a static address space — a run-time choice makes the compiler fall back
 // to flat_* instructions for the LDS state, which costs hundreds of cycles per dependent access): 0 = solver state in global scratch, 1 = hot state + column boxes in LDS (row boxes
 // in global scratch), 2 = hot state + column boxes + row boxes in LDS.
-template <int kThreads, int lds_mode>
+template <int kThreads, int lds_mode, int RPL>
 __global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __restrict__ tasks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mot_lap_task T = tasks[blockIdx.x];
@@ -108,7 +113,7 @@ __global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __res
   const size_t hot_b = (mot::lap_hot_bytes(n) + 15) & ~size_t(15), cold_b = (mot::lap_cold_bytes(n) + 15) & ~size_t(15);
   mot::LapWork W;
   char* lds = smem + kScratch;
-  if constexpr (lds_mode == 1 || lds_mode == 2) { mot::lap_carve_hot(W, lds, n); lds += hot_b; }
+  if constexpr (lds_mode == 2) { mot::lap_carve_hot(W, lds, n); lds += hot_b; }
   else mot::lap_carve_hot(W, gw, n);
   if constexpr (lds_mode == 3) {  // lean: only the per-column duals and column->row map in LDS (12 B per extended row)
     W.v = reinterpret_cast<double*>(lds);
@@ -119,11 +124,12 @@ __global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __res
   int path;
   if (T.geom.a != nullptr) {
     float* gbox = reinterpret_cast<float*>(gw + hot_b + cold_b);
-    float* cp;
-    if constexpr (lds_mode == 1 || lds_mode == 2) cp = reinterpret_cast<float*>(lds); else cp = gbox + 5 * nr;
+    // column boxes: global scratch (they are copied into registers below; memory only backs arbitrary-column reads);
+    // row boxes: LDS in mode 2 (one uniform read per row pass), global scratch otherwise
+    float* cp = gbox + 5 * nr;
     float* cf = cp + 5 * nc;
     float* rp;
-    if constexpr (lds_mode == 2) rp = cf + nc; else rp = gbox;
+    if constexpr (lds_mode == 2) rp = reinterpret_cast<float*>(lds); else rp = gbox;
     const mot_iou_task& G = T.geom;
     for (int i = t; i < nr; i += kThreads) {
       const int gi = G.aidx ? G.aidx[i] : i;
@@ -141,13 +147,14 @@ __global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __res
       cf[j] = G.bconf ? G.bconf[gj] : 0.0f;
     }
     g.sync();
-    mot::IouCost C;
+    mot::IouCostT<RPL> C;
     C.rows = mot::BoxPlanes{rp, nr};
     C.cols = mot::BoxPlanes{cp, nc};
     C.conf = G.bconf ? cf : nullptr;
     C.prm = mot::CostParams{G.mode, G.prox_thresh, G.app_thresh, G.fuse, G.emb != nullptr, G.emb == nullptr && G.lde < 0};
     C.emb = G.emb;
     C.lde = G.lde;
+    C.load_owned(t, kThreads, nc);
     path = gate_and_solve<kThreads>(g, C, T, W);
   } else {
     const mot::MatrixCost C{T.cost, T.ldc};
@@ -168,33 +175,42 @@ size_t lap_scratch_bytes(int n, int m) {
 // large AND there are too few problems to fill the chip anyway, where 4 wavefronts cut the latency of a row pass.
 hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool geom, hipStream_t st) {
   if (ntasks <= 0) return hipSuccess;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const void* fns[] = {reinterpret_cast<const void*>(&lap_kernel<64, 1>), reinterpret_cast<const void*>(&lap_kernel<64, 2>),
-                         reinterpret_cast<const void*>(&lap_kernel<64, 3>), reinterpret_cast<const void*>(&lap_kernel<256, 1>),
-                         reinterpret_cast<const void*>(&lap_kernel<256, 2>), reinterpret_cast<const void*>(&lap_kernel<256, 3>)};
-    for (const void* f : fns) {
-      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
-      if (e != hipSuccess) return e;
-    }
-    attr_set = true;
-  }
   const size_t n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1, nm = n + m;
   const size_t hot = (lap_hot_bytes(nm) + 15) & ~size_t(15);
-  const size_t b1 = kScratch + hot + (geom ? 24 * m + 16 : 0);
-  const size_t b2 = b1 + (geom ? 20 * n + 16 : 0);
-  const size_t b3 = kScratch + 12 * nm + 16;
+  const size_t b2 = kScratch + hot + (geom ? 20 * n + 16 : 0);  // full hot state (+ row boxes) in LDS
+  const size_t b3 = kScratch + 12 * nm + 16;                    // lean: duals + y
   int mode;
   size_t lds;
-  if (b2 <= 18 * 1024) { mode = 2; lds = b2; }            // everything in LDS and still >= 8 problems per CU
-  else if (b3 <= 40 * 1024) { mode = 3; lds = b3; }       // lean: duals + y in LDS, >= 4 (typically 8) problems per CU
-  else if (b1 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 1; lds = b1; }
+  if (b2 <= 18 * 1024) { mode = 2; lds = b2; }             // >= 8 problems per CU
+  else if (b3 <= 40 * 1024) { mode = 3; lds = b3; }        // >= 4 (north-star: 8) problems per CU
+  else if (b2 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 2; lds = b2; }
   else { mode = 0; lds = kScratch; }
   const bool wide = (nm > 3072) && (ntasks < 512);
-#define MOT_LAUNCH(T, M) hipLaunchKernelGGL((lap_kernel<T, M>), dim3(ntasks), dim3(T), lds, st, tasks)
-  if (wide) { if (mode == 2) MOT_LAUNCH(256, 2); else if (mode == 3) MOT_LAUNCH(256, 3); else if (mode == 1) MOT_LAUNCH(256, 1); else MOT_LAUNCH(256, 0); }
-  else { if (mode == 2) MOT_LAUNCH(64, 2); else if (mode == 3) MOT_LAUNCH(64, 3); else if (mode == 1) MOT_LAUNCH(64, 1); else MOT_LAUNCH(64, 0); }
-#undef MOT_LAUNCH
+  // lane-owned column boxes in registers: one wavefront per problem, <= 8 real columns per lane
+  int rpl = 0;
+  if (geom && !wide) rpl = (m <= 256) ? 4 : (m <= 512 ? 8 : 0);
+  static bool attr_set = false;
+#define MOT_LAP_VARIANTS(X) X(64, 0, 0) X(64, 2, 0) X(64, 3, 0) X(64, 0, 4) X(64, 2, 4) X(64, 3, 4) X(64, 0, 8) X(64, 2, 8) X(64, 3, 8) \
+                            X(256, 0, 0) X(256, 2, 0) X(256, 3, 0)
+  if (!attr_set) {
+#define MOT_ATTR(T, M, R)                                                                                                  \
+    { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_kernel<T, M, R>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget); \
+      if (e != hipSuccess) return e; }
+    MOT_LAP_VARIANTS(MOT_ATTR)
+#undef MOT_ATTR
+    attr_set = true;
+  }
+  const int threads = wide ? 256 : 64;
+  bool launched = false;
+#define MOT_TRY(T, M, R)                                                                                   \
+  if (!launched && threads == T && mode == M && rpl == R) {                                                \
+    hipLaunchKernelGGL((lap_kernel<T, M, R>), dim3(ntasks), dim3(T), lds, st, tasks);                      \
+    launched = true;                                                                                       \
+  }
+  MOT_LAP_VARIANTS(MOT_TRY)
+#undef MOT_TRY
+#undef MOT_LAP_VARIANTS
+  if (!launched) return hipErrorInvalidValue;
   return hipGetLastError();
 }
 }  // namespace mot

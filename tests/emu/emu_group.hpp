@@ -58,6 +58,14 @@ struct EmuGroup {
     for (int t = 1; t < sh->T; ++t) r = top2_merge(r, s[t]);
     return r;
   }
+  double exclusive_scan_min(double v) {
+    auto& s = sh->s_f64[phase++ & 1];
+    s[tid_] = v;
+    sync();
+    double r = 1e300;
+    for (int t = 0; t < tid_; ++t) r = (s[t] < r) ? s[t] : r;
+    return r;
+  }
   int exclusive_scan(int v, int* total) {
     auto& s = sh->s_int[phase++ & 1];
     s[tid_] = v;

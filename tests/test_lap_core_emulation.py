@@ -28,12 +28,12 @@ def emu():
 def emu_iou():
     lib = C.CDLL(build_lap_emu())
 
-    def run(a, b, conf, mode, th, T):
+    def run(a, b, conf, mode, th, T, rpl=0):
         a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
         conf = np.ascontiguousarray(conf, np.float32)
         x, y = np.zeros(a.shape[0], np.int32), np.zeros(b.shape[0], np.int32)
         lib.emu_lap_iou(a.ctypes.data_as(C.c_void_p), a.shape[0], b.ctypes.data_as(C.c_void_p), b.shape[0],
-                        conf.ctypes.data_as(C.c_void_p), mode, C.c_float(th), T, x.ctypes.data_as(C.c_void_p),
+                        conf.ctypes.data_as(C.c_void_p), mode, C.c_float(th), T, rpl, x.ctypes.data_as(C.c_void_p),
                         y.ctypes.data_as(C.c_void_p))
         return x, y
     return run
@@ -52,8 +52,9 @@ def test_on_the_fly_cost_functor_matches_materialised_matrix(orc, emu_iou):
         for mode, th in ((1, 0.7), (2, 0.8), (3, -0.3)):
             cost = {1: orc.iou_distance(a, b), 2: orc.fuse_score(orc.iou_distance(a, b), conf), 3: -orc.iou_batch(a, b)}[mode]
             xo, yo = orc.linear_assignment(cost, th)
-            xe, ye = emu_iou(a, b, conf, mode, th, 8)
-            assert (xo == xe).all() and (yo == ye).all(), (n, m, mode)
+            for rpl in (0, 4, 8):  # 0: boxes from memory; 4/8: lane-owned register cache (+ leftover columns when 8*rpl < m)
+                xe, ye = emu_iou(a, b, conf, mode, th, 8, rpl)
+                assert (xo == xe).all() and (yo == ye).all(), (n, m, mode, rpl)
 
 
 def gen(r, kind, n, m):

@@ -197,7 +197,9 @@ def main():
     prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
     if os.path.exists(prof):
         try:
-            roof["traffic"] = json.load(open(prof)).get(fam, {}).get("hbm_bytes_per_launch")
+            per_problem = json.load(open(prof)).get(fam, {}).get("hbm_bytes_per_problem")
+            if per_problem is not None:  # PMC passes are separate runs (profiles/README.md); scaled to this run's problems per launch
+                roof["traffic"] = per_problem * st["tasks"] / launches
         except Exception:
             pass
     kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["launches"],

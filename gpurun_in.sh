@@ -1,7 +1,7 @@
-export TMPDIR=/tmp
-R=$PWD
-mkdir -p $R/gpurun_out /tmp/pmcout
-cd /tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcout -o f1 -- python $R/bench.py --workload C2 --steps 5 --warmup 40 --streams 2048 --no-cpu-baseline > /tmp/pmcout/b1.json 2> /tmp/pmcout/b1.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmcout -o w1 -- python $R/bench.py --workload C2 --steps 5 --warmup 40 --streams 2048 --no-cpu-baseline > /tmp/pmcout/b2.json 2> /tmp/pmcout/b2.err
-cd $R; python gpurun_pmc_agg.py
+mkdir -p gpurun_out
+python gpurun_lapprof.py
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+for cfg in "NS 2048 32 2 12 35" "C2 4096 16 1 12 40"; do set -- $cfg
+  timeout 600 python bench.py --workload $1 --steps $5 --warmup $6 --streams $2 --threads $3 --pipeline $4 --no-cpu-baseline > gpurun_out/b.json 2> gpurun_out/b.err; python -c "
+import json;d=json.load(open('gpurun_out/b.json'));print('$1 S=$2 thr=$3 pipe=$4 fps',round(d['value'],1),'ms/step',round(d['ms_per_step'],2),'busy',round(d['gpu_busy_frac'],3),'host',{k:round(v,2) for k,v in d['host_ms_per_step'].items()},{k:round(v['ms_total']/v['launches'],3) for k,v in d['kernels'].items()})" || tail -5 gpurun_out/b.err
+done

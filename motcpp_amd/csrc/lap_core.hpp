@@ -17,6 +17,7 @@
 // one wavefront/LDS reduction (grp.hpp). Sequential dependencies between rows are kept.
 #pragma once
 #include "grp.hpp"
+#include "mem.hpp"
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MOT_CLOCK() static_cast<long long>(__builtin_readcyclecounter())
@@ -27,22 +28,21 @@
 namespace mot {
 
 // Cost functors. A functor exposes the real nr x nc block of the problem:
-//   Row row(i)        row-invariant context (pointer to the matrix row, or the row's box in registers)
-//   Row::at(j)        element (i, j) as double
+//   Row row(i)        row-invariant context (pointer to the matrix row, or the row's box in registers) — plain data,
+//                     no pointer back to the functor, so that functor and context both stay in registers
+//   at(row, j)        element (i, j) as double
 //   at(i, j)          same, without a row context (column scans)
 // MatrixCost reads a materialised float matrix; IouCost (lap_cost.hpp) recomputes IoU-family costs from boxes
 // staged in LDS, so the N x M matrix never exists in memory.
 struct MatrixCost {
   static constexpr int kRPL = 0;  // no lane-owned column cache
-  const float* cost;  // nr x nc, row-major, leading dimension ld
+  const float* cost;  // nr x nc, row-major, leading dimension ld (global memory)
   int ld;
-  struct Row {
-    const float* p;
-    MOT_DEV double at(int j) const { return static_cast<double>(p[j]); }
-    MOT_DEV double at_owned(int, int j) const { return at(j); }
-  };
+  struct Row { const float* p; };
   MOT_DEV Row row(int i) const { return Row{cost + static_cast<size_t>(i) * ld}; }
-  MOT_DEV double at(int i, int j) const { return static_cast<double>(cost[static_cast<size_t>(i) * ld + j]); }
+  MOT_DEV double at(const Row& r, int j) const { return static_cast<double>(gld(r.p, j)); }
+  MOT_DEV double at_owned(const Row& r, int, int j) const { return at(r, j); }
+  MOT_DEV double at(int i, int j) const { return static_cast<double>(gld(cost, static_cast<size_t>(i) * ld + j)); }
 };
 struct LapDims {
   int nr, nc;
@@ -51,37 +51,42 @@ struct LapDims {
 // Workspace, each array n = nr + nc long. The HOT arrays are touched by every row pass and live in LDS when
 // the problem fits; the COLD arrays are only used by the general shortest-path search (rare on tracking costs)
 // and the phase-1 row list, and always live in global scratch.
-struct LapWork {
+// VS = address space of v/y, XS = of x/fr (mem.hpp); the cold arrays are always global.
+template <int VS, int XS>
+struct LapWorkT {
   // hot
-  double* v;   // column duals
-  int* x;      // row -> col (extended)
-  int* y;      // col -> row (extended)
-  int* fr;     // free-row list (doubles as the column-hit counter in phase 1)
+  MemPtr<double, VS> v;   // column duals
+  MemPtr<int, XS> x;      // row -> col (extended)
+  MemPtr<int, VS> y;      // col -> row (extended)
+  MemPtr<int, XS> fr;     // free-row list (doubles as the column-hit counter in phase 1)
   // cold
-  double* d;   // shortest-path distances
-  int* pred;   // path predecessors
-  int* cols;   // lapjv's column permutation / phase-1 unique-row list
-  int* tmp;    // tie flags (slow path)
-  int* lst;    // compacted tie positions (slow path)
+  MemPtr<double, kMemGlobal> d;   // shortest-path distances
+  MemPtr<int, kMemGlobal> pred;   // path predecessors
+  MemPtr<int, kMemGlobal> cols;   // lapjv's column permutation / phase-1 unique-row list
+  MemPtr<int, kMemGlobal> tmp;    // tie flags (slow path)
+  MemPtr<int, kMemGlobal> lst;    // compacted tie positions (slow path)
   long long* cyc = nullptr;  // optional profiling: [0..3] cycles in phase 1a (column minima), 1b (transfer), 2, 3; [4..7] pass counts
 };
+using LapWork = LapWorkT<kMemAny, kMemAny>;
 MOT_HD size_t lap_hot_bytes(int n) { return static_cast<size_t>(n) * (sizeof(double) + 3 * sizeof(int)); }
 MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (sizeof(double) + 4 * sizeof(int)); }
 MOT_HD size_t lap_work_bytes(int n) { return lap_hot_bytes(n) + lap_cold_bytes(n); }
-MOT_HD void lap_carve_hot(LapWork& w, void* base, int n) {
+template <class Work>
+MOT_HD void lap_carve_hot(Work& w, void* base, int n) {
   char* p = static_cast<char*>(base);
-  w.v = reinterpret_cast<double*>(p); p += sizeof(double) * n;
-  w.x = reinterpret_cast<int*>(p); p += sizeof(int) * n;
-  w.y = reinterpret_cast<int*>(p); p += sizeof(int) * n;
-  w.fr = reinterpret_cast<int*>(p);
+  w.v.p = reinterpret_cast<double*>(p); p += sizeof(double) * n;
+  w.x.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.y.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.fr.p = reinterpret_cast<int*>(p);
 }
-MOT_HD void lap_carve_cold(LapWork& w, void* base, int n) {
+template <class Work>
+MOT_HD void lap_carve_cold(Work& w, void* base, int n) {
   char* p = static_cast<char*>(base);
-  w.d = reinterpret_cast<double*>(p); p += sizeof(double) * n;
-  w.pred = reinterpret_cast<int*>(p); p += sizeof(int) * n;
-  w.cols = reinterpret_cast<int*>(p); p += sizeof(int) * n;
-  w.tmp = reinterpret_cast<int*>(p); p += sizeof(int) * n;
-  w.lst = reinterpret_cast<int*>(p);
+  w.d.p = reinterpret_cast<double*>(p); p += sizeof(double) * n;
+  w.pred.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.cols.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.tmp.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.lst.p = reinterpret_cast<int*>(p);
 }
 MOT_HD LapWork lap_carve(void* base, int n) {  // hot then cold, contiguous
   LapWork w;
@@ -98,8 +103,8 @@ struct ExtRow {
   bool real;
   double left, right;  // dummy row: value for j < nc; any row: value for j >= nc
   int nc;
-  MOT_DEV double at(int j) const {
-    if (j < nc) return real ? r.at(j) : left;
+  MOT_DEV double at(const Cost& C, int j) const {
+    if (j < nc) return real ? C.at(r, j) : left;
     return right;
   }
 };
@@ -108,7 +113,17 @@ MOT_DEV ExtRow<Cost> ext_row(const Cost& C, const LapDims& P, int i) {
   ExtRow<Cost> e;
   e.nc = P.nc;
   e.real = i < P.nr;
-  e.r = C.row(e.real ? i : 0);
+  if (e.real) { e.r = C.row(i); e.left = 0.0; e.right = P.half; }
+  else { e.r = typename Cost::Row(); e.left = P.half; e.right = 0.0; }  // dummy rows have no box: nothing to fetch
+  return e;
+}
+// same, with the row context already fetched (software prefetch one round ahead)
+template <class Cost>
+MOT_DEV ExtRow<Cost> ext_row_pf(const LapDims& P, int i, const typename Cost::Row& r) {
+  ExtRow<Cost> e;
+  e.nc = P.nc;
+  e.real = i < P.nr;
+  e.r = r;
   if (e.real) { e.left = 0.0; e.right = P.half; }
   else { e.left = P.half; e.right = 0.0; }
   return e;
@@ -117,20 +132,20 @@ MOT_DEV ExtRow<Cost> ext_row(const Cost& C, const LapDims& P, int i) {
 // Visits the calling lane's columns (j = t, t+T, ...) of extended row view R in ascending order and hands each reduced
 // cost c = R(j) - v[j] to f(c, j). The real block (j < nc) and the dummy block (j >= nc) are separate loops so that
 // neither carries the other's branches; within a lane the order stays ascending, which the callers' tie rules rely on.
-template <class Cost, class F>
-MOT_DEV void for_lane_columns(const ExtRow<Cost>& R, const double* v, int t, int T, int nc, int n, F f) {
+template <class Cost, class VP, class F>
+MOT_DEV void for_lane_columns(const Cost& C, const ExtRow<Cost>& R, const VP& v, int t, int T, int nc, int n, F f) {
   int j = t;
   if (R.real) {
     if constexpr (Cost::kRPL > 0) {  // lane-owned column boxes in registers: fully unrolled, no box loads
 #pragma unroll
       for (int k = 0; k < Cost::kRPL; ++k) {
         const int jj = t + k * T;
-        if (jj < nc) f(R.r.at_owned(k, jj) - v[jj], jj);
+        if (jj < nc) f(C.at_owned(R.r, k, jj) - v[jj], jj);
       }
-      for (int jj = t + Cost::kRPL * T; jj < nc; jj += T) f(R.r.at(jj) - v[jj], jj);  // columns beyond the register cache
+      for (int jj = t + Cost::kRPL * T; jj < nc; jj += T) f(C.at(R.r, jj) - v[jj], jj);  // columns beyond the register cache
       j = t + ((nc > t) ? ((nc - t + T - 1) / T) * T : 0);
     } else {
-      for (; j < nc; j += T) f(R.r.at(j) - v[j], j);
+      for (; j < nc; j += T) f(C.at(R.r, j) - v[j], j);
     }
   } else { const double l = R.left; for (; j < nc; j += T) f(l - v[j], j); }
   const double rr = R.right;
@@ -138,8 +153,8 @@ MOT_DEV void for_lane_columns(const ExtRow<Cost>& R, const double* v, int t, int
 }
 
 // Compacts {i in [0,n) : flag(i)} in ascending order into out[]; returns the count (uniform).
-template <class G, class F>
-MOT_DEV int compact_ascending(G& g, int n, F flag, int* out) {
+template <class G, class F, class Out>
+MOT_DEV int compact_ascending(G& g, int n, F flag, const Out& out) {
   const int T = g.size(), t = g.tid();
   const int L = (n + T - 1) / T;
   const int b = t * L, e = (b + L < n) ? b + L : n;
@@ -155,8 +170,8 @@ MOT_DEV int compact_ascending(G& g, int n, F flag, int* out) {
 
 // Solves one problem. On return W.x[0..nr) / W.y[0..nc) hold extended assignments; callers map
 // x >= nc / y >= nr to -1 (lap_solver.hpp:326-331). All threads of the group must call this.
-template <class G, class Cost>
-MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) {
+template <class G, class Cost, class Work>
+MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
   const int T = g.size(), t = g.tid();
   const int nr = P.nr, nc = P.nc, n = nr + nc;
   const double half = P.half;
@@ -169,8 +184,8 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
   auto publish_column = [&](int j, double vm, int im) {
     W.v[j] = vm;
     W.y[j] = im;
-    G::atomic_max(&W.x[im], j);   // x[i] = largest column whose minimum sits in row i (:47-55)
-    G::atomic_add(&W.fr[im], 1);
+    G::atomic_max(W.x.raw(im), j);   // x[i] = largest column whose minimum sits in row i (:47-55)
+    G::atomic_add(W.fr.raw(im), 1);
   };
   int j_first = t;  // first column of this lane not handled by the register-cached sweep below
   if constexpr (Cost::kRPL > 0) {
@@ -185,7 +200,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
       for (int k = 0; k < Cost::kRPL; ++k) {
         const int jj = t + k * T;
         if (jj < nc) {
-          const double c = R.at_owned(k, jj);
+          const double c = C.at_owned(R, k, jj);
           if (c < vmk[k]) { vmk[k] = c; imk[k] = i; }
         }
       }
@@ -227,12 +242,15 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
   // rows that own exactly one column get their dual tightened, in ascending row order (:57-69)
   const int n_uniq = compact_ascending(g, n, [&](int i) { return W.x[i] >= 0 && W.fr[i] == 1; }, W.cols);
   int nfree = compact_ascending(g, n, [&](int i) { return W.x[i] < 0; }, W.fr);
+  int pf_i = (n_uniq > 0) ? W.cols[0] : 0;
+  int pf_j = (n_uniq > 0) ? W.x[pf_i] : 0;
   for (int u = 0; u < n_uniq; ++u) {
-    const int i = W.cols[u];
-    const int j = W.x[i];
+    const int i = pf_i;
+    const int j = pf_j;
     const ExtRow<Cost> R = ext_row(C, P, i);
+    if (u + 1 < n_uniq) { pf_i = W.cols[u + 1]; pf_j = W.x[pf_i]; }  // next round's indices: latency overlaps this round
     double mn = kLapLarge;
-    for_lane_columns(R, W.v, t, T, nc, n, [&](double c, int j2) { if (j2 != j && c < mn) mn = c; });
+    for_lane_columns(C, R, W.v, t, T, nc, n, [&](double c, int j2) { if (j2 != j && c < mn) mn = c; });
     mn = g.reduce_min(mn);
     if ((j % T) == t) W.v[j] -= mn;  // owner lane: next reader of v[j] is this same lane
   }
@@ -246,12 +264,23 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
     int forwarded = -1;  // row re-queued by free_rows[--current] = i0, consumed next iteration
     bool dc_valid = false;
     Top2 dc = top2_empty();
+    // software prefetch: the next unread free-list entry and its row context are fetched one round ahead (entries at or
+    // beyond the read position are never rewritten during a pass, so the prefetched value cannot go stale)
+    int nxt = W.fr[0];
+    typename Cost::Row nxt_row = (nxt < nr) ? C.row(nxt) : typename Cost::Row();
     while (current < static_cast<unsigned>(nfree)) {
       ++rr_cnt;
       ++n_carr;
-      const int fi = (forwarded >= 0) ? forwarded : W.fr[current];
+      const bool from_list = forwarded < 0;
+      const int fi = from_list ? nxt : forwarded;
+      typename Cost::Row fi_row = nxt_row;
+      if (!from_list && fi < nr) fi_row = C.row(fi);
       forwarded = -1;
       ++current;
+      if (from_list && current < static_cast<unsigned>(nfree)) {
+        nxt = W.fr[current];
+        nxt_row = (nxt < nr) ? C.row(nxt) : typename Cost::Row();
+      }
       // Dummy rows (fi >= nr) all have the same cost row, so while no dual changes their top-2 is the same tuple:
       // it is reduced once and reused until some v[j] is written (the extension makes these rounds a large share).
       const bool dummy_row = fi >= nr;
@@ -260,9 +289,9 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
         tt = dc;
         g.sync();  // stands in for the reduction's barrier: last round's owner writes are visible before y/v are read
       } else {
-        const ExtRow<Cost> R = ext_row(C, P, fi);
+        const ExtRow<Cost> R = ext_row_pf<Cost>(P, fi, fi_row);
         tt = top2_empty();
-        for_lane_columns(R, W.v, t, T, nc, n, [&](double c, int j) {
+        for_lane_columns(C, R, W.v, t, T, nc, n, [&](double c, int j) {
           if (c < tt.v2) {  // a lane visits its columns in ascending order: strict < keeps the lowest index on ties
             if (c < tt.v1) { tt.v2 = tt.v1; tt.j2 = tt.j1; tt.v1 = c; tt.j1 = j; }
             else { tt.v2 = c; tt.j2 = j; }
@@ -304,10 +333,16 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
   bool da_valid = false;  // dummy-start cache: valid while no dual has changed (single-step paths never change duals)
   double da_g0 = 0.0;
   int da_ptr = -1;        // this lane's largest column that may still be a free member of the tied-minimum set
+  int pf_start = (nfree > 0) ? W.fr[0] : 0;
+  typename Cost::Row pf_row = (nfree > 0 && pf_start < nr) ? C.row(pf_start) : typename Cost::Row();
   for (int f = 0; f < nfree; ++f) {
-    const int start = W.fr[f];
+    const int start = pf_start;
     ++n_paths;
-    const ExtRow<Cost> R0 = ext_row(C, P, start);
+    const ExtRow<Cost> R0 = ext_row_pf<Cost>(P, start, pf_row);
+    if (f + 1 < nfree) {  // next start and its row context, one round ahead (the free list is not modified in this phase)
+      pf_start = W.fr[f + 1];
+      pf_row = (pf_start < nr) ? C.row(pf_start) : typename Cost::Row();
+    }
     const bool dummy_row = start >= nr;
     int final_j;
     if (dummy_row && da_valid) {
@@ -318,19 +353,19 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
       final_j = g.reduce_max(da_ptr);
     } else {
       double mn = 1e300;
-      for_lane_columns(R0, W.v, t, T, nc, n, [&](double dj, int) { if (dj < mn) mn = dj; });
+      for_lane_columns(C, R0, W.v, t, T, nc, n, [&](double dj, int) { if (dj < mn) mn = dj; });
       const double g0 = g.reduce_min(mn);
       // First _find_dense from cols = identity leaves the tied-minimum columns in ascending
       // order in [0,hi) and the sink test (:174-177) keeps the LAST free one.
       int cand = -1;
-      for_lane_columns(R0, W.v, t, T, nc, n, [&](double dj, int j) { if (dj == g0 && W.y[j] < 0) cand = j; });
+      for_lane_columns(C, R0, W.v, t, T, nc, n, [&](double dj, int j) { if (dj == g0 && W.y[j] < 0) cand = j; });
       final_j = g.reduce_max(cand);
       if (dummy_row) { da_valid = true; da_g0 = g0; da_ptr = cand; }
     }
     if (final_j < 0) {
       // ---- general path: exact emulation of find_path_dense (:157-193) ----
       da_valid = false;  // the dual update below changes v
-      for (int j = t; j < n; j += T) { W.cols[j] = j; W.pred[j] = start; W.d[j] = R0.at(j) - W.v[j]; }
+      for (int j = t; j < n; j += T) { W.cols[j] = j; W.pred[j] = start; W.d[j] = R0.at(C, j) - W.v[j]; }
       g.sync();
       unsigned lo = 0, hi = 0, n_ready = 0;
       while (final_j == -1) {
@@ -391,12 +426,12 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const LapWork& W) 
             const int i = W.y[jq];
             const double mind = W.d[jq];
             const ExtRow<Cost> R = ext_row(C, P, i);
-            const double h = R.at(jq) - W.v[jq] - mind;
+            const double h = R.at(C, jq) - W.v[jq] - mind;
             g.sync();
             int first_sink = kNoIdx, any_tie = 0;
             for (int k = static_cast<int>(shi) + t; k < n; k += T) {
               const int j = W.cols[k];
-              const double cred = R.at(j) - W.v[j] - h;
+              const double cred = R.at(C, j) - W.v[j] - h;
               int flag = 0;
               if (cred < W.d[j]) {
                 W.d[j] = cred;

@@ -5,16 +5,19 @@
 // that overlap enough for it to matter.
 #pragma once
 #include "cost_math.hpp"
+#include "mem.hpp"
 
 namespace mot {
 
 // Boxes staged for one problem: planes x1,y1,x2,y2,area of length ld each (+ per-column confidence).
+template <int AS>
 struct BoxPlanes {
   const float* p;
   int ld;
   MOT_DEV void load(int i, float b[4], float* area) const {
-    b[0] = p[i]; b[1] = p[ld + i]; b[2] = p[2 * ld + i]; b[3] = p[3 * ld + i];
-    *area = p[4 * ld + i];
+    b[0] = mem_load<AS>(p + i); b[1] = mem_load<AS>(p + ld + i); b[2] = mem_load<AS>(p + 2 * ld + i);
+    b[3] = mem_load<AS>(p + 3 * ld + i);
+    *area = mem_load<AS>(p + 4 * ld + i);
   }
 };
 
@@ -22,10 +25,13 @@ struct BoxPlanes {
 // The solver's row passes only ever touch a lane's own columns, so with RPL > 0 a pass reads no box from memory at
 // all: the row box sits in registers for the pass, the column boxes for the whole solve. `cols` (memory) still backs the
 // rare arbitrary-column accesses (general path search, result read-out).
-template <int RPL>
+// ROWS = address space of the staged row boxes (LDS or global scratch); column boxes, confidences and the appearance
+// distances are always global.
+template <int RPL, int ROWS = kMemAny>
 struct IouCostT {
   static constexpr int kRPL = RPL;
-  BoxPlanes rows, cols;
+  BoxPlanes<ROWS> rows;
+  BoxPlanes<kMemGlobal> cols;
   const float* conf;  // [nc] or nullptr
   CostParams prm;
   const float* emb;   // nr x nc cosine distances (global memory) or nullptr
@@ -37,37 +43,36 @@ struct IouCostT {
     for (int k = 0; k < RPL; ++k) {
       const int j = t + k * T;
       Owned o{{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f};
-      if (j < nc) { cols.load(j, o.b, &o.area); o.conf = conf ? conf[j] : 0.0f; }
+      if (j < nc) { cols.load(j, o.b, &o.area); o.conf = conf ? gld(conf, j) : 0.0f; }
       own[k] = o;
     }
   }
-  struct Row {
-    const IouCostT* c;
+  struct Row {  // plain data: the row's box
     int i;
     float a[4], area;
-    MOT_DEV double eval(const float b[4], float barea, float cf, int j) const {
-      const float iou = iou_pair(a, area, b, barea);
-      const float* e = c->emb;
-      const size_t off = static_cast<size_t>(i) * c->lde + j;
-      return static_cast<double>(cost_from_iou(c->prm, iou, cf, [&]() { return e[off]; }));
-    }
-    MOT_DEV double at(int j) const {
-      float b[4], barea;
-      c->cols.load(j, b, &barea);
-      return eval(b, barea, c->conf ? c->conf[j] : 0.0f, j);
-    }
-    MOT_DEV double at_owned(int k, int j) const {  // k must be a compile-time constant after unrolling
-      const Owned& o = c->own[k];
-      return eval(o.b, o.area, o.conf, j);
-    }
   };
+  MOT_DEV double eval(const Row& r, const float b[4], float barea, float cf, int j) const {
+    const float iou = iou_pair(r.a, r.area, b, barea);
+    const float* e = emb;
+    const size_t off = static_cast<size_t>(r.i) * lde + j;
+    return static_cast<double>(cost_from_iou(prm, iou, cf, [&]() { return gld(e, off); }));
+  }
+  MOT_DEV double at(const Row& r, int j) const {
+    float b[4], barea;
+    cols.load(j, b, &barea);
+    return eval(r, b, barea, conf ? gld(conf, j) : 0.0f, j);
+  }
+  MOT_DEV double at_owned(const Row& r, int k, int j) const {  // k must be a compile-time constant after unrolling
+    const Owned& o = own[k];
+    return eval(r, o.b, o.area, o.conf, j);
+  }
   MOT_DEV Row row(int i) const {
     Row r;
-    r.c = this; r.i = i;
+    r.i = i;
     rows.load(i, r.a, &r.area);
     return r;
   }
-  MOT_DEV double at(int i, int j) const { return row(i).at(j); }
+  MOT_DEV double at(int i, int j) const { return at(row(i), j); }
 };
 using IouCost = IouCostT<0>;
 

@@ -26,15 +26,15 @@ namespace {
 constexpr int kScratch = 1024;  // DevGroup reduction scratch: 2 halves x 16 wavefronts x 32 bytes
 constexpr int kLdsBudget = 160 * 1024;
 
-template <int kThreads, class Cost>
-__device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, const mot_lap_task& T, const mot::LapWork& W) {
+template <int kThreads, class Cost, class Work>
+__device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, const mot_lap_task& T, const Work& W) {
   const int nr = T.n, nc = T.m, t = threadIdx.x;
   int path = 0;
   if (T.mode == MOT_LAP_GATE_MIN) {
     double mn = 1e300;
     for (int i = 0; i < nr; ++i) {
       const typename Cost::Row R = C.row(i);
-      for (int j = t; j < nc; j += kThreads) { const double c = R.at(j); if (c < mn) mn = c; }
+      for (int j = t; j < nc; j += kThreads) { const double c = C.at(R, j); if (c < mn) mn = c; }
     }
     mn = g.reduce_min(mn);
     if (!(mn < static_cast<double>(T.gate))) path = 2;
@@ -47,10 +47,10 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
     for (int j = t; j < nc; j += kThreads) {
       int c = 0, last = -1;
       for (int i = 0; i < nr; ++i)
-        if (T.iou[static_cast<size_t>(i) * T.ldi + j] > T.gate) {
+        if (mot::gld(T.iou, static_cast<size_t>(i) * T.ldi + j) > T.gate) {
           ++c; last = i;
-          mot::DevGroup::atomic_add(&W.fr[i], 1);
-          mot::DevGroup::atomic_max(&W.x[i], j);
+          mot::DevGroup::atomic_add(W.fr.raw(i), 1);
+          mot::DevGroup::atomic_max(W.x.raw(i), j);
         }
       W.y[j] = (c == 1) ? last : -1;
       if (c > max_col) max_col = c;
@@ -82,7 +82,7 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
     T.x[i] = xi;
     if (T.xval) {
       float v = 0.f;
-      if (xi >= 0) v = T.iou ? T.iou[static_cast<size_t>(i) * T.ldi + xi] : static_cast<float>(C.at(i, xi));
+      if (xi >= 0) v = T.iou ? mot::gld(T.iou, static_cast<size_t>(i) * T.ldi + xi) : static_cast<float>(C.at(i, xi));
       T.xval[i] = v;
     }
   }
@@ -111,13 +111,16 @@ __global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __res
   // global scratch layout: [hot (mode 0 only)] [cold] [row boxes 5*nr floats] [col boxes 6*nc floats]
   char* gw = static_cast<char*>(T.work);
   const size_t hot_b = (mot::lap_hot_bytes(n) + 15) & ~size_t(15), cold_b = (mot::lap_cold_bytes(n) + 15) & ~size_t(15);
-  mot::LapWork W;
+  constexpr int kVS = (lds_mode == 0) ? mot::kMemGlobal : mot::kMemLds;  // v, y
+  constexpr int kXS = (lds_mode == 2) ? mot::kMemLds : mot::kMemGlobal;  // x, free list
+  constexpr int kRS = (lds_mode == 2) ? mot::kMemLds : mot::kMemGlobal;  // row boxes
+  mot::LapWorkT<kVS, kXS> W;
   char* lds = smem + kScratch;
   if constexpr (lds_mode == 2) { mot::lap_carve_hot(W, lds, n); lds += hot_b; }
   else mot::lap_carve_hot(W, gw, n);
   if constexpr (lds_mode == 3) {  // lean: only the per-column duals and column->row map in LDS (12 B per extended row)
-    W.v = reinterpret_cast<double*>(lds);
-    W.y = reinterpret_cast<int*>(lds + sizeof(double) * static_cast<size_t>(n));
+    W.v.p = reinterpret_cast<double*>(lds);
+    W.y.p = reinterpret_cast<int*>(lds + sizeof(double) * static_cast<size_t>(n));
   }
   mot::lap_carve_cold(W, gw + hot_b, n);
   W.cyc = T.prof;
@@ -147,9 +150,9 @@ __global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __res
       cf[j] = G.bconf ? G.bconf[gj] : 0.0f;
     }
     g.sync();
-    mot::IouCostT<RPL> C;
-    C.rows = mot::BoxPlanes{rp, nr};
-    C.cols = mot::BoxPlanes{cp, nc};
+    mot::IouCostT<RPL, kRS> C;
+    C.rows = mot::BoxPlanes<kRS>{rp, nr};
+    C.cols = mot::BoxPlanes<mot::kMemGlobal>{cp, nc};
     C.conf = G.bconf ? cf : nullptr;
     C.prm = mot::CostParams{G.mode, G.prox_thresh, G.app_thresh, G.fuse, G.emb != nullptr, G.emb == nullptr && G.lde < 0};
     C.emb = G.emb;

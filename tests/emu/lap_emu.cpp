@@ -43,8 +43,8 @@ static int run_iou(const float* a, int nr, const float* b, int nc, const float* 
   for (int t = 0; t < T; ++t)
     th.emplace_back([&, t]() {
       IouCostT<RPL> C;  // per lane, like the kernel: the owned-column cache is lane-private
-      C.rows = BoxPlanes{rp.data(), nr};
-      C.cols = BoxPlanes{cp.data(), nc};
+      C.rows = BoxPlanes<kMemAny>{rp.data(), nr};
+      C.cols = BoxPlanes<kMemGlobal>{cp.data(), nc};
       C.conf = conf;
       C.prm = CostParams{mode, 0.f, 0.f, 0, false, false};
       C.emb = nullptr; C.lde = 0;

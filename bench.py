@@ -45,8 +45,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (0: workload default)")
-    ap.add_argument("--threads", type=int, default=0, help="host threads for the per-stream lifecycle (0: all cores, max 16)")
+    ap.add_argument("--threads", type=int, default=0, help="host worker threads for the per-stream lifecycle, shared by the sub-batches (0: min(64, cores))")
     ap.add_argument("--gather-every", type=int, default=8)
+    ap.add_argument("--pin", type=int, default=1, help="pin each sub-batch's host worker team to its own consecutive CPUs")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="split a rank's streams into this many sub-batches with their own HIP stream, stepped concurrently so one's host lifecycle overlaps another's kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -74,8 +75,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     tracker, P, M, D, desc = WORKLOADS[args.workload]
-    S = args.streams or {"C2": 4096, "SORT": 4096, "NS": 512, "C5": 512, "C3": 64, "C4": 8}[args.workload]
-    threads = args.threads or min(16, os.cpu_count() or 1)
+    S = args.streams or {"C2": 8192, "SORT": 8192, "NS": 8192, "C5": 4096, "C3": 512, "C4": 8}[args.workload]
+    # host workers block between phases, so more workers than the box's CPU quota (16 on the GPU boxes) still pay off:
+    # the bursts of lifecycle work get shorter and the workers sleep through the GPU waits
+    threads = args.threads or min(64, os.cpu_count() or 1)
     K, W = args.steps, args.warmup
     F = K + W
 
@@ -95,7 +98,7 @@ def main():
     frame_bytes = S * 6 * M * 4
 
     if args.pipeline <= 0:
-        args.pipeline = 1 if args.workload in ("C2", "SORT") else 2  # C2 is host-bound (more host threads per batch win), the rest GPU-bound
+        args.pipeline = {"C2": 2, "SORT": 2, "NS": 4, "C5": 4}.get(args.workload, 2)  # measured on MI355X
     PIPE = max(1, min(args.pipeline, S))
     bounds = [S * p // PIPE for p in range(PIPE + 1)]
     batches = [L.Batch(tracker, bounds[p + 1] - bounds[p], device=local, threads=max(1, threads // PIPE), record_laps=False,
@@ -105,7 +108,16 @@ def main():
     out_all = np.zeros((S, cap, 8), np.float32)
     cnt_all = np.zeros(S, np.int32)
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(PIPE) if PIPE > 1 else None
+    # one dedicated driver thread per sub-batch: its worker team (and the CPUs that team is pinned to) never changes
+    pools = [ThreadPoolExecutor(1) for _ in range(PIPE)] if PIPE > 1 else None
+    tpb = max(1, threads // PIPE)
+    if args.pin:
+        for p in range(PIPE):
+            first = local * threads + p * tpb
+            if pools is None:
+                batches[p].pin_threads(first)
+            else:
+                pools[p].submit(batches[p].pin_threads, first).result()
 
     def sub_step(p, f):
         s0, s1 = bounds[p], bounds[p + 1]
@@ -115,10 +127,11 @@ def main():
         cnt_all[s0:s1] = c
 
     def step(f):
-        if pool is None:
+        if pools is None:
             sub_step(0, f)
         else:
-            list(pool.map(lambda p: sub_step(p, f), range(PIPE)))
+            for fut in [pools[p].submit(sub_step, p, f) for p in range(PIPE)]:
+                fut.result()
         return out_all, cnt_all
 
     def counters():

@@ -47,6 +47,10 @@ int motcpp_batch_step(motcpp_batch* b, const float* dets, const int* counts, int
 int motcpp_batch_step_resident(motcpp_batch* b, const float* dets, const int* counts, int max_n, const void* d_dets_soa,
                                const float* embs, int d, float* out, int* out_counts, int cap);
 int motcpp_batch_set_threads(motcpp_batch* b, int threads);
+/* Pins the CALLING thread's worker team (set_threads many) to consecutive CPUs of the process's allowed set, starting at
+ * its first_cpu-th one; call it from the thread that will call motcpp_batch_step. Sub-batches stepped from different
+ * threads should get disjoint ranges. Optional: unpinned teams work, pinned ones step a frame about 1.5x faster. */
+int motcpp_batch_pin_threads(motcpp_batch* b, int first_cpu);
 int motcpp_batch_record_laps(motcpp_batch* b, int on); /* keep per-frame assignment records for the parity hooks (default on) */
 /* per-kernel-family HIP-event timing on the device's stream. enable=1 resets the counters. Families (rows):
  * 0 det_prepare 1 feat 2 kf_initiate 3 kf_update 4 kf_predict 5 kf_boxes 6 cosine 7 iou 8 ocsort_cost 9 lap.

@@ -179,6 +179,7 @@ def host():
         H.motcpp_batch_step_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_int]
         H.motcpp_batch_set_threads.argtypes = [C.c_void_p, C.c_int]
+        H.motcpp_batch_pin_threads.argtypes = [C.c_void_p, C.c_int]
         H.motcpp_batch_record_laps.argtypes = [C.c_void_p, C.c_int]
         H.motcpp_profile.argtypes = [C.c_int, C.c_int]
         H.motcpp_profile_stats.argtypes = [C.c_int, C.c_void_p, C.c_int]
@@ -279,6 +280,10 @@ class Batch:
         host().motcpp_batch_record_laps(self.h, 1 if record_laps else 0)
         self._out = None
         self._cnt = np.zeros(self.S, np.int32)
+
+    def pin_threads(self, first_cpu):
+        """Pin the calling thread's worker team to consecutive allowed CPUs (call from the thread that steps the batch)."""
+        host().motcpp_batch_pin_threads(self.h, int(first_cpu))
 
     def close(self):
         if getattr(self, "h", None):

@@ -4,6 +4,8 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+#include <functional>
 #include "motcpp_c.h"
 #include "staged.hpp"
 
@@ -39,7 +41,7 @@ struct motcpp_batch {
   std::vector<std::unique_ptr<motcpp_tracker>> trk;
   std::vector<std::vector<float>> colmajor;
   long frames = 0;
-  int threads = 1;
+  std::unique_ptr<Team> team;  // nullptr: the caller's thread does everything
 };
 
 namespace {
@@ -153,7 +155,20 @@ int motcpp_batch_profile_stats(motcpp_batch* b, double* out, int cap_rows) {
   return n;
 }
 void motcpp_batch_destroy(motcpp_batch* b) { delete b; }
-int motcpp_batch_set_threads(motcpp_batch* b, int threads) { b->threads = threads < 1 ? 1 : threads; return 0; }
+int motcpp_batch_set_threads(motcpp_batch* b, int threads) {
+  try {
+    if (threads > Device::kMaxHostThreads) threads = Device::kMaxHostThreads;
+    b->team.reset();
+    if (threads > 1) b->team = std::make_unique<Team>(threads);
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int motcpp_batch_pin_threads(motcpp_batch* b, int first_cpu) {
+  if (first_cpu < 0) return 0;
+  if (b->team) b->team->pin(first_cpu);
+  else Team(1).pin(first_cpu);
+  return 0;
+}
 int motcpp_batch_record_laps(motcpp_batch* b, int on) { for (auto& t : b->trk) t->impl->record_laps = on != 0; return 0; }
 int motcpp_batch_tracker_count(motcpp_batch* b) { return static_cast<int>(b->trk.size()); }
 motcpp_tracker* motcpp_batch_tracker(motcpp_batch* b, int s) { return b->trk[s].get(); }
@@ -172,24 +187,25 @@ static int batch_step_impl(motcpp_batch* b, const float* dets, const int* counts
     const int S = static_cast<int>(b->trk.size());
     std::vector<FrameIn> in(S);
     std::vector<Staged*> st(S);
-    const int thr = b->threads;
-#pragma omp parallel for num_threads(thr) schedule(static) if (thr > 1 && S > 8)
-    for (int s = 0; s < S; ++s) {
+    auto for_streams = [&](const std::function<void(int)>& fn) {
+      if (b->team && S > 8) b->team->parallel_for(S, fn);
+      else for (int s = 0; s < S; ++s) fn(s);
+    };
+    for_streams([&](int s) {
       to_colmajor(dets + static_cast<size_t>(s) * max_n * 6, counts[s], b->colmajor[s]);
       in[s] = frame_in(b->colmajor[s], counts[s], embs ? embs + static_cast<size_t>(s) * max_n * d : nullptr, d);
       if (d_dets) { in[s].d_dets = d_dets + static_cast<size_t>(s) * 6 * max_n; in[s].d_ld = max_n; }
       st[s] = b->trk[s]->impl.get();
-    }
-    run_frame(*b->dev, st.data(), in.data(), S, b->threads);
+    });
+    run_frame(*b->dev, st.data(), in.data(), S, b->team.get());
     b->frames += S;
-    int bad = 0;
-#pragma omp parallel for num_threads(thr) schedule(static) reduction(| : bad) if (thr > 1 && S > 8)
-    for (int s = 0; s < S; ++s) {
+    std::atomic<int> bad{0};
+    for_streams([&](int s) {
       const int m = copy_rows(st[s]->rows(), out + static_cast<size_t>(s) * cap * 8, cap);
-      if (m < 0) bad |= 1;
+      if (m < 0) bad.store(1, std::memory_order_relaxed);
       else out_counts[s] = m;
-    }
-    if (bad) { g_err = "output capacity too small"; return -1; }
+    });
+    if (bad.load()) { g_err = "output capacity too small"; return -1; }
     return S;
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }

@@ -4,13 +4,14 @@
 #include <chrono>
 #include <map>
 
-#include <omp.h>
+#include "team.hpp"
 
 namespace motcpp::rt {
 
 // ---- Arena ---------------------------------------------------------------------------------
 Arena::Arena(mot_ctx* ctx, size_t chunk_bytes, bool host_mirror) : ctx_(ctx), chunk_bytes_(chunk_bytes), host_(host_mirror) {
   chunks_.reserve(1024);  // the vector never reallocates while other threads index it
+  leases_.resize(Device::kMaxHostThreads);
 }
 Arena::~Arena() {
   for (auto& c : chunks_) {
@@ -21,6 +22,27 @@ Arena::~Arena() {
 void Arena::raw_alloc(size_t bytes, void** h, void** d) {
   bytes = (bytes + 255) & ~size_t(255);
   if (bytes == 0) bytes = 256;
+  // Small requests are served from a per-thread lease (a private slice of the current chunk): the shared bump pointer
+  // is one cache line, and with tens of host threads on two sockets hammering it per allocation it becomes the
+  // bottleneck of the whole host side. A lease dies at every transfer (its unused tail has already been copied).
+  if (bytes <= kLeaseBytes / 4) {
+    const int th = Team::worker_id();
+    Lease& L = leases_[th < Device::kMaxHostThreads ? th : 0];
+    const uint64_t ep = epoch_.load(std::memory_order_relaxed);
+    if (L.epoch != ep || L.off + bytes > L.end) {
+      void *lh, *ld;
+      shared_alloc(kLeaseBytes, &lh, &ld);
+      L.h = static_cast<char*>(lh); L.d = static_cast<char*>(ld);
+      L.off = 0; L.end = kLeaseBytes; L.epoch = ep;
+    }
+    *h = L.h ? L.h + L.off : nullptr;
+    *d = L.d + L.off;
+    L.off += bytes;
+    return;
+  }
+  shared_alloc(bytes, h, d);
+}
+void Arena::shared_alloc(size_t bytes, void** h, void** d) {
   while (true) {
     const size_t ci = cur_.load(std::memory_order_acquire);
     if (ci < n_chunks_.load(std::memory_order_acquire)) {
@@ -57,10 +79,12 @@ void Arena::raw_alloc(size_t bytes, void** h, void** d) {
   }
 }
 void Arena::reset() {
+  epoch_.fetch_add(1, std::memory_order_relaxed);
   for (auto& c : chunks_) { c->top.store(0, std::memory_order_relaxed); c->mark = 0; }
   cur_.store(0, std::memory_order_release);
 }
 void Arena::upload() {
+  epoch_.fetch_add(1, std::memory_order_relaxed);
   for (auto& c : chunks_) {
     const size_t top = std::min(c->top.load(std::memory_order_relaxed), c->cap);
     if (top > c->mark) {
@@ -70,6 +94,7 @@ void Arena::upload() {
   }
 }
 void Arena::download() {
+  epoch_.fetch_add(1, std::memory_order_relaxed);
   for (auto& c : chunks_) {
     const size_t top = std::min(c->top.load(std::memory_order_relaxed), c->cap);
     if (top > c->mark) {
@@ -160,7 +185,7 @@ void Device::TaskLists::append(TaskLists& o) {
   o.lap_geom = false;
 }
 Device::TaskLists& Device::q() {
-  const int t = omp_get_thread_num();
+  const int t = Team::worker_id();
   return lists[t < kMaxHostThreads ? t : 0];
 }
 bool Device::pending() const {

@@ -57,7 +57,16 @@ class Arena {
     std::atomic<size_t> top{0};
     size_t mark = 0;
   };
+  struct alignas(64) Lease {  // per host thread: private slice of a chunk
+    char* h = nullptr; char* d = nullptr;
+    size_t off = 0, end = 0;
+    uint64_t epoch = 0;
+  };
+  static constexpr size_t kLeaseBytes = size_t(128) << 10;
   void raw_alloc(size_t bytes, void** h, void** d);
+  void shared_alloc(size_t bytes, void** h, void** d);
+  std::vector<Lease> leases_;
+  std::atomic<uint64_t> epoch_{1};  // bumped at every reset/transfer (single-threaded points)
   mot_ctx* ctx_;
   size_t chunk_bytes_;
   bool host_;

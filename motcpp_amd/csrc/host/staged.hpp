@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "runtime.hpp"
+#include "team.hpp"
 
 namespace motcpp::rt {
 
@@ -75,7 +76,7 @@ class Staged {
 };
 
 // Runs one frame for a set of trackers sharing a Device in lockstep: one kernel launch per kernel family per stage.
-void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, int threads = 1);
+void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, Team* team = nullptr);
 
 // factories (parameter vectors: same layout as documented in include/motcpp_c.h)
 Staged* make_sort(std::shared_ptr<Device>, float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold);

@@ -1,6 +1,9 @@
 // BaseTracker / DeviceTracker / StreamBatch and the four public tracker classes (constructor signatures of
 // the reference's include/motcpp/trackers/*.hpp), plus the frame driver that steps stage machines in lockstep.
 #include <chrono>
+#include <algorithm>
+#include <functional>
+#include <mutex>
 #include <stdexcept>
 
 #include "motcpp/motcpp.hpp"
@@ -44,46 +47,48 @@ void BaseTracker::setup_detection_format(const Eigen::MatrixXf& dets) {
 }
 
 namespace rt {
-void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, int threads) {
+void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, Team* team) {
   using clk = std::chrono::steady_clock;
   auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   dev.begin_frame();
   std::vector<char> done(count, 0);
   std::string err;
+  std::mutex err_mu;
+  auto fail = [&](const std::exception& e) { std::lock_guard<std::mutex> g(err_mu); err = e.what(); };
+  // Host lifecycle of different streams is independent: the team's workers step the stage machines of their own
+  // contiguous slice of streams (task lists and arena leases are per worker; kernels are launched once per stage).
+  auto for_streams = [&](const std::function<void(int)>& fn) {
+    if (team && count > 1) team->parallel_for(count, fn);
+    else for (int i = 0; i < count; ++i) fn(i);
+  };
   auto t0 = clk::now();
-  const bool par = threads > 1 && count > 1;
-  // Host lifecycle of different streams is independent: step the stage machines from several host threads
-  // (arena allocation and task-list appends are serialised by Device::mu; kernels are launched once per stage).
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 4) if (par)
-  for (int i = 0; i < count; ++i) {
+  for_streams([&](int i) {
     try { trackers[i]->begin(inputs[i]); }
-    catch (const std::exception& e) {
-#pragma omp critical
-      err = e.what();
-    }
-  }
+    catch (const std::exception& e) { fail(e); }
+  });
   if (!err.empty()) throw Error(err);
   dev.counters.ms_begin += ms(t0, clk::now());
+  std::vector<int> any_w(team ? team->size() : 1);
   while (true) {
     auto t1 = clk::now();
     if (dev.pending()) dev.flush();
     auto t2 = clk::now();
     dev.counters.ms_flush += ms(t1, t2);
-    int any = 0;
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 4) reduction(| : any) if (par)
-    for (int i = 0; i < count; ++i) {
-      if (done[i]) continue;
+    std::fill(any_w.begin(), any_w.end(), 0);
+    for_streams([&](int i) {
+      if (done[i]) return;
       try {
-        if (trackers[i]->advance()) any |= 1;
+        if (trackers[i]->advance()) any_w[Team::worker_id() % any_w.size()] = 1;
         else done[i] = 1;
       } catch (const std::exception& e) {
         done[i] = 1;
-#pragma omp critical
-        err = e.what();
+        fail(e);
       }
-    }
+    });
     dev.counters.ms_advance += ms(t2, clk::now());
     if (!err.empty()) throw Error(err);
+    int any = 0;
+    for (int a : any_w) any |= a;
     if (!any) break;
   }
 }

@@ -129,12 +129,13 @@ MOT_DEV ExtRow<Cost> ext_row_pf(const LapDims& P, int i, const typename Cost::Ro
   return e;
 }
 
-// Visits the calling lane's columns (j = t, t+T, ...) of extended row view R in ascending order and hands each reduced
-// cost c = R(j) - v[j] to f(c, j). The real block (j < nc) and the dummy block (j >= nc) are separate loops so that
-// neither carries the other's branches; within a lane the order stays ascending, which the callers' tie rules rely on.
+// The calling lane's columns are j = t, t+T, ...; first_dummy() is the first of them in the dummy block (j >= nc).
+MOT_DEV int first_dummy(int t, int T, int nc) { return t + ((nc > t) ? ((nc - t + T - 1) / T) * T : 0); }
+
+// Visits the lane's REAL columns (j < nc) of extended row view R in ascending order and hands each reduced cost
+// c = R(j) - v[j] to f(c, j).
 template <class Cost, class VP, class F>
-MOT_DEV void for_lane_columns(const Cost& C, const ExtRow<Cost>& R, const VP& v, int t, int T, int nc, int n, F f) {
-  int j = t;
+MOT_DEV void for_lane_real(const Cost& C, const ExtRow<Cost>& R, const VP& v, int t, int T, int nc, F f) {
   if (R.real) {
     if constexpr (Cost::kRPL > 0) {  // lane-owned column boxes in registers: fully unrolled, no box loads
 #pragma unroll
@@ -143,13 +144,21 @@ MOT_DEV void for_lane_columns(const Cost& C, const ExtRow<Cost>& R, const VP& v,
         if (jj < nc) f(C.at_owned(R.r, k, jj) - v[jj], jj);
       }
       for (int jj = t + Cost::kRPL * T; jj < nc; jj += T) f(C.at(R.r, jj) - v[jj], jj);  // columns beyond the register cache
-      j = t + ((nc > t) ? ((nc - t + T - 1) / T) * T : 0);
     } else {
-      for (; j < nc; j += T) f(C.at(R.r, j) - v[j], j);
+      for (int j = t; j < nc; j += T) f(C.at(R.r, j) - v[j], j);
     }
-  } else { const double l = R.left; for (; j < nc; j += T) f(l - v[j], j); }
-  const double rr = R.right;
-  for (; j < n; j += T) f(rr - v[j], j);
+  } else { const double l = R.left; for (int j = t; j < nc; j += T) f(l - v[j], j); }
+}
+// Same for the lane's DUMMY columns (j >= nc), whose cost is the row constant `right`.
+template <class VP, class F>
+MOT_DEV void for_lane_dummy(double right, const VP& v, int t, int T, int nc, int n, F f) {
+  for (int j = first_dummy(t, T, nc); j < n; j += T) f(right - v[j], j);
+}
+// Real block then dummy block: within a lane the order stays ascending, which the callers' tie rules rely on.
+template <class Cost, class VP, class F>
+MOT_DEV void for_lane_columns(const Cost& C, const ExtRow<Cost>& R, const VP& v, int t, int T, int nc, int n, F f) {
+  for_lane_real(C, R, v, t, T, nc, f);
+  for_lane_dummy(R.right, v, t, T, nc, n, f);
 }
 
 // Compacts {i in [0,n) : flag(i)} in ascending order into out[]; returns the count (uniform).
@@ -194,14 +203,23 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     int imk[Cost::kRPL];
 #pragma unroll
     for (int k = 0; k < Cost::kRPL; ++k) { vmk[k] = kLapLarge; imk[k] = 0; }
-    for (int i = 0; i < nr; ++i) {
-      const typename Cost::Row R = C.row(i);
+    constexpr int kRowBatch = 4;  // row contexts are fetched a batch at a time so that their load latencies overlap
+    for (int i0 = 0; i0 < nr; i0 += kRowBatch) {
+      typename Cost::Row RB[kRowBatch];
 #pragma unroll
-      for (int k = 0; k < Cost::kRPL; ++k) {
-        const int jj = t + k * T;
-        if (jj < nc) {
-          const double c = C.at_owned(R, k, jj);
-          if (c < vmk[k]) { vmk[k] = c; imk[k] = i; }
+      for (int u = 0; u < kRowBatch; ++u) RB[u] = C.row((i0 + u < nr) ? i0 + u : nr - 1);
+#pragma unroll
+      for (int u = 0; u < kRowBatch; ++u) {
+        const int i = i0 + u;
+        if (i < nr) {
+#pragma unroll
+          for (int k = 0; k < Cost::kRPL; ++k) {
+            const int jj = t + k * T;
+            if (jj < nc) {
+              const double c = C.at_owned(RB[u], k, jj);
+              if (c < vmk[k]) { vmk[k] = c; imk[k] = i; }
+            }
+          }
         }
       }
     }
@@ -227,7 +245,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     if (half < vm) { vm = half; im = nr; }
     publish_column(j, vm, im);
   }
-  for (int j = t + ((nc > t) ? ((nc - t + T - 1) / T) * T : 0); j < n; j += T) {  // dummy columns
+  for (int j = first_dummy(t, T, nc); j < n; j += T) {  // dummy columns
     double vm = kLapLarge;
     int im = 0;
     if (half < vm) { vm = half; im = 0; }   // rows 0..nr-1 are all `half`
@@ -242,6 +260,25 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
   // rows that own exactly one column get their dual tightened, in ascending row order (:57-69)
   const int n_uniq = compact_ascending(g, n, [&](int i) { return W.x[i] >= 0 && W.fr[i] == 1; }, W.cols);
   int nfree = compact_ascending(g, n, [&](int i) { return W.x[i] < 0; }, W.fr);
+  // Per-lane cache over the lane's DUMMY columns as seen from a real row (cost `half` everywhere): the two
+  // lexicographically smallest (half - v[j], j) and the largest column attaining the minimum. It does not depend on the
+  // row, so it stays valid until the dual of some dummy column is written (rare: the dummy block is one big tie).
+  bool dq_ok = false;   // uniform
+  Top2 dq = top2_empty();
+  int dq_ptr = -1;
+  auto ensure_dq = [&]() {
+    if (dq_ok) return;
+    dq = top2_empty();
+    dq_ptr = -1;
+    for_lane_dummy(half, W.v, t, T, nc, n, [&](double c, int j) {
+      if (c < dq.v2) {
+        if (c < dq.v1) { dq.v2 = dq.v1; dq.j2 = dq.j1; dq.v1 = c; dq.j1 = j; dq_ptr = j; }
+        else { dq.v2 = c; dq.j2 = j; }
+      }
+      if (c == dq.v1) dq_ptr = j;
+    });
+    dq_ok = true;
+  };
   int pf_i = (n_uniq > 0) ? W.cols[0] : 0;
   int pf_j = (n_uniq > 0) ? W.x[pf_i] : 0;
   for (int u = 0; u < n_uniq; ++u) {
@@ -250,9 +287,17 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     const ExtRow<Cost> R = ext_row(C, P, i);
     if (u + 1 < n_uniq) { pf_i = W.cols[u + 1]; pf_j = W.x[pf_i]; }  // next round's indices: latency overlaps this round
     double mn = kLapLarge;
-    for_lane_columns(C, R, W.v, t, T, nc, n, [&](double c, int j2) { if (j2 != j && c < mn) mn = c; });
+    if (R.real) {
+      ensure_dq();
+      for_lane_real(C, R, W.v, t, T, nc, [&](double c, int j2) { if (j2 != j && c < mn) mn = c; });
+      const double dm = (dq.j1 == j) ? dq.v2 : dq.v1;  // minimum over the lane's dummy columns other than j
+      if (dm < mn) mn = dm;
+    } else {
+      for_lane_columns(C, R, W.v, t, T, nc, n, [&](double c, int j2) { if (j2 != j && c < mn) mn = c; });
+    }
     mn = g.reduce_min(mn);
     if ((j % T) == t) W.v[j] -= mn;  // owner lane: next reader of v[j] is this same lane
+    if (j >= nc) dq_ok = false;
   }
   g.sync();
 
@@ -291,12 +336,20 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
       } else {
         const ExtRow<Cost> R = ext_row_pf<Cost>(P, fi, fi_row);
         tt = top2_empty();
-        for_lane_columns(C, R, W.v, t, T, nc, n, [&](double c, int j) {
+        auto push = [&](double c, int j) {
           if (c < tt.v2) {  // a lane visits its columns in ascending order: strict < keeps the lowest index on ties
             if (c < tt.v1) { tt.v2 = tt.v1; tt.j2 = tt.j1; tt.v1 = c; tt.j1 = j; }
             else { tt.v2 = c; tt.j2 = j; }
           }
-        });
+        };
+        if (!dummy_row) {
+          ensure_dq();
+          for_lane_real(C, R, W.v, t, T, nc, push);
+          push(dq.v1, dq.j1);  // the lane's dummy columns come after its real ones, best first
+          push(dq.v2, dq.j2);
+        } else {
+          for_lane_columns(C, R, W.v, t, T, nc, n, push);
+        }
         tt = g.reduce_top2(tt);
         if (dummy_row) { dc = tt; dc_valid = true; }
       }
@@ -310,7 +363,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
       const double v1_new = vj1 - (v2 - v1);
       const bool lowers = v1_new < vj1;
       if (rr_cnt < current * static_cast<unsigned>(n)) {
-        if (lowers) { if ((j1 % T) == t) W.v[j1] = v1_new; dc_valid = false; }
+        if (lowers) { if ((j1 % T) == t) W.v[j1] = v1_new; dc_valid = false; if (j1 >= nc) dq_ok = false; }
         else if (i0 >= 0 && j2 >= 0) { j1 = j2; i0 = yj2; }
         if (i0 >= 0) {
           if (lowers) { --current; if (t == 0) W.fr[current] = i0; forwarded = i0; }
@@ -352,19 +405,44 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
       if (da_ptr < 0) da_ptr = -1;
       final_j = g.reduce_max(da_ptr);
     } else {
+      // One sweep: the lane's minimum and the LAST free column attaining it. After the group minimum g0 is known only
+      // lanes whose own minimum equals g0 can hold a member of the tied set. (First _find_dense from cols = identity
+      // leaves the tied-minimum columns in ascending order in [0,hi) and the sink test (:174-177) keeps the LAST free one.)
       double mn = 1e300;
-      for_lane_columns(C, R0, W.v, t, T, nc, n, [&](double dj, int) { if (dj < mn) mn = dj; });
-      const double g0 = g.reduce_min(mn);
-      // First _find_dense from cols = identity leaves the tied-minimum columns in ascending
-      // order in [0,hi) and the sink test (:174-177) keeps the LAST free one.
       int cand = -1;
-      for_lane_columns(C, R0, W.v, t, T, nc, n, [&](double dj, int j) { if (dj == g0 && W.y[j] < 0) cand = j; });
-      final_j = g.reduce_max(cand);
-      if (dummy_row) { da_valid = true; da_g0 = g0; da_ptr = cand; }
+      auto visit = [&](double dj, int j) {
+        if (dj <= mn) {
+          const bool is_free = W.y[j] < 0;
+          if (dj < mn) { mn = dj; cand = is_free ? j : -1; }
+          else if (is_free) cand = j;
+        }
+      };
+      if (!dummy_row) {
+        ensure_dq();
+        for_lane_real(C, R0, W.v, t, T, nc, visit);
+        const double lane_mn = (dq.v1 < mn) ? dq.v1 : mn;
+        const double g0 = g.reduce_min(lane_mn);
+        if (!(mn == g0)) cand = -1;
+        if (dq.v1 == g0) {
+          // tied dummy columns: same pointer walk as the dummy-start cache below — the tied set among the lane's dummy
+          // columns is the same for every real start while no dummy dual changes, and only shrinks as columns get assigned
+          while (dq_ptr >= nc && !((half - W.v[dq_ptr]) == g0 && W.y[dq_ptr] < 0)) dq_ptr -= T;
+          if (dq_ptr >= nc) cand = dq_ptr;  // dummy columns come after the lane's real ones
+        }
+        final_j = g.reduce_max(cand);
+      } else {
+        for_lane_columns(C, R0, W.v, t, T, nc, n, visit);
+        const double g0 = g.reduce_min(mn);
+        if (!(mn == g0)) cand = -1;
+        final_j = g.reduce_max(cand);
+        da_valid = true; da_g0 = g0;
+        da_ptr = cand;  // this lane's largest column that may still be a free member of the tied set
+      }
     }
     if (final_j < 0) {
       // ---- general path: exact emulation of find_path_dense (:157-193) ----
       da_valid = false;  // the dual update below changes v
+      dq_ok = false;
       for (int j = t; j < n; j += T) { W.cols[j] = j; W.pred[j] = start; W.d[j] = R0.at(C, j) - W.v[j]; }
       g.sync();
       unsigned lo = 0, hi = 0, n_ready = 0;

@@ -314,6 +314,62 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     int nxt = W.fr[0];
     typename Cost::Row nxt_row = (nxt < nr) ? C.row(nxt) : typename Cost::Row();
     while (current < static_cast<unsigned>(nfree)) {
+      // ---- run of dummy rows in closed form ----
+      // A dummy row's two best columns are the cached tuple dc. When they tie exactly (v2 == v1: always, until a real
+      // row pulls a dummy column's dual down) the round changes no dual: the row takes j1 if that column is free, else
+      // j2, whose previous owner goes back to the free list. A run of K consecutive dummy rows of the free list is
+      // therefore a chain — each row takes j2 and displaces its predecessor — whose outcome is written here in one
+      // step instead of K serial rounds. (The extension makes every unmatched detection such a row.)
+      if (forwarded < 0 && dc_valid && nxt >= nr && dc.v1 == dc.v2 && dc.v2 < kLapLarge && dc.j2 != kNoIdx &&
+          (rr_cnt + 1u) < (current + 1u) * static_cast<unsigned>(n)) {
+        const int cj1 = dc.j1, cj2 = dc.j2;
+        g.sync();  // the previous round's owner writes to y[] are visible
+        const int a0 = W.y[cj1], b0 = W.y[cj2];
+        const int s = (a0 < 0) ? 1 : 0;   // rows of the run that take j1 (at most the first)
+        const int bi = (b0 >= 0) ? 1 : 0; // j2's owner before the run is displaced first
+        const int nf0 = new_free;
+        int k0 = 0, prev_last = -1, last_row = -1;
+        bool open = true;
+        while (open && current < static_cast<unsigned>(nfree)) {
+          const unsigned idx = current + static_cast<unsigned>(t);
+          const int r = (idx < static_cast<unsigned>(nfree)) ? static_cast<int>(W.fr[idx]) : -1;
+          const bool ok = r >= nr;
+          int cnt = g.reduce_min_int(ok ? kNoIdx : t);  // leading lanes whose entry is a dummy row
+          if (cnt > T) cnt = T;
+          if (cnt == 0) break;
+          const int rprev_lane = (t > 0 && t < cnt) ? static_cast<int>(W.fr[idx - 1]) : prev_last;
+          const int chunk_last = g.reduce_max((t == cnt - 1) ? r : -1);
+          g.sync();  // every lane has read its entries before the list is rewritten below
+          if (t < cnt) {
+            const int k = k0 + t;
+            if (k < s) { W.x[r] = cj1; W.y[cj1] = r; }
+            else {
+              W.x[r] = cj2;
+              if (k == s) { if (bi) W.fr[nf0] = b0; }
+              else W.fr[nf0 + bi + (k - s - 1)] = rprev_lane;
+            }
+          }
+          k0 += cnt;
+          current += static_cast<unsigned>(cnt);
+          prev_last = chunk_last;
+          last_row = chunk_last;
+          open = cnt == T;
+        }
+        if (k0 > 0) {
+          if (k0 > s) {
+            if (t == 0) W.y[cj2] = last_row;
+            new_free = nf0 + bi + (k0 - s - 1);
+          }
+          rr_cnt += static_cast<unsigned>(k0);
+          n_carr += k0;
+          g.sync();
+          if (current < static_cast<unsigned>(nfree)) {
+            nxt = W.fr[current];
+            nxt_row = (nxt < nr) ? C.row(nxt) : typename Cost::Row();
+          }
+          continue;
+        }
+      }
       ++rr_cnt;
       ++n_carr;
       const bool from_list = forwarded < 0;
@@ -389,6 +445,42 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
   int pf_start = (nfree > 0) ? W.fr[0] : 0;
   typename Cost::Row pf_row = (nfree > 0 && pf_start < nr) ? C.row(pf_start) : typename Cost::Row();
   for (int f = 0; f < nfree; ++f) {
+    // ---- run of dummy starts in closed form ----
+    // While the dummy-start cache is valid every dummy start takes the largest free member of the same tied set and
+    // changes no dual, so a run of K consecutive dummy starts takes the K largest members in descending order.
+    if (da_valid && pf_start >= nr && f + 1 < nfree && static_cast<int>(W.fr[f + 1]) >= nr) {
+      g.sync();
+      const int nl = compact_ascending(g, n, [&](int q) {
+        const int j = n - 1 - q;
+        return (((j < nc) ? half : 0.0) - W.v[j]) == da_g0 && W.y[j] < 0;
+      }, W.lst);  // lst[k] = n-1 - (k-th largest free tied column)
+      int m = 0;
+      bool open = nl > 0;
+      while (open) {
+        const int idx = f + m + t;
+        const int r = (idx < nfree && m + t < nl) ? static_cast<int>(W.fr[idx]) : -1;
+        int cnt = g.reduce_min_int((r >= nr) ? kNoIdx : t);
+        if (cnt > T) cnt = T;
+        if (t < cnt) {
+          const int j = n - 1 - static_cast<int>(W.lst[m + t]);
+          W.y[j] = r;
+          W.x[r] = j;
+        }
+        m += cnt;
+        open = cnt == T;
+      }
+      g.sync();
+      if (m > 0) {
+        n_paths += m;
+        f += m;
+        if (f < nfree) {
+          pf_start = W.fr[f];
+          pf_row = (pf_start < nr) ? C.row(pf_start) : typename Cost::Row();
+        }
+        --f;  // the loop increment
+        continue;
+      }
+    }
     const int start = pf_start;
     ++n_paths;
     const ExtRow<Cost> R0 = ext_row_pf<Cost>(P, start, pf_row);

@@ -80,6 +80,12 @@ struct DevGroup {
 #undef MOT_STEP
     return bcast63_f64(v);
   }
+  static __device__ __forceinline__ float wave_min_f32(float v) {  // NaN never wins (same as `o < v ? o : v` folding)
+#define MOT_STEP(C, M) { const float o = __int_as_float(dpp<C, M>(__float_as_int(v))); v = (o < v) ? o : v; }
+    MOT_DPP_STEPS(MOT_STEP)
+#undef MOT_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  }
   static __device__ __forceinline__ int wave_max_i32(int v) {
 #define MOT_STEP(C, M) { const int o = dpp<C, M>(v); v = (o > v) ? o : v; }
     MOT_DPP_STEPS(MOT_STEP)
@@ -109,6 +115,17 @@ struct DevGroup {
     __syncthreads();
     double r = s[0];
     for (int w = 1; w < nw; ++w) { double o = s[w]; r = (o < r) ? o : r; }
+    return r;
+  }
+  __device__ __forceinline__ float reduce_min_f32(float v) {
+    v = wave_min_f32(v);
+    const int nw = (size_ + 63) >> 6;
+    if (nw == 1) return v;
+    float* s = slot<float>();
+    if ((tid_ & 63) == 0) s[tid_ >> 6] = v;
+    __syncthreads();
+    float r = s[0];
+    for (int w = 1; w < nw; ++w) { float o = s[w]; r = (o < r) ? o : r; }
     return r;
   }
   __device__ __forceinline__ int reduce_max(int v) {

@@ -30,7 +30,7 @@ namespace mot {
 // Cost functors. A functor exposes the real nr x nc block of the problem:
 //   Row row(i)        row-invariant context (pointer to the matrix row, or the row's box in registers) — plain data,
 //                     no pointer back to the functor, so that functor and context both stay in registers
-//   at(row, j)        element (i, j) as double
+//   at(row, j)        element (i, j) as double (the conversion of a float: every cost is a float, lap_solver.hpp:303)
 //   at(i, j)          same, without a row context (column scans)
 // MatrixCost reads a materialised float matrix; IouCost (lap_cost.hpp) recomputes IoU-family costs from boxes
 // staged in LDS, so the N x M matrix never exists in memory.
@@ -42,6 +42,7 @@ struct MatrixCost {
   MOT_DEV Row row(int i) const { return Row{cost + static_cast<size_t>(i) * ld}; }
   MOT_DEV double at(const Row& r, int j) const { return static_cast<double>(gld(r.p, j)); }
   MOT_DEV double at_owned(const Row& r, int, int j) const { return at(r, j); }
+  MOT_DEV float at_owned_f(const Row& r, int, int j) const { return gld(r.p, j); }
   MOT_DEV double at(int i, int j) const { return static_cast<double>(gld(cost, static_cast<size_t>(i) * ld + j)); }
 };
 struct LapDims {
@@ -65,11 +66,12 @@ struct LapWorkT {
   MemPtr<int, kMemGlobal> cols;   // lapjv's column permutation / phase-1 unique-row list
   MemPtr<int, kMemGlobal> tmp;    // tie flags (slow path)
   MemPtr<int, kMemGlobal> lst;    // compacted tie positions (slow path)
-  long long* cyc = nullptr;  // optional profiling: [0..3] cycles in phase 1a (column minima), 1b (transfer), 2, 3; [4..7] pass counts
+  MemPtr<double, kMemGlobal> rlb; // per real row: minimum raw cost over the real columns (phase 1), see "hopeless rows"
+  long long* cyc = nullptr;  // optional profiling: [0..3] cycles in phase 1a (column minima), 1b (transfer), 2, 3; [4..7] n_uniq, serial row-reduction rounds, serial augmentations, n
 };
 using LapWork = LapWorkT<kMemAny, kMemAny>;
 MOT_HD size_t lap_hot_bytes(int n) { return static_cast<size_t>(n) * (sizeof(double) + 3 * sizeof(int)); }
-MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (sizeof(double) + 4 * sizeof(int)); }
+MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 4 * sizeof(int)); }
 MOT_HD size_t lap_work_bytes(int n) { return lap_hot_bytes(n) + lap_cold_bytes(n); }
 template <class Work>
 MOT_HD void lap_carve_hot(Work& w, void* base, int n) {
@@ -83,6 +85,7 @@ template <class Work>
 MOT_HD void lap_carve_cold(Work& w, void* base, int n) {
   char* p = static_cast<char*>(base);
   w.d.p = reinterpret_cast<double*>(p); p += sizeof(double) * n;
+  w.rlb.p = reinterpret_cast<double*>(p); p += sizeof(double) * n;
   w.pred.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.cols.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.tmp.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
@@ -197,43 +200,68 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     G::atomic_add(W.fr.raw(im), 1);
   };
   int j_first = t;  // first column of this lane not handled by the register-cached sweep below
+  // "Hopeless rows": lapjv's duals only ever decrease, so rlb[i] - (largest column dual after the column reduction) stays
+  // a lower bound of every reduced cost of real row i over the real columns for the whole solve. A row whose bound lies
+  // above the best dummy-column values can only ever pick dummy columns — such rows (every track with no detection near
+  // it) are resolved in closed-form runs below, exactly like the dummy rows. Needs the row-major sweep of phase 1.
+  const bool have_lb = Cost::kRPL > 0 && nc <= Cost::kRPL * T;
+  double vmax0 = 0.0;
   if constexpr (Cost::kRPL > 0) {
     // all of the lane's cached real columns advance together down the rows: one row-box fetch per row, no column loads
-    double vmk[Cost::kRPL];
+    // (in float: every cost IS a float and float -> double is exact and monotone, so minima and their rows are the same)
+    float vmk[Cost::kRPL];
     int imk[Cost::kRPL];
 #pragma unroll
-    for (int k = 0; k < Cost::kRPL; ++k) { vmk[k] = kLapLarge; imk[k] = 0; }
+    for (int k = 0; k < Cost::kRPL; ++k) { vmk[k] = static_cast<float>(kLapLarge); imk[k] = 0; }
+    double neg_vmax = 1e300;
     constexpr int kRowBatch = 4;  // row contexts are fetched a batch at a time so that their load latencies overlap
     for (int i0 = 0; i0 < nr; i0 += kRowBatch) {
       typename Cost::Row RB[kRowBatch];
 #pragma unroll
       for (int u = 0; u < kRowBatch; ++u) RB[u] = C.row((i0 + u < nr) ? i0 + u : nr - 1);
+      float rm[kRowBatch];  // this lane's share of each row's minimum
 #pragma unroll
       for (int u = 0; u < kRowBatch; ++u) {
         const int i = i0 + u;
+        rm[u] = 3.0e38f;
         if (i < nr) {
 #pragma unroll
           for (int k = 0; k < Cost::kRPL; ++k) {
             const int jj = t + k * T;
             if (jj < nc) {
-              const double c = C.at_owned(RB[u], k, jj);
+              const float c = C.at_owned_f(RB[u], k, jj);
               if (c < vmk[k]) { vmk[k] = c; imk[k] = i; }
+              if (c < rm[u]) rm[u] = c;
             }
           }
         }
+      }
+      if (have_lb) {
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) rm[u] = g.reduce_min_f32(rm[u]);  // independent chains: they interleave
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u)
+          if (t == 0 && i0 + u < nr) W.rlb[i0 + u] = static_cast<double>(rm[u]);
       }
     }
 #pragma unroll
     for (int k = 0; k < Cost::kRPL; ++k) {
       const int jj = t + k * T;
       if (jj < nc) {
-        double vm = vmk[k];
+        double vm = static_cast<double>(vmk[k]);
         int im = imk[k];
+        if (!(vmk[k] < static_cast<float>(kLapLarge))) { vm = kLapLarge; im = 0; }  // nothing below LARGE (:41-46)
         if (half < vm) { vm = half; im = nr; }  // rows nr.. are all `half`: only the first can win
         publish_column(jj, vm, im);
+        if (-vm < neg_vmax) neg_vmax = -vm;  // (negated: the group primitive is a minimum)
       }
     }
     j_first = t + Cost::kRPL * T;
+    if (have_lb) {
+      vmax0 = -g.reduce_min(neg_vmax);
+      g.sync();
+      for (int i = t; i < nr; i += T) W.rlb[i] -= vmax0;  // raw row minimum -> lower bound of the row's reduced costs
+    }
   }
   for (int j = j_first; j < nc; j += T) {  // real columns outside the register cache (or all of them without one)
     double vm = kLapLarge;
@@ -265,6 +293,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
   // row, so it stays valid until the dual of some dummy column is written (rare: the dummy block is one big tie).
   bool dq_ok = false;   // uniform
   Top2 dq = top2_empty();
+  Top2 dqg = top2_empty();  // the same over the whole group (only kept when row lower bounds exist)
   int dq_ptr = -1;
   auto ensure_dq = [&]() {
     if (dq_ok) return;
@@ -277,8 +306,11 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
       }
       if (c == dq.v1) dq_ptr = j;
     });
+    if (have_lb) dqg = g.reduce_top2(dq);
     dq_ok = true;
   };
+  // real row r cannot prefer any real column to the dummy columns whose value is <= bound (call with dq current)
+  auto hopeless = [&](int r, double bound) { return r >= 0 && r < nr && static_cast<double>(W.rlb[r]) > bound; };
   int pf_i = (n_uniq > 0) ? W.cols[0] : 0;
   int pf_j = (n_uniq > 0) ? W.x[pf_i] : 0;
   for (int u = 0; u < n_uniq; ++u) {
@@ -314,15 +346,28 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     int nxt = W.fr[0];
     typename Cost::Row nxt_row = (nxt < nr) ? C.row(nxt) : typename Cost::Row();
     while (current < static_cast<unsigned>(nfree)) {
-      // ---- run of dummy rows in closed form ----
-      // A dummy row's two best columns are the cached tuple dc. When they tie exactly (v2 == v1: always, until a real
-      // row pulls a dummy column's dual down) the round changes no dual: the row takes j1 if that column is free, else
-      // j2, whose previous owner goes back to the free list. A run of K consecutive dummy rows of the free list is
-      // therefore a chain — each row takes j2 and displaces its predecessor — whose outcome is written here in one
-      // step instead of K serial rounds. (The extension makes every unmatched detection such a row.)
-      if (forwarded < 0 && dc_valid && nxt >= nr && dc.v1 == dc.v2 && dc.v2 < kLapLarge && dc.j2 != kNoIdx &&
-          (rr_cnt + 1u) < (current + 1u) * static_cast<unsigned>(n)) {
-        const int cj1 = dc.j1, cj2 = dc.j2;
+      // ---- runs of rows with a fixed, exactly tied pair of best columns, in closed form ----
+      // A dummy row's two best columns are the cached tuple dc; a hopeless real row's are the two best dummy columns
+      // dqg. When the pair ties exactly (v2 == v1: always, until some row pulls a dummy column's dual down) the round
+      // changes no dual: the row takes j1 if that column is free, else j2, whose previous owner goes back to the free
+      // list. A run of K consecutive such rows of the free list is therefore a chain — each row takes j2 and displaces
+      // its predecessor — whose outcome is written here in one step instead of K serial rounds. (The extension turns
+      // every unmatched detection into a dummy row and every unmatched track into a hopeless one.)
+      bool use_d = false, use_h = false;
+      int cj1 = -1, cj2 = -1;
+      if (forwarded < 0 && (rr_cnt + 1u) < (current + 1u) * static_cast<unsigned>(n)) {
+        const bool d_tie = dc_valid && dc.v1 == dc.v2 && dc.v2 < kLapLarge && dc.j2 != kNoIdx;
+        if (have_lb) ensure_dq();
+        const bool h_tie = have_lb && dqg.v1 == dqg.v2 && dqg.v2 < kLapLarge && dqg.j2 != kNoIdx;
+        if (nxt >= nr) {
+          if (d_tie) { use_d = true; cj1 = dc.j1; cj2 = dc.j2; use_h = h_tie && dqg.j1 == cj1 && dqg.j2 == cj2; }
+        } else if (h_tie && hopeless(nxt, dqg.v2)) {
+          use_h = true; cj1 = dqg.j1; cj2 = dqg.j2;
+          use_d = d_tie && dc.j1 == cj1 && dc.j2 == cj2;
+        }
+      }
+      if (use_d || use_h) {
+        const double hb = dqg.v2;
         g.sync();  // the previous round's owner writes to y[] are visible
         const int a0 = W.y[cj1], b0 = W.y[cj2];
         const int s = (a0 < 0) ? 1 : 0;   // rows of the run that take j1 (at most the first)
@@ -333,8 +378,8 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
         while (open && current < static_cast<unsigned>(nfree)) {
           const unsigned idx = current + static_cast<unsigned>(t);
           const int r = (idx < static_cast<unsigned>(nfree)) ? static_cast<int>(W.fr[idx]) : -1;
-          const bool ok = r >= nr;
-          int cnt = g.reduce_min_int(ok ? kNoIdx : t);  // leading lanes whose entry is a dummy row
+          const bool ok = (use_d && r >= nr) || (use_h && hopeless(r, hb));
+          int cnt = g.reduce_min_int(ok ? kNoIdx : t);  // leading lanes whose entry belongs to the run
           if (cnt > T) cnt = T;
           if (cnt == 0) break;
           const int rprev_lane = (t > 0 && t < cnt) ? static_cast<int>(W.fr[idx - 1]) : prev_last;
@@ -361,7 +406,6 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             new_free = nf0 + bi + (k0 - s - 1);
           }
           rr_cnt += static_cast<unsigned>(k0);
-          n_carr += k0;
           g.sync();
           if (current < static_cast<unsigned>(nfree)) {
             nxt = W.fr[current];
@@ -401,6 +445,10 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
         if (!dummy_row) {
           ensure_dq();
           for_lane_real(C, R, W.v, t, T, nc, push);
+          if (have_lb) {  // the row's current minimum over the real columns: a tighter bound from here on
+            const double rreal = g.reduce_min(tt.v1);
+            if (t == 0) W.rlb[fi] = rreal;
+          }
           push(dq.v1, dq.j1);  // the lane's dummy columns come after its real ones, best first
           push(dq.v2, dq.j2);
         } else {
@@ -445,6 +493,46 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
   int pf_start = (nfree > 0) ? W.fr[0] : 0;
   typename Cost::Row pf_row = (nfree > 0 && pf_start < nr) ? C.row(pf_start) : typename Cost::Row();
   for (int f = 0; f < nfree; ++f) {
+    // ---- run of hopeless real starts in closed form ----
+    // Such a start's minimum is the best dummy-column value, its tied set the free dummy columns attaining it, and it
+    // changes no dual: a run of K of them takes the K largest members in descending order.
+    if (have_lb && pf_start < nr && f + 1 < nfree) {
+      ensure_dq();
+      const double hb = dqg.v1;
+      if (hb < kLapLarge && hopeless(pf_start, hb) && hopeless(static_cast<int>(W.fr[f + 1]), hb)) {
+        g.sync();
+        const int nd = n - nc;
+        const int nl = compact_ascending(g, nd, [&](int q) {
+          const int j = n - 1 - q;
+          return (half - W.v[j]) == hb && W.y[j] < 0;
+        }, W.lst);
+        int m = 0;
+        bool open = nl > 0;
+        while (open) {
+          const int idx = f + m + t;
+          const int r = (idx < nfree && m + t < nl) ? static_cast<int>(W.fr[idx]) : -1;
+          int cnt = g.reduce_min_int(hopeless(r, hb) ? kNoIdx : t);
+          if (cnt > T) cnt = T;
+          if (t < cnt) {
+            const int j = n - 1 - static_cast<int>(W.lst[m + t]);
+            W.y[j] = r;
+            W.x[r] = j;
+          }
+          m += cnt;
+          open = cnt == T;
+        }
+        g.sync();
+        if (m > 0) {
+          f += m;
+          if (f < nfree) {
+            pf_start = W.fr[f];
+            pf_row = (pf_start < nr) ? C.row(pf_start) : typename Cost::Row();
+          }
+          --f;  // the loop increment
+          continue;
+        }
+      }
+    }
     // ---- run of dummy starts in closed form ----
     // While the dummy-start cache is valid every dummy start takes the largest free member of the same tied set and
     // changes no dual, so a run of K consecutive dummy starts takes the K largest members in descending order.
@@ -471,7 +559,6 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
       }
       g.sync();
       if (m > 0) {
-        n_paths += m;
         f += m;
         if (f < nfree) {
           pf_start = W.fr[f];

@@ -51,11 +51,18 @@ struct IouCostT {
     int i;
     float a[4], area;
   };
-  MOT_DEV double eval(const Row& r, const float b[4], float barea, float cf, int j) const {
+  MOT_DEV float eval_f(const Row& r, const float b[4], float barea, float cf, int j) const {
     const float iou = iou_pair(r.a, r.area, b, barea);
     const float* e = emb;
     const size_t off = static_cast<size_t>(r.i) * lde + j;
-    return static_cast<double>(cost_from_iou(prm, iou, cf, [&]() { return gld(e, off); }));
+    return cost_from_iou(prm, iou, cf, [&]() { return gld(e, off); });
+  }
+  MOT_DEV double eval(const Row& r, const float b[4], float barea, float cf, int j) const {
+    return static_cast<double>(eval_f(r, b, barea, cf, j));
+  }
+  MOT_DEV float at_owned_f(const Row& r, int k, int j) const {  // the cost as the float it is (phase 1 works in float)
+    const Owned& o = own[k];
+    return eval_f(r, o.b, o.area, o.conf, j);
   }
   MOT_DEV double at(const Row& r, int j) const {
     float b[4], barea;

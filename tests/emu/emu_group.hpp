@@ -41,6 +41,7 @@ struct EmuGroup {
     for (int t = 1; t < sh->T; ++t) r = (s[t] < r) ? s[t] : r;
     return r;
   }
+  float reduce_min_f32(float v) { return static_cast<float>(reduce_min(static_cast<double>(v))); }
   int reduce_max(int v) {
     auto& s = sh->s_int[phase++ & 1];
     s[tid_] = v;

@@ -96,3 +96,28 @@ def test_emulated_kernel_north_star_shape(orc, emu):
     xo, yo = orc.linear_assignment(c, th)
     xe, ye = emu(c, th, 8)
     assert (xo == xe).all() and (yo == ye).all()
+
+
+def test_unmatched_tracks_and_detections_closed_form_runs(orc, emu_iou):
+    # tracking-like scenes: most tracks have no detection near them (rows that can only take dummy columns) and many
+    # detections start new tracks (dummy rows) — the closed-form run handling of lap_core.hpp must reproduce lapjv's
+    # serial displacement chains exactly, including runs interrupted by contested rows and partially filled chunks
+    r = np.random.default_rng(11)
+    for n, m, near, T, rpl in [(300, 100, 60, 16, 8), (150, 200, 90, 64, 4), (90, 40, 0, 8, 8), (64, 64, 64, 8, 8),
+                               (257, 129, 100, 64, 4), (33, 17, 9, 3, 8)]:
+        cx, cy = r.uniform(0, 6000, n), r.uniform(0, 4000, n)
+        w = r.uniform(30, 90, n)
+        a = np.stack([cx - w / 2, cy - w, cx + w / 2, cy + w], 1).astype(np.float32)
+        b = np.zeros((m, 4), np.float32)
+        pick = r.permutation(n)[:near]
+        b[:near] = a[pick] + r.normal(0, 6, (near, 4)).astype(np.float32)
+        k = m - near
+        fx, fy, fw = r.uniform(0, 6000, k), r.uniform(0, 4000, k), r.uniform(30, 90, k)
+        b[near:] = np.stack([fx - fw / 2, fy - fw, fx + fw / 2, fy + fw], 1)
+        b = b[r.permutation(m)]
+        conf = r.uniform(0.3, 1, m).astype(np.float32)
+        for mode, th in ((1, 0.7), (2, 0.8), (1, 0.3)):
+            cost = {1: orc.iou_distance(a, b), 2: orc.fuse_score(orc.iou_distance(a, b), conf)}[mode]
+            xo, yo = orc.linear_assignment(cost, th)
+            xe, ye = emu_iou(a, b, conf, mode, th, T, rpl)
+            assert (xo == xe).all() and (yo == ye).all(), (n, m, near, T, rpl, mode, th)

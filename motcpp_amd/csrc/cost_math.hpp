@@ -38,13 +38,8 @@ struct CostParams {
 };
 template <class EmbFn>
 MOT_HD float cost_from_iou(const CostParams& p, float iou, float conf, EmbFn emb_at) {
-  if (p.mode == MOT_COST_IOU) return iou;
-  if (p.mode == MOT_COST_NEG_IOU) return -iou;
   float d = 1.0f - iou;  // iou_distance
-  if (p.mode == MOT_COST_IOU_DIST_FUSE) {  // fuse_score: 1 - (1 - d) * conf
-    const float sim = 1.0f - d;
-    d = 1.0f - sim * conf;
-  } else if (p.mode == MOT_COST_BOTSORT) {
+  if (p.mode == MOT_COST_BOTSORT) {
     const bool far = d > p.prox;  // mask from the un-fused distance (botsort.cpp:439)
     if (p.fuse) { const float sim = 1.0f - d; d = 1.0f - sim * conf; }
     if (p.has_emb || p.const_emb) {
@@ -56,8 +51,14 @@ MOT_HD float cost_from_iou(const CostParams& p, float iou, float conf, EmbFn emb
       }
       d = smin(d, e);
     }
+    return d;
   }
-  return d;
+  // the four plain modes as selects on the (uniform) mode rather than branches: inside the assignment solver this runs
+  // once per visited pair, where a taken scalar branch costs more than the two spare multiplies
+  const float fused = 1.0f - (1.0f - d) * conf;  // fuse_score: 1 - (1 - d) * conf
+  const float dist = (p.mode == MOT_COST_IOU_DIST_FUSE) ? fused : d;
+  const float sim = (p.mode == MOT_COST_NEG_IOU) ? -iou : iou;
+  return (p.mode == MOT_COST_IOU || p.mode == MOT_COST_NEG_IOU) ? sim : dist;
 }
 
 }  // namespace mot

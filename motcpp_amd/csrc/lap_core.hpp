@@ -345,6 +345,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     // beyond the read position are never rewritten during a pass, so the prefetched value cannot go stale)
     int nxt = W.fr[0];
     typename Cost::Row nxt_row = (nxt < nr) ? C.row(nxt) : typename Cost::Row();
+    double nxt_lb = (have_lb && nxt < nr) ? static_cast<double>(W.rlb[nxt]) : 0.0;  // (an older bound is still a bound)
     while (current < static_cast<unsigned>(nfree)) {
       // ---- runs of rows with a fixed, exactly tied pair of best columns, in closed form ----
       // A dummy row's two best columns are the cached tuple dc; a hopeless real row's are the two best dummy columns
@@ -361,7 +362,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
         const bool h_tie = have_lb && dqg.v1 == dqg.v2 && dqg.v2 < kLapLarge && dqg.j2 != kNoIdx;
         if (nxt >= nr) {
           if (d_tie) { use_d = true; cj1 = dc.j1; cj2 = dc.j2; use_h = h_tie && dqg.j1 == cj1 && dqg.j2 == cj2; }
-        } else if (h_tie && hopeless(nxt, dqg.v2)) {
+        } else if (h_tie && nxt_lb > dqg.v2) {
           use_h = true; cj1 = dqg.j1; cj2 = dqg.j2;
           use_d = d_tie && dc.j1 == cj1 && dc.j2 == cj2;
         }
@@ -410,6 +411,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           if (current < static_cast<unsigned>(nfree)) {
             nxt = W.fr[current];
             nxt_row = (nxt < nr) ? C.row(nxt) : typename Cost::Row();
+            nxt_lb = (have_lb && nxt < nr) ? static_cast<double>(W.rlb[nxt]) : 0.0;
           }
           continue;
         }
@@ -425,6 +427,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
       if (from_list && current < static_cast<unsigned>(nfree)) {
         nxt = W.fr[current];
         nxt_row = (nxt < nr) ? C.row(nxt) : typename Cost::Row();
+        nxt_lb = (have_lb && nxt < nr) ? static_cast<double>(W.rlb[nxt]) : 0.0;
       }
       // Dummy rows (fi >= nr) all have the same cost row, so while no dual changes their top-2 is the same tuple:
       // it is reduced once and reused until some v[j] is written (the extension makes these rounds a large share).

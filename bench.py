@@ -38,6 +38,23 @@ WORKLOADS = {
 }
 
 
+def cpu_budget():
+    """CPUs this process may use on average: the cgroup quota if there is one, else the online CPUs."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def world_local():
+    """ranks sharing this node (torchrun sets LOCAL_WORLD_SIZE)"""
+    return int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,9 +93,10 @@ def main():
 
     tracker, P, M, D, desc = WORKLOADS[args.workload]
     S = args.streams or {"C2": 8192, "SORT": 8192, "NS": 8192, "C5": 4096, "C3": 512, "C4": 8}[args.workload]
-    # host workers block between phases, so more workers than the box's CPU quota (16 on the GPU boxes) still pay off:
-    # the bursts of lifecycle work get shorter and the workers sleep through the GPU waits
-    threads = args.threads or min(64, os.cpu_count() or 1)
+    # host workers block between phases, so about twice as many workers as the box's CPU quota pay off (the bursts of
+    # lifecycle work get shorter and the workers sleep through the GPU waits); far more than that and the cgroup
+    # throttles the whole process (measured on the 16-CPU-quota GPU boxes: 32 workers 456k frames/s, 64 workers 268k)
+    threads = args.threads or max(2, min(os.cpu_count() or 1, 64, 2 * cpu_budget() // max(1, world_local())))
     K, W = args.steps, args.warmup
     F = K + W
 

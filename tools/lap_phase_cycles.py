@@ -1,4 +1,6 @@
-import sys, time; sys.path.insert(0,'.')
+"""Per-phase cycle counters of ONE assignment problem (mot_lap_task.prof) at the C2 and north-star shapes: the tool behind
+the latency numbers in DESIGN.md §4. Needs a gfx950 GPU: `gpurun -- python tools/lap_phase_cycles.py`."""
+import sys, time; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from motcpp_amd import _lib as L
 from motcpp_amd.synth import SynthStream

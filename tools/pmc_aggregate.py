@@ -1,3 +1,5 @@
+"""Sums rocprofv3 --pmc counter_collection CSVs per kernel into one small JSON (the raw CSVs are too big to bring back from
+the GPU box). Run on the box after `rocprofv3 --pmc ... -d /tmp/pmcout`."""
 import csv, collections, json, sys, glob
 out={}
 for f in sorted(glob.glob('/tmp/pmcout/*counter_collection.csv')):

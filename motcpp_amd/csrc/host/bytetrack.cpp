@@ -77,8 +77,9 @@ class ByteTrackGpu final : public Staged {
 
     lap1_ = Core::Lap();
     if (np > 0) {
-      std::vector<int> src(np), dst(np);
-      std::vector<uint8_t> fl(np);
+      std::vector<int>&src = w_src_, &dst = w_dst_;
+      std::vector<uint8_t>& fl = w_fl_;
+      src.resize(np); dst.resize(np); fl.resize(np);
       for (int i = 0; i < np; ++i) {
         const Trk& t = trk(pool_[i]);
         src[i] = t.slot; dst[i] = core_.scratch_slot(i);
@@ -119,18 +120,22 @@ class ByteTrackGpu final : public Staged {
   void after_first() {
     queued_ = false;
     const int np = static_cast<int>(pool_.size()), nd = static_cast<int>(high_.size());
-    std::vector<int> x(np, -1), y(nd, -1);
+    const int32_t* x;
+    const int32_t* y;
     if (lap1_.queued) {
       record(lap1_);
-      x.assign(lap1_.x.h, lap1_.x.h + np);
-      y.assign(lap1_.y.h, lap1_.y.h + nd);
+      x = lap1_.x.h;
+      y = lap1_.y.h;
     } else {
-      if (record_laps) laps_.push_back(LapRecord{x, y});  // utils::linear_assignment's empty-side early return (matching.cpp:20-27)
+      w_x_.assign(np, -1); w_y_.assign(nd, -1);
+      x = w_x_.data(); y = w_y_.data();
+      if (record_laps) laps_.push_back(LapRecord{std::vector<int>(np, -1), std::vector<int>(nd, -1)});  // utils::linear_assignment's empty-side early return (matching.cpp:20-27)
     }
     upd_src_.clear(); upd_dst_.clear(); upd_meas_.clear();
     refind_.clear();
     u_det_.clear();
-    std::vector<int> u_track;
+    std::vector<int>& u_track = w_utrack_;
+    u_track.clear();
     for (int i = 0; i < np; ++i) {
       if (x[i] < 0) { u_track.push_back(i); continue; }
       Trk& t = trk(pool_[i]);
@@ -147,7 +152,8 @@ class ByteTrackGpu final : public Staged {
       if (pool_[i].in_active && active_[pool_[i].idx].state == Tracked) { r_tracked_.push_back(pool_[i].idx); r_pool_.push_back(i); }
     lap2_ = Core::Lap(); lap3_ = Core::Lap();
     if (!second_.empty() && !r_tracked_.empty()) {
-      std::vector<int> slots;
+      std::vector<int>& slots = w_slots_;
+      slots.clear();
       for (int ai : r_tracked_) slots.push_back(active_[ai].slot);
       float* rb = core_.boxes(slots, nullptr);
       second_d_ = core_.ints(second_);
@@ -160,7 +166,8 @@ class ByteTrackGpu final : public Staged {
     }
     // unconfirmed tracks (stored, un-predicted state) vs. leftover high detections (:455-542)
     if (!unconf_idx_.empty() && !u_det_.empty()) {
-      std::vector<int> slots, rem;
+      std::vector<int>&slots = w_slots2_, &rem = w_rem_;
+      slots.clear(); rem.clear();
       for (int ai : unconf_idx_) slots.push_back(active_[ai].slot);
       for (int j : u_det_) rem.push_back(high_[j]);
       float* ub = core_.boxes(slots, nullptr);
@@ -175,8 +182,9 @@ class ByteTrackGpu final : public Staged {
   }
 
   void after_second() {
-    std::vector<Trk> lost_new;
-    std::vector<int> removed_ids;
+    std::vector<Trk>& lost_new = w_lost_new_;
+    std::vector<int>& removed_ids = w_removed_;
+    lost_new.clear(); removed_ids.clear();
     if (lap2_.queued) {
       record(lap2_);
       for (int i = 0; i < lap2_.n; ++i) {
@@ -191,7 +199,8 @@ class ByteTrackGpu final : public Staged {
         }
       }
     }
-    std::vector<int> u_det_final;
+    std::vector<int>& u_det_final = w_udet_final_;
+    u_det_final.clear();
     if (lap3_.queued) {
       record(lap3_);
       for (int j = 0; j < lap3_.m; ++j) if (lap3_.y.h[j] < 0) u_det_final.push_back(u_det_[j]);
@@ -211,8 +220,9 @@ class ByteTrackGpu final : public Staged {
       u_det_final = u_det_;
     }
     // new tracks (:546-554)
-    std::vector<Trk> fresh;
-    std::vector<int> init_dst, init_meas;
+    std::vector<Trk>& fresh = w_fresh_;
+    std::vector<int>&init_dst = w_init_dst_, &init_meas = w_init_meas_;
+    fresh.clear(); init_dst.clear(); init_meas.clear();
     for (int j : u_det_final) {
       const int det = high_[j];
       if (det_conf_[det] >= det_thresh_) {
@@ -231,7 +241,8 @@ class ByteTrackGpu final : public Staged {
       if (frame_count_ - t.frame_id > max_time_lost_) { t.state = Removed; removed_ids.push_back(t.id); }
 
     // list algebra (:565-580). Copies in the reference == moves here: one slot per id.
-    std::vector<Trk> na;
+    std::vector<Trk>& na = w_na_;
+    na.clear();
     IdSet& active_ids = set_a_;
     active_ids.clear();
     for (const Trk& t : active_)
@@ -241,7 +252,8 @@ class ByteTrackGpu final : public Staged {
     for (int id : refind_)
       for (const Trk& t : lost_)
         if (t.id == id && active_ids.insert(id)) na.push_back(t);
-    std::vector<Trk> nl;
+    std::vector<Trk>& nl = w_nl_;
+    nl.clear();
     IdSet& rm = set_b_;
     rm.clear();
     for (int id : removed_ids) rm.insert(id);
@@ -252,8 +264,8 @@ class ByteTrackGpu final : public Staged {
     }
     for (const Trk& t : lost_new)
       if (!rm.count(t.id)) nl.push_back(t);
-    active_ = std::move(na);
-    lost_ = std::move(nl);
+    active_.swap(na);  // (swap, not move: both buffers keep their capacity for the next frame)
+    lost_.swap(nl);
 
     core_.initiate(init_dst, init_meas, dets_);
     core_.update(upd_src_, upd_dst_, upd_meas_, dets_);
@@ -261,7 +273,8 @@ class ByteTrackGpu final : public Staged {
   }
 
   void queue_boxes_and_dups(int cap) {
-    std::vector<int> sa, sl;
+    std::vector<int>&sa = w_sa_, &sl = w_sl_;
+    sa.clear(); sl.clear();
     for (const Trk& t : active_) sa.push_back(t.slot);
     for (const Trk& t : lost_) sl.push_back(t.slot);
     abox_ = Span<float>();
@@ -288,15 +301,17 @@ class ByteTrackGpu final : public Staged {
         queue_boxes_and_dups(np + 16);
         return false;
       }
-      std::vector<char> dupa(active_.size(), 0), dupb(lost_.size(), 0);
+      std::vector<char>&dupa = w_dupa_, &dupb = w_dupb_;
+      dupa.assign(active_.size(), 0); dupb.assign(lost_.size(), 0);
       for (int k = 0; k < np; ++k) {
         const int i = pairs_.h[2 * k], j = pairs_.h[2 * k + 1];
         const int tp = active_[i].frame_id - active_[i].start_frame;
         const int tq = lost_[j].frame_id - lost_[j].start_frame;
         if (tp > tq) dupb[j] = 1; else dupa[i] = 1;
       }
-      std::vector<Trk> ra, rb;
-      std::vector<int> keep_cols;
+      std::vector<Trk>&ra = w_na_, &rb = w_nl_;
+      std::vector<int>& keep_cols = w_cols_;
+      ra.clear(); rb.clear(); keep_cols.clear();
       for (size_t i = 0; i < active_.size(); ++i) {
         if (!dupa[i]) { ra.push_back(active_[i]); keep_cols.push_back(static_cast<int>(i)); }
         else dead_slots_.push_back(active_[i].slot);
@@ -306,9 +321,10 @@ class ByteTrackGpu final : public Staged {
         else dead_slots_.push_back(lost_[j].slot);
       }
       emit(ra, keep_cols, static_cast<int>(active_.size()));
-      active_ = std::move(ra); lost_ = std::move(rb);
+      active_.swap(ra); lost_.swap(rb);
     } else {
-      std::vector<int> cols(active_.size());
+      std::vector<int>& cols = w_cols_;
+      cols.resize(active_.size());
       for (size_t i = 0; i < cols.size(); ++i) cols[i] = static_cast<int>(i);
       emit(active_, cols, static_cast<int>(active_.size()));
     }
@@ -341,6 +357,12 @@ class ByteTrackGpu final : public Staged {
   int pairs_cap_ = 0;
   Core::Lap lap1_, lap2_, lap3_;
   std::vector<int> upd_src_, upd_dst_, upd_meas_, dead_slots_;
+  // reusable work buffers: the lifecycle allocates nothing in steady state
+  std::vector<int> w_src_, w_dst_, w_x_, w_y_, w_utrack_, w_slots_, w_slots2_, w_rem_, w_removed_, w_udet_final_, w_init_dst_,
+      w_init_meas_, w_sa_, w_sl_, w_cols_;
+  std::vector<uint8_t> w_fl_;
+  std::vector<char> w_dupa_, w_dupb_;
+  std::vector<Trk> w_lost_new_, w_fresh_, w_na_, w_nl_;
 };
 
 }  // namespace

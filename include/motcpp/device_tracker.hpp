@@ -2,6 +2,7 @@
 // (motcpp::rt::Staged) whose numeric work runs in HIP kernels behind the C ABI of motcpp_amd.h.
 #pragma once
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "tracker.hpp"
@@ -28,6 +29,7 @@ class DeviceTracker : public BaseTracker {
   bool validate_inputs_ = true;  // SORT does not call check_inputs (sort.cpp:102-110)
   bool skip_empty_ = false;      // BoT-SORT returns before touching any state when dets is empty (botsort.cpp:267-269)
   std::shared_ptr<rt::Device> dev_;
+  std::string asso_error_;       // OC-SORT with an unknown asso_func: update() throws this (ocsort.cpp:413 -> iou.hpp:405-407)
 
  private:
   std::unique_ptr<rt::Staged> impl_;

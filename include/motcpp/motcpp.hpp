@@ -7,3 +7,4 @@
 #include "trackers/ocsort.hpp"
 #include "trackers/botsort.hpp"
 #include "utils/matching.hpp"
+#include "utils/iou.hpp"

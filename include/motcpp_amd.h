@@ -125,6 +125,11 @@ typedef enum mot_cost_mode {
   MOT_COST_NEG_IOU = 3,       /* -iou (OC-SORT rematch)                                       */
   MOT_COST_BOTSORT = 4        /* min(fuse?(1-iou), gate(emb/2)) — botsort.cpp:433-466          */
 } mot_cost_mode;
+/* the pairwise similarity the cost is built from (AssociationFunction modes, include/motcpp/utils/iou.hpp:371-414);
+ * "iou" in the cost-mode formulas above means this value */
+typedef enum mot_assoc {
+  MOT_ASSOC_IOU = 0, MOT_ASSOC_HMIOU = 1, MOT_ASSOC_GIOU = 2, MOT_ASSOC_CIOU = 3, MOT_ASSOC_DIOU = 4, MOT_ASSOC_CENTROID = 5
+} mot_assoc;
 typedef struct mot_iou_task {
   int32_t n, m;
   const float* a; int32_t lda; const int32_t* aidx; /* row boxes [4][lda], optional gather       */
@@ -135,6 +140,8 @@ typedef struct mot_iou_task {
   const float* emb; int32_t lde;                    /* BOTSORT: cosine distances n x m (emb NULL and lde < 0: constant 1) */
   float prox_thresh, app_thresh; int32_t fuse;      /* BOTSORT                                   */
   int32_t* pairs; int32_t* npairs; int32_t pairs_cap; float pair_thresh; /* optional: (i,j) with value < thresh */
+  int32_t assoc;     /* mot_assoc (0 = IoU)                                                          */
+  float frame_diag;  /* CENTROID: sqrt(w*w + h*h) of the frame                                       */
 } mot_iou_task;
 int mot_iou_cost(mot_ctx* ctx, const mot_iou_task* tasks, int ntasks, int max_n, int max_m);
 
@@ -146,6 +153,7 @@ typedef struct mot_ocsort_task {
   const float* prev; int32_t ldp;  /* [5][ldp] k-previous observation x1,y1,x2,y2,score (-1: none)     */
   float vdc_weight;
   float* cost; float* iou; int32_t ldc; /* out nd x nt row-major: -(iou + angle) and iou               */
+  int32_t assoc; float frame_diag;      /* similarity used as "iou" (mot_assoc), frame diagonal for CENTROID */
 } mot_ocsort_task;
 int mot_ocsort_cost(mot_ctx* ctx, const mot_ocsort_task* tasks, int ntasks, int max_nd, int max_nt);
 
@@ -198,6 +206,10 @@ int mot_lap_solve(mot_ctx* ctx, const mot_lap_task* tasks, int ntasks, int max_n
 /* ---- host-pointer conveniences (synchronous; row-major matrices) ---------------------- */
 int mot_iou_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_xyxy, int m,
                       const float* bconf_or_null, int mode, float* cost);
+/* same with the similarity measure chosen (mot_assoc; frame size only matters for CENTROID):
+ * replaces utils::AssociationFunction(w, h, name)(a, b), include/motcpp/utils/iou.hpp:371-414, with mode = MOT_COST_IOU */
+int mot_assoc_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_xyxy, int m, const float* bconf_or_null,
+                        int mode, int assoc, int frame_w, int frame_h, float* cost);
 int mot_cosine_cost_host(mot_ctx* ctx, const float* a, int n, const float* b, int m, int d, float* out);
 int mot_ocsort_cost_host(mot_ctx* ctx, const float* dets5, int nd, const float* trks4, int nt,
                          const float* vel2, const float* prev5, float vdc_weight, float* cost, float* iou);

@@ -88,6 +88,15 @@ class Context:
                                              int(mode), _p(out)))
         return out
 
+    def assoc_cost(self, a, b, assoc, frame=(1920, 1080), mode=COST_IOU, conf=None):
+        """AssociationFunction(w, h, name)(a, b): assoc 0 iou, 1 hmiou, 2 giou, 3 ciou, 4 diou, 5 centroid."""
+        a, b = f32(a).reshape(-1, 4), f32(b).reshape(-1, 4)
+        out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+        c = f32(conf) if conf is not None else None
+        self._chk(self.lib.mot_assoc_cost_host(self.h, _p(a), a.shape[0], _p(b), b.shape[0], _p(c) if c is not None else None,
+                                               int(mode), int(assoc), int(frame[0]), int(frame[1]), _p(out)))
+        return out
+
     def cosine_cost(self, a, b):
         a, b = f32(a), f32(b)
         out = np.zeros((a.shape[0], b.shape[0]), np.float32)

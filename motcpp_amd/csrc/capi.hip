@@ -139,6 +139,10 @@ static void to_soa4(const float* aos, int n, int cols, int stride, std::vector<f
 }
 
 int mot_iou_cost_host(mot_ctx* c, const float* a, int n, const float* b, int m, const float* bconf, int mode, float* cost) {
+  return mot_assoc_cost_host(c, a, n, b, m, bconf, mode, MOT_ASSOC_IOU, 1, 1, cost);
+}
+int mot_assoc_cost_host(mot_ctx* c, const float* a, int n, const float* b, int m, const float* bconf, int mode, int assoc,
+                        int frame_w, int frame_h, float* cost) {
   if (n <= 0 || m <= 0) return MOT_OK;
   std::vector<float> sa, sb;
   to_soa4(a, n, 4, 4, sa);
@@ -152,6 +156,8 @@ int mot_iou_cost_host(mot_ctx* c, const float* a, int n, const float* b, int m, 
   mot_iou_task t{};
   t.n = n; t.m = m; t.a = da.as<float>(); t.lda = n; t.b = db.as<float>(); t.ldb = m;
   t.bconf = bconf ? dc.as<float>() : nullptr; t.cost = dcost.as<float>(); t.ldc = m; t.mode = mode;
+  t.assoc = assoc;
+  t.frame_diag = static_cast<float>(sqrt(static_cast<double>(frame_w * frame_w + frame_h * frame_h)));  // iou.hpp:329
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, mot::launch_iou(dt.as<mot_iou_task>(), 1, n, m, c->stream));
   MOT_HIP(c, hipMemcpyAsync(cost, dcost.p, static_cast<size_t>(n) * m * 4, hipMemcpyDeviceToHost, c->stream));

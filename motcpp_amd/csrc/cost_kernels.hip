@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(kThreads) iou_kernel(const mot_iou_task* __res
   }
   __syncthreads();
   const int tx = tid & 15, ty = tid >> 4;
-  const mot::CostParams cp{T.mode, T.prox_thresh, T.app_thresh, T.fuse, T.emb != nullptr, T.emb == nullptr && T.lde < 0};
+  const mot::CostParams cp{T.mode, T.prox_thresh, T.app_thresh, T.fuse, T.emb != nullptr, T.emb == nullptr && T.lde < 0, T.assoc, T.frame_diag};
   float bb[4][4], barea[4], bc[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(kThreads) iou_kernel(const mot_iou_task* __res
     float out[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float iou = iou_pair(aa, aarea, bb[q], barea[q]);
+      const float iou = mot::assoc_pair(cp.assoc, cp.frame_diag, aa, aarea, bb[q], barea[q]);
       const int cq = tx * 4 + q;
       const float v = mot::cost_from_iou(cp, iou, bc[q], [&]() {
         return (cq < ncol) ? T.emb[static_cast<size_t>(row0 + r) * T.lde + col0 + cq] : 0.f;
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(kThreads) ocsort_kernel(const mot_ocsort_task*
     for (int q = 0; q < 4; ++q) {
       const int c = tx * 4 + q;
       const float tb[4] = {K.c[0][c], K.c[1][c], K.c[2][c], K.c[3][c]};
-      const float iou = iou_pair(da, darea, tb, K.area[c]);
+      const float iou = mot::assoc_pair(T.assoc, T.frame_diag, da, darea, tb, K.area[c]);
       const float dx = dcx[r] - K.pcx[c], dy = dcy[r] - K.pcy[c];
       const float norm = sqrtf(dx * dx + dy * dy) + 1e-6f;
       const float Y = dy / norm, X = dx / norm;

@@ -3,6 +3,7 @@
 // to the materialised matrix. Reference order of operations: include/motcpp/utils/iou.hpp:85-95,
 // src/utils/matching.cpp:62-65,130-143, src/trackers/botsort.cpp:439-465.
 #pragma once
+#include <cmath>
 #include "grp.hpp"
 #include "../../include/motcpp_amd.h"
 
@@ -28,6 +29,54 @@ MOT_HD float iou_pair(const float a[4], float area_a, const float b[4], float ar
   return (uni > 0.0f) ? (inter / uni) : 0.0f;
 }
 
+// The other association measures of AssociationFunction (include/motcpp/utils/iou.hpp:122-334), elementwise in the
+// reference's operation order. a = first argument (detections in OC-SORT), b = second. atan: correctly rounded float
+// through double (the reference's libm atanf is < 1 ulp and version dependent; same convention as OC-SORT's acos).
+MOT_HD float assoc_pair(int assoc, float frame_diag, const float a[4], float area_a, const float b[4], float area_b) {
+  if (assoc == MOT_ASSOC_CENTROID) {  // :303-334
+    const float dx = (a[0] + a[2]) / 2.0f - (b[0] + b[2]) / 2.0f;
+    const float dy = (a[1] + a[3]) / 2.0f - (b[1] + b[3]) / 2.0f;
+    const float dist = sqrtf(dx * dx + dy * dy);
+    return 1.0f - dist / frame_diag;
+  }
+  const float iou = iou_pair(a, area_a, b, area_b);
+  if (assoc == MOT_ASSOC_IOU) return iou;
+  if (assoc == MOT_ASSOC_HMIOU) {  // :122-150
+    const float ih = smax(smin(a[3], b[3]) - smax(a[1], b[1]), 0.0f);
+    const float uh = smax(smax(a[3], b[3]) - smin(a[1], b[1]), 1e-10f);
+    return iou * (ih / uh);
+  }
+  const float ox = smax(a[2], b[2]) - smin(a[0], b[0]);  // smallest enclosing box
+  const float oy = smax(a[3], b[3]) - smin(a[1], b[1]);
+  if (assoc == MOT_ASSOC_GIOU) {  // :155-193
+    const float area_enclose = ox * oy;
+    const float intersection = iou * (area_a + area_b) / (iou + 1e-10f);
+    const float union_area = area_a + area_b - intersection;
+    const float g = iou - (area_enclose - union_area) / (area_enclose + 1e-10f);
+    return (g + 1.0f) / 2.0f;
+  }
+  const float ddx = (a[0] + a[2]) / 2.0f - (b[0] + b[2]) / 2.0f;
+  const float ddy = (a[1] + a[3]) / 2.0f - (b[1] + b[3]) / 2.0f;
+  const float inner = ddx * ddx + ddy * ddy;
+  if (assoc == MOT_ASSOC_DIOU) {  // :261-298
+    const float outer = ox * ox + oy * oy;
+    const float d = iou - inner / (outer + 1e-10f);
+    return (d + 1.0f) / 2.0f;
+  }
+  // CIoU :198-256
+  const float epsilon = 1e-7f;
+  const float outer = ox * ox + oy * oy + epsilon;
+  const float w1 = a[2] - a[0], h1 = a[3] - a[1], w2 = b[2] - b[0], h2 = b[3] - b[1];
+  const float ad = static_cast<float>(atan(static_cast<double>(w2 / (h2 + epsilon)))) -
+                   static_cast<float>(atan(static_cast<double>(w1 / (h1 + epsilon))));
+  const float k = 4.0f / static_cast<float>(3.14159265358979323846 * 3.14159265358979323846);
+  const float v = k * (ad * ad);
+  const float S = 1.0f - iou;
+  const float alpha = v / (S + v + epsilon);
+  const float c = iou - inner / outer + alpha * v;
+  return (c + 1.0f) / 2.0f;
+}
+
 // cost of one pair given its IoU. `emb_at()` is only evaluated when the appearance term can matter.
 struct CostParams {
   int mode;
@@ -35,6 +84,8 @@ struct CostParams {
   int fuse;
   bool has_emb;    // an embedding-distance matrix exists
   bool const_emb;  // no features at all: the cosine distance is the constant 1
+  int assoc = MOT_ASSOC_IOU;  // similarity the cost is built from
+  float frame_diag = 1.0f;
 };
 template <class EmbFn>
 MOT_HD float cost_from_iou(const CostParams& p, float iou, float conf, EmbFn emb_at) {

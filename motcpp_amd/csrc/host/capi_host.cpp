@@ -22,7 +22,7 @@ Staged* make(std::shared_ptr<Device> dev, int kind, const float* p, int np) {
                                   (int)P(p, np, 4, 30), (int)P(p, np, 5, 30), (int)P(p, np, 6, 50));
     case 2: return make_ocsort(dev, P(p, np, 0, 0.2f), (int)P(p, np, 1, 30), (int)P(p, np, 2, 50), (int)P(p, np, 3, 3), P(p, np, 4, 0.3f),
                                P(p, np, 5, 0.1f), (int)P(p, np, 6, 3), P(p, np, 7, 0.2f), P(p, np, 8, 0.f) != 0.f, P(p, np, 9, 0.01f),
-                               P(p, np, 10, 0.0001f));
+                               P(p, np, 10, 0.0001f), (int)P(p, np, 11, 0.f));
     case 3: return make_botsort(dev, P(p, np, 0, 0.5f), P(p, np, 1, 0.1f), P(p, np, 2, 0.6f), (int)P(p, np, 3, 30), P(p, np, 4, 0.8f),
                                 P(p, np, 5, 0.5f), P(p, np, 6, 0.25f), (int)P(p, np, 7, 30), P(p, np, 8, 0.f) != 0.f,
                                 P(p, np, 9, 1.f) != 0.f, (int)P(p, np, 10, 30), (int)P(p, np, 11, 50));

@@ -28,9 +28,9 @@ struct Trk {
 class OCSortGpu final : public Staged {
  public:
   OCSortGpu(std::shared_ptr<Device> dev, float det_thresh, int max_age, int /*max_obs*/, int min_hits, float iou_threshold,
-            float min_conf, int delta_t, float inertia, bool use_byte, float q_xy, float q_s)
+            float min_conf, int delta_t, float inertia, bool use_byte, float q_xy, float q_s, int asso)
       : core_(std::move(dev), MOT_KF_XYSR), det_thresh_(det_thresh), max_age_(max_age), min_hits_(min_hits), thr_(iou_threshold),
-        min_conf_(min_conf), delta_t_(delta_t), inertia_(inertia), use_byte_(use_byte) {
+        min_conf_(min_conf), delta_t_(delta_t), inertia_(inertia), use_byte_(use_byte), asso_(asso) {
     core_.q[0] = 0.01f * q_xy;  // Q5: the tracker scales the constructor's already-scaled entries again (ocsort.cpp:77-79)
     core_.q[1] = 0.01f * q_xy;
     core_.q[2] = 0.0001f * q_s;
@@ -45,6 +45,9 @@ class OCSortGpu final : public Staged {
     rows_.clear(); laps_.clear();
     ++frame_count_;
     stage_ = 0;
+    // AssociationFunction(img_w, img_h, asso_func) is rebuilt every frame (ocsort.cpp:295-296,413): the centroid
+    // measure is normalised by the frame diagonal, std::sqrt(int) -> double -> float (iou.hpp:329)
+    frame_diag_ = static_cast<float>(std::sqrt(static_cast<double>(in.img_w * in.img_w + in.img_h * in.img_h)));
     high_.clear(); second_.clear();
     raw_.assign(static_cast<size_t>(6) * in.n, 0.f);
     n_ = in.n;
@@ -204,6 +207,7 @@ class OCSortGpu final : public Staged {
       t.nd = nd; t.nt = nt; t.dbox = dets_.d_box; t.ldd = dets_.n; t.didx = high_d_.d; t.dconf = dets_.d_conf();
       t.tbox = pbox_d_; t.ldt = nt0_; t.vel = dv.d; t.ldv = nt; t.prev = dp.d; t.ldp = nt; t.vdc_weight = inertia_;
       t.cost = cost; t.iou = iou_d_; t.ldc = ld;
+      t.assoc = asso_; t.frame_diag = frame_diag_;
       core_.dev().q().oc.push_back(t);
     }
     assoc_nt_ = nt;
@@ -236,7 +240,7 @@ class OCSortGpu final : public Staged {
     Core::IouArgs a;
     a.a = dets_.d_box; a.lda = dets_.n; a.aidx = second_d_.d; a.n = static_cast<int>(second_.size());
     a.b = pbox_d_; a.ldb = nt0_; a.bidx = um_trks_d_.d; a.m = static_cast<int>(um_trks_.size());
-    a.mode = MOT_COST_NEG_IOU;
+    a.mode = MOT_COST_NEG_IOU; a.assoc = asso_; a.frame_diag = frame_diag_;
     byte_ = core_.lap_geom(a, -thr_, MOT_LAP_GATE_MIN, -thr_, true);
   }
   void after_byte() {
@@ -267,7 +271,7 @@ class OCSortGpu final : public Staged {
     Core::IouArgs a;
     a.a = dets_.d_box; a.lda = dets_.n; a.aidx = left_d_.d; a.n = static_cast<int>(didx.size());
     a.b = dlt.d; a.ldb = nl; a.m = nl;
-    a.mode = MOT_COST_NEG_IOU;
+    a.mode = MOT_COST_NEG_IOU; a.assoc = asso_; a.frame_diag = frame_diag_;
     rematch_ = core_.lap_geom(a, -thr_, MOT_LAP_GATE_MIN, -thr_, true);
   }
   void after_rematch() {
@@ -372,6 +376,8 @@ class OCSortGpu final : public Staged {
   Span<float> pbox_, sbox_;
   float* pbox_d_ = nullptr;
   float* iou_d_ = nullptr;
+  int asso_ = MOT_ASSOC_IOU;
+  float frame_diag_ = 1.f;
   Span<int32_t> high_d_, second_d_, um_trks_d_, left_d_;
   Core::Lap assoc_, byte_, rematch_;
 
@@ -380,8 +386,8 @@ class OCSortGpu final : public Staged {
 }  // namespace
 
 Staged* make_ocsort(std::shared_ptr<Device> dev, float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold,
-                    float min_conf, int delta_t, float inertia, bool use_byte, float q_xy, float q_s) {
-  return new OCSortGpu(std::move(dev), det_thresh, max_age, max_obs, min_hits, iou_threshold, min_conf, delta_t, inertia, use_byte, q_xy, q_s);
+                    float min_conf, int delta_t, float inertia, bool use_byte, float q_xy, float q_s, int asso) {
+  return new OCSortGpu(std::move(dev), det_thresh, max_age, max_obs, min_hits, iou_threshold, min_conf, delta_t, inertia, use_byte, q_xy, q_s, asso);
 }
 
 }  // namespace motcpp::rt

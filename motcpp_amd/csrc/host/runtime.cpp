@@ -472,6 +472,7 @@ float* Core::iou_cost(const IouArgs& a, int* ldc) {
   mot_iou_task t{};
   t.n = a.n; t.m = a.m; t.a = a.a; t.lda = a.lda; t.aidx = a.aidx; t.b = a.b; t.ldb = a.ldb; t.bidx = a.bidx; t.bconf = a.bconf;
   t.cost = cost; t.ldc = ld; t.mode = a.mode; t.emb = a.emb; t.lde = a.lde; t.prox_thresh = a.prox; t.app_thresh = a.app; t.fuse = a.fuse;
+  t.assoc = a.assoc; t.frame_diag = a.frame_diag;
   dev_->q().iou.push_back(t);
   *ldc = ld;
   return cost;
@@ -506,6 +507,7 @@ Core::Lap Core::lap_geom(const IouArgs& a, float thresh, int mode, float gate, b
   t.geom.n = a.n; t.geom.m = a.m; t.geom.a = a.a; t.geom.lda = a.lda; t.geom.aidx = a.aidx; t.geom.b = a.b; t.geom.ldb = a.ldb;
   t.geom.bidx = a.bidx; t.geom.bconf = a.bconf; t.geom.mode = a.mode; t.geom.emb = a.emb; t.geom.lde = a.lde;
   t.geom.prox_thresh = a.prox; t.geom.app_thresh = a.app; t.geom.fuse = a.fuse;
+  t.geom.assoc = a.assoc; t.geom.frame_diag = a.frame_diag;
   dev_->q().lap.push_back(t);
   dev_->q().lap_geom = true;
   r.queued = true;

@@ -189,6 +189,7 @@ class Core {
     const float* bconf = nullptr;
     int mode = MOT_COST_IOU_DIST;
     const float* emb = nullptr; int lde = 0; float prox = 0.f, app = 0.f; int fuse = 0;
+    int assoc = MOT_ASSOC_IOU; float frame_diag = 1.f;  // similarity measure (AssociationFunction mode)
   };
   float* iou_cost(const IouArgs& a, int* ldc);  // returns device cost matrix (tmp arena)
   Lap lap(const float* cost, int ldc, int n, int m, float thresh, int mode = MOT_LAP_PLAIN, const float* iou = nullptr,

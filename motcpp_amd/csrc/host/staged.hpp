@@ -83,7 +83,10 @@ Staged* make_sort(std::shared_ptr<Device>, float det_thresh, int max_age, int ma
 Staged* make_bytetrack(std::shared_ptr<Device>, float min_conf, float track_thresh, float match_thresh, int track_buffer,
                        int frame_rate, int max_age, int max_obs);
 Staged* make_ocsort(std::shared_ptr<Device>, float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold,
-                    float min_conf, int delta_t, float inertia, bool use_byte, float q_xy, float q_s);
+                    float min_conf, int delta_t, float inertia, bool use_byte, float q_xy, float q_s, int asso = 0);
+// "iou" | "hmiou" | "giou" | "ciou" | "diou" | "centroid" -> mot_assoc, or -1 (AssociationFunction::get_asso_func, iou.hpp:385-408;
+// the oriented-box modes are out of scope)
+int asso_kind(const std::string& name);
 Staged* make_botsort(std::shared_ptr<Device>, float track_high, float track_low, float new_track, int track_buffer,
                      float match_thresh, float proximity, float appearance, int frame_rate, bool fuse_first, bool with_reid,
                      int max_age, int max_obs);

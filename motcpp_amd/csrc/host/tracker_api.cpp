@@ -47,6 +47,12 @@ void BaseTracker::setup_detection_format(const Eigen::MatrixXf& dets) {
 }
 
 namespace rt {
+int asso_kind(const std::string& name) {
+  static const char* const names[] = {"iou", "hmiou", "giou", "ciou", "diou", "centroid"};
+  for (int k = 0; k < 6; ++k)
+    if (name == names[k]) return k;
+  return -1;
+}
 void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, Team* team) {
   using clk = std::chrono::steady_clock;
   auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -98,10 +104,7 @@ void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int 
 DeviceTracker::DeviceTracker(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class,
                              int nr_classes, const std::string& asso_func, bool is_obb, int device_index)
     : BaseTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb),
-      dev_(rt::Device::shared(device_index)) {
-  if (asso_func != "iou")
-    throw std::invalid_argument("motcpp_amd: association function '" + asso_func + "' is not built yet (only \"iou\")");
-}
+      dev_(rt::Device::shared(device_index)) {}  // asso_func is only read by OC-SORT, at update time (ocsort.cpp:413)
 DeviceTracker::~DeviceTracker() = default;
 void DeviceTracker::adopt(rt::Staged* impl) { impl_.reset(impl); }
 void DeviceTracker::reset() {
@@ -130,6 +133,7 @@ Eigen::MatrixXf to_matrix(const std::vector<float>& rows) {
 }  // namespace
 
 Eigen::MatrixXf DeviceTracker::update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) {
+  if (!asso_error_.empty()) throw std::invalid_argument(asso_error_);
   if (validate_inputs_) check_inputs(dets, img, skip_empty_ ? Eigen::MatrixXf() : embs);
   if (skip_empty_ && dets.rows() == 0) return Eigen::MatrixXf(0, 8);
   setup_detection_format(dets);
@@ -180,8 +184,15 @@ OCSort::OCSort(float det_thresh, int max_age, int max_obs, int min_hits, float i
                const std::string& asso_func, bool is_obb, float min_conf, int delta_t, float inertia, bool use_byte,
                float Q_xy_scaling, float Q_s_scaling, int device_index)
     : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
+  int asso = rt::asso_kind(asso_func);
+  if (asso < 0) {  // like the reference, the constructor accepts any name and update() throws (AssociationFunction, iou.hpp:405-407)
+    asso_error_ = (asso_func == "iou_obb" || asso_func == "centroid_obb")
+                      ? "motcpp_amd: oriented-box association mode '" + asso_func + "' is out of scope"
+                      : "Invalid association mode: " + asso_func;
+    asso = 0;
+  }
   adopt(rt::make_ocsort(dev_, det_thresh_, max_age_, max_obs_, min_hits_, iou_threshold_, min_conf, delta_t, inertia, use_byte,
-                        Q_xy_scaling, Q_s_scaling));
+                        Q_xy_scaling, Q_s_scaling, asso));
 }
 BotSort::BotSort(const std::string& reid_weights, bool /*use_half*/, bool /*use_gpu*/, float det_thresh, int max_age, int max_obs,
                  int min_hits, float iou_threshold, bool per_class, int nr_classes, const std::string& asso_func, bool is_obb,
@@ -228,18 +239,37 @@ LinearAssignmentResult linear_assignment(const Eigen::MatrixXf& cost, float thre
   for (int j = 0; j < m; ++j) if (y[j] < 0) r.unmatched_b.push_back(j);
   return r;
 }
-static Eigen::MatrixXf iou_mode(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, int mode, int device_index) {
+static Eigen::MatrixXf iou_mode(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, int mode, int device_index,
+                                int assoc = MOT_ASSOC_IOU, int fw = 1, int fh = 1) {
   const int n = static_cast<int>(a.rows()), m = static_cast<int>(b.rows());
   Eigen::MatrixXf out(n, m);
-  if (n == 0 || m == 0) return out;
+  if (n == 0 || m == 0) { out.setZero(); return out; }  // Zero(N, M), iou.hpp:68-70,127-129
   auto dev = rt::Device::shared(device_index);
   std::vector<float> ra = row_major(a, 4), rb = row_major(b, 4), c(static_cast<size_t>(n) * m);
-  chk(*dev, mot_iou_cost_host(dev->ctx, ra.data(), n, rb.data(), m, nullptr, mode, c.data()), "mot_iou_cost_host");
+  chk(*dev, mot_assoc_cost_host(dev->ctx, ra.data(), n, rb.data(), m, nullptr, mode, assoc, fw, fh, c.data()), "mot_assoc_cost_host");
   for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) out(i, j) = c[static_cast<size_t>(i) * m + j];
   return out;
 }
 Eigen::MatrixXf iou_batch(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, int device_index) { return iou_mode(a, b, MOT_COST_IOU, device_index); }
 Eigen::MatrixXf iou_distance(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, int device_index) { return iou_mode(a, b, MOT_COST_IOU_DIST, device_index); }
+Eigen::MatrixXf hmiou_batch(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, int d) { return iou_mode(a, b, MOT_COST_IOU, d, MOT_ASSOC_HMIOU); }
+Eigen::MatrixXf giou_batch(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, int d) { return iou_mode(a, b, MOT_COST_IOU, d, MOT_ASSOC_GIOU); }
+Eigen::MatrixXf ciou_batch(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, int d) { return iou_mode(a, b, MOT_COST_IOU, d, MOT_ASSOC_CIOU); }
+Eigen::MatrixXf diou_batch(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, int d) { return iou_mode(a, b, MOT_COST_IOU, d, MOT_ASSOC_DIOU); }
+Eigen::MatrixXf centroid_batch(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, int w, int h, int d) {
+  return iou_mode(a, b, MOT_COST_IOU, d, MOT_ASSOC_CENTROID, w, h);
+}
+AssociationFunction::AssociationFunction(int w, int h, const std::string& asso_mode, int device_index)
+    : frame_width_(w), frame_height_(h), kind_(rt::asso_kind(asso_mode)), device_(device_index) {
+  if (kind_ < 0) {
+    if (asso_mode == "iou_obb" || asso_mode == "centroid_obb")
+      throw std::invalid_argument("motcpp_amd: oriented-box association mode '" + asso_mode + "' is out of scope");
+    throw std::invalid_argument("Invalid association mode: " + asso_mode);
+  }
+}
+Eigen::MatrixXf AssociationFunction::operator()(const Eigen::MatrixXf& a, const Eigen::MatrixXf& b) const {
+  return iou_mode(a, b, MOT_COST_IOU, device_, kind_, frame_width_, frame_height_);
+}
 Eigen::MatrixXf embedding_distance(const Eigen::MatrixXf& t, const Eigen::MatrixXf& d, const std::string& metric, int device_index) {
   if (metric != "cosine") throw std::invalid_argument("Unknown metric: " + metric);
   const int n = static_cast<int>(t.rows()), m = static_cast<int>(d.rows()), dim = static_cast<int>(t.cols());

@@ -52,7 +52,7 @@ struct IouCostT {
     float a[4], area;
   };
   MOT_DEV float eval_f(const Row& r, const float b[4], float barea, float cf, int j) const {
-    const float iou = iou_pair(r.a, r.area, b, barea);
+    const float iou = assoc_pair(prm.assoc, prm.frame_diag, r.a, r.area, b, barea);
     const float* e = emb;
     const size_t off = static_cast<size_t>(r.i) * lde + j;
     return cost_from_iou(prm, iou, cf, [&]() { return gld(e, off); });

@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __res
     C.rows = mot::BoxPlanes<kRS>{rp, nr};
     C.cols = mot::BoxPlanes<mot::kMemGlobal>{cp, nc};
     C.conf = G.bconf ? cf : nullptr;
-    C.prm = mot::CostParams{G.mode, G.prox_thresh, G.app_thresh, G.fuse, G.emb != nullptr, G.emb == nullptr && G.lde < 0};
+    C.prm = mot::CostParams{G.mode, G.prox_thresh, G.app_thresh, G.fuse, G.emb != nullptr, G.emb == nullptr && G.lde < 0, G.assoc, G.frame_diag};
     C.emb = G.emb;
     C.lde = G.lde;
     C.load_owned(t, kThreads, nc);

@@ -60,6 +60,7 @@ void* orc_tracker_create(int kind, const float* p, int np) {
                                        (int)P(p, np, 3, 3), P(p, np, 4, 0.3f), P(p, np, 5, 0.1f),
                                        (int)P(p, np, 6, 3), P(p, np, 7, 0.2f), P(p, np, 8, 0.f) != 0.f,
                                        P(p, np, 9, 0.01f), P(p, np, 10, 0.0001f));
+      h->oc->set_asso((int)P(p, np, 11, 0.f), (int)P(p, np, 12, 1920.f), (int)P(p, np, 13, 1080.f));
       break;
     case 3:
       h->bot = std::make_unique<BotSort>(P(p, np, 0, 0.5f), P(p, np, 1, 0.1f), P(p, np, 2, 0.6f),
@@ -158,6 +159,11 @@ void orc_linear_assignment(const float* cost, int n, int m, float thresh, int* x
   LapResult r = linear_assignment(as_mat(cost, n, m), thresh);
   if (n) std::memcpy(x, r.x.data(), sizeof(int) * n);
   if (m) std::memcpy(y, r.y.data(), sizeof(int) * m);
+}
+// association measures (iou.hpp:122-414): kind 0 iou, 1 hmiou, 2 giou, 3 ciou, 4 diou, 5 centroid; a n x 4, b m x 4 -> out n x m
+void orc_asso_batch(int kind, const float* a, int n, const float* b, int m, int frame_w, int frame_h, float* out) {
+  Mat r = asso_batch(kind, as_mat(a, n, 4), as_mat(b, m, 4), frame_w, frame_h);
+  std::memcpy(out, r.a.data(), sizeof(float) * r.a.size());
 }
 // work counters of the last assignment solved on this thread (instrumentation)
 void orc_lap_stats(long* out) {

@@ -104,6 +104,126 @@ inline Mat iou_batch(const Mat& A, const Mat& B) {
   return out;
 }
 
+// ---- iou.hpp:122-366 — the other association measures (AssociationFunction, iou.hpp:371-414) -------------
+// Elementwise float expressions in the reference's operation order. `atan` is taken as the correctly rounded float
+// (through double) — the reference calls libm's atanf (<1 ulp, libm dependent); same convention as acos in OC-SORT.
+enum AssoKind { ASSO_IOU = 0, ASSO_HMIOU = 1, ASSO_GIOU = 2, ASSO_CIOU = 3, ASSO_DIOU = 4, ASSO_CENTROID = 5 };
+inline float emax(float a, float b) { return (a < b) ? b : a; }  // Eigen cwiseMax / std::max
+inline float emin(float a, float b) { return (b < a) ? b : a; }  // Eigen cwiseMin / std::min
+inline float atan_f32(float x) { return static_cast<float>(std::atan(static_cast<double>(x))); }
+
+inline Mat hmiou_batch(const Mat& A, const Mat& B) {  // :122-150
+  const int N = A.r, M = B.r;
+  Mat out(N, M, 0.0f);
+  if (N == 0 || M == 0) return out;
+  const Mat iou = iou_batch(A, B);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < M; ++j) {
+      const float iy1 = emax(A(i, 1), B(j, 1)), iy2 = emin(A(i, 3), B(j, 3));
+      const float ih = emax(iy2 - iy1, 0.0f);
+      const float uy1 = emin(A(i, 1), B(j, 1)), uy2 = emax(A(i, 3), B(j, 3));
+      const float uh = emax(uy2 - uy1, 1e-10f);
+      const float o = ih / uh;
+      out(i, j) = iou(i, j) * o;
+    }
+  return out;
+}
+inline Mat giou_batch(const Mat& A, const Mat& B) {  // :155-193
+  const int N = A.r, M = B.r;
+  Mat out(N, M, 0.0f);
+  if (N == 0 || M == 0) return out;
+  const Mat iou = iou_batch(A, B);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < M; ++j) {
+      const float xxc1 = emin(A(i, 0), B(j, 0)), yyc1 = emin(A(i, 1), B(j, 1));
+      const float xxc2 = emax(A(i, 2), B(j, 2)), yyc2 = emax(A(i, 3), B(j, 3));
+      const float wc = xxc2 - xxc1, hc = yyc2 - yyc1;
+      const float area_enclose = wc * hc;
+      const float area1 = (A(i, 2) - A(i, 0)) * (A(i, 3) - A(i, 1));
+      const float area2 = (B(j, 2) - B(j, 0)) * (B(j, 3) - B(j, 1));
+      const float intersection = iou(i, j) * (area1 + area2) / (iou(i, j) + 1e-10f);
+      const float union_area = area1 + area2 - intersection;
+      float g = iou(i, j) - (area_enclose - union_area) / (area_enclose + 1e-10f);
+      out(i, j) = (g + 1.0f) / 2.0f;
+    }
+  return out;
+}
+inline Mat ciou_batch(const Mat& A, const Mat& B) {  // :198-256
+  const int N = A.r, M = B.r;
+  Mat out(N, M, 0.0f);
+  if (N == 0 || M == 0) return out;
+  const float epsilon = 1e-7f;
+  const Mat iou = iou_batch(A, B);
+  const float pi_squared = static_cast<float>(M_PI * M_PI);
+  const float k = 4.0f / pi_squared;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < M; ++j) {
+      const float cx1 = (A(i, 0) + A(i, 2)) / 2.0f, cy1 = (A(i, 1) + A(i, 3)) / 2.0f;
+      const float cx2 = (B(j, 0) + B(j, 2)) / 2.0f, cy2 = (B(j, 1) + B(j, 3)) / 2.0f;
+      const float ddx = cx1 - cx2, ddy = cy1 - cy2;
+      const float inner = ddx * ddx + ddy * ddy;
+      const float xxc1 = emin(A(i, 0), B(j, 0)), yyc1 = emin(A(i, 1), B(j, 1));
+      const float xxc2 = emax(A(i, 2), B(j, 2)), yyc2 = emax(A(i, 3), B(j, 3));
+      const float ox = xxc2 - xxc1, oy = yyc2 - yyc1;
+      const float outer = ox * ox + oy * oy + epsilon;
+      const float w1 = A(i, 2) - A(i, 0), h1 = A(i, 3) - A(i, 1);
+      const float w2 = B(j, 2) - B(j, 0), h2 = B(j, 3) - B(j, 1);
+      const float ad = atan_f32(w2 / (h2 + epsilon)) - atan_f32(w1 / (h1 + epsilon));
+      const float v = k * (ad * ad);
+      const float S = 1.0f - iou(i, j);
+      const float alpha = v / (S + v + epsilon);
+      const float c = iou(i, j) - inner / outer + alpha * v;
+      out(i, j) = (c + 1.0f) / 2.0f;
+    }
+  return out;
+}
+inline Mat diou_batch(const Mat& A, const Mat& B) {  // :261-298
+  const int N = A.r, M = B.r;
+  Mat out(N, M, 0.0f);
+  if (N == 0 || M == 0) return out;
+  const Mat iou = iou_batch(A, B);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < M; ++j) {
+      const float cx1 = (A(i, 0) + A(i, 2)) / 2.0f, cy1 = (A(i, 1) + A(i, 3)) / 2.0f;
+      const float cx2 = (B(j, 0) + B(j, 2)) / 2.0f, cy2 = (B(j, 1) + B(j, 3)) / 2.0f;
+      const float ddx = cx1 - cx2, ddy = cy1 - cy2;
+      const float inner = ddx * ddx + ddy * ddy;
+      const float xxc1 = emin(A(i, 0), B(j, 0)), yyc1 = emin(A(i, 1), B(j, 1));
+      const float xxc2 = emax(A(i, 2), B(j, 2)), yyc2 = emax(A(i, 3), B(j, 3));
+      const float ox = xxc2 - xxc1, oy = yyc2 - yyc1;
+      const float outer = ox * ox + oy * oy;
+      const float d = iou(i, j) - inner / (outer + 1e-10f);
+      out(i, j) = (d + 1.0f) / 2.0f;
+    }
+  return out;
+}
+inline Mat centroid_batch(const Mat& A, const Mat& B, int frame_width, int frame_height) {  // :303-334
+  const int N = A.r, M = B.r;
+  Mat out(N, M, 0.0f);
+  if (N == 0 || M == 0) return out;
+  const float norm = static_cast<float>(std::sqrt(static_cast<double>(frame_width * frame_width + frame_height * frame_height)));
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < M; ++j) {
+      const float cx1 = (A(i, 0) + A(i, 2)) / 2.0f, cy1 = (A(i, 1) + A(i, 3)) / 2.0f;
+      const float cx2 = (B(j, 0) + B(j, 2)) / 2.0f, cy2 = (B(j, 1) + B(j, 3)) / 2.0f;
+      const float dx = cx1 - cx2, dy = cy1 - cy2;
+      const float dist = std::sqrt(dx * dx + dy * dy);
+      out(i, j) = 1.0f - dist / norm;
+    }
+  return out;
+}
+// AssociationFunction::operator(), iou.hpp:371-414 (the oriented-box modes are out of scope)
+inline Mat asso_batch(int kind, const Mat& A, const Mat& B, int frame_width, int frame_height) {
+  switch (kind) {
+    case ASSO_HMIOU: return hmiou_batch(A, B);
+    case ASSO_GIOU: return giou_batch(A, B);
+    case ASSO_CIOU: return ciou_batch(A, B);
+    case ASSO_DIOU: return diou_batch(A, B);
+    case ASSO_CENTROID: return centroid_batch(A, B, frame_width, frame_height);
+    default: return iou_batch(A, B);
+  }
+}
+
 // matching.cpp:62-65 — 1 - IoU. (The pointer-list templates, matching.hpp:134-136,163-165,
 // return Ones(m,n) for an empty side; callers below handle that case where it matters.)
 inline Mat iou_distance(const Mat& A, const Mat& B) {

@@ -436,6 +436,9 @@ class OCSort {
     p_.det_thresh = det_thresh; p_.max_age = max_age; p_.max_obs = max_obs;
     p_.min_hits = min_hits; p_.iou_threshold = iou_threshold; p_.normalise();
   }
+  // asso_func (BaseTracker ctor argument, ocsort.cpp:413,438,494) and the frame size it is built with (:295-296)
+  void set_asso(int kind, int img_w, int img_h) { asso_kind_ = kind; img_w_ = img_w; img_h_ = img_h; }
+  Mat asso(const Mat& a, const Mat& b) const { return asso_batch(asso_kind_, a, b, img_w_, img_h_); }
   void reset() { frame_count_ = 0; trk_.clear(); }
 
   struct Obs5 { float v[5]; };
@@ -492,7 +495,7 @@ class OCSort {
       Mat ut(static_cast<int>(as.um_trks.size()), 5), sd(static_cast<int>(second.size()), 5);
       for (int i = 0; i < ut.r; ++i) for (int c = 0; c < 5; ++c) ut(i, c) = trks[as.um_trks[i]][c];
       for (int i = 0; i < sd.r; ++i) { sd(i,0)=second[i].x1; sd(i,1)=second[i].y1; sd(i,2)=second[i].x2; sd(i,3)=second[i].y2; sd(i,4)=second[i].conf; }
-      Mat iou = iou_batch(sd, ut);
+      Mat iou = asso(sd, ut);
       float mx = -std::numeric_limits<float>::infinity();
       for (float v : iou.a) mx = std::max(mx, v);
       if (mx > asso_thr_) {
@@ -516,7 +519,7 @@ class OCSort {
       Mat ld(static_cast<int>(as.um_dets.size()), 4), lt(static_cast<int>(as.um_trks.size()), 4);
       for (int i = 0; i < ld.r; ++i) { const Det7& d = high[as.um_dets[i]]; ld(i,0)=d.x1; ld(i,1)=d.y1; ld(i,2)=d.x2; ld(i,3)=d.y2; }
       for (int i = 0; i < lt.r; ++i) for (int c = 0; c < 4; ++c) lt(i, c) = trk_[as.um_trks[i]].last_obs.v[c];
-      Mat iou = iou_batch(ld, lt);
+      Mat iou = asso(ld, lt);
       float mx = -std::numeric_limits<float>::infinity();
       for (float v : iou.a) mx = std::max(mx, v);
       if (mx > asso_thr_) {
@@ -598,7 +601,7 @@ class OCSort {
         angle(j, i) = a * dets(j, 4);
       }
     }
-    Mat iou = iou_batch(dets, trks);
+    Mat iou = asso(dets, trks);
     last_iou = iou;
     if (nd > 0) {
       int max_row = 0, max_col = 0;
@@ -694,6 +697,7 @@ class OCSort {
   }
 
   BaseParams p_;
+  int asso_kind_ = ASSO_IOU, img_w_ = 1920, img_h_ = 1080;
   float min_conf_, asso_thr_;
   int delta_t_;
   float inertia_;

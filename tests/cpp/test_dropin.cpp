@@ -91,6 +91,32 @@ int main() {
     Sort s;  // SORT never calls check_inputs (sort.cpp:102-110)
     CHECK(s.update(single, cv::Mat()).cols() == 8);
   }
+  {  // asso_func: stored by every tracker, read only by OC-SORT, at update time (ocsort.cpp:413; iou.hpp:385-408)
+    ByteTrack bt(0.3f, 30, 50, 3, 0.3f, false, 80, "no-such-measure");
+    CHECK(bt.update(multi, img).cols() == 8);
+    OCSort good(0.2f, 30, 50, 3, 0.3f, false, 80, "giou");
+    CHECK(good.update(multi, img).cols() == 8);
+    OCSort bad(0.2f, 30, 50, 3, 0.3f, false, 80, "no-such-measure");  // the constructor accepts it, like the reference
+    bool threw = false;
+    try { bad.update(multi, img); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    // tests/test_iou.cpp:75-116
+    Eigen::MatrixXf b1(1, 4), b2(1, 4), b3(1, 4);
+    b1 << 0, 0, 100, 100;
+    b2 << 50, 50, 150, 150;
+    b3 << 200, 200, 300, 300;
+    using namespace motcpp::utils;
+    const float g = giou_batch(b1, b2)(0, 0), d = diou_batch(b1, b2)(0, 0), c = ciou_batch(b1, b2)(0, 0);
+    CHECK(g >= 0.f && g <= 1.f && d >= 0.f && d <= 1.f && c >= 0.f && c <= 1.f);
+    const float ce = centroid_batch(b1, b3, 640, 480)(0, 0);
+    CHECK(ce > 0.f && ce < 1.f);
+    AssociationFunction asso(640, 480, "iou");
+    Eigen::MatrixXf r = asso(b1, b2);
+    CHECK(r.rows() == 1 && r.cols() == 1 && std::fabs(r(0, 0) - 0.143f) < 0.01f);
+    threw = false;
+    try { AssociationFunction nope(640, 480, "nope"); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+  }
   {  // test_matching.cpp:24-110
     using motcpp::utils::linear_assignment;
     Eigen::MatrixXf c1(1, 1);

@@ -55,6 +55,14 @@ class Oracle:
                                b.shape[1] if b.ndim == 2 else 4, out.ctypes)
         return out
 
+    def asso_batch(self, kind, a, b, frame=(1920, 1080)):
+        a, b = f32(a).reshape(-1, 4), f32(b).reshape(-1, 4)
+        out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+        if out.size:
+            self.lib.orc_asso_batch(int(kind), a.ctypes.data_as(C.c_void_p), a.shape[0], b.ctypes.data_as(C.c_void_p), b.shape[0],
+                                    int(frame[0]), int(frame[1]), out.ctypes.data_as(C.c_void_p))
+        return out
+
     def iou_distance(self, a, b):
         a, b = f32(a).reshape(-1, 4), f32(b).reshape(-1, 4)
         out = np.zeros((a.shape[0], b.shape[0]), np.float32)

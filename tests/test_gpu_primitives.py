@@ -224,3 +224,21 @@ def test_kalman_predict_flags(ctx, orc):
     mo, co = orc.kf_predict(L.KF_XYAH, mref, c)
     mg, cg = ctx.kf_apply(L.KF_XYAH, 1, m, c, flags=flags)
     assert np.array_equal(mg, mo) and np.array_equal(cg, co)
+
+
+@pytest.mark.parametrize("kind", [1, 2, 3, 4, 5])  # hmiou, giou, ciou, diou, centroid (include/motcpp/utils/iou.hpp:122-414)
+def test_association_measures(ctx, orc, kind):
+    for n, m in [(1, 1), (3, 130), (65, 63), (256, 128)]:
+        r = np.random.default_rng(kind * 100 + n)
+        a, b = boxes(r, n, (600, 400)), boxes(r, m, (600, 400))
+        k = min(n, m) // 2
+        b[:k] = a[:k] + r.normal(0, 3, (k, 4)).astype(np.float32)
+        ref = orc.asso_batch(kind, a, b, (640, 480))
+        got = ctx.assoc_cost(a, b, kind, (640, 480))
+        if kind == 3:  # ciou: atan through fp64 on both sides; last-bit differences only where two fp64 libms disagree
+            assert np.allclose(got, ref, rtol=1e-4, atol=1e-6)
+            assert (got == ref).mean() >= 0.999
+        else:
+            assert np.array_equal(got, ref), np.abs(got - ref).max()
+        neg = ctx.assoc_cost(a, b, kind, (640, 480), mode=L.COST_NEG_IOU)
+        assert np.array_equal(neg, -got)

@@ -115,6 +115,12 @@ def test_ocsort_use_byte():
     run_stream("ocsort", orclib.OCSORT, 120, 80, 40, params=[0.5, 30, 50, 3, 0.3, 0.1, 3, 0.2, 1], exact=False)
 
 
+@pytest.mark.parametrize("asso", [1, 2, 3, 4, 5])  # hmiou, giou, ciou, diou, centroid
+def test_ocsort_association_measures(asso):
+    # asso_func reaches all three association stages (ocsort.cpp:413,438,494); use_byte on so that all of them run
+    run_stream("ocsort", orclib.OCSORT, 150, 90, 40, params=[0.5, 30, 50, 3, 0.3, 0.1, 3, 0.2, 1, 0.01, 0.0001, asso], exact=False)
+
+
 def test_botsort_with_embeddings():
     run_stream("botsort", orclib.BOTSORT, 256, 128, 40, emb_dim=64)
 

@@ -1,0 +1,153 @@
+"""MOT I/O + motcpp_eval-compatible command line (reference: src/data/mot17_dataset.cpp:12-241,
+include/motcpp/utils/mot_format.hpp:23-79, tools/motcpp_eval.cpp:19-468). The reader/writer are host-only C++ and are
+checked on CPU against this file's own reading of the same fixtures; the command line is run on the GPU box and its
+result files are compared byte for byte with the oracle's tables pushed through a Python mirror of the writer."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import mot17, orclib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "_build", "test_mot_io")
+EVAL = os.path.join(ROOT, "motcpp_amd", "bin", "motcpp_eval")
+
+
+def build():
+    from motcpp_amd import _lib
+    if not (os.path.exists(_lib.HIP_LIB) and os.path.exists(_lib.HOST_LIB) and os.path.exists(EVAL)):
+        _lib.build()
+    os.makedirs(os.path.dirname(BIN), exist_ok=True)
+    src = os.path.join(ROOT, "tests", "cpp", "test_mot_io.cpp")
+    if not os.path.exists(BIN) or os.path.getmtime(src) > os.path.getmtime(BIN) or os.path.getmtime(_lib.HOST_LIB) > os.path.getmtime(BIN):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), src, "-o", BIN,
+                               "-L", _lib.LIBDIR, "-lmotcpp", "-lmotcpp_hip", "-Wl,-rpath," + _lib.LIBDIR])
+    return BIN
+
+
+def make_root(tmp, gt_frames=None, seqinfo=True):
+    """<tmp>/train/<seq>/det/det.txt from the gzipped fixtures (+ seqinfo.ini, optional gt.txt with frames 1..gt_frames)."""
+    root = os.path.join(tmp, "train")
+    for seq in mot17.SEQS:
+        d = os.path.join(root, seq, "det")
+        os.makedirs(d)
+        with gzip.open(os.path.join(ROOT, "tests", "golden", "MOT17-mini", seq + ".det.txt.gz"), "rb") as src, \
+                open(os.path.join(d, "det.txt"), "wb") as dst:
+            shutil.copyfileobj(src, dst)
+        if seqinfo:
+            with open(os.path.join(root, seq, "seqinfo.ini"), "w") as f:
+                f.write("[Sequence]\nname=%s\nframeRate=25\nimWidth=1920\nimHeight=1080\n" % seq)
+        if gt_frames:
+            os.makedirs(os.path.join(root, seq, "gt"))
+            with open(os.path.join(root, seq, "gt", "gt.txt"), "w") as f:
+                for fr in range(1, gt_frames[seq] + 1):
+                    f.write("%d,1,10,10,20,40,1,1,1\n" % fr)
+    open(os.path.join(root, "not-a-sequence.txt"), "w").close()
+    return root
+
+
+def mot_lines(table, frame):
+    """Python mirror of convert_to_mot_format + write_mot_results (mot_format.hpp:23-79)."""
+    out = []
+    for r in np.asarray(table, np.float32):
+        w, h = np.float32(r[2] - r[0]), np.float32(r[3] - r[1])
+        out.append("%d,%d,%d,%d,%d,%d,%.6f,-1,-1,-1\n" % (frame, int(r[4]), int(r[0]), int(r[1]), int(w), int(h), float(r[5])))
+    return out
+
+
+def test_reader_matches_fixture_reading(tmp_path):
+    root = make_root(str(tmp_path))
+    out = subprocess.run([build(), "index", root], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("SEQ ")]
+    assert [l.split()[1] for l in lines] == sorted(mot17.SEQS)  # sorted by name, the stray file is ignored
+    for l in lines:
+        kv = dict(p.split("=") for p in l.split()[2:])
+        seq = l.split()[1]
+        frames = mot17.load(seq)
+        nonempty = [i + 1 for i, f in enumerate(frames) if f.shape[0]]
+        assert int(kv["fps"]) == 25 and kv["size"] == "1920x1080" and kv["det"] == "det.txt"
+        assert int(kv["frames"]) == len(nonempty) and int(kv["first"]) == nonempty[0] and int(kv["last"]) == nonempty[-1]
+        assert int(kv["rows"]) == sum(f.shape[0] for f in frames) and int(kv["max_rows"]) == max(f.shape[0] for f in frames)
+        want = sum(float((f.astype(np.float64) * np.arange(1, 7)).sum()) for f in frames)
+        assert abs(float(kv["sum"]) - want) <= 1e-6 * abs(want)  # same float32 boxes (x2 = x1 + w in float), file order irrelevant here
+    assert "NOTFOUND 1" in out.stdout
+
+
+def test_reader_defaults_and_pregenerated_format(tmp_path):
+    root = make_root(str(tmp_path), seqinfo=False)
+    # pre-generated detections: <det_emb_root>/<model>/dets/MOT17-02.txt, whitespace separated "frame x1 y1 x2 y2 conf cls"
+    dets_dir = os.path.join(str(tmp_path), "yolox", "yolox", "dets")
+    os.makedirs(dets_dir)
+    with open(os.path.join(dets_dir, "MOT17-02.txt"), "w") as f:
+        f.write("# comment\n1 10 20 30 60 0.9 0\n1 100 20 130 60 0.8 2\n3 5 5 15 25 0.7 0\nshort 1 2\n")
+    os.makedirs(os.path.join(root, "MOT17-04-FRCNN", "img1"))  # indexed through its image directory (the reference's rule)
+    open(os.path.join(root, "MOT17-04-FRCNN", "img1", "000007.jpg"), "w").close()
+    out = subprocess.run([build(), "index", root, os.path.join(str(tmp_path), "yolox"), "yolox"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = {l.split()[1]: dict(p.split("=") for p in l.split()[2:]) for l in out.stdout.splitlines() if l.startswith("SEQ ")}
+    a = lines["MOT17-02-FRCNN"]
+    assert a["fps"] == "30" and a["det"] == "MOT17-02.txt" and a["frames"] == "2" and a["rows"] == "3" and a["last"] == "3"
+    assert lines["MOT17-04-FRCNN"]["frames"] == "0"  # no file for it under dets/: empty map, not an error
+
+
+def test_writer_format(tmp_path):
+    path = os.path.join(str(tmp_path), "sub", "dir", "out.txt")  # parent directories are created
+    assert subprocess.run([build(), "write", path], timeout=60).returncode == 0
+    t = np.array([[100.7, 50.2, 180.9, 260.4, 7, 0.912345678, 0, 3], [-5.5, 10.99, 20.25, 99.999, 12, 0.5, 1, 0],
+                  [1919.6, 1000.4, 1925.1, 1085.9, 3, 1.0, 0, 1]], np.float32)
+    assert open(path).read() == "".join(mot_lines(t, 42) + mot_lines(t, 43))  # the second call appends
+    assert open(path).readline() == "42,7,100,50,80,210,0.912346,-1,-1,-1\n"  # truncation, 6 decimals
+
+
+def test_cli_usage_and_unknown_method(tmp_path):
+    build()
+    assert subprocess.run([EVAL], capture_output=True, timeout=60).returncode == 1
+    root = make_root(str(tmp_path))
+    out = subprocess.run([EVAL, root, os.path.join(str(tmp_path), "res"), "deepocsort"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "Unknown tracking method" in out.stderr
+    out = subprocess.run([EVAL, os.path.join(str(tmp_path), "nope"), os.path.join(str(tmp_path), "res")], capture_output=True, text=True,
+                         timeout=60)
+    assert out.returncode == 1 and "does not exist" in out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,kind,params", [("sort", orclib.SORT, [0.3, 1, 50, 3, 0.3]),
+                                                ("bytetrack", orclib.BYTETRACK, [0.1, 0.45, 0.8, 30, 25, 30, 50])])
+def test_cli_results_match_oracle(tmp_path, orc, method, kind, params):
+    build()
+    root, res = make_root(str(tmp_path)), os.path.join(str(tmp_path), "results")
+    out = subprocess.run([EVAL, root, res, method], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for seq in mot17.SEQS:
+        trk = orc.tracker(kind, params)
+        want = []
+        for f, d in enumerate(mot17.load(seq), start=1):
+            if d.shape[0] == 0:
+                continue  # only frames that have detections are fed (motcpp_eval.cpp:314-319)
+            want += mot_lines(trk.update(d), f)
+        got = open(os.path.join(res, seq + ".txt")).read()
+        assert got == "".join(want), seq
+
+
+@pytest.mark.gpu
+def test_cli_ablation_offset(tmp_path, orc):
+    build()
+    gt = {"MOT17-02-FRCNN": 300, "MOT17-04-FRCNN": 1050}  # 02: det frames run to 600 > 1.5 x 300 -> offset 300; 04: no offset
+    root, res = make_root(str(tmp_path), gt_frames=gt), os.path.join(str(tmp_path), "results")
+    out = subprocess.run([EVAL, root, res, "sort"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Detected ablation offset: 300" in out.stdout
+    trk = orc.tracker(orclib.SORT, [0.3, 1, 50, 3, 0.3])
+    want = []
+    for f, d in enumerate(mot17.load("MOT17-02-FRCNN"), start=1):
+        if d.shape[0] == 0 or f <= 300:
+            continue  # frames at or below the offset never reach the tracker
+        want += mot_lines(trk.update(d), f - 300)
+    assert open(os.path.join(res, "MOT17-02-FRCNN.txt")).read() == "".join(want)
+    first = open(os.path.join(res, "MOT17-04-FRCNN.txt")).readline()
+    assert int(first.split(",")[0]) >= 1 and "1050" in open(os.path.join(res, "MOT17-04-FRCNN.txt")).read()

@@ -144,6 +144,9 @@ typedef struct mot_iou_task {
   float frame_diag;  /* CENTROID: sqrt(w*w + h*h) of the frame                                       */
 } mot_iou_task;
 int mot_iou_cost(mot_ctx* ctx, const mot_iou_task* tasks, int ntasks, int max_n, int max_m);
+/* flags: the caller promises properties of the whole task array so that a leaner kernel instance can be launched */
+enum { MOT_COST_F_IOU_ONLY = 1 /* every task has assoc == MOT_ASSOC_IOU */ };
+int mot_iou_cost_ex(mot_ctx* ctx, const mot_iou_task* tasks, int ntasks, int max_n, int max_m, int flags);
 
 typedef struct mot_ocsort_task {
   int32_t nd, nt;
@@ -156,6 +159,7 @@ typedef struct mot_ocsort_task {
   int32_t assoc; float frame_diag;      /* similarity used as "iou" (mot_assoc), frame diagonal for CENTROID */
 } mot_ocsort_task;
 int mot_ocsort_cost(mot_ctx* ctx, const mot_ocsort_task* tasks, int ntasks, int max_nd, int max_nt);
+int mot_ocsort_cost_ex(mot_ctx* ctx, const mot_ocsort_task* tasks, int ntasks, int max_nd, int max_nt, int flags);
 
 /* ---- appearance ---------------------------------------------------------------------- */
 typedef struct mot_cos_task {
@@ -199,7 +203,11 @@ typedef struct mot_lap_task {
   mot_iou_task geom;
   long long* prof; /* optional out [8]: shader cycles per solver phase + pass counts (diagnostics) */
 } mot_lap_task;
-enum { MOT_LAP_F_GEOM = 1 /* some task carries geom: reserve LDS for the staged boxes */ };
+enum {
+  MOT_LAP_F_GEOM = 1, /* some task carries geom: reserve LDS for the staged boxes */
+  MOT_LAP_F_ASSOC = 2 /* some geom.assoc != MOT_ASSOC_IOU: run the variants compiled with every association measure
+                         (the default variants evaluate plain IoU only and ignore geom.assoc) */
+};
 size_t mot_lap_work_bytes(int n, int m);
 int mot_lap_solve(mot_ctx* ctx, const mot_lap_task* tasks, int ntasks, int max_n, int max_m, int flags);
 

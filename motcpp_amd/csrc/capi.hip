@@ -14,11 +14,11 @@
 namespace mot {
 hipError_t launch_kf_op(int op, int kind, const mot_kf_task*, int, int, hipStream_t);
 hipError_t launch_det(int kind, const mot_det_task*, int, int, hipStream_t);
-hipError_t launch_iou(const mot_iou_task*, int, int, int, hipStream_t);
-hipError_t launch_ocsort(const mot_ocsort_task*, int, int, int, hipStream_t);
+hipError_t launch_iou(const mot_iou_task*, int, int, int, bool, hipStream_t);
+hipError_t launch_ocsort(const mot_ocsort_task*, int, int, int, bool, hipStream_t);
 hipError_t launch_feat(const mot_feat_task*, int, int, hipStream_t);
 hipError_t launch_cosine(const mot_cos_task*, int, int, int, hipStream_t);
-hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, hipStream_t);
+hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, hipStream_t);
 size_t lap_scratch_bytes(int n, int m);
 }  // namespace mot
 
@@ -124,12 +124,20 @@ int mot_kf_initiate(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_
 int mot_kf_predict(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_kf_op(1, kind, t, nt, max_n, c->stream)); return MOT_OK; }
 int mot_kf_update(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_kf_op(2, kind, t, nt, max_n, c->stream)); return MOT_OK; }
 int mot_kf_boxes(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_kf_op(3, kind, t, nt, max_n, c->stream)); return MOT_OK; }
-int mot_iou_cost(mot_ctx* c, const mot_iou_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_iou(t, nt, max_n, max_m, c->stream)); return MOT_OK; }
-int mot_ocsort_cost(mot_ctx* c, const mot_ocsort_task* t, int nt, int max_nd, int max_nt) { MOT_HIP(c, mot::launch_ocsort(t, nt, max_nd, max_nt, c->stream)); return MOT_OK; }
+int mot_iou_cost(mot_ctx* c, const mot_iou_task* t, int nt, int max_n, int max_m) { return mot_iou_cost_ex(c, t, nt, max_n, max_m, 0); }
+int mot_iou_cost_ex(mot_ctx* c, const mot_iou_task* t, int nt, int max_n, int max_m, int flags) {
+  MOT_HIP(c, mot::launch_iou(t, nt, max_n, max_m, (flags & MOT_COST_F_IOU_ONLY) != 0, c->stream));
+  return MOT_OK;
+}
+int mot_ocsort_cost(mot_ctx* c, const mot_ocsort_task* t, int nt, int max_nd, int max_nt) { return mot_ocsort_cost_ex(c, t, nt, max_nd, max_nt, 0); }
+int mot_ocsort_cost_ex(mot_ctx* c, const mot_ocsort_task* t, int nt, int max_nd, int max_nt, int flags) {
+  MOT_HIP(c, mot::launch_ocsort(t, nt, max_nd, max_nt, (flags & MOT_COST_F_IOU_ONLY) != 0, c->stream));
+  return MOT_OK;
+}
 int mot_cosine_cost(mot_ctx* c, const mot_cos_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_cosine(t, nt, max_n, max_m, c->stream)); return MOT_OK; }
 int mot_feat_update(mot_ctx* c, const mot_feat_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_feat(t, nt, max_n, c->stream)); return MOT_OK; }
 size_t mot_lap_work_bytes(int n, int m) { return (mot::lap_scratch_bytes(n, m) + 255) & ~size_t(255); }
-int mot_lap_solve(mot_ctx* c, const mot_lap_task* t, int nt, int max_n, int max_m, int flags) { MOT_HIP(c, mot::launch_lap(t, nt, max_n, max_m, (flags & MOT_LAP_F_GEOM) != 0, c->stream)); return MOT_OK; }
+int mot_lap_solve(mot_ctx* c, const mot_lap_task* t, int nt, int max_n, int max_m, int flags) { MOT_HIP(c, mot::launch_lap(t, nt, max_n, max_m, (flags & MOT_LAP_F_GEOM) != 0, (flags & MOT_LAP_F_ASSOC) != 0, c->stream)); return MOT_OK; }
 
 // ---- host-pointer conveniences ------------------------------------------------------------------
 static void to_soa4(const float* aos, int n, int cols, int stride, std::vector<float>& soa) {
@@ -159,7 +167,7 @@ int mot_assoc_cost_host(mot_ctx* c, const float* a, int n, const float* b, int m
   t.assoc = assoc;
   t.frame_diag = static_cast<float>(sqrt(static_cast<double>(frame_w * frame_w + frame_h * frame_h)));  // iou.hpp:329
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
-  MOT_HIP(c, mot::launch_iou(dt.as<mot_iou_task>(), 1, n, m, c->stream));
+  MOT_HIP(c, mot::launch_iou(dt.as<mot_iou_task>(), 1, n, m, assoc == MOT_ASSOC_IOU, c->stream));
   MOT_HIP(c, hipMemcpyAsync(cost, dcost.p, static_cast<size_t>(n) * m * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   return MOT_OK;
@@ -204,7 +212,7 @@ int mot_ocsort_cost_host(mot_ctx* c, const float* dets5, int nd, const float* tr
   t.tbox = dtb.as<float>(); t.ldt = nt; t.vel = dv.as<float>(); t.ldv = nt; t.prev = dp.as<float>(); t.ldp = nt;
   t.vdc_weight = vdc; t.cost = dc.as<float>(); t.iou = di.as<float>(); t.ldc = nt;
   MOT_HIP(c, hipMemcpyAsync(dtask.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
-  MOT_HIP(c, mot::launch_ocsort(dtask.as<mot_ocsort_task>(), 1, nd, nt, c->stream));
+  MOT_HIP(c, mot::launch_ocsort(dtask.as<mot_ocsort_task>(), 1, nd, nt, true, c->stream));
   MOT_HIP(c, hipMemcpyAsync(cost, dc.p, static_cast<size_t>(nd) * nt * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(iou, di.p, static_cast<size_t>(nd) * nt * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
@@ -232,7 +240,7 @@ int mot_lap_solve_host(mot_ctx* c, const float* cost, int n, int m, float thresh
   t.mode = mode; t.iou = iou ? di.as<float>() : nullptr; t.ldi = m; t.gate = gate; t.info = dinfo.as<int>();
   t.work = dwork.p;
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
-  MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n, m, false, c->stream));
+  MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n, m, false, false, c->stream));
   MOT_HIP(c, hipMemcpyAsync(x, dx.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(y, dy.p, m * 4, hipMemcpyDeviceToHost, c->stream));
   int inf = 0;
@@ -270,7 +278,7 @@ int mot_lap_geom_host(mot_ctx* c, const float* a, int n, const float* b, int m, 
   t.geom.n = n; t.geom.m = m; t.geom.a = da.as<float>(); t.geom.lda = n; t.geom.b = db.as<float>(); t.geom.ldb = m;
   t.geom.bconf = bconf ? dc.as<float>() : nullptr; t.geom.mode = cost_mode;
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
-  MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n, m, true, c->stream));
+  MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n, m, true, false, c->stream));
   MOT_HIP(c, hipMemcpyAsync(x, dx.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(y, dy.p, m * 4, hipMemcpyDeviceToHost, c->stream));
   std::vector<float> hv(n);

@@ -46,6 +46,8 @@ __device__ __forceinline__ void stage_boxes(BoxTile& t, const float* base, int l
   }
 }
 
+// GENERAL: any mot_assoc measure; the default instance evaluates plain IoU only (half the registers, twice as fast)
+template <bool GENERAL>
 __global__ void __launch_bounds__(kThreads) iou_kernel(const mot_iou_task* __restrict__ tasks) {
   const mot_iou_task T = tasks[blockIdx.z];
   const int row0 = blockIdx.y * kTile, col0 = blockIdx.x * kTile;
@@ -83,7 +85,9 @@ __global__ void __launch_bounds__(kThreads) iou_kernel(const mot_iou_task* __res
     float out[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float iou = mot::assoc_pair(cp.assoc, cp.frame_diag, aa, aarea, bb[q], barea[q]);
+      float iou;
+      if constexpr (GENERAL) iou = mot::assoc_pair(cp.assoc, cp.frame_diag, aa, aarea, bb[q], barea[q]);
+      else iou = iou_pair(aa, aarea, bb[q], barea[q]);
       const int cq = tx * 4 + q;
       const float v = mot::cost_from_iou(cp, iou, bc[q], [&]() {
         return (cq < ncol) ? T.emb[static_cast<size_t>(row0 + r) * T.lde + col0 + cq] : 0.f;
@@ -121,6 +125,7 @@ struct TrkTile {
   float pcx[kTile], pcy[kTile], valid[kTile];
 };
 
+template <bool GENERAL>
 __global__ void __launch_bounds__(kThreads) ocsort_kernel(const mot_ocsort_task* __restrict__ tasks) {
   const mot_ocsort_task T = tasks[blockIdx.z];
   const int row0 = blockIdx.y * kTile, col0 = blockIdx.x * kTile;
@@ -174,7 +179,9 @@ __global__ void __launch_bounds__(kThreads) ocsort_kernel(const mot_ocsort_task*
     for (int q = 0; q < 4; ++q) {
       const int c = tx * 4 + q;
       const float tb[4] = {K.c[0][c], K.c[1][c], K.c[2][c], K.c[3][c]};
-      const float iou = mot::assoc_pair(T.assoc, T.frame_diag, da, darea, tb, K.area[c]);
+      float iou;
+      if constexpr (GENERAL) iou = mot::assoc_pair(T.assoc, T.frame_diag, da, darea, tb, K.area[c]);
+      else iou = iou_pair(da, darea, tb, K.area[c]);
       const float dx = dcx[r] - K.pcx[c], dy = dcy[r] - K.pcy[c];
       const float norm = sqrtf(dx * dx + dy * dy) + 1e-6f;
       const float Y = dy / norm, X = dx / norm;
@@ -215,16 +222,18 @@ __global__ void __launch_bounds__(kThreads) feat_kernel(const mot_feat_task* __r
 }  // namespace
 
 namespace mot {
-hipError_t launch_iou(const mot_iou_task* tasks, int ntasks, int max_n, int max_m, hipStream_t st) {
+hipError_t launch_iou(const mot_iou_task* tasks, int ntasks, int max_n, int max_m, bool iou_only, hipStream_t st) {
   if (ntasks <= 0 || max_n <= 0 || max_m <= 0) return hipSuccess;
   dim3 grid((max_m + kTile - 1) / kTile, (max_n + kTile - 1) / kTile, ntasks);
-  hipLaunchKernelGGL(iou_kernel, grid, dim3(kThreads), 0, st, tasks);
+  if (iou_only) hipLaunchKernelGGL(iou_kernel<false>, grid, dim3(kThreads), 0, st, tasks);
+  else hipLaunchKernelGGL(iou_kernel<true>, grid, dim3(kThreads), 0, st, tasks);
   return hipGetLastError();
 }
-hipError_t launch_ocsort(const mot_ocsort_task* tasks, int ntasks, int max_nd, int max_nt, hipStream_t st) {
+hipError_t launch_ocsort(const mot_ocsort_task* tasks, int ntasks, int max_nd, int max_nt, bool iou_only, hipStream_t st) {
   if (ntasks <= 0 || max_nd <= 0 || max_nt <= 0) return hipSuccess;
   dim3 grid((max_nt + kTile - 1) / kTile, (max_nd + kTile - 1) / kTile, ntasks);
-  hipLaunchKernelGGL(ocsort_kernel, grid, dim3(kThreads), 0, st, tasks);
+  if (iou_only) hipLaunchKernelGGL(ocsort_kernel<false>, grid, dim3(kThreads), 0, st, tasks);
+  else hipLaunchKernelGGL(ocsort_kernel<true>, grid, dim3(kThreads), 0, st, tasks);
   return hipGetLastError();
 }
 hipError_t launch_feat(const mot_feat_task* tasks, int ntasks, int max_n, hipStream_t st) {

@@ -166,6 +166,7 @@ void Device::TaskLists::clear() {
   for (int k = 0; k < 3; ++k) { det[k].clear(); kf_init[k].clear(); kf_upd[k].clear(); kf_pred[k].clear(); kf_box[k].clear(); }
   feat_set.clear(); feat_ema.clear(); cos.clear(); iou.clear(); oc.clear(); lap.clear();
   lap_geom = false;
+  lap_assoc = false;
 }
 namespace {
 template <class T>
@@ -183,6 +184,8 @@ void Device::TaskLists::append(TaskLists& o) {
   move_back(oc, o.oc); move_back(lap, o.lap);
   lap_geom = lap_geom || o.lap_geom;
   o.lap_geom = false;
+  lap_assoc = lap_assoc || o.lap_assoc;
+  o.lap_assoc = false;
 }
 Device::TaskLists& Device::q() {
   const int t = Team::worker_id();
@@ -239,7 +242,7 @@ void Device::flush() {
   auto &iou = L.iou;
   auto &oc = L.oc;
   auto &lap = L.lap;
-  const bool lap_geom = L.lap_geom;
+  const bool lap_geom = L.lap_geom, lap_assoc = L.lap_assoc;
   const mot_det_task* d_det[3];
   const mot_kf_task *d_init[3], *d_upd[3], *d_pred[3], *d_box[3];
   for (int k = 0; k < 3; ++k) {
@@ -313,18 +316,18 @@ void Device::flush() {
   {
     double b = 0;
     for (const mot_iou_task& t : iou) b += 16.0 * (t.n + t.m) + (t.cost ? 4.0 * t.n * (double)t.m : 0.0) + (t.emb ? 4.0 * t.n * (double)t.m : 0.0);
-    run(F_IOU, iou.size(), b, 0, [&] { check(mot_iou_cost(ctx, d_iou, (int)iou.size(), maxn(iou, [](const mot_iou_task& t) { return t.n; }), maxn(iou, [](const mot_iou_task& t) { return t.m; })), "mot_iou_cost"); });
+    run(F_IOU, iou.size(), b, 0, [&] { check(mot_iou_cost_ex(ctx, d_iou, (int)iou.size(), maxn(iou, [](const mot_iou_task& t) { return t.n; }), maxn(iou, [](const mot_iou_task& t) { return t.m; }), maxn(iou, [](const mot_iou_task& t) { return t.assoc; }) == 0 ? MOT_COST_F_IOU_ONLY : 0), "mot_iou_cost"); });
   }
   {
     double b = 0;
     for (const mot_ocsort_task& t : oc) b += 20.0 * t.nd + 44.0 * t.nt + 8.0 * t.nd * (double)t.nt;
-    run(F_OCSORT, oc.size(), b, 0, [&] { check(mot_ocsort_cost(ctx, d_oc, (int)oc.size(), maxn(oc, [](const mot_ocsort_task& t) { return t.nd; }), maxn(oc, [](const mot_ocsort_task& t) { return t.nt; })), "mot_ocsort_cost"); });
+    run(F_OCSORT, oc.size(), b, 0, [&] { check(mot_ocsort_cost_ex(ctx, d_oc, (int)oc.size(), maxn(oc, [](const mot_ocsort_task& t) { return t.nd; }), maxn(oc, [](const mot_ocsort_task& t) { return t.nt; }), maxn(oc, [](const mot_ocsort_task& t) { return t.assoc; }) == 0 ? MOT_COST_F_IOU_ONLY : 0), "mot_ocsort_cost"); });
   }
   {
     double b = 0;
     for (const mot_lap_task& t : lap)
       b += (t.geom.a ? 20.0 * (t.n + t.m) : 4.0 * t.n * (double)t.m) + (t.iou ? 4.0 * t.n * (double)t.m : 0.0) + 4.0 * (t.n + t.m);
-    run(F_LAP, lap.size(), b, 0, [&] { check(mot_lap_solve(ctx, d_lap, (int)lap.size(), maxn(lap, [](const mot_lap_task& t) { return t.n; }), maxn(lap, [](const mot_lap_task& t) { return t.m; }), lap_geom ? MOT_LAP_F_GEOM : 0), "mot_lap_solve"); });
+    run(F_LAP, lap.size(), b, 0, [&] { check(mot_lap_solve(ctx, d_lap, (int)lap.size(), maxn(lap, [](const mot_lap_task& t) { return t.n; }), maxn(lap, [](const mot_lap_task& t) { return t.m; }), (lap_geom ? MOT_LAP_F_GEOM : 0) | (lap_assoc ? MOT_LAP_F_ASSOC : 0)), "mot_lap_solve"); });
   }
   down->download();
   zdown->download();
@@ -510,6 +513,7 @@ Core::Lap Core::lap_geom(const IouArgs& a, float thresh, int mode, float gate, b
   t.geom.assoc = a.assoc; t.geom.frame_diag = a.frame_diag;
   dev_->q().lap.push_back(t);
   dev_->q().lap_geom = true;
+  if (a.assoc != MOT_ASSOC_IOU) dev_->q().lap_assoc = true;
   r.queued = true;
   return r;
 }

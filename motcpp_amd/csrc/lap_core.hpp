@@ -215,10 +215,18 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     for (int k = 0; k < Cost::kRPL; ++k) { vmk[k] = static_cast<float>(kLapLarge); imk[k] = 0; }
     double neg_vmax = 1e300;
     constexpr int kRowBatch = 4;  // row contexts are fetched a batch at a time so that their load latencies overlap
+    // ... and a batch ahead of their use: under load (a thousand problems in flight) a global load takes microseconds
+    typename Cost::Row RN[kRowBatch];
+#pragma unroll
+    for (int u = 0; u < kRowBatch; ++u) RN[u] = C.row((u < nr) ? u : nr - 1);
     for (int i0 = 0; i0 < nr; i0 += kRowBatch) {
       typename Cost::Row RB[kRowBatch];
 #pragma unroll
-      for (int u = 0; u < kRowBatch; ++u) RB[u] = C.row((i0 + u < nr) ? i0 + u : nr - 1);
+      for (int u = 0; u < kRowBatch; ++u) RB[u] = RN[u];
+      if (i0 + kRowBatch < nr) {
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) RN[u] = C.row((i0 + kRowBatch + u < nr) ? i0 + kRowBatch + u : nr - 1);
+      }
       float rm[kRowBatch];  // this lane's share of each row's minimum
 #pragma unroll
       for (int u = 0; u < kRowBatch; ++u) {
@@ -311,13 +319,22 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
   };
   // real row r cannot prefer any real column to the dummy columns whose value is <= bound (call with dq current)
   auto hopeless = [&](int r, double bound) { return r >= 0 && r < nr && static_cast<double>(W.rlb[r]) > bound; };
-  int pf_i = (n_uniq > 0) ? W.cols[0] : 0;
-  int pf_j = (n_uniq > 0) ? W.x[pf_i] : 0;
+  // three-deep software pipeline over the (fixed) list of rows: the index two rounds ahead, its column and row box one
+  // round ahead — each a dependent global load whose latency then overlaps a whole round (x[] and cols[] do not change here)
+  int pf_i = (n_uniq > 0) ? static_cast<int>(W.cols[0]) : 0;
+  int pf_j = (n_uniq > 0) ? static_cast<int>(W.x[pf_i]) : 0;
+  typename Cost::Row pf_box = (n_uniq > 0 && pf_i < nr) ? C.row(pf_i) : typename Cost::Row();
+  int pf_i2 = (n_uniq > 1) ? static_cast<int>(W.cols[1]) : 0;
   for (int u = 0; u < n_uniq; ++u) {
     const int i = pf_i;
     const int j = pf_j;
-    const ExtRow<Cost> R = ext_row(C, P, i);
-    if (u + 1 < n_uniq) { pf_i = W.cols[u + 1]; pf_j = W.x[pf_i]; }  // next round's indices: latency overlaps this round
+    const ExtRow<Cost> R = ext_row_pf<Cost>(P, i, pf_box);
+    if (u + 1 < n_uniq) {
+      pf_i = pf_i2;
+      pf_j = W.x[pf_i];
+      pf_box = (pf_i < nr) ? C.row(pf_i) : typename Cost::Row();
+      if (u + 2 < n_uniq) pf_i2 = W.cols[u + 2];
+    }
     double mn = kLapLarge;
     if (R.real) {
       ensure_dq();

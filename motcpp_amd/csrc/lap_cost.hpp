@@ -27,7 +27,10 @@ struct BoxPlanes {
 // rare arbitrary-column accesses (general path search, result read-out).
 // ROWS = address space of the staged row boxes (LDS or global scratch); column boxes, confidences and the appearance
 // distances are always global.
-template <int RPL, int ROWS = kMemAny>
+// GENERAL = the similarity may be any mot_assoc measure (cost_math.hpp::assoc_pair: fp64 atan, sqrt, ...). Inlined into
+// every unrolled evaluation site that costs ~100 VGPRs, i.e. half the resident wavefronts — so the hot variants are
+// compiled for plain IoU only and tasks with another measure run the GENERAL variants.
+template <int RPL, int ROWS = kMemAny, bool GENERAL = false>
 struct IouCostT {
   static constexpr int kRPL = RPL;
   BoxPlanes<ROWS> rows;
@@ -52,7 +55,9 @@ struct IouCostT {
     float a[4], area;
   };
   MOT_DEV float eval_f(const Row& r, const float b[4], float barea, float cf, int j) const {
-    const float iou = assoc_pair(prm.assoc, prm.frame_diag, r.a, r.area, b, barea);
+    float iou;
+    if constexpr (GENERAL) iou = assoc_pair(prm.assoc, prm.frame_diag, r.a, r.area, b, barea);
+    else iou = iou_pair(r.a, r.area, b, barea);
     const float* e = emb;
     const size_t off = static_cast<size_t>(r.i) * lde + j;
     return cost_from_iou(prm, iou, cf, [&]() { return gld(e, off); });

@@ -95,7 +95,7 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
 // lds_mode (compile-time, so every pointer has a static address space — a run-time choice makes the compiler fall back
 // to flat_* instructions for the LDS state, which costs hundreds of cycles per dependent access): 0 = solver state in global scratch, 1 = hot state + column boxes in LDS (row boxes
 // in global scratch), 2 = hot state + column boxes + row boxes in LDS.
-template <int kThreads, int lds_mode, int RPL>
+template <int kThreads, int lds_mode, int RPL, bool GENERAL>
 __global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __restrict__ tasks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mot_lap_task T = tasks[blockIdx.x];
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __res
       cf[j] = G.bconf ? G.bconf[gj] : 0.0f;
     }
     g.sync();
-    mot::IouCostT<RPL, kRS> C;
+    mot::IouCostT<RPL, kRS, GENERAL> C;
     C.rows = mot::BoxPlanes<kRS>{rp, nr};
     C.cols = mot::BoxPlanes<mot::kMemGlobal>{cp, nc};
     C.conf = G.bconf ? cf : nullptr;
@@ -176,7 +176,7 @@ size_t lap_scratch_bytes(int n, int m) {
 
 // Threads per problem: one wavefront (no barriers, no LDS merges; 4-8 problems co-resident per CU) unless the problem is
 // large AND there are too few problems to fill the chip anyway, where 4 wavefronts cut the latency of a row pass.
-hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool geom, hipStream_t st) {
+hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool geom, bool general_assoc, hipStream_t st) {
   if (ntasks <= 0) return hipSuccess;
   const size_t n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1, nm = n + m;
   const size_t hot = (lap_hot_bytes(nm) + 15) & ~size_t(15);
@@ -191,13 +191,14 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   const bool wide = (nm > 3072) && (ntasks < 512);
   // lane-owned column boxes in registers: one wavefront per problem, <= 8 real columns per lane
   int rpl = 0;
-  if (geom && !wide) rpl = (m <= 256) ? 4 : (m <= 512 ? 8 : 0);
+  if (geom && !wide && !general_assoc) rpl = (m <= 256) ? 4 : (m <= 512 ? 8 : 0);
   static bool attr_set = false;
-#define MOT_LAP_VARIANTS(X) X(64, 0, 0) X(64, 2, 0) X(64, 3, 0) X(64, 0, 4) X(64, 2, 4) X(64, 3, 4) X(64, 0, 8) X(64, 2, 8) X(64, 3, 8) \
-                            X(256, 0, 0) X(256, 2, 0) X(256, 3, 0)
+#define MOT_LAP_VARIANTS(X) X(64, 0, 0, false) X(64, 2, 0, false) X(64, 3, 0, false) X(64, 0, 4, false) X(64, 2, 4, false) X(64, 3, 4, false) \
+                            X(64, 0, 8, false) X(64, 2, 8, false) X(64, 3, 8, false) X(256, 0, 0, false) X(256, 2, 0, false) X(256, 3, 0, false) \
+                            X(64, 0, 0, true) X(64, 2, 0, true) X(64, 3, 0, true) X(256, 0, 0, true) X(256, 2, 0, true) X(256, 3, 0, true)
   if (!attr_set) {
-#define MOT_ATTR(T, M, R)                                                                                                  \
-    { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_kernel<T, M, R>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget); \
+#define MOT_ATTR(T, M, R, G)                                                                                               \
+    { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_kernel<T, M, R, G>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget); \
       if (e != hipSuccess) return e; }
     MOT_LAP_VARIANTS(MOT_ATTR)
 #undef MOT_ATTR
@@ -205,9 +206,9 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   }
   const int threads = wide ? 256 : 64;
   bool launched = false;
-#define MOT_TRY(T, M, R)                                                                                   \
-  if (!launched && threads == T && mode == M && rpl == R) {                                                \
-    hipLaunchKernelGGL((lap_kernel<T, M, R>), dim3(ntasks), dim3(T), lds, st, tasks);                      \
+#define MOT_TRY(T, M, R, G)                                                                                \
+  if (!launched && threads == T && mode == M && rpl == R && general_assoc == G) {                          \
+    hipLaunchKernelGGL((lap_kernel<T, M, R, G>), dim3(ntasks), dim3(T), lds, st, tasks);                   \
     launched = true;                                                                                       \
   }
   MOT_LAP_VARIANTS(MOT_TRY)

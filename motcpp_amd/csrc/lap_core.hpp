@@ -67,11 +67,13 @@ struct LapWorkT {
   MemPtr<int, kMemGlobal> tmp;    // tie flags (slow path)
   MemPtr<int, kMemGlobal> lst;    // compacted tie positions (slow path)
   MemPtr<double, kMemGlobal> rlb; // per real row: minimum raw cost over the real columns (phase 1), see "hopeless rows"
+  MemPtr<int, kMemGlobal> inv;    // inverse of cols[] (position of a column), slow path
+  MemPtr<int, kMemGlobal> tie;    // tie flags by position during a scan (all zero between scans), slow path
   long long* cyc = nullptr;  // optional profiling: [0..3] cycles in phase 1a (column minima), 1b (transfer), 2, 3; [4..7] n_uniq, serial row-reduction rounds, serial augmentations, n
 };
 using LapWork = LapWorkT<kMemAny, kMemAny>;
 MOT_HD size_t lap_hot_bytes(int n) { return static_cast<size_t>(n) * (sizeof(double) + 3 * sizeof(int)); }
-MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 4 * sizeof(int)); }
+MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 6 * sizeof(int)); }
 MOT_HD size_t lap_work_bytes(int n) { return lap_hot_bytes(n) + lap_cold_bytes(n); }
 template <class Work>
 MOT_HD void lap_carve_hot(Work& w, void* base, int n) {
@@ -89,7 +91,9 @@ MOT_HD void lap_carve_cold(Work& w, void* base, int n) {
   w.pred.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.cols.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.tmp.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
-  w.lst.p = reinterpret_cast<int*>(p);
+  w.lst.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.inv.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.tie.p = reinterpret_cast<int*>(p);
 }
 MOT_HD LapWork lap_carve(void* base, int n) {  // hot then cold, contiguous
   LapWork w;
@@ -151,6 +155,19 @@ MOT_DEV void for_lane_real(const Cost& C, const ExtRow<Cost>& R, const VP& v, in
       for (int j = t; j < nc; j += T) f(C.at(R.r, j) - v[j], j);
     }
   } else { const double l = R.left; for (int j = t; j < nc; j += T) f(l - v[j], j); }
+}
+// Rolled variant with the column boxes read from memory: for the rare general path, where an unrolled, register-cached
+// sweep would only add register pressure (occupancy is set by the kernel's worst site).
+template <class Cost, class VP, class F>
+MOT_DEV void for_lane_real_rolled(const Cost& C, const ExtRow<Cost>& R, const VP& v, int t, int T, int nc, F f) {
+  if (R.real) {
+#pragma nounroll
+    for (int j = t; j < nc; j += T) f(C.at(R.r, j) - v[j], j);
+  } else {
+    const double l = R.left;
+#pragma nounroll
+    for (int j = t; j < nc; j += T) f(l - v[j], j);
+  }
 }
 // Same for the lane's DUMMY columns (j >= nc), whose cost is the row constant `right`.
 template <class VP, class F>
@@ -642,9 +659,11 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
       // ---- general path: exact emulation of find_path_dense (:157-193) ----
       da_valid = false;  // the dual update below changes v
       dq_ok = false;
-      for (int j = t; j < n; j += T) { W.cols[j] = j; W.pred[j] = start; W.d[j] = R0.at(C, j) - W.v[j]; }
+      for (int j = t; j < n; j += T) { W.cols[j] = j; W.inv[j] = j; W.tie[j] = 0; W.pred[j] = start; W.d[j] = R0.at(C, j) - W.v[j]; }
       g.sync();
       unsigned lo = 0, hi = 0, n_ready = 0;
+      // largest h of a fully swept dummy row / of a real row's dummy-column part so far in this search (see the scan)
+      double hmax_dummy_row = -1e300, hmax_real_row = -1e300;
       while (final_j == -1) {
         if (lo == hi) {
           n_ready = lo;
@@ -677,8 +696,10 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 const int j = W.cols[k];
                 const double dj = W.d[j];
                 if (dj < mind) { h2 = lo; mind = dj; }
-                W.cols[k] = W.cols[h2];
-                W.cols[h2++] = j;
+                const int jh = W.cols[h2];
+                W.cols[k] = jh; W.inv[jh] = k;
+                W.cols[h2] = j; W.inv[j] = static_cast<int>(h2);
+                ++h2;
               }
               int fj = -1;
               for (unsigned k = lo; k < h2; ++k) {
@@ -698,51 +719,87 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           // _scan_dense (:129-155) on local copies of lo/hi, written back only on normal exit
           unsigned slo = lo, shi = hi;
           bool returned = false;
+          // software pipeline: the next member of the SCAN set, its row, distance and row box are fetched while the
+          // current one is swept (cols[] below shi, y[] and the d[] of SCAN members do not change during a sweep)
+          int pq_j = W.cols[slo];
+          int pq_i = W.y[pq_j];
+          double pq_d = W.d[pq_j];
           while (slo != shi) {
-            const int jq = W.cols[slo++];
-            const int i = W.y[jq];
-            const double mind = W.d[jq];
+            const int jq = pq_j;
+            const int i = pq_i;
+            const double mind = pq_d;
             const ExtRow<Cost> R = ext_row(C, P, i);
+            ++slo;
+            const bool fetched = slo != shi;
+            if (fetched) {
+              pq_j = W.cols[slo];
+              pq_i = W.y[pq_j];
+              pq_d = W.d[pq_j];
+            }
             const double h = R.at(C, jq) - W.v[jq] - mind;
             g.sync();
+            // The relaxation sweep, by OWNER lanes (coalesced d[], conflict-free v[], register-cached boxes) rather than
+            // by cols[] position; inv[] tells whether a column is still TODO and where it sits for the order-dependent
+            // parts. Rows of one kind share their cost over part of the columns — dummy rows over all of them, real rows
+            // over the dummy block — where cred = base(j) - v[j] - h; a row whose h does not exceed the largest h swept so
+            // far cannot undercut what that sweep left (d only falls), so that part of its sweep is skipped. lapjv scans
+            // every member of a tied set one by one, and the extension makes those sets hundreds of such rows long.
+            bool sweep_real = true, sweep_dummy = true;
+            if (i >= nr) {
+              if (h <= hmax_dummy_row) { sweep_real = false; sweep_dummy = false; }
+              else hmax_dummy_row = h;
+            } else {
+              if (h <= hmax_real_row) sweep_dummy = false;
+              else hmax_real_row = h;
+            }
             int first_sink = kNoIdx, any_tie = 0;
-            for (int k = static_cast<int>(shi) + t; k < n; k += T) {
-              const int j = W.cols[k];
-              const double cred = R.at(C, j) - W.v[j] - h;
-              int flag = 0;
+            auto relax = [&](double red, int j) {
+              const int k = W.inv[j];
+              if (k < static_cast<int>(shi)) return;  // already SCAN/READY
+              const double cred = red - h;
               if (cred < W.d[j]) {
                 W.d[j] = cred;
                 W.pred[j] = i;
                 if (cred == mind) {
-                  flag = 1;
+                  W.tie[k] = 1;
                   any_tie = 1;
                   if (W.y[j] < 0 && k < first_sink) first_sink = k;
                 }
               }
-              W.tmp[k] = flag;
-            }
-            first_sink = g.reduce_min_int(first_sink);
-            if (first_sink != kNoIdx) {
-              final_j = W.cols[first_sink];
+            };
+            if (sweep_real) for_lane_real(C, R, W.v, t, T, nc, relax);
+            if (sweep_dummy) for_lane_dummy(R.right, W.v, t, T, nc, n, relax);
+            // one reduction for both outcomes: the first sink position, or "ties but no sink", or nothing
+            const int key = g.reduce_min_int((first_sink != kNoIdx) ? first_sink : (any_tie ? kNoIdx - 1 : kNoIdx));
+            if (key < kNoIdx - 1) {
+              final_j = W.cols[key];
               returned = true;
               g.sync();
               break;
             }
             const int base = static_cast<int>(shi);
             int nt = 0;
-            if (g.reduce_max(any_tie) > 0) {  // ties are rare on real-valued costs: skip the ordered compaction without them
-              nt = compact_ascending(g, n - base, [&](int q) { return W.tmp[base + q] != 0; }, W.lst);
+            if (key == kNoIdx - 1) {  // ties are rare on real-valued costs: skip the ordered compaction without them
+              g.sync();
+              nt = compact_ascending(g, n - base, [&](int q) { return W.tie[base + q] != 0; }, W.lst);
               if (t == 0) {
                 for (int q = 0; q < nt; ++q) {  // ties join the SCAN set in ascending k (:146-147)
                   const int k = base + W.lst[q];
+                  W.tie[k] = 0;
                   const int j = W.cols[k];
-                  W.cols[k] = W.cols[shi + q];
-                  W.cols[shi + q] = j;
+                  const int js = W.cols[shi + q];
+                  W.cols[k] = js; W.inv[js] = k;
+                  W.cols[shi + q] = j; W.inv[j] = static_cast<int>(shi) + q;
                 }
               }
             }
             shi += static_cast<unsigned>(nt);
             g.sync();
+            if (!fetched && slo != shi) {  // the SCAN set was empty until this sweep's ties joined it
+              pq_j = W.cols[slo];
+              pq_i = W.y[pq_j];
+              pq_d = W.d[pq_j];
+            }
           }
           if (!returned) { lo = slo; hi = shi; }
         }

@@ -95,8 +95,11 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
 // lds_mode (compile-time, so every pointer has a static address space — a run-time choice makes the compiler fall back
 // to flat_* instructions for the LDS state, which costs hundreds of cycles per dependent access): 0 = solver state in global scratch, 1 = hot state + column boxes in LDS (row boxes
 // in global scratch), 2 = hot state + column boxes + row boxes in LDS.
+// second launch bound = wavefronts per SIMD the register allocator must leave room for: the solver is latency-bound per
+// wavefront, throughput comes from co-resident ones (RPL 8: 2, i.e. <= 256 VGPRs; RPL 4: 3, <= 168; else whatever fits)
+constexpr int lap_min_waves(int threads, int rpl, bool general) { return (threads > 64 || general) ? 1 : (rpl >= 8 ? 2 : (rpl >= 4 ? 3 : 4)); }
 template <int kThreads, int lds_mode, int RPL, bool GENERAL>
-__global__ void __launch_bounds__(kThreads) lap_kernel(const mot_lap_task* __restrict__ tasks) {
+__global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, GENERAL)) lap_kernel(const mot_lap_task* __restrict__ tasks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mot_lap_task T = tasks[blockIdx.x];
   const int nr = T.n, nc = T.m, n = nr + nc;

@@ -92,7 +92,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     tracker, P, M, D, desc = WORKLOADS[args.workload]
-    S = args.streams or {"C2": 12288, "SORT": 12288, "NS": 6144, "C5": 6144, "C3": 512, "C4": 8}[args.workload]
+    S = args.streams or {"C2": 12288, "SORT": 12288, "NS": 6144, "C5": 6144, "C3": 1536, "C4": 8}[args.workload]
     # host workers block between phases, so about twice as many workers as the box's CPU quota pay off (the bursts of
     # lifecycle work get shorter and the workers sleep through the GPU waits); far more than that and the cgroup
     # throttles the whole process (measured on the 16-CPU-quota GPU boxes: 32 workers 456k frames/s, 64 workers 268k)
@@ -116,7 +116,7 @@ def main():
     frame_bytes = S * 6 * M * 4
 
     if args.pipeline <= 0:
-        args.pipeline = {"C2": 3, "SORT": 3, "NS": 3, "C5": 3}.get(args.workload, 2)  # measured on MI355X
+        args.pipeline = {"C2": 3, "SORT": 3, "NS": 3, "C5": 3, "C3": 3}.get(args.workload, 2)  # measured on MI355X
     PIPE = max(1, min(args.pipeline, S))
     bounds = [S * p // PIPE for p in range(PIPE + 1)]
     batches = [L.Batch(tracker, bounds[p + 1] - bounds[p], device=local, threads=max(1, threads // PIPE), record_laps=False,

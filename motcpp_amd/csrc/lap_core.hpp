@@ -156,19 +156,6 @@ MOT_DEV void for_lane_real(const Cost& C, const ExtRow<Cost>& R, const VP& v, in
     }
   } else { const double l = R.left; for (int j = t; j < nc; j += T) f(l - v[j], j); }
 }
-// Rolled variant with the column boxes read from memory: for the rare general path, where an unrolled, register-cached
-// sweep would only add register pressure (occupancy is set by the kernel's worst site).
-template <class Cost, class VP, class F>
-MOT_DEV void for_lane_real_rolled(const Cost& C, const ExtRow<Cost>& R, const VP& v, int t, int T, int nc, F f) {
-  if (R.real) {
-#pragma nounroll
-    for (int j = t; j < nc; j += T) f(C.at(R.r, j) - v[j], j);
-  } else {
-    const double l = R.left;
-#pragma nounroll
-    for (int j = t; j < nc; j += T) f(l - v[j], j);
-  }
-}
 // Same for the lane's DUMMY columns (j >= nc), whose cost is the row constant `right`.
 template <class VP, class F>
 MOT_DEV void for_lane_dummy(double right, const VP& v, int t, int T, int nc, int n, F f) {
@@ -725,6 +712,28 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           int pq_i = W.y[pq_j];
           double pq_d = W.d[pq_j];
           while (slo != shi) {
+            // Runs of dummy-row members whose sweep is void (h <= hmax_dummy_row, see below) leave the SCAN set together:
+            // each lane classifies one member ahead, one reduction counts the leading void ones. With more detections
+            // than tracks the tied sets are hundreds of such rows (one per unmatched detection).
+            if (pq_i >= nr && (((pq_j < nc) ? half : 0.0) - W.v[pq_j] - pq_d) <= hmax_dummy_row) {
+              const unsigned idx = slo + static_cast<unsigned>(t);
+              bool ok = false;
+              if (idx < shi) {
+                const int mj = W.cols[idx];
+                const int mi = W.y[mj];
+                if (mi >= nr) ok = (((mj < nc) ? half : 0.0) - W.v[mj] - W.d[mj]) <= hmax_dummy_row;
+              }
+              int cnt = g.reduce_min_int(ok ? kNoIdx : t);
+              const int avail = (shi - slo < static_cast<unsigned>(T)) ? static_cast<int>(shi - slo) : T;
+              if (cnt > avail) cnt = avail;
+              slo += static_cast<unsigned>(cnt);  // cnt >= 1: lane 0 looked at the current member
+              if (slo != shi) {
+                pq_j = W.cols[slo];
+                pq_i = W.y[pq_j];
+                pq_d = W.d[pq_j];
+              }
+              continue;
+            }
             const int jq = pq_j;
             const int i = pq_i;
             const double mind = pq_d;

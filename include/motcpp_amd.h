@@ -140,7 +140,7 @@ typedef struct mot_iou_task {
   const float* emb; int32_t lde;                    /* BOTSORT: cosine distances n x m (emb NULL and lde < 0: constant 1) */
   float prox_thresh, app_thresh; int32_t fuse;      /* BOTSORT                                   */
   int32_t* pairs; int32_t* npairs; int32_t pairs_cap; float pair_thresh; /* optional: (i,j) with value < thresh */
-  int32_t assoc;     /* mot_assoc (0 = IoU)                                                          */
+  int32_t assoc;     /* a mot_assoc value, 0 = IoU                                                          */
   float frame_diag;  /* CENTROID: sqrt(w*w + h*h) of the frame                                       */
 } mot_iou_task;
 int mot_iou_cost(mot_ctx* ctx, const mot_iou_task* tasks, int ntasks, int max_n, int max_m);

@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (0: workload default)")
     ap.add_argument("--threads", type=int, default=0, help="host worker threads for the per-stream lifecycle, shared by the sub-batches (0: min(64, cores))")
     ap.add_argument("--gather-every", type=int, default=8)
+    ap.add_argument("--lifecycle", choices=["auto", "device", "host"], default="auto",
+                    help="where the per-stream track bookkeeping runs: device = mot_bt_* (ByteTrack only: four small kernels per frame, "
+                         "no host decisions), host = the C++ stage machines; auto = device where it exists")
     ap.add_argument("--pin", type=int, default=1, help="pin each sub-batch's host worker team to its own consecutive CPUs")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="split a rank's streams into this many sub-batches with their own HIP stream, stepped concurrently so one's host lifecycle overlaps another's kernels")
@@ -119,8 +122,16 @@ def main():
         args.pipeline = {"C2": 3, "SORT": 3, "NS": 3, "C5": 3, "C3": 3}.get(args.workload, 2)  # measured on MI355X
     PIPE = max(1, min(args.pipeline, S))
     bounds = [S * p // PIPE for p in range(PIPE + 1)]
-    batches = [L.Batch(tracker, bounds[p + 1] - bounds[p], device=local, threads=max(1, threads // PIPE), record_laps=False,
-                       private_device=PIPE > 1) for p in range(PIPE)]
+    on_device = tracker == "bytetrack" and args.lifecycle in ("auto", "device")
+    if args.lifecycle == "device" and not on_device:
+        raise SystemExit("--lifecycle device exists for the ByteTrack workloads only")
+    if on_device:
+        cap_tracks = (2 * P + 63) // 64 * 64  # tracked + lost never get near twice the object count (else mot_bt_step reports it)
+        batches = [L.DeviceByteTrack(bounds[p + 1] - bounds[p], cap_tracks, M, device=local) for p in range(PIPE)]
+        full_counts = [np.full(bounds[p + 1] - bounds[p], M, np.int32) for p in range(PIPE)]
+    else:
+        batches = [L.Batch(tracker, bounds[p + 1] - bounds[p], device=local, threads=max(1, threads // PIPE), record_laps=False,
+                           private_device=PIPE > 1) for p in range(PIPE)]
     cap = max(2 * M, 64)
     gathered = None
     out_all = np.zeros((S, cap, 8), np.float32)
@@ -129,7 +140,7 @@ def main():
     # one dedicated driver thread per sub-batch: its worker team (and the CPUs that team is pinned to) never changes
     pools = [ThreadPoolExecutor(1) for _ in range(PIPE)] if PIPE > 1 else None
     tpb = max(1, threads // PIPE)
-    if args.pin:
+    if args.pin and not on_device:
         for p in range(PIPE):
             first = local * threads + p * tpb
             if pools is None:
@@ -139,8 +150,11 @@ def main():
 
     def sub_step(p, f):
         s0, s1 = bounds[p], bounds[p + 1]
-        o, c = batches[p].step(host[f, s0:s1], embs=embs[f, s0:s1] if D else None, cap=cap,
-                               resident_ptr=dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4)
+        if on_device:
+            o, c = batches[p].step(resident_ptr=dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4, counts=full_counts[p], cap=cap)
+        else:
+            o, c = batches[p].step(host[f, s0:s1], embs=embs[f, s0:s1] if D else None, cap=cap,
+                                   resident_ptr=dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4)
         out_all[s0:s1] = o[:, :cap]
         cnt_all[s0:s1] = c
 
@@ -154,6 +168,8 @@ def main():
 
     def counters():
         tot = {}
+        if on_device:  # no flushes: a frame is a fixed sequence of 14 launches + 1 result copy per sub-batch
+            return {"flushes": 0, "launches": 0, "ms_begin": 0.0, "ms_flush": 0.0, "ms_advance": 0.0, "ms_sync_wait": 0.0}
         for b in batches:
             for k, v in b.counters().items():
                 tot[k] = tot.get(k, 0) + v
@@ -189,7 +205,13 @@ def main():
     t1 = time.perf_counter()
     stats = {}
     for b in batches:
-        for k, v in b.profile_stats().items():
+        ps = b.profile_stats()
+        if on_device:  # the solver's launches are timed on the device stream; "frame" = all 14 launches of a frame
+            ps = {"lap": {"ms": ps["lap1_ms"] + ps["lap23_ms"], "launches": 2 * ps["frames"], "tasks": ps["lap1_problems"] + ps["lap23_problems"],
+                          "bytes": 24.0 * (ps["lap1_nm"] + ps["lap23_nm"]), "flops": 0.0},
+                  "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
+                                        "bytes": 0.0, "flops": 0.0}}
+        for k, v in ps.items():
             a = stats.setdefault(k, {"ms": 0.0, "launches": 0, "tasks": 0, "bytes": 0.0, "flops": 0.0})
             for kk in a:
                 a[kk] += v[kk]
@@ -209,7 +231,7 @@ def main():
     frames = world * S * K
     value = frames / elapsed
     # ---- roofline of the dominant kernel family (largest summed event time in the timed region) ----
-    fam = max(stats, key=lambda k: stats[k]["ms"])
+    fam = max((k for k in stats if k != "frame_all_kernels"), key=lambda k: stats[k]["ms"])
     st = stats[fam]
     launches = max(st["launches"], 1)
     avg_ms = st["ms"] / launches
@@ -236,7 +258,7 @@ def main():
     kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["launches"],
                    "GB/s": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 2) if v["ms"] > 0 else 0.0}
                for k, v in stats.items() if v["launches"]}
-    gpu_busy_ms = sum(v["ms"] for v in stats.values())
+    gpu_busy_ms = stats["frame_all_kernels"]["ms"] if on_device else sum(v["ms"] for v in stats.values())
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference path) on one core, stream 0 ----
     cpu = None
@@ -289,7 +311,8 @@ def main():
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "tracker": tracker, "tracks": P, "dets_per_frame": M, "emb_dim": D,
-                   "streams_per_gpu": S, "frames_per_step": world * S, "host_threads": threads, "sub_batches": PIPE,
+                   "streams_per_gpu": S, "frames_per_step": world * S, "host_threads": PIPE if on_device else threads, "sub_batches": PIPE,
+                   "lifecycle": "device (mot_bt_*: 14 launches per frame, no host decisions)" if on_device else "host stage machines",
                    "parallelism": f"{world} GPU(s) x {S} independent streams, lockstep stages",
                    "inputs": "detections resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity,

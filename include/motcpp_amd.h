@@ -48,7 +48,8 @@ typedef enum mot_status {
   MOT_ERR_INVALID = -1,   /* bad argument */
   MOT_ERR_HIP = -2,       /* a HIP runtime call failed; see mot_ctx_last_error */
   MOT_ERR_NOMEM = -3,
-  MOT_ERR_NODEVICE = -4   /* no gfx950 device visible */
+  MOT_ERR_NODEVICE = -4,  /* no gfx950 device visible */
+  MOT_ERR_CAPACITY = -5   /* a fixed device-side capacity was exceeded (mot_bt_*) */
 } mot_status;
 
 /* ---- context, stream, memory --------------------------------------------------------- */
@@ -140,6 +141,9 @@ typedef struct mot_iou_task {
   const float* emb; int32_t lde;                    /* BOTSORT: cosine distances n x m (emb NULL and lde < 0: constant 1) */
   float prox_thresh, app_thresh; int32_t fuse;      /* BOTSORT                                   */
   int32_t* pairs; int32_t* npairs; int32_t pairs_cap; float pair_thresh; /* optional: (i,j) with value < thresh */
+  /* optional duplicate marking instead of a pair list (ByteTrack remove_duplicate_stracks, bytetrack.cpp:659-706): for
+   * every pair with value < pair_thresh, dup_b[j] = 1 if age_a[i] > age_b[j], else dup_a[i] = 1 (flags zeroed by the caller) */
+  const int32_t* age_a; const int32_t* age_b; uint8_t* dup_a; uint8_t* dup_b;
   int32_t assoc;     /* a mot_assoc value, 0 = IoU                                                          */
   float frame_diag;  /* CENTROID: sqrt(w*w + h*h) of the frame                                       */
 } mot_iou_task;
@@ -210,6 +214,28 @@ enum {
 };
 size_t mot_lap_work_bytes(int n, int m);
 int mot_lap_solve(mot_ctx* ctx, const mot_lap_task* tasks, int ntasks, int max_n, int max_m, int flags);
+
+/* ---- ByteTrack with the per-stream lifecycle on the device ------------------------------ */
+/* S independent ByteTrack streams whose whole update() (src/trackers/bytetrack.cpp:166-706: detection split, pools,
+ * three associations, Kalman updates, list algebra, duplicate removal, output table) runs on the GPU; the host only
+ * enqueues a fixed sequence of launches per frame. params: [min_conf, track_thresh, match_thresh, track_buffer, frame_rate].
+ * cap_tracks bounds tracked+lost tracks per stream, max_dets the detections per frame (exceeding either sets an error
+ * flag that mot_bt_step returns as MOT_ERR_CAPACITY). */
+typedef struct mot_bt_batch mot_bt_batch;
+int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, const float* params5, mot_bt_batch** out);
+void mot_bt_destroy(mot_bt_batch* b);
+int mot_bt_reset(mot_bt_batch* b);
+/* d_dets: device, SoA [S][6][max_dets]; h_counts: host [S]; out (host) [S][cap_out][8] rows x1,y1,x2,y2,id,conf,cls,det_ind;
+ * out_counts (host) [S]. Synchronous: returns when the outputs are in host memory. */
+int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float* out, int* out_counts, int cap_out);
+/* parity hook: ids and Kalman states of stream s's live tracks in list order (active then lost): ids [cap], mean [cap][8],
+ * cov [cap][64]; returns the number of tracks */
+int mot_bt_dump(mot_bt_batch* b, int s, int* ids, float* mean, float* cov, int cap);
+/* HIP-event timing of the assignment launches (enable = 1 resets). out8: [0] summed ms of the first-association launches,
+ * [1] of the second/unconfirmed launches, [2] of whole frames on the stream, [3] frames; problems queued and the sum of their
+ * n + m: [4],[5] first association, [6],[7] second + unconfirmed */
+int mot_bt_profile(mot_bt_batch* b, int enable);
+int mot_bt_profile_stats(mot_bt_batch* b, double* out8);
 
 /* ---- host-pointer conveniences (synchronous; row-major matrices) ---------------------- */
 int mot_iou_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_xyxy, int m,

@@ -1,0 +1,692 @@
+// ByteTrack with the per-stream lifecycle ON THE DEVICE (reference: src/trackers/bytetrack.cpp:166-706).
+//
+// The host-side stage machine (host/bytetrack.cpp) spends ~14 us of one CPU core per stream-frame on list bookkeeping
+// and needs three host<->device round trips per frame; on a box whose CPU quota is 16 cores that, not the GPU, bounds
+// the 256x128 configuration. Here the bookkeeping itself runs in four small kernels (one wavefront per stream) between
+// the numeric kernels, which read their task descriptors from device memory anyway: a frame is a FIXED sequence of 14
+// launches for all streams with no host decision in between, and one copy of the output tables at the end.
+//
+// Track records are indexed by their Kalman slot (a track keeps its slot for life), the active/lost lists are arrays of
+// slots in the reference's list order, and every "for ... push_back" of the reference becomes an order-preserving
+// wavefront compaction (ballot + popcount prefix). Sizes are fixed at creation (cap_tracks, max_dets); exceeding them
+// raises the stream's error flag instead of reallocating.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/motcpp_amd.h"
+
+#include "ctx.hpp"
+
+namespace mot {
+hipError_t launch_kf_op(int op, int kind, const mot_kf_task*, int, int, hipStream_t);
+hipError_t launch_det(int kind, const mot_det_task*, int, int, hipStream_t);
+hipError_t launch_iou(const mot_iou_task*, int, int, int, bool, hipStream_t);
+hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, hipStream_t);
+size_t lap_scratch_bytes(int n, int m);
+}  // namespace mot
+
+namespace {
+
+enum St { New = 0, Tracked = 1, Lost = 2, Removed = 3 };
+
+struct BtParams {
+  float min_conf, track_thresh, match_thresh, det_thresh;
+  int max_time_lost;
+};
+
+// Everything one stream owns, device resident. Arrays are CAP (tracks) or D (detections) long.
+struct BtStream {
+  // ---- persistent ----
+  int frame_count, next_id, next_slot, n_free, n_active, n_lost, err;
+  int* free_stack;
+  int* active[2]; int* lost[2]; int cur;  // lists of slots, ping-pong buffers
+  int *t_id, *t_state, *t_act, *t_tlen, *t_fid, *t_sf, *t_cls, *t_det;
+  float* t_conf;
+  // ---- frame input ----
+  const float* dets; int ld, n;  // SoA [6][ld]
+  // ---- frame scratch ----
+  int *high, *second; int n_high, n_second;
+  int* pool_slot; int n_pool, n_tracked;   // pool = tracked (from active) ++ lost
+  int* unconf_slot; int n_unconf;
+  int *pred_src, *pred_dst; unsigned char* pred_flags;
+  int *x1, *y1, *x2, *y2, *x3, *y3;
+  int *upd_src, *upd_dst, *upd_meas; int n_upd;
+  int* refind; int n_refind;
+  int* u_track; int n_utrack;
+  int* u_det; int n_udet;
+  int *r_slot, *r_pool; int n_r;
+  int* rem;
+  int lap2_q, lap3_q;
+  int *init_dst, *init_meas; int n_init;
+  int* lost_new; int n_lost_new;
+  int *age_a, *age_b; unsigned char *dup_a, *dup_b;
+  float* abox;  // [4][CAP] boxes of the new active list (output rows)
+};
+
+constexpr int kW = 64;  // one wavefront per stream
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x; }
+// order-preserving append of the lanes whose pred holds; `base` (uniform) advances
+__device__ __forceinline__ int compact(bool pred, int& base) {
+  const unsigned long long m = __ballot(pred);
+  const int pos = base + __popcll(m & ((1ull << lane_id()) - 1ull));
+  base += __popcll(m);
+  return pos;
+}
+
+// ---- K0: detection split, pools, predict + first-association tasks (bytetrack.cpp:166-265) ----
+// stats[0] = assignment problems queued, stats[1] = sum of their n + m (algorithmic bytes of the solver: 24 B per row/column)
+__global__ void __launch_bounds__(kW) bt_begin(BtStream* streams, BtParams P, int CAP, int D, const int* counts, const float* dets_base,
+                                                mot_det_task* det_t, mot_kf_task* pred_t, mot_lap_task* lap1_t, unsigned long long* stats) {
+  BtStream& S = streams[blockIdx.x];
+  const int t = lane_id();
+  const int n = counts[blockIdx.x];
+  const float* dets = dets_base + static_cast<size_t>(blockIdx.x) * 6 * D;
+  if (t == 0) {
+    S.frame_count += 1;
+    S.dets = dets; S.ld = D; S.n = n;
+    if (n > D) S.err = 1;
+  }
+  const float* conf = dets + static_cast<size_t>(4) * D;
+  int nh = 0, ns = 0;
+  for (int i0 = 0; i0 < n; i0 += kW) {
+    const int i = i0 + t;
+    const float c = (i < n) ? conf[i] : 0.f;
+    const bool hi = i < n && c > P.track_thresh;
+    const bool lo = i < n && c > P.min_conf && c < P.track_thresh;
+    const int ph = compact(hi, nh);
+    if (hi) S.high[ph] = i;
+    const int pl = compact(lo, ns);
+    if (lo) S.second[pl] = i;
+  }
+  const int* act = S.active[S.cur];
+  const int* lst = S.lost[S.cur];
+  int np = 0, nu = 0;
+  for (int i0 = 0; i0 < S.n_active; i0 += kW) {
+    const int i = i0 + t;
+    const int slot = (i < S.n_active) ? act[i] : 0;
+    const bool a = i < S.n_active && S.t_act[slot] != 0;
+    const bool u = i < S.n_active && S.t_act[slot] == 0;
+    const int pa = compact(a, np);
+    if (a) S.pool_slot[pa] = slot;
+    const int pu = compact(u, nu);
+    if (u) S.unconf_slot[pu] = slot;
+  }
+  const int n_tracked = np;
+  for (int i0 = 0; i0 < S.n_lost; i0 += kW) {  // tracked and lost are disjoint by id at frame start (:565-580 of the previous frame)
+    const int i = i0 + t;
+    const bool v = i < S.n_lost;
+    const int p = compact(v, np);
+    if (v) S.pool_slot[p] = lst[i];
+  }
+  __syncthreads();
+  for (int i = t; i < np; i += kW) {  // predicted COPIES of the pool go to scratch slots CAP + i (:251-265)
+    const int slot = S.pool_slot[i];
+    S.pred_src[i] = slot;
+    S.pred_dst[i] = CAP + i;
+    S.pred_flags[i] = (S.t_state[slot] != Tracked) ? MOT_KF_ZERO_V7 : 0;
+  }
+  if (t == 0) {
+    S.n_high = nh; S.n_second = ns; S.n_pool = np; S.n_tracked = n_tracked; S.n_unconf = nu;
+    S.n_upd = 0; S.n_refind = 0; S.n_utrack = 0; S.n_udet = 0; S.n_r = 0; S.n_init = 0; S.n_lost_new = 0; S.lap2_q = 0; S.lap3_q = 0;
+    det_t[blockIdx.x].dets = dets; det_t[blockIdx.x].ld = D; det_t[blockIdx.x].n = (n <= D) ? n : 0;
+    pred_t[blockIdx.x].n = np;
+    mot_lap_task& L = lap1_t[blockIdx.x];
+    const bool q = np > 0 && nh > 0;
+    L.n = q ? np : 0; L.m = q ? nh : 0;
+    L.geom.n = L.n; L.geom.m = L.m;
+    L.geom.bconf = conf;  // score fusion reads the frame's confidences (:300-312)
+    if (q) { atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], static_cast<unsigned long long>(np + nh)); }
+  }
+}
+
+// ---- K1: apply the first association, queue the second and the unconfirmed one (:267-455) ----
+__global__ void __launch_bounds__(kW) bt_after_first(BtStream* streams, BtParams P, int CAP, mot_kf_task* box_t, mot_lap_task* lap23_t,
+                                                      unsigned long long* stats) {
+  BtStream& S = streams[blockIdx.x];
+  const int t = lane_id();
+  const int np = S.n_pool, nd = S.n_high;
+  const bool have = np > 0 && nd > 0;
+  int n_upd = 0, n_ref = 0, n_ut = 0, n_ud = 0;
+  for (int i0 = 0; i0 < np; i0 += kW) {
+    const int i = i0 + t;
+    const bool v = i < np;
+    const int x = (v && have) ? S.x1[i] : -1;
+    const int slot = v ? S.pool_slot[i] : 0;
+    const bool m = v && x >= 0;
+    const bool was_tracked = m && S.t_state[slot] == Tracked;
+    const int pu = compact(m, n_upd);
+    if (m) {
+      const int det = S.high[x];
+      S.upd_src[pu] = CAP + i; S.upd_dst[pu] = slot; S.upd_meas[pu] = det;
+      // STrack::update :71-89 / re_activate :55-69
+      if (was_tracked) { S.t_fid[slot] = S.frame_count; S.t_tlen[slot] += 1; }
+      else { S.t_tlen[slot] = 0; S.t_fid[slot] = S.frame_count; }
+      S.t_state[slot] = Tracked; S.t_act[slot] = 1;
+      S.t_conf[slot] = S.dets[static_cast<size_t>(4) * S.ld + det];
+      S.t_cls[slot] = static_cast<int>(S.dets[static_cast<size_t>(5) * S.ld + det]);
+      S.t_det[slot] = det;
+    }
+    const bool rf = m && !was_tracked;
+    const int pr = compact(rf, n_ref);
+    if (rf) S.refind[pr] = slot;
+    const bool um = v && x < 0;
+    const int pt = compact(um, n_ut);
+    if (um) S.u_track[pt] = i;
+  }
+  for (int j0 = 0; j0 < nd; j0 += kW) {
+    const int j = j0 + t;
+    const bool u = j < nd && (!have || S.y1[j] < 0);
+    const int p = compact(u, n_ud);
+    if (u) S.u_det[p] = j;
+  }
+  __syncthreads();
+  // second association: the still-Tracked, still-unmatched pool members that came from the active list (:367-442)
+  int n_r = 0;
+  for (int k0 = 0; k0 < n_ut; k0 += kW) {
+    const int k = k0 + t;
+    const int i = (k < n_ut) ? S.u_track[k] : 0;
+    const int slot = (k < n_ut) ? S.pool_slot[i] : 0;
+    const bool r = k < n_ut && i < S.n_tracked && S.t_state[slot] == Tracked;
+    const int p = compact(r, n_r);
+    if (r) { S.r_slot[p] = slot; S.r_pool[p] = i; }
+  }
+  for (int k = t; k < n_ud; k += kW) S.rem[k] = S.high[S.u_det[k]];
+  __syncthreads();
+  if (t == 0) {
+    S.n_upd = n_upd; S.n_refind = n_ref; S.n_utrack = n_ut; S.n_udet = n_ud; S.n_r = n_r;
+    const bool q2 = S.n_second > 0 && n_r > 0;
+    const bool q3 = S.n_unconf > 0 && n_ud > 0;
+    S.lap2_q = q2; S.lap3_q = q3;
+    box_t[2 * blockIdx.x + 0].n = q2 ? n_r : 0;
+    box_t[2 * blockIdx.x + 1].n = q3 ? S.n_unconf : 0;
+    mot_lap_task& A = lap23_t[2 * blockIdx.x + 0];
+    A.n = q2 ? n_r : 0; A.m = q2 ? S.n_second : 0; A.geom.n = A.n; A.geom.m = A.m;
+    mot_lap_task& B = lap23_t[2 * blockIdx.x + 1];
+    B.n = q3 ? S.n_unconf : 0; B.m = q3 ? n_ud : 0; B.geom.n = B.n; B.geom.m = B.m;
+    B.geom.bconf = S.dets + static_cast<size_t>(4) * S.ld;
+    if (q2) { atomicAdd(&stats[2], 1ull); atomicAdd(&stats[3], static_cast<unsigned long long>(A.n + A.m)); }
+    if (q3) { atomicAdd(&stats[2], 1ull); atomicAdd(&stats[3], static_cast<unsigned long long>(B.n + B.m)); }
+  }
+}
+
+// ---- K2: apply associations 2 and 3, births, deaths, list algebra, queue the Kalman work (:442-580) ----
+__global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParams P, int CAP, mot_kf_task* init_t, mot_kf_task* upd_t,
+                                                       mot_kf_task* box2_t, mot_iou_task* dup_t) {
+  BtStream& S = streams[blockIdx.x];
+  const int t = lane_id();
+  int n_upd = S.n_upd, n_ln = 0;
+  if (S.lap2_q) {
+    for (int i0 = 0; i0 < S.n_r; i0 += kW) {
+      const int i = i0 + t;
+      const bool v = i < S.n_r;
+      const int slot = v ? S.r_slot[i] : 0;
+      const int j = v ? S.x2[i] : -1;
+      const bool m = v && j >= 0;
+      const int pu = compact(m, n_upd);
+      if (m) {
+        const int det = S.second[j];
+        S.upd_src[pu] = CAP + S.r_pool[i]; S.upd_dst[pu] = slot; S.upd_meas[pu] = det;
+        S.t_fid[slot] = S.frame_count; S.t_tlen[slot] += 1;  // state is Tracked here
+        S.t_state[slot] = Tracked; S.t_act[slot] = 1;
+        S.t_conf[slot] = S.dets[static_cast<size_t>(4) * S.ld + det];
+        S.t_cls[slot] = static_cast<int>(S.dets[static_cast<size_t>(5) * S.ld + det]);
+        S.t_det[slot] = det;
+      }
+      const bool l = v && j < 0 && S.t_state[slot] != Lost;
+      const int pl = compact(l, n_ln);
+      if (l) { S.t_state[slot] = Lost; S.lost_new[pl] = slot; }
+    }
+  }
+  // unconfirmed tracks vs. the leftover high detections (:455-542); u_det_final = detections nobody took
+  int* udf = S.y3;  // reuse: final unmatched detection list (indices into high) is written over y3 once it has been read
+  int n_udf = 0;
+  if (S.lap3_q) {
+    // first gather the unmatched columns (read y3 completely before overwriting it: one chunk at a time, in order)
+    for (int j0 = 0; j0 < S.n_udet; j0 += kW) {
+      const int j = j0 + t;
+      const bool u = j < S.n_udet && S.y3[j] < 0;
+      const int val = (j < S.n_udet) ? S.u_det[j] : 0;
+      __syncthreads();
+      const int p = compact(u, n_udf);  // p <= j: never overwrites an unread entry
+      if (u) udf[p] = val;
+      __syncthreads();
+    }
+    for (int i0 = 0; i0 < S.n_unconf; i0 += kW) {
+      const int i = i0 + t;
+      const bool v = i < S.n_unconf;
+      const int slot = v ? S.unconf_slot[i] : 0;
+      const int j = v ? S.x3[i] : -1;
+      const bool m = v && j >= 0;
+      const int pu = compact(m, n_upd);
+      if (m) {
+        const int det = S.high[S.u_det[j]];
+        S.upd_src[pu] = slot; S.upd_dst[pu] = slot; S.upd_meas[pu] = det;  // un-predicted state (:524-527)
+        if (S.t_state[slot] == Tracked) { S.t_fid[slot] = S.frame_count; S.t_tlen[slot] += 1; }
+        else { S.t_tlen[slot] = 0; S.t_fid[slot] = S.frame_count; }
+        S.t_state[slot] = Tracked; S.t_act[slot] = 1;
+        S.t_conf[slot] = S.dets[static_cast<size_t>(4) * S.ld + det];
+        S.t_cls[slot] = static_cast<int>(S.dets[static_cast<size_t>(5) * S.ld + det]);
+        S.t_det[slot] = det;
+      }
+      if (v && j < 0) S.t_state[slot] = Removed;
+    }
+  } else {
+    for (int j = t; j < S.n_udet; j += kW) udf[j] = S.u_det[j];
+    n_udf = S.n_udet;
+  }
+  __syncthreads();
+  // births (:546-554): ids in list order
+  int n_init = 0;
+  int free_top = S.n_free, next_slot = S.next_slot, err = 0;
+  for (int j0 = 0; j0 < n_udf; j0 += kW) {
+    const int k = j0 + t;
+    const int det = (k < n_udf) ? S.high[udf[k]] : 0;
+    const float c = (k < n_udf) ? S.dets[static_cast<size_t>(4) * S.ld + det] : 0.f;
+    const bool b = k < n_udf && c >= P.det_thresh;
+    const int base0 = n_init;
+    const int p = compact(b, n_init);
+    const int births = n_init - base0;
+    // slots: from the free stack first, then fresh ones (which physical slot a track gets is not observable)
+    int slot = -1;
+    if (b) {
+      const int r = p - base0;
+      if (r < free_top) slot = S.free_stack[free_top - 1 - r];
+      else { slot = next_slot + (r - free_top); if (slot >= CAP) { slot = CAP - 1; err = 1; } }
+      S.t_id[slot] = S.next_id + p + 1;
+      S.t_conf[slot] = c;
+      S.t_cls[slot] = static_cast<int>(S.dets[static_cast<size_t>(5) * S.ld + det]);
+      S.t_det[slot] = det;
+      S.t_tlen[slot] = 0; S.t_state[slot] = Tracked;
+      S.t_act[slot] = (S.frame_count == 1) ? 1 : 0;
+      S.t_fid[slot] = S.frame_count; S.t_sf[slot] = S.frame_count;
+      S.init_dst[p] = slot; S.init_meas[p] = det;
+    }
+    const int from_free = (births < free_top) ? births : free_top;
+    next_slot += births - from_free;
+    free_top -= from_free;
+  }
+  err = __any(err) ? 1 : 0;
+  const int* lst = S.lost[S.cur];
+  const int* act = S.active[S.cur];
+  for (int i = t; i < S.n_lost; i += kW) {  // :557-562
+    const int slot = lst[i];
+    if (S.frame_count - S.t_fid[slot] > P.max_time_lost) S.t_state[slot] = Removed;
+  }
+  __syncthreads();
+  // list algebra (:565-580). A track lives in exactly one record, so the reference's copies are moves.
+  int* na = S.active[S.cur ^ 1];
+  int* nl = S.lost[S.cur ^ 1];
+  int n_na = 0, n_nl = 0;
+  for (int i0 = 0; i0 < S.n_active; i0 += kW) {
+    const int i = i0 + t;
+    const int slot = (i < S.n_active) ? act[i] : 0;
+    const int st = (i < S.n_active) ? S.t_state[slot] : -1;
+    const bool k = st == Tracked;
+    const int p = compact(k, n_na);
+    if (k) na[p] = slot;
+    const bool dead = st == Removed;
+    const int pf = compact(dead, free_top);
+    if (dead) S.free_stack[pf] = slot;
+  }
+  if (n_na + n_init + S.n_refind > CAP) err = 1;
+  else {
+    for (int i = t; i < n_init; i += kW) na[n_na + i] = S.init_dst[i];
+    n_na += n_init;
+    for (int i = t; i < S.n_refind; i += kW) na[n_na + i] = S.refind[i];  // re-found lost tracks, in match order
+    n_na += S.n_refind;
+  }
+  for (int i0 = 0; i0 < S.n_lost; i0 += kW) {
+    const int i = i0 + t;
+    const int slot = (i < S.n_lost) ? lst[i] : 0;
+    const int st = (i < S.n_lost) ? S.t_state[slot] : -1;
+    const bool k = st == Lost;          // Tracked = re-found (now active), Removed = aged out
+    const int p = compact(k, n_nl);
+    if (k) nl[p] = slot;
+    const bool dead = st == Removed;
+    const int pf = compact(dead, free_top);
+    if (dead) S.free_stack[pf] = slot;
+  }
+  if (n_nl + n_ln > CAP) err = 1;
+  else {
+    for (int i = t; i < n_ln; i += kW) nl[n_nl + i] = S.lost_new[i];
+    n_nl += n_ln;
+  }
+  __syncthreads();
+  for (int i = t; i < n_na && i < CAP; i += kW) { const int slot = na[i]; S.age_a[i] = S.t_fid[slot] - S.t_sf[slot]; S.dup_a[i] = 0; }
+  for (int i = t; i < n_nl && i < CAP; i += kW) { const int slot = nl[i]; S.age_b[i] = S.t_fid[slot] - S.t_sf[slot]; S.dup_b[i] = 0; }
+  if (t == 0) {
+    S.n_upd = n_upd; S.n_init = n_init; S.n_lost_new = n_ln;
+    S.next_id += n_init; S.next_slot = next_slot; S.n_free = free_top;
+    S.n_active = n_na; S.n_lost = n_nl; S.cur ^= 1;
+    if (err) S.err = 1;
+    init_t[blockIdx.x].n = n_init;
+    upd_t[blockIdx.x].n = n_upd;
+    mot_kf_task& BA = box2_t[2 * blockIdx.x + 0];
+    BA.n = n_na; BA.src = na;
+    mot_kf_task& BL = box2_t[2 * blockIdx.x + 1];
+    BL.n = (n_na > 0 && n_nl > 0) ? n_nl : 0; BL.src = nl;
+    mot_iou_task& U = dup_t[blockIdx.x];
+    U.n = (n_na > 0 && n_nl > 0) ? n_na : 0; U.m = (n_na > 0 && n_nl > 0) ? n_nl : 0;
+  }
+}
+
+// ---- K3: duplicate removal and the output table (:582-621, :659-706) ----
+__global__ void __launch_bounds__(kW) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out) {
+  BtStream& S = streams[blockIdx.x];
+  const int t = lane_id();
+  int* act = S.active[S.cur];
+  int* lst = S.lost[S.cur];
+  float* rows = out + static_cast<size_t>(blockIdx.x) * cap_out * 8;
+  const bool dups = S.n_active > 0 && S.n_lost > 0;
+  int free_top = S.n_free;
+  int n_keep = 0, n_rows = 0;
+  for (int i0 = 0; i0 < S.n_active; i0 += kW) {
+    const int i = i0 + t;
+    const bool v = i < S.n_active;
+    const int slot = v ? act[i] : 0;
+    const bool dup = v && dups && S.dup_a[i] != 0;
+    const bool keep = v && !dup;
+    const bool emit = keep && S.t_act[slot] != 0;
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (emit) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) b[k] = S.abox[static_cast<size_t>(k) * CAP + i];
+    }
+    __syncthreads();  // act[] entries of this chunk are read before the compacted list overwrites them (p <= i)
+    const int p = compact(keep, n_keep);
+    if (keep) act[p] = slot;
+    const int pr = compact(emit, n_rows);
+    if (emit && pr < cap_out) {
+      float* r = rows + static_cast<size_t>(pr) * 8;
+      r[0] = b[0]; r[1] = b[1]; r[2] = b[2]; r[3] = b[3];
+      r[4] = static_cast<float>(S.t_id[slot]); r[5] = S.t_conf[slot];
+      r[6] = static_cast<float>(S.t_cls[slot]); r[7] = static_cast<float>(S.t_det[slot]);
+    }
+    const int pf = compact(dup, free_top);
+    if (dup) S.free_stack[pf] = slot;
+    __syncthreads();
+  }
+  int n_keep_l = 0;
+  for (int i0 = 0; i0 < S.n_lost; i0 += kW) {
+    const int i = i0 + t;
+    const bool v = i < S.n_lost;
+    const int slot = v ? lst[i] : 0;
+    const bool dup = v && dups && S.dup_b[i] != 0;
+    const bool keep = v && !dup;
+    __syncthreads();
+    const int p = compact(keep, n_keep_l);
+    if (keep) lst[p] = slot;
+    const int pf = compact(dup, free_top);
+    if (dup) S.free_stack[pf] = slot;
+    __syncthreads();
+  }
+  if (t == 0) {
+    S.n_active = n_keep; S.n_lost = n_keep_l; S.n_free = free_top;
+    if (n_rows > cap_out) S.err = 2;
+    out_counts[blockIdx.x] = (n_rows <= cap_out) ? n_rows : -n_rows;
+  }
+}
+
+__global__ void bt_collect_err(const BtStream* streams, int n, int* err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && streams[i].err) atomicMax(err, streams[i].err);
+}
+
+}  // namespace
+
+// ---- host side: allocation and the per-frame launch sequence -----------------------------------------------------------
+struct mot_bt_batch {
+  mot_ctx* ctx = nullptr;
+  int S = 0, CAP = 0, D = 0;
+  BtParams prm{};
+  std::vector<void*> allocs;
+  BtStream* d_streams = nullptr;
+  std::vector<BtStream> h_streams;  // host mirror of the pointers (scalars are only valid on the device)
+  int* d_counts = nullptr;
+  int* d_err = nullptr;
+  float* d_out = nullptr; int* d_out_counts = nullptr; int out_cap = 0;
+  mot_det_task* det_t = nullptr;
+  mot_kf_task *pred_t = nullptr, *box_t = nullptr, *init_t = nullptr, *upd_t = nullptr, *box2_t = nullptr;
+  mot_lap_task *lap1_t = nullptr, *lap23_t = nullptr;
+  mot_iou_task* dup_t = nullptr;
+  float* mean = nullptr; float* cov = nullptr;  // [S][8][2CAP], [S][64][2CAP]
+  // profiling (bench.py's roofline leg): HIP events around the two assignment launches and the whole frame
+  bool profile = false;
+  unsigned long long* d_stats = nullptr;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double lap_ms[2] = {0.0, 0.0}, frame_ms = 0.0;
+  long frames = 0;
+  template <class T>
+  T* dalloc(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+    allocs.push_back(p);
+    return static_cast<T*>(p);
+  }
+};
+
+#define BT_HIP(b, call)                                                                                  \
+  do {                                                                                                   \
+    hipError_t e_ = (call);                                                                              \
+    if (e_ != hipSuccess) { (b)->ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return MOT_ERR_HIP; } \
+  } while (0)
+
+extern "C" {
+
+void mot_bt_destroy(mot_bt_batch* b) {
+  if (!b) return;
+  for (void* p : b->allocs) (void)hipFree(p);
+  for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+  delete b;
+}
+
+int mot_bt_reset(mot_bt_batch* b) {
+  // scalars back to zero; the arrays need no clearing (everything is rebuilt from the empty lists)
+  std::vector<BtStream> h = b->h_streams;
+  BT_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(BtStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
+  BT_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
+  BT_HIP(b, hipStreamSynchronize(b->ctx->stream));
+  return MOT_OK;
+}
+
+int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, const float* p5, mot_bt_batch** out) {
+  if (!ctx || !out || nstreams <= 0 || cap_tracks <= 0 || max_dets <= 0) return MOT_ERR_INVALID;
+  auto* b = new mot_bt_batch();
+  b->ctx = ctx; b->S = nstreams; b->CAP = cap_tracks; b->D = max_dets;
+  const float min_conf = p5 ? p5[0] : 0.1f, track_thresh = p5 ? p5[1] : 0.45f, match_thresh = p5 ? p5[2] : 0.8f;
+  const int track_buffer = p5 ? static_cast<int>(p5[3]) : 25, frame_rate = p5 ? static_cast<int>(p5[4]) : 30;
+  b->prm.min_conf = min_conf; b->prm.track_thresh = track_thresh; b->prm.match_thresh = match_thresh;
+  b->prm.det_thresh = track_thresh;                                                    // bytetrack.cpp:145
+  b->prm.max_time_lost = static_cast<int>(frame_rate / 30.0f * track_buffer);           // :141-142
+  const int S = nstreams, CAP = cap_tracks, D = max_dets, C2 = 2 * cap_tracks;
+  const size_t ints_per = static_cast<size_t>(CAP) * 28 + static_cast<size_t>(D) * 9;
+  int* ip = b->dalloc<int>(ints_per * S);
+  float* fp = b->dalloc<float>((static_cast<size_t>(CAP) * (1 + 4 * 5) + static_cast<size_t>(D) * 8) * S);
+  unsigned char* bp = b->dalloc<unsigned char>(static_cast<size_t>(CAP) * 3 * S);
+  b->mean = b->dalloc<float>(static_cast<size_t>(S) * 8 * C2);
+  b->cov = b->dalloc<float>(static_cast<size_t>(S) * 64 * C2);
+  b->d_streams = b->dalloc<BtStream>(S);
+  b->d_counts = b->dalloc<int>(S);
+  b->d_err = b->dalloc<int>(1);
+  b->d_stats = b->dalloc<unsigned long long>(4);
+  if (b->d_stats) (void)hipMemset(b->d_stats, 0, 4 * sizeof(unsigned long long));
+  for (auto& e : b->ev) (void)hipEventCreate(&e);
+  b->det_t = b->dalloc<mot_det_task>(S);
+  b->pred_t = b->dalloc<mot_kf_task>(S); b->box_t = b->dalloc<mot_kf_task>(2 * S); b->init_t = b->dalloc<mot_kf_task>(S);
+  b->upd_t = b->dalloc<mot_kf_task>(S); b->box2_t = b->dalloc<mot_kf_task>(2 * S);
+  b->lap1_t = b->dalloc<mot_lap_task>(S); b->lap23_t = b->dalloc<mot_lap_task>(2 * S);
+  b->dup_t = b->dalloc<mot_iou_task>(S);
+  const size_t wb1 = (mot::lap_scratch_bytes(CAP, D) + 255) & ~size_t(255);
+  char* work = b->dalloc<char>(wb1 * 3 * S);
+  int* info = b->dalloc<int>(static_cast<size_t>(4) * 3 * S);
+  if (!ip || !fp || !bp || !b->mean || !b->cov || !b->d_streams || !b->d_counts || !b->d_err || !b->det_t || !b->pred_t || !b->box_t ||
+      !b->init_t || !b->upd_t || !b->box2_t || !b->lap1_t || !b->lap23_t || !b->dup_t || !work || !info) {
+    mot_bt_destroy(b);
+    return MOT_ERR_NOMEM;
+  }
+  std::vector<BtStream> hs(S);
+  std::vector<mot_det_task> det(S);
+  std::vector<mot_kf_task> pred(S), box(2 * S), init(S), upd(S), box2(2 * S);
+  std::vector<mot_lap_task> lap1(S), lap23(2 * S);
+  std::vector<mot_iou_task> dup(S);
+  for (int s = 0; s < S; ++s) {
+    BtStream& T = hs[s];
+    std::memset(&T, 0, sizeof(T));
+    int* i = ip + ints_per * s;
+    auto I = [&](int n) { int* r = i; i += n; return r; };
+    T.free_stack = I(CAP); T.active[0] = I(CAP); T.active[1] = I(CAP); T.lost[0] = I(CAP); T.lost[1] = I(CAP);
+    T.t_id = I(CAP); T.t_state = I(CAP); T.t_act = I(CAP); T.t_tlen = I(CAP); T.t_fid = I(CAP); T.t_sf = I(CAP); T.t_cls = I(CAP); T.t_det = I(CAP);
+    T.pool_slot = I(CAP); T.unconf_slot = I(CAP); T.pred_src = I(CAP); T.pred_dst = I(CAP);
+    T.x1 = I(CAP); T.x2 = I(CAP); T.x3 = I(CAP); T.upd_src = I(CAP); T.upd_dst = I(CAP); T.upd_meas = I(CAP);
+    T.refind = I(CAP); T.u_track = I(CAP); T.r_slot = I(CAP); T.r_pool = I(CAP); T.lost_new = I(CAP);  // 28 CAP-sized arrays
+    T.high = I(D); T.second = I(D); T.y1 = I(D); T.y2 = I(D); T.y3 = I(D); T.u_det = I(D); T.rem = I(D); T.init_dst = I(D); T.init_meas = I(D);
+    float* f = fp + (static_cast<size_t>(CAP) * 21 + static_cast<size_t>(D) * 8) * s;
+    auto F = [&](int n) { float* r = f; f += n; return r; };
+    T.t_conf = F(CAP);
+    float* pool_box = F(4 * CAP); float* rbox = F(4 * CAP); float* ubox = F(4 * CAP); T.abox = F(4 * CAP); float* lbox = F(4 * CAP);
+    float* d_box = F(4 * D); float* d_meas = F(4 * D);
+    unsigned char* u = bp + static_cast<size_t>(CAP) * 3 * s;
+    T.pred_flags = u; T.dup_a = u + CAP; T.dup_b = u + 2 * CAP;
+    float* mean = b->mean + static_cast<size_t>(s) * 8 * C2;
+    float* cov = b->cov + static_cast<size_t>(s) * 64 * C2;
+    // ---- static parts of the task descriptors ----
+    std::memset(&det[s], 0, sizeof(mot_det_task));
+    det[s].box = d_box; det[s].ldb = D; det[s].meas = d_meas; det[s].ldm = D;
+    auto kf = [&](mot_kf_task& k) { std::memset(&k, 0, sizeof(k)); k.mean = mean; k.cov = cov; k.cap = C2; };
+    kf(pred[s]); pred[s].src = T.pred_src; pred[s].dst = T.pred_dst; pred[s].flags = T.pred_flags; pred[s].boxes = pool_box; pred[s].ldb = CAP;
+    kf(box[2 * s]); box[2 * s].src = T.r_slot; box[2 * s].boxes = rbox; box[2 * s].ldb = CAP;
+    kf(box[2 * s + 1]); box[2 * s + 1].src = T.unconf_slot; box[2 * s + 1].boxes = ubox; box[2 * s + 1].ldb = CAP;
+    kf(init[s]); init[s].src = T.init_dst; init[s].dst = T.init_dst; init[s].meas = d_meas; init[s].ldm = D; init[s].midx = T.init_meas;
+    kf(upd[s]); upd[s].src = T.upd_src; upd[s].dst = T.upd_dst; upd[s].meas = d_meas; upd[s].ldm = D; upd[s].midx = T.upd_meas;
+    kf(box2[2 * s]); box2[2 * s].boxes = T.abox; box2[2 * s].ldb = CAP;
+    kf(box2[2 * s + 1]); box2[2 * s + 1].boxes = lbox; box2[2 * s + 1].ldb = CAP;
+    auto lap = [&](mot_lap_task& L, int k, int* x, int* y, const float* a, const int* bidx, const float* bconf, int mode, float thresh) {
+      std::memset(&L, 0, sizeof(L));
+      L.x = x; L.y = y; L.thresh = thresh; L.mode = MOT_LAP_PLAIN; L.info = info + (static_cast<size_t>(s) * 3 + k) * 4;
+      L.work = work + (static_cast<size_t>(s) * 3 + k) * wb1;
+      L.geom.a = a; L.geom.lda = CAP; L.geom.b = d_box; L.geom.ldb = D; L.geom.bidx = bidx; L.geom.bconf = bconf; L.geom.mode = mode;
+    };
+    lap(lap1[s], 0, T.x1, T.y1, pool_box, T.high, nullptr, MOT_COST_IOU_DIST_FUSE, match_thresh);
+    lap(lap23[2 * s], 1, T.x2, T.y2, rbox, T.second, nullptr, MOT_COST_IOU_DIST, 0.5f);
+    lap(lap23[2 * s + 1], 2, T.x3, T.y3, ubox, T.rem, nullptr, MOT_COST_IOU_DIST_FUSE, 0.7f);
+    std::memset(&dup[s], 0, sizeof(mot_iou_task));
+    dup[s].a = T.abox; dup[s].lda = CAP; dup[s].b = lbox; dup[s].ldb = CAP; dup[s].mode = MOT_COST_IOU_DIST; dup[s].pair_thresh = 0.15f;
+    dup[s].dup_a = T.dup_a; dup[s].dup_b = T.dup_b;
+  }
+  // age arrays: carve from a separate allocation (kept out of the int pool arithmetic above)
+  int* ages = b->dalloc<int>(static_cast<size_t>(2) * CAP * S);
+  if (!ages) { mot_bt_destroy(b); return MOT_ERR_NOMEM; }
+  for (int s = 0; s < S; ++s) {
+    hs[s].age_a = ages + static_cast<size_t>(2) * CAP * s; hs[s].age_b = hs[s].age_a + CAP;
+    dup[s].age_a = hs[s].age_a; dup[s].age_b = hs[s].age_b;
+  }
+  b->h_streams = hs;
+  hipStream_t st = ctx->stream;
+#define BT_UP(dst, vec) BT_HIP(b, hipMemcpyAsync(dst, vec.data(), sizeof(vec[0]) * vec.size(), hipMemcpyHostToDevice, st))
+  BT_UP(b->d_streams, hs); BT_UP(b->det_t, det); BT_UP(b->pred_t, pred); BT_UP(b->box_t, box); BT_UP(b->init_t, init); BT_UP(b->upd_t, upd);
+  BT_UP(b->box2_t, box2); BT_UP(b->lap1_t, lap1); BT_UP(b->lap23_t, lap23); BT_UP(b->dup_t, dup);
+#undef BT_UP
+  BT_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), st));
+  BT_HIP(b, hipStreamSynchronize(st));
+  *out = b;
+  return MOT_OK;
+}
+
+int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float* out, int* out_counts, int cap_out) {
+  hipStream_t st = b->ctx->stream;
+  const int S = b->S, CAP = b->CAP, D = b->D;
+  if (cap_out > b->out_cap) {
+    b->d_out = b->dalloc<float>(static_cast<size_t>(S) * cap_out * 8);
+    b->d_out_counts = b->d_out_counts ? b->d_out_counts : b->dalloc<int>(S);
+    if (!b->d_out || !b->d_out_counts) return MOT_ERR_NOMEM;
+    b->out_cap = cap_out;
+  }
+  BT_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  const bool prof = b->profile;
+  if (prof) BT_HIP(b, hipEventRecord(b->ev[0], st));
+  hipLaunchKernelGGL(bt_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, b->d_stats);
+  BT_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, D, st));
+  BT_HIP(b, mot::launch_kf_op(1, MOT_KF_XYAH, b->pred_t, S, CAP, st));
+  if (prof) BT_HIP(b, hipEventRecord(b->ev[1], st));
+  BT_HIP(b, mot::launch_lap(b->lap1_t, S, CAP, D, true, false, st));
+  if (prof) BT_HIP(b, hipEventRecord(b->ev[2], st));
+  hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, b->d_stats);
+  BT_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, CAP, st));
+  if (prof) BT_HIP(b, hipEventRecord(b->ev[3], st));
+  BT_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, CAP, D, true, false, st));
+  if (prof) BT_HIP(b, hipEventRecord(b->ev[4], st));
+  hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t);
+  BT_HIP(b, mot::launch_kf_op(0, MOT_KF_XYAH, b->init_t, S, D, st));
+  BT_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, CAP, st));
+  BT_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, CAP, st));
+  BT_HIP(b, mot::launch_iou(b->dup_t, S, CAP, CAP, true, st));
+  hipLaunchKernelGGL(bt_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out);
+  hipLaunchKernelGGL(bt_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
+  if (prof) BT_HIP(b, hipEventRecord(b->ev[5], st));
+  BT_HIP(b, hipGetLastError());
+  int err = 0;
+  BT_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
+  BT_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  BT_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  BT_HIP(b, hipStreamSynchronize(st));
+  if (prof) {
+    float ms = 0.f;
+    BT_HIP(b, hipEventElapsedTime(&ms, b->ev[1], b->ev[2])); b->lap_ms[0] += ms;
+    BT_HIP(b, hipEventElapsedTime(&ms, b->ev[3], b->ev[4])); b->lap_ms[1] += ms;
+    BT_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[5])); b->frame_ms += ms;
+    b->frames += 1;
+  }
+  if (err) { b->ctx->err = "mot_bt_step: a stream exceeded cap_tracks / max_dets / cap_out"; return MOT_ERR_CAPACITY; }
+  return MOT_OK;
+}
+
+int mot_bt_profile(mot_bt_batch* b, int enable) {
+  b->profile = enable != 0;
+  if (enable) {
+    b->lap_ms[0] = b->lap_ms[1] = b->frame_ms = 0.0;
+    b->frames = 0;
+    BT_HIP(b, hipMemsetAsync(b->d_stats, 0, 4 * sizeof(unsigned long long), b->ctx->stream));
+    BT_HIP(b, hipStreamSynchronize(b->ctx->stream));
+  }
+  return MOT_OK;
+}
+
+int mot_bt_profile_stats(mot_bt_batch* b, double* out8) {
+  unsigned long long h[4] = {0, 0, 0, 0};
+  BT_HIP(b, hipMemcpy(h, b->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+  out8[0] = b->lap_ms[0]; out8[1] = b->lap_ms[1]; out8[2] = b->frame_ms; out8[3] = static_cast<double>(b->frames);
+  out8[4] = static_cast<double>(h[0]); out8[5] = static_cast<double>(h[1]); out8[6] = static_cast<double>(h[2]); out8[7] = static_cast<double>(h[3]);
+  return MOT_OK;
+}
+
+int mot_bt_dump(mot_bt_batch* b, int s, int* ids, float* mean, float* cov, int cap) {
+  hipStream_t st = b->ctx->stream;
+  BtStream h;
+  BT_HIP(b, hipMemcpyAsync(&h, b->d_streams + s, sizeof(BtStream), hipMemcpyDeviceToHost, st));
+  BT_HIP(b, hipStreamSynchronize(st));
+  const int n = h.n_active + h.n_lost;
+  if (n > cap) return -n;
+  std::vector<int> slots(n), tid(b->CAP);
+  if (h.n_active) BT_HIP(b, hipMemcpyAsync(slots.data(), h.active[h.cur], sizeof(int) * h.n_active, hipMemcpyDeviceToHost, st));
+  if (h.n_lost) BT_HIP(b, hipMemcpyAsync(slots.data() + h.n_active, h.lost[h.cur], sizeof(int) * h.n_lost, hipMemcpyDeviceToHost, st));
+  BT_HIP(b, hipMemcpyAsync(tid.data(), h.t_id, sizeof(int) * b->CAP, hipMemcpyDeviceToHost, st));
+  const int C2 = 2 * b->CAP;
+  std::vector<float> m(static_cast<size_t>(8) * C2), c(static_cast<size_t>(64) * C2);
+  BT_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 8 * C2, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
+  BT_HIP(b, hipMemcpyAsync(c.data(), b->cov + static_cast<size_t>(s) * 64 * C2, sizeof(float) * c.size(), hipMemcpyDeviceToHost, st));
+  BT_HIP(b, hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) {
+    const int sl = slots[i];
+    ids[i] = tid[sl];
+    for (int k = 0; k < 8; ++k) mean[static_cast<size_t>(i) * 8 + k] = m[static_cast<size_t>(k) * C2 + sl];
+    for (int k = 0; k < 64; ++k) cov[static_cast<size_t>(i) * 64 + k] = c[static_cast<size_t>(k) * C2 + sl];
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -22,13 +22,7 @@ hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, hipStream_
 size_t lap_scratch_bytes(int n, int m);
 }  // namespace mot
 
-struct mot_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  std::string err;
-};
+#include "ctx.hpp"
 
 namespace {
 int fail(mot_ctx* c, hipError_t e, const char* what) {

@@ -114,6 +114,14 @@ __global__ void __launch_bounds__(kThreads) iou_kernel(const mot_iou_task* __res
           if (k < T.pairs_cap) { T.pairs[2 * k] = gr; T.pairs[2 * k + 1] = gc + q; }
         }
     }
+    if (T.dup_a) {  // idempotent byte stores: no counter, no overflow
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (tx * 4 + q < ncol && out[q] < T.pair_thresh) {
+          if (T.age_a[gr] > T.age_b[gc + q]) T.dup_b[gc + q] = 1;
+          else T.dup_a[gr] = 1;
+        }
+    }
   }
 }
 

@@ -1,0 +1,94 @@
+"""ByteTrack with the lifecycle on the device (mot_bt_*, motcpp_amd/csrc/bt_device.hip) against the CPU oracle: output
+tables, track ids and the Kalman state of every live track, bit for bit, on seeded streams with ragged and empty frames."""
+import numpy as np
+import pytest
+
+from motcpp_amd import _lib as L
+from motcpp_amd.synth import SynthStream
+from tests import orclib
+
+pytestmark = pytest.mark.gpu
+
+
+def run(shapes, frames, cap, maxd, params=None, check_states_every=7):
+    orc = orclib.load()
+    S = len(shapes)
+    dev = L.DeviceByteTrack(S, cap, maxd, params)
+    streams = [SynthStream(P, M, 1234 + i) for i, (P, M) in enumerate(shapes)]
+    oracles = [orc.tracker(orclib.BYTETRACK, params + [30, 50] if params else None) for _ in range(S)]
+    rows = 0
+    for f in range(frames):
+        dets = np.zeros((S, maxd, 6), np.float32)
+        cnt = np.zeros(S, np.int32)
+        per = []
+        for s, st in enumerate(streams):
+            d, _ = st.next_frame()
+            if (f + s) % 13 == 11:
+                d = d[:0]  # an empty frame now and then
+            per.append(d)
+            cnt[s] = len(d)
+            dets[s, :len(d)] = d
+        out, oc = dev.step(dets, cnt)
+        for s in range(S):
+            oo = oracles[s].update(per[s])
+            assert oc[s] == oo.shape[0], (f, s, oc[s], oo.shape)
+            assert np.array_equal(out[s, :oc[s]], oo), (f, s)
+            rows += oo.shape[0]
+            if f % check_states_every == check_states_every - 1:
+                ids, mean, cov = dev.dump(s)
+                so = oracles[s].dump_states()
+                assert len(ids) == so.shape[0], (f, s)
+                if len(ids):
+                    assert np.array_equal(ids, so[:, 0].astype(np.int32)), (f, s)
+                    assert np.array_equal(mean, so[:, 1:9]), (f, s)
+                    assert np.array_equal(cov.reshape(len(ids), -1), so[:, 9:73]), (f, s)
+    assert rows > 0
+    dev.close()
+
+
+def test_small_streams():
+    run([(24, 12), (40, 30), (8, 8), (64, 40), (1, 1), (90, 64)], 60, cap=256, maxd=64)
+
+
+def test_c2_shape():
+    run([(256, 128), (256, 128), (200, 100)], 45, cap=512, maxd=128)
+
+
+def test_custom_thresholds():
+    run([(64, 40), (64, 48)], 40, cap=256, maxd=64, params=[0.2, 0.6, 0.7, 10, 30])
+
+
+def test_capacity_error_is_reported():
+    dev = L.DeviceByteTrack(1, 16, 64)
+    st = SynthStream(64, 40, 3)
+    with pytest.raises(L.MotError):
+        for _ in range(5):
+            d, _ = st.next_frame()
+            dets = np.zeros((1, 64, 6), np.float32)
+            dets[0, :len(d)] = d
+            dev.step(dets, np.array([len(d)], np.int32))
+    dev.close()
+
+
+def test_north_star_shape():
+    run([(1000, 500), (1000, 500)], 24, cap=2048, maxd=512, check_states_every=8)
+
+
+def test_reset_restarts_ids():
+    orc = orclib.load()
+    dev = L.DeviceByteTrack(2, 128, 32)
+    for rep in range(2):
+        streams = [SynthStream(20, 12, 77 + i) for i in range(2)]
+        oracles = [orc.tracker(orclib.BYTETRACK) for _ in range(2)]
+        for f in range(12):
+            dets = np.zeros((2, 32, 6), np.float32)
+            cnt = np.zeros(2, np.int32)
+            per = []
+            for s, st in enumerate(streams):
+                d, _ = st.next_frame()
+                per.append(d); cnt[s] = len(d); dets[s, :len(d)] = d
+            out, oc = dev.step(dets, cnt)
+            for s in range(2):
+                assert np.array_equal(out[s, :oc[s]], oracles[s].update(per[s])), (rep, f, s)
+        dev.reset()
+    dev.close()

@@ -134,8 +134,12 @@ def main():
                            private_device=PIPE > 1) for p in range(PIPE)]
     cap = max(2 * M, 64)
     gathered = None
-    out_all = np.zeros((S, cap, 8), np.float32)
-    cnt_all = np.zeros(S, np.int32)
+    if on_device:  # page-locked, so that the one result copy of a frame runs at PCIe speed
+        out_all = torch.zeros((S, cap, 8), dtype=torch.float32).pin_memory().numpy()
+        cnt_all = torch.zeros((S,), dtype=torch.int32).pin_memory().numpy()
+    else:
+        out_all = np.zeros((S, cap, 8), np.float32)
+        cnt_all = np.zeros(S, np.int32)
     from concurrent.futures import ThreadPoolExecutor
     # one dedicated driver thread per sub-batch: its worker team (and the CPUs that team is pinned to) never changes
     pools = [ThreadPoolExecutor(1) for _ in range(PIPE)] if PIPE > 1 else None
@@ -150,8 +154,10 @@ def main():
 
     def sub_step(p, f):
         s0, s1 = bounds[p], bounds[p + 1]
-        if on_device:
-            o, c = batches[p].step(resident_ptr=dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4, counts=full_counts[p], cap=cap)
+        if on_device:  # tables land directly in this sub-batch's slice of the rank's output
+            batches[p].step(resident_ptr=dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4, counts=full_counts[p],
+                            out=out_all[s0:s1], out_counts=cnt_all[s0:s1])
+            return
         else:
             o, c = batches[p].step(host[f, s0:s1], embs=embs[f, s0:s1] if D else None, cap=cap,
                                    resident_ptr=dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4)

@@ -366,6 +366,18 @@ def profile_stats(device=0):
             for i in range(len(FAMILIES))}
 
 
+def pinned_array(ctx, shape, dtype):
+    """numpy array over page-locked host memory (mot_host_alloc): device -> host copies into it run at PCIe speed and
+    asynchronously; pageable memory goes through a staging buffer at a fraction of that. Freed with the context's process."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = C.c_void_p()
+    ctx._chk(ctx.lib.mot_host_alloc(ctx.h, C.c_size_t(max(n, 16)), C.byref(ptr)))
+    buf = (C.c_char * max(n, 16)).from_address(ptr.value)
+    a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    a[...] = 0
+    return a
+
+
 class DeviceByteTrack:
     """S ByteTrack streams whose whole per-frame lifecycle runs on the GPU (mot_bt_*, csrc/bt_device.hip): the host
     enqueues a fixed launch sequence per frame. params = [min_conf, track_thresh, match_thresh, track_buffer, frame_rate]."""
@@ -381,7 +393,7 @@ class DeviceByteTrack:
         self.ctx._chk(self.lib.mot_malloc(self.ctx.h, C.c_size_t(self.S * 6 * self.D * 4), C.byref(self._ddets)))
         self._soa = np.zeros((self.S, 6, self.D), np.float32)
         self._out = None
-        self._cnt = np.zeros(self.S, np.int32)
+        self._cnt = pinned_array(self.ctx, (self.S,), np.int32)
         self.lib.mot_bt_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         self.lib.mot_bt_dump.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         self.lib.mot_bt_profile.argtypes = [C.c_void_p, C.c_int]
@@ -389,8 +401,9 @@ class DeviceByteTrack:
         self.lib.mot_bt_reset.argtypes = [C.c_void_p]
         self.lib.mot_bt_destroy.argtypes = [C.c_void_p]
 
-    def step(self, dets=None, counts=None, cap=None, resident_ptr=None):
-        """dets [S, N, 6] host rows (uploaded as SoA), or resident_ptr = device SoA [S][6][max_dets] + counts."""
+    def step(self, dets=None, counts=None, cap=None, resident_ptr=None, out=None, out_counts=None):
+        """dets [S, N, 6] host rows (uploaded as SoA), or resident_ptr = device SoA [S][6][max_dets] + counts.
+        out [S, cap, 8] / out_counts [S] (C-contiguous float32 / int32): write the tables there instead of an internal buffer."""
         if resident_ptr is None:
             dets = f32(dets)
             n = dets.shape[1]
@@ -402,9 +415,14 @@ class DeviceByteTrack:
         else:
             counts = np.ascontiguousarray(counts, np.int32)
             ptr = C.c_void_p(int(resident_ptr))
+        if out is not None:
+            assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.shape[0] == self.S and out.shape[2] == 8
+            assert out_counts is not None and out_counts.dtype == np.int32 and out_counts.flags["C_CONTIGUOUS"]
+            self.ctx._chk(self.lib.mot_bt_step(self.h, ptr, _p(counts), _p(out), _p(out_counts), int(out.shape[1])))
+            return out, out_counts
         cap = int(cap or max(2 * self.D, 64))
         if self._out is None or self._out.shape[1] != cap:
-            self._out = np.zeros((self.S, cap, 8), np.float32)
+            self._out = pinned_array(self.ctx, (self.S, cap, 8), np.float32)
         self.ctx._chk(self.lib.mot_bt_step(self.h, ptr, _p(counts), _p(self._out), _p(self._cnt), cap))
         return self._out, self._cnt
 

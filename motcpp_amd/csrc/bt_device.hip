@@ -20,6 +20,7 @@
 #include "../../include/motcpp_amd.h"
 
 #include "ctx.hpp"
+#include "cost_math.hpp"
 
 namespace mot {
 hipError_t launch_kf_op(int op, int kind, const mot_kf_task*, int, int, hipStream_t);
@@ -65,6 +66,7 @@ struct BtStream {
   int* lost_new; int n_lost_new;
   int *age_a, *age_b; unsigned char *dup_a, *dup_b;
   float* abox;  // [4][CAP] boxes of the new active list (output rows)
+  float* lbox;  // [4][CAP] boxes of the new lost list (duplicate test)
 };
 
 constexpr int kW = 64;  // one wavefront per stream
@@ -375,6 +377,27 @@ __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParam
   }
 }
 
+// ---- duplicate marking (remove_duplicate_stracks :659-706): iou_distance(active, lost) < 0.15 -> the younger one goes.
+// Same pair arithmetic as the N x M cost kernel (cost_math.hpp), one workgroup per stream over its own na x nl pairs
+// (a launch of the tiled cost kernel over the capacity bound spends 0.5 ms on tiles that exit at once).
+__global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP) {
+  BtStream& S = streams[blockIdx.x];
+  const int na = S.n_active, nl = S.n_lost;
+  if (na <= 0 || nl <= 0) return;
+  const int total = na * nl;
+  for (int p = threadIdx.x; p < total; p += 256) {
+    const int i = p / nl, j = p - i * nl;
+    float a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = S.abox[static_cast<size_t>(k) * CAP + i]; b[k] = S.lbox[static_cast<size_t>(k) * CAP + j]; }
+    const float iou = mot::iou_pair(a, (a[2] - a[0]) * (a[3] - a[1]), b, (b[2] - b[0]) * (b[3] - b[1]));
+    if (1.0f - iou < 0.15f) {
+      if (S.age_a[i] > S.age_b[j]) S.dup_b[j] = 1;
+      else S.dup_a[i] = 1;
+    }
+  }
+}
+
 // ---- K3: duplicate removal and the output table (:582-621, :659-706) ----
 __global__ void __launch_bounds__(kW) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out) {
   BtStream& S = streams[blockIdx.x];
@@ -549,6 +572,7 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
     auto F = [&](int n) { float* r = f; f += n; return r; };
     T.t_conf = F(CAP);
     float* pool_box = F(4 * CAP); float* rbox = F(4 * CAP); float* ubox = F(4 * CAP); T.abox = F(4 * CAP); float* lbox = F(4 * CAP);
+    T.lbox = lbox;
     float* d_box = F(4 * D); float* d_meas = F(4 * D);
     unsigned char* u = bp + static_cast<size_t>(CAP) * 3 * s;
     T.pred_flags = u; T.dup_a = u + CAP; T.dup_b = u + 2 * CAP;
@@ -624,7 +648,7 @@ int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float
   BT_HIP(b, mot::launch_kf_op(0, MOT_KF_XYAH, b->init_t, S, D, st));
   BT_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, CAP, st));
   BT_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, CAP, st));
-  BT_HIP(b, mot::launch_iou(b->dup_t, S, CAP, CAP, true, st));
+  hipLaunchKernelGGL(bt_dups, dim3(S), dim3(256), 0, st, b->d_streams, CAP);
   hipLaunchKernelGGL(bt_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out);
   hipLaunchKernelGGL(bt_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
   if (prof) BT_HIP(b, hipEventRecord(b->ev[5], st));

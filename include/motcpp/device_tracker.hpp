@@ -49,4 +49,27 @@ class StreamBatch {
   std::vector<DeviceTracker*> trackers_;
 };
 
+// S independent ByteTrack streams whose whole update() runs on the GPU (C ABI: mot_bt_*, motcpp_amd/csrc/bt_device.hip):
+// per frame the host enqueues a fixed sequence of launches and copies the output tables back — no per-stream host work.
+// Same semantics per stream as trackers::ByteTrack(…).update(dets, img) with the default BaseTracker arguments; ids are
+// per stream. cap_tracks bounds tracked + lost tracks of a stream, max_dets the detections of a frame (std::runtime_error
+// when a stream exceeds them).
+class ByteTrackDeviceBatch {
+ public:
+  ByteTrackDeviceBatch(int nstreams, int cap_tracks, int max_dets, float min_conf = 0.1f, float track_thresh = 0.45f,
+                       float match_thresh = 0.8f, int track_buffer = 25, int frame_rate = 30, int device_index = 0);
+  ~ByteTrackDeviceBatch();
+  ByteTrackDeviceBatch(const ByteTrackDeviceBatch&) = delete;
+  ByteTrackDeviceBatch& operator=(const ByteTrackDeviceBatch&) = delete;
+  // dets[s]: N_s x 6 column-major [x1,y1,x2,y2,conf,cls]; returns per-stream M_s x 8 tables [x1,y1,x2,y2,id,conf,cls,det_ind]
+  std::vector<Eigen::MatrixXf> update(const std::vector<Eigen::MatrixXf>& dets);
+  void reset();
+  size_t size() const { return static_cast<size_t>(n_); }
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+  int n_, cap_, maxd_;
+};
+
 }  // namespace motcpp

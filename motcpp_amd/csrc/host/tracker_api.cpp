@@ -1,6 +1,7 @@
 // BaseTracker / DeviceTracker / StreamBatch and the four public tracker classes (constructor signatures of
 // the reference's include/motcpp/trackers/*.hpp), plus the frame driver that steps stage machines in lockstep.
 #include <chrono>
+#include <cstring>
 #include <algorithm>
 #include <functional>
 #include <mutex>
@@ -207,6 +208,66 @@ BotSort::BotSort(const std::string& reid_weights, bool /*use_half*/, bool /*use_
                          proximity_thresh, appearance_thresh, frame_rate, fuse_first_associate, with_reid, max_age_, max_obs_));
 }
 }  // namespace trackers
+
+// ---- ByteTrackDeviceBatch ----------------------------------------------------------------------
+struct ByteTrackDeviceBatch::Impl {
+  std::shared_ptr<rt::Device> dev;
+  mot_bt_batch* bt = nullptr;
+  void* d_dets = nullptr;
+  std::vector<float> soa, out;
+  std::vector<int> counts, out_counts;
+};
+ByteTrackDeviceBatch::ByteTrackDeviceBatch(int nstreams, int cap_tracks, int max_dets, float min_conf, float track_thresh,
+                                           float match_thresh, int track_buffer, int frame_rate, int device_index)
+    : impl_(std::make_unique<Impl>()), n_(nstreams), cap_(cap_tracks), maxd_(max_dets) {
+  impl_->dev = rt::Device::shared(device_index);
+  const float p[5] = {min_conf, track_thresh, match_thresh, static_cast<float>(track_buffer), static_cast<float>(frame_rate)};
+  if (mot_bt_create(impl_->dev->ctx, nstreams, cap_tracks, max_dets, p, &impl_->bt) != MOT_OK)
+    throw std::runtime_error(std::string("motcpp_amd: mot_bt_create failed: ") + mot_ctx_last_error(impl_->dev->ctx));
+  impl_->soa.assign(static_cast<size_t>(nstreams) * 6 * max_dets, 0.f);
+  impl_->counts.assign(nstreams, 0);
+  impl_->out_counts.assign(nstreams, 0);
+  if (mot_malloc(impl_->dev->ctx, impl_->soa.size() * sizeof(float), &impl_->d_dets) != MOT_OK)
+    throw std::runtime_error("motcpp_amd: device allocation failed");
+}
+ByteTrackDeviceBatch::~ByteTrackDeviceBatch() {
+  if (impl_->bt) mot_bt_destroy(impl_->bt);
+  if (impl_->d_dets) mot_free(impl_->dev->ctx, impl_->d_dets);
+}
+void ByteTrackDeviceBatch::reset() {
+  if (mot_bt_reset(impl_->bt) != MOT_OK) throw std::runtime_error(mot_ctx_last_error(impl_->dev->ctx));
+}
+std::vector<Eigen::MatrixXf> ByteTrackDeviceBatch::update(const std::vector<Eigen::MatrixXf>& dets) {
+  if (static_cast<int>(dets.size()) != n_) throw std::invalid_argument("ByteTrackDeviceBatch: one detection matrix per stream");
+  Impl& I = *impl_;
+  for (int s = 0; s < n_; ++s) {
+    const Eigen::MatrixXf& d = dets[s];
+    const int n = static_cast<int>(d.rows());
+    if (n > 0 && d.cols() != 6) throw std::invalid_argument("ByteTrackDeviceBatch: detections must be N x 6");
+    if (n > maxd_) throw std::invalid_argument("ByteTrackDeviceBatch: more detections than max_dets");
+    I.counts[s] = n;
+    float* dst = I.soa.data() + static_cast<size_t>(s) * 6 * maxd_;
+    for (int k = 0; k < 6; ++k)  // a column-major N x 6 matrix IS the SoA layout
+      if (n > 0) std::memcpy(dst + static_cast<size_t>(k) * maxd_, d.data() + static_cast<size_t>(k) * n, sizeof(float) * n);
+  }
+  mot_ctx* ctx = I.dev->ctx;
+  if (mot_memcpy_h2d(ctx, I.d_dets, I.soa.data(), I.soa.size() * sizeof(float)) != MOT_OK) throw std::runtime_error(mot_ctx_last_error(ctx));
+  const int cap_out = cap_;  // a stream never reports more rows than it has tracks
+  I.out.resize(static_cast<size_t>(n_) * cap_out * 8);
+  const int rc = mot_bt_step(I.bt, static_cast<const float*>(I.d_dets), I.counts.data(), I.out.data(), I.out_counts.data(), cap_out);
+  if (rc != MOT_OK) throw std::runtime_error(std::string("motcpp_amd: mot_bt_step failed: ") + mot_ctx_last_error(ctx));
+  std::vector<Eigen::MatrixXf> res;
+  res.reserve(n_);
+  for (int s = 0; s < n_; ++s) {
+    const int m = I.out_counts[s];
+    Eigen::MatrixXf t(m, 8);
+    const float* rows = I.out.data() + static_cast<size_t>(s) * cap_out * 8;
+    for (int i = 0; i < m; ++i)
+      for (int k = 0; k < 8; ++k) t(i, k) = rows[static_cast<size_t>(i) * 8 + k];
+    res.push_back(std::move(t));
+  }
+  return res;
+}
 
 // ---- utils:: primitive seam ----------------------------------------------------------------------
 namespace utils {

@@ -91,6 +91,24 @@ int main() {
     Sort s;  // SORT never calls check_inputs (sort.cpp:102-110)
     CHECK(s.update(single, cv::Mat()).cols() == 8);
   }
+  {  // the device-lifecycle batch gives each stream exactly what a ByteTrack instance gives it
+    motcpp::ByteTrackDeviceBatch batch(2, 64, 16);
+    ByteTrack a, b;
+    for (int f = 0; f < 6; ++f) {
+      Eigen::MatrixXf da = multi, db = single;
+      for (int i = 0; i < da.rows(); ++i) { da(i, 0) += 2.f * f; da(i, 2) += 2.f * f; }
+      auto out = batch.update({da, db});
+      Eigen::MatrixXf ra = a.update(da, img), rb = b.update(db, img);
+      CHECK(out.size() == 2 && out[0].rows() == ra.rows() && out[1].rows() == rb.rows());
+      for (int i = 0; i < ra.rows(); ++i)
+        for (int k = 0; k < 8; ++k) CHECK(out[0](i, k) == ra(i, k));
+      for (int i = 0; i < rb.rows(); ++i)
+        for (int k = 0; k < 8; ++k) CHECK(out[1](i, k) == rb(i, k));
+    }
+    bool threw = false;
+    try { batch.update({multi}); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+  }
   {  // asso_func: stored by every tracker, read only by OC-SORT, at update time (ocsort.cpp:413; iou.hpp:385-408)
     ByteTrack bt(0.3f, 30, 50, 3, 0.3f, false, 80, "no-such-measure");
     CHECK(bt.update(multi, img).cols() == 8);

@@ -142,7 +142,10 @@ __global__ void __launch_bounds__(kW) bt_begin(BtStream* streams, BtParams P, in
     L.n = q ? np : 0; L.m = q ? nh : 0;
     L.geom.n = L.n; L.geom.m = L.m;
     L.geom.bconf = conf;  // score fusion reads the frame's confidences (:300-312)
-    if (q) { atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], static_cast<unsigned long long>(np + nh)); }
+    if (stats && q) {  // 64 counter sets, so that thousands of streams do not serialise on one address
+      unsigned long long* st = stats + (blockIdx.x & 63) * 4;
+      atomicAdd(&st[0], 1ull); atomicAdd(&st[1], static_cast<unsigned long long>(np + nh));
+    }
   }
 }
 
@@ -211,8 +214,11 @@ __global__ void __launch_bounds__(kW) bt_after_first(BtStream* streams, BtParams
     mot_lap_task& B = lap23_t[2 * blockIdx.x + 1];
     B.n = q3 ? S.n_unconf : 0; B.m = q3 ? n_ud : 0; B.geom.n = B.n; B.geom.m = B.m;
     B.geom.bconf = S.dets + static_cast<size_t>(4) * S.ld;
-    if (q2) { atomicAdd(&stats[2], 1ull); atomicAdd(&stats[3], static_cast<unsigned long long>(A.n + A.m)); }
-    if (q3) { atomicAdd(&stats[2], 1ull); atomicAdd(&stats[3], static_cast<unsigned long long>(B.n + B.m)); }
+    if (stats) {
+      unsigned long long* st = stats + (blockIdx.x & 63) * 4;
+      const int cnt = (q2 ? 1 : 0) + (q3 ? 1 : 0);
+      if (cnt) { atomicAdd(&st[2], static_cast<unsigned long long>(cnt)); atomicAdd(&st[3], static_cast<unsigned long long>(A.n + A.m + B.n + B.m)); }
+    }
   }
 }
 
@@ -536,8 +542,8 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   b->d_streams = b->dalloc<BtStream>(S);
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
-  b->d_stats = b->dalloc<unsigned long long>(4);
-  if (b->d_stats) (void)hipMemset(b->d_stats, 0, 4 * sizeof(unsigned long long));
+  b->d_stats = b->dalloc<unsigned long long>(4 * 64);
+  if (b->d_stats) (void)hipMemset(b->d_stats, 0, 4 * 64 * sizeof(unsigned long long));
   for (auto& e : b->ev) (void)hipEventCreate(&e);
   b->det_t = b->dalloc<mot_det_task>(S);
   b->pred_t = b->dalloc<mot_kf_task>(S); b->box_t = b->dalloc<mot_kf_task>(2 * S); b->init_t = b->dalloc<mot_kf_task>(S);
@@ -633,13 +639,13 @@ int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float
   BT_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
   const bool prof = b->profile;
   if (prof) BT_HIP(b, hipEventRecord(b->ev[0], st));
-  hipLaunchKernelGGL(bt_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, b->d_stats);
+  hipLaunchKernelGGL(bt_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr);
   BT_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, D, st));
   BT_HIP(b, mot::launch_kf_op(1, MOT_KF_XYAH, b->pred_t, S, CAP, st));
   if (prof) BT_HIP(b, hipEventRecord(b->ev[1], st));
   BT_HIP(b, mot::launch_lap(b->lap1_t, S, CAP, D, true, false, st));
   if (prof) BT_HIP(b, hipEventRecord(b->ev[2], st));
-  hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, b->d_stats);
+  hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr);
   BT_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, CAP, st));
   if (prof) BT_HIP(b, hipEventRecord(b->ev[3], st));
   BT_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, CAP, D, true, false, st));
@@ -674,15 +680,18 @@ int mot_bt_profile(mot_bt_batch* b, int enable) {
   if (enable) {
     b->lap_ms[0] = b->lap_ms[1] = b->frame_ms = 0.0;
     b->frames = 0;
-    BT_HIP(b, hipMemsetAsync(b->d_stats, 0, 4 * sizeof(unsigned long long), b->ctx->stream));
+    BT_HIP(b, hipMemsetAsync(b->d_stats, 0, 4 * 64 * sizeof(unsigned long long), b->ctx->stream));
     BT_HIP(b, hipStreamSynchronize(b->ctx->stream));
   }
   return MOT_OK;
 }
 
 int mot_bt_profile_stats(mot_bt_batch* b, double* out8) {
+  unsigned long long raw[4 * 64];
+  BT_HIP(b, hipMemcpy(raw, b->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
   unsigned long long h[4] = {0, 0, 0, 0};
-  BT_HIP(b, hipMemcpy(h, b->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 64; ++i)
+    for (int k = 0; k < 4; ++k) h[k] += raw[i * 4 + k];
   out8[0] = b->lap_ms[0]; out8[1] = b->lap_ms[1]; out8[2] = b->frame_ms; out8[3] = static_cast<double>(b->frames);
   out8[4] = static_cast<double>(h[0]); out8[5] = static_cast<double>(h[1]); out8[6] = static_cast<double>(h[2]); out8[7] = static_cast<double>(h[3]);
   return MOT_OK;

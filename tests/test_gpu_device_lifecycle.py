@@ -92,3 +92,28 @@ def test_reset_restarts_ids():
                 assert np.array_equal(out[s, :oc[s]], oracles[s].update(per[s])), (rep, f, s)
         dev.reset()
     dev.close()
+
+
+def test_long_run_recycles_slots_and_ages_out_lost_tracks():
+    # 350 frames: lost tracks age out after track_buffer frames, their slots are reused by later births, ids keep growing
+    run([(30, 18), (12, 12), (50, 20)], 350, cap=128, maxd=32, check_states_every=50)
+
+
+def test_all_streams_empty_then_busy():
+    orc = orclib.load()
+    dev = L.DeviceByteTrack(3, 64, 16)
+    oracles = [orc.tracker(orclib.BYTETRACK) for _ in range(3)]
+    st = [SynthStream(10, 8, 500 + i) for i in range(3)]
+    for f in range(20):
+        dets = np.zeros((3, 16, 6), np.float32)
+        cnt = np.zeros(3, np.int32)
+        per = []
+        for s in range(3):
+            d, _ = st[s].next_frame()
+            if f < 5 or s == 1:  # the first frames have no detections at all; stream 1 never has any
+                d = d[:0]
+            per.append(d); cnt[s] = len(d); dets[s, :len(d)] = d
+        out, oc = dev.step(dets, cnt)
+        for s in range(3):
+            assert np.array_equal(out[s, :oc[s]], oracles[s].update(per[s])), (f, s)
+    dev.close()

@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP) {
 }
 
 // ---- K3: duplicate removal and the output table (:582-621, :659-706) ----
-__global__ void __launch_bounds__(kW) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out) {
+__global__ void __launch_bounds__(kW) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks) {
   BtStream& S = streams[blockIdx.x];
   const int t = lane_id();
   int* act = S.active[S.cur];
@@ -458,6 +458,8 @@ __global__ void __launch_bounds__(kW) bt_finish(BtStream* streams, int CAP, floa
     S.n_active = n_keep; S.n_lost = n_keep_l; S.n_free = free_top;
     if (n_rows > cap_out) S.err = 2;
     out_counts[blockIdx.x] = (n_rows <= cap_out) ? n_rows : -n_rows;
+    // tracks alive after this frame: an exact upper bound of every problem side of the next frame (64 slots: no hot address)
+    atomicMax(&max_tracks[blockIdx.x & 63], n_keep + n_keep_l);
   }
 }
 
@@ -478,6 +480,8 @@ struct mot_bt_batch {
   std::vector<BtStream> h_streams;  // host mirror of the pointers (scalars are only valid on the device)
   int* d_counts = nullptr;
   int* d_err = nullptr;
+  int* d_maxt = nullptr;  // [64] per-frame maxima of tracks alive (bt_finish)
+  int bound_n = 0;        // upper bound of tracked + lost per stream for the NEXT frame (0 right after creation / reset)
   float* d_out = nullptr; int* d_out_counts = nullptr; int out_cap = 0;
   mot_det_task* det_t = nullptr;
   mot_kf_task *pred_t = nullptr, *box_t = nullptr, *init_t = nullptr, *upd_t = nullptr, *box2_t = nullptr;
@@ -520,6 +524,7 @@ int mot_bt_reset(mot_bt_batch* b) {
   BT_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(BtStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
   BT_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
   BT_HIP(b, hipStreamSynchronize(b->ctx->stream));
+  b->bound_n = 0;
   return MOT_OK;
 }
 
@@ -542,6 +547,7 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   b->d_streams = b->dalloc<BtStream>(S);
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
+  b->d_maxt = b->dalloc<int>(64);
   b->d_stats = b->dalloc<unsigned long long>(4 * 64);
   if (b->d_stats) (void)hipMemset(b->d_stats, 0, 4 * 64 * sizeof(unsigned long long));
   for (auto& e : b->ev) (void)hipEventCreate(&e);
@@ -637,25 +643,33 @@ int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float
     b->out_cap = cap_out;
   }
   BT_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  BT_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
+  // Launch bounds (grid sizes, the solver's LDS layout and variant) from exact upper bounds instead of the capacities:
+  // no side of any problem of this frame exceeds the tracks alive after the previous frame (bn) / this frame's detections (bd)
+  int bd = 1;
+  for (int s = 0; s < S; ++s) bd = (h_counts[s] > bd) ? h_counts[s] : bd;
+  if (bd > D) bd = D;
+  const int bn = (b->bound_n < 1) ? 1 : (b->bound_n > CAP ? CAP : b->bound_n);
+  const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;  // lists after this frame's births
   const bool prof = b->profile;
   if (prof) BT_HIP(b, hipEventRecord(b->ev[0], st));
   hipLaunchKernelGGL(bt_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr);
-  BT_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, D, st));
-  BT_HIP(b, mot::launch_kf_op(1, MOT_KF_XYAH, b->pred_t, S, CAP, st));
+  BT_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, bd, st));
+  BT_HIP(b, mot::launch_kf_op(1, MOT_KF_XYAH, b->pred_t, S, bn, st));
   if (prof) BT_HIP(b, hipEventRecord(b->ev[1], st));
-  BT_HIP(b, mot::launch_lap(b->lap1_t, S, CAP, D, true, false, st));
+  BT_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, st));
   if (prof) BT_HIP(b, hipEventRecord(b->ev[2], st));
   hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr);
-  BT_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, CAP, st));
+  BT_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, bn, st));
   if (prof) BT_HIP(b, hipEventRecord(b->ev[3], st));
-  BT_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, CAP, D, true, false, st));
+  BT_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, st));
   if (prof) BT_HIP(b, hipEventRecord(b->ev[4], st));
   hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t);
-  BT_HIP(b, mot::launch_kf_op(0, MOT_KF_XYAH, b->init_t, S, D, st));
-  BT_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, CAP, st));
-  BT_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, CAP, st));
+  BT_HIP(b, mot::launch_kf_op(0, MOT_KF_XYAH, b->init_t, S, bd, st));
+  BT_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, bn, st));
+  BT_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, bn2, st));
   hipLaunchKernelGGL(bt_dups, dim3(S), dim3(256), 0, st, b->d_streams, CAP);
-  hipLaunchKernelGGL(bt_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out);
+  hipLaunchKernelGGL(bt_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);
   hipLaunchKernelGGL(bt_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
   if (prof) BT_HIP(b, hipEventRecord(b->ev[5], st));
   BT_HIP(b, hipGetLastError());
@@ -663,7 +677,11 @@ int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float
   BT_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
   BT_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
   BT_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  int maxt[64];
+  BT_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
   BT_HIP(b, hipStreamSynchronize(st));
+  b->bound_n = 0;
+  for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
   if (prof) {
     float ms = 0.f;
     BT_HIP(b, hipEventElapsedTime(&ms, b->ev[1], b->ev[2])); b->lap_ms[0] += ms;

@@ -261,6 +261,16 @@ def main():
                 roof["traffic"] = per_problem * st["tasks"] / launches
         except Exception:
             pass
+    sqf = os.path.join(ROOT, "profiles", "r01e_pmc_sq_lap.json")
+    if fam == "lap" and os.path.exists(sqf):
+        try:  # what actually bounds this kernel: instruction issue of the serial row passes (SQ counters, separate PMC run)
+            sq = json.load(open(sqf)).get(args.workload)
+            if sq:
+                roof["issue"] = {"wave_cycles_issuing_frac": sq["active_frac"], "wave_cycles_waiting_frac": sq["wait_any_frac"],
+                                 "valu_insts_per_problem": sq["per_problem"]["SQ_INSTS_VALU"],
+                                 "salu_insts_per_problem": sq["per_problem"]["SQ_INSTS_SALU"], "source": "profiles/r01e_pmc_sq_lap.json"}
+        except Exception:
+            pass
     kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["launches"],
                    "GB/s": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 2) if v["ms"] > 0 else 0.0}
                for k, v in stats.items() if v["launches"]}

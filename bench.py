@@ -122,12 +122,13 @@ def main():
         args.pipeline = {"C2": 3, "SORT": 3, "NS": 3, "C5": 3, "C3": 3}.get(args.workload, 2)  # measured on MI355X
     PIPE = max(1, min(args.pipeline, S))
     bounds = [S * p // PIPE for p in range(PIPE + 1)]
-    on_device = tracker == "bytetrack" and args.lifecycle in ("auto", "device")
+    on_device = tracker in ("bytetrack", "sort") and args.lifecycle in ("auto", "device")
     if args.lifecycle == "device" and not on_device:
-        raise SystemExit("--lifecycle device exists for the ByteTrack workloads only")
+        raise SystemExit("--lifecycle device exists for the ByteTrack and SORT workloads only")
     if on_device:
         cap_tracks = (2 * P + 63) // 64 * 64  # tracked + lost never get near twice the object count (else mot_bt_step reports it)
-        batches = [L.DeviceByteTrack(bounds[p + 1] - bounds[p], cap_tracks, M, device=local) for p in range(PIPE)]
+        Dev = L.DeviceByteTrack if tracker == "bytetrack" else L.DeviceSort
+        batches = [Dev(bounds[p + 1] - bounds[p], cap_tracks, M, device=local) for p in range(PIPE)]
         full_counts = [np.full(bounds[p + 1] - bounds[p], M, np.int32) for p in range(PIPE)]
     else:
         batches = [L.Batch(tracker, bounds[p + 1] - bounds[p], device=local, threads=max(1, threads // PIPE), record_laps=False,
@@ -213,7 +214,7 @@ def main():
     for b in batches:
         ps = b.profile_stats()
         if on_device:  # the solver's launches are timed on the device stream; "frame" = all 14 launches of a frame
-            ps = {"lap": {"ms": ps["lap1_ms"] + ps["lap23_ms"], "launches": 2 * ps["frames"], "tasks": ps["lap1_problems"] + ps["lap23_problems"],
+            ps = {"lap": {"ms": ps["lap1_ms"] + ps["lap23_ms"], "launches": (2 if tracker == "bytetrack" else 1) * ps["frames"], "tasks": ps["lap1_problems"] + ps["lap23_problems"],
                           "bytes": 24.0 * (ps["lap1_nm"] + ps["lap23_nm"]), "flops": 0.0},
                   "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
                                         "bytes": 0.0, "flops": 0.0}}
@@ -328,7 +329,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "tracker": tracker, "tracks": P, "dets_per_frame": M, "emb_dim": D,
                    "streams_per_gpu": S, "frames_per_step": world * S, "host_threads": PIPE if on_device else threads, "sub_batches": PIPE,
-                   "lifecycle": "device (mot_bt_*: 14 launches per frame, no host decisions)" if on_device else "host stage machines",
+                   "lifecycle": "device (mot_bt_* / mot_sort_*: a fixed launch sequence per frame, no host decisions)" if on_device else "host stage machines",
                    "parallelism": f"{world} GPU(s) x {S} independent streams, lockstep stages",
                    "inputs": "detections resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity,

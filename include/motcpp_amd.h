@@ -237,6 +237,19 @@ int mot_bt_dump(mot_bt_batch* b, int s, int* ids, float* mean, float* cov, int c
 int mot_bt_profile(mot_bt_batch* b, int enable);
 int mot_bt_profile_stats(mot_bt_batch* b, double* out8);
 
+/* ---- SORT with the per-stream lifecycle on the device ----------------------------------- */
+/* Same contract as mot_bt_* for Sort::update (src/trackers/sort.cpp:102-255). params: [det_thresh, max_age, max_obs (unused),
+ * min_hits, iou_threshold]. mot_sort_reset keeps the id counters running (sort.cpp:97-100). mot_sort_dump: mean [cap][7],
+ * cov [cap][49] of the live tracks in list order. */
+typedef struct mot_sort_batch mot_sort_batch;
+int mot_sort_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, const float* params5, mot_sort_batch** out);
+void mot_sort_destroy(mot_sort_batch* b);
+int mot_sort_reset(mot_sort_batch* b);
+int mot_sort_step(mot_sort_batch* b, const float* d_dets, const int* h_counts, float* out, int* out_counts, int cap_out);
+int mot_sort_dump(mot_sort_batch* b, int s, int* ids, float* mean, float* cov, int cap);
+int mot_sort_profile(mot_sort_batch* b, int enable);         /* same layout as mot_bt_profile_stats ([1], [6], [7] = 0) */
+int mot_sort_profile_stats(mot_sort_batch* b, double* out8);
+
 /* ---- host-pointer conveniences (synchronous; row-major matrices) ---------------------- */
 int mot_iou_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_xyxy, int m,
                       const float* bconf_or_null, int mode, float* cost);

@@ -454,3 +454,75 @@ class DeviceByteTrack:
             self.h = None
             self.lib.mot_free(self.ctx.h, self._ddets)
             self.ctx.close()
+
+
+class DeviceSort:
+    """S SORT streams with the whole per-frame lifecycle on the GPU (mot_sort_*, csrc/sort_device.hip).
+    params = [det_thresh, max_age, max_obs, min_hits, iou_threshold]."""
+
+    def __init__(self, nstreams, cap_tracks, max_dets, params=None, device=0):
+        self.ctx = Context(device)
+        self.lib = self.ctx.lib
+        self.S, self.CAP, self.D = int(nstreams), int(cap_tracks), int(max_dets)
+        p = f32(params if params is not None else [0.3, 1, 50, 3, 0.3])
+        self.h = C.c_void_p()
+        self.ctx._chk(self.lib.mot_sort_create(self.ctx.h, self.S, self.CAP, self.D, _p(p), C.byref(self.h)))
+        self._ddets = C.c_void_p()
+        self.ctx._chk(self.lib.mot_malloc(self.ctx.h, C.c_size_t(self.S * 6 * self.D * 4), C.byref(self._ddets)))
+        self._soa = np.zeros((self.S, 6, self.D), np.float32)
+        self._out = None
+        self._cnt = pinned_array(self.ctx, (self.S,), np.int32)
+        self.lib.mot_sort_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.lib.mot_sort_dump.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.lib.mot_sort_reset.argtypes = [C.c_void_p]
+        self.lib.mot_sort_destroy.argtypes = [C.c_void_p]
+
+    def step(self, dets=None, counts=None, cap=None, resident_ptr=None, out=None, out_counts=None):
+        if resident_ptr is None:
+            dets = f32(dets)
+            n = dets.shape[1]
+            assert dets.shape[0] == self.S and n <= self.D
+            counts = np.full(self.S, n, np.int32) if counts is None else np.ascontiguousarray(counts, np.int32)
+            self._soa[:, :, :n] = dets.transpose(0, 2, 1)
+            self.ctx._chk(self.lib.mot_memcpy_h2d(self.ctx.h, self._ddets, _p(self._soa), C.c_size_t(self._soa.nbytes)))
+            ptr = self._ddets
+        else:
+            counts = np.ascontiguousarray(counts, np.int32)
+            ptr = C.c_void_p(int(resident_ptr))
+        if out is not None:
+            self.ctx._chk(self.lib.mot_sort_step(self.h, ptr, _p(counts), _p(out), _p(out_counts), int(out.shape[1])))
+            return out, out_counts
+        cap = int(cap or max(2 * self.D, 64))
+        if self._out is None or self._out.shape[1] != cap:
+            self._out = pinned_array(self.ctx, (self.S, cap, 8), np.float32)
+        self.ctx._chk(self.lib.mot_sort_step(self.h, ptr, _p(counts), _p(self._out), _p(self._cnt), cap))
+        return self._out, self._cnt
+
+    def dump(self, s):
+        ids = np.zeros(self.CAP, np.int32)
+        mean, cov = np.zeros((self.CAP, 7), np.float32), np.zeros((self.CAP, 49), np.float32)
+        n = self.lib.mot_sort_dump(self.h, int(s), _p(ids), _p(mean), _p(cov), self.CAP)
+        if n < 0:
+            raise MotError("mot_sort_dump failed")
+        return ids[:n].copy(), mean[:n].copy(), cov[:n].copy()
+
+    def reset(self):
+        self.ctx._chk(self.lib.mot_sort_reset(self.h))
+
+    def profile(self, on):
+        self.lib.mot_sort_profile.argtypes = [C.c_void_p, C.c_int]
+        self.ctx._chk(self.lib.mot_sort_profile(self.h, 1 if on else 0))
+
+    def profile_stats(self):
+        o = np.zeros(8, np.float64)
+        self.lib.mot_sort_profile_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_sort_profile_stats(self.h, _p(o)))
+        return {"lap1_ms": o[0], "lap23_ms": o[1], "frame_ms": o[2], "frames": int(o[3]), "lap1_problems": o[4], "lap1_nm": o[5],
+                "lap23_problems": o[6], "lap23_nm": o[7]}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mot_sort_destroy(self.h)
+            self.h = None
+            self.lib.mot_free(self.ctx.h, self._ddets)
+            self.ctx.close()

@@ -1,0 +1,474 @@
+// SORT with the per-stream lifecycle ON THE DEVICE (reference: src/trackers/sort.cpp:102-255), same construction as
+// bt_device.hip: track records indexed by Kalman slot, the track list an array of slots in the reference's order, every
+// "for ... push_back" an order-preserving wavefront compaction, a frame a fixed sequence of launches for all streams:
+//   sort_begin -> det_prepare, kf_predict (in place) -> sort_assoc (NaN rule) -> lap -> sort_apply -> kf_initiate,
+//   kf_update, kf_boxes -> sort_emit, then one copy of the output tables.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/motcpp_amd.h"
+#include "ctx.hpp"
+
+namespace mot {
+hipError_t launch_kf_op(int op, int kind, const mot_kf_task*, int, int, hipStream_t);
+hipError_t launch_det(int kind, const mot_det_task*, int, int, hipStream_t);
+hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, hipStream_t);
+size_t lap_scratch_bytes(int n, int m);
+}  // namespace mot
+
+namespace {
+
+struct SortParams {
+  float det_thresh, iou_thr;
+  int max_age, min_hits;
+};
+
+struct SortStream {
+  // persistent
+  int frame_count, next_id, next_slot, n_free, n_trk, cur, err;
+  int* free_stack;
+  int* trk[2];  // slots in list order, ping-pong
+  int *t_id, *t_cls, *t_det, *t_hits, *t_tsu, *t_age;
+  float* t_conf;
+  // frame
+  const float* dets; int ld, n;
+  int* valid; int n_valid;
+  int* keep; int n_keep;      // positions (into the predicted-box planes) of the tracks that survive the NaN rule
+  int *x, *y;
+  int *upd_slot, *upd_meas; int n_upd;
+  int *init_slot, *init_meas; int n_init;
+  int* out_slot; int n_out;
+  float* pbox;  // [4][CAP] predicted boxes, column = position in the track list at frame start
+  float* obox;  // [4][CAP] boxes of the rows to emit
+};
+
+constexpr int kW = 64;
+__device__ __forceinline__ int compact(bool pred, int& base) {
+  const unsigned long long m = __ballot(pred);
+  const int pos = base + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+  base += __popcll(m);
+  return pos;
+}
+
+// detections with conf >= det_thresh (:112-120), ++age / ++time_since_update of every track (SortTrack::predict :43-51)
+__global__ void __launch_bounds__(kW) sort_begin(SortStream* streams, SortParams P, int CAP, int D, const int* counts, const float* dets_base,
+                                                  mot_det_task* det_t, mot_kf_task* pred_t) {
+  SortStream& S = streams[blockIdx.x];
+  const int t = threadIdx.x;
+  const int n = counts[blockIdx.x];
+  const float* dets = dets_base + static_cast<size_t>(blockIdx.x) * 6 * D;
+  const float* conf = dets + static_cast<size_t>(4) * D;
+  int nv = 0;
+  for (int i0 = 0; i0 < n; i0 += kW) {
+    const int i = i0 + t;
+    const bool v = i < n && conf[i] >= P.det_thresh;
+    const int p = compact(v, nv);
+    if (v) S.valid[p] = i;
+  }
+  const int* trk = S.trk[S.cur];
+  for (int i = t; i < S.n_trk; i += kW) { const int slot = trk[i]; S.t_age[slot] += 1; S.t_tsu[slot] += 1; }
+  if (t == 0) {
+    S.frame_count += 1;
+    S.dets = dets; S.ld = D; S.n = n; S.n_valid = nv;
+    if (n > D) S.err = 1;
+    det_t[blockIdx.x].dets = dets; det_t[blockIdx.x].ld = D; det_t[blockIdx.x].n = (n <= D) ? n : 0;
+    pred_t[blockIdx.x].n = S.n_trk; pred_t[blockIdx.x].src = trk;
+  }
+}
+
+// NaN rule (:132-150): tracks whose predicted box has a NaN are dropped, the survivors are associated
+__global__ void __launch_bounds__(kW) sort_assoc(SortStream* streams, int CAP, mot_lap_task* lap_t, unsigned long long* stats) {
+  SortStream& S = streams[blockIdx.x];
+  const int t = threadIdx.x;
+  const int nt = S.n_trk;
+  const int* trk = S.trk[S.cur];
+  int* kept = S.trk[S.cur ^ 1];
+  int nk = 0, free_top = S.n_free;
+  for (int i0 = 0; i0 < nt; i0 += kW) {
+    const int i = i0 + t;
+    const bool v = i < nt;
+    float s = 0.f;
+    if (v) s = S.pbox[i] + S.pbox[static_cast<size_t>(CAP) + i] + S.pbox[static_cast<size_t>(2) * CAP + i] + S.pbox[static_cast<size_t>(3) * CAP + i];
+    const bool ok = v && !(s != s);
+    const int slot = v ? trk[i] : 0;
+    const int p = compact(ok, nk);
+    if (ok) { kept[p] = slot; S.keep[p] = i; }
+    const bool dead = v && !ok;
+    const int pf = compact(dead, free_top);
+    if (dead) S.free_stack[pf] = slot;
+  }
+  if (t == 0) {
+    S.n_trk = nk; S.cur ^= 1; S.n_keep = nk; S.n_free = free_top;
+    mot_lap_task& L = lap_t[blockIdx.x];
+    const bool q = nk > 0 && S.n_valid > 0;
+    L.n = q ? nk : 0; L.m = q ? S.n_valid : 0;
+    L.geom.n = L.n; L.geom.m = L.m;
+    if (stats && q) { atomicAdd(&stats[(blockIdx.x & 63) * 2], 1ull); atomicAdd(&stats[(blockIdx.x & 63) * 2 + 1], static_cast<unsigned long long>(nk + S.n_valid)); }
+  }
+}
+
+// matches -> SortTrack::update (:53-70), unmatched detections -> new trackers (:196-204), deaths (:208-216), rows to emit
+__global__ void __launch_bounds__(kW) sort_apply(SortStream* streams, SortParams P, int CAP, mot_kf_task* init_t, mot_kf_task* upd_t,
+                                                  mot_kf_task* box_t) {
+  SortStream& S = streams[blockIdx.x];
+  const int t = threadIdx.x;
+  const int nt = S.n_trk, nd = S.n_valid;
+  const bool have = nt > 0 && nd > 0;
+  const int* trk = S.trk[S.cur];
+  int* next = S.trk[S.cur ^ 1];
+  int n_upd = 0;
+  for (int i0 = 0; i0 < nt; i0 += kW) {
+    const int i = i0 + t;
+    const bool v = i < nt;
+    const int x = (v && have) ? S.x[i] : -1;
+    const bool m = v && x >= 0;
+    const int slot = v ? trk[i] : 0;
+    const int p = compact(m, n_upd);
+    if (m) {
+      const int det = S.valid[x];
+      S.t_conf[slot] = S.dets[static_cast<size_t>(4) * S.ld + det];
+      S.t_cls[slot] = static_cast<int>(S.dets[static_cast<size_t>(5) * S.ld + det]);
+      S.t_det[slot] = det;
+      S.t_hits[slot] += 1; S.t_tsu[slot] = 0;
+      S.upd_slot[p] = slot; S.upd_meas[p] = det;
+    }
+  }
+  __syncthreads();
+  // survivors of the age rule, in order (new tracks have time_since_update 0 and always stay)
+  int n_next = 0, free_top = S.n_free;
+  for (int i0 = 0; i0 < nt; i0 += kW) {
+    const int i = i0 + t;
+    const bool v = i < nt;
+    const int slot = v ? trk[i] : 0;
+    const bool k = v && S.t_tsu[slot] <= P.max_age;
+    const int p = compact(k, n_next);
+    if (k) next[p] = slot;
+    const bool dead = v && !k;
+    const int pf = compact(dead, free_top);
+    if (dead) S.free_stack[pf] = slot;
+  }
+  // births, ids in detection order. Slots: the free stack as it was at kernel entry first (the slots freed just above sit
+  // on top of it and are left alone: a dying track's state must not be overwritten before it is gone), then fresh ones.
+  int n_init = 0, err = 0;
+  int avail = S.n_free, next_slot = S.next_slot;
+  for (int j0 = 0; j0 < nd; j0 += kW) {
+    const int j = j0 + t;
+    const bool b = j < nd && (!have || S.y[j] < 0);
+    const int base0 = n_init;
+    const int p = compact(b, n_init);
+    const int births = n_init - base0;
+    if (b) {
+      const int r = p - base0;
+      int slot;
+      if (r < avail) slot = S.free_stack[avail - 1 - r];
+      else { slot = next_slot + (r - avail); if (slot >= CAP) { slot = CAP - 1; err = 1; } }
+      const int det = S.valid[j];
+      S.t_id[slot] = S.next_id + p + 1;
+      S.t_conf[slot] = S.dets[static_cast<size_t>(4) * S.ld + det];
+      S.t_cls[slot] = static_cast<int>(S.dets[static_cast<size_t>(5) * S.ld + det]);
+      S.t_det[slot] = det;
+      S.t_hits[slot] = 1; S.t_tsu[slot] = 0; S.t_age[slot] = 1;
+      S.init_slot[p] = slot; S.init_meas[p] = det;
+      if (n_next + p < CAP) next[n_next + p] = slot; else err = 1;
+    }
+    const int from_free = (births < avail) ? births : avail;
+    next_slot += births - from_free;
+    avail -= from_free;
+  }
+  err = __any(err) ? 1 : 0;
+  // the free stack now: [0, avail) untouched old entries, [S.n_free, free_top) the slots freed above -> close the gap
+  __syncthreads();
+  const int freed = free_top - S.n_free;
+  if (avail < S.n_free) {
+    for (int i0 = 0; i0 < freed; i0 += kW) {  // ascending copy to lower addresses: chunk by chunk, read before write
+      const int i = i0 + t;
+      const int v = (i < freed) ? S.free_stack[S.n_free + i] : 0;
+      __syncthreads();
+      if (i < freed) S.free_stack[avail + i] = v;
+      __syncthreads();
+    }
+  }
+  const int n_all = n_next + n_init;
+  __syncthreads();
+  // rows to emit (:218-246)
+  int n_out = 0;
+  for (int i0 = 0; i0 < n_all && i0 < CAP; i0 += kW) {
+    const int i = i0 + t;
+    const bool v = i < n_all && i < CAP;
+    const int slot = v ? next[i] : 0;
+    const bool o = v && S.t_tsu[slot] == 0 && (S.t_hits[slot] >= P.min_hits || S.frame_count <= P.min_hits);
+    const int p = compact(o, n_out);
+    if (o) S.out_slot[p] = slot;
+  }
+  if (t == 0) {
+    if (n_all > CAP) err = 1;
+    S.n_trk = (n_all <= CAP) ? n_all : CAP; S.cur ^= 1;
+    S.n_upd = n_upd; S.n_init = n_init; S.n_out = n_out;
+    S.next_id += n_init; S.next_slot = next_slot; S.n_free = avail + freed;
+    if (err) S.err = 1;
+    init_t[blockIdx.x].n = n_init;
+    upd_t[blockIdx.x].n = n_upd;
+    box_t[blockIdx.x].n = n_out;
+  }
+}
+
+__global__ void __launch_bounds__(kW) sort_emit(SortStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks) {
+  SortStream& S = streams[blockIdx.x];
+  const int t = threadIdx.x;
+  float* rows = out + static_cast<size_t>(blockIdx.x) * cap_out * 8;
+  const int n = S.n_out;
+  for (int k = t; k < n && k < cap_out; k += kW) {
+    const int slot = S.out_slot[k];
+    float* r = rows + static_cast<size_t>(k) * 8;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = S.obox[static_cast<size_t>(c) * CAP + k];
+    r[4] = static_cast<float>(S.t_id[slot]); r[5] = S.t_conf[slot];
+    r[6] = static_cast<float>(S.t_cls[slot]); r[7] = static_cast<float>(S.t_det[slot]);
+  }
+  if (t == 0) {
+    if (n > cap_out) S.err = 2;
+    out_counts[blockIdx.x] = (n <= cap_out) ? n : -n;
+    atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk);
+  }
+}
+
+__global__ void sort_collect_err(const SortStream* streams, int n, int* err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && streams[i].err) atomicMax(err, streams[i].err);
+}
+
+}  // namespace
+
+struct mot_sort_batch {
+  mot_ctx* ctx = nullptr;
+  int S = 0, CAP = 0, D = 0;
+  SortParams prm{};
+  std::vector<void*> allocs;
+  SortStream* d_streams = nullptr;
+  std::vector<SortStream> h_streams;
+  int *d_counts = nullptr, *d_err = nullptr, *d_maxt = nullptr;
+  int bound_n = 0;
+  float* d_out = nullptr; int* d_out_counts = nullptr; int out_cap = 0;
+  mot_det_task* det_t = nullptr;
+  mot_kf_task *pred_t = nullptr, *init_t = nullptr, *upd_t = nullptr, *box_t = nullptr;
+  mot_lap_task* lap_t = nullptr;
+  float *mean = nullptr, *cov = nullptr;  // [S][7][CAP], [S][49][CAP]
+  bool profile = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double lap_ms = 0.0, frame_ms = 0.0;
+  long frames = 0;
+  unsigned long long* d_stats = nullptr;  // [64][2]: problems, sum of n + m
+  template <class T>
+  T* dalloc(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+    allocs.push_back(p);
+    return static_cast<T*>(p);
+  }
+};
+
+#define SD_HIP(b, call)                                                                                  \
+  do {                                                                                                   \
+    hipError_t e_ = (call);                                                                              \
+    if (e_ != hipSuccess) { (b)->ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return MOT_ERR_HIP; } \
+  } while (0)
+
+extern "C" {
+
+void mot_sort_destroy(mot_sort_batch* b) {
+  if (!b) return;
+  for (void* p : b->allocs) (void)hipFree(p);
+  for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+  delete b;
+}
+
+int mot_sort_reset(mot_sort_batch* b) {  // sort.cpp:97-100: the tracks go, the id counter keeps counting
+  std::vector<SortStream> cur(b->S);
+  SD_HIP(b, hipMemcpy(cur.data(), b->d_streams, sizeof(SortStream) * b->S, hipMemcpyDeviceToHost));
+  std::vector<SortStream> h = b->h_streams;
+  for (int s = 0; s < b->S; ++s) h[s].next_id = cur[s].next_id;
+  SD_HIP(b, hipMemcpy(b->d_streams, h.data(), sizeof(SortStream) * b->S, hipMemcpyHostToDevice));
+  SD_HIP(b, hipMemset(b->d_err, 0, sizeof(int)));
+  b->bound_n = 0;
+  return MOT_OK;
+}
+
+int mot_sort_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, const float* p5, mot_sort_batch** out) {
+  if (!ctx || !out || nstreams <= 0 || cap_tracks <= 0 || max_dets <= 0) return MOT_ERR_INVALID;
+  auto* b = new mot_sort_batch();
+  b->ctx = ctx; b->S = nstreams; b->CAP = cap_tracks; b->D = max_dets;
+  b->prm.det_thresh = p5 ? p5[0] : 0.3f;
+  b->prm.max_age = p5 ? static_cast<int>(p5[1]) : 1;
+  b->prm.min_hits = p5 ? static_cast<int>(p5[3]) : 3;
+  b->prm.iou_thr = p5 ? p5[4] : 0.3f;
+  const int S = nstreams, CAP = cap_tracks, D = max_dets;
+  const size_t ints_per = static_cast<size_t>(CAP) * 14 + static_cast<size_t>(D) * 4;
+  int* ip = b->dalloc<int>(ints_per * S);
+  float* fp = b->dalloc<float>((static_cast<size_t>(CAP) * 9 + static_cast<size_t>(D) * 8) * S);
+  b->mean = b->dalloc<float>(static_cast<size_t>(S) * 7 * CAP);
+  b->cov = b->dalloc<float>(static_cast<size_t>(S) * 49 * CAP);
+  b->d_streams = b->dalloc<SortStream>(S);
+  b->d_counts = b->dalloc<int>(S);
+  b->d_err = b->dalloc<int>(1);
+  b->d_maxt = b->dalloc<int>(64);
+  b->d_stats = b->dalloc<unsigned long long>(128);
+  if (b->d_stats) (void)hipMemset(b->d_stats, 0, 128 * sizeof(unsigned long long));
+  for (auto& e : b->ev) (void)hipEventCreate(&e);
+  b->det_t = b->dalloc<mot_det_task>(S);
+  b->pred_t = b->dalloc<mot_kf_task>(S); b->init_t = b->dalloc<mot_kf_task>(S); b->upd_t = b->dalloc<mot_kf_task>(S); b->box_t = b->dalloc<mot_kf_task>(S);
+  b->lap_t = b->dalloc<mot_lap_task>(S);
+  const size_t wb = (mot::lap_scratch_bytes(CAP, D) + 255) & ~size_t(255);
+  char* work = b->dalloc<char>(wb * S);
+  int* info = b->dalloc<int>(static_cast<size_t>(4) * S);
+  if (!ip || !fp || !b->mean || !b->cov || !b->d_streams || !b->d_counts || !b->d_err || !b->d_maxt || !b->det_t || !b->pred_t || !b->init_t ||
+      !b->upd_t || !b->box_t || !b->lap_t || !work || !info) {
+    mot_sort_destroy(b);
+    return MOT_ERR_NOMEM;
+  }
+  std::vector<SortStream> hs(S);
+  std::vector<mot_det_task> det(S);
+  std::vector<mot_kf_task> pred(S), init(S), upd(S), box(S);
+  std::vector<mot_lap_task> lap(S);
+  for (int s = 0; s < S; ++s) {
+    SortStream& T = hs[s];
+    std::memset(&T, 0, sizeof(T));
+    int* i = ip + ints_per * s;
+    auto I = [&](int n) { int* r = i; i += n; return r; };
+    T.free_stack = I(CAP); T.trk[0] = I(CAP); T.trk[1] = I(CAP);
+    T.t_id = I(CAP); T.t_cls = I(CAP); T.t_det = I(CAP); T.t_hits = I(CAP); T.t_tsu = I(CAP); T.t_age = I(CAP);
+    T.keep = I(CAP); T.x = I(CAP); T.upd_slot = I(CAP); T.upd_meas = I(CAP); T.out_slot = I(CAP);  // 14 CAP-sized arrays
+    T.valid = I(D); T.y = I(D); T.init_slot = I(D); T.init_meas = I(D);
+    float* f = fp + (static_cast<size_t>(CAP) * 9 + static_cast<size_t>(D) * 8) * s;
+    auto F = [&](int n) { float* r = f; f += n; return r; };
+    T.t_conf = F(CAP); T.pbox = F(4 * CAP); T.obox = F(4 * CAP);
+    float* d_box = F(4 * D); float* d_meas = F(4 * D);
+    float* mean = b->mean + static_cast<size_t>(s) * 7 * CAP;
+    float* cov = b->cov + static_cast<size_t>(s) * 49 * CAP;
+    std::memset(&det[s], 0, sizeof(mot_det_task));
+    det[s].box = d_box; det[s].ldb = D; det[s].meas = d_meas; det[s].ldm = D;
+    auto kf = [&](mot_kf_task& k) {
+      std::memset(&k, 0, sizeof(k));
+      k.mean = mean; k.cov = cov; k.cap = CAP;
+      k.q[0] = 0.01f; k.q[1] = 0.01f; k.q[2] = 0.0001f;  // xysr_kf.cpp:52-65
+    };
+    kf(pred[s]); pred[s].boxes = T.pbox; pred[s].ldb = CAP;  // in place: dst = src (set per frame: the list buffer alternates)
+    kf(init[s]); init[s].src = T.init_slot; init[s].dst = T.init_slot; init[s].meas = d_meas; init[s].ldm = D; init[s].midx = T.init_meas;
+    kf(upd[s]); upd[s].src = T.upd_slot; upd[s].dst = T.upd_slot; upd[s].meas = d_meas; upd[s].ldm = D; upd[s].midx = T.upd_meas;
+    kf(box[s]); box[s].src = T.out_slot; box[s].boxes = T.obox; box[s].ldb = CAP;
+    mot_lap_task& L = lap[s];
+    std::memset(&L, 0, sizeof(L));
+    L.x = T.x; L.y = T.y; L.thresh = 1.0f - b->prm.iou_thr; L.mode = MOT_LAP_PLAIN; L.info = info + static_cast<size_t>(s) * 4;
+    L.work = work + static_cast<size_t>(s) * wb;
+    L.geom.a = T.pbox; L.geom.lda = CAP; L.geom.aidx = T.keep; L.geom.b = d_box; L.geom.ldb = D; L.geom.bidx = T.valid;
+    L.geom.mode = MOT_COST_IOU_DIST;
+  }
+  b->h_streams = hs;
+  hipStream_t st = ctx->stream;
+#define SD_UP(dst, vec) SD_HIP(b, hipMemcpyAsync(dst, vec.data(), sizeof(vec[0]) * vec.size(), hipMemcpyHostToDevice, st))
+  SD_UP(b->d_streams, hs); SD_UP(b->det_t, det); SD_UP(b->pred_t, pred); SD_UP(b->init_t, init); SD_UP(b->upd_t, upd); SD_UP(b->box_t, box);
+  SD_UP(b->lap_t, lap);
+#undef SD_UP
+  SD_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), st));
+  SD_HIP(b, hipStreamSynchronize(st));
+  *out = b;
+  return MOT_OK;
+}
+
+int mot_sort_step(mot_sort_batch* b, const float* d_dets, const int* h_counts, float* out, int* out_counts, int cap_out) {
+  hipStream_t st = b->ctx->stream;
+  const int S = b->S, CAP = b->CAP, D = b->D;
+  if (cap_out > b->out_cap) {
+    b->d_out = b->dalloc<float>(static_cast<size_t>(S) * cap_out * 8);
+    b->d_out_counts = b->d_out_counts ? b->d_out_counts : b->dalloc<int>(S);
+    if (!b->d_out || !b->d_out_counts) return MOT_ERR_NOMEM;
+    b->out_cap = cap_out;
+  }
+  SD_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  SD_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
+  int bd = 1;
+  for (int s = 0; s < S; ++s) bd = (h_counts[s] > bd) ? h_counts[s] : bd;
+  if (bd > D) bd = D;
+  const int bn = (b->bound_n < 1) ? 1 : (b->bound_n > CAP ? CAP : b->bound_n);  // tracks alive after the previous frame
+  const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;
+  const bool prof = b->profile;
+  if (prof) SD_HIP(b, hipEventRecord(b->ev[0], st));
+  hipLaunchKernelGGL(sort_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t);
+  SD_HIP(b, mot::launch_det(MOT_DET_XYSR, b->det_t, S, bd, st));
+  SD_HIP(b, mot::launch_kf_op(1, MOT_KF_XYSR, b->pred_t, S, bn, st));
+  hipLaunchKernelGGL(sort_assoc, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->lap_t, prof ? b->d_stats : nullptr);
+  if (prof) SD_HIP(b, hipEventRecord(b->ev[1], st));
+  SD_HIP(b, mot::launch_lap(b->lap_t, S, bn, bd, true, false, st));
+  if (prof) SD_HIP(b, hipEventRecord(b->ev[2], st));
+  hipLaunchKernelGGL(sort_apply, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box_t);
+  SD_HIP(b, mot::launch_kf_op(0, MOT_KF_XYSR, b->init_t, S, bd, st));
+  SD_HIP(b, mot::launch_kf_op(2, MOT_KF_XYSR, b->upd_t, S, bn, st));
+  SD_HIP(b, mot::launch_kf_op(3, MOT_KF_XYSR, b->box_t, S, bn2, st));
+  hipLaunchKernelGGL(sort_emit, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);
+  hipLaunchKernelGGL(sort_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
+  if (prof) SD_HIP(b, hipEventRecord(b->ev[3], st));
+  SD_HIP(b, hipGetLastError());
+  int err = 0, maxt[64];
+  SD_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
+  SD_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  SD_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  SD_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
+  SD_HIP(b, hipStreamSynchronize(st));
+  b->bound_n = 0;
+  for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
+  if (prof) {
+    float ms = 0.f;
+    SD_HIP(b, hipEventElapsedTime(&ms, b->ev[1], b->ev[2])); b->lap_ms += ms;
+    SD_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[3])); b->frame_ms += ms;
+    b->frames += 1;
+  }
+  if (err) { b->ctx->err = "mot_sort_step: a stream exceeded cap_tracks / max_dets / cap_out"; return MOT_ERR_CAPACITY; }
+  return MOT_OK;
+}
+
+int mot_sort_profile(mot_sort_batch* b, int enable) {
+  b->profile = enable != 0;
+  if (enable) {
+    b->lap_ms = b->frame_ms = 0.0;
+    b->frames = 0;
+    SD_HIP(b, hipMemset(b->d_stats, 0, 128 * sizeof(unsigned long long)));
+  }
+  return MOT_OK;
+}
+int mot_sort_profile_stats(mot_sort_batch* b, double* out8) {
+  unsigned long long raw[128];
+  SD_HIP(b, hipMemcpy(raw, b->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
+  unsigned long long pr = 0, nm = 0;
+  for (int i = 0; i < 64; ++i) { pr += raw[2 * i]; nm += raw[2 * i + 1]; }
+  out8[0] = b->lap_ms; out8[1] = 0.0; out8[2] = b->frame_ms; out8[3] = static_cast<double>(b->frames);
+  out8[4] = static_cast<double>(pr); out8[5] = static_cast<double>(nm); out8[6] = 0.0; out8[7] = 0.0;
+  return MOT_OK;
+}
+
+int mot_sort_dump(mot_sort_batch* b, int s, int* ids, float* mean, float* cov, int cap) {
+  hipStream_t st = b->ctx->stream;
+  SortStream h;
+  SD_HIP(b, hipMemcpyAsync(&h, b->d_streams + s, sizeof(SortStream), hipMemcpyDeviceToHost, st));
+  SD_HIP(b, hipStreamSynchronize(st));
+  const int n = h.n_trk;
+  if (n > cap) return -n;
+  std::vector<int> slots(n), tid(b->CAP);
+  if (n) SD_HIP(b, hipMemcpyAsync(slots.data(), h.trk[h.cur], sizeof(int) * n, hipMemcpyDeviceToHost, st));
+  SD_HIP(b, hipMemcpyAsync(tid.data(), h.t_id, sizeof(int) * b->CAP, hipMemcpyDeviceToHost, st));
+  const int C = b->CAP;
+  std::vector<float> m(static_cast<size_t>(7) * C), c(static_cast<size_t>(49) * C);
+  SD_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 7 * C, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
+  SD_HIP(b, hipMemcpyAsync(c.data(), b->cov + static_cast<size_t>(s) * 49 * C, sizeof(float) * c.size(), hipMemcpyDeviceToHost, st));
+  SD_HIP(b, hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) {
+    const int sl = slots[i];
+    ids[i] = tid[sl];
+    for (int k = 0; k < 7; ++k) mean[static_cast<size_t>(i) * 7 + k] = m[static_cast<size_t>(k) * C + sl];
+    for (int k = 0; k < 49; ++k) cov[static_cast<size_t>(i) * 49 + k] = c[static_cast<size_t>(k) * C + sl];
+  }
+  return n;
+}
+
+}  // extern "C"

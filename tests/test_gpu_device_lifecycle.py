@@ -117,3 +117,61 @@ def test_all_streams_empty_then_busy():
         for s in range(3):
             assert np.array_equal(out[s, :oc[s]], oracles[s].update(per[s])), (f, s)
     dev.close()
+
+
+# ---- SORT with the lifecycle on the device (mot_sort_*) ----
+def run_sort(shapes, frames, cap, maxd, params=None, check_states_every=9, nan_at=None):
+    orc = orclib.load()
+    S = len(shapes)
+    dev = L.DeviceSort(S, cap, maxd, params)
+    streams = [SynthStream(P, M, 4321 + i) for i, (P, M) in enumerate(shapes)]
+    oracles = [orc.tracker(orclib.SORT, params) for _ in range(S)]
+    rows = 0
+    for f in range(frames):
+        dets = np.zeros((S, maxd, 6), np.float32)
+        cnt = np.zeros(S, np.int32)
+        per = []
+        for s, st in enumerate(streams):
+            d, _ = st.next_frame()
+            if (f + 2 * s) % 11 == 7:
+                d = d[:0]
+            per.append(d); cnt[s] = len(d); dets[s, :len(d)] = d
+        out, oc = dev.step(dets, cnt)
+        for s in range(S):
+            oo = oracles[s].update(per[s])
+            assert oc[s] == oo.shape[0], (f, s, oc[s], oo.shape)
+            assert np.array_equal(out[s, :oc[s]], oo), (f, s)
+            rows += oo.shape[0]
+            if f % check_states_every == check_states_every - 1:
+                ids, mean, cov = dev.dump(s)
+                so = oracles[s].dump_states()
+                assert len(ids) == so.shape[0], (f, s)
+                if len(ids):
+                    assert np.array_equal(ids, so[:, 0].astype(np.int32)), (f, s)
+                    assert np.array_equal(mean, so[:, 1:8]), (f, s)
+                    assert np.array_equal(cov, so[:, 8:57]), (f, s)
+    assert rows > 0
+    dev.close()
+
+
+def test_sort_device_streams():
+    run_sort([(24, 12), (40, 30), (8, 8), (64, 40), (1, 1)], 70, cap=256, maxd=64)
+
+
+def test_sort_device_c2_shape_and_max_age():
+    run_sort([(256, 128), (200, 100)], 40, cap=512, maxd=128)
+    run_sort([(30, 20), (30, 12)], 60, cap=128, maxd=32, params=[0.3, 5, 50, 2, 0.2])  # tracks survive 5 missed frames
+
+
+def test_sort_device_mot17_mini():
+    from tests import mot17
+    orc = orclib.load()
+    for seq in mot17.SEQS:
+        dev = L.DeviceSort(1, 256, 64, [0.3, 1, 50, 3, 0.3])
+        to = orc.tracker(orclib.SORT, [0.3, 1, 50, 3, 0.3])
+        for f, d in enumerate(mot17.load(seq)):
+            dets = np.zeros((1, 64, 6), np.float32)
+            dets[0, :len(d)] = d
+            out, oc = dev.step(dets, np.array([len(d)], np.int32))
+            assert np.array_equal(out[0, :oc[0]], to.update(d)), (seq, f)
+        dev.close()

@@ -54,22 +54,36 @@ class StreamBatch {
 // Same semantics per stream as trackers::ByteTrack(…).update(dets, img) with the default BaseTracker arguments; ids are
 // per stream. cap_tracks bounds tracked + lost tracks of a stream, max_dets the detections of a frame (std::runtime_error
 // when a stream exceeds them).
-class ByteTrackDeviceBatch {
+class DeviceLifecycleBatch {
  public:
-  ByteTrackDeviceBatch(int nstreams, int cap_tracks, int max_dets, float min_conf = 0.1f, float track_thresh = 0.45f,
-                       float match_thresh = 0.8f, int track_buffer = 25, int frame_rate = 30, int device_index = 0);
-  ~ByteTrackDeviceBatch();
-  ByteTrackDeviceBatch(const ByteTrackDeviceBatch&) = delete;
-  ByteTrackDeviceBatch& operator=(const ByteTrackDeviceBatch&) = delete;
+  virtual ~DeviceLifecycleBatch();
+  DeviceLifecycleBatch(const DeviceLifecycleBatch&) = delete;
+  DeviceLifecycleBatch& operator=(const DeviceLifecycleBatch&) = delete;
   // dets[s]: N_s x 6 column-major [x1,y1,x2,y2,conf,cls]; returns per-stream M_s x 8 tables [x1,y1,x2,y2,id,conf,cls,det_ind]
   std::vector<Eigen::MatrixXf> update(const std::vector<Eigen::MatrixXf>& dets);
   void reset();
   size_t size() const { return static_cast<size_t>(n_); }
 
+ protected:
+  DeviceLifecycleBatch(int kind, int nstreams, int cap_tracks, int max_dets, const float params[5], int device_index);
+
  private:
   struct Impl;
   std::unique_ptr<Impl> impl_;
   int n_, cap_, maxd_;
+};
+
+class ByteTrackDeviceBatch : public DeviceLifecycleBatch {
+ public:
+  ByteTrackDeviceBatch(int nstreams, int cap_tracks, int max_dets, float min_conf = 0.1f, float track_thresh = 0.45f,
+                       float match_thresh = 0.8f, int track_buffer = 25, int frame_rate = 30, int device_index = 0);
+};
+
+// The same for trackers::Sort (C ABI: mot_sort_*, motcpp_amd/csrc/sort_device.hip); reset() keeps the ids counting (sort.cpp:97-100)
+class SortDeviceBatch : public DeviceLifecycleBatch {
+ public:
+  SortDeviceBatch(int nstreams, int cap_tracks, int max_dets, float det_thresh = 0.3f, int max_age = 1, int min_hits = 3,
+                  float iou_threshold = 0.3f, int device_index = 0);
 };
 
 }  // namespace motcpp

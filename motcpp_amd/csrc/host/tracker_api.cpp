@@ -209,42 +209,45 @@ BotSort::BotSort(const std::string& reid_weights, bool /*use_half*/, bool /*use_
 }
 }  // namespace trackers
 
-// ---- ByteTrackDeviceBatch ----------------------------------------------------------------------
-struct ByteTrackDeviceBatch::Impl {
+// ---- DeviceLifecycleBatch: ByteTrack (mot_bt_*) and SORT (mot_sort_*) with the lifecycle on the device ----------
+struct DeviceLifecycleBatch::Impl {
   std::shared_ptr<rt::Device> dev;
+  int kind = 0;  // 0 ByteTrack, 1 SORT
   mot_bt_batch* bt = nullptr;
+  mot_sort_batch* so = nullptr;
   void* d_dets = nullptr;
   std::vector<float> soa, out;
   std::vector<int> counts, out_counts;
 };
-ByteTrackDeviceBatch::ByteTrackDeviceBatch(int nstreams, int cap_tracks, int max_dets, float min_conf, float track_thresh,
-                                           float match_thresh, int track_buffer, int frame_rate, int device_index)
+DeviceLifecycleBatch::DeviceLifecycleBatch(int kind, int nstreams, int cap_tracks, int max_dets, const float p[5], int device_index)
     : impl_(std::make_unique<Impl>()), n_(nstreams), cap_(cap_tracks), maxd_(max_dets) {
   impl_->dev = rt::Device::shared(device_index);
-  const float p[5] = {min_conf, track_thresh, match_thresh, static_cast<float>(track_buffer), static_cast<float>(frame_rate)};
-  if (mot_bt_create(impl_->dev->ctx, nstreams, cap_tracks, max_dets, p, &impl_->bt) != MOT_OK)
-    throw std::runtime_error(std::string("motcpp_amd: mot_bt_create failed: ") + mot_ctx_last_error(impl_->dev->ctx));
+  impl_->kind = kind;
+  mot_ctx* ctx = impl_->dev->ctx;
+  const int rc = kind == 0 ? mot_bt_create(ctx, nstreams, cap_tracks, max_dets, p, &impl_->bt) : mot_sort_create(ctx, nstreams, cap_tracks, max_dets, p, &impl_->so);
+  if (rc != MOT_OK) throw std::runtime_error(std::string("motcpp_amd: device-lifecycle batch creation failed: ") + mot_ctx_last_error(ctx));
   impl_->soa.assign(static_cast<size_t>(nstreams) * 6 * max_dets, 0.f);
   impl_->counts.assign(nstreams, 0);
   impl_->out_counts.assign(nstreams, 0);
-  if (mot_malloc(impl_->dev->ctx, impl_->soa.size() * sizeof(float), &impl_->d_dets) != MOT_OK)
-    throw std::runtime_error("motcpp_amd: device allocation failed");
+  if (mot_malloc(ctx, impl_->soa.size() * sizeof(float), &impl_->d_dets) != MOT_OK) throw std::runtime_error("motcpp_amd: device allocation failed");
 }
-ByteTrackDeviceBatch::~ByteTrackDeviceBatch() {
+DeviceLifecycleBatch::~DeviceLifecycleBatch() {
   if (impl_->bt) mot_bt_destroy(impl_->bt);
+  if (impl_->so) mot_sort_destroy(impl_->so);
   if (impl_->d_dets) mot_free(impl_->dev->ctx, impl_->d_dets);
 }
-void ByteTrackDeviceBatch::reset() {
-  if (mot_bt_reset(impl_->bt) != MOT_OK) throw std::runtime_error(mot_ctx_last_error(impl_->dev->ctx));
+void DeviceLifecycleBatch::reset() {
+  const int rc = impl_->kind == 0 ? mot_bt_reset(impl_->bt) : mot_sort_reset(impl_->so);
+  if (rc != MOT_OK) throw std::runtime_error(mot_ctx_last_error(impl_->dev->ctx));
 }
-std::vector<Eigen::MatrixXf> ByteTrackDeviceBatch::update(const std::vector<Eigen::MatrixXf>& dets) {
-  if (static_cast<int>(dets.size()) != n_) throw std::invalid_argument("ByteTrackDeviceBatch: one detection matrix per stream");
+std::vector<Eigen::MatrixXf> DeviceLifecycleBatch::update(const std::vector<Eigen::MatrixXf>& dets) {
+  if (static_cast<int>(dets.size()) != n_) throw std::invalid_argument("device-lifecycle batch: one detection matrix per stream");
   Impl& I = *impl_;
   for (int s = 0; s < n_; ++s) {
     const Eigen::MatrixXf& d = dets[s];
     const int n = static_cast<int>(d.rows());
-    if (n > 0 && d.cols() != 6) throw std::invalid_argument("ByteTrackDeviceBatch: detections must be N x 6");
-    if (n > maxd_) throw std::invalid_argument("ByteTrackDeviceBatch: more detections than max_dets");
+    if (n > 0 && d.cols() != 6) throw std::invalid_argument("device-lifecycle batch: detections must be N x 6");
+    if (n > maxd_) throw std::invalid_argument("device-lifecycle batch: more detections than max_dets");
     I.counts[s] = n;
     float* dst = I.soa.data() + static_cast<size_t>(s) * 6 * maxd_;
     for (int k = 0; k < 6; ++k)  // a column-major N x 6 matrix IS the SoA layout
@@ -254,8 +257,10 @@ std::vector<Eigen::MatrixXf> ByteTrackDeviceBatch::update(const std::vector<Eige
   if (mot_memcpy_h2d(ctx, I.d_dets, I.soa.data(), I.soa.size() * sizeof(float)) != MOT_OK) throw std::runtime_error(mot_ctx_last_error(ctx));
   const int cap_out = cap_;  // a stream never reports more rows than it has tracks
   I.out.resize(static_cast<size_t>(n_) * cap_out * 8);
-  const int rc = mot_bt_step(I.bt, static_cast<const float*>(I.d_dets), I.counts.data(), I.out.data(), I.out_counts.data(), cap_out);
-  if (rc != MOT_OK) throw std::runtime_error(std::string("motcpp_amd: mot_bt_step failed: ") + mot_ctx_last_error(ctx));
+  const float* dd = static_cast<const float*>(I.d_dets);
+  const int rc = I.kind == 0 ? mot_bt_step(I.bt, dd, I.counts.data(), I.out.data(), I.out_counts.data(), cap_out)
+                             : mot_sort_step(I.so, dd, I.counts.data(), I.out.data(), I.out_counts.data(), cap_out);
+  if (rc != MOT_OK) throw std::runtime_error(std::string("motcpp_amd: device-lifecycle step failed: ") + mot_ctx_last_error(ctx));
   std::vector<Eigen::MatrixXf> res;
   res.reserve(n_);
   for (int s = 0; s < n_; ++s) {
@@ -268,6 +273,17 @@ std::vector<Eigen::MatrixXf> ByteTrackDeviceBatch::update(const std::vector<Eige
   }
   return res;
 }
+namespace {
+struct P5 { float v[5]; };
+}
+ByteTrackDeviceBatch::ByteTrackDeviceBatch(int nstreams, int cap_tracks, int max_dets, float min_conf, float track_thresh, float match_thresh,
+                                           int track_buffer, int frame_rate, int device_index)
+    : DeviceLifecycleBatch(0, nstreams, cap_tracks, max_dets,
+                           P5{{min_conf, track_thresh, match_thresh, static_cast<float>(track_buffer), static_cast<float>(frame_rate)}}.v, device_index) {}
+SortDeviceBatch::SortDeviceBatch(int nstreams, int cap_tracks, int max_dets, float det_thresh, int max_age, int min_hits, float iou_threshold,
+                                 int device_index)
+    : DeviceLifecycleBatch(1, nstreams, cap_tracks, max_dets,
+                           P5{{det_thresh, static_cast<float>(max_age), 50.f, static_cast<float>(min_hits), iou_threshold}}.v, device_index) {}
 
 // ---- utils:: primitive seam ----------------------------------------------------------------------
 namespace utils {

@@ -108,6 +108,17 @@ int main() {
     bool threw = false;
     try { batch.update({multi}); } catch (const std::invalid_argument&) { threw = true; }
     CHECK(threw);
+    motcpp::SortDeviceBatch sbatch(1, 64, 16);
+    Sort ref;
+    for (int f = 0; f < 6; ++f) {
+      Eigen::MatrixXf d = multi;
+      for (int i = 0; i < d.rows(); ++i) { d(i, 0) += 3.f * f; d(i, 2) += 3.f * f; }
+      auto out = sbatch.update({d});
+      Eigen::MatrixXf r = ref.update(d, img);
+      CHECK(out[0].rows() == r.rows());
+      for (int i = 0; i < r.rows(); ++i)
+        for (int k = 0; k < 8; ++k) CHECK(out[0](i, k) == r(i, k));
+    }
   }
   {  // asso_func: stored by every tracker, read only by OC-SORT, at update time (ocsort.cpp:413; iou.hpp:385-408)
     ByteTrack bt(0.3f, 30, 50, 3, 0.3f, false, 80, "no-such-measure");

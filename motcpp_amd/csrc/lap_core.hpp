@@ -675,31 +675,78 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             }
             g.sync();
             const int nrec = compact_ascending(g, cnt, [&](int q) { return W.tmp[first + q] != 0; }, W.lst);
-            if (t == 0) {
+            bool replayed = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (T == 64) {
+              // One wavefront: the replay runs out of registers. A chunk of 64 records (position, column, distance) is
+              // gathered in parallel, one per lane, together with a 64-entry window of cols[] at the insertion point; the
+              // serial walk then reads them with v_readlane and keeps the window current with a lane-select, so that an
+              // iteration costs ~25 instructions instead of three dependent global loads. (A later record's position is
+              // never touched by an earlier step: h2 <= lo + r < k_r.) The stores to cols[] / inv[] still go to memory.
               unsigned h2 = lo + 1;
               double mind = m0;
-              for (int r = 0; r < nrec; ++r) {
-                const int k = first + W.lst[r];
-                const int j = W.cols[k];
-                const double dj = W.d[j];
-                if (dj < mind) { h2 = lo; mind = dj; }
-                const int jh = W.cols[h2];
-                W.cols[k] = jh; W.inv[jh] = k;
-                W.cols[h2] = j; W.inv[j] = static_cast<int>(h2);
-                ++h2;
+              for (int r0 = 0; r0 < nrec; r0 += 64) {
+                const int r = r0 + t;
+                int rk = 0, rj = 0;
+                double rd = 0.0;
+                if (r < nrec) { rk = first + static_cast<int>(W.lst[r]); rj = W.cols[rk]; rd = W.d[rj]; }
+                const unsigned wb = (r0 == 0) ? lo : h2;  // window base: covers a restart (h2 = lo) in the first chunk
+                int win = (wb + static_cast<unsigned>(t) < static_cast<unsigned>(n)) ? static_cast<int>(W.cols[wb + t]) : 0;
+                const int cc = (nrec - r0 < 64) ? nrec - r0 : 64;
+                for (int q = 0; q < cc; ++q) {
+                  const int k = __builtin_amdgcn_readlane(rk, q), j = __builtin_amdgcn_readlane(rj, q);
+                  const double dj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rd), q), __builtin_amdgcn_readlane(__double2loint(rd), q));
+                  if (dj < mind) { h2 = lo; mind = dj; }
+                  const unsigned off = h2 - wb, offk = static_cast<unsigned>(k) - wb;
+                  int jh;
+                  if (off < 64u) jh = __builtin_amdgcn_readlane(win, static_cast<int>(off));
+                  else jh = W.cols[h2];
+                  if (t == 0) {
+                    W.cols[k] = jh; W.inv[jh] = k;
+                    W.cols[h2] = j; W.inv[j] = static_cast<int>(h2);
+                  }
+                  if (static_cast<unsigned>(t) == offk) win = jh;  // (offk >= 64 matches no lane)
+                  if (static_cast<unsigned>(t) == off) win = j;
+                  ++h2;
+                }
               }
-              int fj = -1;
-              for (unsigned k = lo; k < h2; ++k) {
-                const int j = W.cols[k];
-                if (W.y[j] < 0) fj = j;
+              g.sync();  // lane 0's stores to cols[] are visible to everyone
+              int best = -1;
+              for (unsigned k = lo + static_cast<unsigned>(t); k < h2; k += 64u)
+                if (static_cast<int>(W.y[static_cast<int>(W.cols[k])]) < 0) best = static_cast<int>(k);  // the LAST free member (:174-177)
+              best = g.reduce_max(best);
+              hi = h2;
+              final_j = (best >= 0) ? static_cast<int>(W.cols[best]) : -1;
+              replayed = true;
+            }
+#endif
+            if (!replayed) {
+              if (t == 0) {
+                unsigned h2 = lo + 1;
+                double mind = m0;
+                for (int r = 0; r < nrec; ++r) {
+                  const int k = first + W.lst[r];
+                  const int j = W.cols[k];
+                  const double dj = W.d[j];
+                  if (dj < mind) { h2 = lo; mind = dj; }
+                  const int jh = W.cols[h2];
+                  W.cols[k] = jh; W.inv[jh] = k;
+                  W.cols[h2] = j; W.inv[j] = static_cast<int>(h2);
+                  ++h2;
+                }
+                int fj = -1;
+                for (unsigned k = lo; k < h2; ++k) {
+                  const int j = W.cols[k];
+                  if (W.y[j] < 0) fj = j;
+                }
+                W.tmp[0] = static_cast<int>(h2);
+                W.tmp[1] = fj;
               }
-              W.tmp[0] = static_cast<int>(h2);
-              W.tmp[1] = fj;
+              g.sync();
+              hi = static_cast<unsigned>(W.tmp[0]);
+              final_j = W.tmp[1];
             }
           }
-          g.sync();
-          hi = static_cast<unsigned>(W.tmp[0]);
-          final_j = W.tmp[1];
           g.sync();
         }
         if (final_j == -1) {

@@ -97,7 +97,10 @@ int mot_det_prepare(mot_ctx* ctx, int det_kind, const mot_det_task* tasks, int n
 typedef enum mot_kf_kind { MOT_KF_XYSR = 0 /* d=7 */, MOT_KF_XYAH = 1 /* d=8 */, MOT_KF_XYWH = 2 /* d=8 */ } mot_kf_kind;
 enum {
   MOT_KF_ZERO_V7 = 1,     /* predict: mean[7] = 0 first (ByteTrack, non-Tracked: bytetrack.cpp:108-110) */
-  MOT_KF_OCSORT_CLAMP = 2 /* predict: if x6 + x2 <= 0 then x6 = 0 (ocsort.cpp:134-136)                  */
+  MOT_KF_OCSORT_CLAMP = 2,/* predict: if x6 + x2 <= 0 then x6 = 0 (ocsort.cpp:134-136)                  */
+  MOT_KF_NO_STORE = 4,    /* predict: only the boxes are wanted, the predicted state is not written      */
+  MOT_KF_PREDICT_FIRST = 8/* update: predict the loaded state first (honouring MOT_KF_ZERO_V7), then update: with NO_STORE
+                             predictions this replaces "predict into a scratch slot, update from it" without the round trip */
 };
 /* Track-state slab, SoA: mean plane k at mean + k*cap, covariance element (r,c) at cov + (r*d+c)*cap. */
 typedef struct mot_kf_task {

@@ -55,7 +55,7 @@ struct BtStream {
   int* unconf_slot; int n_unconf;
   int *pred_src, *pred_dst; unsigned char* pred_flags;
   int *x1, *y1, *x2, *y2, *x3, *y3;
-  int *upd_src, *upd_dst, *upd_meas; int n_upd;
+  int *upd_src, *upd_dst, *upd_meas; unsigned char* upd_flags; int n_upd;
   int* refind; int n_refind;
   int* u_track; int n_utrack;
   int* u_det; int n_udet;
@@ -126,11 +126,12 @@ __global__ void __launch_bounds__(kW) bt_begin(BtStream* streams, BtParams P, in
     if (v) S.pool_slot[p] = lst[i];
   }
   __syncthreads();
-  for (int i = t; i < np; i += kW) {  // predicted COPIES of the pool go to scratch slots CAP + i (:251-265)
+  for (int i = t; i < np; i += kW) {  // the reference predicts COPIES of the pool (:251-265): here the prediction is box-only
     const int slot = S.pool_slot[i];
     S.pred_src[i] = slot;
-    S.pred_dst[i] = CAP + i;
-    S.pred_flags[i] = (S.t_state[slot] != Tracked) ? MOT_KF_ZERO_V7 : 0;
+    S.pred_dst[i] = slot;
+    // only the predicted BOXES are needed now; a matched track is re-predicted inside its update (MOT_KF_PREDICT_FIRST)
+    S.pred_flags[i] = ((S.t_state[slot] != Tracked) ? MOT_KF_ZERO_V7 : 0) | MOT_KF_NO_STORE;
   }
   if (t == 0) {
     S.n_high = nh; S.n_second = ns; S.n_pool = np; S.n_tracked = n_tracked; S.n_unconf = nu;
@@ -167,7 +168,8 @@ __global__ void __launch_bounds__(kW) bt_after_first(BtStream* streams, BtParams
     const int pu = compact(m, n_upd);
     if (m) {
       const int det = S.high[x];
-      S.upd_src[pu] = CAP + i; S.upd_dst[pu] = slot; S.upd_meas[pu] = det;
+      S.upd_src[pu] = slot; S.upd_dst[pu] = slot; S.upd_meas[pu] = det;
+      S.upd_flags[pu] = (S.pred_flags[i] & MOT_KF_ZERO_V7) | MOT_KF_PREDICT_FIRST;  // the update starts from the PREDICTED copy (:251-265)
       // STrack::update :71-89 / re_activate :55-69
       if (was_tracked) { S.t_fid[slot] = S.frame_count; S.t_tlen[slot] += 1; }
       else { S.t_tlen[slot] = 0; S.t_fid[slot] = S.frame_count; }
@@ -238,7 +240,8 @@ __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParam
       const int pu = compact(m, n_upd);
       if (m) {
         const int det = S.second[j];
-        S.upd_src[pu] = CAP + S.r_pool[i]; S.upd_dst[pu] = slot; S.upd_meas[pu] = det;
+        S.upd_src[pu] = slot; S.upd_dst[pu] = slot; S.upd_meas[pu] = det;
+        S.upd_flags[pu] = (S.pred_flags[S.r_pool[i]] & MOT_KF_ZERO_V7) | MOT_KF_PREDICT_FIRST;
         S.t_fid[slot] = S.frame_count; S.t_tlen[slot] += 1;  // state is Tracked here
         S.t_state[slot] = Tracked; S.t_act[slot] = 1;
         S.t_conf[slot] = S.dets[static_cast<size_t>(4) * S.ld + det];
@@ -274,6 +277,7 @@ __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParam
       if (m) {
         const int det = S.high[S.u_det[j]];
         S.upd_src[pu] = slot; S.upd_dst[pu] = slot; S.upd_meas[pu] = det;  // un-predicted state (:524-527)
+        S.upd_flags[pu] = 0;
         if (S.t_state[slot] == Tracked) { S.t_fid[slot] = S.frame_count; S.t_tlen[slot] += 1; }
         else { S.t_tlen[slot] = 0; S.t_fid[slot] = S.frame_count; }
         S.t_state[slot] = Tracked; S.t_act[slot] = 1;
@@ -537,11 +541,11 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   b->prm.min_conf = min_conf; b->prm.track_thresh = track_thresh; b->prm.match_thresh = match_thresh;
   b->prm.det_thresh = track_thresh;                                                    // bytetrack.cpp:145
   b->prm.max_time_lost = static_cast<int>(frame_rate / 30.0f * track_buffer);           // :141-142
-  const int S = nstreams, CAP = cap_tracks, D = max_dets, C2 = 2 * cap_tracks;
+  const int S = nstreams, CAP = cap_tracks, D = max_dets, C2 = cap_tracks;  // (no scratch slots: predictions are box-only)
   const size_t ints_per = static_cast<size_t>(CAP) * 28 + static_cast<size_t>(D) * 9;
   int* ip = b->dalloc<int>(ints_per * S);
   float* fp = b->dalloc<float>((static_cast<size_t>(CAP) * (1 + 4 * 5) + static_cast<size_t>(D) * 8) * S);
-  unsigned char* bp = b->dalloc<unsigned char>(static_cast<size_t>(CAP) * 3 * S);
+  unsigned char* bp = b->dalloc<unsigned char>(static_cast<size_t>(CAP) * 4 * S);
   b->mean = b->dalloc<float>(static_cast<size_t>(S) * 8 * C2);
   b->cov = b->dalloc<float>(static_cast<size_t>(S) * 64 * C2);
   b->d_streams = b->dalloc<BtStream>(S);
@@ -586,8 +590,8 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
     float* pool_box = F(4 * CAP); float* rbox = F(4 * CAP); float* ubox = F(4 * CAP); T.abox = F(4 * CAP); float* lbox = F(4 * CAP);
     T.lbox = lbox;
     float* d_box = F(4 * D); float* d_meas = F(4 * D);
-    unsigned char* u = bp + static_cast<size_t>(CAP) * 3 * s;
-    T.pred_flags = u; T.dup_a = u + CAP; T.dup_b = u + 2 * CAP;
+    unsigned char* u = bp + static_cast<size_t>(CAP) * 4 * s;
+    T.pred_flags = u; T.dup_a = u + CAP; T.dup_b = u + 2 * CAP; T.upd_flags = u + 3 * CAP;
     float* mean = b->mean + static_cast<size_t>(s) * 8 * C2;
     float* cov = b->cov + static_cast<size_t>(s) * 64 * C2;
     // ---- static parts of the task descriptors ----
@@ -599,6 +603,7 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
     kf(box[2 * s + 1]); box[2 * s + 1].src = T.unconf_slot; box[2 * s + 1].boxes = ubox; box[2 * s + 1].ldb = CAP;
     kf(init[s]); init[s].src = T.init_dst; init[s].dst = T.init_dst; init[s].meas = d_meas; init[s].ldm = D; init[s].midx = T.init_meas;
     kf(upd[s]); upd[s].src = T.upd_src; upd[s].dst = T.upd_dst; upd[s].meas = d_meas; upd[s].ldm = D; upd[s].midx = T.upd_meas;
+    upd[s].flags = T.upd_flags;
     kf(box2[2 * s]); box2[2 * s].boxes = T.abox; box2[2 * s].ldb = CAP;
     kf(box2[2 * s + 1]); box2[2 * s + 1].boxes = lbox; box2[2 * s + 1].ldb = CAP;
     auto lap = [&](mot_lap_task& L, int k, int* x, int* y, const float* a, const int* bidx, const float* bconf, int mode, float thresh) {
@@ -726,7 +731,7 @@ int mot_bt_dump(mot_bt_batch* b, int s, int* ids, float* mean, float* cov, int c
   if (h.n_active) BT_HIP(b, hipMemcpyAsync(slots.data(), h.active[h.cur], sizeof(int) * h.n_active, hipMemcpyDeviceToHost, st));
   if (h.n_lost) BT_HIP(b, hipMemcpyAsync(slots.data() + h.n_active, h.lost[h.cur], sizeof(int) * h.n_lost, hipMemcpyDeviceToHost, st));
   BT_HIP(b, hipMemcpyAsync(tid.data(), h.t_id, sizeof(int) * b->CAP, hipMemcpyDeviceToHost, st));
-  const int C2 = 2 * b->CAP;
+  const int C2 = b->CAP;
   std::vector<float> m(static_cast<size_t>(8) * C2), c(static_cast<size_t>(64) * C2);
   BT_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 8 * C2, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
   BT_HIP(b, hipMemcpyAsync(c.data(), b->cov + static_cast<size_t>(s) * 64 * C2, sizeof(float) * c.size(), hipMemcpyDeviceToHost, st));

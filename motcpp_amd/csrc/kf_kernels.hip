@@ -361,6 +361,7 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
   const int src = T.src ? T.src[i] : i;
   const int dst = T.dst ? T.dst[i] : src;
   St<D> s;
+  bool no_store = false;
   float z[4] = {0.f, 0.f, 0.f, 0.f};
   if (OP == OP_INIT || OP == OP_UPDATE) {
     const int c = T.midx ? T.midx[i] : i;
@@ -384,10 +385,20 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
         s8_predict<KIND>(s);
       }
     } else {
+      if (f & MOT_KF_PREDICT_FIRST) {
+        if constexpr (KIND == MOT_KF_XYSR) {
+          if ((f & MOT_KF_OCSORT_CLAMP) && (s.m[6] + s.m[2]) <= 0.0f) s.m[6] = 0.0f;
+          xysr_predict(s, T.q);
+        } else {
+          if (f & MOT_KF_ZERO_V7) s.m[7] = 0.0f;
+          s8_predict<KIND>(s);
+        }
+      }
       if constexpr (KIND == MOT_KF_XYSR) xysr_update(s, z); else s8_update<KIND>(s, z);
     }
+    no_store = (OP == OP_PREDICT) && (f & MOT_KF_NO_STORE);
   }
-  if (OP != OP_BOXES) store_state<D>(s, T.mean, T.cov, T.cap, dst);
+  if (OP != OP_BOXES && !no_store) store_state<D>(s, T.mean, T.cov, T.cap, dst);
   if (T.boxes) {
     float b[4];
     if constexpr (KIND == MOT_KF_XYSR) xysr_box(s, b); else s8_box<KIND>(s, b);

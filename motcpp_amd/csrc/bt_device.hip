@@ -390,16 +390,29 @@ __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParam
 // ---- duplicate marking (remove_duplicate_stracks :659-706): iou_distance(active, lost) < 0.15 -> the younger one goes.
 // Same pair arithmetic as the N x M cost kernel (cost_math.hpp), one workgroup per stream over its own na x nl pairs
 // (a launch of the tiled cost kernel over the capacity bound spends 0.5 ms on tiles that exit at once).
+template <bool STAGED>  // STAGED: the boxes of both lists are copied to LDS once (they must fit in the launch's dynamic LDS)
 __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP) {
+  extern __shared__ float sbox[];  // [4][na] active boxes, [4][nl] lost boxes
   BtStream& S = streams[blockIdx.x];
   const int na = S.n_active, nl = S.n_lost;
   if (na <= 0 || nl <= 0) return;
+  const float* sa = S.abox;
+  const float* sl = S.lbox;
+  int lda = CAP, ldl = CAP;
+  if constexpr (STAGED) {
+    float* wa = sbox;
+    float* wl = sbox + 4 * na;
+    for (int i = threadIdx.x; i < 4 * na; i += 256) wa[i] = S.abox[static_cast<size_t>(i / na) * CAP + (i % na)];
+    for (int i = threadIdx.x; i < 4 * nl; i += 256) wl[i] = S.lbox[static_cast<size_t>(i / nl) * CAP + (i % nl)];
+    __syncthreads();
+    sa = wa; sl = wl; lda = na; ldl = nl;
+  }
   const int total = na * nl;
   for (int p = threadIdx.x; p < total; p += 256) {
     const int i = p / nl, j = p - i * nl;
     float a[4], b[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { a[k] = S.abox[static_cast<size_t>(k) * CAP + i]; b[k] = S.lbox[static_cast<size_t>(k) * CAP + j]; }
+    for (int k = 0; k < 4; ++k) { a[k] = sa[static_cast<size_t>(k) * lda + i]; b[k] = sl[static_cast<size_t>(k) * ldl + j]; }
     const float iou = mot::iou_pair(a, (a[2] - a[0]) * (a[3] - a[1]), b, (b[2] - b[0]) * (b[3] - b[1]));
     if (1.0f - iou < 0.15f) {
       if (S.age_a[i] > S.age_b[j]) S.dup_b[j] = 1;
@@ -673,7 +686,11 @@ int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float
   BT_HIP(b, mot::launch_kf_op(0, MOT_KF_XYAH, b->init_t, S, bd, st));
   BT_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, bn, st));
   BT_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, bn2, st));
-  hipLaunchKernelGGL(bt_dups, dim3(S), dim3(256), 0, st, b->d_streams, CAP);
+  {
+    const size_t lds = static_cast<size_t>(8) * bn2 * sizeof(float);  // na, nl <= bn2
+    if (lds <= 48 * 1024) hipLaunchKernelGGL(bt_dups<true>, dim3(S), dim3(256), lds, st, b->d_streams, CAP);
+    else hipLaunchKernelGGL(bt_dups<false>, dim3(S), dim3(256), 0, st, b->d_streams, CAP);
+  }
   hipLaunchKernelGGL(bt_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);
   hipLaunchKernelGGL(bt_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
   if (prof) BT_HIP(b, hipEventRecord(b->ev[5], st));

@@ -10,27 +10,17 @@
 // slots in the reference's list order, and every "for ... push_back" of the reference becomes an order-preserving
 // wavefront compaction (ballot + popcount prefix). Sizes are fixed at creation (cap_tracks, max_dets); exceeding them
 // raises the stream's error flag instead of reallocating.
-#include <hip/hip_runtime.h>
-
 #include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
 
-#include "../../include/motcpp_amd.h"
-
-#include "ctx.hpp"
+#include "lifecycle_common.hpp"
 #include "cost_math.hpp"
 
-namespace mot {
-hipError_t launch_kf_op(int op, int kind, const mot_kf_task*, int, int, hipStream_t);
-hipError_t launch_det(int kind, const mot_det_task*, int, int, hipStream_t);
-hipError_t launch_iou(const mot_iou_task*, int, int, int, bool, hipStream_t);
-hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, hipStream_t);
-size_t lap_scratch_bytes(int n, int m);
-}  // namespace mot
-
 namespace {
+using mot::lifecycle::compact;
+using mot::lifecycle::kW;
 
 enum St { New = 0, Tracked = 1, Lost = 2, Removed = 3 };
 
@@ -69,23 +59,14 @@ struct BtStream {
   float* lbox;  // [4][CAP] boxes of the new lost list (duplicate test)
 };
 
-constexpr int kW = 64;  // one wavefront per stream
 
-__device__ __forceinline__ int lane_id() { return threadIdx.x; }
-// order-preserving append of the lanes whose pred holds; `base` (uniform) advances
-__device__ __forceinline__ int compact(bool pred, int& base) {
-  const unsigned long long m = __ballot(pred);
-  const int pos = base + __popcll(m & ((1ull << lane_id()) - 1ull));
-  base += __popcll(m);
-  return pos;
-}
 
 // ---- K0: detection split, pools, predict + first-association tasks (bytetrack.cpp:166-265) ----
 // stats[0] = assignment problems queued, stats[1] = sum of their n + m (algorithmic bytes of the solver: 24 B per row/column)
 __global__ void __launch_bounds__(kW) bt_begin(BtStream* streams, BtParams P, int CAP, int D, const int* counts, const float* dets_base,
                                                 mot_det_task* det_t, mot_kf_task* pred_t, mot_lap_task* lap1_t, unsigned long long* stats) {
   BtStream& S = streams[blockIdx.x];
-  const int t = lane_id();
+  const int t = static_cast<int>(threadIdx.x);
   const int n = counts[blockIdx.x];
   const float* dets = dets_base + static_cast<size_t>(blockIdx.x) * 6 * D;
   if (t == 0) {
@@ -154,7 +135,7 @@ __global__ void __launch_bounds__(kW) bt_begin(BtStream* streams, BtParams P, in
 __global__ void __launch_bounds__(kW) bt_after_first(BtStream* streams, BtParams P, int CAP, mot_kf_task* box_t, mot_lap_task* lap23_t,
                                                       unsigned long long* stats) {
   BtStream& S = streams[blockIdx.x];
-  const int t = lane_id();
+  const int t = static_cast<int>(threadIdx.x);
   const int np = S.n_pool, nd = S.n_high;
   const bool have = np > 0 && nd > 0;
   int n_upd = 0, n_ref = 0, n_ut = 0, n_ud = 0;
@@ -228,7 +209,7 @@ __global__ void __launch_bounds__(kW) bt_after_first(BtStream* streams, BtParams
 __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParams P, int CAP, mot_kf_task* init_t, mot_kf_task* upd_t,
                                                        mot_kf_task* box2_t, mot_iou_task* dup_t) {
   BtStream& S = streams[blockIdx.x];
-  const int t = lane_id();
+  const int t = static_cast<int>(threadIdx.x);
   int n_upd = S.n_upd, n_ln = 0;
   if (S.lap2_q) {
     for (int i0 = 0; i0 < S.n_r; i0 += kW) {
@@ -424,7 +405,7 @@ __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP) {
 // ---- K3: duplicate removal and the output table (:582-621, :659-706) ----
 __global__ void __launch_bounds__(kW) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks) {
   BtStream& S = streams[blockIdx.x];
-  const int t = lane_id();
+  const int t = static_cast<int>(threadIdx.x);
   int* act = S.active[S.cur];
   int* lst = S.lost[S.cur];
   float* rows = out + static_cast<size_t>(blockIdx.x) * cap_out * 8;
@@ -492,7 +473,7 @@ struct mot_bt_batch {
   mot_ctx* ctx = nullptr;
   int S = 0, CAP = 0, D = 0;
   BtParams prm{};
-  std::vector<void*> allocs;
+  mot::lifecycle::Allocs mem;
   BtStream* d_streams = nullptr;
   std::vector<BtStream> h_streams;  // host mirror of the pointers (scalars are only valid on the device)
   int* d_counts = nullptr;
@@ -512,25 +493,15 @@ struct mot_bt_batch {
   double lap_ms[2] = {0.0, 0.0}, frame_ms = 0.0;
   long frames = 0;
   template <class T>
-  T* dalloc(size_t n) {
-    void* p = nullptr;
-    if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
-    allocs.push_back(p);
-    return static_cast<T*>(p);
-  }
+  T* dalloc(size_t n) { return mem.get<T>(n); }
 };
 
-#define BT_HIP(b, call)                                                                                  \
-  do {                                                                                                   \
-    hipError_t e_ = (call);                                                                              \
-    if (e_ != hipSuccess) { (b)->ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return MOT_ERR_HIP; } \
-  } while (0)
 
 extern "C" {
 
 void mot_bt_destroy(mot_bt_batch* b) {
   if (!b) return;
-  for (void* p : b->allocs) (void)hipFree(p);
+  b->mem.release();
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   delete b;
 }
@@ -538,9 +509,9 @@ void mot_bt_destroy(mot_bt_batch* b) {
 int mot_bt_reset(mot_bt_batch* b) {
   // scalars back to zero; the arrays need no clearing (everything is rebuilt from the empty lists)
   std::vector<BtStream> h = b->h_streams;
-  BT_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(BtStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
-  BT_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
-  BT_HIP(b, hipStreamSynchronize(b->ctx->stream));
+  MOT_LC_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(BtStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
+  MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
+  MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
   b->bound_n = 0;
   return MOT_OK;
 }
@@ -641,12 +612,12 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   }
   b->h_streams = hs;
   hipStream_t st = ctx->stream;
-#define BT_UP(dst, vec) BT_HIP(b, hipMemcpyAsync(dst, vec.data(), sizeof(vec[0]) * vec.size(), hipMemcpyHostToDevice, st))
+#define BT_UP(dst, vec) MOT_LC_HIP(b, hipMemcpyAsync(dst, vec.data(), sizeof(vec[0]) * vec.size(), hipMemcpyHostToDevice, st))
   BT_UP(b->d_streams, hs); BT_UP(b->det_t, det); BT_UP(b->pred_t, pred); BT_UP(b->box_t, box); BT_UP(b->init_t, init); BT_UP(b->upd_t, upd);
   BT_UP(b->box2_t, box2); BT_UP(b->lap1_t, lap1); BT_UP(b->lap23_t, lap23); BT_UP(b->dup_t, dup);
 #undef BT_UP
-  BT_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), st));
-  BT_HIP(b, hipStreamSynchronize(st));
+  MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
   *out = b;
   return MOT_OK;
 }
@@ -660,8 +631,8 @@ int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float
     if (!b->d_out || !b->d_out_counts) return MOT_ERR_NOMEM;
     b->out_cap = cap_out;
   }
-  BT_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
-  BT_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
+  MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
   // Launch bounds (grid sizes, the solver's LDS layout and variant) from exact upper bounds instead of the capacities:
   // no side of any problem of this frame exceeds the tracks alive after the previous frame (bn) / this frame's detections (bd)
   int bd = 1;
@@ -670,22 +641,22 @@ int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float
   const int bn = (b->bound_n < 1) ? 1 : (b->bound_n > CAP ? CAP : b->bound_n);
   const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;  // lists after this frame's births
   const bool prof = b->profile;
-  if (prof) BT_HIP(b, hipEventRecord(b->ev[0], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[0], st));
   hipLaunchKernelGGL(bt_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr);
-  BT_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, bd, st));
-  BT_HIP(b, mot::launch_kf_op(1, MOT_KF_XYAH, b->pred_t, S, bn, st));
-  if (prof) BT_HIP(b, hipEventRecord(b->ev[1], st));
-  BT_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, st));
-  if (prof) BT_HIP(b, hipEventRecord(b->ev[2], st));
+  MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, bd, st));
+  MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYAH, b->pred_t, S, bn, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
+  MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[2], st));
   hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr);
-  BT_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, bn, st));
-  if (prof) BT_HIP(b, hipEventRecord(b->ev[3], st));
-  BT_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, st));
-  if (prof) BT_HIP(b, hipEventRecord(b->ev[4], st));
+  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, bn, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[3], st));
+  MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[4], st));
   hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t);
-  BT_HIP(b, mot::launch_kf_op(0, MOT_KF_XYAH, b->init_t, S, bd, st));
-  BT_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, bn, st));
-  BT_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, bn2, st));
+  MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYAH, b->init_t, S, bd, st));
+  MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, bn, st));
+  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, bn2, st));
   {
     const size_t lds = static_cast<size_t>(8) * bn2 * sizeof(float);  // na, nl <= bn2
     if (lds <= 48 * 1024) hipLaunchKernelGGL(bt_dups<true>, dim3(S), dim3(256), lds, st, b->d_streams, CAP);
@@ -693,22 +664,22 @@ int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float
   }
   hipLaunchKernelGGL(bt_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);
   hipLaunchKernelGGL(bt_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
-  if (prof) BT_HIP(b, hipEventRecord(b->ev[5], st));
-  BT_HIP(b, hipGetLastError());
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[5], st));
+  MOT_LC_HIP(b, hipGetLastError());
   int err = 0;
-  BT_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
-  BT_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
-  BT_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   int maxt[64];
-  BT_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
-  BT_HIP(b, hipStreamSynchronize(st));
+  MOT_LC_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
   if (prof) {
     float ms = 0.f;
-    BT_HIP(b, hipEventElapsedTime(&ms, b->ev[1], b->ev[2])); b->lap_ms[0] += ms;
-    BT_HIP(b, hipEventElapsedTime(&ms, b->ev[3], b->ev[4])); b->lap_ms[1] += ms;
-    BT_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[5])); b->frame_ms += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[1], b->ev[2])); b->lap_ms[0] += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[3], b->ev[4])); b->lap_ms[1] += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[5])); b->frame_ms += ms;
     b->frames += 1;
   }
   if (err) { b->ctx->err = "mot_bt_step: a stream exceeded cap_tracks / max_dets / cap_out"; return MOT_ERR_CAPACITY; }
@@ -720,15 +691,15 @@ int mot_bt_profile(mot_bt_batch* b, int enable) {
   if (enable) {
     b->lap_ms[0] = b->lap_ms[1] = b->frame_ms = 0.0;
     b->frames = 0;
-    BT_HIP(b, hipMemsetAsync(b->d_stats, 0, 4 * 64 * sizeof(unsigned long long), b->ctx->stream));
-    BT_HIP(b, hipStreamSynchronize(b->ctx->stream));
+    MOT_LC_HIP(b, hipMemsetAsync(b->d_stats, 0, 4 * 64 * sizeof(unsigned long long), b->ctx->stream));
+    MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
   }
   return MOT_OK;
 }
 
 int mot_bt_profile_stats(mot_bt_batch* b, double* out8) {
   unsigned long long raw[4 * 64];
-  BT_HIP(b, hipMemcpy(raw, b->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
+  MOT_LC_HIP(b, hipMemcpy(raw, b->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
   unsigned long long h[4] = {0, 0, 0, 0};
   for (int i = 0; i < 64; ++i)
     for (int k = 0; k < 4; ++k) h[k] += raw[i * 4 + k];
@@ -740,19 +711,19 @@ int mot_bt_profile_stats(mot_bt_batch* b, double* out8) {
 int mot_bt_dump(mot_bt_batch* b, int s, int* ids, float* mean, float* cov, int cap) {
   hipStream_t st = b->ctx->stream;
   BtStream h;
-  BT_HIP(b, hipMemcpyAsync(&h, b->d_streams + s, sizeof(BtStream), hipMemcpyDeviceToHost, st));
-  BT_HIP(b, hipStreamSynchronize(st));
+  MOT_LC_HIP(b, hipMemcpyAsync(&h, b->d_streams + s, sizeof(BtStream), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
   const int n = h.n_active + h.n_lost;
   if (n > cap) return -n;
   std::vector<int> slots(n), tid(b->CAP);
-  if (h.n_active) BT_HIP(b, hipMemcpyAsync(slots.data(), h.active[h.cur], sizeof(int) * h.n_active, hipMemcpyDeviceToHost, st));
-  if (h.n_lost) BT_HIP(b, hipMemcpyAsync(slots.data() + h.n_active, h.lost[h.cur], sizeof(int) * h.n_lost, hipMemcpyDeviceToHost, st));
-  BT_HIP(b, hipMemcpyAsync(tid.data(), h.t_id, sizeof(int) * b->CAP, hipMemcpyDeviceToHost, st));
+  if (h.n_active) MOT_LC_HIP(b, hipMemcpyAsync(slots.data(), h.active[h.cur], sizeof(int) * h.n_active, hipMemcpyDeviceToHost, st));
+  if (h.n_lost) MOT_LC_HIP(b, hipMemcpyAsync(slots.data() + h.n_active, h.lost[h.cur], sizeof(int) * h.n_lost, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(tid.data(), h.t_id, sizeof(int) * b->CAP, hipMemcpyDeviceToHost, st));
   const int C2 = b->CAP;
   std::vector<float> m(static_cast<size_t>(8) * C2), c(static_cast<size_t>(64) * C2);
-  BT_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 8 * C2, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
-  BT_HIP(b, hipMemcpyAsync(c.data(), b->cov + static_cast<size_t>(s) * 64 * C2, sizeof(float) * c.size(), hipMemcpyDeviceToHost, st));
-  BT_HIP(b, hipStreamSynchronize(st));
+  MOT_LC_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 8 * C2, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(c.data(), b->cov + static_cast<size_t>(s) * 64 * C2, sizeof(float) * c.size(), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
   for (int i = 0; i < n; ++i) {
     const int sl = slots[i];
     ids[i] = tid[sl];

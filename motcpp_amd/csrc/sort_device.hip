@@ -3,23 +3,16 @@
 // "for ... push_back" an order-preserving wavefront compaction, a frame a fixed sequence of launches for all streams:
 //   sort_begin -> det_prepare, kf_predict (in place) -> sort_assoc (NaN rule) -> lap -> sort_apply -> kf_initiate,
 //   kf_update, kf_boxes -> sort_emit, then one copy of the output tables.
-#include <hip/hip_runtime.h>
-
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
 
-#include "../../include/motcpp_amd.h"
-#include "ctx.hpp"
-
-namespace mot {
-hipError_t launch_kf_op(int op, int kind, const mot_kf_task*, int, int, hipStream_t);
-hipError_t launch_det(int kind, const mot_det_task*, int, int, hipStream_t);
-hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, hipStream_t);
-size_t lap_scratch_bytes(int n, int m);
-}  // namespace mot
+#include "lifecycle_common.hpp"
 
 namespace {
+using mot::lifecycle::compact;
+using mot::lifecycle::kW;
 
 struct SortParams {
   float det_thresh, iou_thr;
@@ -45,13 +38,6 @@ struct SortStream {
   float* obox;  // [4][CAP] boxes of the rows to emit
 };
 
-constexpr int kW = 64;
-__device__ __forceinline__ int compact(bool pred, int& base) {
-  const unsigned long long m = __ballot(pred);
-  const int pos = base + __popcll(m & ((1ull << threadIdx.x) - 1ull));
-  base += __popcll(m);
-  return pos;
-}
 
 // detections with conf >= det_thresh (:112-120), ++age / ++time_since_update of every track (SortTrack::predict :43-51)
 __global__ void __launch_bounds__(kW) sort_begin(SortStream* streams, SortParams P, int CAP, int D, const int* counts, const float* dets_base,
@@ -246,7 +232,7 @@ struct mot_sort_batch {
   mot_ctx* ctx = nullptr;
   int S = 0, CAP = 0, D = 0;
   SortParams prm{};
-  std::vector<void*> allocs;
+  mot::lifecycle::Allocs mem;
   SortStream* d_streams = nullptr;
   std::vector<SortStream> h_streams;
   int *d_counts = nullptr, *d_err = nullptr, *d_maxt = nullptr;
@@ -262,36 +248,26 @@ struct mot_sort_batch {
   long frames = 0;
   unsigned long long* d_stats = nullptr;  // [64][2]: problems, sum of n + m
   template <class T>
-  T* dalloc(size_t n) {
-    void* p = nullptr;
-    if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
-    allocs.push_back(p);
-    return static_cast<T*>(p);
-  }
+  T* dalloc(size_t n) { return mem.get<T>(n); }
 };
 
-#define SD_HIP(b, call)                                                                                  \
-  do {                                                                                                   \
-    hipError_t e_ = (call);                                                                              \
-    if (e_ != hipSuccess) { (b)->ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return MOT_ERR_HIP; } \
-  } while (0)
 
 extern "C" {
 
 void mot_sort_destroy(mot_sort_batch* b) {
   if (!b) return;
-  for (void* p : b->allocs) (void)hipFree(p);
+  b->mem.release();
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   delete b;
 }
 
 int mot_sort_reset(mot_sort_batch* b) {  // sort.cpp:97-100: the tracks go, the id counter keeps counting
   std::vector<SortStream> cur(b->S);
-  SD_HIP(b, hipMemcpy(cur.data(), b->d_streams, sizeof(SortStream) * b->S, hipMemcpyDeviceToHost));
+  MOT_LC_HIP(b, hipMemcpy(cur.data(), b->d_streams, sizeof(SortStream) * b->S, hipMemcpyDeviceToHost));
   std::vector<SortStream> h = b->h_streams;
   for (int s = 0; s < b->S; ++s) h[s].next_id = cur[s].next_id;
-  SD_HIP(b, hipMemcpy(b->d_streams, h.data(), sizeof(SortStream) * b->S, hipMemcpyHostToDevice));
-  SD_HIP(b, hipMemset(b->d_err, 0, sizeof(int)));
+  MOT_LC_HIP(b, hipMemcpy(b->d_streams, h.data(), sizeof(SortStream) * b->S, hipMemcpyHostToDevice));
+  MOT_LC_HIP(b, hipMemset(b->d_err, 0, sizeof(int)));
   b->bound_n = 0;
   return MOT_OK;
 }
@@ -367,12 +343,12 @@ int mot_sort_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, co
   }
   b->h_streams = hs;
   hipStream_t st = ctx->stream;
-#define SD_UP(dst, vec) SD_HIP(b, hipMemcpyAsync(dst, vec.data(), sizeof(vec[0]) * vec.size(), hipMemcpyHostToDevice, st))
+#define SD_UP(dst, vec) MOT_LC_HIP(b, hipMemcpyAsync(dst, vec.data(), sizeof(vec[0]) * vec.size(), hipMemcpyHostToDevice, st))
   SD_UP(b->d_streams, hs); SD_UP(b->det_t, det); SD_UP(b->pred_t, pred); SD_UP(b->init_t, init); SD_UP(b->upd_t, upd); SD_UP(b->box_t, box);
   SD_UP(b->lap_t, lap);
 #undef SD_UP
-  SD_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), st));
-  SD_HIP(b, hipStreamSynchronize(st));
+  MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
   *out = b;
   return MOT_OK;
 }
@@ -386,42 +362,42 @@ int mot_sort_step(mot_sort_batch* b, const float* d_dets, const int* h_counts, f
     if (!b->d_out || !b->d_out_counts) return MOT_ERR_NOMEM;
     b->out_cap = cap_out;
   }
-  SD_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
-  SD_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
+  MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
   int bd = 1;
   for (int s = 0; s < S; ++s) bd = (h_counts[s] > bd) ? h_counts[s] : bd;
   if (bd > D) bd = D;
   const int bn = (b->bound_n < 1) ? 1 : (b->bound_n > CAP ? CAP : b->bound_n);  // tracks alive after the previous frame
   const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;
   const bool prof = b->profile;
-  if (prof) SD_HIP(b, hipEventRecord(b->ev[0], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[0], st));
   hipLaunchKernelGGL(sort_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t);
-  SD_HIP(b, mot::launch_det(MOT_DET_XYSR, b->det_t, S, bd, st));
-  SD_HIP(b, mot::launch_kf_op(1, MOT_KF_XYSR, b->pred_t, S, bn, st));
+  MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYSR, b->det_t, S, bd, st));
+  MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYSR, b->pred_t, S, bn, st));
   hipLaunchKernelGGL(sort_assoc, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->lap_t, prof ? b->d_stats : nullptr);
-  if (prof) SD_HIP(b, hipEventRecord(b->ev[1], st));
-  SD_HIP(b, mot::launch_lap(b->lap_t, S, bn, bd, true, false, st));
-  if (prof) SD_HIP(b, hipEventRecord(b->ev[2], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
+  MOT_LC_HIP(b, mot::launch_lap(b->lap_t, S, bn, bd, true, false, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[2], st));
   hipLaunchKernelGGL(sort_apply, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box_t);
-  SD_HIP(b, mot::launch_kf_op(0, MOT_KF_XYSR, b->init_t, S, bd, st));
-  SD_HIP(b, mot::launch_kf_op(2, MOT_KF_XYSR, b->upd_t, S, bn, st));
-  SD_HIP(b, mot::launch_kf_op(3, MOT_KF_XYSR, b->box_t, S, bn2, st));
+  MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYSR, b->init_t, S, bd, st));
+  MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYSR, b->upd_t, S, bn, st));
+  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYSR, b->box_t, S, bn2, st));
   hipLaunchKernelGGL(sort_emit, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);
   hipLaunchKernelGGL(sort_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
-  if (prof) SD_HIP(b, hipEventRecord(b->ev[3], st));
-  SD_HIP(b, hipGetLastError());
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[3], st));
+  MOT_LC_HIP(b, hipGetLastError());
   int err = 0, maxt[64];
-  SD_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
-  SD_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
-  SD_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  SD_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
-  SD_HIP(b, hipStreamSynchronize(st));
+  MOT_LC_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
   if (prof) {
     float ms = 0.f;
-    SD_HIP(b, hipEventElapsedTime(&ms, b->ev[1], b->ev[2])); b->lap_ms += ms;
-    SD_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[3])); b->frame_ms += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[1], b->ev[2])); b->lap_ms += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[3])); b->frame_ms += ms;
     b->frames += 1;
   }
   if (err) { b->ctx->err = "mot_sort_step: a stream exceeded cap_tracks / max_dets / cap_out"; return MOT_ERR_CAPACITY; }
@@ -433,13 +409,13 @@ int mot_sort_profile(mot_sort_batch* b, int enable) {
   if (enable) {
     b->lap_ms = b->frame_ms = 0.0;
     b->frames = 0;
-    SD_HIP(b, hipMemset(b->d_stats, 0, 128 * sizeof(unsigned long long)));
+    MOT_LC_HIP(b, hipMemset(b->d_stats, 0, 128 * sizeof(unsigned long long)));
   }
   return MOT_OK;
 }
 int mot_sort_profile_stats(mot_sort_batch* b, double* out8) {
   unsigned long long raw[128];
-  SD_HIP(b, hipMemcpy(raw, b->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
+  MOT_LC_HIP(b, hipMemcpy(raw, b->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
   unsigned long long pr = 0, nm = 0;
   for (int i = 0; i < 64; ++i) { pr += raw[2 * i]; nm += raw[2 * i + 1]; }
   out8[0] = b->lap_ms; out8[1] = 0.0; out8[2] = b->frame_ms; out8[3] = static_cast<double>(b->frames);
@@ -450,18 +426,18 @@ int mot_sort_profile_stats(mot_sort_batch* b, double* out8) {
 int mot_sort_dump(mot_sort_batch* b, int s, int* ids, float* mean, float* cov, int cap) {
   hipStream_t st = b->ctx->stream;
   SortStream h;
-  SD_HIP(b, hipMemcpyAsync(&h, b->d_streams + s, sizeof(SortStream), hipMemcpyDeviceToHost, st));
-  SD_HIP(b, hipStreamSynchronize(st));
+  MOT_LC_HIP(b, hipMemcpyAsync(&h, b->d_streams + s, sizeof(SortStream), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
   const int n = h.n_trk;
   if (n > cap) return -n;
   std::vector<int> slots(n), tid(b->CAP);
-  if (n) SD_HIP(b, hipMemcpyAsync(slots.data(), h.trk[h.cur], sizeof(int) * n, hipMemcpyDeviceToHost, st));
-  SD_HIP(b, hipMemcpyAsync(tid.data(), h.t_id, sizeof(int) * b->CAP, hipMemcpyDeviceToHost, st));
+  if (n) MOT_LC_HIP(b, hipMemcpyAsync(slots.data(), h.trk[h.cur], sizeof(int) * n, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(tid.data(), h.t_id, sizeof(int) * b->CAP, hipMemcpyDeviceToHost, st));
   const int C = b->CAP;
   std::vector<float> m(static_cast<size_t>(7) * C), c(static_cast<size_t>(49) * C);
-  SD_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 7 * C, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
-  SD_HIP(b, hipMemcpyAsync(c.data(), b->cov + static_cast<size_t>(s) * 49 * C, sizeof(float) * c.size(), hipMemcpyDeviceToHost, st));
-  SD_HIP(b, hipStreamSynchronize(st));
+  MOT_LC_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 7 * C, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(c.data(), b->cov + static_cast<size_t>(s) * 49 * C, sizeof(float) * c.size(), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
   for (int i = 0; i < n; ++i) {
     const int sl = slots[i];
     ids[i] = tid[sl];

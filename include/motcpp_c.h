@@ -26,6 +26,11 @@ void motcpp_tracker_destroy(motcpp_tracker* t);
 int motcpp_tracker_reset(motcpp_tracker* t);
 /* dets: n x 6 [x1,y1,x2,y2,conf,cls]; embs: n x d or NULL; out: cap x 8. Returns rows, or -(rows needed) - 1000000 if cap is too small. */
 int motcpp_tracker_update(motcpp_tracker* t, const float* dets, int n, const float* embs, int d, float* out, int cap);
+/* BoT-SORT: the 2x3 row-major warp the reference's cmc_->apply(img, dets) would return for the NEXT update (applied to
+ * the predicted track states, botsort.cpp:317-324, BotSTrack::multi_gmc :60-91); it is consumed by that update. NULL
+ * withdraws it. The image registration that estimates the warp (ECC/ORB/SOF) stays with the caller. Returns 0, or -1
+ * for the other trackers. A tracker inside a batch takes its warp through motcpp_batch_tracker(b, s). */
+int motcpp_tracker_set_camera_motion(motcpp_tracker* t, const float* warp2x3);
 /* parity hooks: assignments solved during the last update, and the Kalman states of the live tracks */
 int motcpp_tracker_lap_count(motcpp_tracker* t);
 int motcpp_tracker_lap_get(motcpp_tracker* t, int k, int* n, int* m, int* x, int* y, int cap);

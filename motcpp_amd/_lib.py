@@ -154,6 +154,19 @@ class Context:
                                              _p(mean), _p(cov), _p(boxes) if boxes is not None else None))
         return (mean, cov, boxes) if want_boxes else (mean, cov)
 
+    def kf_warp(self, kind, mean, cov, warp9, predict_first=False, q=None, want_boxes=False):
+        """mot_kf_warp on AoS states (predict_first: one predict launch with the warp applied after it)."""
+        mean, cov = f32(mean).copy(), f32(cov).copy()
+        n = mean.shape[0]
+        w = f32(warp9).reshape(9)
+        qq = f32(q) if q is not None else None
+        boxes = np.zeros((n, 4), np.float32) if want_boxes else None
+        self.lib.mot_kf_warp_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
+        self._chk(self.lib.mot_kf_warp_host(self.h, int(kind), n, _p(w), 1 if predict_first else 0, _p(qq) if qq is not None else None,
+                                            _p(mean), _p(cov), _p(boxes) if boxes is not None else None))
+        return (mean, cov, boxes) if want_boxes else (mean, cov)
+
 
 # ---- tracker handles (libmotcpp.so: C++17 host library over the C ABI) ------------------------------------
 SORT, BYTETRACK, OCSORT, BOTSORT = 0, 1, 2, 3
@@ -253,6 +266,14 @@ class Tracker(_Hooks):
 
     def reset(self):
         host().motcpp_tracker_reset(self.h)
+
+    def set_camera_motion(self, warp2x3):
+        """BoT-SORT: 2x3 warp of the next update (BotSTrack::multi_gmc, botsort.cpp:60-91,317-324); None withdraws it."""
+        H = host()
+        H.motcpp_tracker_set_camera_motion.argtypes = [C.c_void_p, C.c_void_p]
+        w = f32(warp2x3).reshape(6) if warp2x3 is not None else None
+        if H.motcpp_tracker_set_camera_motion(self.h, _p(w) if w is not None else None) != 0:
+            raise MotError(H.motcpp_last_error().decode())
 
     def update(self, dets, embs=None):
         dets = f32(dets).reshape(-1, 6)

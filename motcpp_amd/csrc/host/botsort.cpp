@@ -37,9 +37,20 @@ class BotSortGpu final : public Staged {
     for (const Trk& t : lost_) { ids->push_back(t.id); slots->push_back(t.slot); }
   }
 
+  bool set_camera_motion(const float* w) override {
+    has_warp_ = (w != nullptr);
+    if (w) {  // Matrix3f::Identity() with the top two rows replaced (:320-321)
+      for (int i = 0; i < 6; ++i) warp_[i] = w[i];
+      warp_[6] = 0.0f; warp_[7] = 0.0f; warp_[8] = 1.0f;
+    }
+    return true;
+  }
+
   void begin(const FrameIn& in) override {
     rows_.clear(); laps_.clear();
-    idle_ = (in.n == 0);  // :267-269: nothing happens, not even frame_count++
+    const bool warp_now = has_warp_;  // consumed by this frame, used or not
+    has_warp_ = false;
+    idle_ = (in.n == 0);  // :267-269: nothing happens, not even frame_count++ (nor the CMC step)
     if (idle_) return;
     ++frame_count_;
     stage_ = 0;
@@ -80,13 +91,19 @@ class BotSortGpu final : public Staged {
       t.n = in.n; t.d = D_; t.feat = emb_norm_; t.ldf = D_; t.src = emb_raw_; t.lds = D_; t.mode = 0; t.alpha = 0.9f;
       core_.dev().q().feat_set.push_back(t);
     }
+    if (warp_now && !unconf_.empty()) {  // multi_gmc(unconfirmed) :323 — these are not predicted
+      std::vector<int> us;
+      for (int ai : unconf_) us.push_back(active_[ai].slot);
+      core_.warp(us, warp_);
+    }
     const int np = static_cast<int>(pool_.size());
     lap1_ = Core::Lap();
     pool_box_ = nullptr;
     if (np > 0) {
       std::vector<int> slots(np);
       for (int i = 0; i < np; ++i) slots[i] = trk(pool_[i]).slot;
-      pool_box_ = core_.predict(slots, nullptr, nullptr, nullptr);  // multi_predict :54-58, in place
+      // multi_predict :54-58 in place, then multi_gmc :60-91 on the predicted states when a warp was supplied (:317-324)
+      pool_box_ = core_.predict(slots, nullptr, nullptr, nullptr, warp_now ? warp_ : nullptr);
       if (!first_.empty()) {
         first_d_ = core_.ints(first_);
         lap1_ = queue_assoc(pool_box_, np, nullptr, slots, first_d_, static_cast<int>(first_.size()), fuse_first_ ? 1 : 0, match_);
@@ -312,6 +329,8 @@ class BotSortGpu final : public Staged {
   float* emb_norm_ = nullptr;
   std::vector<Trk> active_, lost_;
   std::vector<PoolRef> pool_;
+  float warp_[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+  bool has_warp_ = false;
   std::vector<int> first_, second_, unconf_, u_det_, r_tracked_, cls_, out_idx_, lost_new_, dead_;
   std::vector<int> upd_slot_, upd_meas_, ema_slot_, ema_det_, set_slot_, set_det_;
   std::vector<float> conf_;

@@ -81,6 +81,11 @@ void motcpp_tracker_destroy(motcpp_tracker* t) { delete t; }
 int motcpp_tracker_reset(motcpp_tracker* t) {
   try { t->impl->reset(); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
+int motcpp_tracker_set_camera_motion(motcpp_tracker* t, const float* warp2x3) {
+  if (t->impl->set_camera_motion(warp2x3)) return 0;
+  g_err = "this tracker has no camera-motion step (BoT-SORT only)";
+  return -1;
+}
 int motcpp_tracker_update(motcpp_tracker* t, const float* dets, int n, const float* embs, int d, float* out, int cap) {
   try {
     to_colmajor(dets, n, t->colmajor);

@@ -47,6 +47,9 @@ class Staged {
   virtual bool advance() = 0;                 // consume the flushed stage, queue the next; false = frame finished
   virtual void reset() = 0;
   virtual Core& core() = 0;
+  // Camera-motion warp (2x3 row-major, what the reference's cmc_->apply(img, dets) returns) for the NEXT frame only;
+  // nullptr withdraws it. false: this tracker has no camera-motion step (only BoT-SORT has, botsort.cpp:317-324).
+  virtual bool set_camera_motion(const float* /*warp2x3*/) { return false; }
   const std::vector<float>& rows() const { return rows_; }  // output rows [x1,y1,x2,y2,id,conf,cls,det_ind]
   const std::vector<LapRecord>& laps() const { return laps_; }
   bool record_laps = true;  // parity hook; switched off for throughput runs

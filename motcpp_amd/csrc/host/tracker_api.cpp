@@ -136,7 +136,10 @@ Eigen::MatrixXf to_matrix(const std::vector<float>& rows) {
 Eigen::MatrixXf DeviceTracker::update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) {
   if (!asso_error_.empty()) throw std::invalid_argument(asso_error_);
   if (validate_inputs_) check_inputs(dets, img, skip_empty_ ? Eigen::MatrixXf() : embs);
-  if (skip_empty_ && dets.rows() == 0) return Eigen::MatrixXf(0, 8);
+  if (skip_empty_ && dets.rows() == 0) {
+    impl_->set_camera_motion(nullptr);  // the reference returns before its CMC step: this frame's warp is dropped
+    return Eigen::MatrixXf(0, 8);
+  }
   setup_detection_format(dets);
   setup_association_function(img);
   ++frame_count_;
@@ -206,6 +209,11 @@ BotSort::BotSort(const std::string& reid_weights, bool /*use_half*/, bool /*use_
   skip_empty_ = true;
   adopt(rt::make_botsort(dev_, track_high_thresh, track_low_thresh, new_track_thresh, track_buffer, match_thresh,
                          proximity_thresh, appearance_thresh, frame_rate, fuse_first_associate, with_reid, max_age_, max_obs_));
+}
+void BotSort::set_camera_motion(const Eigen::MatrixXf& warp) {
+  if (warp.rows() != 2 || warp.cols() != 3) throw std::invalid_argument("BotSort::set_camera_motion: the warp must be 2 x 3");
+  const float w[6] = {warp(0, 0), warp(0, 1), warp(0, 2), warp(1, 0), warp(1, 1), warp(1, 2)};
+  staged()->set_camera_motion(w);
 }
 }  // namespace trackers
 

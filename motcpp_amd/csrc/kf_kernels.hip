@@ -347,10 +347,62 @@ __device__ __forceinline__ void s8_box(const St<8>& s, float b[4]) {
   b[0] = s.m[0] - w * 0.5f; b[1] = s.m[1] - h * 0.5f; b[2] = s.m[0] + w * 0.5f; b[3] = s.m[1] + h * 0.5f;
 }
 
+// ---- camera-motion compensation with a caller-supplied warp W (3x3 row-major) --------------------
+// BotSTrack::multi_gmc, botsort.cpp:60-91: the corners of the state's box through W, then back to cx,cy,w,h.
+__device__ __forceinline__ void s8_warp_xywh(St<8>& s, const float* W) {
+  float b[4];
+  s8_box<MOT_KF_XYWH>(s, b);
+  float p[2][3];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) p[c][r] = W[r * 3] * b[2 * c] + W[r * 3 + 1] * b[2 * c + 1] + W[r * 3 + 2] * 1.0f;
+  const float x1 = p[0][0] / p[0][2], y1 = p[0][1] / p[0][2];
+  const float x2 = p[1][0] / p[1][2], y2 = p[1][1] / p[1][2];
+  const float w = x2 - x1, h = y2 - y1;
+  s.m[0] = x1 + w / 2.0f; s.m[1] = y1 + h / 2.0f; s.m[2] = w; s.m[3] = h;
+}
+// KalmanFilterXYSR::apply_affine_correction, xysr_kf.cpp:114-141: m = W[0:2,0:2], t = W[0:2,2].
+__device__ __forceinline__ void warp_block2(St<7>& s, const float m[2][2], int r0, int c0) {  // P[r0:,c0:] = m * P[r0:,c0:] * m^T
+  float A[2][2], T[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) A[i][j] = s.P[r0 + i][c0 + j];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) T[i][j] = m[i][0] * A[0][j] + m[i][1] * A[1][j];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) s.P[r0 + i][c0 + j] = T[i][0] * m[j][0] + T[i][1] * m[j][1];
+}
+__device__ __forceinline__ void xysr_warp(St<7>& s, const float* W) {
+  const float m[2][2] = {{W[0], W[1]}, {W[3], W[4]}};
+  const float cx = s.m[0], cy = s.m[1], vx = s.m[4], vy = s.m[5];
+  s.m[0] = (m[0][0] * cx + m[0][1] * cy) + W[2];
+  s.m[1] = (m[1][0] * cx + m[1][1] * cy) + W[5];
+  s.m[4] = m[0][0] * vx + m[0][1] * vy;
+  s.m[5] = m[1][0] * vx + m[1][1] * vy;
+  warp_block2(s, m, 0, 0);
+  warp_block2(s, m, 4, 4);
+  warp_block2(s, m, 0, 4);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) s.P[4 + i][j] = s.P[j][4 + i];
+}
+template <int KIND, int D>
+__device__ __forceinline__ void state_warp(St<D>& s, const float* W) {
+  if constexpr (KIND == MOT_KF_XYSR) xysr_warp(s, W);
+  else if constexpr (KIND == MOT_KF_XYWH) s8_warp_xywh(s, W);
+}
+
 template <int KIND> struct Dim { static constexpr int D = 8; };
 template <> struct Dim<MOT_KF_XYSR> { static constexpr int D = 7; };
 
-enum { OP_INIT = 0, OP_PREDICT = 1, OP_UPDATE = 2, OP_BOXES = 3 };
+enum { OP_INIT = 0, OP_PREDICT = 1, OP_UPDATE = 2, OP_BOXES = 3, OP_WARP = 4 };
 
 template <int KIND, int OP>
 __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restrict__ tasks) {
@@ -373,6 +425,9 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
   } else if (OP == OP_BOXES) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) s.m[k] = T.mean[static_cast<size_t>(k) * T.cap + src];
+  } else if (OP == OP_WARP) {
+    load_state<D>(s, T.mean, T.cov, T.cap, src);
+    state_warp<KIND, D>(s, T.warp);
   } else {
     load_state<D>(s, T.mean, T.cov, T.cap, src);
     const unsigned f = T.flags ? T.flags[i] : 0u;
@@ -384,6 +439,7 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
         if (f & MOT_KF_ZERO_V7) s.m[7] = 0.0f;
         s8_predict<KIND>(s);
       }
+      if (T.warp_on) state_warp<KIND, D>(s, T.warp);
     } else {
       if (f & MOT_KF_PREDICT_FIRST) {
         if constexpr (KIND == MOT_KF_XYSR) {
@@ -461,6 +517,7 @@ hipError_t launch_kf_op(int op, int kind, const mot_kf_task* tasks, int ntasks, 
     case OP_PREDICT: return launch_kf<OP_PREDICT>(kind, tasks, ntasks, max_n, st);
     case OP_UPDATE: return launch_kf<OP_UPDATE>(kind, tasks, ntasks, max_n, st);
     case OP_BOXES: return launch_kf<OP_BOXES>(kind, tasks, ntasks, max_n, st);
+    case OP_WARP: return (kind == MOT_KF_XYAH) ? hipErrorInvalidValue : launch_kf<OP_WARP>(kind, tasks, ntasks, max_n, st);
   }
   return hipErrorInvalidValue;
 }

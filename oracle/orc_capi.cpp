@@ -83,6 +83,14 @@ void orc_tracker_reset(void* hv) {
   if (h->bot) h->bot->reset();
 }
 
+// BoT-SORT only: the 2x3 camera-motion warp of the next update() (returns 0, or -1 for the other trackers)
+int orc_tracker_set_warp(void* hv, const float* w2x3) {
+  auto* h = static_cast<Handle*>(hv);
+  if (!h->bot) return -1;
+  h->bot->set_warp(w2x3);
+  return 0;
+}
+
 // dets: row-major n x 6. embs: row-major n x d or null. out: row-major cap x 8. Returns rows (or -needed).
 int orc_tracker_update(void* hv, const float* dets, int n, const float* embs, int d, float* out, int cap) {
   auto* h = static_cast<Handle*>(hv);
@@ -268,6 +276,29 @@ void orc_kf_update(int kind, int n, const float* meas, const float* q, float* me
       store8(s, mean + 8 * t, cov + 64 * t);
     }
   }
+}
+// camera-motion warp of stored states, warp9 = 3x3 row-major: kind 0 KalmanFilterXYSR::apply_affine_correction
+// (m = W[0:2,0:2], t = W[0:2,2]); kind 2 BotSTrack::multi_gmc on the XYWH state. Returns -1 for XYAH (no such step).
+int orc_kf_warp(int kind, int n, const float* warp9, float* mean, float* cov) {
+  if (kind == 1) return -1;
+  for (int t = 0; t < n; ++t) {
+    if (kind == 0) {
+      KfXYSR k; load_xysr(k, mean + 7 * t, cov + 49 * t, nullptr);
+      const float m[2][2] = {{warp9[0], warp9[1]}, {warp9[3], warp9[4]}};
+      const float tr[2] = {warp9[2], warp9[5]};
+      k.apply_affine_correction(m, tr);
+      store_xysr(k, mean + 7 * t, cov + 49 * t);
+    } else {
+      BotSort::BTrack b;
+      b.has_state = true;
+      load8(b.kf, mean + 8 * t, cov + 64 * t);
+      float W[3][3];
+      for (int i = 0; i < 9; ++i) W[i / 3][i % 3] = warp9[i];
+      BotSort::gmc(b, W);
+      store8(b.kf, mean + 8 * t, cov + 64 * t);
+    }
+  }
+  return 0;
 }
 // box conversions exposed for known-answer tests: op 0 xyxy2xysr, 1 xysr2xyxy, 2 xyxy2xywh, 3 xywh2xyxy,
 // 4 xywh2tlwh, 5 tlwh2xyah, 6 xyah2xywh

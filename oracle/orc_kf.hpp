@@ -210,6 +210,25 @@ struct KfXYSR {
     SMat<7, 7> second = mul(mul(K, R), transpose(K));
     P = add(first, second);
   }
+  // apply_affine_correction :114-141 — x[:2] = m x[:2] + t, x[4:6] = m x[4:6], and the position, velocity and
+  // position-velocity blocks of P become m B m^T (the lower-left block is the transpose of the new upper-right one).
+  void apply_affine_correction(const float m[2][2], const float t[2]) {
+    const float cx = x[0], cy = x[1], vx = x[4], vy = x[5];
+    x[0] = (m[0][0] * cx + m[0][1] * cy) + t[0];
+    x[1] = (m[1][0] * cx + m[1][1] * cy) + t[1];
+    x[4] = m[0][0] * vx + m[0][1] * vy;
+    x[5] = m[1][0] * vx + m[1][1] * vy;
+    auto block = [&](int r0, int c0) {
+      float A[2][2], T[2][2];
+      for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) A[i][j] = P[r0 + i][c0 + j];
+      for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) T[i][j] = m[i][0] * A[0][j] + m[i][1] * A[1][j];
+      for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) P[r0 + i][c0 + j] = T[i][0] * m[j][0] + T[i][1] * m[j][1];
+    };
+    block(0, 0);
+    block(4, 4);
+    block(0, 4);
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) P[4 + i][j] = P[j][4 + i];
+  }
 };
 
 // ---------------------------------------------------------------------------------------

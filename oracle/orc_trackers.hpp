@@ -722,6 +722,13 @@ class BotSort {
     max_time_lost_ = static_cast<int>(frame_rate / 30.0f * track_buffer);  // botsort.cpp:236-237
   }
   void reset() { frame_count_ = 0; active_.clear(); lost_.clear(); next_id_ = 0; }  // :252-258
+  // The warp cmc_->apply(img, dets) would return for the next frame (:317-324), supplied by the caller: 2x3 row-major.
+  // It is consumed by the next update(), used or not (an empty frame returns before the CMC step, :267-269).
+  void set_warp(const float w2x3[6]) {
+    for (int i = 0; i < 6; ++i) warp_[i / 3][i % 3] = w2x3[i];
+    warp_[2][0] = 0.0f; warp_[2][1] = 0.0f; warp_[2][2] = 1.0f;  // Matrix3f::Identity() with the top rows replaced (:320-321)
+    has_warp_ = true;
+  }
 
   enum State { New = 0, Tracked = 1, Lost = 2, Removed = 3 };
   struct BTrack {  // BotSTrack :23-193
@@ -741,8 +748,22 @@ class BotSort {
     }
   };
 
+  // BotSTrack::multi_gmc :60-91 for one track
+  static void gmc(BTrack& t, const float W[3][3]) {
+    const Box b = t.xyxy();
+    float p[2][3];
+    for (int c = 0; c < 2; ++c)
+      for (int r = 0; r < 3; ++r) p[c][r] = W[r][0] * b[2 * c] + W[r][1] * b[2 * c + 1] + W[r][2] * 1.0f;
+    const float x1 = p[0][0] / p[0][2], y1 = p[0][1] / p[0][2];
+    const float x2 = p[1][0] / p[1][2], y2 = p[1][1] / p[1][2];
+    const float w = x2 - x1, h = y2 - y1;
+    t.kf.mean[0] = x1 + w / 2.0f; t.kf.mean[1] = y1 + h / 2.0f; t.kf.mean[2] = w; t.kf.mean[3] = h;
+  }
+
   OutTable update(const float* dets, int n, const float* embs, int emb_dim) {  // :260-359
     laps.clear();
+    const bool warp_now = has_warp_;
+    has_warp_ = false;
     if (n == 0) return {};  // :267-269 (no predict, no frame_count++)
     ++frame_count_;
     std::vector<Det7> all = wrap_dets(dets, n);
@@ -763,6 +784,10 @@ class BotSort {
     for (BTrack& t : lost_) lost_ptrs.push_back(&t);
     std::vector<BTrack*> pool = joint(act_ptrs, lost_ptrs);
     for (BTrack* t : pool) KfXYWH::predict(t->kf);  // multi_predict :54-58 (in place)
+    if (warp_now) {  // :317-324
+      for (BTrack* t : pool) if (t->has_state) gmc(*t, warp_);
+      for (BTrack* t : unconfirmed) if (t->has_state) gmc(*t, warp_);
+    }
 
     std::vector<BTrack*> activated, refind, lost_new, removed_new;
 
@@ -967,6 +992,8 @@ class BotSort {
   bool fuse_first_, with_reid_;
   int max_time_lost_;
   int frame_count_ = 0, next_id_ = 0;
+  float warp_[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
+  bool has_warp_ = false;
   std::vector<BTrack> active_, lost_;
 };
 

@@ -120,6 +120,26 @@ int main() {
         for (int k = 0; k < 8; ++k) CHECK(out[0](i, k) == r(i, k));
     }
   }
+  {  // camera motion (botsort.cpp:317-324 with the warp supplied by the caller): a camera jumping 60 px per frame
+    BotSort cmc, plain;
+    Eigen::MatrixXf warp(2, 3);
+    warp << 1, 0, 60, 0, 1, 0;
+    for (int f = 0; f < 6; ++f) {
+      Eigen::MatrixXf d = multi;
+      for (int i = 0; i < d.rows(); ++i) { d(i, 0) += 60.f * f; d(i, 2) += 60.f * f; }
+      if (f > 0) cmc.set_camera_motion(warp);
+      Eigen::MatrixXf r = cmc.update(d, img);
+      plain.update(d, img);
+      CHECK(r.rows() == multi.rows());
+      for (int i = 0; i < r.rows(); ++i) {  // each id stays on its own detection, at the detection's place
+        const int det = static_cast<int>(r(i, 7));
+        CHECK(static_cast<int>(r(i, 4)) == det + 1 && std::fabs(r(i, 0) - d(det, 0)) < 0.5f);
+      }
+    }
+    bool threw = false;
+    try { cmc.set_camera_motion(Eigen::MatrixXf(3, 3)); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+  }
   {  // asso_func: stored by every tracker, read only by OC-SORT, at update time (ocsort.cpp:413; iou.hpp:385-408)
     ByteTrack bt(0.3f, 30, 50, 3, 0.3f, false, 80, "no-such-measure");
     CHECK(bt.update(multi, img).cols() == 8);

@@ -38,6 +38,8 @@ class Oracle:
         L.orc_tracker_create.argtypes = [C.c_int, C.c_void_p, C.c_int]
         L.orc_tracker_destroy.argtypes = [C.c_void_p]
         L.orc_tracker_reset.argtypes = [C.c_void_p]
+        L.orc_tracker_set_warp.restype = C.c_int
+        L.orc_tracker_set_warp.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_tracker_update.restype = C.c_int
         L.orc_tracker_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.orc_tracker_lap_count.restype = C.c_int
@@ -130,6 +132,12 @@ class Oracle:
         self.lib.orc_kf_update(kind, mean.shape[0], meas.ctypes, qp, mean.ctypes, cov.ctypes)
         return mean, cov
 
+    def kf_warp(self, kind, mean, cov, warp9):
+        mean, cov, w = f32(mean).copy(), f32(cov).copy(), f32(warp9).reshape(9)
+        if self.lib.orc_kf_warp(kind, mean.shape[0], w.ctypes, mean.ctypes, cov.ctypes) != 0:
+            raise ValueError("orc_kf_warp: filter kind without a camera-motion step")
+        return mean, cov
+
     def box_convert(self, op, boxes):
         boxes = f32(boxes).reshape(-1, 4)
         out = np.zeros_like(boxes)
@@ -155,6 +163,11 @@ class OracleTracker:
 
     def reset(self):
         self.orc.lib.orc_tracker_reset(self.h)
+
+    def set_camera_motion(self, warp2x3):
+        w = f32(warp2x3).reshape(6)
+        if self.orc.lib.orc_tracker_set_warp(self.h, w.ctypes) != 0:
+            raise ValueError("only BoT-SORT takes a camera-motion warp")
 
     def update(self, dets, embs=None):
         dets = f32(dets).reshape(-1, 6)

@@ -242,3 +242,46 @@ def test_association_measures(ctx, orc, kind):
             assert np.array_equal(got, ref), np.abs(got - ref).max()
         neg = ctx.assoc_cost(a, b, kind, (640, 480), mode=L.COST_NEG_IOU)
         assert np.array_equal(neg, -got)
+
+
+def _warps(r):
+    # identity, pure translation, a small similarity (what ECC returns between consecutive frames), a full affine, and a
+    # projective one (multi_gmc divides by the third coordinate; the XYSR rule ignores the last row)
+    th = 0.02
+    sim = [[1.01 * np.cos(th), -1.01 * np.sin(th), 3.5], [1.01 * np.sin(th), 1.01 * np.cos(th), -2.25], [0, 0, 1]]
+    return [np.eye(3), [[1, 0, 12.5], [0, 1, -7.25], [0, 0, 1]], sim,
+            [[0.97, 0.04, 5], [-0.03, 1.02, 1], [0, 0, 1]], [[1, 0.01, 2], [0.02, 1, 3], [1e-5, -2e-5, 1.001]]]
+
+
+@pytest.mark.parametrize("kind", [L.KF_XYSR, L.KF_XYWH])
+def test_camera_motion_warp_bit_exact(ctx, orc, kind):
+    # mot_kf_warp against BotSTrack::multi_gmc (botsort.cpp:60-91) / KalmanFilterXYSR::apply_affine_correction
+    # (xysr_kf.cpp:114-141) as restated in oracle/; standalone and fused behind a predict
+    r = np.random.default_rng(40 + kind)
+    n = 300
+    b = boxes(r, n)
+    w, h = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    cx, cy = b[:, 0] + w / 2, b[:, 1] + h / 2
+    z = (np.stack([cx, cy, w * h, w / h], 1) if kind == L.KF_XYSR else np.stack([cx, cy, w, h], 1)).astype(np.float32)
+    m0, c0 = orc.kf_initiate(kind, z)
+    m0[:, 4:] = r.normal(0, 2, m0[:, 4:].shape).astype(np.float32)
+    m0, c0 = orc.kf_predict(kind, m0, c0)  # off-diagonal covariance terms
+    for W in _warps(r):
+        W = np.asarray(W, np.float32)
+        mo, co = orc.kf_warp(kind, m0, c0, W)
+        mg, cg, bx = ctx.kf_warp(kind, m0, c0, W, want_boxes=True)
+        assert np.array_equal(mg, mo) and np.array_equal(cg, co)
+        if kind == L.KF_XYWH:
+            ref = np.stack([mo[:, 0] - mo[:, 2] / 2, mo[:, 1] - mo[:, 3] / 2, mo[:, 0] + mo[:, 2] / 2, mo[:, 1] + mo[:, 3] / 2], 1)
+            assert np.array_equal(bx, ref.astype(np.float32))
+            assert np.array_equal(cg, c0) and np.array_equal(mg[:, 4:], m0[:, 4:])  # only cx,cy,w,h move
+        mp, cp = orc.kf_predict(kind, m0, c0)
+        mo, co = orc.kf_warp(kind, mp, cp, W)
+        mg, cg = ctx.kf_warp(kind, m0, c0, W, predict_first=True)
+        assert np.array_equal(mg, mo) and np.array_equal(cg, co)
+
+
+def test_camera_motion_warp_rejects_xyah(ctx):
+    m, c = np.zeros((2, 8), np.float32), np.zeros((2, 8, 8), np.float32)
+    with pytest.raises(L.MotError):
+        ctx.kf_warp(L.KF_XYAH, m, c, np.eye(3, dtype=np.float32))

@@ -133,6 +133,43 @@ def test_botsort_without_embeddings():
     run_stream("botsort", orclib.BOTSORT, 120, 70, 40)
 
 
+def test_botsort_camera_motion():
+    # a caller-supplied warp per frame (what cmc_->apply returns in botsort.cpp:317-324): a panning, slightly zooming camera;
+    # every third frame has none, and a warp handed over before an empty frame is dropped with it (:267-269)
+    orc = orclib.load()
+    tg, to = L.Tracker("botsort"), orc.tracker(orclib.BOTSORT)
+    s = SynthStream(200, 110, 77, 32)
+    r = np.random.default_rng(5)
+    pan = np.zeros(2, np.float32)
+    n_out = 0
+    for f in range(50):
+        d, e = s.next_frame()
+        step = r.uniform(-6, 6, 2).astype(np.float32)
+        pan += step
+        d = d.copy()
+        d[:, [0, 2]] += pan[0]
+        d[:, [1, 3]] += pan[1]
+        if f % 11 == 7:
+            d, e = d[:0], e[:0]
+        if f % 3 != 2:
+            k = np.float32(1.0 + r.uniform(-0.004, 0.004))
+            W = np.array([[k, 0.001, step[0]], [-0.001, k, step[1]]], np.float32)
+            tg.set_camera_motion(W)
+            to.set_camera_motion(W)
+        og, oo = tg.update(d, e), to.update(d, e)
+        check_frame(f, og, oo, tg, to)
+        n_out += og.shape[0]
+    assert n_out > 1000
+    tg.close()
+
+
+def test_camera_motion_only_for_botsort():
+    t = L.Tracker("bytetrack")
+    with pytest.raises(L.MotError):
+        t.set_camera_motion(np.eye(3, dtype=np.float32)[:2])
+    t.close()
+
+
 def test_batch_matches_single_streams():
     S, P, M = 5, 120, 60
     b = L.Batch("bytetrack", S)

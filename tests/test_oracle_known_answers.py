@@ -383,3 +383,113 @@ def test_ocsort_runs_with_every_association_measure(orc):
         assert n > 0
         outs[name] = n
     assert len(set(outs.values())) > 1  # the measures do change what gets associated
+
+
+# ---- camera-motion compensation of track states: botsort.cpp:60-91,317-324; xysr_kf.cpp:114-141 ----
+def _xywh_state(orc, box):
+    x1, y1, x2, y2 = box
+    z = np.array([[(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1]], np.float32)
+    m, c = orc.kf_initiate(orclib.KF_XYWH, z)
+    m[:, 4:] = [1.5, -0.5, 0.25, 0.125]
+    return m, c
+
+
+def test_multi_gmc_hand_computed(orc):  # both corners through the warp, then back to cx,cy,w,h; nothing else changes
+    m, c = _xywh_state(orc, (10, 20, 30, 60))
+    cases = [
+        (np.eye(3), [20, 40, 20, 40]),
+        ([[1, 0, 5], [0, 1, -3], [0, 0, 1]], [25, 37, 20, 40]),       # translation
+        ([[2, 0, 0], [0, 2, 0], [0, 0, 1]], [40, 80, 40, 80]),        # zoom about the origin
+        ([[1, 0, 0], [0, 1, 0], [0, 0, 2]], [10, 20, 10, 20]),        # the projective divide of :75-78
+        ([[0, 1, 0], [1, 0, 0], [0, 0, 1]], [40, 20, 40, 20]),        # x <-> y
+    ]
+    for W, want in cases:
+        mo, co = orc.kf_warp(orclib.KF_XYWH, m, c, np.asarray(W, np.float32))
+        assert np.array_equal(mo[0, :4], np.asarray(want, np.float32)), (W, mo[0, :4])
+        assert np.array_equal(mo[0, 4:], m[0, 4:]) and np.array_equal(co, c)
+
+
+def test_xysr_affine_correction_hand_computed(orc):  # a quarter turn plus a shift: everything is exact in float32
+    mean = np.array([[3, 4, 500, 0.5, 1, 2, 7]], np.float32)
+    cov = np.zeros((1, 7, 7), np.float32)
+    a, b, cc = 4.0, 1.0, 9.0
+    cov[0, :2, :2] = [[a, b], [b, cc]]
+    cov[0, 4:6, 4:6] = [[16, 2], [2, 25]]
+    cov[0, :2, 4:6] = [[1, 2], [3, 4]]
+    cov[0, 4:6, :2] = cov[0, :2, 4:6].T
+    cov[0, 2, 2] = 11; cov[0, 3, 3] = 12; cov[0, 6, 6] = 13; cov[0, 2, 6] = cov[0, 6, 2] = 5
+    W = np.array([[0, -1, 1], [1, 0, 2], [0, 0, 1]], np.float32)
+    mo, co = orc.kf_warp(orclib.KF_XYSR, mean, cov, W)
+    assert np.array_equal(mo[0], np.array([-3, 5, 500, 0.5, -2, 1, 7], np.float32))  # x[:2] = m x[:2] + t, x[4:6] = m x[4:6]
+    R = W[:2, :2].astype(np.float64)
+    want = cov[0].astype(np.float64).copy()
+    want[:2, :2] = R @ want[:2, :2] @ R.T
+    want[4:6, 4:6] = R @ want[4:6, 4:6] @ R.T
+    want[:2, 4:6] = R @ cov[0, :2, 4:6] @ R.T
+    want[4:6, :2] = want[:2, 4:6].T
+    assert np.array_equal(co[0], want.astype(np.float32))
+    with pytest.raises(ValueError):
+        orc.kf_warp(orclib.KF_XYAH, np.zeros((1, 8), np.float32), np.zeros((1, 8, 8), np.float32), W)
+
+
+def test_xysr_affine_correction_vs_float64(orc):
+    r = np.random.default_rng(9)
+    n = 64
+    mean = r.normal(0, 50, (n, 7)).astype(np.float32)
+    A = r.normal(0, 1, (n, 7, 7))
+    cov = (A @ A.transpose(0, 2, 1)).astype(np.float32)
+    th = 0.03
+    W = np.array([[1.02 * np.cos(th), -1.02 * np.sin(th), 4.0], [1.02 * np.sin(th), 1.02 * np.cos(th), -6.0], [0, 0, 1]], np.float32)
+    mo, co = orc.kf_warp(orclib.KF_XYSR, mean, cov, W)
+    R, t = W[:2, :2].astype(np.float64), W[:2, 2].astype(np.float64)
+    wm, wc = mean.astype(np.float64).copy(), cov.astype(np.float64).copy()
+    wm[:, :2] = mean[:, :2] @ R.T + t
+    wm[:, 4:6] = mean[:, 4:6] @ R.T
+    for blk in ((slice(0, 2), slice(0, 2)), (slice(4, 6), slice(4, 6)), (slice(0, 2), slice(4, 6))):
+        wc[(slice(None),) + blk] = R @ cov[(slice(None),) + blk].astype(np.float64) @ R.T
+    wc[:, 4:6, :2] = wc[:, :2, 4:6].transpose(0, 2, 1)
+    assert np.allclose(mo, wm, rtol=1e-5, atol=1e-4) and np.allclose(co, wc, rtol=1e-5, atol=1e-4)
+
+
+def _panning_frames(frames, shift):
+    # five static objects seen by a camera that jumps `shift` px per frame: without compensation consecutive boxes do not overlap
+    base = np.array([[100 + 150 * i, 200, 140 + 150 * i, 290, 0.9, 0] for i in range(5)], np.float32)
+    out = []
+    for f in range(frames):
+        d = base.copy()
+        d[:, [0, 2]] += shift * f
+        out.append(d)
+    return out
+
+
+def test_botsort_warp_keeps_tracks_on_their_objects_under_camera_pan(orc):
+    shift = 60.0
+    W = np.array([[1, 0, shift], [0, 1, 0]], np.float32)
+    with_cmc, without = orc.tracker(orclib.BOTSORT), orc.tracker(orclib.BOTSORT)
+    for f, d in enumerate(_panning_frames(8, shift)):
+        if f > 0:
+            with_cmc.set_camera_motion(W)
+        oc, on = with_cmc.update(d), without.update(d)
+        # compensated: the five ids of frame 1 stay on their detections (det_ind = row of the matched detection)
+        assert sorted(oc[:, 4].astype(int)) == [1, 2, 3, 4, 5]
+        order = np.argsort(oc[:, 4])
+        assert np.array_equal(oc[order, 7].astype(int), np.arange(5))
+        assert np.allclose(oc[order, :4], d[:, :4], atol=1e-2)
+    # uncompensated: nothing overlaps from one frame to the next, the boxes that come out are not where the objects are
+    assert on.shape[0] == 0 or np.abs(on[np.argsort(on[:, 4]), 0][:1] - d[0, 0]) > 100
+
+
+def test_botsort_warp_is_one_shot_and_dropped_with_an_empty_frame(orc):
+    frames = _panning_frames(3, 0.0)
+    W = np.array([[1, 0, 500], [0, 1, 0]], np.float32)
+    a, b = orc.tracker(orclib.BOTSORT), orc.tracker(orclib.BOTSORT)
+    for t in (a, b):
+        t.update(frames[0])
+    a.set_camera_motion(W)
+    assert a.update(frames[1][:0]).shape[0] == 0 and b.update(frames[1][:0]).shape[0] == 0  # botsort.cpp:267-269: returns before CMC
+    assert np.array_equal(a.update(frames[1]), b.update(frames[1]))  # the warp went with the empty frame
+    a.set_camera_motion(np.array([[1, 0, 0], [0, 1, 0]], np.float32))
+    a.update(frames[2]); b.update(frames[2])
+    assert np.array_equal(a.update(frames[2])[:, 4:], b.update(frames[2])[:, 4:])
+    with pytest.raises(ValueError):
+        orc.tracker(orclib.SORT).set_camera_motion(W)

@@ -113,8 +113,8 @@ typedef struct mot_kf_task {
   const int32_t* midx;       /* [n] measurement column per item (NULL: item index)            */
   float* boxes; int32_t ldb; /* optional out [4][ldb]: xyxy of the written state, column = item */
   float q[3];                /* XYSR only: Q(4,4), Q(5,5), Q(6,6)                             */
-  int32_t warp_on;           /* predict: apply `warp` to every item right after the predict   */
-  float warp[9];             /* camera-motion warp, 3x3 row-major (mot_kf_warp / warp_on)     */
+  int32_t reserved;
+  float warp[9];             /* camera-motion warp, 3x3 row-major (mot_kf_warp, mot_kf_predict_warp) */
 } mot_kf_task;
 int mot_kf_dim(int kf_kind);
 int mot_kf_initiate(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
@@ -126,8 +126,11 @@ int mot_kf_boxes(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks
  * state's box go through the 3x3 warp (projective divide included), mean[0..3] = the new cx,cy,w,h, covariance untouched.
  * MOT_KF_XYSR: KalmanFilterXYSR::apply_affine_correction (src/motion/kalman_filters/xysr_kf.cpp:114-141) with
  * m = warp[0:2,0:2], t = warp[0:2,2] — centre, velocity and the position/velocity covariance blocks. MOT_KF_XYAH has no
- * such step in the reference: MOT_ERR_INVALID. `boxes`, if set, receives the xyxy of the warped states. */
+ * such step in the reference: MOT_ERR_INVALID. `boxes`, if set, receives the xyxy of the warped states.
+ * mot_kf_predict_warp = mot_kf_predict followed by mot_kf_warp on the same items, in one launch (BoT-SORT's pool,
+ * botsort.cpp:314-322). */
 int mot_kf_warp(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
+int mot_kf_predict_warp(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
 
 /* ---- N x M box costs ----------------------------------------------------------------- */
 typedef enum mot_cost_mode {
@@ -280,7 +283,7 @@ int mot_lap_geom_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_x
 /* mean: n x d, cov: n x d x d row-major (AoS); op: 0 initiate (mean/cov out), 1 predict, 2 update */
 int mot_kf_apply_host(mot_ctx* ctx, int kf_kind, int op, int n, const float* meas4, const float* q3_or_null,
                       const unsigned char* flags_or_null, float* mean, float* cov, float* boxes4_or_null);
-/* mot_kf_warp on AoS host states; predict_first != 0: one predict launch with warp_on instead (predict, then warp) */
+/* mot_kf_warp on AoS host states; predict_first != 0: mot_kf_predict_warp instead (predict, then warp, one launch) */
 int mot_kf_warp_host(mot_ctx* ctx, int kf_kind, int n, const float* warp9, int predict_first, const float* q3_or_null,
                      float* mean, float* cov, float* boxes4_or_null);
 

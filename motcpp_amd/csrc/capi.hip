@@ -123,6 +123,11 @@ int mot_kf_warp(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) {
   MOT_HIP(c, mot::launch_kf_op(4, kind, t, nt, max_n, c->stream));
   return MOT_OK;
 }
+int mot_kf_predict_warp(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) {
+  if (kind == MOT_KF_XYAH) { c->err = "mot_kf_predict_warp: the XYAH filter has no camera-motion step"; return MOT_ERR_INVALID; }
+  MOT_HIP(c, mot::launch_kf_op(5, kind, t, nt, max_n, c->stream));
+  return MOT_OK;
+}
 int mot_iou_cost(mot_ctx* c, const mot_iou_task* t, int nt, int max_n, int max_m) { return mot_iou_cost_ex(c, t, nt, max_n, max_m, 0); }
 int mot_iou_cost_ex(mot_ctx* c, const mot_iou_task* t, int nt, int max_n, int max_m, int flags) {
   MOT_HIP(c, mot::launch_iou(t, nt, max_n, max_m, (flags & MOT_COST_F_IOU_ONLY) != 0, c->stream));
@@ -314,10 +319,7 @@ static int kf_host(mot_ctx* c, int kind, int op, int n, const float* meas4, cons
   t.mean = dm.as<float>(); t.cov = dcv.as<float>(); t.cap = n; t.n = n; t.flags = flags ? df.as<uint8_t>() : nullptr;
   t.meas = dz.as<float>(); t.ldm = n; t.boxes = boxes4 ? db.as<float>() : nullptr; t.ldb = n;
   t.q[0] = q3 ? q3[0] : 0.01f; t.q[1] = q3 ? q3[1] : 0.01f; t.q[2] = q3 ? q3[2] : 0.0001f;
-  if (warp9) {
-    std::memcpy(t.warp, warp9, sizeof(t.warp));
-    t.warp_on = (op == 1);
-  }
+  if (warp9) std::memcpy(t.warp, warp9, sizeof(t.warp));
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, mot::launch_kf_op(op, kind, dt.as<mot_kf_task>(), 1, n, c->stream));
   MOT_HIP(c, hipMemcpyAsync(sm.data(), dm.p, sm.size() * 4, hipMemcpyDeviceToHost, c->stream));
@@ -341,7 +343,7 @@ int mot_kf_apply_host(mot_ctx* c, int kind, int op, int n, const float* meas4, c
 int mot_kf_warp_host(mot_ctx* c, int kind, int n, const float* warp9, int predict_first, const float* q3, float* mean, float* cov,
                      float* boxes4) {
   if (!warp9 || kind == MOT_KF_XYAH) { c->err = "mot_kf_warp_host: needs a warp and an XYSR or XYWH filter"; return MOT_ERR_INVALID; }
-  return kf_host(c, kind, predict_first ? 1 : 4, n, nullptr, q3, nullptr, warp9, mean, cov, boxes4);
+  return kf_host(c, kind, predict_first ? 5 : 4, n, nullptr, q3, nullptr, warp9, mean, cov, boxes4);
 }
 
 }  // extern "C"

@@ -159,11 +159,11 @@ void Device::begin_frame() {
 }
 bool Device::TaskLists::empty() const {
   for (int k = 0; k < 3; ++k)
-    if (!det[k].empty() || !kf_init[k].empty() || !kf_upd[k].empty() || !kf_pred[k].empty() || !kf_box[k].empty() || !kf_warp[k].empty()) return false;
+    if (!det[k].empty() || !kf_init[k].empty() || !kf_upd[k].empty() || !kf_pred[k].empty() || !kf_box[k].empty() || !kf_warp[k].empty() || !kf_predw[k].empty()) return false;
   return feat_set.empty() && feat_ema.empty() && cos.empty() && iou.empty() && oc.empty() && lap.empty();
 }
 void Device::TaskLists::clear() {
-  for (int k = 0; k < 3; ++k) { det[k].clear(); kf_init[k].clear(); kf_upd[k].clear(); kf_pred[k].clear(); kf_box[k].clear(); kf_warp[k].clear(); }
+  for (int k = 0; k < 3; ++k) { det[k].clear(); kf_init[k].clear(); kf_upd[k].clear(); kf_pred[k].clear(); kf_box[k].clear(); kf_warp[k].clear(); kf_predw[k].clear(); }
   feat_set.clear(); feat_ema.clear(); cos.clear(); iou.clear(); oc.clear(); lap.clear();
   lap_geom = false;
   lap_assoc = false;
@@ -178,7 +178,7 @@ void move_back(std::vector<T>& dst, std::vector<T>& src) {
 void Device::TaskLists::append(TaskLists& o) {
   for (int k = 0; k < 3; ++k) {
     move_back(det[k], o.det[k]); move_back(kf_init[k], o.kf_init[k]); move_back(kf_upd[k], o.kf_upd[k]);
-    move_back(kf_pred[k], o.kf_pred[k]); move_back(kf_box[k], o.kf_box[k]); move_back(kf_warp[k], o.kf_warp[k]);
+    move_back(kf_pred[k], o.kf_pred[k]); move_back(kf_box[k], o.kf_box[k]); move_back(kf_warp[k], o.kf_warp[k]); move_back(kf_predw[k], o.kf_predw[k]);
   }
   move_back(feat_set, o.feat_set); move_back(feat_ema, o.feat_ema); move_back(cos, o.cos); move_back(iou, o.iou);
   move_back(oc, o.oc); move_back(lap, o.lap);
@@ -237,6 +237,7 @@ void Device::flush() {
   auto& kf_pred = L.kf_pred;
   auto& kf_box = L.kf_box;
   auto& kf_warp = L.kf_warp;
+  auto& kf_predw = L.kf_predw;
   auto& feat_set = L.feat_set;
   auto& feat_ema = L.feat_ema;
   auto &cos = L.cos;
@@ -245,7 +246,7 @@ void Device::flush() {
   auto &lap = L.lap;
   const bool lap_geom = L.lap_geom, lap_assoc = L.lap_assoc;
   const mot_det_task* d_det[3];
-  const mot_kf_task *d_init[3], *d_upd[3], *d_pred[3], *d_box[3], *d_warp[3];
+  const mot_kf_task *d_init[3], *d_upd[3], *d_pred[3], *d_box[3], *d_warp[3], *d_predw[3];
   for (int k = 0; k < 3; ++k) {
     d_det[k] = stage_tasks(*up, det[k]);
     d_init[k] = stage_tasks(*up, kf_init[k]);
@@ -253,6 +254,7 @@ void Device::flush() {
     d_pred[k] = stage_tasks(*up, kf_pred[k]);
     d_box[k] = stage_tasks(*up, kf_box[k]);
     d_warp[k] = stage_tasks(*up, kf_warp[k]);
+    d_predw[k] = stage_tasks(*up, kf_predw[k]);
   }
   const mot_feat_task* d_fset = stage_tasks(*up, feat_set);
   const mot_feat_task* d_fema = stage_tasks(*up, feat_ema);
@@ -302,6 +304,8 @@ void Device::flush() {
   }
   for (int k = 0; k < 3; ++k)
     run(F_KF_PREDICT, kf_pred[k].size(), kf_bytes(kf_pred[k], k, 2.0), 0, [&] { check(mot_kf_predict(ctx, k, d_pred[k], (int)kf_pred[k].size(), maxn(kf_pred[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_predict"); });
+  for (int k = 0; k < 3; ++k)  // predict + camera-motion warp in one pass over the states
+    run(F_KF_PREDICT, kf_predw[k].size(), kf_bytes(kf_predw[k], k, 2.0), 0, [&] { check(mot_kf_predict_warp(ctx, k, d_predw[k], (int)kf_predw[k].size(), maxn(kf_predw[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_predict_warp"); });
   for (int k = 0; k < 3; ++k)  // camera-motion warp of states that are not predicted this frame (their slots are disjoint from the predicted ones)
     run(F_KF_PREDICT, kf_warp[k].size(), kf_bytes(kf_warp[k], k, 2.0), 0, [&] { check(mot_kf_warp(ctx, k, d_warp[k], (int)kf_warp[k].size(), maxn(kf_warp[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_warp"); });
   for (int k = 0; k < 3; ++k) {
@@ -442,8 +446,8 @@ float* Core::predict(const std::vector<int>& src, const std::vector<int>* dst, c
   mot_kf_task t{};
   t.mean = mean_; t.cov = cov_; t.cap = cap_; t.n = n; t.src = s.d; t.dst = dst ? d.d : nullptr; t.flags = flags ? f.d : nullptr;
   t.boxes = bx; t.ldb = n; t.q[0] = q[0]; t.q[1] = q[1]; t.q[2] = q[2];
-  if (warp9) { t.warp_on = 1; std::memcpy(t.warp, warp9, sizeof(t.warp)); }
-  dev_->q().kf_pred[kind_].push_back(t);
+  if (warp9) { std::memcpy(t.warp, warp9, sizeof(t.warp)); dev_->q().kf_predw[kind_].push_back(t); }
+  else dev_->q().kf_pred[kind_].push_back(t);
   return bx;
 }
 void Core::warp(const std::vector<int>& slots, const float* warp9) {

@@ -106,7 +106,7 @@ class Device {
   // per host thread: a stage machine appends to the set of the thread it runs on, without locking.
   struct TaskLists {
     std::vector<mot_det_task> det[3];
-    std::vector<mot_kf_task> kf_init[3], kf_upd[3], kf_pred[3], kf_box[3], kf_warp[3];
+    std::vector<mot_kf_task> kf_init[3], kf_upd[3], kf_pred[3], kf_box[3], kf_warp[3], kf_predw[3];
     std::vector<mot_feat_task> feat_set, feat_ema;
     std::vector<mot_cos_task> cos;
     std::vector<mot_iou_task> iou;
@@ -172,7 +172,7 @@ class Core {
   Span<float> floats(const std::vector<float>& v);
 
   // predict src slots into dst slots (nullptr: in place); returns device boxes [4][n] (ld = n)
-  // warp9: optional 3x3 row-major camera-motion warp applied to every predicted state (mot_kf_task::warp_on)
+  // warp9: optional 3x3 row-major camera-motion warp applied to every predicted state (mot_kf_predict_warp)
   float* predict(const std::vector<int>& src, const std::vector<int>* dst, const std::vector<uint8_t>* flags, Span<float>* boxes_dl,
                  const float* warp9 = nullptr);
   void warp(const std::vector<int>& slots, const float* warp9);  // camera-motion warp of stored states, no predict

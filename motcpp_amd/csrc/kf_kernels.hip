@@ -402,7 +402,7 @@ __device__ __forceinline__ void state_warp(St<D>& s, const float* W) {
 template <int KIND> struct Dim { static constexpr int D = 8; };
 template <> struct Dim<MOT_KF_XYSR> { static constexpr int D = 7; };
 
-enum { OP_INIT = 0, OP_PREDICT = 1, OP_UPDATE = 2, OP_BOXES = 3, OP_WARP = 4 };
+enum { OP_INIT = 0, OP_PREDICT = 1, OP_UPDATE = 2, OP_BOXES = 3, OP_WARP = 4, OP_PREDICT_WARP = 5 };
 
 template <int KIND, int OP>
 __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restrict__ tasks) {
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
   } else {
     load_state<D>(s, T.mean, T.cov, T.cap, src);
     const unsigned f = T.flags ? T.flags[i] : 0u;
-    if (OP == OP_PREDICT) {
+    if (OP == OP_PREDICT || OP == OP_PREDICT_WARP) {
       if constexpr (KIND == MOT_KF_XYSR) {
         if ((f & MOT_KF_OCSORT_CLAMP) && (s.m[6] + s.m[2]) <= 0.0f) s.m[6] = 0.0f;
         xysr_predict(s, T.q);
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
         if (f & MOT_KF_ZERO_V7) s.m[7] = 0.0f;
         s8_predict<KIND>(s);
       }
-      if (T.warp_on) state_warp<KIND, D>(s, T.warp);
+      if (OP == OP_PREDICT_WARP) state_warp<KIND, D>(s, T.warp);
     } else {
       if (f & MOT_KF_PREDICT_FIRST) {
         if constexpr (KIND == MOT_KF_XYSR) {
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
       }
       if constexpr (KIND == MOT_KF_XYSR) xysr_update(s, z); else s8_update<KIND>(s, z);
     }
-    no_store = (OP == OP_PREDICT) && (f & MOT_KF_NO_STORE);
+    no_store = (OP == OP_PREDICT || OP == OP_PREDICT_WARP) && (f & MOT_KF_NO_STORE);
   }
   if (OP != OP_BOXES && !no_store) store_state<D>(s, T.mean, T.cov, T.cap, dst);
   if (T.boxes) {
@@ -518,6 +518,7 @@ hipError_t launch_kf_op(int op, int kind, const mot_kf_task* tasks, int ntasks, 
     case OP_UPDATE: return launch_kf<OP_UPDATE>(kind, tasks, ntasks, max_n, st);
     case OP_BOXES: return launch_kf<OP_BOXES>(kind, tasks, ntasks, max_n, st);
     case OP_WARP: return (kind == MOT_KF_XYAH) ? hipErrorInvalidValue : launch_kf<OP_WARP>(kind, tasks, ntasks, max_n, st);
+    case OP_PREDICT_WARP: return (kind == MOT_KF_XYAH) ? hipErrorInvalidValue : launch_kf<OP_PREDICT_WARP>(kind, tasks, ntasks, max_n, st);
   }
   return hipErrorInvalidValue;
 }

@@ -262,6 +262,15 @@ def main():
                 roof["traffic"] = per_problem * st["tasks"] / launches
         except Exception:
             pass
+    # The same throughput priced with SURVEY §8(d)'s per-frame bytes — the formulation that materialises each stage's cost
+    # matrix (written once, read once by the solver), nominal N = P tracks, K = M matches, first/biggest stage only, as in
+    # its worked values (C2 0.49 MB, NS 4.9 MB). `achieved` above counts what the fused kernels need instead: the
+    # assignment kernel recomputes costs from the boxes, so the 2·n·m·4 B term never exists in HBM.
+    kf_d = 7 if tracker in ("sort", "ocsort") else 8
+    survey_bytes = 4.0 * (2 * P * (kf_d + kf_d * kf_d) + 2 * M * (kf_d + kf_d * kf_d) + 4 * (P + M) + M + 2 * P * M + (P + M) * D + 8 * M)
+    roof["survey_8d_equivalent"] = {"bytes_per_frame": survey_bytes, "GB/s_per_gpu": value / world * survey_bytes / 1e9,
+                                    "frac": value / world * survey_bytes / 1e9 / HBM_PEAK_GBS,
+                                    "note": "whole-job frames/s x SURVEY 8(d) bytes per frame (cost matrix materialised); not a kernel measurement"}
     sqf = os.path.join(ROOT, "profiles", "r01e_pmc_sq_lap.json")
     if fam == "lap" and os.path.exists(sqf):
         try:  # what actually bounds this kernel: instruction issue of the serial row passes (SQ counters, separate PMC run)

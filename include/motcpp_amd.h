@@ -223,8 +223,9 @@ typedef struct mot_lap_task {
 } mot_lap_task;
 enum {
   MOT_LAP_F_GEOM = 1, /* some task carries geom: reserve LDS for the staged boxes */
-  MOT_LAP_F_ASSOC = 2 /* some geom.assoc != MOT_ASSOC_IOU: run the variants compiled with every association measure
+  MOT_LAP_F_ASSOC = 2, /* some geom.assoc != MOT_ASSOC_IOU: run the variants compiled with every association measure
                          (the default variants evaluate plain IoU only and ignore geom.assoc) */
+  MOT_LAP_F_PLAIN = 4 /* no geom.mode is MOT_COST_BOTSORT: the variants without the gated appearance term may run */
 };
 size_t mot_lap_work_bytes(int n, int m);
 int mot_lap_solve(mot_ctx* ctx, const mot_lap_task* tasks, int ntasks, int max_n, int max_m, int flags);

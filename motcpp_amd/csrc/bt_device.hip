@@ -646,12 +646,12 @@ int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, bd, st));
   MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYAH, b->pred_t, S, bn, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
-  MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, st));
+  MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, true, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[2], st));
   hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr);
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, bn, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[3], st));
-  MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, st));
+  MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, true, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[4], st));
   hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t);
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYAH, b->init_t, S, bd, st));

@@ -18,7 +18,7 @@ hipError_t launch_iou(const mot_iou_task*, int, int, int, bool, hipStream_t);
 hipError_t launch_ocsort(const mot_ocsort_task*, int, int, int, bool, hipStream_t);
 hipError_t launch_feat(const mot_feat_task*, int, int, hipStream_t);
 hipError_t launch_cosine(const mot_cos_task*, int, int, int, hipStream_t);
-hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, hipStream_t);
+hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, bool, hipStream_t);
 size_t lap_scratch_bytes(int n, int m);
 }  // namespace mot
 
@@ -141,7 +141,7 @@ int mot_ocsort_cost_ex(mot_ctx* c, const mot_ocsort_task* t, int nt, int max_nd,
 int mot_cosine_cost(mot_ctx* c, const mot_cos_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_cosine(t, nt, max_n, max_m, c->stream)); return MOT_OK; }
 int mot_feat_update(mot_ctx* c, const mot_feat_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_feat(t, nt, max_n, c->stream)); return MOT_OK; }
 size_t mot_lap_work_bytes(int n, int m) { return (mot::lap_scratch_bytes(n, m) + 255) & ~size_t(255); }
-int mot_lap_solve(mot_ctx* c, const mot_lap_task* t, int nt, int max_n, int max_m, int flags) { MOT_HIP(c, mot::launch_lap(t, nt, max_n, max_m, (flags & MOT_LAP_F_GEOM) != 0, (flags & MOT_LAP_F_ASSOC) != 0, c->stream)); return MOT_OK; }
+int mot_lap_solve(mot_ctx* c, const mot_lap_task* t, int nt, int max_n, int max_m, int flags) { MOT_HIP(c, mot::launch_lap(t, nt, max_n, max_m, (flags & MOT_LAP_F_GEOM) != 0, (flags & MOT_LAP_F_ASSOC) != 0, (flags & MOT_LAP_F_PLAIN) != 0, c->stream)); return MOT_OK; }
 
 // ---- host-pointer conveniences ------------------------------------------------------------------
 static void to_soa4(const float* aos, int n, int cols, int stride, std::vector<float>& soa) {
@@ -244,7 +244,7 @@ int mot_lap_solve_host(mot_ctx* c, const float* cost, int n, int m, float thresh
   t.mode = mode; t.iou = iou ? di.as<float>() : nullptr; t.ldi = m; t.gate = gate; t.info = dinfo.as<int>();
   t.work = dwork.p;
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
-  MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n, m, false, false, c->stream));
+  MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n, m, false, false, false, c->stream));
   MOT_HIP(c, hipMemcpyAsync(x, dx.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(y, dy.p, m * 4, hipMemcpyDeviceToHost, c->stream));
   int inf = 0;
@@ -282,7 +282,7 @@ int mot_lap_geom_host(mot_ctx* c, const float* a, int n, const float* b, int m, 
   t.geom.n = n; t.geom.m = m; t.geom.a = da.as<float>(); t.geom.lda = n; t.geom.b = db.as<float>(); t.geom.ldb = m;
   t.geom.bconf = bconf ? dc.as<float>() : nullptr; t.geom.mode = cost_mode;
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
-  MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n, m, true, false, c->stream));
+  MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n, m, true, false, cost_mode != MOT_COST_BOTSORT, c->stream));
   MOT_HIP(c, hipMemcpyAsync(x, dx.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(y, dy.p, m * 4, hipMemcpyDeviceToHost, c->stream));
   std::vector<float> hv(n);

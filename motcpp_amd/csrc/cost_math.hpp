@@ -87,10 +87,12 @@ struct CostParams {
   int assoc = MOT_ASSOC_IOU;  // similarity the cost is built from
   float frame_diag = 1.0f;
 };
-template <class EmbFn>
+// WITH_APPEARANCE = false: the caller guarantees mode != MOT_COST_BOTSORT and the gated-appearance branch is not compiled
+// (the assignment kernel's variants for ByteTrack/SORT/OC-SORT launches: fewer scalar registers and branches per pair)
+template <bool WITH_APPEARANCE = true, class EmbFn>
 MOT_HD float cost_from_iou(const CostParams& p, float iou, float conf, EmbFn emb_at) {
   float d = 1.0f - iou;  // iou_distance
-  if (p.mode == MOT_COST_BOTSORT) {
+  if (WITH_APPEARANCE && p.mode == MOT_COST_BOTSORT) {
     const bool far = d > p.prox;  // mask from the un-fused distance (botsort.cpp:439)
     if (p.fuse) { const float sim = 1.0f - d; d = 1.0f - sim * conf; }
     if (p.has_emb || p.const_emb) {

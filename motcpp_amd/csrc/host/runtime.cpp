@@ -167,6 +167,7 @@ void Device::TaskLists::clear() {
   feat_set.clear(); feat_ema.clear(); cos.clear(); iou.clear(); oc.clear(); lap.clear();
   lap_geom = false;
   lap_assoc = false;
+  lap_appearance = false;
 }
 namespace {
 template <class T>
@@ -186,6 +187,8 @@ void Device::TaskLists::append(TaskLists& o) {
   o.lap_geom = false;
   lap_assoc = lap_assoc || o.lap_assoc;
   o.lap_assoc = false;
+  lap_appearance = lap_appearance || o.lap_appearance;
+  o.lap_appearance = false;
 }
 Device::TaskLists& Device::q() {
   const int t = Team::worker_id();
@@ -244,7 +247,7 @@ void Device::flush() {
   auto &iou = L.iou;
   auto &oc = L.oc;
   auto &lap = L.lap;
-  const bool lap_geom = L.lap_geom, lap_assoc = L.lap_assoc;
+  const bool lap_geom = L.lap_geom, lap_assoc = L.lap_assoc, lap_appearance = L.lap_appearance;
   const mot_det_task* d_det[3];
   const mot_kf_task *d_init[3], *d_upd[3], *d_pred[3], *d_box[3], *d_warp[3], *d_predw[3];
   for (int k = 0; k < 3; ++k) {
@@ -335,7 +338,7 @@ void Device::flush() {
     double b = 0;
     for (const mot_lap_task& t : lap)
       b += (t.geom.a ? 20.0 * (t.n + t.m) : 4.0 * t.n * (double)t.m) + (t.iou ? 4.0 * t.n * (double)t.m : 0.0) + 4.0 * (t.n + t.m);
-    run(F_LAP, lap.size(), b, 0, [&] { check(mot_lap_solve(ctx, d_lap, (int)lap.size(), maxn(lap, [](const mot_lap_task& t) { return t.n; }), maxn(lap, [](const mot_lap_task& t) { return t.m; }), (lap_geom ? MOT_LAP_F_GEOM : 0) | (lap_assoc ? MOT_LAP_F_ASSOC : 0)), "mot_lap_solve"); });
+    run(F_LAP, lap.size(), b, 0, [&] { check(mot_lap_solve(ctx, d_lap, (int)lap.size(), maxn(lap, [](const mot_lap_task& t) { return t.n; }), maxn(lap, [](const mot_lap_task& t) { return t.m; }), (lap_geom ? MOT_LAP_F_GEOM : 0) | (lap_assoc ? MOT_LAP_F_ASSOC : 0) | (lap_appearance ? 0 : MOT_LAP_F_PLAIN)), "mot_lap_solve"); });
   }
   down->download();
   zdown->download();
@@ -533,6 +536,7 @@ Core::Lap Core::lap_geom(const IouArgs& a, float thresh, int mode, float gate, b
   dev_->q().lap.push_back(t);
   dev_->q().lap_geom = true;
   if (a.assoc != MOT_ASSOC_IOU) dev_->q().lap_assoc = true;
+  if (a.mode == MOT_COST_BOTSORT) dev_->q().lap_appearance = true;
   r.queued = true;
   return r;
 }

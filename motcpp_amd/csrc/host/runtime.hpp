@@ -114,6 +114,7 @@ class Device {
     std::vector<mot_lap_task> lap;
     bool lap_geom = false;  // some queued LAP task carries on-the-fly geometry
     bool lap_assoc = false; // ... with an association measure other than IoU
+    bool lap_appearance = false;  // ... with BoT-SORT's gated appearance cost (MOT_COST_BOTSORT)
     bool empty() const;
     void clear();
     void append(TaskLists& o);  // moves o's tasks behind this one's

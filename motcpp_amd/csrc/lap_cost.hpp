@@ -30,7 +30,8 @@ struct BoxPlanes {
 // GENERAL = the similarity may be any mot_assoc measure (cost_math.hpp::assoc_pair: fp64 atan, sqrt, ...). Inlined into
 // every unrolled evaluation site that costs ~100 VGPRs, i.e. half the resident wavefronts — so the hot variants are
 // compiled for plain IoU only and tasks with another measure run the GENERAL variants.
-template <int RPL, int ROWS = kMemAny, bool GENERAL = false>
+// PLAIN = no task of the launch uses MOT_COST_BOTSORT: the gated appearance term is compiled out as well.
+template <int RPL, int ROWS = kMemAny, bool GENERAL = false, bool PLAIN = false>
 struct IouCostT {
   static constexpr int kRPL = RPL;
   BoxPlanes<ROWS> rows;
@@ -60,7 +61,7 @@ struct IouCostT {
     else iou = iou_pair(r.a, r.area, b, barea);
     const float* e = emb;
     const size_t off = static_cast<size_t>(r.i) * lde + j;
-    return cost_from_iou(prm, iou, cf, [&]() { return gld(e, off); });
+    return cost_from_iou<!PLAIN>(prm, iou, cf, [&]() { return gld(e, off); });
   }
   MOT_DEV double eval(const Row& r, const float b[4], float barea, float cf, int j) const {
     return static_cast<double>(eval_f(r, b, barea, cf, j));

@@ -98,8 +98,11 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
 // second launch bound = wavefronts per SIMD the register allocator must leave room for: the solver is latency-bound per
 // wavefront, throughput comes from co-resident ones (RPL 8: 2, i.e. <= 256 VGPRs; RPL 4: 3, <= 168; else whatever fits)
 constexpr int lap_min_waves(int threads, int rpl, bool general) { return (threads > 64 || general) ? 1 : (rpl >= 8 ? 2 : (rpl >= 4 ? 3 : 4)); }
-template <int kThreads, int lds_mode, int RPL, bool GENERAL>
-__global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, GENERAL)) lap_kernel(const mot_lap_task* __restrict__ tasks) {
+// FLAVOR of the on-the-fly cost: 0 plain IoU modes only, 1 + BoT-SORT's gated appearance term, 2 every association measure
+template <int kThreads, int lds_mode, int RPL, int FLAVOR>
+__global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR == 2)) lap_kernel(const mot_lap_task* __restrict__ tasks) {
+  constexpr bool GENERAL = FLAVOR == 2;
+  constexpr bool PLAIN = FLAVOR == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mot_lap_task T = tasks[blockIdx.x];
   const int nr = T.n, nc = T.m, n = nr + nc;
@@ -153,7 +156,7 @@ __global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, GENERAL
       cf[j] = G.bconf ? G.bconf[gj] : 0.0f;
     }
     g.sync();
-    mot::IouCostT<RPL, kRS, GENERAL> C;
+    mot::IouCostT<RPL, kRS, GENERAL, PLAIN> C;
     C.rows = mot::BoxPlanes<kRS>{rp, nr};
     C.cols = mot::BoxPlanes<mot::kMemGlobal>{cp, nc};
     C.conf = G.bconf ? cf : nullptr;
@@ -179,7 +182,8 @@ size_t lap_scratch_bytes(int n, int m) {
 
 // Threads per problem: one wavefront (no barriers, no LDS merges; 4-8 problems co-resident per CU) unless the problem is
 // large AND there are too few problems to fill the chip anyway, where 4 wavefronts cut the latency of a row pass.
-hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool geom, bool general_assoc, hipStream_t st) {
+hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool geom, bool general_assoc, bool plain_costs,
+                      hipStream_t st) {
   if (ntasks <= 0) return hipSuccess;
   const size_t n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1, nm = n + m;
   const size_t hot = (lap_hot_bytes(nm) + 15) & ~size_t(15);
@@ -196,9 +200,12 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   int rpl = 0;
   if (geom && !wide && !general_assoc) rpl = (m <= 256) ? 4 : (m <= 512 ? 8 : 0);
   static bool attr_set = false;
-#define MOT_LAP_VARIANTS(X) X(64, 0, 0, false) X(64, 2, 0, false) X(64, 3, 0, false) X(64, 0, 4, false) X(64, 2, 4, false) X(64, 3, 4, false) \
-                            X(64, 0, 8, false) X(64, 2, 8, false) X(64, 3, 8, false) X(256, 0, 0, false) X(256, 2, 0, false) X(256, 3, 0, false) \
-                            X(64, 0, 0, true) X(64, 2, 0, true) X(64, 3, 0, true) X(256, 0, 0, true) X(256, 2, 0, true) X(256, 3, 0, true)
+#define MOT_LAP_VARIANTS(X) X(64, 0, 0, 1) X(64, 2, 0, 1) X(64, 3, 0, 1) X(64, 0, 4, 1) X(64, 2, 4, 1) X(64, 3, 4, 1) \
+                            X(64, 0, 8, 1) X(64, 2, 8, 1) X(64, 3, 8, 1) X(256, 0, 0, 1) X(256, 2, 0, 1) X(256, 3, 0, 1) \
+                            X(64, 0, 4, 0) X(64, 2, 4, 0) X(64, 3, 4, 0) X(64, 0, 8, 0) X(64, 2, 8, 0) X(64, 3, 8, 0) \
+                            X(64, 0, 0, 2) X(64, 2, 0, 2) X(64, 3, 0, 2) X(256, 0, 0, 2) X(256, 2, 0, 2) X(256, 3, 0, 2)
+  // plain-cost variants exist for the register-cached column layouts only (the hot ones)
+  const int flavor = general_assoc ? 2 : ((plain_costs && rpl > 0) ? 0 : 1);
   if (!attr_set) {
 #define MOT_ATTR(T, M, R, G)                                                                                               \
     { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_kernel<T, M, R, G>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget); \
@@ -210,7 +217,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   const int threads = wide ? 256 : 64;
   bool launched = false;
 #define MOT_TRY(T, M, R, G)                                                                                \
-  if (!launched && threads == T && mode == M && rpl == R && general_assoc == G) {                          \
+  if (!launched && threads == T && mode == M && rpl == R && flavor == G) {                                 \
     hipLaunchKernelGGL((lap_kernel<T, M, R, G>), dim3(ntasks), dim3(T), lds, st, tasks);                   \
     launched = true;                                                                                       \
   }

@@ -14,7 +14,7 @@ namespace mot {
 hipError_t launch_kf_op(int op, int kind, const mot_kf_task*, int, int, hipStream_t);
 hipError_t launch_det(int kind, const mot_det_task*, int, int, hipStream_t);
 hipError_t launch_iou(const mot_iou_task*, int, int, int, bool, hipStream_t);
-hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, hipStream_t);
+hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, bool, hipStream_t);
 size_t lap_scratch_bytes(int n, int m);
 
 namespace lifecycle {

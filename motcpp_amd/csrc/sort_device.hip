@@ -376,7 +376,7 @@ int mot_sort_step(mot_sort_batch* b, const float* d_dets, const int* h_counts, f
   MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYSR, b->pred_t, S, bn, st));
   hipLaunchKernelGGL(sort_assoc, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->lap_t, prof ? b->d_stats : nullptr);
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
-  MOT_LC_HIP(b, mot::launch_lap(b->lap_t, S, bn, bd, true, false, st));
+  MOT_LC_HIP(b, mot::launch_lap(b->lap_t, S, bn, bd, true, false, true, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[2], st));
   hipLaunchKernelGGL(sort_apply, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box_t);
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYSR, b->init_t, S, bd, st));

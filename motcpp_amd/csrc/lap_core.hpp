@@ -16,6 +16,7 @@
 // between an update and its next read); every O(n) scan of lapjv becomes a strided loop plus
 // one wavefront/LDS reduction (grp.hpp). Sequential dependencies between rows are kept.
 #pragma once
+#include <type_traits>
 #include "grp.hpp"
 #include "mem.hpp"
 
@@ -36,6 +37,7 @@ namespace mot {
 // staged in LDS, so the N x M matrix never exists in memory.
 struct MatrixCost {
   static constexpr int kRPL = 0;  // no lane-owned column cache
+  static constexpr bool kPlain = false;
   const float* cost;  // nr x nc, row-major, leading dimension ld (global memory)
   int ld;
   struct Row { const float* p; };
@@ -168,6 +170,134 @@ MOT_DEV void for_lane_columns(const Cost& C, const ExtRow<Cost>& R, const VP& v,
   for_lane_dummy(R.right, v, t, T, nc, n, f);
 }
 
+// Order-preserving map float -> int (signed compare == float compare for non-NaN values; +NaN sorts above +inf, -NaN below
+// -inf) and back.
+MOT_HD int f32_key(float x) {
+  const int b = __builtin_bit_cast(int, x);
+  return b ^ ((b >> 31) & 0x7fffffff);
+}
+MOT_HD float key_f32(int k) { return __builtin_bit_cast(float, k ^ ((k >> 31) & 0x7fffffff)); }
+
+// Sparse column minima for the plain IoU-family functor (Cost::kPlain, every real column lane-owned). lapjv's column
+// reduction wants, per column, the smallest cost and the lowest row attaining it. A row whose box does not intersect the
+// column's costs zc = zero_cost_f(column) whatever the row, so only rows that can intersect need evaluating:
+//   rows sorted by x1 (rank by counting, ties by index)      -> a0 < b2 holds exactly on a prefix [0, p_hi)
+//   prefix maximum of x2 along that order                    -> a2 > b0 cannot hold before p_lo
+//   candidates [p_lo, p_hi) evaluated with the full arithmetic; all other rows cost zc, the lowest of them is found by
+//   walking i = 0, 1, ... until one is not a candidate (its rank is outside the range).
+// The result is the lexicographic minimum of (cost, row) over all rows — what the ascending strict-< scan computes. A
+// column box holding a NaN takes every row as candidate (a NaN column coordinate does not zero the intersection the way
+// a NaN row coordinate does). Also leaves in W.rlb a lower bound of each row's minimum over the real columns (the
+// evaluated pairs by atomic minimum, the rest by the smallest zc). Work arrays: five cold int arrays, free in phase 1.
+constexpr int kSparseOwnRows = 16;  // rows per lane whose ranks are counted in registers
+constexpr int kSparseMinRows = 32;
+template <class G, class Cost, class Work>
+MOT_DEV void sparse_column_minima(G& g, const Cost& C, const Work& W, int nr, int nc, float* vmk, int* imk) {
+  const int T = g.size(), t = g.tid();
+  // The sorted tables live where the column duals and the column->row map will be written when the columns are published
+  // (after this function's closing barrier) — LDS whenever the problem fits; v holds 2n ints, y holds n, n >= nr.
+  using VT = decltype(W.v);
+  using YT = decltype(W.y);
+  const YT SIDX = W.y;                                                   // row at sorted position p
+  const YT SKEY{reinterpret_cast<int*>(W.v.raw())};                      // key of its x1
+  const YT PM{reinterpret_cast<int*>(W.v.raw()) + (nr + nc)};            // prefix maximum of the x2 keys along the sorted order
+  static_assert(sizeof(*W.v.raw()) == 2 * sizeof(int), "two ints per dual");
+  (void)sizeof(VT);
+  const auto& RANK = W.inv;   // sorted position of row i
+  const auto& RMK = W.tie;    // ~key of the row's smallest evaluated cost (atomic max)
+  const int none = ~f32_key(3.0e38f);
+  // ---- ranks: every lane counts, for its own rows (in registers), the rows that sort before them ----
+  auto count_ranks = [&](auto slots_tag) {
+    constexpr int kS = decltype(slots_tag)::value;
+    int okey[kS], ornk[kS];
+#pragma unroll
+    for (int u = 0; u < kS; ++u) {
+      const int i = t + u * T;
+      okey[u] = (i < nr) ? f32_key(C.row_x1(i)) : 0;
+      ornk[u] = 0;
+    }
+    for (int q = 0; q < nr; ++q) {
+      const int kq = f32_key(C.row_x1(q));
+#pragma unroll
+      for (int u = 0; u < kS; ++u) {
+        const int i = t + u * T;
+        ornk[u] += ((kq < okey[u]) || (kq == okey[u] && q < i)) ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kS; ++u) {
+      const int i = t + u * T;
+      if (i < nr) { SIDX[ornk[u]] = i; SKEY[ornk[u]] = okey[u]; RANK[i] = ornk[u]; RMK[i] = none; }
+    }
+  };
+  if (nr <= 4 * T) count_ranks(std::integral_constant<int, 4>());
+  else if (nr <= 8 * T) count_ranks(std::integral_constant<int, 8>());
+  else count_ranks(std::integral_constant<int, kSparseOwnRows>());
+  g.sync();
+  // ---- prefix maximum of x2 in sorted order: a contiguous chunk per lane, one scan across the lanes ----
+  {
+    const int L = (nr + T - 1) / T;
+    const int b = t * L, e = (b + L < nr) ? b + L : nr;
+    int run = static_cast<int>(0x80000000u);
+    for (int p = b; p < e; ++p) {
+      const int k2 = f32_key(C.row_x2(static_cast<int>(SIDX[p])));
+      if (k2 > run) run = k2;
+      PM[p] = run;
+    }
+    const double ex = g.exclusive_scan_min(-static_cast<double>(run));
+    if (ex < 1e299) {
+      const int prev = static_cast<int>(-ex);
+      for (int p = b; p < e; ++p)
+        if (static_cast<int>(PM[p]) < prev) PM[p] = prev;
+    }
+  }
+  g.sync();
+  // ---- columns ----
+  float zmin = 3.0e38f;
+#pragma unroll
+  for (int k = 0; k < Cost::kRPL; ++k) {
+    const int jj = t + k * T;
+    if (jj < nc) {
+      const bool all_rows = C.owned_has_nan(k);
+      int plo = 0, phi = nr;
+      if (!all_rows) {
+        const int kb2 = f32_key(C.owned_x2(k)), kb0 = f32_key(C.owned_x1(k));
+        int lo = 0, hi = nr;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (static_cast<int>(SKEY[mid]) < kb2) lo = mid + 1; else hi = mid; }
+        phi = lo;
+        lo = 0; hi = phi;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (static_cast<int>(PM[mid]) > kb0) hi = mid; else lo = mid + 1; }
+        plo = lo;
+      }
+      float vm = static_cast<float>(kLapLarge);
+      int im = 0;
+      for (int p = plo; p < phi; ++p) {
+        const int i = SIDX[p];
+        const float c = C.at_owned_f(C.row(i), k, jj);
+        if (c < vm || (c == vm && i < im)) { vm = c; im = i; }
+        G::atomic_max(RMK.raw(i), ~f32_key(c));
+      }
+      if (!all_rows) {
+        int i0 = 0;
+        while (i0 < nr) { const int r = RANK[i0]; if (r < plo || r >= phi) break; ++i0; }
+        if (i0 < nr) {
+          const float zc = C.zero_cost_f(k);
+          if (zc < vm || (zc == vm && i0 < im)) { vm = zc; im = i0; }
+          if (zc < zmin) zmin = zc;
+        }
+      }
+      vmk[k] = vm; imk[k] = im;
+    }
+  }
+  zmin = g.reduce_min_f32(zmin);
+  g.sync();
+  for (int i = t; i < nr; i += T) {
+    const float rm = key_f32(~static_cast<int>(RMK[i]));
+    W.rlb[i] = static_cast<double>((zmin < rm) ? zmin : rm);
+  }
+  // (the caller's barrier after publishing the columns orders these writes before any later use of the work arrays)
+}
+
 // Compacts {i in [0,n) : flag(i)} in ascending order into out[]; returns the count (uniform).
 template <class G, class F, class Out>
 MOT_DEV int compact_ascending(G& g, int n, F flag, const Out& out) {
@@ -218,12 +348,21 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
 #pragma unroll
     for (int k = 0; k < Cost::kRPL; ++k) { vmk[k] = static_cast<float>(kLapLarge); imk[k] = 0; }
     double neg_vmax = 1e300;
+    bool swept = false;
+    if constexpr (Cost::kPlain) {
+      if (have_lb && nr >= kSparseMinRows && nr <= kSparseOwnRows * T) {
+        sparse_column_minima(g, C, W, nr, nc, vmk, imk);
+        swept = true;
+      }
+    }
     constexpr int kRowBatch = 4;  // row contexts are fetched a batch at a time so that their load latencies overlap
     // ... and a batch ahead of their use: under load (a thousand problems in flight) a global load takes microseconds
     typename Cost::Row RN[kRowBatch];
+    if (!swept) {
 #pragma unroll
-    for (int u = 0; u < kRowBatch; ++u) RN[u] = C.row((u < nr) ? u : nr - 1);
-    for (int i0 = 0; i0 < nr; i0 += kRowBatch) {
+      for (int u = 0; u < kRowBatch; ++u) RN[u] = C.row((u < nr) ? u : nr - 1);
+    }
+    for (int i0 = swept ? nr : 0; i0 < nr; i0 += kRowBatch) {
       typename Cost::Row RB[kRowBatch];
 #pragma unroll
       for (int u = 0; u < kRowBatch; ++u) RB[u] = RN[u];

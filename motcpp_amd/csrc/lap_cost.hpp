@@ -34,6 +34,11 @@ struct BoxPlanes {
 template <int RPL, int ROWS = kMemAny, bool GENERAL = false, bool PLAIN = false>
 struct IouCostT {
   static constexpr int kRPL = RPL;
+  // plain IoU-family costs: a pair whose boxes do not intersect costs the same whatever the row is (cost_from_iou of +0),
+  // which is what lets the solver's first phase look at the intersecting pairs only (lap_core.hpp, "sparse column minima")
+  // ... offered only while the row boxes are not in global scratch: the candidate rows are gathered box by box, which
+  // pays from LDS (C2-sized problems, +7 %) and loses to the streaming sweep from global memory (north-star size, -4 %)
+  static constexpr bool kPlain = PLAIN && !GENERAL && ROWS != kMemGlobal;
   BoxPlanes<ROWS> rows;
   BoxPlanes<kMemGlobal> cols;
   const float* conf;  // [nc] or nullptr
@@ -78,6 +83,18 @@ struct IouCostT {
   MOT_DEV double at_owned(const Row& r, int k, int j) const {  // k must be a compile-time constant after unrolling
     const Owned& o = own[k];
     return eval(r, o.b, o.area, o.conf, j);
+  }
+  MOT_DEV float row_x1(int i) const { return mem_load<ROWS>(rows.p + i); }
+  MOT_DEV float row_x2(int i) const { return mem_load<ROWS>(rows.p + 2 * rows.ld + i); }
+  MOT_DEV bool owned_has_nan(int k) const {
+    const Owned& o = own[k];
+    return (o.b[0] != o.b[0]) || (o.b[1] != o.b[1]) || (o.b[2] != o.b[2]) || (o.b[3] != o.b[3]);
+  }
+  MOT_DEV float owned_x1(int k) const { return own[k].b[0]; }
+  MOT_DEV float owned_x2(int k) const { return own[k].b[2]; }
+  // cost of owned column k against any row it does not intersect: iou_pair gives +0 there (inter == 0)
+  MOT_DEV float zero_cost_f(int k) const {
+    return cost_from_iou<!PLAIN>(prm, 0.0f, own[k].conf, []() { return 0.0f; });
   }
   MOT_DEV Row row(int i) const {
     Row r;

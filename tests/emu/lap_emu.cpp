@@ -28,7 +28,7 @@ extern "C" int emu_lap(const float* cost, int nr, int nc, int ld, float thresh, 
 
 // same solver with the on-the-fly IoU-family cost functor (row boxes a: nr x 4, column boxes b: nc x 4, row-major);
 // rpl > 0 additionally exercises the lane-owned register cache of column boxes (unrolled path + leftover columns)
-template <int RPL>
+template <int RPL, bool PLAIN = false>
 static int run_iou(const float* a, int nr, const float* b, int nc, const float* conf, int mode, float thresh, int T, int* x, int* y) {
   using namespace mot;
   const int n = nr + nc;
@@ -42,7 +42,7 @@ static int run_iou(const float* a, int nr, const float* b, int nc, const float* 
   std::vector<std::thread> th;
   for (int t = 0; t < T; ++t)
     th.emplace_back([&, t]() {
-      IouCostT<RPL> C;  // per lane, like the kernel: the owned-column cache is lane-private
+      IouCostT<RPL, kMemAny, false, PLAIN> C;  // per lane, like the kernel: the owned-column cache is lane-private
       C.rows = BoxPlanes<kMemAny>{rp.data(), nr};
       C.cols = BoxPlanes<kMemGlobal>{cp.data(), nc};
       C.conf = conf;
@@ -59,6 +59,8 @@ static int run_iou(const float* a, int nr, const float* b, int nc, const float* 
 }
 extern "C" int emu_lap_iou(const float* a, int nr, const float* b, int nc, const float* conf, int mode, float thresh, int T,
                            int rpl, int* x, int* y) {
+  if (rpl == 104) return run_iou<4, true>(a, nr, b, nc, conf, mode, thresh, T, x, y);  // 100 + rpl: the plain-cost variants
+  if (rpl == 108) return run_iou<8, true>(a, nr, b, nc, conf, mode, thresh, T, x, y);
   if (rpl == 4) return run_iou<4>(a, nr, b, nc, conf, mode, thresh, T, x, y);
   if (rpl == 8) return run_iou<8>(a, nr, b, nc, conf, mode, thresh, T, x, y);
   return run_iou<0>(a, nr, b, nc, conf, mode, thresh, T, x, y);

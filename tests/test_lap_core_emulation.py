@@ -121,3 +121,42 @@ def test_unmatched_tracks_and_detections_closed_form_runs(orc, emu_iou):
             xo, yo = orc.linear_assignment(cost, th)
             xe, ye = emu_iou(a, b, conf, mode, th, T, rpl)
             assert (xo == xe).all() and (yo == ye).all(), (n, m, near, T, rpl, mode, th)
+
+
+def test_sparse_column_minima_make_the_same_decisions(orc, emu_iou):
+    # the plain-cost variants (rpl 104 / 108 = register cache 4 / 8 + Cost::kPlain) replace phase 1's sweep over all
+    # rows by candidate ranges from the x-sorted rows; everything downstream must come out identical to the oracle on the
+    # materialised matrix — with clustered boxes (long candidate lists), exact duplicates (cost ties, equal x1), boxes
+    # that touch without intersecting, NaN rows / columns, and every plain cost mode
+    r = np.random.default_rng(11)
+    T = 8
+    cases = 0
+    for trial in range(60):
+        rpl = (4, 8)[trial % 2]
+        n = int(r.integers(32, 16 * T + 1))
+        m = int(r.integers(1, rpl * T + 1))
+        spread = (60, 400, 2000)[trial % 3]
+        cx, cy = r.uniform(0, spread, n), r.uniform(0, spread / 2, n)
+        w, h = r.uniform(10, 90, n), r.uniform(20, 160, n)
+        a = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32)
+        if trial % 4 == 0:
+            a = np.round(a / 8) * 8  # a coarse grid: equal x1 among rows, touching boxes
+        src = r.integers(0, n, m)
+        b = (a[src] + r.normal(0, 2.5, (m, 4))).astype(np.float32)
+        b[::3] = a[src[::3]]  # exact copies: exact ties between columns and rows
+        if trial % 5 == 1:
+            a[r.integers(0, n, 3), r.integers(0, 4, 3)] = np.nan
+        if trial % 5 == 2:
+            b[r.integers(0, m), r.integers(0, 4)] = np.nan
+        if trial % 7 == 3:
+            a[:, [0, 2]] -= spread  # negative coordinates
+            b[:, [0, 2]] -= spread
+        conf = r.uniform(0.3, 1, m).astype(np.float32)
+        for mode, th in ((0, 0.3), (1, 0.7), (2, 0.8), (3, -0.3)):
+            iou = orc.iou_batch(a, b)
+            cost = {0: iou, 1: orc.iou_distance(a, b), 2: orc.fuse_score(orc.iou_distance(a, b), conf), 3: -iou}[mode]
+            xo, yo = orc.linear_assignment(cost, th)
+            xe, ye = emu_iou(a, b, conf, mode, th, T, 100 + rpl)
+            assert (xo == xe).all() and (yo == ye).all(), (trial, n, m, mode, rpl)
+            cases += 1
+    assert cases == 240

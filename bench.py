@@ -271,14 +271,14 @@ def main():
     roof["survey_8d_equivalent"] = {"bytes_per_frame": survey_bytes, "GB/s_per_gpu": value / world * survey_bytes / 1e9,
                                     "frac": value / world * survey_bytes / 1e9 / HBM_PEAK_GBS,
                                     "note": "whole-job frames/s x SURVEY 8(d) bytes per frame (cost matrix materialised); not a kernel measurement"}
-    sqf = os.path.join(ROOT, "profiles", "r01e_pmc_sq_lap.json")
+    sqf = os.path.join(ROOT, "profiles", "r01g_pmc_sq_lap.json")
     if fam == "lap" and os.path.exists(sqf):
         try:  # what actually bounds this kernel: instruction issue of the serial row passes (SQ counters, separate PMC run)
             sq = json.load(open(sqf)).get(args.workload)
             if sq:
                 roof["issue"] = {"wave_cycles_issuing_frac": sq["active_frac"], "wave_cycles_waiting_frac": sq["wait_any_frac"],
                                  "valu_insts_per_problem": sq["per_problem"]["SQ_INSTS_VALU"],
-                                 "salu_insts_per_problem": sq["per_problem"]["SQ_INSTS_SALU"], "source": "profiles/r01e_pmc_sq_lap.json"}
+                                 "salu_insts_per_problem": sq["per_problem"]["SQ_INSTS_SALU"], "source": "profiles/r01g_pmc_sq_lap.json"}
         except Exception:
             pass
     kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["launches"],

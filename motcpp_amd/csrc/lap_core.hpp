@@ -196,13 +196,11 @@ MOT_DEV void sparse_column_minima(G& g, const Cost& C, const Work& W, int nr, in
   const int T = g.size(), t = g.tid();
   // The sorted tables live where the column duals and the column->row map will be written when the columns are published
   // (after this function's closing barrier) — LDS whenever the problem fits; v holds 2n ints, y holds n, n >= nr.
-  using VT = decltype(W.v);
-  using YT = decltype(W.y);
+  using YT = decltype(W.y);  // (v and y share an address space)
+  static_assert(sizeof(*W.v.raw()) == 2 * sizeof(int), "two ints per dual");
   const YT SIDX = W.y;                                                   // row at sorted position p
   const YT SKEY{reinterpret_cast<int*>(W.v.raw())};                      // key of its x1
   const YT PM{reinterpret_cast<int*>(W.v.raw()) + (nr + nc)};            // prefix maximum of the x2 keys along the sorted order
-  static_assert(sizeof(*W.v.raw()) == 2 * sizeof(int), "two ints per dual");
-  (void)sizeof(VT);
   const auto& RANK = W.inv;   // sorted position of row i
   const auto& RMK = W.tie;    // ~key of the row's smallest evaluated cost (atomic max)
   const int none = ~f32_key(3.0e38f);

@@ -213,7 +213,8 @@ typedef struct mot_lap_task {
   int32_t mode;
   const float* iou; int32_t ldi; float gate;
   float* xval;  /* optional out [n]: iou (if given, else cost) at (i, x[i])     */
-  int32_t* info;/* optional out [1]: 0 lapjv, 1 trivial shortcut, 2 gated off   */
+  int32_t* info;/* optional out [1]: 0 lapjv, 1 trivial shortcut, 2 gated off,
+                 * -1 refused (MOT_LAP_F_PLAIN given but geom.mode is MOT_COST_BOTSORT: everything unmatched) */
   void* work;   /* REQUIRED scratch of mot_lap_work_bytes(n, m) bytes (cold path arrays, staged boxes, overflow of the LDS state) */
   /* on-the-fly cost: when geom.a != NULL the cost of pair (i,j) is recomputed inside the solver from geom's row /
    * column boxes with mot_iou_cost's arithmetic for geom.mode (cost, ldc are ignored; geom.cost/pairs unused): the

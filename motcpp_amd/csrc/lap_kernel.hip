@@ -113,6 +113,14 @@ __global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR 
     if (T.info && t == 0) T.info[0] = 2;
     return;
   }
+  if constexpr (PLAIN) {
+    if (T.geom.a != nullptr && T.geom.mode == MOT_COST_BOTSORT) {  // MOT_LAP_F_PLAIN was a false promise: refuse loudly
+      for (int i = t; i < nr; i += kThreads) { T.x[i] = -1; if (T.xval) T.xval[i] = 0.f; }
+      for (int j = t; j < nc; j += kThreads) T.y[j] = -1;
+      if (T.info && t == 0) T.info[0] = -1;
+      return;
+    }
+  }
   mot::DevGroup g(smem);
   // global scratch layout: [hot (mode 0 only)] [cold] [row boxes 5*nr floats] [col boxes 6*nc floats]
   char* gw = static_cast<char*>(T.work);

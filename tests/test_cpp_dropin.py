@@ -30,3 +30,29 @@ def test_dropin_behaviour_on_gpu():
     out = subprocess.run([build()], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "drop-in ok" in out.stdout
+
+
+CBIN = os.path.join(ROOT, "tests", "_build", "test_capi_batched")
+
+
+def build_c():
+    from motcpp_amd import _lib
+    if not os.path.exists(_lib.HIP_LIB):
+        _lib.build()
+    os.makedirs(os.path.dirname(CBIN), exist_ok=True)
+    src = os.path.join(ROOT, "tests", "cpp", "test_capi_batched.c")
+    if not os.path.exists(CBIN) or os.path.getmtime(src) > os.path.getmtime(CBIN) or os.path.getmtime(_lib.HIP_LIB) > os.path.getmtime(CBIN):
+        subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", CBIN,
+                               "-L", _lib.LIBDIR, "-lmotcpp_hip", "-Wl,-rpath," + _lib.LIBDIR])
+    return CBIN
+
+
+def test_c_consumer_of_the_batched_abi_compiles_as_c():
+    assert os.path.exists(build_c())
+
+
+@pytest.mark.gpu
+def test_batched_c_abi_and_launch_flags_on_gpu():
+    out = subprocess.run([build_c()], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "batched C ABI ok" in out.stdout

@@ -139,6 +139,26 @@ int main() {
     bool threw = false;
     try { cmc.set_camera_motion(Eigen::MatrixXf(3, 3)); } catch (const std::invalid_argument&) { threw = true; }
     CHECK(threw);
+    // two cameras in one StreamBatch, each with its own warp per frame (one predict+warp launch carries both), against
+    // the same trackers stepped one by one
+    BotSort b0, b1, s0, s1;
+    motcpp::StreamBatch batch({&b0, &b1});
+    Eigen::MatrixXf w0(2, 3), w1(2, 3);
+    w0 << 1, 0, 25, 0, 1, -10;
+    w1 << 1.01f, 0, -15, 0, 1.01f, 5;
+    for (int f = 0; f < 5; ++f) {
+      Eigen::MatrixXf d0 = multi, d1 = multi;
+      for (int i = 0; i < multi.rows(); ++i) {
+        d0(i, 0) += 25.f * f; d0(i, 2) += 25.f * f; d0(i, 1) -= 10.f * f; d0(i, 3) -= 10.f * f;
+        d1(i, 0) -= 15.f * f; d1(i, 2) -= 15.f * f; d1(i, 1) += 5.f * f; d1(i, 3) += 5.f * f;
+      }
+      if (f > 0) { b0.set_camera_motion(w0); b1.set_camera_motion(w1); s0.set_camera_motion(w0); s1.set_camera_motion(w1); }
+      auto out = batch.update({d0, d1}, img);
+      Eigen::MatrixXf r0 = s0.update(d0, img), r1 = s1.update(d1, img);
+      CHECK(out.size() == 2 && out[0].rows() == r0.rows() && out[1].rows() == r1.rows() && r0.rows() == multi.rows());
+      for (int i = 0; i < r0.rows(); ++i)
+        for (int k = 0; k < 8; ++k) CHECK(out[0](i, k) == r0(i, k) && out[1](i, k) == r1(i, k));
+    }
   }
   {  // asso_func: stored by every tracker, read only by OC-SORT, at update time (ocsort.cpp:413; iou.hpp:385-408)
     ByteTrack bt(0.3f, 30, 50, 3, 0.3f, false, 80, "no-such-measure");

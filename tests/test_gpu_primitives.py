@@ -285,3 +285,30 @@ def test_camera_motion_warp_rejects_xyah(ctx):
     m, c = np.zeros((2, 8), np.float32), np.zeros((2, 8, 8), np.float32)
     with pytest.raises(L.MotError):
         ctx.kf_warp(L.KF_XYAH, m, c, np.eye(3, dtype=np.float32))
+
+
+@pytest.mark.parametrize("n,m,world", [(33, 7, 300), (200, 150, 400), (300, 100, 600), (400, 50, 1920), (256, 128, 250), (128, 256, 500)])
+def test_lap_sparse_first_phase_shapes(ctx, orc, n, m, world):
+    # the plain-cost kernel variants with LDS-resident rows take phase 1's column minima from x-sorted candidate rows
+    # (lap_core.hpp::sparse_column_minima): every rank-counting width (<= 4, 8, 16 rows per lane), crowded scenes (long
+    # candidate lists), a coarse coordinate grid (equal x1, touching boxes, exact cost ties), NaN rows and a NaN column
+    r = np.random.default_rng(n * 7 + m)
+    a = boxes(r, n, (world, world // 2))
+    k = min(n, m)
+    b = boxes(r, m, (world, world // 2))
+    b[:k] = a[r.permutation(n)[:k]] + r.normal(0, 2, (k, 4)).astype(np.float32)
+    b[::4] = np.round(b[::4] / 8) * 8
+    a[::3] = np.round(a[::3] / 8) * 8
+    b[1] = b[0]
+    a[5, 2] = np.nan
+    a[min(n - 1, 40), 0] = np.nan
+    if m > 20:
+        b[17, 3] = np.nan
+    conf = r.uniform(0.3, 1, m).astype(np.float32)
+    iou = orc.iou_batch(a, b)
+    dist = orc.iou_distance(a, b)
+    for mode, cost, th in ((L.COST_IOU, iou, 0.3), (L.COST_IOU_DIST, dist, 0.7), (L.COST_IOU_DIST_FUSE, orc.fuse_score(dist, conf), 0.8),
+                           (L.COST_NEG_IOU, -iou, -0.3)):
+        xo, yo = orc.linear_assignment(cost, th)
+        xg, yg, xv, info = ctx.lap_geom(a, b, th, mode, conf)
+        assert info == 0 and np.array_equal(xg, xo) and np.array_equal(yg, yo), (n, m, mode)

@@ -252,6 +252,9 @@ int mot_bt_dump(mot_bt_batch* b, int s, int* ids, float* mean, float* cov, int c
  * n + m: [4],[5] first association, [6],[7] second + unconfirmed */
 int mot_bt_profile(mot_bt_batch* b, int enable);
 int mot_bt_profile_stats(mot_bt_batch* b, double* out8);
+/* the achieved problem sizes behind those counts: summed rows (tracks) and columns (detections) of the queued problems,
+ * [0],[1] first association, [2],[3] second + unconfirmed (divide by out8[4] / out8[6] for the mean N x M) */
+int mot_bt_profile_dims(mot_bt_batch* b, double* out4);
 
 /* ---- SORT with the per-stream lifecycle on the device ----------------------------------- */
 /* Same contract as mot_bt_* for Sort::update (src/trackers/sort.cpp:102-255). params: [det_thresh, max_age, max_obs (unused),

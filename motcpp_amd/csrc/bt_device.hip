@@ -125,8 +125,8 @@ __global__ void __launch_bounds__(kW) bt_begin(BtStream* streams, BtParams P, in
     L.geom.n = L.n; L.geom.m = L.m;
     L.geom.bconf = conf;  // score fusion reads the frame's confidences (:300-312)
     if (stats && q) {  // 64 counter sets, so that thousands of streams do not serialise on one address
-      unsigned long long* st = stats + (blockIdx.x & 63) * 4;
-      atomicAdd(&st[0], 1ull); atomicAdd(&st[1], static_cast<unsigned long long>(np + nh));
+      unsigned long long* st = stats + (blockIdx.x & 63) * 8;
+      atomicAdd(&st[0], 1ull); atomicAdd(&st[1], static_cast<unsigned long long>(np + nh)); atomicAdd(&st[4], static_cast<unsigned long long>(np));
     }
   }
 }
@@ -198,9 +198,12 @@ __global__ void __launch_bounds__(kW) bt_after_first(BtStream* streams, BtParams
     B.n = q3 ? S.n_unconf : 0; B.m = q3 ? n_ud : 0; B.geom.n = B.n; B.geom.m = B.m;
     B.geom.bconf = S.dets + static_cast<size_t>(4) * S.ld;
     if (stats) {
-      unsigned long long* st = stats + (blockIdx.x & 63) * 4;
+      unsigned long long* st = stats + (blockIdx.x & 63) * 8;
       const int cnt = (q2 ? 1 : 0) + (q3 ? 1 : 0);
-      if (cnt) { atomicAdd(&st[2], static_cast<unsigned long long>(cnt)); atomicAdd(&st[3], static_cast<unsigned long long>(A.n + A.m + B.n + B.m)); }
+      if (cnt) {
+        atomicAdd(&st[2], static_cast<unsigned long long>(cnt)); atomicAdd(&st[3], static_cast<unsigned long long>(A.n + A.m + B.n + B.m));
+        atomicAdd(&st[5], static_cast<unsigned long long>(A.n + B.n));
+      }
     }
   }
 }
@@ -536,8 +539,8 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
   b->d_maxt = b->dalloc<int>(64);
-  b->d_stats = b->dalloc<unsigned long long>(4 * 64);
-  if (b->d_stats) (void)hipMemset(b->d_stats, 0, 4 * 64 * sizeof(unsigned long long));
+  b->d_stats = b->dalloc<unsigned long long>(8 * 64);
+  if (b->d_stats) (void)hipMemset(b->d_stats, 0, 8 * 64 * sizeof(unsigned long long));
   for (auto& e : b->ev) (void)hipEventCreate(&e);
   b->det_t = b->dalloc<mot_det_task>(S);
   b->pred_t = b->dalloc<mot_kf_task>(S); b->box_t = b->dalloc<mot_kf_task>(2 * S); b->init_t = b->dalloc<mot_kf_task>(S);
@@ -691,20 +694,31 @@ int mot_bt_profile(mot_bt_batch* b, int enable) {
   if (enable) {
     b->lap_ms[0] = b->lap_ms[1] = b->frame_ms = 0.0;
     b->frames = 0;
-    MOT_LC_HIP(b, hipMemsetAsync(b->d_stats, 0, 4 * 64 * sizeof(unsigned long long), b->ctx->stream));
+    MOT_LC_HIP(b, hipMemsetAsync(b->d_stats, 0, 8 * 64 * sizeof(unsigned long long), b->ctx->stream));
     MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
   }
   return MOT_OK;
 }
 
 int mot_bt_profile_stats(mot_bt_batch* b, double* out8) {
-  unsigned long long raw[4 * 64];
+  unsigned long long raw[8 * 64];
   MOT_LC_HIP(b, hipMemcpy(raw, b->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
   unsigned long long h[4] = {0, 0, 0, 0};
   for (int i = 0; i < 64; ++i)
-    for (int k = 0; k < 4; ++k) h[k] += raw[i * 4 + k];
+    for (int k = 0; k < 4; ++k) h[k] += raw[i * 8 + k];
   out8[0] = b->lap_ms[0]; out8[1] = b->lap_ms[1]; out8[2] = b->frame_ms; out8[3] = static_cast<double>(b->frames);
   out8[4] = static_cast<double>(h[0]); out8[5] = static_cast<double>(h[1]); out8[6] = static_cast<double>(h[2]); out8[7] = static_cast<double>(h[3]);
+  return MOT_OK;
+}
+
+int mot_bt_profile_dims(mot_bt_batch* b, double* out4) {
+  unsigned long long raw[8 * 64];
+  MOT_LC_HIP(b, hipMemcpy(raw, b->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
+  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 64; ++i)
+    for (int k = 0; k < 8; ++k) h[k] += raw[i * 8 + k];
+  out4[0] = static_cast<double>(h[4]); out4[1] = static_cast<double>(h[1] - h[4]);
+  out4[2] = static_cast<double>(h[5]); out4[3] = static_cast<double>(h[3] - h[5]);
   return MOT_OK;
 }
 

@@ -199,6 +199,9 @@ struct DevGroup {
   }
   static __device__ __forceinline__ void atomic_max(int* p, int v) { atomicMax(p, v); }
   static __device__ __forceinline__ int atomic_add(int* p, int v) { return atomicAdd(p, v); }
+  static __device__ __forceinline__ void atomic_min(int* p, int v) { atomicMin(p, v); }
+  static __device__ __forceinline__ void atomic_or(int* p, int v) { atomicOr(p, v); }
+  static __device__ __forceinline__ void atomic_and(int* p, int v) { atomicAnd(p, v); }
 };
 #endif  // __HIPCC__
 

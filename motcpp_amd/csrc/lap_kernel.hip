@@ -20,6 +20,7 @@
 #include "../../include/motcpp_amd.h"
 #include "lap_core.hpp"
 #include "lap_cost.hpp"
+#include "lap_sparse.hpp"
 
 namespace {
 
@@ -100,13 +101,15 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
 constexpr int lap_min_waves(int threads, int rpl, bool general) { return (threads > 64 || general) ? 1 : (rpl >= 8 ? 2 : (rpl >= 4 ? 3 : 4)); }
 // FLAVOR of the on-the-fly cost: 0 plain IoU modes only, 1 + BoT-SORT's gated appearance term, 2 every association measure
 template <int kThreads, int lds_mode, int RPL, int FLAVOR>
-__global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR == 2)) lap_kernel(const mot_lap_task* __restrict__ tasks) {
+__global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR == 2)) lap_kernel(const mot_lap_task* __restrict__ tasks, int check_status) {
   constexpr bool GENERAL = FLAVOR == 2;
   constexpr bool PLAIN = FLAVOR == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mot_lap_task T = tasks[blockIdx.x];
   const int nr = T.n, nc = T.m, n = nr + nc;
   const int t = threadIdx.x;
+  // the fast path (lap_sparse_kernel) ran first over the same tasks: problems it finished carry status 1
+  if (check_status && *reinterpret_cast<const int*>(static_cast<const char*>(T.work) + mot::lap_task_scratch_bytes(nr, nc) - 16) == 1) return;
   if (nr <= 0 || nc <= 0) {
     for (int i = t; i < nr; i += kThreads) { T.x[i] = -1; if (T.xval) T.xval[i] = 0.f; }
     for (int j = t; j < nc; j += kThreads) T.y[j] = -1;
@@ -183,16 +186,20 @@ __global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR 
 }  // namespace
 
 namespace mot {
-size_t lap_scratch_bytes(int n, int m) {
-  const size_t nm = static_cast<size_t>(n) + m;
-  return ((lap_hot_bytes(nm) + 15) & ~size_t(15)) + ((lap_cold_bytes(nm) + 15) & ~size_t(15)) + 4 * (5 * static_cast<size_t>(n) + 6 * static_cast<size_t>(m)) + 256;
-}
+size_t lap_scratch_bytes(int n, int m) { return lap_task_scratch_bytes(n, m); }
+hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool plain_costs, hipStream_t st);
 
 // Threads per problem: one wavefront (no barriers, no LDS merges; 4-8 problems co-resident per CU) unless the problem is
 // large AND there are too few problems to fill the chip anyway, where 4 wavefronts cut the latency of a row pass.
 hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool geom, bool general_assoc, bool plain_costs,
                       hipStream_t st) {
   if (ntasks <= 0) return hipSuccess;
+  // fast path first (not for the general association measures: there a pair that does not intersect has no constant cost)
+  const bool fast = !general_assoc;
+  if (fast) {
+    hipError_t e = launch_lap_sparse(tasks, ntasks, max_n, max_m, plain_costs, st);
+    if (e != hipSuccess) return e;
+  }
   const size_t n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1, nm = n + m;
   const size_t hot = (lap_hot_bytes(nm) + 15) & ~size_t(15);
   const size_t b2 = kScratch + hot + (geom ? 20 * n + 16 : 0);  // full hot state (+ row boxes) in LDS
@@ -226,7 +233,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   bool launched = false;
 #define MOT_TRY(T, M, R, G)                                                                                \
   if (!launched && threads == T && mode == M && rpl == R && flavor == G) {                                 \
-    hipLaunchKernelGGL((lap_kernel<T, M, R, G>), dim3(ntasks), dim3(T), lds, st, tasks);                   \
+    hipLaunchKernelGGL((lap_kernel<T, M, R, G>), dim3(ntasks), dim3(T), lds, st, tasks, fast ? 1 : 0);     \
     launched = true;                                                                                       \
   }
   MOT_LAP_VARIANTS(MOT_TRY)

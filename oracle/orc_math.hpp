@@ -20,6 +20,8 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -473,6 +475,11 @@ inline void lapjv_rect(const float* cost, int nr, int nc, int ld, double thresh,
         std::swap(j, x[i]);
       }
     }
+  }
+  if (std::getenv("ORC_LAP_TRACE")) {  // instrumentation only
+    const LapStats& s = lap_stats();
+    std::fprintf(stderr, "lapjv %dx%d: free_after_colred %ld uniq %ld carr %ld paths %ld finds %ld records %ld scan_rows %ld ties %ld\n", nr, nc,
+                 s.free_after_colred, s.unique_rows, s.carr_iters, s.paths, s.finds, s.find_records, s.scan_rows, s.scan_ties);
   }
   x_out.assign(nr, -1);
   y_out.assign(nc, -1);

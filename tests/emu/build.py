@@ -10,7 +10,7 @@ def build_lap_emu():
     os.makedirs(OUT, exist_ok=True)
     so = os.path.join(OUT, "liblapemu.so")
     srcs = [os.path.join(ROOT, "tests", "emu", f) for f in ("lap_emu.cpp", "emu_group.hpp")] + \
-           [os.path.join(ROOT, "motcpp_amd", "csrc", f) for f in ("lap_core.hpp", "lap_cost.hpp", "cost_math.hpp", "grp.hpp", "mem.hpp")]
+           [os.path.join(ROOT, "motcpp_amd", "csrc", f) for f in ("lap_core.hpp", "lap_cost.hpp", "lap_sparse.hpp", "cost_math.hpp", "grp.hpp", "mem.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
                                "-o", so, srcs[0]])

@@ -81,6 +81,12 @@ struct EmuGroup {
     while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   }
   static int atomic_add(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+  static void atomic_min(int* p, int v) {
+    int cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (cur > v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  }
+  static void atomic_or(int* p, int v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+  static void atomic_and(int* p, int v) { __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
 };
 
 }  // namespace mot

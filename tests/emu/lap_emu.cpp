@@ -8,6 +8,7 @@
 #include "emu_group.hpp"
 #include "../../motcpp_amd/csrc/lap_core.hpp"
 #include "../../motcpp_amd/csrc/lap_cost.hpp"
+#include "../../motcpp_amd/csrc/lap_sparse.hpp"
 
 extern "C" int emu_lap(const float* cost, int nr, int nc, int ld, float thresh, int T, int* x, int* y) {
   using namespace mot;
@@ -64,4 +65,62 @@ extern "C" int emu_lap_iou(const float* a, int nr, const float* b, int nc, const
   if (rpl == 4) return run_iou<4>(a, nr, b, nc, conf, mode, thresh, T, x, y);
   if (rpl == 8) return run_iou<8>(a, nr, b, nc, conf, mode, thresh, T, x, y);
   return run_iou<0>(a, nr, b, nc, conf, mode, thresh, T, x, y);
+}
+
+// ---- sparse fast path (lap_sparse.hpp) on host threads: returns 1 when it certified the unique optimum (x, y filled),
+// 0 when it hands the problem to the exact emulation. boxes == nullptr: matrix source.
+static int run_sparse(const float* cost, int ld, const float* a, const float* b, const float* conf, int mode, int nr, int nc,
+                      float thresh, int T, int* x, int* y, double* mincost) {
+  using namespace mot;
+  using W = SparseWorkT<kMemAny>;
+  std::vector<char> hot(sparse_hot_bytes(nr, nc) + 64), cold(sparse_cold_bytes(nr, nc) + 64);
+  W w;
+  sparse_carve_hot(w, hot.data(), nr, nc);
+  sparse_carve_cold(w, cold.data(), nr, nc);
+  std::vector<float> ap(4 * (nr > 0 ? nr : 1)), bp(4 * (nc > 0 ? nc : 1));  // planes [4][n]
+  if (a) {
+    for (int i = 0; i < nr; ++i) for (int k = 0; k < 4; ++k) ap[k * nr + i] = a[i * 4 + k];
+    for (int j = 0; j < nc; ++j) for (int k = 0; k < 4; ++k) bp[k * nc + j] = b[j * 4 + k];
+  }
+  EmuShared sh(T);
+  std::vector<int> res(T, 0);
+  std::vector<double> mins(T, 0.0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t]() {
+      EmuGroup g(&sh, t);
+      SparseEnum e;
+      if (a) {
+        IouCostT<0, kMemAny, false, false> C;
+        C.prm = CostParams{mode, 0.f, 0.f, 0, false, false};
+        C.emb = nullptr; C.lde = 0; C.conf = nullptr;
+        using Row = typename IouCostT<0, kMemAny, false, false>::Row;
+        auto eval = [&](int i, const float ra[4], float raa, const float cb[4], float cba, float cf, int j) {
+          Row r; r.i = i; for (int k = 0; k < 4; ++k) r.a[k] = ra[k]; r.area = raa;
+          return C.eval_f(r, cb, cba, cf, j);
+        };
+        auto zc = [&](float cf) { return cost_from_iou<true>(C.prm, 0.0f, cf, []() { return 0.0f; }); };
+        e = sparse_enumerate_boxes(g, w, nr, nc, SparseBoxes{ap.data(), nr, nullptr}, SparseBoxes{bp.data(), nc, nullptr}, conf, nullptr,
+                                   thresh, eval, zc);
+      } else {
+        e = sparse_enumerate_matrix(g, w, nr, nc, cost, ld, thresh);
+      }
+      mins[t] = e.mincost;
+      res[t] = e.ok ? sparse_solve(g, w, nr, nc, thresh) : -1;
+    });
+  for (auto& t : th) t.join();
+  for (int t = 1; t < T; ++t) if (res[t] != res[0]) return -99;  // must be uniform
+  if (mincost) *mincost = mins[0];
+  if (res[0] == 1) {
+    for (int i = 0; i < nr; ++i) x[i] = w.x[i];
+    for (int j = 0; j < nc; ++j) y[j] = w.y[j];
+  }
+  return res[0];
+}
+extern "C" int emu_sparse_matrix(const float* cost, int nr, int nc, int ld, float thresh, int T, int* x, int* y, double* mincost) {
+  return run_sparse(cost, ld, nullptr, nullptr, nullptr, 0, nr, nc, thresh, T, x, y, mincost);
+}
+extern "C" int emu_sparse_boxes(const float* a, int nr, const float* b, int nc, const float* conf, int mode, float thresh, int T,
+                                int* x, int* y, double* mincost) {
+  return run_sparse(nullptr, 0, a, b, conf, mode, nr, nc, thresh, T, x, y, mincost);
 }

@@ -133,6 +133,8 @@ def main():
     else:
         batches = [L.Batch(tracker, bounds[p + 1] - bounds[p], device=local, threads=max(1, threads // PIPE), record_laps=False,
                            private_device=PIPE > 1) for p in range(PIPE)]
+    # rows of an output table: every emitted track consumed one detection of the frame, so M rows suffice on the device path
+    # (an overflow raises MOT_ERR_CAPACITY, never truncates); the host trackers keep the 2M of round 1
     cap = max(2 * M, 64)
     gathered = None
     if on_device:  # page-locked, so that the one result copy of a frame runs at PCIe speed
@@ -198,6 +200,8 @@ def main():
     torch.cuda.synchronize()
     for b in batches:
         b.profile(True)
+    diag_ctx = L.Context(local)
+    diag_ctx.lap_fast_stats(reset=True)
     c0 = counters()
     t0 = time.perf_counter()
     for k in range(K):
@@ -224,6 +228,7 @@ def main():
                 a[kk] += v[kk]
         b.profile(False)
     c1 = counters()
+    fast_stats = diag_ctx.lap_fast_stats()
     elapsed = t1 - t0
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
@@ -343,6 +348,7 @@ def main():
                    "inputs": "detections resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         "kernels": kernels,
+        "lap_fast_path": fast_stats,
         "gpu_busy_frac": gpu_busy_ms / (elapsed * 1e3) if elapsed > 0 else None,
         "flushes_per_step": (c1["flushes"] - c0["flushes"]) / K, "launches_per_step": (c1["launches"] - c0["launches"]) / K,
         "host_ms_per_step": {k: (c1[k] - c0[k]) / K for k in ("ms_begin", "ms_flush", "ms_advance", "ms_sync_wait")},

@@ -229,6 +229,18 @@ enum {
   MOT_LAP_F_PLAIN = 4 /* no geom.mode is MOT_COST_BOTSORT: the variants without the gated appearance term may run */
 };
 size_t mot_lap_work_bytes(int n, int m);
+/* mot_lap_solve runs two kernels over the task array: a fast path (viable pairs only, shortest augmenting paths, and a
+ * certificate that the optimum is unique — then it IS lapjv's answer) and, for the problems the fast path does not certify, the
+ * step-by-step lapjv emulation that reproduces the reference's tie-breaks. Diagnostics: outcome counts of the fast path on this
+ * device since the last reset (synchronises the context's stream): [0] finished by the fast path, [1] declined while listing the
+ * viable pairs (a cost within 1e-9 of the threshold, NaN/inf, more than 16 viable pairs in a column, ...), [2] a path search
+ * grew too large, [3] certificate arithmetic, [4] too many tight pairs, [5] optimum not unique (a tie), [6] not attempted
+ * (prof requested, cost flavour), [7] empty problems; [8..11] summed shader cycles of the fast path's stages (listing the viable
+ * pairs, initial matching, path searches, certificate), [12] path searches, [13] column scans inside them, [14] declined: a column with more than 16 viable
+ * pairs, [15] declined: more viable pairs than the list holds; [16..18] cycles inside [8]: bucketing
+ * the rows, the candidate sweep, the list build; [19] candidate rows looked at by lane 0, [20] pairs it evaluated; declined: [21] NaN / inf /
+ * out-of-range input, [22] pairs that do not intersect would be viable, [23] a cost within 1e-9 of the threshold. */
+int mot_lap_fast_stats(mot_ctx* ctx, unsigned long long* out24, int reset);
 int mot_lap_solve(mot_ctx* ctx, const mot_lap_task* tasks, int ntasks, int max_n, int max_m, int flags);
 
 /* ---- ByteTrack with the per-stream lifecycle on the device ------------------------------ */

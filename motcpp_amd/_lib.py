@@ -121,7 +121,18 @@ class Context:
                                               _p(i) if i is not None else None, C.c_float(gate), _p(x), _p(y), C.byref(info)))
         return x[:n], y[:m], info.value
 
-    def lap_geom(self, a, b, thresh, cost_mode=COST_IOU_DIST, conf=None, lap_mode=LAP_PLAIN, gate=0.0):
+    def lap_fast_stats(self, reset=False):
+        """Outcome counts of the assignment fast path on this device since the last reset (see mot_lap_fast_stats)."""
+        o = np.zeros(24, np.uint64)
+        self._chk(self.lib.mot_lap_fast_stats(self.h, _p(o), 1 if reset else 0))
+        return dict(zip(("fast", "declined_enum", "search_too_large", "certificate_arith", "too_many_tight", "not_unique", "not_attempted", "empty",
+                         "cycles_enumerate", "cycles_init", "cycles_search", "cycles_certificate", "searches", "column_scans",
+                         "declined_column_list_full", "declined_pair_list_full", "cycles_enum_bucket_rows", "cycles_enum_candidates",
+                         "cycles_enum_list", "lane0_candidates", "lane0_pairs_evaluated", "declined_nonfinite", "declined_viable_disjoint",
+                         "declined_threshold_tie"),
+                        (int(v) for v in o[:24])))
+
+    def lap_geom(self, a, b, thresh, cost_mode=COST_IOU_DIST, conf=None, lap_mode=LAP_PLAIN, gate=0.0, prof=False):
         """Assignment straight from boxes (on-the-fly IoU-family cost inside the solver; no matrix in memory)."""
         a, b = f32(a).reshape(-1, 4), f32(b).reshape(-1, 4)
         n, m = a.shape[0], b.shape[0]
@@ -132,7 +143,7 @@ class Context:
         c = f32(conf) if conf is not None else None
         self._chk(self.lib.mot_lap_geom_host(self.h, _p(a), n, _p(b), m, _p(c) if c is not None else None, int(cost_mode),
                                              C.c_float(thresh), int(lap_mode), C.c_float(gate), _p(x), _p(y), _p(xv), C.byref(info),
-                                             _p(self._prof)))
+                                             _p(self._prof) if prof else None))
         return x[:n], y[:m], xv[:n], info.value
 
     def kf_apply(self, kind, op, mean, cov, meas=None, q=None, flags=None, want_boxes=False):

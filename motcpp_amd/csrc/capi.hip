@@ -20,6 +20,7 @@ hipError_t launch_feat(const mot_feat_task*, int, int, hipStream_t);
 hipError_t launch_cosine(const mot_cos_task*, int, int, int, hipStream_t);
 hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, bool, hipStream_t);
 size_t lap_scratch_bytes(int n, int m);
+hipError_t lap_fast_stats(unsigned long long* out16, bool reset, hipStream_t st);
 }  // namespace mot
 
 #include "ctx.hpp"
@@ -140,6 +141,7 @@ int mot_ocsort_cost_ex(mot_ctx* c, const mot_ocsort_task* t, int nt, int max_nd,
 }
 int mot_cosine_cost(mot_ctx* c, const mot_cos_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_cosine(t, nt, max_n, max_m, c->stream)); return MOT_OK; }
 int mot_feat_update(mot_ctx* c, const mot_feat_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_feat(t, nt, max_n, c->stream)); return MOT_OK; }
+int mot_lap_fast_stats(mot_ctx* c, unsigned long long* out16, int reset) { MOT_HIP(c, mot::lap_fast_stats(out16, reset != 0, c->stream)); return MOT_OK; }
 size_t mot_lap_work_bytes(int n, int m) { return (mot::lap_scratch_bytes(n, m) + 255) & ~size_t(255); }
 int mot_lap_solve(mot_ctx* c, const mot_lap_task* t, int nt, int max_n, int max_m, int flags) { MOT_HIP(c, mot::launch_lap(t, nt, max_n, max_m, (flags & MOT_LAP_F_GEOM) != 0, (flags & MOT_LAP_F_ASSOC) != 0, (flags & MOT_LAP_F_PLAIN) != 0, c->stream)); return MOT_OK; }
 

@@ -197,6 +197,22 @@ struct DevGroup {
     *total = tot;
     return base + inc - v;
   }
+  // rank of the calling thread among the threads whose flag is set (ascending thread id) and their number
+  __device__ __forceinline__ int flag_rank(bool flag, int* total) {
+    if (size_ <= 64) {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+      *total = __builtin_popcountll(m);
+      return __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0u));
+    }
+    return exclusive_scan(flag ? 1 : 0, total);
+  }
+  // lexicographic (value, index) minimum over the group
+  __device__ __forceinline__ void reduce_lexmin(double& v, int& j) {
+    if (size_ <= 64) { wave_lexmin(v, j); return; }
+    Top2 t{v, 1e300, j, kNoIdx};
+    t = reduce_top2(t);
+    v = t.v1; j = t.j1;
+  }
   static __device__ __forceinline__ void atomic_max(int* p, int v) { atomicMax(p, v); }
   static __device__ __forceinline__ int atomic_add(int* p, int v) { return atomicAdd(p, v); }
   static __device__ __forceinline__ void atomic_min(int* p, int v) { atomicMin(p, v); }

@@ -10,7 +10,7 @@
 // pairs only:
 //   1. enumerate the viable pairs, per column (geometry: rows bucketed by x1, only rows that can intersect the column are
 //      evaluated, with the cost kernel's own arithmetic — a pair that does not intersect costs the same whatever the row
-//      is; materialised matrix: one coalesced sweep);
+//      is; materialised matrix: one coalesced sweep), compacted into a CSR list;
 //   2. column duals v_j = min_i w_ij, every column proposes to its best row, a row keeps its lowest proposer;
 //   3. each remaining column is inserted by a shortest augmenting path search (Dijkstra over the viable pairs with the
 //      reduced costs w_ij - u_i - v_j; a column may also end unmatched, at reduced cost -v_j), duals updated as in lapjv;
@@ -24,95 +24,168 @@
 //
 // eps = 1e-9 on costs of magnitude O(1): far above the rounding of either solver's fp64 duals (~n * 2^-52), far below the
 // spacing of float costs (IoU-family costs are multiples of 2^-24), so in practice it fires on exact ties only.
+//
+// Memory: everything the serial part touches (duals, assignments, the CSR list, search slots, and — while the pairs are
+// enumerated — the bucket-ordered row boxes, which share their bytes with the row duals/assignments that only exist
+// afterwards) is "hot" and sits in LDS when the problem fits; the per-column staging lists of the enumeration, the free list
+// and the certificate's arc list are "cold" (global scratch, streamed).
 #pragma once
 #include "cost_math.hpp"
 #include "grp.hpp"
 #include "lap_core.hpp"
 #include "mem.hpp"
 
+#if !defined(__HIPCC__) && defined(MOT_SPARSE_DEBUG)
+#include <cstdio>
+#define SPDBG(...) std::fprintf(stderr, __VA_ARGS__)
+#else
+#define SPDBG(...) ((void)0)
+#endif
+
 namespace mot {
 
-constexpr int kSpK = 8;            // viable pairs kept per column (more: fall back)
+constexpr int kSpK = 16;           // viable pairs kept per column (more: fall back)
 constexpr int kSpBuckets = 256;    // x1 buckets of the row boxes
 constexpr int kSpSlots = 64;       // rows one path search may reach (more: fall back)
-constexpr int kSpArcs = 256;       // eps-tight non-matching pairs the certificate may hold (more: fall back)
+constexpr int kSpQ = 32;           // rows that intersect one column (more: fall back)
 constexpr double kSpEps = 1e-9;    // tie margin
 constexpr double kSpTol = 1e-11;   // tolerated violation of dual feasibility / complementary slackness (fp64 rounding)
 constexpr int kSpIntMax = 0x7fffffff;
 constexpr float kSpHuge = 1.0e30f; // boxes / costs beyond this magnitude are left to the exact path
+MOT_HD int sparse_arc_cap(int nr, int nc) { return nr + nc + 64; }  // eps-tight non-matching pairs the certificate may hold
+
+struct alignas(16) SpBox { float x1, y1, x2, y2; };
 
 // Workspace. HS = address space of the hot arrays (LDS when the problem fits, else global scratch).
 template <int HS>
 struct SparseWorkT {
-  MemPtr<double, HS> u, v;       // row / column duals
-  MemPtr<int, HS> x, y;          // row -> column, column -> row (-1: unmatched)
+  // region R, 16 bytes per row: u | x | slot — or, while the pairs are enumerated, the bucket-ordered row boxes
+  MemPtr<double, HS> u;          // row duals
+  MemPtr<int, HS> x;             // row -> column (-1: unmatched)
   MemPtr<int, HS> slot;          // per row: 1 + search slot during a path search; flag bits during the certificate
+  MemPtr<SpBox, HS> sbox;        // [nr] (aliases u, x, slot)
+  MemPtr<unsigned short, HS> sidx;  // [nr] row index of a bucket-ordered position
+  MemPtr<double, HS> v;          // column duals
+  MemPtr<int, HS> y;             // column -> row
+  MemPtr<int, HS> eoff;          // [nc+1] CSR offsets of the viable pairs of a column
+  MemPtr<int, HS> erow;          // [ecap] row ...
+  MemPtr<float, HS> ecost;       // [ecap] ... and cost of a viable pair
   MemPtr<double, HS> sdist;      // search slots [kSpSlots]: distance label,
   MemPtr<int, HS> srow, spred, sstate;  // row, column it was reached from, 1 reached / 2 scanned
   MemPtr<int, HS> bstart, bcur, bmax;   // x1 buckets: [B+1] start, [B] fill cursor, [B] prefix maximum of the x2 keys
-  MemPtr<int, HS> ctr;           // [4] counters (arc count, flags)
-  MemPtr<int, kMemGlobal> erow;    // [nc][kSpK] viable pairs of a column: row (-1 ends the list) ...
-  MemPtr<float, kMemGlobal> ecost; // ... and cost
-  MemPtr<int, kMemGlobal> freel;   // [nc] columns still to insert
-  MemPtr<float, kMemGlobal> sbox;  // [nr][4] row boxes in bucket order
-  MemPtr<int, kMemGlobal> sidx;    // [nr] their row indices
-  MemPtr<int, kMemGlobal> arcs;    // [kSpArcs][2] eps-tight pair: (row, owner of its column)
+  MemPtr<int, HS> ctr;           // [4] counters
+  MemPtr<unsigned short, HS> hq; // [kSpQ][64] per-lane queue of intersecting candidate positions (enumeration from boxes)
+  int ecap = 0;
+  MemPtr<int, kMemGlobal> strow;    // [nc][kSpK] staging of a column's viable pairs while they are enumerated: row ...
+  MemPtr<float, kMemGlobal> stcost; // ... cost
+  MemPtr<int, kMemGlobal> freel;    // [nc] columns still to insert
+  MemPtr<int, kMemGlobal> arcs;     // [sparse_arc_cap][2] eps-tight pair: (row, owner of its column)
 };
-MOT_HD size_t sparse_hot_bytes(int nr, int nc) {
-  return static_cast<size_t>(nr) * 16 + static_cast<size_t>(nc) * 12 + kSpSlots * 20 + (3 * kSpBuckets + 1 + 4) * 4 + 16;
+MOT_HD size_t sparse_hot_bytes(int nr, int nc, int ecap) {
+  return static_cast<size_t>(nr) * 16 + ((static_cast<size_t>(nr) * 2 + 15) & ~size_t(15)) + static_cast<size_t>(nc) * 12 + 4 * (static_cast<size_t>(nc) + 4) +
+         static_cast<size_t>(ecap) * 8 + kSpSlots * 20 + (3 * kSpBuckets + 4 + 4) * 4 + kSpQ * 64 * 2 + 64;
 }
+MOT_HD int sparse_default_ecap(int nc) { return 5 * nc + 64; }
 MOT_HD size_t sparse_cold_bytes(int nr, int nc) {
-  return static_cast<size_t>(nc) * (8 * kSpK + 4) + static_cast<size_t>(nr) * 20 + kSpArcs * 8 + 64;
+  return static_cast<size_t>(nc) * (8 * kSpK + 4) + static_cast<size_t>(sparse_arc_cap(nr, nc)) * 8 + 64;
 }
-// Scratch of one task (mot_lap_work_bytes): the exact solver's hot + cold arrays and staged boxes, or — they are never live
-// at the same time — the fast path's lists; the last 16 bytes hold the task's status word (1: finished by the fast path).
+// Scratch of one task (mot_lap_work_bytes): the exact solver's hot + cold arrays and staged boxes, then the fast path's
+// cold lists and (when it does not fit in LDS) hot state with the default list capacity; the last 16 bytes hold the task's
+// status word (1: finished by the fast path).
 MOT_HD size_t lap_task_scratch_bytes(int n, int m) {
   const size_t rn = n > 0 ? n : 0, rm = m > 0 ? m : 0, nm = rn + rm;
-  return ((lap_hot_bytes(static_cast<int>(nm)) + 15) & ~size_t(15)) + ((lap_cold_bytes(static_cast<int>(nm)) + 15) & ~size_t(15)) + 4 * (5 * rn + 6 * rm) + 256 + 8192;
+  const int in = static_cast<int>(rn), im = static_cast<int>(rm);
+  return ((lap_hot_bytes(static_cast<int>(nm)) + 15) & ~size_t(15)) + ((lap_cold_bytes(static_cast<int>(nm)) + 15) & ~size_t(15)) + 4 * (5 * rn + 6 * rm) + 256 +
+         ((sparse_cold_bytes(in, im) + sparse_hot_bytes(in, im, sparse_default_ecap(im)) + 63) & ~size_t(15));
 }
 template <class W>
-MOT_HD void sparse_carve_hot(W& w, void* base, int nr, int nc) {
+MOT_HD void sparse_carve_hot(W& w, void* base, int nr, int nc, int ecap) {
   char* p = static_cast<char*>(base);
-  w.u.p = reinterpret_cast<double*>(p); p += 8 * static_cast<size_t>(nr);
+  w.u.p = reinterpret_cast<double*>(p);
+  w.sbox.p = reinterpret_cast<SpBox*>(p);
+  w.x.p = reinterpret_cast<int*>(p + 8 * static_cast<size_t>(nr));
+  w.slot.p = reinterpret_cast<int*>(p + 12 * static_cast<size_t>(nr));
+  p += 16 * static_cast<size_t>(nr);
   w.v.p = reinterpret_cast<double*>(p); p += 8 * static_cast<size_t>(nc);
   w.sdist.p = reinterpret_cast<double*>(p); p += 8 * kSpSlots;
-  w.x.p = reinterpret_cast<int*>(p); p += 4 * static_cast<size_t>(nr);
-  w.slot.p = reinterpret_cast<int*>(p); p += 4 * static_cast<size_t>(nr);
+  w.sidx.p = reinterpret_cast<unsigned short*>(p); p += (2 * static_cast<size_t>(nr) + 15) & ~size_t(15);
   w.y.p = reinterpret_cast<int*>(p); p += 4 * static_cast<size_t>(nc);
+  w.eoff.p = reinterpret_cast<int*>(p); p += 4 * (static_cast<size_t>(nc) + 4);
+  w.erow.p = reinterpret_cast<int*>(p); p += 4 * static_cast<size_t>(ecap);
+  w.ecost.p = reinterpret_cast<float*>(p); p += 4 * static_cast<size_t>(ecap);
   w.srow.p = reinterpret_cast<int*>(p); p += 4 * kSpSlots;
   w.spred.p = reinterpret_cast<int*>(p); p += 4 * kSpSlots;
   w.sstate.p = reinterpret_cast<int*>(p); p += 4 * kSpSlots;
-  w.bstart.p = reinterpret_cast<int*>(p); p += 4 * (kSpBuckets + 1);
+  w.bstart.p = reinterpret_cast<int*>(p); p += 4 * (kSpBuckets + 4);
   w.bcur.p = reinterpret_cast<int*>(p); p += 4 * kSpBuckets;
   w.bmax.p = reinterpret_cast<int*>(p); p += 4 * kSpBuckets;
-  w.ctr.p = reinterpret_cast<int*>(p);
+  w.ctr.p = reinterpret_cast<int*>(p); p += 16;
+  w.hq.p = reinterpret_cast<unsigned short*>(p);
+  w.ecap = ecap;
 }
 template <class W>
 MOT_HD void sparse_carve_cold(W& w, void* base, int nr, int nc) {
+  (void)nr;
   char* p = static_cast<char*>(base);
-  w.sbox.p = reinterpret_cast<float*>(p); p += 16 * static_cast<size_t>(nr);
-  w.sidx.p = reinterpret_cast<int*>(p); p += 4 * static_cast<size_t>(nr);
-  w.erow.p = reinterpret_cast<int*>(p); p += 4 * static_cast<size_t>(kSpK) * nc;
-  w.ecost.p = reinterpret_cast<float*>(p); p += 4 * static_cast<size_t>(kSpK) * nc;
+  w.strow.p = reinterpret_cast<int*>(p); p += 4 * static_cast<size_t>(kSpK) * nc;
+  w.stcost.p = reinterpret_cast<float*>(p); p += 4 * static_cast<size_t>(kSpK) * nc;
   w.freel.p = reinterpret_cast<int*>(p); p += 4 * static_cast<size_t>(nc);
   w.arcs.p = reinterpret_cast<int*>(p);
 }
 
 // Outcome of the enumeration of viable pairs.
 struct SparseEnum {
-  int ok;          // 0: something the fast path does not decide was seen (tie with the threshold, NaN, overflow ...)
-  double mincost;  // minimum cost over ALL pairs (MOT_LAP_GATE_MIN)
+  SparseEnum() = default;
+  MOT_DEV SparseEnum(int ok_, double mn) : ok(ok_), mincost(mn) {}
+  long long c_stage = 0, c_cand = 0, c_csr = 0;  // diagnostics: shader cycles of bucketing the rows / the candidate sweep / the CSR build
+  long long n_cand = 0, n_hit = 0;               // this lane's candidate rows looked at / intersecting pairs evaluated
+  int ok = 0;      // 1 fine; <= 0: something the fast path does not decide was seen — 0 (matrix source: a tie with the threshold /
+                   // NaN / inf), -10 more than kSpK viable pairs in a column, -11 the CSR list does not fit, -12 NaN / inf / out of
+                   // range, -13 pairs that do not intersect would be viable, -14 a cost within eps of the threshold
+  double mincost = 0.0;  // minimum cost over ALL pairs (MOT_LAP_GATE_MIN)
 };
+
+MOT_DEV int sp_e0(int e) { return e & 0xffffff; }          // packed CSR entry of a column: start | count << 24
+MOT_DEV int sp_deg(int e) { return (e >> 24) & 0xff; }
+// per-column staging lists (counts in y[j], which has no other use yet) -> CSR in the hot space; false when the list does not fit
+template <class G, class W>
+MOT_DEV bool sparse_build_csr(G& g, const W& w, int nc) {
+  const int T = g.size(), t = g.tid();
+  const int L = (nc + T - 1) / T;
+  const int j0 = t * L, j1 = (j0 + L < nc) ? j0 + L : nc;
+  int s = 0;
+  for (int j = j0; j < j1; ++j) s += static_cast<int>(w.y[j]);
+  int total;
+  int base = g.exclusive_scan(s, &total);
+  for (int j = j0; j < j1; ++j) {
+    const int c = w.y[j];
+    w.eoff[j] = base | (c << 24);
+    base += c;
+  }
+  g.sync();
+  if (total > w.ecap) return false;
+  for (int j = t; j < nc; j += T) {
+    const int e = w.eoff[j], b = sp_e0(e), c = sp_deg(e);
+    for (int k = 0; k < c; ++k) {
+      w.erow[b + k] = w.strow[static_cast<size_t>(j) * kSpK + k];
+      w.ecost[b + k] = w.stcost[static_cast<size_t>(j) * kSpK + k];
+    }
+  }
+  g.sync();
+  return true;
+}
 
 // ---- 1a. viable pairs from boxes ---------------------------------------------------------------------------------
 // Box source of one problem: planes [4][ld] with an optional gather index, as in mot_iou_task.
 struct SparseBoxes {
   const float* p; int ld; const int* idx;
+  MOT_DEV int gather(int i) const { return idx ? gld(idx, i) : i; }
   MOT_DEV void load(int i, float b[4]) const {
-    const int gi = idx ? gld(idx, i) : i;
+    const int gi = gather(i);
 #pragma unroll
     for (int k = 0; k < 4; ++k) b[k] = gld(p, static_cast<size_t>(k) * ld + gi);
   }
+  MOT_DEV float load_x1(int i) const { return gld(p, static_cast<size_t>(gather(i))); }
 };
 MOT_DEV bool sp_finite4(const float b[4]) {
   bool ok = true;
@@ -122,27 +195,60 @@ MOT_DEV bool sp_finite4(const float b[4]) {
 }
 // EvalFn(row index, row box, row area, column box, column area, column confidence, column index) -> float cost with the
 // cost kernel's arithmetic; zc(conf) = cost of a pair that does not intersect.
-template <class G, class W, class EvalFn, class ZeroFn>
+// A lane sweeps the candidate rows of one of its columns with box tests only, queueing the positions that intersect (LDS,
+// kSpQ per lane), then evaluates the queued pairs back to back — the expensive arithmetic runs with every lane busy instead
+// of under a one-in-seven branch — and writes the viable ones straight into a CSR segment it reserved for the queue's length.
+constexpr int kSpRC = 20;  // rows per lane whose x1 / gather index stay in registers across the three bucketing passes
+struct SpNoMinIou { MOT_DEV float operator()(float) const { return 0.0f; } };
+template <class G, class W, class EvalFn, class ZeroFn, class MinIouFn = SpNoMinIou>
 MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, const SparseBoxes& A, const SparseBoxes& Bx,
-                                          const float* bconf, const int* bidx, float thresh, EvalFn eval, ZeroFn zero_cost) {
+                                          const float* bconf, const int* bidx, float thresh, EvalFn eval, ZeroFn zero_cost,
+                                          MinIouFn min_iou_of = MinIouFn()) {
+  // min_iou_of(conf) > 0: the caller guarantees that a pair of that column whose IoU is not above the value (a 1 % margin
+  // already taken off) costs more than thresh + eps — such pairs are dropped by a division-free test
+  // (inter > min_iou * union) before the exact arithmetic; the minimum cost over all pairs is then not reported
   const int T = g.size(), t = g.tid();
   const double th = static_cast<double>(thresh);
-  int bad = 0;
+  const long long ec0 = MOT_CLOCK();
+  long long n_cand = 0, n_hit = 0;
+  // bits: 1 tie with the threshold, 2 column list full, 4 NaN / inf / out of range, 8 viable pairs that do not intersect, 16 CSR full
+  int bad = (nr > 65535 || T > 64) ? 4 : 0;
   // ---- rows into x1 buckets ----
+  const bool cached = nr <= T * kSpRC;
+  float rx1[kSpRC];
+  int rgi[kSpRC];
   float xlo = 3.0e38f, xhi = -3.0e38f;
-  for (int i = t; i < nr; i += T) {
-    float a[4];
-    A.load(i, a);
-    if (!sp_finite4(a)) bad = 1;
-    if (a[0] < xlo) xlo = a[0];
-    if (a[0] > xhi) xhi = a[0];
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < kSpRC; ++u) { const int i = t + u * T; rgi[u] = (i < nr) ? A.gather(i) : 0; }
+#pragma unroll
+    for (int u = 0; u < kSpRC; ++u) { const int i = t + u * T; rx1[u] = (i < nr) ? gld(A.p, static_cast<size_t>(rgi[u])) : 0.0f; }
+#pragma unroll
+    for (int u = 0; u < kSpRC; ++u) {
+      const int i = t + u * T;
+      if (i < nr) {
+        const float a0 = rx1[u];
+        if (!(a0 > -kSpHuge && a0 < kSpHuge)) bad |= 4;
+        if (a0 < xlo) xlo = a0;
+        if (a0 > xhi) xhi = a0;
+      }
+    }
+  } else {
+#pragma unroll 4
+    for (int i = t; i < nr; i += T) {
+      const float a0 = A.load_x1(i);
+      if (!(a0 > -kSpHuge && a0 < kSpHuge)) bad |= 4;
+      if (a0 < xlo) xlo = a0;
+      if (a0 > xhi) xhi = a0;
+    }
   }
   for (int b = t; b <= kSpBuckets; b += T) w.bstart[b] = 0;
   for (int b = t; b < kSpBuckets; b += T) w.bmax[b] = static_cast<int>(0x80000000u);
+  if (t == 0) w.ctr[2] = 0;
   xlo = static_cast<float>(g.reduce_min(static_cast<double>(xlo)));
   xhi = -static_cast<float>(g.reduce_min(-static_cast<double>(xhi)));
   bad = g.reduce_max(bad);
-  if (bad) return SparseEnum{0, 0.0};
+  if (bad) return SparseEnum(-12, 0.0);
   const float span = xhi - xlo;
   const float scale = (span > 0.0f) ? static_cast<float>(kSpBuckets) / span : 0.0f;
   // monotone non-decreasing in x (so a0 < b2 implies bucket(a0) <= bucket(b2)); any x maps into [0, B)
@@ -152,10 +258,13 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
     return (b < kSpBuckets) ? b : kSpBuckets - 1;
   };
   g.sync();
-  for (int i = t; i < nr; i += T) {
-    float a[4];
-    A.load(i, a);
-    G::atomic_add(w.bstart.raw(bucket(a[0]) + 1), 1);
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < kSpRC; ++u)
+      if (t + u * T < nr) G::atomic_add(w.bstart.raw(bucket(rx1[u]) + 1), 1);
+  } else {
+#pragma unroll 4
+    for (int i = t; i < nr; i += T) G::atomic_add(w.bstart.raw(bucket(A.load_x1(i)) + 1), 1);
   }
   g.sync();
   {  // exclusive scan of the bucket counts: contiguous chunk per lane
@@ -172,15 +281,29 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
     }
   }
   g.sync();
-  for (int i = t; i < nr; i += T) {
-    float a[4];
-    A.load(i, a);
+  auto place = [&](int i, const float a[4]) {
+    if (!sp_finite4(a)) bad |= 4;
     const int b = bucket(a[0]);
     const int pos = G::atomic_add(w.bcur.raw(b), 1);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) w.sbox[4 * static_cast<size_t>(pos) + k] = a[k];
-    w.sidx[pos] = i;
+    w.sbox[pos] = SpBox{a[0], a[1], a[2], a[3]};
+    w.sidx[pos] = static_cast<unsigned short>(i);
     G::atomic_max(w.bmax.raw(b), f32_key(a[2]));
+  };
+  if (cached) {
+    float r1[kSpRC], r2[kSpRC], r3[kSpRC];
+#pragma unroll
+    for (int u = 0; u < kSpRC; ++u) {
+      const bool in = t + u * T < nr;
+      r1[u] = in ? gld(A.p, static_cast<size_t>(A.ld) + rgi[u]) : 0.0f;
+      r2[u] = in ? gld(A.p, static_cast<size_t>(2) * A.ld + rgi[u]) : 0.0f;
+      r3[u] = in ? gld(A.p, static_cast<size_t>(3) * A.ld + rgi[u]) : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < kSpRC; ++u)
+      if (t + u * T < nr) { const float a[4] = {rx1[u], r1[u], r2[u], r3[u]}; place(t + u * T, a); }
+  } else {
+#pragma unroll 2
+    for (int i = t; i < nr; i += T) { float a[4]; A.load(i, a); place(i, a); }
   }
   g.sync();
   // after the fill bcur[b] = end of bucket b; bstart[b] = start: bstart[0] = 0, bstart[b+1] = bcur[b]
@@ -204,50 +327,110 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
   }
   g.sync();
   // ---- columns: candidates = rows of the buckets [blo, bhi] ----
+  const long long ec1 = MOT_CLOCK();
   double mn = 1e300;
   for (int j = t; j < nc; j += T) {
     float b[4];
     Bx.load(j, b);
     const int gj = bidx ? gld(bidx, j) : j;
     const float conf = bconf ? gld(bconf, gj) : 0.0f;
-    int ne = 0;
-    if (!sp_finite4(b) || !(conf > -kSpHuge && conf < kSpHuge)) bad = 1;
+    if (!sp_finite4(b) || !(conf > -kSpHuge && conf < kSpHuge)) bad |= 4;
     const float barea = (b[2] - b[0]) * (b[3] - b[1]);
     const float zc = zero_cost(conf);
-    if (!(static_cast<double>(zc) > th + kSpEps)) bad = 1;  // a non-intersecting pair would be viable (or zc is NaN)
-    int ninter = 0;
+    const float min_iou = min_iou_of(conf);
+    if (!(static_cast<double>(zc) > th + kSpEps)) bad |= 8;  // a non-intersecting pair would be viable (or zc is NaN)
+    int nq = 0, ne = 0, base = 0, seg = -1, ninter = 0;
     if (!bad) {
       const int bhi = bucket(b[2]);
       const int kb0 = f32_key(b[0]);
       int lo = 0, hi = bhi + 1;  // first bucket whose prefix maximum of x2 exceeds b0
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (static_cast<int>(w.bmax[mid]) > kb0) hi = mid; else lo = mid + 1; }
       const int ps = w.bstart[lo], pe = w.bstart[bhi + 1];
-      for (int p = ps; p < pe; ++p) {
-        float a[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) a[k] = w.sbox[4 * static_cast<size_t>(p) + k];
-        // w > 0 and h > 0 of iou_pair (finite boxes): anything else has inter == 0 and costs zc
-        if (!(a[0] < b[2] && a[2] > b[0] && a[1] < b[3] && a[3] > b[1])) continue;
-        const int i = w.sidx[p];
+      n_cand += pe - ps;
+      // evaluates the queued pairs, marks the viable ones, reserves exactly that many CSR entries (the most a column may
+      // hold if more candidates are still to come) and evaluates the viable ones once more to store them
+      auto pair_cost = [&](int q, int* row) {
+        const int pp = w.hq[q * 64 + t];
+        const SpBox s = w.sbox[pp];
+        *row = w.sidx[pp];
+        const float a[4] = {s.x1, s.y1, s.x2, s.y2};
         const float aarea = (a[2] - a[0]) * (a[3] - a[1]);
-        const float c = eval(i, a, aarea, b, barea, conf, j);
-        ++ninter;
-        if (!(c > -kSpHuge && c < kSpHuge)) { bad = 1; break; }
-        const double cd = static_cast<double>(c);
-        if (cd < mn) mn = cd;
-        if (cd < th - kSpEps) {
-          if (ne < kSpK) { w.erow[static_cast<size_t>(j) * kSpK + ne] = i; w.ecost[static_cast<size_t>(j) * kSpK + ne] = c; ++ne; }
-          else { bad = 1; break; }
-        } else if (!(cd > th + kSpEps)) { bad = 1; break; }  // tie with the threshold
+        return eval(*row, a, aarea, b, barea, conf, j);
+      };
+      auto drain = [&](bool last) {
+        if (nq == 0) return;
+        unsigned viable = 0u;
+        for (int q = 0; q < nq; ++q) {
+          int i;
+          const float c = pair_cost(q, &i);
+          if (!(c > -kSpHuge && c < kSpHuge)) { bad |= 4; continue; }
+          const double cd = static_cast<double>(c);
+          if (cd < mn) mn = cd;
+          // a cost EQUAL to the threshold stays in the graph as a pair of weight 0: it matters only if it is tight in the
+          // optimum, which the certificate checks like any other tie (float costs are not otherwise within eps of it)
+          if (cd < th - kSpEps || cd == th) viable |= 1u << q;
+          else if (!(cd > th + kSpEps)) bad |= 1;
+        }
+        const int nv = __builtin_popcount(viable);
+        if (seg < 0 && nv > 0) {
+          seg = last ? nv : kSpK;
+          if (seg > kSpK) { bad |= 2; seg = 0; }
+          base = (seg > 0) ? G::atomic_add(w.ctr.raw(2), seg) : 0;
+          if (base + seg > w.ecap) { bad |= 16; seg = 0; }
+        }
+        while (viable) {
+          const int q = __builtin_ctz(viable);
+          viable &= viable - 1u;
+          int i;
+          const float c = pair_cost(q, &i);
+          if (ne < seg) { w.erow[base + ne] = i; w.ecost[base + ne] = c; ++ne; }
+          else if (!(bad & 16)) bad |= 2;
+        }
+        ninter += nq;
+        nq = 0;
+      };
+      // w > 0 and h > 0 of iou_pair (finite boxes): anything else has inter == 0 and costs zc
+      auto hits = [&](const SpBox& s) {
+        if (!(s.x1 < b[2] && s.x2 > b[0] && s.y1 < b[3] && s.y2 > b[1])) return false;
+        if (min_iou > 0.0f) {  // iou_pair's intersection and union, without the division
+          const float iw = smin(s.x2, b[2]) - smax(s.x1, b[0]), ih = smin(s.y2, b[3]) - smax(s.y1, b[1]);
+          const float inter = iw * ih;
+          const float uni = (s.x2 - s.x1) * (s.y2 - s.y1) + barea - inter;
+          return inter > min_iou * uni;
+        }
+        return true;
+      };
+      auto push = [&](int p) { w.hq[nq * 64 + t] = static_cast<unsigned short>(p); if (++nq == kSpQ) drain(false); };
+      int p = ps;
+      for (; p + 4 <= pe; p += 4) {  // four boxes per round trip
+        const SpBox s0 = w.sbox[p], s1 = w.sbox[p + 1], s2 = w.sbox[p + 2], s3 = w.sbox[p + 3];
+        if (hits(s0)) push(p);
+        if (hits(s1)) push(p + 1);
+        if (hits(s2)) push(p + 2);
+        if (hits(s3)) push(p + 3);
       }
+      for (; p < pe; ++p) {
+        const SpBox s0 = w.sbox[p];
+        if (hits(s0)) push(p);
+      }
+      drain(true);
+      n_hit += ninter;
     }
-    if (ninter < nr && static_cast<double>(zc) < mn) mn = static_cast<double>(zc);
-    if (ne < kSpK) w.erow[static_cast<size_t>(j) * kSpK + ne] = -1;
+    nq = ninter;
+    if (nq < nr && static_cast<double>(zc) < mn) mn = static_cast<double>(zc);
+    w.eoff[j] = base | (ne << 24);
   }
-  bad = g.reduce_max(bad);
+  {  // OR of the lanes' flags
+    int any = 0;
+    for (int bit = 1; bit <= 16; bit <<= 1) any |= g.reduce_max((bad & bit) ? bit : 0);
+    bad = any;
+  }
   mn = g.reduce_min(mn);
   g.sync();
-  return SparseEnum{bad ? 0 : 1, mn};
+  SparseEnum out(1, mn);
+  if (bad) out.ok = (bad & 4) ? -12 : ((bad & 8) ? -13 : ((bad & 1) ? -14 : ((bad & 2) ? -10 : -11)));
+  out.c_stage = ec1 - ec0; out.c_cand = MOT_CLOCK() - ec1; out.c_csr = 0; out.n_cand = n_cand; out.n_hit = n_hit;
+  return out;
 }
 
 // ---- 1b. viable pairs from a materialised matrix (row-major, lane-owned columns: coalesced) -------------------------
@@ -259,41 +442,49 @@ MOT_DEV SparseEnum sparse_enumerate_matrix(G& g, const W& w, int nr, int nc, con
   double mn = 1e300;
   for (int j = t; j < nc; j += T) {
     int ne = 0;
-    for (int i = 0; i < nr && !bad; ++i) {
+#pragma unroll 8
+    for (int i = 0; i < nr; ++i) {
       const float c = gld(cost, static_cast<size_t>(i) * ld + j);
-      if (!(c > -kSpHuge && c < kSpHuge)) { bad = 1; break; }
+      if (!(c > -kSpHuge && c < kSpHuge)) bad = 1;
       const double cd = static_cast<double>(c);
       if (cd < mn) mn = cd;
-      if (cd < th - kSpEps) {
-        if (ne < kSpK) { w.erow[static_cast<size_t>(j) * kSpK + ne] = i; w.ecost[static_cast<size_t>(j) * kSpK + ne] = c; ++ne; }
-        else bad = 1;
-      } else if (!(cd > th + kSpEps)) bad = 1;
+      if (cd < th - kSpEps || cd == th) {  // (a cost equal to the threshold: a pair of weight 0, left to the certificate)
+        if (ne < kSpK) { w.strow[static_cast<size_t>(j) * kSpK + ne] = i; w.stcost[static_cast<size_t>(j) * kSpK + ne] = c; ++ne; }
+        else bad |= 2;
+      } else if (!(cd > th + kSpEps)) bad |= 1;
     }
-    if (ne < kSpK) w.erow[static_cast<size_t>(j) * kSpK + ne] = -1;
+    w.y[j] = ne;
   }
   bad = g.reduce_max(bad);
   mn = g.reduce_min(mn);
   g.sync();
-  return SparseEnum{bad ? 0 : 1, mn};
+  if (bad) return SparseEnum((bad & 1) ? 0 : -10, mn);
+  return SparseEnum(sparse_build_csr(g, w, nc) ? 1 : -11, mn);
 }
 
 // ---- 2-4. matching over the viable pairs + certificate ---------------------------------------------------------------
+struct SparseProf {  // diagnostics: shader cycles of the three stages, path searches and column scans
+  long long c_init = 0, c_search = 0, c_cert = 0;
+  int n_search = 0, n_scan = 0;
+};
 // Returns 1 with w.x / w.y holding THE minimum-weight matching (unique by more than kSpEps); else a reason <= 0 for the
 // exact path to take over (-2 a search reached too many rows, -3 certificate arithmetic, -4 too many tight pairs, -5 not unique).
 template <class G, class W>
-MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh) {
+MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh, SparseProf* prof = nullptr) {
   const int T = g.size(), t = g.tid();
   const double th = static_cast<double>(thresh);
+  const long long pc0 = MOT_CLOCK();
+  int n_scan = 0;
   for (int i = t; i < nr; i += T) { w.u[i] = 0.0; w.x[i] = kSpIntMax; w.slot[i] = 0; }
   g.sync();
   // column duals and proposals
   for (int j = t; j < nc; j += T) {
     float bc = 0.0f;
     int br = -1;
-    for (int k = 0; k < kSpK; ++k) {
-      const int r = w.erow[static_cast<size_t>(j) * kSpK + k];
-      if (r < 0) break;
-      const float c = w.ecost[static_cast<size_t>(j) * kSpK + k];
+    const int ee = w.eoff[j], e0 = sp_e0(ee), e1 = e0 + sp_deg(ee);
+    for (int k = e0; k < e1; ++k) {
+      const int r = w.erow[k];
+      const float c = w.ecost[k];
       if (br < 0 || c < bc || (c == bc && r < br)) { bc = c; br = r; }
     }
     w.v[j] = (br >= 0) ? static_cast<double>(bc) - th : 0.0;
@@ -304,13 +495,13 @@ MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh) {
   int nfree = 0;
   for (int j0 = 0; j0 < nc; j0 += T) {  // losers of a conflict, in ascending column order
     const int j = j0 + t;
-    int lose = 0;
+    bool lose = false;
     if (j < nc) {
       const int br = w.y[j];
-      if (br >= 0 && static_cast<int>(w.x[br]) != j) { lose = 1; w.y[j] = -1; }
+      if (br >= 0 && static_cast<int>(w.x[br]) != j) { lose = true; w.y[j] = -1; }
     }
     int tot;
-    const int pos = g.exclusive_scan(lose, &tot);
+    const int pos = g.flag_rank(lose, &tot);
     if (lose) w.freel[nfree + pos] = j;
     nfree += tot;
   }
@@ -319,9 +510,12 @@ MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh) {
     if (static_cast<int>(w.x[i]) == kSpIntMax) w.x[i] = -1;
   g.sync();
 
+  const long long pc1 = MOT_CLOCK();
   // ---- shortest augmenting path per remaining column ----
+  int j_next = (nfree > 0) ? static_cast<int>(w.freel[0]) : 0;
   for (int f = 0; f < nfree; ++f) {
-    const int j0 = w.freel[f];
+    const int j0 = j_next;
+    if (f + 1 < nfree) j_next = w.freel[f + 1];  // (global memory: fetched one search ahead)
     double L = -static_cast<double>(w.v[j0]);  // leave j0 unmatched
     int term_row = -1, term_col = j0;           // terminal: a free row, or the column that ends unmatched
     int cur = j0;
@@ -329,28 +523,24 @@ MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh) {
     int nslots = 0;
     bool overflow = false;
     for (;;) {
+      ++n_scan;
       // relax the viable pairs of column `cur`
       {
         const double vc = w.v[cur];
-        int need = 0, er = -1;
+        const int ee = w.eoff[cur], e0 = sp_e0(ee), deg = sp_deg(ee);
+        bool need = false;
+        int er = -1;
         double nd = 0.0;
-        if (t < kSpK) {
-          er = w.erow[static_cast<size_t>(cur) * kSpK + t];
-          // (entries after the -1 terminator are stale: a lane is valid only if every earlier entry is)
-        }
-        // validity prefix: the list ends at the first negative row
-        int firstneg = g.reduce_min_int((t < kSpK && er < 0) ? t : kSpIntMax);
-        const bool valid = t < kSpK && t < firstneg;
-        if (valid) {
-          const double red = (static_cast<double>(static_cast<float>(w.ecost[static_cast<size_t>(cur) * kSpK + t])) - th) -
-                             static_cast<double>(w.u[er]) - vc;
+        if (t < deg) {
+          er = w.erow[e0 + t];
+          const double red = (static_cast<double>(static_cast<float>(w.ecost[e0 + t])) - th) - static_cast<double>(w.u[er]) - vc;
           nd = D + red;
           const int s = w.slot[er];
-          if (s == 0) need = 1;
+          if (s == 0) need = true;
           else if (static_cast<int>(w.sstate[s - 1]) == 1 && nd < static_cast<double>(w.sdist[s - 1])) { w.sdist[s - 1] = nd; w.spred[s - 1] = cur; }
         }
         int tot;
-        const int pos = g.exclusive_scan(need, &tot);
+        const int pos = g.flag_rank(need, &tot);
         if (nslots + tot > kSpSlots) { overflow = true; break; }
         if (need) {
           const int q = nslots + pos;
@@ -360,19 +550,24 @@ MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh) {
       }
       g.sync();
       // nearest reached, not yet scanned row (ties: lowest row index)
-      Top2 tt = top2_empty();
+      double bd = 1e300;
+      int brow = kNoIdx;
       for (int q = t; q < nslots; q += T)
-        if (static_cast<int>(w.sstate[q]) == 1) top2_push(tt, static_cast<double>(w.sdist[q]), static_cast<int>(w.srow[q]));
-      tt = g.reduce_top2(tt);
-      if (tt.j1 == kNoIdx || !(tt.v1 < L)) break;
-      const int row = tt.j1;
+        if (static_cast<int>(w.sstate[q]) == 1) {
+          const double d = w.sdist[q];
+          const int r = w.srow[q];
+          if (lex_less(d, r, bd, brow)) { bd = d; brow = r; }
+        }
+      g.reduce_lexmin(bd, brow);
+      if (brow == kNoIdx || !(bd < L)) break;
+      const int row = brow;
       const int q = static_cast<int>(w.slot[row]) - 1;
       const int xc = w.x[row];
-      if (xc < 0) { L = tt.v1; term_row = row; term_col = -1; break; }
+      if (xc < 0) { L = bd; term_row = row; term_col = -1; break; }
       g.sync();
       if (t == 0) w.sstate[q] = 2;
       cur = xc;
-      D = tt.v1;
+      D = bd;
       const double cand = D - static_cast<double>(w.v[cur]);
       if (cand < L) { L = cand; term_row = -1; term_col = cur; }
       g.sync();
@@ -409,6 +604,8 @@ MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh) {
     g.sync();
   }
 
+  const long long pc2 = MOT_CLOCK();
+  if (prof) { prof->c_init = pc1 - pc0; prof->c_search = pc2 - pc1; prof->n_search = nfree; prof->n_scan = n_scan; }
   // ---- certificate ----
   enum : int { kStart = 1, kEnd = 2, kReach = 4, kArrived = 8, kFreeCol = 16, kIn = 32 };
   for (int i = t; i < nr; i += T) {
@@ -424,22 +621,23 @@ MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh) {
   if (t == 0) { w.ctr[0] = 0; w.ctr[1] = 0; }
   g.sync();
   int bad = 0;
+  const int arc_cap = sparse_arc_cap(nr, nc);
   for (int j = t; j < nc; j += T) {
     const double vj = w.v[j];
     const int yj = w.y[j];
     if (yj < 0 && !(vj >= -kSpTol && vj <= kSpTol)) bad = 1;  // an unmatched column carries no dual
     if (!(vj <= kSpTol)) bad = 1;
-    for (int k = 0; k < kSpK; ++k) {
-      const int r = w.erow[static_cast<size_t>(j) * kSpK + k];
-      if (r < 0) break;
-      const double red = (static_cast<double>(static_cast<float>(w.ecost[static_cast<size_t>(j) * kSpK + k])) - th) - static_cast<double>(w.u[r]) - vj;
+    const int ee = w.eoff[j], e0 = sp_e0(ee), e1 = e0 + sp_deg(ee);
+    for (int k = e0; k < e1; ++k) {
+      const int r = w.erow[k];
+      const double red = (static_cast<double>(static_cast<float>(w.ecost[k])) - th) - static_cast<double>(w.u[r]) - vj;
       if (r == yj) { if (!(red >= -kSpTol && red <= kSpTol)) bad = 1; continue; }
       if (!(red >= -kSpTol)) { bad = 1; continue; }
       if (red <= kSpEps) {
         if (yj < 0) G::atomic_or(w.slot.raw(r), kFreeCol | kEnd);
         else {
           const int a = G::atomic_add(w.ctr.raw(0), 1);
-          if (a < kSpArcs) { w.arcs[2 * a] = r; w.arcs[2 * a + 1] = yj; }
+          if (a < arc_cap) { w.arcs[2 * a] = r; w.arcs[2 * a + 1] = yj; }
         }
       }
     }
@@ -453,11 +651,12 @@ MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh) {
   g.sync();
   const int narcs = w.ctr[0];
   if (bad) return -3;
-  if (narcs > kSpArcs) return -4;
+  if (narcs > arc_cap) return -4;
   int nonuniq = 0;
   for (int i = t; i < nr; i += T) {
     const int fl = w.slot[i];
-    if ((fl & kStart) && (fl & kFreeCol)) nonuniq = 1;  // changes its column for free
+    if ((fl & kStart) && (fl & kEnd) && static_cast<int>(w.x[i]) >= 0) nonuniq = 1;  // a matched pair of weight ~0: dropping it is free
+    if ((fl & kStart) && (fl & kFreeCol)) { nonuniq = 1; SPDBG("k0 row %d x %d u %.17g\n", i, (int)w.x[i], (double)w.u[i]); }  // changes its column for free
   }
   if (narcs > 0) {
     // reachability from the rows that can start a path
@@ -478,19 +677,14 @@ MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh) {
     }
     for (int a = t; a < narcs; a += T) {
       const int fl = w.slot[static_cast<int>(w.arcs[2 * a + 1])];
-      if ((fl & kArrived) && (fl & kEnd)) nonuniq = 1;
+      if ((fl & kArrived) && (fl & kEnd)) { nonuniq = 1; SPDBG("path end row %d fl %d\n", (int)w.arcs[2 * a + 1], fl); }
     }
     // alternating cycle: peel arcs whose source has no live incoming arc; anything left lies on or behind a cycle
+    // (a dead arc keeps its source as -1 - source)
     int alive_n = narcs;
-    // arcs[2a] >= 0 marks a live arc (dead: source stored as -1 - source)
     for (int it = 0; it <= narcs && alive_n > 0; ++it) {
       for (int a = t; a < narcs; a += T) {
-        const int d = w.arcs[2 * a + 1];
-        const int s = w.arcs[2 * a];
-        (void)s;
-        G::atomic_and(w.slot.raw(d), ~kIn);
-      }
-      for (int a = t; a < narcs; a += T) {  // (sources may not be destinations of any arc: clear theirs too)
+        G::atomic_and(w.slot.raw(static_cast<int>(w.arcs[2 * a + 1])), ~kIn);
         const int s = w.arcs[2 * a];
         if (s >= 0) G::atomic_and(w.slot.raw(s), ~kIn);
       }
@@ -512,10 +706,11 @@ MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh) {
       g.sync();
       if (tk == 0) break;
     }
-    if (alive_n > 0) nonuniq = 1;
+    if (alive_n > 0) { nonuniq = 1; SPDBG("cycle alive %d\n", alive_n); }
   }
   nonuniq = g.reduce_max(nonuniq);
   g.sync();
+  if (prof) prof->c_cert = MOT_CLOCK() - pc2;
   return nonuniq ? -5 : 1;
 }
 

@@ -14,12 +14,20 @@ namespace {
 
 constexpr int kScratch = 1024;  // DevGroup reduction scratch
 
+// Outcome histogram of the fast path since the last reset (diagnostics, one atomic per problem): [0] finished here,
+// [1] enumeration declined (tie with the threshold, NaN/inf, list overflow, viable non-intersecting pairs), [2] a path search
+// reached too many rows, [3] certificate arithmetic, [4] too many tight pairs, [5] optimum not unique, [6] not attempted
+// (diagnostics requested / cost flavour), [7] empty problems
+__device__ unsigned long long g_fast_hist[64 * 24];  // 64 sets (block & 63) so that thousands of problems do not serialise on one line;  // [8..] cycles: enumeration, matching init, path searches, certificate; [12] searches, [13] column scans
+__device__ __forceinline__ unsigned long long* hist_set() { return g_fast_hist + (blockIdx.x & 63) * 24; }
+__device__ __forceinline__ void count_outcome(int k) { if (threadIdx.x == 0) atomicAdd(hist_set() + k, 1ull); }
+
 __device__ __forceinline__ int* status_word(const mot_lap_task& T, size_t scratch_bytes) {
   return reinterpret_cast<int*>(static_cast<char*>(T.work) + scratch_bytes - 16);
 }
 
 template <bool PLAIN, int HS>
-__global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __restrict__ tasks) {
+__global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __restrict__ tasks, int lds_ecap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mot_lap_task T = tasks[blockIdx.x];
   const int nr = T.n, nc = T.m, t = threadIdx.x;
@@ -28,6 +36,7 @@ __global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __re
     for (int i = t; i < nr; i += 64) { T.x[i] = -1; if (T.xval) T.xval[i] = 0.f; }
     for (int j = t; j < nc; j += 64) T.y[j] = -1;
     if (t == 0) { if (T.info) T.info[0] = 2; *status = 1; }
+    count_outcome(7);
     return;
   }
   const bool geom = T.geom.a != nullptr;
@@ -38,15 +47,15 @@ __global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __re
     if (PLAIN) skip = true;
     else if (!(1.0f > T.geom.prox_thresh)) skip = true;
   }
-  if (skip) { if (t == 0) *status = 0; return; }
+  if (skip) { if (t == 0) *status = 0; count_outcome(6); return; }
 
   mot::DevGroup g(smem);
   mot::SparseWorkT<HS> w;
   char* cold = static_cast<char*>(T.work);
   const size_t cold_b = (mot::sparse_cold_bytes(nr, nc) + 15) & ~size_t(15);
   mot::sparse_carve_cold(w, cold, nr, nc);
-  if constexpr (HS == mot::kMemLds) mot::sparse_carve_hot(w, smem + kScratch, nr, nc);
-  else mot::sparse_carve_hot(w, cold + cold_b, nr, nc);
+  if constexpr (HS == mot::kMemLds) mot::sparse_carve_hot(w, smem + kScratch, nr, nc, lds_ecap);
+  else mot::sparse_carve_hot(w, cold + cold_b, nr, nc, mot::sparse_default_ecap(nc));
 
   int path = 0;
   if (T.mode == MOT_LAP_OCSORT) {
@@ -76,7 +85,8 @@ __global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __re
     g.sync();
     if (max_row == 1 && max_col == 1) path = 1;
   }
-  int solved = 1;
+  int solved = 1, reason = 0;
+  const long long ck0 = MOT_CLOCK();
   if (path == 0) {
     mot::SparseEnum e;
     if (geom) {
@@ -96,16 +106,49 @@ __global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __re
         return C.eval_f(r, cb, cba, cf, j);
       };
       auto zc = [&](float cf) { return mot::cost_from_iou<!PLAIN>(C.prm, 0.0f, cf, []() { return 0.0f; }); };
+      // IoU a pair of a column with confidence cf needs before it can be viable (costs fall with the IoU in these modes),
+      // 1 % taken off; 0 = no bound (then every intersecting pair is evaluated)
+      const bool bound_ok = T.mode == MOT_LAP_PLAIN;
+      const int cmode = G.mode, cfuse = G.fuse;
+      const float th_f = T.thresh, prox = G.prox_thresh;
+      auto min_iou = [=](float cf) {
+        if (!bound_ok) return 0.0f;
+        float need = 0.0f;
+        if (cmode == MOT_COST_IOU_DIST) need = 1.0f - th_f;
+        else if (cmode == MOT_COST_NEG_IOU) need = -th_f;
+        else if (cmode == MOT_COST_IOU_DIST_FUSE) need = (cf > 0.0f) ? (1.0f - th_f) / cf : 2.0f;  // conf <= 0: never below 1
+        else if (cmode == MOT_COST_BOTSORT) {
+          const float plain = cfuse ? ((cf > 0.0f) ? (1.0f - th_f) / cf : 2.0f) : 1.0f - th_f;
+          need = mot::smin(plain, 1.0f - prox);  // the appearance term needs 1 - iou <= prox
+        }
+        if (!(need > 1.0e-3f)) return 0.0f;
+        return (need < 1.0f) ? 0.99f * need : 0.99f;
+      };
       e = mot::sparse_enumerate_boxes(g, w, nr, nc, mot::SparseBoxes{G.a, G.lda, G.aidx}, mot::SparseBoxes{G.b, G.ldb, G.bidx},
-                                      G.bconf, G.bidx, T.thresh, eval, zc);
+                                      G.bconf, G.bidx, T.thresh, eval, zc, min_iou);
     } else {
       e = mot::sparse_enumerate_matrix(g, w, nr, nc, T.cost, T.ldc, T.thresh);
     }
-    if (!e.ok) solved = 0;
+    if (e.ok <= 0) { solved = 0; reason = (e.ok == -10) ? 14 : ((e.ok == -11) ? 15 : ((e.ok == -12) ? 21 : ((e.ok == -13) ? 22 : ((e.ok == -14) ? 23 : 1)))); }
     else if (T.mode == MOT_LAP_GATE_MIN && !(e.mincost < static_cast<double>(T.gate))) path = 2;
-    else solved = (mot::sparse_solve(g, w, nr, nc, T.thresh) == 1) ? 1 : 0;
+    else {
+      const long long ck1 = MOT_CLOCK();
+      mot::SparseProf pf;
+      const int r = mot::sparse_solve(g, w, nr, nc, T.thresh, &pf);
+      solved = (r == 1) ? 1 : 0;
+      reason = (r >= -5 && r <= -2) ? -r : 1;
+      if (t == 0) {
+        unsigned long long* h = hist_set();
+        atomicAdd(h + 8, static_cast<unsigned long long>(ck1 - ck0)); atomicAdd(h + 9, static_cast<unsigned long long>(pf.c_init));
+        atomicAdd(h + 10, static_cast<unsigned long long>(pf.c_search)); atomicAdd(h + 11, static_cast<unsigned long long>(pf.c_cert));
+        atomicAdd(h + 12, static_cast<unsigned long long>(pf.n_search)); atomicAdd(h + 13, static_cast<unsigned long long>(pf.n_scan));
+        atomicAdd(h + 16, static_cast<unsigned long long>(e.c_stage)); atomicAdd(h + 17, static_cast<unsigned long long>(e.c_cand));
+        atomicAdd(h + 18, static_cast<unsigned long long>(e.c_csr)); atomicAdd(h + 19, static_cast<unsigned long long>(e.n_cand));
+        atomicAdd(h + 20, static_cast<unsigned long long>(e.n_hit));
+      }
+    }
   }
-  if (!solved) { if (t == 0) *status = 0; return; }
+  if (!solved) { if (t == 0) *status = 0; count_outcome(reason); return; }
   if (path == 2) {
     for (int i = t; i < nr; i += 64) w.x[i] = -1;
     for (int j = t; j < nc; j += 64) w.y[j] = -1;
@@ -120,11 +163,9 @@ __global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __re
         if (T.iou) v = mot::gld(T.iou, static_cast<size_t>(i) * T.ldi + xi);
         else if (!geom) v = mot::gld(T.cost, static_cast<size_t>(i) * T.ldc + xi);
         else {  // the pair's cost as enumerated (bit-identical to the cost kernel's value)
-          for (int k = 0; k < mot::kSpK; ++k) {
-            const int r = w.erow[static_cast<size_t>(xi) * mot::kSpK + k];
-            if (r < 0) break;
-            if (r == i) { v = w.ecost[static_cast<size_t>(xi) * mot::kSpK + k]; break; }
-          }
+          const int ee = w.eoff[xi], e0 = mot::sp_e0(ee);
+          for (int k = e0; k < e0 + mot::sp_deg(ee); ++k)
+            if (static_cast<int>(w.erow[k]) == i) { v = w.ecost[k]; break; }
         }
       }
       T.xval[i] = v;
@@ -132,24 +173,45 @@ __global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __re
   }
   for (int j = t; j < nc; j += 64) T.y[j] = w.y[j];
   if (t == 0) { if (T.info) T.info[0] = path; *status = 1; }
+  count_outcome(0);
 }
 
 }  // namespace
 
 namespace mot {
-// Launches the fast path over the task array. Hot state in LDS when it fits next to 7 other problems' (<= 20 KB) or at
-// least alone in 60 KB; else in the task's global scratch.
+// Launches the fast path over the task array. Hot state in LDS when it fits in 64 KB (the CSR list's capacity gives way first:
+// 5 pairs per column by default, never fewer than 3), else in the task's global scratch.
 hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool plain_costs, hipStream_t st) {
   if (ntasks <= 0) return hipSuccess;
-  const size_t hot = kScratch + sparse_hot_bytes(max_n > 0 ? max_n : 1, max_m > 0 ? max_m : 1) + 16;
-  const bool lds = hot <= 60 * 1024;
+  const int n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1;
+  constexpr size_t kBudget = 64 * 1024 - 64;
+  int ecap = sparse_default_ecap(m);
+  size_t hot = kScratch + sparse_hot_bytes(n, m, ecap);
+  if (hot > kBudget) {
+    const size_t fixed = kScratch + sparse_hot_bytes(n, m, 0);
+    ecap = (fixed < kBudget) ? static_cast<int>((kBudget - fixed) / 8) : 0;
+    hot = kScratch + sparse_hot_bytes(n, m, ecap);
+  }
+  const bool lds = ecap >= 3 * m + 16;
   if (lds) {
-    if (plain_costs) hipLaunchKernelGGL((lap_sparse_kernel<true, kMemLds>), dim3(ntasks), dim3(64), hot, st, tasks);
-    else hipLaunchKernelGGL((lap_sparse_kernel<false, kMemLds>), dim3(ntasks), dim3(64), hot, st, tasks);
+    if (plain_costs) hipLaunchKernelGGL((lap_sparse_kernel<true, kMemLds>), dim3(ntasks), dim3(64), hot, st, tasks, ecap);
+    else hipLaunchKernelGGL((lap_sparse_kernel<false, kMemLds>), dim3(ntasks), dim3(64), hot, st, tasks, ecap);
   } else {
-    if (plain_costs) hipLaunchKernelGGL((lap_sparse_kernel<true, kMemGlobal>), dim3(ntasks), dim3(64), kScratch, st, tasks);
-    else hipLaunchKernelGGL((lap_sparse_kernel<false, kMemGlobal>), dim3(ntasks), dim3(64), kScratch, st, tasks);
+    if (plain_costs) hipLaunchKernelGGL((lap_sparse_kernel<true, kMemGlobal>), dim3(ntasks), dim3(64), kScratch, st, tasks, 0);
+    else hipLaunchKernelGGL((lap_sparse_kernel<false, kMemGlobal>), dim3(ntasks), dim3(64), kScratch, st, tasks, 0);
   }
   return hipGetLastError();
+}
+hipError_t lap_fast_stats(unsigned long long* out16 /* [24] */, bool reset, hipStream_t st) {
+  hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  if (out16) {
+    unsigned long long raw[64 * 24];
+    e = hipMemcpyFromSymbol(raw, HIP_SYMBOL(g_fast_hist), sizeof(raw));
+    if (e != hipSuccess) return e;
+    for (int k = 0; k < 24; ++k) { out16[k] = 0; for (int s = 0; s < 64; ++s) out16[k] += raw[s * 24 + k]; }
+  }
+  if (reset) { static const unsigned long long z[64 * 24] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_fast_hist), z, sizeof(z)); }
+  return e;
 }
 }  // namespace mot

@@ -476,6 +476,24 @@ inline void lapjv_rect(const float* cost, int nr, int nc, int ld, double thresh,
       }
     }
   }
+  bool dump_it = std::getenv("ORC_LAP_DUMP") != nullptr;
+  if (dump_it && std::getenv("ORC_LAP_DUMP_TIES")) {  // only problems holding a cost within 1e-9 of the threshold
+    dump_it = false;
+    for (int i = 0; i < nr && !dump_it; ++i)
+      for (int j = 0; j < nc; ++j)
+        if (std::fabs(static_cast<double>(cost[static_cast<size_t>(i) * ld + j]) - thresh) <= 1e-9) { dump_it = true; break; }
+  }
+  if (const char* dd = dump_it ? std::getenv("ORC_LAP_DUMP") : nullptr) {  // instrumentation only: the problem as raw floats, for offline replay
+    static int seq = 0;
+    char path[512];
+    std::snprintf(path, sizeof(path), "%s/lap_%04d_%dx%d.bin", dd, seq++, nr, nc);
+    if (FILE* f = std::fopen(path, "wb")) {
+      const float th = static_cast<float>(thresh);
+      std::fwrite(&th, 4, 1, f);
+      for (int i = 0; i < nr; ++i) std::fwrite(cost + static_cast<size_t>(i) * ld, 4, nc, f);
+      std::fclose(f);
+    }
+  }
   if (std::getenv("ORC_LAP_TRACE")) {  // instrumentation only
     const LapStats& s = lap_stats();
     std::fprintf(stderr, "lapjv %dx%d: free_after_colred %ld uniq %ld carr %ld paths %ld finds %ld records %ld scan_rows %ld ties %ld\n", nr, nc,

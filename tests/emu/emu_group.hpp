@@ -76,6 +76,12 @@ struct EmuGroup {
     *total = tot;
     return base;
   }
+  int flag_rank(bool flag, int* total) { return exclusive_scan(flag ? 1 : 0, total); }
+  void reduce_lexmin(double& v, int& j) {
+    Top2 t{v, 1e300, j, kNoIdx};
+    t = reduce_top2(t);
+    v = t.v1; j = t.j1;
+  }
   static void atomic_max(int* p, int v) {
     int cur = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}

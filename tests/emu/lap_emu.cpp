@@ -73,9 +73,11 @@ static int run_sparse(const float* cost, int ld, const float* a, const float* b,
                       float thresh, int T, int* x, int* y, double* mincost) {
   using namespace mot;
   using W = SparseWorkT<kMemAny>;
-  std::vector<char> hot(sparse_hot_bytes(nr, nc) + 64), cold(sparse_cold_bytes(nr, nc) + 64);
+  const int ecap = kSpK * nc + 16;
+  std::vector<char> hotv(sparse_hot_bytes(nr, nc, ecap) + 64), cold(sparse_cold_bytes(nr, nc) + 64);
+  char* hot = hotv.data() + ((16 - (reinterpret_cast<size_t>(hotv.data()) & 15)) & 15);  // SpBox is 16-byte aligned
   W w;
-  sparse_carve_hot(w, hot.data(), nr, nc);
+  sparse_carve_hot(w, hot, nr, nc, ecap);
   sparse_carve_cold(w, cold.data(), nr, nc);
   std::vector<float> ap(4 * (nr > 0 ? nr : 1)), bp(4 * (nc > 0 ? nc : 1));  // planes [4][n]
   if (a) {
@@ -100,13 +102,21 @@ static int run_sparse(const float* cost, int ld, const float* a, const float* b,
           return C.eval_f(r, cb, cba, cf, j);
         };
         auto zc = [&](float cf) { return cost_from_iou<true>(C.prm, 0.0f, cf, []() { return 0.0f; }); };
+        auto min_iou = [=](float cf) {  // as lap_sparse_kernel.hip does for the plain modes
+          float need = 0.0f;
+          if (mode == MOT_COST_IOU_DIST) need = 1.0f - thresh;
+          else if (mode == MOT_COST_NEG_IOU) need = -thresh;
+          else if (mode == MOT_COST_IOU_DIST_FUSE) need = (cf > 0.0f) ? (1.0f - thresh) / cf : 2.0f;
+          if (!(need > 1.0e-3f)) return 0.0f;
+          return (need < 1.0f) ? 0.99f * need : 0.99f;
+        };
         e = sparse_enumerate_boxes(g, w, nr, nc, SparseBoxes{ap.data(), nr, nullptr}, SparseBoxes{bp.data(), nc, nullptr}, conf, nullptr,
-                                   thresh, eval, zc);
+                                   thresh, eval, zc, min_iou);
       } else {
         e = sparse_enumerate_matrix(g, w, nr, nc, cost, ld, thresh);
       }
       mins[t] = e.mincost;
-      res[t] = e.ok ? sparse_solve(g, w, nr, nc, thresh) : -1;
+      res[t] = (e.ok == 1) ? sparse_solve(g, w, nr, nc, thresh) : ((e.ok == 0 || e.ok <= -12) ? -1 : e.ok);
     });
   for (auto& t : th) t.join();
   for (int t = 1; t < T; ++t) if (res[t] != res[0]) return -99;  // must be uniform

@@ -20,7 +20,7 @@ for seed in range(120):
     tb = np.stack([s.c[:, 0] - s.w / 2, s.c[:, 1] - s.h / 2, s.c[:, 0] + s.w / 2, s.c[:, 1] + s.h / 2], 1).astype(np.float32)
     tb = tb + np.random.RandomState(seed).randn(*tb.shape).astype(np.float32) * 2
     hi = d[d[:, 4] > 0.45]
-    ctx.lap_geom(tb, hi[:, :4], 0.8, L.COST_IOU_DIST_FUSE, hi[:, 4])
+    ctx.lap_geom(tb, hi[:, :4], 0.8, L.COST_IOU_DIST_FUSE, hi[:, 4], prof=True)
     p = np.array(ctx._prof, np.int64)
     tot.append(p[:4].sum())
     phases.append(p[:8].copy())

@@ -47,7 +47,7 @@ namespace mot {
 constexpr int kSpK = 16;           // viable pairs kept per column (more: fall back)
 constexpr int kSpBuckets = 256;    // x1 buckets of the row boxes
 constexpr int kSpSlots = 64;       // rows one path search may reach (more: fall back)
-constexpr int kSpQ = 32;           // rows that intersect one column (more: fall back)
+constexpr int kSpQ = 8;            // per-lane queue of candidate rows awaiting the exact arithmetic (drained when full)
 constexpr double kSpEps = 1e-9;    // tie margin
 constexpr double kSpTol = 1e-11;   // tolerated violation of dual feasibility / complementary slackness (fp64 rounding)
 constexpr int kSpIntMax = 0x7fffffff;
@@ -59,33 +59,36 @@ struct alignas(16) SpBox { float x1, y1, x2, y2; };
 // Workspace. HS = address space of the hot arrays (LDS when the problem fits, else global scratch).
 template <int HS>
 struct SparseWorkT {
-  // region R, 16 bytes per row: u | x | slot — or, while the pairs are enumerated, the bucket-ordered row boxes
+  // state of the matching: u | x | slot (16 bytes per row), v | y (12 bytes per column) — or, while the pairs are
+  // enumerated, the bucket-ordered row boxes (over u, x, slot) and the x1 buckets + candidate queues (over v, y)
   MemPtr<double, HS> u;          // row duals
   MemPtr<int, HS> x;             // row -> column (-1: unmatched)
   MemPtr<int, HS> slot;          // per row: 1 + search slot during a path search; flag bits during the certificate
-  MemPtr<SpBox, HS> sbox;        // [nr] (aliases u, x, slot)
-  MemPtr<unsigned short, HS> sidx;  // [nr] row index of a bucket-ordered position
   MemPtr<double, HS> v;          // column duals
   MemPtr<int, HS> y;             // column -> row
-  MemPtr<int, HS> eoff;          // [nc+1] CSR offsets of the viable pairs of a column
-  MemPtr<int, HS> erow;          // [ecap] row ...
+  MemPtr<SpBox, HS> sbox;        // [nr] (aliases u, x, slot)
+  MemPtr<int, HS> bstart, bcur, bmax;  // x1 buckets: [B+4] start, [B] fill cursor, [B] prefix maximum of the x2 keys (alias v, y)
+  MemPtr<unsigned short, HS> hq; // [kSpQ][64] per-lane queue of candidate positions worth the exact arithmetic (aliases v, y)
+  MemPtr<unsigned short, HS> sidx;  // [nr] row index of a bucket-ordered position
+  MemPtr<int, HS> eoff;          // [nc] CSR entry of a column: start | count << 24
+  MemPtr<unsigned short, HS> erow;  // [ecap] row ...
   MemPtr<float, HS> ecost;       // [ecap] ... and cost of a viable pair
   MemPtr<double, HS> sdist;      // search slots [kSpSlots]: distance label,
   MemPtr<int, HS> srow, spred, sstate;  // row, column it was reached from, 1 reached / 2 scanned
-  MemPtr<int, HS> bstart, bcur, bmax;   // x1 buckets: [B+1] start, [B] fill cursor, [B] prefix maximum of the x2 keys
   MemPtr<int, HS> ctr;           // [4] counters
-  MemPtr<unsigned short, HS> hq; // [kSpQ][64] per-lane queue of intersecting candidate positions (enumeration from boxes)
   int ecap = 0;
-  MemPtr<int, kMemGlobal> strow;    // [nc][kSpK] staging of a column's viable pairs while they are enumerated: row ...
+  MemPtr<int, kMemGlobal> strow;    // [nc][kSpK] staging of a column's viable pairs (matrix source): row ...
   MemPtr<float, kMemGlobal> stcost; // ... cost
   MemPtr<int, kMemGlobal> freel;    // [nc] columns still to insert
   MemPtr<int, kMemGlobal> arcs;     // [sparse_arc_cap][2] eps-tight pair: (row, owner of its column)
 };
+constexpr size_t kSpEnumBytes = 4 * (kSpBuckets + 4) + 8 * kSpBuckets + 2 * kSpQ * 64;  // buckets + queues
+MOT_HD size_t sparse_vy_bytes(int nc) { const size_t b = 12 * static_cast<size_t>(nc); return ((b > kSpEnumBytes ? b : kSpEnumBytes) + 15) & ~size_t(15); }
 MOT_HD size_t sparse_hot_bytes(int nr, int nc, int ecap) {
-  return static_cast<size_t>(nr) * 16 + ((static_cast<size_t>(nr) * 2 + 15) & ~size_t(15)) + static_cast<size_t>(nc) * 12 + 4 * (static_cast<size_t>(nc) + 4) +
-         static_cast<size_t>(ecap) * 8 + kSpSlots * 20 + (3 * kSpBuckets + 4 + 4) * 4 + kSpQ * 64 * 2 + 64;
+  return static_cast<size_t>(nr) * 16 + sparse_vy_bytes(nc) + ((static_cast<size_t>(nr) * 2 + 15) & ~size_t(15)) + 4 * (static_cast<size_t>(nc) + 4) +
+         ((static_cast<size_t>(ecap) * 2 + 15) & ~size_t(15)) + static_cast<size_t>(ecap) * 4 + kSpSlots * 20 + 16 + 64;
 }
-MOT_HD int sparse_default_ecap(int nc) { return 5 * nc + 64; }
+MOT_HD int sparse_default_ecap(int nc) { return 4 * nc + 64; }
 MOT_HD size_t sparse_cold_bytes(int nr, int nc) {
   return static_cast<size_t>(nc) * (8 * kSpK + 4) + static_cast<size_t>(sparse_arc_cap(nr, nc)) * 8 + 64;
 }
@@ -106,21 +109,22 @@ MOT_HD void sparse_carve_hot(W& w, void* base, int nr, int nc, int ecap) {
   w.x.p = reinterpret_cast<int*>(p + 8 * static_cast<size_t>(nr));
   w.slot.p = reinterpret_cast<int*>(p + 12 * static_cast<size_t>(nr));
   p += 16 * static_cast<size_t>(nr);
-  w.v.p = reinterpret_cast<double*>(p); p += 8 * static_cast<size_t>(nc);
+  w.v.p = reinterpret_cast<double*>(p);
+  w.y.p = reinterpret_cast<int*>(p + 8 * static_cast<size_t>(nc));
+  w.bstart.p = reinterpret_cast<int*>(p);
+  w.bcur.p = w.bstart.p + kSpBuckets + 4;
+  w.bmax.p = w.bcur.p + kSpBuckets;
+  w.hq.p = reinterpret_cast<unsigned short*>(w.bmax.p + kSpBuckets);
+  p += sparse_vy_bytes(nc);
   w.sdist.p = reinterpret_cast<double*>(p); p += 8 * kSpSlots;
   w.sidx.p = reinterpret_cast<unsigned short*>(p); p += (2 * static_cast<size_t>(nr) + 15) & ~size_t(15);
-  w.y.p = reinterpret_cast<int*>(p); p += 4 * static_cast<size_t>(nc);
+  w.erow.p = reinterpret_cast<unsigned short*>(p); p += (2 * static_cast<size_t>(ecap) + 15) & ~size_t(15);
   w.eoff.p = reinterpret_cast<int*>(p); p += 4 * (static_cast<size_t>(nc) + 4);
-  w.erow.p = reinterpret_cast<int*>(p); p += 4 * static_cast<size_t>(ecap);
   w.ecost.p = reinterpret_cast<float*>(p); p += 4 * static_cast<size_t>(ecap);
   w.srow.p = reinterpret_cast<int*>(p); p += 4 * kSpSlots;
   w.spred.p = reinterpret_cast<int*>(p); p += 4 * kSpSlots;
   w.sstate.p = reinterpret_cast<int*>(p); p += 4 * kSpSlots;
-  w.bstart.p = reinterpret_cast<int*>(p); p += 4 * (kSpBuckets + 4);
-  w.bcur.p = reinterpret_cast<int*>(p); p += 4 * kSpBuckets;
-  w.bmax.p = reinterpret_cast<int*>(p); p += 4 * kSpBuckets;
-  w.ctr.p = reinterpret_cast<int*>(p); p += 16;
-  w.hq.p = reinterpret_cast<unsigned short*>(p);
+  w.ctr.p = reinterpret_cast<int*>(p);
   w.ecap = ecap;
 }
 template <class W>
@@ -167,7 +171,7 @@ MOT_DEV bool sparse_build_csr(G& g, const W& w, int nc) {
   for (int j = t; j < nc; j += T) {
     const int e = w.eoff[j], b = sp_e0(e), c = sp_deg(e);
     for (int k = 0; k < c; ++k) {
-      w.erow[b + k] = w.strow[static_cast<size_t>(j) * kSpK + k];
+      w.erow[b + k] = static_cast<unsigned short>(static_cast<int>(w.strow[static_cast<size_t>(j) * kSpK + k]));
       w.ecost[b + k] = w.stcost[static_cast<size_t>(j) * kSpK + k];
     }
   }
@@ -329,11 +333,18 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
   // ---- columns: candidates = rows of the buckets [blo, bhi] ----
   const long long ec1 = MOT_CLOCK();
   double mn = 1e300;
-  for (int j = t; j < nc; j += T) {
-    float b[4];
-    Bx.load(j, b);
+  // the next column's box and confidence are fetched while the current one is processed
+  float nb[4] = {0.f, 0.f, 0.f, 0.f}, nconf = 0.0f;
+  auto fetch_column = [&](int j) {
+    Bx.load(j, nb);
     const int gj = bidx ? gld(bidx, j) : j;
-    const float conf = bconf ? gld(bconf, gj) : 0.0f;
+    nconf = bconf ? gld(bconf, gj) : 0.0f;
+  };
+  if (t < nc) fetch_column(t);
+  for (int j = t; j < nc; j += T) {
+    const float b[4] = {nb[0], nb[1], nb[2], nb[3]};
+    const float conf = nconf;
+    if (j + T < nc) fetch_column(j + T);
     if (!sp_finite4(b) || !(conf > -kSpHuge && conf < kSpHuge)) bad |= 4;
     const float barea = (b[2] - b[0]) * (b[3] - b[1]);
     const float zc = zero_cost(conf);
@@ -383,7 +394,7 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
           viable &= viable - 1u;
           int i;
           const float c = pair_cost(q, &i);
-          if (ne < seg) { w.erow[base + ne] = i; w.ecost[base + ne] = c; ++ne; }
+          if (ne < seg) { w.erow[base + ne] = static_cast<unsigned short>(i); w.ecost[base + ne] = c; ++ne; }
           else if (!(bad & 16)) bad |= 2;
         }
         ninter += nq;
@@ -438,7 +449,7 @@ template <class G, class W>
 MOT_DEV SparseEnum sparse_enumerate_matrix(G& g, const W& w, int nr, int nc, const float* cost, int ld, float thresh) {
   const int T = g.size(), t = g.tid();
   const double th = static_cast<double>(thresh);
-  int bad = 0;
+  int bad = (nr > 65535) ? 1 : 0;
   double mn = 1e300;
   for (int j = t; j < nc; j += T) {
     int ne = 0;

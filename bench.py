@@ -14,6 +14,7 @@ summed HIP-event time inside the timed region) and `cpu_baseline` (the CPU oracl
 timed on one host core on a bounded sample of stream 0).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -60,7 +61,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="NS", choices=sorted(WORKLOADS),
+                    help="NS = the north-star shape the >= 50 k frames/s bar is set on (ByteTrack, 1000 tracks x 500 detections)")
+    ap.add_argument("--settle", type=int, default=30,
+                    help="untimed frames stepped before the warm-up so that the track pools are in steady state whatever --warmup is "
+                         "(a stream starts by giving birth to its whole population at once)")
+    ap.add_argument("--host-input-steps", type=int, default=8,
+                    help="after the timed region: this many more steps with the detections uploaded from page-locked host memory inside "
+                         "the step (reported as host_input; 0 = skip). Device-lifecycle workloads only")
     ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (0: workload default)")
     ap.add_argument("--threads", type=int, default=0, help="host worker threads for the per-stream lifecycle, shared by the sub-batches (0: min(64, cores))")
     ap.add_argument("--gather-every", type=int, default=8)
@@ -101,7 +109,12 @@ def main():
     # throttles the whole process (measured on the 16-CPU-quota GPU boxes: 32 workers 456k frames/s, 64 workers 268k)
     threads = args.threads or max(2, min(os.cpu_count() or 1, 64, 2 * cpu_budget() // max(1, world_local())))
     K, W = args.steps, args.warmup
-    F = K + W
+    on_device_wl = tracker in ("bytetrack", "sort") and args.lifecycle in ("auto", "device")
+    Z = max(0, args.settle)
+    H = max(0, args.host_input_steps) if on_device_wl else 0
+    W0 = W            # the warm-up the caller asked for (reported); the settling frames are stepped before it
+    W = W + Z
+    F = K + W + H
 
     # ---- synthetic streams (seed 1234 + global stream id), generated before anything is timed ----
     host = np.zeros((F, S, M, 6), np.float32)
@@ -192,8 +205,9 @@ def main():
     kept = []  # stream 0 outputs of rank 0 for the parity spot check
     for f in range(W):
         out, cnt = step(f)
-        if rank == 0:
+        if rank == 0 and f < 40:
             kept.append(out[0, :cnt[0]].copy())
+    n_kept_warm = len(kept)
     if world > 1:
         gather(out, cnt)
         dist.barrier()
@@ -215,6 +229,14 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     stats = {}
+    achieved_dims = None
+    if on_device and tracker == "bytetrack":
+        dims = np.sum([b.profile_dims() for b in batches], axis=0)
+        pc = [sum(b.profile_stats()[k] for b in batches) for k in ("lap1_problems", "lap23_problems")]
+        achieved_dims = {"first_association": {"problems": int(pc[0]), "mean_tracks_N": dims[0] / max(pc[0], 1), "mean_dets_M": dims[1] / max(pc[0], 1)},
+                    "second_and_unconfirmed": {"problems": int(pc[1]), "mean_tracks_N": dims[2] / max(pc[1], 1), "mean_dets_M": dims[3] / max(pc[1], 1)},
+                    "note": "rows x columns of the assignment problems actually queued in the timed region (pool of tracked + lost tracks x "
+                            "high-score detections; then remaining tracked x low-score detections and unconfirmed x remaining detections)"}
     for b in batches:
         ps = b.profile_stats()
         if on_device:  # the solver's launches are timed on the device stream; "frame" = all 14 launches of a frame
@@ -230,6 +252,33 @@ def main():
     c1 = counters()
     fast_stats = diag_ctx.lap_fast_stats()
     elapsed = t1 - t0
+    # ---- the same steps with the detections coming from (page-locked) host memory inside the step ----
+    host_input = None
+    if H > 0 and on_device:
+        pinned = torch.from_numpy(np.ascontiguousarray(host[W + K:W + K + H].transpose(0, 1, 3, 2))).pin_memory()  # [H, S, 6, M]
+        stage = [torch.empty((bounds[p + 1] - bounds[p], 6, M), dtype=torch.float32, device=f"cuda:{local}") for p in range(PIPE)]
+
+        def sub_step_host(p, h):
+            s0, s1 = bounds[p], bounds[p + 1]
+            b = batches[p]
+            src = pinned[h, s0:s1]
+            b.ctx._chk(b.lib.mot_memcpy_h2d(b.ctx.h, C.c_void_p(stage[p].data_ptr()), C.c_void_p(src.data_ptr()), C.c_size_t(src.numel() * 4)))
+            b.step(resident_ptr=stage[p].data_ptr(), counts=full_counts[p], out=out_all[s0:s1], out_counts=cnt_all[s0:s1])
+
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for h in range(H):
+            if pools is None:
+                sub_step_host(0, h)
+            else:
+                for fut in [pools[p].submit(sub_step_host, p, h) for p in range(PIPE)]:
+                    fut.result()
+        torch.cuda.synchronize()
+        th1 = time.perf_counter()
+        host_input = {"value": S * H / (th1 - th0), "unit": "frames/s (this rank)", "steps": H, "ms_per_step": (th1 - th0) / H * 1e3,
+                      "h2d_bytes_per_step": S * 6 * M * 4,
+                      "note": "same tracker state, the frames after the timed region; detections copied from page-locked host memory on the "
+                              "sub-batch's stream inside each step (PCIe-inclusive rate; never the headline value)"}
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -300,15 +349,18 @@ def main():
         kind = {"sort": orclib.SORT, "bytetrack": orclib.BYTETRACK, "ocsort": orclib.OCSORT, "botsort": orclib.BOTSORT}[tracker]
         to = orc.tracker(kind)
         mism = 0
-        for f in range(len(kept)):  # parity spot check on the frames the GPU path just processed
-            fi = f if f < W else W + (f - W)
+        # parity spot check on frames the GPU path just processed: the first frames of stream 0 and the first timed ones
+        # (the oracle steps through every frame in between: its state has to be the tracker's)
+        want = {f: kept[f] for f in range(n_kept_warm)}
+        want.update({W + k: kept[n_kept_warm + k] for k in range(len(kept) - n_kept_warm)})
+        for fi in range(max(want) + 1):
             oo = to.update(host[fi, 0], embs[fi, 0] if D else None)
-            if oo.shape != kept[f].shape or not np.array_equal(oo, kept[f]):
+            if fi in want and (oo.shape != want[fi].shape or not np.array_equal(oo, want[fi])):
                 mism += 1
         parity = {"stream0_frames_checked": len(kept), "mismatching_frames": mism}
         to2 = orc.tracker(kind)
         st0 = SynthStream(P, M, 1234, D)
-        for _ in range(W):
+        for _ in range(min(W, 40)):
             d, e = st0.next_frame()
             to2.update(d, e)
         n, tc = 0, 0.0
@@ -319,7 +371,7 @@ def main():
             tc += time.perf_counter() - ta
             n += 1
         cpu = {"value": n / tc, "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{n} consecutive frames of stream 0 after {W} warm-up frames ({tc:.1f} s), oracle/ (scalar C++17, -O2)",
+               "sample": f"{n} consecutive frames of stream 0 after {min(W, 40)} warm-up frames ({tc:.1f} s), oracle/ (scalar C++17, -O2)",
                "host_cores_available": os.cpu_count()}
         # the reference is single-threaded per tracker; "one tracker per core"  = independent oracle
         # processes, as many as this box's CPU budget, each on its own stream, all running at the same time; only the tracker calls are timed
@@ -338,17 +390,18 @@ def main():
 
     line = {
         "metric": "tracker.update() frames/sec at N_tracks x M_dets (assignment indices identical to the reference path)",
-        "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W0,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "tracker": tracker, "tracks": P, "dets_per_frame": M, "emb_dim": D,
-                   "streams_per_gpu": S, "frames_per_step": world * S, "host_threads": PIPE if on_device else threads, "sub_batches": PIPE,
+                   "streams_per_gpu": S, "frames_per_step": world * S, "settle_frames": Z, "host_threads": PIPE if on_device else threads, "sub_batches": PIPE,
                    "lifecycle": "device (mot_bt_* / mot_sort_*: a fixed launch sequence per frame, no host decisions)" if on_device else "host stage machines",
                    "parallelism": f"{world} GPU(s) x {S} independent streams, lockstep stages",
                    "inputs": "detections resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         "kernels": kernels,
         "lap_fast_path": fast_stats,
+        "achieved_problem_sizes": achieved_dims, "host_input": host_input,
         "gpu_busy_frac": gpu_busy_ms / (elapsed * 1e3) if elapsed > 0 else None,
         "flushes_per_step": (c1["flushes"] - c0["flushes"]) / K, "launches_per_step": (c1["launches"] - c0["launches"]) / K,
         "host_ms_per_step": {k: (c1[k] - c0[k]) / K for k in ("ms_begin", "ms_flush", "ms_advance", "ms_sync_wait")},

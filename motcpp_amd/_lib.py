@@ -480,6 +480,13 @@ class DeviceByteTrack:
         return {"lap1_ms": o[0], "lap23_ms": o[1], "frame_ms": o[2], "frames": int(o[3]), "lap1_problems": o[4], "lap1_nm": o[5],
                 "lap23_problems": o[6], "lap23_nm": o[7]}
 
+    def profile_dims(self):
+        """summed rows / columns of the queued assignment problems: [first N, first M, second+unconfirmed N, second+unconfirmed M]"""
+        o = np.zeros(4, np.float64)
+        self.lib.mot_bt_profile_dims.argtypes = [C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_bt_profile_dims(self.h, _p(o)))
+        return o
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.mot_bt_destroy(self.h)

@@ -102,7 +102,9 @@ enum {
   MOT_KF_PREDICT_FIRST = 8/* update: predict the loaded state first (honouring MOT_KF_ZERO_V7), then update: with NO_STORE
                              predictions this replaces "predict into a scratch slot, update from it" without the round trip */
 };
-/* Track-state slab, SoA: mean plane k at mean + k*cap, covariance element (r,c) at cov + (r*d+c)*cap. */
+/* Track-state slab: an array of `cap` records, the record of slot s at mean + s*(d + d*d) = mean[d] followed by the d x d
+ * covariance, row-major (288 bytes for the 8-state filters, 224 for XYSR; `mean` 16-byte aligned). The items of a launch are a
+ * gather over slots, and a record is one contiguous run whatever the slot is. `cov` is informational (= mean + d). */
 typedef struct mot_kf_task {
   float* mean; float* cov; int32_t cap;
   int32_t n;                 /* items                                                         */

@@ -488,7 +488,7 @@ struct mot_bt_batch {
   mot_kf_task *pred_t = nullptr, *box_t = nullptr, *init_t = nullptr, *upd_t = nullptr, *box2_t = nullptr;
   mot_lap_task *lap1_t = nullptr, *lap23_t = nullptr;
   mot_iou_task* dup_t = nullptr;
-  float* mean = nullptr; float* cov = nullptr;  // [S][8][2CAP], [S][64][2CAP]
+  float* mean = nullptr;  // [S][CAP] records of 8 + 64 floats (mot_kf_task's slab)
   // profiling (bench.py's roofline leg): HIP events around the two assignment launches and the whole frame
   bool profile = false;
   unsigned long long* d_stats = nullptr;
@@ -533,8 +533,7 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   int* ip = b->dalloc<int>(ints_per * S);
   float* fp = b->dalloc<float>((static_cast<size_t>(CAP) * (1 + 4 * 5) + static_cast<size_t>(D) * 8) * S);
   unsigned char* bp = b->dalloc<unsigned char>(static_cast<size_t>(CAP) * 4 * S);
-  b->mean = b->dalloc<float>(static_cast<size_t>(S) * 8 * C2);
-  b->cov = b->dalloc<float>(static_cast<size_t>(S) * 64 * C2);
+  b->mean = b->dalloc<float>(static_cast<size_t>(S) * 72 * C2);
   b->d_streams = b->dalloc<BtStream>(S);
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
@@ -550,7 +549,7 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   const size_t wb1 = (mot::lap_scratch_bytes(CAP, D) + 255) & ~size_t(255);
   char* work = b->dalloc<char>(wb1 * 3 * S);
   int* info = b->dalloc<int>(static_cast<size_t>(4) * 3 * S);
-  if (!ip || !fp || !bp || !b->mean || !b->cov || !b->d_streams || !b->d_counts || !b->d_err || !b->det_t || !b->pred_t || !b->box_t ||
+  if (!ip || !fp || !bp || !b->mean || !b->d_streams || !b->d_counts || !b->d_err || !b->det_t || !b->pred_t || !b->box_t ||
       !b->init_t || !b->upd_t || !b->box2_t || !b->lap1_t || !b->lap23_t || !b->dup_t || !work || !info) {
     mot_bt_destroy(b);
     return MOT_ERR_NOMEM;
@@ -579,8 +578,8 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
     float* d_box = F(4 * D); float* d_meas = F(4 * D);
     unsigned char* u = bp + static_cast<size_t>(CAP) * 4 * s;
     T.pred_flags = u; T.dup_a = u + CAP; T.dup_b = u + 2 * CAP; T.upd_flags = u + 3 * CAP;
-    float* mean = b->mean + static_cast<size_t>(s) * 8 * C2;
-    float* cov = b->cov + static_cast<size_t>(s) * 64 * C2;
+    float* mean = b->mean + static_cast<size_t>(s) * 72 * C2;
+    float* cov = mean + 8;
     // ---- static parts of the task descriptors ----
     std::memset(&det[s], 0, sizeof(mot_det_task));
     det[s].box = d_box; det[s].ldb = D; det[s].meas = d_meas; det[s].ldm = D;
@@ -734,15 +733,14 @@ int mot_bt_dump(mot_bt_batch* b, int s, int* ids, float* mean, float* cov, int c
   if (h.n_lost) MOT_LC_HIP(b, hipMemcpyAsync(slots.data() + h.n_active, h.lost[h.cur], sizeof(int) * h.n_lost, hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(tid.data(), h.t_id, sizeof(int) * b->CAP, hipMemcpyDeviceToHost, st));
   const int C2 = b->CAP;
-  std::vector<float> m(static_cast<size_t>(8) * C2), c(static_cast<size_t>(64) * C2);
-  MOT_LC_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 8 * C2, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(c.data(), b->cov + static_cast<size_t>(s) * 64 * C2, sizeof(float) * c.size(), hipMemcpyDeviceToHost, st));
+  std::vector<float> m(static_cast<size_t>(72) * C2);
+  MOT_LC_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 72 * C2, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipStreamSynchronize(st));
   for (int i = 0; i < n; ++i) {
     const int sl = slots[i];
     ids[i] = tid[sl];
-    for (int k = 0; k < 8; ++k) mean[static_cast<size_t>(i) * 8 + k] = m[static_cast<size_t>(k) * C2 + sl];
-    for (int k = 0; k < 64; ++k) cov[static_cast<size_t>(i) * 64 + k] = c[static_cast<size_t>(k) * C2 + sl];
+    for (int k = 0; k < 8; ++k) mean[static_cast<size_t>(i) * 8 + k] = m[static_cast<size_t>(sl) * 72 + k];
+    for (int k = 0; k < 64; ++k) cov[static_cast<size_t>(i) * 64 + k] = m[static_cast<size_t>(sl) * 72 + 8 + k];
   }
   return n;
 }

@@ -302,36 +302,35 @@ static int kf_host(mot_ctx* c, int kind, int op, int n, const float* meas4, cons
                    const float* warp9, float* mean, float* cov, float* boxes4) {
   if (n <= 0) return MOT_OK;
   const int D = mot_kf_dim(kind);
-  std::vector<float> sm(static_cast<size_t>(D) * n), sc(static_cast<size_t>(D) * D * n), sz;
+  const int RS = D + D * D;  // one record per track: mean then covariance (the slab layout of mot_kf_task)
+  std::vector<float> sm(static_cast<size_t>(RS) * n), sz;
   for (int i = 0; i < n; ++i) {
-    for (int k = 0; k < D; ++k) sm[static_cast<size_t>(k) * n + i] = mean[static_cast<size_t>(i) * D + k];
-    for (int k = 0; k < D * D; ++k) sc[static_cast<size_t>(k) * n + i] = cov[static_cast<size_t>(i) * D * D + k];
+    for (int k = 0; k < D; ++k) sm[static_cast<size_t>(i) * RS + k] = mean[static_cast<size_t>(i) * D + k];
+    for (int k = 0; k < D * D; ++k) sm[static_cast<size_t>(i) * RS + D + k] = cov[static_cast<size_t>(i) * D * D + k];
   }
-  DBuf dm, dcv, dz, df, db, dt;
-  MOT_HIP(c, dm.alloc(sm.size() * 4)); MOT_HIP(c, dcv.alloc(sc.size() * 4)); MOT_HIP(c, dz.alloc(static_cast<size_t>(4) * n * 4));
+  DBuf dm, dz, df, db, dt;
+  MOT_HIP(c, dm.alloc(sm.size() * 4)); MOT_HIP(c, dz.alloc(static_cast<size_t>(4) * n * 4));
   MOT_HIP(c, df.alloc(n)); MOT_HIP(c, db.alloc(static_cast<size_t>(4) * n * 4)); MOT_HIP(c, dt.alloc(sizeof(mot_kf_task)));
   MOT_HIP(c, hipMemcpyAsync(dm.p, sm.data(), sm.size() * 4, hipMemcpyHostToDevice, c->stream));
-  MOT_HIP(c, hipMemcpyAsync(dcv.p, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, c->stream));
   if (meas4) {
     to_soa4(meas4, n, 4, 4, sz);
     MOT_HIP(c, hipMemcpyAsync(dz.p, sz.data(), sz.size() * 4, hipMemcpyHostToDevice, c->stream));
   }
   if (flags) MOT_HIP(c, hipMemcpyAsync(df.p, flags, n, hipMemcpyHostToDevice, c->stream));
   mot_kf_task t{};
-  t.mean = dm.as<float>(); t.cov = dcv.as<float>(); t.cap = n; t.n = n; t.flags = flags ? df.as<uint8_t>() : nullptr;
+  t.mean = dm.as<float>(); t.cov = dm.as<float>() + D; t.cap = n; t.n = n; t.flags = flags ? df.as<uint8_t>() : nullptr;
   t.meas = dz.as<float>(); t.ldm = n; t.boxes = boxes4 ? db.as<float>() : nullptr; t.ldb = n;
   t.q[0] = q3 ? q3[0] : 0.01f; t.q[1] = q3 ? q3[1] : 0.01f; t.q[2] = q3 ? q3[2] : 0.0001f;
   if (warp9) std::memcpy(t.warp, warp9, sizeof(t.warp));
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, mot::launch_kf_op(op, kind, dt.as<mot_kf_task>(), 1, n, c->stream));
   MOT_HIP(c, hipMemcpyAsync(sm.data(), dm.p, sm.size() * 4, hipMemcpyDeviceToHost, c->stream));
-  MOT_HIP(c, hipMemcpyAsync(sc.data(), dcv.p, sc.size() * 4, hipMemcpyDeviceToHost, c->stream));
   std::vector<float> sb(static_cast<size_t>(4) * n);
   if (boxes4) MOT_HIP(c, hipMemcpyAsync(sb.data(), db.p, sb.size() * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < n; ++i) {
-    for (int k = 0; k < D; ++k) mean[static_cast<size_t>(i) * D + k] = sm[static_cast<size_t>(k) * n + i];
-    for (int k = 0; k < D * D; ++k) cov[static_cast<size_t>(i) * D * D + k] = sc[static_cast<size_t>(k) * n + i];
+    for (int k = 0; k < D; ++k) mean[static_cast<size_t>(i) * D + k] = sm[static_cast<size_t>(i) * RS + k];
+    for (int k = 0; k < D * D; ++k) cov[static_cast<size_t>(i) * D * D + k] = sm[static_cast<size_t>(i) * RS + D + k];
     if (boxes4) for (int k = 0; k < 4; ++k) boxes4[static_cast<size_t>(i) * 4 + k] = sb[static_cast<size_t>(k) * n + i];
   }
   return MOT_OK;

@@ -115,15 +115,14 @@ int motcpp_tracker_dump_states(motcpp_tracker* t, float* out, int cap_floats, in
     const int rows = static_cast<int>(ids.size());
     if (static_cast<size_t>(rows) * w > static_cast<size_t>(cap_floats)) return -rows - 1000000;
     if (rows == 0) return 0;
-    std::vector<float> mean(static_cast<size_t>(D) * cap), cov(static_cast<size_t>(D) * D * cap);
-    c.dev().check(mot_memcpy_d2h(c.dev().ctx, mean.data(), c.d_mean(), mean.size() * sizeof(float)), "state readback");
-    c.dev().check(mot_memcpy_d2h(c.dev().ctx, cov.data(), c.d_cov(), cov.size() * sizeof(float)), "state readback");
+    const size_t rec = static_cast<size_t>(D) * (D + 1);  // slab record: mean then covariance
+    std::vector<float> slab(rec * cap);
+    c.dev().check(mot_memcpy_d2h(c.dev().ctx, slab.data(), c.d_mean(), slab.size() * sizeof(float)), "state readback");
     c.dev().check(mot_ctx_sync(c.dev().ctx), "state readback");
     for (int r = 0; r < rows; ++r) {
       float* o = out + static_cast<size_t>(r) * w;
       o[0] = static_cast<float>(ids[r]);
-      for (int k = 0; k < D; ++k) o[1 + k] = mean[static_cast<size_t>(k) * cap + slots[r]];
-      for (int k = 0; k < D * D; ++k) o[1 + D + k] = cov[static_cast<size_t>(k) * cap + slots[r]];
+      for (size_t k = 0; k < rec; ++k) o[1 + k] = slab[rec * slots[r] + k];
     }
     return rows;
   } catch (const std::exception& e) { g_err = e.what(); return -1; }

@@ -363,24 +363,20 @@ void Device::flush() {
 Core::Core(std::shared_ptr<Device> dev, int kf_kind) : dev_(std::move(dev)), kind_(kf_kind), D_(mot_kf_dim(kf_kind)) {}
 Core::~Core() {
   if (mean_) mot_free(dev_->ctx, mean_);
-  if (cov_) mot_free(dev_->ctx, cov_);
 }
+// The slab is an array of records (mean[D] then the D x D covariance, mot_kf_task's layout): growing it is one copy.
 void Core::grow(int pcap, int scap) {
   const int ncap = pcap + scap;
-  void *nm = nullptr, *nc = nullptr;
-  dev_->check(mot_malloc(dev_->ctx, sizeof(float) * D_ * ncap, &nm), "slab alloc");
-  dev_->check(mot_malloc(dev_->ctx, sizeof(float) * D_ * D_ * ncap, &nc), "slab alloc");
+  const size_t rec = static_cast<size_t>(D_) * (D_ + 1);
+  void* nm = nullptr;
+  dev_->check(mot_malloc(dev_->ctx, sizeof(float) * rec * ncap, &nm), "slab alloc");
   if (mean_ && next_ > 0) {
-    for (int k = 0; k < D_; ++k)
-      dev_->check(mot_memcpy_d2d(dev_->ctx, static_cast<float*>(nm) + static_cast<size_t>(k) * ncap, mean_ + static_cast<size_t>(k) * cap_, sizeof(float) * next_), "slab copy");
-    for (int k = 0; k < D_ * D_; ++k)
-      dev_->check(mot_memcpy_d2d(dev_->ctx, static_cast<float*>(nc) + static_cast<size_t>(k) * ncap, cov_ + static_cast<size_t>(k) * cap_, sizeof(float) * next_), "slab copy");
+    dev_->check(mot_memcpy_d2d(dev_->ctx, nm, mean_, sizeof(float) * rec * next_), "slab copy");
     dev_->check(mot_ctx_sync(dev_->ctx), "slab copy sync");
   }
   if (mean_) mot_free(dev_->ctx, mean_);
-  if (cov_) mot_free(dev_->ctx, cov_);
   mean_ = static_cast<float*>(nm);
-  cov_ = static_cast<float*>(nc);
+  cov_ = mean_ + D_;
   pcap_ = pcap; scap_ = scap; cap_ = ncap;
 }
 void Core::reserve(int extra_persistent, int scratch) {

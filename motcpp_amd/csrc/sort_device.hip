@@ -241,7 +241,7 @@ struct mot_sort_batch {
   mot_det_task* det_t = nullptr;
   mot_kf_task *pred_t = nullptr, *init_t = nullptr, *upd_t = nullptr, *box_t = nullptr;
   mot_lap_task* lap_t = nullptr;
-  float *mean = nullptr, *cov = nullptr;  // [S][7][CAP], [S][49][CAP]
+  float* mean = nullptr;  // [S][CAP] records of 7 + 49 floats (mot_kf_task's slab)
   bool profile = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   double lap_ms = 0.0, frame_ms = 0.0;
@@ -284,8 +284,7 @@ int mot_sort_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, co
   const size_t ints_per = static_cast<size_t>(CAP) * 14 + static_cast<size_t>(D) * 4;
   int* ip = b->dalloc<int>(ints_per * S);
   float* fp = b->dalloc<float>((static_cast<size_t>(CAP) * 9 + static_cast<size_t>(D) * 8) * S);
-  b->mean = b->dalloc<float>(static_cast<size_t>(S) * 7 * CAP);
-  b->cov = b->dalloc<float>(static_cast<size_t>(S) * 49 * CAP);
+  b->mean = b->dalloc<float>(static_cast<size_t>(S) * 56 * CAP);
   b->d_streams = b->dalloc<SortStream>(S);
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
@@ -299,7 +298,7 @@ int mot_sort_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, co
   const size_t wb = (mot::lap_scratch_bytes(CAP, D) + 255) & ~size_t(255);
   char* work = b->dalloc<char>(wb * S);
   int* info = b->dalloc<int>(static_cast<size_t>(4) * S);
-  if (!ip || !fp || !b->mean || !b->cov || !b->d_streams || !b->d_counts || !b->d_err || !b->d_maxt || !b->det_t || !b->pred_t || !b->init_t ||
+  if (!ip || !fp || !b->mean || !b->d_streams || !b->d_counts || !b->d_err || !b->d_maxt || !b->det_t || !b->pred_t || !b->init_t ||
       !b->upd_t || !b->box_t || !b->lap_t || !work || !info) {
     mot_sort_destroy(b);
     return MOT_ERR_NOMEM;
@@ -321,8 +320,8 @@ int mot_sort_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, co
     auto F = [&](int n) { float* r = f; f += n; return r; };
     T.t_conf = F(CAP); T.pbox = F(4 * CAP); T.obox = F(4 * CAP);
     float* d_box = F(4 * D); float* d_meas = F(4 * D);
-    float* mean = b->mean + static_cast<size_t>(s) * 7 * CAP;
-    float* cov = b->cov + static_cast<size_t>(s) * 49 * CAP;
+    float* mean = b->mean + static_cast<size_t>(s) * 56 * CAP;
+    float* cov = mean + 7;
     std::memset(&det[s], 0, sizeof(mot_det_task));
     det[s].box = d_box; det[s].ldb = D; det[s].meas = d_meas; det[s].ldm = D;
     auto kf = [&](mot_kf_task& k) {
@@ -434,15 +433,14 @@ int mot_sort_dump(mot_sort_batch* b, int s, int* ids, float* mean, float* cov, i
   if (n) MOT_LC_HIP(b, hipMemcpyAsync(slots.data(), h.trk[h.cur], sizeof(int) * n, hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(tid.data(), h.t_id, sizeof(int) * b->CAP, hipMemcpyDeviceToHost, st));
   const int C = b->CAP;
-  std::vector<float> m(static_cast<size_t>(7) * C), c(static_cast<size_t>(49) * C);
-  MOT_LC_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 7 * C, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(c.data(), b->cov + static_cast<size_t>(s) * 49 * C, sizeof(float) * c.size(), hipMemcpyDeviceToHost, st));
+  std::vector<float> m(static_cast<size_t>(56) * C);
+  MOT_LC_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 56 * C, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipStreamSynchronize(st));
   for (int i = 0; i < n; ++i) {
     const int sl = slots[i];
     ids[i] = tid[sl];
-    for (int k = 0; k < 7; ++k) mean[static_cast<size_t>(i) * 7 + k] = m[static_cast<size_t>(k) * C + sl];
-    for (int k = 0; k < 49; ++k) cov[static_cast<size_t>(i) * 49 + k] = c[static_cast<size_t>(k) * C + sl];
+    for (int k = 0; k < 7; ++k) mean[static_cast<size_t>(i) * 7 + k] = m[static_cast<size_t>(sl) * 56 + k];
+    for (int k = 0; k < 49; ++k) cov[static_cast<size_t>(i) * 49 + k] = m[static_cast<size_t>(sl) * 56 + 7 + k];
   }
   return n;
 }

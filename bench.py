@@ -146,11 +146,18 @@ def main():
     else:
         batches = [L.Batch(tracker, bounds[p + 1] - bounds[p], device=local, threads=max(1, threads // PIPE), record_laps=False,
                            private_device=PIPE > 1) for p in range(PIPE)]
-    # rows of an output table: every emitted track consumed one detection of the frame, so M rows suffice on the device path
-    # (an overflow raises MOT_ERR_CAPACITY, never truncates); the host trackers keep the 2M of round 1
     cap = max(2 * M, 64)
     gathered = None
-    if on_device:  # page-locked, so that the one result copy of a frame runs at PCIe speed
+    # ByteTrack on the device: packed output (mot_bt_step_packed) — the emitted rows of a sub-batch back to back, so that only
+    # rows that exist cross PCIe (a padded [S, 2M, 8] table is 2-4x the bytes) and no stream has a row limit
+    packed = on_device and tracker == "bytetrack"
+    rows_cap = [int((bounds[p + 1] - bounds[p]) * M * 1.25) + 64 for p in range(PIPE)]
+    if packed:
+        rows_p = [torch.zeros((rows_cap[p], 8), dtype=torch.float32).pin_memory().numpy() for p in range(PIPE)]
+        tot_p = [0] * PIPE
+        out_all = None
+        cnt_all = torch.zeros((S,), dtype=torch.int32).pin_memory().numpy()
+    elif on_device:  # page-locked, so that the one result copy of a frame runs at PCIe speed
         out_all = torch.zeros((S, cap, 8), dtype=torch.float32).pin_memory().numpy()
         cnt_all = torch.zeros((S,), dtype=torch.int32).pin_memory().numpy()
     else:
@@ -170,6 +177,9 @@ def main():
 
     def sub_step(p, f):
         s0, s1 = bounds[p], bounds[p + 1]
+        if packed:
+            tot_p[p] = batches[p].step_packed(dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4, full_counts[p], rows_p[p], cnt_all[s0:s1])
+            return
         if on_device:  # tables land directly in this sub-batch's slice of the rank's output
             batches[p].step(resident_ptr=dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4, counts=full_counts[p],
                             out=out_all[s0:s1], out_counts=cnt_all[s0:s1])
@@ -198,15 +208,27 @@ def main():
         return tot
 
     def gather(out, cnt):
-        # final track tables of this rank's streams -> every rank (RCCL all_gather over xGMI), padded [S, cap, 8] + counts
+        # final track tables of this rank's streams -> every rank (RCCL all_gather over xGMI)
         nonlocal gathered
+        if packed:  # straight from the device-resident packed tables of the last step: no copy through the host
+            dv = torch.device("cuda", local)
+            rl, cl = [], []
+            for p in range(PIPE):
+                r_ptr, _o_ptr, c_ptr = batches[p].device_output()
+                rl.append(mdist.device_view(r_ptr, (tot_p[p], 8), torch.float32, dv) if tot_p[p] else torch.zeros((0, 8), device=dv))
+                cl.append(mdist.device_view(c_ptr, (bounds[p + 1] - bounds[p],), torch.int32, dv))
+            gathered = mdist.gather_packed(rl, cl, sum(rows_cap))
+            return
         gathered = mdist.gather_tables(out[:, :cap], cnt.astype(np.int32), device=torch.device("cuda", local))
+
+    def stream0_rows(out, cnt):
+        return rows_p[0][:cnt[0]].copy() if packed else out[0, :cnt[0]].copy()
 
     kept = []  # stream 0 outputs of rank 0 for the parity spot check
     for f in range(W):
         out, cnt = step(f)
         if rank == 0 and f < 40:
-            kept.append(out[0, :cnt[0]].copy())
+            kept.append(stream0_rows(out, cnt))
     n_kept_warm = len(kept)
     if world > 1:
         gather(out, cnt)
@@ -223,7 +245,7 @@ def main():
         if world > 1 and ((k + 1) % args.gather_every == 0 or k == K - 1):
             gather(out, cnt)
         if rank == 0 and k < 24:
-            kept.append(out[0, :cnt[0]].copy())
+            kept.append(stream0_rows(out, cnt))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -263,7 +285,10 @@ def main():
             b = batches[p]
             src = pinned[h, s0:s1]
             b.ctx._chk(b.lib.mot_memcpy_h2d(b.ctx.h, C.c_void_p(stage[p].data_ptr()), C.c_void_p(src.data_ptr()), C.c_size_t(src.numel() * 4)))
-            b.step(resident_ptr=stage[p].data_ptr(), counts=full_counts[p], out=out_all[s0:s1], out_counts=cnt_all[s0:s1])
+            if packed:
+                tot_p[p] = b.step_packed(stage[p].data_ptr(), full_counts[p], rows_p[p], cnt_all[s0:s1])
+            else:
+                b.step(resident_ptr=stage[p].data_ptr(), counts=full_counts[p], out=out_all[s0:s1], out_counts=cnt_all[s0:s1])
 
         torch.cuda.synchronize()
         th0 = time.perf_counter()

@@ -258,6 +258,15 @@ int mot_bt_reset(mot_bt_batch* b);
 /* d_dets: device, SoA [S][6][max_dets]; h_counts: host [S]; out (host) [S][cap_out][8] rows x1,y1,x2,y2,id,conf,cls,det_ind;
  * out_counts (host) [S]. Synchronous: returns when the outputs are in host memory. */
 int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float* out, int* out_counts, int cap_out);
+/* Same frame, packed output: the emitted rows of all streams back to back (stream s's rows start at the sum of the counts
+ * before it), so that only rows that exist cross PCIe and no stream has a row limit short of cap_tracks (the reference's
+ * ByteTrack can emit more rows than the frame has detections). rows (host) [rows_cap][8]; out_counts (host) [S];
+ * *total_rows = rows written. MOT_ERR_CAPACITY if the frame has more than rows_cap rows (nothing is copied). */
+int mot_bt_step_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts, float* rows, int rows_cap, int* out_counts,
+                       int* total_rows);
+/* device-resident result of the last mot_bt_step_packed: packed rows [total][8], offsets [S+1] (offsets[S] = total), counts [S] —
+ * what a gather over xGMI reads directly (no copy through the host) */
+int mot_bt_device_output(mot_bt_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts);
 /* parity hook: ids and Kalman states of stream s's live tracks in list order (active then lost): ids [cap], mean [cap][8],
  * cov [cap][64]; returns the number of tracks */
 int mot_bt_dump(mot_bt_batch* b, int s, int* ids, float* mean, float* cov, int cap);

@@ -458,6 +458,25 @@ class DeviceByteTrack:
         self.ctx._chk(self.lib.mot_bt_step(self.h, ptr, _p(counts), _p(self._out), _p(self._cnt), cap))
         return self._out, self._cnt
 
+    def step_packed(self, resident_ptr, counts, rows, out_counts):
+        """One frame, packed output (mot_bt_step_packed): rows [cap, 8] float32 and out_counts [S] int32 are caller buffers
+        (page-locked for speed); returns the number of rows written — stream s's rows start at out_counts[:s].sum()."""
+        counts = np.ascontiguousarray(counts, np.int32)
+        assert rows.dtype == np.float32 and rows.flags["C_CONTIGUOUS"] and rows.shape[1] == 8
+        assert out_counts.dtype == np.int32 and out_counts.flags["C_CONTIGUOUS"] and out_counts.shape[0] == self.S
+        total = C.c_int(0)
+        self.lib.mot_bt_step_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_bt_step_packed(self.h, C.c_void_p(int(resident_ptr)), _p(counts), _p(rows), int(rows.shape[0]),
+                                                  _p(out_counts), C.byref(total)))
+        return total.value
+
+    def device_output(self):
+        """(rows ptr, offsets ptr, counts ptr): device addresses of the last packed result (mot_bt_device_output)."""
+        r, o, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.lib.mot_bt_device_output.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_bt_device_output(self.h, C.byref(r), C.byref(o), C.byref(c)))
+        return r.value, o.value, c.value
+
     def dump(self, s):
         """(ids [n], mean [n,8], cov [n,8,8]) of stream s's live tracks, active list then lost list."""
         cap = 2 * self.CAP

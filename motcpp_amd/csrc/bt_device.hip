@@ -374,34 +374,45 @@ __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParam
 // ---- duplicate marking (remove_duplicate_stracks :659-706): iou_distance(active, lost) < 0.15 -> the younger one goes.
 // Same pair arithmetic as the N x M cost kernel (cost_math.hpp), one workgroup per stream over its own na x nl pairs
 // (a launch of the tiled cost kernel over the capacity bound spends 0.5 ms on tiles that exit at once).
-template <bool STAGED>  // STAGED: the boxes of both lists are copied to LDS once (they must fit in the launch's dynamic LDS)
+// A thread owns an active track (box in registers) and walks the lost boxes, which every lane of its wavefront reads from
+// the same LDS address (one broadcast ds_read_b128 per box). Duplicates need IoU > 0.85, so a pair is first put through
+// iou_pair's own intersection and union without the division: only pairs with inter > 0.8 * union (a few per frame)
+// reach the exact arithmetic — same marks as evaluating all na x nl pairs.
+template <bool STAGED>  // STAGED: the lost boxes are copied to LDS once (they must fit in the launch's dynamic LDS)
 __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP) {
-  extern __shared__ float sbox[];  // [4][na] active boxes, [4][nl] lost boxes
+  extern __shared__ __attribute__((aligned(16))) float sbox[];  // [nl] lost boxes as x1,y1,x2,y2
   BtStream& S = streams[blockIdx.x];
   const int na = S.n_active, nl = S.n_lost;
   if (na <= 0 || nl <= 0) return;
-  const float* sa = S.abox;
-  const float* sl = S.lbox;
-  int lda = CAP, ldl = CAP;
+  float4* wl = reinterpret_cast<float4*>(sbox);
   if constexpr (STAGED) {
-    float* wa = sbox;
-    float* wl = sbox + 4 * na;
-    for (int i = threadIdx.x; i < 4 * na; i += 256) wa[i] = S.abox[static_cast<size_t>(i / na) * CAP + (i % na)];
-    for (int i = threadIdx.x; i < 4 * nl; i += 256) wl[i] = S.lbox[static_cast<size_t>(i / nl) * CAP + (i % nl)];
+    for (int j = threadIdx.x; j < nl; j += 256)
+      wl[j] = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
     __syncthreads();
-    sa = wa; sl = wl; lda = na; ldl = nl;
   }
-  const int total = na * nl;
-  for (int p = threadIdx.x; p < total; p += 256) {
-    const int i = p / nl, j = p - i * nl;
-    float a[4], b[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { a[k] = sa[static_cast<size_t>(k) * lda + i]; b[k] = sl[static_cast<size_t>(k) * ldl + j]; }
-    const float iou = mot::iou_pair(a, (a[2] - a[0]) * (a[3] - a[1]), b, (b[2] - b[0]) * (b[3] - b[1]));
-    if (1.0f - iou < 0.15f) {
-      if (S.age_a[i] > S.age_b[j]) S.dup_b[j] = 1;
-      else S.dup_a[i] = 1;
+  for (int i = threadIdx.x; i < na; i += 256) {
+    const float a[4] = {S.abox[i], S.abox[static_cast<size_t>(CAP) + i], S.abox[static_cast<size_t>(2) * CAP + i], S.abox[static_cast<size_t>(3) * CAP + i]};
+    const float area_a = (a[2] - a[0]) * (a[3] - a[1]);
+    const int age_a = S.age_a[i];
+    bool dup_me = false;
+    for (int j = 0; j < nl; ++j) {
+      float4 bb;
+      if constexpr (STAGED) bb = wl[j];
+      else bb = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
+      const float iw = mot::smax(0.0f, mot::smin(a[2], bb.z) - mot::smax(a[0], bb.x));
+      const float ih = mot::smax(0.0f, mot::smin(a[3], bb.w) - mot::smax(a[1], bb.y));
+      const float inter = iw * ih;
+      const float area_b = (bb.z - bb.x) * (bb.w - bb.y);
+      const float uni = area_a + area_b - inter;
+      if (inter > 0.8f * uni) {
+        const float iou = (uni > 0.0f) ? (inter / uni) : 0.0f;  // iou_pair's value (cost_math.hpp), inter and uni as it computes them
+        if (1.0f - iou < 0.15f) {
+          if (age_a > S.age_b[j]) S.dup_b[j] = 1;
+          else dup_me = true;
+        }
+      }
     }
+    if (dup_me) S.dup_a[i] = 1;
   }
 }
 
@@ -484,6 +495,7 @@ struct mot_bt_batch {
   int* d_maxt = nullptr;  // [64] per-frame maxima of tracks alive (bt_finish)
   int bound_n = 0;        // upper bound of tracked + lost per stream for the NEXT frame (0 right after creation / reset)
   float* d_out = nullptr; int* d_out_counts = nullptr; int out_cap = 0;
+  float* d_packed = nullptr; int* d_offsets = nullptr; int packed_cap = 0;  // mot_bt_step_packed
   mot_det_task* det_t = nullptr;
   mot_kf_task *pred_t = nullptr, *box_t = nullptr, *init_t = nullptr, *upd_t = nullptr, *box2_t = nullptr;
   mot_lap_task *lap1_t = nullptr, *lap23_t = nullptr;
@@ -624,7 +636,8 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   return MOT_OK;
 }
 
-int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float* out, int* out_counts, int cap_out) {
+// enqueues the frame's launches; the per-stream tables land in b->d_out ([S][cap_out][8]) and b->d_out_counts
+static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_counts, int cap_out) {
   hipStream_t st = b->ctx->stream;
   const int S = b->S, CAP = b->CAP, D = b->D;
   if (cap_out > b->out_cap) {
@@ -660,7 +673,7 @@ int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float
   MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, bn, st));
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, bn2, st));
   {
-    const size_t lds = static_cast<size_t>(8) * bn2 * sizeof(float);  // na, nl <= bn2
+    const size_t lds = static_cast<size_t>(4) * bn2 * sizeof(float);  // nl <= bn2
     if (lds <= 48 * 1024) hipLaunchKernelGGL(bt_dups<true>, dim3(S), dim3(256), lds, st, b->d_streams, CAP);
     else hipLaunchKernelGGL(bt_dups<false>, dim3(S), dim3(256), 0, st, b->d_streams, CAP);
   }
@@ -668,16 +681,20 @@ int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float
   hipLaunchKernelGGL(bt_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[5], st));
   MOT_LC_HIP(b, hipGetLastError());
+  return MOT_OK;
+}
+
+// after the frame's kernels: error flag, launch bounds of the next frame, event times (synchronises the stream)
+static int bt_finish_frame(mot_bt_batch* b) {
+  hipStream_t st = b->ctx->stream;
   int err = 0;
-  MOT_LC_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   int maxt[64];
+  MOT_LC_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipStreamSynchronize(st));
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
-  if (prof) {
+  if (b->profile) {
     float ms = 0.f;
     MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[1], b->ev[2])); b->lap_ms[0] += ms;
     MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[3], b->ev[4])); b->lap_ms[1] += ms;
@@ -685,6 +702,50 @@ int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float
     b->frames += 1;
   }
   if (err) { b->ctx->err = "mot_bt_step: a stream exceeded cap_tracks / max_dets / cap_out"; return MOT_ERR_CAPACITY; }
+  return MOT_OK;
+}
+
+int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float* out, int* out_counts, int cap_out) {
+  hipStream_t st = b->ctx->stream;
+  const int S = b->S;
+  const int rc = bt_enqueue_frame(b, d_dets, h_counts, cap_out);
+  if (rc != MOT_OK) return rc;
+  MOT_LC_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  return bt_finish_frame(b);
+}
+
+int mot_bt_step_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts, float* rows, int rows_cap, int* out_counts, int* total_rows) {
+  hipStream_t st = b->ctx->stream;
+  const int S = b->S;
+  // staging holds a stream's whole track list (no per-stream row limit short of cap_tracks); the packed buffer rows_cap rows
+  const int rc = bt_enqueue_frame(b, d_dets, h_counts, b->CAP);
+  if (rc != MOT_OK) return rc;
+  if (!b->d_offsets) b->d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1);
+  if (rows_cap > b->packed_cap) { b->d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); b->packed_cap = b->d_packed ? rows_cap : 0; }
+  if (!b->d_offsets || !b->d_packed) return MOT_ERR_NOMEM;
+  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, b->d_offsets);
+  hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, b->CAP, b->d_out_counts, b->d_offsets, b->d_packed, rows_cap);
+  MOT_LC_HIP(b, hipGetLastError());
+  int total = 0;
+  MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(&total, b->d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st));
+  const int rc2 = bt_finish_frame(b);  // synchronises: total is known
+  if (total_rows) *total_rows = total;
+  if (rc2 != MOT_OK) return rc2;
+  if (total > rows_cap) { b->ctx->err = "mot_bt_step_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  if (total > 0) {
+    MOT_LC_HIP(b, hipMemcpyAsync(rows, b->d_packed, sizeof(float) * static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, st));
+    MOT_LC_HIP(b, hipStreamSynchronize(st));
+  }
+  return MOT_OK;
+}
+
+int mot_bt_device_output(mot_bt_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts) {
+  if (!b || !b->d_packed || !b->d_offsets) return MOT_ERR_INVALID;
+  if (d_rows) *d_rows = b->d_packed;
+  if (d_offsets) *d_offsets = b->d_offsets;
+  if (d_counts) *d_counts = b->d_out_counts;
   return MOT_OK;
 }
 

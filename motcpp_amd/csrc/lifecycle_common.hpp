@@ -29,6 +29,42 @@ __device__ __forceinline__ int compact(bool pred, int& base) {
   return pos;
 }
 
+// ---- packed output tables -------------------------------------------------------------------------------------------
+// The per-stream tables are written into a staging area of `cap_stage` rows per stream (a stream can emit as many rows as it
+// has tracks: the reference's ByteTrack keeps tracks in its tracked list without a detection in some branches), then packed
+// back to back so that the copy to the host moves the emitted rows only.
+// offsets[s] = first row of stream s, offsets[S] = total; counts < 0 (a staging overflow) count as 0 rows.
+static __global__ void __launch_bounds__(1024) pack_offsets(const int* counts, int S, int* offsets) {
+  __shared__ int part[1024];
+  const int t = static_cast<int>(threadIdx.x);
+  const int L = (S + 1023) / 1024;
+  const int b0 = t * L, b1 = (b0 + L < S) ? b0 + L : S;
+  int s = 0;
+  for (int i = b0; i < b1; ++i) { const int c = counts[i]; s += (c > 0) ? c : 0; }
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan (Hillis-Steele; 10 rounds, once per frame)
+    const int v = (t >= d) ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int base = part[t] - s;
+  for (int i = b0; i < b1; ++i) { offsets[i] = base; const int c = counts[i]; base += (c > 0) ? c : 0; }
+  if (t == 1023) offsets[S] = part[1023];
+}
+static __global__ void __launch_bounds__(256) pack_rows(const float* stage, int cap_stage, const int* counts, const int* offsets, float* packed,
+                                                 int packed_cap) {
+  const int s = blockIdx.x;
+  const int c = counts[s];
+  if (c <= 0) return;
+  const int o = offsets[s];
+  if (o + c > packed_cap) return;  // (the host sees total > packed_cap and reports it)
+  const float4* src = reinterpret_cast<const float4*>(stage + static_cast<size_t>(s) * cap_stage * 8);
+  float4* dst = reinterpret_cast<float4*>(packed + static_cast<size_t>(o) * 8);
+  for (int i = threadIdx.x; i < 2 * c; i += 256) dst[i] = src[i];
+}
+
 // Device allocations of a batch, freed together.
 struct Allocs {
   std::vector<void*> ptrs;

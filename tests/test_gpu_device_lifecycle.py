@@ -175,3 +175,51 @@ def test_sort_device_mot17_mini():
             out, oc = dev.step(dets, np.array([len(d)], np.int32))
             assert np.array_equal(out[0, :oc[0]], to.update(d)), (seq, f)
         dev.close()
+
+
+def test_packed_output_equals_the_padded_tables():
+    """mot_bt_step_packed: the emitted rows of all streams back to back — the same rows, stream after stream, as the oracle's
+    tables, with no per-stream row limit (a stream of the C2 shape has been seen emitting 183 rows for 128 detections) —
+    and the device-resident copy (mot_bt_device_output) that the multi-GPU gather reads holds the same bytes."""
+    import torch
+
+    from motcpp_amd import dist as mdist
+    orc = orclib.load()
+    shapes = [(40, 30), (256, 128), (8, 8), (90, 64), (256, 128)]
+    S, maxd = len(shapes), 128
+    dev = L.DeviceByteTrack(S, 512, maxd)
+    streams = [SynthStream(P, M, 4321 + i) for i, (P, M) in enumerate(shapes)]
+    oracles = [orc.tracker(orclib.BYTETRACK) for _ in range(S)]
+    rows = L.pinned_array(dev.ctx, (S * maxd * 2, 8), np.float32)
+    cnt = L.pinned_array(dev.ctx, (S,), np.int32)
+    ddets = torch.zeros((S, 6, maxd), dtype=torch.float32, device="cuda:0")
+    for f in range(40):
+        counts = np.zeros(S, np.int32)
+        soa = np.zeros((S, 6, maxd), np.float32)
+        per = []
+        for s, st in enumerate(streams):
+            d, _ = st.next_frame()
+            if (f + s) % 11 == 7:
+                d = d[:0]
+            per.append(d)
+            counts[s] = len(d)
+            soa[s, :, :len(d)] = d.T
+        ddets.copy_(torch.from_numpy(soa))
+        torch.cuda.synchronize()
+        total = dev.step_packed(ddets.data_ptr(), counts, rows, cnt)
+        want = [oracles[s].update(per[s]) for s in range(S)]
+        assert total == sum(w.shape[0] for w in want)
+        assert np.array_equal(cnt, np.array([w.shape[0] for w in want], np.int32)), f
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        for s in range(S):
+            assert np.array_equal(rows[off[s]:off[s + 1]], want[s]), (f, s)
+        if f % 9 == 8 and total:
+            r_ptr, o_ptr, c_ptr = dev.device_output()
+            dv = torch.device("cuda", 0)
+            dr = mdist.device_view(r_ptr, (total, 8), torch.float32, dv)
+            do = mdist.device_view(o_ptr, (S + 1,), torch.int32, dv)
+            gt, gc = mdist.gather_packed([dr], [mdist.device_view(c_ptr, (S,), torch.int32, dv)], S * maxd * 2)  # world 1: pack only
+            assert np.array_equal(do.cpu().numpy(), off.astype(np.int32))
+            got = mdist.unpack_packed(gt, gc)
+            assert all(np.array_equal(got[s], want[s]) for s in range(S))
+    dev.close()

@@ -312,3 +312,40 @@ def test_lap_sparse_first_phase_shapes(ctx, orc, n, m, world):
         xo, yo = orc.linear_assignment(cost, th)
         xg, yg, xv, info = ctx.lap_geom(a, b, th, mode, conf)
         assert info == 0 and np.array_equal(xg, xo) and np.array_equal(yg, yo), (n, m, mode)
+
+
+@pytest.mark.parametrize("n,m", [(64, 40), (300, 200), (1000, 500), (700, 1500)])
+def test_lap_fast_path_and_exact_path_agree_with_the_oracle(ctx, orc, n, m):
+    """mot_lap_solve = lap_sparse_kernel (certifies the unique optimum over the viable pairs) + lap_kernel (the exact lapjv
+    emulation for everything else). Clean tracking problems must be finished by the fast path; the same problems forced down
+    the exact path (prof requested) and problems with ties (which the fast path must decline) give the oracle's answer too."""
+    r = np.random.default_rng(3 * n + m)
+    a = boxes(r, n, (1920, 1080))
+    k = min(n, m)
+    b = boxes(r, m, (1920, 1080))
+    b[:k] = a[r.permutation(n)[:k]] + r.normal(0, 2, (k, 4)).astype(np.float32)
+    conf = r.uniform(0.3, 1, m).astype(np.float32)
+    dist = orc.iou_distance(a, b)
+    cases = ((L.COST_IOU_DIST, dist, 0.7), (L.COST_IOU_DIST_FUSE, orc.fuse_score(dist, conf), 0.8), (L.COST_NEG_IOU, -orc.iou_batch(a, b), -0.3))
+    ctx.lap_fast_stats(reset=True)
+    for mode, cost, th in cases:
+        xo, yo = orc.linear_assignment(cost, th)
+        for prof in (False, True):  # False: fast path first; True: straight to the exact emulation
+            xg, yg, xv, info = ctx.lap_geom(a, b, th, mode, conf, prof=prof)
+            assert info == 0 and np.array_equal(xg, xo) and np.array_equal(yg, yo), (n, m, mode, prof)
+            hit = xg >= 0
+            assert np.array_equal(xv[hit], cost[np.arange(n)[hit], xg[hit]])
+        xm, ym, _ = ctx.lap(cost, th)  # materialised-matrix source of the fast path
+        assert np.array_equal(xm, xo) and np.array_equal(ym, yo)
+    st = ctx.lap_fast_stats()
+    assert st["fast"] == 2 * len(cases) and st["not_attempted"] == len(cases), st
+    # ties: a duplicated detection -> declined by the certificate, solved by the exact path, same answer
+    b2 = b.copy()
+    b2[1] = b2[0]
+    cost = orc.fuse_score(orc.iou_distance(a, b2), conf)
+    xo, yo = orc.linear_assignment(cost, 0.8)
+    ctx.lap_fast_stats(reset=True)
+    xg, yg, _, _ = ctx.lap_geom(a, b2, 0.8, L.COST_IOU_DIST_FUSE, conf)
+    assert np.array_equal(xg, xo) and np.array_equal(yg, yo)
+    if (cost[:, 0] < 0.8).any():
+        assert ctx.lap_fast_stats()["fast"] == 0

@@ -1,0 +1,143 @@
+"""Host logic test of the assignment FAST PATH: motcpp_amd/csrc/lap_sparse.hpp (the code the gfx950 kernel
+lap_sparse_kernel runs) executed on T host threads through tests/emu. Contract: whenever it reports 1 ("certified as the
+unique optimum") its x/y are the oracle's lapjv answer index for index; otherwise it must decline (<= 0) and the exact
+emulation takes over — on ties (quantised costs, duplicated rows, a cost equal to the threshold that is tight in the
+optimum), on dense problems that overflow its lists, on NaNs. It never decides a tie."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.emu.build import build_lap_emu
+
+
+@pytest.fixture(scope="module")
+def sp():
+    lib = C.CDLL(build_lap_emu())
+
+    def matrix(cost, th, T=16):
+        cost = np.ascontiguousarray(cost, np.float32)
+        n, m = cost.shape
+        x, y = np.zeros(n, np.int32), np.zeros(m, np.int32)
+        mc = C.c_double(0)
+        r = lib.emu_sparse_matrix(cost.ctypes.data_as(C.c_void_p), n, m, m, C.c_float(th), T, x.ctypes.data_as(C.c_void_p),
+                                  y.ctypes.data_as(C.c_void_p), C.byref(mc))
+        return r, x, y, mc.value
+
+    def boxes(a, b, conf, mode, th, T=16):
+        a, b, conf = [np.ascontiguousarray(v, np.float32) for v in (a, b, conf)]
+        x, y = np.zeros(len(a), np.int32), np.zeros(len(b), np.int32)
+        mc = C.c_double(0)
+        r = lib.emu_sparse_boxes(a.ctypes.data_as(C.c_void_p), len(a), b.ctypes.data_as(C.c_void_p), len(b),
+                                 conf.ctypes.data_as(C.c_void_p), mode, C.c_float(th), T, x.ctypes.data_as(C.c_void_p),
+                                 y.ctypes.data_as(C.c_void_p), C.byref(mc))
+        return r, x, y, mc.value
+    return matrix, boxes
+
+
+def gen(r, kind, n, m):
+    if kind == "dense":
+        return r.uniform(0, 1, (n, m)).astype(np.float32), 0.8
+    if kind == "neg":
+        return (-r.uniform(0, 1, (n, m))).astype(np.float32), -0.3
+    if kind == "negsparse":  # OC-SORT style: -(iou + angle), most pairs just above the threshold
+        c = r.uniform(-0.1, 0.1, (n, m)).astype(np.float32)
+        e = r.uniform(0, 1, (n, m)) < 3.0 / max(n, m)
+        c[e] = -r.uniform(0.2, 1.1, e.sum()).astype(np.float32)
+        return c, -0.3
+    if kind == "quant":
+        return (r.integers(0, 6, (n, m)) / 5.0).astype(np.float32), 0.7
+    if kind == "const":
+        return np.full((n, m), 0.3, np.float32), 0.8
+    c = np.ones((n, m), np.float32)  # IoU-like
+    for i in range(n):
+        if r.uniform() < 0.8:
+            c[i, r.integers(m)] = r.uniform(0.05, 0.6)
+    e = r.uniform(0, 1, (n, m)) < 0.03
+    c[e] = r.uniform(0.2, 0.95, e.sum()).astype(np.float32)
+    return c, 0.8
+
+
+@pytest.mark.parametrize("kind,min_certified", [("iou", 0.8), ("negsparse", 0.8), ("dense", 0.0), ("neg", 0.0), ("quant", 0.0), ("const", 0.0)])
+def test_matrix_source_never_disagrees_with_lapjv(orc, sp, kind, min_certified):
+    matrix, _ = sp
+    r = np.random.default_rng(sum(map(ord, kind)))
+    certified = total = 0
+    for _ in range(40):
+        n, m = int(r.integers(1, 70)), int(r.integers(1, 70))
+        c, th = gen(r, kind, n, m)
+        res, x, y, mc = matrix(c, th, T=int(r.choice([16, 19, 32])))
+        assert res <= 1 and res != -99  # -99: the lanes disagreed on the outcome
+        total += 1
+        if res == 1:
+            certified += 1
+            xo, yo = orc.linear_assignment(c, th)
+            assert np.array_equal(x, xo) and np.array_equal(y, yo), (kind, n, m)
+            assert mc == float(c.min())
+    assert certified >= min_certified * total
+    if kind in ("quant", "const"):
+        assert certified == 0  # ties everywhere: always left to the exact emulation
+
+
+def test_box_source_matches_lapjv_on_the_cost_kernels_arithmetic(orc, sp):
+    _, boxes = sp
+    r = np.random.default_rng(7)
+    for mode, th in ((1, 0.7), (2, 0.8), (3, -0.3)):
+        certified = 0
+        for trial in range(25):
+            n, m = int(r.integers(2, 160)), int(r.integers(2, 120))
+            cx, cy = r.uniform(0, 800, n), r.uniform(0, 500, n)
+            w = r.uniform(30, 90, n)
+            a = np.stack([cx - w / 2, cy - w, cx + w / 2, cy + w], 1).astype(np.float32)
+            b = a[r.integers(0, n, m)] + r.normal(0, 3, (m, 4)).astype(np.float32)
+            conf = r.uniform(0.3, 1, m).astype(np.float32)
+            cost = {1: orc.iou_distance(a, b), 2: orc.fuse_score(orc.iou_distance(a, b), conf), 3: -orc.iou_batch(a, b)}[mode]
+            res, x, y, _ = boxes(a, b, conf, mode, th, T=int(r.choice([16, 64])))
+            assert res <= 1 and res != -99
+            if res == 1:
+                certified += 1
+                xo, yo = orc.linear_assignment(cost, th)
+                assert np.array_equal(x, xo) and np.array_equal(y, yo), (mode, n, m, trial)
+        assert certified >= 20
+
+
+def test_duplicated_columns_are_left_to_the_exact_path(orc, sp):
+    matrix, boxes = sp
+    r = np.random.default_rng(3)
+    c, th = gen(r, "iou", 30, 20)
+    c[:, 7] = c[:, 3]  # two identical columns with a viable pair: which one is matched is a lapjv tie-break
+    c[5, 3] = c[5, 7] = 0.2
+    res, *_ = matrix(c, th)
+    assert res <= 0
+    a = np.array([[0, 0, 50, 100], [200, 0, 250, 100]], np.float32)
+    b = np.array([[2, 1, 52, 101], [2, 1, 52, 101], [500, 500, 550, 600]], np.float32)  # the same detection twice
+    res, *_ = boxes(a, b, np.ones(3, np.float32), 1, 0.7)
+    assert res <= 0
+
+
+def test_cost_equal_to_the_threshold(orc, sp):
+    matrix, _ = sp
+    th = np.float32(0.8)
+    # dominated: the row and the column of the tied pair both have something better -> certified, same as lapjv
+    c = np.ones((3, 3), np.float32)
+    c[0, 0] = 0.3; c[1, 1] = 0.4; c[0, 1] = th
+    res, x, y, _ = matrix(c, float(th))
+    xo, yo = orc.linear_assignment(c, float(th))
+    assert res == 1 and np.array_equal(x, xo) and np.array_equal(y, yo)
+    # free on both sides: matching the pair or not costs the same -> declined
+    c = np.ones((3, 3), np.float32)
+    c[0, 0] = 0.3; c[2, 2] = th
+    res, *_ = matrix(c, float(th))
+    assert res <= 0
+
+
+def test_nan_and_inf_are_declined(sp):
+    matrix, boxes = sp
+    c = np.ones((4, 4), np.float32)
+    c[1, 2] = np.nan
+    assert matrix(c, 0.8)[0] <= 0
+    a = np.array([[0, 0, 10, 10], [np.nan, 0, 10, 10]], np.float32)
+    b = np.array([[1, 1, 11, 11]], np.float32)
+    assert boxes(a, b, np.ones(1, np.float32), 1, 0.7)[0] <= 0
+    a[1] = [0, 0, np.inf, 10]
+    assert boxes(a, b, np.ones(1, np.float32), 1, 0.7)[0] <= 0

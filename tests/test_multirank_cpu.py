@@ -30,6 +30,14 @@ def worker(rank, world, port, q):
     gt, gc = mdist.gather_tables(padded, cnt)
     got = mdist.unpack_tables(gt, gc)
     ok = set(got) == set(range(world * S)) and all(np.array_equal(got[g], fake_table(g)) for g in got)
+    # the packed form (what mot_bt_step_packed leaves on the device): two "sub-batches" of rows back to back + counts
+    tabs = [fake_table(g) for g in ids]
+    halves = [tabs[:2], tabs[2:]]
+    rows_list = [torch.from_numpy(np.concatenate(h) if h else np.zeros((0, 8), np.float32)) for h in halves]
+    counts_list = [torch.tensor([t.shape[0] for t in h], dtype=torch.int32) for h in halves]
+    pt, pc = mdist.gather_packed(rows_list, counts_list, S * CAP)
+    got2 = mdist.unpack_packed(pt, pc)
+    ok = ok and set(got2) == set(range(world * S)) and all(np.array_equal(got2[g], fake_table(g)) for g in got2)
     # same barrier + max-over-ranks timing pattern as bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.barrier()

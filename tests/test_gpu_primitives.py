@@ -347,5 +347,13 @@ def test_lap_fast_path_and_exact_path_agree_with_the_oracle(ctx, orc, n, m):
     ctx.lap_fast_stats(reset=True)
     xg, yg, _, _ = ctx.lap_geom(a, b2, 0.8, L.COST_IOU_DIST_FUSE, conf)
     assert np.array_equal(xg, xo) and np.array_equal(yg, yo)
-    if (cost[:, 0] < 0.8).any():
-        assert ctx.lap_fast_stats()["fast"] == 0
+    # ... and a case where the duplicate certainly decides the matching: one track, the same detection twice
+    a1 = np.array([[0, 0, 50, 100], [900, 500, 950, 600]], np.float32)
+    b1 = np.array([[2, 1, 52, 101], [2, 1, 52, 101], [1500, 800, 1550, 900]], np.float32)
+    c1 = orc.iou_distance(a1, b1)
+    xo, yo = orc.linear_assignment(c1, 0.7)
+    ctx.lap_fast_stats(reset=True)
+    xg, yg, _, _ = ctx.lap_geom(a1, b1, 0.7, L.COST_IOU_DIST, None)
+    assert np.array_equal(xg, xo) and np.array_equal(yg, yo)
+    st = ctx.lap_fast_stats()
+    assert st["fast"] == 0 and st["not_unique"] == 1, st

@@ -241,8 +241,10 @@ size_t mot_lap_work_bytes(int n, int m);
  * pairs, initial matching, path searches, certificate), [12] path searches, [13] column scans inside them, [14] declined: a column with more than 16 viable
  * pairs, [15] declined: more viable pairs than the list holds; [16..18] cycles inside [8]: bucketing
  * the rows, the candidate sweep, the list build; [19] candidate rows looked at by lane 0, [20] pairs it evaluated; declined: [21] NaN / inf /
- * out-of-range input, [22] pairs that do not intersect would be viable, [23] a cost within 1e-9 of the threshold. */
-int mot_lap_fast_stats(mot_ctx* ctx, unsigned long long* out24, int reset);
+ * out-of-range input, [22] pairs that do not intersect would be viable, [23] a cost within 1e-9 of the threshold; [24..27] cycles inside [10]
+ * (four-wavefront launches): fetching a column's pairs, delivering labels, picking the nearest row, dual update + augmentation;
+ * [28..31] reserved. */
+int mot_lap_fast_stats(mot_ctx* ctx, unsigned long long* out32, int reset);
 int mot_lap_solve(mot_ctx* ctx, const mot_lap_task* tasks, int ntasks, int max_n, int max_m, int flags);
 
 /* ---- ByteTrack with the per-stream lifecycle on the device ------------------------------ */

@@ -206,6 +206,13 @@ struct DevGroup {
     }
     return exclusive_scan(flag ? 1 : 0, total);
   }
+  // single-wavefront groups only: mask of the lanes whose flag is set, a lane's value for everyone, a value pushed to a lane
+  __device__ __forceinline__ unsigned long long ballot(bool flag) { return __builtin_amdgcn_ballot_w64(flag); }
+  __device__ __forceinline__ int push_i32(int v, int dst, bool active) { return __builtin_amdgcn_ds_permute((active ? dst : 63) << 2, active ? v : 0); }
+  __device__ __forceinline__ int bcast_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+  __device__ __forceinline__ double bcast_f64(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+  }
   // lexicographic (value, index) minimum over the group
   __device__ __forceinline__ void reduce_lexmin(double& v, int& j) {
     if (size_ <= 64) { wave_lexmin(v, j); return; }
@@ -218,6 +225,69 @@ struct DevGroup {
   static __device__ __forceinline__ void atomic_min(int* p, int v) { atomicMin(p, v); }
   static __device__ __forceinline__ void atomic_or(int* p, int v) { atomicOr(p, v); }
   static __device__ __forceinline__ void atomic_and(int* p, int v) { atomicAnd(p, v); }
+};
+
+// ---- single-wavefront helpers shared by DevGroup (64-thread blocks) and DevWave ----
+struct WaveOps {
+  // minimum over the wavefront of an unsigned key (DPP, one v_min per step)
+  static __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define MOT_STEP(C, M) { const unsigned o = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), C, M, 0xf, false)); v = (o < v) ? o : v; }
+    MOT_DPP_STEPS(MOT_STEP)
+#undef MOT_STEP
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+  }
+  // lexicographic (value, index) minimum: the double through its order-preserving 2 x 32-bit key (high word, then low word
+  // among the lanes that tie on it), the index among the lanes that tie on the value; lanes that do not take part pass j = kNoIdx
+  static __device__ __forceinline__ void lexmin(double& v, int& j) {
+    const bool in = j != kNoIdx;
+    const int hi = __double2hiint(v), lo = __double2loint(v);
+    const unsigned khi = in ? (static_cast<unsigned>(hi) ^ ((hi < 0) ? 0xffffffffu : 0x80000000u)) : 0xffffffffu;
+    const unsigned klo = static_cast<unsigned>(lo) ^ ((hi < 0) ? 0xffffffffu : 0u);
+    const unsigned mhi = wave_min_u32(khi);
+    const unsigned mlo = wave_min_u32((in && khi == mhi) ? klo : 0xffffffffu);
+    const bool tied = in && khi == mhi && klo == mlo;
+    const unsigned mj = wave_min_u32(tied ? static_cast<unsigned>(j) : 0xffffffffu);
+    const unsigned long long who = __builtin_amdgcn_ballot_w64(tied && static_cast<unsigned>(j) == mj);
+    if (who == 0ull) { j = kNoIdx; return; }
+    const int src = __builtin_ctzll(who);
+    v = __hiloint2double(__builtin_amdgcn_readlane(hi, src), __builtin_amdgcn_readlane(lo, src));
+    j = static_cast<int>(mj);
+  }
+  // push: every lane with `active` sends v to lane dst (distinct destinations, never lane 63); returns what this lane
+  // received (0 if nothing). ds_permute has no "do not send": the other lanes send a 0 to lane 63, which is nobody's target.
+  static __device__ __forceinline__ int push_i32(int v, int dst, bool active) {
+    return __builtin_amdgcn_ds_permute((active ? dst : 63) << 2, active ? v : 0);
+  }
+};
+
+// One wavefront acting as a group of its own inside a larger workgroup (the serial path searches of lap_sparse.hpp while
+// the other wavefronts of the block wait at the block's next barrier): reductions are DPP-only, sync() orders the wavefront's
+// LDS / global accesses without touching the block barrier.
+struct DevWave {
+  int lane_;
+  __device__ DevWave() : lane_(threadIdx.x & 63) {}
+  __device__ __forceinline__ int tid() const { return lane_; }
+  __device__ __forceinline__ int size() const { return 64; }
+  __device__ __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  __device__ __forceinline__ int flag_rank(bool flag, int* total) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+    *total = __builtin_popcountll(m);
+    return __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0u));
+  }
+  __device__ __forceinline__ void reduce_lexmin(double& v, int& j) { WaveOps::lexmin(v, j); }
+  __device__ __forceinline__ int push_i32(int v, int dst, bool active) { return WaveOps::push_i32(v, dst, active); }
+  __device__ __forceinline__ unsigned long long ballot(bool flag) { return __builtin_amdgcn_ballot_w64(flag); }
+  __device__ __forceinline__ int bcast_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+  __device__ __forceinline__ double bcast_f64(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+  }
+  __device__ __forceinline__ double reduce_min(double v) { return DevGroup::wave_min_f64(v); }
+  __device__ __forceinline__ int reduce_max(int v) { return DevGroup::wave_max_i32(v); }
+  __device__ __forceinline__ int reduce_min_int(int v) { return -DevGroup::wave_max_i32(-v); }
 };
 #endif  // __HIPCC__
 

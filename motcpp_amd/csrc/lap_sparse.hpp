@@ -46,7 +46,7 @@ namespace mot {
 
 constexpr int kSpK = 16;           // viable pairs kept per column (more: fall back)
 constexpr int kSpBuckets = 256;    // x1 buckets of the row boxes
-constexpr int kSpSlots = 64;       // rows one path search may reach (more: fall back)
+constexpr int kSpSlots = 63;       // rows one path search may reach (more: fall back); lane q holds slot q, lane 63 none
 constexpr int kSpQ = 8;            // per-lane queue of candidate rows awaiting the exact arithmetic (drained when full)
 constexpr double kSpEps = 1e-9;    // tie margin
 constexpr double kSpTol = 1e-11;   // tolerated violation of dual feasibility / complementary slackness (fp64 rounding)
@@ -68,13 +68,11 @@ struct SparseWorkT {
   MemPtr<int, HS> y;             // column -> row
   MemPtr<SpBox, HS> sbox;        // [nr] (aliases u, x, slot)
   MemPtr<int, HS> bstart, bcur, bmax;  // x1 buckets: [B+4] start, [B] fill cursor, [B] prefix maximum of the x2 keys (alias v, y)
-  MemPtr<unsigned short, HS> hq; // [kSpQ][64] per-lane queue of candidate positions worth the exact arithmetic (aliases v, y)
+  MemPtr<unsigned short, HS> hq; // [kSpQ][threads] per-lane queue of candidate positions worth the exact arithmetic (aliases v, y)
   MemPtr<unsigned short, HS> sidx;  // [nr] row index of a bucket-ordered position
   MemPtr<int, HS> eoff;          // [nc] CSR entry of a column: start | count << 24
   MemPtr<unsigned short, HS> erow;  // [ecap] row ...
   MemPtr<float, HS> ecost;       // [ecap] ... and cost of a viable pair
-  MemPtr<double, HS> sdist;      // search slots [kSpSlots]: distance label,
-  MemPtr<int, HS> srow, spred, sstate;  // row, column it was reached from, 1 reached / 2 scanned
   MemPtr<int, HS> ctr;           // [4] counters
   int ecap = 0;
   MemPtr<int, kMemGlobal> strow;    // [nc][kSpK] staging of a column's viable pairs (matrix source): row ...
@@ -82,11 +80,12 @@ struct SparseWorkT {
   MemPtr<int, kMemGlobal> freel;    // [nc] columns still to insert
   MemPtr<int, kMemGlobal> arcs;     // [sparse_arc_cap][2] eps-tight pair: (row, owner of its column)
 };
-constexpr size_t kSpEnumBytes = 4 * (kSpBuckets + 4) + 8 * kSpBuckets + 2 * kSpQ * 64;  // buckets + queues
+constexpr int kSpMaxThreads = 256;  // lanes that may enumerate one problem together
+constexpr size_t kSpEnumBytes = 4 * (kSpBuckets + 4) + 8 * kSpBuckets + 2 * kSpQ * kSpMaxThreads;  // buckets + queues
 MOT_HD size_t sparse_vy_bytes(int nc) { const size_t b = 12 * static_cast<size_t>(nc); return ((b > kSpEnumBytes ? b : kSpEnumBytes) + 15) & ~size_t(15); }
 MOT_HD size_t sparse_hot_bytes(int nr, int nc, int ecap) {
   return static_cast<size_t>(nr) * 16 + sparse_vy_bytes(nc) + ((static_cast<size_t>(nr) * 2 + 15) & ~size_t(15)) + 4 * (static_cast<size_t>(nc) + 4) +
-         ((static_cast<size_t>(ecap) * 2 + 15) & ~size_t(15)) + static_cast<size_t>(ecap) * 4 + kSpSlots * 20 + 16 + 64;
+         ((static_cast<size_t>(ecap) * 2 + 15) & ~size_t(15)) + static_cast<size_t>(ecap) * 4 + 16 + 64;
 }
 MOT_HD int sparse_default_ecap(int nc) { return 4 * nc + 64; }
 MOT_HD size_t sparse_cold_bytes(int nr, int nc) {
@@ -116,14 +115,10 @@ MOT_HD void sparse_carve_hot(W& w, void* base, int nr, int nc, int ecap) {
   w.bmax.p = w.bcur.p + kSpBuckets;
   w.hq.p = reinterpret_cast<unsigned short*>(w.bmax.p + kSpBuckets);
   p += sparse_vy_bytes(nc);
-  w.sdist.p = reinterpret_cast<double*>(p); p += 8 * kSpSlots;
   w.sidx.p = reinterpret_cast<unsigned short*>(p); p += (2 * static_cast<size_t>(nr) + 15) & ~size_t(15);
   w.erow.p = reinterpret_cast<unsigned short*>(p); p += (2 * static_cast<size_t>(ecap) + 15) & ~size_t(15);
   w.eoff.p = reinterpret_cast<int*>(p); p += 4 * (static_cast<size_t>(nc) + 4);
   w.ecost.p = reinterpret_cast<float*>(p); p += 4 * static_cast<size_t>(ecap);
-  w.srow.p = reinterpret_cast<int*>(p); p += 4 * kSpSlots;
-  w.spred.p = reinterpret_cast<int*>(p); p += 4 * kSpSlots;
-  w.sstate.p = reinterpret_cast<int*>(p); p += 4 * kSpSlots;
   w.ctr.p = reinterpret_cast<int*>(p);
   w.ecap = ecap;
 }
@@ -216,7 +211,7 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
   const long long ec0 = MOT_CLOCK();
   long long n_cand = 0, n_hit = 0;
   // bits: 1 tie with the threshold, 2 column list full, 4 NaN / inf / out of range, 8 viable pairs that do not intersect, 16 CSR full
-  int bad = (nr > 65535 || T > 64) ? 4 : 0;
+  int bad = (nr > 65535 || T > kSpMaxThreads) ? 4 : 0;
   // ---- rows into x1 buckets ----
   const bool cached = nr <= T * kSpRC;
   float rx1[kSpRC];
@@ -361,7 +356,7 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
       // evaluates the queued pairs, marks the viable ones, reserves exactly that many CSR entries (the most a column may
       // hold if more candidates are still to come) and evaluates the viable ones once more to store them
       auto pair_cost = [&](int q, int* row) {
-        const int pp = w.hq[q * 64 + t];
+        const int pp = w.hq[q * T + t];
         const SpBox s = w.sbox[pp];
         *row = w.sidx[pp];
         const float a[4] = {s.x1, s.y1, s.x2, s.y2};
@@ -411,7 +406,7 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
         }
         return true;
       };
-      auto push = [&](int p) { w.hq[nq * 64 + t] = static_cast<unsigned short>(p); if (++nq == kSpQ) drain(false); };
+      auto push = [&](int p) { w.hq[nq * T + t] = static_cast<unsigned short>(p); if (++nq == kSpQ) drain(false); };
       int p = ps;
       for (; p + 4 <= pe; p += 4) {  // four boxes per round trip
         const SpBox s0 = w.sbox[p], s1 = w.sbox[p + 1], s2 = w.sbox[p + 2], s3 = w.sbox[p + 3];
@@ -478,14 +473,11 @@ struct SparseProf {  // diagnostics: shader cycles of the three stages, path sea
   long long c_init = 0, c_search = 0, c_cert = 0;
   int n_search = 0, n_scan = 0;
 };
-// Returns 1 with w.x / w.y holding THE minimum-weight matching (unique by more than kSpEps); else a reason <= 0 for the
-// exact path to take over (-2 a search reached too many rows, -3 certificate arithmetic, -4 too many tight pairs, -5 not unique).
+// 2. column duals, proposals, the columns left to insert (returns their number; the list is w.freel)
 template <class G, class W>
-MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh, SparseProf* prof = nullptr) {
+MOT_DEV int sparse_init(G& g, const W& w, int nr, int nc, float thresh) {
   const int T = g.size(), t = g.tid();
   const double th = static_cast<double>(thresh);
-  const long long pc0 = MOT_CLOCK();
-  int n_scan = 0;
   for (int i = t; i < nr; i += T) { w.u[i] = 0.0; w.x[i] = kSpIntMax; w.slot[i] = 0; }
   g.sync();
   // column duals and proposals
@@ -521,103 +513,133 @@ MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh, SparseP
     if (static_cast<int>(w.x[i]) == kSpIntMax) w.x[i] = -1;
   g.sync();
 
-  const long long pc1 = MOT_CLOCK();
-  // ---- shortest augmenting path per remaining column ----
+  return nfree;
+}
+
+// 3. a shortest augmenting path per remaining column. The group may be a single wavefront of a larger workgroup (the searches
+// are serial; their reductions then stay inside the wavefront). Returns 1, or -2 when a search reached too many rows.
+// The rows a search has reached live in the lanes' registers — lane q is slot q: row, label, the column it was reached from,
+// its current column, state — so that picking the nearest one is a register reduction and relaxing a column costs three
+// LDS round trips (the column's list entry and dual; its pairs; their rows' duals and slots); labels travel between lanes
+// by broadcast. Needs at least kSpSlots lanes.
+template <class G, class W>
+MOT_DEV int sparse_search(G& g, const W& w, int nfree, float thresh, int* scans = nullptr, long long* seg = nullptr) {
+  const int T = g.size(), t = g.tid();
+  const double th = static_cast<double>(thresh);
+  int n_scan = 0;
+  if (T < kSpSlots + 1) return (nfree > 0) ? -2 : 1;
   int j_next = (nfree > 0) ? static_cast<int>(w.freel[0]) : 0;
   for (int f = 0; f < nfree; ++f) {
     const int j0 = j_next;
     if (f + 1 < nfree) j_next = w.freel[f + 1];  // (global memory: fetched one search ahead)
     double L = -static_cast<double>(w.v[j0]);  // leave j0 unmatched
-    int term_row = -1, term_col = j0;           // terminal: a free row, or the column that ends unmatched
+    int term_slot = -1, term_col = j0;          // terminal: the slot of a free row, or the column that ends unmatched
     int cur = j0;
     double D = 0.0;
     int nslots = 0;
+    // this lane's slot
+    int my_row = -1, my_pred = -1, my_x = -1, my_state = 0;  // state: 0 empty, 1 reached, 2 scanned
+    double my_dist = 0.0;
     bool overflow = false;
     for (;;) {
       ++n_scan;
-      // relax the viable pairs of column `cur`
-      {
-        const double vc = w.v[cur];
-        const int ee = w.eoff[cur], e0 = sp_e0(ee), deg = sp_deg(ee);
-        bool need = false;
-        int er = -1;
-        double nd = 0.0;
-        if (t < deg) {
-          er = w.erow[e0 + t];
-          const double red = (static_cast<double>(static_cast<float>(w.ecost[e0 + t])) - th) - static_cast<double>(w.u[er]) - vc;
-          nd = D + red;
-          const int s = w.slot[er];
-          if (s == 0) need = true;
-          else if (static_cast<int>(w.sstate[s - 1]) == 1 && nd < static_cast<double>(w.sdist[s - 1])) { w.sdist[s - 1] = nd; w.spred[s - 1] = cur; }
-        }
-        int tot;
-        const int pos = g.flag_rank(need, &tot);
-        if (nslots + tot > kSpSlots) { overflow = true; break; }
-        if (need) {
-          const int q = nslots + pos;
-          w.srow[q] = er; w.sdist[q] = nd; w.spred[q] = cur; w.sstate[q] = 1; w.slot[er] = q + 1;
-        }
-        nslots += tot;
+      const long long q0 = MOT_CLOCK();
+      // relax the viable pairs of column `cur`: lane k < deg handles pair k
+      const double vc = w.v[cur];
+      const int ee = w.eoff[cur], e0 = sp_e0(ee), deg = sp_deg(ee);
+      int er = -1, es = 0, ex = -1;
+      double nd = 0.0;
+      if (t < deg) {
+        er = w.erow[e0 + t];
+        const double red = (static_cast<double>(static_cast<float>(w.ecost[e0 + t])) - th) - static_cast<double>(w.u[er]) - vc;
+        nd = D + red;
+        es = w.slot[er];
+        ex = w.x[er];
       }
-      g.sync();
-      // nearest reached, not yet scanned row (ties: lowest row index)
-      double bd = 1e300;
-      int brow = kNoIdx;
-      for (int q = t; q < nslots; q += T)
-        if (static_cast<int>(w.sstate[q]) == 1) {
-          const double d = w.sdist[q];
-          const int r = w.srow[q];
-          if (lex_less(d, r, bd, brow)) { bd = d; brow = r; }
+      const bool need = t < deg && es == 0;
+      int tot;
+      const int pos = g.flag_rank(need, &tot);
+      if (nslots + tot > kSpSlots) { overflow = true; break; }
+      if (need) w.slot[er] = nslots + pos + 1;
+      const long long q1 = MOT_CLOCK();
+      // labels to their slots: a pair whose row already has one improves it; the others open slots nslots, nslots + 1, ...
+      // (each pair lane pushes its label to the lane that owns the slot: distinct rows, distinct destinations)
+      {
+        const bool send = t < deg;
+        const int dstl = (es != 0) ? es - 1 : nslots + pos;
+        const int got = g.push_i32(1 + ((es == 0) ? 1 : 0), dstl, send);  // 0 nothing, 1 an improvement offer, 2 a new slot
+        const int g_lo = g.push_i32(__builtin_bit_cast(long long, nd) & 0xffffffffll, dstl, send);
+        const int g_hi = g.push_i32(static_cast<int>(__builtin_bit_cast(long long, nd) >> 32), dstl, send);
+        const int g_row = g.push_i32(er, dstl, send);
+        const int g_x = g.push_i32(ex, dstl, send);
+        if (got != 0) {
+          const double kd = __builtin_bit_cast(double, (static_cast<long long>(g_hi) << 32) | static_cast<long long>(static_cast<unsigned>(g_lo)));
+          if (got == 2) { my_row = g_row; my_dist = kd; my_pred = cur; my_x = g_x; my_state = 1; }
+          else if (my_state == 1 && kd < my_dist) { my_dist = kd; my_pred = cur; }
         }
+      }
+      nslots += tot;
+      const long long q2 = MOT_CLOCK();
+      // nearest reached, not yet scanned row (ties: lowest row index)
+      double bd = (my_state == 1) ? my_dist : 1e300;
+      int brow = (my_state == 1) ? my_row : kNoIdx;  // (kNoIdx: takes no part)
       g.reduce_lexmin(bd, brow);
+      const long long q3 = MOT_CLOCK();
+      if (seg) { seg[0] += q1 - q0; seg[1] += q2 - q1; seg[2] += q3 - q2; }
       if (brow == kNoIdx || !(bd < L)) break;
-      const int row = brow;
-      const int q = static_cast<int>(w.slot[row]) - 1;
-      const int xc = w.x[row];
-      if (xc < 0) { L = bd; term_row = row; term_col = -1; break; }
-      g.sync();
-      if (t == 0) w.sstate[q] = 2;
+      const unsigned long long own = g.ballot(my_state == 1 && my_row == brow);
+      const int q = __builtin_ctzll(own);
+      const int xc = g.bcast_i32(my_x, q);
+      if (xc < 0) { L = bd; term_slot = q; term_col = -1; break; }
+      if (t == q) my_state = 2;
       cur = xc;
       D = bd;
       const double cand = D - static_cast<double>(w.v[cur]);
-      if (cand < L) { L = cand; term_row = -1; term_col = cur; }
-      g.sync();
+      if (cand < L) { L = cand; term_slot = -1; term_col = cur; }
     }
     if (overflow) return -2;
-    g.sync();
+    const long long q4 = MOT_CLOCK();
     // duals: scanned rows and their columns move by (L - label); the source by L
-    for (int q = t; q < nslots; q += T)
-      if (static_cast<int>(w.sstate[q]) == 2) {
-        const int r = w.srow[q];
-        const double dl = L - static_cast<double>(w.sdist[q]);
-        w.u[r] -= dl;
-        w.v[static_cast<int>(w.x[r])] += dl;
-      }
+    if (my_state == 2) {
+      const double dl = L - my_dist;
+      w.u[my_row] -= dl;
+      w.v[my_x] += dl;
+    }
     if (t == 0) w.v[j0] += L;
     g.sync();
-    // augment (one lane walks the path)
-    if (t == 0) {
-      int r = -1;
-      if (term_row >= 0) r = term_row;
-      else if (term_col != j0) { r = w.y[term_col]; w.y[term_col] = -1; }
-      while (r >= 0) {
-        const int q = static_cast<int>(w.slot[r]) - 1;
-        const int p = w.spred[q];
+    // augment: the path is walked by everyone in step (slots are read by broadcast), one lane writes
+    {
+      int q = -1;
+      if (term_slot >= 0) q = term_slot;
+      else if (term_col != j0) {
+        const int r = w.y[term_col];
+        g.sync();
+        if (t == 0) w.y[term_col] = -1;
+        q = static_cast<int>(w.slot[r]) - 1;
+      }
+      while (q >= 0) {
+        const int r = g.bcast_i32(my_row, q), p = g.bcast_i32(my_pred, q);
         const int rn = w.y[p];
-        w.y[p] = r;
-        w.x[r] = p;
+        g.sync();
+        if (t == 0) { w.y[p] = r; w.x[r] = p; }
         if (p == j0) break;
-        r = rn;
+        q = static_cast<int>(w.slot[rn]) - 1;
       }
     }
     g.sync();
-    for (int q = t; q < nslots; q += T) w.slot[static_cast<int>(w.srow[q])] = 0;
+    if (my_state != 0) w.slot[my_row] = 0;
     g.sync();
+    if (seg) seg[3] += MOT_CLOCK() - q4;
   }
+  if (scans) *scans = n_scan;
+  return 1;
+}
 
-  const long long pc2 = MOT_CLOCK();
-  if (prof) { prof->c_init = pc1 - pc0; prof->c_search = pc2 - pc1; prof->n_search = nfree; prof->n_scan = n_scan; }
-  // ---- certificate ----
+// 4. certificate: 1 when w.x / w.y is the unique optimum by more than kSpEps, else -3 / -4 / -5
+template <class G, class W>
+MOT_DEV int sparse_certify(G& g, const W& w, int nr, int nc, float thresh) {
+  const int T = g.size(), t = g.tid();
+  const double th = static_cast<double>(thresh);
   enum : int { kStart = 1, kEnd = 2, kReach = 4, kArrived = 8, kFreeCol = 16, kIn = 32 };
   for (int i = t; i < nr; i += T) {
     const int xc = w.x[i];
@@ -721,8 +743,26 @@ MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh, SparseP
   }
   nonuniq = g.reduce_max(nonuniq);
   g.sync();
-  if (prof) prof->c_cert = MOT_CLOCK() - pc2;
   return nonuniq ? -5 : 1;
+}
+
+
+// 2-4 by one group. Returns 1 with w.x / w.y holding THE minimum-weight matching (unique by more than kSpEps); else a reason
+// <= 0 for the exact path to take over (-2 a search reached too many rows, -3 certificate arithmetic, -4 too many tight
+// pairs, -5 not unique).
+template <class G, class W>
+MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh, SparseProf* prof = nullptr) {
+  const long long pc0 = MOT_CLOCK();
+  const int nfree = sparse_init(g, w, nr, nc, thresh);
+  const long long pc1 = MOT_CLOCK();
+  int scans = 0;
+  const int rs = sparse_search(g, w, nfree, thresh, &scans);
+  const long long pc2 = MOT_CLOCK();
+  if (prof) { prof->c_init = pc1 - pc0; prof->c_search = pc2 - pc1; prof->n_search = nfree; prof->n_scan = scans; }
+  if (rs != 1) return rs;
+  const int rc = sparse_certify(g, w, nr, nc, thresh);
+  if (prof) prof->c_cert = MOT_CLOCK() - pc2;
+  return rc;
 }
 
 }  // namespace mot

@@ -18,23 +18,26 @@ constexpr int kScratch = 1024;  // DevGroup reduction scratch
 // [1] enumeration declined (tie with the threshold, NaN/inf, list overflow, viable non-intersecting pairs), [2] a path search
 // reached too many rows, [3] certificate arithmetic, [4] too many tight pairs, [5] optimum not unique, [6] not attempted
 // (diagnostics requested / cost flavour), [7] empty problems
-__device__ unsigned long long g_fast_hist[64 * 24];  // 64 sets (block & 63) so that thousands of problems do not serialise on one line;  // [8..] cycles: enumeration, matching init, path searches, certificate; [12] searches, [13] column scans
-__device__ __forceinline__ unsigned long long* hist_set() { return g_fast_hist + (blockIdx.x & 63) * 24; }
+__device__ unsigned long long g_fast_hist[64 * 32];  // 64 sets (block & 63) so that thousands of problems do not serialise on one line;  // [8..] cycles: enumeration, matching init, path searches, certificate; [12] searches, [13] column scans
+__device__ __forceinline__ unsigned long long* hist_set() { return g_fast_hist + (blockIdx.x & 63) * 32; }
 __device__ __forceinline__ void count_outcome(int k) { if (threadIdx.x == 0) atomicAdd(hist_set() + k, 1ull); }
 
 __device__ __forceinline__ int* status_word(const mot_lap_task& T, size_t scratch_bytes) {
   return reinterpret_cast<int*>(static_cast<char*>(T.work) + scratch_bytes - 16);
 }
 
-template <bool PLAIN, int HS>
-__global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __restrict__ tasks, int lds_ecap) {
+// kThreads = 64: one wavefront does everything. kThreads = 256: four wavefronts enumerate the viable pairs, build the initial
+// matching and check the certificate together (those loops run over rows / columns / pairs); the serial path searches in
+// between are done by the first wavefront alone while the others wait at the next barrier.
+template <bool PLAIN, int HS, int kThreads>
+__global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task* __restrict__ tasks, int lds_ecap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mot_lap_task T = tasks[blockIdx.x];
   const int nr = T.n, nc = T.m, t = threadIdx.x;
   int* status = status_word(T, mot::lap_task_scratch_bytes(nr, nc));
   if (nr <= 0 || nc <= 0) {
-    for (int i = t; i < nr; i += 64) { T.x[i] = -1; if (T.xval) T.xval[i] = 0.f; }
-    for (int j = t; j < nc; j += 64) T.y[j] = -1;
+    for (int i = t; i < nr; i += kThreads) { T.x[i] = -1; if (T.xval) T.xval[i] = 0.f; }
+    for (int j = t; j < nc; j += kThreads) T.y[j] = -1;
     if (t == 0) { if (T.info) T.info[0] = 2; *status = 1; }
     count_outcome(7);
     return;
@@ -61,9 +64,9 @@ __global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __re
   if (T.mode == MOT_LAP_OCSORT) {
     // a = (iou > gate); trivial one-to-one case iff max row sum == 1 and max col sum == 1 (ocsort.cpp:684-696)
     int max_row = 0, max_col = 0;
-    for (int i = t; i < nr; i += 64) { w.x[i] = -1; w.slot[i] = 0; }
+    for (int i = t; i < nr; i += kThreads) { w.x[i] = -1; w.slot[i] = 0; }
     g.sync();
-    for (int j = t; j < nc; j += 64) {
+    for (int j = t; j < nc; j += kThreads) {
       int c = 0, last = -1;
       for (int i = 0; i < nr; ++i)
         if (mot::gld(T.iou, static_cast<size_t>(i) * T.ldi + j) > T.gate) {
@@ -75,7 +78,7 @@ __global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __re
       if (c > max_col) max_col = c;
     }
     g.sync();
-    for (int i = t; i < nr; i += 64) {
+    for (int i = t; i < nr; i += kThreads) {
       const int c = w.slot[i];
       if (c != 1) w.x[i] = -1;
       if (c > max_row) max_row = c;
@@ -134,7 +137,31 @@ __global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __re
     else {
       const long long ck1 = MOT_CLOCK();
       mot::SparseProf pf;
-      const int r = mot::sparse_solve(g, w, nr, nc, T.thresh, &pf);
+      int r;
+      if constexpr (kThreads == 64) r = mot::sparse_solve(g, w, nr, nc, T.thresh, &pf);
+      else {
+        const int nfree = mot::sparse_init(g, w, nr, nc, T.thresh);
+        const long long ck2 = MOT_CLOCK();
+        if (t < 64) {
+          mot::DevWave gw;
+          int scans = 0;
+          long long seg[4] = {0, 0, 0, 0};
+          const int rs = mot::sparse_search(gw, w, nfree, T.thresh, &scans, seg);
+          if (t == 0) {
+            w.ctr[3] = rs;
+            unsigned long long* h = hist_set();  // where the searches spend their cycles
+            atomicAdd(h + 24, static_cast<unsigned long long>(seg[0])); atomicAdd(h + 25, static_cast<unsigned long long>(seg[1]));
+            atomicAdd(h + 26, static_cast<unsigned long long>(seg[2])); atomicAdd(h + 27, static_cast<unsigned long long>(seg[3]));
+          }
+          pf.n_scan = scans;
+        }
+        g.sync();
+        const long long ck3 = MOT_CLOCK();
+        r = w.ctr[3];
+        g.sync();
+        if (r == 1) r = mot::sparse_certify(g, w, nr, nc, T.thresh);
+        pf.c_init = ck2 - ck1; pf.c_search = ck3 - ck2; pf.c_cert = MOT_CLOCK() - ck3; pf.n_search = nfree;
+      }
       solved = (r == 1) ? 1 : 0;
       reason = (r >= -5 && r <= -2) ? -r : 1;
       if (t == 0) {
@@ -150,11 +177,11 @@ __global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __re
   }
   if (!solved) { if (t == 0) *status = 0; count_outcome(reason); return; }
   if (path == 2) {
-    for (int i = t; i < nr; i += 64) w.x[i] = -1;
-    for (int j = t; j < nc; j += 64) w.y[j] = -1;
+    for (int i = t; i < nr; i += kThreads) w.x[i] = -1;
+    for (int j = t; j < nc; j += kThreads) w.y[j] = -1;
   }
   g.sync();
-  for (int i = t; i < nr; i += 64) {
+  for (int i = t; i < nr; i += kThreads) {
     const int xi = w.x[i];
     T.x[i] = xi;
     if (T.xval) {
@@ -171,7 +198,7 @@ __global__ void __launch_bounds__(64) lap_sparse_kernel(const mot_lap_task* __re
       T.xval[i] = v;
     }
   }
-  for (int j = t; j < nc; j += 64) T.y[j] = w.y[j];
+  for (int j = t; j < nc; j += kThreads) T.y[j] = w.y[j];
   if (t == 0) { if (T.info) T.info[0] = path; *status = 1; }
   count_outcome(0);
 }
@@ -193,25 +220,30 @@ hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, i
     hot = kScratch + sparse_hot_bytes(n, m, ecap);
   }
   const bool lds = ecap >= 3 * m + 16;
+  // four wavefronts per problem once there is enough to enumerate (the pairs are listed four times faster; the hot state's
+  // LDS, which bounds the problems resident per CU, is the same)
+  const bool wide = lds && (static_cast<long>(n) * m >= 64 * 1024);
+#define MOT_SP_LAUNCH(P, H, TH, BYTES) hipLaunchKernelGGL((lap_sparse_kernel<P, H, TH>), dim3(ntasks), dim3(TH), BYTES, st, tasks, ecap)
   if (lds) {
-    if (plain_costs) hipLaunchKernelGGL((lap_sparse_kernel<true, kMemLds>), dim3(ntasks), dim3(64), hot, st, tasks, ecap);
-    else hipLaunchKernelGGL((lap_sparse_kernel<false, kMemLds>), dim3(ntasks), dim3(64), hot, st, tasks, ecap);
+    if (wide) { if (plain_costs) MOT_SP_LAUNCH(true, kMemLds, 256, hot); else MOT_SP_LAUNCH(false, kMemLds, 256, hot); }
+    else { if (plain_costs) MOT_SP_LAUNCH(true, kMemLds, 64, hot); else MOT_SP_LAUNCH(false, kMemLds, 64, hot); }
   } else {
-    if (plain_costs) hipLaunchKernelGGL((lap_sparse_kernel<true, kMemGlobal>), dim3(ntasks), dim3(64), kScratch, st, tasks, 0);
-    else hipLaunchKernelGGL((lap_sparse_kernel<false, kMemGlobal>), dim3(ntasks), dim3(64), kScratch, st, tasks, 0);
+    ecap = 0;
+    if (plain_costs) MOT_SP_LAUNCH(true, kMemGlobal, 64, kScratch); else MOT_SP_LAUNCH(false, kMemGlobal, 64, kScratch);
   }
+#undef MOT_SP_LAUNCH
   return hipGetLastError();
 }
-hipError_t lap_fast_stats(unsigned long long* out16 /* [24] */, bool reset, hipStream_t st) {
+hipError_t lap_fast_stats(unsigned long long* out16 /* [32] */, bool reset, hipStream_t st) {
   hipError_t e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
   if (out16) {
-    unsigned long long raw[64 * 24];
+    unsigned long long raw[64 * 32];
     e = hipMemcpyFromSymbol(raw, HIP_SYMBOL(g_fast_hist), sizeof(raw));
     if (e != hipSuccess) return e;
-    for (int k = 0; k < 24; ++k) { out16[k] = 0; for (int s = 0; s < 64; ++s) out16[k] += raw[s * 24 + k]; }
+    for (int k = 0; k < 32; ++k) { out16[k] = 0; for (int s = 0; s < 64; ++s) out16[k] += raw[s * 32 + k]; }
   }
-  if (reset) { static const unsigned long long z[64 * 24] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_fast_hist), z, sizeof(z)); }
+  if (reset) { static const unsigned long long z[64 * 32] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_fast_hist), z, sizeof(z)); }
   return e;
 }
 }  // namespace mot

@@ -34,7 +34,7 @@ __device__ __forceinline__ int compact(bool pred, int& base) {
 // has tracks: the reference's ByteTrack keeps tracks in its tracked list without a detection in some branches), then packed
 // back to back so that the copy to the host moves the emitted rows only.
 // offsets[s] = first row of stream s, offsets[S] = total; counts < 0 (a staging overflow) count as 0 rows.
-static __global__ void __launch_bounds__(1024) pack_offsets(const int* counts, int S, int* offsets) {
+[[maybe_unused]] static __global__ void __launch_bounds__(1024) pack_offsets(const int* counts, int S, int* offsets) {
   __shared__ int part[1024];
   const int t = static_cast<int>(threadIdx.x);
   const int L = (S + 1023) / 1024;
@@ -53,7 +53,7 @@ static __global__ void __launch_bounds__(1024) pack_offsets(const int* counts, i
   for (int i = b0; i < b1; ++i) { offsets[i] = base; const int c = counts[i]; base += (c > 0) ? c : 0; }
   if (t == 1023) offsets[S] = part[1023];
 }
-static __global__ void __launch_bounds__(256) pack_rows(const float* stage, int cap_stage, const int* counts, const int* offsets, float* packed,
+[[maybe_unused]] static __global__ void __launch_bounds__(256) pack_rows(const float* stage, int cap_stage, const int* counts, const int* offsets, float* packed,
                                                  int packed_cap) {
   const int s = blockIdx.x;
   const int c = counts[s];

@@ -77,6 +77,36 @@ struct EmuGroup {
     return base;
   }
   int flag_rank(bool flag, int* total) { return exclusive_scan(flag ? 1 : 0, total); }
+  unsigned long long ballot(bool flag) {
+    auto& s = sh->s_int[phase++ & 1];
+    s[tid_] = flag ? 1 : 0;
+    sync();
+    unsigned long long m = 0;
+    for (int t = 0; t < sh->T && t < 64; ++t) if (s[t]) m |= 1ull << t;
+    return m;
+  }
+  int push_i32(int v, int dst, bool active) {  // every active lane sends v to lane dst; a lane that gets nothing reads 0
+    auto& s = sh->s_int[phase++ & 1];
+    s[tid_] = 0;
+    sync();
+    if (active && dst >= 0 && dst < sh->T && dst != 63) s[dst] = v;  // (lane 63 is the device's "send nothing" target)
+    sync();
+    const int r = s[tid_];
+    sync();
+    return r;
+  }
+  int bcast_i32(int v, int src) {
+    auto& s = sh->s_int[phase++ & 1];
+    s[tid_] = v;
+    sync();
+    return s[src];
+  }
+  double bcast_f64(double v, int src) {
+    auto& s = sh->s_f64[phase++ & 1];
+    s[tid_] = v;
+    sync();
+    return s[src];
+  }
   void reduce_lexmin(double& v, int& j) {
     Top2 t{v, 1e300, j, kNoIdx};
     t = reduce_top2(t);

@@ -122,6 +122,10 @@ int mot_kf_dim(int kf_kind);
 int mot_kf_initiate(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
 int mot_kf_predict(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
 int mot_kf_update(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
+/* boxes of the PREDICTED states, nothing stored (what mot_kf_predict does for items flagged MOT_KF_NO_STORE, for a launch
+ * in which every item is): the box depends on the predicted mean only, so 32 bytes of a record are read instead of all of it.
+ * flags: MOT_KF_ZERO_V7 / MOT_KF_OCSORT_CLAMP as in mot_kf_predict. ByteTrack's pool copies, bytetrack.cpp:251-265. */
+int mot_kf_predict_boxes(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
 int mot_kf_boxes(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
 /* Camera-motion compensation of the stored states with a caller-supplied warp (the image registration that produces it
  * is outside this library). MOT_KF_XYWH: BotSTrack::multi_gmc (src/trackers/botsort.cpp:60-91) — both corners of the

@@ -659,7 +659,7 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[0], st));
   hipLaunchKernelGGL(bt_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, bd, st));
-  MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYAH, b->pred_t, S, bn, st));
+  MOT_LC_HIP(b, mot::launch_kf_op(6, MOT_KF_XYAH, b->pred_t, S, bn, st));  // predicted boxes of the pool (box-only: nothing is stored)
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, true, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[2], st));

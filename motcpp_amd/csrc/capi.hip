@@ -117,6 +117,7 @@ int mot_kf_dim(int kind) { return kind == MOT_KF_XYSR ? 7 : 8; }
 int mot_det_prepare(mot_ctx* c, int kind, const mot_det_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_det(kind, t, nt, max_n, c->stream)); return MOT_OK; }
 int mot_kf_initiate(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_kf_op(0, kind, t, nt, max_n, c->stream)); return MOT_OK; }
 int mot_kf_predict(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_kf_op(1, kind, t, nt, max_n, c->stream)); return MOT_OK; }
+int mot_kf_predict_boxes(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_kf_op(6, kind, t, nt, max_n, c->stream)); return MOT_OK; }
 int mot_kf_update(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_kf_op(2, kind, t, nt, max_n, c->stream)); return MOT_OK; }
 int mot_kf_boxes(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_kf_op(3, kind, t, nt, max_n, c->stream)); return MOT_OK; }
 int mot_kf_warp(mot_ctx* c, int kind, const mot_kf_task* t, int nt, int max_n) {

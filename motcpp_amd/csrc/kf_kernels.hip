@@ -436,7 +436,7 @@ __device__ __forceinline__ void state_warp(St<D>& s, const float* W) {
 template <int KIND> struct Dim { static constexpr int D = 8; };
 template <> struct Dim<MOT_KF_XYSR> { static constexpr int D = 7; };
 
-enum { OP_INIT = 0, OP_PREDICT = 1, OP_UPDATE = 2, OP_BOXES = 3, OP_WARP = 4, OP_PREDICT_WARP = 5 };
+enum { OP_INIT = 0, OP_PREDICT = 1, OP_UPDATE = 2, OP_BOXES = 3, OP_WARP = 4, OP_PREDICT_WARP = 5, OP_PREDICT_BOXES = 6 };
 
 template <int KIND, int OP>
 __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restrict__ tasks) {
@@ -461,6 +461,26 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
     if (active) {  // only the first four mean components are needed: one 16-byte load per track
       const float4 m4 = *reinterpret_cast<const float4*>(T.mean + static_cast<size_t>(src) * rec_floats<D>());
       s.m[0] = m4.x; s.m[1] = m4.y; s.m[2] = m4.z; s.m[3] = m4.w;
+    }
+  } else if (OP == OP_PREDICT_BOXES) {
+    // Boxes of the predicted states, nothing stored: the box is a function of the predicted MEAN alone (x' = F x, the same
+    // additions as motion<>), so only the first 32 bytes of a record are read — not the covariance.
+    if (active) {
+      const float4* mp = reinterpret_cast<const float4*>(T.mean + static_cast<size_t>(src) * rec_floats<D>());
+      const float4 a = mp[0], b = mp[1];
+      float m[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      const unsigned f = T.flags ? T.flags[i] : 0u;
+      if constexpr (KIND == MOT_KF_XYSR) {
+        if ((f & MOT_KF_OCSORT_CLAMP) && (m[6] + m[2]) <= 0.0f) m[6] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) m[k] = m[k] + m[k + 4];
+      } else {
+        if (f & MOT_KF_ZERO_V7) m[7] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = m[k] + m[k + 4];
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k) s.m[k] = m[k];
     }
   } else {
     if (OP != OP_INIT) {
@@ -571,6 +591,7 @@ hipError_t launch_kf_op(int op, int kind, const mot_kf_task* tasks, int ntasks, 
     case OP_BOXES: return launch_kf<OP_BOXES>(kind, tasks, ntasks, max_n, st);
     case OP_WARP: return (kind == MOT_KF_XYAH) ? hipErrorInvalidValue : launch_kf<OP_WARP>(kind, tasks, ntasks, max_n, st);
     case OP_PREDICT_WARP: return (kind == MOT_KF_XYAH) ? hipErrorInvalidValue : launch_kf<OP_PREDICT_WARP>(kind, tasks, ntasks, max_n, st);
+    case OP_PREDICT_BOXES: return launch_kf<OP_PREDICT_BOXES>(kind, tasks, ntasks, max_n, st);
   }
   return hipErrorInvalidValue;
 }

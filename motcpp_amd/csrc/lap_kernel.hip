@@ -17,6 +17,8 @@
 // only because the brief asks for it — its real bound is issue latency of the serial row passes.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "../../include/motcpp_amd.h"
 #include "lap_core.hpp"
 #include "lap_cost.hpp"
@@ -101,11 +103,10 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
 constexpr int lap_min_waves(int threads, int rpl, bool general) { return (threads > 64 || general) ? 1 : (rpl >= 8 ? 2 : (rpl >= 4 ? 3 : 4)); }
 // FLAVOR of the on-the-fly cost: 0 plain IoU modes only, 1 + BoT-SORT's gated appearance term, 2 every association measure
 template <int kThreads, int lds_mode, int RPL, int FLAVOR>
-__global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR == 2)) lap_kernel(const mot_lap_task* __restrict__ tasks, int check_status) {
+__device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status) {
   constexpr bool GENERAL = FLAVOR == 2;
   constexpr bool PLAIN = FLAVOR == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const mot_lap_task T = tasks[blockIdx.x];
   const int nr = T.n, nc = T.m, n = nr + nc;
   const int t = threadIdx.x;
   // the fast path (lap_sparse_kernel) ran first over the same tasks: problems it finished carry status 1
@@ -183,6 +184,16 @@ __global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR 
   if (T.info && t == 0) T.info[0] = path;
 }
 
+template <int kThreads, int lds_mode, int RPL, int FLAVOR>
+__global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR == 2)) lap_kernel(const mot_lap_task* __restrict__ tasks, int ntasks, int check_status) {
+  // behind the fast path the grid is smaller than the task array: a block walks its share of it and solves what is left
+  for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+    const mot_lap_task T = tasks[task];
+    lap_one<kThreads, lds_mode, RPL, FLAVOR>(T, check_status);
+    if (task + static_cast<int>(gridDim.x) < ntasks) __syncthreads();  // the LDS state of this problem is dead before the next one starts
+  }
+}
+
 }  // namespace
 
 namespace mot {
@@ -214,26 +225,34 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   // lane-owned column boxes in registers: one wavefront per problem, <= 8 real columns per lane
   int rpl = 0;
   if (geom && !wide && !general_assoc) rpl = (m <= 256) ? 4 : (m <= 512 ? 8 : 0);
-  static bool attr_set = false;
+  // the dynamic-LDS attribute is per device: set once for each device this process launches on
+  static std::mutex attr_mu;
+  static bool attr_set_dev[64] = {};
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  const int dev_slot = (dev_id >= 0 && dev_id < 64) ? dev_id : 0;
+  // behind the fast path almost every block would find its problem finished: launch fewer and let them walk the task array
+  const int grid = (fast && ntasks > 512) ? 512 : ntasks;
 #define MOT_LAP_VARIANTS(X) X(64, 0, 0, 1) X(64, 2, 0, 1) X(64, 3, 0, 1) X(64, 0, 4, 1) X(64, 2, 4, 1) X(64, 3, 4, 1) \
                             X(64, 0, 8, 1) X(64, 2, 8, 1) X(64, 3, 8, 1) X(256, 0, 0, 1) X(256, 2, 0, 1) X(256, 3, 0, 1) \
                             X(64, 0, 4, 0) X(64, 2, 4, 0) X(64, 3, 4, 0) X(64, 0, 8, 0) X(64, 2, 8, 0) X(64, 3, 8, 0) \
                             X(64, 0, 0, 2) X(64, 2, 0, 2) X(64, 3, 0, 2) X(256, 0, 0, 2) X(256, 2, 0, 2) X(256, 3, 0, 2)
   // plain-cost variants exist for the register-cached column layouts only (the hot ones)
   const int flavor = general_assoc ? 2 : ((plain_costs && rpl > 0) ? 0 : 1);
-  if (!attr_set) {
+  std::lock_guard<std::mutex> attr_lock(attr_mu);
+  if (!attr_set_dev[dev_slot]) {
 #define MOT_ATTR(T, M, R, G)                                                                                               \
     { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_kernel<T, M, R, G>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget); \
       if (e != hipSuccess) return e; }
     MOT_LAP_VARIANTS(MOT_ATTR)
 #undef MOT_ATTR
-    attr_set = true;
+    attr_set_dev[dev_slot] = true;
   }
   const int threads = wide ? 256 : 64;
   bool launched = false;
 #define MOT_TRY(T, M, R, G)                                                                                \
   if (!launched && threads == T && mode == M && rpl == R && flavor == G) {                                 \
-    hipLaunchKernelGGL((lap_kernel<T, M, R, G>), dim3(ntasks), dim3(T), lds, st, tasks, fast ? 1 : 0);     \
+    hipLaunchKernelGGL((lap_kernel<T, M, R, G>), dim3(grid), dim3(T), lds, st, tasks, ntasks, fast ? 1 : 0); \
     launched = true;                                                                                       \
   }
   MOT_LAP_VARIANTS(MOT_TRY)

@@ -191,15 +191,22 @@ typedef struct mot_cos_task {
   const float* a; int32_t lda; const int32_t* aidx; /* track features, rows of length d (gathered) */
   const float* b; int32_t ldb; const int32_t* bidx; /* detection features                          */
   float* out; int32_t ldo;                          /* n x m: max(0, 1 - a.b / (|a||b| + 1e-10))   */
-  float* norm_a; float* norm_b;                     /* scratch [n], [m]                            */
+  float* norm_a; float* norm_b;                     /* unused (the row norms are accumulated inside the kernel); may be NULL */
 } mot_cos_task;
 int mot_cosine_cost(mot_ctx* ctx, const mot_cos_task* tasks, int ntasks, int max_n, int max_m);
+/* the other metrics over the same task layout: MOT_EMB_COSINE = mot_cosine_cost; MOT_EMB_DOT: out = a_i . b_j (the raw
+ * similarity DeepOC-SORT builds its embedding cost from, src/trackers/deepocsort.cpp:404; fp32 MFMA, k-ordered);
+ * MOT_EMB_EUCLIDEAN: out = |a_i - b_j| (utils::embedding_distance(metric = "euclidean"), src/utils/matching.cpp:93-101) */
+typedef enum mot_emb_metric { MOT_EMB_COSINE = 0, MOT_EMB_DOT = 1, MOT_EMB_EUCLIDEAN = 2 } mot_emb_metric;
+int mot_embedding_cost(mot_ctx* ctx, int metric, const mot_cos_task* tasks, int ntasks, int max_n, int max_m);
 
 typedef struct mot_feat_task {
   int32_t n, d;
   float* feat; int32_t ldf; const int32_t* slot;          /* destination rows feat[slot[i]*ldf ..]   */
   const float* src; int32_t lds; const int32_t* sidx;     /* raw detection feature rows              */
-  int32_t mode;                                           /* 0: set = src/|src|, 1: EMA then renormalise */
+  int32_t mode;                                           /* 0: set = src/|src|, 1: EMA then renormalise,
+                                                             2: src/|src| only where |src| > 1e-6 (ReIDBackend::normalize_features,
+                                                                src/appearance/reid_backend.cpp:72-88) */
   float alpha;                                            /* EMA weight of the old feature (0.9)     */
 } mot_feat_task;
 int mot_feat_update(mot_ctx* ctx, const mot_feat_task* tasks, int ntasks, int max_n);
@@ -306,6 +313,9 @@ int mot_iou_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_x
 int mot_assoc_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_xyxy, int m, const float* bconf_or_null,
                         int mode, int assoc, int frame_w, int frame_h, float* cost);
 int mot_cosine_cost_host(mot_ctx* ctx, const float* a, int n, const float* b, int m, int d, float* out);
+int mot_embedding_cost_host(mot_ctx* ctx, int metric, const float* a, int n, const float* b, int m, int d, float* out);
+/* mot_feat_update on host rows: feat [n][d] in/out (read by mode 1), src [n][d] */
+int mot_feat_update_host(mot_ctx* ctx, int mode, float alpha, int n, int d, float* feat, const float* src);
 int mot_ocsort_cost_host(mot_ctx* ctx, const float* dets5, int nd, const float* trks4, int nt,
                          const float* vel2, const float* prev5, float vdc_weight, float* cost, float* iou);
 int mot_lap_solve_host(mot_ctx* ctx, const float* cost, int n, int m, float thresh, int mode,

@@ -34,7 +34,10 @@ int motcpp_tracker_set_camera_motion(motcpp_tracker* t, const float* warp2x3);
 /* parity hooks: assignments solved during the last update, and the Kalman states of the live tracks */
 int motcpp_tracker_lap_count(motcpp_tracker* t);
 int motcpp_tracker_lap_get(motcpp_tracker* t, int k, int* n, int* m, int* x, int* y, int cap);
-int motcpp_tracker_dump_states(motcpp_tracker* t, float* out, int cap_floats, int* width); /* rows [id, mean(d), cov(d*d)] */
+int motcpp_tracker_dump_states(motcpp_tracker* t, float* out, int cap_floats, int* width);
+/* BoT-SORT parity hook: smooth features (botsort.hpp smooth_feat_) of the live tracks in dump_states order, *dim floats per row
+ * (zeros for a track that has none yet; *dim = 0 when the tracker holds no features); returns the number of rows */
+int motcpp_tracker_dump_features(motcpp_tracker* t, float* out, int cap_floats, int* dim); /* rows [id, mean(d), cov(d*d)] */
 
 /* S independent streams stepped in lockstep on one GPU (one kernel launch per kernel family per stage). */
 motcpp_batch* motcpp_batch_create(int kind, const float* params, int nparams, int nstreams, int device);

@@ -121,6 +121,22 @@ class Context:
                                               _p(i) if i is not None else None, C.c_float(gate), _p(x), _p(y), C.byref(info)))
         return x[:n], y[:m], info.value
 
+    def embedding_cost(self, metric, a, b):
+        """metric 0 cosine distance, 1 raw dot product, 2 euclidean distance (mot_embedding_cost_host)"""
+        a, b = f32(a), f32(b)
+        out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+        self.lib.mot_embedding_cost_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self._chk(self.lib.mot_embedding_cost_host(self.h, int(metric), _p(a), a.shape[0], _p(b), b.shape[0], a.shape[1], _p(out)))
+        return out
+
+    def feat_update(self, mode, feat, src, alpha=0.9):
+        """mot_feat_update on host rows: mode 0 set+normalise, 1 EMA+normalise, 2 ReID normalise (norm > 1e-6). Returns new feat."""
+        feat, src = f32(feat).copy(), f32(src)
+        n, d = src.shape
+        self.lib.mot_feat_update_host.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.mot_feat_update_host(self.h, int(mode), C.c_float(alpha), n, d, _p(feat), _p(src)))
+        return feat
+
     def lap_fast_stats(self, reset=False):
         """Outcome counts of the assignment fast path on this device since the last reset (see mot_lap_fast_stats)."""
         o = np.zeros(32, np.uint64)
@@ -251,6 +267,16 @@ class _Hooks:
             if r > -1000000:
                 raise MotError(_err())
             buf = np.zeros((-r - 1000000 + 8) * max(w.value, 1), np.float32)
+
+    def dump_features(self):
+        """BoT-SORT: smooth features of the live tracks in dump_states order, [rows, dim] (dim 0: no features)."""
+        H, d = host(), C.c_int()
+        H.motcpp_tracker_dump_features.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        buf = np.zeros(1 << 22, np.float32)
+        r = H.motcpp_tracker_dump_features(self.h, _p(buf), buf.size, C.byref(d))
+        if r < 0:
+            raise MotError(_err())
+        return buf[:r * d.value].reshape(r, d.value).copy() if d.value else np.zeros((r, 0), np.float32)
 
 
 class Tracker(_Hooks):

@@ -17,6 +17,7 @@ hipError_t launch_det(int kind, const mot_det_task*, int, int, hipStream_t);
 hipError_t launch_iou(const mot_iou_task*, int, int, int, bool, hipStream_t);
 hipError_t launch_ocsort(const mot_ocsort_task*, int, int, int, bool, hipStream_t);
 hipError_t launch_feat(const mot_feat_task*, int, int, hipStream_t);
+hipError_t launch_embed(int metric, const mot_cos_task*, int, int, int, hipStream_t);
 hipError_t launch_cosine(const mot_cos_task*, int, int, int, hipStream_t);
 hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, bool, hipStream_t);
 size_t lap_scratch_bytes(int n, int m);
@@ -180,8 +181,11 @@ int mot_assoc_cost_host(mot_ctx* c, const float* a, int n, const float* b, int m
   return MOT_OK;
 }
 
-int mot_cosine_cost_host(mot_ctx* c, const float* a, int n, const float* b, int m, int d, float* out) {
+int mot_embedding_cost(mot_ctx* c, int metric, const mot_cos_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_embed(metric, t, nt, max_n, max_m, c->stream)); return MOT_OK; }
+int mot_cosine_cost_host(mot_ctx* c, const float* a, int n, const float* b, int m, int d, float* out) { return mot_embedding_cost_host(c, MOT_EMB_COSINE, a, n, b, m, d, out); }
+int mot_embedding_cost_host(mot_ctx* c, int metric, const float* a, int n, const float* b, int m, int d, float* out) {
   if (n <= 0 || m <= 0) return MOT_OK;
+  if (metric < 0 || metric > 2) return MOT_ERR_INVALID;
   DBuf da, db, dout, dna, dnb, dt;
   MOT_HIP(c, da.alloc(static_cast<size_t>(n) * d * 4)); MOT_HIP(c, db.alloc(static_cast<size_t>(m) * d * 4));
   MOT_HIP(c, dout.alloc(static_cast<size_t>(n) * m * 4)); MOT_HIP(c, dna.alloc(n * 4)); MOT_HIP(c, dnb.alloc(m * 4));
@@ -192,7 +196,7 @@ int mot_cosine_cost_host(mot_ctx* c, const float* a, int n, const float* b, int 
   t.n = n; t.m = m; t.d = d; t.a = da.as<float>(); t.lda = d; t.b = db.as<float>(); t.ldb = d;
   t.out = dout.as<float>(); t.ldo = m; t.norm_a = dna.as<float>(); t.norm_b = dnb.as<float>();
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
-  MOT_HIP(c, mot::launch_cosine(dt.as<mot_cos_task>(), 1, n, m, c->stream));
+  MOT_HIP(c, mot::launch_embed(metric, dt.as<mot_cos_task>(), 1, n, m, c->stream));
   MOT_HIP(c, hipMemcpyAsync(out, dout.p, static_cast<size_t>(n) * m * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   return MOT_OK;
@@ -334,6 +338,23 @@ static int kf_host(mot_ctx* c, int kind, int op, int n, const float* meas4, cons
     for (int k = 0; k < D * D; ++k) cov[static_cast<size_t>(i) * D * D + k] = sm[static_cast<size_t>(i) * RS + D + k];
     if (boxes4) for (int k = 0; k < 4; ++k) boxes4[static_cast<size_t>(i) * 4 + k] = sb[static_cast<size_t>(k) * n + i];
   }
+  return MOT_OK;
+}
+
+int mot_feat_update_host(mot_ctx* c, int mode, float alpha, int n, int d, float* feat, const float* src) {
+  if (n <= 0 || d <= 0) return MOT_OK;
+  if (mode < 0 || mode > 2 || !feat || !src) return MOT_ERR_INVALID;
+  const size_t bytes = static_cast<size_t>(n) * d * 4;
+  DBuf df, ds, dt;
+  MOT_HIP(c, df.alloc(bytes)); MOT_HIP(c, ds.alloc(bytes)); MOT_HIP(c, dt.alloc(sizeof(mot_feat_task)));
+  MOT_HIP(c, hipMemcpyAsync(df.p, feat, bytes, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(ds.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  mot_feat_task t{};
+  t.n = n; t.d = d; t.feat = df.as<float>(); t.ldf = d; t.src = ds.as<float>(); t.lds = d; t.mode = mode; t.alpha = alpha;
+  MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, mot::launch_feat(dt.as<mot_feat_task>(), 1, n, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(feat, df.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
   return MOT_OK;
 }
 

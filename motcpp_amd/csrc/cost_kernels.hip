@@ -208,23 +208,69 @@ __global__ void __launch_bounds__(kThreads) ocsort_kernel(const mot_ocsort_task*
   }
 }
 
-// ---- BoT-SORT appearance features: one lane per track, k-ordered fmaf chains -------------------
-__global__ void __launch_bounds__(kThreads) feat_kernel(const mot_feat_task* __restrict__ tasks) {
+// ---- BoT-SORT appearance features --------------------------------------------------------------------------------------
+// mode 0: feat = src / |src| (BotSTrack ctor, botsort.cpp:38-46); 1: feat = alpha*feat + (1-alpha)*src, renormalised
+// (update_features, botsort.cpp:158-169); 2: feat = src / |src| if |src| > 1e-6 else src (ReIDBackend::normalize_features,
+// reid_backend.cpp:72-88). One lane owns one row for the arithmetic — the squared norm is the k-ordered fmaf chain of the
+// CPU restatement — but the rows travel through an LDS tile in 32-column chunks: the wavefront reads / writes each chunk
+// of its 64 rows with coalesced 128-byte runs (a lane walking its own row in global memory touches a different line per lane).
+constexpr int kFeatChunk = 32;
+__global__ void __launch_bounds__(64) feat_kernel(const mot_feat_task* __restrict__ tasks) {
+  __shared__ float tf[64 * (kFeatChunk + 1)], ts[64 * (kFeatChunk + 1)];
   const mot_feat_task T = tasks[blockIdx.y];
-  const int i = blockIdx.x * kThreads + threadIdx.x;
-  if (i >= T.n) return;
-  float* f = T.feat + static_cast<size_t>(T.slot ? T.slot[i] : i) * T.ldf;
-  const float* s = T.src + static_cast<size_t>(T.sidx ? T.sidx[i] : i) * T.lds;
+  const int lane = threadIdx.x;
+  const int i0 = blockIdx.x * 64;
+  if (i0 >= T.n) return;
+  const int i = i0 + lane;
+  const bool active = i < T.n;
+  const size_t frow = active ? static_cast<size_t>(T.slot ? T.slot[i] : i) * T.ldf : 0;
+  const size_t srow = active ? static_cast<size_t>(T.sidx ? T.sidx[i] : i) * T.lds : 0;
+  const int rows = (T.n - i0 < 64) ? T.n - i0 : 64;
+  const int cl = lane & (kFeatChunk - 1), half = lane / kFeatChunk;  // chunk column / which of two rows per pass
   float nn = 0.0f;
-  for (int k = 0; k < T.d; ++k) {
-    float v = s[k];
-    if (T.mode == 1) v = T.alpha * f[k] + (1.0f - T.alpha) * v;  // botsort.cpp:163
-    f[k] = v;
-    nn = __builtin_fmaf(v, v, nn);
+  for (int pass = 0; pass < 2; ++pass) {  // 0: blend + squared norm (v stored), 1: divide
+    float inv_applies = 0.0f, nrm = 1.0f;
+    if (pass == 1) {
+      nrm = sqrtf(nn);
+      inv_applies = (T.mode == 2) ? ((nrm > 1e-6f) ? 1.0f : 0.0f) : ((nrm > 0.0f) ? 1.0f : 0.0f);
+    }
+    for (int c0 = 0; c0 < T.d; c0 += kFeatChunk) {
+      // rows -> tile: two rows per step, 32 consecutive floats each
+#pragma unroll 8
+      for (int r0 = 0; r0 < rows; r0 += 2) {  // (uniform trip count: the shuffles below read every lane's registers)
+        const int r = r0 + half;
+        const bool rv = r < rows;
+        const size_t fr = __shfl(static_cast<long long>(frow), rv ? r : 0, 64), sr = __shfl(static_cast<long long>(srow), rv ? r : 0, 64);
+        if (rv && c0 + cl < T.d) {
+          if (pass == 1 || T.mode == 1) tf[r * (kFeatChunk + 1) + cl] = T.feat[fr + c0 + cl];
+          if (pass == 0) ts[r * (kFeatChunk + 1) + cl] = T.src[sr + c0 + cl];
+        }
+      }
+      __syncthreads();
+      if (active) {
+        for (int k = 0; k < kFeatChunk && c0 + k < T.d; ++k) {
+          float* e = &tf[lane * (kFeatChunk + 1) + k];
+          if (pass == 0) {
+            float v = ts[lane * (kFeatChunk + 1) + k];
+            if (T.mode == 1) v = T.alpha * (*e) + (1.0f - T.alpha) * v;  // botsort.cpp:163
+            *e = v;
+            nn = __builtin_fmaf(v, v, nn);
+          } else if (inv_applies != 0.0f) {
+            *e = *e / nrm;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int r0 = 0; r0 < rows; r0 += 2) {
+        const int r = r0 + half;
+        const bool rv = r < rows;
+        const size_t fr = __shfl(static_cast<long long>(frow), rv ? r : 0, 64);
+        if (rv && c0 + cl < T.d) T.feat[fr + c0 + cl] = tf[r * (kFeatChunk + 1) + cl];
+      }
+      __syncthreads();
+    }
   }
-  nn = sqrtf(nn);
-  if (nn > 0.0f)
-    for (int k = 0; k < T.d; ++k) f[k] = f[k] / nn;
 }
 
 }  // namespace
@@ -246,8 +292,8 @@ hipError_t launch_ocsort(const mot_ocsort_task* tasks, int ntasks, int max_nd, i
 }
 hipError_t launch_feat(const mot_feat_task* tasks, int ntasks, int max_n, hipStream_t st) {
   if (ntasks <= 0 || max_n <= 0) return hipSuccess;
-  dim3 grid((max_n + kThreads - 1) / kThreads, ntasks);
-  hipLaunchKernelGGL(feat_kernel, grid, dim3(kThreads), 0, st, tasks);
+  dim3 grid((max_n + 63) / 64, ntasks);
+  hipLaunchKernelGGL(feat_kernel, grid, dim3(64), 0, st, tasks);
   return hipGetLastError();
 }
 }  // namespace mot

@@ -37,6 +37,13 @@ class BotSortGpu final : public Staged {
     for (const Trk& t : lost_) { ids->push_back(t.id); slots->push_back(t.slot); }
   }
 
+  const float* feature_slab(int* dim, std::vector<char>* has) const override {
+    *dim = D_;
+    for (const Trk& t : active_) has->push_back(t.has_feat ? 1 : 0);
+    for (const Trk& t : lost_) has->push_back(t.has_feat ? 1 : 0);
+    return feat_;
+  }
+
   bool set_camera_motion(const float* w) override {
     has_warp_ = (w != nullptr);
     if (w) {  // Matrix3f::Identity() with the top two rows replaced (:320-321)

@@ -128,6 +128,27 @@ int motcpp_tracker_dump_states(motcpp_tracker* t, float* out, int cap_floats, in
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 
+// BoT-SORT: smooth features of the live tracks, dump_states order, rows of *dim floats (a track without a feature yet: zeros)
+int motcpp_tracker_dump_features(motcpp_tracker* t, float* out, int cap_floats, int* dim) {
+  try {
+    std::vector<int> ids, slots;
+    t->impl->live_tracks(&ids, &slots);
+    std::vector<char> has;
+    const float* slab = t->impl->feature_slab(dim, &has);
+    const int rows = static_cast<int>(ids.size());
+    if (!slab || *dim <= 0) { *dim = 0; return rows; }
+    if (static_cast<size_t>(rows) * *dim > static_cast<size_t>(cap_floats)) return -rows - 1000000;
+    Core& c = t->impl->core();
+    for (int r = 0; r < rows; ++r) {
+      float* o = out + static_cast<size_t>(r) * *dim;
+      if (has[r]) c.dev().check(mot_memcpy_d2h(c.dev().ctx, o, slab + static_cast<size_t>(slots[r]) * *dim, sizeof(float) * *dim), "feature readback");
+      else std::memset(o, 0, sizeof(float) * *dim);
+    }
+    c.dev().check(mot_ctx_sync(c.dev().ctx), "feature readback");
+    return rows;
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
 static motcpp_batch* batch_create(int kind, const float* params, int nparams, int nstreams, int device, bool private_dev) {
   try {
     auto b = std::make_unique<motcpp_batch>();

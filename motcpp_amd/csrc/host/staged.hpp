@@ -55,6 +55,8 @@ class Staged {
   bool record_laps = true;  // parity hook; switched off for throughput runs
   // parity hook: slots of the live tracks in list order with their ids (states are read back by the caller)
   virtual void live_tracks(std::vector<int>* ids, std::vector<int>* slots) const = 0;
+  // parity hook (BoT-SORT): device address of the smooth-feature slab [slot][dim] (nullptr: none), which tracks have one
+  virtual const float* feature_slab(int* dim, std::vector<char>* has) const { *dim = 0; (void)has; return nullptr; }
 
  protected:
   void record(const Core::Lap& l) {

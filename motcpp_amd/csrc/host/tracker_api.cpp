@@ -356,13 +356,15 @@ Eigen::MatrixXf AssociationFunction::operator()(const Eigen::MatrixXf& a, const 
   return iou_mode(a, b, MOT_COST_IOU, device_, kind_, frame_width_, frame_height_);
 }
 Eigen::MatrixXf embedding_distance(const Eigen::MatrixXf& t, const Eigen::MatrixXf& d, const std::string& metric, int device_index) {
-  if (metric != "cosine") throw std::invalid_argument("Unknown metric: " + metric);
+  // "cosine" (matching.cpp:79-92) on the fp32 matrix cores, "euclidean" (matching.cpp:93-101) on the vector ALUs
+  const int metric_id = (metric == "cosine") ? MOT_EMB_COSINE : ((metric == "euclidean") ? MOT_EMB_EUCLIDEAN : -1);
+  if (metric_id < 0) throw std::invalid_argument("Unknown metric: " + metric);
   const int n = static_cast<int>(t.rows()), m = static_cast<int>(d.rows()), dim = static_cast<int>(t.cols());
   Eigen::MatrixXf out(n, m);
   if (n == 0 || m == 0) return out;
   auto dev = rt::Device::shared(device_index);
   std::vector<float> ra = row_major(t, dim), rb = row_major(d, dim), c(static_cast<size_t>(n) * m);
-  chk(*dev, mot_cosine_cost_host(dev->ctx, ra.data(), n, rb.data(), m, dim, c.data()), "mot_cosine_cost_host");
+  chk(*dev, mot_embedding_cost_host(dev->ctx, metric_id, ra.data(), n, rb.data(), m, dim, c.data()), "mot_embedding_cost_host");
   for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) out(i, j) = c[static_cast<size_t>(i) * m + j];
   return out;
 }

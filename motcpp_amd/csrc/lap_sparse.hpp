@@ -87,7 +87,8 @@ MOT_HD size_t sparse_hot_bytes(int nr, int nc, int ecap) {
   return static_cast<size_t>(nr) * 16 + sparse_vy_bytes(nc) + ((static_cast<size_t>(nr) * 2 + 15) & ~size_t(15)) + 4 * (static_cast<size_t>(nc) + 4) +
          ((static_cast<size_t>(ecap) * 2 + 15) & ~size_t(15)) + static_cast<size_t>(ecap) * 4 + 16 + 64;
 }
-MOT_HD int sparse_default_ecap(int nc) { return 4 * nc + 64; }
+MOT_HD int sparse_default_ecap(int nc) { return 4 * nc + 64; }   // in LDS
+MOT_HD int sparse_global_ecap(int nc) { return 8 * nc + 64; }    // hot state in global scratch: room is not the issue
 MOT_HD size_t sparse_cold_bytes(int nr, int nc) {
   return static_cast<size_t>(nc) * (8 * kSpK + 4) + static_cast<size_t>(sparse_arc_cap(nr, nc)) * 8 + 64;
 }
@@ -98,7 +99,7 @@ MOT_HD size_t lap_task_scratch_bytes(int n, int m) {
   const size_t rn = n > 0 ? n : 0, rm = m > 0 ? m : 0, nm = rn + rm;
   const int in = static_cast<int>(rn), im = static_cast<int>(rm);
   return ((lap_hot_bytes(static_cast<int>(nm)) + 15) & ~size_t(15)) + ((lap_cold_bytes(static_cast<int>(nm)) + 15) & ~size_t(15)) + 4 * (5 * rn + 6 * rm) + 256 +
-         ((sparse_cold_bytes(in, im) + sparse_hot_bytes(in, im, sparse_default_ecap(im)) + 63) & ~size_t(15));
+         ((sparse_cold_bytes(in, im) + sparse_hot_bytes(in, im, sparse_global_ecap(im)) + 63) & ~size_t(15));
 }
 template <class W>
 MOT_HD void sparse_carve_hot(W& w, void* base, int nr, int nc, int ecap) {

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task
   const size_t cold_b = (mot::sparse_cold_bytes(nr, nc) + 15) & ~size_t(15);
   mot::sparse_carve_cold(w, cold, nr, nc);
   if constexpr (HS == mot::kMemLds) mot::sparse_carve_hot(w, smem + kScratch, nr, nc, lds_ecap);
-  else mot::sparse_carve_hot(w, cold + cold_b, nr, nc, mot::sparse_default_ecap(nc));
+  else mot::sparse_carve_hot(w, cold + cold_b, nr, nc, mot::sparse_global_ecap(nc));
 
   int path = 0;
   if (T.mode == MOT_LAP_OCSORT) {

@@ -163,6 +163,20 @@ void orc_cosine_distance(const float* t, int n, const float* dd, int m, int d, f
   if (r.size()) std::memcpy(out, r.a.data(), sizeof(float) * r.size());
 }
 // x: n ints, y: m ints (-1 = unmatched)
+// matching.cpp:93-101 — euclidean metric: |t_i - d_j|, restated as the k-ordered chain of squared differences (Eigen's
+// reduction order is unspecified; same convention as dot_chain); metric 1: the raw inner product t_i . d_j (deepocsort.cpp:404)
+void orc_embedding_distance(int metric, const float* t, int n, const float* dd, int m, int d, float* out) {
+  if (metric == 0) { orc_cosine_distance(t, n, dd, m, d, out); return; }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < m; ++j) {
+      const float* a = t + static_cast<size_t>(i) * d;
+      const float* b = dd + static_cast<size_t>(j) * d;
+      float s = 0.0f;
+      if (metric == 1) s = dot_chain(a, b, d);
+      else { for (int k = 0; k < d; ++k) { const float df = a[k] - b[k]; s = std::fmaf(df, df, s); } s = std::sqrt(s); }
+      out[static_cast<size_t>(i) * m + j] = s;
+    }
+}
 void orc_linear_assignment(const float* cost, int n, int m, float thresh, int* x, int* y) {
   LapResult r = linear_assignment(as_mat(cost, n, m), thresh);
   if (n) std::memcpy(x, r.x.data(), sizeof(int) * n);
@@ -174,6 +188,32 @@ void orc_asso_batch(int kind, const float* a, int n, const float* b, int m, int 
   std::memcpy(out, r.a.data(), sizeof(float) * r.a.size());
 }
 // work counters of the last assignment solved on this thread (instrumentation)
+// Appearance post-processing. mode 0: BotSTrack ctor botsort.cpp:38-46 (set, normalise if norm > 0);
+// 1: update_features botsort.cpp:158-169 (EMA with alpha, normalise if norm > 0); 2: ReIDBackend::normalize_features
+// reid_backend.cpp:72-88 (normalise if norm > 1e-6). norm = sqrt of the k-ordered inner product (orc_math.hpp dot_chain).
+void orc_feat_update(int mode, float alpha, int n, int d, float* feat, const float* src) {
+  for (int i = 0; i < n; ++i) {
+    float* f = feat + static_cast<size_t>(i) * d;
+    const float* s = src + static_cast<size_t>(i) * d;
+    for (int k = 0; k < d; ++k) f[k] = (mode == 1) ? alpha * f[k] + (1.0f - alpha) * s[k] : s[k];
+    const float nn = std::sqrt(dot_chain(f, f, d));
+    const bool go = (mode == 2) ? (nn > 1e-6f) : (nn > 0.0f);
+    if (go) for (int k = 0; k < d; ++k) f[k] /= nn;
+  }
+}
+// smooth features of the live BoT-SORT tracks, dump_states order: returns rows, *d = feature length (0: none yet)
+int orc_tracker_dump_features(void* hv, float* out, int cap_floats, int* d) {
+  auto* h = static_cast<Handle*>(hv);
+  *d = 0;
+  if (h->kind != 3) return 0;
+  const std::vector<std::vector<float>> f = h->bot->dump_features();
+  for (const auto& r : f) if (!r.empty()) *d = static_cast<int>(r.size());
+  if (*d == 0) return static_cast<int>(f.size());
+  if (f.size() * static_cast<size_t>(*d) > static_cast<size_t>(cap_floats)) return -static_cast<int>(f.size());
+  for (size_t i = 0; i < f.size(); ++i)
+    for (int k = 0; k < *d; ++k) out[i * *d + k] = (k < static_cast<int>(f[i].size())) ? f[i][k] : 0.0f;
+  return static_cast<int>(f.size());
+}
 void orc_lap_stats(long* out) {
   const LapStats& s = lap_stats();
   long v[9] = {s.n, s.free_after_colred, s.unique_rows, s.carr_iters, s.paths, s.finds, s.find_records, s.scan_rows, s.scan_ties};

@@ -893,6 +893,12 @@ class BotSort {
     for (const BTrack& t : lost_) push(t);
     return v;
   }
+  std::vector<std::vector<float>> dump_features() const {  // smooth_feat_ of the live tracks, same order (empty: no feature yet)
+    std::vector<std::vector<float>> v;
+    for (const BTrack& t : active_) v.push_back(t.smooth_feat);
+    for (const BTrack& t : lost_) v.push_back(t.smooth_feat);
+    return v;
+  }
 
  private:
   static BTrack make_det(const Det7& d) {  // :23-36

@@ -83,6 +83,14 @@ class Oracle:
         self.lib.orc_cosine_distance(t.ctypes, t.shape[0], d.ctypes, d.shape[0], t.shape[1], out.ctypes)
         return out
 
+    def embedding_distance(self, metric, t, d):
+        """metric 0 cosine, 1 raw dot product, 2 euclidean"""
+        t, d = f32(t), f32(d)
+        out = np.zeros((t.shape[0], d.shape[0]), np.float32)
+        self.lib.orc_embedding_distance.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.lib.orc_embedding_distance(int(metric), t.ctypes, t.shape[0], d.ctypes, d.shape[0], t.shape[1], out.ctypes)
+        return out
+
     def linear_assignment(self, cost, thresh):
         cost = f32(cost)
         n, m = cost.shape
@@ -111,6 +119,13 @@ class Oracle:
                                           C.c_float(thr), C.c_float(vdc), matches.ctypes, umd.ctypes,
                                           C.byref(n_umd), umt.ctypes, C.byref(n_umt), C.byref(used))
         return matches[:2 * k].reshape(-1, 2).copy(), umd[:n_umd.value].copy(), umt[:n_umt.value].copy(), bool(used.value)
+
+    def feat_update(self, mode, feat, src, alpha=0.9):
+        feat, src = f32(feat).copy(), f32(src)
+        n, d = src.shape
+        self.lib.orc_feat_update.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self.lib.orc_feat_update(int(mode), C.c_float(alpha), n, d, feat.ctypes, src.ctypes)
+        return feat
 
     def kf_initiate(self, kind, meas):
         meas = f32(meas).reshape(-1, 4)
@@ -201,6 +216,14 @@ class OracleTracker:
             if r >= 0:
                 return buf[:r * w.value].reshape(r, w.value).copy() if r else np.zeros((0, 0), np.float32)
             buf = np.zeros((-r + 8) * max(w.value, 1), np.float32)
+
+    def dump_features(self):
+        d = C.c_int()
+        buf = np.zeros(1 << 22, np.float32)
+        self.orc.lib.orc_tracker_dump_features.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        r = self.orc.lib.orc_tracker_dump_features(self.h, buf.ctypes, buf.size, C.byref(d))
+        assert r >= 0
+        return buf[:r * d.value].reshape(r, d.value).copy() if d.value else np.zeros((r, 0), np.float32)
 
 
 _cached = None

@@ -357,3 +357,45 @@ def test_lap_fast_path_and_exact_path_agree_with_the_oracle(ctx, orc, n, m):
     assert np.array_equal(xg, xo) and np.array_equal(yg, yo)
     st = ctx.lap_fast_stats()
     assert st["fast"] == 0 and st["not_unique"] == 1, st
+
+
+@pytest.mark.parametrize("n,d", [(1, 8), (77, 64), (512, 256), (130, 100)])
+def test_appearance_post_processing_bit_exact(ctx, orc, n, d):
+    """mot_feat_update against the oracle's restatement of BotSTrack's feature handling (botsort.cpp:38-46 set +
+    normalise, :158-169 EMA 0.9 / 0.1 + renormalise) and of ReIDBackend::normalize_features (reid_backend.cpp:72-88, rows of
+    norm <= 1e-6 left alone). Same k-ordered inner product on both sides: bit-identical."""
+    r = np.random.default_rng(n * 7 + d)
+    src = r.standard_normal((n, d)).astype(np.float32)
+    if n > 3:
+        src[1] = 0.0            # a zero row is not normalised in any mode
+        src[2] *= 1e-9          # norm below the ReID rule's 1e-6 but > 0
+    old = r.standard_normal((n, d)).astype(np.float32)
+    old /= np.maximum(np.linalg.norm(old, axis=1, keepdims=True), 1e-12).astype(np.float32)
+    for mode in (0, 1, 2):
+        g = ctx.feat_update(mode, old, src)
+        o = orc.feat_update(mode, old, src)
+        assert np.array_equal(g, o), (mode, np.abs(g - o).max())
+    if n > 3:
+        assert np.array_equal(ctx.feat_update(2, old, src)[2], src[2])  # untouched by the ReID rule
+        assert abs(np.linalg.norm(ctx.feat_update(0, old, src)[2]) - 1.0) < 1e-5  # but normalised by BotSTrack's
+    # two EMA steps in a row stay unit-norm and follow the oracle
+    g1, o1 = ctx.feat_update(1, old, src), orc.feat_update(1, old, src)
+    src2 = r.standard_normal((n, d)).astype(np.float32)
+    assert np.array_equal(ctx.feat_update(1, g1, src2), orc.feat_update(1, o1, src2))
+
+
+@pytest.mark.parametrize("n,m,d", [(3, 5, 7), (64, 64, 32), (200, 130, 100), (1024, 512, 256)])
+def test_embedding_metrics(ctx, orc, n, m, d):
+    """utils::embedding_distance: cosine (matching.cpp:79-92), euclidean (:93-101) and the raw dot product DeepOC-SORT uses
+    (deepocsort.cpp:404), all k-ordered fp32 chains -> bit-identical to the restatement; plus the float64 value within 1e-4."""
+    r = np.random.default_rng(n + m + d)
+    a = r.standard_normal((n, d)).astype(np.float32)
+    b = r.standard_normal((m, d)).astype(np.float32)
+    for metric in (0, 1, 2):
+        g, o = ctx.embedding_cost(metric, a, b), orc.embedding_distance(metric, a, b)
+        assert np.array_equal(g, o), (metric, np.abs(g - o).max())
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    eu = np.sqrt(((a64[:, None, :] - b64[None, :, :]) ** 2).sum(-1)) if n * m * d < 5e7 else None
+    if eu is not None:
+        assert np.allclose(ctx.embedding_cost(2, a, b), eu, rtol=1e-4)
+    assert np.allclose(ctx.embedding_cost(1, a, b), a64 @ b64.T, rtol=1e-4, atol=1e-4)

@@ -32,6 +32,12 @@ def check_frame(f, out_g, out_o, trk_g, trk_o, exact=True):
     if exact:
         assert np.array_equal(out_g, out_o), f
         assert np.array_equal(sg, so), (f, np.abs(sg - so).max())
+    if hasattr(trk_o, "dump_features") and trk_o.kind == orclib.BOTSORT and f % 5 == 4:
+        # the stored appearance state (botsort.hpp smooth_feat_: normalised at birth, EMA 0.9/0.1 + renormalise per update)
+        fg, fo = trk_g.dump_features(), trk_o.dump_features()
+        assert fg.shape[0] == fo.shape[0], f
+        if fo.shape[1]:
+            assert fg.shape == fo.shape and np.array_equal(fg, fo), (f, np.abs(fg - fo).max())
 
 
 def run_stream(kind_g, kind_o, P, M, frames, emb_dim=0, params=None, seed=1234, exact=True):

@@ -128,6 +128,7 @@ def main():
                 embs[f, s] = e
     # detection payload resident in HBM as SoA [F, S, 6, M] before the timed region
     dev_dets = torch.from_numpy(np.ascontiguousarray(host.transpose(0, 1, 3, 2))).cuda(local)
+    dev_embs = torch.from_numpy(embs).cuda(local) if D else None  # [F, S, M, D] row-major, resident like the detections
     torch.cuda.synchronize()
     frame_bytes = S * 6 * M * 4
 
@@ -185,8 +186,9 @@ def main():
                             out=out_all[s0:s1], out_counts=cnt_all[s0:s1])
             return
         else:
-            o, c = batches[p].step(host[f, s0:s1], embs=embs[f, s0:s1] if D else None, cap=cap,
-                                   resident_ptr=dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4)
+            o, c = batches[p].step(host[f, s0:s1], embs=None, cap=cap,
+                                   resident_ptr=dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4,
+                                   resident_embs=(dev_embs.data_ptr() + (f * S + s0) * M * D * 4, D) if D else None)
         out_all[s0:s1] = o[:, :cap]
         cnt_all[s0:s1] = c
 
@@ -422,7 +424,7 @@ def main():
                    "streams_per_gpu": S, "frames_per_step": world * S, "settle_frames": Z, "host_threads": PIPE if on_device else threads, "sub_batches": PIPE,
                    "lifecycle": "device (mot_bt_* / mot_sort_*: a fixed launch sequence per frame, no host decisions)" if on_device else "host stage machines",
                    "parallelism": f"{world} GPU(s) x {S} independent streams, lockstep stages",
-                   "inputs": "detections resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},
+                   "inputs": "detections (and embeddings) resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         "kernels": kernels,
         "lap_fast_path": fast_stats,

@@ -55,6 +55,9 @@ int motcpp_batch_step(motcpp_batch* b, const float* dets, const int* counts, int
  * per-stage index lists crosses PCIe inside the call. The host copy is still needed for the lifecycle decisions. */
 int motcpp_batch_step_resident(motcpp_batch* b, const float* dets, const int* counts, int max_n, const void* d_dets_soa,
                                const float* embs, int d, float* out, int* out_counts, int cap);
+/* same, with the embeddings resident too: d_embs = device [S][max_n][d] row-major (BoT-SORT); no payload crosses PCIe */
+int motcpp_batch_step_resident_embs(motcpp_batch* b, const float* dets, const int* counts, int max_n, const void* d_dets_soa,
+                                    const void* d_embs, int d, float* out, int* out_counts, int cap);
 int motcpp_batch_set_threads(motcpp_batch* b, int threads);
 /* Pins the CALLING thread's worker team (set_threads many) to consecutive CPUs of the process's allowed set, starting at
  * its first_cpu-th one; call it from the thread that will call motcpp_batch_step. Sub-batches stepped from different

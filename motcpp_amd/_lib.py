@@ -383,9 +383,10 @@ class Batch:
         return {"frames": a[0], "flushes": a[1], "launches": a[2], "ms_begin": h[0], "ms_flush": h[1], "ms_advance": h[2],
                 "ms_sync_wait": h[3]}
 
-    def step(self, dets, counts=None, embs=None, cap=None, resident_ptr=None):
+    def step(self, dets, counts=None, embs=None, cap=None, resident_ptr=None, resident_embs=None):
         """dets [S, N, 6] (counts[s] valid rows each); returns (out [S, cap, 8], out_counts [S]).
-        resident_ptr: device address of the same detections as SoA [S, 6, N] already in HBM (no payload upload)."""
+        resident_ptr: device address of the same detections as SoA [S, 6, N] already in HBM (no payload upload);
+        resident_embs: (device address of [S, N, D] row-major embeddings, D) — then `embs` is not read."""
         dets = f32(dets)
         S, N = dets.shape[0], dets.shape[1]
         assert S == self.S
@@ -397,7 +398,14 @@ class Batch:
         if embs is not None:
             embs = f32(embs)
             e, d = _p(embs), embs.shape[2]
-        if resident_ptr:
+        if resident_ptr and resident_embs:
+            H = host()
+            H.motcpp_batch_step_resident_embs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                          C.c_void_p, C.c_void_p, C.c_int]
+            r = H.motcpp_batch_step_resident_embs(self.h, _p(dets), _p(counts), N, C.c_void_p(int(resident_ptr)),
+                                                  C.c_void_p(int(resident_embs[0])), int(resident_embs[1]), _p(self._out), _p(self._cnt),
+                                                  self._out.shape[1])
+        elif resident_ptr:
             r = host().motcpp_batch_step_resident(self.h, _p(dets), _p(counts), N, C.c_void_p(int(resident_ptr)), e, d,
                                                   _p(self._out), _p(self._cnt), self._out.shape[1])
         else:

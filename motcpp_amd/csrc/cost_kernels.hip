@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(64) feat_kernel(const mot_feat_task* __restric
     for (int c0 = 0; c0 < T.d; c0 += kFeatChunk) {
       // rows -> tile: two rows per step, 32 consecutive floats each
 #pragma unroll 8
-      for (int r0 = 0; r0 < rows; r0 += 2) {  // (uniform trip count: the shuffles below read every lane's registers)
+      for (int r0 = 0; r0 < 64; r0 += 2) {  // (fixed trip count: unrollable, and the shuffles below read every lane's registers)
         const int r = r0 + half;
         const bool rv = r < rows;
         const size_t fr = __shfl(static_cast<long long>(frow), rv ? r : 0, 64), sr = __shfl(static_cast<long long>(srow), rv ? r : 0, 64);
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(64) feat_kernel(const mot_feat_task* __restric
       }
       __syncthreads();
 #pragma unroll 8
-      for (int r0 = 0; r0 < rows; r0 += 2) {
+      for (int r0 = 0; r0 < 64; r0 += 2) {
         const int r = r0 + half;
         const bool rv = r < rows;
         const size_t fr = __shfl(static_cast<long long>(frow), rv ? r : 0, 64);

@@ -82,17 +82,20 @@ class BotSortGpu final : public Staged {
     core_.reserve(static_cast<int>(first_.size()) + 8, 8);
     dets_ = core_.upload_dets(in.dets, in.n, in.ld, MOT_DET_XYWH, in.d_dets, in.d_ld);
     // appearance: raw rows for every detection, L2-normalised copies for the association (:38-46)
-    have_emb_ = with_reid_ && in.embs != nullptr && in.emb_dim > 0;
+    have_emb_ = with_reid_ && (in.embs != nullptr || in.d_embs != nullptr) && in.emb_dim > 0;
     if (have_emb_) {
       if (D_ == 0) D_ = in.emb_dim;
       if (D_ != in.emb_dim) throw Error("BotSort: embedding dimension changed between frames");
       ensure_feat_slab();
-      Span<float> raw = core_.dev().up->alloc<float>(static_cast<size_t>(in.n) * D_);
-      if (in.embs_rowmajor) std::memcpy(raw.h, in.embs, sizeof(float) * static_cast<size_t>(in.n) * D_);
-      else
-        for (int i = 0; i < in.n; ++i)
-          for (int k = 0; k < D_; ++k) raw.h[static_cast<size_t>(i) * D_ + k] = in.embs[static_cast<size_t>(k) * in.emb_ld + i];
-      emb_raw_ = raw.d;
+      if (in.d_embs) emb_raw_ = in.d_embs;  // already in HBM
+      else {
+        Span<float> raw = core_.dev().up->alloc<float>(static_cast<size_t>(in.n) * D_);
+        if (in.embs_rowmajor) std::memcpy(raw.h, in.embs, sizeof(float) * static_cast<size_t>(in.n) * D_);
+        else
+          for (int i = 0; i < in.n; ++i)
+            for (int k = 0; k < D_; ++k) raw.h[static_cast<size_t>(i) * D_ + k] = in.embs[static_cast<size_t>(k) * in.emb_ld + i];
+        emb_raw_ = raw.d;
+      }
       emb_norm_ = core_.dev().tmp->alloc<float>(static_cast<size_t>(in.n) * D_).d;
       mot_feat_task t{};
       t.n = in.n; t.d = D_; t.feat = emb_norm_; t.ldf = D_; t.src = emb_raw_; t.lds = D_; t.mode = 0; t.alpha = 0.9f;

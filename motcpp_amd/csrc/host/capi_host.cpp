@@ -207,7 +207,7 @@ int motcpp_batch_host_ms(motcpp_batch* b, double* out4) {
   return 0;
 }
 static int batch_step_impl(motcpp_batch* b, const float* dets, const int* counts, int max_n, const float* d_dets,
-                           const float* embs, int d, float* out, int* out_counts, int cap) {
+                           const float* embs, int d, float* out, int* out_counts, int cap, const float* d_embs = nullptr) {
   try {
     const int S = static_cast<int>(b->trk.size());
     std::vector<FrameIn> in(S);
@@ -220,6 +220,7 @@ static int batch_step_impl(motcpp_batch* b, const float* dets, const int* counts
       to_colmajor(dets + static_cast<size_t>(s) * max_n * 6, counts[s], b->colmajor[s]);
       in[s] = frame_in(b->colmajor[s], counts[s], embs ? embs + static_cast<size_t>(s) * max_n * d : nullptr, d);
       if (d_dets) { in[s].d_dets = d_dets + static_cast<size_t>(s) * 6 * max_n; in[s].d_ld = max_n; }
+      if (d_embs && d > 0) { in[s].d_embs = d_embs + static_cast<size_t>(s) * max_n * d; in[s].emb_dim = d; in[s].embs_rowmajor = true; }
       st[s] = b->trk[s]->impl.get();
     });
     run_frame(*b->dev, st.data(), in.data(), S, b->team.get());
@@ -241,6 +242,11 @@ int motcpp_batch_step(motcpp_batch* b, const float* dets, const int* counts, int
 int motcpp_batch_step_resident(motcpp_batch* b, const float* dets, const int* counts, int max_n, const void* d_dets_soa,
                                const float* embs, int d, float* out, int* out_counts, int cap) {
   return batch_step_impl(b, dets, counts, max_n, static_cast<const float*>(d_dets_soa), embs, d, out, out_counts, cap);
+}
+int motcpp_batch_step_resident_embs(motcpp_batch* b, const float* dets, const int* counts, int max_n, const void* d_dets_soa,
+                                    const void* d_embs, int d, float* out, int* out_counts, int cap) {
+  return batch_step_impl(b, dets, counts, max_n, static_cast<const float*>(d_dets_soa), nullptr, d, out, out_counts, cap,
+                         static_cast<const float*>(d_embs));
 }
 int motcpp_profile(int device, int enable) {
   try {

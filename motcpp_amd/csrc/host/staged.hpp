@@ -17,6 +17,7 @@ struct FrameIn {
   int img_w = 0, img_h = 0;
   const float* d_dets = nullptr;  // optional: the same detections already resident in HBM, SoA [6][d_ld]
   int d_ld = 0;
+  const float* d_embs = nullptr;  // optional: the embeddings already resident in HBM, row-major n x emb_dim (nothing is uploaded)
 };
 
 // Set of small non-negative ints (track ids) with O(1) clear: a generation stamp per id, no hashing, no allocation

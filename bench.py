@@ -365,6 +365,10 @@ def main():
     kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["launches"],
                    "GB/s": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 2) if v["ms"] > 0 else 0.0}
                for k, v in stats.items() if v["launches"]}
+    for k, v in stats.items():  # the one contraction on the path: fp32 MFMA rate against the 157.3 TFLOP/s peak
+        if v.get("flops", 0) > 0 and v["ms"] > 0:
+            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            kernels[k].update({"TFLOP/s": round(tf, 2), "mfma_f32_frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
     gpu_busy_ms = stats["frame_all_kernels"]["ms"] if on_device else sum(v["ms"] for v in stats.values())
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference path) on one core, stream 0 ----

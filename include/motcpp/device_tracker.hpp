@@ -21,6 +21,13 @@ class DeviceTracker : public BaseTracker {
   void reset() override;
   rt::Staged* staged() const { return impl_.get(); }
   const std::shared_ptr<rt::Device>& device() const { return dev_; }
+  // the checks and bookkeeping update() does before any track is touched (check_inputs, the asso_func error, detection
+  // format, frame counter); false = this frame is skipped. StreamBatch calls it per stream. Throws what update() throws.
+  bool prepare_update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs);
+  // Threading: like the reference, a tracker instance is not re-entrant. Different tracker instances MAY be updated from
+  // different host threads; those created on the same GPU share that GPU's runtime (arenas, stream) and their frames are
+  // serialised by a mutex inside it — for concurrency across streams use StreamBatch / DeviceLifecycleBatch, or one process
+  // per GPU.
 
  protected:
   DeviceTracker(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class,

@@ -20,7 +20,9 @@ Staged* make(std::shared_ptr<Device> dev, int kind, const float* p, int np) {
     case 0: return make_sort(dev, P(p, np, 0, 0.3f), (int)P(p, np, 1, 1), (int)P(p, np, 2, 50), (int)P(p, np, 3, 3), P(p, np, 4, 0.3f));
     case 1: return make_bytetrack(dev, P(p, np, 0, 0.1f), P(p, np, 1, 0.45f), P(p, np, 2, 0.8f), (int)P(p, np, 3, 25),
                                   (int)P(p, np, 4, 30), (int)P(p, np, 5, 30), (int)P(p, np, 6, 50));
-    case 2: return make_ocsort(dev, P(p, np, 0, 0.2f), (int)P(p, np, 1, 30), (int)P(p, np, 2, 50), (int)P(p, np, 3, 3), P(p, np, 4, 0.3f),
+    case 2:
+      if ((int)P(p, np, 11, 0.f) < 0 || (int)P(p, np, 11, 0.f) > 5) throw Error("OC-SORT: association measure (param 11) must be a mot_assoc value in [0, 5]");
+      return make_ocsort(dev, P(p, np, 0, 0.2f), (int)P(p, np, 1, 30), (int)P(p, np, 2, 50), (int)P(p, np, 3, 3), P(p, np, 4, 0.3f),
                                P(p, np, 5, 0.1f), (int)P(p, np, 6, 3), P(p, np, 7, 0.2f), P(p, np, 8, 0.f) != 0.f, P(p, np, 9, 0.01f),
                                P(p, np, 10, 0.0001f), (int)P(p, np, 11, 0.f));
     case 3: return make_botsort(dev, P(p, np, 0, 0.5f), P(p, np, 1, 0.1f), P(p, np, 2, 0.6f), (int)P(p, np, 3, 30), P(p, np, 4, 0.8f),
@@ -210,6 +212,8 @@ static int batch_step_impl(motcpp_batch* b, const float* dets, const int* counts
                            const float* embs, int d, float* out, int* out_counts, int cap, const float* d_embs = nullptr) {
   try {
     const int S = static_cast<int>(b->trk.size());
+    for (int s = 0; s < S; ++s)
+      if (counts[s] < 0 || counts[s] > max_n) { g_err = "motcpp_batch_step: counts[s] must be in [0, max_n]"; return -1; }
     std::vector<FrameIn> in(S);
     std::vector<Staged*> st(S);
     auto for_streams = [&](const std::function<void(int)>& fn) {

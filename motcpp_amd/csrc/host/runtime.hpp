@@ -99,6 +99,10 @@ class Device {
 
   mot_ctx* ctx = nullptr;
   int index = 0;
+  // One frame (run_frame) or one utils:: call at a time per Device: its arenas, task lists and event pool are per-frame state.
+  // Trackers that share the process-wide Device of a GPU may be updated from different host threads (one tracker per camera
+  // thread, as the reference allows); their frames then serialise here. A batch created with a private Device has its own.
+  std::mutex frame_mu;
   std::unique_ptr<Arena> up, down, tmp;
   std::unique_ptr<Arena> zdown;  // like `down`, but the device side is zeroed before the stage's kernels run (atomic counters)
 

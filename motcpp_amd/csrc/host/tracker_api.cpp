@@ -57,6 +57,7 @@ int asso_kind(const std::string& name) {
 void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, Team* team) {
   using clk = std::chrono::steady_clock;
   auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  std::lock_guard<std::mutex> frame_lock(dev.frame_mu);  // (trackers sharing a Device updated from several threads)
   dev.begin_frame();
   std::vector<char> done(count, 0);
   std::string err;
@@ -133,16 +134,28 @@ Eigen::MatrixXf to_matrix(const std::vector<float>& rows) {
 }
 }  // namespace
 
-Eigen::MatrixXf DeviceTracker::update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) {
+// What the reference's update() does before it touches a track (checks, format and association setup, frame counter):
+// shared by the single-tracker call and by StreamBatch, so that a batched tracker rejects exactly what it rejects alone.
+// false: the frame is skipped (BoT-SORT's empty-frame early return, botsort.cpp:267-269).
+bool DeviceTracker::prepare_update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) {
   if (!asso_error_.empty()) throw std::invalid_argument(asso_error_);
   if (validate_inputs_) check_inputs(dets, img, skip_empty_ ? Eigen::MatrixXf() : embs);
+  // botsort.cpp reads embs.row(first_indices[i]) under an index guard; here the rows are consumed wholesale on the device
+  if (embs.rows() > 0 && embs.cols() > 0 && embs.rows() != dets.rows())
+    throw std::invalid_argument("motcpp_amd: embs must have one row per detection (" + std::to_string(embs.rows()) + " vs " +
+                                std::to_string(dets.rows()) + ")");
   if (skip_empty_ && dets.rows() == 0) {
     impl_->set_camera_motion(nullptr);  // the reference returns before its CMC step: this frame's warp is dropped
-    return Eigen::MatrixXf(0, 8);
+    return false;
   }
   setup_detection_format(dets);
   setup_association_function(img);
   ++frame_count_;
+  return true;
+}
+
+Eigen::MatrixXf DeviceTracker::update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) {
+  if (!prepare_update(dets, img, embs)) return Eigen::MatrixXf(0, 8);
   rt::FrameIn in = make_input(dets, img, embs);
   rt::Staged* s = impl_.get();
   rt::run_frame(*dev_, &s, &in, 1);
@@ -156,16 +169,20 @@ StreamBatch::StreamBatch(std::vector<DeviceTracker*> trackers) : trackers_(std::
 std::vector<Eigen::MatrixXf> StreamBatch::update(const std::vector<Eigen::MatrixXf>& dets, const cv::Mat& img,
                                                  const std::vector<Eigen::MatrixXf>& embs) {
   if (dets.size() != trackers_.size()) throw std::invalid_argument("StreamBatch: one detection matrix per stream");
-  std::vector<rt::FrameIn> in(trackers_.size());
-  std::vector<rt::Staged*> st(trackers_.size());
+  std::vector<rt::FrameIn> in;
+  std::vector<rt::Staged*> st;
+  std::vector<int> who;
   static const Eigen::MatrixXf kNone;
-  for (size_t i = 0; i < trackers_.size(); ++i) {
-    in[i] = make_input(dets[i], img, i < embs.size() ? embs[i] : kNone);
-    st[i] = trackers_[i]->staged();
+  for (size_t i = 0; i < trackers_.size(); ++i) {  // every stream goes through its tracker's own checks and bookkeeping
+    const Eigen::MatrixXf& e = i < embs.size() ? embs[i] : kNone;
+    if (!trackers_[i]->prepare_update(dets[i], img, e)) continue;  // skipped frame: empty table
+    in.push_back(make_input(dets[i], img, e));
+    st.push_back(trackers_[i]->staged());
+    who.push_back(static_cast<int>(i));
   }
-  if (!trackers_.empty()) rt::run_frame(*trackers_[0]->device(), st.data(), in.data(), static_cast<int>(st.size()));
-  std::vector<Eigen::MatrixXf> out;
-  for (rt::Staged* s : st) out.push_back(to_matrix(s->rows()));
+  if (!st.empty()) rt::run_frame(*trackers_[0]->device(), st.data(), in.data(), static_cast<int>(st.size()));
+  std::vector<Eigen::MatrixXf> out(trackers_.size(), Eigen::MatrixXf(0, 8));
+  for (size_t k = 0; k < st.size(); ++k) out[who[k]] = to_matrix(st[k]->rows());
   return out;
 }
 
@@ -314,6 +331,7 @@ LinearAssignmentResult linear_assignment(const Eigen::MatrixXf& cost, float thre
     return r;
   }
   auto dev = rt::Device::shared(device_index);
+  std::lock_guard<std::mutex> dev_lock(dev->frame_mu);  // the context's stream and scratch are shared with the trackers on this GPU
   std::vector<float> c = row_major(cost, m);
   std::vector<int> x(n), y(m);
   chk(*dev, mot_lap_solve_host(dev->ctx, c.data(), n, m, thresh, MOT_LAP_PLAIN, nullptr, 0.f, x.data(), y.data(), nullptr), "mot_lap_solve_host");
@@ -330,6 +348,7 @@ static Eigen::MatrixXf iou_mode(const Eigen::MatrixXf& a, const Eigen::MatrixXf&
   Eigen::MatrixXf out(n, m);
   if (n == 0 || m == 0) { out.setZero(); return out; }  // Zero(N, M), iou.hpp:68-70,127-129
   auto dev = rt::Device::shared(device_index);
+  std::lock_guard<std::mutex> dev_lock(dev->frame_mu);  // the context's stream and scratch are shared with the trackers on this GPU
   std::vector<float> ra = row_major(a, 4), rb = row_major(b, 4), c(static_cast<size_t>(n) * m);
   chk(*dev, mot_assoc_cost_host(dev->ctx, ra.data(), n, rb.data(), m, nullptr, mode, assoc, fw, fh, c.data()), "mot_assoc_cost_host");
   for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) out(i, j) = c[static_cast<size_t>(i) * m + j];
@@ -363,6 +382,7 @@ Eigen::MatrixXf embedding_distance(const Eigen::MatrixXf& t, const Eigen::Matrix
   Eigen::MatrixXf out(n, m);
   if (n == 0 || m == 0) return out;
   auto dev = rt::Device::shared(device_index);
+  std::lock_guard<std::mutex> dev_lock(dev->frame_mu);  // the context's stream and scratch are shared with the trackers on this GPU
   std::vector<float> ra = row_major(t, dim), rb = row_major(d, dim), c(static_cast<size_t>(n) * m);
   chk(*dev, mot_embedding_cost_host(dev->ctx, metric_id, ra.data(), n, rb.data(), m, dim, c.data()), "mot_embedding_cost_host");
   for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) out(i, j) = c[static_cast<size_t>(i) * m + j];

@@ -74,6 +74,10 @@ def test_north_star_shape():
     run([(1000, 500), (1000, 500)], 24, cap=2048, maxd=512, check_states_every=8)
 
 
+def test_c5_per_gpu_shape():
+    run([(1000, 512), (1000, 512)], 16, cap=2048, maxd=512, check_states_every=8)
+
+
 def test_reset_restarts_ids():
     orc = orclib.load()
     dev = L.DeviceByteTrack(2, 128, 32)

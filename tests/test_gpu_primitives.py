@@ -60,11 +60,12 @@ def test_cosine_mfma_matches_fmaf_chain(ctx, orc, n, m, d):
     assert np.array_equal(got, ref), f"max abs diff {np.abs(got - ref).max()}"
 
 
-@pytest.mark.parametrize("nd,nt", [(9, 5), (64, 64), (200, 333), (512, 1024)])
+@pytest.mark.parametrize("nd,nt", [(9, 5), (64, 64), (200, 333), (512, 1024), (2048, 4096)])  # the last: BASELINE configs[3]
 def test_ocsort_cost(ctx, orc, nd, nt):
     r = np.random.default_rng(nd + nt)
-    trks = boxes(r, nt, (800, 600))
-    dets = np.concatenate([boxes(r, nd, (800, 600)), r.uniform(0.3, 1, (nd, 1)).astype(np.float32)], 1)
+    world = (800, 600) if nd * nt < 1e6 else (1920, 1080)
+    trks = boxes(r, nt, world)
+    dets = np.concatenate([boxes(r, nd, world), r.uniform(0.3, 1, (nd, 1)).astype(np.float32)], 1)
     k = min(nd, nt) // 2
     dets[:k, :4] = trks[:k] + r.normal(0, 3, (k, 4)).astype(np.float32)
     vel = r.standard_normal((nt, 2)).astype(np.float32)

@@ -117,6 +117,18 @@ def test_ocsort_stream():
     run_stream("ocsort", orclib.OCSORT, 300, 150, 60, exact=False)
 
 
+def test_ocsort_c4_shape():
+    # BASELINE configs[3]: 4096 objects, 2048 detections per frame. From the fourth frame on the reference's OC-SORT carries
+    # duplicated tracks (Q4: a match rejected by the IoU post-filter is pushed to the unmatched lists twice, ocsort.cpp:709-734),
+    # i.e. exact ties: those associations are the exact lapjv emulation's, the earlier ones the fast path's.
+    run_stream("ocsort", orclib.OCSORT, 4096, 2048, 6, exact=False)
+
+
+def test_bytetrack_c5_shape():
+    # the per-GPU shape of BASELINE configs[4]: 1000 objects x 512 detections
+    run_stream("bytetrack", orclib.BYTETRACK, 1000, 512, 12)
+
+
 def test_ocsort_use_byte():
     run_stream("ocsort", orclib.OCSORT, 120, 80, 40, params=[0.5, 30, 50, 3, 0.3, 0.1, 3, 0.2, 1], exact=False)
 

@@ -6,5 +6,6 @@
 #include "trackers/bytetrack.hpp"
 #include "trackers/ocsort.hpp"
 #include "trackers/botsort.hpp"
+#include "trackers/deepocsort.hpp"
 #include "utils/matching.hpp"
 #include "utils/iou.hpp"

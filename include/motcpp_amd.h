@@ -185,6 +185,22 @@ typedef struct mot_ocsort_task {
 int mot_ocsort_cost(mot_ctx* ctx, const mot_ocsort_task* tasks, int ntasks, int max_nd, int max_nt);
 int mot_ocsort_cost_ex(mot_ctx* ctx, const mot_ocsort_task* tasks, int ntasks, int max_nd, int max_nt, int flags);
 
+/* ---- DeepOC-SORT: the embedding term of the association cost (src/trackers/deepocsort.cpp:294-346, 419-441) ---------- */
+/* emb: nd x nt similarities dets_embs . trk_embs^T (mot_embedding_cost, MOT_EMB_DOT); iou, cost: what mot_ocsort_cost wrote
+ * (cost = -(iou + angle)). Entries with iou <= 0 count as 0; with aw_off == 0 row i is weighted by
+ * rw_i = 1 - max(second_i / max_i - aw_param, 0) / (1 - aw_param) from the two largest entries of the row (0 if the largest
+ * is 0, 1 if the row has fewer than two entries), columns likewise, final = ((w * rw_i) * cw_j) * emb; with aw_off it is
+ * emb * w. cost becomes -((iou + angle) + final). rw / cw: scratch [nd] / [nt]. */
+typedef struct mot_deep_task {
+  int32_t nd, nt;
+  const float* emb; int32_t lde;
+  const float* iou; int32_t ldi;
+  float* cost; int32_t ldc;
+  float* rw; float* cw;
+  float w, aw_param; int32_t aw_off;
+} mot_deep_task;
+int mot_deepoc_cost(mot_ctx* ctx, const mot_deep_task* tasks, int ntasks, int max_nd, int max_nt);
+
 /* ---- appearance ---------------------------------------------------------------------- */
 typedef struct mot_cos_task {
   int32_t n, m, d;
@@ -204,9 +220,13 @@ typedef struct mot_feat_task {
   int32_t n, d;
   float* feat; int32_t ldf; const int32_t* slot;          /* destination rows feat[slot[i]*ldf ..]   */
   const float* src; int32_t lds; const int32_t* sidx;     /* raw detection feature rows              */
+  const float* alpha_i;                                   /* optional [n]: per-item EMA weight (DeepOC-SORT's dets_alpha,
+                                                             deepocsort.cpp:646-648); NULL: `alpha` for every item */
   int32_t mode;                                           /* 0: set = src/|src|, 1: EMA then renormalise,
                                                              2: src/|src| only where |src| > 1e-6 (ReIDBackend::normalize_features,
-                                                                src/appearance/reid_backend.cpp:72-88) */
+                                                                src/appearance/reid_backend.cpp:72-88; DeepOCSortKalmanBoxTracker
+                                                                ctor deepocsort.cpp:73-79), 3: EMA then normalise where the norm
+                                                                exceeds 1e-6 (update_emb, deepocsort.cpp:132-150) */
   float alpha;                                            /* EMA weight of the old feature (0.9)     */
 } mot_feat_task;
 int mot_feat_update(mot_ctx* ctx, const mot_feat_task* tasks, int ntasks, int max_n);

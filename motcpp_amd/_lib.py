@@ -197,7 +197,7 @@ class Context:
 
 # ---- tracker handles (libmotcpp.so: C++17 host library over the C ABI) ------------------------------------
 SORT, BYTETRACK, OCSORT, BOTSORT = 0, 1, 2, 3
-KIND = {"sort": SORT, "bytetrack": BYTETRACK, "ocsort": OCSORT, "botsort": BOTSORT}
+KIND = {"sort": SORT, "bytetrack": BYTETRACK, "ocsort": OCSORT, "botsort": BOTSORT, "deepocsort": 4}
 _host = None
 
 

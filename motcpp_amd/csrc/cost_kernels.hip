@@ -226,13 +226,14 @@ __global__ void __launch_bounds__(64) feat_kernel(const mot_feat_task* __restric
   const size_t frow = active ? static_cast<size_t>(T.slot ? T.slot[i] : i) * T.ldf : 0;
   const size_t srow = active ? static_cast<size_t>(T.sidx ? T.sidx[i] : i) * T.lds : 0;
   const int rows = (T.n - i0 < 64) ? T.n - i0 : 64;
+  const float alpha = (active && T.alpha_i) ? T.alpha_i[i] : T.alpha;
   const int cl = lane & (kFeatChunk - 1), half = lane / kFeatChunk;  // chunk column / which of two rows per pass
   float nn = 0.0f;
   for (int pass = 0; pass < 2; ++pass) {  // 0: blend + squared norm (v stored), 1: divide
     float inv_applies = 0.0f, nrm = 1.0f;
     if (pass == 1) {
       nrm = sqrtf(nn);
-      inv_applies = (T.mode == 2) ? ((nrm > 1e-6f) ? 1.0f : 0.0f) : ((nrm > 0.0f) ? 1.0f : 0.0f);
+      inv_applies = (T.mode >= 2) ? ((nrm > 1e-6f) ? 1.0f : 0.0f) : ((nrm > 0.0f) ? 1.0f : 0.0f);
     }
     for (int c0 = 0; c0 < T.d; c0 += kFeatChunk) {
       // rows -> tile: two rows per step, 32 consecutive floats each
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(64) feat_kernel(const mot_feat_task* __restric
         const bool rv = r < rows;
         const size_t fr = __shfl(static_cast<long long>(frow), rv ? r : 0, 64), sr = __shfl(static_cast<long long>(srow), rv ? r : 0, 64);
         if (rv && c0 + cl < T.d) {
-          if (pass == 1 || T.mode == 1) tf[r * (kFeatChunk + 1) + cl] = T.feat[fr + c0 + cl];
+          if (pass == 1 || T.mode == 1 || T.mode == 3) tf[r * (kFeatChunk + 1) + cl] = T.feat[fr + c0 + cl];
           if (pass == 0) ts[r * (kFeatChunk + 1) + cl] = T.src[sr + c0 + cl];
         }
       }
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(64) feat_kernel(const mot_feat_task* __restric
           float* e = &tf[lane * (kFeatChunk + 1) + k];
           if (pass == 0) {
             float v = ts[lane * (kFeatChunk + 1) + k];
-            if (T.mode == 1) v = T.alpha * (*e) + (1.0f - T.alpha) * v;  // botsort.cpp:163
+            if (T.mode == 1 || T.mode == 3) v = alpha * (*e) + (1.0f - alpha) * v;  // botsort.cpp:163 / deepocsort.cpp:143
             *e = v;
             nn = __builtin_fmaf(v, v, nn);
           } else if (inv_applies != 0.0f) {
@@ -273,9 +274,68 @@ __global__ void __launch_bounds__(64) feat_kernel(const mot_feat_task* __restric
   }
 }
 
+// ---- DeepOC-SORT's embedding term (deepocsort.cpp:294-346, 419-441) ----------------------------------------------------
+// aw_stats: one wavefront per row (blockIdx.x < nd) or column of emb' = (iou <= 0 ? 0 : emb): its two largest VALUES (a value
+// that occurs twice is both) -> the weight of that row / column.
+__device__ __forceinline__ void top2_merge_f(float& m1, float& m2, float o1, float o2) {
+  const float lo = (o1 < m1) ? o1 : m1;   // the smaller of the two maxima
+  const float hi = (o1 < m1) ? m1 : o1;
+  const float s = (o2 < m2) ? m2 : o2;    // the larger of the two seconds
+  m1 = hi;
+  m2 = (s < lo) ? lo : s;
+}
+__global__ void __launch_bounds__(64) deep_stats_kernel(const mot_deep_task* __restrict__ tasks) {
+  const mot_deep_task T = tasks[blockIdx.y];
+  if (T.aw_off) return;
+  const int q = blockIdx.x, lane = threadIdx.x;
+  if (q >= T.nd + T.nt) return;
+  const bool row = q < T.nd;
+  const int idx = row ? q : q - T.nd, len = row ? T.nt : T.nd;
+  const float ninf = -__builtin_huge_valf();
+  float m1 = ninf, m2 = ninf;
+  for (int k = lane; k < len; k += 64) {
+    const size_t oe = row ? static_cast<size_t>(idx) * T.lde + k : static_cast<size_t>(k) * T.lde + idx;
+    const size_t oi = row ? static_cast<size_t>(idx) * T.ldi + k : static_cast<size_t>(k) * T.ldi + idx;
+    const float v = (T.iou[oi] <= 0.0f) ? 0.0f : T.emb[oe];
+    if (v > m1) { m2 = m1; m1 = v; } else if (v > m2) m2 = v;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float o1 = __shfl_xor(m1, d, 64), o2 = __shfl_xor(m2, d, 64);
+    top2_merge_f(m1, m2, o1, o2);
+  }
+  if (lane == 0) {
+    float wgt = 1.0f;  // fewer than two entries: the reference skips the row / column
+    if (len >= 2) wgt = (m1 == 0.0f) ? 0.0f : 1.0f - mot::smax((m2 / m1) - T.aw_param, 0.0f) / (1.0f - T.aw_param);
+    (row ? T.rw : T.cw)[idx] = wgt;
+  }
+}
+__global__ void __launch_bounds__(256) deep_combine_kernel(const mot_deep_task* __restrict__ tasks) {
+  const mot_deep_task T = tasks[blockIdx.z];
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (i >= T.nd || j >= T.nt) return;
+  const float e = (T.iou[static_cast<size_t>(i) * T.ldi + j] <= 0.0f) ? 0.0f : T.emb[static_cast<size_t>(i) * T.lde + j];
+  float fin;
+  if (T.aw_off) fin = e * T.w;
+  else {
+    // w_emb = Constant(w); row(i) *= rw (or setZero); col(j) *= cw (or setZero); then w_emb .* emb
+    const float wr = (T.nt >= 2) ? T.w * T.rw[i] : T.w;
+    const float wc = (T.nd >= 2) ? wr * T.cw[j] : wr;
+    fin = wc * e;
+  }
+  float* c = T.cost + static_cast<size_t>(i) * T.ldc + j;
+  *c = *c - fin;  // -(iou + angle) - fin == -((iou + angle) + fin): negation and subtraction round alike
+}
+
 }  // namespace
 
 namespace mot {
+hipError_t launch_deep(const mot_deep_task* tasks, int ntasks, int max_nd, int max_nt, hipStream_t st) {
+  if (ntasks <= 0 || max_nd <= 0 || max_nt <= 0) return hipSuccess;
+  hipLaunchKernelGGL(deep_stats_kernel, dim3(max_nd + max_nt, ntasks), dim3(64), 0, st, tasks);
+  hipLaunchKernelGGL(deep_combine_kernel, dim3((max_nt + 255) / 256, max_nd, ntasks), dim3(256), 0, st, tasks);
+  return hipGetLastError();
+}
 hipError_t launch_iou(const mot_iou_task* tasks, int ntasks, int max_n, int max_m, bool iou_only, hipStream_t st) {
   if (ntasks <= 0 || max_n <= 0 || max_m <= 0) return hipSuccess;
   dim3 grid((max_m + kTile - 1) / kTile, (max_n + kTile - 1) / kTile, ntasks);

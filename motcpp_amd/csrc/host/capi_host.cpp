@@ -28,6 +28,12 @@ Staged* make(std::shared_ptr<Device> dev, int kind, const float* p, int np) {
     case 3: return make_botsort(dev, P(p, np, 0, 0.5f), P(p, np, 1, 0.1f), P(p, np, 2, 0.6f), (int)P(p, np, 3, 30), P(p, np, 4, 0.8f),
                                 P(p, np, 5, 0.5f), P(p, np, 6, 0.25f), (int)P(p, np, 7, 30), P(p, np, 8, 0.f) != 0.f,
                                 P(p, np, 9, 1.f) != 0.f, (int)P(p, np, 10, 30), (int)P(p, np, 11, 50));
+    case 4:  // det_thresh, max_age, max_obs, min_hits, iou_thr, delta_t, inertia, w_emb, alpha_fixed, aw_param, emb_off, cmc_off, aw_off, q_xy, q_s, asso
+      if ((int)P(p, np, 15, 0.f) < 0 || (int)P(p, np, 15, 0.f) > 5) throw Error("DeepOC-SORT: association measure (param 15) must be a mot_assoc value in [0, 5]");
+      return make_deepocsort(dev, P(p, np, 0, 0.3f), (int)P(p, np, 1, 30), (int)P(p, np, 2, 50), (int)P(p, np, 3, 3), P(p, np, 4, 0.3f),
+                             (int)P(p, np, 5, 3), P(p, np, 6, 0.2f), P(p, np, 7, 0.5f), P(p, np, 8, 0.95f), P(p, np, 9, 0.5f),
+                             P(p, np, 10, 0.f) != 0.f, P(p, np, 11, 0.f) != 0.f, P(p, np, 12, 0.f) != 0.f, P(p, np, 13, 0.01f),
+                             P(p, np, 14, 0.0001f), (int)P(p, np, 15, 0.f));
   }
   throw Error("unknown tracker kind");
 }

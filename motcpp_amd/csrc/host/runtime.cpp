@@ -160,11 +160,11 @@ void Device::begin_frame() {
 bool Device::TaskLists::empty() const {
   for (int k = 0; k < 3; ++k)
     if (!det[k].empty() || !kf_init[k].empty() || !kf_upd[k].empty() || !kf_pred[k].empty() || !kf_box[k].empty() || !kf_warp[k].empty() || !kf_predw[k].empty()) return false;
-  return feat_set.empty() && feat_ema.empty() && cos.empty() && iou.empty() && oc.empty() && lap.empty();
+  return feat_set.empty() && feat_ema.empty() && cos.empty() && dot.empty() && deep.empty() && iou.empty() && oc.empty() && lap.empty();
 }
 void Device::TaskLists::clear() {
   for (int k = 0; k < 3; ++k) { det[k].clear(); kf_init[k].clear(); kf_upd[k].clear(); kf_pred[k].clear(); kf_box[k].clear(); kf_warp[k].clear(); kf_predw[k].clear(); }
-  feat_set.clear(); feat_ema.clear(); cos.clear(); iou.clear(); oc.clear(); lap.clear();
+  feat_set.clear(); feat_ema.clear(); cos.clear(); dot.clear(); deep.clear(); iou.clear(); oc.clear(); lap.clear();
   lap_geom = false;
   lap_assoc = false;
   lap_appearance = false;
@@ -181,7 +181,7 @@ void Device::TaskLists::append(TaskLists& o) {
     move_back(det[k], o.det[k]); move_back(kf_init[k], o.kf_init[k]); move_back(kf_upd[k], o.kf_upd[k]);
     move_back(kf_pred[k], o.kf_pred[k]); move_back(kf_box[k], o.kf_box[k]); move_back(kf_warp[k], o.kf_warp[k]); move_back(kf_predw[k], o.kf_predw[k]);
   }
-  move_back(feat_set, o.feat_set); move_back(feat_ema, o.feat_ema); move_back(cos, o.cos); move_back(iou, o.iou);
+  move_back(feat_set, o.feat_set); move_back(feat_ema, o.feat_ema); move_back(cos, o.cos); move_back(dot, o.dot); move_back(deep, o.deep); move_back(iou, o.iou);
   move_back(oc, o.oc); move_back(lap, o.lap);
   lap_geom = lap_geom || o.lap_geom;
   o.lap_geom = false;
@@ -262,6 +262,8 @@ void Device::flush() {
   const mot_feat_task* d_fset = stage_tasks(*up, feat_set);
   const mot_feat_task* d_fema = stage_tasks(*up, feat_ema);
   const mot_cos_task* d_cos = stage_tasks(*up, cos);
+  const mot_cos_task* d_dot = stage_tasks(*up, L.dot);
+  const mot_deep_task* d_deep = stage_tasks(*up, L.deep);
   const mot_iou_task* d_iou = stage_tasks(*up, iou);
   const mot_ocsort_task* d_oc = stage_tasks(*up, oc);
   const mot_lap_task* d_lap = stage_tasks(*up, lap);
@@ -325,6 +327,14 @@ void Device::flush() {
     });
   }
   {
+    auto& dot = L.dot;
+    double b = 0, fl = 0;
+    for (const mot_cos_task& t : dot) { b += 4.0 * ((double)(t.n + t.m) * t.d + (double)t.n * t.m); fl += 2.0 * t.n * (double)t.m * t.d; }
+    run(F_COSINE, dot.size(), b, fl, [&] {
+      check(mot_embedding_cost(ctx, MOT_EMB_DOT, d_dot, (int)dot.size(), maxn(dot, [](const mot_cos_task& t) { return t.n; }), maxn(dot, [](const mot_cos_task& t) { return t.m; })), "mot_embedding_cost");
+    });
+  }
+  {
     double b = 0;
     for (const mot_iou_task& t : iou) b += 16.0 * (t.n + t.m) + (t.cost ? 4.0 * t.n * (double)t.m : 0.0) + (t.emb ? 4.0 * t.n * (double)t.m : 0.0);
     run(F_IOU, iou.size(), b, 0, [&] { check(mot_iou_cost_ex(ctx, d_iou, (int)iou.size(), maxn(iou, [](const mot_iou_task& t) { return t.n; }), maxn(iou, [](const mot_iou_task& t) { return t.m; }), maxn(iou, [](const mot_iou_task& t) { return t.assoc; }) == 0 ? MOT_COST_F_IOU_ONLY : 0), "mot_iou_cost"); });
@@ -333,6 +343,15 @@ void Device::flush() {
     double b = 0;
     for (const mot_ocsort_task& t : oc) b += 20.0 * t.nd + 44.0 * t.nt + 8.0 * t.nd * (double)t.nt;
     run(F_OCSORT, oc.size(), b, 0, [&] { check(mot_ocsort_cost_ex(ctx, d_oc, (int)oc.size(), maxn(oc, [](const mot_ocsort_task& t) { return t.nd; }), maxn(oc, [](const mot_ocsort_task& t) { return t.nt; }), maxn(oc, [](const mot_ocsort_task& t) { return t.assoc; }) == 0 ? MOT_COST_F_IOU_ONLY : 0), "mot_ocsort_cost"); });
+  }
+  {
+    auto& deep = L.deep;
+    double b = 0;
+    for (const mot_deep_task& t : deep) b += 16.0 * t.nd * (double)t.nt;
+    run(F_OCSORT, deep.size(), b, 0, [&] {
+      check(mot_deepoc_cost(ctx, d_deep, (int)deep.size(), maxn(deep, [](const mot_deep_task& t) { return t.nd; }), maxn(deep, [](const mot_deep_task& t) { return t.nt; })), "mot_deepoc_cost");
+      ++counters.launches;
+    });
   }
   {
     double b = 0;

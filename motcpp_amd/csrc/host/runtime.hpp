@@ -113,6 +113,8 @@ class Device {
     std::vector<mot_kf_task> kf_init[3], kf_upd[3], kf_pred[3], kf_box[3], kf_warp[3], kf_predw[3];
     std::vector<mot_feat_task> feat_set, feat_ema;
     std::vector<mot_cos_task> cos;
+    std::vector<mot_cos_task> dot;    // raw inner products (DeepOC-SORT's embedding similarity)
+    std::vector<mot_deep_task> deep;  // ... and its weighting into the association cost (after the OC-SORT cost, before the LAP)
     std::vector<mot_iou_task> iou;
     std::vector<mot_ocsort_task> oc;
     std::vector<mot_lap_task> lap;

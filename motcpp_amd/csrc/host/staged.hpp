@@ -93,6 +93,9 @@ Staged* make_ocsort(std::shared_ptr<Device>, float det_thresh, int max_age, int 
 // "iou" | "hmiou" | "giou" | "ciou" | "diou" | "centroid" -> mot_assoc, or -1 (AssociationFunction::get_asso_func, iou.hpp:385-408;
 // the oriented-box modes are out of scope)
 int asso_kind(const std::string& name);
+Staged* make_deepocsort(std::shared_ptr<Device>, float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold,
+                        int delta_t, float inertia, float w_emb, float alpha_fixed, float aw_param, bool emb_off, bool cmc_off,
+                        bool aw_off, float q_xy, float q_s, int asso);
 Staged* make_botsort(std::shared_ptr<Device>, float track_high, float track_low, float new_track, int track_buffer,
                      float match_thresh, float proximity, float appearance, int frame_rate, bool fuse_first, bool with_reid,
                      int max_age, int max_obs);

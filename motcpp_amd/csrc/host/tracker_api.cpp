@@ -227,6 +227,26 @@ BotSort::BotSort(const std::string& reid_weights, bool /*use_half*/, bool /*use_
   adopt(rt::make_botsort(dev_, track_high_thresh, track_low_thresh, new_track_thresh, track_buffer, match_thresh,
                          proximity_thresh, appearance_thresh, frame_rate, fuse_first_associate, with_reid, max_age_, max_obs_));
 }
+DeepOCSort::DeepOCSort(const std::string& /*reid_weights*/, bool /*use_half*/, bool /*use_gpu*/, float det_thresh, int max_age, int max_obs,
+                       int min_hits, float iou_threshold, bool per_class, int nr_classes, const std::string& asso_func, bool is_obb,
+                       int delta_t, float inertia, float w_association_emb, float alpha_fixed_emb, float aw_param, bool embedding_off,
+                       bool cmc_off, bool aw_off, float Q_xy_scaling, float Q_s_scaling, int device_index)
+    : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
+  int asso = rt::asso_kind(asso_func);
+  if (asso < 0) {  // the association function is built inside update() (deepocsort.cpp:762): an unknown name throws there
+    asso_error_ = (asso_func == "iou_obb" || asso_func == "centroid_obb")
+                      ? "motcpp_amd: oriented-box association mode '" + asso_func + "' is out of scope"
+                      : "Invalid association mode: " + asso_func;
+    asso = 0;
+  }
+  adopt(rt::make_deepocsort(dev_, det_thresh_, max_age_, max_obs_, min_hits_, iou_threshold_, delta_t, inertia, w_association_emb,
+                            alpha_fixed_emb, aw_param, embedding_off, cmc_off, aw_off, Q_xy_scaling, Q_s_scaling, asso));
+}
+void DeepOCSort::set_camera_motion(const Eigen::MatrixXf& warp) {
+  if (warp.rows() != 2 || warp.cols() != 3) throw std::invalid_argument("DeepOCSort::set_camera_motion: the warp must be 2 x 3");
+  const float w[6] = {warp(0, 0), warp(0, 1), warp(0, 2), warp(1, 0), warp(1, 1), warp(1, 2)};
+  staged()->set_camera_motion(w);
+}
 void BotSort::set_camera_motion(const Eigen::MatrixXf& warp) {
   if (warp.rows() != 2 || warp.cols() != 3) throw std::invalid_argument("BotSort::set_camera_motion: the warp must be 2 x 3");
   const float w[6] = {warp(0, 0), warp(0, 1), warp(0, 2), warp(1, 0), warp(1, 1), warp(1, 2)};

@@ -16,11 +16,13 @@ struct Handle {
   std::unique_ptr<ByteTrack> byte;
   std::unique_ptr<OCSort> oc;
   std::unique_ptr<BotSort> bot;
+  std::unique_ptr<DeepOCSort> deep;
   const std::vector<LapResult>* laps() const {
     switch (kind) {
       case 1: return &byte->laps;
       case 2: return &oc->laps;
       case 3: return &bot->laps;
+      case 4: return &deep->laps;
       default: return nullptr;
     }
   }
@@ -68,6 +70,13 @@ void* orc_tracker_create(int kind, const float* p, int np) {
                                          P(p, np, 6, 0.25f), (int)P(p, np, 7, 30), P(p, np, 8, 0.f) != 0.f,
                                          P(p, np, 9, 1.f) != 0.f, (int)P(p, np, 10, 30), (int)P(p, np, 11, 50));
       break;
+    case 4:  // det_thresh, max_age, max_obs, min_hits, iou_thr, delta_t, inertia, w_emb, alpha_fixed, aw_param, emb_off, cmc_off, aw_off, q_xy, q_s, asso, w, h
+      h->deep = std::make_unique<DeepOCSort>(P(p, np, 0, 0.3f), (int)P(p, np, 1, 30), (int)P(p, np, 2, 50), (int)P(p, np, 3, 3),
+                                             P(p, np, 4, 0.3f), (int)P(p, np, 5, 3), P(p, np, 6, 0.2f), P(p, np, 7, 0.5f),
+                                             P(p, np, 8, 0.95f), P(p, np, 9, 0.5f), P(p, np, 10, 0.f) != 0.f, P(p, np, 11, 0.f) != 0.f,
+                                             P(p, np, 12, 0.f) != 0.f, P(p, np, 13, 0.01f), P(p, np, 14, 0.0001f));
+      h->deep->set_asso((int)P(p, np, 15, 0.f), (int)P(p, np, 16, 1920.f), (int)P(p, np, 17, 1080.f));
+      break;
     default:
       delete h;
       return nullptr;
@@ -81,11 +90,13 @@ void orc_tracker_reset(void* hv) {
   if (h->byte) h->byte->reset();
   if (h->oc) h->oc->reset();
   if (h->bot) h->bot->reset();
+  if (h->deep) h->deep->reset();
 }
 
 // BoT-SORT only: the 2x3 camera-motion warp of the next update() (returns 0, or -1 for the other trackers)
 int orc_tracker_set_warp(void* hv, const float* w2x3) {
   auto* h = static_cast<Handle*>(hv);
+  if (h->deep) { h->deep->set_warp(w2x3); return 0; }
   if (!h->bot) return -1;
   h->bot->set_warp(w2x3);
   return 0;
@@ -105,6 +116,7 @@ int orc_tracker_update(void* hv, const float* dets, int n, const float* embs, in
     case 1: t = h->byte->update(dets, n); break;
     case 2: t = h->oc->update(dets, n); break;
     case 3: t = h->bot->update(dets, n, embs, d); break;
+    case 4: t = h->deep->update(dets, n, embs, d); break;
   }
   const int rows = static_cast<int>(t.size());
   if (rows > cap) return -rows;
@@ -137,6 +149,7 @@ int orc_tracker_dump_states(void* hv, float* out, int cap_floats, int* w) {
     case 1: s = h->byte->dump_states(); break;
     case 2: s = h->oc->dump_states(); break;
     case 3: s = h->bot->dump_states(); break;
+    case 4: s = h->deep->dump_states(); break;
   }
   *w = s.empty() ? 0 : static_cast<int>(s[0].size());
   size_t need = s.size() * static_cast<size_t>(*w);
@@ -205,8 +218,8 @@ void orc_feat_update(int mode, float alpha, int n, int d, float* feat, const flo
 int orc_tracker_dump_features(void* hv, float* out, int cap_floats, int* d) {
   auto* h = static_cast<Handle*>(hv);
   *d = 0;
-  if (h->kind != 3) return 0;
-  const std::vector<std::vector<float>> f = h->bot->dump_features();
+  if (h->kind != 3 && h->kind != 4) return 0;
+  const std::vector<std::vector<float>> f = (h->kind == 3) ? h->bot->dump_features() : h->deep->dump_features();
   for (const auto& r : f) if (!r.empty()) *d = static_cast<int>(r.size());
   if (*d == 0) return static_cast<int>(f.size());
   if (f.size() * static_cast<size_t>(*d) > static_cast<size_t>(cap_floats)) return -static_cast<int>(f.size());

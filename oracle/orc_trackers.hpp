@@ -449,6 +449,7 @@ class OCSort {
     Obs5 last_obs{{-1, -1, -1, -1, -1}};
     std::map<int, Obs5> observations;  // age -> box (+conf)
     float vel[2] = {0.f, 0.f};         // (dy, dx)
+    std::vector<float> emb;            // DeepOC-SORT only (DeepOCSortKalmanBoxTracker::emb_)
   };
 
   OutTable update(const float* dets, int n) {  // ocsort.cpp:285-606
@@ -642,7 +643,7 @@ class OCSort {
   // rounded fp32 result obtained through double precision, which any platform can reproduce.
   static float acos_f32(float c) { return static_cast<float>(std::acos(static_cast<double>(c))); }
 
- private:
+ protected:
   Track spawn(const Det7& d) {  // ctor :53-87
     Track t;
     t.id = ++next_id_;
@@ -705,6 +706,270 @@ class OCSort {
   float q_xy_, q_s_;
   int frame_count_ = 0, next_id_ = 0;
   std::vector<Track> trk_;
+};
+
+// =======================================================================================
+// DeepOC-SORT — deepocsort.cpp. OC-SORT's lifecycle plus: an embedding per track (normalised when its
+// norm exceeds 1e-6, :73-79; EMA with a per-detection alpha, :132-150), the similarity dets_embs * trk_embs^T (:746-757)
+// zeroed where the IoU is not positive and weighted adaptively (compute_aw_max_metric :294-346) or by a constant, added
+// to IoU + direction in the association cost (:437-481); detections kept are conf > det_thresh only (no BYTE stage);
+// in the LAP branch every unmatched detection / track ends up in the unmatched lists TWICE (:456-503: the assignment's
+// unmatched lists are appended, then the sweep appends everything that is not in a match again), so the OCR stage sees
+// duplicated rows / columns and each unmatched detection spawns two tracks; camera motion (caller-supplied 2x3 warp, :633-643)
+// also moves last_observation and the observations inside the delta_t window (:189-236). ReID inference and the image
+// registration are outside the path: embeddings and warps are passed in. Ids are per instance, from 1 (:27-30).
+// =======================================================================================
+class DeepOCSort : public OCSort {
+ public:
+  explicit DeepOCSort(float det_thresh = 0.3f, int max_age = 30, int max_obs = 50, int min_hits = 3, float iou_threshold = 0.3f,
+                      int delta_t = 3, float inertia = 0.2f, float w_emb = 0.5f, float alpha_fixed = 0.95f, float aw_param = 0.5f,
+                      bool embedding_off = false, bool cmc_off = false, bool aw_off = false, float q_xy = 0.01f, float q_s = 0.0001f)
+      : OCSort(det_thresh, max_age, max_obs, min_hits, iou_threshold, 0.1f, delta_t, inertia, false, q_xy, q_s),
+        w_emb_(w_emb), alpha_fixed_(alpha_fixed), aw_param_(aw_param), emb_off_(embedding_off), cmc_off_(cmc_off), aw_off_(aw_off) {}
+  void set_warp(const float w2x3[6]) { for (int i = 0; i < 6; ++i) warp_[i] = w2x3[i]; has_warp_ = true; }
+  void reset() { OCSort::reset(); next_id_ = 0; has_warp_ = false; }
+
+  // compute_aw_max_metric :294-346 (emb: nd x nt, already zeroed where IoU <= 0)
+  static Mat aw_max_metric(const Mat& emb, float w, float bottom) {
+    Mat wm(emb.r, emb.c, w);
+    auto top2 = [](std::vector<float> v, float* mx, float* second) {  // descending sort of the values
+      std::sort(v.begin(), v.end(), [](float a, float b) { return a > b; });
+      *mx = v[0]; *second = v[1];
+    };
+    for (int i = 0; i < emb.r; ++i) {
+      if (emb.c < 2) continue;
+      std::vector<float> v(emb.c);
+      for (int j = 0; j < emb.c; ++j) v[j] = emb(i, j);
+      float mx, sc;
+      top2(v, &mx, &sc);
+      if (mx == 0.0f) { for (int j = 0; j < emb.c; ++j) wm(i, j) = 0.0f; }
+      else {
+        const float rw = 1.0f - std::max((sc / mx) - bottom, 0.0f) / (1.0f - bottom);
+        for (int j = 0; j < emb.c; ++j) wm(i, j) *= rw;
+      }
+    }
+    for (int j = 0; j < emb.c; ++j) {
+      if (emb.r < 2) continue;
+      std::vector<float> v(emb.r);
+      for (int i = 0; i < emb.r; ++i) v[i] = emb(i, j);
+      float mx, sc;
+      top2(v, &mx, &sc);
+      if (mx == 0.0f) { for (int i = 0; i < emb.r; ++i) wm(i, j) = 0.0f; }
+      else {
+        const float cw = 1.0f - std::max((sc / mx) - bottom, 0.0f) / (1.0f - bottom);
+        for (int i = 0; i < emb.r; ++i) wm(i, j) *= cw;
+      }
+    }
+    Mat out(emb.r, emb.c);
+    for (int i = 0; i < emb.r; ++i) for (int j = 0; j < emb.c; ++j) out(i, j) = wm(i, j) * emb(i, j);
+    return out;
+  }
+
+  OutTable update(const float* dets, int n, const float* embs, int d) {  // :589-945
+    std::vector<Det7> all = wrap_dets(dets, n);
+    ++frame_count_;
+    laps.clear();
+    std::vector<Det7> high;
+    for (const Det7& dd : all) if (dd.conf > p_.det_thresh) high.push_back(dd);
+    const int nd = static_cast<int>(high.size());
+    // dets_embs :619-633 — ones when the embedding is off (or nothing survived), the supplied rows otherwise
+    int D = 1;
+    std::vector<std::vector<float>> de(nd);
+    if (emb_off_ || nd == 0 || embs == nullptr || d <= 0) for (auto& r : de) r.assign(1, 1.0f);
+    else { D = d; for (int i = 0; i < nd; ++i) de[i].assign(embs + static_cast<size_t>(high[i].ind) * d, embs + static_cast<size_t>(high[i].ind + 1) * d); }
+    const bool warp_now = has_warp_;
+    has_warp_ = false;
+    if (!cmc_off_ && warp_now) {  // :633-643
+      const float m[2][2] = {{warp_[0], warp_[1]}, {warp_[3], warp_[4]}}, t[2] = {warp_[2], warp_[5]};
+      for (Track& tr : trk_) affine(tr, m, t);
+    }
+    std::vector<float> alpha(nd);
+    for (int i = 0; i < nd; ++i) {  // :646-648
+      const float trust = (high[i].conf - p_.det_thresh) / (1.0f - p_.det_thresh);
+      alpha[i] = alpha_fixed_ + (1.0f - alpha_fixed_) * (1.0f - trust);
+    }
+    auto spawn_all = [&]() { for (int i = 0; i < nd; ++i) trk_.push_back(spawn_deep(high[i], de[i])); };
+    size_t nt = trk_.size();
+    if (nt == 0) { spawn_all(); return {}; }  // :652-664
+    std::vector<std::array<float, 5>> trks(nt);
+    std::vector<int> to_del;
+    for (size_t t = 0; t < nt; ++t) {
+      Box pos = predict(trk_[t]);
+      trks[t] = {pos[0], pos[1], pos[2], pos[3], 0.0f};
+      if (std::isnan(pos[0]) || std::isnan(pos[1]) || std::isnan(pos[2]) || std::isnan(pos[3])) to_del.push_back(static_cast<int>(t));
+    }
+    for (auto it = to_del.rbegin(); it != to_del.rend(); ++it) { trk_.erase(trk_.begin() + *it); --nt; }
+    trks.resize(nt);  // the FIRST nt rows (:690), like OC-SORT
+    if (nt == 0) { spawn_all(); return {}; }  // :692-705
+    Mat vel(static_cast<int>(nt), 2), kobs(static_cast<int>(nt), 5);
+    for (size_t t = 0; t < nt; ++t) {
+      vel(t, 0) = trk_[t].vel[0]; vel(t, 1) = trk_[t].vel[1];
+      Obs5 k = k_previous_obs(trk_[t], delta_t_);
+      for (int c = 0; c < 5; ++c) kobs(t, c) = k.v[c];
+    }
+    // track embedding matrix :722-741 (the surviving tracks' embeddings in order; dimension of the first one)
+    int TD = trk_[0].emb.empty() ? 0 : static_cast<int>(trk_[0].emb.size());
+    Mat emb;  // nd x nt similarity, empty when off (:744-760)
+    if (!emb_off_ && nd > 0) {
+      emb = Mat(nd, static_cast<int>(nt), 0.0f);
+      const int tdim = TD > 0 ? TD : D;
+      if (D == tdim)
+        for (int i = 0; i < nd; ++i)
+          for (size_t t = 0; t < nt; ++t) {
+            const std::vector<float>& te = trk_[t].emb;
+            std::vector<float> row(tdim, TD > 0 ? 0.0f : 1.0f);
+            if (TD > 0 && static_cast<int>(te.size()) == TD) row = te;
+            emb(i, static_cast<int>(t)) = dot_chain(de[i].data(), row.data(), tdim);
+          }
+    }
+    Mat dm(nd, 5), tm(static_cast<int>(nt), 5);
+    for (int i = 0; i < nd; ++i) { dm(i,0)=high[i].x1; dm(i,1)=high[i].y1; dm(i,2)=high[i].x2; dm(i,3)=high[i].y2; dm(i,4)=high[i].conf; }
+    for (int i = 0; i < tm.r; ++i) for (int c = 0; c < 5; ++c) tm(i, c) = trks[i][c];
+    Assoc as = associate_deep(dm, tm, asso_thr_, vel, kobs, inertia_, emb);
+    for (const auto& m : as.matches) { apply(trk_[m[1]], high[m[0]]); update_emb(trk_[m[1]], de[m[0]], alpha[m[0]]); }
+    if (!as.um_dets.empty() && !as.um_trks.empty()) {  // OCR :796-872 over the (duplicated) lists
+      Mat ld(static_cast<int>(as.um_dets.size()), 4), lt(static_cast<int>(as.um_trks.size()), 4);
+      for (int i = 0; i < ld.r; ++i) { const Det7& q = high[as.um_dets[i]]; ld(i,0)=q.x1; ld(i,1)=q.y1; ld(i,2)=q.x2; ld(i,3)=q.y2; }
+      for (int i = 0; i < lt.r; ++i) for (int c = 0; c < 4; ++c) lt(i, c) = trk_[as.um_trks[i]].last_obs.v[c];
+      Mat iou = asso(ld, lt);
+      float mx = -std::numeric_limits<float>::infinity();
+      for (float v : iou.a) mx = std::max(mx, v);
+      if (mx > asso_thr_) {
+        Mat cost = iou; for (float& v : cost.a) v = -v;
+        LapResult r = linear_assignment(cost, -asso_thr_);
+        laps.push_back(r);
+        std::unordered_set<int> rmd, rmt;
+        for (const auto& m : r.matches) {
+          int di = as.um_dets[m[0]], ti = as.um_trks[m[1]];
+          if (iou(m[0], m[1]) < asso_thr_) continue;
+          apply(trk_[ti], high[di]);
+          update_emb(trk_[ti], de[di], alpha[di]);
+          rmd.insert(di); rmt.insert(ti);
+        }
+        std::vector<int> kd, kt;
+        for (int q : as.um_dets) if (!rmd.count(q)) kd.push_back(q);
+        for (int q : as.um_trks) if (!rmt.count(q)) kt.push_back(q);
+        as.um_dets = kd; as.um_trks = kt;
+      }
+    }
+    for (int t : as.um_trks) trk_[t].det_ind = 0;  // update(None) :875-877 (twice for a duplicated entry: same effect)
+    for (int q : as.um_dets) trk_.push_back(spawn_deep(high[q], de[q]));  // :880-890, once per list entry
+    OutTable out;
+    for (int i = static_cast<int>(trk_.size()) - 1; i >= 0; --i) {  // :896-920
+      Track& t = trk_[i];
+      Box b;
+      float ls = t.last_obs.v[0] + t.last_obs.v[1] + t.last_obs.v[2] + t.last_obs.v[3];
+      if (ls < 0) b = state_box(t);
+      else b = {t.last_obs.v[0], t.last_obs.v[1], t.last_obs.v[2], t.last_obs.v[3]};
+      if (t.tsu < 1 && (t.hit_streak >= p_.min_hits || frame_count_ <= p_.min_hits))
+        out.push_back({b[0], b[1], b[2], b[3], static_cast<float>(t.id), t.conf, static_cast<float>(t.cls), static_cast<float>(t.det_ind)});
+      if (t.tsu > p_.max_age) trk_.erase(trk_.begin() + i);
+    }
+    return out;
+  }
+  std::vector<std::vector<float>> dump_features() const {
+    std::vector<std::vector<float>> v;
+    for (const Track& t : trk_) v.push_back(t.emb);
+    return v;
+  }
+
+  // deepocsort_assoc::associate :351-507. emb: nd x nt similarity or empty.
+  Assoc associate_deep(const Mat& dets, const Mat& trks, float thr, const Mat& vel, const Mat& prev, float vdc, const Mat& emb_in) {
+    Assoc R;
+    const int nd = dets.r, ntk = trks.r;
+    if (ntk == 0) { for (int i = 0; i < nd; ++i) R.um_dets.push_back(i); return R; }
+    Mat angle(nd, ntk);
+    for (int i = 0; i < ntk; ++i)
+      for (int j = 0; j < nd; ++j) {
+        float cx1 = (dets(j, 0) + dets(j, 2)) / 2.0f, cy1 = (dets(j, 1) + dets(j, 3)) / 2.0f;
+        float cx2 = (prev(i, 0) + prev(i, 2)) / 2.0f, cy2 = (prev(i, 1) + prev(i, 3)) / 2.0f;
+        float dx = cx1 - cx2, dy = cy1 - cy2;
+        float norm = std::sqrt(dx * dx + dy * dy) + 1e-6f;
+        float Y = dy / norm, X = dx / norm;
+        float c = vel(i, 1) * X + vel(i, 0) * Y;
+        c = std::min(std::max(c, -1.0f), 1.0f);
+        const float PI = 3.14159265358979323846f;
+        float da = (PI / 2.0f - std::fabs(acos_f32(c))) / PI;
+        float valid = (prev(i, 4) >= 0.0f) ? 1.0f : 0.0f;
+        angle(j, i) = ((valid * da) * vdc) * dets(j, 4);
+      }
+    Mat iou = asso(dets, trks);
+    last_iou = iou;
+    Mat fe(nd, ntk, 0.0f);
+    if (emb_in.r > 0 && emb_in.c > 0) {  // :419-436
+      fe = emb_in;
+      for (int i = 0; i < nd; ++i) for (int j = 0; j < ntk; ++j) if (iou(i, j) <= 0.0f) fe(i, j) = 0.0f;
+      if (!aw_off_) fe = aw_max_metric(fe, w_emb_, aw_param_);
+      else for (float& v : fe.a) v *= w_emb_;
+    }
+    if (nd > 0) {
+      int max_row = 0, max_col = 0;
+      std::vector<int> colsum(ntk, 0);
+      for (int i = 0; i < nd; ++i) {
+        int rs = 0;
+        for (int j = 0; j < ntk; ++j) if (iou(i, j) > thr) { ++rs; ++colsum[j]; }
+        max_row = std::max(max_row, rs);
+      }
+      for (int j = 0; j < ntk; ++j) max_col = std::max(max_col, colsum[j]);
+      if (max_row == 1 && max_col == 1) {
+        for (int i = 0; i < nd; ++i) for (int j = 0; j < ntk; ++j) if (iou(i, j) > thr) R.matches.push_back({i, j});
+      } else {
+        Mat fc(nd, ntk);
+        for (int i = 0; i < nd; ++i) for (int j = 0; j < ntk; ++j) fc(i, j) = -((iou(i, j) + angle(i, j)) + fe(i, j));
+        LapResult r = linear_assignment(fc, -thr);
+        laps.push_back(r);
+        for (const auto& m : r.matches) {
+          if (iou(m[0], m[1]) >= thr) R.matches.push_back({m[0], m[1]});
+          else { R.um_dets.push_back(m[0]); R.um_trks.push_back(m[1]); }
+        }
+        for (int i : r.unmatched_a) R.um_dets.push_back(i);  // :484-489 — and again by the sweep below
+        for (int j : r.unmatched_b) R.um_trks.push_back(j);
+      }
+    }
+    std::unordered_set<int> md, mt;
+    for (const auto& m : R.matches) { md.insert(m[0]); mt.insert(m[1]); }
+    for (int i = 0; i < nd; ++i) if (!md.count(i)) R.um_dets.push_back(i);
+    for (int i = 0; i < ntk; ++i) if (!mt.count(i)) R.um_trks.push_back(i);
+    return R;
+  }
+
+ private:
+  static void normalise(std::vector<float>& e) {  // norm > 1e-6 rule (:73-79, :146-149)
+    if (e.empty()) return;
+    const float nn = std::sqrt(dot_chain(e.data(), e.data(), static_cast<int>(e.size())));
+    if (nn > 1e-6f) for (float& v : e) v /= nn;
+  }
+  Track spawn_deep(const Det7& d, const std::vector<float>& e) {
+    Track t = spawn(d);  // same constructor arithmetic as OC-SORT (:53-87 / deepocsort.cpp:50-99); ids from 1
+    t.emb = e;
+    normalise(t.emb);
+    return t;
+  }
+  static void update_emb(Track& t, const std::vector<float>& e, float alpha) {  // :132-150
+    if (e.empty()) return;
+    if (t.emb.empty()) t.emb = e;
+    else for (size_t k = 0; k < e.size(); ++k) t.emb[k] = alpha * t.emb[k] + (1.0f - alpha) * e[k];
+    normalise(t.emb);
+  }
+  void affine(Track& t, const float m[2][2], const float tr[2]) const {  // apply_affine_correction :189-236
+    auto move = [&](float* o) {  // corners through m, then + t (Eigen: m * corners, column += t)
+      const float x1 = o[0], y1 = o[1], x2 = o[2], y2 = o[3];
+      o[0] = (m[0][0] * x1 + m[0][1] * y1) + tr[0];
+      o[1] = (m[1][0] * x1 + m[1][1] * y1) + tr[1];
+      o[2] = (m[0][0] * x2 + m[0][1] * y2) + tr[0];
+      o[3] = (m[1][0] * x2 + m[1][1] * y2) + tr[1];
+    };
+    if (t.last_obs.v[0] + t.last_obs.v[1] + t.last_obs.v[2] + t.last_obs.v[3] > 0) move(t.last_obs.v);
+    for (int dt = delta_t_; dt >= 0; --dt) {
+      auto it = t.observations.find(t.age - dt);
+      if (it != t.observations.end() && it->second.v[0] + it->second.v[1] + it->second.v[2] + it->second.v[3] > 0) move(it->second.v);
+    }
+    t.kf.apply_affine_correction(m, tr);
+  }
+  float w_emb_, alpha_fixed_, aw_param_;
+  bool emb_off_, cmc_off_, aw_off_;
+  float warp_[6] = {1, 0, 0, 0, 1, 0};
+  bool has_warp_ = false;
 };
 
 // =======================================================================================

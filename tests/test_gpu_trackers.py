@@ -32,11 +32,11 @@ def check_frame(f, out_g, out_o, trk_g, trk_o, exact=True):
     if exact:
         assert np.array_equal(out_g, out_o), f
         assert np.array_equal(sg, so), (f, np.abs(sg - so).max())
-    if hasattr(trk_o, "dump_features") and trk_o.kind == orclib.BOTSORT and f % 5 == 4:
+    if hasattr(trk_o, "dump_features") and trk_o.kind in (orclib.BOTSORT, orclib.DEEPOCSORT) and f % 5 == 4:
         # the stored appearance state (botsort.hpp smooth_feat_: normalised at birth, EMA 0.9/0.1 + renormalise per update)
         fg, fo = trk_g.dump_features(), trk_o.dump_features()
         assert fg.shape[0] == fo.shape[0], f
-        if fo.shape[1]:
+        if fo.shape[1] and fg.shape[1]:  # (DeepOC-SORT with embedding_off keeps a dummy 1-d embedding in the reference: nothing to compare)
             assert fg.shape == fo.shape and np.array_equal(fg, fo), (f, np.abs(fg - fo).max())
 
 
@@ -204,3 +204,47 @@ def test_batch_matches_single_streams():
             assert cnt[s] == ref.shape[0] and np.array_equal(out[s, :cnt[s]], ref)
     assert b.counters()["frames"] == 25 * S
     assert batch_flushes <= 25 * 4  # lockstep: at most 4 flushes per frame however many streams are in the batch
+
+
+# ---- DeepOC-SORT: OC-SORT's lifecycle + embedding similarity in the cost, per-detection EMA, CMC on
+# observations. params: det_thresh, max_age, max_obs, min_hits, iou_thr, delta_t, inertia, w_emb, alpha_fixed, aw_param,
+# emb_off, cmc_off, aw_off, q_xy, q_s, asso
+def test_deepocsort_stream():
+    run_stream("deepocsort", orclib.DEEPOCSORT, 200, 110, 50, emb_dim=32, exact=False)
+
+
+def test_deepocsort_fixed_weight_and_larger_embedding():
+    run_stream("deepocsort", orclib.DEEPOCSORT, 150, 90, 35, emb_dim=128, exact=False,
+               params=[0.3, 30, 50, 3, 0.3, 3, 0.2, 0.5, 0.95, 0.5, 0, 0, 1])  # aw_off
+
+
+def test_deepocsort_without_embeddings_is_not_ocsort():
+    # embedding_off: the cost is OC-SORT's, but the duplicated unmatched lists (two tracks per unmatched detection) remain
+    run_stream("deepocsort", orclib.DEEPOCSORT, 120, 70, 35, exact=False, params=[0.3, 30, 50, 3, 0.3, 3, 0.2, 0.5, 0.95, 0.5, 1, 0, 0])
+
+
+def test_deepocsort_camera_motion():
+    orc = orclib.load()
+    tg, to = L.Tracker("deepocsort"), orc.tracker(orclib.DEEPOCSORT)
+    s = SynthStream(150, 90, 91, 24)
+    r = np.random.default_rng(8)
+    pan = np.zeros(2, np.float32)
+    n_out = 0
+    for f in range(40):
+        d, e = s.next_frame()
+        step = r.uniform(-5, 5, 2).astype(np.float32)
+        pan += step
+        d = d.copy()
+        d[:, [0, 2]] += pan[0]
+        d[:, [1, 3]] += pan[1]
+        if f % 3 != 2:  # a warp for two frames out of three (what cmc_->apply would have returned)
+            k = np.float32(1.0 + r.uniform(-0.003, 0.003))
+            W = np.array([[k, 0.001, step[0]], [-0.001, k, step[1]]], np.float32)
+            tg.set_camera_motion(W)
+            to.set_camera_motion(W)
+        og, oo = tg.update(d, e), to.update(d, e)
+        check_frame(f, og, oo, tg, to, exact=False)
+        fg, fo = tg.dump_features(), to.dump_features()
+        assert fg.shape == fo.shape and np.allclose(fg, fo, rtol=1e-5, atol=1e-6), f
+        n_out += len(oo)
+    assert n_out > 500

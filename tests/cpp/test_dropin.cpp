@@ -16,6 +16,7 @@ static int g_fail = 0;
 
 using motcpp::trackers::BotSort;
 using motcpp::trackers::ByteTrack;
+using motcpp::trackers::DeepOCSort;
 using motcpp::trackers::OCSort;
 using motcpp::trackers::Sort;
 
@@ -228,6 +229,41 @@ int main() {
       CHECK(out.size() == 2 && out[0].rows() == r1.rows() && out[1].rows() == r2.rows());
       for (int i = 0; i < r1.rows(); ++i) for (int k = 0; k < 8; ++k) CHECK(out[0](i, k) == r1(i, k));
     }
+  }
+  {  // DeepOCSort (deepocsort.hpp:97-119): embeddings come with update(); without them it throws unless embedding_off
+    DeepOCSort t("", false, false, 0.3f, 30, 50, 1);
+    Eigen::MatrixXf e(3, 8);
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 8; ++k) e(i, k) = (i == k % 3) ? 1.0f : 0.1f;
+    CHECK(t.update(multi, img, e).rows() == 0);  // first frame: tracks are born, nothing is emitted (deepocsort.cpp:652-664)
+    auto tr = t.update(multi, img, e);
+    CHECK(tr.rows() == 3 && tr.cols() == 8);
+    bool threw = false;
+    try { DeepOCSort u; u.update(multi, img); } catch (const std::exception&) { threw = true; }
+    CHECK(threw);
+    DeepOCSort off("", false, false, 0.3f, 30, 50, 1, 0.3f, false, 80, "iou", false, 3, 0.2f, 0.5f, 0.95f, 0.5f, true);
+    off.update(multi, img);
+    CHECK(off.update(multi, img).rows() == 3);
+    threw = false;
+    try { Eigen::MatrixXf w(3, 3); off.set_camera_motion(w); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+  }
+  {  // an embedding matrix with the wrong number of rows is rejected, alone and inside a StreamBatch
+    BotSort t;
+    Eigen::MatrixXf e(2, 8);
+    for (int i = 0; i < 2; ++i) for (int k = 0; k < 8; ++k) e(i, k) = 1.0f;
+    bool threw = false;
+    try { t.update(multi, img, e); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    BotSort a, b;
+    motcpp::StreamBatch batch({&a, &b});
+    threw = false;
+    try { batch.update({multi, multi}, img, {e, e}); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    OCSort bad(0.2f, 30, 50, 3, 0.3f, false, 80, "not_a_measure");
+    motcpp::StreamBatch batch2({&bad});
+    threw = false;
+    try { batch2.update({multi}, img); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);  // the batch runs each tracker's own checks
   }
   std::printf(g_fail ? "%d check(s) failed\n" : "drop-in ok\n", g_fail);
   return g_fail ? 1 : 0;

@@ -268,6 +268,12 @@ def main():
                           "bytes": 24.0 * (ps["lap1_nm"] + ps["lap23_nm"]), "flops": 0.0},
                   "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
                                         "bytes": 0.0, "flops": 0.0}}
+            if tracker == "bytetrack":  # the Kalman launches of the same frames (bytes: DESIGN.md's per-item figures)
+                kf = b.profile_kalman()
+                fr = ps["frame_all_kernels"]["launches"]
+                ps["kf_predict_boxes"] = {"ms": kf["predict_boxes_ms"], "launches": fr, "tasks": kf["predict_boxes_items"], "bytes": 52.0 * kf["predict_boxes_items"], "flops": 0.0}
+                ps["kf_initiate"] = {"ms": kf["initiate_ms"], "launches": fr, "tasks": kf["initiate_items"], "bytes": 312.0 * kf["initiate_items"], "flops": 0.0}
+                ps["kf_update"] = {"ms": kf["update_ms"], "launches": fr, "tasks": kf["update_items"], "bytes": 604.0 * kf["update_items"], "flops": 0.0}
         for k, v in ps.items():
             a = stats.setdefault(k, {"ms": 0.0, "launches": 0, "tasks": 0, "bytes": 0.0, "flops": 0.0})
             for kk in a:

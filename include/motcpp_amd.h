@@ -311,6 +311,9 @@ int mot_bt_profile_stats(mot_bt_batch* b, double* out8);
 /* the achieved problem sizes behind those counts: summed rows (tracks) and columns (detections) of the queued problems,
  * [0],[1] first association, [2],[3] second + unconfirmed (divide by out8[4] / out8[6] for the mean N x M) */
 int mot_bt_profile_dims(mot_bt_batch* b, double* out4);
+/* the Kalman launches of the same frames: summed ms and items of [0],[1] the box-only prediction of the pool (32 B of mean read,
+ * 16 B box written per track), [2],[3] initiations, [4],[5] predict-first updates (one 288-byte record read and written) */
+int mot_bt_profile_kalman(mot_bt_batch* b, double* out6);
 
 /* ---- SORT with the per-stream lifecycle on the device ----------------------------------- */
 /* Same contract as mot_bt_* for Sort::update (src/trackers/sort.cpp:102-255). params: [det_thresh, max_age, max_obs (unused),

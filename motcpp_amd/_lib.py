@@ -540,6 +540,14 @@ class DeviceByteTrack:
         self.ctx._chk(self.lib.mot_bt_profile_dims(self.h, _p(o)))
         return o
 
+    def profile_kalman(self):
+        """HIP-event ms and items of the frame's Kalman launches: predicted boxes of the pool, initiations, updates"""
+        o = np.zeros(6, np.float64)
+        self.lib.mot_bt_profile_kalman.argtypes = [C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_bt_profile_kalman(self.h, _p(o)))
+        return {"predict_boxes_ms": o[0], "predict_boxes_items": o[1], "initiate_ms": o[2], "initiate_items": o[3],
+                "update_ms": o[4], "update_items": o[5]}
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.mot_bt_destroy(self.h)

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(kW) bt_after_first(BtStream* streams, BtParams
 
 // ---- K2: apply associations 2 and 3, births, deaths, list algebra, queue the Kalman work (:442-580) ----
 __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParams P, int CAP, mot_kf_task* init_t, mot_kf_task* upd_t,
-                                                       mot_kf_task* box2_t, mot_iou_task* dup_t) {
+                                                       mot_kf_task* box2_t, mot_iou_task* dup_t, unsigned long long* stats) {
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
   int n_upd = S.n_upd, n_ln = 0;
@@ -362,6 +362,10 @@ __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParam
     if (err) S.err = 1;
     init_t[blockIdx.x].n = n_init;
     upd_t[blockIdx.x].n = n_upd;
+    if (stats) {  // stats[6] / stats[7]: Kalman updates / initiations queued (profile leg: bytes moved by those launches)
+      unsigned long long* st = stats + (blockIdx.x & 63) * 8;
+      atomicAdd(&st[6], static_cast<unsigned long long>(n_upd)); atomicAdd(&st[7], static_cast<unsigned long long>(n_init));
+    }
     mot_kf_task& BA = box2_t[2 * blockIdx.x + 0];
     BA.n = n_na; BA.src = na;
     mot_kf_task& BL = box2_t[2 * blockIdx.x + 1];
@@ -504,8 +508,8 @@ struct mot_bt_batch {
   // profiling (bench.py's roofline leg): HIP events around the two assignment launches and the whole frame
   bool profile = false;
   unsigned long long* d_stats = nullptr;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  double lap_ms[2] = {0.0, 0.0}, frame_ms = 0.0;
+  hipEvent_t ev[12] = {};
+  double lap_ms[2] = {0.0, 0.0}, frame_ms = 0.0, kf_ms[3] = {0.0, 0.0, 0.0};  // kf_ms: predict(boxes), initiate, update
   long frames = 0;
   template <class T>
   T* dalloc(size_t n) { return mem.get<T>(n); }
@@ -659,6 +663,7 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[0], st));
   hipLaunchKernelGGL(bt_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, bd, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[6], st));
   MOT_LC_HIP(b, mot::launch_kf_op(6, MOT_KF_XYAH, b->pred_t, S, bn, st));  // predicted boxes of the pool (box-only: nothing is stored)
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, true, st));
@@ -668,9 +673,12 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[3], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, true, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[4], st));
-  hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t);
+  hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t, prof ? b->d_stats : nullptr);
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[7], st));
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYAH, b->init_t, S, bd, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[8], st));
   MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, bn, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[9], st));
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, bn2, st));
   {
     const size_t lds = static_cast<size_t>(4) * bn2 * sizeof(float);  // nl <= bn2
@@ -699,6 +707,9 @@ static int bt_finish_frame(mot_bt_batch* b) {
     MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[1], b->ev[2])); b->lap_ms[0] += ms;
     MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[3], b->ev[4])); b->lap_ms[1] += ms;
     MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[5])); b->frame_ms += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[6], b->ev[1])); b->kf_ms[0] += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[7], b->ev[8])); b->kf_ms[1] += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[8], b->ev[9])); b->kf_ms[2] += ms;
     b->frames += 1;
   }
   if (err) { b->ctx->err = "mot_bt_step: a stream exceeded cap_tracks / max_dets / cap_out"; return MOT_ERR_CAPACITY; }
@@ -753,6 +764,7 @@ int mot_bt_profile(mot_bt_batch* b, int enable) {
   b->profile = enable != 0;
   if (enable) {
     b->lap_ms[0] = b->lap_ms[1] = b->frame_ms = 0.0;
+    b->kf_ms[0] = b->kf_ms[1] = b->kf_ms[2] = 0.0;
     b->frames = 0;
     MOT_LC_HIP(b, hipMemsetAsync(b->d_stats, 0, 8 * 64 * sizeof(unsigned long long), b->ctx->stream));
     MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
@@ -779,6 +791,18 @@ int mot_bt_profile_dims(mot_bt_batch* b, double* out4) {
     for (int k = 0; k < 8; ++k) h[k] += raw[i * 8 + k];
   out4[0] = static_cast<double>(h[4]); out4[1] = static_cast<double>(h[1] - h[4]);
   out4[2] = static_cast<double>(h[5]); out4[3] = static_cast<double>(h[3] - h[5]);
+  return MOT_OK;
+}
+
+int mot_bt_profile_kalman(mot_bt_batch* b, double* out6) {
+  unsigned long long raw[8 * 64];
+  MOT_LC_HIP(b, hipMemcpy(raw, b->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
+  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 64; ++i)
+    for (int k = 0; k < 8; ++k) h[k] += raw[i * 8 + k];
+  out6[0] = b->kf_ms[0]; out6[1] = static_cast<double>(h[4]);  // predicted boxes: pool tracks of the first association
+  out6[2] = b->kf_ms[1]; out6[3] = static_cast<double>(h[7]);  // initiations
+  out6[4] = b->kf_ms[2]; out6[5] = static_cast<double>(h[6]);  // updates
   return MOT_OK;
 }
 

@@ -108,8 +108,8 @@ def test_cli_usage_and_unknown_method(tmp_path):
     build()
     assert subprocess.run([EVAL], capture_output=True, timeout=60).returncode == 1
     root = make_root(str(tmp_path))
-    out = subprocess.run([EVAL, root, os.path.join(str(tmp_path), "res"), "deepocsort"], capture_output=True, text=True, timeout=60)
-    assert out.returncode == 1 and "Unknown tracking method" in out.stderr
+    out = subprocess.run([EVAL, root, os.path.join(str(tmp_path), "res"), "strongsort"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "unknown tracking method" in out.stderr
     out = subprocess.run([EVAL, os.path.join(str(tmp_path), "nope"), os.path.join(str(tmp_path), "res")], capture_output=True, text=True,
                          timeout=60)
     assert out.returncode == 1 and "does not exist" in out.stderr
@@ -141,7 +141,7 @@ def test_cli_ablation_offset(tmp_path, orc):
     root, res = make_root(str(tmp_path), gt_frames=gt), os.path.join(str(tmp_path), "results")
     out = subprocess.run([EVAL, root, res, "sort"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "Detected ablation offset: 300" in out.stdout
+    assert "skipping the first 300 frames" in out.stdout
     trk = orc.tracker(orclib.SORT, [0.3, 1, 50, 3, 0.3])
     want = []
     for f, d in enumerate(mot17.load("MOT17-02-FRCNN"), start=1):

@@ -339,8 +339,10 @@ def main():
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
     roof.update({"kernel": fam, "avg_launch_ms": avg_ms, "launches": st["launches"], "problems_per_launch": st["tasks"] / launches,
                  "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": None,
-                 "note": "lap is one workgroup per problem and latency/dependency-bound (sequential rows of lapjv); "
-                         "its HBM fraction is reported as measured, see DESIGN.md"})
+                 "note": "lap = the two assignment launches of a frame, each a certified sparse solver (lap_sparse_kernel, one workgroup "
+                         "per problem) followed by the exact lapjv emulation for the problems it declined (lap_kernel); algorithmic bytes "
+                         "= 24 B per row and column (boxes + score in, x/y out); the kernel is latency/dependency-bound (augmenting-path "
+                         "search), its HBM fraction is reported as measured, see DESIGN.md"})
     prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
     if os.path.exists(prof):
         try:
@@ -358,14 +360,15 @@ def main():
     roof["survey_8d_equivalent"] = {"bytes_per_frame": survey_bytes, "GB/s_per_gpu": value / world * survey_bytes / 1e9,
                                     "frac": value / world * survey_bytes / 1e9 / HBM_PEAK_GBS,
                                     "note": "whole-job frames/s x SURVEY 8(d) bytes per frame (cost matrix materialised); not a kernel measurement"}
-    sqf = os.path.join(ROOT, "profiles", "r01g_pmc_sq_lap.json")
+    sqf = os.path.join(ROOT, "profiles", "r02_pmc_sq_lap.json")
     if fam == "lap" and os.path.exists(sqf):
         try:  # what actually bounds this kernel: instruction issue of the serial row passes (SQ counters, separate PMC run)
             sq = json.load(open(sqf)).get(args.workload)
             if sq:
                 roof["issue"] = {"wave_cycles_issuing_frac": sq["active_frac"], "wave_cycles_waiting_frac": sq["wait_any_frac"],
                                  "valu_insts_per_problem": sq["per_problem"]["SQ_INSTS_VALU"],
-                                 "salu_insts_per_problem": sq["per_problem"]["SQ_INSTS_SALU"], "source": "profiles/r01g_pmc_sq_lap.json"}
+                                 "salu_insts_per_problem": sq["per_problem"]["SQ_INSTS_SALU"], "kernel": sq.get("kernel"),
+                                 "source": "profiles/r02_pmc_sq_lap.json"}
         except Exception:
             pass
     kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["launches"],

@@ -138,13 +138,42 @@ int mot_kf_boxes(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks
 int mot_kf_warp(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
 int mot_kf_predict_warp(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
 
+/* ---- gating distances (StrongSORT's motion gate) ---------------------------------------- */
+/* Squared distance between every track's projected state and every measurement of the frame:
+ *   MOT_KF_XYAH  BaseKalmanFilter::gating_distance (src/motion/kalman_filter.cpp:148-176): S = H P H^T + R (project(), :60-75,
+ *                confidence 0), metric 0 "maha": z = LLT(S[:dim,:dim]).solve(d), |z|^2 — plain |d|^2 when the factorisation
+ *                fails; metric 1 "gaussian": |d|^2
+ *   MOT_KF_XYWH  KalmanFilterXYWH::gating_distance (include/motcpp/motion/kalman_filters/xywh_kf.hpp:140-176):
+ *                d^T S^-1 d with the partial-pivot LU inverse (only_position: its leading 2 x 2 block)
+ * and, fused into the same pass, what the two callers do with it:
+ *   MOT_GATE_FUSE_MOTION  utils::fuse_motion (include/motcpp/utils/matching.hpp:60-94): +inf above chi2inv95[dim-1],
+ *                         else lambda * cost + (1 - lambda) * distance
+ *   MOT_GATE_STRONGSORT   gate_cost_matrix (src/trackers/strongsort.cpp:449-492): cost replaced by gated_cost above 9.4877,
+ *                         then EVERY entry blended lambda * cost + (1 - lambda) * distance
+ * dim = 2 (only_position) or 4. meas: SoA [4][ldm] (xyah for XYAH, xywh for XYWH), what mot_det_prepare writes. */
+typedef enum mot_gate_mode { MOT_GATE_DISTANCE = 0, MOT_GATE_FUSE_MOTION = 1, MOT_GATE_STRONGSORT = 2 } mot_gate_mode;
+typedef struct mot_gate_task {
+  int32_t n, m;                        /* tracks x measurements                                              */
+  const float* mean; const int32_t* src; /* Kalman records (see mot_kf_task) and the slot of each row, NULL = identity */
+  const float* meas; int32_t ldm;
+  const float* cost; int32_t ldc;      /* n x m row-major input (modes 1, 2)                                 */
+  float* out; int32_t ldo;             /* n x m row-major                                                    */
+  int32_t mode, only_position, metric; /* metric 0 = "maha", 1 = "gaussian" (XYAH only)                      */
+  float lambda, gated_cost;
+} mot_gate_task;
+int mot_gate_cost(mot_ctx* ctx, int kf_kind, const mot_gate_task* tasks, int ntasks, int max_n, int max_m);
+/* host-pointer form: mean8 [n][8], cov [n][64], meas row-major [m][4], cost/out row-major n x m (cost NULL for mode 0) */
+int mot_gate_cost_host(mot_ctx* ctx, int kf_kind, int mode, int n, int m, const float* mean8, const float* cov64, const float* meas4,
+                       const float* cost_or_null, int only_position, int metric, float lambda, float gated_cost, float* out);
+
 /* ---- N x M box costs ----------------------------------------------------------------- */
 typedef enum mot_cost_mode {
   MOT_COST_IOU = 0,           /* iou                                                          */
   MOT_COST_IOU_DIST = 1,      /* 1 - iou                                                      */
   MOT_COST_IOU_DIST_FUSE = 2, /* 1 - (1 - (1 - iou)) * conf_j                                 */
   MOT_COST_NEG_IOU = 3,       /* -iou (OC-SORT rematch)                                       */
-  MOT_COST_BOTSORT = 4        /* min(fuse?(1-iou), gate(emb/2)) — botsort.cpp:433-466          */
+  MOT_COST_BOTSORT = 4,       /* min(fuse?(1-iou), gate(emb/2)) — botsort.cpp:433-466          */
+  MOT_COST_FUSE_IOU = 5       /* fuse_iou (matching.cpp:109-128): 1 - (1 - emb_ij) * (1 + (1 - (1 - iou))) / 2, emb = ReID cost n x m */
 } mot_cost_mode;
 /* the pairwise similarity the cost is built from (AssociationFunction modes, include/motcpp/utils/iou.hpp:371-414);
  * "iou" in the cost-mode formulas above means this value */
@@ -328,6 +357,23 @@ int mot_sort_dump(mot_sort_batch* b, int s, int* ids, float* mean, float* cov, i
 int mot_sort_profile(mot_sort_batch* b, int enable);         /* same layout as mot_bt_profile_stats ([1], [6], [7] = 0) */
 int mot_sort_profile_stats(mot_sort_batch* b, double* out8);
 
+/* ---- multi-GPU: gather of the track tables over RCCL ------------------------------------ */
+/* one process per GPU, rank r owns streams [r*S, (r+1)*S) and never exchanges tracker state; the only
+ * collective is the gather of the output tables, done on the device tables (mot_bt_device_output) with RCCL on the context's
+ * stream — the counterpart of nothing in the single-process reference (its trackers return one Eigen matrix per call).
+ * mot_comm_unique_id: rank 0 fills 128 bytes (ncclUniqueId) and hands them to the other ranks through whatever channel the
+ * host program has (torch.distributed, MPI, a file). mot_comm_create: collective over all ranks.
+ * mot_comm_gather_tables: d_rows [sum(counts)][8] + d_counts [nstreams] of this rank -> d_rows_all (every rank's rows,
+ * rank-major, then stream-major inside a rank, packed), h_counts_all [world][nstreams] on the host, h_rank_rows [world]
+ * (optional) = rows per rank. Enqueued on the context's stream; returns after the counts are known (one stream
+ * synchronisation), the row exchange itself completes in stream order. RCCL is loaded at first use (dlopen). */
+typedef struct mot_comm mot_comm;
+int mot_comm_unique_id(void* id128);
+int mot_comm_create(mot_ctx* ctx, int world, int rank, const void* id128, mot_comm** out);
+int mot_comm_destroy(mot_comm* comm);
+int mot_comm_gather_tables(mot_comm* comm, const float* d_rows, const int* d_counts, int nstreams, float* d_rows_all, int rows_cap,
+                           int* h_counts_all, int* h_rank_rows);
+
 /* ---- host-pointer conveniences (synchronous; row-major matrices) ---------------------- */
 int mot_iou_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_xyxy, int m,
                       const float* bconf_or_null, int mode, float* cost);
@@ -335,6 +381,8 @@ int mot_iou_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_x
  * replaces utils::AssociationFunction(w, h, name)(a, b), include/motcpp/utils/iou.hpp:371-414, with mode = MOT_COST_IOU */
 int mot_assoc_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_xyxy, int m, const float* bconf_or_null,
                         int mode, int assoc, int frame_w, int frame_h, float* cost);
+/* utils::fuse_iou(reid_cost, tracks_xyxy, detections_xyxy, confs) — src/utils/matching.cpp:109-128 (the confidences are unused there) */
+int mot_fuse_iou_host(mot_ctx* ctx, const float* reid_cost, const float* a_xyxy, int n, const float* b_xyxy, int m, float* cost);
 int mot_cosine_cost_host(mot_ctx* ctx, const float* a, int n, const float* b, int m, int d, float* out);
 int mot_embedding_cost_host(mot_ctx* ctx, int metric, const float* a, int n, const float* b, int m, int d, float* out);
 /* mot_feat_update on host rows: feat [n][d] in/out (read by mode 1), src [n][d] */

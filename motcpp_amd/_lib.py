@@ -129,6 +129,27 @@ class Context:
         self._chk(self.lib.mot_embedding_cost_host(self.h, int(metric), _p(a), a.shape[0], _p(b), b.shape[0], a.shape[1], _p(out)))
         return out
 
+    def gate_cost(self, kind, mode, mean, cov, meas, cost=None, only_position=False, metric=0, lam=0.98, gated_cost=1e5):
+        """mot_gate_cost_host: kind KF_XYAH / KF_XYWH; mode 0 gating distances, 1 utils::fuse_motion, 2 StrongSORT's gate_cost_matrix"""
+        mean, cov, meas = f32(mean).reshape(-1, 8), f32(cov).reshape(-1, 64), f32(meas).reshape(-1, 4)
+        n, m = mean.shape[0], meas.shape[0]
+        out = np.zeros((n, m), np.float32)
+        cost = f32(cost) if cost is not None else None
+        self.lib.mot_gate_cost_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        self._chk(self.lib.mot_gate_cost_host(self.h, int(kind), int(mode), n, m, _p(mean), _p(cov), _p(meas),
+                                              _p(cost) if cost is not None else None, int(only_position), int(metric),
+                                              C.c_float(lam), C.c_float(gated_cost), _p(out)))
+        return out
+
+    def fuse_iou(self, reid_cost, a, b):
+        """utils::fuse_iou (mot_fuse_iou_host)"""
+        reid_cost, a, b = f32(reid_cost), f32(a).reshape(-1, 4), f32(b).reshape(-1, 4)
+        out = np.zeros_like(reid_cost)
+        self.lib.mot_fuse_iou_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        self._chk(self.lib.mot_fuse_iou_host(self.h, _p(reid_cost), _p(a), a.shape[0], _p(b), b.shape[0], _p(out)))
+        return out
+
     def feat_update(self, mode, feat, src, alpha=0.9):
         """mot_feat_update on host rows: mode 0 set+normalise, 1 EMA+normalise, 2 ReID normalise (norm > 1e-6). Returns new feat."""
         feat, src = f32(feat).copy(), f32(src)

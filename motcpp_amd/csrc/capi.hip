@@ -14,6 +14,7 @@
 namespace mot {
 hipError_t launch_kf_op(int op, int kind, const mot_kf_task*, int, int, hipStream_t);
 hipError_t launch_det(int kind, const mot_det_task*, int, int, hipStream_t);
+hipError_t launch_gate(int kind, const mot_gate_task*, int, int, int, hipStream_t);
 hipError_t launch_iou(const mot_iou_task*, int, int, int, bool, hipStream_t);
 hipError_t launch_ocsort(const mot_ocsort_task*, int, int, int, bool, hipStream_t);
 hipError_t launch_feat(const mot_feat_task*, int, int, hipStream_t);
@@ -179,6 +180,67 @@ int mot_assoc_cost_host(mot_ctx* c, const float* a, int n, const float* b, int m
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, mot::launch_iou(dt.as<mot_iou_task>(), 1, n, m, assoc == MOT_ASSOC_IOU, c->stream));
   MOT_HIP(c, hipMemcpyAsync(cost, dcost.p, static_cast<size_t>(n) * m * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+
+// fuse_iou (matching.cpp:109-128): the ReID cost matrix blended with the IoU of the same pairs
+int mot_fuse_iou_host(mot_ctx* c, const float* reid_cost, const float* a, int n, const float* b, int m, float* cost) {
+  if (n <= 0 || m <= 0) return MOT_OK;
+  std::vector<float> sa, sb;
+  to_soa4(a, n, 4, 4, sa);
+  to_soa4(b, m, 4, 4, sb);
+  DBuf da, db, de, dcost, dt;
+  MOT_HIP(c, da.alloc(sa.size() * 4)); MOT_HIP(c, db.alloc(sb.size() * 4)); MOT_HIP(c, de.alloc(static_cast<size_t>(n) * m * 4));
+  MOT_HIP(c, dcost.alloc(static_cast<size_t>(n) * m * 4)); MOT_HIP(c, dt.alloc(sizeof(mot_iou_task)));
+  MOT_HIP(c, hipMemcpyAsync(da.p, sa.data(), sa.size() * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(db.p, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(de.p, reid_cost, static_cast<size_t>(n) * m * 4, hipMemcpyHostToDevice, c->stream));
+  mot_iou_task t{};
+  t.n = n; t.m = m; t.a = da.as<float>(); t.lda = n; t.b = db.as<float>(); t.ldb = m;
+  t.cost = dcost.as<float>(); t.ldc = m; t.mode = MOT_COST_FUSE_IOU; t.emb = de.as<float>(); t.lde = m;
+  MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, mot::launch_iou(dt.as<mot_iou_task>(), 1, n, m, true, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(cost, dcost.p, static_cast<size_t>(n) * m * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+
+int mot_gate_cost(mot_ctx* c, int kind, const mot_gate_task* t, int nt, int max_n, int max_m) {
+  MOT_HIP(c, mot::launch_gate(kind, t, nt, max_n, max_m, c->stream));
+  return MOT_OK;
+}
+int mot_gate_cost_host(mot_ctx* c, int kind, int mode, int n, int m, const float* mean8, const float* cov64, const float* meas4,
+                       const float* cost, int only_position, int metric, float lambda, float gated_cost, float* out) {
+  if (n <= 0 || m <= 0) return MOT_OK;
+  if ((kind != MOT_KF_XYAH && kind != MOT_KF_XYWH) || mode < 0 || mode > 2 || (mode != 0 && !cost)) return MOT_ERR_INVALID;
+  std::vector<float> rec(static_cast<size_t>(n) * 72), sm;
+  for (int i = 0; i < n; ++i) {
+    std::memcpy(&rec[static_cast<size_t>(i) * 72], mean8 + static_cast<size_t>(i) * 8, 8 * sizeof(float));
+    std::memcpy(&rec[static_cast<size_t>(i) * 72 + 8], cov64 + static_cast<size_t>(i) * 64, 64 * sizeof(float));
+  }
+  to_soa4(meas4, m, 4, 4, sm);
+  DBuf dr, dm, dc, dout, dt;
+  MOT_HIP(c, dr.alloc(rec.size() * 4)); MOT_HIP(c, dm.alloc(sm.size() * 4)); MOT_HIP(c, dc.alloc(static_cast<size_t>(n) * m * 4));
+  MOT_HIP(c, dout.alloc(static_cast<size_t>(n) * m * 4)); MOT_HIP(c, dt.alloc(sizeof(mot_gate_task)));
+  MOT_HIP(c, hipMemcpyAsync(dr.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(dm.p, sm.data(), sm.size() * 4, hipMemcpyHostToDevice, c->stream));
+  if (cost) MOT_HIP(c, hipMemcpyAsync(dc.p, cost, static_cast<size_t>(n) * m * 4, hipMemcpyHostToDevice, c->stream));
+  mot_gate_task t{};
+  t.n = n; t.m = m; t.mean = dr.as<float>(); t.src = nullptr; t.meas = dm.as<float>(); t.ldm = m;
+  t.cost = dc.as<float>(); t.ldc = m; t.out = dout.as<float>(); t.ldo = m;
+  t.mode = mode; t.only_position = only_position; t.metric = metric; t.lambda = lambda; t.gated_cost = gated_cost;
+  MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+  for (int r0 = 0; r0 < n; r0 += 32768) {  // grid.y limit
+    mot_gate_task tt = t;
+    tt.n = (n - r0 < 32768) ? n - r0 : 32768;
+    tt.mean = t.mean + static_cast<size_t>(r0) * 72; tt.cost = t.cost + static_cast<size_t>(r0) * m; tt.out = t.out + static_cast<size_t>(r0) * m;
+    MOT_HIP(c, hipMemcpyAsync(dt.p, &tt, sizeof(tt), hipMemcpyHostToDevice, c->stream));
+    MOT_HIP(c, hipStreamSynchronize(c->stream));
+    MOT_HIP(c, mot::launch_gate(kind, dt.as<mot_gate_task>(), 1, tt.n, m, c->stream));
+    MOT_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  MOT_HIP(c, hipMemcpyAsync(out, dout.p, static_cast<size_t>(n) * m * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   return MOT_OK;
 }

@@ -106,6 +106,12 @@ MOT_HD float cost_from_iou(const CostParams& p, float iou, float conf, EmbFn emb
     }
     return d;
   }
+  if (WITH_APPEARANCE && p.mode == MOT_COST_FUSE_IOU) {  // fuse_iou (matching.cpp:109-128): 1 - (1 - reid) * (1 + iou_sim) / 2
+    const float reid_sim = 1.0f - emb_at();
+    const float iou_sim = 1.0f - d;
+    const float fuse_sim = reid_sim * ((1.0f + iou_sim) / 2.0f);
+    return 1.0f - fuse_sim;
+  }
   // the four plain modes as selects on the (uniform) mode rather than branches: inside the assignment solver this runs
   // once per visited pair, where a taken scalar branch costs more than the two spare multiplies
   const float fused = 1.0f - (1.0f - d) * conf;  // fuse_score: 1 - (1 - d) * conf

@@ -408,6 +408,57 @@ Eigen::MatrixXf embedding_distance(const Eigen::MatrixXf& t, const Eigen::Matrix
   for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) out(i, j) = c[static_cast<size_t>(i) * m + j];
   return out;
 }
+Eigen::MatrixXf fuse_iou(const Eigen::MatrixXf& reid, const Eigen::MatrixXf& a, const Eigen::MatrixXf& b, const Eigen::MatrixXf&, int device_index) {
+  const int n = static_cast<int>(reid.rows()), m = static_cast<int>(reid.cols());
+  if (n == 0 || m == 0) return reid;  // matching.cpp:113-115
+  if (a.rows() != n || b.rows() != m || a.cols() < 4 || b.cols() < 4) throw std::invalid_argument("fuse_iou: boxes do not match the cost matrix");
+  auto dev = rt::Device::shared(device_index);
+  std::lock_guard<std::mutex> dev_lock(dev->frame_mu);
+  std::vector<float> rr = row_major(reid, m), ra = row_major(a, 4), rb = row_major(b, 4), c(static_cast<size_t>(n) * m);
+  chk(*dev, mot_fuse_iou_host(dev->ctx, rr.data(), ra.data(), n, rb.data(), m, c.data()), "mot_fuse_iou_host");
+  Eigen::MatrixXf out(n, m);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) out(i, j) = c[static_cast<size_t>(i) * m + j];
+  return out;
+}
+
+namespace {
+Eigen::MatrixXf gate_call(const std::string& filter, int mode, const Eigen::MatrixXf* cost, const Eigen::MatrixXf& means,
+                          const Eigen::MatrixXf& covs, const Eigen::MatrixXf& meas, bool only_position, int metric, float lambda,
+                          float gated_cost, int device_index) {
+  const int kind = (filter == "xyah") ? MOT_KF_XYAH : ((filter == "xywh") ? MOT_KF_XYWH : -1);
+  if (kind < 0) throw std::invalid_argument("gating: unknown filter '" + filter + "' (xyah | xywh)");
+  const int n = static_cast<int>(means.rows()), m = static_cast<int>(meas.rows());
+  if (means.cols() != 8 || covs.rows() != n || covs.cols() != 64 || (m && meas.cols() < 4))
+    throw std::invalid_argument("gating: means n x 8, covariances n x 64, measurements m x 4 expected");
+  if (cost && (cost->rows() != n || cost->cols() != m)) throw std::invalid_argument("gating: cost matrix is not tracks x measurements");
+  Eigen::MatrixXf out(n, m);
+  if (n == 0 || m == 0) return out;
+  auto dev = rt::Device::shared(device_index);
+  std::lock_guard<std::mutex> dev_lock(dev->frame_mu);
+  std::vector<float> rm = row_major(means, 8), rc = row_major(covs, 64), rz = row_major(meas, 4), c(static_cast<size_t>(n) * m), ci;
+  if (cost) ci = row_major(*cost, m);
+  chk(*dev, mot_gate_cost_host(dev->ctx, kind, mode, n, m, rm.data(), rc.data(), rz.data(), cost ? ci.data() : nullptr, only_position ? 1 : 0,
+                               metric, lambda, gated_cost, c.data()), "mot_gate_cost_host");
+  for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) out(i, j) = c[static_cast<size_t>(i) * m + j];
+  return out;
+}
+}  // namespace
+
+Eigen::MatrixXf gating_distance(const std::string& filter, const Eigen::MatrixXf& means, const Eigen::MatrixXf& covs, const Eigen::MatrixXf& meas,
+                                bool only_position, const std::string& metric, int device_index) {
+  const int metric_id = (metric == "maha") ? 0 : ((metric == "gaussian") ? 1 : -1);
+  if (metric_id < 0) throw std::invalid_argument("Invalid metric: " + metric);  // kalman_filter.cpp:172-174
+  return gate_call(filter, MOT_GATE_DISTANCE, nullptr, means, covs, meas, only_position, metric_id, 0.f, 0.f, device_index);
+}
+Eigen::MatrixXf fuse_motion(const std::string& filter, const Eigen::MatrixXf& cost, const Eigen::MatrixXf& means, const Eigen::MatrixXf& covs,
+                            const Eigen::MatrixXf& meas, bool only_position, float lambda, int device_index) {
+  if (cost.rows() == 0 || cost.cols() == 0) return cost;  // matching.hpp:67-69
+  return gate_call(filter, MOT_GATE_FUSE_MOTION, &cost, means, covs, meas, only_position, 0, lambda, 0.f, device_index);
+}
+Eigen::MatrixXf gate_cost_matrix(const std::string& filter, const Eigen::MatrixXf& cost, const Eigen::MatrixXf& means, const Eigen::MatrixXf& covs,
+                                 const Eigen::MatrixXf& meas, float mc_lambda, float gated_cost, bool only_position, int device_index) {
+  return gate_call(filter, MOT_GATE_STRONGSORT, &cost, means, covs, meas, only_position, 0, mc_lambda, gated_cost, device_index);
+}
 }  // namespace utils
 
 }  // namespace motcpp

@@ -16,6 +16,8 @@
 // to it (F = I + shift and H = [I 0] are applied structurally: the skipped terms are exact zeros).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/motcpp_amd.h"
 
 namespace {
@@ -567,6 +569,283 @@ __global__ void __launch_bounds__(kThreads) det_kernel(const mot_det_task* __res
   }
 }
 
+// ---- 8-state update, one lane per covariance ROW -------------------------------------------------------------------
+// The lane-per-track kernel above keeps a whole 8x8 state (and the update's temporaries) in one lane: 242 VGPRs, two
+// wavefronts per SIMD, and a 64-track wavefront waits on its 27 memory instructions with nothing else to run (measured
+// 12 % of the HBM roof). Here a 256-thread workgroup owns 32 tracks and lane (track, r) owns row r of P, K and K S:
+// ~100 VGPRs, eight times the wavefronts per track. The 4x4 innovation covariance is factored redundantly by the eight lanes of
+// a track from the tile in LDS (broadcast reads, a few dozen flops); the gain rows meet once in LDS for P - (K S) K^T.
+// Every element is produced by the same operations in the same order as s8_predict / s8_update: results are bit-identical.
+constexpr int kUpdTracks = 32;
+
+template <int KIND>
+__global__ void __launch_bounds__(256) kf_update8_kernel(const mot_kf_task* __restrict__ tasks) {
+  constexpr int RS = tile_stride<8>();  // 76 floats = 19 float4
+  __shared__ __attribute__((aligned(16))) float tile[kUpdTracks * RS];
+  __shared__ __attribute__((aligned(16))) float kbuf[kUpdTracks * 32];
+  __shared__ int s_src[kUpdTracks], s_dst[kUpdTracks];
+  const mot_kf_task T = tasks[blockIdx.y];
+  const int base = blockIdx.x * kUpdTracks;
+  if (base >= T.n) return;
+  const int tid = threadIdx.x;
+  if (tid < kUpdTracks) {
+    const int i = base + tid;
+    const bool a = i < T.n;
+    const int src = a ? (T.src ? T.src[i] : i) : -1;
+    s_src[tid] = src;
+    s_dst[tid] = a ? (T.dst ? T.dst[i] : src) : -1;
+  }
+  __syncthreads();
+  {
+    const float4* slab4 = reinterpret_cast<const float4*>(T.mean);
+    float4* tile4 = reinterpret_cast<float4*>(tile);
+    for (int p = tid; p < kUpdTracks * 18; p += 256) {
+      const int rec = p / 18, q = p - rec * 18;
+      const int slot = s_src[rec];
+      if (slot >= 0) tile4[rec * 19 + q] = slab4[static_cast<size_t>(slot) * 18 + q];
+    }
+  }
+  __syncthreads();
+  const int tr = tid >> 3, r = tid & 7;
+  const int item = base + tr;
+  const bool active = item < T.n;
+  float* rec = tile + tr * RS;
+  float z[4] = {0.f, 0.f, 0.f, 0.f};
+  unsigned f = 0u;
+  if (active) {
+    const int c = T.midx ? T.midx[item] : item;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = T.meas[static_cast<size_t>(k) * T.ldm + c];
+    f = T.flags ? T.flags[item] : 0u;
+  }
+  float P[8];
+  {
+    const float4 a = *reinterpret_cast<const float4*>(rec + 8 + r * 8), b = *reinterpret_cast<const float4*>(rec + 12 + r * 8);
+    P[0] = a.x; P[1] = a.y; P[2] = a.z; P[3] = a.w; P[4] = b.x; P[5] = b.y; P[6] = b.z; P[7] = b.w;
+  }
+  float m = rec[r];
+  if (f & MOT_KF_PREDICT_FIRST) {  // s8_predict: x' = F x, P' = F P F^T + Q with h taken before the motion step
+    const bool zero_v7 = (f & MOT_KF_ZERO_V7) != 0;
+    const float h = rec[3];
+    if (zero_v7 && r == 7) m = 0.0f;
+    if (r < 4) {
+      float mh = rec[r + 4];
+      if (zero_v7 && r == 3) mh = 0.0f;
+      m = m + mh;
+      const float4 a = *reinterpret_cast<const float4*>(rec + 8 + (r + 4) * 8), b = *reinterpret_cast<const float4*>(rec + 12 + (r + 4) * 8);
+      const float hi[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) P[j] = P[j] + hi[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) P[j] = P[j] + P[j + 4];
+    float sd = (r < 4) ? kWp * h : kWv * h;
+    if (KIND == MOT_KF_XYAH) { if (r == 2) sd = 1e-2f; if (r == 6) sd = 1e-5f; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j == r) P[j] = P[j] + sd * sd;
+  }
+  __syncthreads();  // every lane has read the stored rows it needs
+  rec[r] = m;
+  *reinterpret_cast<float4*>(rec + 8 + r * 8) = make_float4(P[0], P[1], P[2], P[3]);
+  *reinterpret_cast<float4*>(rec + 12 + r * 8) = make_float4(P[4], P[5], P[6], P[7]);
+  __syncthreads();
+  // s8_update on the (predicted) state in the tile
+  const float h = rec[3];
+  float sd[4] = {kWp * h, kWp * h, kWp * h, kWp * h};
+  if (KIND == MOT_KF_XYAH) {
+    sd[2] = 1e-1f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sd[i] = sd[i] * (1.0f - 0.0f);
+  }
+  float S[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 a = *reinterpret_cast<const float4*>(rec + 8 + i * 8);
+    S[i][0] = a.x; S[i][1] = a.y; S[i][2] = a.z; S[i][3] = a.w;
+    S[i][i] = S[i][i] + sd[i] * sd[i];
+  }
+  float K[4];
+  bool solved = false;
+  if (KIND == MOT_KF_XYAH) {
+    float L[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) L[i][j] = S[i][j];
+    if (chol4(L)) {
+      K[0] = P[0]; K[1] = P[1]; K[2] = P[2]; K[3] = P[3];
+      chol4_solve(L, K);
+      solved = true;
+    }
+  }
+  if (!solved) {
+    float Sinv[4][4];
+    inv_lu4(S, Sinv);
+    const float pr[4] = {P[0], P[1], P[2], P[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) K[j] = dot4(pr, Sinv[0][j], Sinv[1][j], Sinv[2][j], Sinv[3][j]);
+  }
+  float inn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) inn[i] = z[i] - rec[i];
+  const float m_new = m + dot4(K, inn[0], inn[1], inn[2], inn[3]);
+  float KS[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) KS[j] = dot4(K, S[0][j], S[1][j], S[2][j], S[3][j]);
+  *reinterpret_cast<float4*>(kbuf + tr * 32 + r * 4) = make_float4(K[0], K[1], K[2], K[3]);
+  __syncthreads();  // gains published; every lane is done reading S and the mean from the tile
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float4 kj = *reinterpret_cast<const float4*>(kbuf + tr * 32 + j * 4);
+    P[j] = P[j] - dot4(KS, kj.x, kj.y, kj.z, kj.w);
+  }
+  rec[r] = m_new;
+  *reinterpret_cast<float4*>(rec + 8 + r * 8) = make_float4(P[0], P[1], P[2], P[3]);
+  *reinterpret_cast<float4*>(rec + 12 + r * 8) = make_float4(P[4], P[5], P[6], P[7]);
+  __syncthreads();
+  {
+    float4* slab4 = reinterpret_cast<float4*>(T.mean);
+    const float4* tile4 = reinterpret_cast<const float4*>(tile);
+    for (int p = tid; p < kUpdTracks * 18; p += 256) {
+      const int rc = p / 18, q = p - rc * 18;
+      const int slot = s_dst[rc];
+      if (slot >= 0) slab4[static_cast<size_t>(slot) * 18 + q] = tile4[rc * 19 + q];
+    }
+  }
+  if (T.boxes && active && r < 4) {  // xyxy of the written state: lane r writes component r
+    float w = rec[2];
+    const float hh = rec[3];
+    if (KIND == MOT_KF_XYAH) w = rec[2] * rec[3];
+    const float b = (r == 0) ? rec[0] - w * 0.5f : (r == 1) ? rec[1] - hh * 0.5f : (r == 2) ? rec[0] + w * 0.5f : rec[1] + hh * 0.5f;
+    T.boxes[static_cast<size_t>(r) * T.ldb + item] = b;
+  }
+}
+
+// ---- gating: squared distances between the projected states and the frame's measurements --------------------------
+// BaseKalmanFilter::gating_distance (kalman_filter.cpp:148-176, the XYAH filter StrongSORT carries) and
+// KalmanFilterXYWH::gating_distance (xywh_kf.hpp:140-176), with the two callers' blends fused into the same pass:
+// utils::fuse_motion (matching.hpp:60-94) and StrongSORT's gate_cost_matrix (strongsort.cpp:449-492).
+// Grid: x = 256-column chunks, y = track row, z = task. A thread owns one measurement; the row's 4x4 innovation covariance
+// and its factor are uniform over the block (built from 20 scalar-cached floats of the record, a few dozen flops), so the
+// pass reads the cost matrix once and writes the result once: 8 B per pair + 16 B per measurement per row chunk.
+constexpr int kGateThreads = 256;
+
+__device__ __forceinline__ bool chol2(float A[2][2]) {  // the same unblocked recurrence on the leading 2x2
+  float x = A[0][0];
+  if (!(x > 0.0f)) return false;
+  x = sqrtf(x);
+  A[0][0] = x;
+  A[1][0] = A[1][0] / x;
+  float y = A[1][1];
+  y -= A[1][0] * A[1][0];
+  if (!(y > 0.0f)) return false;
+  A[1][1] = sqrtf(y);
+  return true;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(kGateThreads) gate_kernel(const mot_gate_task* __restrict__ tasks) {
+  const mot_gate_task T = tasks[blockIdx.z];
+  const int row = blockIdx.y;
+  const int j = blockIdx.x * kGateThreads + threadIdx.x;
+  if (row >= T.n || blockIdx.x * kGateThreads >= T.m) return;
+  const int slot = T.src ? T.src[row] : row;
+  const float* rec = T.mean + static_cast<size_t>(slot) * rec_floats<8>();
+  float pm[4], S[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pm[k] = rec[k];  // H = [I 0]: the projected mean is the first four components
+  const float h = pm[3];
+  float sd[4] = {kWp * h, kWp * h, kWp * h, kWp * h};
+  if (KIND == MOT_KF_XYAH) {
+    sd[2] = 1e-1f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sd[k] = sd[k] * (1.0f - 0.0f);  // project() with the default confidence 0 (kalman_filter.cpp:67)
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) S[a][b] = rec[8 + a * 8 + b] + ((a == b) ? sd[a] * sd[a] : 0.0f);
+  const bool pos = T.only_position != 0;
+  // row-uniform factorisation
+  float L4[4][4], L2[2][2], Sinv[4][4];
+  bool ok = true;
+  if (KIND == MOT_KF_XYAH) {
+    if (T.metric == 0) {
+      if (pos) {
+        L2[0][0] = S[0][0]; L2[0][1] = S[0][1]; L2[1][0] = S[1][0]; L2[1][1] = S[1][1];
+        ok = chol2(L2);
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) L4[a][b] = S[a][b];
+        ok = chol4(L4);
+      }
+    }
+  } else {
+    inv_lu4(S, Sinv);
+  }
+  if (j >= T.m) return;
+  float d[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d[k] = T.meas[static_cast<size_t>(k) * T.ldm + j] - pm[k];
+  float g;
+  if (KIND == MOT_KF_XYAH) {
+    if (T.metric != 0 || !ok) {  // "gaussian", or the LLT failed: plain squared norm (:161-167)
+      g = d[0] * d[0];
+      g += d[1] * d[1];
+      if (!pos) { g += d[2] * d[2]; g += d[3] * d[3]; }
+    } else if (pos) {  // z = (L L^T)^-1 d, |z|^2 (:169-170: the solve, not the half-solve)
+      float z0 = d[0] / L2[0][0];
+      float z1 = d[1] - z0 * L2[1][0];
+      z1 = z1 / L2[1][1];
+      z1 = z1 / L2[1][1];
+      z0 = z0 - L2[1][0] * z1;
+      z0 = z0 / L2[0][0];
+      g = z0 * z0;
+      g += z1 * z1;
+    } else {
+      chol4_solve(L4, d);
+      g = d[0] * d[0];
+      g += d[1] * d[1];
+      g += d[2] * d[2];
+      g += d[3] * d[3];
+    }
+  } else {  // d^T S^-1 d with the LU inverse; position only: the leading 2x2 block of the 4x4 inverse (:168-174)
+    if (pos) {
+      float t0 = d[0] * Sinv[0][0]; t0 += d[1] * Sinv[1][0];
+      float t1 = d[0] * Sinv[0][1]; t1 += d[1] * Sinv[1][1];
+      g = t0 * d[0];
+      g += t1 * d[1];
+    } else {
+      float t[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float a = d[0] * Sinv[0][c];
+        a += d[1] * Sinv[1][c];
+        a += d[2] * Sinv[2][c];
+        a += d[3] * Sinv[3][c];
+        t[c] = a;
+      }
+      g = t[0] * d[0];
+      g += t[1] * d[1];
+      g += t[2] * d[2];
+      g += t[3] * d[3];
+    }
+  }
+  float out = g;
+  if (T.mode == MOT_GATE_FUSE_MOTION) {
+    const float thr = pos ? 5.9915f : 9.4877f;  // chi2inv95[dim - 1] (matching.hpp:16-26)
+    const float c = T.cost[static_cast<size_t>(row) * T.ldc + j];
+    out = (g > thr) ? __builtin_inff() : (T.lambda * c + (1.0f - T.lambda) * g);
+  } else if (T.mode == MOT_GATE_STRONGSORT) {
+    float c = T.cost[static_cast<size_t>(row) * T.ldc + j];
+    if (g > 9.4877f) c = T.gated_cost;  // the 4-dof quantile whatever only_position is (strongsort.cpp:461)
+    out = T.lambda * c + (1.0f - T.lambda) * g;
+  }
+  T.out[static_cast<size_t>(row) * T.ldo + j] = out;
+}
+
 template <int OP>
 hipError_t launch_kf(int kind, const mot_kf_task* tasks, int ntasks, int max_n, hipStream_t st) {
   if (ntasks <= 0 || max_n <= 0) return hipSuccess;
@@ -587,13 +866,33 @@ hipError_t launch_kf_op(int op, int kind, const mot_kf_task* tasks, int ntasks, 
   switch (op) {
     case OP_INIT: return launch_kf<OP_INIT>(kind, tasks, ntasks, max_n, st);
     case OP_PREDICT: return launch_kf<OP_PREDICT>(kind, tasks, ntasks, max_n, st);
-    case OP_UPDATE: return launch_kf<OP_UPDATE>(kind, tasks, ntasks, max_n, st);
+    case OP_UPDATE:
+      static const bool lane_per_track = std::getenv("MOT_KF_UPDATE_LANE_PER_TRACK") != nullptr;  // measurement aid (tools/kf_update_microbench.py)
+      if ((kind == MOT_KF_XYAH || kind == MOT_KF_XYWH) && !lane_per_track) {  // the 8-state filters: one lane per covariance row
+        if (ntasks <= 0 || max_n <= 0) return hipSuccess;
+        dim3 grid((max_n + kUpdTracks - 1) / kUpdTracks, ntasks), block(256);
+        if (kind == MOT_KF_XYAH) hipLaunchKernelGGL((kf_update8_kernel<MOT_KF_XYAH>), grid, block, 0, st, tasks);
+        else hipLaunchKernelGGL((kf_update8_kernel<MOT_KF_XYWH>), grid, block, 0, st, tasks);
+        return hipGetLastError();
+      }
+      return launch_kf<OP_UPDATE>(kind, tasks, ntasks, max_n, st);
     case OP_BOXES: return launch_kf<OP_BOXES>(kind, tasks, ntasks, max_n, st);
     case OP_WARP: return (kind == MOT_KF_XYAH) ? hipErrorInvalidValue : launch_kf<OP_WARP>(kind, tasks, ntasks, max_n, st);
     case OP_PREDICT_WARP: return (kind == MOT_KF_XYAH) ? hipErrorInvalidValue : launch_kf<OP_PREDICT_WARP>(kind, tasks, ntasks, max_n, st);
     case OP_PREDICT_BOXES: return launch_kf<OP_PREDICT_BOXES>(kind, tasks, ntasks, max_n, st);
   }
   return hipErrorInvalidValue;
+}
+hipError_t launch_gate(int kind, const mot_gate_task* tasks, int ntasks, int max_n, int max_m, hipStream_t st) {
+  if (ntasks <= 0 || max_n <= 0 || max_m <= 0) return hipSuccess;
+  if (max_n > 65535) return hipErrorInvalidValue;
+  dim3 grid((max_m + kGateThreads - 1) / kGateThreads, max_n, ntasks), block(kGateThreads);
+  switch (kind) {
+    case MOT_KF_XYAH: hipLaunchKernelGGL((gate_kernel<MOT_KF_XYAH>), grid, block, 0, st, tasks); break;
+    case MOT_KF_XYWH: hipLaunchKernelGGL((gate_kernel<MOT_KF_XYWH>), grid, block, 0, st, tasks); break;
+    default: return hipErrorInvalidValue;  // the XYSR filter has no gating distance in the reference
+  }
+  return hipGetLastError();
 }
 hipError_t launch_det(int kind, const mot_det_task* tasks, int ntasks, int max_n, hipStream_t st) {
   if (ntasks <= 0 || max_n <= 0) return hipSuccess;

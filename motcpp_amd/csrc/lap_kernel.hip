@@ -118,7 +118,7 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status)
     return;
   }
   if constexpr (PLAIN) {
-    if (T.geom.a != nullptr && T.geom.mode == MOT_COST_BOTSORT) {  // MOT_LAP_F_PLAIN was a false promise: refuse loudly
+    if (T.geom.a != nullptr && T.geom.mode >= MOT_COST_BOTSORT) {  // (BOTSORT, FUSE_IOU) MOT_LAP_F_PLAIN was a false promise: refuse loudly
       for (int i = t; i < nr; i += kThreads) { T.x[i] = -1; if (T.xval) T.xval[i] = 0.f; }
       for (int j = t; j < nc; j += kThreads) T.y[j] = -1;
       if (T.info && t == 0) T.info[0] = -1;

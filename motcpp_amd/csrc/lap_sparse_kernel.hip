@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task
     if (PLAIN) skip = true;
     else if (!(1.0f > T.geom.prox_thresh)) skip = true;
   }
+  if (geom && T.geom.mode == MOT_COST_FUSE_IOU) skip = true;  // cost depends on a per-pair ReID term whatever the overlap
   if (skip) { if (t == 0) *status = 0; count_outcome(6); return; }
 
   mot::DevGroup g(smem);

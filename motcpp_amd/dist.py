@@ -105,3 +105,50 @@ def unpack_packed(gt, gc):
         for s in range(S):
             out[r * S + s] = gt[r, off[s]:off[s + 1]].copy()
     return out
+
+
+# ---- native gather (mot_comm_*: RCCL called from the library on the context's stream) ------------------------------------
+class NativeComm:
+    """One RCCL communicator bound to a motcpp_amd Context. The 128-byte unique id travels through `exchange`, a callable
+    that takes rank 0's bytes (None on the other ranks) and returns them on every rank — e.g. a torch.distributed broadcast
+    (default when a process group is initialised), MPI, or a file. World size 1 needs no exchange."""
+
+    def __init__(self, ctx, world=None, rank=None, exchange=None):
+        import ctypes as C
+        self.ctx, self.lib = ctx, ctx.lib
+        if world is None:
+            import torch.distributed as dist
+            world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
+        self.world, self.rank = int(world), int(rank)
+        buf = (C.c_char * 128)()
+        if self.rank == 0:
+            if self.lib.mot_comm_unique_id(buf) != 0:
+                raise RuntimeError("mot_comm_unique_id failed (librccl not loadable?)")
+        raw = bytes(buf)
+        if self.world > 1:
+            raw = (exchange or self._torch_exchange)(raw if self.rank == 0 else None)
+        self.h = C.c_void_p()
+        self.lib.mot_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+        ctx._chk(self.lib.mot_comm_create(ctx.h, self.world, self.rank, raw, C.byref(self.h)))
+
+    @staticmethod
+    def _torch_exchange(raw):
+        import torch.distributed as dist
+        box = [raw]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def gather_tables(self, d_rows, d_counts, nstreams, d_rows_all, rows_cap):
+        """device pointers in, device pointer out (see mot_comm_gather_tables); returns (counts [world, S], rows per rank [world])"""
+        import ctypes as C
+        counts = np.zeros((self.world, nstreams), np.int32)
+        per_rank = np.zeros(self.world, np.int32)
+        self.lib.mot_comm_gather_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_comm_gather_tables(self.h, C.c_void_p(d_rows), C.c_void_p(d_counts), int(nstreams), C.c_void_p(d_rows_all),
+                                                      int(rows_cap), counts.ctypes.data_as(C.c_void_p), per_rank.ctypes.data_as(C.c_void_p)))
+        return counts, per_rank
+
+    def close(self):
+        if self.h:
+            self.lib.mot_comm_destroy(self.h)
+            self.h = None

@@ -2,6 +2,7 @@
 // Flat C entry points over the CPU restatement so tests/ and bench.py's cpu_baseline leg can
 // drive it through ctypes. Nothing in the product links or loads this library.
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <variant>
 
@@ -188,6 +189,46 @@ void orc_embedding_distance(int metric, const float* t, int n, const float* dd, 
       if (metric == 1) s = dot_chain(a, b, d);
       else { for (int k = 0; k < d; ++k) { const float df = a[k] - b[k]; s = std::fmaf(df, df, s); } s = std::sqrt(s); }
       out[static_cast<size_t>(i) * m + j] = s;
+    }
+}
+// gating distances and the two blends built on them (StrongSORT's gate; matching.hpp:60-94, strongsort.cpp:449-492).
+// kind 1 = XYAH (BaseKalmanFilter), 2 = XYWH. mean [n][8], cov [n][64], meas [m][4]; mode 0: distances, 1: fuse_motion,
+// 2: gate_cost_matrix. out n x m row-major.
+void orc_gate_cost(int kind, int mode, int n, int m, const float* mean, const float* cov, const float* meas, const float* cost,
+                   int only_position, int metric, float lambda, float gated_cost, float* out) {
+  static const float chi2inv95[] = {3.8415f, 5.9915f, 7.8147f, 9.4877f};  // matching.hpp:16-26
+  std::vector<float> g(static_cast<size_t>(m > 0 ? m : 1));
+  for (int i = 0; i < n; ++i) {
+    State8 s;
+    for (int k = 0; k < 8; ++k) s.mean[k] = mean[8 * i + k];
+    for (int a = 0; a < 8; ++a)
+      for (int b = 0; b < 8; ++b) s.cov[a][b] = cov[64 * static_cast<size_t>(i) + 8 * a + b];
+    if (kind == 1) gating_xyah(s, meas, m, only_position != 0, metric, g.data());
+    else gating_xywh(s, meas, m, only_position != 0, g.data());
+    for (int j = 0; j < m; ++j) {
+      const size_t o = static_cast<size_t>(i) * m + j;
+      if (mode == 0) out[o] = g[j];
+      else if (mode == 1) {
+        const float thr = chi2inv95[(only_position ? 2 : 4) - 1];
+        out[o] = (g[j] > thr) ? std::numeric_limits<float>::infinity() : lambda * cost[o] + (1.0f - lambda) * g[j];
+      } else {
+        float c = cost[o];
+        if (g[j] > 9.4877f) c = gated_cost;
+        out[o] = lambda * c + (1.0f - lambda) * g[j];
+      }
+    }
+  }
+}
+// fuse_iou, matching.cpp:109-128
+void orc_fuse_iou(const float* reid, int n, int m, const float* a, const float* b, float* out) {
+  Mat d = iou_distance(as_mat(a, n, 4), as_mat(b, m, 4));
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < m; ++j) {
+      const size_t o = static_cast<size_t>(i) * m + j;
+      const float reid_sim = 1.0f - reid[o];
+      const float iou_sim = 1.0f - d.a[o];
+      const float fuse_sim = reid_sim * ((1.0f + iou_sim) / 2.0f);
+      out[o] = 1.0f - fuse_sim;
     }
 }
 void orc_linear_assignment(const float* cost, int n, int m, float thresh, int* x, int* y) {

@@ -365,4 +365,68 @@ struct KfXYWH {
   }
 };
 
+// ---- gating distances (StrongSORT's motion gate; "parity unpinned": the reference holds no known answer for them) ----
+// BaseKalmanFilter::gating_distance, kalman_filter.cpp:148-176, for the XYAH filter: project() (:60-75, confidence 0), the
+// leading dim x dim block of S, d = z - H x. "maha" (metric 0): z = LLT(S_sub).solve(d) — the full solve, so the value is
+// |S^-1 d|^2, not d^T S^-1 d — summed in component order; a failed factorisation or "gaussian" (metric 1): |d|^2.
+// meas: n rows of 4 (xyah). The dynamic-size triangular solves are restated with chol_solve's operation order.
+inline void gating_xyah(const State8& s, const float* meas, int n, bool only_position, int metric, float* out) {
+  const float h = s.mean[3];
+  float sd[4] = {KfXYAH::wp * h, KfXYAH::wp * h, 1e-1f, KfXYAH::wp * h};
+  for (float& v : sd) v = v * (1.0f - 0.0f);
+  const SMat<4, 8> H = obs8();
+  SMat<4, 4> Rn = SMat<4, 4>::zero();
+  for (int i = 0; i < 4; ++i) Rn[i][i] = sd[i] * sd[i];
+  const SMat<4, 4> S = add(mul(mul(H, s.cov), transpose(H)), Rn);
+  float pm[4];
+  for (int i = 0; i < 4; ++i) {
+    float acc = H[i][0] * s.mean[0];
+    for (int k = 1; k < 8; ++k) acc += H[i][k] * s.mean[k];
+    pm[i] = acc;
+  }
+  const int dim = only_position ? 2 : 4;
+  SMat<4, 4> L4 = S;
+  SMat<2, 2> L2;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) L2[a][b] = S[a][b];
+  const bool ok = (metric == 0) && (only_position ? cholesky(L2) : cholesky(L4));
+  for (int j = 0; j < n; ++j) {
+    float d[4];
+    for (int k = 0; k < dim; ++k) d[k] = meas[4 * j + k] - pm[k];
+    if (ok) { if (only_position) chol_solve(L2, d); else chol_solve(L4, d); }
+    float g = d[0] * d[0];
+    for (int k = 1; k < dim; ++k) g += d[k] * d[k];
+    out[j] = g;
+  }
+}
+// KalmanFilterXYWH::gating_distance, xywh_kf.hpp:140-176: S = H P H^T + diag((wp h)^2), S^-1 by partial-pivot LU,
+// d^T S^-1 d as (d^T S^-1) d; only_position uses the leading 2 x 2 block of the 4 x 4 inverse. meas: n rows of 4 (xywh).
+inline void gating_xywh(const State8& s, const float* meas, int n, bool only_position, float* out) {
+  const float h = s.mean[3];
+  const SMat<4, 8> H = obs8();
+  SMat<4, 4> Rn = SMat<4, 4>::zero();
+  for (int i = 0; i < 4; ++i) { const float sd = KfXYWH::wp * h; Rn[i][i] = sd * sd; }
+  const SMat<4, 4> S = add(mul(mul(H, s.cov), transpose(H)), Rn);
+  const SMat<4, 4> Si = inverse_lu4(S);
+  float pm[4];
+  for (int i = 0; i < 4; ++i) {
+    float acc = H[i][0] * s.mean[0];
+    for (int k = 1; k < 8; ++k) acc += H[i][k] * s.mean[k];
+    pm[i] = acc;
+  }
+  const int dim = only_position ? 2 : 4;
+  for (int j = 0; j < n; ++j) {
+    float d[4], t[4];
+    for (int k = 0; k < 4; ++k) d[k] = meas[4 * j + k] - pm[k];
+    for (int c = 0; c < dim; ++c) {
+      float a = d[0] * Si[0][c];
+      for (int k = 1; k < dim; ++k) a += d[k] * Si[k][c];
+      t[c] = a;
+    }
+    float g = t[0] * d[0];
+    for (int k = 1; k < dim; ++k) g += t[k] * d[k];
+    out[j] = g;
+  }
+}
+
 }  // namespace orc

@@ -265,6 +265,41 @@ int main() {
     try { batch2.update({multi}, img); } catch (const std::invalid_argument&) { threw = true; }
     CHECK(threw);  // the batch runs each tracker's own checks
   }
+  {  // the motion gate and fuse_iou seams (matching.hpp:60-103): shapes, the chi-square gate, argument errors
+    namespace U = motcpp::utils;
+    Eigen::MatrixXf means(2, 8), covs(2, 64), meas(3, 4), cost(2, 3);
+    for (int i = 0; i < 2; ++i) {
+      for (int k = 0; k < 8; ++k) means(i, k) = 0.0f;
+      for (int k = 0; k < 64; ++k) covs(i, k) = 0.0f;
+      for (int k = 0; k < 8; ++k) covs(i, 9 * k) = 4.0f;
+      means(i, 0) = 100.0f * (i + 1); means(i, 1) = 50.0f; means(i, 2) = 0.5f; means(i, 3) = 80.0f;
+      for (int j = 0; j < 3; ++j) cost(i, j) = 0.5f;
+    }
+    const float z[3][4] = {{100.f, 50.f, 0.5f, 80.f}, {200.f, 50.f, 0.5f, 80.f}, {900.f, 700.f, 0.5f, 80.f}};
+    for (int j = 0; j < 3; ++j) for (int k = 0; k < 4; ++k) meas(j, k) = z[j][k];
+    const Eigen::MatrixXf g = U::gating_distance("xyah", means, covs, meas);
+    CHECK(g.rows() == 2 && g.cols() == 3);
+    CHECK(g(0, 0) == 0.0f && g(1, 1) == 0.0f && g(0, 2) > 9.4877f);
+    const Eigen::MatrixXf f = U::fuse_motion("xyah", cost, means, covs, meas);
+    CHECK(f(0, 0) == 0.98f * 0.5f && std::isinf(f(0, 2)) && std::isinf(f(1, 0)));
+    const Eigen::MatrixXf s2 = U::gate_cost_matrix("xyah", cost, means, covs, meas, 0.995f, 1e5f);
+    CHECK(s2(0, 0) == 0.995f * 0.5f && s2(0, 2) > 1e4f);
+    CHECK(U::gating_distance("xywh", means, covs, meas, true)(1, 1) == 0.0f);
+    bool threw = false;
+    try { U::gating_distance("xyah", means, covs, meas, false, "euclid"); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    try { U::gating_distance("xysr", means, covs, meas); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    Eigen::MatrixXf a(2, 4), b(3, 4), reid(2, 3);
+    const float ab[3][4] = {{0, 0, 10, 10}, {20, 20, 40, 40}, {100, 100, 110, 110}};
+    for (int k = 0; k < 4; ++k) { a(0, k) = ab[0][k]; a(1, k) = ab[1][k]; }
+    for (int j = 0; j < 3; ++j) for (int k = 0; k < 4; ++k) b(j, k) = ab[j][k];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) reid(i, j) = 0.25f;
+    const Eigen::MatrixXf fi = U::fuse_iou(reid, a, b);
+    CHECK(fi(0, 0) == 0.25f && fi(1, 1) == 0.25f);  // iou 1: 1 - 0.75 * (1 + 1) / 2
+    CHECK(fi(0, 2) == 1.0f - 0.75f * 0.5f);         // iou 0: 1 - 0.75 * (1 + 0) / 2
+  }
   std::printf(g_fail ? "%d check(s) failed\n" : "drop-in ok\n", g_fail);
   return g_fail ? 1 : 0;
 }

@@ -91,6 +91,25 @@ class Oracle:
         self.lib.orc_embedding_distance(int(metric), t.ctypes, t.shape[0], d.ctypes, d.shape[0], t.shape[1], out.ctypes)
         return out
 
+    def gate_cost(self, kind, mode, mean, cov, meas, cost=None, only_position=False, metric=0, lam=0.98, gated_cost=1e5):
+        """kind 1 XYAH / 2 XYWH; mode 0 gating distances, 1 utils::fuse_motion, 2 StrongSORT's gate_cost_matrix"""
+        mean, cov, meas = f32(mean).reshape(-1, 8), f32(cov).reshape(-1, 64), f32(meas).reshape(-1, 4)
+        n, m = mean.shape[0], meas.shape[0]
+        out = np.zeros((n, m), np.float32)
+        cost = f32(cost) if cost is not None else np.zeros((n, m), np.float32)
+        self.lib.orc_gate_cost.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_int, C.c_float, C.c_float, C.c_void_p]
+        self.lib.orc_gate_cost(int(kind), int(mode), n, m, mean.ctypes.data, cov.ctypes.data, meas.ctypes.data, cost.ctypes.data,
+                               int(only_position), int(metric), C.c_float(lam), C.c_float(gated_cost), out.ctypes.data)
+        return out
+
+    def fuse_iou(self, reid, a, b):
+        reid, a, b = f32(reid), f32(a).reshape(-1, 4), f32(b).reshape(-1, 4)
+        out = np.zeros_like(reid)
+        self.lib.orc_fuse_iou.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.orc_fuse_iou(reid.ctypes.data, a.shape[0], b.shape[0], a.ctypes.data, b.ctypes.data, out.ctypes.data)
+        return out
+
     def linear_assignment(self, cost, thresh):
         cost = f32(cost)
         n, m = cost.shape

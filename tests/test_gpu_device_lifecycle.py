@@ -197,6 +197,7 @@ def test_packed_output_equals_the_padded_tables():
     rows = L.pinned_array(dev.ctx, (S * maxd * 2, 8), np.float32)
     cnt = L.pinned_array(dev.ctx, (S,), np.int32)
     ddets = torch.zeros((S, 6, maxd), dtype=torch.float32, device="cuda:0")
+    comm = None
     for f in range(40):
         counts = np.zeros(S, np.int32)
         soa = np.zeros((S, 6, maxd), np.float32)
@@ -226,4 +227,16 @@ def test_packed_output_equals_the_padded_tables():
             assert np.array_equal(do.cpu().numpy(), off.astype(np.int32))
             got = mdist.unpack_packed(gt, gc)
             assert all(np.array_equal(got[s], want[s]) for s in range(S))
+            # the native gather (mot_comm_*: RCCL from the library on the context's stream), one-rank communicator
+            if comm is None:
+                comm = mdist.NativeComm(dev.ctx, world=1, rank=0)
+                all_rows = torch.zeros((S * maxd * 2, 8), dtype=torch.float32, device=dv)
+            all_rows.zero_()
+            torch.cuda.synchronize()
+            counts_all, per_rank = comm.gather_tables(r_ptr, c_ptr, S, all_rows.data_ptr(), all_rows.shape[0])
+            dev.ctx._chk(dev.ctx.lib.mot_ctx_sync(dev.ctx.h))
+            assert per_rank.tolist() == [total] and np.array_equal(counts_all[0], cnt)
+            assert np.array_equal(all_rows[:total].cpu().numpy(), rows[:total])
+    assert comm is not None
+    comm.close()
     dev.close()

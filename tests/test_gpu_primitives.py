@@ -400,3 +400,88 @@ def test_embedding_metrics(ctx, orc, n, m, d):
     if eu is not None:
         assert np.allclose(ctx.embedding_cost(2, a, b), eu, rtol=1e-4)
     assert np.allclose(ctx.embedding_cost(1, a, b), a64 @ b64.T, rtol=1e-4, atol=1e-4)
+
+
+def _gating_states(orc, kind, n, seed):
+    """n Kalman states a few frames old (initiate, then predict/update rounds with jittered measurements) + their measurements"""
+    r = np.random.default_rng(seed)
+    cx, cy = r.uniform(100, 1800, n), r.uniform(100, 900, n)
+    h = r.uniform(30, 300, n)
+    third = r.uniform(0.3, 0.6, n) if kind == L.KF_XYAH else r.uniform(0.3, 0.6, n) * h  # aspect ratio / width
+    z = np.stack([cx, cy, third, h], 1).astype(np.float32)
+    mean, cov = orc.kf_initiate(kind, z)
+    for _ in range(3):
+        mean, cov = orc.kf_predict(kind, mean, cov)
+        z = (z + r.normal(0, 1, z.shape) * np.array([2.0, 2.0, 0.01 if kind == L.KF_XYAH else 1.0, 2.0])).astype(np.float32)
+        mean, cov = orc.kf_update(kind, mean, cov, z)
+    mean, cov = orc.kf_predict(kind, mean, cov)
+    return mean, cov, z
+
+
+@pytest.mark.parametrize("kind", [L.KF_XYAH, L.KF_XYWH])
+@pytest.mark.parametrize("n,m", [(1, 1), (7, 300), (130, 257), (600, 513)])
+def test_gating_distance_and_blends(ctx, orc, kind, n, m):
+    """gating_distance (kalman_filter.cpp:148-176 / xywh_kf.hpp:140-176), utils::fuse_motion (matching.hpp:60-94) and StrongSORT's
+    gate_cost_matrix (strongsort.cpp:449-492): bit-identical to the restatement; the distances also against float64 linear algebra
+    of the same formula within 1e-4 relative."""
+    mean, cov, z = _gating_states(orc, kind, n, 100 * n + m + kind)
+    r = np.random.default_rng(n * m + kind)
+    # measurements: every track's own (jittered) measurement is in the set -> both sides of every threshold occur
+    meas = np.concatenate([z + r.normal(0, 1, z.shape).astype(np.float32) * np.array([3, 3, 0.02, 3], np.float32),
+                           z[r.integers(0, n, m)] + r.normal(0, 40, (m, 4)).astype(np.float32) * np.array([1, 1, 0.001, 0.2], np.float32)])[:m]
+    meas = meas.astype(np.float32)
+    cost = r.uniform(0, 1, (n, meas.shape[0])).astype(np.float32)
+    for pos in (False, True):
+        for metric in ((0, 1) if kind == L.KF_XYAH else (0,)):
+            g = ctx.gate_cost(kind, 0, mean, cov, meas, only_position=pos, metric=metric)
+            o = orc.gate_cost(kind, 0, mean, cov, meas, only_position=pos, metric=metric)
+            assert np.array_equal(g, o), (pos, metric, np.abs(g - o).max())
+        dim = 2 if pos else 4
+        S = cov.astype(np.float64)[:, :4, :4].copy()
+        hh = mean[:, 3].astype(np.float64)
+        for i in range(n):
+            sd = np.full(4, hh[i] / 20.0)
+            if kind == L.KF_XYAH:
+                sd[2] = 0.1
+            S[i] += np.diag(sd ** 2)
+        d = meas.astype(np.float64)[None, :, :dim] - mean.astype(np.float64)[:, None, :dim]
+        if kind == L.KF_XYAH:  # |S_sub^-1 d|^2 (the full LLT solve, kalman_filter.cpp:169-170)
+            zz = np.einsum("nab,nmb->nma", np.linalg.inv(S[:, :dim, :dim]), d)
+            ref = (zz ** 2).sum(-1)
+        else:  # d^T (S^-1)[:dim,:dim] d
+            ref = np.einsum("nma,nab,nmb->nm", d, np.linalg.inv(S)[:, :dim, :dim], d)
+        g = ctx.gate_cost(kind, 0, mean, cov, meas, only_position=pos)
+        assert np.allclose(g, ref, rtol=1e-3, atol=1e-6), np.abs(g / np.maximum(ref, 1e-30) - 1).max()
+        thr = 5.9915 if pos else 9.4877
+        if n * m > 100:
+            assert (g > thr).any() and (g <= thr).any()
+        for mode, lam, gc in ((1, 0.98, 0.0), (2, 0.995, 1e5)):
+            a = ctx.gate_cost(kind, mode, mean, cov, meas, cost, only_position=pos, lam=lam, gated_cost=gc)
+            b = orc.gate_cost(kind, mode, mean, cov, meas, cost, only_position=pos, lam=lam, gated_cost=gc)
+            assert np.array_equal(a, b), (mode, pos)
+            if mode == 1:
+                assert np.array_equal(np.isinf(a), g > np.float32(thr))
+
+
+def test_gating_failed_factorisation_falls_back(ctx, orc):
+    """a covariance that is not positive definite: the XYAH distance becomes the plain squared norm (kalman_filter.cpp:161-167)"""
+    mean = np.array([[10, 20, 0.5, 100, 0, 0, 0, 0]], np.float32)
+    cov = np.zeros((1, 8, 8), np.float32)
+    cov[0, 0, 0] = -1000.0
+    meas = np.array([[13, 24, 0.5, 100], [10, 20, 0.5, 100]], np.float32)
+    g = ctx.gate_cost(L.KF_XYAH, 0, mean, cov, meas)
+    assert np.array_equal(g, orc.gate_cost(L.KF_XYAH, 0, mean, cov, meas))
+    assert g[0, 0] == 25.0 and g[0, 1] == 0.0
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (33, 65), (300, 500)])
+def test_fuse_iou(ctx, orc, n, m):
+    """utils::fuse_iou (matching.cpp:109-128): 1 - (1 - reid) * (1 + iou) / 2 in the reference's operation order"""
+    r = np.random.default_rng(n + m)
+    a, b = boxes(r, n), boxes(r, m)
+    b[: min(n, m)] = a[: min(n, m)] + r.normal(0, 3, (min(n, m), 4)).astype(np.float32)
+    reid = r.uniform(0, 1, (n, m)).astype(np.float32)
+    g, o = ctx.fuse_iou(reid, a, b), orc.fuse_iou(reid, a, b)
+    assert np.array_equal(g, o)
+    iou = orc.iou_batch(a, b).astype(np.float64)
+    assert np.allclose(g, 1 - (1 - reid.astype(np.float64)) * (1 + iou) / 2, atol=1e-6)

@@ -1,0 +1,36 @@
+"""Turns the per-kernel PMC sums of tools/collect_profiles.sh into the two small files bench.py quotes:
+  profiles/pmc_<WL>.json            HBM bytes per assignment problem (FETCH_SIZE doubled: gfx950 reports half of wide reads)
+  profiles/<tag>_pmc_sq_lap.json    SQ counters of the dominant assignment kernel per problem (= per workgroup)
+usage: python tools/pmc_derive.py <tag> <WL> <streams of the PMC passes>"""
+import json, os, sys
+
+tag, wl, S = sys.argv[1], sys.argv[2], int(sys.argv[3])
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+ld = lambda n: json.load(open(os.path.join(P, f"{tag}_pmc_{n}_{wl}.json")))
+fetch, write, sq1, sq2 = ld("fetch"), ld("write"), ld("sq1"), ld("sq2")
+# the assignment kernels of a frame: the sparse certified solver (every problem) + the exact solver (the problems it declined)
+laps = [k for k in fetch if k.startswith("lap_")]
+main = max((k for k in laps if k.startswith("lap_sparse")), key=lambda k: fetch[k]["FETCH_SIZE"]["sum"])
+disp = fetch[main]["FETCH_SIZE"]["dispatches"]
+per_launch = 1.5 * S  # ByteTrack: S first-association problems in one launch, 2S (second + unconfirmed) in the other
+fb = sum(fetch[k]["FETCH_SIZE"]["sum"] for k in laps) * 1024.0 / disp
+wb = sum(write[k]["WRITE_SIZE"]["sum"] for k in laps if k in write) * 1024.0 / disp
+out = {"_comment": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --workload {wl} --streams {S} --pipeline 1 --steps 2 "
+                   f"--warmup 5` (device lifecycle); kernels {laps}; KB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md (an upper bound for "
+                   f"4-byte accesses). Raw sums: {tag}_pmc_fetch_{wl}.json, {tag}_pmc_write_{wl}.json",
+       "lap": {"fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb, "problems_per_launch": per_launch,
+               "hbm_bytes_per_problem": (2.0 * fb + wb) / per_launch}}
+json.dump(out, open(os.path.join(P, f"pmc_{wl}.json"), "w"), indent=1)
+c = {}
+for src in (sq1, sq2):
+    for name, v in src[main].items():
+        c[name] = v["sum"] / v["dispatches"] / per_launch
+sq = {"kernel": main, "problems_per_launch": per_launch, "waves_per_problem": c.get("SQ_WAVES"),
+      "per_problem": {k: round(v, 1) for k, v in c.items() if k != "SQ_WAVES"},
+      "active_frac": round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3), "wait_any_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3)}
+path = os.path.join(P, f"{tag}_pmc_sq_lap.json")
+allsq = json.load(open(path)) if os.path.exists(path) else {}
+allsq[wl] = sq
+json.dump(allsq, open(path, "w"), indent=1)
+print(json.dumps(out["lap"]), json.dumps(sq))

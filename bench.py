@@ -59,11 +59,11 @@ def world_local():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 60; C4: 3 - a step there is 256 assignment problems of 4096 x 2048)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 40; C4: 1)")
     ap.add_argument("--workload", default="NS", choices=sorted(WORKLOADS),
                     help="NS = the north-star shape the >= 50 k frames/s bar is set on (ByteTrack, 1000 tracks x 500 detections)")
-    ap.add_argument("--settle", type=int, default=30,
+    ap.add_argument("--settle", type=int, default=None,
                     help="untimed frames stepped before the warm-up so that the track pools are in steady state whatever --warmup is "
                          "(a stream starts by giving birth to its whole population at once)")
     ap.add_argument("--host-input-steps", type=int, default=8,
@@ -103,12 +103,16 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     tracker, P, M, D, desc = WORKLOADS[args.workload]
-    S = args.streams or {"C2": 12288, "SORT": 12288, "NS": 6144, "C5": 6144, "C3": 1536, "C4": 64}[args.workload]
+    S = args.streams or {"C2": 12288, "SORT": 12288, "NS": 6144, "C5": 6144, "C3": 1536, "C4": 256}[args.workload]
     # host workers block between phases, so about twice as many workers as the box's CPU quota pay off (the bursts of
     # lifecycle work get shorter and the workers sleep through the GPU waits); far more than that and the cgroup
     # throttles the whole process (measured on the 16-CPU-quota GPU boxes: 32 workers 456k frames/s, 64 workers 268k)
     threads = args.threads or max(2, min(os.cpu_count() or 1, 64, 2 * cpu_budget() // max(1, world_local())))
-    K, W = args.steps, args.warmup
+    heavy = args.workload == "C4"  # seconds per step: keep the default run within minutes
+    K = args.steps if args.steps is not None else (3 if heavy else 60)
+    W = args.warmup if args.warmup is not None else (1 if heavy else 40)
+    if args.settle is None:
+        args.settle = 5 if heavy else 30
     on_device_wl = tracker in ("bytetrack", "sort") and args.lifecycle in ("auto", "device")
     Z = max(0, args.settle)
     H = max(0, args.host_input_steps) if on_device_wl else 0

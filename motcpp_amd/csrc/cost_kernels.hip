@@ -208,68 +208,79 @@ __global__ void __launch_bounds__(kThreads) ocsort_kernel(const mot_ocsort_task*
   }
 }
 
-// ---- BoT-SORT appearance features --------------------------------------------------------------------------------------
+// ---- appearance rows: normalise / exponential moving average ------------------------------------------------------------
 // mode 0: feat = src / |src| (BotSTrack ctor, botsort.cpp:38-46); 1: feat = alpha*feat + (1-alpha)*src, renormalised
 // (update_features, botsort.cpp:158-169); 2: feat = src / |src| if |src| > 1e-6 else src (ReIDBackend::normalize_features,
-// reid_backend.cpp:72-88). One lane owns one row for the arithmetic — the squared norm is the k-ordered fmaf chain of the
-// CPU restatement — but the rows travel through an LDS tile in 32-column chunks: the wavefront reads / writes each chunk
-// of its 64 rows with coalesced 128-byte runs (a lane walking its own row in global memory touches a different line per lane).
-constexpr int kFeatChunk = 32;
-__global__ void __launch_bounds__(64) feat_kernel(const mot_feat_task* __restrict__ tasks) {
-  __shared__ float tf[64 * (kFeatChunk + 1)], ts[64 * (kFeatChunk + 1)];
+// reid_backend.cpp:72-88); 3: the EMA with that 1e-6 rule (update_emb, deepocsort.cpp:132-150).
+// The squared norm is a k-ordered fmaf chain — that order IS the result, so one lane walks one row for it — but everything
+// else is parallel: a 256-thread workgroup owns 32 rows, its four wavefronts stream the rows into an LDS tile with 256-byte
+// coalesced runs and blend them on the way (the EMA is elementwise), lanes 0..31 run the 32 chains out of LDS (odd row
+// stride: conflict-free), and the wavefronts divide and write back coalesced. A row of up to 256 columns is read once and
+// written once; longer rows go through the tile in 256-column chunks (the chain carries over) with one more round trip
+// for the division.
+constexpr int kFeatRows = 32, kFeatCols = 256;
+__global__ void __launch_bounds__(256) feat_kernel(const mot_feat_task* __restrict__ tasks) {
+  __shared__ float tile[kFeatRows * (kFeatCols + 1)];
+  __shared__ unsigned long long s_f[kFeatRows], s_s[kFeatRows];
+  __shared__ float s_alpha[kFeatRows], s_nrm[kFeatRows];
   const mot_feat_task T = tasks[blockIdx.y];
-  const int lane = threadIdx.x;
-  const int i0 = blockIdx.x * 64;
+  const int i0 = blockIdx.x * kFeatRows;
   if (i0 >= T.n) return;
-  const int i = i0 + lane;
-  const bool active = i < T.n;
-  const size_t frow = active ? static_cast<size_t>(T.slot ? T.slot[i] : i) * T.ldf : 0;
-  const size_t srow = active ? static_cast<size_t>(T.sidx ? T.sidx[i] : i) * T.lds : 0;
-  const int rows = (T.n - i0 < 64) ? T.n - i0 : 64;
-  const float alpha = (active && T.alpha_i) ? T.alpha_i[i] : T.alpha;
-  const int cl = lane & (kFeatChunk - 1), half = lane / kFeatChunk;  // chunk column / which of two rows per pass
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rows = (T.n - i0 < kFeatRows) ? T.n - i0 : kFeatRows;
+  if (tid < rows) {
+    const int i = i0 + tid;
+    s_f[tid] = static_cast<unsigned long long>(T.slot ? T.slot[i] : i) * T.ldf;
+    s_s[tid] = static_cast<unsigned long long>(T.sidx ? T.sidx[i] : i) * T.lds;
+    s_alpha[tid] = T.alpha_i ? T.alpha_i[i] : T.alpha;
+  }
+  __syncthreads();
+  const bool ema = T.mode == 1 || T.mode == 3;
+  const bool single = T.d <= kFeatCols;
+  constexpr int RS = kFeatCols + 1;
   float nn = 0.0f;
-  for (int pass = 0; pass < 2; ++pass) {  // 0: blend + squared norm (v stored), 1: divide
-    float inv_applies = 0.0f, nrm = 1.0f;
-    if (pass == 1) {
-      nrm = sqrtf(nn);
-      inv_applies = (T.mode >= 2) ? ((nrm > 1e-6f) ? 1.0f : 0.0f) : ((nrm > 0.0f) ? 1.0f : 0.0f);
+  for (int c0 = 0; c0 < T.d; c0 += kFeatCols) {
+    const int cols = (T.d - c0 < kFeatCols) ? T.d - c0 : kFeatCols;
+    for (int r = wave; r < rows; r += 4) {
+      const float* sp = T.src + s_s[r] + c0;
+      const float* fp = T.feat + s_f[r] + c0;
+      const float a = s_alpha[r];
+#pragma unroll 4
+      for (int k = lane; k < cols; k += 64) {
+        float v = sp[k];
+        if (ema) v = a * fp[k] + (1.0f - a) * v;  // botsort.cpp:163 / deepocsort.cpp:143
+        tile[r * RS + k] = v;
+      }
     }
-    for (int c0 = 0; c0 < T.d; c0 += kFeatChunk) {
-      // rows -> tile: two rows per step, 32 consecutive floats each
+    __syncthreads();
+    if (tid < rows) {
+      const float* row = tile + tid * RS;
 #pragma unroll 8
-      for (int r0 = 0; r0 < 64; r0 += 2) {  // (fixed trip count: unrollable, and the shuffles below read every lane's registers)
-        const int r = r0 + half;
-        const bool rv = r < rows;
-        const size_t fr = __shfl(static_cast<long long>(frow), rv ? r : 0, 64), sr = __shfl(static_cast<long long>(srow), rv ? r : 0, 64);
-        if (rv && c0 + cl < T.d) {
-          if (pass == 1 || T.mode == 1 || T.mode == 3) tf[r * (kFeatChunk + 1) + cl] = T.feat[fr + c0 + cl];
-          if (pass == 0) ts[r * (kFeatChunk + 1) + cl] = T.src[sr + c0 + cl];
-        }
+      for (int k = 0; k < cols; ++k) nn = __builtin_fmaf(row[k], row[k], nn);
+      if (c0 + cols >= T.d) {
+        const float nrm = sqrtf(nn);
+        const bool go = (T.mode >= 2) ? (nrm > 1e-6f) : (nrm > 0.0f);
+        s_nrm[tid] = go ? nrm : 0.0f;  // 0 = leave the row as it is
       }
-      __syncthreads();
-      if (active) {
-        for (int k = 0; k < kFeatChunk && c0 + k < T.d; ++k) {
-          float* e = &tf[lane * (kFeatChunk + 1) + k];
-          if (pass == 0) {
-            float v = ts[lane * (kFeatChunk + 1) + k];
-            if (T.mode == 1 || T.mode == 3) v = alpha * (*e) + (1.0f - alpha) * v;  // botsort.cpp:163 / deepocsort.cpp:143
-            *e = v;
-            nn = __builtin_fmaf(v, v, nn);
-          } else if (inv_applies != 0.0f) {
-            *e = *e / nrm;
-          }
-        }
+    }
+    __syncthreads();
+    for (int r = wave; r < rows; r += 4) {
+      float* fp = T.feat + s_f[r] + c0;
+      const float nrm = single ? s_nrm[r] : 0.0f;
+#pragma unroll 4
+      for (int k = lane; k < cols; k += 64) {
+        const float v = tile[r * RS + k];
+        fp[k] = (nrm != 0.0f) ? v / nrm : v;
       }
-      __syncthreads();
-#pragma unroll 8
-      for (int r0 = 0; r0 < 64; r0 += 2) {
-        const int r = r0 + half;
-        const bool rv = r < rows;
-        const size_t fr = __shfl(static_cast<long long>(frow), rv ? r : 0, 64);
-        if (rv && c0 + cl < T.d) T.feat[fr + c0 + cl] = tf[r * (kFeatChunk + 1) + cl];
-      }
-      __syncthreads();
+    }
+    __syncthreads();
+  }
+  if (!single) {  // long rows: the blended values were stored un-normalised; divide them now
+    for (int r = wave; r < rows; r += 4) {
+      const float nrm = s_nrm[r];
+      if (nrm == 0.0f) continue;
+      float* fp = T.feat + s_f[r];
+      for (int k = lane; k < T.d; k += 64) fp[k] = fp[k] / nrm;
     }
   }
 }
@@ -352,8 +363,8 @@ hipError_t launch_ocsort(const mot_ocsort_task* tasks, int ntasks, int max_nd, i
 }
 hipError_t launch_feat(const mot_feat_task* tasks, int ntasks, int max_n, hipStream_t st) {
   if (ntasks <= 0 || max_n <= 0) return hipSuccess;
-  dim3 grid((max_n + 63) / 64, ntasks);
-  hipLaunchKernelGGL(feat_kernel, grid, dim3(64), 0, st, tasks);
+  dim3 grid((max_n + kFeatRows - 1) / kFeatRows, ntasks);
+  hipLaunchKernelGGL(feat_kernel, grid, dim3(256), 0, st, tasks);
   return hipGetLastError();
 }
 }  // namespace mot

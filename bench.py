@@ -113,7 +113,7 @@ def main():
     W = args.warmup if args.warmup is not None else (1 if heavy else 40)
     if args.settle is None:
         args.settle = 5 if heavy else 30
-    on_device_wl = tracker in ("bytetrack", "sort") and args.lifecycle in ("auto", "device")
+    on_device_wl = tracker in ("bytetrack", "sort") and args.lifecycle in ("auto", "device")  # (host-input leg: detections only)
     Z = max(0, args.settle)
     H = max(0, args.host_input_steps) if on_device_wl else 0
     W0 = W            # the warm-up the caller asked for (reported); the settling frames are stepped before it
@@ -140,13 +140,16 @@ def main():
         args.pipeline = {"C2": 3, "SORT": 3, "NS": 3, "C5": 3, "C3": 3}.get(args.workload, 2)  # measured on MI355X
     PIPE = max(1, min(args.pipeline, S))
     bounds = [S * p // PIPE for p in range(PIPE + 1)]
-    on_device = tracker in ("bytetrack", "sort") and args.lifecycle in ("auto", "device")
+    on_device = tracker in ("bytetrack", "sort", "botsort") and args.lifecycle in ("auto", "device")
     if args.lifecycle == "device" and not on_device:
-        raise SystemExit("--lifecycle device exists for the ByteTrack and SORT workloads only")
+        raise SystemExit("--lifecycle device exists for the ByteTrack, SORT and BoT-SORT workloads only")
     if on_device:
         cap_tracks = (2 * P + 63) // 64 * 64  # tracked + lost never get near twice the object count (else mot_bt_step reports it)
-        Dev = L.DeviceByteTrack if tracker == "bytetrack" else L.DeviceSort
-        batches = [Dev(bounds[p + 1] - bounds[p], cap_tracks, M, device=local) for p in range(PIPE)]
+        if tracker == "botsort":
+            batches = [L.DeviceBotSort(bounds[p + 1] - bounds[p], cap_tracks, M, D, device=local) for p in range(PIPE)]
+        else:
+            Dev = L.DeviceByteTrack if tracker == "bytetrack" else L.DeviceSort
+            batches = [Dev(bounds[p + 1] - bounds[p], cap_tracks, M, device=local) for p in range(PIPE)]
         full_counts = [np.full(bounds[p + 1] - bounds[p], M, np.int32) for p in range(PIPE)]
     else:
         batches = [L.Batch(tracker, bounds[p + 1] - bounds[p], device=local, threads=max(1, threads // PIPE), record_laps=False,
@@ -155,8 +158,8 @@ def main():
     gathered = None
     # ByteTrack on the device: packed output (mot_bt_step_packed) — the emitted rows of a sub-batch back to back, so that only
     # rows that exist cross PCIe (a padded [S, 2M, 8] table is 2-4x the bytes) and no stream has a row limit
-    packed = on_device and tracker == "bytetrack"
-    rows_cap = [int((bounds[p + 1] - bounds[p]) * M * 1.25) + 64 for p in range(PIPE)]
+    packed = on_device and tracker in ("bytetrack", "botsort")
+    rows_cap = [int((bounds[p + 1] - bounds[p]) * (M if tracker == "bytetrack" else max(M, P)) * 1.25) + 64 for p in range(PIPE)]
     if packed:
         rows_p = [torch.zeros((rows_cap[p], 8), dtype=torch.float32).pin_memory().numpy() for p in range(PIPE)]
         tot_p = [0] * PIPE
@@ -182,6 +185,10 @@ def main():
 
     def sub_step(p, f):
         s0, s1 = bounds[p], bounds[p + 1]
+        if packed and tracker == "botsort":  # detections and raw embeddings resident: [S][6][M] and [S][M][D]
+            tot_p[p] = batches[p].step_packed(dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4, full_counts[p], rows_p[p], cnt_all[s0:s1],
+                                              embs_ptr=(dev_embs.data_ptr() + (f * S + s0) * M * D * 4) if D else None)
+            return
         if packed:
             tot_p[p] = batches[p].step_packed(dev_dets.data_ptr() + (f * S + s0) * 6 * M * 4, full_counts[p], rows_p[p], cnt_all[s0:s1])
             return
@@ -267,7 +274,13 @@ def main():
                             "high-score detections; then remaining tracked x low-score detections and unconfirmed x remaining detections)"}
     for b in batches:
         ps = b.profile_stats()
-        if on_device:  # the solver's launches are timed on the device stream; "frame" = all 14 launches of a frame
+        if on_device and tracker == "botsort":
+            ps = {"lap": {"ms": ps["lap_ms"], "launches": 2 * ps["frames"], "tasks": ps["lap_problems"], "bytes": 24.0 * ps["lap_nm"], "flops": 0.0},
+                  "cosine": {"ms": ps["cos_ms"], "launches": ps["frames"], "tasks": ps["frames"] * (bounds[1] - bounds[0]),
+                             "bytes": 0.0, "flops": 2.0 * ps["cos_nm"] * D},
+                  "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
+                                        "bytes": 0.0, "flops": 0.0}}
+        elif on_device:  # the solver's launches are timed on the device stream; "frame" = all 14 launches of a frame
             ps = {"lap": {"ms": ps["lap1_ms"] + ps["lap23_ms"], "launches": (2 if tracker == "bytetrack" else 1) * ps["frames"], "tasks": ps["lap1_problems"] + ps["lap23_problems"],
                           "bytes": 24.0 * (ps["lap1_nm"] + ps["lap23_nm"]), "flops": 0.0},
                   "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
@@ -439,7 +452,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "tracker": tracker, "tracks": P, "dets_per_frame": M, "emb_dim": D,
                    "streams_per_gpu": S, "frames_per_step": world * S, "settle_frames": Z, "host_threads": PIPE if on_device else threads, "sub_batches": PIPE,
-                   "lifecycle": "device (mot_bt_* / mot_sort_*: a fixed launch sequence per frame, no host decisions)" if on_device else "host stage machines",
+                   "lifecycle": "device (mot_bt_* / mot_sort_* / mot_bot_*: a fixed launch sequence per frame, no host decisions)" if on_device else "host stage machines",
                    "parallelism": f"{world} GPU(s) x {S} independent streams, lockstep stages",
                    "inputs": "detections (and embeddings) resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity,

@@ -344,6 +344,30 @@ int mot_bt_profile_dims(mot_bt_batch* b, double* out4);
  * 16 B box written per track), [2],[3] initiations, [4],[5] predict-first updates (one 288-byte record read and written) */
 int mot_bt_profile_kalman(mot_bt_batch* b, double* out6);
 
+/* ---- BoT-SORT with the per-stream lifecycle on the device -------------------------------- */
+/* Same contract as mot_bt_* for BotSort::update (src/trackers/botsort.cpp:260-764): S independent streams, one fixed launch
+ * sequence per frame, packed output rows [x1,y1,x2,y2,id,conf,cls,det_ind]. params10: [track_high_thresh, track_low_thresh,
+ * new_track_thresh, track_buffer, match_thresh, proximity_thresh, appearance_thresh, frame_rate, fuse_first_associate,
+ * with_reid] (botsort.hpp:108-144 defaults when NULL). emb_dim > 0 reserves the smooth-feature slab [S][cap_tracks][emb_dim].
+ * Per frame: d_dets SoA [S][6][max_dets] (device), h_counts [S] (host; a stream with 0 detections is left untouched,
+ * botsort.cpp:267-269), d_embs [S][max_dets][emb_dim] row-major raw detection features (device; NULL: no features this frame),
+ * h_warps6 [S][6] + h_has_warp [S]: the 2x3 camera-motion warp of streams that have one for this frame (what
+ * cmc_->apply(img, dets) returns, :317-324; NULL: none). mot_bot_dump: live tracks of stream s, tracked list then lost list:
+ * ids, mean [cap][8], cov [cap][64], feats [cap][emb_dim] (may be NULL), has_feat [cap] (may be NULL). */
+typedef struct mot_bot_batch mot_bot_batch;
+int mot_bot_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, int emb_dim, const float* params10, mot_bot_batch** out);
+void mot_bot_destroy(mot_bot_batch* b);
+int mot_bot_reset(mot_bot_batch* b);
+int mot_bot_step_packed(mot_bot_batch* b, const float* d_dets, const int* h_counts, const float* d_embs, const float* h_warps6,
+                        const unsigned char* h_has_warp, float* rows, int rows_cap, int* out_counts, int* total_rows);
+int mot_bot_device_output(mot_bot_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts);
+int mot_bot_dump(mot_bot_batch* b, int s, int* ids, float* mean, float* cov, float* feats, unsigned char* has_feat, int cap);
+/* HIP-event timing (enable = 1 resets). out8: [0] summed ms of the three assignment launches, [1] of the first cosine launch,
+ * [2] of whole frames, [3] frames, [4] assignment problems queued, [5] sum of their n + m, [6] sum of n*m over the cosine
+ * problems, [7] emb_dim */
+int mot_bot_profile(mot_bot_batch* b, int enable);
+int mot_bot_profile_stats(mot_bot_batch* b, double* out8);
+
 /* ---- SORT with the per-stream lifecycle on the device ----------------------------------- */
 /* Same contract as mot_bt_* for Sort::update (src/trackers/sort.cpp:102-255). params: [det_thresh, max_age, max_obs (unused),
  * min_hits, iou_threshold]. mot_sort_reset keeps the id counters running (sort.cpp:97-100). mot_sort_dump: mean [cap][7],

@@ -577,6 +577,106 @@ class DeviceByteTrack:
             self.ctx.close()
 
 
+class DeviceBotSort:
+    """S BoT-SORT streams whose whole per-frame lifecycle runs on the GPU (mot_bot_*, csrc/bot_device.hip).
+    params = [track_high, track_low, new_track, track_buffer, match_thresh, proximity, appearance, frame_rate, fuse_first, with_reid]."""
+
+    def __init__(self, nstreams, cap_tracks, max_dets, emb_dim=0, params=None, device=0):
+        self.ctx = Context(device)
+        self.lib = self.ctx.lib
+        self.S, self.CAP, self.D, self.E = int(nstreams), int(cap_tracks), int(max_dets), int(emb_dim)
+        p = f32(params if params is not None else [0.5, 0.1, 0.6, 30, 0.8, 0.5, 0.25, 30, 0, 1])
+        self.h = C.c_void_p()
+        self.lib.mot_bot_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        self.ctx._chk(self.lib.mot_bot_create(self.ctx.h, self.S, self.CAP, self.D, self.E, _p(p), C.byref(self.h)))
+        self.lib.mot_bot_step_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p]
+        self.lib.mot_bot_dump.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.lib.mot_bot_destroy.argtypes = [C.c_void_p]
+        self.lib.mot_bot_reset.argtypes = [C.c_void_p]
+        self.lib.mot_bot_profile.argtypes = [C.c_void_p, C.c_int]
+        self.lib.mot_bot_profile_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self._ddets = self._dembs = None
+        self._rows = self._cnt = None
+
+    def _dev(self, nbytes):
+        p = C.c_void_p()
+        self.ctx._chk(self.lib.mot_malloc(self.ctx.h, C.c_size_t(nbytes), C.byref(p)))
+        return p
+
+    def step_packed(self, dets_ptr, counts, rows, out_counts, embs_ptr=None, warps=None, has_warp=None):
+        """device pointers in (dets SoA [S][6][D], embs [S][D][E] or None), caller buffers out; returns the number of rows"""
+        counts = np.ascontiguousarray(counts, np.int32)
+        total = C.c_int(0)
+        w = f32(warps).reshape(self.S, 6) if warps is not None else None
+        hw = np.ascontiguousarray(has_warp, np.uint8) if has_warp is not None else None
+        self.ctx._chk(self.lib.mot_bot_step_packed(self.h, C.c_void_p(int(dets_ptr)), _p(counts), C.c_void_p(int(embs_ptr)) if embs_ptr else None,
+                                                   _p(w) if w is not None else None, _p(hw) if hw is not None else None, _p(rows),
+                                                   int(rows.shape[0]), _p(out_counts), C.byref(total)))
+        return total.value
+
+    def step(self, dets, counts, embs=None, warps=None, has_warp=None):
+        """host convenience: dets [S, N, 6] rows, embs [S, N, E] or None -> list of per-stream tables"""
+        dets = f32(dets)
+        n = dets.shape[1]
+        assert dets.shape[0] == self.S and n <= self.D
+        if self._ddets is None:
+            self._ddets = self._dev(self.S * 6 * self.D * 4)
+            self._rows = pinned_array(self.ctx, (self.S * self.CAP, 8), np.float32)
+            self._cnt = pinned_array(self.ctx, (self.S,), np.int32)
+        soa = np.zeros((self.S, 6, self.D), np.float32)
+        soa[:, :, :n] = dets.transpose(0, 2, 1)
+        self.ctx._chk(self.lib.mot_memcpy_h2d(self.ctx.h, self._ddets, _p(soa), C.c_size_t(soa.nbytes)))
+        eptr = None
+        if embs is not None and self.E:
+            if self._dembs is None:
+                self._dembs = self._dev(self.S * self.D * self.E * 4)
+            e = np.zeros((self.S, self.D, self.E), np.float32)
+            e[:, :n] = f32(embs)
+            self.ctx._chk(self.lib.mot_memcpy_h2d(self.ctx.h, self._dembs, _p(e), C.c_size_t(e.nbytes)))
+            eptr = self._dembs.value
+        self.ctx._chk(self.lib.mot_ctx_sync(self.ctx.h))
+        total = self.step_packed(self._ddets.value, counts, self._rows, self._cnt, eptr, warps, has_warp)
+        off = np.concatenate([[0], np.cumsum(self._cnt)])
+        assert off[-1] == total
+        return [self._rows[off[s]:off[s + 1]].copy() for s in range(self.S)]
+
+    def dump(self, s):
+        """(ids [n], mean [n,8], cov [n,8,8], feats [n,E], has_feat [n]) of stream s's live tracks, tracked list then lost list"""
+        cap = 2 * self.CAP
+        ids = np.zeros(cap, np.int32)
+        mean, cov = np.zeros((cap, 8), np.float32), np.zeros((cap, 64), np.float32)
+        feats = np.zeros((cap, max(self.E, 1)), np.float32)
+        has = np.zeros(cap, np.uint8)
+        n = self.lib.mot_bot_dump(self.h, int(s), _p(ids), _p(mean), _p(cov), _p(feats) if self.E else None, _p(has), cap)
+        if n < 0:
+            raise MotError("mot_bot_dump failed")
+        return ids[:n].copy(), mean[:n].copy(), cov[:n].reshape(-1, 8, 8).copy(), feats[:n, :self.E].copy(), has[:n].copy()
+
+    def device_output(self):
+        """(rows ptr, offsets ptr, counts ptr): device addresses of the last packed result (mot_bot_device_output)."""
+        r, o, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.lib.mot_bot_device_output.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_bot_device_output(self.h, C.byref(r), C.byref(o), C.byref(c)))
+        return r.value, o.value, c.value
+
+    def profile(self, on):
+        self.ctx._chk(self.lib.mot_bot_profile(self.h, 1 if on else 0))
+
+    def profile_stats(self):
+        o = np.zeros(8, np.float64)
+        self.ctx._chk(self.lib.mot_bot_profile_stats(self.h, _p(o)))
+        return {"lap_ms": o[0], "cos_ms": o[1], "frame_ms": o[2], "frames": int(o[3]), "lap_problems": o[4], "lap_nm": o[5], "cos_nm": o[6], "emb_dim": int(o[7])}
+
+    def reset(self):
+        self.ctx._chk(self.lib.mot_bot_reset(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.mot_bot_destroy(self.h)
+            self.h = None
+
+
 class DeviceSort:
     """S SORT streams with the whole per-frame lifecycle on the GPU (mot_sort_*, csrc/sort_device.hip).
     params = [det_thresh, max_age, max_obs, min_hits, iou_threshold]."""

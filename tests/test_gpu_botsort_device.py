@@ -1,0 +1,101 @@
+"""BoT-SORT with the lifecycle on the device (mot_bot_*, motcpp_amd/csrc/bot_device.hip) against the CPU oracle: output tables,
+track ids, the Kalman state and the smooth feature of every live track, bit for bit, on seeded streams with ragged and empty
+frames, with and without embeddings, with per-stream camera-motion warps."""
+import numpy as np
+import pytest
+
+from motcpp_amd import _lib as L
+from motcpp_amd.synth import SynthStream
+from tests import orclib
+
+pytestmark = pytest.mark.gpu
+
+
+def run(shapes, frames, cap, maxd, emb_dim=0, params=None, warps=False, check_states_every=5, empty_every=13):
+    orc = orclib.load()
+    S = len(shapes)
+    dev = L.DeviceBotSort(S, cap, maxd, emb_dim, params)
+    streams = [SynthStream(P, M, 4321 + i, emb_dim) for i, (P, M) in enumerate(shapes)]
+    oracles = [orc.tracker(orclib.BOTSORT, (list(params) + [30, 50]) if params else None) for _ in range(S)]
+    r = np.random.default_rng(9)
+    pan = np.zeros((S, 2), np.float32)
+    rows = 0
+    for f in range(frames):
+        dets = np.zeros((S, maxd, 6), np.float32)
+        embs = np.zeros((S, maxd, emb_dim), np.float32) if emb_dim else None
+        cnt = np.zeros(S, np.int32)
+        W = np.zeros((S, 6), np.float32)
+        hw = np.zeros(S, np.uint8)
+        per = []
+        for s, st in enumerate(streams):
+            d, e = st.next_frame()
+            if warps:  # a panning camera: detections move with it, the warp says by how much
+                step = r.uniform(-5, 5, 2).astype(np.float32)
+                pan[s] += step
+                d = d.copy()
+                d[:, [0, 2]] += pan[s, 0]
+                d[:, [1, 3]] += pan[s, 1]
+                if (f + s) % 3 != 2:
+                    k = np.float32(1.0 + r.uniform(-0.004, 0.004))
+                    W[s] = [k, 0.001, step[0], -0.001, k, step[1]]
+                    hw[s] = 1
+            if empty_every and (f + s) % empty_every == empty_every - 2:
+                d = d[:0]
+                e = e[:0] if e is not None else None
+            per.append((d, e))
+            cnt[s] = len(d)
+            dets[s, :len(d)] = d
+            if emb_dim:
+                embs[s, :len(d)] = e
+        tables = dev.step(dets, cnt, embs, W if warps else None, hw if warps else None)
+        for s in range(S):
+            d, e = per[s]
+            if warps and hw[s]:
+                oracles[s].set_camera_motion(W[s].reshape(2, 3))
+            oo = oracles[s].update(d, e if emb_dim else None)
+            assert tables[s].shape == oo.shape, (f, s, tables[s].shape, oo.shape)
+            assert np.array_equal(tables[s], oo), (f, s)
+            rows += oo.shape[0]
+            if f % check_states_every == check_states_every - 1:
+                ids, mean, cov, feats, has = dev.dump(s)
+                so = oracles[s].dump_states()
+                assert len(ids) == so.shape[0], (f, s)
+                if len(ids):
+                    assert np.array_equal(ids, so[:, 0].astype(np.int32)), (f, s)
+                    assert np.array_equal(mean, so[:, 1:9]), (f, s)
+                    assert np.array_equal(cov.reshape(len(ids), -1), so[:, 9:73]), (f, s)
+                if emb_dim:
+                    fo = oracles[s].dump_features()
+                    assert fo.shape[0] == len(ids)
+                    if fo.shape[1]:
+                        assert np.array_equal(feats[has != 0], fo[has != 0]), (f, s)
+    assert rows > 0
+    dev.close()
+
+
+def test_small_streams_with_embeddings():
+    run([(40, 30), (256, 128), (8, 8), (90, 64)], 45, 768, 128, emb_dim=64)
+
+
+def test_without_embeddings():
+    run([(120, 70), (30, 20), (200, 100)], 40, 512, 128)
+
+
+def test_reid_on_but_no_features_in_the_frames():
+    run([(60, 40), (100, 50)], 30, 512, 64, emb_dim=0, params=[0.5, 0.1, 0.6, 30, 0.8, 0.5, 0.25, 30, 0, 1])
+
+
+def test_camera_motion_per_stream():
+    run([(200, 110), (80, 50), (150, 90)], 50, 768, 128, emb_dim=32, warps=True, empty_every=11)
+
+
+def test_custom_thresholds_and_score_fusion():
+    run([(150, 80), (60, 60)], 40, 512, 128, emb_dim=16, params=[0.55, 0.15, 0.65, 20, 0.75, 0.6, 0.3, 25, 1, 1])
+
+
+def test_c3_shape():
+    run([(1024, 512)], 6, 2048, 512, emb_dim=256, empty_every=0)
+
+
+def test_long_run_recycles_slots():
+    run([(50, 30), (25, 20)], 220, 256, 64, emb_dim=8, params=[0.5, 0.1, 0.6, 5, 0.8, 0.5, 0.25, 30, 0, 1], check_states_every=20)

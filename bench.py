@@ -140,13 +140,15 @@ def main():
         args.pipeline = {"C2": 3, "SORT": 3, "NS": 3, "C5": 3, "C3": 3}.get(args.workload, 2)  # measured on MI355X
     PIPE = max(1, min(args.pipeline, S))
     bounds = [S * p // PIPE for p in range(PIPE + 1)]
-    on_device = tracker in ("bytetrack", "sort", "botsort") and args.lifecycle in ("auto", "device")
+    on_device = tracker in ("bytetrack", "sort", "botsort", "ocsort") and args.lifecycle in ("auto", "device")
     if args.lifecycle == "device" and not on_device:
-        raise SystemExit("--lifecycle device exists for the ByteTrack, SORT and BoT-SORT workloads only")
+        raise SystemExit("--lifecycle device exists for the ByteTrack, SORT, BoT-SORT and OC-SORT workloads only")
     if on_device:
         cap_tracks = (2 * P + 63) // 64 * 64  # tracked + lost never get near twice the object count (else mot_bt_step reports it)
         if tracker == "botsort":
             batches = [L.DeviceBotSort(bounds[p + 1] - bounds[p], cap_tracks, M, D, device=local) for p in range(PIPE)]
+        elif tracker == "ocsort":
+            batches = [L.DeviceOCSort(bounds[p + 1] - bounds[p], cap_tracks, M, device=local) for p in range(PIPE)]
         else:
             Dev = L.DeviceByteTrack if tracker == "bytetrack" else L.DeviceSort
             batches = [Dev(bounds[p + 1] - bounds[p], cap_tracks, M, device=local) for p in range(PIPE)]
@@ -158,7 +160,7 @@ def main():
     gathered = None
     # ByteTrack on the device: packed output (mot_bt_step_packed) — the emitted rows of a sub-batch back to back, so that only
     # rows that exist cross PCIe (a padded [S, 2M, 8] table is 2-4x the bytes) and no stream has a row limit
-    packed = on_device and tracker in ("bytetrack", "botsort")
+    packed = on_device and tracker in ("bytetrack", "botsort", "ocsort")
     rows_cap = [int((bounds[p + 1] - bounds[p]) * (M if tracker == "bytetrack" else max(M, P)) * 1.25) + 64 for p in range(PIPE)]
     if packed:
         rows_p = [torch.zeros((rows_cap[p], 8), dtype=torch.float32).pin_memory().numpy() for p in range(PIPE)]
@@ -274,7 +276,12 @@ def main():
                             "high-score detections; then remaining tracked x low-score detections and unconfirmed x remaining detections)"}
     for b in batches:
         ps = b.profile_stats()
-        if on_device and tracker == "botsort":
+        if on_device and tracker == "ocsort":
+            ps = {"lap": {"ms": ps["lap_ms"], "launches": ps["frames"], "tasks": ps["lap_problems"], "bytes": 4.0 * ps["lap_nm"], "flops": 0.0},
+                  "ocsort_cost": {"ms": ps["cost_ms"], "launches": ps["frames"], "tasks": ps["lap_problems"], "bytes": 8.0 * ps["lap_nm"], "flops": 0.0},
+                  "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
+                                        "bytes": 0.0, "flops": 0.0}}
+        elif on_device and tracker == "botsort":
             ps = {"lap": {"ms": ps["lap_ms"], "launches": 2 * ps["frames"], "tasks": ps["lap_problems"], "bytes": 24.0 * ps["lap_nm"], "flops": 0.0},
                   "cosine": {"ms": ps["cos_ms"], "launches": ps["frames"], "tasks": ps["frames"] * (bounds[1] - bounds[0]),
                              "bytes": 0.0, "flops": 2.0 * ps["cos_nm"] * D},
@@ -452,7 +459,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "tracker": tracker, "tracks": P, "dets_per_frame": M, "emb_dim": D,
                    "streams_per_gpu": S, "frames_per_step": world * S, "settle_frames": Z, "host_threads": PIPE if on_device else threads, "sub_batches": PIPE,
-                   "lifecycle": "device (mot_bt_* / mot_sort_* / mot_bot_*: a fixed launch sequence per frame, no host decisions)" if on_device else "host stage machines",
+                   "lifecycle": "device (mot_bt_* / mot_sort_* / mot_bot_* / mot_oc_*: a fixed launch sequence per frame, no host decisions)" if on_device else "host stage machines",
                    "parallelism": f"{world} GPU(s) x {S} independent streams, lockstep stages",
                    "inputs": "detections (and embeddings) resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity,

@@ -66,13 +66,16 @@ class DeviceLifecycleBatch {
   virtual ~DeviceLifecycleBatch();
   DeviceLifecycleBatch(const DeviceLifecycleBatch&) = delete;
   DeviceLifecycleBatch& operator=(const DeviceLifecycleBatch&) = delete;
-  // dets[s]: N_s x 6 column-major [x1,y1,x2,y2,conf,cls]; returns per-stream M_s x 8 tables [x1,y1,x2,y2,id,conf,cls,det_ind]
-  std::vector<Eigen::MatrixXf> update(const std::vector<Eigen::MatrixXf>& dets);
+  // dets[s]: N_s x 6 column-major [x1,y1,x2,y2,conf,cls]; returns per-stream M_s x 8 tables [x1,y1,x2,y2,id,conf,cls,det_ind].
+  // BoT-SORT batches also take embs[s] (N_s x emb_dim, one row per detection; empty vector: no features this frame) and
+  // warps[s] (2 x 3 camera-motion warp of stream s for this frame, or a 0 x 0 matrix for none; empty vector: none at all).
+  std::vector<Eigen::MatrixXf> update(const std::vector<Eigen::MatrixXf>& dets, const std::vector<Eigen::MatrixXf>& embs = {},
+                                      const std::vector<Eigen::MatrixXf>& warps = {});
   void reset();
   size_t size() const { return static_cast<size_t>(n_); }
 
  protected:
-  DeviceLifecycleBatch(int kind, int nstreams, int cap_tracks, int max_dets, const float params[5], int device_index);
+  DeviceLifecycleBatch(int kind, int nstreams, int cap_tracks, int max_dets, const float* params, int device_index, int emb_dim = 0);
 
  private:
   struct Impl;
@@ -91,6 +94,24 @@ class SortDeviceBatch : public DeviceLifecycleBatch {
  public:
   SortDeviceBatch(int nstreams, int cap_tracks, int max_dets, float det_thresh = 0.3f, int max_age = 1, int min_hits = 3,
                   float iou_threshold = 0.3f, int device_index = 0);
+};
+
+// trackers::OCSort on the device (C ABI: mot_oc_*, motcpp_amd/csrc/oc_device.hip); asso_func as in OCSort ("iou", "hmiou", "giou", ...)
+class OCSortDeviceBatch : public DeviceLifecycleBatch {
+ public:
+  OCSortDeviceBatch(int nstreams, int cap_tracks, int max_dets, float det_thresh = 0.2f, int max_age = 30, int min_hits = 3,
+                    float iou_threshold = 0.3f, float min_conf = 0.1f, int delta_t = 3, float inertia = 0.2f, bool use_byte = false,
+                    float Q_xy_scaling = 0.01f, float Q_s_scaling = 0.0001f, const std::string& asso_func = "iou", int frame_width = 1920,
+                    int frame_height = 1080, int device_index = 0);
+};
+
+// trackers::BotSort on the device (C ABI: mot_bot_*, motcpp_amd/csrc/bot_device.hip); emb_dim = 0: no appearance features
+class BotSortDeviceBatch : public DeviceLifecycleBatch {
+ public:
+  BotSortDeviceBatch(int nstreams, int cap_tracks, int max_dets, int emb_dim, float track_high_thresh = 0.5f, float track_low_thresh = 0.1f,
+                     float new_track_thresh = 0.6f, int track_buffer = 30, float match_thresh = 0.8f, float proximity_thresh = 0.5f,
+                     float appearance_thresh = 0.25f, int frame_rate = 30, bool fuse_first_associate = false, bool with_reid = true,
+                     int device_index = 0);
 };
 
 }  // namespace motcpp

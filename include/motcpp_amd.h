@@ -368,6 +368,26 @@ int mot_bot_dump(mot_bot_batch* b, int s, int* ids, float* mean, float* cov, flo
 int mot_bot_profile(mot_bot_batch* b, int enable);
 int mot_bot_profile_stats(mot_bot_batch* b, double* out8);
 
+/* ---- OC-SORT with the per-stream lifecycle on the device --------------------------------- */
+/* Same contract as mot_bt_* for OCSort::update (src/trackers/ocsort.cpp:285-606): S independent streams, one fixed launch
+ * sequence per frame (predict, NaN-row rule, IoU + velocity-direction cost, trivial-case shortcut or lapjv, optional BYTE
+ * stage, observation-centric rematch, spawns, Kalman updates, output rows newest tracker first), packed output rows
+ * [x1,y1,x2,y2,id,conf,cls,det_ind]. params14: [det_thresh, max_age, max_obs (unused), min_hits, iou_threshold, min_conf,
+ * delta_t, inertia, use_byte, Q_xy_scaling, Q_s_scaling, asso (mot_assoc), frame_w, frame_h] (ocsort.hpp:88-108 defaults when
+ * NULL). A track that quirk Q4 has updated more than 4 times in one frame raises MOT_ERR_CAPACITY (never observed).
+ * mot_oc_dump: the tracker list of stream s in list order: ids, mean [cap][7], cov [cap][49]. */
+typedef struct mot_oc_batch mot_oc_batch;
+int mot_oc_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, const float* params14, mot_oc_batch** out);
+void mot_oc_destroy(mot_oc_batch* b);
+int mot_oc_reset(mot_oc_batch* b);
+int mot_oc_step_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts, float* rows, int rows_cap, int* out_counts, int* total_rows);
+int mot_oc_device_output(mot_oc_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts);
+int mot_oc_dump(mot_oc_batch* b, int s, int* ids, float* mean, float* cov, int cap);
+/* out8: [0] summed ms of the first-association assignment launches, [1] of the cost-matrix launches, [2] of whole frames,
+ * [3] frames, [4] first-association problems queued, [5] sum of their n*m */
+int mot_oc_profile(mot_oc_batch* b, int enable);
+int mot_oc_profile_stats(mot_oc_batch* b, double* out8);
+
 /* ---- SORT with the per-stream lifecycle on the device ----------------------------------- */
 /* Same contract as mot_bt_* for Sort::update (src/trackers/sort.cpp:102-255). params: [det_thresh, max_age, max_obs (unused),
  * min_hits, iou_threshold]. mot_sort_reset keeps the id counters running (sort.cpp:97-100). mot_sort_dump: mean [cap][7],

@@ -677,6 +677,85 @@ class DeviceBotSort:
             self.h = None
 
 
+class DeviceOCSort:
+    """S OC-SORT streams whose whole per-frame lifecycle runs on the GPU (mot_oc_*, csrc/oc_device.hip).
+    params = [det_thresh, max_age, max_obs, min_hits, iou_threshold, min_conf, delta_t, inertia, use_byte, Q_xy, Q_s, asso, w, h]."""
+
+    def __init__(self, nstreams, cap_tracks, max_dets, params=None, device=0):
+        self.ctx = Context(device)
+        self.lib = self.ctx.lib
+        self.S, self.CAP, self.D = int(nstreams), int(cap_tracks), int(max_dets)
+        p = f32(params if params is not None else [0.2, 30, 50, 3, 0.3, 0.1, 3, 0.2, 0, 0.01, 0.0001, 0, 1920, 1080])
+        self.h = C.c_void_p()
+        self.lib.mot_oc_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        self.ctx._chk(self.lib.mot_oc_create(self.ctx.h, self.S, self.CAP, self.D, _p(p), C.byref(self.h)))
+        self.lib.mot_oc_step_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.lib.mot_oc_dump.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.lib.mot_oc_destroy.argtypes = [C.c_void_p]
+        self.lib.mot_oc_reset.argtypes = [C.c_void_p]
+        self.lib.mot_oc_profile.argtypes = [C.c_void_p, C.c_int]
+        self.lib.mot_oc_profile_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self._ddets = None
+
+    def step_packed(self, dets_ptr, counts, rows, out_counts):
+        counts = np.ascontiguousarray(counts, np.int32)
+        total = C.c_int(0)
+        self.ctx._chk(self.lib.mot_oc_step_packed(self.h, C.c_void_p(int(dets_ptr)), _p(counts), _p(rows), int(rows.shape[0]), _p(out_counts),
+                                                  C.byref(total)))
+        return total.value
+
+    def step(self, dets, counts):
+        """host convenience: dets [S, N, 6] rows -> list of per-stream tables"""
+        dets = f32(dets)
+        n = dets.shape[1]
+        assert dets.shape[0] == self.S and n <= self.D
+        if self._ddets is None:
+            self._ddets = C.c_void_p()
+            self.ctx._chk(self.lib.mot_malloc(self.ctx.h, C.c_size_t(self.S * 6 * self.D * 4), C.byref(self._ddets)))
+            self._rows = pinned_array(self.ctx, (self.S * self.CAP, 8), np.float32)
+            self._cnt = pinned_array(self.ctx, (self.S,), np.int32)
+        soa = np.zeros((self.S, 6, self.D), np.float32)
+        soa[:, :, :n] = dets.transpose(0, 2, 1)
+        self.ctx._chk(self.lib.mot_memcpy_h2d(self.ctx.h, self._ddets, _p(soa), C.c_size_t(soa.nbytes)))
+        self.ctx._chk(self.lib.mot_ctx_sync(self.ctx.h))
+        total = self.step_packed(self._ddets.value, counts, self._rows, self._cnt)
+        off = np.concatenate([[0], np.cumsum(self._cnt)])
+        assert off[-1] == total
+        return [self._rows[off[s]:off[s + 1]].copy() for s in range(self.S)]
+
+    def device_output(self):
+        r, o, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.lib.mot_oc_device_output.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_oc_device_output(self.h, C.byref(r), C.byref(o), C.byref(c)))
+        return r.value, o.value, c.value
+
+    def dump(self, s):
+        """(ids [n], mean [n,7], cov [n,7,7]) of stream s's trackers in list order"""
+        cap = self.CAP
+        ids = np.zeros(cap, np.int32)
+        mean, cov = np.zeros((cap, 7), np.float32), np.zeros((cap, 49), np.float32)
+        n = self.lib.mot_oc_dump(self.h, int(s), _p(ids), _p(mean), _p(cov), cap)
+        if n < 0:
+            raise MotError("mot_oc_dump failed")
+        return ids[:n].copy(), mean[:n].copy(), cov[:n].reshape(-1, 7, 7).copy()
+
+    def profile(self, on):
+        self.ctx._chk(self.lib.mot_oc_profile(self.h, 1 if on else 0))
+
+    def profile_stats(self):
+        o = np.zeros(8, np.float64)
+        self.ctx._chk(self.lib.mot_oc_profile_stats(self.h, _p(o)))
+        return {"lap_ms": o[0], "cost_ms": o[1], "frame_ms": o[2], "frames": int(o[3]), "lap_problems": o[4], "lap_nm": o[5]}
+
+    def reset(self):
+        self.ctx._chk(self.lib.mot_oc_reset(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.mot_oc_destroy(self.h)
+            self.h = None
+
+
 class DeviceSort:
     """S SORT streams with the whole per-frame lifecycle on the GPU (mot_sort_*, csrc/sort_device.hip).
     params = [det_thresh, max_age, max_obs, min_hits, iou_threshold]."""

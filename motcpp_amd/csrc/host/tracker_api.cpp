@@ -254,40 +254,69 @@ void BotSort::set_camera_motion(const Eigen::MatrixXf& warp) {
 }
 }  // namespace trackers
 
-// ---- DeviceLifecycleBatch: ByteTrack (mot_bt_*) and SORT (mot_sort_*) with the lifecycle on the device ----------
+// ---- DeviceLifecycleBatch: ByteTrack (mot_bt_*), SORT (mot_sort_*), OC-SORT (mot_oc_*), BoT-SORT (mot_bot_*) on the device ----------
 struct DeviceLifecycleBatch::Impl {
   std::shared_ptr<rt::Device> dev;
-  int kind = 0;  // 0 ByteTrack, 1 SORT
+  int kind = 0;  // 0 ByteTrack, 1 SORT, 2 OC-SORT, 3 BoT-SORT
+  int emb_dim = 0;
   mot_bt_batch* bt = nullptr;
   mot_sort_batch* so = nullptr;
+  mot_oc_batch* oc = nullptr;
+  mot_bot_batch* bot = nullptr;
   void* d_dets = nullptr;
-  std::vector<float> soa, out;
+  void* d_embs = nullptr;
+  std::vector<float> soa, out, embs, warps;
+  std::vector<unsigned char> has_warp;
   std::vector<int> counts, out_counts;
 };
-DeviceLifecycleBatch::DeviceLifecycleBatch(int kind, int nstreams, int cap_tracks, int max_dets, const float p[5], int device_index)
+DeviceLifecycleBatch::DeviceLifecycleBatch(int kind, int nstreams, int cap_tracks, int max_dets, const float* p, int device_index, int emb_dim)
     : impl_(std::make_unique<Impl>()), n_(nstreams), cap_(cap_tracks), maxd_(max_dets) {
   impl_->dev = rt::Device::shared(device_index);
   impl_->kind = kind;
+  impl_->emb_dim = emb_dim;
   mot_ctx* ctx = impl_->dev->ctx;
-  const int rc = kind == 0 ? mot_bt_create(ctx, nstreams, cap_tracks, max_dets, p, &impl_->bt) : mot_sort_create(ctx, nstreams, cap_tracks, max_dets, p, &impl_->so);
+  std::lock_guard<std::mutex> dev_lock(impl_->dev->frame_mu);
+  int rc = MOT_ERR_INVALID;
+  if (kind == 0) rc = mot_bt_create(ctx, nstreams, cap_tracks, max_dets, p, &impl_->bt);
+  else if (kind == 1) rc = mot_sort_create(ctx, nstreams, cap_tracks, max_dets, p, &impl_->so);
+  else if (kind == 2) rc = mot_oc_create(ctx, nstreams, cap_tracks, max_dets, p, &impl_->oc);
+  else if (kind == 3) rc = mot_bot_create(ctx, nstreams, cap_tracks, max_dets, emb_dim, p, &impl_->bot);
   if (rc != MOT_OK) throw std::runtime_error(std::string("motcpp_amd: device-lifecycle batch creation failed: ") + mot_ctx_last_error(ctx));
   impl_->soa.assign(static_cast<size_t>(nstreams) * 6 * max_dets, 0.f);
   impl_->counts.assign(nstreams, 0);
   impl_->out_counts.assign(nstreams, 0);
   if (mot_malloc(ctx, impl_->soa.size() * sizeof(float), &impl_->d_dets) != MOT_OK) throw std::runtime_error("motcpp_amd: device allocation failed");
+  if (kind == 3 && emb_dim > 0) {
+    impl_->embs.assign(static_cast<size_t>(nstreams) * max_dets * emb_dim, 0.f);
+    if (mot_malloc(ctx, impl_->embs.size() * sizeof(float), &impl_->d_embs) != MOT_OK) throw std::runtime_error("motcpp_amd: device allocation failed");
+  }
 }
 DeviceLifecycleBatch::~DeviceLifecycleBatch() {
   if (impl_->bt) mot_bt_destroy(impl_->bt);
   if (impl_->so) mot_sort_destroy(impl_->so);
+  if (impl_->oc) mot_oc_destroy(impl_->oc);
+  if (impl_->bot) mot_bot_destroy(impl_->bot);
   if (impl_->d_dets) mot_free(impl_->dev->ctx, impl_->d_dets);
+  if (impl_->d_embs) mot_free(impl_->dev->ctx, impl_->d_embs);
 }
 void DeviceLifecycleBatch::reset() {
-  const int rc = impl_->kind == 0 ? mot_bt_reset(impl_->bt) : mot_sort_reset(impl_->so);
+  std::lock_guard<std::mutex> dev_lock(impl_->dev->frame_mu);
+  int rc = MOT_OK;
+  if (impl_->bt) rc = mot_bt_reset(impl_->bt);
+  if (impl_->so) rc = mot_sort_reset(impl_->so);
+  if (impl_->oc) rc = mot_oc_reset(impl_->oc);
+  if (impl_->bot) rc = mot_bot_reset(impl_->bot);
   if (rc != MOT_OK) throw std::runtime_error(mot_ctx_last_error(impl_->dev->ctx));
 }
-std::vector<Eigen::MatrixXf> DeviceLifecycleBatch::update(const std::vector<Eigen::MatrixXf>& dets) {
+std::vector<Eigen::MatrixXf> DeviceLifecycleBatch::update(const std::vector<Eigen::MatrixXf>& dets, const std::vector<Eigen::MatrixXf>& embs,
+                                                          const std::vector<Eigen::MatrixXf>& warps) {
   if (static_cast<int>(dets.size()) != n_) throw std::invalid_argument("device-lifecycle batch: one detection matrix per stream");
   Impl& I = *impl_;
+  const bool use_embs = I.kind == 3 && I.emb_dim > 0 && !embs.empty();
+  const bool use_warps = I.kind == 3 && !warps.empty();
+  if ((!embs.empty() || !warps.empty()) && I.kind != 3) throw std::invalid_argument("device-lifecycle batch: only BoT-SORT takes embeddings / camera-motion warps");
+  if (use_embs && static_cast<int>(embs.size()) != n_) throw std::invalid_argument("device-lifecycle batch: one embedding matrix per stream");
+  if (use_warps && static_cast<int>(warps.size()) != n_) throw std::invalid_argument("device-lifecycle batch: one warp (or an empty matrix) per stream");
   for (int s = 0; s < n_; ++s) {
     const Eigen::MatrixXf& d = dets[s];
     const int n = static_cast<int>(d.rows());
@@ -297,29 +326,58 @@ std::vector<Eigen::MatrixXf> DeviceLifecycleBatch::update(const std::vector<Eige
     float* dst = I.soa.data() + static_cast<size_t>(s) * 6 * maxd_;
     for (int k = 0; k < 6; ++k)  // a column-major N x 6 matrix IS the SoA layout
       if (n > 0) std::memcpy(dst + static_cast<size_t>(k) * maxd_, d.data() + static_cast<size_t>(k) * n, sizeof(float) * n);
+    if (use_embs) {
+      const Eigen::MatrixXf& e = embs[s];
+      if (n > 0 && (e.rows() != n || e.cols() != I.emb_dim)) throw std::invalid_argument("device-lifecycle batch: embeddings must be N x emb_dim, one row per detection");
+      float* ed = I.embs.data() + static_cast<size_t>(s) * maxd_ * I.emb_dim;
+      for (int i = 0; i < n; ++i)
+        for (int k = 0; k < I.emb_dim; ++k) ed[static_cast<size_t>(i) * I.emb_dim + k] = e(i, k);
+    }
   }
+  if (use_warps) {
+    I.warps.assign(static_cast<size_t>(n_) * 6, 0.f);
+    I.has_warp.assign(n_, 0);
+    for (int s = 0; s < n_; ++s) {
+      const Eigen::MatrixXf& w = warps[s];
+      if (w.rows() == 0 && w.cols() == 0) continue;
+      if (w.rows() != 2 || w.cols() != 3) throw std::invalid_argument("device-lifecycle batch: a camera-motion warp is 2 x 3");
+      for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) I.warps[static_cast<size_t>(s) * 6 + r * 3 + c] = w(r, c);
+      I.has_warp[s] = 1;
+    }
+  }
+  std::lock_guard<std::mutex> dev_lock(I.dev->frame_mu);  // the context's stream is shared with the other trackers of this GPU
   mot_ctx* ctx = I.dev->ctx;
   if (mot_memcpy_h2d(ctx, I.d_dets, I.soa.data(), I.soa.size() * sizeof(float)) != MOT_OK) throw std::runtime_error(mot_ctx_last_error(ctx));
+  if (use_embs && mot_memcpy_h2d(ctx, I.d_embs, I.embs.data(), I.embs.size() * sizeof(float)) != MOT_OK) throw std::runtime_error(mot_ctx_last_error(ctx));
   const int cap_out = cap_;  // a stream never reports more rows than it has tracks
   I.out.resize(static_cast<size_t>(n_) * cap_out * 8);
   const float* dd = static_cast<const float*>(I.d_dets);
-  const int rc = I.kind == 0 ? mot_bt_step(I.bt, dd, I.counts.data(), I.out.data(), I.out_counts.data(), cap_out)
-                             : mot_sort_step(I.so, dd, I.counts.data(), I.out.data(), I.out_counts.data(), cap_out);
+  int rc = MOT_OK, total = 0;
+  const bool packed = I.kind >= 2;
+  if (I.kind == 0) rc = mot_bt_step(I.bt, dd, I.counts.data(), I.out.data(), I.out_counts.data(), cap_out);
+  else if (I.kind == 1) rc = mot_sort_step(I.so, dd, I.counts.data(), I.out.data(), I.out_counts.data(), cap_out);
+  else if (I.kind == 2) rc = mot_oc_step_packed(I.oc, dd, I.counts.data(), I.out.data(), n_ * cap_out, I.out_counts.data(), &total);
+  else rc = mot_bot_step_packed(I.bot, dd, I.counts.data(), use_embs ? static_cast<const float*>(I.d_embs) : nullptr,
+                                use_warps ? I.warps.data() : nullptr, use_warps ? I.has_warp.data() : nullptr, I.out.data(), n_ * cap_out,
+                                I.out_counts.data(), &total);
   if (rc != MOT_OK) throw std::runtime_error(std::string("motcpp_amd: device-lifecycle step failed: ") + mot_ctx_last_error(ctx));
   std::vector<Eigen::MatrixXf> res;
   res.reserve(n_);
+  size_t off = 0;
   for (int s = 0; s < n_; ++s) {
     const int m = I.out_counts[s];
     Eigen::MatrixXf t(m, 8);
-    const float* rows = I.out.data() + static_cast<size_t>(s) * cap_out * 8;
+    const float* rows = packed ? I.out.data() + off * 8 : I.out.data() + static_cast<size_t>(s) * cap_out * 8;
     for (int i = 0; i < m; ++i)
       for (int k = 0; k < 8; ++k) t(i, k) = rows[static_cast<size_t>(i) * 8 + k];
+    off += static_cast<size_t>(m);
     res.push_back(std::move(t));
   }
   return res;
 }
 namespace {
 struct P5 { float v[5]; };
+struct P14 { float v[14]; };
 }
 ByteTrackDeviceBatch::ByteTrackDeviceBatch(int nstreams, int cap_tracks, int max_dets, float min_conf, float track_thresh, float match_thresh,
                                            int track_buffer, int frame_rate, int device_index)
@@ -329,6 +387,25 @@ SortDeviceBatch::SortDeviceBatch(int nstreams, int cap_tracks, int max_dets, flo
                                  int device_index)
     : DeviceLifecycleBatch(1, nstreams, cap_tracks, max_dets,
                            P5{{det_thresh, static_cast<float>(max_age), 50.f, static_cast<float>(min_hits), iou_threshold}}.v, device_index) {}
+namespace {
+float asso_or_throw(const std::string& name) {
+  const int k = rt::asso_kind(name);
+  if (k < 0) throw std::invalid_argument("Invalid or unsupported association function: " + name);
+  return static_cast<float>(k);
+}
+}  // namespace
+OCSortDeviceBatch::OCSortDeviceBatch(int nstreams, int cap_tracks, int max_dets, float det_thresh, int max_age, int min_hits, float iou_threshold,
+                                     float min_conf, int delta_t, float inertia, bool use_byte, float q_xy, float q_s, const std::string& asso_func,
+                                     int frame_width, int frame_height, int device_index)
+    : DeviceLifecycleBatch(2, nstreams, cap_tracks, max_dets,
+                           P14{{det_thresh, static_cast<float>(max_age), 50.f, static_cast<float>(min_hits), iou_threshold, min_conf,
+                                static_cast<float>(delta_t), inertia, use_byte ? 1.f : 0.f, q_xy, q_s, asso_or_throw(asso_func),
+                                static_cast<float>(frame_width), static_cast<float>(frame_height)}}.v, device_index) {}
+BotSortDeviceBatch::BotSortDeviceBatch(int nstreams, int cap_tracks, int max_dets, int emb_dim, float hi, float lo, float newt, int track_buffer,
+                                       float match, float prox, float app, int frame_rate, bool fuse_first, bool with_reid, int device_index)
+    : DeviceLifecycleBatch(3, nstreams, cap_tracks, max_dets,
+                           P14{{hi, lo, newt, static_cast<float>(track_buffer), match, prox, app, static_cast<float>(frame_rate),
+                                fuse_first ? 1.f : 0.f, with_reid ? 1.f : 0.f, 0.f, 0.f, 0.f, 0.f}}.v, device_index, emb_dim) {}
 
 // ---- utils:: primitive seam ----------------------------------------------------------------------
 namespace utils {

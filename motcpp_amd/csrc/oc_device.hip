@@ -1,0 +1,823 @@
+// OC-SORT with the per-stream lifecycle ON THE DEVICE (reference: src/trackers/ocsort.cpp:285-738; the host-side stage machine
+// with the same semantics is host/ocsort.cpp).
+//
+// Same construction as bt_device.hip / bot_device.hip: the tracker list is an array of Kalman slots in the reference's order,
+// per-track records (age, hits, hit streak, last observation, the observation history that k_previous_obs looks into, the
+// velocity direction) are indexed by slot, and the reference's bookkeeping runs in small kernels (one wavefront per stream)
+// between the numeric ones. A frame of S streams is a FIXED launch sequence:
+//   oc_begin -> det_prepare, kf_predict (x6 clamp, in place) -> oc_nan (NaN-row rule, velocity / k-previous-observation planes)
+//   -> ocsort cost matrix -> assignment 1 (trivial-case shortcut or lapjv) -> oc_after_first (IoU filter, quirk Q4)
+//   [-> assignment BYTE -> oc_after_byte] -> assignment OCR (last observations, -IoU, min gate) -> oc_finish (spawns, update
+//   rounds, rows) -> kf_initiate, kf_update x kRounds, kf_boxes -> oc_emit (output rows newest first, age-out).
+// Quirk Q4 (ocsort.cpp:699-714 + :716-727): a pair the assignment made but the IoU filter rejects puts its detection and its
+// track on the unmatched lists TWICE; the lists therefore carry repeats, a track can be updated more than once in a frame (in
+// list order: the Kalman updates run in kRounds sequential launches, a slot's r-th update of the frame in launch r) and a
+// detection left over twice spawns two tracks.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lifecycle_common.hpp"
+
+namespace mot {
+hipError_t launch_ocsort(const mot_ocsort_task*, int, int, int, bool, hipStream_t);
+}
+
+namespace {
+using mot::lifecycle::compact;
+using mot::lifecycle::kW;
+
+constexpr int kRounds = 4;  // Kalman updates one slot can receive in a frame before the stream reports an error
+
+struct OcParams {
+  float det_thresh, thr, min_conf, inertia, frame_diag;
+  int max_age, min_hits, delta_t, use_byte, asso, K;
+};
+
+struct OcStream {
+  // ---- persistent ----
+  int frame_count, next_id, next_slot, n_free, n_trk, cur, err;
+  int* free_stack;
+  int* trk[2];
+  int *t_id, *t_age, *t_hits, *t_streak, *t_tsu, *t_cls, *t_det, *t_nobs, *t_need;
+  float *t_conf, *t_last, *t_vel;  // [CAP], [CAP][5], [CAP][2]
+  int* t_oage;                      // [CAP][K]
+  float* t_obs;                     // [CAP][K][5]
+  // ---- frame ----
+  const float* dets; int ld, n;
+  int *high, *second; int n_high, n_second;
+  int nt0, silent, lap1_q, byte_q, rem_q;
+  float *pbox, *vel, *prev, *lbox, *sbox;  // [4][CAP], [2][CAP], [5][CAP], [4][CAP], [4][CAP]
+  int *x1, *y1, *xb, *yb, *xr, *yr;
+  float *xval1, *xvalb, *xvalr;
+  int *info1, *infob, *infor;
+  unsigned char *md, *mt, *rm_d, *rm_t;
+  int *um_dets, *um_trks; int n_umd, n_umt;
+  int* left;
+  int *upd_slot, *upd_meas, *upd_round; int n_upd;
+  int* slot_cnt;
+  int *init_dst, *init_meas; int n_init;
+  int* need_slot; int n_need;
+  int* r_slot[kRounds]; int* r_meas[kRounds];
+};
+
+struct OcTasks {
+  mot_det_task* det;
+  mot_kf_task *pred, *init, *upd /*[kRounds][S]*/, *sbox;
+  mot_ocsort_task* cost;
+  mot_lap_task *lap1, *lapb, *lapr;
+};
+
+// k_previous_obs, ocsort.cpp:24-51: the observation made at age - k, else age - k + 1, ..., else the newest one
+__device__ __forceinline__ void k_previous(const OcStream& S, int K, int slot, int k, float out[5]) {
+  const int n = S.t_nobs[slot];
+  if (n == 0) { for (int c = 0; c < 5; ++c) out[c] = -1.0f; return; }
+  const int age = S.t_age[slot];
+  const int* oa = S.t_oage + static_cast<size_t>(slot) * K;
+  const float* ob = S.t_obs + static_cast<size_t>(slot) * K * 5;
+  for (int i = 0; i < k; ++i) {
+    const int key = age - (k - i);
+    for (int q = 0; q < n; ++q)
+      if (oa[q] == key) { for (int c = 0; c < 5; ++c) out[c] = ob[q * 5 + c]; return; }
+  }
+  for (int c = 0; c < 5; ++c) out[c] = ob[(n - 1) * 5 + c];
+}
+__device__ __forceinline__ void speed_direction(const float* b1, const float* b2, float out[2]) {  // :160-172
+  const float cx1 = (b1[0] + b1[2]) / 2.0f, cy1 = (b1[1] + b1[3]) / 2.0f;
+  const float cx2 = (b2[0] + b2[2]) / 2.0f, cy2 = (b2[1] + b2[3]) / 2.0f;
+  const float dy = cy2 - cy1, dx = cx2 - cx1;
+  const float norm = sqrtf(dy * dy + dx * dx) + 1e-6f;
+  out[0] = dy / norm; out[1] = dx / norm;
+}
+// KalmanBoxTracker::update :89-130 without the Kalman part (queued by the caller)
+__device__ __forceinline__ void apply(OcStream& S, const OcParams& P, int slot, int det) {
+  S.t_det[slot] = det;
+  const float conf = S.dets[static_cast<size_t>(4) * S.ld + det];
+  S.t_conf[slot] = conf;
+  S.t_cls[slot] = static_cast<int>(S.dets[static_cast<size_t>(5) * S.ld + det]);
+  float b[4];
+  for (int k = 0; k < 4; ++k) b[k] = S.dets[static_cast<size_t>(k) * S.ld + det];
+  float* last = S.t_last + static_cast<size_t>(slot) * 5;
+  const float ls = last[0] + last[1] + last[2] + last[3];
+  if (ls >= 0) {
+    float pb[5], v[2];
+    k_previous(S, P.K, slot, P.delta_t, pb);
+    if (pb[0] + pb[1] + pb[2] + pb[3] >= 0) speed_direction(pb, b, v);
+    else speed_direction(last, b, v);
+    S.t_vel[slot * 2] = v[0]; S.t_vel[slot * 2 + 1] = v[1];
+  }
+  for (int k = 0; k < 4; ++k) last[k] = b[k];
+  last[4] = conf;
+  int n = S.t_nobs[slot];
+  int* oa = S.t_oage + static_cast<size_t>(slot) * P.K;
+  float* ob = S.t_obs + static_cast<size_t>(slot) * P.K * 5;
+  const int age = S.t_age[slot];
+  if (n > 0 && oa[n - 1] == age) {
+    for (int c = 0; c < 5; ++c) ob[(n - 1) * 5 + c] = last[c];
+  } else {
+    if (n == P.K) {  // keep the newest delta_t + 2 entries (older ones are never looked up)
+      for (int q = 1; q < n; ++q) { oa[q - 1] = oa[q]; for (int c = 0; c < 5; ++c) ob[(q - 1) * 5 + c] = ob[q * 5 + c]; }
+      n -= 1;
+    }
+    oa[n] = age;
+    for (int c = 0; c < 5; ++c) ob[n * 5 + c] = last[c];
+    S.t_nobs[slot] = n + 1;
+  }
+  S.t_tsu[slot] = 0; S.t_hits[slot] += 1; S.t_streak[slot] += 1;
+}
+
+// One chunk of (slot, det) updates in list order: appends them to the frame's update list with the round each belongs to
+// and applies them — lanes that hit the same track go one after the other, in lane order.
+__device__ __forceinline__ void apply_chunk(OcStream& S, const OcParams& P, bool valid, int slot, int det, int& n_upd, int* lds_slot) {
+  const int lane = static_cast<int>(threadIdx.x);
+  lds_slot[lane] = valid ? slot : -1;
+  __syncthreads();
+  int rank = 0;
+  if (valid)
+    for (int j = 0; j < lane; ++j) rank += (lds_slot[j] == slot) ? 1 : 0;
+  const int base = valid ? S.slot_cnt[slot] : 0;
+  __syncthreads();
+  const int p = compact(valid, n_upd);
+  if (valid) {
+    S.upd_slot[p] = slot; S.upd_meas[p] = det; S.upd_round[p] = base + rank;
+    atomicAdd(&S.slot_cnt[slot], 1);
+  }
+  int maxr = rank;
+  for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(maxr, o, 64); maxr = (v > maxr) ? v : maxr; }
+  for (int r = 0; r <= maxr; ++r) {
+    if (valid && rank == r) apply(S, P, slot, det);
+    __syncthreads();
+  }
+}
+
+// removes every entry e of list[0..n) with flag[e] != 0, order preserved, in place; returns the new length
+__device__ __forceinline__ int filter_list(int* list, int n, const unsigned char* flag) {
+  const int t = static_cast<int>(threadIdx.x);
+  int m = 0;
+  for (int k0 = 0; k0 < n; k0 += kW) {
+    const int k = k0 + t;
+    const int e = (k < n) ? list[k] : 0;
+    const bool keep = k < n && flag[e] == 0;
+    __syncthreads();
+    const int p = compact(keep, m);  // p <= k
+    if (keep) list[p] = e;
+    __syncthreads();
+  }
+  return m;
+}
+
+// ---- K0: detection split, KalmanBoxTracker::predict's counters (:132-148), the predict task ----
+__global__ void __launch_bounds__(kW) oc_begin(OcStream* streams, OcParams P, int CAP, int D, const int* counts, const float* dets_base, OcTasks K) {
+  const int s = blockIdx.x;
+  OcStream& S = streams[s];
+  const int t = static_cast<int>(threadIdx.x);
+  int n = counts[s];
+  const float* dets = dets_base + static_cast<size_t>(s) * 6 * D;
+  const bool over = n > D;
+  if (over || n < 0) n = 0;
+  const float* conf = dets + static_cast<size_t>(4) * D;
+  int nh = 0, ns = 0;
+  for (int i0 = 0; i0 < n; i0 += kW) {
+    const int i = i0 + t;
+    const float c = (i < n) ? conf[i] : 0.f;
+    const bool lo = i < n && c > P.min_conf && c < P.det_thresh;
+    const bool hi = i < n && c > P.det_thresh;
+    const int pl = compact(lo, ns);
+    if (lo) S.second[pl] = i;
+    const int ph = compact(hi, nh);
+    if (hi) S.high[ph] = i;
+  }
+  const int* trk = S.trk[S.cur];
+  for (int i = t; i < S.n_trk; i += kW) {
+    const int slot = trk[i];
+    S.t_age[slot] += 1;
+    if (S.t_tsu[slot] > 0) S.t_streak[slot] = 0;
+    S.t_tsu[slot] += 1;
+    S.slot_cnt[slot] = 0;
+  }
+  if (t == 0) {
+    S.frame_count += 1;
+    S.dets = dets; S.ld = D; S.n = n;
+    if (over) S.err = 1;
+    S.n_high = nh; S.n_second = ns; S.nt0 = S.n_trk;
+    S.n_upd = 0; S.n_umd = 0; S.n_umt = 0; S.n_init = 0; S.n_need = 0; S.silent = 0; S.lap1_q = 0; S.byte_q = 0; S.rem_q = 0;
+    K.det[s].dets = dets; K.det[s].ld = D; K.det[s].n = n;
+    K.pred[s].n = S.n_trk; K.pred[s].src = trk;
+  }
+}
+
+// ---- K1: NaN-row rule (:353-364), the cost kernel's per-track planes, the first association's tasks ----
+__global__ void __launch_bounds__(kW) oc_nan(OcStream* streams, OcParams P, int CAP, OcTasks K, unsigned long long* stats) {
+  const int s = blockIdx.x;
+  OcStream& S = streams[s];
+  const int t = static_cast<int>(threadIdx.x);
+  const int nt = S.nt0;
+  const int* trk = S.trk[S.cur];
+  int* kept = S.trk[S.cur ^ 1];
+  int nk = 0, free_top = S.n_free;
+  for (int i0 = 0; i0 < nt; i0 += kW) {
+    const int i = i0 + t;
+    const bool v = i < nt;
+    bool bad = false;
+    if (v)
+      for (int c = 0; c < 4; ++c) { const float x = S.pbox[static_cast<size_t>(c) * CAP + i]; bad = bad || (x != x); }
+    const bool ok = v && !bad;
+    const int slot = v ? trk[i] : 0;
+    const int p = compact(ok, nk);
+    if (ok) kept[p] = slot;
+    const bool dead = v && bad;
+    const int pf = compact(dead, free_top);
+    if (dead) S.free_stack[pf] = slot;
+  }
+  __syncthreads();
+  // rows of `trks` are the FIRST nk predicted boxes (:363-364), velocities / k-previous observations those of the survivors
+  for (int i = t; i < nk; i += kW) {
+    const int slot = kept[i];
+    S.vel[i] = S.t_vel[slot * 2]; S.vel[static_cast<size_t>(CAP) + i] = S.t_vel[slot * 2 + 1];
+    float kp[5];
+    k_previous(S, P.K, slot, P.delta_t, kp);
+    for (int c = 0; c < 5; ++c) S.prev[static_cast<size_t>(c) * CAP + i] = kp[c];
+  }
+  if (t == 0) {
+    S.n_trk = nk; S.cur ^= 1; S.n_free = free_top;
+    S.silent = (nk == 0) ? 1 : 0;  // :366-383
+    const bool q = nk > 0 && S.n_high > 0;
+    S.lap1_q = q;
+    mot_ocsort_task& C = K.cost[s];
+    C.nd = q ? S.n_high : 0; C.nt = q ? nk : 0; C.dconf = S.dets + static_cast<size_t>(4) * S.ld;
+    mot_lap_task& L = K.lap1[s];
+    L.n = q ? S.n_high : 0; L.m = q ? nk : 0;
+    K.lapb[s].n = 0; K.lapb[s].m = 0; K.lapb[s].geom.n = 0; K.lapb[s].geom.m = 0;
+    K.lapr[s].n = 0; K.lapr[s].m = 0; K.lapr[s].geom.n = 0; K.lapr[s].geom.m = 0;
+    if (stats && q) { unsigned long long* st = stats + (s & 63) * 8; atomicAdd(&st[0], 1ull); atomicAdd(&st[1], static_cast<unsigned long long>(S.n_high) * nk); }
+  }
+}
+
+// OCR rematch (:475-540): leftover detections against the LAST OBSERVATIONS of the leftover tracks
+__device__ __forceinline__ void queue_rematch(OcStream& S, int ldl, mot_lap_task& L) {
+  const int t = static_cast<int>(threadIdx.x);
+  const bool q = S.n_umd > 0 && S.n_umt > 0;
+  if (q) {
+    const int* trk = S.trk[S.cur];
+    for (int k = t; k < S.n_umt; k += kW) {
+      const float* last = S.t_last + static_cast<size_t>(trk[S.um_trks[k]]) * 5;
+      for (int c = 0; c < 4; ++c) S.lbox[static_cast<size_t>(c) * ldl + k] = last[c];
+    }
+    for (int k = t; k < S.n_umd; k += kW) S.left[k] = S.high[S.um_dets[k]];
+  }
+  if (t == 0) {
+    S.rem_q = q;
+    L.n = q ? S.n_umd : 0; L.m = q ? S.n_umt : 0; L.geom.n = L.n; L.geom.m = L.m;
+  }
+}
+
+// ---- K2: ocsort_assoc::associate's filter (:699-727), Q4, the BYTE / OCR tasks ----
+__global__ void __launch_bounds__(kW) oc_after_first(OcStream* streams, OcParams P, int CAP, int D, OcTasks K) {
+  __shared__ int lds_slot[kW];
+  const int s = blockIdx.x;
+  OcStream& S = streams[s];
+  const int t = static_cast<int>(threadIdx.x);
+  const int nd = S.n_high, nt = S.n_trk;
+  int n_umd = 0, n_umt = 0, n_upd = 0;
+  if (S.silent) {  // no tracker left: every detection is unmatched, nothing is emitted or aged out this frame
+    for (int i = t; i < nd; i += kW) S.um_dets[i] = i;
+    if (t == 0) { S.n_umd = nd; S.n_umt = 0; S.n_upd = 0; S.byte_q = 0; S.rem_q = 0; }
+    return;
+  }
+  for (int i = t; i < nd; i += kW) S.md[i] = 0;
+  for (int j = t; j < nt; j += kW) S.mt[j] = 0;
+  __syncthreads();
+  const int* trk = S.trk[S.cur];
+  if (S.lap1_q) {
+    const int path = S.info1[0];
+    for (int i0 = 0; i0 < nd; i0 += kW) {
+      const int i = i0 + t;
+      const int j = (i < nd) ? S.x1[i] : -1;
+      const bool has = i < nd && j >= 0;
+      const bool acc = has && (path == 1 || S.xval1[i] >= P.thr);
+      const bool q4 = has && !acc;
+      if (acc) { S.md[i] = 1; S.mt[j] = 1; }
+      const int pq = compact(q4, n_umd);
+      if (q4) { S.um_dets[pq] = i; S.um_trks[pq] = j; }
+      apply_chunk(S, P, acc, acc ? trk[j] : 0, acc ? S.high[i] : 0, n_upd, lds_slot);
+    }
+    n_umt = n_umd;
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < nd; i0 += kW) {
+    const int i = i0 + t;
+    const bool u = i < nd && S.md[i] == 0;
+    const int p = compact(u, n_umd);
+    if (u) S.um_dets[p] = i;
+  }
+  for (int j0 = 0; j0 < nt; j0 += kW) {
+    const int j = j0 + t;
+    const bool u = j < nt && S.mt[j] == 0;
+    const int p = compact(u, n_umt);
+    if (u) S.um_trks[p] = j;
+  }
+  __syncthreads();
+  if (t == 0) { S.n_umd = n_umd; S.n_umt = n_umt; S.n_upd = n_upd; }
+  __syncthreads();
+  if (P.use_byte) {  // :430-472
+    if (t == 0) {
+      const bool q = S.n_second > 0 && n_umt > 0;
+      S.byte_q = q;
+      mot_lap_task& L = K.lapb[s];
+      L.n = q ? S.n_second : 0; L.m = q ? n_umt : 0; L.geom.n = L.n; L.geom.m = L.m;
+    }
+  } else {
+    queue_rematch(S, CAP + D, K.lapr[s]);
+  }
+}
+
+// ---- K3 (use_byte): BYTE association applied, leftover tracks filtered, OCR task ----
+__global__ void __launch_bounds__(kW) oc_after_byte(OcStream* streams, OcParams P, int CAP, int D, OcTasks K) {
+  __shared__ int lds_slot[kW];
+  const int s = blockIdx.x;
+  OcStream& S = streams[s];
+  const int t = static_cast<int>(threadIdx.x);
+  if (S.silent) return;
+  if (S.byte_q && S.infob[0] != 2) {
+    const int* trk = S.trk[S.cur];
+    int n_upd = S.n_upd;
+    for (int j = t; j < S.n_trk; j += kW) S.rm_t[j] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < S.n_second; i0 += kW) {
+      const int i = i0 + t;
+      const int j = (i < S.n_second) ? S.xb[i] : -1;
+      const bool ok = i < S.n_second && j >= 0 && !(-S.xvalb[i] < P.thr);
+      const int ti = ok ? S.um_trks[j] : 0;
+      if (ok) S.rm_t[ti] = 1;
+      apply_chunk(S, P, ok, ok ? trk[ti] : 0, ok ? S.second[i] : 0, n_upd, lds_slot);
+    }
+    __syncthreads();
+    const int m = filter_list(S.um_trks, S.n_umt, S.rm_t);
+    if (t == 0) { S.n_umt = m; S.n_upd = n_upd; }
+    __syncthreads();
+  }
+  queue_rematch(S, CAP + D, K.lapr[s]);
+}
+
+// ---- K4: OCR applied, "None" updates, spawns, Kalman update rounds, rows that need the filter state (:541-587) ----
+__global__ void __launch_bounds__(kW) oc_finish(OcStream* streams, OcParams P, int CAP, int D, int S_total, OcTasks K) {
+  __shared__ int lds_slot[kW];
+  const int s = blockIdx.x;
+  OcStream& S = streams[s];
+  const int t = static_cast<int>(threadIdx.x);
+  int* trk = S.trk[S.cur];
+  int n_upd = S.n_upd;
+  if (!S.silent && S.rem_q && S.infor[0] != 2) {
+    for (int i = t; i < S.n_high; i += kW) S.rm_d[i] = 0;
+    for (int j = t; j < S.n_trk; j += kW) S.rm_t[j] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < S.n_umd; i0 += kW) {
+      const int i = i0 + t;
+      const int j = (i < S.n_umd) ? S.xr[i] : -1;
+      const bool ok = i < S.n_umd && j >= 0 && !(-S.xvalr[i] < P.thr);
+      const int di = ok ? S.um_dets[i] : 0, ti = ok ? S.um_trks[j] : 0;
+      if (ok) { S.rm_d[di] = 1; S.rm_t[ti] = 1; }
+      apply_chunk(S, P, ok, ok ? trk[ti] : 0, ok ? S.high[di] : 0, n_upd, lds_slot);
+    }
+    __syncthreads();
+    const int md = filter_list(S.um_dets, S.n_umd, S.rm_d);
+    const int mt = filter_list(S.um_trks, S.n_umt, S.rm_t);
+    if (t == 0) { S.n_umd = md; S.n_umt = mt; }
+    __syncthreads();
+  }
+  const int n_umd = S.n_umd, n_umt = S.n_umt;
+  for (int k = t; k < n_umt; k += kW) S.t_det[trk[S.um_trks[k]]] = 0;  // update(None): det_ind = 0 (:543-545)
+  // spawns (:548-556); a detection listed twice spawns twice (Q4)
+  int err = 0;
+  const int n_trk = S.n_trk;
+  {
+    const int free_top = S.n_free, next_slot = S.next_slot;
+    for (int k = t; k < n_umd; k += kW) {
+      int slot;
+      if (k < free_top) slot = S.free_stack[free_top - 1 - k];
+      else { slot = next_slot + (k - free_top); if (slot >= CAP) { slot = CAP - 1; err = 1; } }
+      const int det = S.high[S.um_dets[k]];
+      S.t_id[slot] = S.next_id + k + 1;
+      S.t_conf[slot] = S.dets[static_cast<size_t>(4) * S.ld + det];
+      S.t_cls[slot] = static_cast<int>(S.dets[static_cast<size_t>(5) * S.ld + det]);
+      S.t_det[slot] = det;
+      S.t_age[slot] = 0; S.t_hits[slot] = 0; S.t_streak[slot] = 0; S.t_tsu[slot] = 0; S.t_nobs[slot] = 0;
+      for (int c = 0; c < 5; ++c) S.t_last[static_cast<size_t>(slot) * 5 + c] = -1.0f;
+      S.t_vel[slot * 2] = 0.f; S.t_vel[slot * 2 + 1] = 0.f;
+      S.init_dst[k] = slot; S.init_meas[k] = det;
+      if (n_trk + k < CAP) trk[n_trk + k] = slot; else err = 1;
+    }
+  }
+  err = __any(err) ? 1 : 0;
+  __syncthreads();
+  const int n_all = (n_trk + n_umd <= CAP) ? n_trk + n_umd : CAP;
+  // Kalman update rounds: a slot's r-th update of this frame runs in launch r
+  int n_round[kRounds];
+  for (int r = 0; r < kRounds; ++r) {
+    int m = 0;
+    for (int k0 = 0; k0 < n_upd; k0 += kW) {
+      const int k = k0 + t;
+      const bool v = k < n_upd && S.upd_round[k] == r;
+      const int p = compact(v, m);
+      if (v) { S.r_slot[r][p] = S.upd_slot[k]; S.r_meas[r][p] = S.upd_meas[k]; }
+    }
+    n_round[r] = m;
+  }
+  for (int k = t; k < n_upd; k += kW) if (S.upd_round[k] >= kRounds) err = 1;
+  err = __any(err) ? 1 : 0;
+  // rows to emit newest first (:562-587); the ones without an observation yet take their box from the filter state
+  int n_need = 0;
+  if (!S.silent) {
+    for (int q0 = 0; q0 < n_all; q0 += kW) {
+      const int q = q0 + t;
+      const int i = n_all - 1 - q;
+      const bool v = q < n_all;
+      const int slot = v ? trk[i] : 0;
+      const bool e = v && S.t_tsu[slot] < 1 && (S.t_streak[slot] >= P.min_hits || S.frame_count <= P.min_hits);
+      const float* last = S.t_last + static_cast<size_t>(slot) * 5;
+      const bool need = e && (last[0] + last[1] + last[2] + last[3] < 0);
+      const int p = compact(need, n_need);
+      if (need) { S.need_slot[p] = slot; S.t_need[slot] = p; }
+    }
+  }
+  if (t == 0) {
+    const int from_free = (n_umd < S.n_free) ? n_umd : S.n_free;
+    S.next_slot += n_umd - from_free; S.n_free -= from_free;
+    S.next_id += n_umd;
+    S.n_trk = n_all; S.n_upd = n_upd; S.n_init = n_umd; S.n_need = n_need;
+    if (err) S.err = 1;
+    K.init[s].n = n_umd;
+    for (int r = 0; r < kRounds; ++r) K.upd[static_cast<size_t>(r) * S_total + s].n = n_round[r];
+    K.sbox[s].n = n_need;
+  }
+}
+
+// ---- K5: the output table (newest tracker first) and the age-out (:562-606) ----
+__global__ void __launch_bounds__(kW) oc_emit(OcStream* streams, OcParams P, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks) {
+  OcStream& S = streams[blockIdx.x];
+  const int t = static_cast<int>(threadIdx.x);
+  if (S.silent) {
+    if (t == 0) { out_counts[blockIdx.x] = 0; atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk); }
+    return;
+  }
+  const int* trk = S.trk[S.cur];
+  int* next = S.trk[S.cur ^ 1];
+  float* rows = out + static_cast<size_t>(blockIdx.x) * cap_out * 8;
+  const int n_all = S.n_trk;
+  int n_rows = 0;
+  for (int q0 = 0; q0 < n_all; q0 += kW) {
+    const int q = q0 + t;
+    const int i = n_all - 1 - q;
+    const bool v = q < n_all;
+    const int slot = v ? trk[i] : 0;
+    const bool e = v && S.t_tsu[slot] < 1 && (S.t_streak[slot] >= P.min_hits || S.frame_count <= P.min_hits);
+    const int p = compact(e, n_rows);
+    if (e && p < cap_out) {
+      const float* last = S.t_last + static_cast<size_t>(slot) * 5;
+      float b[4] = {last[0], last[1], last[2], last[3]};
+      if (b[0] + b[1] + b[2] + b[3] < 0) {
+        const int k = S.t_need[slot];
+        for (int c = 0; c < 4; ++c) b[c] = S.sbox[static_cast<size_t>(c) * CAP + k];
+      }
+      float* r = rows + static_cast<size_t>(p) * 8;
+      r[0] = b[0]; r[1] = b[1]; r[2] = b[2]; r[3] = b[3];
+      r[4] = static_cast<float>(S.t_id[slot] + 1); r[5] = S.t_conf[slot];
+      r[6] = static_cast<float>(S.t_cls[slot]); r[7] = static_cast<float>(S.t_det[slot]);
+    }
+  }
+  int n_keep = 0, free_top = S.n_free;
+  for (int i0 = 0; i0 < n_all; i0 += kW) {  // trackers not updated for more than max_age frames go (:598-604)
+    const int i = i0 + t;
+    const bool v = i < n_all;
+    const int slot = v ? trk[i] : 0;
+    const bool k = v && !(S.t_tsu[slot] > P.max_age);
+    const int p = compact(k, n_keep);
+    if (k) next[p] = slot;
+    const bool dead = v && !k;
+    const int pf = compact(dead, free_top);
+    if (dead) S.free_stack[pf] = slot;
+  }
+  if (t == 0) {
+    S.n_trk = n_keep; S.cur ^= 1; S.n_free = free_top;
+    if (n_rows > cap_out) S.err = 2;
+    out_counts[blockIdx.x] = (n_rows <= cap_out) ? n_rows : -n_rows;
+    atomicMax(&max_tracks[blockIdx.x & 63], n_keep);
+  }
+}
+
+__global__ void oc_collect_err(const OcStream* streams, int n, int* err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && streams[i].err) atomicMax(err, streams[i].err);
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+struct mot_oc_batch {
+  mot_ctx* ctx = nullptr;
+  int S = 0, CAP = 0, D = 0;
+  OcParams prm{};
+  mot::lifecycle::Allocs mem;
+  OcStream* d_streams = nullptr;
+  std::vector<OcStream> h_streams;
+  OcTasks tasks{};
+  int* d_counts = nullptr;
+  int* d_err = nullptr;
+  int* d_maxt = nullptr;
+  int bound_n = 0;
+  float* d_out = nullptr; int* d_out_counts = nullptr;
+  float* d_packed = nullptr; int* d_offsets = nullptr; int packed_cap = 0;
+  float* mean = nullptr;  // [S][CAP] records of 7 + 49 floats
+  bool profile = false;
+  unsigned long long* d_stats = nullptr;
+  hipEvent_t ev[6] = {};
+  double lap_ms = 0.0, cost_ms = 0.0, frame_ms = 0.0;
+  long frames = 0;
+  template <class T>
+  T* dalloc(size_t n) { return mem.get<T>(n); }
+};
+
+extern "C" {
+
+void mot_oc_destroy(mot_oc_batch* b) {
+  if (!b) return;
+  b->mem.release();
+  for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+  delete b;
+}
+
+int mot_oc_reset(mot_oc_batch* b) {  // OCSort::reset: the tracker list is dropped, the id counter keeps running in the reference's
+                                     // process-global static; per stream here it restarts with the list (parity is defined per stream)
+  std::vector<OcStream> h = b->h_streams;
+  MOT_LC_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(OcStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
+  MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
+  MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
+  b->bound_n = 0;
+  return MOT_OK;
+}
+
+int mot_oc_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, const float* p14, mot_oc_batch** out) {
+  if (!ctx || !out || nstreams <= 0 || cap_tracks <= 0 || max_dets <= 0) return MOT_ERR_INVALID;
+  auto P_ = [&](int i, float d) { return p14 ? p14[i] : d; };
+  auto* b = new mot_oc_batch();
+  b->ctx = ctx; b->S = nstreams; b->CAP = cap_tracks; b->D = max_dets;
+  OcParams& P = b->prm;
+  // [det_thresh, max_age, max_obs (unused), min_hits, iou_threshold, min_conf, delta_t, inertia, use_byte, Q_xy, Q_s, asso, w, h]
+  P.det_thresh = P_(0, 0.2f); P.max_age = static_cast<int>(P_(1, 30)); P.min_hits = static_cast<int>(P_(3, 3)); P.thr = P_(4, 0.3f);
+  P.min_conf = P_(5, 0.1f); P.delta_t = static_cast<int>(P_(6, 3)); P.inertia = P_(7, 0.2f); P.use_byte = P_(8, 0.f) != 0.f;
+  const float q_xy = P_(9, 0.01f), q_s = P_(10, 0.0001f);
+  P.asso = static_cast<int>(P_(11, 0.f));
+  if (P.asso < 0 || P.asso > MOT_ASSOC_CENTROID || P.delta_t < 0 || P.delta_t > 64) { delete b; return MOT_ERR_INVALID; }
+  const int iw = static_cast<int>(P_(12, 1920.f)), ih = static_cast<int>(P_(13, 1080.f));
+  P.frame_diag = static_cast<float>(std::sqrt(static_cast<double>(iw * iw + ih * ih)));  // iou.hpp:329
+  P.K = P.delta_t + 2;
+  const int S = nstreams, CAP = cap_tracks, D = max_dets, K = P.K;
+  const int UPD = 4 * D + CAP;                 // updates a frame can queue: first + BYTE + OCR matches
+  const int UMD = 2 * D, UMT = D + CAP;        // unmatched lists with their Q4 repeats
+  const int ldc = (CAP + 3) & ~3;
+  const size_t ints_per = static_cast<size_t>(CAP) * (14 + K) + static_cast<size_t>(D) * 5 + static_cast<size_t>(UMD) * 4 + static_cast<size_t>(UMT) +
+                          static_cast<size_t>(UPD) * (3 + 2 * kRounds) + 16;
+  const size_t floats_per = static_cast<size_t>(CAP) * (23 + 5 * K) + static_cast<size_t>(UMT) * 4 + static_cast<size_t>(D) * 10 + static_cast<size_t>(UMD) + 8;
+  const size_t bytes_per = static_cast<size_t>(CAP) * 2 + static_cast<size_t>(D) * 2;
+  int* ip = b->dalloc<int>(ints_per * S);
+  float* fp = b->dalloc<float>(floats_per * S);
+  unsigned char* bp = b->dalloc<unsigned char>(bytes_per * S);
+  unsigned char* clamp = b->dalloc<unsigned char>(CAP);
+  b->mean = b->dalloc<float>(static_cast<size_t>(S) * 56 * CAP);
+  float* mats = b->dalloc<float>(static_cast<size_t>(S) * 2 * D * ldc);  // cost and IoU matrices of the first association
+  b->d_streams = b->dalloc<OcStream>(S);
+  b->d_counts = b->dalloc<int>(S);
+  b->d_err = b->dalloc<int>(1);
+  b->d_maxt = b->dalloc<int>(64);
+  b->d_stats = b->dalloc<unsigned long long>(8 * 64);
+  b->d_out = b->dalloc<float>(static_cast<size_t>(S) * CAP * 8);
+  b->d_out_counts = b->dalloc<int>(S);
+  b->d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1);
+  OcTasks& T = b->tasks;
+  T.det = b->dalloc<mot_det_task>(S);
+  T.pred = b->dalloc<mot_kf_task>(S); T.init = b->dalloc<mot_kf_task>(S); T.upd = b->dalloc<mot_kf_task>(static_cast<size_t>(kRounds) * S);
+  T.sbox = b->dalloc<mot_kf_task>(S);
+  T.cost = b->dalloc<mot_ocsort_task>(S);
+  T.lap1 = b->dalloc<mot_lap_task>(S); T.lapb = b->dalloc<mot_lap_task>(S); T.lapr = b->dalloc<mot_lap_task>(S);
+  const size_t wb1 = (mot::lap_scratch_bytes(D, CAP) + 255) & ~size_t(255);      // rows = detections, columns = tracks
+  const size_t wbb = (mot::lap_scratch_bytes(D, UMT) + 255) & ~size_t(255);      // BYTE: low detections x the unmatched-track list
+  const size_t wbr = (mot::lap_scratch_bytes(UMD, UMT) + 255) & ~size_t(255);    // OCR: the unmatched lists with repeats
+  const size_t wall = wb1 + wbb + wbr;
+  char* work = b->dalloc<char>(wall * S);
+  if (!ip || !fp || !bp || !clamp || !b->mean || !mats || !b->d_streams || !b->d_counts || !b->d_err || !b->d_maxt || !b->d_stats || !b->d_out ||
+      !b->d_out_counts || !b->d_offsets || !T.det || !T.pred || !T.init || !T.upd || !T.sbox || !T.cost || !T.lap1 || !T.lapb || !T.lapr || !work) {
+    mot_oc_destroy(b);
+    return MOT_ERR_NOMEM;
+  }
+  (void)hipMemset(b->d_stats, 0, 8 * 64 * sizeof(unsigned long long));
+  (void)hipMemset(clamp, MOT_KF_OCSORT_CLAMP, CAP);
+  for (auto& e : b->ev) (void)hipEventCreate(&e);
+  std::vector<OcStream> hs(S);
+  std::vector<mot_det_task> det(S);
+  std::vector<mot_kf_task> pred(S), init(S), upd(static_cast<size_t>(kRounds) * S), sbox(S);
+  std::vector<mot_ocsort_task> cost(S);
+  std::vector<mot_lap_task> lap1(S), lapb(S), lapr(S);
+  for (int s = 0; s < S; ++s) {
+    OcStream& Z = hs[s];
+    std::memset(&Z, 0, sizeof(Z));
+    int* i = ip + ints_per * s;
+    auto I = [&](size_t n) { int* r = i; i += n; return r; };
+    Z.free_stack = I(CAP); Z.trk[0] = I(CAP); Z.trk[1] = I(CAP);
+    Z.t_id = I(CAP); Z.t_age = I(CAP); Z.t_hits = I(CAP); Z.t_streak = I(CAP); Z.t_tsu = I(CAP); Z.t_cls = I(CAP); Z.t_det = I(CAP); Z.t_nobs = I(CAP);
+    Z.t_need = I(CAP);
+    Z.t_oage = I(static_cast<size_t>(CAP) * K);
+    Z.slot_cnt = I(CAP); Z.need_slot = I(CAP);
+    Z.high = I(D); Z.second = I(D);
+    Z.x1 = I(D); Z.xb = I(D); Z.info1 = I(4); Z.infob = I(4); Z.infor = I(4);
+    Z.init_dst = I(UMD); Z.init_meas = I(UMD); Z.um_dets = I(UMD); Z.xr = I(UMD); Z.left = I(D);
+    Z.um_trks = I(UMT);
+    Z.upd_slot = I(UPD); Z.upd_meas = I(UPD); Z.upd_round = I(UPD);
+    for (int r = 0; r < kRounds; ++r) { Z.r_slot[r] = I(UPD); Z.r_meas[r] = I(UPD); }
+    float* f = fp + floats_per * s;
+    auto F = [&](size_t n) { float* r = f; f += n; return r; };
+    Z.t_conf = F(CAP); Z.t_last = F(static_cast<size_t>(CAP) * 5); Z.t_vel = F(static_cast<size_t>(CAP) * 2);
+    Z.t_obs = F(static_cast<size_t>(CAP) * K * 5);
+    Z.pbox = F(4 * CAP); Z.vel = F(2 * CAP); Z.prev = F(5 * CAP); Z.lbox = F(static_cast<size_t>(4) * UMT); Z.sbox = F(4 * CAP);
+    float* d_box = F(4 * D); float* d_meas = F(4 * D);
+    Z.xval1 = F(D); Z.xvalb = F(D); Z.xvalr = F(UMD);
+    unsigned char* u = bp + bytes_per * s;
+    Z.mt = u; Z.rm_t = u + CAP; Z.md = u + 2 * CAP; Z.rm_d = u + 2 * CAP + D;
+    float* mean = b->mean + static_cast<size_t>(s) * 56 * CAP;
+    float* cmat = mats + static_cast<size_t>(s) * 2 * D * ldc;
+    float* imat = cmat + static_cast<size_t>(D) * ldc;
+    std::memset(&det[s], 0, sizeof(mot_det_task));
+    det[s].box = d_box; det[s].ldb = D; det[s].meas = d_meas; det[s].ldm = D;
+    auto kf = [&](mot_kf_task& k) {
+      std::memset(&k, 0, sizeof(k));
+      k.mean = mean; k.cov = mean + 7; k.cap = CAP;
+      k.q[0] = 0.01f * q_xy; k.q[1] = 0.01f * q_xy; k.q[2] = 0.0001f * q_s;  // Q5: scaled twice (ocsort.cpp:77-79)
+    };
+    kf(pred[s]); pred[s].flags = clamp; pred[s].boxes = Z.pbox; pred[s].ldb = CAP;
+    kf(init[s]); init[s].src = Z.init_dst; init[s].dst = Z.init_dst; init[s].meas = d_meas; init[s].ldm = D; init[s].midx = Z.init_meas;
+    for (int r = 0; r < kRounds; ++r) {
+      mot_kf_task& U = upd[static_cast<size_t>(r) * S + s];
+      kf(U); U.src = Z.r_slot[r]; U.dst = Z.r_slot[r]; U.meas = d_meas; U.ldm = D; U.midx = Z.r_meas[r];
+    }
+    kf(sbox[s]); sbox[s].src = Z.need_slot; sbox[s].boxes = Z.sbox; sbox[s].ldb = CAP;
+    mot_ocsort_task& C = cost[s];
+    std::memset(&C, 0, sizeof(C));
+    C.dbox = d_box; C.ldd = D; C.didx = Z.high; C.tbox = Z.pbox; C.ldt = CAP; C.vel = Z.vel; C.ldv = CAP; C.prev = Z.prev; C.ldp = CAP;
+    C.vdc_weight = P.inertia; C.cost = cmat; C.iou = imat; C.ldc = ldc; C.assoc = P.asso; C.frame_diag = P.frame_diag;
+    // y arrays (track-sided) of the three assignments live in one more int block
+    mot_lap_task& L1 = lap1[s];
+    std::memset(&L1, 0, sizeof(L1));
+    L1.cost = cmat; L1.ldc = ldc; L1.thresh = -P.thr; L1.x = Z.x1; L1.mode = MOT_LAP_OCSORT; L1.iou = imat; L1.ldi = ldc; L1.gate = P.thr;
+    L1.xval = Z.xval1; L1.info = Z.info1; L1.work = work + wall * s;
+    auto geom = [&](mot_lap_task& L, int* x, float* xval, int* info, char* w, const int* aidx, const float* bbox, int ldb, const int* bidx) {
+      std::memset(&L, 0, sizeof(L));
+      L.x = x; L.thresh = -P.thr; L.mode = MOT_LAP_GATE_MIN; L.gate = -P.thr; L.xval = xval; L.info = info; L.work = w;
+      L.geom.a = d_box; L.geom.lda = D; L.geom.aidx = aidx; L.geom.b = bbox; L.geom.ldb = ldb; L.geom.bidx = bidx;
+      L.geom.mode = MOT_COST_NEG_IOU; L.geom.assoc = P.asso; L.geom.frame_diag = P.frame_diag;
+    };
+    geom(lapb[s], Z.xb, Z.xvalb, Z.infob, work + wall * s + wb1, Z.second, Z.pbox, CAP, Z.um_trks);
+    geom(lapr[s], Z.xr, Z.xvalr, Z.infor, work + wall * s + wb1 + wbb, Z.left, Z.lbox, UMT, nullptr);
+  }
+  const size_t ys_per = static_cast<size_t>(CAP) + 2 * static_cast<size_t>(UMT);  // y arrays are track-sided
+  int* ys = b->dalloc<int>(ys_per * S);
+  if (!ys) { mot_oc_destroy(b); return MOT_ERR_NOMEM; }
+  for (int s = 0; s < S; ++s) {
+    int* y = ys + ys_per * s;
+    hs[s].y1 = y; hs[s].yb = y + CAP; hs[s].yr = y + CAP + UMT;
+    lap1[s].y = hs[s].y1; lapb[s].y = hs[s].yb; lapr[s].y = hs[s].yr;
+  }
+  b->h_streams = hs;
+  hipStream_t st = ctx->stream;
+#define OC_UP(dst, vec) MOT_LC_HIP(b, hipMemcpyAsync(dst, vec.data(), sizeof(vec[0]) * vec.size(), hipMemcpyHostToDevice, st))
+  OC_UP(b->d_streams, hs); OC_UP(T.det, det); OC_UP(T.pred, pred); OC_UP(T.init, init); OC_UP(T.upd, upd); OC_UP(T.sbox, sbox);
+  OC_UP(T.cost, cost); OC_UP(T.lap1, lap1); OC_UP(T.lapb, lapb); OC_UP(T.lapr, lapr);
+#undef OC_UP
+  MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
+  *out = b;
+  return MOT_OK;
+}
+
+int mot_oc_step_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts, float* rows, int rows_cap, int* out_counts, int* total_rows) {
+  if (!b || !d_dets || !h_counts || !rows || !out_counts) return MOT_ERR_INVALID;
+  hipStream_t st = b->ctx->stream;
+  const int S = b->S, CAP = b->CAP, D = b->D;
+  MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
+  int bd = 1;
+  for (int s = 0; s < S; ++s) bd = (h_counts[s] > bd) ? h_counts[s] : bd;
+  if (bd > D) bd = D;
+  const int bn = (b->bound_n < 1) ? 1 : (b->bound_n > CAP ? CAP : b->bound_n);
+  const int bn2 = (bn + 2 * bd > CAP) ? CAP : bn + 2 * bd;
+  const bool prof = b->profile;
+  const bool general = b->prm.asso != MOT_ASSOC_IOU;
+  const OcTasks& K = b->tasks;
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[0], st));
+  hipLaunchKernelGGL(oc_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, K);
+  MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYSR, K.det, S, bd, st));
+  MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYSR, K.pred, S, bn, st));
+  hipLaunchKernelGGL(oc_nan, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K, prof ? b->d_stats : nullptr);
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[2], st));
+  MOT_LC_HIP(b, mot::launch_ocsort(K.cost, S, bd, bn, !general, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[3], st));
+  MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bd, bn, false, false, true, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[4], st));
+  hipLaunchKernelGGL(oc_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, K);
+  if (b->prm.use_byte) {
+    MOT_LC_HIP(b, mot::launch_lap(K.lapb, S, bd, (bn + bd > CAP + D) ? CAP + D : bn + bd, true, general, true, st));
+    hipLaunchKernelGGL(oc_after_byte, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, K);
+  }
+  MOT_LC_HIP(b, mot::launch_lap(K.lapr, S, 2 * bd, bn + bd, true, general, true, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[5], st));
+  hipLaunchKernelGGL(oc_finish, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, S, K);
+  MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYSR, K.init, S, 2 * bd, st));
+  for (int r = 0; r < kRounds; ++r) MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYSR, K.upd + static_cast<size_t>(r) * S, S, (r == 0) ? bn : 2 * bd, st));
+  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYSR, K.sbox, S, bn2, st));
+  hipLaunchKernelGGL(oc_emit, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt);
+  hipLaunchKernelGGL(oc_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
+  if (rows_cap > b->packed_cap) { b->d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); b->packed_cap = b->d_packed ? rows_cap : 0; }
+  if (!b->d_packed) return MOT_ERR_NOMEM;
+  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, b->d_offsets);
+  hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, CAP, b->d_out_counts, b->d_offsets, b->d_packed, rows_cap);
+  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
+  MOT_LC_HIP(b, hipGetLastError());
+  int total = 0, err = 0;
+  int maxt[64];
+  MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(&total, b->d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
+  b->bound_n = 0;
+  for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
+  if (prof) {
+    float ms = 0.f;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[1])); b->frame_ms += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[2], b->ev[3])); b->cost_ms += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[3], b->ev[4])); b->lap_ms += ms;
+    b->frames += 1;
+  }
+  if (total_rows) *total_rows = total;
+  if (err) { b->ctx->err = "mot_oc_step_packed: a stream exceeded cap_tracks / max_dets / the update rounds of a frame"; return MOT_ERR_CAPACITY; }
+  if (total > rows_cap) { b->ctx->err = "mot_oc_step_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  if (total > 0) {
+    MOT_LC_HIP(b, hipMemcpyAsync(rows, b->d_packed, sizeof(float) * static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, st));
+    MOT_LC_HIP(b, hipStreamSynchronize(st));
+  }
+  return MOT_OK;
+}
+
+int mot_oc_device_output(mot_oc_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts) {
+  if (!b || !b->d_packed || !b->d_offsets) return MOT_ERR_INVALID;
+  if (d_rows) *d_rows = b->d_packed;
+  if (d_offsets) *d_offsets = b->d_offsets;
+  if (d_counts) *d_counts = b->d_out_counts;
+  return MOT_OK;
+}
+
+int mot_oc_profile(mot_oc_batch* b, int enable) {
+  b->profile = enable != 0;
+  if (enable) {
+    b->lap_ms = b->cost_ms = b->frame_ms = 0.0;
+    b->frames = 0;
+    MOT_LC_HIP(b, hipMemsetAsync(b->d_stats, 0, 8 * 64 * sizeof(unsigned long long), b->ctx->stream));
+    MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
+  }
+  return MOT_OK;
+}
+
+int mot_oc_profile_stats(mot_oc_batch* b, double* out8) {
+  unsigned long long raw[8 * 64];
+  MOT_LC_HIP(b, hipMemcpy(raw, b->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
+  unsigned long long h[2] = {0, 0};
+  for (int i = 0; i < 64; ++i)
+    for (int k = 0; k < 2; ++k) h[k] += raw[i * 8 + k];
+  out8[0] = b->lap_ms; out8[1] = b->cost_ms; out8[2] = b->frame_ms; out8[3] = static_cast<double>(b->frames);
+  out8[4] = static_cast<double>(h[0]); out8[5] = static_cast<double>(h[1]); out8[6] = 0.0; out8[7] = 0.0;
+  return MOT_OK;
+}
+
+int mot_oc_dump(mot_oc_batch* b, int s, int* ids, float* mean, float* cov, int cap) {
+  hipStream_t st = b->ctx->stream;
+  OcStream h;
+  MOT_LC_HIP(b, hipMemcpyAsync(&h, b->d_streams + s, sizeof(OcStream), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
+  const int n = h.n_trk;
+  if (n > cap) return -n;
+  const int CAP = b->CAP;
+  std::vector<int> slots(n), tid(CAP);
+  if (n) MOT_LC_HIP(b, hipMemcpyAsync(slots.data(), h.trk[h.cur], sizeof(int) * n, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(tid.data(), h.t_id, sizeof(int) * CAP, hipMemcpyDeviceToHost, st));
+  std::vector<float> m(static_cast<size_t>(56) * CAP);
+  MOT_LC_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 56 * CAP, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) {
+    const int sl = slots[i];
+    ids[i] = tid[sl];
+    for (int k = 0; k < 7; ++k) mean[static_cast<size_t>(i) * 7 + k] = m[static_cast<size_t>(sl) * 56 + k];
+    for (int k = 0; k < 49; ++k) cov[static_cast<size_t>(i) * 49 + k] = m[static_cast<size_t>(sl) * 56 + 7 + k];
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -121,6 +121,38 @@ int main() {
         for (int k = 0; k < 8; ++k) CHECK(out[0](i, k) == r(i, k));
     }
   }
+  {  // OC-SORT and BoT-SORT with the lifecycle on the device: each stream gets what a tracker instance gives it
+    motcpp::OCSortDeviceBatch ob(2, 64, 16);
+    OCSort oa, obb;
+    motcpp::BotSortDeviceBatch bb(1, 64, 16, 8);
+    BotSort bref;
+    Eigen::MatrixXf warp(2, 3);
+    warp << 1, 0, 5, 0, 1, 0;
+    for (int f = 0; f < 6; ++f) {
+      Eigen::MatrixXf da = multi, db = single;
+      for (int i = 0; i < da.rows(); ++i) { da(i, 0) += 5.f * f; da(i, 2) += 5.f * f; }
+      auto out = ob.update({da, db});
+      Eigen::MatrixXf ra = oa.update(da, img), rb = obb.update(db, img);
+      CHECK(out.size() == 2 && out[0].rows() == ra.rows() && out[1].rows() == rb.rows());
+      for (int i = 0; i < ra.rows() && i < out[0].rows(); ++i)
+        for (int k = 0; k < 8; ++k) CHECK(out[0](i, k) == ra(i, k));
+      Eigen::MatrixXf e(da.rows(), 8);
+      for (int i = 0; i < da.rows(); ++i) for (int k = 0; k < 8; ++k) e(i, k) = (k == i % 8) ? 1.0f : 0.1f * static_cast<float>(f + 1);
+      std::vector<Eigen::MatrixXf> ws;
+      if (f > 0) { ws.push_back(warp); bref.set_camera_motion(warp); }
+      auto bo = bb.update({da}, {e}, ws);
+      Eigen::MatrixXf br = bref.update(da, img, e);
+      CHECK(bo[0].rows() == br.rows());
+      for (int i = 0; i < br.rows() && i < bo[0].rows(); ++i)
+        for (int k = 0; k < 8; ++k) CHECK(bo[0](i, k) == br(i, k));
+    }
+    bool threw = false;
+    try { ob.update({multi, single}, {multi}); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);  // only BoT-SORT batches take embeddings
+    threw = false;
+    try { motcpp::OCSortDeviceBatch bad(1, 64, 16, 0.2f, 30, 3, 0.3f, 0.1f, 3, 0.2f, false, 0.01f, 0.0001f, "iou_obb"); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+  }
   {  // camera motion (botsort.cpp:317-324 with the warp supplied by the caller): a camera jumping 60 px per frame
     BotSort cmc, plain;
     Eigen::MatrixXf warp(2, 3);

@@ -1,0 +1,86 @@
+"""OC-SORT with the lifecycle on the device (mot_oc_*, motcpp_amd/csrc/oc_device.hip) against the CPU oracle: output tables and
+track ids exactly, boxes and Kalman states within 1e-4 (the direction cost goes through acos) and bit for bit in
+practice, on seeded streams with ragged and empty frames, with the BYTE stage, other association measures, and the duplicate
+tracks of quirk Q4 (a track updated twice in a frame, a detection spawning two tracks)."""
+import numpy as np
+import pytest
+
+from motcpp_amd import _lib as L
+from motcpp_amd.synth import SynthStream
+from tests import orclib
+
+pytestmark = pytest.mark.gpu
+
+
+def run(shapes, frames, cap, maxd, params=None, check_states_every=5, empty_every=13, min_exact=0.999):
+    orc = orclib.load()
+    S = len(shapes)
+    dev = L.DeviceOCSort(S, cap, maxd, params)
+    streams = [SynthStream(P, M, 2468 + i) for i, (P, M) in enumerate(shapes)]
+    oracles = [orc.tracker(orclib.OCSORT, list(params) if params else None) for _ in range(S)]
+    rows = exact = 0
+    for f in range(frames):
+        dets = np.zeros((S, maxd, 6), np.float32)
+        cnt = np.zeros(S, np.int32)
+        per = []
+        for s, st in enumerate(streams):
+            d, _ = st.next_frame()
+            if empty_every and (f + s) % empty_every == empty_every - 2:
+                d = d[:0]
+            per.append(d)
+            cnt[s] = len(d)
+            dets[s, :len(d)] = d
+        tables = dev.step(dets, cnt)
+        for s in range(S):
+            oo = oracles[s].update(per[s])
+            assert tables[s].shape == oo.shape, (f, s, tables[s].shape, oo.shape)
+            assert np.array_equal(tables[s][:, 4:], oo[:, 4:]), (f, s)  # id, conf, cls, det_ind
+            assert np.allclose(tables[s][:, :4], oo[:, :4], rtol=1e-4, atol=1e-3), (f, s)
+            rows += oo.shape[0]
+            exact += int(np.sum(np.all(tables[s] == oo, axis=1)))
+            if f % check_states_every == check_states_every - 1:
+                ids, mean, cov = dev.dump(s)
+                so = oracles[s].dump_states()
+                assert len(ids) == so.shape[0], (f, s, len(ids), so.shape)
+                if len(ids):
+                    assert np.array_equal(ids, so[:, 0].astype(np.int32)), (f, s)
+                    assert np.allclose(mean, so[:, 1:8], rtol=1e-4, atol=1e-4), (f, s)
+                    assert np.allclose(cov.reshape(len(ids), -1), so[:, 8:57], rtol=1e-4, atol=1e-4), (f, s)
+    assert rows > 0 and exact >= min_exact * rows, (rows, exact)
+    dev.close()
+
+
+def test_small_streams():
+    run([(40, 30), (256, 128), (8, 8), (90, 64)], 45, 768, 128)
+
+
+def test_byte_stage():
+    run([(150, 90), (60, 40)], 40, 512, 128, params=[0.4, 30, 50, 3, 0.3, 0.1, 3, 0.2, 1, 0.01, 0.0001, 0, 1920, 1080])
+
+
+@pytest.mark.parametrize("asso", [1, 2, 3, 4, 5])
+def test_association_measures(asso):
+    run([(80, 50), (30, 30)], 25, 512, 64, params=[0.2, 30, 50, 3, 0.3, 0.1, 3, 0.2, 0, 0.01, 0.0001, asso, 1920, 1080])
+
+
+def test_short_max_age_recycles_slots():
+    run([(50, 30), (25, 20)], 200, 256, 64, params=[0.2, 3, 50, 1, 0.3, 0.1, 2, 0.2, 0, 0.01, 0.0001, 0, 1920, 1080], check_states_every=20)
+
+
+def test_streams_with_q4_duplicates():
+    """streams in which the oracle is known to hold duplicate tracks (assignments the IoU filter rejects put a detection on the
+    unmatched list twice, quirk Q4: two identical tracks are born, 3 such events in the first 30 frames of the 256 x 128 stream)"""
+    orc = orclib.load()
+    t = orc.tracker(orclib.OCSORT)
+    st = SynthStream(256, 128, 2468)
+    dup = 0
+    for _ in range(30):
+        t.update(st.next_frame()[0])
+        m = t.dump_states()[:, 1:8]
+        dup += len(m) - len(np.unique(m, axis=0))
+    assert dup > 0
+    run([(256, 128), (512, 256)], 40, 2048, 256, empty_every=0)
+
+
+def test_c4_shape():
+    run([(4096, 2048)], 5, 8192, 2048, empty_every=0)

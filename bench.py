@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--host-input-steps", type=int, default=8,
                     help="after the timed region: this many more steps with the detections uploaded from page-locked host memory inside "
                          "the step (reported as host_input; 0 = skip). Device-lifecycle workloads only")
+    ap.add_argument("--isolated-steps", type=int, default=None,
+                    help="after the timed region: this many steps with the sub-batches one after the other, for per-kernel times "
+                         "without time-sharing (reported as kernels_isolated; default 4, C4: 0)")
     ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (0: workload default)")
     ap.add_argument("--threads", type=int, default=0, help="host worker threads for the per-stream lifecycle, shared by the sub-batches (0: min(64, cores))")
     ap.add_argument("--gather-every", type=int, default=8)
@@ -113,12 +116,15 @@ def main():
     W = args.warmup if args.warmup is not None else (1 if heavy else 40)
     if args.settle is None:
         args.settle = 5 if heavy else 30
+    if args.isolated_steps is None:
+        args.isolated_steps = 0 if heavy else 4
     on_device_wl = tracker in ("bytetrack", "sort") and args.lifecycle in ("auto", "device")  # (host-input leg: detections only)
     Z = max(0, args.settle)
     H = max(0, args.host_input_steps) if on_device_wl else 0
     W0 = W            # the warm-up the caller asked for (reported); the settling frames are stepped before it
     W = W + Z
-    F = K + W + H
+    ISO = max(0, args.isolated_steps)
+    F = K + W + H + ISO
 
     # ---- synthetic streams (seed 1234 + global stream id), generated before anything is timed ----
     host = np.zeros((F, S, M, 6), np.float32)
@@ -265,7 +271,6 @@ def main():
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    stats = {}
     achieved_dims = None
     if on_device and tracker == "bytetrack":
         dims = np.sum([b.profile_dims() for b in batches], axis=0)
@@ -274,35 +279,41 @@ def main():
                     "second_and_unconfirmed": {"problems": int(pc[1]), "mean_tracks_N": dims[2] / max(pc[1], 1), "mean_dets_M": dims[3] / max(pc[1], 1)},
                     "note": "rows x columns of the assignment problems actually queued in the timed region (pool of tracked + lost tracks x "
                             "high-score detections; then remaining tracked x low-score detections and unconfirmed x remaining detections)"}
-    for b in batches:
-        ps = b.profile_stats()
-        if on_device and tracker == "ocsort":
-            ps = {"lap": {"ms": ps["lap_ms"], "launches": ps["frames"], "tasks": ps["lap_problems"], "bytes": 4.0 * ps["lap_nm"], "flops": 0.0},
-                  "ocsort_cost": {"ms": ps["cost_ms"], "launches": ps["frames"], "tasks": ps["lap_problems"], "bytes": 8.0 * ps["lap_nm"], "flops": 0.0},
-                  "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
-                                        "bytes": 0.0, "flops": 0.0}}
-        elif on_device and tracker == "botsort":
-            ps = {"lap": {"ms": ps["lap_ms"], "launches": 2 * ps["frames"], "tasks": ps["lap_problems"], "bytes": 24.0 * ps["lap_nm"], "flops": 0.0},
-                  "cosine": {"ms": ps["cos_ms"], "launches": ps["frames"], "tasks": ps["frames"] * (bounds[1] - bounds[0]),
-                             "bytes": 0.0, "flops": 2.0 * ps["cos_nm"] * D},
-                  "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
-                                        "bytes": 0.0, "flops": 0.0}}
-        elif on_device:  # the solver's launches are timed on the device stream; "frame" = all 14 launches of a frame
-            ps = {"lap": {"ms": ps["lap1_ms"] + ps["lap23_ms"], "launches": (2 if tracker == "bytetrack" else 1) * ps["frames"], "tasks": ps["lap1_problems"] + ps["lap23_problems"],
-                          "bytes": 24.0 * (ps["lap1_nm"] + ps["lap23_nm"]), "flops": 0.0},
-                  "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
-                                        "bytes": 0.0, "flops": 0.0}}
-            if tracker == "bytetrack":  # the Kalman launches of the same frames (bytes: DESIGN.md's per-item figures)
-                kf = b.profile_kalman()
-                fr = ps["frame_all_kernels"]["launches"]
-                ps["kf_predict_boxes"] = {"ms": kf["predict_boxes_ms"], "launches": fr, "tasks": kf["predict_boxes_items"], "bytes": 52.0 * kf["predict_boxes_items"], "flops": 0.0}
-                ps["kf_initiate"] = {"ms": kf["initiate_ms"], "launches": fr, "tasks": kf["initiate_items"], "bytes": 312.0 * kf["initiate_items"], "flops": 0.0}
-                ps["kf_update"] = {"ms": kf["update_ms"], "launches": fr, "tasks": kf["update_items"], "bytes": 604.0 * kf["update_items"], "flops": 0.0}
-        for k, v in ps.items():
-            a = stats.setdefault(k, {"ms": 0.0, "launches": 0, "tasks": 0, "bytes": 0.0, "flops": 0.0})
-            for kk in a:
-                a[kk] += v[kk]
-        b.profile(False)
+    def collect_families():
+        """per kernel family: summed HIP-event ms, launches, tasks, algorithmic bytes / flops since profile(True); stops profiling"""
+        acc = {}
+        for b in batches:
+            ps = b.profile_stats()
+            if on_device and tracker == "ocsort":
+                ps = {"lap": {"ms": ps["lap_ms"], "launches": ps["frames"], "tasks": ps["lap_problems"], "bytes": 4.0 * ps["lap_nm"], "flops": 0.0},
+                      "ocsort_cost": {"ms": ps["cost_ms"], "launches": ps["frames"], "tasks": ps["lap_problems"], "bytes": 8.0 * ps["lap_nm"], "flops": 0.0},
+                      "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
+                                            "bytes": 0.0, "flops": 0.0}}
+            elif on_device and tracker == "botsort":
+                ps = {"lap": {"ms": ps["lap_ms"], "launches": 2 * ps["frames"], "tasks": ps["lap_problems"], "bytes": 24.0 * ps["lap_nm"], "flops": 0.0},
+                      "cosine": {"ms": ps["cos_ms"], "launches": ps["frames"], "tasks": ps["frames"] * (bounds[1] - bounds[0]),
+                                 "bytes": 0.0, "flops": 2.0 * ps["cos_nm"] * D},
+                      "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
+                                            "bytes": 0.0, "flops": 0.0}}
+            elif on_device:  # the solver's launches are timed on the device stream; "frame" = all 14 launches of a frame
+                ps = {"lap": {"ms": ps["lap1_ms"] + ps["lap23_ms"], "launches": (2 if tracker == "bytetrack" else 1) * ps["frames"], "tasks": ps["lap1_problems"] + ps["lap23_problems"],
+                              "bytes": 24.0 * (ps["lap1_nm"] + ps["lap23_nm"]), "flops": 0.0},
+                      "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
+                                            "bytes": 0.0, "flops": 0.0}}
+                if tracker == "bytetrack":  # the Kalman launches of the same frames (bytes: DESIGN.md's per-item figures)
+                    kf = b.profile_kalman()
+                    fr = ps["frame_all_kernels"]["launches"]
+                    ps["kf_predict_boxes"] = {"ms": kf["predict_boxes_ms"], "launches": fr, "tasks": kf["predict_boxes_items"], "bytes": 52.0 * kf["predict_boxes_items"], "flops": 0.0}
+                    ps["kf_initiate"] = {"ms": kf["initiate_ms"], "launches": fr, "tasks": kf["initiate_items"], "bytes": 312.0 * kf["initiate_items"], "flops": 0.0}
+                    ps["kf_update"] = {"ms": kf["update_ms"], "launches": fr, "tasks": kf["update_items"], "bytes": 604.0 * kf["update_items"], "flops": 0.0}
+            for k, v in ps.items():
+                a = acc.setdefault(k, {"ms": 0.0, "launches": 0, "tasks": 0, "bytes": 0.0, "flops": 0.0})
+                for kk in a:
+                    a[kk] += v[kk]
+            b.profile(False)
+        return acc
+
+    stats = collect_families()
     c1 = counters()
     fast_stats = diag_ctx.lap_fast_stats()
     elapsed = t1 - t0
@@ -336,6 +347,32 @@ def main():
                       "h2d_bytes_per_step": S * 6 * M * 4,
                       "note": "same tracker state, the frames after the timed region; detections copied from page-locked host memory on the "
                               "sub-batch's stream inside each step (PCIe-inclusive rate; never the headline value)"}
+    # ---- the same kernels without the sub-batches time-sharing the GPU: a few more steps, one sub-batch at a time ----
+    # (inside the timed region three sub-batches run on their own HIP streams, so a kernel's start-to-end time includes the other
+    # sub-batches' kernels; these numbers are what a launch costs when it has the GPU to itself)
+    isolated = None
+    if ISO > 0:
+        for b in batches:
+            b.profile(True)
+        torch.cuda.synchronize()
+        for k in range(ISO):
+            for p in range(PIPE):
+                sub_step(p, W + K + H + k)
+        torch.cuda.synchronize()
+        iso = collect_families()
+        isolated = {}
+        for k, v in iso.items():
+            if not v["launches"] or v["ms"] <= 0:
+                continue
+            e = {"avg_launch_ms": round(v["ms"] / v["launches"], 4)}
+            if v["bytes"] > 0:
+                e["GB/s"] = round(v["bytes"] / v["ms"] / 1e6, 1)
+                e["hbm_frac"] = round(v["bytes"] / v["ms"] / 1e6 / HBM_PEAK_GBS, 4)
+            if v["flops"] > 0:
+                e["TFLOP/s"] = round(v["flops"] / v["ms"] / 1e9, 2)
+                e["mfma_f32_frac"] = round(v["flops"] / v["ms"] / 1e9 / MFMA_F32_PEAK_TFLOPS, 4)
+            isolated[k] = e
+        isolated["note"] = f"{ISO} steps after the timed region with the sub-batches stepped one after the other (no time-sharing)"
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -367,6 +404,8 @@ def main():
                          "per problem) followed by the exact lapjv emulation for the problems it declined (lap_kernel); algorithmic bytes "
                          "= 24 B per row and column (boxes + score in, x/y out); the kernel is latency/dependency-bound (augmenting-path "
                          "search), its HBM fraction is reported as measured, see DESIGN.md"})
+    if isolated and fam in isolated:  # the same family with the GPU to itself (see kernels_isolated)
+        roof["isolated"] = isolated[fam]
     prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
     if os.path.exists(prof):
         try:
@@ -465,6 +504,7 @@ def main():
         "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         "kernels": kernels,
         "lap_fast_path": fast_stats,
+        "kernels_isolated": isolated,
         "achieved_problem_sizes": achieved_dims, "host_input": host_input,
         "gpu_busy_frac": gpu_busy_ms / (elapsed * 1e3) if elapsed > 0 else None,
         "flushes_per_step": (c1["flushes"] - c0["flushes"]) / K, "launches_per_step": (c1["launches"] - c0["launches"]) / K,

@@ -14,29 +14,37 @@
 // not a contraction) over the same slabs.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/motcpp_amd.h"
 
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kTile = 64;
 constexpr int kSlab = 32;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { kCosine = 0, kDot = 1, kEuclid = 2 };
 
-template <int METRIC>
+// TILE = 64: a wavefront owns one 32 x 32 MFMA tile. TILE = 128 (problems with at least 128 rows and columns): a wavefront owns
+// 64 x 64 = 2 x 2 MFMA tiles — four independent accumulator chains per wavefront, one LDS operand read per MFMA instead of two,
+// and half the feature bytes per flop out of L2 (each row tile is re-read once per column tile of the problem: at 64 x 64 the
+// fp32 MFMA rate would need ~10 TB/s of L2 reads). Every output element is still the k-ordered chain of its own products.
+template <int METRIC, int TILE>
 __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __restrict__ tasks) {
+  constexpr int TPR = kThreads / TILE;  // threads staging one row of a slab
+  constexpr int QPT = 8 / TPR;          // 16-byte pieces of a slab row per thread
+  constexpr int NA = TILE / 64;         // MFMA tiles per wavefront and dimension
+  static_assert(METRIC != kEuclid || TILE == 64, "the euclidean variant keeps the 64 x 64 tile");
   const mot_cos_task T = tasks[blockIdx.z];
-  const int row0 = blockIdx.y * kTile, col0 = blockIdx.x * kTile;
+  const int row0 = blockIdx.y * TILE, col0 = blockIdx.x * TILE;
   if (row0 >= T.n || col0 >= T.m) return;
-  __shared__ float As[kTile][kSlab + 1];
-  __shared__ float Bs[kTile][kSlab + 1];
-  __shared__ float nrm[2 * kTile];
+  __shared__ float As[TILE][kSlab + 1];
+  __shared__ float Bs[TILE][kSlab + 1];
+  __shared__ float nrm[2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // staging role: row tid >> 2 of each tile, k quads (tid & 3) and 4 + (tid & 3) of a slab
-  const int sr = tid >> 2, sq = tid & 3;
+  const int sr = tid / TPR, sq = tid % TPR;
   const float* pa = nullptr;
   const float* pb = nullptr;
   {
@@ -45,11 +53,11 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
     if (c < T.m) pb = T.b + static_cast<size_t>(T.bidx ? T.bidx[c] : c) * T.ldb;
   }
   const bool vec = ((T.lda | T.ldb | T.d) & 3) == 0 && ((reinterpret_cast<size_t>(T.a) | reinterpret_cast<size_t>(T.b)) & 15) == 0;
-  float4 ra[2], rb[2];
+  float4 ra[QPT], rb[QPT];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = k0 + 16 * h + 4 * sq;
+    for (int h = 0; h < QPT; ++h) {
+      const int k = k0 + 4 * (h * TPR + sq);
       float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
       if (vec && k + 3 < T.d) {
         if (pa) va = *reinterpret_cast<const float4*>(pa + k);
@@ -66,16 +74,24 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
       ra[h] = va; rb[h] = vb;
     }
   };
-  const int wr = wave >> 1, wc = wave & 1;  // wavefront -> 32x32 sub-tile
-  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  // norm role (cosine): lane < 32 of wavefront w owns row q = 32 w + lane of [A rows 0..63 | B rows 0..63]
-  const int q = wave * 32 + (lane & 31);
+  const int wr = wave >> 1, wc = wave & 1;  // wavefront -> (TILE/2) x (TILE/2) sub-tile
+  f32x16 acc[NA][NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // norm role (cosine): the 2 * TILE rows [A rows | B rows] are dealt to the threads, TILE / 128 ... one row per (wave, lane slot)
+  constexpr int NQ = (2 * TILE) / 128;            // 1 (lanes < 32 of each wavefront) or 2 (every lane)
+  const bool norm_lane = (NQ == 2) || lane < 32;
+  const int q = (NQ == 2) ? wave * 64 + lane : wave * 32 + (lane & 31);
   float nsum = 0.0f;
   fetch(0);
   for (int k0 = 0; k0 < T.d; k0 += kSlab) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = 16 * h + 4 * sq;
+    for (int h = 0; h < QPT; ++h) {
+      const int k = 4 * (h * TPR + sq);
       As[sr][k] = ra[h].x; As[sr][k + 1] = ra[h].y; As[sr][k + 2] = ra[h].z; As[sr][k + 3] = ra[h].w;
       Bs[sr][k] = rb[h].x; Bs[sr][k + 1] = rb[h].y; Bs[sr][k + 2] = rb[h].z; Bs[sr][k + 3] = rb[h].w;
     }
@@ -86,20 +102,27 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
       // 64 x 64 distances on the vector ALUs: thread -> row tid >> 2, columns (tid & 3) + 4 j; chains in k order
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        float sacc = acc[j];
+        float sacc = acc[0][0][j];
         const int cc = sq + 4 * j;
         for (int kk = 0; kk < kk_end; ++kk) { const float df = As[sr][kk] - Bs[cc][kk]; sacc = __builtin_fmaf(df, df, sacc); }
-        acc[j] = sacc;
+        acc[0][0][j] = sacc;
       }
     } else {
-      if (METRIC == kCosine && lane < 32) {
-        const float* rowp = (q < kTile) ? As[q] : Bs[q - kTile];
+      if (METRIC == kCosine && norm_lane) {
+        const float* rowp = (q < TILE) ? As[q] : Bs[q - TILE];
         for (int kk = 0; kk < kk_end; ++kk) nsum = __builtin_fmaf(rowp[kk], rowp[kk], nsum);
       }
       for (int kk = 0; kk < kk_end; kk += 2) {  // k-ascending chain: D = fma(a_k1,b_k1, fma(a_k0,b_k0, C))
-        const float a = As[wr * 32 + (lane & 31)][kk + (lane >> 5)];
-        const float b = Bs[wc * 32 + (lane & 31)][kk + (lane >> 5)];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        float a[NA], b[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          a[i] = As[wr * (TILE / 2) + 32 * i + (lane & 31)][kk + (lane >> 5)];
+          b[i] = Bs[wc * (TILE / 2) + 32 * i + (lane & 31)][kk + (lane >> 5)];
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+          for (int j = 0; j < NA; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -110,29 +133,34 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int c = col0 + sq + 4 * j;
-        if (c < T.m) T.out[static_cast<size_t>(r) * T.ldo + c] = sqrtf(acc[j]);
+        if (c < T.m) T.out[static_cast<size_t>(r) * T.ldo + c] = sqrtf(acc[0][0][j]);
       }
     }
     return;
   }
   if (METRIC == kCosine) {
-    if (lane < 32) nrm[q] = sqrtf(nsum);
+    if (norm_lane) nrm[q] = sqrtf(nsum);
     __syncthreads();
   }
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const int cl = wc * 32 + (lane & 31);
-  const int c = col0 + cl;
-  if (c < T.m) {
-    const float nb = (METRIC == kCosine) ? nrm[kTile + cl] : 0.0f;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int rl = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      const int r = row0 + rl;
-      if (r < T.n) {
-        if (METRIC == kDot) { T.out[static_cast<size_t>(r) * T.ldo + c] = acc[reg]; continue; }
-        const float sim = acc[reg] / (nrm[rl] * nb + 1e-10f);
-        const float v = 1.0f - sim;
-        T.out[static_cast<size_t>(r) * T.ldo + c] = (0.0f < v) ? v : 0.0f;  // std::max(0.0f, v)
+  for (int j = 0; j < NA; ++j) {
+    const int cl = wc * (TILE / 2) + 32 * j + (lane & 31);
+    const int c = col0 + cl;
+    if (c >= T.m) continue;
+    const float nb = (METRIC == kCosine) ? nrm[TILE + cl] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int rl = wr * (TILE / 2) + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int r = row0 + rl;
+        if (r < T.n) {
+          if (METRIC == kDot) { T.out[static_cast<size_t>(r) * T.ldo + c] = acc[i][j][reg]; continue; }
+          const float sim = acc[i][j][reg] / (nrm[rl] * nb + 1e-10f);
+          const float v = 1.0f - sim;
+          T.out[static_cast<size_t>(r) * T.ldo + c] = (0.0f < v) ? v : 0.0f;  // std::max(0.0f, v)
+        }
       }
     }
   }
@@ -144,10 +172,15 @@ namespace mot {
 // metric: 0 cosine distance, 1 raw dot product, 2 euclidean distance
 hipError_t launch_embed(int metric, const mot_cos_task* tasks, int ntasks, int max_n, int max_m, hipStream_t st) {
   if (ntasks <= 0 || max_n <= 0 || max_m <= 0) return hipSuccess;
-  dim3 g2((max_m + kTile - 1) / kTile, (max_n + kTile - 1) / kTile, ntasks);
-  if (metric == kCosine) hipLaunchKernelGGL(embed_kernel<kCosine>, g2, dim3(kThreads), 0, st, tasks);
-  else if (metric == kDot) hipLaunchKernelGGL(embed_kernel<kDot>, g2, dim3(kThreads), 0, st, tasks);
-  else if (metric == kEuclid) hipLaunchKernelGGL(embed_kernel<kEuclid>, g2, dim3(kThreads), 0, st, tasks);
+  static const bool force64 = std::getenv("MOT_EMBED_TILE64") != nullptr;  // measurement aid (A/B of the two tilings)
+  const bool big = max_n >= 128 && max_m >= 128 && metric != kEuclid && !force64;
+  const int tile = big ? 128 : 64;
+  dim3 g2((max_m + tile - 1) / tile, (max_n + tile - 1) / tile, ntasks);
+  if (metric == kCosine && big) hipLaunchKernelGGL((embed_kernel<kCosine, 128>), g2, dim3(kThreads), 0, st, tasks);
+  else if (metric == kCosine) hipLaunchKernelGGL((embed_kernel<kCosine, 64>), g2, dim3(kThreads), 0, st, tasks);
+  else if (metric == kDot && big) hipLaunchKernelGGL((embed_kernel<kDot, 128>), g2, dim3(kThreads), 0, st, tasks);
+  else if (metric == kDot) hipLaunchKernelGGL((embed_kernel<kDot, 64>), g2, dim3(kThreads), 0, st, tasks);
+  else if (metric == kEuclid) hipLaunchKernelGGL((embed_kernel<kEuclid, 64>), g2, dim3(kThreads), 0, st, tasks);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -117,6 +117,9 @@ typedef struct mot_kf_task {
   float q[3];                /* XYSR only: Q(4,4), Q(5,5), Q(6,6)                             */
   int32_t reserved;
   float warp[9];             /* camera-motion warp, 3x3 row-major (mot_kf_warp, mot_kf_predict_warp) */
+  const float* conf;         /* optional, MOT_KF_XYAH update: detection confidences, indexed like `meas` — the NSA Kalman rule of
+                                BaseKalmanFilter::project, R = ((1 - conf) * std)^2 (src/motion/kalman_filter.cpp:60-75; StrongSORT's
+                                Track::update passes the detection's confidence, strongsort.cpp:153). NULL: confidence 0 */
 } mot_kf_task;
 int mot_kf_dim(int kf_kind);
 int mot_kf_initiate(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
@@ -443,6 +446,8 @@ int mot_lap_geom_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_x
 int mot_kf_apply_host(mot_ctx* ctx, int kf_kind, int op, int n, const float* meas4, const float* q3_or_null,
                       const unsigned char* flags_or_null, float* mean, float* cov, float* boxes4_or_null);
 /* mot_kf_warp on AoS host states; predict_first != 0: mot_kf_predict_warp instead (predict, then warp, one launch) */
+/* mot_kf_update for host arrays with per-measurement confidences (NSA Kalman; XYAH only, conf NULL = 0) */
+int mot_kf_update_conf_host(mot_ctx* ctx, int kf_kind, int n, const float* meas4, const float* conf_or_null, float* mean, float* cov);
 int mot_kf_warp_host(mot_ctx* ctx, int kf_kind, int n, const float* warp9, int predict_first, const float* q3_or_null,
                      float* mean, float* cov, float* boxes4_or_null);
 

@@ -202,6 +202,13 @@ class Context:
                                              _p(mean), _p(cov), _p(boxes) if boxes is not None else None))
         return (mean, cov, boxes) if want_boxes else (mean, cov)
 
+    def kf_update_conf(self, mean, cov, meas, conf):
+        """XYAH Kalman update with per-measurement confidences (NSA Kalman, mot_kf_update_conf_host)"""
+        mean, cov, meas, conf = f32(mean).copy(), f32(cov).copy(), f32(meas).reshape(-1, 4), f32(conf)
+        self.lib.mot_kf_update_conf_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.mot_kf_update_conf_host(self.h, KF_XYAH, mean.shape[0], _p(meas), _p(conf), _p(mean), _p(cov)))
+        return mean, cov
+
     def kf_warp(self, kind, mean, cov, warp9, predict_first=False, q=None, want_boxes=False):
         """mot_kf_warp on AoS states (predict_first: one predict launch with the warp applied after it)."""
         mean, cov = f32(mean).copy(), f32(cov).copy()

@@ -368,7 +368,7 @@ int mot_lap_geom_host(mot_ctx* c, const float* a, int n, const float* b, int m, 
 }
 
 static int kf_host(mot_ctx* c, int kind, int op, int n, const float* meas4, const float* q3, const unsigned char* flags,
-                   const float* warp9, float* mean, float* cov, float* boxes4) {
+                   const float* warp9, float* mean, float* cov, float* boxes4, const float* conf = nullptr) {
   if (n <= 0) return MOT_OK;
   const int D = mot_kf_dim(kind);
   const int RS = D + D * D;  // one record per track: mean then covariance (the slab layout of mot_kf_task)
@@ -377,8 +377,9 @@ static int kf_host(mot_ctx* c, int kind, int op, int n, const float* meas4, cons
     for (int k = 0; k < D; ++k) sm[static_cast<size_t>(i) * RS + k] = mean[static_cast<size_t>(i) * D + k];
     for (int k = 0; k < D * D; ++k) sm[static_cast<size_t>(i) * RS + D + k] = cov[static_cast<size_t>(i) * D * D + k];
   }
-  DBuf dm, dz, df, db, dt;
+  DBuf dm, dz, df, db, dt, dcf;
   MOT_HIP(c, dm.alloc(sm.size() * 4)); MOT_HIP(c, dz.alloc(static_cast<size_t>(4) * n * 4));
+  if (conf) { MOT_HIP(c, dcf.alloc(static_cast<size_t>(n) * 4)); MOT_HIP(c, hipMemcpyAsync(dcf.p, conf, static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, c->stream)); }
   MOT_HIP(c, df.alloc(n)); MOT_HIP(c, db.alloc(static_cast<size_t>(4) * n * 4)); MOT_HIP(c, dt.alloc(sizeof(mot_kf_task)));
   MOT_HIP(c, hipMemcpyAsync(dm.p, sm.data(), sm.size() * 4, hipMemcpyHostToDevice, c->stream));
   if (meas4) {
@@ -391,6 +392,7 @@ static int kf_host(mot_ctx* c, int kind, int op, int n, const float* meas4, cons
   t.meas = dz.as<float>(); t.ldm = n; t.boxes = boxes4 ? db.as<float>() : nullptr; t.ldb = n;
   t.q[0] = q3 ? q3[0] : 0.01f; t.q[1] = q3 ? q3[1] : 0.01f; t.q[2] = q3 ? q3[2] : 0.0001f;
   if (warp9) std::memcpy(t.warp, warp9, sizeof(t.warp));
+  t.conf = conf ? dcf.as<float>() : nullptr;
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, mot::launch_kf_op(op, kind, dt.as<mot_kf_task>(), 1, n, c->stream));
   MOT_HIP(c, hipMemcpyAsync(sm.data(), dm.p, sm.size() * 4, hipMemcpyDeviceToHost, c->stream));
@@ -403,6 +405,11 @@ static int kf_host(mot_ctx* c, int kind, int op, int n, const float* meas4, cons
     if (boxes4) for (int k = 0; k < 4; ++k) boxes4[static_cast<size_t>(i) * 4 + k] = sb[static_cast<size_t>(k) * n + i];
   }
   return MOT_OK;
+}
+
+int mot_kf_update_conf_host(mot_ctx* c, int kind, int n, const float* meas4, const float* conf, float* mean, float* cov) {
+  if (conf && kind != MOT_KF_XYAH) return MOT_ERR_INVALID;
+  return kf_host(c, kind, 2, n, meas4, nullptr, nullptr, nullptr, mean, cov, nullptr, conf);
 }
 
 int mot_feat_update_host(mot_ctx* c, int mode, float alpha, int n, int d, float* feat, const float* src) {

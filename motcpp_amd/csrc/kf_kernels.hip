@@ -312,13 +312,13 @@ __device__ __forceinline__ void s8_predict(St<8>& s) {
   for (int i = 0; i < 8; ++i) s.P[i][i] = s.P[i][i] + sd[i] * sd[i];
 }
 template <int KIND>
-__device__ __forceinline__ void s8_update(St<8>& s, const float z[4]) {
+__device__ __forceinline__ void s8_update(St<8>& s, const float z[4], float conf = 0.0f) {
   const float h = s.m[3];
   float sd[4] = {kWp * h, kWp * h, kWp * h, kWp * h};
   if (KIND == MOT_KF_XYAH) {
     sd[2] = 1e-1f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sd[i] = sd[i] * (1.0f - 0.0f);  // NSA factor with confidence 0 (kalman_filter.cpp:67)
+    for (int i = 0; i < 4; ++i) sd[i] = sd[i] * (1.0f - conf);  // NSA Kalman: R_k = ((1 - c_k) std)^2 (kalman_filter.cpp:67)
   }
   float S[4][4];
 #pragma unroll
@@ -454,10 +454,12 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
   St<D> s;
   bool no_store = false;
   float z[4] = {0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] float zc = 0.0f;
   if ((OP == OP_INIT || OP == OP_UPDATE) && active) {
     const int c = T.midx ? T.midx[i] : i;
 #pragma unroll
     for (int k = 0; k < 4; ++k) z[k] = T.meas[static_cast<size_t>(k) * T.ldm + c];
+    if (OP == OP_UPDATE && KIND == MOT_KF_XYAH && T.conf) zc = T.conf[c];
   }
   if (OP == OP_BOXES) {
     if (active) {  // only the first four mean components are needed: one 16-byte load per track
@@ -517,7 +519,7 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
               s8_predict<KIND>(s);
             }
           }
-          if constexpr (KIND == MOT_KF_XYSR) xysr_update(s, z); else s8_update<KIND>(s, z);
+          if constexpr (KIND == MOT_KF_XYSR) xysr_update(s, z); else s8_update<KIND>(s, z, zc);
         }
         no_store = (OP == OP_PREDICT || OP == OP_PREDICT_WARP) && (f & MOT_KF_NO_STORE);
       }
@@ -611,12 +613,14 @@ __global__ void __launch_bounds__(256) kf_update8_kernel(const mot_kf_task* __re
   const bool active = item < T.n;
   float* rec = tile + tr * RS;
   float z[4] = {0.f, 0.f, 0.f, 0.f};
+  float zc = 0.0f;
   unsigned f = 0u;
   if (active) {
     const int c = T.midx ? T.midx[item] : item;
 #pragma unroll
     for (int k = 0; k < 4; ++k) z[k] = T.meas[static_cast<size_t>(k) * T.ldm + c];
     f = T.flags ? T.flags[item] : 0u;
+    if (KIND == MOT_KF_XYAH && T.conf) zc = T.conf[c];
   }
   float P[8];
   {
@@ -655,7 +659,7 @@ __global__ void __launch_bounds__(256) kf_update8_kernel(const mot_kf_task* __re
   if (KIND == MOT_KF_XYAH) {
     sd[2] = 1e-1f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sd[i] = sd[i] * (1.0f - 0.0f);
+    for (int i = 0; i < 4; ++i) sd[i] = sd[i] * (1.0f - zc);  // NSA Kalman (kalman_filter.cpp:67); 0 unless the task carries confidences
   }
   float S[4][4];
 #pragma unroll

@@ -371,6 +371,14 @@ void orc_kf_update(int kind, int n, const float* meas, const float* q, float* me
     }
   }
 }
+// XYAH update with per-measurement confidences (NSA Kalman, kalman_filter.cpp:60-75; StrongSORT's Track::update, strongsort.cpp:153)
+void orc_kf_update_conf(int n, const float* meas, const float* conf, float* mean, float* cov) {
+  for (int t = 0; t < n; ++t) {
+    State8 s; load8(s, mean + 8 * t, cov + 64 * t);
+    KfXYAH::update(s, meas + 4 * t, conf ? conf[t] : 0.0f);
+    store8(s, mean + 8 * t, cov + 64 * t);
+  }
+}
 // camera-motion warp of stored states, warp9 = 3x3 row-major: kind 0 KalmanFilterXYSR::apply_affine_correction
 // (m = W[0:2,0:2], t = W[0:2,2]); kind 2 BotSTrack::multi_gmc on the XYWH state. Returns -1 for XYAH (no such step).
 int orc_kf_warp(int kind, int n, const float* warp9, float* mean, float* cov) {

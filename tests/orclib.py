@@ -166,6 +166,13 @@ class Oracle:
         self.lib.orc_kf_update(kind, mean.shape[0], meas.ctypes, qp, mean.ctypes, cov.ctypes)
         return mean, cov
 
+    def kf_update_conf(self, mean, cov, meas, conf):
+        """XYAH update with per-measurement confidences (NSA Kalman)"""
+        mean, cov, meas, conf = f32(mean).copy(), f32(cov).copy(), f32(meas).reshape(-1, 4), f32(conf)
+        self.lib.orc_kf_update_conf.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.orc_kf_update_conf(mean.shape[0], meas.ctypes.data, conf.ctypes.data, mean.ctypes.data, cov.ctypes.data)
+        return mean, cov
+
     def kf_warp(self, kind, mean, cov, warp9):
         mean, cov, w = f32(mean).copy(), f32(cov).copy(), f32(warp9).reshape(9)
         if self.lib.orc_kf_warp(kind, mean.shape[0], w.ctypes, mean.ctypes, cov.ctypes) != 0:

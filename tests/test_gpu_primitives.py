@@ -485,3 +485,20 @@ def test_fuse_iou(ctx, orc, n, m):
     assert np.array_equal(g, o)
     iou = orc.iou_batch(a, b).astype(np.float64)
     assert np.allclose(g, 1 - (1 - reid.astype(np.float64)) * (1 + iou) / 2, atol=1e-6)
+
+
+@pytest.mark.parametrize("n", [1, 64, 333, 5000])
+def test_nsa_kalman_update(ctx, orc, n):
+    """BaseKalmanFilter::update(mean, cov, z, confidence) (kalman_filter.cpp:60-112): the measurement noise is scaled by
+    (1 - confidence) per detection — StrongSORT's Track::update (strongsort.cpp:153). Bit-identical to the restatement, and
+    confidence 0 is the plain update."""
+    mean, cov, z = _gating_states(orc, L.KF_XYAH, n, 7 * n)
+    r = np.random.default_rng(n)
+    conf = r.uniform(0.0, 1.0, n).astype(np.float32)
+    conf[::7] = 0.0
+    gm, gc = ctx.kf_update_conf(mean, cov, z, conf)
+    om, oc = orc.kf_update_conf(mean, cov, z, conf)
+    assert np.array_equal(gm, om) and np.array_equal(gc, oc)
+    pm, pc = orc.kf_update(L.KF_XYAH, mean, cov, z)
+    assert np.array_equal(gm[::7], pm[::7]) and np.array_equal(gc[::7], pc[::7])
+    assert n < 8 or not np.array_equal(gm, pm)

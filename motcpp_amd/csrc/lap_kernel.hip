@@ -185,7 +185,9 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status)
 }
 
 template <int kThreads, int lds_mode, int RPL, int FLAVOR>
-__global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR == 2)) lap_kernel(const mot_lap_task* __restrict__ tasks, int ntasks, int check_status) {
+__global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR == 2)) lap_kernel(const mot_lap_task* __restrict__ tasks, int ntasks, int check_status, const int* declined) {
+  // behind the fast path: its count of declined problems; usually zero, and then there is nothing to look for
+  if (check_status && declined != nullptr && *declined == 0) return;
   // behind the fast path the grid is smaller than the task array: a block walks its share of it and solves what is left
   for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
     const mot_lap_task T = tasks[task];
@@ -198,7 +200,18 @@ __global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR 
 
 namespace mot {
 size_t lap_scratch_bytes(int n, int m) { return lap_task_scratch_bytes(n, m); }
-hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool plain_costs, hipStream_t st);
+hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool plain_costs, int* declined, hipStream_t st);
+
+namespace {
+// one counter per launch in flight (the sparse kernel counts the problems it declines, the exact kernel reads it): a ring of
+// device ints per device, handed out round-robin — far more slots than launches can be in flight at once
+constexpr int kDeclSlots = 4096;
+int* decl_ring(int dev_slot) {
+  static int* ring[64] = {};
+  if (!ring[dev_slot]) { if (hipMalloc(reinterpret_cast<void**>(&ring[dev_slot]), sizeof(int) * kDeclSlots) != hipSuccess) ring[dev_slot] = nullptr; }
+  return ring[dev_slot];
+}
+}  // namespace
 
 // Threads per problem: one wavefront (no barriers, no LDS merges; 4-8 problems co-resident per CU) unless the problem is
 // large AND there are too few problems to fill the chip anyway, where 4 wavefronts cut the latency of a row pass.
@@ -207,8 +220,22 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   if (ntasks <= 0) return hipSuccess;
   // fast path first (not for the general association measures: there a pair that does not intersect has no constant cost)
   const bool fast = !general_assoc;
+  int* declined = nullptr;
   if (fast) {
-    hipError_t e = launch_lap_sparse(tasks, ntasks, max_n, max_m, plain_costs, st);
+    static std::mutex ring_mu;
+    static unsigned next_slot[64] = {};
+    int dev0 = 0;
+    (void)hipGetDevice(&dev0);
+    const int ds = (dev0 >= 0 && dev0 < 64) ? dev0 : 0;
+    {
+      std::lock_guard<std::mutex> lk(ring_mu);
+      int* ring = decl_ring(ds);
+      if (!ring) return hipErrorOutOfMemory;
+      declined = ring + (next_slot[ds]++ % kDeclSlots);
+    }
+    hipError_t e = hipMemsetAsync(declined, 0, sizeof(int), st);
+    if (e != hipSuccess) return e;
+    e = launch_lap_sparse(tasks, ntasks, max_n, max_m, plain_costs, declined, st);
     if (e != hipSuccess) return e;
   }
   const size_t n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1, nm = n + m;
@@ -252,7 +279,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   bool launched = false;
 #define MOT_TRY(T, M, R, G)                                                                                \
   if (!launched && threads == T && mode == M && rpl == R && flavor == G) {                                 \
-    hipLaunchKernelGGL((lap_kernel<T, M, R, G>), dim3(grid), dim3(T), lds, st, tasks, ntasks, fast ? 1 : 0); \
+    hipLaunchKernelGGL((lap_kernel<T, M, R, G>), dim3(grid), dim3(T), lds, st, tasks, ntasks, fast ? 1 : 0, declined); \
     launched = true;                                                                                       \
   }
   MOT_LAP_VARIANTS(MOT_TRY)

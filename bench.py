@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--isolated-steps", type=int, default=None,
                     help="after the timed region: this many steps with the sub-batches one after the other, for per-kernel times "
                          "without time-sharing (reported as kernels_isolated; default 4, C4: 0)")
+    ap.add_argument("--no-in-flight", dest="in_flight", action="store_false",
+                    help="ByteTrack on the device keeps two frames in flight per sub-batch from ONE host thread (mot_bt_enqueue_packed / "
+                         "mot_bt_collect_packed: the result copy of frame f overlaps the kernels of frame f + 1; measured 1.6 M against "
+                         "1.13 M frames/s at the north-star shape); this flag goes back to one driver thread per sub-batch waiting for each frame")
     ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (0: workload default)")
     ap.add_argument("--threads", type=int, default=0, help="host worker threads for the per-stream lifecycle, shared by the sub-batches (0: min(64, cores))")
     ap.add_argument("--gather-every", type=int, default=8)
@@ -245,11 +249,36 @@ def main():
     def stream0_rows(out, cnt):
         return rows_p[0][:cnt[0]].copy() if packed else out[0, :cnt[0]].copy()
 
+    in_flight = args.in_flight and packed and tracker == "bytetrack"
+
+    def run_pipelined(f0, n, keep_limit):
+        """frames f0 .. f0+n-1 with two frames in flight per sub-batch, one host thread; returns when the last one is collected"""
+        def enq(f):
+            for p in range(PIPE):
+                batches[p].enqueue_packed(dev_dets.data_ptr() + (f * S + bounds[p]) * 6 * M * 4, full_counts[p], rows_cap[p])
+
+        def col(k):
+            for p in range(PIPE):
+                tot_p[p] = batches[p].collect_packed(rows_p[p], cnt_all[bounds[p]:bounds[p + 1]])
+            if rank == 0 and k < keep_limit:
+                kept.append(stream0_rows(None, cnt_all))
+            if world > 1 and f0 >= W and ((k + 1) % args.gather_every == 0 or k == n - 1):
+                gather(None, cnt_all)
+        enq(f0)
+        for k in range(1, n):
+            enq(f0 + k)
+            col(k - 1)
+        col(n - 1)
+
     kept = []  # stream 0 outputs of rank 0 for the parity spot check
-    for f in range(W):
-        out, cnt = step(f)
-        if rank == 0 and f < 40:
-            kept.append(stream0_rows(out, cnt))
+    if in_flight:
+        run_pipelined(0, W, 40)
+        out, cnt = None, cnt_all
+    else:
+        for f in range(W):
+            out, cnt = step(f)
+            if rank == 0 and f < 40:
+                kept.append(stream0_rows(out, cnt))
     n_kept_warm = len(kept)
     if world > 1:
         gather(out, cnt)
@@ -261,12 +290,15 @@ def main():
     diag_ctx.lap_fast_stats(reset=True)
     c0 = counters()
     t0 = time.perf_counter()
-    for k in range(K):
-        out, cnt = step(W + k)
-        if world > 1 and ((k + 1) % args.gather_every == 0 or k == K - 1):
-            gather(out, cnt)
-        if rank == 0 and k < 24:
-            kept.append(stream0_rows(out, cnt))
+    if in_flight:
+        run_pipelined(W, K, 24)
+    else:
+        for k in range(K):
+            out, cnt = step(W + k)
+            if world > 1 and ((k + 1) % args.gather_every == 0 or k == K - 1):
+                gather(out, cnt)
+            if rank == 0 and k < 24:
+                kept.append(stream0_rows(out, cnt))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -334,13 +366,34 @@ def main():
                 b.step(resident_ptr=stage[p].data_ptr(), counts=full_counts[p], out=out_all[s0:s1], out_counts=cnt_all[s0:s1])
 
         torch.cuda.synchronize()
-        th0 = time.perf_counter()
-        for h in range(H):
-            if pools is None:
-                sub_step_host(0, h)
-            else:
-                for fut in [pools[p].submit(sub_step_host, p, h) for p in range(PIPE)]:
-                    fut.result()
+        if in_flight:  # the same two-frames-in-flight pipeline, each frame preceded by its H2D copy on the sub-batch's stream
+            stage2 = [[stage[p], torch.empty_like(stage[p])] for p in range(PIPE)]
+
+            def enq_h(h):
+                for p in range(PIPE):
+                    b = batches[p]
+                    src = pinned[h, bounds[p]:bounds[p + 1]]
+                    dst = stage2[p][h & 1]
+                    b.ctx._chk(b.lib.mot_memcpy_h2d(b.ctx.h, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), C.c_size_t(src.numel() * 4)))
+                    b.enqueue_packed(dst.data_ptr(), full_counts[p], rows_cap[p])
+
+            def col_h():
+                for p in range(PIPE):
+                    tot_p[p] = batches[p].collect_packed(rows_p[p], cnt_all[bounds[p]:bounds[p + 1]])
+            th0 = time.perf_counter()
+            enq_h(0)
+            for h in range(1, H):
+                enq_h(h)
+                col_h()
+            col_h()
+        else:
+            th0 = time.perf_counter()
+            for h in range(H):
+                if pools is None:
+                    sub_step_host(0, h)
+                else:
+                    for fut in [pools[p].submit(sub_step_host, p, h) for p in range(PIPE)]:
+                        fut.result()
         torch.cuda.synchronize()
         th1 = time.perf_counter()
         host_input = {"value": S * H / (th1 - th0), "unit": "frames/s (this rank)", "steps": H, "ms_per_step": (th1 - th0) / H * 1e3,
@@ -497,7 +550,7 @@ def main():
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "tracker": tracker, "tracks": P, "dets_per_frame": M, "emb_dim": D,
-                   "streams_per_gpu": S, "frames_per_step": world * S, "settle_frames": Z, "host_threads": PIPE if on_device else threads, "sub_batches": PIPE,
+                   "streams_per_gpu": S, "frames_per_step": world * S, "settle_frames": Z, "host_threads": ((1 if in_flight else PIPE) if on_device else threads), "sub_batches": PIPE, "frames_in_flight": 2 if in_flight else 1,
                    "lifecycle": "device (mot_bt_* / mot_sort_* / mot_bot_* / mot_oc_*: a fixed launch sequence per frame, no host decisions)" if on_device else "host stage machines",
                    "parallelism": f"{world} GPU(s) x {S} independent streams, lockstep stages",
                    "inputs": "detections (and embeddings) resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},

@@ -332,6 +332,13 @@ int mot_bt_step_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts
 /* device-resident result of the last mot_bt_step_packed: packed rows [total][8], offsets [S+1] (offsets[S] = total), counts [S] —
  * what a gather over xGMI reads directly (no copy through the host) */
 int mot_bt_device_output(mot_bt_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts);
+/* Frames in flight: mot_bt_step_packed split in two so that ONE host thread overlaps the result copy of frame f with the
+ * kernels of frame f + 1. mot_bt_enqueue_packed queues a frame's launches and returns (at most two frames may be pending;
+ * h_counts is copied before the call returns); mot_bt_collect_packed waits for the OLDEST pending frame only and delivers its
+ * packed rows (copied on a second stream while the next frame runs). Frames come back in the order they went in; mixing with
+ * mot_bt_step / mot_bt_step_packed while frames are pending is an error. */
+int mot_bt_enqueue_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts, int rows_cap);
+int mot_bt_collect_packed(mot_bt_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows);
 /* parity hook: ids and Kalman states of stream s's live tracks in list order (active then lost): ids [cap], mean [cap][8],
  * cov [cap][64]; returns the number of tracks */
 int mot_bt_dump(mot_bt_batch* b, int s, int* ids, float* mean, float* cov, int cap);

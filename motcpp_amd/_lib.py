@@ -532,6 +532,19 @@ class DeviceByteTrack:
                                                   _p(out_counts), C.byref(total)))
         return total.value
 
+    def enqueue_packed(self, resident_ptr, counts, rows_cap):
+        """queue one frame and return at once (mot_bt_enqueue_packed); at most two frames may be pending"""
+        counts = np.ascontiguousarray(counts, np.int32)
+        self.lib.mot_bt_enqueue_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.ctx._chk(self.lib.mot_bt_enqueue_packed(self.h, C.c_void_p(int(resident_ptr)), _p(counts), int(rows_cap)))
+
+    def collect_packed(self, rows, out_counts):
+        """wait for the oldest pending frame and fetch its packed rows (mot_bt_collect_packed); returns the number of rows"""
+        total = C.c_int(0)
+        self.lib.mot_bt_collect_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_bt_collect_packed(self.h, _p(rows), int(rows.shape[0]), _p(out_counts), C.byref(total)))
+        return total.value
+
     def device_output(self):
         """(rows ptr, offsets ptr, counts ptr): device addresses of the last packed result (mot_bt_device_output)."""
         r, o, c = C.c_void_p(), C.c_void_p(), C.c_void_p()

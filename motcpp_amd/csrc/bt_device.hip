@@ -500,6 +500,19 @@ struct mot_bt_batch {
   int bound_n = 0;        // upper bound of tracked + lost per stream for the NEXT frame (0 right after creation / reset)
   float* d_out = nullptr; int* d_out_counts = nullptr; int out_cap = 0;
   float* d_packed = nullptr; int* d_offsets = nullptr; int packed_cap = 0;  // mot_bt_step_packed
+  // frames in flight (mot_bt_enqueue_packed / mot_bt_collect_packed): two sets of packed tables, page-locked result words
+  struct Flight {
+    float* d_packed = nullptr; int* d_offsets = nullptr; int* d_counts = nullptr; int packed_cap = 0;
+    int* h_meta = nullptr;  // pinned: [0] total rows, [1] error flag, [2..66) maxima of tracks alive, then counts out [S], counts in [S]
+    hipEvent_t done = nullptr;
+    hipEvent_t ev[12] = {};
+    bool pending = false, prof = false;
+    int bd = 0;
+  } fl[2];
+  int fl_head = 0, fl_count = 0;  // oldest pending frame, frames pending
+  const int* d_counts_last = nullptr;  // the frame mot_bt_device_output describes: per-stream row counts, rows, offsets
+  const float* d_rows_last = nullptr; const int* d_offsets_last = nullptr;
+  hipStream_t copy_st = nullptr;
   mot_det_task* det_t = nullptr;
   mot_kf_task *pred_t = nullptr, *box_t = nullptr, *init_t = nullptr, *upd_t = nullptr, *box2_t = nullptr;
   mot_lap_task *lap1_t = nullptr, *lap23_t = nullptr;
@@ -520,6 +533,12 @@ extern "C" {
 
 void mot_bt_destroy(mot_bt_batch* b) {
   if (!b) return;
+  for (auto& f : b->fl) {
+    if (f.h_meta) (void)hipHostFree(f.h_meta);
+    if (f.done) (void)hipEventDestroy(f.done);
+    for (auto& e : f.ev) if (e) (void)hipEventDestroy(e);
+  }
+  if (b->copy_st) (void)hipStreamDestroy(b->copy_st);
   b->mem.release();
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   delete b;
@@ -641,7 +660,8 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
 }
 
 // enqueues the frame's launches; the per-stream tables land in b->d_out ([S][cap_out][8]) and b->d_out_counts
-static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_counts, int cap_out) {
+static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_counts, int cap_out, hipEvent_t* ev = nullptr) {
+  if (!ev) ev = b->ev;
   hipStream_t st = b->ctx->stream;
   const int S = b->S, CAP = b->CAP, D = b->D;
   if (cap_out > b->out_cap) {
@@ -660,25 +680,25 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   const int bn = (b->bound_n < 1) ? 1 : (b->bound_n > CAP ? CAP : b->bound_n);
   const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;  // lists after this frame's births
   const bool prof = b->profile;
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[0], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
   hipLaunchKernelGGL(bt_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, bd, st));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[6], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[6], st));
   MOT_LC_HIP(b, mot::launch_kf_op(6, MOT_KF_XYAH, b->pred_t, S, bn, st));  // predicted boxes of the pool (box-only: nothing is stored)
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, true, st));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[2], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
   hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr);
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, bn, st));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[3], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, true, st));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[4], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
   hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t, prof ? b->d_stats : nullptr);
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[7], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[7], st));
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYAH, b->init_t, S, bd, st));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[8], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[8], st));
   MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, bn, st));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[9], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[9], st));
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, bn2, st));
   {
     const size_t lds = static_cast<size_t>(4) * bn2 * sizeof(float);  // nl <= bn2
@@ -687,12 +707,25 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   }
   hipLaunchKernelGGL(bt_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);
   hipLaunchKernelGGL(bt_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[5], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[5], st));
   MOT_LC_HIP(b, hipGetLastError());
   return MOT_OK;
 }
 
 // after the frame's kernels: error flag, launch bounds of the next frame, event times (synchronises the stream)
+// adds one frame's event times to the profile sums (the events have completed)
+static int bt_account_events(mot_bt_batch* b, hipEvent_t* ev) {
+  float ms = 0.f;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[1], ev[2])); b->lap_ms[0] += ms;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[3], ev[4])); b->lap_ms[1] += ms;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[0], ev[5])); b->frame_ms += ms;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[6], ev[1])); b->kf_ms[0] += ms;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[7], ev[8])); b->kf_ms[1] += ms;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[8], ev[9])); b->kf_ms[2] += ms;
+  b->frames += 1;
+  return MOT_OK;
+}
+
 static int bt_finish_frame(mot_bt_batch* b) {
   hipStream_t st = b->ctx->stream;
   int err = 0;
@@ -703,14 +736,8 @@ static int bt_finish_frame(mot_bt_batch* b) {
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
   if (b->profile) {
-    float ms = 0.f;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[1], b->ev[2])); b->lap_ms[0] += ms;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[3], b->ev[4])); b->lap_ms[1] += ms;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[5])); b->frame_ms += ms;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[6], b->ev[1])); b->kf_ms[0] += ms;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[7], b->ev[8])); b->kf_ms[1] += ms;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[8], b->ev[9])); b->kf_ms[2] += ms;
-    b->frames += 1;
+    const int rce = bt_account_events(b, b->ev);
+    if (rce != MOT_OK) return rce;
   }
   if (err) { b->ctx->err = "mot_bt_step: a stream exceeded cap_tracks / max_dets / cap_out"; return MOT_ERR_CAPACITY; }
   return MOT_OK;
@@ -730,6 +757,7 @@ int mot_bt_step_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts
   hipStream_t st = b->ctx->stream;
   const int S = b->S;
   // staging holds a stream's whole track list (no per-stream row limit short of cap_tracks); the packed buffer rows_cap rows
+  if (b->fl_count > 0) { b->ctx->err = "mot_bt_step_packed: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
   const int rc = bt_enqueue_frame(b, d_dets, h_counts, b->CAP);
   if (rc != MOT_OK) return rc;
   if (!b->d_offsets) b->d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1);
@@ -738,6 +766,7 @@ int mot_bt_step_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts
   hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, b->d_offsets);
   hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, b->CAP, b->d_out_counts, b->d_offsets, b->d_packed, rows_cap);
   MOT_LC_HIP(b, hipGetLastError());
+  b->d_rows_last = b->d_packed; b->d_offsets_last = b->d_offsets; b->d_counts_last = b->d_out_counts;
   int total = 0;
   MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(&total, b->d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -753,10 +782,78 @@ int mot_bt_step_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts
 }
 
 int mot_bt_device_output(mot_bt_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts) {
-  if (!b || !b->d_packed || !b->d_offsets) return MOT_ERR_INVALID;
-  if (d_rows) *d_rows = b->d_packed;
-  if (d_offsets) *d_offsets = b->d_offsets;
-  if (d_counts) *d_counts = b->d_out_counts;
+  if (!b || !b->d_rows_last || !b->d_offsets_last) return MOT_ERR_INVALID;
+  if (d_rows) *d_rows = b->d_rows_last;
+  if (d_offsets) *d_offsets = b->d_offsets_last;
+  if (d_counts) *d_counts = b->d_counts_last;
+  return MOT_OK;
+}
+
+// ---- frames in flight ------------------------------------------------------------------------------------------------
+// mot_bt_step_packed waits for its frame: the host sits idle while the GPU works and the GPU sits idle while the rows
+// cross PCIe. Split in two, a single host thread keeps two frames in flight: enqueue(f + 1) returns as soon as the launches
+// are queued, collect(f) then waits for frame f only (an event), and copies its rows on a second stream while frame f + 1
+// runs. The launch bounds of a frame come from the tracks alive after the last COLLECTED frame plus the detections of the
+// frames enqueued since (a stream gains at most one track per detection).
+int mot_bt_enqueue_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts, int rows_cap) {
+  if (!b || !d_dets || !h_counts || rows_cap <= 0) return MOT_ERR_INVALID;
+  if (b->fl_count >= 2) { b->ctx->err = "mot_bt_enqueue_packed: two frames are already in flight (collect one first)"; return MOT_ERR_INVALID; }
+  hipStream_t st = b->ctx->stream;
+  const int S = b->S;
+  const int slot = (b->fl_head + b->fl_count) & 1;
+  mot_bt_batch::Flight& F = b->fl[slot];
+  if (!b->copy_st) MOT_LC_HIP(b, hipStreamCreateWithFlags(&b->copy_st, hipStreamNonBlocking));
+  if (!F.done) MOT_LC_HIP(b, hipEventCreateWithFlags(&F.done, hipEventDisableTiming));
+  if (!F.h_meta) MOT_LC_HIP(b, hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (66 + 2 * static_cast<size_t>(S)), hipHostMallocDefault));
+  if (!F.d_offsets) { F.d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1); F.d_counts = b->dalloc<int>(S); }
+  if (rows_cap > F.packed_cap) { F.d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); F.packed_cap = F.d_packed ? rows_cap : 0; }
+  if (!F.d_offsets || !F.d_counts || !F.d_packed) return MOT_ERR_NOMEM;
+  int bd = 1;
+  int* counts_in = F.h_meta + 66 + S;  // page-locked copy: the caller's array may change as soon as this call returns
+  for (int s = 0; s < S; ++s) { counts_in[s] = h_counts[s]; bd = (h_counts[s] > bd) ? h_counts[s] : bd; }
+  const int saved = b->bound_n;
+  const mot_bt_batch::Flight& O = b->fl[slot ^ 1];
+  b->bound_n = saved + (O.pending ? O.bd : 0);  // tracks the frame still in flight may have added
+  if (b->bound_n > b->CAP) b->bound_n = b->CAP;
+  if (b->profile && !F.ev[0]) for (auto& e : F.ev) MOT_LC_HIP(b, hipEventCreate(&e));
+  F.prof = b->profile;
+  const int rc = bt_enqueue_frame(b, d_dets, counts_in, b->CAP, F.prof ? F.ev : nullptr);
+  b->bound_n = saved;
+  if (rc != MOT_OK) return rc;
+  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, F.d_offsets);
+  hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, b->CAP, b->d_out_counts, F.d_offsets, F.d_packed, rows_cap);
+  MOT_LC_HIP(b, hipGetLastError());
+  MOT_LC_HIP(b, hipMemcpyAsync(F.d_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToDevice, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta, F.d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 1, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 2, b->d_maxt, sizeof(int) * 64, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 66, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipEventRecord(F.done, st));
+  F.pending = true; F.bd = bd;
+  b->fl_count += 1;
+  return MOT_OK;
+}
+
+int mot_bt_collect_packed(mot_bt_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows) {
+  if (!b || !rows || !out_counts) return MOT_ERR_INVALID;
+  if (b->fl_count <= 0) { b->ctx->err = "mot_bt_collect_packed: no frame in flight"; return MOT_ERR_INVALID; }
+  mot_bt_batch::Flight& F = b->fl[b->fl_head];
+  MOT_LC_HIP(b, hipEventSynchronize(F.done));
+  F.pending = false;
+  b->fl_head ^= 1; b->fl_count -= 1;
+  if (F.prof) { const int rce = bt_account_events(b, F.ev); if (rce != MOT_OK) return rce; }
+  const int total = F.h_meta[0], err = F.h_meta[1];
+  b->bound_n = 0;
+  for (int i = 0; i < 64; ++i) b->bound_n = (F.h_meta[2 + i] > b->bound_n) ? F.h_meta[2 + i] : b->bound_n;
+  std::memcpy(out_counts, F.h_meta + 66, sizeof(int) * b->S);
+  if (total_rows) *total_rows = total;
+  b->d_rows_last = F.d_packed; b->d_offsets_last = F.d_offsets; b->d_counts_last = F.d_counts;  // mot_bt_device_output: the frame just collected
+  if (err) { b->ctx->err = "mot_bt_collect_packed: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
+  if (total > rows_cap || total > F.packed_cap) { b->ctx->err = "mot_bt_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  if (total > 0) {
+    MOT_LC_HIP(b, hipMemcpyAsync(rows, F.d_packed, sizeof(float) * static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, b->copy_st));
+    MOT_LC_HIP(b, hipStreamSynchronize(b->copy_st));
+  }
   return MOT_OK;
 }
 

@@ -240,3 +240,56 @@ def test_packed_output_equals_the_padded_tables():
     assert comm is not None
     comm.close()
     dev.close()
+
+
+def test_two_frames_in_flight_give_the_same_tables():
+    """mot_bt_enqueue_packed / mot_bt_collect_packed: one host thread keeps two frames in flight (frame f + 1 is queued before
+    frame f is fetched); every frame's packed rows still equal the oracle's tables, in order, and a third enqueue is refused."""
+    import torch
+    orc = orclib.load()
+    shapes = [(40, 30), (256, 128), (8, 8), (90, 64), (200, 128)]
+    S, maxd = len(shapes), 128
+    dev = L.DeviceByteTrack(S, 512, maxd)
+    streams = [SynthStream(P, M, 777 + i) for i, (P, M) in enumerate(shapes)]
+    oracles = [orc.tracker(orclib.BYTETRACK) for _ in range(S)]
+    F = 36
+    soa = np.zeros((F, S, 6, maxd), np.float32)
+    counts = np.zeros((F, S), np.int32)
+    want = []
+    for f in range(F):
+        per = []
+        for s, st in enumerate(streams):
+            d, _ = st.next_frame()
+            if (f + 2 * s) % 9 == 4:
+                d = d[:0]
+            counts[f, s] = len(d)
+            soa[f, s, :, :len(d)] = d.T
+            per.append(oracles[s].update(d))
+        want.append(per)
+    ddets = torch.from_numpy(soa).cuda()
+    rows = L.pinned_array(dev.ctx, (S * maxd * 2, 8), np.float32)
+    cnt = L.pinned_array(dev.ctx, (S,), np.int32)
+    cap = rows.shape[0]
+
+    def check(f):
+        total = dev.collect_packed(rows, cnt)
+        assert total == sum(w.shape[0] for w in want[f]), f
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        for s in range(S):
+            assert np.array_equal(rows[off[s]:off[s + 1]], want[f][s]), (f, s)
+
+    ptr = lambda f: ddets.data_ptr() + f * S * 6 * maxd * 4
+    dev.enqueue_packed(ptr(0), counts[0], cap)
+    for f in range(1, F):
+        dev.enqueue_packed(ptr(f), counts[f].copy(), cap)
+        if f == 5:
+            with pytest.raises(L.MotError):
+                dev.enqueue_packed(ptr(f), counts[f], cap)  # two frames are pending
+        check(f - 1)
+    check(F - 1)
+    with pytest.raises(L.MotError):
+        dev.collect_packed(rows, cnt)  # nothing pending
+    # the synchronous call still works afterwards and continues the same streams
+    total = dev.step_packed(ptr(F - 1), np.zeros(S, np.int32), rows, cnt)
+    assert total >= 0
+    dev.close()

@@ -73,7 +73,7 @@ def main():
                     help="after the timed region: this many steps with the sub-batches one after the other, for per-kernel times "
                          "without time-sharing (reported as kernels_isolated; default 4, C4: 0)")
     ap.add_argument("--no-in-flight", dest="in_flight", action="store_false",
-                    help="ByteTrack on the device keeps two frames in flight per sub-batch from ONE host thread (mot_bt_enqueue_packed / "
+                    help="ByteTrack and BoT-SORT on the device keep two frames in flight per sub-batch from ONE host thread (mot_bt_enqueue_packed / "
                          "mot_bt_collect_packed: the result copy of frame f overlaps the kernels of frame f + 1; measured 1.6 M against "
                          "1.13 M frames/s at the north-star shape); this flag goes back to one driver thread per sub-batch waiting for each frame")
     ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (0: workload default)")
@@ -249,13 +249,17 @@ def main():
     def stream0_rows(out, cnt):
         return rows_p[0][:cnt[0]].copy() if packed else out[0, :cnt[0]].copy()
 
-    in_flight = args.in_flight and packed and tracker == "bytetrack"
+    in_flight = args.in_flight and packed and tracker in ("bytetrack", "botsort")
 
     def run_pipelined(f0, n, keep_limit):
         """frames f0 .. f0+n-1 with two frames in flight per sub-batch, one host thread; returns when the last one is collected"""
         def enq(f):
             for p in range(PIPE):
-                batches[p].enqueue_packed(dev_dets.data_ptr() + (f * S + bounds[p]) * 6 * M * 4, full_counts[p], rows_cap[p])
+                dp = dev_dets.data_ptr() + (f * S + bounds[p]) * 6 * M * 4
+                if tracker == "botsort":
+                    batches[p].enqueue_packed(dp, full_counts[p], rows_cap[p], embs_ptr=(dev_embs.data_ptr() + (f * S + bounds[p]) * M * D * 4) if D else None)
+                else:
+                    batches[p].enqueue_packed(dp, full_counts[p], rows_cap[p])
 
         def col(k):
             for p in range(PIPE):

@@ -371,6 +371,10 @@ int mot_bot_reset(mot_bot_batch* b);
 int mot_bot_step_packed(mot_bot_batch* b, const float* d_dets, const int* h_counts, const float* d_embs, const float* h_warps6,
                         const unsigned char* h_has_warp, float* rows, int rows_cap, int* out_counts, int* total_rows);
 int mot_bot_device_output(mot_bot_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts);
+/* frames in flight, as mot_bt_enqueue_packed / mot_bt_collect_packed (h_counts and the warps are copied before the call returns) */
+int mot_bot_enqueue_packed(mot_bot_batch* b, const float* d_dets, const int* h_counts, const float* d_embs, const float* h_warps6,
+                           const unsigned char* h_has_warp, int rows_cap);
+int mot_bot_collect_packed(mot_bot_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows);
 int mot_bot_dump(mot_bot_batch* b, int s, int* ids, float* mean, float* cov, float* feats, unsigned char* has_feat, int cap);
 /* HIP-event timing (enable = 1 resets). out8: [0] summed ms of the three assignment launches, [1] of the first cosine launch,
  * [2] of whole frames, [3] frames, [4] assignment problems queued, [5] sum of their n + m, [6] sum of n*m over the cosine

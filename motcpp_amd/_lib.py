@@ -635,6 +635,22 @@ class DeviceBotSort:
                                                    int(rows.shape[0]), _p(out_counts), C.byref(total)))
         return total.value
 
+    def enqueue_packed(self, dets_ptr, counts, rows_cap, embs_ptr=None, warps=None, has_warp=None):
+        """queue one frame and return at once (mot_bot_enqueue_packed); at most two frames may be pending"""
+        counts = np.ascontiguousarray(counts, np.int32)
+        w = f32(warps).reshape(self.S, 6) if warps is not None else None
+        hw = np.ascontiguousarray(has_warp, np.uint8) if has_warp is not None else None
+        self.lib.mot_bot_enqueue_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.ctx._chk(self.lib.mot_bot_enqueue_packed(self.h, C.c_void_p(int(dets_ptr)), _p(counts), C.c_void_p(int(embs_ptr)) if embs_ptr else None,
+                                                      _p(w) if w is not None else None, _p(hw) if hw is not None else None, int(rows_cap)))
+
+    def collect_packed(self, rows, out_counts):
+        """wait for the oldest pending frame and fetch its packed rows (mot_bot_collect_packed); returns the number of rows"""
+        total = C.c_int(0)
+        self.lib.mot_bot_collect_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_bot_collect_packed(self.h, _p(rows), int(rows.shape[0]), _p(out_counts), C.byref(total)))
+        return total.value
+
     def step(self, dets, counts, embs=None, warps=None, has_warp=None):
         """host convenience: dets [S, N, 6] rows, embs [S, N, E] or None -> list of per-stream tables"""
         dets = f32(dets)

@@ -460,6 +460,17 @@ struct mot_bot_batch {
   int bound_n = 0;
   float* d_out = nullptr; int* d_out_counts = nullptr;
   float* d_packed = nullptr; int* d_offsets = nullptr; int packed_cap = 0;
+  struct Flight {  // a frame in flight (mot_bot_enqueue_packed / mot_bot_collect_packed)
+    float* d_packed = nullptr; int* d_offsets = nullptr; int* d_counts = nullptr; int packed_cap = 0;
+    int* h_meta = nullptr;
+    hipEvent_t done = nullptr;
+    hipEvent_t ev[8] = {};
+    bool pending = false, prof = false;
+    int bd = 0;
+  } fl[2];
+  int fl_head = 0, fl_count = 0;
+  hipStream_t copy_st = nullptr;
+  const float* d_rows_last = nullptr; const int* d_offsets_last = nullptr; const int* d_counts_last = nullptr;
   float* mean = nullptr;   // [S][CAP] Kalman records (8 + 64 floats)
   float* feat = nullptr;   // [S][CAP][E] smooth features
   bool profile = false;
@@ -475,6 +486,12 @@ extern "C" {
 
 void mot_bot_destroy(mot_bot_batch* b) {
   if (!b) return;
+  for (auto& f : b->fl) {
+    if (f.h_meta) (void)hipHostFree(f.h_meta);
+    if (f.done) (void)hipEventDestroy(f.done);
+    for (auto& e : f.ev) if (e) (void)hipEventDestroy(e);
+  }
+  if (b->copy_st) (void)hipStreamDestroy(b->copy_st);
   b->mem.release();
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   delete b;
@@ -623,13 +640,78 @@ int mot_bot_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, int
   return MOT_OK;
 }
 
+}  // extern "C"
+
+// queues one frame's launches: counts already on their way to b->d_counts, warps (if any) to b->d_warps / b->d_has_warp
+static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_counts, const float* d_embs, bool any_warp, int bound_n,
+                       float* d_packed, int* d_offsets, int rows_cap, hipEvent_t* ev) {
+  hipStream_t st = b->ctx->stream;
+  const int S = b->S, CAP = b->CAP, D = b->D;
+  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
+  int bd = 1;
+  for (int s = 0; s < S; ++s) bd = (h_counts[s] > bd) ? h_counts[s] : bd;
+  if (bd > D) bd = D;
+  const int bn = (bound_n < 1) ? 1 : (bound_n > CAP ? CAP : bound_n);
+  const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;
+  const bool emb = b->prm.with_reid && d_embs != nullptr;
+  const bool prof = ev != nullptr;
+  const BotTasks& K = b->tasks;
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
+  hipLaunchKernelGGL(bot_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, emb ? d_embs : nullptr, b->d_warps,
+                     any_warp ? b->d_has_warp : nullptr, K, prof ? b->d_stats : nullptr);
+  MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYWH, K.det, S, bd, st));
+  if (emb) MOT_LC_HIP(b, mot::launch_feat(K.featn, S, bd, st));
+  if (any_warp) {
+    MOT_LC_HIP(b, mot::launch_kf_op(4, MOT_KF_XYWH, K.warp, S, bn, st));       // multi_gmc(unconfirmed) :323
+    MOT_LC_HIP(b, mot::launch_kf_op(5, MOT_KF_XYWH, K.predw, S, bn, st));      // multi_predict + multi_gmc(pool) :316-322
+  }
+  MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYWH, K.pred, S, bn, st));         // multi_predict :316
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
+  if (emb) MOT_LC_HIP(b, mot::launch_embed(MOT_EMB_COSINE, K.cos1, S, bn, bd, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
+  MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bn, bd, true, false, false, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
+  hipLaunchKernelGGL(bot_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K, prof ? b->d_stats : nullptr);
+  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYWH, K.ubox, S, bn, st));
+  if (emb) MOT_LC_HIP(b, mot::launch_embed(MOT_EMB_COSINE, K.cos3, S, bn, bd, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[5], st));
+  MOT_LC_HIP(b, mot::launch_lap(K.lap23, 2 * S, bn, bd, true, false, false, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[6], st));
+  hipLaunchKernelGGL(bot_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K);
+  MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYWH, K.init, S, bd, st));
+  MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYWH, K.upd, S, bn, st));
+  if (emb) {
+    MOT_LC_HIP(b, mot::launch_feat(K.fset, S, bn2, st));
+    MOT_LC_HIP(b, mot::launch_feat(K.fema, S, bn, st));
+  }
+  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYWH, K.obox, S, bn2, st));
+  hipLaunchKernelGGL(bot_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt);
+  hipLaunchKernelGGL(bot_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
+  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, d_offsets);
+  hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, CAP, b->d_out_counts, d_offsets, d_packed, rows_cap);
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
+  MOT_LC_HIP(b, hipGetLastError());
+  return MOT_OK;
+}
+static int bot_account_events(mot_bot_batch* b, hipEvent_t* ev) {
+  float ms = 0.f;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[0], ev[1])); b->frame_ms += ms;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[2], ev[3])); b->cos_ms += ms;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[3], ev[4])); b->lap_ms += ms;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[5], ev[6])); b->lap_ms += ms;
+  b->frames += 1;
+  return MOT_OK;
+}
+
+extern "C" {
+
 int mot_bot_step_packed(mot_bot_batch* b, const float* d_dets, const int* h_counts, const float* d_embs, const float* h_warps6,
                         const unsigned char* h_has_warp, float* rows, int rows_cap, int* out_counts, int* total_rows) {
   if (!b || !d_dets || !h_counts || !rows || !out_counts) return MOT_ERR_INVALID;
+  if (b->fl_count > 0) { b->ctx->err = "mot_bot_step_packed: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
   hipStream_t st = b->ctx->stream;
-  const int S = b->S, CAP = b->CAP, D = b->D;
+  const int S = b->S;
   MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
-  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
   bool any_warp = false;
   std::vector<int> hw;
   if (h_warps6 && h_has_warp) {
@@ -641,51 +723,11 @@ int mot_bot_step_packed(mot_bot_batch* b, const float* d_dets, const int* h_coun
     MOT_LC_HIP(b, hipMemcpyAsync(b->d_has_warp, hw.data(), sizeof(int) * S, hipMemcpyHostToDevice, st));
     MOT_LC_HIP(b, hipStreamSynchronize(st));  // hw is a local
   }
-  int bd = 1;
-  for (int s = 0; s < S; ++s) bd = (h_counts[s] > bd) ? h_counts[s] : bd;
-  if (bd > D) bd = D;
-  const int bn = (b->bound_n < 1) ? 1 : (b->bound_n > CAP ? CAP : b->bound_n);
-  const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;
-  const bool emb = b->prm.with_reid && d_embs != nullptr;
-  const bool prof = b->profile;
-  const BotTasks& K = b->tasks;
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[0], st));
-  hipLaunchKernelGGL(bot_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, emb ? d_embs : nullptr, b->d_warps,
-                     any_warp ? b->d_has_warp : nullptr, K, prof ? b->d_stats : nullptr);
-  MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYWH, K.det, S, bd, st));
-  if (emb) MOT_LC_HIP(b, mot::launch_feat(K.featn, S, bd, st));
-  if (any_warp) {
-    MOT_LC_HIP(b, mot::launch_kf_op(4, MOT_KF_XYWH, K.warp, S, bn, st));       // multi_gmc(unconfirmed) :323
-    MOT_LC_HIP(b, mot::launch_kf_op(5, MOT_KF_XYWH, K.predw, S, bn, st));      // multi_predict + multi_gmc(pool) :316-322
-  }
-  MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYWH, K.pred, S, bn, st));         // multi_predict :316
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[2], st));
-  if (emb) MOT_LC_HIP(b, mot::launch_embed(MOT_EMB_COSINE, K.cos1, S, bn, bd, st));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[3], st));
-  MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bn, bd, true, false, false, st));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[4], st));
-  hipLaunchKernelGGL(bot_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K, prof ? b->d_stats : nullptr);
-  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYWH, K.ubox, S, bn, st));
-  if (emb) MOT_LC_HIP(b, mot::launch_embed(MOT_EMB_COSINE, K.cos3, S, bn, bd, st));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[5], st));
-  MOT_LC_HIP(b, mot::launch_lap(K.lap23, 2 * S, bn, bd, true, false, false, st));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[6], st));
-  hipLaunchKernelGGL(bot_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K);
-  MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYWH, K.init, S, bd, st));
-  MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYWH, K.upd, S, bn, st));
-  if (emb) {
-    MOT_LC_HIP(b, mot::launch_feat(K.fset, S, bn2, st));
-    MOT_LC_HIP(b, mot::launch_feat(K.fema, S, bn, st));
-  }
-  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYWH, K.obox, S, bn2, st));
-  hipLaunchKernelGGL(bot_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt);
-  hipLaunchKernelGGL(bot_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
   if (rows_cap > b->packed_cap) { b->d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); b->packed_cap = b->d_packed ? rows_cap : 0; }
   if (!b->d_packed) return MOT_ERR_NOMEM;
-  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, b->d_offsets);
-  hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, CAP, b->d_out_counts, b->d_offsets, b->d_packed, rows_cap);
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
-  MOT_LC_HIP(b, hipGetLastError());
+  const int rc = bot_enqueue(b, d_dets, h_counts, d_embs, any_warp, b->bound_n, b->d_packed, b->d_offsets, rows_cap, b->profile ? b->ev : nullptr);
+  if (rc != MOT_OK) return rc;
+  b->d_rows_last = b->d_packed; b->d_offsets_last = b->d_offsets; b->d_counts_last = b->d_out_counts;
   int total = 0, err = 0;
   int maxt[64];
   MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
@@ -695,14 +737,7 @@ int mot_bot_step_packed(mot_bot_batch* b, const float* d_dets, const int* h_coun
   MOT_LC_HIP(b, hipStreamSynchronize(st));
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
-  if (prof) {
-    float ms = 0.f;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[1])); b->frame_ms += ms;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[2], b->ev[3])); b->cos_ms += ms;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[3], b->ev[4])); b->lap_ms += ms;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[5], b->ev[6])); b->lap_ms += ms;
-    b->frames += 1;
-  }
+  if (b->profile) { const int rce = bot_account_events(b, b->ev); if (rce != MOT_OK) return rce; }
   if (total_rows) *total_rows = total;
   if (err) { b->ctx->err = "mot_bot_step_packed: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
   if (total > rows_cap) { b->ctx->err = "mot_bot_step_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
@@ -713,11 +748,86 @@ int mot_bot_step_packed(mot_bot_batch* b, const float* d_dets, const int* h_coun
   return MOT_OK;
 }
 
+// Frames in flight (see mot_bt_enqueue_packed): enqueue returns once the launches are queued, collect waits for the oldest
+// pending frame and copies its rows on a second stream while the next frame runs.
+int mot_bot_enqueue_packed(mot_bot_batch* b, const float* d_dets, const int* h_counts, const float* d_embs, const float* h_warps6,
+                           const unsigned char* h_has_warp, int rows_cap) {
+  if (!b || !d_dets || !h_counts || rows_cap <= 0) return MOT_ERR_INVALID;
+  if (b->fl_count >= 2) { b->ctx->err = "mot_bot_enqueue_packed: two frames are already in flight (collect one first)"; return MOT_ERR_INVALID; }
+  hipStream_t st = b->ctx->stream;
+  const int S = b->S;
+  const int slot = (b->fl_head + b->fl_count) & 1;
+  mot_bot_batch::Flight& F = b->fl[slot];
+  if (!b->copy_st) MOT_LC_HIP(b, hipStreamCreateWithFlags(&b->copy_st, hipStreamNonBlocking));
+  if (!F.done) MOT_LC_HIP(b, hipEventCreateWithFlags(&F.done, hipEventDisableTiming));
+  // pinned: [0] total, [1] err, [2..66) maxima, counts out [S], counts in [S], has_warp [S], warps [6 S] (as float bits)
+  if (!F.h_meta) MOT_LC_HIP(b, hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (66 + 9 * static_cast<size_t>(S)), hipHostMallocDefault));
+  if (!F.d_offsets) { F.d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1); F.d_counts = b->dalloc<int>(S); }
+  if (rows_cap > F.packed_cap) { F.d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); F.packed_cap = F.d_packed ? rows_cap : 0; }
+  if (!F.d_offsets || !F.d_counts || !F.d_packed) return MOT_ERR_NOMEM;
+  int* counts_in = F.h_meta + 66 + S;
+  int* hw = F.h_meta + 66 + 2 * S;
+  float* wp = reinterpret_cast<float*>(F.h_meta + 66 + 3 * S);
+  int bd = 1;
+  bool any_warp = false;
+  for (int s = 0; s < S; ++s) {
+    counts_in[s] = h_counts[s];
+    bd = (h_counts[s] > bd) ? h_counts[s] : bd;
+    hw[s] = (h_warps6 && h_has_warp && h_has_warp[s]) ? 1 : 0;
+    any_warp = any_warp || hw[s];
+  }
+  MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, counts_in, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  if (any_warp) {
+    std::memcpy(wp, h_warps6, sizeof(float) * 6 * S);
+    MOT_LC_HIP(b, hipMemcpyAsync(b->d_warps, wp, sizeof(float) * 6 * S, hipMemcpyHostToDevice, st));
+    MOT_LC_HIP(b, hipMemcpyAsync(b->d_has_warp, hw, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  }
+  const mot_bot_batch::Flight& O = b->fl[slot ^ 1];
+  int bound = b->bound_n + (O.pending ? O.bd : 0);
+  if (bound > b->CAP) bound = b->CAP;
+  if (b->profile && !F.ev[0]) for (auto& e : F.ev) MOT_LC_HIP(b, hipEventCreate(&e));
+  F.prof = b->profile;
+  const int rc = bot_enqueue(b, d_dets, counts_in, d_embs, any_warp, bound, F.d_packed, F.d_offsets, rows_cap, F.prof ? F.ev : nullptr);
+  if (rc != MOT_OK) return rc;
+  MOT_LC_HIP(b, hipMemcpyAsync(F.d_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToDevice, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta, F.d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 1, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 2, b->d_maxt, sizeof(int) * 64, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 66, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipEventRecord(F.done, st));
+  F.pending = true; F.bd = bd;
+  b->fl_count += 1;
+  return MOT_OK;
+}
+
+int mot_bot_collect_packed(mot_bot_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows) {
+  if (!b || !rows || !out_counts) return MOT_ERR_INVALID;
+  if (b->fl_count <= 0) { b->ctx->err = "mot_bot_collect_packed: no frame in flight"; return MOT_ERR_INVALID; }
+  mot_bot_batch::Flight& F = b->fl[b->fl_head];
+  MOT_LC_HIP(b, hipEventSynchronize(F.done));
+  F.pending = false;
+  b->fl_head ^= 1; b->fl_count -= 1;
+  if (F.prof) { const int rce = bot_account_events(b, F.ev); if (rce != MOT_OK) return rce; }
+  const int total = F.h_meta[0], err = F.h_meta[1];
+  b->bound_n = 0;
+  for (int i = 0; i < 64; ++i) b->bound_n = (F.h_meta[2 + i] > b->bound_n) ? F.h_meta[2 + i] : b->bound_n;
+  std::memcpy(out_counts, F.h_meta + 66, sizeof(int) * b->S);
+  if (total_rows) *total_rows = total;
+  b->d_rows_last = F.d_packed; b->d_offsets_last = F.d_offsets; b->d_counts_last = F.d_counts;
+  if (err) { b->ctx->err = "mot_bot_collect_packed: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
+  if (total > rows_cap || total > F.packed_cap) { b->ctx->err = "mot_bot_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  if (total > 0) {
+    MOT_LC_HIP(b, hipMemcpyAsync(rows, F.d_packed, sizeof(float) * static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, b->copy_st));
+    MOT_LC_HIP(b, hipStreamSynchronize(b->copy_st));
+  }
+  return MOT_OK;
+}
+
 int mot_bot_device_output(mot_bot_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts) {
-  if (!b || !b->d_packed || !b->d_offsets) return MOT_ERR_INVALID;
-  if (d_rows) *d_rows = b->d_packed;
-  if (d_offsets) *d_offsets = b->d_offsets;
-  if (d_counts) *d_counts = b->d_out_counts;
+  if (!b || !b->d_rows_last || !b->d_offsets_last) return MOT_ERR_INVALID;
+  if (d_rows) *d_rows = b->d_rows_last;
+  if (d_offsets) *d_offsets = b->d_offsets_last;
+  if (d_counts) *d_counts = b->d_counts_last;
   return MOT_OK;
 }
 

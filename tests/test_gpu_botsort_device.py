@@ -99,3 +99,58 @@ def test_c3_shape():
 
 def test_long_run_recycles_slots():
     run([(50, 30), (25, 20)], 220, 256, 64, emb_dim=8, params=[0.5, 0.1, 0.6, 5, 0.8, 0.5, 0.25, 30, 0, 1], check_states_every=20)
+
+
+def test_two_frames_in_flight_give_the_same_tables():
+    """mot_bot_enqueue_packed / mot_bot_collect_packed with embeddings and per-stream warps: frame f + 1 is queued before frame f
+    is fetched; the packed rows of every frame equal the oracle's tables"""
+    import torch
+    orc = orclib.load()
+    shapes = [(60, 40), (200, 120), (30, 30)]
+    S, maxd, E, F = len(shapes), 128, 16, 30
+    dev = L.DeviceBotSort(S, 512, maxd, E)
+    streams = [SynthStream(P, M, 999 + i, E) for i, (P, M) in enumerate(shapes)]
+    oracles = [orc.tracker(orclib.BOTSORT) for _ in range(S)]
+    r = np.random.default_rng(3)
+    soa = np.zeros((F, S, 6, maxd), np.float32)
+    emb = np.zeros((F, S, maxd, E), np.float32)
+    counts = np.zeros((F, S), np.int32)
+    W = np.zeros((F, S, 6), np.float32)
+    HW = np.zeros((F, S), np.uint8)
+    want = []
+    for f in range(F):
+        per = []
+        for s, st in enumerate(streams):
+            d, e = st.next_frame()
+            if (f + s) % 7 == 5:
+                d, e = d[:0], e[:0]
+            if (f + s) % 4 == 1:
+                W[f, s] = [1.0, 0.0, r.uniform(-3, 3), 0.0, 1.0, r.uniform(-3, 3)]
+                HW[f, s] = 1
+                oracles[s].set_camera_motion(W[f, s].reshape(2, 3))
+            counts[f, s] = len(d)
+            soa[f, s, :, :len(d)] = d.T
+            emb[f, s, :len(d)] = e
+            per.append(oracles[s].update(d, e))
+        want.append(per)
+    ddets, dembs = torch.from_numpy(soa).cuda(), torch.from_numpy(emb).cuda()
+    rows = L.pinned_array(dev.ctx, (S * 512, 8), np.float32)
+    cnt = L.pinned_array(dev.ctx, (S,), np.int32)
+
+    def enq(f):
+        dev.enqueue_packed(ddets.data_ptr() + f * S * 6 * maxd * 4, counts[f].copy(), rows.shape[0],
+                           embs_ptr=dembs.data_ptr() + f * S * maxd * E * 4, warps=W[f].copy(), has_warp=HW[f].copy())
+
+    def check(f):
+        total = dev.collect_packed(rows, cnt)
+        assert total == sum(w.shape[0] for w in want[f]), f
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        for s in range(S):
+            assert np.array_equal(rows[off[s]:off[s + 1]], want[f][s]), (f, s)
+
+    enq(0)
+    for f in range(1, F):
+        enq(f)
+        check(f - 1)
+    check(F - 1)
+    dev.close()

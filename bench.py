@@ -480,7 +480,7 @@ def main():
     roof["survey_8d_equivalent"] = {"bytes_per_frame": survey_bytes, "GB/s_per_gpu": value / world * survey_bytes / 1e9,
                                     "frac": value / world * survey_bytes / 1e9 / HBM_PEAK_GBS,
                                     "note": "whole-job frames/s x SURVEY 8(d) bytes per frame (cost matrix materialised); not a kernel measurement"}
-    sqf = os.path.join(ROOT, "profiles", "r02_pmc_sq_lap.json")
+    sqf = os.path.join(ROOT, "profiles", "r02z_pmc_sq_lap.json")
     if fam == "lap" and os.path.exists(sqf):
         try:  # what actually bounds this kernel: instruction issue of the serial row passes (SQ counters, separate PMC run)
             sq = json.load(open(sqf)).get(args.workload)
@@ -488,7 +488,7 @@ def main():
                 roof["issue"] = {"wave_cycles_issuing_frac": sq["active_frac"], "wave_cycles_waiting_frac": sq["wait_any_frac"],
                                  "valu_insts_per_problem": sq["per_problem"]["SQ_INSTS_VALU"],
                                  "salu_insts_per_problem": sq["per_problem"]["SQ_INSTS_SALU"], "kernel": sq.get("kernel"),
-                                 "source": "profiles/r02_pmc_sq_lap.json"}
+                                 "source": "profiles/r02z_pmc_sq_lap.json"}
         except Exception:
             pass
     kernels = {k: {"ms_total": round(v["ms"], 3), "launches": v["launches"],

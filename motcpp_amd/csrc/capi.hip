@@ -230,15 +230,14 @@ int mot_gate_cost_host(mot_ctx* c, int kind, int mode, int n, int m, const float
   t.n = n; t.m = m; t.mean = dr.as<float>(); t.src = nullptr; t.meas = dm.as<float>(); t.ldm = m;
   t.cost = dc.as<float>(); t.ldc = m; t.out = dout.as<float>(); t.ldo = m;
   t.mode = mode; t.only_position = only_position; t.metric = metric; t.lambda = lambda; t.gated_cost = gated_cost;
-  MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
-  for (int r0 = 0; r0 < n; r0 += 32768) {  // grid.y limit
+  for (int r0 = 0; r0 < n; r0 += 32768) {  // grid.y limit: at most 32768 track rows per launch
     mot_gate_task tt = t;
     tt.n = (n - r0 < 32768) ? n - r0 : 32768;
     tt.mean = t.mean + static_cast<size_t>(r0) * 72; tt.cost = t.cost + static_cast<size_t>(r0) * m; tt.out = t.out + static_cast<size_t>(r0) * m;
     MOT_HIP(c, hipMemcpyAsync(dt.p, &tt, sizeof(tt), hipMemcpyHostToDevice, c->stream));
-    MOT_HIP(c, hipStreamSynchronize(c->stream));
+    MOT_HIP(c, hipStreamSynchronize(c->stream));  // tt is a local
     MOT_HIP(c, mot::launch_gate(kind, dt.as<mot_gate_task>(), 1, tt.n, m, c->stream));
-    MOT_HIP(c, hipStreamSynchronize(c->stream));
+    MOT_HIP(c, hipStreamSynchronize(c->stream));  // the descriptor is rewritten by the next slice
   }
   MOT_HIP(c, hipMemcpyAsync(out, dout.p, static_cast<size_t>(n) * m * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));

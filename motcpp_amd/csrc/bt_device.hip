@@ -11,6 +11,7 @@
 // wavefront compaction (ballot + popcount prefix). Sizes are fixed at creation (cap_tracks, max_dets); exceeding them
 // raises the stream's error flag instead of reallocating.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -378,20 +379,56 @@ __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParam
 // ---- duplicate marking (remove_duplicate_stracks :659-706): iou_distance(active, lost) < 0.15 -> the younger one goes.
 // Same pair arithmetic as the N x M cost kernel (cost_math.hpp), one workgroup per stream over its own na x nl pairs
 // (a launch of the tiled cost kernel over the capacity bound spends 0.5 ms on tiles that exit at once).
-// A thread owns an active track (box in registers) and walks the lost boxes, which every lane of its wavefront reads from
-// the same LDS address (one broadcast ds_read_b128 per box). Duplicates need IoU > 0.85, so a pair is first put through
-// iou_pair's own intersection and union without the division: only pairs with inter > 0.8 * union (a few per frame)
-// reach the exact arithmetic — same marks as evaluating all na x nl pairs.
-template <bool STAGED>  // STAGED: the lost boxes are copied to LDS once (they must fit in the launch's dynamic LDS)
-__global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP) {
-  extern __shared__ __attribute__((aligned(16))) float sbox[];  // [nl] lost boxes as x1,y1,x2,y2
+// A thread owns an active track (box in registers). Duplicates need IoU > 0.85, so a pair is first put through iou_pair's own
+// intersection and union without the division: only pairs with inter > 0.8 * union reach the exact arithmetic.
+// SORTED (the lost boxes fit in LDS): evaluating all na x nl prefilters was 10 % of a north-star frame's kernel time, pure
+// VALU. inter > 0.8 * union with positive widths forces |x1_a - x1_b| < 0.25 * w_a (inter <= iw * min(h) and
+// union >= max(area) give iw > 0.8 * max(w_a, w_b), and iw <= w - |x1_a - x1_b| on the side that starts later), so the
+// lost boxes are ranked by x1 in LDS and an active box looks only at the ranks inside x1_a -/+ 0.3 * w_a (binary search;
+// the margin dwarfs any rounding). Lost boxes with a non-finite coordinate are ranked first and always visited; an active
+// box whose width is not a positive finite number visits everything. `verify` (MOT_BT_DUPS_VERIFY=1, tests): the full scan
+// runs as well and any pair it would mark outside the window raises the stream's error flag 3.
+template <int MODE>  // 0: lost boxes read from global, all pairs; 1: staged in LDS, sorted window; 2: staged in LDS, all pairs
+__global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP, int verify) {
+  extern __shared__ __attribute__((aligned(16))) float sbox[];  // [nl] float4 boxes, [nl] sorted x1 keys, [nl] sorted indices, [nl] keys
   BtStream& S = streams[blockIdx.x];
   const int na = S.n_active, nl = S.n_lost;
   if (na <= 0 || nl <= 0) return;
   float4* wl = reinterpret_cast<float4*>(sbox);
-  if constexpr (STAGED) {
+  float* sx = sbox + static_cast<size_t>(4) * nl;
+  int* si = reinterpret_cast<int*>(sx + nl);
+  __shared__ int n_irr;
+  if constexpr (MODE == 2) {
     for (int j = threadIdx.x; j < nl; j += 256)
       wl[j] = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
+    __syncthreads();
+  }
+  if constexpr (MODE == 1) {
+    if (threadIdx.x == 0) n_irr = 0;
+    for (int j = threadIdx.x; j < nl; j += 256)
+      wl[j] = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
+    __syncthreads();
+    // rank by (key, index) with key = x1, or -inf for a box with a non-finite coordinate: nl is a few hundred at most,
+    // counting against the key array (one broadcast LDS read and three VALU operations per comparison) beats a sorting network
+    float* key = reinterpret_cast<float*>(si + nl);
+    for (int j = threadIdx.x; j < nl; j += 256) {
+      const float4 b = wl[j];
+      const bool irr = !(fabsf(b.x) < 3.0e38f && fabsf(b.y) < 3.0e38f && fabsf(b.z) < 3.0e38f && fabsf(b.w) < 3.0e38f);
+      key[j] = irr ? -3.4e38f : b.x;
+      if (irr) atomicAdd(&n_irr, 1);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nl; j += 256) {
+      const float kj = key[j];
+      int rank = 0;
+#pragma unroll 8
+      for (int k = 0; k < nl; ++k) {
+        const float kk = key[k];
+        rank += (kk < kj || (kk == kj && k < j)) ? 1 : 0;
+      }
+      sx[rank] = kj;
+      si[rank] = j;
+    }
     __syncthreads();
   }
   for (int i = threadIdx.x; i < na; i += 256) {
@@ -399,9 +436,9 @@ __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP) {
     const float area_a = (a[2] - a[0]) * (a[3] - a[1]);
     const int age_a = S.age_a[i];
     bool dup_me = false;
-    for (int j = 0; j < nl; ++j) {
+    auto test = [&](int j, bool mark) {
       float4 bb;
-      if constexpr (STAGED) bb = wl[j];
+      if constexpr (MODE != 0) bb = wl[j];
       else bb = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
       const float iw = mot::smax(0.0f, mot::smin(a[2], bb.z) - mot::smax(a[0], bb.x));
       const float ih = mot::smax(0.0f, mot::smin(a[3], bb.w) - mot::smax(a[1], bb.y));
@@ -411,10 +448,35 @@ __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP) {
       if (inter > 0.8f * uni) {
         const float iou = (uni > 0.0f) ? (inter / uni) : 0.0f;  // iou_pair's value (cost_math.hpp), inter and uni as it computes them
         if (1.0f - iou < 0.15f) {
+          if (!mark) return true;
           if (age_a > S.age_b[j]) S.dup_b[j] = 1;
           else dup_me = true;
+          return true;
         }
       }
+      return false;
+    };
+    if constexpr (MODE == 1) {
+      const float wa = a[2] - a[0];
+      const bool regular = wa > 0.0f && wa < 3.0e38f && fabsf(a[0]) < 3.0e38f;
+      int lo = 0, hi = nl;
+      if (regular) {
+        const float xl = a[0] - 0.3f * wa, xh = a[0] + 0.3f * wa;
+        const int ni = n_irr;
+        for (int j = 0; j < ni; ++j) test(si[j], true);  // lost boxes with non-finite coordinates: no window applies
+        int l = ni, h = nl;
+        while (l < h) { const int m = (l + h) >> 1; if (sx[m] < xl) l = m + 1; else h = m; }
+        lo = l; h = nl;
+        while (l < h) { const int m = (l + h) >> 1; if (sx[m] <= xh) l = m + 1; else h = m; }
+        hi = l;
+      }
+      for (int r = lo; r < hi; ++r) test(si[r], true);
+      if (verify && regular) {  // the full scan must not find a pair outside the window
+        for (int r = n_irr; r < nl; ++r)
+          if ((r < lo || r >= hi) && test(si[r], false)) S.err = 3;
+      }
+    } else {
+      for (int j = 0; j < nl; ++j) test(j, true);
     }
     if (dup_me) S.dup_a[i] = 1;
   }
@@ -701,9 +763,12 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[9], st));
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, bn2, st));
   {
-    const size_t lds = static_cast<size_t>(4) * bn2 * sizeof(float);  // nl <= bn2
-    if (lds <= 48 * 1024) hipLaunchKernelGGL(bt_dups<true>, dim3(S), dim3(256), lds, st, b->d_streams, CAP);
-    else hipLaunchKernelGGL(bt_dups<false>, dim3(S), dim3(256), 0, st, b->d_streams, CAP);
+    static const int verify = std::getenv("MOT_BT_DUPS_VERIFY") != nullptr ? 1 : 0;  // tests: cross-check the sorted window
+    const size_t lds = static_cast<size_t>(7) * bn2 * sizeof(float);  // nl <= bn2: boxes + sorted keys + sorted indices + keys
+    static const bool full = std::getenv("MOT_BT_DUPS_FULL") != nullptr;  // measurement aid: every pair, boxes staged in LDS
+    if (full && lds <= 48 * 1024) hipLaunchKernelGGL(bt_dups<2>, dim3(S), dim3(256), static_cast<size_t>(4) * bn2 * sizeof(float), st, b->d_streams, CAP, 0);
+    else if (lds <= 48 * 1024) hipLaunchKernelGGL(bt_dups<1>, dim3(S), dim3(256), lds, st, b->d_streams, CAP, verify);
+    else hipLaunchKernelGGL(bt_dups<0>, dim3(S), dim3(256), 0, st, b->d_streams, CAP, 0);
   }
   hipLaunchKernelGGL(bt_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);
   hipLaunchKernelGGL(bt_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);

@@ -44,7 +44,7 @@ def run_stream(kind_g, kind_o, P, M, frames, emb_dim=0, params=None, seed=1234, 
     orc = orclib.load()
     tg, to = L.Tracker(kind_g, params), orc.tracker(kind_o, params)
     s = SynthStream(P, M, seed, emb_dim)
-    n_out = 0
+    n_out = n_exact = 0
     for f in range(frames):
         d, e = s.next_frame()
         if f % 17 == 13:
@@ -53,7 +53,11 @@ def run_stream(kind_g, kind_o, P, M, frames, emb_dim=0, params=None, seed=1234, 
         og, oo = tg.update(d, e), to.update(d, e)
         check_frame(f, og, oo, tg, to, exact)
         n_out += og.shape[0]
+        n_exact += int(np.sum(np.all(og == oo, axis=1))) if og.shape == oo.shape else 0
     assert n_out > 0
+    # trackers whose cost goes through acos are compared at 1e-4, but at least 99.9 % of their output
+    # rows must still be bit-identical to the oracle's at tracker level (in practice all of them are)
+    assert n_exact >= 0.999 * n_out, (n_exact, n_out)
     tg.close()
 
 

@@ -409,6 +409,13 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
       };
       auto push = [&](int p) { w.hq[nq * T + t] = static_cast<unsigned short>(p); if (++nq == kSpQ) drain(false); };
       int p = ps;
+      for (; p + 8 <= pe; p += 8) {  // eight boxes per round trip, the tests folded into one mask before any queue write
+        const SpBox s0 = w.sbox[p], s1 = w.sbox[p + 1], s2 = w.sbox[p + 2], s3 = w.sbox[p + 3];
+        const SpBox s4 = w.sbox[p + 4], s5 = w.sbox[p + 5], s6 = w.sbox[p + 6], s7 = w.sbox[p + 7];
+        unsigned m = (hits(s0) ? 1u : 0u) | (hits(s1) ? 2u : 0u) | (hits(s2) ? 4u : 0u) | (hits(s3) ? 8u : 0u) |
+                     (hits(s4) ? 16u : 0u) | (hits(s5) ? 32u : 0u) | (hits(s6) ? 64u : 0u) | (hits(s7) ? 128u : 0u);
+        while (m) { const int q = __builtin_ctz(m); m &= m - 1u; push(p + q); }
+      }
       for (; p + 4 <= pe; p += 4) {  // four boxes per round trip
         const SpBox s0 = w.sbox[p], s1 = w.sbox[p + 1], s2 = w.sbox[p + 2], s3 = w.sbox[p + 3];
         if (hits(s0)) push(p);

@@ -17,6 +17,8 @@
 // only because the brief asks for it — its real bound is issue latency of the serial row passes.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <mutex>
 
 #include "../../include/motcpp_amd.h"
@@ -262,6 +264,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   const int grid = (fast && ntasks > 512) ? 512 : ntasks;
 #define MOT_LAP_VARIANTS(X) X(64, 0, 0, 1) X(64, 2, 0, 1) X(64, 3, 0, 1) X(64, 0, 4, 1) X(64, 2, 4, 1) X(64, 3, 4, 1) \
                             X(64, 0, 8, 1) X(64, 2, 8, 1) X(64, 3, 8, 1) X(256, 0, 0, 1) X(256, 2, 0, 1) X(256, 3, 0, 1) \
+                            X(1024, 0, 0, 1) X(1024, 2, 0, 1) X(1024, 3, 0, 1) \
                             X(64, 0, 4, 0) X(64, 2, 4, 0) X(64, 3, 4, 0) X(64, 0, 8, 0) X(64, 2, 8, 0) X(64, 3, 8, 0) \
                             X(64, 0, 0, 2) X(64, 2, 0, 2) X(64, 3, 0, 2) X(256, 0, 0, 2) X(256, 2, 0, 2) X(256, 3, 0, 2)
   // plain-cost variants exist for the register-cached column layouts only (the hot ones)
@@ -275,7 +278,11 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
 #undef MOT_ATTR
     attr_set_dev[dev_slot] = true;
   }
-  const int threads = wide ? 256 : 64;
+  // 16 wavefronts per problem when there are no more problems than CUs anyway (OC-SORT 4096 x 2048: the dense row sweeps of the
+  // shortest-path search are 6144 columns wide) — MOT_LAP_WIDE16=0 switches it off (measurement aid)
+  static const bool wide16_ok = !(std::getenv("MOT_LAP_WIDE16") && std::getenv("MOT_LAP_WIDE16")[0] == '0');
+  const bool wide16 = wide && wide16_ok && ntasks <= 256 && flavor == 1;
+  const int threads = wide16 ? 1024 : (wide ? 256 : 64);
   bool launched = false;
 #define MOT_TRY(T, M, R, G)                                                                                \
   if (!launched && threads == T && mode == M && rpl == R && flavor == G) {                                 \

@@ -6,7 +6,7 @@ from motcpp_amd import _lib as L
 from motcpp_amd.synth import SynthStream
 from tests import orclib
 o = orclib.load(); ctx = L.Context(0)
-for P,M in ((256,128),(1000,500)):
+for P,M in ((256,128),(1000,500),(4096,2048)):
     s=SynthStream(P,M,1); d,_=s.next_frame()
     tb=np.stack([s.c[:,0]-s.w/2,s.c[:,1]-s.h/2,s.c[:,0]+s.w/2,s.c[:,1]+s.h/2],1).astype(np.float32)
     hi=d[d[:,4]>0.45]

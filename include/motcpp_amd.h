@@ -450,6 +450,10 @@ int mot_ocsort_cost_host(mot_ctx* ctx, const float* dets5, int nd, const float* 
 int mot_lap_solve_host(mot_ctx* ctx, const float* cost, int n, int m, float thresh, int mode,
                        const float* iou_or_null, float gate, int* x, int* y, int* info_or_null);
 /* assignment straight from boxes (on-the-fly cost, no matrix): cost_mode is a mot_cost_mode */
+/* the same with the exact solver's per-phase shader cycles (diagnostics; see mot_lap_task.prof): [0] column minima, [1] reduction
+ * transfer, [2] augmenting row reduction, [3] augmentation, [4..6] their pass counts, [7] n + m */
+int mot_lap_solve_prof_host(mot_ctx* ctx, const float* cost, int n, int m, float thresh, int mode,
+                            const float* iou_or_null, float gate, int* x, int* y, int* info, long long* prof8);
 int mot_lap_geom_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b_xyxy, int m, const float* bconf_or_null,
                       int cost_mode, float thresh, int lap_mode, float gate, int* x, int* y, float* xval_or_null,
                       int* info_or_null, long long* prof8_or_null);

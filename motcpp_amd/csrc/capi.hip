@@ -295,13 +295,17 @@ int mot_ocsort_cost_host(mot_ctx* c, const float* dets5, int nd, const float* tr
 
 int mot_lap_solve_host(mot_ctx* c, const float* cost, int n, int m, float thresh, int mode, const float* iou, float gate,
                        int* x, int* y, int* info) {
+  return mot_lap_solve_prof_host(c, cost, n, m, thresh, mode, iou, gate, x, y, info, nullptr);
+}
+int mot_lap_solve_prof_host(mot_ctx* c, const float* cost, int n, int m, float thresh, int mode, const float* iou, float gate,
+                            int* x, int* y, int* info, long long* prof8) {
   if (n <= 0 || m <= 0) {
     for (int i = 0; i < n; ++i) x[i] = -1;
     for (int j = 0; j < m; ++j) y[j] = -1;
     if (info) *info = 2;
     return MOT_OK;
   }
-  DBuf dc, di, dx, dy, dinfo, dwork, dt;
+  DBuf dc, di, dx, dy, dinfo, dwork, dt, dprof;
   MOT_HIP(c, dc.alloc(static_cast<size_t>(n) * m * 4)); MOT_HIP(c, dx.alloc(n * 4)); MOT_HIP(c, dy.alloc(m * 4));
   MOT_HIP(c, dinfo.alloc(16)); MOT_HIP(c, dwork.alloc(mot_lap_work_bytes(n, m))); MOT_HIP(c, dt.alloc(sizeof(mot_lap_task)));
   MOT_HIP(c, hipMemcpyAsync(dc.p, cost, static_cast<size_t>(n) * m * 4, hipMemcpyHostToDevice, c->stream));
@@ -313,12 +317,18 @@ int mot_lap_solve_host(mot_ctx* c, const float* cost, int n, int m, float thresh
   t.n = n; t.m = m; t.cost = dc.as<float>(); t.ldc = m; t.thresh = thresh; t.x = dx.as<int>(); t.y = dy.as<int>();
   t.mode = mode; t.iou = iou ? di.as<float>() : nullptr; t.ldi = m; t.gate = gate; t.info = dinfo.as<int>();
   t.work = dwork.p;
+  if (prof8) {  // per-phase shader cycles of the exact solver (the sparse solver leaves a task that asks for them alone)
+    MOT_HIP(c, dprof.alloc(64));
+    MOT_HIP(c, hipMemsetAsync(dprof.p, 0, 64, c->stream));
+    t.prof = dprof.as<long long>();
+  }
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, mot::launch_lap(dt.as<mot_lap_task>(), 1, n, m, false, false, false, c->stream));
   MOT_HIP(c, hipMemcpyAsync(x, dx.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(y, dy.p, m * 4, hipMemcpyDeviceToHost, c->stream));
   int inf = 0;
   MOT_HIP(c, hipMemcpyAsync(&inf, dinfo.p, 4, hipMemcpyDeviceToHost, c->stream));
+  if (prof8) MOT_HIP(c, hipMemcpyAsync(prof8, dprof.p, 64, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   if (info) *info = inf;
   return MOT_OK;

@@ -79,6 +79,10 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (0: workload default)")
     ap.add_argument("--threads", type=int, default=0, help="host worker threads for the per-stream lifecycle, shared by the sub-batches (0: min(64, cores))")
     ap.add_argument("--gather-every", type=int, default=8)
+    ap.add_argument("--gather", default="torch", choices=["torch", "native"],
+                    help="how the ranks' packed track tables are gathered: torch = torch.distributed.all_gather_into_tensor on zero-copy views of "
+                         "the library's device buffers (padded to a fixed size); native = mot_comm_gather_tables, RCCL called from the library on "
+                         "the sub-batch's stream with exact sizes (also runs with one rank, as a self-test)")
     ap.add_argument("--lifecycle", choices=["auto", "device", "host"], default="auto",
                     help="where the per-stream track bookkeeping runs: device = mot_bt_* (ByteTrack only: four small kernels per frame, "
                          "no host decisions), host = the C++ stage machines; auto = device where it exists")
@@ -88,6 +92,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+    # stdout carries exactly one JSON line: libraries that print there (RCCL's version banner at communicator creation) are
+    # sent to stderr for the whole run, the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -232,9 +241,20 @@ def main():
                 tot[k] = tot.get(k, 0) + v
         return tot
 
+    comms, native_bufs = None, None
+
     def gather(out, cnt):
         # final track tables of this rank's streams -> every rank (RCCL all_gather over xGMI)
-        nonlocal gathered
+        nonlocal gathered, comms, native_bufs
+        if packed and args.gather == "native":  # RCCL from the library, one communicator per sub-batch (its context's stream)
+            res = []
+            for p in range(PIPE):
+                r_ptr, _o_ptr, c_ptr = batches[p].device_output()
+                res.append(comms[p].gather_tables(r_ptr, c_ptr, bounds[p + 1] - bounds[p], native_bufs[p].data_ptr(), world * rows_cap[p]))
+            for p in range(PIPE):
+                batches[p].ctx._chk(batches[p].lib.mot_ctx_sync(batches[p].ctx.h))
+            gathered = (native_bufs, res)
+            return
         if packed:  # straight from the device-resident packed tables of the last step: no copy through the host
             dv = torch.device("cuda", local)
             rl, cl = [], []
@@ -266,7 +286,7 @@ def main():
                 tot_p[p] = batches[p].collect_packed(rows_p[p], cnt_all[bounds[p]:bounds[p + 1]])
             if rank == 0 and k < keep_limit:
                 kept.append(stream0_rows(None, cnt_all))
-            if world > 1 and f0 >= W and ((k + 1) % args.gather_every == 0 or k == n - 1):
+            if (world > 1 or args.gather == "native") and f0 >= W and ((k + 1) % args.gather_every == 0 or k == n - 1):
                 gather(None, cnt_all)
         enq(f0)
         for k in range(1, n):
@@ -274,6 +294,9 @@ def main():
             col(k - 1)
         col(n - 1)
 
+    if packed and args.gather == "native":  # communicators are created outside the timed region (RCCL initialisation takes seconds)
+        comms = [mdist.NativeComm(batches[p].ctx, world=world, rank=rank) for p in range(PIPE)]
+        native_bufs = [torch.empty((world * rows_cap[p], 8), dtype=torch.float32, device=f"cuda:{local}") for p in range(PIPE)]
     kept = []  # stream 0 outputs of rank 0 for the parity spot check
     if in_flight:
         run_pipelined(0, W, 40)
@@ -567,7 +590,8 @@ def main():
         "flushes_per_step": (c1["flushes"] - c0["flushes"]) / K, "launches_per_step": (c1["launches"] - c0["launches"]) / K,
         "host_ms_per_step": {k: (c1[k] - c0[k]) / K for k in ("ms_begin", "ms_flush", "ms_advance", "ms_sync_wait")},
     }
-    print(json.dumps(line))
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

@@ -766,8 +766,10 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
     static const int verify = std::getenv("MOT_BT_DUPS_VERIFY") != nullptr ? 1 : 0;  // tests: cross-check the sorted window
     const size_t lds = static_cast<size_t>(7) * bn2 * sizeof(float);  // nl <= bn2: boxes + sorted keys + sorted indices + keys
     static const bool full = std::getenv("MOT_BT_DUPS_FULL") != nullptr;  // measurement aid: every pair, boxes staged in LDS
-    if (full && lds <= 48 * 1024) hipLaunchKernelGGL(bt_dups<2>, dim3(S), dim3(256), static_cast<size_t>(4) * bn2 * sizeof(float), st, b->d_streams, CAP, 0);
-    else if (lds <= 48 * 1024) hipLaunchKernelGGL(bt_dups<1>, dim3(S), dim3(256), lds, st, b->d_streams, CAP, verify);
+    constexpr size_t kLdsMax = 64 * 1024;  // dynamic LDS a launch may ask for without raising the function's limit
+    const size_t lds_full = static_cast<size_t>(4) * bn2 * sizeof(float);
+    if (!full && lds <= kLdsMax) hipLaunchKernelGGL(bt_dups<1>, dim3(S), dim3(256), lds, st, b->d_streams, CAP, verify);
+    else if (lds_full <= kLdsMax) hipLaunchKernelGGL(bt_dups<2>, dim3(S), dim3(256), lds_full, st, b->d_streams, CAP, 0);
     else hipLaunchKernelGGL(bt_dups<0>, dim3(S), dim3(256), 0, st, b->d_streams, CAP, 0);
   }
   hipLaunchKernelGGL(bt_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);

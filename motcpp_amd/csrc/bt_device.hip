@@ -389,21 +389,24 @@ __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParam
 // box whose width is not a positive finite number visits everything. `verify` (MOT_BT_DUPS_VERIFY=1, tests): the full scan
 // runs as well and any pair it would mark outside the window raises the stream's error flag 3.
 template <int MODE>  // 0: lost boxes read from global, all pairs; 1: staged in LDS, sorted window; 2: staged in LDS, all pairs
-__global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP, int verify) {
+__global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP, int verify, int lds_items) {
   extern __shared__ __attribute__((aligned(16))) float sbox[];  // [nl] float4 boxes, [nl] sorted x1 keys, [nl] sorted indices, [nl] keys
   BtStream& S = streams[blockIdx.x];
   const int na = S.n_active, nl = S.n_lost;
   if (na <= 0 || nl <= 0) return;
+  // the launch reserves LDS for lds_items lost boxes (far more than a stream usually has); a stream with more reads them from
+  // global memory and tests every pair
+  const bool staged = MODE != 0 && nl <= lds_items;
   float4* wl = reinterpret_cast<float4*>(sbox);
   float* sx = sbox + static_cast<size_t>(4) * nl;
   int* si = reinterpret_cast<int*>(sx + nl);
   __shared__ int n_irr;
-  if constexpr (MODE == 2) {
+  if (MODE == 2 && staged) {
     for (int j = threadIdx.x; j < nl; j += 256)
       wl[j] = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
     __syncthreads();
   }
-  if constexpr (MODE == 1) {
+  if (MODE == 1 && staged) {
     if (threadIdx.x == 0) n_irr = 0;
     for (int j = threadIdx.x; j < nl; j += 256)
       wl[j] = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
@@ -438,7 +441,7 @@ __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP, int v
     bool dup_me = false;
     auto test = [&](int j, bool mark) {
       float4 bb;
-      if constexpr (MODE != 0) bb = wl[j];
+      if (staged) bb = wl[j];
       else bb = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
       const float iw = mot::smax(0.0f, mot::smin(a[2], bb.z) - mot::smax(a[0], bb.x));
       const float ih = mot::smax(0.0f, mot::smin(a[3], bb.w) - mot::smax(a[1], bb.y));
@@ -456,7 +459,7 @@ __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP, int v
       }
       return false;
     };
-    if constexpr (MODE == 1) {
+    if (MODE == 1 && staged) {
       const float wa = a[2] - a[0];
       const bool regular = wa > 0.0f && wa < 3.0e38f && fabsf(a[0]) < 3.0e38f;
       int lo = 0, hi = nl;
@@ -764,13 +767,11 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, bn2, st));
   {
     static const int verify = std::getenv("MOT_BT_DUPS_VERIFY") != nullptr ? 1 : 0;  // tests: cross-check the sorted window
-    const size_t lds = static_cast<size_t>(7) * bn2 * sizeof(float);  // nl <= bn2: boxes + sorted keys + sorted indices + keys
     static const bool full = std::getenv("MOT_BT_DUPS_FULL") != nullptr;  // measurement aid: every pair, boxes staged in LDS
-    constexpr size_t kLdsMax = 64 * 1024;  // dynamic LDS a launch may ask for without raising the function's limit
-    const size_t lds_full = static_cast<size_t>(4) * bn2 * sizeof(float);
-    if (!full && lds <= kLdsMax) hipLaunchKernelGGL(bt_dups<1>, dim3(S), dim3(256), lds, st, b->d_streams, CAP, verify);
-    else if (lds_full <= kLdsMax) hipLaunchKernelGGL(bt_dups<2>, dim3(S), dim3(256), lds_full, st, b->d_streams, CAP, 0);
-    else hipLaunchKernelGGL(bt_dups<0>, dim3(S), dim3(256), 0, st, b->d_streams, CAP, 0);
+    // LDS for up to 1024 lost boxes per stream (28 KB: five workgroups per CU); the rare stream with more takes the global path
+    const int items = (bn2 < 1024) ? bn2 : 1024;
+    if (!full) hipLaunchKernelGGL(bt_dups<1>, dim3(S), dim3(256), static_cast<size_t>(28) * items, st, b->d_streams, CAP, verify, items);
+    else hipLaunchKernelGGL(bt_dups<2>, dim3(S), dim3(256), static_cast<size_t>(16) * items, st, b->d_streams, CAP, 0, items);
   }
   hipLaunchKernelGGL(bt_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);
   hipLaunchKernelGGL(bt_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);

@@ -65,7 +65,7 @@ struct BtStream {
 // ---- K0: detection split, pools, predict + first-association tasks (bytetrack.cpp:166-265) ----
 // stats[0] = assignment problems queued, stats[1] = sum of their n + m (algorithmic bytes of the solver: 24 B per row/column)
 __global__ void __launch_bounds__(kW) bt_begin(BtStream* streams, BtParams P, int CAP, int D, const int* counts, const float* dets_base,
-                                                mot_det_task* det_t, mot_kf_task* pred_t, mot_lap_task* lap1_t, unsigned long long* stats) {
+                                                mot_det_task* det_t, mot_kf_task* pred_t, mot_lap_task* lap1_t, unsigned long long* stats, int* maxt) {
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
   const int n = counts[blockIdx.x];
@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(kW) bt_begin(BtStream* streams, BtParams P, in
     L.n = q ? np : 0; L.m = q ? nh : 0;
     L.geom.n = L.n; L.geom.m = L.m;
     L.geom.bconf = conf;  // score fusion reads the frame's confidences (:300-312)
+    if (q) atomicMax(&maxt[64 + (blockIdx.x & 63)], np);
     if (stats && q) {  // 64 counter sets, so that thousands of streams do not serialise on one address
       unsigned long long* st = stats + (blockIdx.x & 63) * 8;
       atomicAdd(&st[0], 1ull); atomicAdd(&st[1], static_cast<unsigned long long>(np + nh)); atomicAdd(&st[4], static_cast<unsigned long long>(np));
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(kW) bt_begin(BtStream* streams, BtParams P, in
 
 // ---- K1: apply the first association, queue the second and the unconfirmed one (:267-455) ----
 __global__ void __launch_bounds__(kW) bt_after_first(BtStream* streams, BtParams P, int CAP, mot_kf_task* box_t, mot_lap_task* lap23_t,
-                                                      unsigned long long* stats) {
+                                                      unsigned long long* stats, int* maxt) {
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
   const int np = S.n_pool, nd = S.n_high;
@@ -198,6 +199,10 @@ __global__ void __launch_bounds__(kW) bt_after_first(BtStream* streams, BtParams
     mot_lap_task& B = lap23_t[2 * blockIdx.x + 1];
     B.n = q3 ? S.n_unconf : 0; B.m = q3 ? n_ud : 0; B.geom.n = B.n; B.geom.m = B.m;
     B.geom.bconf = S.dets + static_cast<size_t>(4) * S.ld;
+    {
+      const int mn = (A.n > B.n) ? A.n : B.n, mm = (A.m > B.m) ? A.m : B.m;
+      if (mn > 0) { atomicMax(&maxt[128 + (blockIdx.x & 63)], mn); atomicMax(&maxt[192 + (blockIdx.x & 63)], mm); }
+    }
     if (stats) {
       unsigned long long* st = stats + (blockIdx.x & 63) * 8;
       const int cnt = (q2 ? 1 : 0) + (q3 ? 1 : 0);
@@ -561,14 +566,16 @@ struct mot_bt_batch {
   std::vector<BtStream> h_streams;  // host mirror of the pointers (scalars are only valid on the device)
   int* d_counts = nullptr;
   int* d_err = nullptr;
-  int* d_maxt = nullptr;  // [64] per-frame maxima of tracks alive (bt_finish)
+  int* d_maxt = nullptr;  // [4][64] per-frame maxima: tracks alive (bt_finish), pool rows of the first association (bt_begin), rows and
+                          // columns of the second / unconfirmed associations (bt_after_first) — bounds and LDS hints of the next frame
+  int hint1_n = 0, hint23_n = 0, hint23_m = 0;
   int bound_n = 0;        // upper bound of tracked + lost per stream for the NEXT frame (0 right after creation / reset)
   float* d_out = nullptr; int* d_out_counts = nullptr; int out_cap = 0;
   float* d_packed = nullptr; int* d_offsets = nullptr; int packed_cap = 0;  // mot_bt_step_packed
   // frames in flight (mot_bt_enqueue_packed / mot_bt_collect_packed): two sets of packed tables, page-locked result words
   struct Flight {
     float* d_packed = nullptr; int* d_offsets = nullptr; int* d_counts = nullptr; int packed_cap = 0;
-    int* h_meta = nullptr;  // pinned: [0] total rows, [1] error flag, [2..66) maxima of tracks alive, then counts out [S], counts in [S]
+    int* h_meta = nullptr;  // pinned: [0] total rows, [1] error flag, [2..258) the frame's maxima (d_maxt), then counts out [S], counts in [S]
     hipEvent_t done = nullptr;
     hipEvent_t ev[12] = {};
     bool pending = false, prof = false;
@@ -615,7 +622,7 @@ int mot_bt_reset(mot_bt_batch* b) {
   MOT_LC_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(BtStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
   MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
   MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
-  b->bound_n = 0;
+  b->bound_n = 0; b->hint1_n = b->hint23_n = b->hint23_m = 0;
   return MOT_OK;
 }
 
@@ -637,7 +644,7 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   b->d_streams = b->dalloc<BtStream>(S);
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
-  b->d_maxt = b->dalloc<int>(64);
+  b->d_maxt = b->dalloc<int>(256);
   b->d_stats = b->dalloc<unsigned long long>(8 * 64);
   if (b->d_stats) (void)hipMemset(b->d_stats, 0, 8 * 64 * sizeof(unsigned long long));
   for (auto& e : b->ev) (void)hipEventCreate(&e);
@@ -736,7 +743,7 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
     b->out_cap = cap_out;
   }
   MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
-  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
+  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 256 * sizeof(int), st));
   // Launch bounds (grid sizes, the solver's LDS layout and variant) from exact upper bounds instead of the capacities:
   // no side of any problem of this frame exceeds the tracks alive after the previous frame (bn) / this frame's detections (bd)
   int bd = 1;
@@ -746,17 +753,17 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;  // lists after this frame's births
   const bool prof = b->profile;
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
-  hipLaunchKernelGGL(bt_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr);
+  hipLaunchKernelGGL(bt_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr, b->d_maxt);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, bd, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[6], st));
   MOT_LC_HIP(b, mot::launch_kf_op(6, MOT_KF_XYAH, b->pred_t, S, bn, st));  // predicted boxes of the pool (box-only: nothing is stored)
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
-  MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, true, st));
+  MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, true, st, b->hint1_n, 0));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
-  hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr);
+  hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr, b->d_maxt);
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, bn, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
-  MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, true, st));
+  MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, true, st, b->hint23_n, b->hint23_m));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
   hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t, prof ? b->d_stats : nullptr);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[7], st));
@@ -781,6 +788,15 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
 }
 
 // after the frame's kernels: error flag, launch bounds of the next frame, event times (synchronises the stream)
+// LDS hints of the next frame's assignment launches from this frame's largest problems (a quarter more, and some)
+static void bt_set_hints(mot_bt_batch* b, const int* maxt) {
+  int m1 = 0, m2 = 0, m3 = 0;
+  for (int i = 0; i < 64; ++i) { m1 = (maxt[64 + i] > m1) ? maxt[64 + i] : m1; m2 = (maxt[128 + i] > m2) ? maxt[128 + i] : m2; m3 = (maxt[192 + i] > m3) ? maxt[192 + i] : m3; }
+  b->hint1_n = m1 > 0 ? m1 + m1 / 4 + 64 : 0;
+  b->hint23_n = m2 > 0 ? m2 + m2 / 4 + 32 : 0;
+  b->hint23_m = m3 > 0 ? m3 + m3 / 4 + 32 : 0;
+}
+
 // adds one frame's event times to the profile sums (the events have completed)
 static int bt_account_events(mot_bt_batch* b, hipEvent_t* ev) {
   float ms = 0.f;
@@ -797,12 +813,13 @@ static int bt_account_events(mot_bt_batch* b, hipEvent_t* ev) {
 static int bt_finish_frame(mot_bt_batch* b) {
   hipStream_t st = b->ctx->stream;
   int err = 0;
-  int maxt[64];
+  int maxt[256];
   MOT_LC_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipStreamSynchronize(st));
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
+  bt_set_hints(b, maxt);
   if (b->profile) {
     const int rce = bt_account_events(b, b->ev);
     if (rce != MOT_OK) return rce;
@@ -872,12 +889,12 @@ int mot_bt_enqueue_packed(mot_bt_batch* b, const float* d_dets, const int* h_cou
   mot_bt_batch::Flight& F = b->fl[slot];
   if (!b->copy_st) MOT_LC_HIP(b, hipStreamCreateWithFlags(&b->copy_st, hipStreamNonBlocking));
   if (!F.done) MOT_LC_HIP(b, hipEventCreateWithFlags(&F.done, hipEventDisableTiming));
-  if (!F.h_meta) MOT_LC_HIP(b, hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (66 + 2 * static_cast<size_t>(S)), hipHostMallocDefault));
+  if (!F.h_meta) MOT_LC_HIP(b, hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (258 + 2 * static_cast<size_t>(S)), hipHostMallocDefault));
   if (!F.d_offsets) { F.d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1); F.d_counts = b->dalloc<int>(S); }
   if (rows_cap > F.packed_cap) { F.d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); F.packed_cap = F.d_packed ? rows_cap : 0; }
   if (!F.d_offsets || !F.d_counts || !F.d_packed) return MOT_ERR_NOMEM;
   int bd = 1;
-  int* counts_in = F.h_meta + 66 + S;  // page-locked copy: the caller's array may change as soon as this call returns
+  int* counts_in = F.h_meta + 258 + S;  // page-locked copy: the caller's array may change as soon as this call returns
   for (int s = 0; s < S; ++s) { counts_in[s] = h_counts[s]; bd = (h_counts[s] > bd) ? h_counts[s] : bd; }
   const int saved = b->bound_n;
   const mot_bt_batch::Flight& O = b->fl[slot ^ 1];
@@ -894,8 +911,8 @@ int mot_bt_enqueue_packed(mot_bt_batch* b, const float* d_dets, const int* h_cou
   MOT_LC_HIP(b, hipMemcpyAsync(F.d_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToDevice, st));
   MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta, F.d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 1, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 2, b->d_maxt, sizeof(int) * 64, hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 66, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 2, b->d_maxt, sizeof(int) * 256, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 258, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipEventRecord(F.done, st));
   F.pending = true; F.bd = bd;
   b->fl_count += 1;
@@ -913,7 +930,8 @@ int mot_bt_collect_packed(mot_bt_batch* b, float* rows, int rows_cap, int* out_c
   const int total = F.h_meta[0], err = F.h_meta[1];
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (F.h_meta[2 + i] > b->bound_n) ? F.h_meta[2 + i] : b->bound_n;
-  std::memcpy(out_counts, F.h_meta + 66, sizeof(int) * b->S);
+  std::memcpy(out_counts, F.h_meta + 258, sizeof(int) * b->S);
+  bt_set_hints(b, F.h_meta + 2);
   if (total_rows) *total_rows = total;
   b->d_rows_last = F.d_packed; b->d_offsets_last = F.d_offsets; b->d_counts_last = F.d_counts;  // mot_bt_device_output: the frame just collected
   if (err) { b->ctx->err = "mot_bt_collect_packed: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }

@@ -202,7 +202,8 @@ __global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR 
 
 namespace mot {
 size_t lap_scratch_bytes(int n, int m) { return lap_task_scratch_bytes(n, m); }
-hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool plain_costs, int* declined, hipStream_t st);
+hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool plain_costs, int* declined, hipStream_t st,
+                             int hint_n, int hint_m);
 
 namespace {
 // one counter per launch in flight (the sparse kernel counts the problems it declines, the exact kernel reads it): a ring of
@@ -218,7 +219,7 @@ int* decl_ring(int dev_slot) {
 // Threads per problem: one wavefront (no barriers, no LDS merges; 4-8 problems co-resident per CU) unless the problem is
 // large AND there are too few problems to fill the chip anyway, where 4 wavefronts cut the latency of a row pass.
 hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool geom, bool general_assoc, bool plain_costs,
-                      hipStream_t st) {
+                      hipStream_t st, int hint_n, int hint_m) {
   if (ntasks <= 0) return hipSuccess;
   // fast path first (not for the general association measures: there a pair that does not intersect has no constant cost)
   const bool fast = !general_assoc;
@@ -237,7 +238,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
     }
     hipError_t e = hipMemsetAsync(declined, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
-    e = launch_lap_sparse(tasks, ntasks, max_n, max_m, plain_costs, declined, st);
+    e = launch_lap_sparse(tasks, ntasks, max_n, max_m, plain_costs, declined, st, hint_n, hint_m);
     if (e != hipSuccess) return e;
   }
   const size_t n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1, nm = n + m;

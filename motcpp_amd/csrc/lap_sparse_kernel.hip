@@ -30,7 +30,7 @@ __device__ __forceinline__ int* status_word(const mot_lap_task& T, size_t scratc
 // matching and check the certificate together (those loops run over rows / columns / pairs); the serial path searches in
 // between are done by the first wavefront alone while the others wait at the next barrier.
 template <bool PLAIN, int HS, int kThreads>
-__global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task* __restrict__ tasks, int lds_ecap, int* declined) {
+__global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task* __restrict__ tasks, int lds_ecap, int* declined, int lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mot_lap_task T = tasks[blockIdx.x];
   const int nr = T.n, nc = T.m, t = threadIdx.x;
@@ -51,6 +51,9 @@ __global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task
     else if (!(1.0f > T.geom.prox_thresh)) skip = true;
   }
   if (geom && T.geom.mode == MOT_COST_FUSE_IOU) skip = true;  // cost depends on a per-pair ReID term whatever the overlap
+  // the launch's LDS was sized from a hint of the problem sizes (tighter than the hard bounds): a problem that does not fit is left
+  // to the exact path
+  if (HS == mot::kMemLds && static_cast<size_t>(kScratch) + mot::sparse_hot_bytes(nr, nc, lds_ecap) > static_cast<size_t>(lds_bytes)) skip = true;
   if (skip) { if (t == 0) { *status = 0; atomicAdd(declined, 1); } count_outcome(6); return; }
 
   mot::DevGroup g(smem);
@@ -209,9 +212,13 @@ __global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task
 namespace mot {
 // Launches the fast path over the task array. Hot state in LDS when it fits in 64 KB (the CSR list's capacity gives way first:
 // 5 pairs per column by default, never fewer than 3), else in the task's global scratch.
-hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool plain_costs, int* declined, hipStream_t st) {
+hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool plain_costs, int* declined, hipStream_t st,
+                             int hint_n, int hint_m) {
   if (ntasks <= 0) return hipSuccess;
-  const int n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1;
+  // LDS per problem (which decides how many problems a CU holds) from the caller's hint of the sizes when it has one
+  int n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1;
+  if (hint_n > 0 && hint_n < n) n = hint_n;
+  if (hint_m > 0 && hint_m < m) m = hint_m;
   constexpr size_t kBudget = 64 * 1024 - 64;
   int ecap = sparse_default_ecap(m);
   size_t hot = kScratch + sparse_hot_bytes(n, m, ecap);
@@ -224,7 +231,7 @@ hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, i
   // four wavefronts per problem once there is enough to enumerate (the pairs are listed four times faster; the hot state's
   // LDS, which bounds the problems resident per CU, is the same)
   const bool wide = lds && (static_cast<long>(n) * m >= 64 * 1024);
-#define MOT_SP_LAUNCH(P, H, TH, BYTES) hipLaunchKernelGGL((lap_sparse_kernel<P, H, TH>), dim3(ntasks), dim3(TH), BYTES, st, tasks, ecap, declined)
+#define MOT_SP_LAUNCH(P, H, TH, BYTES) hipLaunchKernelGGL((lap_sparse_kernel<P, H, TH>), dim3(ntasks), dim3(TH), BYTES, st, tasks, ecap, declined, static_cast<int>(BYTES))
   if (lds) {
     if (wide) { if (plain_costs) MOT_SP_LAUNCH(true, kMemLds, 256, hot); else MOT_SP_LAUNCH(false, kMemLds, 256, hot); }
     else { if (plain_costs) MOT_SP_LAUNCH(true, kMemLds, 64, hot); else MOT_SP_LAUNCH(false, kMemLds, 64, hot); }

@@ -86,7 +86,7 @@ __device__ __forceinline__ void apply_match(BotStream& S, int slot, int det) {
 // ---- K0: empty-frame rule, detection split, pools, predict / warp / first-association tasks (:267-330) ----
 __global__ void __launch_bounds__(kW) bot_begin(BotStream* streams, BotParams P, int CAP, int D, const int* counts, const float* dets_base,
                                                  const float* embs_base, const float* warps6, const int* has_warp, BotTasks K,
-                                                 unsigned long long* stats) {
+                                                 unsigned long long* stats, int* maxt) {
   const int s = blockIdx.x;
   BotStream& S = streams[s];
   const int t = static_cast<int>(threadIdx.x);
@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(kW) bot_begin(BotStream* streams, BotParams P,
       W.warp[6] = 0.f; W.warp[7] = 0.f; W.warp[8] = 1.f; PW.warp[6] = 0.f; PW.warp[7] = 0.f; PW.warp[8] = 1.f;
     }
     const bool q = np > 0 && nf > 0;
+    if (q) atomicMax(&maxt[64 + (s & 63)], np);
     mot_cos_task& C1 = K.cos1[s];
     C1.n = (q && have_emb) ? np : 0; C1.m = (q && have_emb) ? nf : 0;
     mot_lap_task& L = K.lap1[s];
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(kW) bot_begin(BotStream* streams, BotParams P,
 }
 
 // ---- K1: apply the first association, queue the second and the unconfirmed one (:332-563) ----
-__global__ void __launch_bounds__(kW) bot_after_first(BotStream* streams, BotParams P, int CAP, BotTasks K, unsigned long long* stats) {
+__global__ void __launch_bounds__(kW) bot_after_first(BotStream* streams, BotParams P, int CAP, BotTasks K, unsigned long long* stats, int* maxt) {
   const int s = blockIdx.x;
   BotStream& S = streams[s];
   if (S.idle) return;
@@ -244,6 +245,10 @@ __global__ void __launch_bounds__(kW) bot_after_first(BotStream* streams, BotPar
     B.geom.bconf = S.dets + static_cast<size_t>(4) * S.ld;
     B.geom.emb = S.have_emb ? C3.out : nullptr;
     B.geom.lde = S.have_emb ? C3.ldo : (P.with_reid ? -1 : 0);
+    {
+      const int mn = (A.n > B.n) ? A.n : B.n, mm = (A.m > B.m) ? A.m : B.m;
+      if (mn > 0) { atomicMax(&maxt[128 + (s & 63)], mn); atomicMax(&maxt[192 + (s & 63)], mm); }
+    }
     if (stats) {
       unsigned long long* st = stats + (s & 63) * 8;
       const int cnt = (q2 ? 1 : 0) + (q3 ? 1 : 0);
@@ -455,7 +460,8 @@ struct mot_bot_batch {
   BotTasks tasks{};
   int* d_counts = nullptr;
   int* d_err = nullptr;
-  int* d_maxt = nullptr;
+  int* d_maxt = nullptr;  // [4][64]: tracks alive, pool rows of the first association, rows / columns of the second and third
+  int hint1_n = 0, hint23_n = 0, hint23_m = 0;  // LDS hints for the next frame's assignment launches
   float* d_warps = nullptr; int* d_has_warp = nullptr;
   int bound_n = 0;
   float* d_out = nullptr; int* d_out_counts = nullptr;
@@ -502,7 +508,7 @@ int mot_bot_reset(mot_bot_batch* b) {  // BotSort::reset :252-258: ids restart
   MOT_LC_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(BotStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
   MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
   MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
-  b->bound_n = 0;
+  b->bound_n = 0; b->hint1_n = b->hint23_n = b->hint23_m = 0;
   return MOT_OK;
 }
 
@@ -536,7 +542,7 @@ int mot_bot_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, int
   b->d_streams = b->dalloc<BotStream>(S);
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
-  b->d_maxt = b->dalloc<int>(64);
+  b->d_maxt = b->dalloc<int>(256);
   b->d_warps = b->dalloc<float>(static_cast<size_t>(S) * 6);
   b->d_has_warp = b->dalloc<int>(S);
   b->d_stats = b->dalloc<unsigned long long>(8 * 64);
@@ -647,7 +653,7 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
                        float* d_packed, int* d_offsets, int rows_cap, hipEvent_t* ev) {
   hipStream_t st = b->ctx->stream;
   const int S = b->S, CAP = b->CAP, D = b->D;
-  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
+  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 256 * sizeof(int), st));
   int bd = 1;
   for (int s = 0; s < S; ++s) bd = (h_counts[s] > bd) ? h_counts[s] : bd;
   if (bd > D) bd = D;
@@ -658,7 +664,7 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
   const BotTasks& K = b->tasks;
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
   hipLaunchKernelGGL(bot_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, emb ? d_embs : nullptr, b->d_warps,
-                     any_warp ? b->d_has_warp : nullptr, K, prof ? b->d_stats : nullptr);
+                     any_warp ? b->d_has_warp : nullptr, K, prof ? b->d_stats : nullptr, b->d_maxt);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYWH, K.det, S, bd, st));
   if (emb) MOT_LC_HIP(b, mot::launch_feat(K.featn, S, bd, st));
   if (any_warp) {
@@ -669,13 +675,13 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
   if (emb) MOT_LC_HIP(b, mot::launch_embed(MOT_EMB_COSINE, K.cos1, S, bn, bd, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
-  MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bn, bd, true, false, false, st));
+  MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bn, bd, true, false, false, st, b->hint1_n, 0));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
-  hipLaunchKernelGGL(bot_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K, prof ? b->d_stats : nullptr);
+  hipLaunchKernelGGL(bot_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K, prof ? b->d_stats : nullptr, b->d_maxt);
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYWH, K.ubox, S, bn, st));
   if (emb) MOT_LC_HIP(b, mot::launch_embed(MOT_EMB_COSINE, K.cos3, S, bn, bd, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[5], st));
-  MOT_LC_HIP(b, mot::launch_lap(K.lap23, 2 * S, bn, bd, true, false, false, st));
+  MOT_LC_HIP(b, mot::launch_lap(K.lap23, 2 * S, bn, bd, true, false, false, st, b->hint23_n, b->hint23_m));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[6], st));
   hipLaunchKernelGGL(bot_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K);
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYWH, K.init, S, bd, st));
@@ -692,6 +698,13 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
   MOT_LC_HIP(b, hipGetLastError());
   return MOT_OK;
+}
+static void bot_set_hints(mot_bot_batch* b, const int* maxt) {  // next frame's LDS hints: this frame's largest problems, a quarter more
+  int m1 = 0, m2 = 0, m3 = 0;
+  for (int i = 0; i < 64; ++i) { m1 = (maxt[64 + i] > m1) ? maxt[64 + i] : m1; m2 = (maxt[128 + i] > m2) ? maxt[128 + i] : m2; m3 = (maxt[192 + i] > m3) ? maxt[192 + i] : m3; }
+  b->hint1_n = m1 > 0 ? m1 + m1 / 4 + 64 : 0;
+  b->hint23_n = m2 > 0 ? m2 + m2 / 4 + 32 : 0;
+  b->hint23_m = m3 > 0 ? m3 + m3 / 4 + 32 : 0;
 }
 static int bot_account_events(mot_bot_batch* b, hipEvent_t* ev) {
   float ms = 0.f;
@@ -729,7 +742,7 @@ int mot_bot_step_packed(mot_bot_batch* b, const float* d_dets, const int* h_coun
   if (rc != MOT_OK) return rc;
   b->d_rows_last = b->d_packed; b->d_offsets_last = b->d_offsets; b->d_counts_last = b->d_out_counts;
   int total = 0, err = 0;
-  int maxt[64];
+  int maxt[256];
   MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(&total, b->d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -737,6 +750,7 @@ int mot_bot_step_packed(mot_bot_batch* b, const float* d_dets, const int* h_coun
   MOT_LC_HIP(b, hipStreamSynchronize(st));
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
+  bot_set_hints(b, maxt);
   if (b->profile) { const int rce = bot_account_events(b, b->ev); if (rce != MOT_OK) return rce; }
   if (total_rows) *total_rows = total;
   if (err) { b->ctx->err = "mot_bot_step_packed: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
@@ -760,14 +774,14 @@ int mot_bot_enqueue_packed(mot_bot_batch* b, const float* d_dets, const int* h_c
   mot_bot_batch::Flight& F = b->fl[slot];
   if (!b->copy_st) MOT_LC_HIP(b, hipStreamCreateWithFlags(&b->copy_st, hipStreamNonBlocking));
   if (!F.done) MOT_LC_HIP(b, hipEventCreateWithFlags(&F.done, hipEventDisableTiming));
-  // pinned: [0] total, [1] err, [2..66) maxima, counts out [S], counts in [S], has_warp [S], warps [6 S] (as float bits)
-  if (!F.h_meta) MOT_LC_HIP(b, hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (66 + 9 * static_cast<size_t>(S)), hipHostMallocDefault));
+  // pinned: [0] total, [1] err, [2..258) maxima, counts out [S], counts in [S], has_warp [S], warps [6 S] (as float bits)
+  if (!F.h_meta) MOT_LC_HIP(b, hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (258 + 9 * static_cast<size_t>(S)), hipHostMallocDefault));
   if (!F.d_offsets) { F.d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1); F.d_counts = b->dalloc<int>(S); }
   if (rows_cap > F.packed_cap) { F.d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); F.packed_cap = F.d_packed ? rows_cap : 0; }
   if (!F.d_offsets || !F.d_counts || !F.d_packed) return MOT_ERR_NOMEM;
-  int* counts_in = F.h_meta + 66 + S;
-  int* hw = F.h_meta + 66 + 2 * S;
-  float* wp = reinterpret_cast<float*>(F.h_meta + 66 + 3 * S);
+  int* counts_in = F.h_meta + 258 + S;
+  int* hw = F.h_meta + 258 + 2 * S;
+  float* wp = reinterpret_cast<float*>(F.h_meta + 258 + 3 * S);
   int bd = 1;
   bool any_warp = false;
   for (int s = 0; s < S; ++s) {
@@ -792,8 +806,8 @@ int mot_bot_enqueue_packed(mot_bot_batch* b, const float* d_dets, const int* h_c
   MOT_LC_HIP(b, hipMemcpyAsync(F.d_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToDevice, st));
   MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta, F.d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 1, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 2, b->d_maxt, sizeof(int) * 64, hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 66, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 2, b->d_maxt, sizeof(int) * 256, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 258, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipEventRecord(F.done, st));
   F.pending = true; F.bd = bd;
   b->fl_count += 1;
@@ -811,7 +825,8 @@ int mot_bot_collect_packed(mot_bot_batch* b, float* rows, int rows_cap, int* out
   const int total = F.h_meta[0], err = F.h_meta[1];
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (F.h_meta[2 + i] > b->bound_n) ? F.h_meta[2 + i] : b->bound_n;
-  std::memcpy(out_counts, F.h_meta + 66, sizeof(int) * b->S);
+  std::memcpy(out_counts, F.h_meta + 258, sizeof(int) * b->S);
+  bot_set_hints(b, F.h_meta + 2);
   if (total_rows) *total_rows = total;
   b->d_rows_last = F.d_packed; b->d_offsets_last = F.d_offsets; b->d_counts_last = F.d_counts;
   if (err) { b->ctx->err = "mot_bot_collect_packed: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }

@@ -154,3 +154,38 @@ def test_two_frames_in_flight_give_the_same_tables():
         check(f - 1)
     check(F - 1)
     dev.close()
+
+
+def test_capacity_error_is_reported():
+    dev = L.DeviceBotSort(1, 16, 64, 8)
+    st = SynthStream(64, 40, 3, 8)
+    with pytest.raises(L.MotError):
+        for _ in range(5):
+            d, e = st.next_frame()
+            dets = np.zeros((1, 64, 6), np.float32)
+            embs = np.zeros((1, 64, 8), np.float32)
+            dets[0, :len(d)] = d
+            embs[0, :len(d)] = e
+            dev.step(dets, np.array([len(d)], np.int32), embs)
+    dev.close()
+
+
+def test_reset_restarts_ids():
+    orc = orclib.load()
+    dev = L.DeviceBotSort(2, 128, 32, 4)
+    for rep in range(2):
+        streams = [SynthStream(20, 12, 77 + i, 4) for i in range(2)]
+        oracles = [orc.tracker(orclib.BOTSORT) for _ in range(2)]
+        for f in range(12):
+            dets = np.zeros((2, 32, 6), np.float32)
+            embs = np.zeros((2, 32, 4), np.float32)
+            cnt = np.zeros(2, np.int32)
+            per = []
+            for s, st in enumerate(streams):
+                d, e = st.next_frame()
+                per.append((d, e)); cnt[s] = len(d); dets[s, :len(d)] = d; embs[s, :len(d)] = e
+            tables = dev.step(dets, cnt, embs)
+            for s in range(2):
+                assert np.array_equal(tables[s], oracles[s].update(*per[s])), (rep, f, s)
+        dev.reset()
+    dev.close()

@@ -84,3 +84,42 @@ def test_streams_with_q4_duplicates():
 
 def test_c4_shape():
     run([(4096, 2048)], 5, 8192, 2048, empty_every=0)
+
+
+def test_capacity_error_is_reported():
+    dev = L.DeviceOCSort(1, 16, 64)
+    st = SynthStream(64, 40, 3)
+    with pytest.raises(L.MotError):
+        for _ in range(5):
+            d, _ = st.next_frame()
+            dets = np.zeros((1, 64, 6), np.float32)
+            dets[0, :len(d)] = d
+            dev.step(dets, np.array([len(d)], np.int32))
+    dev.close()
+
+
+def test_reset_restarts_the_streams():
+    orc = orclib.load()
+    dev = L.DeviceOCSort(2, 128, 32)
+    for rep in range(2):
+        streams = [SynthStream(20, 12, 77 + i) for i in range(2)]
+        oracles = [orc.tracker(orclib.OCSORT) for _ in range(2)]
+        for f in range(12):
+            dets = np.zeros((2, 32, 6), np.float32)
+            cnt = np.zeros(2, np.int32)
+            per = []
+            for s, st in enumerate(streams):
+                d, _ = st.next_frame()
+                per.append(d); cnt[s] = len(d); dets[s, :len(d)] = d
+            tables = dev.step(dets, cnt)
+            for s in range(2):
+                oo = oracles[s].update(per[s])
+                assert tables[s].shape == oo.shape and np.array_equal(tables[s][:, 4:], oo[:, 4:]), (rep, f, s)
+                assert np.allclose(tables[s][:, :4], oo[:, :4], rtol=1e-4, atol=1e-3), (rep, f, s)
+        dev.reset()
+    dev.close()
+
+
+def test_invalid_parameters_are_refused():
+    with pytest.raises(L.MotError):
+        L.DeviceOCSort(1, 64, 16, params=[0.2, 30, 50, 3, 0.3, 0.1, 3, 0.2, 0, 0.01, 0.0001, 9, 1920, 1080])  # no such association measure

@@ -37,6 +37,7 @@ namespace mot {
 // staged in LDS, so the N x M matrix never exists in memory.
 struct MatrixCost {
   static constexpr int kRPL = 0;  // no lane-owned column cache
+  static constexpr bool kMatrix = true;  // rows are loads from a float matrix: worth prefetching a sweep ahead
   static constexpr bool kPlain = false;
   const float* cost;  // nr x nc, row-major, leading dimension ld (global memory)
   int ld;
@@ -47,6 +48,10 @@ struct MatrixCost {
   MOT_DEV float at_owned_f(const Row& r, int, int j) const { return gld(r.p, j); }
   MOT_DEV double at(int i, int j) const { return static_cast<double>(gld(cost, static_cast<size_t>(i) * ld + j)); }
 };
+template <class Cost, class = void>
+struct is_matrix_cost { static constexpr bool value = false; };
+template <class Cost>
+struct is_matrix_cost<Cost, decltype(void(Cost::kMatrix))> { static constexpr bool value = Cost::kMatrix; };
 struct LapDims {
   int nr, nc;
   double half;  // thresh / 2 (lap_solver.hpp:300)
@@ -895,6 +900,12 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           int pq_j = W.cols[slo];
           int pq_i = W.y[pq_j];
           double pq_d = W.d[pq_j];
+          constexpr int kSweep = 4;
+          float pf[kSweep] = {0.f, 0.f, 0.f, 0.f}, pf_next[kSweep] = {0.f, 0.f, 0.f, 0.f};
+          float pf_h = 0.f, pf_next_h = 0.f;
+          int pf_row = -1, pf_next_row = -1;  // the matrix row pf[] / pf_next[] hold (-1: none)
+          int pf_col = -1, pf_next_col = -1;  // the column pf_h / pf_next_h is the element of
+          (void)pf; (void)pf_next; (void)pf_row; (void)pf_next_row; (void)pf_h; (void)pf_next_h; (void)pf_col; (void)pf_next_col;
           while (slo != shi) {
             // Runs of dummy-row members whose sweep is void (h <= hmax_dummy_row, see below) leave the SCAN set together:
             // each lane classifies one member ahead, one reduction counts the leading void ones. With more detections
@@ -929,7 +940,28 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               pq_i = W.y[pq_j];
               pq_d = W.d[pq_j];
             }
-            const double h = R.at(C, jq) - W.v[jq] - mind;
+            if constexpr (is_matrix_cost<Cost>::value) {
+              // the next member's matrix row (the lane's first kSweep columns) is requested now and consumed one sweep later:
+              // a row of a matrix tens of MB large misses L2, and the sweep below would otherwise wait for it load by load
+              if (fetched && pq_i < nr && pq_i != pf_row) {
+                const float* rp = C.row(pq_i).p;
+#pragma unroll
+                for (int k = 0; k < kSweep; ++k) {
+                  const int j = t + k * T;
+                  pf_next[k] = (j < nc) ? gld(rp, j) : 0.f;
+                }
+                pf_next_h = (pq_j < nc) ? gld(rp, pq_j) : 0.f;  // the member's own element, head of the next sweep
+                pf_next_row = pq_i;
+                pf_next_col = pq_j;
+              }
+            }
+            double h;
+            if constexpr (is_matrix_cost<Cost>::value) {
+              const bool have_h = pf_row == i && pf_col == jq && jq < nc;
+              h = (have_h ? static_cast<double>(pf_h) : R.at(C, jq)) - W.v[jq] - mind;
+            } else {
+              h = R.at(C, jq) - W.v[jq] - mind;
+            }
             g.sync();
             // The relaxation sweep, by OWNER lanes (coalesced d[], conflict-free v[], register-cached boxes) rather than
             // by cols[] position; inv[] tells whether a column is still TODO and where it sits for the order-dependent
@@ -946,11 +978,10 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               else hmax_real_row = h;
             }
             int first_sink = kNoIdx, any_tie = 0;
-            auto relax = [&](double red, int j) {
-              const int k = W.inv[j];
+            auto relax_pre = [&](double red, int j, int k, double dj) {  // k = inv[j], dj = d[j]
               if (k < static_cast<int>(shi)) return;  // already SCAN/READY
               const double cred = red - h;
-              if (cred < W.d[j]) {
+              if (cred < dj) {
                 W.d[j] = cred;
                 W.pred[j] = i;
                 if (cred == mind) {
@@ -960,8 +991,56 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 }
               }
             };
-            if (sweep_real) for_lane_real(C, R, W.v, t, T, nc, relax);
-            if (sweep_dummy) for_lane_dummy(R.right, W.v, t, T, nc, n, relax);
+            auto relax = [&](double red, int j) { relax_pre(red, j, W.inv[j], W.d[j]); };
+            if constexpr (is_matrix_cost<Cost>::value) {
+              // kSweep of the lane's columns at a time: their cost, inv[] and d[] loads are all in flight before the first
+              // relaxation (a lane owns its columns, so nothing it stores below aliases what it preloaded; inv[] does not
+              // change during a sweep)
+              auto sweep = [&](int jb, int je, auto load, auto value) {  // load: the float to fetch for column j; value: its cost
+                for (int j0 = jb; j0 < je; j0 += kSweep * T) {
+                  float cv[kSweep];
+                  double dd[kSweep];
+                  int kk[kSweep];
+#pragma unroll
+                  for (int k = 0; k < kSweep; ++k) {
+                    const int j = j0 + k * T;
+                    if (j < je) { cv[k] = load(j, k, j0 == jb); kk[k] = W.inv[j]; dd[k] = W.d[j]; }
+                  }
+#pragma unroll
+                  for (int k = 0; k < kSweep; ++k) {
+                    const int j = j0 + k * T;
+                    if (j < je) relax_pre(value(cv[k]) - W.v[j], j, kk[k], dd[k]);
+                  }
+                }
+              };
+              auto no_load = [](int, int, bool) { return 0.f; };
+              if (sweep_real) {
+                if (R.real) {
+                  const float* rp = R.r.p;
+                  const bool have = pf_row == i;
+                  sweep(t, nc, [&](int j, int k, bool first) { return (first && have) ? pf[k] : gld(rp, j); },
+                        [](float c) { return static_cast<double>(c); });
+                } else {
+                  const double l = R.left;
+                  sweep(t, nc, no_load, [l](float) { return l; });
+                }
+              }
+              if (sweep_dummy) {
+                const double r = R.right;
+                sweep(first_dummy(t, T, nc), n, no_load, [r](float) { return r; });
+              }
+              if (pf_next_row >= 0) {  // rotate the prefetched row in for the next sweep
+#pragma unroll
+                for (int k = 0; k < kSweep; ++k) pf[k] = pf_next[k];
+                pf_h = pf_next_h;
+                pf_row = pf_next_row;
+                pf_col = pf_next_col;
+                pf_next_row = -1;
+              }
+            } else {
+              if (sweep_real) for_lane_real(C, R, W.v, t, T, nc, relax);
+              if (sweep_dummy) for_lane_dummy(R.right, W.v, t, T, nc, n, relax);
+            }
             // one reduction for both outcomes: the first sink position, or "ties but no sink", or nothing
             const int key = g.reduce_min_int((first_sink != kNoIdx) ? first_sink : (any_tie ? kNoIdx - 1 : kNoIdx));
             if (key < kNoIdx - 1) {

@@ -51,6 +51,14 @@ struct DevGroup {
   __device__ __forceinline__ int tid() const { return tid_; }
   __device__ __forceinline__ int size() const { return size_; }
   __device__ __forceinline__ void sync() { __syncthreads(); }
+  // Every wavefront of the group can keep a 64-entry table with one entry per lane and read entry `src` (the same for all lanes)
+  // with v_readlane: lap_core.hpp's window of upcoming SCAN members. Groups without wavefronts (tests/emu) do not define it.
+  static constexpr bool kWaveTable = true;
+  __device__ __forceinline__ int wave_lane() const { return tid_ & 63; }
+  static __device__ __forceinline__ int wave_get(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+  static __device__ __forceinline__ double wave_get(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+  }
 
   // ---- wavefront reductions on DPP (row_shr 1,2,4,8 then row_bcast 15/31): VALU-only, no LDS crossbar round trips.
   // After the sequence lane 63 holds the reduction of all 64 lanes; v_readlane broadcasts it.

@@ -52,6 +52,10 @@ template <class Cost, class = void>
 struct is_matrix_cost { static constexpr bool value = false; };
 template <class Cost>
 struct is_matrix_cost<Cost, decltype(void(Cost::kMatrix))> { static constexpr bool value = Cost::kMatrix; };
+template <class G, class = void>
+struct has_wave_table { static constexpr bool value = false; };
+template <class G>
+struct has_wave_table<G, decltype(void(G::kWaveTable))> { static constexpr bool value = G::kWaveTable; };
 struct LapDims {
   int nr, nc;
   double half;  // thresh / 2 (lap_solver.hpp:300)
@@ -897,9 +901,39 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           bool returned = false;
           // software pipeline: the next member of the SCAN set, its row, distance and row box are fetched while the
           // current one is swept (cols[] below shi, y[] and the d[] of SCAN members do not change during a sweep)
-          int pq_j = W.cols[slo];
-          int pq_i = W.y[pq_j];
-          double pq_d = W.d[pq_j];
+          // On wavefront hardware the upcoming members are read 64 at a time, member slo + l by lane l of every wavefront, and
+          // handed out with v_readlane: the dependent cols[] -> y[] -> d[] loads (global memory for the wide problems) are
+          // paid once per 64 members instead of once per sweep. Members that join the set later are picked up by the next fill.
+          constexpr bool kWin = has_wave_table<G>::value;
+          int win_j = 0, win_i = 0;
+          double win_d = 0.0;
+          unsigned win_base = 0, win_cnt = 0;
+          (void)win_j; (void)win_i; (void)win_d; (void)win_base; (void)win_cnt;
+          int pq_j, pq_i;
+          double pq_d;
+          auto member = [&](unsigned pos) {  // pq_* = member `pos` of the SCAN set (pos < shi)
+            if constexpr (kWin) {
+              if (pos - win_base >= win_cnt) {
+                win_base = pos;
+                win_cnt = (shi - pos < 64u) ? (shi - pos) : 64u;
+                const unsigned idx = pos + static_cast<unsigned>(g.wave_lane());
+                if (idx < shi) {
+                  win_j = W.cols[idx];
+                  win_i = W.y[win_j];
+                  win_d = W.d[win_j];
+                }
+              }
+              const int l = static_cast<int>(pos - win_base);
+              pq_j = G::wave_get(win_j, l);
+              pq_i = G::wave_get(win_i, l);
+              pq_d = G::wave_get(win_d, l);
+            } else {
+              pq_j = W.cols[pos];
+              pq_i = W.y[pq_j];
+              pq_d = W.d[pq_j];
+            }
+          };
+          member(slo);
           constexpr int kSweep = 4;
           float pf[kSweep] = {0.f, 0.f, 0.f, 0.f}, pf_next[kSweep] = {0.f, 0.f, 0.f, 0.f};
           float pf_h = 0.f, pf_next_h = 0.f;
@@ -922,11 +956,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               const int avail = (shi - slo < static_cast<unsigned>(T)) ? static_cast<int>(shi - slo) : T;
               if (cnt > avail) cnt = avail;
               slo += static_cast<unsigned>(cnt);  // cnt >= 1: lane 0 looked at the current member
-              if (slo != shi) {
-                pq_j = W.cols[slo];
-                pq_i = W.y[pq_j];
-                pq_d = W.d[pq_j];
-              }
+              if (slo != shi) member(slo);
               continue;
             }
             const int jq = pq_j;
@@ -935,11 +965,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             const ExtRow<Cost> R = ext_row(C, P, i);
             ++slo;
             const bool fetched = slo != shi;
-            if (fetched) {
-              pq_j = W.cols[slo];
-              pq_i = W.y[pq_j];
-              pq_d = W.d[pq_j];
-            }
+            if (fetched) member(slo);
             if constexpr (is_matrix_cost<Cost>::value) {
               // the next member's matrix row (the lane's first kSweep columns) is requested now and consumed one sweep later:
               // a row of a matrix tens of MB large misses L2, and the sweep below would otherwise wait for it load by load
@@ -1067,11 +1093,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             }
             shi += static_cast<unsigned>(nt);
             g.sync();
-            if (!fetched && slo != shi) {  // the SCAN set was empty until this sweep's ties joined it
-              pq_j = W.cols[slo];
-              pq_i = W.y[pq_j];
-              pq_d = W.d[pq_j];
-            }
+            if (!fetched && slo != shi) member(slo);  // the SCAN set was empty until this sweep's ties joined it
           }
           if (!returned) { lo = slo; hi = shi; }
         }

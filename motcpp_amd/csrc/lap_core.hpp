@@ -17,6 +17,12 @@
 // one wavefront/LDS reduction (grp.hpp). Sequential dependencies between rows are kept.
 #pragma once
 #include <type_traits>
+#ifndef MOT_LAP_TIE_PER  // (the host-emulation tests lower both so that small problems take the closed-form tie runs)
+#define MOT_LAP_TIE_PER 4
+#endif
+#ifndef MOT_LAP_TIE_MIN
+#define MOT_LAP_TIE_MIN 128
+#endif
 #include "grp.hpp"
 #include "mem.hpp"
 
@@ -821,77 +827,174 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             }
             g.sync();
             const int nrec = compact_ascending(g, cnt, [&](int q) { return W.tmp[first + q] != 0; }, W.lst);
-            bool replayed = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-            if (T == 64) {
-              // One wavefront: the replay runs out of registers. A chunk of 64 records (position, column, distance) is
-              // gathered in parallel, one per lane, together with a 64-entry window of cols[] at the insertion point; the
-              // serial walk then reads them with v_readlane and keeps the window current with a lane-select, so that an
-              // iteration costs ~25 instructions instead of three dependent global loads. (A later record's position is
-              // never touched by an earlier step: h2 <= lo + r < k_r.) The stores to cols[] / inv[] still go to memory.
-              unsigned h2 = lo + 1;
-              double mind = m0;
-              for (int r0 = 0; r0 < nrec; r0 += 64) {
-                const int r = r0 + t;
-                int rk = 0, rj = 0;
-                double rd = 0.0;
-                if (r < nrec) { rk = first + static_cast<int>(W.lst[r]); rj = W.cols[rk]; rd = W.d[rj]; }
-                const unsigned wb = (r0 == 0) ? lo : h2;  // window base: covers a restart (h2 = lo) in the first chunk
-                int win = (wb + static_cast<unsigned>(t) < static_cast<unsigned>(n)) ? static_cast<int>(W.cols[wb + t]) : 0;
-                const int cc = (nrec - r0 < 64) ? nrec - r0 : 64;
-                for (int q = 0; q < cc; ++q) {
-                  const int k = __builtin_amdgcn_readlane(rk, q), j = __builtin_amdgcn_readlane(rj, q);
-                  const double dj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rd), q), __builtin_amdgcn_readlane(__double2loint(rd), q));
-                  if (dj < mind) { h2 = lo; mind = dj; }
-                  const unsigned off = h2 - wb, offk = static_cast<unsigned>(k) - wb;
-                  int jh;
-                  if (off < 64u) jh = __builtin_amdgcn_readlane(win, static_cast<int>(off));
-                  else jh = W.cols[h2];
-                  if (t == 0) {
-                    W.cols[k] = jh; W.inv[jh] = k;
-                    W.cols[h2] = j; W.inv[j] = static_cast<int>(h2);
-                  }
-                  if (static_cast<unsigned>(t) == offk) win = jh;  // (offk >= 64 matches no lane)
-                  if (static_cast<unsigned>(t) == off) win = j;
-                  ++h2;
-                }
+            // The replay is serial in the number of records, and on tracking problems most of them are TIES with the final
+            // minimum (the dummy block is one big tie: thousands of records per call). After the last record that lowers
+            // the minimum (a "strict" record: it restarts the insertion point at lo and lands there itself) the insertion
+            // point is lo + 1 and every remaining record r = 0..R-1 is one swap of positions s + r and k_r (s = lo + 1,
+            // k_r ascending, k_r >= s + r). Their net effect has a closed form, applied by the whole group:
+            //   * position s + r ends up holding record r's column;
+            //   * an item displaced from s + r0 hops to k_r0, and on from there if k_r0 = s + r1 is itself displaced at
+            //     step r1 > r0, until it lands on a k beyond the last target position: with g(r) = k_r - s that is the
+            //     fixed point of r -> g(r) (g is increasing and injective), found by pointer jumping over the records.
+            // Only items whose position s + r0 is not some earlier record's k start such a chain ("fresh").
+            constexpr int kTiePer = MOT_LAP_TIE_PER;  // tie records per lane held in registers across the read/write barrier
+            constexpr int kTieMin = MOT_LAP_TIE_MIN;  // shorter tie runs stay with the serial replay
+            static_assert(kTiePer <= 32, "one bit per held record in `fresh`");
+            int nser = nrec, R = 0;        // serially replayed records, then R tie records in closed form
+            if (nrec >= kTieMin) {
+              int last_strict = -1;
+              for (int r = t; r < nrec; r += T) {
+                const double dr = W.d[W.cols[first + static_cast<int>(W.lst[r])]];
+                const double dp = r ? static_cast<double>(W.d[W.cols[first + static_cast<int>(W.lst[r - 1])]]) : m0;
+                if (dr < dp) last_strict = r;  // (records are weak: the running minimum before r is record r-1's value)
               }
-              g.sync();  // lane 0's stores to cols[] are visible to everyone
-              int best = -1;
-              for (unsigned k = lo + static_cast<unsigned>(t); k < h2; k += 64u)
-                if (static_cast<int>(W.y[static_cast<int>(W.cols[k])]) < 0) best = static_cast<int>(k);  // the LAST free member (:174-177)
-              best = g.reduce_max(best);
-              hi = h2;
-              final_j = (best >= 0) ? static_cast<int>(W.cols[best]) : -1;
-              replayed = true;
+              last_strict = g.reduce_max(last_strict);
+              const int ties = nrec - 1 - last_strict;
+              if (ties >= kTieMin && ties <= kTiePer * T) { nser = last_strict + 1; R = ties; }
             }
-#endif
-            if (!replayed) {
-              if (t == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            {
+              // The first wavefront replays out of registers (the others wait at the barrier below). A chunk of 64 records
+              // (position, column, distance) is gathered in parallel, one per lane, together with a 64-entry window of cols[] at the insertion point; the
+              // serial walk then reads them with v_readlane and keeps the windows current with lane-selects, so that an
+              // iteration costs ~30 instructions instead of three dependent global loads. (A later record's position is
+              // never touched by an earlier step: h2 <= lo + r < k_r.) The stores to cols[] / inv[] still go to memory.
+              if (t < 64) {
                 unsigned h2 = lo + 1;
                 double mind = m0;
-                for (int r = 0; r < nrec; ++r) {
-                  const int k = first + W.lst[r];
-                  const int j = W.cols[k];
-                  const double dj = W.d[j];
-                  if (dj < mind) { h2 = lo; mind = dj; }
-                  const int jh = W.cols[h2];
-                  W.cols[k] = jh; W.inv[jh] = k;
-                  W.cols[h2] = j; W.inv[j] = static_cast<int>(h2);
-                  ++h2;
+                // Two windows of cols[]: win_lo at lo (where a new minimum restarts the insertion point) and win_ch at the
+                // insertion point the chunk started with. Within a chunk h2 advances by at most 64 and a restart puts it
+                // at lo, so one of them always covers it and the walk has no loads — a load in the loop body would make
+                // every step wait for the previous step's stores (stores count in vmcnt on gfx9).
+                const bool in_lo = lo + static_cast<unsigned>(t) < static_cast<unsigned>(n);
+                int win_lo = in_lo ? static_cast<int>(W.cols[lo + t]) : 0;
+                for (int r0 = 0; r0 < nser; r0 += 64) {
+                  const int r = r0 + t;
+                  int rk = 0, rj = 0;
+                  double rd = 0.0;
+                  if (r < nser) { rk = first + static_cast<int>(W.lst[r]); rj = W.cols[rk]; rd = W.d[rj]; }
+                  const unsigned wb = (r0 == 0) ? lo : h2;
+                  int win_ch = win_lo;
+                  if (r0 != 0) win_ch = (wb + static_cast<unsigned>(t) < static_cast<unsigned>(n)) ? static_cast<int>(W.cols[wb + t]) : 0;
+                  const int cc = (nser - r0 < 64) ? nser - r0 : 64;
+                  for (int q = 0; q < cc; ++q) {
+                    const int k = __builtin_amdgcn_readlane(rk, q), j = __builtin_amdgcn_readlane(rj, q);
+                    const double dj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rd), q), __builtin_amdgcn_readlane(__double2loint(rd), q));
+                    if (dj < mind) { h2 = lo; mind = dj; }
+                    const unsigned off_ch = h2 - wb, off_lo = h2 - lo;
+                    const int jh_ch = __builtin_amdgcn_readlane(win_ch, static_cast<int>(off_ch & 63u));
+                    const int jh_lo = __builtin_amdgcn_readlane(win_lo, static_cast<int>(off_lo & 63u));
+                    const int jh = (off_ch < 64u) ? jh_ch : jh_lo;
+                    if (t == 0) {
+                      W.cols[k] = jh; W.inv[jh] = k;
+                      W.cols[h2] = j; W.inv[j] = static_cast<int>(h2);
+                    }
+                    const unsigned ut = static_cast<unsigned>(t), uk = static_cast<unsigned>(k);
+                    if (ut == uk - wb) win_ch = jh;  // (offsets >= 64 match no lane)
+                    if (ut == off_ch) win_ch = j;
+                    if (ut == uk - lo) win_lo = jh;
+                    if (ut == off_lo) win_lo = j;
+                    ++h2;
+                  }
                 }
-                int fj = -1;
-                for (unsigned k = lo; k < h2; ++k) {
-                  const int j = W.cols[k];
-                  if (W.y[j] < 0) fj = j;
-                }
-                W.tmp[0] = static_cast<int>(h2);
-                W.tmp[1] = fj;
+                if (t == 0) W.tmp[0] = static_cast<int>(h2);  // (tmp[0] is not a record flag: those start at first >= 1)
+              }
+            }
+#else
+            if (t == 0) {  // groups without wavefronts (tests/emu): lane 0 replays
+              unsigned h2 = lo + 1;
+              double mind = m0;
+              for (int r = 0; r < nser; ++r) {
+                const int k = first + W.lst[r];
+                const int j = W.cols[k];
+                const double dj = W.d[j];
+                if (dj < mind) { h2 = lo; mind = dj; }
+                const int jh = W.cols[h2];
+                W.cols[k] = jh; W.inv[jh] = k;
+                W.cols[h2] = j; W.inv[j] = static_cast<int>(h2);
+                ++h2;
+              }
+              W.tmp[0] = static_cast<int>(h2);
+            }
+#endif
+            g.sync();  // the replaying lane's stores to cols[] / inv[] / tmp[0] are visible to everyone
+            unsigned h2;
+            if (R == 0) {
+              h2 = static_cast<unsigned>(W.tmp[0]);
+            } else {
+              const int a = nser;  // first tie record; the serial part left the insertion point at s = lo + 1 = first
+              const int s = first;
+              int gr[kTiePer];
+#pragma unroll
+              for (int q = 0; q < kTiePer; ++q) {
+                const int r = t + q * T;
+                gr[q] = (r < R) ? static_cast<int>(W.lst[a + r]) : 0;  // g(r) = k_r - s
+                if (r < R) W.tmp[r] = 0;
               }
               g.sync();
-              hi = static_cast<unsigned>(W.tmp[0]);
-              final_j = W.tmp[1];
+#pragma unroll
+              for (int q = 0; q < kTiePer; ++q) {
+                const int r = t + q * T;
+                if (r < R && gr[q] < R && gr[q] != r) W.tmp[gr[q]] = 1;  // position s + g is record r's k: not fresh
+              }
+              g.sync();
+              unsigned fresh = 0;
+#pragma unroll
+              for (int q = 0; q < kTiePer; ++q) {
+                const int r = t + q * T;
+                if (r < R && gr[q] != r && W.tmp[r] == 0) fresh |= 1u << q;
+              }
+              g.sync();
+#pragma unroll
+              for (int q = 0; q < kTiePer; ++q) {
+                const int r = t + q * T;
+                if (r < R) W.tmp[r] = (gr[q] < R) ? gr[q] : r;
+              }
+              g.sync();
+              for (;;) {  // pointer jumping, in place: a racing reader sees an older or a newer node of the same chain
+                int changed = 0;
+#pragma unroll
+                for (int q = 0; q < kTiePer; ++q) {
+                  const int r = t + q * T;
+                  if (r < R) {
+                    const int p1 = W.tmp[r];
+                    const int p2 = W.tmp[p1];
+                    if (p2 != p1) { W.tmp[r] = p2; changed = 1; }
+                  }
+                }
+                if (g.reduce_max(changed) == 0) break;
+              }
+              int jr[kTiePer], orig[kTiePer], dst[kTiePer];
+#pragma unroll
+              for (int q = 0; q < kTiePer; ++q) {
+                const int r = t + q * T;
+                jr[q] = 0; orig[q] = 0; dst[q] = 0;
+                if (r < R) {
+                  jr[q] = W.cols[s + gr[q]];
+                  if (fresh & (1u << q)) {
+                    orig[q] = W.cols[s + r];
+                    dst[q] = s + static_cast<int>(W.lst[a + static_cast<int>(W.tmp[r])]);
+                  }
+                }
+              }
+              g.sync();  // every read of the old order is done
+#pragma unroll
+              for (int q = 0; q < kTiePer; ++q) {
+                const int r = t + q * T;
+                if (r < R) {
+                  W.cols[s + r] = jr[q]; W.inv[jr[q]] = s + r;
+                  if (fresh & (1u << q)) { W.cols[dst[q]] = orig[q]; W.inv[orig[q]] = dst[q]; }
+                }
+              }
+              g.sync();
+              h2 = static_cast<unsigned>(s + R);
             }
+            int best = -1;
+            for (unsigned k = lo + static_cast<unsigned>(t); k < h2; k += static_cast<unsigned>(T))
+              if (static_cast<int>(W.y[static_cast<int>(W.cols[k])]) < 0) best = static_cast<int>(k);  // the LAST free member (:174-177)
+            best = g.reduce_max(best);
+            hi = h2;
+            final_j = (best >= 0) ? static_cast<int>(W.cols[best]) : -1;
           }
           g.sync();
         }

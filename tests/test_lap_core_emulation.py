@@ -10,9 +10,9 @@ import pytest
 from tests.emu.build import build_lap_emu
 
 
-@pytest.fixture(scope="module")
-def emu():
-    lib = C.CDLL(build_lap_emu())
+@pytest.fixture(scope="module", params=[False, True], ids=["serial_replay", "closed_form_tie_runs"])
+def emu(request):
+    lib = C.CDLL(build_lap_emu(request.param))
 
     def run(cost, th, T):
         cost = np.ascontiguousarray(cost, np.float32)
@@ -24,9 +24,9 @@ def emu():
     return run
 
 
-@pytest.fixture(scope="module")
-def emu_iou():
-    lib = C.CDLL(build_lap_emu())
+@pytest.fixture(scope="module", params=[False, True], ids=["serial_replay", "closed_form_tie_runs"])
+def emu_iou(request):
+    lib = C.CDLL(build_lap_emu(request.param))
 
     def run(a, b, conf, mode, th, T, rpl=0):
         a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)

@@ -18,7 +18,7 @@
 #pragma once
 #include <type_traits>
 #ifndef MOT_LAP_TIE_PER  // (the host-emulation tests lower both so that small problems take the closed-form tie runs)
-#define MOT_LAP_TIE_PER 4
+#define MOT_LAP_TIE_PER 8
 #endif
 #ifndef MOT_LAP_TIE_MIN
 #define MOT_LAP_TIE_MIN 128
@@ -863,8 +863,8 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 unsigned h2 = lo + 1;
                 double mind = m0;
                 // Two windows of cols[]: win_lo at lo (where a new minimum restarts the insertion point) and win_ch at the
-                // insertion point the chunk started with. Within a chunk h2 advances by at most 64 and a restart puts it
-                // at lo, so one of them always covers it and the walk has no loads — a load in the loop body would make
+                // insertion point the chunk started with. Within a chunk h2 takes at most 64 values from there, or after a
+                // restart at most 64 from lo, so one of them always covers it and the walk has no loads — a load in the loop body would make
                 // every step wait for the previous step's stores (stores count in vmcnt on gfx9).
                 const bool in_lo = lo + static_cast<unsigned>(t) < static_cast<unsigned>(n);
                 int win_lo = in_lo ? static_cast<int>(W.cols[lo + t]) : 0;
@@ -873,9 +873,9 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                   int rk = 0, rj = 0;
                   double rd = 0.0;
                   if (r < nser) { rk = first + static_cast<int>(W.lst[r]); rj = W.cols[rk]; rd = W.d[rj]; }
-                  const unsigned wb = (r0 == 0) ? lo : h2;
-                  int win_ch = win_lo;
-                  if (r0 != 0) win_ch = (wb + static_cast<unsigned>(t) < static_cast<unsigned>(n)) ? static_cast<int>(W.cols[wb + t]) : 0;
+                  const unsigned wb = h2;  // (the first chunk starts at lo + 1: its 64th record may insert at lo + 64)
+                  const int win_ch0 = (wb + static_cast<unsigned>(t) < static_cast<unsigned>(n)) ? static_cast<int>(W.cols[wb + t]) : 0;
+                  int win_ch = win_ch0;
                   const int cc = (nser - r0 < 64) ? nser - r0 : 64;
                   for (int q = 0; q < cc; ++q) {
                     const int k = __builtin_amdgcn_readlane(rk, q), j = __builtin_amdgcn_readlane(rj, q);

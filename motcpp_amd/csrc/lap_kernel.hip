@@ -265,7 +265,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   const int grid = (fast && ntasks > 512) ? 512 : ntasks;
 #define MOT_LAP_VARIANTS(X) X(64, 0, 0, 1) X(64, 2, 0, 1) X(64, 3, 0, 1) X(64, 0, 4, 1) X(64, 2, 4, 1) X(64, 3, 4, 1) \
                             X(64, 0, 8, 1) X(64, 2, 8, 1) X(64, 3, 8, 1) X(256, 0, 0, 1) X(256, 2, 0, 1) X(256, 3, 0, 1) \
-                            X(1024, 0, 0, 1) X(1024, 2, 0, 1) X(1024, 3, 0, 1) \
+                            X(512, 0, 0, 1) X(512, 2, 0, 1) X(512, 3, 0, 1) \
                             X(64, 0, 4, 0) X(64, 2, 4, 0) X(64, 3, 4, 0) X(64, 0, 8, 0) X(64, 2, 8, 0) X(64, 3, 8, 0) \
                             X(64, 0, 0, 2) X(64, 2, 0, 2) X(64, 3, 0, 2) X(256, 0, 0, 2) X(256, 2, 0, 2) X(256, 3, 0, 2)
   // plain-cost variants exist for the register-cached column layouts only (the hot ones)
@@ -279,11 +279,12 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
 #undef MOT_ATTR
     attr_set_dev[dev_slot] = true;
   }
-  // 16 wavefronts per problem when there are no more problems than CUs anyway (OC-SORT 4096 x 2048: the dense row sweeps of the
-  // shortest-path search are 6144 columns wide) — MOT_LAP_WIDE16=0 switches it off (measurement aid)
-  static const bool wide16_ok = !(std::getenv("MOT_LAP_WIDE16") && std::getenv("MOT_LAP_WIDE16")[0] == '0');
-  const bool wide16 = wide && wide16_ok && ntasks <= 256 && flavor == 1;
-  const int threads = wide16 ? 1024 : (wide ? 256 : 64);
+  // 8 wavefronts per problem when there are no more problems than CUs anyway (OC-SORT 4096 x 2048: the dense row sweeps of the
+  // shortest-path search are 6144 columns wide). Measured on C4: 4 / 8 / 16 wavefronts = 53 / 88 / 66-79 frames/s — the uniform
+  // part of a sweep is paid by every wavefront, and 16 of them leave 128 VGPRs each. MOT_LAP_WIDE8=0 switches it off.
+  static const bool wide8_ok = !(std::getenv("MOT_LAP_WIDE8") && std::getenv("MOT_LAP_WIDE8")[0] == '0');
+  const bool wide8 = wide && wide8_ok && ntasks <= 256 && flavor == 1;
+  const int threads = wide8 ? 512 : (wide ? 256 : 64);
   bool launched = false;
 #define MOT_TRY(T, M, R, G)                                                                                \
   if (!launched && threads == T && mode == M && rpl == R && flavor == G) {                                 \

@@ -111,6 +111,24 @@ def test_lap_indices_identical(ctx, orc, kind):
         assert np.array_equal(xg, xo) and np.array_equal(yg, yo), (kind, n, m)
 
 
+@pytest.mark.parametrize("n,m", [(9, 150), (30, 400), (150, 90), (64, 1000), (12, 70), (700, 2600), (2600, 700)])
+def test_lap_contested_rows_over_long_tie_runs(ctx, orc, n, m):
+    # OC-SORT-like costs: almost every entry exactly 0, a few negative ones, several rows wanting the same column. The
+    # augmenting-path searches then rebuild tied sets of tens to thousands of columns (lap_core.hpp: the register replay
+    # of _find_dense across its 64-record chunks, and the closed-form tie runs of the wide variants)
+    r = np.random.default_rng(n * 31 + m)
+    for trial in range(6 if n * m < 100000 else 2):
+        c = np.zeros((n, m), np.float32)
+        hot = r.permutation(m)[: max(2, min(n, m) // 3)]
+        for i in range(n):
+            for j in r.choice(hot, size=min(len(hot), 1 + trial % 3), replace=False):
+                c[i, j] = -np.float32(r.integers(1, 6)) / 5 if trial % 2 else -r.uniform(0.05, 0.9)
+        th = -0.1
+        xo, yo = orc.linear_assignment(c, th)
+        xg, yg, info = ctx.lap(c, th)
+        assert info == 0 and np.array_equal(xg, xo) and np.array_equal(yg, yo), (n, m, trial)
+
+
 def test_lap_north_star_and_global_workspace(ctx, orc):
     r = np.random.default_rng(5)
     for n, m in [(1000, 500), (2600, 1400)]:  # second one exceeds the LDS limit -> global-scratch variant

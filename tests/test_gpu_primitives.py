@@ -115,7 +115,8 @@ def test_lap_indices_identical(ctx, orc, kind):
 def test_lap_contested_rows_over_long_tie_runs(ctx, orc, n, m):
     # OC-SORT-like costs: almost every entry exactly 0, a few negative ones, several rows wanting the same column. The
     # augmenting-path searches then rebuild tied sets of tens to thousands of columns (lap_core.hpp: the register replay
-    # of _find_dense across its 64-record chunks, and the closed-form tie runs of the wide variants)
+    # of _find_dense and the closed-form tie runs of the wide variants). The replay's chunk-boundary case — 64 tie records
+    # with no new minimum among them — is what tests/test_gpu_trackers.py::test_ocsort_association_measures[1] runs into.
     r = np.random.default_rng(n * 31 + m)
     for trial in range(6 if n * m < 100000 else 2):
         c = np.zeros((n, m), np.float32)

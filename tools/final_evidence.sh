@@ -1,3 +1,4 @@
+# Runs ON the GPU box (through gpurun): the default bench of every workload plus rocprofv3 kernel traces of NS and C4, into gpurun_out/r02y_*.
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT; TAG=r02y
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_default_NS.json 2> $OUT/${TAG}_ns.err

@@ -285,7 +285,12 @@ typedef struct mot_lap_task {
    * column boxes with mot_iou_cost's arithmetic for geom.mode (cost, ldc are ignored; geom.cost/pairs unused): the
    * N x M matrix is never materialised. geom.emb (BOTSORT) is still read from memory, for overlapping pairs only. */
   mot_iou_task geom;
-  long long* prof; /* optional out [8]: shader cycles per solver phase + pass counts (diagnostics) */
+  long long* prof; /* optional out [24]: shader cycles per solver phase, pass counts, shortest-path scan counters and cycles (diagnostics) */
+  void* rowlist;   /* optional scratch of mot_lap_rowlist_bytes(n) bytes for a task with a cost MATRIX (geom.a == NULL): the exact
+                    * solver gathers, per row, the entries below thresh/2 there and runs lapjv's shortest-path scans over those
+                    * lists (many SCAN members per step) instead of one dense row sweep per member — same decisions, proved in
+                    * lap_core.hpp; what OC-SORT's first association (4096 x 2048, src/trackers/ocsort.cpp:700-701) needs. NULL:
+                    * dense sweeps. */
 } mot_lap_task;
 enum {
   MOT_LAP_F_GEOM = 1, /* some task carries geom: reserve LDS for the staged boxes */
@@ -294,6 +299,7 @@ enum {
   MOT_LAP_F_PLAIN = 4 /* no geom.mode is MOT_COST_BOTSORT: the variants without the gated appearance term may run */
 };
 size_t mot_lap_work_bytes(int n, int m);
+size_t mot_lap_rowlist_bytes(int n);
 /* mot_lap_solve runs two kernels over the task array: a fast path (viable pairs only, shortest augmenting paths, and a
  * certificate that the optimum is unique — then it IS lapjv's answer) and, for the problems the fast path does not certify, the
  * step-by-step lapjv emulation that reproduces the reference's tie-breaks. Diagnostics: outcome counts of the fast path on this

@@ -25,6 +25,7 @@ hipError_t launch_cosine(const mot_cos_task*, int, int, int, hipStream_t);
 // solver sizes its LDS with them (more problems per CU) and leaves a problem that exceeds them to the exact solver
 hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, bool, hipStream_t, int hint_n = 0, int hint_m = 0);
 size_t lap_scratch_bytes(int n, int m);
+size_t lap_rowlist_scratch_bytes(int n);
 hipError_t lap_fast_stats(unsigned long long* out16, bool reset, hipStream_t st);
 }  // namespace mot
 
@@ -150,6 +151,7 @@ int mot_deepoc_cost(mot_ctx* c, const mot_deep_task* t, int nt, int max_nd, int 
 int mot_feat_update(mot_ctx* c, const mot_feat_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_feat(t, nt, max_n, c->stream)); return MOT_OK; }
 int mot_lap_fast_stats(mot_ctx* c, unsigned long long* out16, int reset) { MOT_HIP(c, mot::lap_fast_stats(out16, reset != 0, c->stream)); return MOT_OK; }
 size_t mot_lap_work_bytes(int n, int m) { return (mot::lap_scratch_bytes(n, m) + 255) & ~size_t(255); }
+size_t mot_lap_rowlist_bytes(int n) { return (mot::lap_rowlist_scratch_bytes(n) + 255) & ~size_t(255); }
 int mot_lap_solve(mot_ctx* c, const mot_lap_task* t, int nt, int max_n, int max_m, int flags) { MOT_HIP(c, mot::launch_lap(t, nt, max_n, max_m, (flags & MOT_LAP_F_GEOM) != 0, (flags & MOT_LAP_F_ASSOC) != 0, (flags & MOT_LAP_F_PLAIN) != 0, c->stream)); return MOT_OK; }
 
 // ---- host-pointer conveniences ------------------------------------------------------------------
@@ -307,8 +309,9 @@ int mot_lap_solve_prof_host(mot_ctx* c, const float* cost, int n, int m, float t
     if (info) *info = 2;
     return MOT_OK;
   }
-  DBuf dc, di, dx, dy, dinfo, dwork, dt, dprof;
+  DBuf dc, di, dx, dy, dinfo, dwork, dt, dprof, drl;
   MOT_HIP(c, dc.alloc(static_cast<size_t>(n) * m * 4)); MOT_HIP(c, dx.alloc(n * 4)); MOT_HIP(c, dy.alloc(m * 4));
+  MOT_HIP(c, drl.alloc(mot_lap_rowlist_bytes(n)));
   MOT_HIP(c, dinfo.alloc(16)); MOT_HIP(c, dwork.alloc(mot_lap_work_bytes(n, m))); MOT_HIP(c, dt.alloc(sizeof(mot_lap_task)));
   MOT_HIP(c, hipMemcpyAsync(dc.p, cost, static_cast<size_t>(n) * m * 4, hipMemcpyHostToDevice, c->stream));
   if (iou) {
@@ -319,9 +322,10 @@ int mot_lap_solve_prof_host(mot_ctx* c, const float* cost, int n, int m, float t
   t.n = n; t.m = m; t.cost = dc.as<float>(); t.ldc = m; t.thresh = thresh; t.x = dx.as<int>(); t.y = dy.as<int>();
   t.mode = mode; t.iou = iou ? di.as<float>() : nullptr; t.ldi = m; t.gate = gate; t.info = dinfo.as<int>();
   t.work = dwork.p;
+  t.rowlist = drl.p;
   if (prof8) {  // per-phase shader cycles of the exact solver (the sparse solver leaves a task that asks for them alone)
-    MOT_HIP(c, dprof.alloc(64));
-    MOT_HIP(c, hipMemsetAsync(dprof.p, 0, 64, c->stream));
+    MOT_HIP(c, dprof.alloc(192));
+    MOT_HIP(c, hipMemsetAsync(dprof.p, 0, 192, c->stream));
     t.prof = dprof.as<long long>();
   }
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
@@ -330,7 +334,7 @@ int mot_lap_solve_prof_host(mot_ctx* c, const float* cost, int n, int m, float t
   MOT_HIP(c, hipMemcpyAsync(y, dy.p, m * 4, hipMemcpyDeviceToHost, c->stream));
   int inf = 0;
   MOT_HIP(c, hipMemcpyAsync(&inf, dinfo.p, 4, hipMemcpyDeviceToHost, c->stream));
-  if (prof8) MOT_HIP(c, hipMemcpyAsync(prof8, dprof.p, 64, hipMemcpyDeviceToHost, c->stream));
+  if (prof8) MOT_HIP(c, hipMemcpyAsync(prof8, dprof.p, 192, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   if (info) *info = inf;
   return MOT_OK;
@@ -358,8 +362,8 @@ int mot_lap_geom_host(mot_ctx* c, const float* a, int n, const float* b, int m, 
   t.n = n; t.m = m; t.thresh = thresh; t.x = dx.as<int>(); t.y = dy.as<int>(); t.mode = lap_mode; t.gate = gate;
   t.xval = dv.as<float>(); t.info = dinfo.as<int>(); t.work = dwork.p;
   DBuf dprof;
-  MOT_HIP(c, dprof.alloc(64));
-  MOT_HIP(c, hipMemsetAsync(dprof.p, 0, 64, c->stream));
+  MOT_HIP(c, dprof.alloc(192));
+  MOT_HIP(c, hipMemsetAsync(dprof.p, 0, 192, c->stream));
   t.prof = prof8 ? dprof.as<long long>() : nullptr;
   t.geom.n = n; t.geom.m = m; t.geom.a = da.as<float>(); t.geom.lda = n; t.geom.b = db.as<float>(); t.geom.ldb = m;
   t.geom.bconf = bconf ? dc.as<float>() : nullptr; t.geom.mode = cost_mode;
@@ -371,7 +375,7 @@ int mot_lap_geom_host(mot_ctx* c, const float* a, int n, const float* b, int m, 
   int inf = 0;
   MOT_HIP(c, hipMemcpyAsync(hv.data(), dv.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(&inf, dinfo.p, 4, hipMemcpyDeviceToHost, c->stream));
-  if (prof8) MOT_HIP(c, hipMemcpyAsync(prof8, dprof.p, 64, hipMemcpyDeviceToHost, c->stream));
+  if (prof8) MOT_HIP(c, hipMemcpyAsync(prof8, dprof.p, 192, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   if (xval) for (int i = 0; i < n; ++i) xval[i] = hv[i];
   if (info) *info = inf;

@@ -233,6 +233,10 @@ struct DevGroup {
   static __device__ __forceinline__ void atomic_min(int* p, int v) { atomicMin(p, v); }
   static __device__ __forceinline__ void atomic_or(int* p, int v) { atomicOr(p, v); }
   static __device__ __forceinline__ void atomic_and(int* p, int v) { atomicAnd(p, v); }
+  // minimum of non-negative doubles (no -0.0, no NaN): their bit patterns order like the values, so one 64-bit integer atomic does it
+  static __device__ __forceinline__ void atomic_min_f64_nonneg(double* p, double v) {
+    atomicMin(reinterpret_cast<long long*>(p), __double_as_longlong(v));
+  }
 };
 
 // ---- single-wavefront helpers shared by DevGroup (64-thread blocks) and DevWave ----

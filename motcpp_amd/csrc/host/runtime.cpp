@@ -528,6 +528,7 @@ Core::Lap Core::lap(const float* cost, int ldc, int n, int m, float thresh, int 
   t.n = n; t.m = m; t.cost = cost; t.ldc = ldc; t.thresh = thresh; t.x = r.x.d; t.y = r.y.d; t.mode = mode; t.iou = iou; t.ldi = ldi; t.gate = gate;
   t.xval = want_xval ? r.xval.d : nullptr; t.info = r.info.d;
   t.work = dev_->tmp->alloc<char>(mot_lap_work_bytes(n, m)).d;
+  if (static_cast<long long>(n) * m >= 16384) t.rowlist = dev_->tmp->alloc<char>(mot_lap_rowlist_bytes(n)).d;
   dev_->q().lap.push_back(t);
   r.queued = true;
   return r;

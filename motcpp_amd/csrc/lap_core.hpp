@@ -69,8 +69,8 @@ struct LapDims {
 // Workspace, each array n = nr + nc long. The HOT arrays are touched by every row pass and live in LDS when
 // the problem fits; the COLD arrays are only used by the general shortest-path search (rare on tracking costs)
 // and the phase-1 row list, and always live in global scratch.
-// VS = address space of v/y, XS = of x/fr (mem.hpp); the cold arrays are always global.
-template <int VS, int XS>
+// VS = address space of v/y, XS = of x/fr, DS = of d (mem.hpp); the other cold arrays are always global.
+template <int VS, int XS, int DS = kMemGlobal>
 struct LapWorkT {
   // hot
   MemPtr<double, VS> v;   // column duals
@@ -78,7 +78,7 @@ struct LapWorkT {
   MemPtr<int, VS> y;      // col -> row (extended)
   MemPtr<int, XS> fr;     // free-row list (doubles as the column-hit counter in phase 1)
   // cold
-  MemPtr<double, kMemGlobal> d;   // shortest-path distances
+  MemPtr<double, DS> d;           // shortest-path distances (LDS for the wide matrix problems: every scan step reads and writes them)
   MemPtr<int, kMemGlobal> pred;   // path predecessors
   MemPtr<int, kMemGlobal> cols;   // lapjv's column permutation / phase-1 unique-row list
   MemPtr<int, kMemGlobal> tmp;    // tie flags (slow path)
@@ -86,11 +86,38 @@ struct LapWorkT {
   MemPtr<double, kMemGlobal> rlb; // per real row: minimum raw cost over the real columns (phase 1), see "hopeless rows"
   MemPtr<int, kMemGlobal> inv;    // inverse of cols[] (position of a column), slow path
   MemPtr<int, kMemGlobal> tie;    // tie flags by position during a scan (all zero between scans), slow path
-  long long* cyc = nullptr;  // optional profiling: [0..3] cycles in phase 1a (column minima), 1b (transfer), 2, 3; [4..7] n_uniq, serial row-reduction rounds, serial augmentations, n
+  // optional (null: the parallel scan steps and the sparse real-row sweeps are off) — see "row lists" in lap_solve
+  MemPtr<int, kMemGlobal> rl_cnt;     // [nr] entries of real row i with cost < half (may exceed kRlCap: then the row has no usable list)
+  MemPtr<int, kMemGlobal> rl_col;     // [nr][kRlCap] their columns ...
+  MemPtr<float, kMemGlobal> rl_cost;  // ... and costs
+  MemPtr<int, VS == kMemAny ? kMemAny : kMemLds> fsw;  // kFsWsInts ints of fast scratch (always LDS on the device): step members + tie events
+  bool cyc_ext = false;      // cyc has 24 entries: [16..23] cycles inside phase 3 (step classification, dry run, apply, event sort, event replay, _find_dense, one-at-a-time sweeps, search set-up)
+  long long* cyc = nullptr;  // optional profiling [16]: [0..3] cycles in phase 1a (column minima), 1b (transfer), 2, 3; [4..7] n_uniq, serial row-reduction rounds, serial augmentations, n;
+                             // [8..15] shortest-path scans: parallel steps, members they consumed, real rows among them, tie events, one-at-a-time sweeps, steps refused (rounding), _find_dense calls, row lists in use
 };
-using LapWork = LapWorkT<kMemAny, kMemAny>;
+using LapWork = LapWorkT<kMemAny, kMemAny, kMemAny>;
 MOT_HD size_t lap_hot_bytes(int n) { return static_cast<size_t>(n) * (sizeof(double) + 3 * sizeof(int)); }
 MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 6 * sizeof(int)); }
+// Row lists (optional scratch of a matrix-cost task, mot_lap_task.rowlist): per real row the entries below thresh/2.
+constexpr int kRlCap = 64;      // entries kept per row (a row with more has no list: its sweeps stay dense)
+constexpr int kFsIter = 8;      // list entries a lane holds in registers during a parallel scan step
+constexpr int kFsMaxMembers = 64;   // real-row members of one step (also bounded by kFsIter * T / kRlCap)
+constexpr int kEvCap = 256;     // tie events one step may produce (more: the step shrinks to one member)
+constexpr int kKeepCap = 512;   // relaxations of one step that lower a distance (more: the step shrinks to one member)
+constexpr int kFsHash = 1024;   // slots of the per-step column table (>= 2 * kKeepCap, a power of two)
+constexpr int kFsMaxN = 8192;   // extended size up to which the TODO bitmask fits
+// fast scratch (ints): members (q, row, list length, h as 2 ints) | counters | column table of a step (key, earliest member) |
+// event list (q, j, k) | sorted events (q, j, k, flags) + head slots (column, event) | TODO bitmask
+constexpr int kFsM = 0, kFsCtr = 5 * kFsMaxMembers, kFsKeep = kFsCtr + 8, kFsEvl = kFsKeep + 2 * kFsHash, kFsEvs = kFsEvl + 3 * kEvCap,
+              kFsTodo = kFsEvs + 6 * kEvCap, kFsWsInts = kFsTodo + kFsMaxN / 32 + 8;
+MOT_HD size_t lap_rowlist_bytes(int nr) { return static_cast<size_t>(nr > 0 ? nr : 0) * (4 + 8 * static_cast<size_t>(kRlCap)) + 32; }
+template <class Work>
+MOT_HD void lap_carve_rowlist(Work& w, void* base, int nr) {
+  char* p = static_cast<char*>(base);
+  w.rl_cnt.p = reinterpret_cast<int*>(p); p += ((sizeof(int) * static_cast<size_t>(nr > 0 ? nr : 0)) + 15) & ~size_t(15);
+  w.rl_col.p = reinterpret_cast<int*>(p); p += sizeof(int) * static_cast<size_t>(kRlCap) * (nr > 0 ? nr : 0);
+  w.rl_cost.p = reinterpret_cast<float*>(p);
+}
 MOT_HD size_t lap_work_bytes(int n) { return lap_hot_bytes(n) + lap_cold_bytes(n); }
 template <class Work>
 MOT_HD void lap_carve_hot(Work& w, void* base, int n) {
@@ -337,8 +364,15 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
 
   long long c0 = MOT_CLOCK();
   long long n_carr = 0, n_paths = 0;
+  long long n_fs_steps = 0, n_fs_members = 0, n_fs_sparse = 0, n_fs_events = 0, n_seq_sweeps = 0, n_fs_bad = 0, n_finds = 0;  // diagnostics
+  long long cy_cls = 0, cy_dry = 0, cy_apply = 0, cy_evsort = 0, cy_evser = 0, cy_find = 0, cy_seq = 0, cy_init = 0;
   // ---- phase 1: column reduction + reduction transfer (_ccrrt_dense, :36-72) ----
+  // Row lists (matrix costs with the optional scratch): per real row the entries with cost < half, gathered by the column
+  // sweep below. The shortest-path search uses them for exact sparse sweeps of real rows (see the scan of phase 3).
+  const bool use_rl = is_matrix_cost<Cost>::value && W.rl_cnt.p != nullptr && W.fsw.p != nullptr && half > -1e300 && half < 1e300 &&
+                      T * kFsIter >= kRlCap && n <= kFsMaxN;
   for (int i = t; i < n; i += T) { W.x[i] = -1; W.fr[i] = 0; }
+  if (use_rl) for (int i = t; i < nr; i += T) W.rl_cnt[i] = 0;
   g.sync();
   auto publish_column = [&](int j, double vm, int im) {
     W.v[j] = vm;
@@ -433,6 +467,12 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     for (int i = 0; i < nr; ++i) {
       const double c = C.at(i, j);
       if (c < vm) { vm = c; im = i; }
+      if constexpr (is_matrix_cost<Cost>::value) {
+        if (use_rl && c < half) {
+          const int slot = G::atomic_add(W.rl_cnt.raw(i), 1);
+          if (slot < kRlCap) { W.rl_col[static_cast<long>(i) * kRlCap + slot] = j; W.rl_cost[static_cast<long>(i) * kRlCap + slot] = static_cast<float>(c); }
+        }
+      }
     }
     if (half < vm) { vm = half; im = nr; }
     publish_column(j, vm, im);
@@ -798,14 +838,23 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
       // ---- general path: exact emulation of find_path_dense (:157-193) ----
       da_valid = false;  // the dual update below changes v
       dq_ok = false;
+      const long long qi0 = MOT_CLOCK();
       for (int j = t; j < n; j += T) { W.cols[j] = j; W.inv[j] = j; W.tie[j] = 0; W.pred[j] = start; W.d[j] = R0.at(C, j) - W.v[j]; }
+      if (use_rl) {  // the steps' column table starts empty; TODO bitmask: one bit per column that has not entered the SCAN set yet
+        for (int w = t; w < kFsHash; w += T) { W.fsw[kFsKeep + w] = -1; W.fsw[kFsKeep + kFsHash + w] = kNoIdx; }
+        for (int w = t; w < (n + 31) / 32; w += T) W.fsw[kFsTodo + w] = (32 * (w + 1) <= n) ? -1 : static_cast<int>((1u << (n & 31)) - 1u);
+      }
       g.sync();
+      cy_init += MOT_CLOCK() - qi0;
       unsigned lo = 0, hi = 0, n_ready = 0;
       // largest h of a fully swept dummy row / of a real row's dummy-column part so far in this search (see the scan)
-      double hmax_dummy_row = -1e300, hmax_real_row = -1e300;
+      // (the initial distances d[j] = E(start, j) - v[j] are a sweep of the start row with h = 0)
+      double hmax_dummy_row = dummy_row ? 0.0 : -1e300, hmax_real_row = dummy_row ? -1e300 : 0.0;
       while (final_j == -1) {
         if (lo == hi) {
           n_ready = lo;
+          ++n_finds;
+          const long long qf0 = MOT_CLOCK();
           // _find_dense (:115-127). Its outcome depends on the ORDER of cols[], which only changes at positions whose
           // value is <= the running minimum ("weak records") — and the values it reads are those of the cols[] order
           // at entry (a swap never touches a position still to be read). So: find the records in parallel (chunk
@@ -993,10 +1042,16 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             for (unsigned k = lo + static_cast<unsigned>(t); k < h2; k += static_cast<unsigned>(T))
               if (static_cast<int>(W.y[static_cast<int>(W.cols[k])]) < 0) best = static_cast<int>(k);  // the LAST free member (:174-177)
             best = g.reduce_max(best);
+            if (use_rl)
+              for (unsigned k = lo + static_cast<unsigned>(t); k < h2; k += static_cast<unsigned>(T)) {
+                const int j = W.cols[k];
+                W.fsw.atomic_and(kFsTodo + (j >> 5), ~(1 << (j & 31)));
+              }
             hi = h2;
             final_j = (best >= 0) ? static_cast<int>(W.cols[best]) : -1;
           }
           g.sync();
+          cy_find += MOT_CLOCK() - qf0;
         }
         if (final_j == -1) {
           // _scan_dense (:129-155) on local copies of lo/hi, written back only on normal exit
@@ -1043,7 +1098,255 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           int pf_row = -1, pf_next_row = -1;  // the matrix row pf[] / pf_next[] hold (-1: none)
           int pf_col = -1, pf_next_col = -1;  // the column pf_h / pf_next_h is the element of
           (void)pf; (void)pf_next; (void)pf_row; (void)pf_next_row; (void)pf_h; (void)pf_next_h; (void)pf_col; (void)pf_next_col;
+          // ---- parallel scan steps (row lists present) ----
+          // lapjv sweeps the members of the SCAN set one at a time; all of them sit at the same distance `mind`. Two exact facts
+          // make most sweeps cheap and independent of each other:
+          //  (1) a dummy row whose h does not exceed the largest h of a dummy row swept before changes nothing (above);
+          //  (2) for a REAL row i with h_i <= that same bound, every real column j with cost(i,j) >= half is a no-op as well:
+          //      d[j] <= fl(fl(half - v[j]) - hmax_dummy_row) <= fl(fl(cost(i,j) - v[j]) - h_i) (rounding is monotone) — so its
+          //      sweep only needs the row's list of entries below half (and, while h_i <= hmax_real_row, no dummy column).
+          // Up to T consecutive members of those two kinds are handled by one step: each lane classifies one member; the
+          // real rows' list entries are relaxed together. The relaxations that lower a distance are collected in LDS; of those
+          // that hit the same column the smallest value wins, among equal values the EARLIEST member (a later equal value does
+          // not replace the predecessor in lapjv either). Values that tie with `mind` become events and are applied in lapjv's
+          // order: by member, then by position in cols[] at that member's turn. A step stops in front of the first member of
+          // any other kind, which takes the one-at-a-time sweep below. If a relaxed value falls below mind (possible only
+          // through rounding) the rest of the SCAN set is swept one member at a time.
+          const int fs_members = use_rl ? ((((kFsIter * T) / kRlCap) < kFsMaxMembers) ? (kFsIter * T) / kRlCap : kFsMaxMembers) : 0;
+          bool fast_ok = fs_members > 0;
+          constexpr int kMQ = kFsM, kMROW = kFsM + kFsMaxMembers, kMCNT = kFsM + 2 * kFsMaxMembers, kMH = kFsM + 3 * kFsMaxMembers;
+          constexpr int kCEV = kFsCtr, kCKEEP = kFsCtr + 1, kCDONE = kFsCtr + 2, kCSINK = kFsCtr + 3;
+          constexpr int kHK = kFsKeep, kHQ = kFsKeep + kFsHash;
+          auto fast_step = [&](double mind_b) -> int {  // 0: nothing done, 1: members consumed, 2: a sink was reached (final_j set)
+            const long long q0 = MOT_CLOCK();
+            const unsigned idx = slo + static_cast<unsigned>(t);
+            int cls = 0, mi = -1, mcnt = 0;  // 0 stop, 1 void dummy row, 2 real row with a list
+            double hh = 0.0;
+            if (idx < shi) {
+              const int mj = W.cols[idx];
+              mi = W.y[mj];
+              const double md = W.d[mj];
+              if (md == mind_b) {
+                if (mi >= nr) {
+                  hh = ((mj < nc) ? half : 0.0) - W.v[mj] - md;
+                  if (hh <= hmax_dummy_row) cls = 1;
+                } else {
+                  mcnt = W.rl_cnt[mi];
+                  const double cij = (mj < nc) ? C.at(mi, mj) : half;
+                  hh = cij - W.v[mj] - md;
+                  if (hh <= hmax_dummy_row && hh <= hmax_real_row && mcnt <= kRlCap) cls = 2;
+                }
+              }
+            }
+            int cnt = g.reduce_min_int((cls == 0) ? t : kNoIdx);
+            const int avail = (shi - slo < static_cast<unsigned>(T)) ? static_cast<int>(shi - slo) : T;
+            if (cnt > avail) cnt = avail;
+            if (cnt == 0) { cy_cls += MOT_CLOCK() - q0; return 0; }
+            const bool sp = t < cnt && cls == 2 && mcnt > 0;  // (a real row without entries below half relaxes nothing)
+            int ns;
+            const int rank = g.flag_rank(sp, &ns);
+            if (ns > fs_members) {  // the step ends in front of the member of rank fs_members
+              cnt = g.reduce_min_int((sp && rank == fs_members) ? t : kNoIdx);
+              ns = fs_members;
+            }
+            if (ns == 0) { slo += static_cast<unsigned>(cnt); ++n_fs_steps; n_fs_members += cnt; cy_cls += MOT_CLOCK() - q0; return 1; }
+            if (sp && rank < ns) {
+              const long long hb = __builtin_bit_cast(long long, hh);
+              W.fsw[kMQ + rank] = t;
+              W.fsw[kMROW + rank] = mi;
+              W.fsw[kMCNT + rank] = mcnt;
+              W.fsw[kMH + 2 * rank] = static_cast<int>(hb & 0xffffffffll);
+              W.fsw[kMH + 2 * rank + 1] = static_cast<int>(hb >> 32);
+            }
+            if (t == 0) W.fsw[kCEV] = 0;
+            g.sync();
+            const long long q1 = MOT_CLOCK();
+            cy_cls += q1 - q0;
+            // dry run: every list entry of the step's real rows, held in registers
+            int ej[kFsIter], eq[kFsIter], er[kFsIter];
+            double ec[kFsIter];
+            unsigned keep = 0u;
+            int bad = 0, nt = 0, nk = 0;
+            auto evaluate = [&](int ns_now) {
+              keep = 0u; nt = 0; nk = 0;
+              float cc[kFsIter];
+#pragma unroll
+              for (int it = 0; it < kFsIter; ++it) {  // the loads of all the lane's entries are in flight together
+                const int item = t + it * T;
+                const int r = item / kRlCap, e = item % kRlCap;
+                ej[it] = -1; cc[it] = 0.f;
+                if (r < ns_now && e < static_cast<int>(W.fsw[kMCNT + r])) {
+                  const int row = W.fsw[kMROW + r];
+                  ej[it] = W.rl_col[static_cast<long>(row) * kRlCap + e];
+                  cc[it] = W.rl_cost[static_cast<long>(row) * kRlCap + e];
+                }
+              }
+#pragma unroll
+              for (int it = 0; it < kFsIter; ++it) {
+                const int j = ej[it];
+                eq[it] = 0; er[it] = 0; ec[it] = 0.0;
+                if (j >= 0 && ((static_cast<int>(W.fsw[kFsTodo + (j >> 5)]) >> (j & 31)) & 1)) {
+                  const int r = (t + it * T) / kRlCap;
+                  const long long hb = (static_cast<long long>(static_cast<int>(W.fsw[kMH + 2 * r + 1])) << 32) |
+                                       static_cast<long long>(static_cast<unsigned>(static_cast<int>(W.fsw[kMH + 2 * r])));
+                  const double cred = static_cast<double>(cc[it]) - W.v[j] - __builtin_bit_cast(double, hb);
+                  const double dj = W.d[j];
+                  if (!(cred >= mind_b)) bad = 1;
+                  if (cred < dj) {
+                    keep |= 1u << it;
+                    eq[it] = W.fsw[kMQ + r]; er[it] = W.fsw[kMROW + r]; ec[it] = cred;
+                    ++nk;
+                    if (cred == mind_b) ++nt;
+                  }
+                }
+              }
+            };
+            evaluate(ns);
+            bad = g.reduce_max(bad);
+            if (bad) { fast_ok = false; ++n_fs_bad; return 0; }
+            int packed_all;
+            g.exclusive_scan((nt << 16) | nk, &packed_all);  // (each count <= kFsIter * T <= 32768)
+            if ((packed_all >> 16) > kEvCap || (packed_all & 0xffff) > kKeepCap) {  // more than the tables hold: this step takes one real row only (<= kRlCap entries)
+              ns = 1;
+              cnt = static_cast<int>(W.fsw[kMQ]) + 1;
+              evaluate(1);
+            }
+            const long long q2 = MOT_CLOCK();
+            cy_dry += q2 - q1;
+            // 1. distances: atomic minimum (all values are >= mind >= 0: the bit patterns order like the doubles)
+#pragma unroll
+            for (int it = 0; it < kFsIter; ++it)
+              if (keep & (1u << it)) mem_atomic_min_f64_nonneg<std::remove_reference_t<decltype(W.d)>::kSpace>(W.d.raw(ej[it]), ec[it]);
+            g.sync();
+            // 2. of the relaxations that attain a column's new distance the EARLIEST member is its predecessor (a later equal
+            //    value does not replace it in lapjv either): they meet in a small open-addressing table keyed by the column
+            int es[kFsIter];
+            unsigned ach = 0u;
+#pragma unroll
+            for (int it = 0; it < kFsIter; ++it) {
+              es[it] = 0;
+              if ((keep & (1u << it)) && static_cast<double>(W.d[ej[it]]) == ec[it]) {
+                int slot = static_cast<int>((static_cast<unsigned>(ej[it]) * 2654435761u) >> 22) & (kFsHash - 1);
+                for (;;) {
+                  const int old = W.fsw.atomic_cas(kHK + slot, -1, ej[it]);
+                  if (old == -1 || old == ej[it]) break;
+                  slot = (slot + 1) & (kFsHash - 1);
+                }
+                W.fsw.atomic_min(kHQ + slot, eq[it]);
+                es[it] = slot;
+                ach |= 1u << it;
+              }
+            }
+            g.sync();
+            unsigned win = 0u;
+#pragma unroll
+            for (int it = 0; it < kFsIter; ++it)
+              if ((ach & (1u << it)) && static_cast<int>(W.fsw[kHQ + es[it]]) == eq[it]) {
+                win |= 1u << it;
+                W.pred[ej[it]] = er[it];
+                if (ec[it] == mind_b) {
+                  const int k = W.inv[ej[it]];  // position in cols[]: the order of the tie events
+                  const int e = W.fsw.atomic_add(kCEV, 1);
+                  W.fsw[kFsEvl + e] = eq[it];
+                  W.fsw[kFsEvl + kEvCap + e] = ej[it];
+                  W.fsw[kFsEvl + 2 * kEvCap + e] = k;
+                }
+              }
+            g.sync();
+#pragma unroll
+            for (int it = 0; it < kFsIter; ++it)
+              if (win & (1u << it)) { W.fsw[kHK + es[it]] = -1; W.fsw[kHQ + es[it]] = kNoIdx; }  // the table is empty again for the next step
+            const int nev = W.fsw[kCEV];
+            const long long q3 = MOT_CLOCK();
+            cy_apply += q3 - q2;
+            ++n_fs_steps; n_fs_members += cnt; n_fs_sparse += ns; n_fs_events += nev;
+            if (nev == 0) { slo += static_cast<unsigned>(cnt); return 1; }
+            // tie events in lapjv's order. Sorted by (member, position at the start of the step); positions only change for
+            // columns that sit in the first nev TODO positions ("head slots": a tie swaps its column with the first TODO one).
+            constexpr int kSQ = kFsEvs, kSJ = kFsEvs + kEvCap, kSK = kFsEvs + 2 * kEvCap, kSF = kFsEvs + 3 * kEvCap, kHC = kFsEvs + 4 * kEvCap, kHE = kFsEvs + 5 * kEvCap;
+            int in_head = 0, first_sink = kNoIdx;
+            for (int e = t; e < nev; e += T) {
+              const int q = W.fsw[kFsEvl + e], j = W.fsw[kFsEvl + kEvCap + e], k = W.fsw[kFsEvl + 2 * kEvCap + e];
+              const int hcol = W.cols[shi + static_cast<unsigned>(e)];
+              const int fl = (static_cast<int>(W.y[j]) < 0) ? 1 : 0;
+              int rk = 0;
+              for (int o = 0; o < nev; ++o) {
+                const int oq = W.fsw[kFsEvl + o], ok = W.fsw[kFsEvl + 2 * kEvCap + o];
+                rk += (oq < q || (oq == q && ok < k)) ? 1 : 0;
+              }
+              W.fsw[kSQ + rk] = q; W.fsw[kSJ + rk] = j; W.fsw[kSK + rk] = k; W.fsw[kSF + rk] = fl;
+              W.fsw[kHC + e] = hcol;
+              W.fsw[kHE + e] = -1;
+              if (k - static_cast<int>(shi) < nev) in_head = 1;
+              if (fl && rk < first_sink) first_sink = rk;
+            }
+            in_head = g.reduce_max(in_head);
+            first_sink = g.reduce_min_int(first_sink);
+            g.sync();
+            const long long q4 = MOT_CLOCK();
+            cy_evsort += q4 - q3;
+            int done, sink = -1;
+            if (!in_head) {
+              // no event column sits in a head slot: positions do not interact, the swaps are independent
+              done = (first_sink < nev) ? first_sink : nev;
+              if (first_sink < nev) sink = W.fsw[kSJ + first_sink];
+              for (int r = t; r < done; r += T) {
+                const int j = W.fsw[kSJ + r], bp = W.fsw[kSK + r], hc = W.fsw[kHC + r];
+                const int hpos = static_cast<int>(shi) + r;
+                W.cols[bp] = hc; W.inv[hc] = bp;
+                W.cols[hpos] = j; W.inv[j] = hpos;
+                W.fsw.atomic_and(kFsTodo + (j >> 5), ~(1 << (j & 31)));
+              }
+              g.sync();
+            } else {
+              for (int e = t; e < nev; e += T) {
+                const int off = static_cast<int>(W.fsw[kSK + e]) - static_cast<int>(shi);
+                if (off < nev) W.fsw[kHE + off] = e;
+              }
+              g.sync();
+              if (t == 0) {
+                int dn = 0, sk = -1, e0 = 0;
+                for (int r = 0; r < nev; ++r) {
+                  while (static_cast<int>(W.fsw[kSF + e0]) & 2) ++e0;
+                  const int q = W.fsw[kSQ + e0];
+                  int best = e0, bp = W.fsw[kSK + e0];
+                  for (int e = e0 + 1; e < nev && static_cast<int>(W.fsw[kSQ + e]) == q; ++e) {
+                    const int pk = W.fsw[kSK + e];
+                    if (!(static_cast<int>(W.fsw[kSF + e]) & 2) && pk < bp) { best = e; bp = pk; }
+                  }
+                  const int j = W.fsw[kSJ + best], fl = W.fsw[kSF + best];
+                  if (fl & 1) { sk = j; break; }
+                  W.fsw[kSF + best] = fl | 2;
+                  const int hpos = static_cast<int>(shi) + r;
+                  if (bp != hpos) {
+                    const int hc = W.fsw[kHC + r], he = W.fsw[kHE + r];
+                    const int off = bp - static_cast<int>(shi);
+                    if (off < nev) { W.fsw[kHC + off] = hc; W.fsw[kHE + off] = he; }
+                    else { W.cols[bp] = hc; W.inv[hc] = bp; }
+                    if (he >= 0) W.fsw[kSK + he] = bp;
+                  }
+                  W.cols[hpos] = j; W.inv[j] = hpos;
+                  W.fsw[kFsTodo + (j >> 5)] = static_cast<int>(W.fsw[kFsTodo + (j >> 5)]) & ~(1 << (j & 31));
+                  ++dn;
+                }
+                W.fsw[kCDONE] = dn;
+                W.fsw[kCSINK] = sk;
+              }
+              g.sync();
+              done = W.fsw[kCDONE]; sink = W.fsw[kCSINK];
+            }
+            cy_evser += MOT_CLOCK() - q4;
+            if (sink >= 0) { final_j = sink; return 2; }
+            shi += static_cast<unsigned>(done);
+            slo += static_cast<unsigned>(cnt);
+            return 1;
+          };
           while (slo != shi) {
+            if (fast_ok) {
+              const int fr = fast_step(pq_d);
+              if (fr == 2) { returned = true; break; }
+              if (fr == 1) { if (slo != shi) member(slo); continue; }
+            }
             // Runs of dummy-row members whose sweep is void (h <= hmax_dummy_row, see below) leave the SCAN set together:
             // each lane classifies one member ahead, one reduction counts the leading void ones. With more detections
             // than tracks the tied sets are hundreds of such rows (one per unmatched detection).
@@ -1062,6 +1365,8 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               if (slo != shi) member(slo);
               continue;
             }
+            ++n_seq_sweeps;
+            const long long qs0 = MOT_CLOCK();
             const int jq = pq_j;
             const int i = pq_i;
             const double mind = pq_d;
@@ -1143,7 +1448,14 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 }
               };
               auto no_load = [](int, int, bool) { return 0.f; };
-              if (sweep_real) {
+              if (sweep_real && R.real && use_rl && h <= hmax_dummy_row && static_cast<int>(W.rl_cnt[i]) <= kRlCap) {
+                // fact (2) above: the columns at or above half cannot be lowered by this row — its list is the whole sweep
+                const int ne = W.rl_cnt[i];
+                for (int e = t; e < ne; e += T) {
+                  const int j = W.rl_col[static_cast<long>(i) * kRlCap + e];
+                  relax_pre(static_cast<double>(static_cast<float>(W.rl_cost[static_cast<long>(i) * kRlCap + e])) - W.v[j], j, W.inv[j], W.d[j]);
+                }
+              } else if (sweep_real) {
                 if (R.real) {
                   const float* rp = R.r.p;
                   const bool have = pf_row == i;
@@ -1191,11 +1503,13 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                   const int js = W.cols[shi + q];
                   W.cols[k] = js; W.inv[js] = k;
                   W.cols[shi + q] = j; W.inv[j] = static_cast<int>(shi) + q;
+                  if (use_rl) W.fsw[kFsTodo + (j >> 5)] = static_cast<int>(W.fsw[kFsTodo + (j >> 5)]) & ~(1 << (j & 31));
                 }
               }
             }
             shi += static_cast<unsigned>(nt);
             g.sync();
+            cy_seq += MOT_CLOCK() - qs0;
             if (!fetched && slo != shi) member(slo);  // the SCAN set was empty until this sweep's ties joined it
           }
           if (!returned) { lo = slo; hi = shi; }
@@ -1232,6 +1546,9 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     const long long c4 = MOT_CLOCK();
     W.cyc[0] = c1 - c0; W.cyc[1] = c2 - c1; W.cyc[2] = c3 - c2; W.cyc[3] = c4 - c3;
     W.cyc[4] = n_uniq; W.cyc[5] = n_carr; W.cyc[6] = n_paths; W.cyc[7] = n;
+    W.cyc[8] = n_fs_steps; W.cyc[9] = n_fs_members; W.cyc[10] = n_fs_sparse; W.cyc[11] = n_fs_events; W.cyc[12] = n_seq_sweeps; W.cyc[13] = n_fs_bad;
+    W.cyc[14] = n_finds; W.cyc[15] = use_rl ? 1 : 0;
+    if (W.cyc_ext) { W.cyc[16] = cy_cls; W.cyc[17] = cy_dry; W.cyc[18] = cy_apply; W.cyc[19] = cy_evsort; W.cyc[20] = cy_evser; W.cyc[21] = cy_find; W.cyc[22] = cy_seq; W.cyc[23] = cy_init; }
   }
 }
 

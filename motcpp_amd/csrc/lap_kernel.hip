@@ -29,6 +29,7 @@
 namespace {
 
 constexpr int kScratch = 1024;  // DevGroup reduction scratch: 2 halves x 16 wavefronts x 32 bytes
+constexpr int kFsLds = (mot::kFsWsInts * 4 + 15) & ~15;  // fast scratch of the parallel scan steps (matrix-cost launches only)
 constexpr int kLdsBudget = 160 * 1024;
 
 template <int kThreads, class Cost, class Work>
@@ -95,7 +96,7 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
   return path;
 }
 
-// lds_mode 3 = lean: duals v[] and y[] in LDS, everything else (x, free list, boxes) in global scratch / L2 —
+// lds_mode 4 = lean + d[] in LDS (20 B per extended row). lds_mode 3 = lean: duals v[] and y[] in LDS, everything else (x, free list, boxes) in global scratch / L2 —
 // 12 B of LDS per extended row, so ~8 north-star-sized problems stay resident per CU.
 // lds_mode (compile-time, so every pointer has a static address space — a run-time choice makes the compiler fall back
 // to flat_* instructions for the LDS state, which costs hundreds of cycles per dependent access): 0 = solver state in global scratch, 1 = hot state + column boxes in LDS (row boxes
@@ -105,7 +106,7 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
 constexpr int lap_min_waves(int threads, int rpl, bool general) { return (threads > 64 || general) ? 1 : (rpl >= 8 ? 2 : (rpl >= 4 ? 3 : 4)); }
 // FLAVOR of the on-the-fly cost: 0 plain IoU modes only, 1 + BoT-SORT's gated appearance term, 2 every association measure
 template <int kThreads, int lds_mode, int RPL, int FLAVOR>
-__device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status) {
+__device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status, int fs_lds) {
   constexpr bool GENERAL = FLAVOR == 2;
   constexpr bool PLAIN = FLAVOR == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -134,16 +135,24 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status)
   constexpr int kVS = (lds_mode == 0) ? mot::kMemGlobal : mot::kMemLds;  // v, y
   constexpr int kXS = (lds_mode == 2) ? mot::kMemLds : mot::kMemGlobal;  // x, free list
   constexpr int kRS = (lds_mode == 2) ? mot::kMemLds : mot::kMemGlobal;  // row boxes
-  mot::LapWorkT<kVS, kXS> W;
+  constexpr int kDS = (lds_mode == 4) ? mot::kMemLds : mot::kMemGlobal;  // shortest-path distances
+  mot::LapWorkT<kVS, kXS, kDS> W;
   char* lds = smem + kScratch;
+  if (fs_lds) {  // the launch reserved the fast scratch: row lists are usable by the tasks that bring the memory for them
+    if (T.rowlist != nullptr && T.geom.a == nullptr) { mot::lap_carve_rowlist(W, T.rowlist, nr); W.fsw.p = reinterpret_cast<int*>(lds); }
+    lds += kFsLds;
+  }
   if constexpr (lds_mode == 2) { mot::lap_carve_hot(W, lds, n); lds += hot_b; }
   else mot::lap_carve_hot(W, gw, n);
-  if constexpr (lds_mode == 3) {  // lean: only the per-column duals and column->row map in LDS (12 B per extended row)
+  if constexpr (lds_mode == 3 || lds_mode == 4) {  // lean: only the per-column duals and column->row map in LDS (12 B per extended row)
     W.v.p = reinterpret_cast<double*>(lds);
     W.y.p = reinterpret_cast<int*>(lds + sizeof(double) * static_cast<size_t>(n));
   }
   mot::lap_carve_cold(W, gw + hot_b, n);
+  if constexpr (lds_mode == 4)  // + the distances of the shortest-path search (wide matrix problems: every scan step reads and writes them)
+    W.d.p = reinterpret_cast<double*>(lds + ((12 * static_cast<size_t>(n) + 15) & ~size_t(15)));
   W.cyc = T.prof;
+  W.cyc_ext = true;  // (mot_lap_task.prof holds 24 entries)
   int path;
   if (T.geom.a != nullptr) {
     float* gbox = reinterpret_cast<float*>(gw + hot_b + cold_b);
@@ -187,13 +196,13 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status)
 }
 
 template <int kThreads, int lds_mode, int RPL, int FLAVOR>
-__global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR == 2)) lap_kernel(const mot_lap_task* __restrict__ tasks, int ntasks, int check_status, const int* declined) {
+__global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR == 2)) lap_kernel(const mot_lap_task* __restrict__ tasks, int ntasks, int check_status, const int* declined, int fs_lds) {
   // behind the fast path: its count of declined problems; usually zero, and then there is nothing to look for
   if (check_status && declined != nullptr && *declined == 0) return;
   // behind the fast path the grid is smaller than the task array: a block walks its share of it and solves what is left
   for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
     const mot_lap_task T = tasks[task];
-    lap_one<kThreads, lds_mode, RPL, FLAVOR>(T, check_status);
+    lap_one<kThreads, lds_mode, RPL, FLAVOR>(T, check_status, fs_lds);
     if (task + static_cast<int>(gridDim.x) < ntasks) __syncthreads();  // the LDS state of this problem is dead before the next one starts
   }
 }
@@ -202,6 +211,7 @@ __global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR 
 
 namespace mot {
 size_t lap_scratch_bytes(int n, int m) { return lap_task_scratch_bytes(n, m); }
+size_t lap_rowlist_scratch_bytes(int n) { return lap_rowlist_bytes(n); }
 hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool plain_costs, int* declined, hipStream_t st,
                              int hint_n, int hint_m);
 
@@ -243,15 +253,19 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   }
   const size_t n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1, nm = n + m;
   const size_t hot = (lap_hot_bytes(nm) + 15) & ~size_t(15);
-  const size_t b2 = kScratch + hot + (geom ? 20 * n + 16 : 0);  // full hot state (+ row boxes) in LDS
-  const size_t b3 = kScratch + 12 * nm + 16;                    // lean: duals + y
+  const int fs_lds = (!geom && n * m >= 16384) ? 1 : 0;  // matrix costs of some size: room for the parallel scan steps' scratch
+  const size_t fsb = fs_lds ? kFsLds : 0;
+  const size_t b2 = kScratch + fsb + hot + (geom ? 20 * n + 16 : 0);  // full hot state (+ row boxes) in LDS
+  const size_t b3 = kScratch + fsb + 12 * nm + 16;                    // lean: duals + y
+  const size_t b4 = kScratch + fsb + 20 * nm + 32;                    // lean + distances
   int mode;
   size_t lds;
   if (b2 <= 18 * 1024) { mode = 2; lds = b2; }             // >= 8 problems per CU
   else if (b3 <= 40 * 1024) { mode = 3; lds = b3; }        // >= 4 (north-star: 8) problems per CU
   else if (b2 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 2; lds = b2; }
-  else { mode = 0; lds = kScratch; }
+  else { mode = 0; lds = kScratch + fsb; }
   const bool wide = (nm > 3072) && (ntasks < 512);
+  if (fs_lds && wide && b4 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 4; lds = b4; }
   // lane-owned column boxes in registers: one wavefront per problem, <= 8 real columns per lane
   int rpl = 0;
   if (geom && !wide && !general_assoc) rpl = (m <= 256) ? 4 : (m <= 512 ? 8 : 0);
@@ -265,7 +279,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   const int grid = (fast && ntasks > 512) ? 512 : ntasks;
 #define MOT_LAP_VARIANTS(X) X(64, 0, 0, 1) X(64, 2, 0, 1) X(64, 3, 0, 1) X(64, 0, 4, 1) X(64, 2, 4, 1) X(64, 3, 4, 1) \
                             X(64, 0, 8, 1) X(64, 2, 8, 1) X(64, 3, 8, 1) X(256, 0, 0, 1) X(256, 2, 0, 1) X(256, 3, 0, 1) \
-                            X(512, 0, 0, 1) X(512, 2, 0, 1) X(512, 3, 0, 1) \
+                            X(512, 0, 0, 1) X(512, 2, 0, 1) X(512, 3, 0, 1) X(512, 4, 0, 1) X(256, 4, 0, 1) \
                             X(64, 0, 4, 0) X(64, 2, 4, 0) X(64, 3, 4, 0) X(64, 0, 8, 0) X(64, 2, 8, 0) X(64, 3, 8, 0) \
                             X(64, 0, 0, 2) X(64, 2, 0, 2) X(64, 3, 0, 2) X(256, 0, 0, 2) X(256, 2, 0, 2) X(256, 3, 0, 2)
   // plain-cost variants exist for the register-cached column layouts only (the hot ones)
@@ -284,11 +298,12 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   // part of a sweep is paid by every wavefront, and 16 of them leave 128 VGPRs each. MOT_LAP_WIDE8=0 switches it off.
   static const bool wide8_ok = !(std::getenv("MOT_LAP_WIDE8") && std::getenv("MOT_LAP_WIDE8")[0] == '0');
   const bool wide8 = wide && wide8_ok && ntasks <= 256 && flavor == 1;
-  const int threads = wide8 ? 512 : (wide ? 256 : 64);
+  static const int wide_t = std::getenv("MOT_LAP_WIDE_T") ? std::atoi(std::getenv("MOT_LAP_WIDE_T")) : 0;  // (experiments)
+  const int threads = (wide && flavor == 1 && (wide_t == 256 || wide_t == 512)) ? wide_t : (wide8 ? 512 : (wide ? 256 : 64));
   bool launched = false;
 #define MOT_TRY(T, M, R, G)                                                                                \
   if (!launched && threads == T && mode == M && rpl == R && flavor == G) {                                 \
-    hipLaunchKernelGGL((lap_kernel<T, M, R, G>), dim3(grid), dim3(T), lds, st, tasks, ntasks, fast ? 1 : 0, declined); \
+    hipLaunchKernelGGL((lap_kernel<T, M, R, G>), dim3(grid), dim3(T), lds, st, tasks, ntasks, fast ? 1 : 0, declined, fs_lds); \
     launched = true;                                                                                       \
   }
   MOT_LAP_VARIANTS(MOT_TRY)

@@ -18,6 +18,7 @@ hipError_t launch_iou(const mot_iou_task*, int, int, int, bool, hipStream_t);
 // solver sizes its LDS with them (more problems per CU) and leaves a problem that exceeds them to the exact solver
 hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, bool, hipStream_t, int hint_n = 0, int hint_m = 0);
 size_t lap_scratch_bytes(int n, int m);
+size_t lap_rowlist_scratch_bytes(int n);
 
 namespace lifecycle {
 

@@ -36,8 +36,50 @@ MOT_DEV void mem_store(T* p, T v) { *p = v; }
 template <class T>
 MOT_DEV T gld(const T* p, size_t i) { return mem_load<kMemGlobal>(p + i); }
 
+template <int AS>
+struct mem_atomic {
+#if defined(__HIP_DEVICE_COMPILE__)
+  template <class T> static MOT_DEV T add(T* q, T v) {
+    if constexpr (AS == kMemLds) return __hip_atomic_fetch_add((MOT_AS(3) T*)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if constexpr (AS == kMemGlobal) return __hip_atomic_fetch_add((MOT_AS(1) T*)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return __hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  template <class T> static MOT_DEV T min(T* q, T v) {
+    if constexpr (AS == kMemLds) return __hip_atomic_fetch_min((MOT_AS(3) T*)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if constexpr (AS == kMemGlobal) return __hip_atomic_fetch_min((MOT_AS(1) T*)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return __hip_atomic_fetch_min(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  template <class T> static MOT_DEV T band(T* q, T v) {
+    if constexpr (AS == kMemLds) return __hip_atomic_fetch_and((MOT_AS(3) T*)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if constexpr (AS == kMemGlobal) return __hip_atomic_fetch_and((MOT_AS(1) T*)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return __hip_atomic_fetch_and(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  template <class T> static MOT_DEV T cas(T* q, T expect, T v) {
+    if constexpr (AS == kMemLds) __hip_atomic_compare_exchange_strong((MOT_AS(3) T*)q, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if constexpr (AS == kMemGlobal) __hip_atomic_compare_exchange_strong((MOT_AS(1) T*)q, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_compare_exchange_strong(q, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return expect;
+  }
+#else
+  template <class T> static MOT_DEV T add(T* q, T v) { return __atomic_fetch_add(q, v, __ATOMIC_RELAXED); }
+  template <class T> static MOT_DEV T min(T* q, T v) {
+    T cur = __atomic_load_n(q, __ATOMIC_RELAXED);
+    while (cur > v && !__atomic_compare_exchange_n(q, &cur, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return cur;
+  }
+  template <class T> static MOT_DEV T band(T* q, T v) { return __atomic_fetch_and(q, v, __ATOMIC_RELAXED); }
+  template <class T> static MOT_DEV T cas(T* q, T expect, T v) { __atomic_compare_exchange_n(q, &expect, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); return expect; }
+#endif
+};
+// minimum of NON-NEGATIVE doubles (no -0.0, no NaN): their bit patterns order like the values, one 64-bit integer atomic does it
+template <int AS>
+MOT_DEV void mem_atomic_min_f64_nonneg(double* q, double v) {
+  mem_atomic<AS>::min(reinterpret_cast<long long*>(q), __builtin_bit_cast(long long, v));
+}
+
 template <class T, int AS>
 struct MemPtr {
+  static constexpr int kSpace = AS;
   T* p = nullptr;
   struct Ref {
     T* q;
@@ -49,6 +91,12 @@ struct MemPtr {
   };
   MOT_DEV Ref operator[](long i) const { return Ref{p + i}; }
   MOT_DEV T* raw(long i = 0) const { return p + i; }  // for atomics
+  // atomics in the pointer's own address space (ds_* / global_* instead of flat_*); relaxed, workgroup scope: the callers
+  // order them with the group's barriers
+  MOT_DEV T atomic_add(long i, T v) const { return mem_atomic<AS>::add(p + i, v); }
+  MOT_DEV T atomic_min(long i, T v) const { return mem_atomic<AS>::min(p + i, v); }
+  MOT_DEV T atomic_and(long i, T v) const { return mem_atomic<AS>::band(p + i, v); }
+  MOT_DEV T atomic_cas(long i, T expect, T v) const { return mem_atomic<AS>::cas(p + i, expect, v); }  // returns the old value
 };
 
 }  // namespace mot

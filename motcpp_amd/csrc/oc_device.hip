@@ -603,7 +603,8 @@ int mot_oc_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   const size_t wb1 = (mot::lap_scratch_bytes(D, CAP) + 255) & ~size_t(255);      // rows = detections, columns = tracks
   const size_t wbb = (mot::lap_scratch_bytes(D, UMT) + 255) & ~size_t(255);      // BYTE: low detections x the unmatched-track list
   const size_t wbr = (mot::lap_scratch_bytes(UMD, UMT) + 255) & ~size_t(255);    // OCR: the unmatched lists with repeats
-  const size_t wall = wb1 + wbb + wbr;
+  const size_t wrl = (mot::lap_rowlist_scratch_bytes(D) + 255) & ~size_t(255);   // first association: per-detection lists of the costs below thresh/2
+  const size_t wall = wb1 + wbb + wbr + wrl;
   char* work = b->dalloc<char>(wall * S);
   if (!ip || !fp || !bp || !clamp || !b->mean || !mats || !b->d_streams || !b->d_counts || !b->d_err || !b->d_maxt || !b->d_stats || !b->d_out ||
       !b->d_out_counts || !b->d_offsets || !T.det || !T.pred || !T.init || !T.upd || !T.sbox || !T.cost || !T.lap1 || !T.lapb || !T.lapr || !work) {
@@ -668,7 +669,7 @@ int mot_oc_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
     mot_lap_task& L1 = lap1[s];
     std::memset(&L1, 0, sizeof(L1));
     L1.cost = cmat; L1.ldc = ldc; L1.thresh = -P.thr; L1.x = Z.x1; L1.mode = MOT_LAP_OCSORT; L1.iou = imat; L1.ldi = ldc; L1.gate = P.thr;
-    L1.xval = Z.xval1; L1.info = Z.info1; L1.work = work + wall * s;
+    L1.xval = Z.xval1; L1.info = Z.info1; L1.work = work + wall * s; L1.rowlist = work + wall * s + wb1 + wbb + wbr;
     auto geom = [&](mot_lap_task& L, int* x, float* xval, int* info, char* w, const int* aidx, const float* bbox, int ldb, const int* bidx) {
       std::memset(&L, 0, sizeof(L));
       L.x = x; L.thresh = -P.thr; L.mode = MOT_LAP_GATE_MIN; L.gate = -P.thr; L.xval = xval; L.info = info; L.work = w;

@@ -121,6 +121,12 @@ struct EmuGroup {
     int cur = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (cur > v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   }
+  static void atomic_min_f64_nonneg(double* p, double v) {
+    long long* q = reinterpret_cast<long long*>(p);
+    const long long nv = __builtin_bit_cast(long long, v);
+    long long cur = __atomic_load_n(q, __ATOMIC_RELAXED);
+    while (cur > nv && !__atomic_compare_exchange_n(q, &cur, nv, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  }
   static void atomic_or(int* p, int v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
   static void atomic_and(int* p, int v) { __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
 };

@@ -1,5 +1,6 @@
 // TEST HARNESS ONLY — runs motcpp_amd/csrc/lap_core.hpp (the exact algorithm the gfx950 kernel
 // executes) on T host threads so its decisions can be compared with the oracle without a GPU.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -10,11 +11,17 @@
 #include "../../motcpp_amd/csrc/lap_cost.hpp"
 #include "../../motcpp_amd/csrc/lap_sparse.hpp"
 
-extern "C" int emu_lap(const float* cost, int nr, int nc, int ld, float thresh, int T, int* x, int* y) {
+// rowlists != 0: with the optional per-row lists of the entries below thresh/2 (mot_lap_task.rowlist) and the fast scratch
+// the kernel keeps in LDS — the parallel scan steps and sparse real-row sweeps of the shortest-path search
+extern "C" int emu_lap_rl(const float* cost, int nr, int nc, int ld, float thresh, int T, int rowlists, int* x, int* y) {
   using namespace mot;
   const int n = nr + nc;
-  std::vector<char> mem(lap_work_bytes(n) + 64);
+  std::vector<char> mem(lap_work_bytes(n) + 64), rl(lap_rowlist_bytes(nr) + 64);
+  std::vector<int> fsw(kFsWsInts);
   LapWork W = lap_carve(mem.data(), n);
+  if (rowlists) { lap_carve_rowlist(W, rl.data(), nr); W.fsw.p = fsw.data(); }
+  long long cyc[16] = {0};
+  W.cyc = cyc;
   const MatrixCost C{cost, ld};
   const LapDims P{nr, nc, static_cast<double>(thresh) / 2.0};
   EmuShared sh(T);
@@ -24,7 +31,13 @@ extern "C" int emu_lap(const float* cost, int nr, int nc, int ld, float thresh, 
   for (auto& t : th) t.join();
   for (int i = 0; i < nr; ++i) x[i] = (W.x[i] >= nc) ? -1 : W.x[i];
   for (int j = 0; j < nc; ++j) y[j] = (W.y[j] >= nr) ? -1 : W.y[j];
+  if (std::getenv("MOT_EMU_LAP_STATS"))
+    std::fprintf(stderr, "emu_lap %dx%d T %d: paths %lld finds %lld | steps %lld members %lld real %lld events %lld | one-at-a-time %lld refused %lld lists %lld\n", nr, nc, T,
+                 cyc[6], cyc[14], cyc[8], cyc[9], cyc[10], cyc[11], cyc[12], cyc[13], cyc[15]);
   return 0;
+}
+extern "C" int emu_lap(const float* cost, int nr, int nc, int ld, float thresh, int T, int* x, int* y) {
+  return emu_lap_rl(cost, nr, nc, ld, thresh, T, 0, x, y);
 }
 
 // same solver with the on-the-fly IoU-family cost functor (row boxes a: nr x 4, column boxes b: nc x 4, row-major);

@@ -160,3 +160,75 @@ def test_sparse_column_minima_make_the_same_decisions(orc, emu_iou):
             assert (xo == xe).all() and (yo == ye).all(), (trial, n, m, mode, rpl)
             cases += 1
     assert cases == 240
+
+
+# ---- row lists: the parallel scan steps + sparse real-row sweeps of the shortest-path search (mot_lap_task.rowlist) ----
+@pytest.fixture(scope="module", params=[False, True], ids=["serial_replay", "closed_form_tie_runs"])
+def emu_rl(request):
+    lib = C.CDLL(build_lap_emu(request.param))
+
+    def run(cost, th, T, rowlists=1):
+        cost = np.ascontiguousarray(cost, np.float32)
+        n, m = cost.shape
+        x, y = np.zeros(n, np.int32), np.zeros(m, np.int32)
+        lib.emu_lap_rl(cost.ctypes.data_as(C.c_void_p), n, m, m, C.c_float(th), T, rowlists, x.ctypes.data_as(C.c_void_p),
+                       y.ctypes.data_as(C.c_void_p))
+        return x, y
+    return run
+
+
+@pytest.mark.parametrize("kind", ["dense", "dense_forced", "neg", "quant", "quant_forced", "const", "sparse"])
+def test_row_lists_generic_costs(orc, emu_rl, kind):
+    # every cost family of the plain test above, now with the row lists in use: short lists, lists that overflow (rows of
+    # `neg` / `dense_forced` have most entries below thresh/2 once m > 64), exact ties (events on every step), T = 8 (one
+    # real row per step) and 16
+    r = np.random.default_rng(hash(kind) % 997)
+    for n, m in [(9, 17), (64, 40), (100, 130), (130, 60)]:
+        for T in (8, 16):
+            c, th = gen(r, kind, n, m)
+            xo, yo = orc.linear_assignment(c, th)
+            xe, ye = emu_rl(c, th, T)
+            assert (xo == xe).all() and (yo == ye).all(), (kind, n, m, T)
+
+
+def ocsort_like_problems(orc, P, M, frames, seed, tmp_path):
+    """First-association and rematch problems of an OC-SORT run of the oracle on a world as crowded as BASELINE config C4
+    (4096 objects on 1920 x 1080: every box overlaps a dozen others; quirk Q4 leaves exactly duplicated tracks)."""
+    import os
+    import motcpp_amd.synth as sy
+    from tests import orclib
+    sc = (P / 4096.0) ** 0.5
+    w0, h0 = sy.W, sy.H
+    os.environ["ORC_LAP_DUMP"] = str(tmp_path)
+    try:
+        sy.W, sy.H = 1920.0 * sc, 1080.0 * sc
+        trk = orc.tracker(orclib.OCSORT)
+        s = sy.SynthStream(P, M, seed)
+        for _ in range(frames):
+            d, _e = s.next_frame()
+            trk.update(d)
+    finally:
+        sy.W, sy.H = w0, h0
+        del os.environ["ORC_LAP_DUMP"]
+    out = []
+    for f in sorted(os.listdir(tmp_path)):
+        nr, nc = map(int, f[:-4].split("_")[-1].split("x"))
+        raw = np.fromfile(os.path.join(tmp_path, f), np.float32)
+        out.append((float(raw[0]), raw[1:].reshape(nr, nc).copy()))
+    return out
+
+
+def test_row_lists_ocsort_crowded_scene(orc, emu_rl, tmp_path):
+    probs = ocsort_like_problems(orc, 160, 80, 8, 5, tmp_path)
+    assert len(probs) >= 10
+    dup = 0
+    for th, c in probs:
+        if c.shape[1] > 1:
+            dup += int(len({c[:, j].tobytes() for j in range(c.shape[1])}) < c.shape[1])
+        xo, yo = orc.linear_assignment(c, th)
+        for T in (8, 64):
+            xe, ye = emu_rl(c, th, T)
+            assert (xo == xe).all() and (yo == ye).all(), (c.shape, T)
+        xe, ye = emu_rl(c, th, 16, 0)  # and without the lists: the dense sweeps
+        assert (xo == xe).all() and (yo == ye).all(), c.shape
+    assert dup >= 2  # problems with exactly duplicated tracks (quirk Q4) are among them

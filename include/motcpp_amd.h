@@ -285,7 +285,7 @@ typedef struct mot_lap_task {
    * column boxes with mot_iou_cost's arithmetic for geom.mode (cost, ldc are ignored; geom.cost/pairs unused): the
    * N x M matrix is never materialised. geom.emb (BOTSORT) is still read from memory, for overlapping pairs only. */
   mot_iou_task geom;
-  long long* prof; /* optional out [24]: shader cycles per solver phase, pass counts, shortest-path scan counters and cycles (diagnostics) */
+  long long* prof; /* optional out [36]: shader cycles per solver phase, pass counts, shortest-path scan counters and cycles (diagnostics) */
   void* rowlist;   /* optional scratch of mot_lap_rowlist_bytes(n) bytes for a task with a cost MATRIX (geom.a == NULL): the exact
                     * solver gathers, per row, the entries below thresh/2 there and runs lapjv's shortest-path scans over those
                     * lists (many SCAN members per step) instead of one dense row sweep per member — same decisions, proved in

@@ -176,7 +176,7 @@ class Context:
         x, y = np.full(max(n, 1), -1, np.int32), np.full(max(m, 1), -1, np.int32)
         xv = np.zeros(max(n, 1), np.float32)
         info = C.c_int(0)
-        self._prof = np.zeros(24, np.int64)
+        self._prof = np.zeros(36, np.int64)
         c = f32(conf) if conf is not None else None
         self._chk(self.lib.mot_lap_geom_host(self.h, _p(a), n, _p(b), m, _p(c) if c is not None else None, int(cost_mode),
                                              C.c_float(thresh), int(lap_mode), C.c_float(gate), _p(x), _p(y), _p(xv), C.byref(info),

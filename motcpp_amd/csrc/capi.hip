@@ -324,8 +324,8 @@ int mot_lap_solve_prof_host(mot_ctx* c, const float* cost, int n, int m, float t
   t.work = dwork.p;
   t.rowlist = drl.p;
   if (prof8) {  // per-phase shader cycles of the exact solver (the sparse solver leaves a task that asks for them alone)
-    MOT_HIP(c, dprof.alloc(192));
-    MOT_HIP(c, hipMemsetAsync(dprof.p, 0, 192, c->stream));
+    MOT_HIP(c, dprof.alloc(288));
+    MOT_HIP(c, hipMemsetAsync(dprof.p, 0, 288, c->stream));
     t.prof = dprof.as<long long>();
   }
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
@@ -334,7 +334,7 @@ int mot_lap_solve_prof_host(mot_ctx* c, const float* cost, int n, int m, float t
   MOT_HIP(c, hipMemcpyAsync(y, dy.p, m * 4, hipMemcpyDeviceToHost, c->stream));
   int inf = 0;
   MOT_HIP(c, hipMemcpyAsync(&inf, dinfo.p, 4, hipMemcpyDeviceToHost, c->stream));
-  if (prof8) MOT_HIP(c, hipMemcpyAsync(prof8, dprof.p, 192, hipMemcpyDeviceToHost, c->stream));
+  if (prof8) MOT_HIP(c, hipMemcpyAsync(prof8, dprof.p, 288, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   if (info) *info = inf;
   return MOT_OK;
@@ -362,8 +362,8 @@ int mot_lap_geom_host(mot_ctx* c, const float* a, int n, const float* b, int m, 
   t.n = n; t.m = m; t.thresh = thresh; t.x = dx.as<int>(); t.y = dy.as<int>(); t.mode = lap_mode; t.gate = gate;
   t.xval = dv.as<float>(); t.info = dinfo.as<int>(); t.work = dwork.p;
   DBuf dprof;
-  MOT_HIP(c, dprof.alloc(192));
-  MOT_HIP(c, hipMemsetAsync(dprof.p, 0, 192, c->stream));
+  MOT_HIP(c, dprof.alloc(288));
+  MOT_HIP(c, hipMemsetAsync(dprof.p, 0, 288, c->stream));
   t.prof = prof8 ? dprof.as<long long>() : nullptr;
   t.geom.n = n; t.geom.m = m; t.geom.a = da.as<float>(); t.geom.lda = n; t.geom.b = db.as<float>(); t.geom.ldb = m;
   t.geom.bconf = bconf ? dc.as<float>() : nullptr; t.geom.mode = cost_mode;
@@ -375,7 +375,7 @@ int mot_lap_geom_host(mot_ctx* c, const float* a, int n, const float* b, int m, 
   int inf = 0;
   MOT_HIP(c, hipMemcpyAsync(hv.data(), dv.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(&inf, dinfo.p, 4, hipMemcpyDeviceToHost, c->stream));
-  if (prof8) MOT_HIP(c, hipMemcpyAsync(prof8, dprof.p, 192, hipMemcpyDeviceToHost, c->stream));
+  if (prof8) MOT_HIP(c, hipMemcpyAsync(prof8, dprof.p, 288, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   if (xval) for (int i = 0; i < n; ++i) xval[i] = hv[i];
   if (info) *info = inf;

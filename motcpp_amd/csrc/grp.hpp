@@ -51,6 +51,14 @@ struct DevGroup {
   __device__ __forceinline__ int tid() const { return tid_; }
   __device__ __forceinline__ int size() const { return size_; }
   __device__ __forceinline__ void sync() { __syncthreads(); }
+  // Barrier that orders LDS traffic only: global loads and stores of the wavefront stay in flight across it (a __syncthreads()
+  // waits for every outstanding memory operation — a global round trip whenever a store or a prefetch is pending). The data
+  // handed from lane to lane across such a barrier must live in LDS.
+  __device__ __forceinline__ void sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  // while set, the barriers INSIDE the reductions / scans below (which exchange their partials through LDS) are of that kind too
+  bool lds_only_ = false;
+  __device__ __forceinline__ void lds_barriers(bool on) { lds_only_ = on; }
+  __device__ __forceinline__ void barrier_() { if (lds_only_) sync_lds(); else __syncthreads(); }
   // Every wavefront of the group can keep a 64-entry table with one entry per lane and read entry `src` (the same for all lanes)
   // with v_readlane: lap_core.hpp's window of upcoming SCAN members. Groups without wavefronts (tests/emu) do not define it.
   static constexpr bool kWaveTable = true;
@@ -120,7 +128,7 @@ struct DevGroup {
     if (nw == 1) return v;
     double* s = slot<double>();
     if ((tid_ & 63) == 0) s[tid_ >> 6] = v;
-    __syncthreads();
+    barrier_();
     double r = s[0];
     for (int w = 1; w < nw; ++w) { double o = s[w]; r = (o < r) ? o : r; }
     return r;
@@ -131,7 +139,7 @@ struct DevGroup {
     if (nw == 1) return v;
     float* s = slot<float>();
     if ((tid_ & 63) == 0) s[tid_ >> 6] = v;
-    __syncthreads();
+    barrier_();
     float r = s[0];
     for (int w = 1; w < nw; ++w) { float o = s[w]; r = (o < r) ? o : r; }
     return r;
@@ -142,7 +150,7 @@ struct DevGroup {
     if (nw == 1) return v;
     int* s = slot<int>();
     if ((tid_ & 63) == 0) s[tid_ >> 6] = v;
-    __syncthreads();
+    barrier_();
     int r = s[0];
     for (int w = 1; w < nw; ++w) { int o = s[w]; r = (o > r) ? o : r; }
     return r;
@@ -161,7 +169,7 @@ struct DevGroup {
     if (nw == 1) return t;
     Top2* s = slot<Top2>();
     if ((tid_ & 63) == 0) s[tid_ >> 6] = t;
-    __syncthreads();
+    barrier_();
     Top2 r = s[0];
     for (int w = 1; w < nw; ++w) r = top2_merge(r, s[w]);
     return r;
@@ -185,7 +193,7 @@ struct DevGroup {
     if (nw > 1) {
       double* s = slot<double>();
       if (lane == 63) s[tid_ >> 6] = inc;
-      __syncthreads();
+      barrier_();
       for (int w = 0; w < (tid_ >> 6); ++w) { const double o = s[w]; if (o < ex) ex = o; }
     }
     return ex;
@@ -199,7 +207,7 @@ struct DevGroup {
     const int nw = (size_ + 63) >> 6;
     int* s = slot<int>();
     if (lane == 63 || tid_ == size_ - 1) s[tid_ >> 6] = inc;
-    __syncthreads();
+    barrier_();
     int base = 0, tot = 0;
     for (int w = 0; w < nw; ++w) { int c = s[w]; if (w < (tid_ >> 6)) base += c; tot += c; }
     *total = tot;
@@ -212,7 +220,35 @@ struct DevGroup {
       *total = __builtin_popcountll(m);
       return __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0u));
     }
-    return exclusive_scan(flag ? 1 : 0, total);
+    // several wavefronts: rank inside the wavefront from the ballot (mbcnt), the wavefronts' counts meet in LDS — no shuffles
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+    const int in_wave = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0u));
+    const int nw = (size_ + 63) >> 6;
+    int* s = slot<int>();
+    if ((tid_ & 63) == 0) s[tid_ >> 6] = __builtin_popcountll(m);
+    barrier_();
+    int base = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) { const int c = s[w]; if (w < (tid_ >> 6)) base += c; tot += c; }
+    *total = tot;
+    return base + in_wave;
+  }
+  // sum of one int per thread (DPP inside the wavefront: lanes without a source add 0)
+  static __device__ __forceinline__ int wave_sum_i32(int v) {
+#define MOT_STEP(C, M) { v += __builtin_amdgcn_update_dpp(0, v, C, M, 0xf, false); }
+    MOT_DPP_STEPS(MOT_STEP)
+#undef MOT_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+  }
+  __device__ __forceinline__ int reduce_sum(int v) {
+    v = wave_sum_i32(v);
+    const int nw = (size_ + 63) >> 6;
+    if (nw == 1) return v;
+    int* s = slot<int>();
+    if ((tid_ & 63) == 0) s[tid_ >> 6] = v;
+    barrier_();
+    int r = s[0];
+    for (int w = 1; w < nw; ++w) r += s[w];
+    return r;
   }
   // single-wavefront groups only: mask of the lanes whose flag is set, a lane's value for everyone, a value pushed to a lane
   __device__ __forceinline__ unsigned long long ballot(bool flag) { return __builtin_amdgcn_ballot_w64(flag); }

@@ -31,6 +31,13 @@
 #else
 #define MOT_CLOCK() 0LL
 #endif
+// clock reads inside the shortest-path search (several per scan step; each is a scalar memory operation the wavefront waits
+// for): only in builds made with -DMOT_LAP_FINE_PROF
+#if defined(MOT_LAP_FINE_PROF)
+#define MOT_FCLOCK() MOT_CLOCK()
+#else
+#define MOT_FCLOCK() 0LL
+#endif
 
 namespace mot {
 
@@ -86,18 +93,19 @@ struct LapWorkT {
   MemPtr<double, kMemGlobal> rlb; // per real row: minimum raw cost over the real columns (phase 1), see "hopeless rows"
   MemPtr<int, kMemGlobal> inv;    // inverse of cols[] (position of a column), slow path
   MemPtr<int, kMemGlobal> tie;    // tie flags by position during a scan (all zero between scans), slow path
+  MemPtr<int, kMemGlobal> sa, sb, sc;  // staging of the closed-form tie runs that do not fit in registers (slow path)
   // optional (null: the parallel scan steps and the sparse real-row sweeps are off) — see "row lists" in lap_solve
   MemPtr<int, kMemGlobal> rl_cnt;     // [nr] entries of real row i with cost < half (may exceed kRlCap: then the row has no usable list)
   MemPtr<int, kMemGlobal> rl_col;     // [nr][kRlCap] their columns ...
   MemPtr<float, kMemGlobal> rl_cost;  // ... and costs
   MemPtr<int, VS == kMemAny ? kMemAny : kMemLds> fsw;  // kFsWsInts ints of fast scratch (always LDS on the device): step members + tie events
-  bool cyc_ext = false;      // cyc has 24 entries: [16..23] cycles inside phase 3 (step classification, dry run, apply, event sort, event replay, _find_dense, one-at-a-time sweeps, search set-up)
+  bool cyc_ext = false;      // cyc has 36 entries: [16..23] cycles inside phase 3 (step classification, dry run, apply, event sort, event replay, _find_dense, one-at-a-time sweeps, search set-up)
   long long* cyc = nullptr;  // optional profiling [16]: [0..3] cycles in phase 1a (column minima), 1b (transfer), 2, 3; [4..7] n_uniq, serial row-reduction rounds, serial augmentations, n;
                              // [8..15] shortest-path scans: parallel steps, members they consumed, real rows among them, tie events, one-at-a-time sweeps, steps refused (rounding), _find_dense calls, row lists in use
 };
 using LapWork = LapWorkT<kMemAny, kMemAny, kMemAny>;
 MOT_HD size_t lap_hot_bytes(int n) { return static_cast<size_t>(n) * (sizeof(double) + 3 * sizeof(int)); }
-MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 6 * sizeof(int)); }
+MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 9 * sizeof(int)); }
 // Row lists (optional scratch of a matrix-cost task, mot_lap_task.rowlist): per real row the entries below thresh/2.
 constexpr int kRlCap = 64;      // entries kept per row (a row with more has no list: its sweeps stay dense)
 constexpr int kFsIter = 8;      // list entries a lane holds in registers during a parallel scan step
@@ -107,9 +115,9 @@ constexpr int kKeepCap = 512;   // relaxations of one step that lower a distance
 constexpr int kFsHash = 1024;   // slots of the per-step column table (>= 2 * kKeepCap, a power of two)
 constexpr int kFsMaxN = 8192;   // extended size up to which the TODO bitmask fits
 // fast scratch (ints): members (q, row, list length, h as 2 ints) | counters | column table of a step (key, earliest member) |
-// event list (q, j, k) | sorted events (q, j, k, flags) + head slots (column, event) | TODO bitmask
-constexpr int kFsM = 0, kFsCtr = 5 * kFsMaxMembers, kFsKeep = kFsCtr + 8, kFsEvl = kFsKeep + 2 * kFsHash, kFsEvs = kFsEvl + 3 * kEvCap,
-              kFsTodo = kFsEvs + 6 * kEvCap, kFsWsInts = kFsTodo + kFsMaxN / 32 + 8;
+// event list (q, j, k, row, cost, list length) | sorted events (q, j, k, flags, row, cost, list length) + head slots (column, event) | TODO bitmask
+constexpr int kFsM = 0, kFsCtr = 5 * kFsMaxMembers, kFsKeep = kFsCtr + 8, kFsEvl = kFsKeep + 2 * kFsHash, kFsEvs = kFsEvl + 6 * kEvCap,
+              kFsTodo = kFsEvs + 9 * kEvCap, kFsWsInts = kFsTodo + kFsMaxN / 32 + 8;
 MOT_HD size_t lap_rowlist_bytes(int nr) { return static_cast<size_t>(nr > 0 ? nr : 0) * (4 + 8 * static_cast<size_t>(kRlCap)) + 32; }
 template <class Work>
 MOT_HD void lap_carve_rowlist(Work& w, void* base, int nr) {
@@ -137,7 +145,10 @@ MOT_HD void lap_carve_cold(Work& w, void* base, int n) {
   w.tmp.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.lst.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.inv.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
-  w.tie.p = reinterpret_cast<int*>(p);
+  w.tie.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.sa.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.sb.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.sc.p = reinterpret_cast<int*>(p);
 }
 MOT_HD LapWork lap_carve(void* base, int n) {  // hot then cold, contiguous
   LapWork w;
@@ -366,6 +377,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
   long long n_carr = 0, n_paths = 0;
   long long n_fs_steps = 0, n_fs_members = 0, n_fs_sparse = 0, n_fs_events = 0, n_seq_sweeps = 0, n_fs_bad = 0, n_finds = 0;  // diagnostics
   long long cy_cls = 0, cy_dry = 0, cy_apply = 0, cy_evsort = 0, cy_evser = 0, cy_find = 0, cy_seq = 0, cy_init = 0;
+  long long cy_sub[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (fine profile builds) classify: loads | reductions; relax: fetch issue | full barrier | evaluate | reductions; apply: A1 | A2 | A3
   // ---- phase 1: column reduction + reduction transfer (_ccrrt_dense, :36-72) ----
   // Row lists (matrix costs with the optional scratch): per real row the entries with cost < half, gathered by the column
   // sweep below. The shortest-path search uses them for exact sparse sweeps of real rows (see the scan of phase 3).
@@ -838,14 +850,14 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
       // ---- general path: exact emulation of find_path_dense (:157-193) ----
       da_valid = false;  // the dual update below changes v
       dq_ok = false;
-      const long long qi0 = MOT_CLOCK();
+      const long long qi0 = MOT_FCLOCK();
       for (int j = t; j < n; j += T) { W.cols[j] = j; W.inv[j] = j; W.tie[j] = 0; W.pred[j] = start; W.d[j] = R0.at(C, j) - W.v[j]; }
       if (use_rl) {  // the steps' column table starts empty; TODO bitmask: one bit per column that has not entered the SCAN set yet
         for (int w = t; w < kFsHash; w += T) { W.fsw[kFsKeep + w] = -1; W.fsw[kFsKeep + kFsHash + w] = kNoIdx; }
         for (int w = t; w < (n + 31) / 32; w += T) W.fsw[kFsTodo + w] = (32 * (w + 1) <= n) ? -1 : static_cast<int>((1u << (n & 31)) - 1u);
       }
       g.sync();
-      cy_init += MOT_CLOCK() - qi0;
+      cy_init += MOT_FCLOCK() - qi0;
       unsigned lo = 0, hi = 0, n_ready = 0;
       // largest h of a fully swept dummy row / of a real row's dummy-column part so far in this search (see the scan)
       // (the initial distances d[j] = E(start, j) - v[j] are a sweep of the start row with h = 0)
@@ -854,7 +866,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
         if (lo == hi) {
           n_ready = lo;
           ++n_finds;
-          const long long qf0 = MOT_CLOCK();
+          const long long qf0 = MOT_FCLOCK();
           // _find_dense (:115-127). Its outcome depends on the ORDER of cols[], which only changes at positions whose
           // value is <= the running minimum ("weak records") — and the values it reads are those of the cols[] order
           // at entry (a swap never touches a position still to be read). So: find the records in parallel (chunk
@@ -899,7 +911,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               }
               last_strict = g.reduce_max(last_strict);
               const int ties = nrec - 1 - last_strict;
-              if (ties >= kTieMin && ties <= kTiePer * T) { nser = last_strict + 1; R = ties; }
+              if (ties >= kTieMin) { nser = last_strict + 1; R = ties; }  // (any length: longer runs are staged through memory)
             }
 #if defined(__HIP_DEVICE_COMPILE__)
             {
@@ -970,6 +982,43 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             unsigned h2;
             if (R == 0) {
               h2 = static_cast<unsigned>(W.tmp[0]);
+            } else if (R > kTiePer * T) {
+              // the same closed form with the per-record values staged through memory instead of registers (any run length)
+              const int a = nser, s = first;
+              for (int r = t; r < R; r += T) W.tmp[r] = 0;
+              g.sync();
+              for (int r = t; r < R; r += T) { const int gq = W.lst[a + r]; if (gq < R && gq != r) W.tmp[gq] = 1; }
+              g.sync();
+              for (int r = t; r < R; r += T) { const int gq = W.lst[a + r]; W.sc[r] = (gq != r && static_cast<int>(W.tmp[r]) == 0) ? 1 : 0; }  // fresh
+              g.sync();
+              for (int r = t; r < R; r += T) { const int gq = W.lst[a + r]; W.tmp[r] = (gq < R) ? gq : r; }
+              g.sync();
+              for (;;) {  // pointer jumping, in place
+                int changed = 0;
+                for (int r = t; r < R; r += T) {
+                  const int p1 = W.tmp[r];
+                  const int p2 = W.tmp[p1];
+                  if (p2 != p1) { W.tmp[r] = p2; changed = 1; }
+                }
+                if (g.reduce_max(changed) == 0) break;
+              }
+              g.sync();
+              for (int r = t; r < R; r += T) {
+                const int gq = W.lst[a + r];
+                W.sa[r] = W.cols[s + gq];
+                if (static_cast<int>(W.sc[r])) {
+                  W.sb[r] = W.cols[s + r];
+                  W.sc[r] = 1 + s + static_cast<int>(W.lst[a + static_cast<int>(W.tmp[r])]);  // 1 + destination of the displaced item
+                }
+              }
+              g.sync();  // every read of the old order is done
+              for (int r = t; r < R; r += T) {
+                const int jr = W.sa[r], dd = W.sc[r];
+                W.cols[s + r] = jr; W.inv[jr] = s + r;
+                if (dd) { const int og = W.sb[r]; W.cols[dd - 1] = og; W.inv[og] = dd - 1; }
+              }
+              g.sync();
+              h2 = static_cast<unsigned>(s + R);
             } else {
               const int a = nser;  // first tie record; the serial part left the insertion point at s = lo + 1 = first
               const int s = first;
@@ -1051,7 +1100,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             final_j = (best >= 0) ? static_cast<int>(W.cols[best]) : -1;
           }
           g.sync();
-          cy_find += MOT_CLOCK() - qf0;
+          cy_find += MOT_FCLOCK() - qf0;
         }
         if (final_j == -1) {
           // _scan_dense (:129-155) on local copies of lo/hi, written back only on normal exit
@@ -1106,42 +1155,68 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           //      d[j] <= fl(fl(half - v[j]) - hmax_dummy_row) <= fl(fl(cost(i,j) - v[j]) - h_i) (rounding is monotone) — so its
           //      sweep only needs the row's list of entries below half (and, while h_i <= hmax_real_row, no dummy column).
           // Up to T consecutive members of those two kinds are handled by one step: each lane classifies one member; the
-          // real rows' list entries are relaxed together. The relaxations that lower a distance are collected in LDS; of those
-          // that hit the same column the smallest value wins, among equal values the EARLIEST member (a later equal value does
-          // not replace the predecessor in lapjv either). Values that tie with `mind` become events and are applied in lapjv's
-          // order: by member, then by position in cols[] at that member's turn. A step stops in front of the first member of
-          // any other kind, which takes the one-at-a-time sweep below. If a relaxed value falls below mind (possible only
-          // through rounding) the rest of the SCAN set is swept one member at a time.
+          // real rows' list entries are relaxed together: distances by an atomic minimum (every value is >= mind >= 0, so the bit
+          // patterns order like the doubles); of the relaxations that attain a column's new distance the EARLIEST member is
+          // the predecessor (a later equal value does not replace it in lapjv either) — they meet in a small table keyed by
+          // the column; values that tie with `mind` become events and are applied in lapjv's order: by member, then by position
+          // in cols[] at that member's turn. A step stops in front of the first member of any other kind, which takes the
+          // one-at-a-time sweep below. If a relaxed value falls below mind (possible only through rounding) the rest of the
+          // SCAN set is swept one member at a time.
+          // Memory traffic of a step: the duals, distances, column->row map, the TODO bitmask and every table of the step are
+          // in LDS (lds mode 4), and the barriers inside a step order LDS only, so that its few global accesses — the rows' lists,
+          // the positions of tie columns, the stores to cols[] / inv[] / pred[] — overlap instead of costing a round trip each;
+          // ONE full barrier per step makes the previous step's stores visible. The members a step appends are classified by
+          // the next step from the event table (row, cost and list length were fetched with the event), not from memory.
           const int fs_members = use_rl ? ((((kFsIter * T) / kRlCap) < kFsMaxMembers) ? (kFsIter * T) / kRlCap : kFsMaxMembers) : 0;
           bool fast_ok = fs_members > 0;
           constexpr int kMQ = kFsM, kMROW = kFsM + kFsMaxMembers, kMCNT = kFsM + 2 * kFsMaxMembers, kMH = kFsM + 3 * kFsMaxMembers;
-          constexpr int kCEV = kFsCtr, kCKEEP = kFsCtr + 1, kCDONE = kFsCtr + 2, kCSINK = kFsCtr + 3;
+          constexpr int kCEV = kFsCtr, kCDONE = kFsCtr + 2, kCSINK = kFsCtr + 3;
           constexpr int kHK = kFsKeep, kHQ = kFsKeep + kFsHash;
-          auto fast_step = [&](double mind_b) -> int {  // 0: nothing done, 1: members consumed, 2: a sink was reached (final_j set)
-            const long long q0 = MOT_CLOCK();
+          constexpr int kEQ = kFsEvl, kEJ = kFsEvl + kEvCap, kEK = kFsEvl + 2 * kEvCap, kEI = kFsEvl + 3 * kEvCap, kEC = kFsEvl + 4 * kEvCap, kEN = kFsEvl + 5 * kEvCap;
+          constexpr int kSQ = kFsEvs, kSJ = kFsEvs + kEvCap, kSK = kFsEvs + 2 * kEvCap, kSF = kFsEvs + 3 * kEvCap, kSI = kFsEvs + 4 * kEvCap,
+                        kSC = kFsEvs + 5 * kEvCap, kSN = kFsEvs + 6 * kEvCap, kHC = kFsEvs + 7 * kEvCap, kHE = kFsEvs + 8 * kEvCap;
+          unsigned qpos = 0u, qlen = 0u;   // SCAN positions [qpos, qpos + qlen) were appended by the last step: their members are in the sorted event table
+          bool need_full = false;          // stores to cols[] that the next classification reads from memory are still in flight
+          bool stepped = false;            // a step ran in this SCAN set (its stores need a full barrier before anyone else reads them)
+          auto fast_step_body = [&](double mind_b) -> int {  // 0: nothing done, 1: members consumed, 2: a sink was reached (final_j set)
+            const long long q0 = MOT_FCLOCK();
+            if (need_full) { g.sync(); need_full = false; }
             const unsigned idx = slo + static_cast<unsigned>(t);
             int cls = 0, mi = -1, mcnt = 0;  // 0 stop, 1 void dummy row, 2 real row with a list
             double hh = 0.0;
             if (idx < shi) {
-              const int mj = W.cols[idx];
-              mi = W.y[mj];
-              const double md = W.d[mj];
+              const unsigned qi = idx - qpos;
+              int mj;
+              double md, cij = half;
+              if (qi < qlen) {  // appended by the last step: d == mind by construction
+                mj = W.fsw[kSJ + qi]; mi = W.fsw[kSI + qi]; md = mind_b;
+                mcnt = W.fsw[kSN + qi];
+                if (mi < nr && mj < nc) cij = static_cast<double>(__builtin_bit_cast(float, static_cast<int>(W.fsw[kSC + qi])));
+              } else {
+                mj = W.cols[idx];
+                mi = W.y[mj];
+                md = W.d[mj];
+                if (mi < nr) {
+                  mcnt = W.rl_cnt[mi];
+                  if (mj < nc) cij = C.at(mi, mj);
+                }
+              }
               if (md == mind_b) {
                 if (mi >= nr) {
                   hh = ((mj < nc) ? half : 0.0) - W.v[mj] - md;
                   if (hh <= hmax_dummy_row) cls = 1;
                 } else {
-                  mcnt = W.rl_cnt[mi];
-                  const double cij = (mj < nc) ? C.at(mi, mj) : half;
                   hh = cij - W.v[mj] - md;
                   if (hh <= hmax_dummy_row && hh <= hmax_real_row && mcnt <= kRlCap) cls = 2;
                 }
               }
             }
+            const long long qa = MOT_FCLOCK();
+            cy_sub[0] += qa - q0;
             int cnt = g.reduce_min_int((cls == 0) ? t : kNoIdx);
             const int avail = (shi - slo < static_cast<unsigned>(T)) ? static_cast<int>(shi - slo) : T;
             if (cnt > avail) cnt = avail;
-            if (cnt == 0) { cy_cls += MOT_CLOCK() - q0; return 0; }
+            if (cnt == 0) { cy_cls += MOT_FCLOCK() - q0; return 0; }
             const bool sp = t < cnt && cls == 2 && mcnt > 0;  // (a real row without entries below half relaxes nothing)
             int ns;
             const int rank = g.flag_rank(sp, &ns);
@@ -1149,7 +1224,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               cnt = g.reduce_min_int((sp && rank == fs_members) ? t : kNoIdx);
               ns = fs_members;
             }
-            if (ns == 0) { slo += static_cast<unsigned>(cnt); ++n_fs_steps; n_fs_members += cnt; cy_cls += MOT_CLOCK() - q0; return 1; }
+            if (ns == 0) { slo += static_cast<unsigned>(cnt); ++n_fs_steps; n_fs_members += cnt; cy_cls += MOT_FCLOCK() - q0; return 1; }
             if (sp && rank < ns) {
               const long long hb = __builtin_bit_cast(long long, hh);
               W.fsw[kMQ + rank] = t;
@@ -1159,72 +1234,116 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               W.fsw[kMH + 2 * rank + 1] = static_cast<int>(hb >> 32);
             }
             if (t == 0) W.fsw[kCEV] = 0;
-            g.sync();
-            const long long q1 = MOT_CLOCK();
+            g.sync_lds();
+            const long long q1 = MOT_FCLOCK();
             cy_cls += q1 - q0;
-            // dry run: every list entry of the step's real rows, held in registers
+            cy_sub[1] += q1 - qa;
+            // every list entry of the step's real rows, held in registers
             int ej[kFsIter], eq[kFsIter], er[kFsIter];
+            float cc[kFsIter];
             double ec[kFsIter];
             unsigned keep = 0u;
             int bad = 0, nt = 0, nk = 0;
-            auto evaluate = [&](int ns_now) {
-              keep = 0u; nt = 0; nk = 0;
-              float cc[kFsIter];
+            // (loads first, arithmetic after: the LDS / global reads of several entries are in flight together instead of one
+            // dependent round trip per entry)
+            auto fetch = [&](int ns_now) {
+              int row[kFsIter], cn[kFsIter];
 #pragma unroll
-              for (int it = 0; it < kFsIter; ++it) {  // the loads of all the lane's entries are in flight together
-                const int item = t + it * T;
-                const int r = item / kRlCap, e = item % kRlCap;
-                ej[it] = -1; cc[it] = 0.f;
-                if (r < ns_now && e < static_cast<int>(W.fsw[kMCNT + r])) {
-                  const int row = W.fsw[kMROW + r];
-                  ej[it] = W.rl_col[static_cast<long>(row) * kRlCap + e];
-                  cc[it] = W.rl_cost[static_cast<long>(row) * kRlCap + e];
-                }
+              for (int it = 0; it < kFsIter; ++it) {
+                const int r = (t + it * T) / kRlCap;
+                const int rr = (r < kFsMaxMembers) ? r : kFsMaxMembers - 1;
+                row[it] = W.fsw[kMROW + rr];
+                cn[it] = W.fsw[kMCNT + rr];
+                if (r >= ns_now) cn[it] = 0;
               }
 #pragma unroll
               for (int it = 0; it < kFsIter; ++it) {
-                const int j = ej[it];
-                eq[it] = 0; er[it] = 0; ec[it] = 0.0;
-                if (j >= 0 && ((static_cast<int>(W.fsw[kFsTodo + (j >> 5)]) >> (j & 31)) & 1)) {
+                const int e = (t + it * T) % kRlCap;
+                ej[it] = -1; cc[it] = 0.f;
+                if (e < cn[it]) {
+                  ej[it] = W.rl_col[static_cast<long>(row[it]) * kRlCap + e];
+                  cc[it] = W.rl_cost[static_cast<long>(row[it]) * kRlCap + e];
+                }
+              }
+            };
+            auto evaluate = [&]() {
+              keep = 0u; nt = 0; nk = 0;
+              constexpr int kHalf = (kFsIter > 4) ? 4 : kFsIter;
+#pragma unroll
+              for (int i0 = 0; i0 < kFsIter; i0 += kHalf) {
+                int tw[kHalf], hlo[kHalf], hhi[kHalf];
+                double vv[kHalf], dd[kHalf];
+#pragma unroll
+                for (int u = 0; u < kHalf; ++u) {
+                  const int it = i0 + u;
+                  const int jc = (ej[it] >= 0) ? ej[it] : 0;
                   const int r = (t + it * T) / kRlCap;
-                  const long long hb = (static_cast<long long>(static_cast<int>(W.fsw[kMH + 2 * r + 1])) << 32) |
-                                       static_cast<long long>(static_cast<unsigned>(static_cast<int>(W.fsw[kMH + 2 * r])));
-                  const double cred = static_cast<double>(cc[it]) - W.v[j] - __builtin_bit_cast(double, hb);
-                  const double dj = W.d[j];
-                  if (!(cred >= mind_b)) bad = 1;
-                  if (cred < dj) {
-                    keep |= 1u << it;
-                    eq[it] = W.fsw[kMQ + r]; er[it] = W.fsw[kMROW + r]; ec[it] = cred;
-                    ++nk;
-                    if (cred == mind_b) ++nt;
+                  const int rr = (r < kFsMaxMembers) ? r : kFsMaxMembers - 1;
+                  tw[u] = W.fsw[kFsTodo + (jc >> 5)];
+                  vv[u] = W.v[jc];
+                  dd[u] = W.d[jc];
+                  hlo[u] = W.fsw[kMH + 2 * rr];
+                  hhi[u] = W.fsw[kMH + 2 * rr + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < kHalf; ++u) {
+                  const int it = i0 + u;
+                  const int j = ej[it];
+                  eq[it] = 0; er[it] = 0; ec[it] = 0.0;
+                  if (j >= 0 && ((tw[u] >> (j & 31)) & 1)) {
+                    const int r = (t + it * T) / kRlCap;
+                    const long long hb = (static_cast<long long>(hhi[u]) << 32) | static_cast<long long>(static_cast<unsigned>(hlo[u]));
+                    const double cred = static_cast<double>(cc[it]) - vv[u] - __builtin_bit_cast(double, hb);
+                    if (!(cred >= mind_b)) bad = 1;
+                    if (cred < dd[u]) {
+                      keep |= 1u << it;
+                      eq[it] = W.fsw[kMQ + r]; er[it] = W.fsw[kMROW + r]; ec[it] = cred;
+                      ++nk;
+                      if (cred == mind_b) ++nt;
+                    }
                   }
                 }
               }
             };
-            evaluate(ns);
+            fetch(ns);
+            const long long qb = MOT_FCLOCK();
+            cy_sub[2] += qb - q1;
+            g.sync();  // the step's full barrier, with the list loads in flight: the previous step's stores to cols[] / inv[] are visible from here on
+            stepped = true;
+            const long long qc = MOT_FCLOCK();
+            cy_sub[3] += qc - qb;
+            evaluate();
+            const long long qd = MOT_FCLOCK();
+            cy_sub[4] += qd - qc;
             bad = g.reduce_max(bad);
             if (bad) { fast_ok = false; ++n_fs_bad; return 0; }
-            int packed_all;
-            g.exclusive_scan((nt << 16) | nk, &packed_all);  // (each count <= kFsIter * T <= 32768)
+            const int packed_all = g.reduce_sum((nt << 16) | nk);  // (each count <= kFsIter * T <= 32768)
             if ((packed_all >> 16) > kEvCap || (packed_all & 0xffff) > kKeepCap) {  // more than the tables hold: this step takes one real row only (<= kRlCap entries)
               ns = 1;
               cnt = static_cast<int>(W.fsw[kMQ]) + 1;
-              evaluate(1);
+#pragma unroll
+              for (int it = 0; it < kFsIter; ++it)
+                if ((t + it * T) / kRlCap >= 1) ej[it] = -1;
+              evaluate();
             }
-            const long long q2 = MOT_CLOCK();
+            const long long q2 = MOT_FCLOCK();
             cy_dry += q2 - q1;
-            // 1. distances: atomic minimum (all values are >= mind >= 0: the bit patterns order like the doubles)
+            cy_sub[5] += q2 - qd;
+            // 1. distances
 #pragma unroll
             for (int it = 0; it < kFsIter; ++it)
               if (keep & (1u << it)) mem_atomic_min_f64_nonneg<std::remove_reference_t<decltype(W.d)>::kSpace>(W.d.raw(ej[it]), ec[it]);
-            g.sync();
-            // 2. of the relaxations that attain a column's new distance the EARLIEST member is its predecessor (a later equal
-            //    value does not replace it in lapjv either): they meet in a small open-addressing table keyed by the column
+            if constexpr (std::remove_reference_t<decltype(W.d)>::kSpace == kMemGlobal) g.sync(); else g.sync_lds();  // (orders the accesses to d[])
+            const long long qe = MOT_FCLOCK();
+            cy_sub[6] += qe - q2;
+            // 2. the earliest member among the relaxations that attain a column's new distance
             int es[kFsIter];
-            unsigned ach = 0u;
+            unsigned ach = 0u, tie = 0u;
+            int tk[kFsIter], ti[kFsIter], tn[kFsIter];
+            float tc[kFsIter];
 #pragma unroll
             for (int it = 0; it < kFsIter; ++it) {
-              es[it] = 0;
+              es[it] = 0; tk[it] = 0; ti[it] = 0; tn[it] = 0; tc[it] = 0.f;
               if ((keep & (1u << it)) && static_cast<double>(W.d[ej[it]]) == ec[it]) {
                 int slot = static_cast<int>((static_cast<unsigned>(ej[it]) * 2654435761u) >> 22) & (kFsHash - 1);
                 for (;;) {
@@ -1235,55 +1354,78 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 W.fsw.atomic_min(kHQ + slot, eq[it]);
                 es[it] = slot;
                 ach |= 1u << it;
+                if (ec[it] == mind_b) {
+                  // a tie with mind: if this relaxation wins it becomes an event. What the event needs from memory — the column's
+                  // position in cols[] (the order of the events), and for the member it appends the row's list length and its cost
+                  // at the column — is requested now and arrives behind the barrier
+                  tie |= 1u << it;
+                  const int j = ej[it], i = W.y[j];
+                  tk[it] = W.inv[j];
+                  ti[it] = i;
+                  if (i >= 0 && i < nr) {
+                    tn[it] = W.rl_cnt[i];
+                    if (j < nc) tc[it] = static_cast<float>(C.at(i, j));
+                  }
+                }
               }
             }
-            g.sync();
+            g.sync_lds();
+            const long long qg = MOT_FCLOCK();
+            cy_sub[7] += qg - qe;
+            // 3. predecessors; the winners that tie with mind become events
             unsigned win = 0u;
 #pragma unroll
-            for (int it = 0; it < kFsIter; ++it)
+            for (int it = 0; it < kFsIter; ++it) {
               if ((ach & (1u << it)) && static_cast<int>(W.fsw[kHQ + es[it]]) == eq[it]) {
                 win |= 1u << it;
                 W.pred[ej[it]] = er[it];
-                if (ec[it] == mind_b) {
-                  const int k = W.inv[ej[it]];  // position in cols[]: the order of the tie events
-                  const int e = W.fsw.atomic_add(kCEV, 1);
-                  W.fsw[kFsEvl + e] = eq[it];
-                  W.fsw[kFsEvl + kEvCap + e] = ej[it];
-                  W.fsw[kFsEvl + 2 * kEvCap + e] = k;
-                }
+              } else {
+                tie &= ~(1u << it);
               }
-            g.sync();
+            }
+#pragma unroll
+            for (int it = 0; it < kFsIter; ++it)
+              if (tie & (1u << it)) {
+                const int e = W.fsw.atomic_add(kCEV, 1);
+                W.fsw[kEQ + e] = eq[it]; W.fsw[kEJ + e] = ej[it]; W.fsw[kEK + e] = tk[it];
+                W.fsw[kEI + e] = ti[it]; W.fsw[kEC + e] = __builtin_bit_cast(int, tc[it]); W.fsw[kEN + e] = tn[it];
+              }
+            g.sync_lds();
 #pragma unroll
             for (int it = 0; it < kFsIter; ++it)
               if (win & (1u << it)) { W.fsw[kHK + es[it]] = -1; W.fsw[kHQ + es[it]] = kNoIdx; }  // the table is empty again for the next step
             const int nev = W.fsw[kCEV];
-            const long long q3 = MOT_CLOCK();
+            const long long q3 = MOT_FCLOCK();
             cy_apply += q3 - q2;
+            cy_sub[8] += q3 - qg;
             ++n_fs_steps; n_fs_members += cnt; n_fs_sparse += ns; n_fs_events += nev;
+            qlen = 0u;
             if (nev == 0) { slo += static_cast<unsigned>(cnt); return 1; }
             // tie events in lapjv's order. Sorted by (member, position at the start of the step); positions only change for
             // columns that sit in the first nev TODO positions ("head slots": a tie swaps its column with the first TODO one).
-            constexpr int kSQ = kFsEvs, kSJ = kFsEvs + kEvCap, kSK = kFsEvs + 2 * kEvCap, kSF = kFsEvs + 3 * kEvCap, kHC = kFsEvs + 4 * kEvCap, kHE = kFsEvs + 5 * kEvCap;
             int in_head = 0, first_sink = kNoIdx;
             for (int e = t; e < nev; e += T) {
-              const int q = W.fsw[kFsEvl + e], j = W.fsw[kFsEvl + kEvCap + e], k = W.fsw[kFsEvl + 2 * kEvCap + e];
-              const int hcol = W.cols[shi + static_cast<unsigned>(e)];
-              const int fl = (static_cast<int>(W.y[j]) < 0) ? 1 : 0;
+              const int hcol = W.cols[shi + static_cast<unsigned>(e)];  // (in flight while the rank is counted)
+              const int q = W.fsw[kEQ + e], j = W.fsw[kEJ + e], k = W.fsw[kEK + e], i = W.fsw[kEI + e];
+              const int fl = (i < 0) ? 1 : 0;
               int rk = 0;
               for (int o = 0; o < nev; ++o) {
-                const int oq = W.fsw[kFsEvl + o], ok = W.fsw[kFsEvl + 2 * kEvCap + o];
+                const int oq = W.fsw[kEQ + o], ok = W.fsw[kEK + o];
                 rk += (oq < q || (oq == q && ok < k)) ? 1 : 0;
               }
               W.fsw[kSQ + rk] = q; W.fsw[kSJ + rk] = j; W.fsw[kSK + rk] = k; W.fsw[kSF + rk] = fl;
+              W.fsw[kSI + rk] = i; W.fsw[kSC + rk] = W.fsw[kEC + e]; W.fsw[kSN + rk] = W.fsw[kEN + e];
               W.fsw[kHC + e] = hcol;
               W.fsw[kHE + e] = -1;
               if (k - static_cast<int>(shi) < nev) in_head = 1;
               if (fl && rk < first_sink) first_sink = rk;
             }
-            in_head = g.reduce_max(in_head);
-            first_sink = g.reduce_min_int(first_sink);
-            g.sync();
-            const long long q4 = MOT_CLOCK();
+            {  // one reduction for both (its barrier also orders the sorted table): -1 when some event column sits in a head slot
+              const int key = g.reduce_min_int(in_head ? -1 : first_sink);
+              in_head = key < 0 ? 1 : 0;
+              first_sink = key;
+            }
+            const long long q4 = MOT_FCLOCK();
             cy_evsort += q4 - q3;
             int done, sink = -1;
             if (!in_head) {
@@ -1297,13 +1439,13 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 W.cols[hpos] = j; W.inv[j] = hpos;
                 W.fsw.atomic_and(kFsTodo + (j >> 5), ~(1 << (j & 31)));
               }
-              g.sync();
+              qpos = shi; qlen = static_cast<unsigned>(done);  // the appended members, in order, are the first `done` sorted events
             } else {
               for (int e = t; e < nev; e += T) {
                 const int off = static_cast<int>(W.fsw[kSK + e]) - static_cast<int>(shi);
                 if (off < nev) W.fsw[kHE + off] = e;
               }
-              g.sync();
+              g.sync_lds();
               if (t == 0) {
                 int dn = 0, sk = -1, e0 = 0;
                 for (int r = 0; r < nev; ++r) {
@@ -1332,20 +1474,35 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 W.fsw[kCDONE] = dn;
                 W.fsw[kCSINK] = sk;
               }
-              g.sync();
+              g.sync_lds();
               done = W.fsw[kCDONE]; sink = W.fsw[kCSINK];
+              ++n_fs_bad;  // (diagnostics: counted with the refused steps)
+              need_full = true;  // (the order the events were applied in is not the sorted one: the next step reads cols[] from memory)
             }
-            cy_evser += MOT_CLOCK() - q4;
+            cy_evser += MOT_FCLOCK() - q4;
             if (sink >= 0) { final_j = sink; return 2; }
             shi += static_cast<unsigned>(done);
             slo += static_cast<unsigned>(cnt);
             return 1;
           };
+          auto fast_step = [&](double mind_b) -> int {
+            g.lds_barriers(true);
+            const int r = fast_step_body(mind_b);
+            g.lds_barriers(false);
+            return r;
+          };
+          const double mind_set = pq_d;  // every member of a SCAN set sits at the same distance
+          bool pq_valid = true;
           while (slo != shi) {
             if (fast_ok) {
-              const int fr = fast_step(pq_d);
+              const int fr = fast_step(mind_set);
               if (fr == 2) { returned = true; break; }
-              if (fr == 1) { if (slo != shi) member(slo); continue; }
+              if (fr == 1) { pq_valid = false; continue; }
+            }
+            if (!pq_valid) {
+              if (stepped) g.sync();  // the steps' stores to cols[] are visible
+              member(slo);
+              pq_valid = true;
             }
             // Runs of dummy-row members whose sweep is void (h <= hmax_dummy_row, see below) leave the SCAN set together:
             // each lane classifies one member ahead, one reduction counts the leading void ones. With more detections
@@ -1366,7 +1523,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               continue;
             }
             ++n_seq_sweeps;
-            const long long qs0 = MOT_CLOCK();
+            const long long qs0 = MOT_FCLOCK();
             const int jq = pq_j;
             const int i = pq_i;
             const double mind = pq_d;
@@ -1509,9 +1666,10 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             }
             shi += static_cast<unsigned>(nt);
             g.sync();
-            cy_seq += MOT_CLOCK() - qs0;
+            cy_seq += MOT_FCLOCK() - qs0;
             if (!fetched && slo != shi) member(slo);  // the SCAN set was empty until this sweep's ties joined it
           }
+          if (stepped) g.sync();  // the steps' stores to cols[] / inv[] / pred[] are visible to what follows
           if (!returned) { lo = slo; hi = shi; }
         }
       }
@@ -1548,7 +1706,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     W.cyc[4] = n_uniq; W.cyc[5] = n_carr; W.cyc[6] = n_paths; W.cyc[7] = n;
     W.cyc[8] = n_fs_steps; W.cyc[9] = n_fs_members; W.cyc[10] = n_fs_sparse; W.cyc[11] = n_fs_events; W.cyc[12] = n_seq_sweeps; W.cyc[13] = n_fs_bad;
     W.cyc[14] = n_finds; W.cyc[15] = use_rl ? 1 : 0;
-    if (W.cyc_ext) { W.cyc[16] = cy_cls; W.cyc[17] = cy_dry; W.cyc[18] = cy_apply; W.cyc[19] = cy_evsort; W.cyc[20] = cy_evser; W.cyc[21] = cy_find; W.cyc[22] = cy_seq; W.cyc[23] = cy_init; }
+    if (W.cyc_ext) { for (int k = 0; k < 12; ++k) W.cyc[24 + k] = cy_sub[k]; W.cyc[16] = cy_cls; W.cyc[17] = cy_dry; W.cyc[18] = cy_apply; W.cyc[19] = cy_evsort; W.cyc[20] = cy_evser; W.cyc[21] = cy_find; W.cyc[22] = cy_seq; W.cyc[23] = cy_init; }
   }
 }
 

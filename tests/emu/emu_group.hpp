@@ -33,6 +33,8 @@ struct EmuGroup {
   int tid() const { return tid_; }
   int size() const { return sh->T; }
   void sync() { pthread_barrier_wait(&sh->bar); }
+  void sync_lds() { sync(); }
+  void lds_barriers(bool) {}
   double reduce_min(double v) {
     auto& s = sh->s_f64[phase++ & 1];
     s[tid_] = v;
@@ -77,6 +79,7 @@ struct EmuGroup {
     return base;
   }
   int flag_rank(bool flag, int* total) { return exclusive_scan(flag ? 1 : 0, total); }
+  int reduce_sum(int v) { int tot; exclusive_scan(v, &tot); return tot; }
   unsigned long long ballot(bool flag) {
     auto& s = sh->s_int[phase++ & 1];
     s[tid_] = flag ? 1 : 0;

@@ -10,7 +10,7 @@ import pytest
 from tests.emu.build import build_lap_emu
 
 
-@pytest.fixture(scope="module", params=[False, True], ids=["serial_replay", "closed_form_tie_runs"])
+@pytest.fixture(scope="module", params=[False, True, "mem"], ids=["serial_replay", "closed_form_tie_runs", "tie_runs_through_memory"])
 def emu(request):
     lib = C.CDLL(build_lap_emu(request.param))
 
@@ -163,7 +163,7 @@ def test_sparse_column_minima_make_the_same_decisions(orc, emu_iou):
 
 
 # ---- row lists: the parallel scan steps + sparse real-row sweeps of the shortest-path search (mot_lap_task.rowlist) ----
-@pytest.fixture(scope="module", params=[False, True], ids=["serial_replay", "closed_form_tie_runs"])
+@pytest.fixture(scope="module", params=[False, "mem"], ids=["serial_replay", "tie_runs_through_memory"])
 def emu_rl(request):
     lib = C.CDLL(build_lap_emu(request.param))
 

@@ -25,7 +25,7 @@ lib.mot_lap_solve_prof_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int
                                         C.c_void_p, C.c_void_p]
 x, y = np.zeros(nd, np.int32), np.zeros(nt, np.int32)
 info = C.c_int(0)
-prof = np.zeros(24, np.int64)
+prof = np.zeros(36, np.int64)
 for rep in range(2):
     t0 = time.time()
     ctx._chk(lib.mot_lap_solve_prof_host(ctx.h, cost.ctypes.data, nd, nt, C.c_float(-0.3), L.LAP_OCSORT if hasattr(L, "LAP_OCSORT") else 2, iou.ctypes.data,

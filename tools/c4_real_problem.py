@@ -20,7 +20,7 @@ for f in sorted(glob.glob(os.path.join(d, "*.bin"))):
     exp = np.load(f + ".npz")
     x, y = np.zeros(nr, np.int32), np.zeros(nc, np.int32)
     info = C.c_int(0)
-    prof = np.zeros(24, np.int64)
+    prof = np.zeros(36, np.int64)
     for rep in range(reps):
         t0 = time.time()
         ctx._chk(lib.mot_lap_solve_prof_host(ctx.h, cost.ctypes.data, nr, nc, C.c_float(th), 0, None, C.c_float(0.0), x.ctypes.data, y.ctypes.data,
@@ -33,5 +33,6 @@ for f in sorted(glob.glob(os.path.join(d, "*.bin"))):
           (p[0] / 1e6, p[1] / 1e6, p[2] / 1e6, p[3] / 1e6, p[:4].sum() / 2.4e6),
           "| carr %d paths %d finds %d | steps %d members %d real %d events %d one-at-a-time %d refused %d lists %d" %
           (p[5], p[6], p[14], p[8], p[9], p[10], p[11], p[12], p[13], p[15]),
-          "| aug Mcycles: classify %.1f dry %.1f apply %.1f evsort %.1f evreplay %.1f find %.1f one-at-a-time %.1f setup %.1f" % tuple(p[16:24] / 1e6), flush=True)
+          "| aug Mcycles: classify %.1f dry %.1f apply %.1f evsort %.1f evreplay %.1f find %.1f one-at-a-time %.1f setup %.1f" % tuple(p[16:24] / 1e6),
+          "| sub: " + " ".join("%.1f" % (v / 1e6) for v in p[24:33]), flush=True)
 print("mismatches", bad)

@@ -526,6 +526,10 @@ struct mot_oc_batch {
   int* d_err = nullptr;
   int* d_maxt = nullptr;
   int bound_n = 0;
+  // first association: when (nearly) every problem of a frame was declined by the certified sparse solver (duplicated tracks, quirk Q4:
+  // the optimum is not unique), the next frames go to the exact kernel directly; the sparse solver is tried again every 8th frame
+  bool lap1_skip_fast = false;
+  int lap1_age = 0;
   float* d_out = nullptr; int* d_out_counts = nullptr;
   float* d_packed = nullptr; int* d_offsets = nullptr; int packed_cap = 0;
   float* mean = nullptr;  // [S][CAP] records of 7 + 49 floats
@@ -554,6 +558,8 @@ int mot_oc_reset(mot_oc_batch* b) {  // OCSort::reset: the tracker list is dropp
   MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
   MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
   b->bound_n = 0;
+  b->lap1_skip_fast = false;
+  b->lap1_age = 0;
   return MOT_OK;
 }
 
@@ -721,7 +727,9 @@ int mot_oc_step_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[2], st));
   MOT_LC_HIP(b, mot::launch_ocsort(K.cost, S, bd, bn, !general, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[3], st));
-  MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bd, bn, false, false, true, st));
+  const bool lap1_fast = !b->lap1_skip_fast || (b->lap1_age % 8) == 0;
+  int* lap1_declined = nullptr;
+  MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bd, bn, false, false, true, st, 0, 0, lap1_fast, &lap1_declined));
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[4], st));
   hipLaunchKernelGGL(oc_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, K);
   if (b->prm.use_byte) {
@@ -748,7 +756,11 @@ int mot_oc_step_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts
   MOT_LC_HIP(b, hipMemcpyAsync(&total, b->d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
+  int declined1 = -1;
+  if (lap1_declined) MOT_LC_HIP(b, hipMemcpyAsync(&declined1, lap1_declined, sizeof(int), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipStreamSynchronize(st));
+  ++b->lap1_age;
+  if (declined1 >= 0) b->lap1_skip_fast = declined1 * 10 >= 9 * S;
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
   if (prof) {

@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0,
                     help="split a rank's streams into this many sub-batches with their own HIP stream, stepped concurrently so one's host lifecycle overlaps another's kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace-steps", action="store_true", help="add the wall time of every timed step to the line (step_ms)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
     # stdout carries exactly one JSON line: libraries that print there (RCCL's version banner at communicator creation) are
@@ -284,6 +285,8 @@ def main():
         def col(k):
             for p in range(PIPE):
                 tot_p[p] = batches[p].collect_packed(rows_p[p], cnt_all[bounds[p]:bounds[p + 1]])
+            if f0 >= W:
+                step_marks.append(time.perf_counter())
             if rank == 0 and k < keep_limit:
                 kept.append(stream0_rows(None, cnt_all))
             if (world > 1 or args.gather == "native") and f0 >= W and ((k + 1) % args.gather_every == 0 or k == n - 1):
@@ -298,6 +301,7 @@ def main():
         comms = [mdist.NativeComm(batches[p].ctx, world=world, rank=rank) for p in range(PIPE)]
         native_bufs = [torch.empty((world * rows_cap[p], 8), dtype=torch.float32, device=f"cuda:{local}") for p in range(PIPE)]
     kept = []  # stream 0 outputs of rank 0 for the parity spot check
+    step_marks = []  # wall clock after every timed step (collected frame)
     if in_flight:
         run_pipelined(0, W, 40)
         out, cnt = None, cnt_all
@@ -315,6 +319,9 @@ def main():
         b.profile(True)
     diag_ctx = L.Context(local)
     diag_ctx.lap_fast_stats(reset=True)
+    import gc
+    gc.collect()
+    gc.disable()  # (a collection of the interpreter's older generations in the middle of the timed region is tens of ms)
     c0 = counters()
     t0 = time.perf_counter()
     if in_flight:
@@ -322,6 +329,7 @@ def main():
     else:
         for k in range(K):
             out, cnt = step(W + k)
+            step_marks.append(time.perf_counter())
             if world > 1 and ((k + 1) % args.gather_every == 0 or k == K - 1):
                 gather(out, cnt)
             if rank == 0 and k < 24:
@@ -330,6 +338,7 @@ def main():
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
+    gc.enable()
     achieved_dims = None
     if on_device and tracker == "bytetrack":
         dims = np.sum([b.profile_dims() for b in batches], axis=0)
@@ -590,6 +599,9 @@ def main():
         "flushes_per_step": (c1["flushes"] - c0["flushes"]) / K, "launches_per_step": (c1["launches"] - c0["launches"]) / K,
         "host_ms_per_step": {k: (c1[k] - c0[k]) / K for k in ("ms_begin", "ms_flush", "ms_advance", "ms_sync_wait")},
     }
+    if args.trace_steps:
+        marks = [t0] + step_marks[:K]
+        line["step_ms"] = [round((marks[i + 1] - marks[i]) * 1e3, 3) for i in range(len(marks) - 1)]
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1:

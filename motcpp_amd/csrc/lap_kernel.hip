@@ -270,7 +270,11 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   else if (b3 <= 40 * 1024) { mode = 3; lds = b3; }        // >= 4 (north-star: 8) problems per CU
   else if (b2 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 2; lds = b2; }
   else { mode = 0; lds = kScratch + fsb; }
-  const bool wide = (nm > 3072) && (ntasks < 512);
+  // Behind the fast path the exact kernel sees the few problems the sparse solver declined, and the launch lasts as long as its
+  // slowest problem: four wavefronts per problem cut that latency (MOT_LAP_BEHIND_T=64 keeps one wavefront per problem).
+  static const int behind_t = std::getenv("MOT_LAP_BEHIND_T") ? std::atoi(std::getenv("MOT_LAP_BEHIND_T")) : 64;
+  const bool behind = fast && behind_t == 256 && n * m >= 65536 && nm <= 3072;
+  const bool wide = ((nm > 3072) && (ntasks < 512)) || behind;
   if (fs_lds && wide && b4 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 4; lds = b4; }
   // lane-owned column boxes in registers: one wavefront per problem, <= 8 real columns per lane
   int rpl = 0;

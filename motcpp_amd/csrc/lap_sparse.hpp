@@ -44,7 +44,10 @@
 
 namespace mot {
 
-constexpr int kSpK = 16;           // viable pairs kept per column (more: fall back)
+constexpr int kSpK = 32;           // viable pairs per column the staging lists of a matrix source hold (more: fall back)
+constexpr int kSpSeg0 = 16;        // box source: list entries reserved for a column whose candidates are still coming in; a column that
+                                   // outgrows its segment moves to one of twice the size ...
+constexpr int kSpKMax = 64;        // ... up to this many viable pairs (more: fall back). A path search relaxes a column with one lane per pair.
 constexpr int kSpBuckets = 256;    // x1 buckets of the row boxes
 constexpr int kSpSlots = 63;       // rows one path search may reach (more: fall back); lane q holds slot q, lane 63 none
 constexpr int kSpQ = 8;            // per-lane queue of candidate rows awaiting the exact arithmetic (drained when full)
@@ -380,8 +383,8 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
         }
         const int nv = __builtin_popcount(viable);
         if (seg < 0 && nv > 0) {
-          seg = last ? nv : kSpK;
-          if (seg > kSpK) { bad |= 2; seg = 0; }
+          seg = last ? nv : ((nv > kSpSeg0) ? nv : kSpSeg0);
+          if (seg > kSpKMax) { bad |= 2; seg = 0; }
           base = (seg > 0) ? G::atomic_add(w.ctr.raw(2), seg) : 0;
           if (base + seg > w.ecap) { bad |= 16; seg = 0; }
         }
@@ -390,6 +393,18 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
           viable &= viable - 1u;
           int i;
           const float c = pair_cost(q, &i);
+          if (ne == seg && seg > 0 && !bad) {  // the column outgrew its segment (a pile-up of lost tracks on one detection): move it
+            const int ns = (2 * seg < kSpKMax) ? 2 * seg : kSpKMax;
+            if (ns == seg) bad |= 2;
+            else {
+              const int nb = G::atomic_add(w.ctr.raw(2), ns);
+              if (nb + ns > w.ecap) bad |= 16;
+              else {
+                for (int k = 0; k < ne; ++k) { w.erow[nb + k] = static_cast<unsigned short>(static_cast<unsigned short>(w.erow[base + k])); w.ecost[nb + k] = static_cast<float>(w.ecost[base + k]); }
+                base = nb; seg = ns;
+              }
+            }
+          }
           if (ne < seg) { w.erow[base + ne] = static_cast<unsigned short>(i); w.ecost[base + ne] = c; ++ne; }
           else if (!(bad & 16)) bad |= 2;
         }

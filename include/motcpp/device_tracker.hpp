@@ -24,6 +24,10 @@ class DeviceTracker : public BaseTracker {
   // the checks and bookkeeping update() does before any track is touched (check_inputs, the asso_func error, detection
   // format, frame counter); false = this frame is skipped. StreamBatch calls it per stream. Throws what update() throws.
   bool prepare_update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs);
+  // the two halves of prepare_update: everything that can throw (no side effect), then the bookkeeping (cannot throw). StreamBatch
+  // validates EVERY stream before it commits any, so that an exception leaves no tracker a frame ahead of its device state.
+  void validate_update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) const;
+  bool commit_update(const Eigen::MatrixXf& dets, const cv::Mat& img);
   // Threading: like the reference, a tracker instance is not re-entrant. Different tracker instances MAY be updated from
   // different host threads; those created on the same GPU share that GPU's runtime (arenas, stream) and their frames are
   // serialised by a mutex inside it — for concurrency across streams use StreamBatch / DeviceLifecycleBatch, or one process

@@ -340,9 +340,12 @@ int mot_bt_step_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts
 int mot_bt_device_output(mot_bt_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts);
 /* Frames in flight: mot_bt_step_packed split in two so that ONE host thread overlaps the result copy of frame f with the
  * kernels of frame f + 1. mot_bt_enqueue_packed queues a frame's launches and returns (at most two frames may be pending;
- * h_counts is copied before the call returns); mot_bt_collect_packed waits for the OLDEST pending frame only and delivers its
- * packed rows (copied on a second stream while the next frame runs). Frames come back in the order they went in; mixing with
- * mot_bt_step / mot_bt_step_packed while frames are pending is an error. */
+ * h_counts is copied before the call returns, but d_dets — and d_embs for mot_bot_* — are read by the queued kernels: the buffers must
+ * stay unmodified until the matching collect has returned, i.e. a caller with two frames in flight needs two input buffers);
+ * mot_bt_collect_packed waits for the OLDEST pending frame only and delivers its
+ * packed rows (copied on a second stream while the next frame runs); MOT_ERR_CAPACITY when the frame has more rows than the rows_cap
+ * of ITS enqueue call or of this collect call. Frames come back in the order they went in; mixing with mot_bt_step /
+ * mot_bt_step_packed while frames are pending is an error (MOT_ERR_INVALID); mot_bt_reset drops the frames still pending. */
 int mot_bt_enqueue_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts, int rows_cap);
 int mot_bt_collect_packed(mot_bt_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows);
 /* parity hook: ids and Kalman states of stream s's live tracks in list order (active then lost): ids [cap], mean [cap][8],
@@ -355,6 +358,9 @@ int mot_bt_profile(mot_bt_batch* b, int enable);
 int mot_bt_profile_stats(mot_bt_batch* b, double* out8);
 /* the achieved problem sizes behind those counts: summed rows (tracks) and columns (detections) of the queued problems,
  * [0],[1] first association, [2],[3] second + unconfirmed (divide by out8[4] / out8[6] for the mean N x M) */
+/* [0] summed HIP-event ms of the FIRST association's sparse-solver kernel alone (lap_sparse_kernel; the exact kernel behind it is
+ * not included), [1] its launches, since profiling was switched on */
+int mot_bt_profile_lap_sparse(mot_bt_batch* b, double* out2);
 int mot_bt_profile_dims(mot_bt_batch* b, double* out4);
 /* the Kalman launches of the same frames: summed ms and items of [0],[1] the box-only prediction of the pool (32 B of mean read,
  * 16 B box written per track), [2],[3] initiations, [4],[5] predict-first updates (one 288-byte record read and written) */
@@ -449,8 +455,10 @@ int mot_assoc_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b
 int mot_fuse_iou_host(mot_ctx* ctx, const float* reid_cost, const float* a_xyxy, int n, const float* b_xyxy, int m, float* cost);
 int mot_cosine_cost_host(mot_ctx* ctx, const float* a, int n, const float* b, int m, int d, float* out);
 int mot_embedding_cost_host(mot_ctx* ctx, int metric, const float* a, int n, const float* b, int m, int d, float* out);
-/* mot_feat_update on host rows: feat [n][d] in/out (read by mode 1), src [n][d] */
+/* mot_feat_update on host rows: feat [n][d] in/out (read by the EMA modes 1 and 3), src [n][d]; modes 0-3 as in mot_feat_task;
+ * alpha_i: optional [n] per-row EMA weights (DeepOC-SORT's dets_alpha), NULL = `alpha` for every row */
 int mot_feat_update_host(mot_ctx* ctx, int mode, float alpha, int n, int d, float* feat, const float* src);
+int mot_feat_update_host_alpha(mot_ctx* ctx, int mode, float alpha, const float* alpha_i, int n, int d, float* feat, const float* src);
 int mot_ocsort_cost_host(mot_ctx* ctx, const float* dets5, int nd, const float* trks4, int nt,
                          const float* vel2, const float* prev5, float vdc_weight, float* cost, float* iou);
 int mot_lap_solve_host(mot_ctx* ctx, const float* cost, int n, int m, float thresh, int mode,

@@ -150,12 +150,14 @@ class Context:
         self._chk(self.lib.mot_fuse_iou_host(self.h, _p(reid_cost), _p(a), a.shape[0], _p(b), b.shape[0], _p(out)))
         return out
 
-    def feat_update(self, mode, feat, src, alpha=0.9):
-        """mot_feat_update on host rows: mode 0 set+normalise, 1 EMA+normalise, 2 ReID normalise (norm > 1e-6). Returns new feat."""
+    def feat_update(self, mode, feat, src, alpha=0.9, alpha_i=None):
+        """mot_feat_update on host rows: mode 0 set+normalise, 1 EMA+normalise, 2 ReID normalise (norm > 1e-6), 3 EMA then normalise
+        where the norm exceeds 1e-6 (DeepOC-SORT's update_emb); alpha_i: optional per-row EMA weights. Returns new feat."""
         feat, src = f32(feat).copy(), f32(src)
         n, d = src.shape
-        self.lib.mot_feat_update_host.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        self._chk(self.lib.mot_feat_update_host(self.h, int(mode), C.c_float(alpha), n, d, _p(feat), _p(src)))
+        ai = f32(alpha_i) if alpha_i is not None else None
+        self.lib.mot_feat_update_host_alpha.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.mot_feat_update_host_alpha(self.h, int(mode), C.c_float(alpha), _p(ai) if ai is not None else None, n, d, _p(feat), _p(src)))
         return feat
 
     def lap_fast_stats(self, reset=False):
@@ -573,6 +575,13 @@ class DeviceByteTrack:
         self.ctx._chk(self.lib.mot_bt_profile_stats(self.h, _p(o)))
         return {"lap1_ms": o[0], "lap23_ms": o[1], "frame_ms": o[2], "frames": int(o[3]), "lap1_problems": o[4], "lap1_nm": o[5],
                 "lap23_problems": o[6], "lap23_nm": o[7]}
+
+    def profile_lap_sparse(self):
+        """HIP-event ms and launches of the first association's sparse-solver kernel alone"""
+        o = np.zeros(2, np.float64)
+        self.lib.mot_bt_profile_lap_sparse.argtypes = [C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_bt_profile_lap_sparse(self.h, _p(o)))
+        return {"ms": o[0], "launches": int(o[1])}
 
     def profile_dims(self):
         """summed rows / columns of the queued assignment problems: [first N, first M, second+unconfirmed N, second+unconfirmed M]"""

@@ -472,6 +472,7 @@ struct mot_bot_batch {
     hipEvent_t done = nullptr;
     hipEvent_t ev[8] = {};
     bool pending = false, prof = false;
+    int rows_cap = 0;  // the row limit pack_rows ran with (the enqueue call's rows_cap)
     int bd = 0;
   } fl[2];
   int fl_head = 0, fl_count = 0;
@@ -507,7 +508,9 @@ int mot_bot_reset(mot_bot_batch* b) {  // BotSort::reset :252-258: ids restart
   std::vector<BotStream> h = b->h_streams;
   MOT_LC_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(BotStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
   MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
-  MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
+  MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));  // (frames still in flight have finished by now: they are dropped with the tracks)
+  for (auto& F : b->fl) F.pending = false;
+  b->fl_head = 0; b->fl_count = 0;
   b->bound_n = 0; b->hint1_n = b->hint23_n = b->hint23_m = 0;
   return MOT_OK;
 }
@@ -809,7 +812,7 @@ int mot_bot_enqueue_packed(mot_bot_batch* b, const float* d_dets, const int* h_c
   MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 2, b->d_maxt, sizeof(int) * 256, hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 258, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipEventRecord(F.done, st));
-  F.pending = true; F.bd = bd;
+  F.pending = true; F.bd = bd; F.rows_cap = rows_cap;
   b->fl_count += 1;
   return MOT_OK;
 }
@@ -830,7 +833,9 @@ int mot_bot_collect_packed(mot_bot_batch* b, float* rows, int rows_cap, int* out
   if (total_rows) *total_rows = total;
   b->d_rows_last = F.d_packed; b->d_offsets_last = F.d_offsets; b->d_counts_last = F.d_counts;
   if (err) { b->ctx->err = "mot_bot_collect_packed: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
-  if (total > rows_cap || total > F.packed_cap) { b->ctx->err = "mot_bot_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  if (total > rows_cap || total > F.rows_cap) {  // (pack_rows skipped the streams that end past the ENQUEUE call's rows_cap)
+    b->ctx->err = "mot_bot_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY;
+  }
   if (total > 0) {
     MOT_LC_HIP(b, hipMemcpyAsync(rows, F.d_packed, sizeof(float) * static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, b->copy_st));
     MOT_LC_HIP(b, hipStreamSynchronize(b->copy_st));

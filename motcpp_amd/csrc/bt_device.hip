@@ -579,6 +579,7 @@ struct mot_bt_batch {
     hipEvent_t done = nullptr;
     hipEvent_t ev[12] = {};
     bool pending = false, prof = false;
+    int rows_cap = 0;  // the row limit pack_rows ran with (the enqueue call's rows_cap)
     int bd = 0;
   } fl[2];
   int fl_head = 0, fl_count = 0;  // oldest pending frame, frames pending
@@ -594,6 +595,7 @@ struct mot_bt_batch {
   bool profile = false;
   unsigned long long* d_stats = nullptr;
   hipEvent_t ev[12] = {};
+  double lap_sparse1_ms = 0.0;
   double lap_ms[2] = {0.0, 0.0}, frame_ms = 0.0, kf_ms[3] = {0.0, 0.0, 0.0};  // kf_ms: predict(boxes), initiate, update
   long frames = 0;
   template <class T>
@@ -621,7 +623,9 @@ int mot_bt_reset(mot_bt_batch* b) {
   std::vector<BtStream> h = b->h_streams;
   MOT_LC_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(BtStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
   MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
-  MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
+  MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));  // (frames still in flight have finished by now: they are dropped with the tracks)
+  for (auto& F : b->fl) F.pending = false;
+  b->fl_head = 0; b->fl_count = 0;
   b->bound_n = 0; b->hint1_n = b->hint23_n = b->hint23_m = 0;
   return MOT_OK;
 }
@@ -758,7 +762,7 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[6], st));
   MOT_LC_HIP(b, mot::launch_kf_op(6, MOT_KF_XYAH, b->pred_t, S, bn, st));  // predicted boxes of the pool (box-only: nothing is stored)
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
-  MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, true, st, b->hint1_n, 0));
+  MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, true, st, b->hint1_n, 0, true, nullptr, prof ? ev[10] : nullptr));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
   hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr, b->d_maxt);
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, bn, st));
@@ -801,6 +805,7 @@ static void bt_set_hints(mot_bt_batch* b, const int* maxt) {
 static int bt_account_events(mot_bt_batch* b, hipEvent_t* ev) {
   float ms = 0.f;
   MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[1], ev[2])); b->lap_ms[0] += ms;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[1], ev[10])); b->lap_sparse1_ms += ms;  // the first association's sparse solver alone
   MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[3], ev[4])); b->lap_ms[1] += ms;
   MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[0], ev[5])); b->frame_ms += ms;
   MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[6], ev[1])); b->kf_ms[0] += ms;
@@ -831,6 +836,7 @@ static int bt_finish_frame(mot_bt_batch* b) {
 int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float* out, int* out_counts, int cap_out) {
   hipStream_t st = b->ctx->stream;
   const int S = b->S;
+  if (b->fl_count > 0) { b->ctx->err = "mot_bt_step: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
   const int rc = bt_enqueue_frame(b, d_dets, h_counts, cap_out);
   if (rc != MOT_OK) return rc;
   MOT_LC_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
@@ -914,7 +920,7 @@ int mot_bt_enqueue_packed(mot_bt_batch* b, const float* d_dets, const int* h_cou
   MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 2, b->d_maxt, sizeof(int) * 256, hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 258, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipEventRecord(F.done, st));
-  F.pending = true; F.bd = bd;
+  F.pending = true; F.bd = bd; F.rows_cap = rows_cap;
   b->fl_count += 1;
   return MOT_OK;
 }
@@ -935,7 +941,9 @@ int mot_bt_collect_packed(mot_bt_batch* b, float* rows, int rows_cap, int* out_c
   if (total_rows) *total_rows = total;
   b->d_rows_last = F.d_packed; b->d_offsets_last = F.d_offsets; b->d_counts_last = F.d_counts;  // mot_bt_device_output: the frame just collected
   if (err) { b->ctx->err = "mot_bt_collect_packed: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
-  if (total > rows_cap || total > F.packed_cap) { b->ctx->err = "mot_bt_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  if (total > rows_cap || total > F.rows_cap) {  // (pack_rows skipped the streams that end past the ENQUEUE call's rows_cap)
+    b->ctx->err = "mot_bt_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY;
+  }
   if (total > 0) {
     MOT_LC_HIP(b, hipMemcpyAsync(rows, F.d_packed, sizeof(float) * static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, b->copy_st));
     MOT_LC_HIP(b, hipStreamSynchronize(b->copy_st));
@@ -947,6 +955,7 @@ int mot_bt_profile(mot_bt_batch* b, int enable) {
   b->profile = enable != 0;
   if (enable) {
     b->lap_ms[0] = b->lap_ms[1] = b->frame_ms = 0.0;
+    b->lap_sparse1_ms = 0.0;
     b->kf_ms[0] = b->kf_ms[1] = b->kf_ms[2] = 0.0;
     b->frames = 0;
     MOT_LC_HIP(b, hipMemsetAsync(b->d_stats, 0, 8 * 64 * sizeof(unsigned long long), b->ctx->stream));
@@ -963,6 +972,11 @@ int mot_bt_profile_stats(mot_bt_batch* b, double* out8) {
     for (int k = 0; k < 4; ++k) h[k] += raw[i * 8 + k];
   out8[0] = b->lap_ms[0]; out8[1] = b->lap_ms[1]; out8[2] = b->frame_ms; out8[3] = static_cast<double>(b->frames);
   out8[4] = static_cast<double>(h[0]); out8[5] = static_cast<double>(h[1]); out8[6] = static_cast<double>(h[2]); out8[7] = static_cast<double>(h[3]);
+  return MOT_OK;
+}
+
+int mot_bt_profile_lap_sparse(mot_bt_batch* b, double* out2) {  // HIP-event ms of the first association's sparse-solver kernel alone, launches
+  out2[0] = b->lap_sparse1_ms; out2[1] = static_cast<double>(b->frames);
   return MOT_OK;
 }
 

@@ -24,7 +24,7 @@ hipError_t launch_cosine(const mot_cos_task*, int, int, int, hipStream_t);
 // hint_n / hint_m (0: none): sizes most problems of the launch stay within, tighter than the hard bounds max_n / max_m — the sparse
 // solver sizes its LDS with them (more problems per CU) and leaves a problem that exceeds them to the exact solver
 hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, bool, hipStream_t, int hint_n = 0, int hint_m = 0, bool try_fast = true,
-                      int** declined_out = nullptr);
+                      int** declined_out = nullptr, hipEvent_t mid_event = nullptr);
 size_t lap_scratch_bytes(int n, int m);
 size_t lap_rowlist_scratch_bytes(int n);
 hipError_t lap_fast_stats(unsigned long long* out16, bool reset, hipStream_t st);
@@ -428,21 +428,29 @@ int mot_kf_update_conf_host(mot_ctx* c, int kind, int n, const float* meas4, con
   return kf_host(c, kind, 2, n, meas4, nullptr, nullptr, nullptr, mean, cov, nullptr, conf);
 }
 
-int mot_feat_update_host(mot_ctx* c, int mode, float alpha, int n, int d, float* feat, const float* src) {
+int mot_feat_update_host_alpha(mot_ctx* c, int mode, float alpha, const float* alpha_i, int n, int d, float* feat, const float* src) {
   if (n <= 0 || d <= 0) return MOT_OK;
-  if (mode < 0 || mode > 2 || !feat || !src) return MOT_ERR_INVALID;
+  if (mode < 0 || mode > 3 || !feat || !src) return MOT_ERR_INVALID;
   const size_t bytes = static_cast<size_t>(n) * d * 4;
-  DBuf df, ds, dt;
+  DBuf df, ds, dt, da;
   MOT_HIP(c, df.alloc(bytes)); MOT_HIP(c, ds.alloc(bytes)); MOT_HIP(c, dt.alloc(sizeof(mot_feat_task)));
   MOT_HIP(c, hipMemcpyAsync(df.p, feat, bytes, hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipMemcpyAsync(ds.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  if (alpha_i) {
+    MOT_HIP(c, da.alloc(static_cast<size_t>(n) * 4));
+    MOT_HIP(c, hipMemcpyAsync(da.p, alpha_i, static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, c->stream));
+  }
   mot_feat_task t{};
   t.n = n; t.d = d; t.feat = df.as<float>(); t.ldf = d; t.src = ds.as<float>(); t.lds = d; t.mode = mode; t.alpha = alpha;
+  t.alpha_i = alpha_i ? da.as<float>() : nullptr;
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, mot::launch_feat(dt.as<mot_feat_task>(), 1, n, c->stream));
   MOT_HIP(c, hipMemcpyAsync(feat, df.p, bytes, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   return MOT_OK;
+}
+int mot_feat_update_host(mot_ctx* c, int mode, float alpha, int n, int d, float* feat, const float* src) {
+  return mot_feat_update_host_alpha(c, mode, alpha, nullptr, n, d, feat, src);
 }
 
 int mot_kf_apply_host(mot_ctx* c, int kind, int op, int n, const float* meas4, const float* q3, const unsigned char* flags,

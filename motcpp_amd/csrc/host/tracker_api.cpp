@@ -137,13 +137,16 @@ Eigen::MatrixXf to_matrix(const std::vector<float>& rows) {
 // What the reference's update() does before it touches a track (checks, format and association setup, frame counter):
 // shared by the single-tracker call and by StreamBatch, so that a batched tracker rejects exactly what it rejects alone.
 // false: the frame is skipped (BoT-SORT's empty-frame early return, botsort.cpp:267-269).
-bool DeviceTracker::prepare_update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) {
+void DeviceTracker::validate_update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) const {
   if (!asso_error_.empty()) throw std::invalid_argument(asso_error_);
   if (validate_inputs_) check_inputs(dets, img, skip_empty_ ? Eigen::MatrixXf() : embs);
   // botsort.cpp reads embs.row(first_indices[i]) under an index guard; here the rows are consumed wholesale on the device
   if (embs.rows() > 0 && embs.cols() > 0 && embs.rows() != dets.rows())
     throw std::invalid_argument("motcpp_amd: embs must have one row per detection (" + std::to_string(embs.rows()) + " vs " +
                                 std::to_string(dets.rows()) + ")");
+  if (dets.rows() > 0 && dets.cols() == 7) throw std::invalid_argument("motcpp_amd: oriented boxes (7 columns) are out of scope");
+}
+bool DeviceTracker::commit_update(const Eigen::MatrixXf& dets, const cv::Mat& img) {
   if (skip_empty_ && dets.rows() == 0) {
     impl_->set_camera_motion(nullptr);  // the reference returns before its CMC step: this frame's warp is dropped
     return false;
@@ -152,6 +155,10 @@ bool DeviceTracker::prepare_update(const Eigen::MatrixXf& dets, const cv::Mat& i
   setup_association_function(img);
   ++frame_count_;
   return true;
+}
+bool DeviceTracker::prepare_update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) {
+  validate_update(dets, img, embs);
+  return commit_update(dets, img);
 }
 
 Eigen::MatrixXf DeviceTracker::update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) {
@@ -173,9 +180,12 @@ std::vector<Eigen::MatrixXf> StreamBatch::update(const std::vector<Eigen::Matrix
   std::vector<rt::Staged*> st;
   std::vector<int> who;
   static const Eigen::MatrixXf kNone;
-  for (size_t i = 0; i < trackers_.size(); ++i) {  // every stream goes through its tracker's own checks and bookkeeping
+  // every stream goes through its tracker's own checks — all of them before any tracker's bookkeeping, so that a rejected stream
+  // leaves no other tracker a frame ahead of its device state
+  for (size_t i = 0; i < trackers_.size(); ++i) trackers_[i]->validate_update(dets[i], img, i < embs.size() ? embs[i] : kNone);
+  for (size_t i = 0; i < trackers_.size(); ++i) {
     const Eigen::MatrixXf& e = i < embs.size() ? embs[i] : kNone;
-    if (!trackers_[i]->prepare_update(dets[i], img, e)) continue;  // skipped frame: empty table
+    if (!trackers_[i]->commit_update(dets[i], img)) continue;  // skipped frame: empty table
     in.push_back(make_input(dets[i], img, e));
     st.push_back(trackers_[i]->staged());
     who.push_back(static_cast<int>(i));
@@ -268,6 +278,14 @@ struct DeviceLifecycleBatch::Impl {
   std::vector<float> soa, out, embs, warps;
   std::vector<unsigned char> has_warp;
   std::vector<int> counts, out_counts;
+  ~Impl() {  // (also runs when the constructor below throws after the batch exists)
+    if (bt) mot_bt_destroy(bt);
+    if (so) mot_sort_destroy(so);
+    if (oc) mot_oc_destroy(oc);
+    if (bot) mot_bot_destroy(bot);
+    if (d_dets) mot_free(dev->ctx, d_dets);
+    if (d_embs) mot_free(dev->ctx, d_embs);
+  }
 };
 DeviceLifecycleBatch::DeviceLifecycleBatch(int kind, int nstreams, int cap_tracks, int max_dets, const float* p, int device_index, int emb_dim)
     : impl_(std::make_unique<Impl>()), n_(nstreams), cap_(cap_tracks), maxd_(max_dets) {
@@ -291,14 +309,7 @@ DeviceLifecycleBatch::DeviceLifecycleBatch(int kind, int nstreams, int cap_track
     if (mot_malloc(ctx, impl_->embs.size() * sizeof(float), &impl_->d_embs) != MOT_OK) throw std::runtime_error("motcpp_amd: device allocation failed");
   }
 }
-DeviceLifecycleBatch::~DeviceLifecycleBatch() {
-  if (impl_->bt) mot_bt_destroy(impl_->bt);
-  if (impl_->so) mot_sort_destroy(impl_->so);
-  if (impl_->oc) mot_oc_destroy(impl_->oc);
-  if (impl_->bot) mot_bot_destroy(impl_->bot);
-  if (impl_->d_dets) mot_free(impl_->dev->ctx, impl_->d_dets);
-  if (impl_->d_embs) mot_free(impl_->dev->ctx, impl_->d_embs);
-}
+DeviceLifecycleBatch::~DeviceLifecycleBatch() = default;
 void DeviceLifecycleBatch::reset() {
   std::lock_guard<std::mutex> dev_lock(impl_->dev->frame_mu);
   int rc = MOT_OK;

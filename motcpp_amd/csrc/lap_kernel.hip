@@ -228,12 +228,12 @@ int* decl_ring(int dev_slot) {
 
 // Threads per problem: one wavefront (no barriers, no LDS merges; 4-8 problems co-resident per CU) unless the problem is
 // large AND there are too few problems to fill the chip anyway, where 4 wavefronts cut the latency of a row pass.
-// try_fast = false: skip the certified sparse solver (a caller that saw it decline every problem of its previous launches — OC-SORT's
+// mid_event: recorded between the sparse solver and the exact kernel (profiling). try_fast = false: skip the certified sparse solver (a caller that saw it decline every problem of its previous launches — OC-SORT's
 // first association once quirk Q4 has put duplicated tracks into every frame — saves its enumeration; results are the exact
 // kernel's either way). declined_out: the device counter of the problems the sparse solver declined in THIS launch (valid once the
 // stream has passed the launch; the slot is recycled after kDeclSlots further launches).
 hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool geom, bool general_assoc, bool plain_costs,
-                      hipStream_t st, int hint_n, int hint_m, bool try_fast, int** declined_out) {
+                      hipStream_t st, int hint_n, int hint_m, bool try_fast, int** declined_out, hipEvent_t mid_event) {
   if (declined_out) *declined_out = nullptr;
   if (ntasks <= 0) return hipSuccess;
   // fast path first (not for the general association measures: there a pair that does not intersect has no constant cost)
@@ -256,6 +256,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
     if (declined_out) *declined_out = declined;
     e = launch_lap_sparse(tasks, ntasks, max_n, max_m, plain_costs, declined, st, hint_n, hint_m);
     if (e != hipSuccess) return e;
+    if (mid_event) { e = hipEventRecord(mid_event, st); if (e != hipSuccess) return e; }  // (profiling: the sparse kernel alone ends here)
   }
   const size_t n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1, nm = n + m;
   const size_t hot = (lap_hot_bytes(nm) + 15) & ~size_t(15);

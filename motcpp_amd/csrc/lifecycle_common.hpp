@@ -17,7 +17,7 @@ hipError_t launch_iou(const mot_iou_task*, int, int, int, bool, hipStream_t);
 // hint_n / hint_m (0: none): sizes most problems of the launch stay within, tighter than the hard bounds max_n / max_m — the sparse
 // solver sizes its LDS with them (more problems per CU) and leaves a problem that exceeds them to the exact solver
 hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, bool, hipStream_t, int hint_n = 0, int hint_m = 0, bool try_fast = true,
-                      int** declined_out = nullptr);
+                      int** declined_out = nullptr, hipEvent_t mid_event = nullptr);
 size_t lap_scratch_bytes(int n, int m);
 size_t lap_rowlist_scratch_bytes(int n);
 

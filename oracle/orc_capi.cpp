@@ -245,16 +245,20 @@ void orc_asso_batch(int kind, const float* a, int n, const float* b, int m, int 
 // Appearance post-processing. mode 0: BotSTrack ctor botsort.cpp:38-46 (set, normalise if norm > 0);
 // 1: update_features botsort.cpp:158-169 (EMA with alpha, normalise if norm > 0); 2: ReIDBackend::normalize_features
 // reid_backend.cpp:72-88 (normalise if norm > 1e-6). norm = sqrt of the k-ordered inner product (orc_math.hpp dot_chain).
-void orc_feat_update(int mode, float alpha, int n, int d, float* feat, const float* src) {
+// modes 0-2: botsort.cpp:38-46 / :158-169 / reid_backend.cpp:72-88; mode 3: DeepOC-SORT's update_emb (deepocsort.cpp:132-150): EMA with
+// the detection's own weight, normalised where the norm exceeds 1e-6. alpha_i: optional per-row weights.
+void orc_feat_update_alpha(int mode, float alpha, const float* alpha_i, int n, int d, float* feat, const float* src) {
   for (int i = 0; i < n; ++i) {
     float* f = feat + static_cast<size_t>(i) * d;
     const float* s = src + static_cast<size_t>(i) * d;
-    for (int k = 0; k < d; ++k) f[k] = (mode == 1) ? alpha * f[k] + (1.0f - alpha) * s[k] : s[k];
+    const float a = alpha_i ? alpha_i[i] : alpha;
+    for (int k = 0; k < d; ++k) f[k] = (mode == 1 || mode == 3) ? a * f[k] + (1.0f - a) * s[k] : s[k];
     const float nn = std::sqrt(dot_chain(f, f, d));
-    const bool go = (mode == 2) ? (nn > 1e-6f) : (nn > 0.0f);
+    const bool go = (mode >= 2) ? (nn > 1e-6f) : (nn > 0.0f);
     if (go) for (int k = 0; k < d; ++k) f[k] /= nn;
   }
 }
+void orc_feat_update(int mode, float alpha, int n, int d, float* feat, const float* src) { orc_feat_update_alpha(mode, alpha, nullptr, n, d, feat, src); }
 // smooth features of the live BoT-SORT tracks, dump_states order: returns rows, *d = feature length (0: none yet)
 int orc_tracker_dump_features(void* hv, float* out, int cap_floats, int* d) {
   auto* h = static_cast<Handle*>(hv);
@@ -268,6 +272,9 @@ int orc_tracker_dump_features(void* hv, float* out, int cap_floats, int* d) {
     for (int k = 0; k < *d; ++k) out[i * *d + k] = (k < static_cast<int>(f[i].size())) ? f[i][k] : 0.0f;
   return static_cast<int>(f.size());
 }
+// arithmetic mode of everything Eigen-dependent (orc_kf.hpp): 0 = the canonical order, 1 = the alternative orders
+void orc_set_arith_mode(int m) { arith_mode() = m; }
+int orc_get_arith_mode() { return arith_mode(); }
 void orc_lap_stats(long* out) {
   const LapStats& s = lap_stats();
   long v[9] = {s.n, s.free_after_colred, s.unique_rows, s.carr_iters, s.paths, s.finds, s.find_records, s.scan_rows, s.scan_ties};

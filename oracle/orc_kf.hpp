@@ -17,6 +17,17 @@
 
 namespace orc {
 
+// Arithmetic mode of the restatement (process-wide; test infrastructure for tests/test_oracle_arith_modes.py).
+// The reference's floats come out of Eigen (absent here), whose summation orders are not part of its interface: mode 0 is the order this
+// oracle — and the gfx950 kernels, bit for bit — use; mode 1 re-derives every Eigen-dependent quantity in a DIFFERENT but equally
+// plausible order, so that a test can show that assignments and track ids do not hinge on the choice:
+//   small matrix products   k-ordered mul+add            -> k-ordered with fused multiply-add (an -mfma build of the reference)
+//   4x4 Cholesky            left-looking (sums, then one subtraction) -> right-looking (the trailing block updated column by column)
+//   triangular solves       column-axpy forward          -> row-dot forward
+//   4x4 inverse (XYWH)      partial-pivot LU             -> cofactor expansion (what Eigen does for FIXED-size 4x4)
+//   dot / norm (cosine)     k-ordered fmaf chain         -> four lane sums, mul then add, pairwise combined (Eigen's SSE reduction)
+inline int& arith_mode() { static int m = 0; return m; }
+
 template <int R, int C>
 struct SMat {
   float a[R][C];
@@ -41,7 +52,8 @@ inline SMat<R, C> mul(const SMat<R, K>& A, const SMat<K, C>& B) {
   for (int i = 0; i < R; ++i)
     for (int j = 0; j < C; ++j) {
       float s = A[i][0] * B[0][j];
-      for (int k = 1; k < K; ++k) s += A[i][k] * B[k][j];
+      if (arith_mode() == 0) { for (int k = 1; k < K; ++k) s += A[i][k] * B[k][j]; }
+      else { for (int k = 1; k < K; ++k) s = std::fmaf(A[i][k], B[k][j], s); }
       o[i][j] = s;
     }
   return o;
@@ -72,6 +84,18 @@ inline SMat<R, C> sub(const SMat<R, C>& A, const SMat<R, C>& B) {
 // column below it; inner sums are formed first and subtracted once.
 template <int N>
 inline bool cholesky(SMat<N, N>& A) {
+  if (arith_mode() != 0) {  // right-looking: every column's outer product is subtracted from the trailing block as soon as it exists
+    for (int k = 0; k < N; ++k) {
+      float x = A[k][k];
+      if (!(x > 0.0f)) return false;
+      x = std::sqrt(x);
+      A[k][k] = x;
+      for (int i = k + 1; i < N; ++i) A[i][k] = A[i][k] / x;
+      for (int j = k + 1; j < N; ++j)
+        for (int i = j; i < N; ++i) A[i][j] -= A[i][k] * A[j][k];
+    }
+    return true;
+  }
   for (int k = 0; k < N; ++k) {
     float x = A[k][k];
     if (k > 0) {
@@ -97,6 +121,13 @@ inline bool cholesky(SMat<N, N>& A) {
 // Solve (L L^T) z = b in place: forward substitution column-axpy style, backward row-dot style.
 template <int N>
 inline void chol_solve(const SMat<N, N>& L, float* b) {
+  if (arith_mode() != 0) {  // forward substitution row-dot style
+    for (int i = 0; i < N; ++i) {
+      float s = 0.0f;
+      for (int j = 0; j < i; ++j) s += L[i][j] * b[j];
+      b[i] = (b[i] - s) / L[i][i];
+    }
+  } else
   for (int i = 0; i < N; ++i) {
     b[i] /= L[i][i];
     for (int r = i + 1; r < N; ++r) b[r] -= b[i] * L[r][i];
@@ -113,6 +144,25 @@ inline void chol_solve(const SMat<N, N>& L, float* b) {
 
 // Partial-pivot LU inverse of a 4x4 (Eigen's dynamic-size inverse() = partialPivLu().inverse()).
 inline SMat<4, 4> inverse_lu4(const SMat<4, 4>& S) {
+  if (arith_mode() != 0) {  // cofactor expansion
+    SMat<4, 4> inv;
+    auto det3 = [&](int r0, int r1, int r2, int c0, int c1, int c2) {
+      return S[r0][c0] * (S[r1][c1] * S[r2][c2] - S[r1][c2] * S[r2][c1]) - S[r0][c1] * (S[r1][c0] * S[r2][c2] - S[r1][c2] * S[r2][c0]) +
+             S[r0][c2] * (S[r1][c0] * S[r2][c1] - S[r1][c1] * S[r2][c0]);
+    };
+    float cof[4][4];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        int r[3], c[3], a = 0, b = 0;
+        for (int q = 0; q < 4; ++q) { if (q != i) r[a++] = q; if (q != j) c[b++] = q; }
+        const float m = det3(r[0], r[1], r[2], c[0], c[1], c[2]);
+        cof[i][j] = ((i + j) & 1) ? -m : m;
+      }
+    const float det = S[0][0] * cof[0][0] + S[0][1] * cof[0][1] + S[0][2] * cof[0][2] + S[0][3] * cof[0][3];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) inv[i][j] = cof[j][i] / det;
+    return inv;
+  }
   SMat<4, 4> lu = S;
   int perm[4] = {0, 1, 2, 3};
   for (int k = 0; k < 4; ++k) {

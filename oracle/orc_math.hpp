@@ -252,7 +252,19 @@ inline Mat fuse_score(const Mat& cost, const std::vector<float>& conf) {
 // absent here, so the oracle fixes a canonical order: a k-ordered fmaf chain (one rounding
 // per term), which is also what the gfx950 fp32 MFMA computes bit-for-bit. |difference to
 // any other fp32 order| <~ 1e-6 relative, inside the 1e-4 budget.
+inline int& arith_mode();  // orc_kf.hpp
 inline float dot_chain(const float* a, const float* b, int d) {
+  if (arith_mode() != 0) {  // four lane sums (mul, then add: no fused operation), combined pairwise, then the tail — an SSE-style reduction
+    float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, l3 = 0.0f;
+    int k = 0;
+    for (; k + 4 <= d; k += 4) {
+      const float p0 = a[k] * b[k], p1 = a[k + 1] * b[k + 1], p2 = a[k + 2] * b[k + 2], p3 = a[k + 3] * b[k + 3];
+      l0 += p0; l1 += p1; l2 += p2; l3 += p3;
+    }
+    float s = (l0 + l2) + (l1 + l3);
+    for (; k < d; ++k) { const float p = a[k] * b[k]; s += p; }
+    return s;
+  }
   float s = 0.0f;
   for (int k = 0; k < d; ++k) s = std::fmaf(a[k], b[k], s);
   return s;

@@ -92,6 +92,20 @@ int main() {
     Sort s;  // SORT never calls check_inputs (sort.cpp:102-110)
     CHECK(s.update(single, cv::Mat()).cols() == 8);
   }
+  {  // a StreamBatch frame that one stream rejects leaves NO tracker a frame ahead: every stream is validated before any is committed
+    ByteTrack a, b, ref;
+    motcpp::StreamBatch sb({&a, &b});
+    Eigen::MatrixXf bad(2, 5);  // 5 columns: check_inputs throws
+    bad.setZero();
+    bool threw = false;
+    try { sb.update({multi, bad}, img); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    auto out = sb.update({multi, single}, img);  // the first frame either tracker really sees: ByteTrack activates its tracks on frame 1 only
+    Eigen::MatrixXf r = ref.update(multi, img);
+    CHECK(out.size() == 2 && out[0].rows() == r.rows() && r.rows() == multi.rows());
+    for (int i = 0; i < r.rows(); ++i)
+      for (int k = 0; k < 8; ++k) CHECK(out[0](i, k) == r(i, k));
+  }
   {  // the device-lifecycle batch gives each stream exactly what a ByteTrack instance gives it
     motcpp::ByteTrackDeviceBatch batch(2, 64, 16);
     ByteTrack a, b;

@@ -139,11 +139,12 @@ class Oracle:
                                           C.byref(n_umd), umt.ctypes, C.byref(n_umt), C.byref(used))
         return matches[:2 * k].reshape(-1, 2).copy(), umd[:n_umd.value].copy(), umt[:n_umt.value].copy(), bool(used.value)
 
-    def feat_update(self, mode, feat, src, alpha=0.9):
+    def feat_update(self, mode, feat, src, alpha=0.9, alpha_i=None):
         feat, src = f32(feat).copy(), f32(src)
         n, d = src.shape
-        self.lib.orc_feat_update.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        self.lib.orc_feat_update(int(mode), C.c_float(alpha), n, d, feat.ctypes, src.ctypes)
+        ai = f32(alpha_i) if alpha_i is not None else None
+        self.lib.orc_feat_update_alpha.argtypes = [C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self.lib.orc_feat_update_alpha(int(mode), C.c_float(alpha), ai.ctypes if ai is not None else None, n, d, feat.ctypes, src.ctypes)
         return feat
 
     def kf_initiate(self, kind, meas):
@@ -184,6 +185,11 @@ class Oracle:
         out = np.zeros_like(boxes)
         self.lib.orc_box_convert(op, boxes.shape[0], boxes.ctypes, out.ctypes)
         return out
+
+    def set_arith_mode(self, mode):
+        """0: the canonical summation orders (what the kernels reproduce bit for bit); 1: the alternative, equally plausible orders of
+        everything that depends on Eigen in the reference (oracle/orc_kf.hpp) — process-wide"""
+        self.lib.orc_set_arith_mode(int(mode))
 
     def tracker(self, kind, params=None):
         return OracleTracker(self, kind, params)

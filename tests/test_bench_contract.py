@@ -23,3 +23,23 @@ def test_refuses_loudly_without_a_gpu():
     assert out.returncode != 0
     assert out.stdout.strip() == ""  # stdout is reserved for the JSON line
     assert "MI355X" in out.stderr or "gfx950" in out.stderr
+
+
+def test_gpus_n_starts_n_ranks_itself():
+    # `python bench.py --gpus 2` with no launcher around it: the command re-executes itself under torch.distributed.run, one process
+    # per GPU, rank r on LOCAL_RANK r. MOT_BENCH_LAUNCH_PROBE=1 stops the ranks right after the rendezvous (gloo here: no GPU is
+    # touched) and makes rank 0 report who is there.
+    import json
+    env = dict(os.environ, MOT_BENCH_LAUNCH_PROBE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                         text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1  # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["probe"] is True and d["world"] == 2
+    assert sorted(r["rank"] for r in d["ranks"]) == [0, 1]
+    assert sorted(r["local_rank"] for r in d["ranks"]) == [0, 1]
+    assert len({r["pid"] for r in d["ranks"]}) == 2  # two processes

@@ -391,10 +391,14 @@ def test_appearance_post_processing_bit_exact(ctx, orc, n, d):
         src[2] *= 1e-9          # norm below the ReID rule's 1e-6 but > 0
     old = r.standard_normal((n, d)).astype(np.float32)
     old /= np.maximum(np.linalg.norm(old, axis=1, keepdims=True), 1e-12).astype(np.float32)
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         g = ctx.feat_update(mode, old, src)
         o = orc.feat_update(mode, old, src)
         assert np.array_equal(g, o), (mode, np.abs(g - o).max())
+    # DeepOC-SORT's update_emb: EMA with a weight per detection (dets_alpha), normalised where the norm exceeds 1e-6
+    ai = r.uniform(0.5, 1.0, n).astype(np.float32)
+    g, o = ctx.feat_update(3, old, src, alpha_i=ai), orc.feat_update(3, old, src, alpha_i=ai)
+    assert np.array_equal(g, o), np.abs(g - o).max()
     if n > 3:
         assert np.array_equal(ctx.feat_update(2, old, src)[2], src[2])  # untouched by the ReID rule
         assert abs(np.linalg.norm(ctx.feat_update(0, old, src)[2]) - 1.0) < 1e-5  # but normalised by BotSTrack's

@@ -40,8 +40,14 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
   const mot_cos_task T = tasks[blockIdx.z];
   const int row0 = blockIdx.y * TILE, col0 = blockIdx.x * TILE;
   if (row0 >= T.n || col0 >= T.m) return;
-  __shared__ float As[TILE][kSlab + 1];
-  __shared__ float Bs[TILE][kSlab + 1];
+  // LDS slab of a matrix tile: row stride kLd floats; inside a row the slab's 32 k-values are stored EVEN ks first, then ODD ks
+  // (position of k = 16 (k & 1) + (k >> 1)). An MFMA step t takes k = 2 t + h from lane half h = lane >> 5, so the four operands a
+  // lane needs for four consecutive steps are one aligned 16-byte read (ds_read_b128), and eight lanes' reads hit all 32 banks once
+  // (stride 36 floats = 4 banks per row). Two slabs in LDS: the next one is written while the current one feeds the MFMAs — one barrier
+  // per slab — and its global loads were issued a slab earlier.
+  constexpr int kLd = kSlab + 4;
+  __shared__ __attribute__((aligned(16))) float As[2][TILE][kLd];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TILE][kLd];
   __shared__ float nrm[2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sr = tid / TPR, sq = tid % TPR;
@@ -54,7 +60,7 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
   }
   const bool vec = ((T.lda | T.ldb | T.d) & 3) == 0 && ((reinterpret_cast<size_t>(T.a) | reinterpret_cast<size_t>(T.b)) & 15) == 0;
   float4 ra[QPT], rb[QPT];
-  auto fetch = [&](int k0) {
+  auto fetch = [&](int k0) {  // (entries beyond d are zeros: they extend every chain by fma(0, 0, s) = s)
 #pragma unroll
     for (int h = 0; h < QPT; ++h) {
       const int k = k0 + 4 * (h * TPR + sq);
@@ -74,6 +80,17 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
       ra[h] = va; rb[h] = vb;
     }
   };
+  auto stage = [&](int buf) {  // registers -> LDS slab `buf`: k, k+2 to the even half, k+1, k+3 to the odd half (two 8-byte stores each)
+#pragma unroll
+    for (int h = 0; h < QPT; ++h) {
+      const int k = 4 * (h * TPR + sq);
+      *reinterpret_cast<float2*>(&As[buf][sr][k >> 1]) = make_float2(ra[h].x, ra[h].z);
+      *reinterpret_cast<float2*>(&As[buf][sr][16 + (k >> 1)]) = make_float2(ra[h].y, ra[h].w);
+      *reinterpret_cast<float2*>(&Bs[buf][sr][k >> 1]) = make_float2(rb[h].x, rb[h].z);
+      *reinterpret_cast<float2*>(&Bs[buf][sr][16 + (k >> 1)]) = make_float2(rb[h].y, rb[h].w);
+    }
+  };
+  auto at = [](int kk) { return 16 * (kk & 1) + (kk >> 1); };  // position of slab entry kk inside a row
   const int wr = wave >> 1, wc = wave & 1;  // wavefront -> (TILE/2) x (TILE/2) sub-tile
   f32x16 acc[NA][NA];
 #pragma unroll
@@ -88,44 +105,59 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
   const int q = (NQ == 2) ? wave * 64 + lane : wave * 32 + (lane & 31);
   float nsum = 0.0f;
   fetch(0);
+  stage(0);
+  if (kSlab < T.d) fetch(kSlab);
+  __syncthreads();
+  int buf = 0;
   for (int k0 = 0; k0 < T.d; k0 += kSlab) {
-#pragma unroll
-    for (int h = 0; h < QPT; ++h) {
-      const int k = 4 * (h * TPR + sq);
-      As[sr][k] = ra[h].x; As[sr][k + 1] = ra[h].y; As[sr][k + 2] = ra[h].z; As[sr][k + 3] = ra[h].w;
-      Bs[sr][k] = rb[h].x; Bs[sr][k + 1] = rb[h].y; Bs[sr][k + 2] = rb[h].z; Bs[sr][k + 3] = rb[h].w;
-    }
-    __syncthreads();
-    if (k0 + kSlab < T.d) fetch(k0 + kSlab);  // in flight while this slab is consumed
-    const int kk_end = min(kSlab, T.d - k0);
     if constexpr (METRIC == kEuclid) {
       // 64 x 64 distances on the vector ALUs: thread -> row tid >> 2, columns (tid & 3) + 4 j; chains in k order
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         float sacc = acc[0][0][j];
         const int cc = sq + 4 * j;
-        for (int kk = 0; kk < kk_end; ++kk) { const float df = As[sr][kk] - Bs[cc][kk]; sacc = __builtin_fmaf(df, df, sacc); }
+        for (int kk = 0; kk < kSlab; ++kk) { const float df = As[buf][sr][at(kk)] - Bs[buf][cc][at(kk)]; sacc = __builtin_fmaf(df, df, sacc); }
         acc[0][0][j] = sacc;
       }
     } else {
       if (METRIC == kCosine && norm_lane) {
-        const float* rowp = (q < TILE) ? As[q] : Bs[q - TILE];
-        for (int kk = 0; kk < kk_end; ++kk) nsum = __builtin_fmaf(rowp[kk], rowp[kk], nsum);
+        const float* rowp = (q < TILE) ? As[buf][q] : Bs[buf][q - TILE];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // even and odd halves by 16-byte reads, consumed in k order
+          const float4 ev = *reinterpret_cast<const float4*>(rowp + 4 * g), od = *reinterpret_cast<const float4*>(rowp + 16 + 4 * g);
+          nsum = __builtin_fmaf(ev.x, ev.x, nsum); nsum = __builtin_fmaf(od.x, od.x, nsum);
+          nsum = __builtin_fmaf(ev.y, ev.y, nsum); nsum = __builtin_fmaf(od.y, od.y, nsum);
+          nsum = __builtin_fmaf(ev.z, ev.z, nsum); nsum = __builtin_fmaf(od.z, od.z, nsum);
+          nsum = __builtin_fmaf(ev.w, ev.w, nsum); nsum = __builtin_fmaf(od.w, od.w, nsum);
+        }
       }
-      for (int kk = 0; kk < kk_end; kk += 2) {  // k-ascending chain: D = fma(a_k1,b_k1, fma(a_k0,b_k0, C))
-        float a[NA], b[NA];
+      const int hoff = 16 * (lane >> 5);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // four MFMA steps per 16-byte operand read; k-ascending chain: D = fma(a_k1,b_k1, fma(a_k0,b_k0, C))
+        float4 a4[NA], b4[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-          a[i] = As[wr * (TILE / 2) + 32 * i + (lane & 31)][kk + (lane >> 5)];
-          b[i] = Bs[wc * (TILE / 2) + 32 * i + (lane & 31)][kk + (lane >> 5)];
+          a4[i] = *reinterpret_cast<const float4*>(&As[buf][wr * (TILE / 2) + 32 * i + (lane & 31)][hoff + 4 * g]);
+          b4[i] = *reinterpret_cast<const float4*>(&Bs[buf][wc * (TILE / 2) + 32 * i + (lane & 31)][hoff + 4 * g]);
         }
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int j = 0; j < NA; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+              const float av = (e == 0) ? a4[i].x : (e == 1) ? a4[i].y : (e == 2) ? a4[i].z : a4[i].w;
+              const float bv = (e == 0) ? b4[j].x : (e == 1) ? b4[j].y : (e == 2) ? b4[j].z : b4[j].w;
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+            }
       }
     }
+    if (k0 + kSlab < T.d) {
+      stage(buf ^ 1);                                   // the slab fetched while the previous one was consumed
+      if (k0 + 2 * kSlab < T.d) fetch(k0 + 2 * kSlab);  // and the one after it is requested now
+    }
     __syncthreads();
+    buf ^= 1;
   }
   if constexpr (METRIC == kEuclid) {
     const int r = row0 + sr;

@@ -64,6 +64,7 @@ struct DevGroup {
   static constexpr bool kWaveTable = true;
   __device__ __forceinline__ int wave_lane() const { return tid_ & 63; }
   static __device__ __forceinline__ int wave_get(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+  static __device__ __forceinline__ unsigned long long wave_ballot(bool f) { return __builtin_amdgcn_ballot_w64(f); }
   static __device__ __forceinline__ double wave_get(double v, int src) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
   }
@@ -155,6 +156,7 @@ struct DevGroup {
     for (int w = 1; w < nw; ++w) { int o = s[w]; r = (o > r) ? o : r; }
     return r;
   }
+  static __device__ __forceinline__ int wave_min_i32(int v) { return -wave_max_i32(-v); }
   __device__ __forceinline__ int reduce_min_int(int v) { return -reduce_max(-v); }
   // two lexicographically smallest (value,index) pairs of the group: wave-level in two DPP passes (the winner,
   // then the best of everything else), wavefront partials merged through LDS

@@ -1446,7 +1446,47 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 if (off < nev) W.fsw[kHE + off] = e;
               }
               g.sync_lds();
-              if (t == 0) {
+              bool by_wave = false;
+              if constexpr (has_wave_table<G>::value) {
+                // the first wavefront replays out of registers: lane e holds sorted event e and head slot e, the serial walk reads
+                // them with v_readlane and finds the next event with one ballot and one DPP minimum (an LDS round trip per field
+                // and event otherwise)
+                if (nev <= 64) {
+                  by_wave = true;
+                  if (t < 64) {
+                    const bool in = t < nev;
+                    const int vq = in ? static_cast<int>(W.fsw[kSQ + t]) : kNoIdx, vj = in ? static_cast<int>(W.fsw[kSJ + t]) : 0;
+                    int vk = in ? static_cast<int>(W.fsw[kSK + t]) : kNoIdx, vf = in ? static_cast<int>(W.fsw[kSF + t]) : 2;
+                    int hc = in ? static_cast<int>(W.fsw[kHC + t]) : 0, he = in ? static_cast<int>(W.fsw[kHE + t]) : -1;
+                    int dn = 0, sk = -1;
+                    for (int r = 0; r < nev; ++r) {
+                      const int e0 = __builtin_ctzll(G::wave_ballot(!(vf & 2)));  // first event not applied yet, in sorted order
+                      const int q = G::wave_get(vq, e0);
+                      const int cand = (!(vf & 2) && vq == q) ? vk : kNoIdx;      // its member's events: the one lowest in cols[] NOW is next
+                      const int bp = G::wave_min_i32(cand);
+                      const int best = __builtin_ctzll(G::wave_ballot(cand == bp));
+                      const int j = G::wave_get(vj, best), fl = G::wave_get(vf, best);
+                      if (fl & 1) { sk = j; break; }
+                      if (t == best) vf |= 2;
+                      const int hpos = static_cast<int>(shi) + r;
+                      if (bp != hpos) {
+                        const int hcr = G::wave_get(hc, r), her = G::wave_get(he, r);
+                        const int off = bp - static_cast<int>(shi);
+                        if (off < nev) { if (t == off) { hc = hcr; he = her; } }
+                        else if (t == 0) { W.cols[bp] = hcr; W.inv[hcr] = bp; }
+                        if (her >= 0 && t == her) vk = bp;
+                      }
+                      if (t == 0) {
+                        W.cols[hpos] = j; W.inv[j] = hpos;
+                        W.fsw[kFsTodo + (j >> 5)] = static_cast<int>(W.fsw[kFsTodo + (j >> 5)]) & ~(1 << (j & 31));
+                      }
+                      ++dn;
+                    }
+                    if (t == 0) { W.fsw[kCDONE] = dn; W.fsw[kCSINK] = sk; }
+                  }
+                }
+              }
+              if (!by_wave && t == 0) {
                 int dn = 0, sk = -1, e0 = 0;
                 for (int r = 0; r < nev; ++r) {
                   while (static_cast<int>(W.fsw[kSF + e0]) & 2) ++e0;

@@ -1,10 +1,11 @@
 """Turns the per-kernel PMC sums of tools/collect_profiles.sh into the two small files bench.py quotes:
   profiles/pmc_<WL>.json            HBM bytes per assignment problem (FETCH_SIZE doubled: gfx950 reports half of wide reads)
   profiles/<tag>_pmc_sq_lap.json    SQ counters of the dominant assignment kernel per problem (= per workgroup)
-usage: python tools/pmc_derive.py <tag> <WL> <streams of the PMC passes>"""
+usage: python tools/pmc_derive.py <tag> <WL> <streams per launch (= per sub-batch) of the PMC passes> ["<bench command of the passes>"]"""
 import json, os, sys
 
 tag, wl, S = sys.argv[1], sys.argv[2], int(sys.argv[3])
+cmd = sys.argv[4] if len(sys.argv) > 4 else f"bench.py --workload {wl} --streams {S} --pipeline 1 --steps 2 --warmup 5"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 ld = lambda n: json.load(open(os.path.join(P, f"{tag}_pmc_{n}_{wl}.json")))
@@ -16,8 +17,7 @@ disp = fetch[main]["FETCH_SIZE"]["dispatches"]
 per_launch = 1.5 * S  # ByteTrack: S first-association problems in one launch, 2S (second + unconfirmed) in the other
 fb = sum(fetch[k]["FETCH_SIZE"]["sum"] for k in laps) * 1024.0 / disp
 wb = sum(write[k]["WRITE_SIZE"]["sum"] for k in laps if k in write) * 1024.0 / disp
-out = {"_comment": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --workload {wl} --streams {S} --pipeline 1 --steps 2 "
-                   f"--warmup 5` (device lifecycle); kernels {laps}; KB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md (an upper bound for "
+out = {"_comment": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `{cmd}` (device lifecycle, {S} streams per launch); kernels {laps}; KB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md (an upper bound for "
                    f"4-byte accesses). Raw sums: {tag}_pmc_fetch_{wl}.json, {tag}_pmc_write_{wl}.json",
        "lap": {"fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb, "problems_per_launch": per_launch,
                "hbm_bytes_per_problem": (2.0 * fb + wb) / per_launch}}

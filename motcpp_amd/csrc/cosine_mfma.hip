@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/motcpp_amd.h"
 
@@ -32,13 +33,26 @@ enum { kCosine = 0, kDot = 1, kEuclid = 2 };
 // and half the feature bytes per flop out of L2 (each row tile is re-read once per column tile of the problem: at 64 x 64 the
 // fp32 MFMA rate would need ~10 TB/s of L2 reads). Every output element is still the k-ordered chain of its own products.
 template <int METRIC, int TILE>
-__global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __restrict__ tasks) {
+__global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __restrict__ tasks, int tiles_x, int tiles_y) {
   constexpr int TPR = kThreads / TILE;  // threads staging one row of a slab
   constexpr int QPT = 8 / TPR;          // 16-byte pieces of a slab row per thread
   constexpr int NA = TILE / 64;         // MFMA tiles per wavefront and dimension
   static_assert(METRIC != kEuclid || TILE == 64, "the euclidean variant keeps the 64 x 64 tile");
-  const mot_cos_task T = tasks[blockIdx.z];
-  const int row0 = blockIdx.y * TILE, col0 = blockIdx.x * TILE;
+  // XCD-aware order of the 1-D grid: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own L2.
+  // The tiles of one task share its feature rows (a row tile is read by every column tile, and the other way round), so the ids an
+  // XCD receives are mapped to CONSECUTIVE tiles: a task's tiles run on one XCD at about the same time and meet in its L2 instead of
+  // each fetching the features from HBM.
+  int v;
+  {
+    const int N = static_cast<int>(gridDim.x), L = static_cast<int>(blockIdx.x), x = L & 7;
+    const int base = N >> 3, rem = N & 7;                  // XCD y owns base + (y < rem) ids
+    v = x * base + ((x < rem) ? x : rem) + (L >> 3);
+  }
+  const int per_task = tiles_x * tiles_y;
+  const int task = v / per_task, tv = v - task * per_task;
+  const int ty = tv / tiles_x, tx = tv - ty * tiles_x;
+  const mot_cos_task T = tasks[task];
+  const int row0 = ty * TILE, col0 = tx * TILE;
   if (row0 >= T.n || col0 >= T.m) return;
   // LDS slab of a matrix tile: row stride kLd floats; inside a row the slab's 32 k-values are stored EVEN ks first, then ODD ks
   // (position of k = 16 (k & 1) + (k >> 1)). An MFMA step t takes k = 2 t + h from lane half h = lane >> 5, so the four operands a
@@ -60,7 +74,19 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
   }
   const bool vec = ((T.lda | T.ldb | T.d) & 3) == 0 && ((reinterpret_cast<size_t>(T.a) | reinterpret_cast<size_t>(T.b)) & 15) == 0;
   float4 ra[QPT], rb[QPT];
-  auto fetch = [&](int k0) {  // (entries beyond d are zeros: they extend every chain by fma(0, 0, s) = s)
+  const float* pa_ld = pa ? pa : T.a;  // (rows outside the problem load a valid address and are zeroed by a select: no branch, so
+  const float* pb_ld = pb ? pb : T.b;  //  that the loads stay in flight until the values are staged — a branch would wait for them)
+  auto fetch = [&](auto fast, int k0) {  // (entries beyond d are zeros: they extend every chain by fma(0, 0, s) = s)
+    if constexpr (decltype(fast)::value) {  // whole slabs of aligned rows: unconditional 16-byte loads
+#pragma unroll
+      for (int h = 0; h < QPT; ++h) {
+        const int k = k0 + 4 * (h * TPR + sq);
+        const float4 va = *reinterpret_cast<const float4*>(pa_ld + k), vb = *reinterpret_cast<const float4*>(pb_ld + k);
+        ra[h] = pa ? va : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[h] = pb ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
 #pragma unroll
     for (int h = 0; h < QPT; ++h) {
       const int k = k0 + 4 * (h * TPR + sq);
@@ -90,7 +116,6 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
       *reinterpret_cast<float2*>(&Bs[buf][sr][16 + (k >> 1)]) = make_float2(rb[h].y, rb[h].w);
     }
   };
-  auto at = [](int kk) { return 16 * (kk & 1) + (kk >> 1); };  // position of slab entry kk inside a row
   const int wr = wave >> 1, wc = wave & 1;  // wavefront -> (TILE/2) x (TILE/2) sub-tile
   f32x16 acc[NA][NA];
 #pragma unroll
@@ -104,61 +129,75 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
   const bool norm_lane = (NQ == 2) || lane < 32;
   const int q = (NQ == 2) ? wave * 64 + lane : wave * 32 + (lane & 31);
   float nsum = 0.0f;
-  fetch(0);
-  stage(0);
-  if (kSlab < T.d) fetch(kSlab);
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = 0; k0 < T.d; k0 += kSlab) {
-    if constexpr (METRIC == kEuclid) {
-      // 64 x 64 distances on the vector ALUs: thread -> row tid >> 2, columns (tid & 3) + 4 j; chains in k order
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float sacc = acc[0][0][j];
-        const int cc = sq + 4 * j;
-        for (int kk = 0; kk < kSlab; ++kk) { const float df = As[buf][sr][at(kk)] - Bs[buf][cc][at(kk)]; sacc = __builtin_fmaf(df, df, sacc); }
-        acc[0][0][j] = sacc;
-      }
-    } else {
-      if (METRIC == kCosine && norm_lane) {
-        const float* rowp = (q < TILE) ? As[buf][q] : Bs[buf][q - TILE];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {  // even and odd halves by 16-byte reads, consumed in k order
-          const float4 ev = *reinterpret_cast<const float4*>(rowp + 4 * g), od = *reinterpret_cast<const float4*>(rowp + 16 + 4 * g);
-          nsum = __builtin_fmaf(ev.x, ev.x, nsum); nsum = __builtin_fmaf(od.x, od.x, nsum);
-          nsum = __builtin_fmaf(ev.y, ev.y, nsum); nsum = __builtin_fmaf(od.y, od.y, nsum);
-          nsum = __builtin_fmaf(ev.z, ev.z, nsum); nsum = __builtin_fmaf(od.z, od.z, nsum);
-          nsum = __builtin_fmaf(ev.w, ev.w, nsum); nsum = __builtin_fmaf(od.w, od.w, nsum);
-        }
-      }
-      const int hoff = 16 * (lane >> 5);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {  // four MFMA steps per 16-byte operand read; k-ascending chain: D = fma(a_k1,b_k1, fma(a_k0,b_k0, C))
-        float4 a4[NA], b4[NA];
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-          a4[i] = *reinterpret_cast<const float4*>(&As[buf][wr * (TILE / 2) + 32 * i + (lane & 31)][hoff + 4 * g]);
-          b4[i] = *reinterpret_cast<const float4*>(&Bs[buf][wc * (TILE / 2) + 32 * i + (lane & 31)][hoff + 4 * g]);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < NA; ++i)
-#pragma unroll
-            for (int j = 0; j < NA; ++j) {
-              const float av = (e == 0) ? a4[i].x : (e == 1) ? a4[i].y : (e == 2) ? a4[i].z : a4[i].w;
-              const float bv = (e == 0) ? b4[j].x : (e == 1) ? b4[j].y : (e == 2) ? b4[j].z : b4[j].w;
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-            }
-      }
-    }
-    if (k0 + kSlab < T.d) {
-      stage(buf ^ 1);                                   // the slab fetched while the previous one was consumed
-      if (k0 + 2 * kSlab < T.d) fetch(k0 + 2 * kSlab);  // and the one after it is requested now
-    }
+  auto contract = [&](auto fast) {
+    fetch(fast, 0);
+    stage(0);
+    if (kSlab < T.d) fetch(fast, kSlab);
     __syncthreads();
-    buf ^= 1;
-  }
+    int buf = 0;
+    for (int k0 = 0; k0 < T.d; k0 += kSlab) {
+      if constexpr (METRIC == kEuclid) {
+        // 64 x 64 distances on the vector ALUs: thread -> row tid >> 2, columns (tid & 3) + 4 j; chains in k order
+  #pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float sacc = acc[0][0][j];
+          const int cc = sq + 4 * j;
+  #pragma unroll
+          for (int g = 0; g < 4; ++g) {  // even and odd halves by 16-byte reads (the same access type as the stores: float vectors), k order
+            const float4 ae = *reinterpret_cast<const float4*>(&As[buf][sr][4 * g]), ao = *reinterpret_cast<const float4*>(&As[buf][sr][16 + 4 * g]);
+            const float4 be = *reinterpret_cast<const float4*>(&Bs[buf][cc][4 * g]), bo = *reinterpret_cast<const float4*>(&Bs[buf][cc][16 + 4 * g]);
+            float df;
+            df = ae.x - be.x; sacc = __builtin_fmaf(df, df, sacc); df = ao.x - bo.x; sacc = __builtin_fmaf(df, df, sacc);
+            df = ae.y - be.y; sacc = __builtin_fmaf(df, df, sacc); df = ao.y - bo.y; sacc = __builtin_fmaf(df, df, sacc);
+            df = ae.z - be.z; sacc = __builtin_fmaf(df, df, sacc); df = ao.z - bo.z; sacc = __builtin_fmaf(df, df, sacc);
+            df = ae.w - be.w; sacc = __builtin_fmaf(df, df, sacc); df = ao.w - bo.w; sacc = __builtin_fmaf(df, df, sacc);
+          }
+          acc[0][0][j] = sacc;
+        }
+      } else {
+        if (METRIC == kCosine && norm_lane) {
+          const float* rowp = (q < TILE) ? As[buf][q] : Bs[buf][q - TILE];
+  #pragma unroll
+          for (int g = 0; g < 4; ++g) {  // even and odd halves by 16-byte reads, consumed in k order
+            const float4 ev = *reinterpret_cast<const float4*>(rowp + 4 * g), od = *reinterpret_cast<const float4*>(rowp + 16 + 4 * g);
+            nsum = __builtin_fmaf(ev.x, ev.x, nsum); nsum = __builtin_fmaf(od.x, od.x, nsum);
+            nsum = __builtin_fmaf(ev.y, ev.y, nsum); nsum = __builtin_fmaf(od.y, od.y, nsum);
+            nsum = __builtin_fmaf(ev.z, ev.z, nsum); nsum = __builtin_fmaf(od.z, od.z, nsum);
+            nsum = __builtin_fmaf(ev.w, ev.w, nsum); nsum = __builtin_fmaf(od.w, od.w, nsum);
+          }
+        }
+        const int hoff = 16 * (lane >> 5);
+  #pragma unroll
+        for (int g = 0; g < 4; ++g) {  // four MFMA steps per 16-byte operand read; k-ascending chain: D = fma(a_k1,b_k1, fma(a_k0,b_k0, C))
+          float4 a4[NA], b4[NA];
+  #pragma unroll
+          for (int i = 0; i < NA; ++i) {
+            a4[i] = *reinterpret_cast<const float4*>(&As[buf][wr * (TILE / 2) + 32 * i + (lane & 31)][hoff + 4 * g]);
+            b4[i] = *reinterpret_cast<const float4*>(&Bs[buf][wc * (TILE / 2) + 32 * i + (lane & 31)][hoff + 4 * g]);
+          }
+  #pragma unroll
+          for (int e = 0; e < 4; ++e)
+  #pragma unroll
+            for (int i = 0; i < NA; ++i)
+  #pragma unroll
+              for (int j = 0; j < NA; ++j) {
+                const float av = (e == 0) ? a4[i].x : (e == 1) ? a4[i].y : (e == 2) ? a4[i].z : a4[i].w;
+                const float bv = (e == 0) ? b4[j].x : (e == 1) ? b4[j].y : (e == 2) ? b4[j].z : b4[j].w;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+              }
+        }
+      }
+      if (k0 + kSlab < T.d) {
+        stage(buf ^ 1);                                   // the slab fetched while the previous one was consumed
+        if (k0 + 2 * kSlab < T.d) fetch(fast, k0 + 2 * kSlab);  // and the one after it is requested now
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  };
+  // two instances of the loop: the common case (aligned rows, d a multiple of the slab) has no branch around its loads, so they stay in
+  // flight across the MFMAs of the current slab; everything else takes the guarded loads
+  if (vec && (T.d % kSlab) == 0) contract(std::true_type()); else contract(std::false_type());
   if constexpr (METRIC == kEuclid) {
     const int r = row0 + sr;
     if (r < T.n) {
@@ -207,12 +246,15 @@ hipError_t launch_embed(int metric, const mot_cos_task* tasks, int ntasks, int m
   static const bool force64 = std::getenv("MOT_EMBED_TILE64") != nullptr;  // measurement aid (A/B of the two tilings)
   const bool big = max_n >= 128 && max_m >= 128 && metric != kEuclid && !force64;
   const int tile = big ? 128 : 64;
-  dim3 g2((max_m + tile - 1) / tile, (max_n + tile - 1) / tile, ntasks);
-  if (metric == kCosine && big) hipLaunchKernelGGL((embed_kernel<kCosine, 128>), g2, dim3(kThreads), 0, st, tasks);
-  else if (metric == kCosine) hipLaunchKernelGGL((embed_kernel<kCosine, 64>), g2, dim3(kThreads), 0, st, tasks);
-  else if (metric == kDot && big) hipLaunchKernelGGL((embed_kernel<kDot, 128>), g2, dim3(kThreads), 0, st, tasks);
-  else if (metric == kDot) hipLaunchKernelGGL((embed_kernel<kDot, 64>), g2, dim3(kThreads), 0, st, tasks);
-  else if (metric == kEuclid) hipLaunchKernelGGL((embed_kernel<kEuclid, 64>), g2, dim3(kThreads), 0, st, tasks);
+  const int tx = (max_m + tile - 1) / tile, ty = (max_n + tile - 1) / tile;
+  const long long nblk = static_cast<long long>(tx) * ty * ntasks;
+  if (nblk > 0x7fffffffll) return hipErrorInvalidValue;
+  const dim3 g1(static_cast<unsigned>(nblk));
+  if (metric == kCosine && big) hipLaunchKernelGGL((embed_kernel<kCosine, 128>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
+  else if (metric == kCosine) hipLaunchKernelGGL((embed_kernel<kCosine, 64>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
+  else if (metric == kDot && big) hipLaunchKernelGGL((embed_kernel<kDot, 128>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
+  else if (metric == kDot) hipLaunchKernelGGL((embed_kernel<kDot, 64>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
+  else if (metric == kEuclid) hipLaunchKernelGGL((embed_kernel<kEuclid, 64>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

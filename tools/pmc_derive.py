@@ -14,7 +14,8 @@ fetch, write, sq1, sq2 = ld("fetch"), ld("write"), ld("sq1"), ld("sq2")
 laps = [k for k in fetch if k.startswith("lap_")]
 main = max((k for k in laps if k.startswith("lap_sparse")), key=lambda k: fetch[k]["FETCH_SIZE"]["sum"])
 disp = fetch[main]["FETCH_SIZE"]["dispatches"]
-per_launch = 1.5 * S  # ByteTrack: S first-association problems in one launch, 2S (second + unconfirmed) in the other
+per_frame = 3.0 * S  # ByteTrack: S first-association problems in one launch, 2S (second + unconfirmed) in the other: both launches are summed
+per_launch = per_frame
 fb = sum(fetch[k]["FETCH_SIZE"]["sum"] for k in laps) * 1024.0 / disp
 wb = sum(write[k]["WRITE_SIZE"]["sum"] for k in laps if k in write) * 1024.0 / disp
 out = {"_comment": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `{cmd}` (device lifecycle, {S} streams per launch); kernels {laps}; KB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md (an upper bound for "
@@ -25,8 +26,8 @@ json.dump(out, open(os.path.join(P, f"pmc_{wl}.json"), "w"), indent=1)
 c = {}
 for src in (sq1, sq2):
     for name, v in src[main].items():
-        c[name] = v["sum"] / v["dispatches"] / per_launch
-sq = {"kernel": main, "problems_per_launch": per_launch, "waves_per_problem": c.get("SQ_WAVES"),
+        c[name] = v["sum"] / v["dispatches"] / S  # (the dominant kernel = the first association's sparse solver: S problems per dispatch)
+sq = {"kernel": main, "problems_per_launch": S, "waves_per_problem": c.get("SQ_WAVES"),
       "per_problem": {k: round(v, 1) for k, v in c.items() if k != "SQ_WAVES"},
       "active_frac": round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3), "wait_any_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3)}
 path = os.path.join(P, f"{tag}_pmc_sq_lap.json")

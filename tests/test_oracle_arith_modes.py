@@ -2,7 +2,7 @@
 This test shows that nothing the parity claims rest on depends on that choice: every stream is tracked twice — arithmetic mode 0 (the
 canonical orders, which the gfx950 kernels reproduce bit for bit) and mode 1 (fused multiply-adds in the small matrix products, a
 right-looking Cholesky, row-dot triangular solves, a cofactor 4x4 inverse, an SSE-style four-lane dot product: oracle/orc_kf.hpp) — over
-200 frames of the BASELINE shapes, and every assignment (index for index), every emitted id and detection index must be identical,
+200 frames of the BASELINE shapes (100 for C3), and every assignment (index for index), every emitted id and detection index must be identical,
 the boxes within 1e-4 relative. tools/arith_mode_report.py runs the same comparison over 8 seeds (profiles/r03_arith_modes.json)."""
 import os
 import sys
@@ -16,8 +16,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 @pytest.mark.parametrize("cfg,seed", [("C2", 1234), ("NS", 1234), ("C3", 1234), ("C4x", 1234), ("C4x", 99), ("SORT", 7)])
 def test_assignments_and_ids_do_not_depend_on_the_summation_order(orc, cfg, seed):
     import arith_mode_report as amr
-    r = amr.compare_stream(orc, cfg, seed, 200)
-    assert r["frames"] == 200 and r["problems"] > 150
+    frames = 100 if cfg == "C3" else 200  # (BoT-SORT 1024 x 512 x 256-d runs 17 frames/s per mode here; the 8-seed report has 200)
+    r = amr.compare_stream(orc, cfg, seed, frames)
+    assert r["frames"] == frames and r["problems"] > 0.7 * frames
     assert r["assignment_mismatches"] == 0 and r["id_mismatch_frames"] == 0, r
     assert r["max_rel_box_diff"] <= 1e-4, r
     if cfg == "C3":  # the one place where the order is visible at all: the cosine distances (the Kalman innovations covariances of

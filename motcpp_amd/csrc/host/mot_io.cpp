@@ -10,11 +10,12 @@
 namespace motcpp::data {
 
 MOT17Dataset::MOT17Dataset(const std::string& mot_root, const std::string& det_emb_root, const std::string& model_name,
-                           const std::string& /*reid_name*/)
+                           const std::string& reid_name)
     : mot_root_(mot_root) {
   if (!det_emb_root.empty() && !model_name.empty()) {  // :18-28
     const std::filesystem::path direct = std::filesystem::path(det_emb_root) / "dets";
     det_path_ = std::filesystem::exists(direct) ? direct : std::filesystem::path(det_emb_root) / model_name / "dets";
+    if (!reid_name.empty()) emb_dir_ = std::filesystem::path(det_emb_root) / model_name / "embs" / reid_name;  // tools/motcpp_eval.cpp:77
   }
   index_sequences();
 }
@@ -126,6 +127,40 @@ std::map<int, Eigen::MatrixXf> MOT17Dataset::load_detections(const std::filesyst
     for (int i = 0; i < n; ++i)
       for (int k = 0; k < 6; ++k) m(i, k) = flat[static_cast<size_t>(i) * 6 + k];
     out.emplace(frame, std::move(m));
+  }
+  return out;
+}
+
+std::filesystem::path MOT17Dataset::embedding_path(const std::string& seq_name) const {
+  return emb_dir_.empty() ? std::filesystem::path() : emb_dir_ / short_det_name(seq_name);
+}
+
+// :243-294. Line k = the k-th detection; detections counted frame by frame in ascending frame order (see the header).
+std::map<int, Eigen::MatrixXf> MOT17Dataset::load_embeddings(const std::filesystem::path& emb_path,
+                                                             const std::map<int, Eigen::MatrixXf>& detections) const {
+  std::map<int, Eigen::MatrixXf> out;
+  if (emb_path.empty() || !std::filesystem::exists(emb_path)) return out;
+  std::ifstream file(emb_path);
+  auto frame = detections.begin();
+  int row = 0;
+  std::map<int, std::vector<std::vector<float>>> rows;
+  for (std::string line; std::getline(file, line);) {
+    if (line.empty() || line[0] == '#') continue;
+    while (frame != detections.end() && row >= frame->second.rows()) { ++frame; row = 0; }
+    if (frame == detections.end()) break;  // more lines than detections (:265)
+    std::vector<float> v;
+    std::istringstream iss(line);
+    for (float x; iss >> x;) v.push_back(x);
+    if (v.empty()) continue;  // (:278: the line is dropped without consuming a detection)
+    rows[frame->first].push_back(std::move(v));
+    ++row;
+  }
+  for (auto& [f, rr] : rows) {
+    const int d = static_cast<int>(rr.back().size());  // the reference resizes to the newest row's width (:287)
+    Eigen::MatrixXf m(static_cast<int>(rr.size()), d);
+    for (int i = 0; i < m.rows(); ++i)
+      for (int k = 0; k < d; ++k) m(i, k) = k < static_cast<int>(rr[i].size()) ? rr[i][k] : 0.0f;
+    out.emplace(f, std::move(m));
   }
   return out;
 }

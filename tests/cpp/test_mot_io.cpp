@@ -34,6 +34,22 @@ int main(int argc, char** argv) {
     std::printf("NOTFOUND %d\n", threw ? 1 : 0);
     return 0;
   }
+  if (mode == "embs") {  // embs <mot_root> <det_emb_root> <model_name> <reid_name>: per sequence and frame the rows, width and a checksum
+    motcpp::data::MOT17Dataset ds(argv[2], argv[3], argv[4], argv[5]);
+    for (const auto& name : ds.sequence_names()) {
+      const auto s = ds.get_sequence_info(name);
+      const auto dets = ds.load_detections(s.det_path);
+      const auto embs = ds.load_embeddings(ds.embedding_path(name), dets);
+      std::printf("EMB %s file=%s frames=%zu\n", name.c_str(), ds.embedding_path(name).filename().string().c_str(), embs.size());
+      for (const auto& [f, m] : embs) {
+        double sum = 0.0;
+        for (int i = 0; i < m.rows(); ++i)
+          for (int k = 0; k < m.cols(); ++k) sum += static_cast<double>(m(i, k)) * (i + 1) * (k + 1);
+        std::printf("F %d rows=%d dets=%d d=%d sum=%.4f\n", f, static_cast<int>(m.rows()), static_cast<int>(dets.at(f).rows()), static_cast<int>(m.cols()), sum);
+      }
+    }
+    return 0;
+  }
   if (mode == "write") {  // write <out_file>: a fixed table through convert_to_mot_format + write_mot_results (twice: it appends)
     Eigen::MatrixXf t(3, 8);
     t << 100.7f, 50.2f, 180.9f, 260.4f, 7, 0.912345678f, 0, 3,

@@ -151,3 +151,69 @@ def test_cli_ablation_offset(tmp_path, orc):
     assert open(os.path.join(res, "MOT17-02-FRCNN.txt")).read() == "".join(want)
     first = open(os.path.join(res, "MOT17-04-FRCNN.txt")).readline()
     assert int(first.split(",")[0]) >= 1 and "1050" in open(os.path.join(res, "MOT17-04-FRCNN.txt")).read()
+
+
+def make_pregenerated(tmp, D=8, frames=12, seed=3):
+    """<tmp>/pre/yolox/{dets,embs/osnet}/MOT17-02.txt: whitespace-separated detections (sorted by frame) + one feature line per detection,
+    in the same order; returns (det_emb_root, per-frame dets, per-frame embs)."""
+    r = np.random.default_rng(seed)
+    base = os.path.join(tmp, "pre")
+    os.makedirs(os.path.join(base, "yolox", "dets"))
+    os.makedirs(os.path.join(base, "yolox", "embs", "osnet"))
+    dets, embs = {}, {}
+    proto = r.standard_normal((6, D)).astype(np.float32)
+    with open(os.path.join(base, "yolox", "dets", "MOT17-02.txt"), "w") as fd, open(os.path.join(base, "yolox", "embs", "osnet", "MOT17-02.txt"), "w") as fe:
+        fe.write("# one line per detection\n")
+        for f in range(1, frames + 1):
+            if f == 5:
+                continue  # a frame without detections
+            n = 6 if f % 3 else 4
+            d = np.zeros((n, 6), np.float32)
+            for i in range(n):
+                x, y = 100 + 220 * i + 3 * f, 200 + 2 * f
+                d[i] = [x, y, x + 60, y + 140, 0.9 - 0.05 * i, 0]
+                fd.write("%d %.2f %.2f %.2f %.2f %.3f 0\n" % (f, *d[i, :5]))
+            e = (proto[:n] + 0.05 * r.standard_normal((n, D))).astype(np.float32)
+            for row in e:
+                fe.write(" ".join("%.6f" % v for v in row) + "\n")
+                fe.write("\n" if f == 2 else "")  # empty lines are skipped
+            dets[f], embs[f] = np.round(d, 3), e
+        fe.write(" ".join(["9"] * D) + "\n")  # one line more than there are detections: ignored
+    return base, dets, embs
+
+
+def test_embedding_file_reader(tmp_path):
+    root = make_root(str(tmp_path))
+    base, dets, embs = make_pregenerated(str(tmp_path))
+    out = subprocess.run([build(), "embs", root, base, "yolox", "osnet"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    seqs = [l.split() for l in out.stdout.splitlines() if l.startswith("EMB ")]
+    assert ["EMB", "MOT17-02-FRCNN", "file=MOT17-02.txt", "frames=%d" % len(embs)] in seqs
+    rows = [dict(p.split("=") for p in l.split()[2:]) | {"f": l.split()[1]} for l in out.stdout.splitlines() if l.startswith("F ")]
+    assert [int(r["f"]) for r in rows] == sorted(embs)
+    for r in rows:
+        e = np.loadtxt([" ".join("%.6f" % v for v in row) for row in embs[int(r["f"])]], dtype=np.float32, ndmin=2)
+        assert int(r["rows"]) == int(r["dets"]) == e.shape[0] and int(r["d"]) == e.shape[1]
+        want = float(np.sum(e.astype(np.float64) * np.arange(1, e.shape[0] + 1)[:, None] * np.arange(1, e.shape[1] + 1)[None, :]))
+        assert abs(float(r["sum"]) - want) < 1e-3 * max(1.0, abs(want)), r
+
+
+@pytest.mark.gpu
+def test_cli_botsort_with_embedding_files(tmp_path, orc):
+    """motcpp_eval <mot_root> <out> botsort <det_emb_root> <model> <reid>: pre-generated detections and one feature per detection reach
+    BoT-SORT's update(dets, img, embs) — the result file against the oracle fed the same rows"""
+    build()
+    root = make_root(str(tmp_path))
+    base, dets, embs = make_pregenerated(str(tmp_path), D=16, frames=30)
+    res = os.path.join(str(tmp_path), "results")
+    out = subprocess.run([EVAL, root, res, "botsort", base, "yolox", "osnet"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "embeddings:" in out.stdout and "(%d frames)" % len(embs) in out.stdout
+    # the tool's BoT-SORT preset (tools/motcpp_eval.cpp) with with_reid on, no camera-motion compensation
+    trk = orc.tracker(orclib.BOTSORT, [0.6, 0.1, 0.7, 30, 0.8, 0.5, 0.25, 25, 0, 1])
+    want = []
+    for f in sorted(dets):
+        d = np.loadtxt(["%.2f %.2f %.2f %.2f %.3f 0" % tuple(r[:5]) for r in dets[f]], dtype=np.float32, ndmin=2)
+        e = np.loadtxt([" ".join("%.6f" % v for v in row) for row in embs[f]], dtype=np.float32, ndmin=2)
+        want += mot_lines(trk.update(d, e), f)
+    assert open(os.path.join(res, "MOT17-02-FRCNN.txt")).read() == "".join(want)

@@ -21,6 +21,8 @@ namespace {
 namespace fs = std::filesystem;
 using TrackerPtr = std::unique_ptr<motcpp::BaseTracker>;
 
+bool g_have_embeddings = false;  // this sequence comes with a feature per detection (with_reid for BoT-SORT)
+
 // Evaluation presets per tracker (the values the reference's tool passes, motcpp_eval.cpp:99-246); fps comes from seqinfo.ini.
 const std::map<std::string, std::function<TrackerPtr(int)>>& tracker_table() {
   namespace T = motcpp::trackers;
@@ -30,11 +32,12 @@ const std::map<std::string, std::function<TrackerPtr(int)>>& tracker_table() {
        [](int fps) { return TrackerPtr(new T::ByteTrack(0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 0.1f, 0.45f, 0.8f, 30, fps)); }},
       {"ocsort",
        [](int) { return TrackerPtr(new T::OCSort(0.2f, 30, 50, 3, 0.3f, false, 80, "iou", false, 0.1f, 3, 0.2f, false, 0.01f, 0.0001f)); }},
-      // no ReID weights on this path: motion-only BoT-SORT / DeepOC-SORT, camera-motion compensation not applied
+      // no ReID model on this path: BoT-SORT / DeepOC-SORT take the features of a pre-generated embedding file when the command line
+      // names one (det_emb_root, model_name, reid_name), else they run motion-only; camera-motion compensation is not applied
       {"botsort",
        [](int fps) {
          return TrackerPtr(new T::BotSort("", false, false, 0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 0.6f, 0.1f, 0.7f, 30, 0.8f, 0.5f,
-                                          0.25f, "ecc", fps, false, false));
+                                          0.25f, "ecc", fps, false, g_have_embeddings));
        }},
       {"deepocsort",
        [](int) {
@@ -84,6 +87,10 @@ int run_sequence(motcpp::data::MOT17Dataset& dataset, const std::string& name, c
   const auto seq = dataset.get_sequence_info(name);
   std::cout << "[" << name << "] detections: " << seq.det_path << (fs::exists(seq.det_path) ? "" : " (missing)") << "\n";
   const auto detections = dataset.load_detections(seq.det_path);
+  const fs::path emb_file = dataset.embedding_path(name);
+  const auto embeddings = dataset.load_embeddings(emb_file, detections);
+  if (!emb_file.empty()) std::cout << "[" << name << "] embeddings: " << emb_file << " (" << embeddings.size() << " frames)\n";
+  g_have_embeddings = !embeddings.empty();
   TrackerPtr tracker = tracker_table().at(method)(seq.fps);
 
   const fs::path result = out_dir / (name + ".txt");
@@ -97,7 +104,8 @@ int run_sequence(motcpp::data::MOT17Dataset& dataset, const std::string& name, c
   for (const int f : plan.frames) {
     try {
       const Eigen::MatrixXf& dets = detections.at(f);
-      const Eigen::MatrixXf tracks = tracker->update(dets, blank, Eigen::MatrixXf(dets.rows(), 0));
+      const auto e = embeddings.find(f);
+      const Eigen::MatrixXf tracks = tracker->update(dets, blank, e != embeddings.end() ? e->second : Eigen::MatrixXf(dets.rows(), 0));
       if (tracks.rows() > 0) motcpp::utils::write_mot_results(result, motcpp::utils::convert_to_mot_format(tracks, f - plan.shift));
       ++done;
     } catch (const std::exception& e) {

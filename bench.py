@@ -227,7 +227,7 @@ def main():
     gathered = None
     # ByteTrack on the device: packed output (mot_bt_step_packed) — the emitted rows of a sub-batch back to back, so that only
     # rows that exist cross PCIe (a padded [S, 2M, 8] table is 2-4x the bytes) and no stream has a row limit
-    packed = on_device and tracker in ("bytetrack", "botsort", "ocsort")
+    packed = on_device  # (all four device lifecycles emit packed tables)
     rows_cap = [int((bounds[p + 1] - bounds[p]) * (M if tracker == "bytetrack" else max(M, P)) * 1.25) + 64 for p in range(PIPE)]
     if packed:
         rows_p = [torch.zeros((rows_cap[p], 8), dtype=torch.float32).pin_memory().numpy() for p in range(PIPE)]
@@ -335,7 +335,7 @@ def main():
                 got[sid] = out[sid, :cnt[sid]].copy()
         return got
 
-    in_flight = args.in_flight and packed and tracker in ("bytetrack", "botsort")
+    in_flight = args.in_flight and packed and not heavy  # (round 3: mot_sort_* and mot_oc_* have enqueue / collect as well; C4 is one long kernel per frame: nothing to overlap)
 
     def run_pipelined(f0, n, keep_limit):
         """frames f0 .. f0+n-1 with two frames in flight per sub-batch, one host thread; returns when the last one is collected"""

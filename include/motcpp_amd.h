@@ -408,6 +408,10 @@ void mot_oc_destroy(mot_oc_batch* b);
 int mot_oc_reset(mot_oc_batch* b);
 int mot_oc_step_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts, float* rows, int rows_cap, int* out_counts, int* total_rows);
 int mot_oc_device_output(mot_oc_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts);
+/* frames in flight, as mot_bt_enqueue_packed / mot_bt_collect_packed (same contract: at most two pending, d_dets unmodified until the
+ * matching collect, the enqueue call's rows_cap bounds the frame). OCSort::update, src/trackers/ocsort.cpp:285-606. */
+int mot_oc_enqueue_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts, int rows_cap);
+int mot_oc_collect_packed(mot_oc_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows);
 int mot_oc_dump(mot_oc_batch* b, int s, int* ids, float* mean, float* cov, int cap);
 /* out8: [0] summed ms of the first-association assignment launches, [1] of the cost-matrix launches, [2] of whole frames,
  * [3] frames, [4] first-association problems queued, [5] sum of their n*m */
@@ -423,6 +427,12 @@ int mot_sort_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, co
 void mot_sort_destroy(mot_sort_batch* b);
 int mot_sort_reset(mot_sort_batch* b);
 int mot_sort_step(mot_sort_batch* b, const float* d_dets, const int* h_counts, float* out, int* out_counts, int cap_out);
+/* packed output and frames in flight, as mot_bt_step_packed / mot_bt_enqueue_packed / mot_bt_collect_packed / mot_bt_device_output
+ * (same contracts). Sort::update, src/trackers/sort.cpp:102-255. */
+int mot_sort_step_packed(mot_sort_batch* b, const float* d_dets, const int* h_counts, float* rows, int rows_cap, int* out_counts, int* total_rows);
+int mot_sort_enqueue_packed(mot_sort_batch* b, const float* d_dets, const int* h_counts, int rows_cap);
+int mot_sort_collect_packed(mot_sort_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows);
+int mot_sort_device_output(mot_sort_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts);
 int mot_sort_dump(mot_sort_batch* b, int s, int* ids, float* mean, float* cov, int cap);
 int mot_sort_profile(mot_sort_batch* b, int enable);         /* same layout as mot_bt_profile_stats ([1], [6], [7] = 0) */
 int mot_sort_profile_stats(mot_sort_batch* b, double* out8);

@@ -749,6 +749,19 @@ class DeviceOCSort:
                                                   C.byref(total)))
         return total.value
 
+    def enqueue_packed(self, dets_ptr, counts, rows_cap):
+        """queue one frame and return at once (mot_oc_enqueue_packed); at most two frames may be pending"""
+        counts = np.ascontiguousarray(counts, np.int32)
+        self.lib.mot_oc_enqueue_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.ctx._chk(self.lib.mot_oc_enqueue_packed(self.h, C.c_void_p(int(dets_ptr)), _p(counts), int(rows_cap)))
+
+    def collect_packed(self, rows, out_counts):
+        """wait for the oldest pending frame and fetch its packed rows (mot_oc_collect_packed); returns the number of rows"""
+        total = C.c_int(0)
+        self.lib.mot_oc_collect_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_oc_collect_packed(self.h, _p(rows), int(rows.shape[0]), _p(out_counts), C.byref(total)))
+        return total.value
+
     def step(self, dets, counts):
         """host convenience: dets [S, N, 6] rows -> list of per-stream tables"""
         dets = f32(dets)
@@ -842,6 +855,34 @@ class DeviceSort:
             self._out = pinned_array(self.ctx, (self.S, cap, 8), np.float32)
         self.ctx._chk(self.lib.mot_sort_step(self.h, ptr, _p(counts), _p(self._out), _p(self._cnt), cap))
         return self._out, self._cnt
+
+    def step_packed(self, resident_ptr, counts, rows, out_counts):
+        """one frame, packed output (mot_sort_step_packed): the emitted rows of all streams back to back; returns their number"""
+        counts = np.ascontiguousarray(counts, np.int32)
+        total = C.c_int(0)
+        self.lib.mot_sort_step_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_sort_step_packed(self.h, C.c_void_p(int(resident_ptr)), _p(counts), _p(rows), int(rows.shape[0]), _p(out_counts),
+                                                    C.byref(total)))
+        return total.value
+
+    def enqueue_packed(self, resident_ptr, counts, rows_cap):
+        """queue one frame and return at once (mot_sort_enqueue_packed); at most two frames may be pending"""
+        counts = np.ascontiguousarray(counts, np.int32)
+        self.lib.mot_sort_enqueue_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.ctx._chk(self.lib.mot_sort_enqueue_packed(self.h, C.c_void_p(int(resident_ptr)), _p(counts), int(rows_cap)))
+
+    def collect_packed(self, rows, out_counts):
+        """wait for the oldest pending frame and fetch its packed rows (mot_sort_collect_packed); returns the number of rows"""
+        total = C.c_int(0)
+        self.lib.mot_sort_collect_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_sort_collect_packed(self.h, _p(rows), int(rows.shape[0]), _p(out_counts), C.byref(total)))
+        return total.value
+
+    def device_output(self):
+        r, o, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.lib.mot_sort_device_output.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_sort_device_output(self.h, C.byref(r), C.byref(o), C.byref(c)))
+        return r.value, o.value, c.value
 
     def dump(self, s):
         ids = np.zeros(self.CAP, np.int32)

@@ -85,6 +85,86 @@ struct Allocs {
   }
 };
 
+// ---- frames in flight (round 3: shared by the SORT and OC-SORT lifecycles; ByteTrack / BoT-SORT carry their own copy of the same scheme) ----
+// step_packed split in two so that ONE host thread overlaps the result copy of frame f with the kernels of frame f + 1: enqueue(f + 1)
+// returns once its launches are queued, collect(f) waits for frame f's event only and copies its rows on a second stream. Two sets of
+// packed tables; what the host needs back from a frame travels in page-locked memory:
+//   h_meta: [0] total rows, [1] error flag, [2] problems the sparse solver declined in the first association (-1: not counted),
+//           [3..67) the frame's per-stream maxima (live tracks), then counts out [S], counts in [S]
+constexpr int kMetaHead = 67;
+struct Flight {
+  float* d_packed = nullptr; int* d_offsets = nullptr; int* d_counts = nullptr; int packed_cap = 0;
+  int* h_meta = nullptr;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+  int rows_cap = 0;  // the row limit pack_rows ran with (the enqueue call's rows_cap)
+  int bd = 0;        // largest detection count of the frame (bounds the tracks it may add)
+};
+struct Flights {
+  Flight fl[2];
+  int head = 0, count = 0;  // oldest pending frame, frames pending
+  hipStream_t copy_st = nullptr;
+  int slot_for_enqueue() const { return (head + count) & 1; }
+  // buffers of the slot (allocated on first use / when rows_cap grows); counts_in = page-locked copy of the caller's counts
+  hipError_t prepare(Allocs& mem, int slot, int S, int rows_cap, const int* h_counts, int** counts_in, int* bd_out) {
+    Flight& F = fl[slot];
+    hipError_t e = hipSuccess;
+    if (!copy_st && (e = hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking)) != hipSuccess) return e;
+    if (!F.done && (e = hipEventCreateWithFlags(&F.done, hipEventDisableTiming)) != hipSuccess) return e;
+    if (!F.h_meta && (e = hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (kMetaHead + 2 * static_cast<size_t>(S)), hipHostMallocDefault)) != hipSuccess) return e;
+    if (!F.d_offsets) { F.d_offsets = mem.get<int>(static_cast<size_t>(S) + 1); F.d_counts = mem.get<int>(S); }
+    if (rows_cap > F.packed_cap) { F.d_packed = mem.get<float>(static_cast<size_t>(rows_cap) * 8); F.packed_cap = F.d_packed ? rows_cap : 0; }
+    if (!F.d_offsets || !F.d_counts || !F.d_packed) return hipErrorOutOfMemory;
+    int* ci = F.h_meta + kMetaHead + S;
+    int bd = 1;
+    for (int s = 0; s < S; ++s) { ci[s] = h_counts[s]; bd = (h_counts[s] > bd) ? h_counts[s] : bd; }
+    *counts_in = ci; *bd_out = bd;
+    return hipSuccess;
+  }
+  // behind the frame's launches: pack the staged tables, bring the small results back, record the frame's event
+  hipError_t finish(int slot, hipStream_t st, const float* d_stage, int cap_stage, const int* d_out_counts, int S, const int* d_err, const int* d_maxt,
+                    const int* d_declined, int rows_cap, int bd) {
+    Flight& F = fl[slot];
+    hipLaunchKernelGGL(pack_offsets, dim3(1), dim3(1024), 0, st, d_out_counts, S, F.d_offsets);
+    hipLaunchKernelGGL(pack_rows, dim3(S), dim3(256), 0, st, d_stage, cap_stage, d_out_counts, F.d_offsets, F.d_packed, rows_cap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    F.h_meta[2] = -1;
+    if ((e = hipMemcpyAsync(F.d_counts, d_out_counts, sizeof(int) * S, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(F.h_meta, F.d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(F.h_meta + 1, d_err, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if (d_declined && (e = hipMemcpyAsync(F.h_meta + 2, d_declined, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(F.h_meta + 3, d_maxt, sizeof(int) * 64, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(F.h_meta + kMetaHead, d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipEventRecord(F.done, st)) != hipSuccess) return e;
+    F.pending = true; F.bd = bd; F.rows_cap = rows_cap;
+    count += 1;
+    return hipSuccess;
+  }
+  // the oldest pending frame: waits for it, hands out its meta words; the caller copies the rows with copy_rows
+  hipError_t pop(Flight** out) {
+    Flight& F = fl[head];
+    const hipError_t e = hipEventSynchronize(F.done);
+    if (e != hipSuccess) return e;
+    F.pending = false;
+    head ^= 1; count -= 1;
+    *out = &F;
+    return hipSuccess;
+  }
+  hipError_t copy_rows(const Flight& F, float* rows, int total) {
+    if (total <= 0) return hipSuccess;
+    const hipError_t e = hipMemcpyAsync(rows, F.d_packed, sizeof(float) * static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, copy_st);
+    return (e != hipSuccess) ? e : hipStreamSynchronize(copy_st);
+  }
+  int pending_bd() const { int v = 0; for (const Flight& F : fl) if (F.pending && F.bd > v) v = F.bd; return v; }
+  void drop_all() { for (Flight& F : fl) F.pending = false; head = 0; count = 0; }
+  void release() {
+    for (Flight& F : fl) { if (F.done) (void)hipEventDestroy(F.done); if (F.h_meta) (void)hipHostFree(F.h_meta); F.done = nullptr; F.h_meta = nullptr; }
+    if (copy_st) (void)hipStreamDestroy(copy_st);
+    copy_st = nullptr;
+  }
+};
+
 }  // namespace lifecycle
 }  // namespace mot
 

@@ -531,7 +531,9 @@ struct mot_oc_batch {
   bool lap1_skip_fast = false;
   int lap1_age = 0;
   float* d_out = nullptr; int* d_out_counts = nullptr;
-  float* d_packed = nullptr; int* d_offsets = nullptr; int packed_cap = 0;
+  const float* d_packed = nullptr; const int* d_offsets = nullptr; const int* d_counts_last = nullptr;  // mot_oc_device_output: the frame collected last
+  mot::lifecycle::Flights flights;  // mot_oc_enqueue_packed / mot_oc_collect_packed (mot_oc_step_packed = one after the other)
+  bool flight_prof[2] = {false, false};
   float* mean = nullptr;  // [S][CAP] records of 7 + 49 floats
   bool profile = false;
   unsigned long long* d_stats = nullptr;
@@ -547,6 +549,7 @@ extern "C" {
 void mot_oc_destroy(mot_oc_batch* b) {
   if (!b) return;
   b->mem.release();
+  b->flights.release();
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   delete b;
 }
@@ -560,6 +563,7 @@ int mot_oc_reset(mot_oc_batch* b) {  // OCSort::reset: the tracker list is dropp
   b->bound_n = 0;
   b->lap1_skip_fast = false;
   b->lap1_age = 0;
+  b->flights.drop_all();  // (frames still in flight have finished: they are dropped with the tracks)
   return MOT_OK;
 }
 
@@ -599,7 +603,6 @@ int mot_oc_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   b->d_stats = b->dalloc<unsigned long long>(8 * 64);
   b->d_out = b->dalloc<float>(static_cast<size_t>(S) * CAP * 8);
   b->d_out_counts = b->dalloc<int>(S);
-  b->d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1);
   OcTasks& T = b->tasks;
   T.det = b->dalloc<mot_det_task>(S);
   T.pred = b->dalloc<mot_kf_task>(S); T.init = b->dalloc<mot_kf_task>(S); T.upd = b->dalloc<mot_kf_task>(static_cast<size_t>(kRounds) * S);
@@ -613,7 +616,7 @@ int mot_oc_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   const size_t wall = wb1 + wbb + wbr + wrl;
   char* work = b->dalloc<char>(wall * S);
   if (!ip || !fp || !bp || !clamp || !b->mean || !mats || !b->d_streams || !b->d_counts || !b->d_err || !b->d_maxt || !b->d_stats || !b->d_out ||
-      !b->d_out_counts || !b->d_offsets || !T.det || !T.pred || !T.init || !T.upd || !T.sbox || !T.cost || !T.lap1 || !T.lapb || !T.lapr || !work) {
+      !b->d_out_counts || !T.det || !T.pred || !T.init || !T.upd || !T.sbox || !T.cost || !T.lap1 || !T.lapb || !T.lapr || !work) {
     mot_oc_destroy(b);
     return MOT_ERR_NOMEM;
   }
@@ -705,18 +708,18 @@ int mot_oc_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   return MOT_OK;
 }
 
-int mot_oc_step_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts, float* rows, int rows_cap, int* out_counts, int* total_rows) {
-  if (!b || !d_dets || !h_counts || !rows || !out_counts) return MOT_ERR_INVALID;
+// queues one frame of every stream up to the staged output tables (counts: host memory that stays valid until its copy has run);
+// bound = live tracks any stream may have; *declined_out = device counter of the first associations the sparse solver declined
+static int oc_enqueue_frame(mot_oc_batch* b, const float* d_dets, const int* counts, int bound, bool prof, int** declined_out) {
   hipStream_t st = b->ctx->stream;
   const int S = b->S, CAP = b->CAP, D = b->D;
-  MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
   MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
   int bd = 1;
-  for (int s = 0; s < S; ++s) bd = (h_counts[s] > bd) ? h_counts[s] : bd;
+  for (int s = 0; s < S; ++s) bd = (counts[s] > bd) ? counts[s] : bd;
   if (bd > D) bd = D;
-  const int bn = (b->bound_n < 1) ? 1 : (b->bound_n > CAP ? CAP : b->bound_n);
+  const int bn = (bound < 1) ? 1 : (bound > CAP ? CAP : bound);
   const int bn2 = (bn + 2 * bd > CAP) ? CAP : bn + 2 * bd;
-  const bool prof = b->profile;
   const bool general = b->prm.asso != MOT_ASSOC_IOU;
   const OcTasks& K = b->tasks;
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[0], st));
@@ -744,23 +747,15 @@ int mot_oc_step_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYSR, K.sbox, S, bn2, st));
   hipLaunchKernelGGL(oc_emit, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt);
   hipLaunchKernelGGL(oc_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
-  if (rows_cap > b->packed_cap) { b->d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); b->packed_cap = b->d_packed ? rows_cap : 0; }
-  if (!b->d_packed) return MOT_ERR_NOMEM;
-  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, b->d_offsets);
-  hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, CAP, b->d_out_counts, b->d_offsets, b->d_packed, rows_cap);
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
   MOT_LC_HIP(b, hipGetLastError());
-  int total = 0, err = 0;
-  int maxt[64];
-  MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(&total, b->d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
-  int declined1 = -1;
-  if (lap1_declined) MOT_LC_HIP(b, hipMemcpyAsync(&declined1, lap1_declined, sizeof(int), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipStreamSynchronize(st));
+  *declined_out = lap1_declined;
+  return MOT_OK;
+}
+// what the host keeps from a finished frame: the launch bound of the next one, whether the sparse solver is worth trying, profile sums
+static int oc_account(mot_oc_batch* b, const int* maxt, int declined1, bool prof) {
   ++b->lap1_age;
-  if (declined1 >= 0) b->lap1_skip_fast = declined1 * 10 >= 9 * S;
+  if (declined1 >= 0) b->lap1_skip_fast = declined1 * 10 >= 9 * b->S;
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
   if (prof) {
@@ -770,21 +765,56 @@ int mot_oc_step_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts
     MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[3], b->ev[4])); b->lap_ms += ms;
     b->frames += 1;
   }
-  if (total_rows) *total_rows = total;
-  if (err) { b->ctx->err = "mot_oc_step_packed: a stream exceeded cap_tracks / max_dets / the update rounds of a frame"; return MOT_ERR_CAPACITY; }
-  if (total > rows_cap) { b->ctx->err = "mot_oc_step_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
-  if (total > 0) {
-    MOT_LC_HIP(b, hipMemcpyAsync(rows, b->d_packed, sizeof(float) * static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, st));
-    MOT_LC_HIP(b, hipStreamSynchronize(st));
-  }
   return MOT_OK;
+}
+
+// Frames in flight (as mot_bt_enqueue_packed / mot_bt_collect_packed): a frame still in flight may add two tracks per detection
+// (quirk Q4: a detection on the unmatched list twice spawns two), which bounds the next frame's launches.
+int mot_oc_enqueue_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts, int rows_cap) {
+  if (!b || !d_dets || !h_counts || rows_cap <= 0) return MOT_ERR_INVALID;
+  if (b->flights.count >= 2) { b->ctx->err = "mot_oc_enqueue_packed: two frames are already in flight (collect one first)"; return MOT_ERR_INVALID; }
+  const int slot = b->flights.slot_for_enqueue();
+  int* counts_in = nullptr;
+  int bd = 0;
+  MOT_LC_HIP(b, b->flights.prepare(b->mem, slot, b->S, rows_cap, h_counts, &counts_in, &bd));
+  const bool prof = b->profile && b->flights.count == 0;  // (one set of events: profiled only when nothing else is in flight)
+  int* declined = nullptr;
+  const int rc = oc_enqueue_frame(b, d_dets, counts_in, b->bound_n + 2 * b->flights.pending_bd(), prof, &declined);
+  if (rc != MOT_OK) return rc;
+  b->flight_prof[slot] = prof;
+  MOT_LC_HIP(b, b->flights.finish(slot, b->ctx->stream, b->d_out, b->CAP, b->d_out_counts, b->S, b->d_err, b->d_maxt, declined, rows_cap, bd));
+  return MOT_OK;
+}
+int mot_oc_collect_packed(mot_oc_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows) {
+  if (!b || !rows || !out_counts) return MOT_ERR_INVALID;
+  if (b->flights.count <= 0) { b->ctx->err = "mot_oc_collect_packed: no frame in flight"; return MOT_ERR_INVALID; }
+  const int slot = b->flights.head;
+  mot::lifecycle::Flight* F = nullptr;
+  MOT_LC_HIP(b, b->flights.pop(&F));
+  const int total = F->h_meta[0], err = F->h_meta[1];
+  const int ra = oc_account(b, F->h_meta + 3, F->h_meta[2], b->flight_prof[slot]);
+  if (ra != MOT_OK) return ra;
+  std::memcpy(out_counts, F->h_meta + mot::lifecycle::kMetaHead, sizeof(int) * b->S);
+  if (total_rows) *total_rows = total;
+  b->d_packed = F->d_packed; b->d_offsets = F->d_offsets;  // mot_oc_device_output: the frame just collected
+  b->d_counts_last = F->d_counts;
+  if (err) { b->ctx->err = "mot_oc_step: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
+  if (total > rows_cap || total > F->rows_cap) { b->ctx->err = "mot_oc_step_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  MOT_LC_HIP(b, b->flights.copy_rows(*F, rows, total));
+  return MOT_OK;
+}
+int mot_oc_step_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts, float* rows, int rows_cap, int* out_counts, int* total_rows) {
+  if (!b || !d_dets || !h_counts || !rows || !out_counts) return MOT_ERR_INVALID;
+  if (b->flights.count > 0) { b->ctx->err = "mot_oc_step_packed: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
+  const int rc = mot_oc_enqueue_packed(b, d_dets, h_counts, rows_cap);
+  return (rc != MOT_OK) ? rc : mot_oc_collect_packed(b, rows, rows_cap, out_counts, total_rows);
 }
 
 int mot_oc_device_output(mot_oc_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts) {
   if (!b || !b->d_packed || !b->d_offsets) return MOT_ERR_INVALID;
   if (d_rows) *d_rows = b->d_packed;
   if (d_offsets) *d_offsets = b->d_offsets;
-  if (d_counts) *d_counts = b->d_out_counts;
+  if (d_counts) *d_counts = b->d_counts_last;
   return MOT_OK;
 }
 

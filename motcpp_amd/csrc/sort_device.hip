@@ -247,6 +247,8 @@ struct mot_sort_batch {
   double lap_ms = 0.0, frame_ms = 0.0;
   long frames = 0;
   unsigned long long* d_stats = nullptr;  // [64][2]: problems, sum of n + m
+  mot::lifecycle::Flights flights;        // mot_sort_enqueue_packed / mot_sort_collect_packed
+  const float* d_rows_last = nullptr; const int* d_offsets_last = nullptr; const int* d_counts_last = nullptr;  // mot_sort_device_output
   template <class T>
   T* dalloc(size_t n) { return mem.get<T>(n); }
 };
@@ -257,11 +259,13 @@ extern "C" {
 void mot_sort_destroy(mot_sort_batch* b) {
   if (!b) return;
   b->mem.release();
+  b->flights.release();
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   delete b;
 }
 
 int mot_sort_reset(mot_sort_batch* b) {  // sort.cpp:97-100: the tracks go, the id counter keeps counting
+  MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
   std::vector<SortStream> cur(b->S);
   MOT_LC_HIP(b, hipMemcpy(cur.data(), b->d_streams, sizeof(SortStream) * b->S, hipMemcpyDeviceToHost));
   std::vector<SortStream> h = b->h_streams;
@@ -269,6 +273,7 @@ int mot_sort_reset(mot_sort_batch* b) {  // sort.cpp:97-100: the tracks go, the 
   MOT_LC_HIP(b, hipMemcpy(b->d_streams, h.data(), sizeof(SortStream) * b->S, hipMemcpyHostToDevice));
   MOT_LC_HIP(b, hipMemset(b->d_err, 0, sizeof(int)));
   b->bound_n = 0;
+  b->flights.drop_all();  // (frames still in flight finished before the copies above: they are dropped with the tracks)
   return MOT_OK;
 }
 
@@ -352,7 +357,9 @@ int mot_sort_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, co
   return MOT_OK;
 }
 
-int mot_sort_step(mot_sort_batch* b, const float* d_dets, const int* h_counts, float* out, int* out_counts, int cap_out) {
+// queues one frame of every stream (counts: host memory that stays valid until the copy has run — the caller's array for the synchronous
+// calls, the flight's page-locked copy for frames in flight); cap_out = staging rows per stream; bound = live tracks any stream may have
+static int sort_enqueue_frame(mot_sort_batch* b, const float* d_dets, const int* counts, int cap_out, int bound, bool prof) {
   hipStream_t st = b->ctx->stream;
   const int S = b->S, CAP = b->CAP, D = b->D;
   if (cap_out > b->out_cap) {
@@ -361,14 +368,13 @@ int mot_sort_step(mot_sort_batch* b, const float* d_dets, const int* h_counts, f
     if (!b->d_out || !b->d_out_counts) return MOT_ERR_NOMEM;
     b->out_cap = cap_out;
   }
-  MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
   MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
   int bd = 1;
-  for (int s = 0; s < S; ++s) bd = (h_counts[s] > bd) ? h_counts[s] : bd;
+  for (int s = 0; s < S; ++s) bd = (counts[s] > bd) ? counts[s] : bd;
   if (bd > D) bd = D;
-  const int bn = (b->bound_n < 1) ? 1 : (b->bound_n > CAP ? CAP : b->bound_n);  // tracks alive after the previous frame
+  const int bn = (bound < 1) ? 1 : (bound > CAP ? CAP : bound);  // tracks alive after the previous frame (+ what frames in flight may add)
   const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;
-  const bool prof = b->profile;
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[0], st));
   hipLaunchKernelGGL(sort_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYSR, b->det_t, S, bd, st));
@@ -385,12 +391,9 @@ int mot_sort_step(mot_sort_batch* b, const float* d_dets, const int* h_counts, f
   hipLaunchKernelGGL(sort_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[3], st));
   MOT_LC_HIP(b, hipGetLastError());
-  int err = 0, maxt[64];
-  MOT_LC_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipStreamSynchronize(st));
+  return MOT_OK;
+}
+static int sort_account(mot_sort_batch* b, const int* maxt, bool prof) {
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
   if (prof) {
@@ -399,7 +402,69 @@ int mot_sort_step(mot_sort_batch* b, const float* d_dets, const int* h_counts, f
     MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[3])); b->frame_ms += ms;
     b->frames += 1;
   }
+  return MOT_OK;
+}
+
+int mot_sort_step(mot_sort_batch* b, const float* d_dets, const int* h_counts, float* out, int* out_counts, int cap_out) {
+  hipStream_t st = b->ctx->stream;
+  const int S = b->S;
+  if (b->flights.count > 0) { b->ctx->err = "mot_sort_step: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
+  const bool prof = b->profile;
+  const int rc = sort_enqueue_frame(b, d_dets, h_counts, cap_out, b->bound_n, prof);
+  if (rc != MOT_OK) return rc;
+  int err = 0, maxt[64];
+  MOT_LC_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipStreamSynchronize(st));
+  const int ra = sort_account(b, maxt, prof);
+  if (ra != MOT_OK) return ra;
   if (err) { b->ctx->err = "mot_sort_step: a stream exceeded cap_tracks / max_dets / cap_out"; return MOT_ERR_CAPACITY; }
+  return MOT_OK;
+}
+
+// ---- packed output + frames in flight (as mot_bt_*; Sort::update, src/trackers/sort.cpp:102-255, emits at most one row per live track) ----
+int mot_sort_enqueue_packed(mot_sort_batch* b, const float* d_dets, const int* h_counts, int rows_cap) {
+  if (!b || !d_dets || !h_counts || rows_cap <= 0) return MOT_ERR_INVALID;
+  if (b->flights.count >= 2) { b->ctx->err = "mot_sort_enqueue_packed: two frames are already in flight (collect one first)"; return MOT_ERR_INVALID; }
+  const int slot = b->flights.slot_for_enqueue();
+  int* counts_in = nullptr;
+  int bd = 0;
+  MOT_LC_HIP(b, b->flights.prepare(b->mem, slot, b->S, rows_cap, h_counts, &counts_in, &bd));
+  const int bound = b->bound_n + b->flights.pending_bd();  // a frame still in flight adds at most one track per detection
+  const int rc = sort_enqueue_frame(b, d_dets, counts_in, b->CAP, bound, false);
+  if (rc != MOT_OK) return rc;
+  MOT_LC_HIP(b, b->flights.finish(slot, b->ctx->stream, b->d_out, b->CAP, b->d_out_counts, b->S, b->d_err, b->d_maxt, nullptr, rows_cap, bd));
+  return MOT_OK;
+}
+int mot_sort_collect_packed(mot_sort_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows) {
+  if (!b || !rows || !out_counts) return MOT_ERR_INVALID;
+  if (b->flights.count <= 0) { b->ctx->err = "mot_sort_collect_packed: no frame in flight"; return MOT_ERR_INVALID; }
+  mot::lifecycle::Flight* F = nullptr;
+  MOT_LC_HIP(b, b->flights.pop(&F));
+  const int total = F->h_meta[0], err = F->h_meta[1];
+  const int ra = sort_account(b, F->h_meta + 3, false);
+  if (ra != MOT_OK) return ra;
+  std::memcpy(out_counts, F->h_meta + mot::lifecycle::kMetaHead, sizeof(int) * b->S);
+  if (total_rows) *total_rows = total;
+  b->d_rows_last = F->d_packed; b->d_offsets_last = F->d_offsets; b->d_counts_last = F->d_counts;
+  if (err) { b->ctx->err = "mot_sort_collect_packed: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
+  if (total > rows_cap || total > F->rows_cap) { b->ctx->err = "mot_sort_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  MOT_LC_HIP(b, b->flights.copy_rows(*F, rows, total));
+  return MOT_OK;
+}
+int mot_sort_step_packed(mot_sort_batch* b, const float* d_dets, const int* h_counts, float* rows, int rows_cap, int* out_counts, int* total_rows) {
+  if (!b) return MOT_ERR_INVALID;
+  if (b->flights.count > 0) { b->ctx->err = "mot_sort_step_packed: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
+  const int rc = mot_sort_enqueue_packed(b, d_dets, h_counts, rows_cap);
+  return (rc != MOT_OK) ? rc : mot_sort_collect_packed(b, rows, rows_cap, out_counts, total_rows);
+}
+int mot_sort_device_output(mot_sort_batch* b, const float** d_rows, const int** d_offsets, const int** d_counts) {
+  if (!b || !b->d_rows_last || !b->d_offsets_last) return MOT_ERR_INVALID;
+  if (d_rows) *d_rows = b->d_rows_last;
+  if (d_offsets) *d_offsets = b->d_offsets_last;
+  if (d_counts) *d_counts = b->d_counts_last;
   return MOT_OK;
 }
 

@@ -293,3 +293,72 @@ def test_two_frames_in_flight_give_the_same_tables():
     total = dev.step_packed(ptr(F - 1), np.zeros(S, np.int32), rows, cnt)
     assert total >= 0
     dev.close()
+
+
+@pytest.mark.parametrize("which", ["sort", "ocsort"])
+def test_two_frames_in_flight_sort_and_ocsort(which):
+    """mot_sort_* / mot_oc_* enqueue_packed / collect_packed (round 3): two frames in flight from one host thread, every frame's packed rows
+    equal to the oracle's tables in order (SORT bit for bit; OC-SORT ids / detection indices exactly and boxes within 1e-4: its direction cost
+    goes through acos), the device-resident copy holds the same bytes, a third enqueue and a collect with nothing pending are refused,
+    and a synchronous step while frames are pending is an error."""
+    import torch
+    from motcpp_amd import dist as mdist
+    orc = orclib.load()
+    shapes = [(40, 30), (256, 128), (8, 8), (90, 64), (200, 128)]
+    S, maxd, cap_tracks = len(shapes), 128, 1024
+    if which == "sort":
+        dev, kind = L.DeviceSort(S, cap_tracks, maxd), orclib.SORT
+    else:
+        dev, kind = L.DeviceOCSort(S, cap_tracks, maxd), orclib.OCSORT
+    streams = [SynthStream(P, M, 4100 + i) for i, (P, M) in enumerate(shapes)]
+    oracles = [orc.tracker(kind) for _ in range(S)]
+    F = 30
+    soa = np.zeros((F, S, 6, maxd), np.float32)
+    counts = np.zeros((F, S), np.int32)
+    want = []
+    for f in range(F):
+        per = []
+        for s, st in enumerate(streams):
+            d, _ = st.next_frame()
+            if (f + 2 * s) % 9 == 4:
+                d = d[:0]
+            counts[f, s] = len(d)
+            soa[f, s, :, :len(d)] = d.T
+            per.append(oracles[s].update(d))
+        want.append(per)
+    ddets = torch.from_numpy(soa).cuda()
+    rows = L.pinned_array(dev.ctx, (S * cap_tracks, 8), np.float32)
+    cnt = L.pinned_array(dev.ctx, (S,), np.int32)
+    cap = rows.shape[0]
+
+    def check(f):
+        total = dev.collect_packed(rows, cnt)
+        assert total == sum(w.shape[0] for w in want[f]), f
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        for s in range(S):
+            got, w = rows[off[s]:off[s + 1]], want[f][s]
+            assert got.shape == w.shape and np.array_equal(got[:, 4:], w[:, 4:]), (f, s)
+            if which == "sort":
+                assert np.array_equal(got, w), (f, s)
+            else:
+                assert np.allclose(got[:, :4], w[:, :4], rtol=1e-4, atol=1e-3), (f, s)
+        if f % 7 == 6 and total:
+            r_ptr, o_ptr, c_ptr = dev.device_output()
+            dv = torch.device("cuda", 0)
+            assert np.array_equal(mdist.device_view(r_ptr, (total, 8), torch.float32, dv).cpu().numpy(), rows[:total])
+            assert np.array_equal(mdist.device_view(c_ptr, (S,), torch.int32, dv).cpu().numpy(), cnt)
+
+    ptr = lambda f: ddets.data_ptr() + f * S * 6 * maxd * 4
+    dev.enqueue_packed(ptr(0), counts[0], cap)
+    for f in range(1, F):
+        dev.enqueue_packed(ptr(f), counts[f].copy(), cap)
+        if f == 5:
+            with pytest.raises(L.MotError):
+                dev.enqueue_packed(ptr(f), counts[f], cap)  # two frames are pending
+            with pytest.raises(L.MotError):
+                dev.step_packed(ptr(f), counts[f], rows, cnt)  # synchronous step while frames are pending
+        check(f - 1)
+    check(F - 1)
+    with pytest.raises(L.MotError):
+        dev.collect_packed(rows, cnt)  # nothing pending
+    dev.close()

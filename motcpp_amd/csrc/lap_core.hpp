@@ -1310,6 +1310,9 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             cy_sub[2] += qb - q1;
             g.sync();  // the step's full barrier, with the list loads in flight: the previous step's stores to cols[] / inv[] are visible from here on
             stepped = true;
+            // the columns in the first TODO positions (where tie events will swap their columns to) are requested now, one per lane, and
+            // consumed by the event sort three phases later: a global round trip off the step's critical path
+            const int hcol_pref = (t < kEvCap && shi + static_cast<unsigned>(t) < static_cast<unsigned>(n)) ? static_cast<int>(W.cols[shi + static_cast<unsigned>(t)]) : 0;
             const long long qc = MOT_FCLOCK();
             cy_sub[3] += qc - qb;
             evaluate();
@@ -1405,7 +1408,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             // columns that sit in the first nev TODO positions ("head slots": a tie swaps its column with the first TODO one).
             int in_head = 0, first_sink = kNoIdx;
             for (int e = t; e < nev; e += T) {
-              const int hcol = W.cols[shi + static_cast<unsigned>(e)];  // (in flight while the rank is counted)
+              const int hcol = (e == t && t < kEvCap) ? hcol_pref : static_cast<int>(W.cols[shi + static_cast<unsigned>(e)]);
               const int q = W.fsw[kEQ + e], j = W.fsw[kEJ + e], k = W.fsw[kEK + e], i = W.fsw[kEI + e];
               const int fl = (i < 0) ? 1 : 0;
               int rk = 0;

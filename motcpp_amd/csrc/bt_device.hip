@@ -134,22 +134,50 @@ __global__ void __launch_bounds__(kW) bt_begin(BtStream* streams, BtParams P, in
 }
 
 // ---- K1: apply the first association, queue the second and the unconfirmed one (:267-455) ----
-__global__ void __launch_bounds__(kW) bt_after_first(BtStream* streams, BtParams P, int CAP, mot_kf_task* box_t, mot_lap_task* lap23_t,
+// Four wavefronts per stream (round 3; one wavefront walked the 1000-row pool in 16 dependent rounds: 215 us per launch at the
+// north-star shape). The lists stay in the reference's order: an append position = entries before this round + entries of the earlier
+// wavefronts of the round + the lane's rank inside its wavefront (ballot + popcount); the wavefronts' counts meet in LDS.
+constexpr int kAF = 256;
+struct Compact3 {  // three order-preserving appends of one round, one exchange
+  int pos[3];
+};
+__device__ __forceinline__ Compact3 compact3_block(bool p0, bool p1, bool p2, int& b0, int& b1, int& b2, int (*cnt)[3]) {
+  const int lane = static_cast<int>(threadIdx.x) & 63, w = static_cast<int>(threadIdx.x) >> 6;
+  const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2);
+  if (lane == 0) { cnt[w][0] = __popcll(m0); cnt[w][1] = __popcll(m1); cnt[w][2] = __popcll(m2); }
+  __syncthreads();
+  int before[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
+  for (int k = 0; k < kAF / 64; ++k)
+    for (int q = 0; q < 3; ++q) { const int c = cnt[k][q]; if (k < w) before[q] += c; tot[q] += c; }
+  __syncthreads();  // (the counts are rewritten by the next round)
+  const unsigned long long below = (1ull << lane) - 1ull;
+  Compact3 r;
+  r.pos[0] = b0 + before[0] + __popcll(m0 & below);
+  r.pos[1] = b1 + before[1] + __popcll(m1 & below);
+  r.pos[2] = b2 + before[2] + __popcll(m2 & below);
+  b0 += tot[0]; b1 += tot[1]; b2 += tot[2];
+  return r;
+}
+__global__ void __launch_bounds__(kAF) bt_after_first(BtStream* streams, BtParams P, int CAP, mot_kf_task* box_t, mot_lap_task* lap23_t,
                                                       unsigned long long* stats, int* maxt) {
+  __shared__ int cnt[kAF / 64][3];
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
   const int np = S.n_pool, nd = S.n_high;
   const bool have = np > 0 && nd > 0;
   int n_upd = 0, n_ref = 0, n_ut = 0, n_ud = 0;
-  for (int i0 = 0; i0 < np; i0 += kW) {
+  for (int i0 = 0; i0 < np; i0 += kAF) {
     const int i = i0 + t;
     const bool v = i < np;
     const int x = (v && have) ? S.x1[i] : -1;
     const int slot = v ? S.pool_slot[i] : 0;
     const bool m = v && x >= 0;
     const bool was_tracked = m && S.t_state[slot] == Tracked;
-    const int pu = compact(m, n_upd);
+    const bool rf = m && !was_tracked;
+    const bool um = v && x < 0;
+    const Compact3 c = compact3_block(m, rf, um, n_upd, n_ref, n_ut, cnt);
     if (m) {
+      const int pu = c.pos[0];
       const int det = S.high[x];
       S.upd_src[pu] = slot; S.upd_dst[pu] = slot; S.upd_meas[pu] = det;
       S.upd_flags[pu] = (S.pred_flags[i] & MOT_KF_ZERO_V7) | MOT_KF_PREDICT_FIRST;  // the update starts from the PREDICTED copy (:251-265)
@@ -161,31 +189,33 @@ __global__ void __launch_bounds__(kW) bt_after_first(BtStream* streams, BtParams
       S.t_cls[slot] = static_cast<int>(S.dets[static_cast<size_t>(5) * S.ld + det]);
       S.t_det[slot] = det;
     }
-    const bool rf = m && !was_tracked;
-    const int pr = compact(rf, n_ref);
-    if (rf) S.refind[pr] = slot;
-    const bool um = v && x < 0;
-    const int pt = compact(um, n_ut);
-    if (um) S.u_track[pt] = i;
+    if (rf) S.refind[c.pos[1]] = slot;
+    if (um) S.u_track[c.pos[2]] = i;
   }
-  for (int j0 = 0; j0 < nd; j0 += kW) {
-    const int j = j0 + t;
-    const bool u = j < nd && (!have || S.y1[j] < 0);
-    const int p = compact(u, n_ud);
-    if (u) S.u_det[p] = j;
+  {
+    int z1 = 0, z2 = 0;
+    for (int j0 = 0; j0 < nd; j0 += kAF) {
+      const int j = j0 + t;
+      const bool u = j < nd && (!have || S.y1[j] < 0);
+      const Compact3 c = compact3_block(u, false, false, n_ud, z1, z2, cnt);
+      if (u) S.u_det[c.pos[0]] = j;
+    }
   }
   __syncthreads();
   // second association: the still-Tracked, still-unmatched pool members that came from the active list (:367-442)
   int n_r = 0;
-  for (int k0 = 0; k0 < n_ut; k0 += kW) {
-    const int k = k0 + t;
-    const int i = (k < n_ut) ? S.u_track[k] : 0;
-    const int slot = (k < n_ut) ? S.pool_slot[i] : 0;
-    const bool r = k < n_ut && i < S.n_tracked && S.t_state[slot] == Tracked;
-    const int p = compact(r, n_r);
-    if (r) { S.r_slot[p] = slot; S.r_pool[p] = i; }
+  {
+    int z1 = 0, z2 = 0;
+    for (int k0 = 0; k0 < n_ut; k0 += kAF) {
+      const int k = k0 + t;
+      const int i = (k < n_ut) ? S.u_track[k] : 0;
+      const int slot = (k < n_ut) ? S.pool_slot[i] : 0;
+      const bool r = k < n_ut && i < S.n_tracked && S.t_state[slot] == Tracked;
+      const Compact3 c = compact3_block(r, false, false, n_r, z1, z2, cnt);
+      if (r) { S.r_slot[c.pos[0]] = slot; S.r_pool[c.pos[0]] = i; }
+    }
   }
-  for (int k = t; k < n_ud; k += kW) S.rem[k] = S.high[S.u_det[k]];
+  for (int k = t; k < n_ud; k += kAF) S.rem[k] = S.high[S.u_det[k]];
   __syncthreads();
   if (t == 0) {
     S.n_upd = n_upd; S.n_refind = n_ref; S.n_utrack = n_ut; S.n_udet = n_ud; S.n_r = n_r;
@@ -764,7 +794,7 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, true, st, b->hint1_n, 0, true, nullptr, prof ? ev[10] : nullptr));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
-  hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr, b->d_maxt);
+  hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(kAF), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr, b->d_maxt);
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, bn, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, true, st, b->hint23_n, b->hint23_m));

@@ -876,18 +876,53 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             const double m0 = W.d[W.cols[lo]];
             const int L = (cnt + T - 1) / T;
             const int b = first + t * L, e = (b + L < n) ? b + L : n;
-            double cm = 1e300;
-            for (int k = b; k < e; ++k) { const double dj = W.d[W.cols[k]]; if (dj < cm) cm = dj; }
-            double run = g.exclusive_scan_min(cm);
-            if (m0 < run) run = m0;
-            for (int k = b; k < e; ++k) {
-              const double dj = W.d[W.cols[k]];
-              int rec = 0;
-              if (dj <= run) { rec = 1; if (dj < run) run = dj; }
-              W.tmp[k] = rec;
+            // (round 3) A lane's chunk of cols[] is read ONCE into registers; the records, their compaction into lst[] and the last
+            // record that lowers the minimum all come out of those registers — the flag array and its three passes over memory
+            // are only the fallback for chunks longer than kFindChunk.
+            constexpr int kFindChunk = 16;
+            int nrec = 0, last_strict_reg = -2;  // (-2: not computed here)
+            if (L <= kFindChunk) {
+              int cj[kFindChunk];
+              double dv[kFindChunk];
+#pragma unroll
+              for (int u = 0; u < kFindChunk; ++u) cj[u] = (b + u < e) ? static_cast<int>(W.cols[b + u]) : 0;
+              double cm = 1e300;
+#pragma unroll
+              for (int u = 0; u < kFindChunk; ++u) {
+                dv[u] = (b + u < e) ? static_cast<double>(W.d[cj[u]]) : 1e300;
+                if (dv[u] < cm) cm = dv[u];
+              }
+              double run = g.exclusive_scan_min(cm);
+              if (m0 < run) run = m0;
+              unsigned recm = 0u;
+              int nl = 0, strict_u = -1;
+#pragma unroll
+              for (int u = 0; u < kFindChunk; ++u)
+                if (b + u < e && dv[u] <= run) {
+                  if (dv[u] < run) { run = dv[u]; strict_u = nl; }  // a strict record: the running minimum falls
+                  recm |= 1u << u;
+                  ++nl;
+                }
+              int base = g.exclusive_scan(nl, &nrec);
+              last_strict_reg = g.reduce_max((strict_u >= 0) ? base + strict_u : -1);
+#pragma unroll
+              for (int u = 0; u < kFindChunk; ++u)
+                if (recm & (1u << u)) W.lst[base++] = (b + u) - first;
+              g.sync();
+            } else {
+              double cm = 1e300;
+              for (int k = b; k < e; ++k) { const double dj = W.d[W.cols[k]]; if (dj < cm) cm = dj; }
+              double run = g.exclusive_scan_min(cm);
+              if (m0 < run) run = m0;
+              for (int k = b; k < e; ++k) {
+                const double dj = W.d[W.cols[k]];
+                int rec = 0;
+                if (dj <= run) { rec = 1; if (dj < run) run = dj; }
+                W.tmp[k] = rec;
+              }
+              g.sync();
+              nrec = compact_ascending(g, cnt, [&](int q) { return W.tmp[first + q] != 0; }, W.lst);
             }
-            g.sync();
-            const int nrec = compact_ascending(g, cnt, [&](int q) { return W.tmp[first + q] != 0; }, W.lst);
             // The replay is serial in the number of records, and on tracking problems most of them are TIES with the final
             // minimum (the dummy block is one big tie: thousands of records per call). After the last record that lowers
             // the minimum (a "strict" record: it restarts the insertion point at lo and lands there itself) the insertion
@@ -898,18 +933,22 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             //     step r1 > r0, until it lands on a k beyond the last target position: with g(r) = k_r - s that is the
             //     fixed point of r -> g(r) (g is increasing and injective), found by pointer jumping over the records.
             // Only items whose position s + r0 is not some earlier record's k start such a chain ("fresh").
+            const long long qf1 = MOT_FCLOCK();
+            cy_sub[9] += qf1 - qf0;
             constexpr int kTiePer = MOT_LAP_TIE_PER;  // tie records per lane held in registers across the read/write barrier
             constexpr int kTieMin = MOT_LAP_TIE_MIN;  // shorter tie runs stay with the serial replay
             static_assert(kTiePer <= 32, "one bit per held record in `fresh`");
             int nser = nrec, R = 0;        // serially replayed records, then R tie records in closed form
             if (nrec >= kTieMin) {
               int last_strict = -1;
+              if (last_strict_reg > -2) last_strict = last_strict_reg;
+              else
               for (int r = t; r < nrec; r += T) {
                 const double dr = W.d[W.cols[first + static_cast<int>(W.lst[r])]];
                 const double dp = r ? static_cast<double>(W.d[W.cols[first + static_cast<int>(W.lst[r - 1])]]) : m0;
                 if (dr < dp) last_strict = r;  // (records are weak: the running minimum before r is record r-1's value)
               }
-              last_strict = g.reduce_max(last_strict);
+              if (last_strict_reg == -2) last_strict = g.reduce_max(last_strict);
               const int ties = nrec - 1 - last_strict;
               if (ties >= kTieMin) { nser = last_strict + 1; R = ties; }  // (any length: longer runs are staged through memory)
             }
@@ -979,6 +1018,8 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             }
 #endif
             g.sync();  // the replaying lane's stores to cols[] / inv[] / tmp[0] are visible to everyone
+            const long long qf2 = MOT_FCLOCK();
+            cy_sub[10] += qf2 - qf1;
             unsigned h2;
             if (R == 0) {
               h2 = static_cast<unsigned>(W.tmp[0]);
@@ -1020,73 +1061,89 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               g.sync();
               h2 = static_cast<unsigned>(s + R);
             } else {
-              const int a = nser;  // first tie record; the serial part left the insertion point at s = lo + 1 = first
-              const int s = first;
-              int gr[kTiePer];
-#pragma unroll
-              for (int q = 0; q < kTiePer; ++q) {
-                const int r = t + q * T;
-                gr[q] = (r < R) ? static_cast<int>(W.lst[a + r]) : 0;  // g(r) = k_r - s
-                if (r < R) W.tmp[r] = 0;
-              }
-              g.sync();
-#pragma unroll
-              for (int q = 0; q < kTiePer; ++q) {
-                const int r = t + q * T;
-                if (r < R && gr[q] < R && gr[q] != r) W.tmp[gr[q]] = 1;  // position s + g is record r's k: not fresh
-              }
-              g.sync();
-              unsigned fresh = 0;
-#pragma unroll
-              for (int q = 0; q < kTiePer; ++q) {
-                const int r = t + q * T;
-                if (r < R && gr[q] != r && W.tmp[r] == 0) fresh |= 1u << q;
-              }
-              g.sync();
-#pragma unroll
-              for (int q = 0; q < kTiePer; ++q) {
-                const int r = t + q * T;
-                if (r < R) W.tmp[r] = (gr[q] < R) ? gr[q] : r;
-              }
-              g.sync();
-              for (;;) {  // pointer jumping, in place: a racing reader sees an older or a newer node of the same chain
-                int changed = 0;
-#pragma unroll
+              // The scratch of the closed form (fresh flags, then the pointer-jumping array: chains of displaced items can be as long as the
+              // run, i.e. ~log2(R) rounds of two dependent reads and a reduction each) lives in LDS when the fast scratch is there and the run
+              // fits (the event tables are free during a find): its phases then meet at LDS-only barriers.
+              auto tie_closed_form = [&](const auto& TMP, const bool in_lds) -> unsigned {
+                auto sync_t = [&]() { if (in_lds) g.sync_lds(); else g.sync(); };
+                const int a = nser;  // first tie record; the serial part left the insertion point at s = lo + 1 = first
+                const int s = first;
+                int gr[kTiePer];
+  #pragma unroll
+                for (int q = 0; q < kTiePer; ++q) {
+                  const int r = t + q * T;
+                  gr[q] = (r < R) ? static_cast<int>(W.lst[a + r]) : 0;  // g(r) = k_r - s
+                  if (r < R) TMP[r] = 0;
+                }
+                sync_t();
+  #pragma unroll
+                for (int q = 0; q < kTiePer; ++q) {
+                  const int r = t + q * T;
+                  if (r < R && gr[q] < R && gr[q] != r) TMP[gr[q]] = 1;  // position s + g is record r's k: not fresh
+                }
+                sync_t();
+                unsigned fresh = 0;
+  #pragma unroll
+                for (int q = 0; q < kTiePer; ++q) {
+                  const int r = t + q * T;
+                  if (r < R && gr[q] != r && TMP[r] == 0) fresh |= 1u << q;
+                }
+                sync_t();
+  #pragma unroll
+                for (int q = 0; q < kTiePer; ++q) {
+                  const int r = t + q * T;
+                  if (r < R) TMP[r] = (gr[q] < R) ? gr[q] : r;
+                }
+                sync_t();
+                g.lds_barriers(in_lds);
+                for (;;) {  // pointer jumping, in place: a racing reader sees an older or a newer node of the same chain
+                  int changed = 0;
+  #pragma unroll
+                  for (int q = 0; q < kTiePer; ++q) {
+                    const int r = t + q * T;
+                    if (r < R) {
+                      const int p1 = TMP[r];
+                      const int p2 = TMP[p1];
+                      if (p2 != p1) { TMP[r] = p2; changed = 1; }
+                    }
+                  }
+                  if (g.reduce_max(changed) == 0) break;
+                }
+                g.lds_barriers(false);
+                int jr[kTiePer], orig[kTiePer], dst[kTiePer];
+  #pragma unroll
+                for (int q = 0; q < kTiePer; ++q) {
+                  const int r = t + q * T;
+                  jr[q] = 0; orig[q] = 0; dst[q] = 0;
+                  if (r < R) {
+                    jr[q] = W.cols[s + gr[q]];
+                    if (fresh & (1u << q)) {
+                      orig[q] = W.cols[s + r];
+                      dst[q] = s + static_cast<int>(W.lst[a + static_cast<int>(TMP[r])]);
+                    }
+                  }
+                }
+                g.sync();  // every read of the old order is done
+  #pragma unroll
                 for (int q = 0; q < kTiePer; ++q) {
                   const int r = t + q * T;
                   if (r < R) {
-                    const int p1 = W.tmp[r];
-                    const int p2 = W.tmp[p1];
-                    if (p2 != p1) { W.tmp[r] = p2; changed = 1; }
+                    W.cols[s + r] = jr[q]; W.inv[jr[q]] = s + r;
+                    if (fresh & (1u << q)) { W.cols[dst[q]] = orig[q]; W.inv[orig[q]] = dst[q]; }
                   }
                 }
-                if (g.reduce_max(changed) == 0) break;
+                g.sync();
+                return static_cast<unsigned>(s + R);
+              };
+              constexpr int kTmpLds = kFsTodo - kFsEvl;  // ints of the event tables
+              if (use_rl && R <= kTmpLds) {
+                const std::remove_cv_t<std::remove_reference_t<decltype(W.fsw)>> TL{W.fsw.raw(kFsEvl)};
+                h2 = tie_closed_form(TL, true);
+              } else {
+                h2 = tie_closed_form(W.tmp, false);
               }
-              int jr[kTiePer], orig[kTiePer], dst[kTiePer];
-#pragma unroll
-              for (int q = 0; q < kTiePer; ++q) {
-                const int r = t + q * T;
-                jr[q] = 0; orig[q] = 0; dst[q] = 0;
-                if (r < R) {
-                  jr[q] = W.cols[s + gr[q]];
-                  if (fresh & (1u << q)) {
-                    orig[q] = W.cols[s + r];
-                    dst[q] = s + static_cast<int>(W.lst[a + static_cast<int>(W.tmp[r])]);
-                  }
-                }
-              }
-              g.sync();  // every read of the old order is done
-#pragma unroll
-              for (int q = 0; q < kTiePer; ++q) {
-                const int r = t + q * T;
-                if (r < R) {
-                  W.cols[s + r] = jr[q]; W.inv[jr[q]] = s + r;
-                  if (fresh & (1u << q)) { W.cols[dst[q]] = orig[q]; W.inv[orig[q]] = dst[q]; }
-                }
-              }
-              g.sync();
-              h2 = static_cast<unsigned>(s + R);
             }
+            cy_sub[11] += MOT_FCLOCK() - qf2;
             int best = -1;
             for (unsigned k = lo + static_cast<unsigned>(t); k < h2; k += static_cast<unsigned>(T))
               if (static_cast<int>(W.y[static_cast<int>(W.cols[k])]) < 0) best = static_cast<int>(k);  // the LAST free member (:174-177)

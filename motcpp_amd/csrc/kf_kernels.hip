@@ -574,54 +574,93 @@ __global__ void __launch_bounds__(kThreads) det_kernel(const mot_det_task* __res
 // ---- 8-state update, one lane per covariance ROW -------------------------------------------------------------------
 // The lane-per-track kernel above keeps a whole 8x8 state (and the update's temporaries) in one lane: 242 VGPRs, two
 // wavefronts per SIMD, and a 64-track wavefront waits on its 27 memory instructions with nothing else to run (measured
-// 12 % of the HBM roof). Here a 256-thread workgroup owns 32 tracks and lane (track, r) owns row r of P, K and K S:
-// ~100 VGPRs, eight times the wavefronts per track. The 4x4 innovation covariance is factored redundantly by the eight lanes of
-// a track from the tile in LDS (broadcast reads, a few dozen flops); the gain rows meet once in LDS for P - (K S) K^T.
+// 12 % of the HBM roof). Here a 256-thread workgroup owns 32 tracks at a time and lane (track, r) owns row r of P, K and K S.
+// The factor of the 4x4 innovation covariance is computed once per track (one lane each, the first 32 lanes of the workgroup)
+// and shared through LDS; the gain rows meet once in LDS for P - (K S) K^T.
 // Every element is produced by the same operations in the same order as s8_predict / s8_update: results are bit-identical.
+// Measured (tools/kf_update_microbench.py, 1 M gathered records): 3.3-3.4 TB/s of record bytes; the same loads and stores with
+// the arithmetic removed reach 4.0 (gathered) - 4.7 TB/s (contiguous), which is what this access pattern (288-byte records
+// read and rewritten in place through LDS) can reach; a float4 copy reaches 6.3.
 constexpr int kUpdTracks = 32;
 
-template <int KIND>
-__global__ void __launch_bounds__(256) kf_update8_kernel(const mot_kf_task* __restrict__ tasks) {
+template <int KIND, int TPB, int TILES>
+__global__ void __launch_bounds__(TPB * 8) kf_update8_kernel(const mot_kf_task* __restrict__ tasks) {
+  // A workgroup walks TILES tiles of TPB tracks. The records (and measurements) of tile k + 1 are requested into registers before tile k is
+  // computed and land in LDS after it: a tile's load latency hides behind the previous tile's arithmetic instead of being waited out with
+  // nothing else to do (measured: the load -> compute -> store phases one after the other reach 3.2 TB/s where the same loads and stores
+  // without the arithmetic reach 4.0-4.7).
+  constexpr int kUpdTracks = TPB, NT = TPB * 8;
+  constexpr int NQ = (TPB * 18 + NT - 1) / NT;  // float4 per thread per tile (18 per record)
   constexpr int RS = tile_stride<8>();  // 76 floats = 19 float4
   __shared__ __attribute__((aligned(16))) float tile[kUpdTracks * RS];
-  __shared__ __attribute__((aligned(16))) float kbuf[kUpdTracks * 32];
-  __shared__ int s_src[kUpdTracks], s_dst[kUpdTracks];
+  __shared__ __attribute__((aligned(16))) float kbuf[kUpdTracks * 36];  // (36: the eight tracks of a wavefront read their gain rows from different banks)
+  __shared__ __attribute__((aligned(16))) float fbuf[kUpdTracks * 20];  // per track: the 4x4 factor (or inverse) of S, [16] = which
+  __shared__ float zbuf[kUpdTracks];
+  __shared__ int s_src[TILES * kUpdTracks], s_dst[TILES * kUpdTracks];
   const mot_kf_task T = tasks[blockIdx.y];
-  const int base = blockIdx.x * kUpdTracks;
-  if (base >= T.n) return;
+  const int base0 = blockIdx.x * (kUpdTracks * TILES);
+  if (base0 >= T.n) return;
   const int tid = threadIdx.x;
-  if (tid < kUpdTracks) {
-    const int i = base + tid;
+  const int tr = tid >> 3, r = tid & 7;
+  const int left = T.n - base0;
+  const int ntiles = (left >= kUpdTracks * TILES) ? TILES : (left + kUpdTracks - 1) / kUpdTracks;
+  for (int u = tid; u < TILES * kUpdTracks; u += NT) {
+    const int i = base0 + u;
     const bool a = i < T.n;
     const int src = a ? (T.src ? T.src[i] : i) : -1;
-    s_src[tid] = src;
-    s_dst[tid] = a ? (T.dst ? T.dst[i] : src) : -1;
+    s_src[u] = src;
+    s_dst[u] = a ? (T.dst ? T.dst[i] : src) : -1;
   }
+  // the next tile's data, in flight while the current one is worked on
+  float4 R[NQ];
+  float zN[4] = {0.f, 0.f, 0.f, 0.f};
+  float zcN = 0.0f;
+  unsigned fN = 0u;
+  auto request = [&](int k, bool records) {
+    const int it = base0 + k * kUpdTracks + tr;
+    zN[0] = zN[1] = zN[2] = zN[3] = 0.f; zcN = 0.0f; fN = 0u;
+    if (it < T.n) {  // the measurement of the lane's track: two dependent loads (index, then value) that overlap the records'
+      const int c = T.midx ? T.midx[it] : it;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) zN[q] = T.meas[static_cast<size_t>(q) * T.ldm + c];
+      fN = T.flags ? T.flags[it] : 0u;
+      if (KIND == MOT_KF_XYAH && T.conf) zcN = T.conf[c];
+    }
+    if (records) {
+      const float4* slab4 = reinterpret_cast<const float4*>(T.mean);
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const int p = tid + u * NT;
+        R[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < kUpdTracks * 18) {
+          const int rc = p / 18, q = p - rc * 18;
+          const int slot = s_src[k * kUpdTracks + rc];
+          if (slot >= 0) R[u] = slab4[static_cast<size_t>(slot) * 18 + q];
+        }
+      }
+    }
+  };
+  request(0, false);  // (the measurement loads do not need the slots: they go out before the barrier)
   __syncthreads();
+  request(0, true);
+  for (int kt = 0; kt < ntiles; ++kt) {
+  const int base = base0 + kt * kUpdTracks;
+  const int item = base + tr;
+  const bool active = item < T.n;
+  const float z[4] = {zN[0], zN[1], zN[2], zN[3]};
+  const float zc = zcN;
+  const unsigned f = fN;
   {
-    const float4* slab4 = reinterpret_cast<const float4*>(T.mean);
     float4* tile4 = reinterpret_cast<float4*>(tile);
-    for (int p = tid; p < kUpdTracks * 18; p += 256) {
-      const int rec = p / 18, q = p - rec * 18;
-      const int slot = s_src[rec];
-      if (slot >= 0) tile4[rec * 19 + q] = slab4[static_cast<size_t>(slot) * 18 + q];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int p = tid + u * NT;
+      if (p < kUpdTracks * 18) { const int rc = p / 18, q = p - rc * 18; tile4[rc * 19 + q] = R[u]; }
     }
   }
   __syncthreads();
-  const int tr = tid >> 3, r = tid & 7;
-  const int item = base + tr;
-  const bool active = item < T.n;
+  if (kt + 1 < ntiles) request(kt + 1, true);
   float* rec = tile + tr * RS;
-  float z[4] = {0.f, 0.f, 0.f, 0.f};
-  float zc = 0.0f;
-  unsigned f = 0u;
-  if (active) {
-    const int c = T.midx ? T.midx[item] : item;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) z[k] = T.meas[static_cast<size_t>(k) * T.ldm + c];
-    f = T.flags ? T.flags[item] : 0u;
-    if (KIND == MOT_KF_XYAH && T.conf) zc = T.conf[c];
-  }
   float P[8];
   {
     const float4 a = *reinterpret_cast<const float4*>(rec + 8 + r * 8), b = *reinterpret_cast<const float4*>(rec + 12 + r * 8);
@@ -661,46 +700,85 @@ __global__ void __launch_bounds__(256) kf_update8_kernel(const mot_kf_task* __re
 #pragma unroll
     for (int i = 0; i < 4; ++i) sd[i] = sd[i] * (1.0f - zc);  // NSA Kalman (kalman_filter.cpp:67); 0 unless the task carries confidences
   }
-  float S[4][4];
+  // S = H P H^T + R is read from the tile where it is needed (the factor, K S) instead of staying in registers.
+  auto load_S = [&](const float* rc, const float sdv[4], float S[4][4]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float4 a = *reinterpret_cast<const float4*>(rec + 8 + i * 8);
-    S[i][0] = a.x; S[i][1] = a.y; S[i][2] = a.z; S[i][3] = a.w;
-    S[i][i] = S[i][i] + sd[i] * sd[i];
-  }
-  float K[4];
-  bool solved = false;
-  if (KIND == MOT_KF_XYAH) {
-    float L[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) L[i][j] = S[i][j];
-    if (chol4(L)) {
-      K[0] = P[0]; K[1] = P[1]; K[2] = P[2]; K[3] = P[3];
-      chol4_solve(L, K);
-      solved = true;
+    for (int i = 0; i < 4; ++i) {
+      const float4 a = *reinterpret_cast<const float4*>(rc + 8 + i * 8);
+      S[i][0] = a.x; S[i][1] = a.y; S[i][2] = a.z; S[i][3] = a.w;
+      S[i][i] = S[i][i] + sdv[i] * sdv[i];
     }
-  }
-  if (!solved) {
-    float Sinv[4][4];
-    inv_lu4(S, Sinv);
-    const float pr[4] = {P[0], P[1], P[2], P[3]};
+  };
+  // The factor of S (XYAH: Cholesky; XYWH, or a failed Cholesky: the pivoted-LU inverse) is the same for the eight rows of a track and
+  // is a serial chain of square roots and divisions: ONE lane per track computes it (the first TPB lanes of the workgroup, a track each)
+  // and leaves it in LDS, instead of every row lane repeating it - a quarter of the kernel's VALU instructions otherwise.
+  if (r == 0) zbuf[tr] = zc;
+  __syncthreads();
+  if (tid < kUpdTracks && base + tid < T.n) {
+    const float* rc = tile + tid * RS;
+    const float hA = rc[3];
+    float sdA[4] = {kWp * hA, kWp * hA, kWp * hA, kWp * hA};
+    if (KIND == MOT_KF_XYAH) {
+      const float zcA = zbuf[tid];
+      sdA[2] = 1e-1f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) K[j] = dot4(pr, Sinv[0][j], Sinv[1][j], Sinv[2][j], Sinv[3][j]);
+      for (int i = 0; i < 4; ++i) sdA[i] = sdA[i] * (1.0f - zcA);
+    }
+    float* fb = fbuf + tid * 20;
+    bool ok = false;
+    if (KIND == MOT_KF_XYAH) {
+      float L[4][4];
+      load_S(rc, sdA, L);
+      ok = chol4(L);
+      if (ok) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(fb + 4 * i) = make_float4(L[i][0], L[i][1], L[i][2], L[i][3]);
+      }
+    }
+    if (!ok) {
+      float S[4][4], Sinv[4][4];
+      load_S(rc, sdA, S);
+      inv_lu4(S, Sinv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(fb + 4 * i) = make_float4(Sinv[i][0], Sinv[i][1], Sinv[i][2], Sinv[i][3]);
+    }
+    fb[16] = ok ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  float K[4];
+  {
+    const float* fb = fbuf + tr * 20;
+    float F[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 a = *reinterpret_cast<const float4*>(fb + 4 * i);
+      F[i][0] = a.x; F[i][1] = a.y; F[i][2] = a.z; F[i][3] = a.w;
+    }
+    if (KIND == MOT_KF_XYAH && fb[16] != 0.0f) {
+      K[0] = P[0]; K[1] = P[1]; K[2] = P[2]; K[3] = P[3];
+      chol4_solve(F, K);
+    } else {
+      const float pr[4] = {P[0], P[1], P[2], P[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) K[j] = dot4(pr, F[0][j], F[1][j], F[2][j], F[3][j]);
+    }
   }
   float inn[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) inn[i] = z[i] - rec[i];
   const float m_new = m + dot4(K, inn[0], inn[1], inn[2], inn[3]);
   float KS[4];
+  {
+    float S[4][4];
+    load_S(rec, sd, S);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) KS[j] = dot4(K, S[0][j], S[1][j], S[2][j], S[3][j]);
-  *reinterpret_cast<float4*>(kbuf + tr * 32 + r * 4) = make_float4(K[0], K[1], K[2], K[3]);
+    for (int j = 0; j < 4; ++j) KS[j] = dot4(K, S[0][j], S[1][j], S[2][j], S[3][j]);
+  }
+  *reinterpret_cast<float4*>(kbuf + tr * 36 + r * 4) = make_float4(K[0], K[1], K[2], K[3]);
   __syncthreads();  // gains published; every lane is done reading S and the mean from the tile
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float4 kj = *reinterpret_cast<const float4*>(kbuf + tr * 32 + j * 4);
+    const float4 kj = *reinterpret_cast<const float4*>(kbuf + tr * 36 + j * 4);
     P[j] = P[j] - dot4(KS, kj.x, kj.y, kj.z, kj.w);
   }
   rec[r] = m_new;
@@ -710,9 +788,10 @@ __global__ void __launch_bounds__(256) kf_update8_kernel(const mot_kf_task* __re
   {
     float4* slab4 = reinterpret_cast<float4*>(T.mean);
     const float4* tile4 = reinterpret_cast<const float4*>(tile);
-    for (int p = tid; p < kUpdTracks * 18; p += 256) {
+#pragma unroll
+    for (int p = tid; p < kUpdTracks * 18; p += NT) {
       const int rc = p / 18, q = p - rc * 18;
-      const int slot = s_dst[rc];
+      const int slot = s_dst[kt * kUpdTracks + rc];
       if (slot >= 0) slab4[static_cast<size_t>(slot) * 18 + q] = tile4[rc * 19 + q];
     }
   }
@@ -722,6 +801,8 @@ __global__ void __launch_bounds__(256) kf_update8_kernel(const mot_kf_task* __re
     if (KIND == MOT_KF_XYAH) w = rec[2] * rec[3];
     const float b = (r == 0) ? rec[0] - w * 0.5f : (r == 1) ? rec[1] - hh * 0.5f : (r == 2) ? rec[0] + w * 0.5f : rec[1] + hh * 0.5f;
     T.boxes[static_cast<size_t>(r) * T.ldb + item] = b;
+  }
+  __syncthreads();  // the tile, the gains and the factors are free for the next tile
   }
 }
 
@@ -874,9 +955,14 @@ hipError_t launch_kf_op(int op, int kind, const mot_kf_task* tasks, int ntasks, 
       static const bool lane_per_track = std::getenv("MOT_KF_UPDATE_LANE_PER_TRACK") != nullptr;  // measurement aid (tools/kf_update_microbench.py)
       if ((kind == MOT_KF_XYAH || kind == MOT_KF_XYWH) && !lane_per_track) {  // the 8-state filters: one lane per covariance row
         if (ntasks <= 0 || max_n <= 0) return hipSuccess;
-        dim3 grid((max_n + kUpdTracks - 1) / kUpdTracks, ntasks), block(256);
-        if (kind == MOT_KF_XYAH) hipLaunchKernelGGL((kf_update8_kernel<MOT_KF_XYAH>), grid, block, 0, st, tasks);
-        else hipLaunchKernelGGL((kf_update8_kernel<MOT_KF_XYWH>), grid, block, 0, st, tasks);
+        static const int tiles = std::getenv("MOT_KF_UPDATE_TILES") ? std::atoi(std::getenv("MOT_KF_UPDATE_TILES")) : 4;  // (measurement aid: 1, 2, 4)
+        const int per = kUpdTracks * ((tiles == 1) ? 1 : (tiles == 2 ? 2 : 4));
+        dim3 grid((max_n + per - 1) / per, ntasks), block(kUpdTracks * 8);
+#define MOT_UPD8(K) { if (tiles == 1) hipLaunchKernelGGL((kf_update8_kernel<K, kUpdTracks, 1>), grid, block, 0, st, tasks); \
+                      else if (tiles == 2) hipLaunchKernelGGL((kf_update8_kernel<K, kUpdTracks, 2>), grid, block, 0, st, tasks); \
+                      else hipLaunchKernelGGL((kf_update8_kernel<K, kUpdTracks, 4>), grid, block, 0, st, tasks); }
+        if (kind == MOT_KF_XYAH) MOT_UPD8(MOT_KF_XYAH) else MOT_UPD8(MOT_KF_XYWH)
+#undef MOT_UPD8
         return hipGetLastError();
       }
       return launch_kf<OP_UPDATE>(kind, tasks, ntasks, max_n, st);

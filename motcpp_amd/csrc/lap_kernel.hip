@@ -275,7 +275,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   // slowest problem: four wavefronts per problem cut that latency (MOT_LAP_BEHIND_T=64 keeps one wavefront per problem).
   static const int behind_t = std::getenv("MOT_LAP_BEHIND_T") ? std::atoi(std::getenv("MOT_LAP_BEHIND_T")) : 64;
   const bool behind = fast && behind_t == 256 && n * m >= 65536 && nm <= 3072;
-  const bool wide = ((nm > 3072) && (ntasks < 512)) || behind;
+  const bool wide = (nm > 3072) || behind;  // (any number of problems: with 64 threads the row lists' parallel scan steps are not available)
   if (fs_lds && wide && b4 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 4; lds = b4; }
   // lane-owned column boxes in registers: one wavefront per problem, <= 8 real columns per lane
   int rpl = 0;
@@ -308,7 +308,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   // shortest-path search are 6144 columns wide). Measured on C4: 4 / 8 / 16 wavefronts = 53 / 88 / 66-79 frames/s — the uniform
   // part of a sweep is paid by every wavefront, and 16 of them leave 128 VGPRs each. MOT_LAP_WIDE8=0 switches it off.
   static const bool wide8_ok = !(std::getenv("MOT_LAP_WIDE8") && std::getenv("MOT_LAP_WIDE8")[0] == '0');
-  const bool wide8 = wide && wide8_ok && ntasks <= 256 && flavor == 1;
+  const bool wide8 = wide && wide8_ok && (ntasks <= 256 || mode == 4) && flavor == 1;  // (mode 4: one problem per CU whatever the width)
   static const int wide_t = std::getenv("MOT_LAP_WIDE_T") ? std::atoi(std::getenv("MOT_LAP_WIDE_T")) : 0;  // (experiments)
   const int threads = (wide && flavor == 1 && (wide_t == 256 || wide_t == 512)) ? wide_t : (wide8 ? 512 : (wide ? 256 : 64));
   bool launched = false;

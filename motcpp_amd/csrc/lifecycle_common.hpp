@@ -90,8 +90,9 @@ struct Allocs {
 // returns once its launches are queued, collect(f) waits for frame f's event only and copies its rows on a second stream. Two sets of
 // packed tables; what the host needs back from a frame travels in page-locked memory:
 //   h_meta: [0] total rows, [1] error flag, [2] problems the sparse solver declined in the first association (-1: not counted),
-//           [3..67) the frame's per-stream maxima (live tracks), then counts out [S], counts in [S]
-constexpr int kMetaHead = 67;
+//           [3..67) the frame's per-stream maxima (live tracks), [67], [68] problems declined in two more associations (-1: not counted),
+//           then counts out [S], counts in [S]
+constexpr int kMetaHead = 69;
 struct Flight {
   float* d_packed = nullptr; int* d_offsets = nullptr; int* d_counts = nullptr; int packed_cap = 0;
   int* h_meta = nullptr;
@@ -123,17 +124,19 @@ struct Flights {
   }
   // behind the frame's launches: pack the staged tables, bring the small results back, record the frame's event
   hipError_t finish(int slot, hipStream_t st, const float* d_stage, int cap_stage, const int* d_out_counts, int S, const int* d_err, const int* d_maxt,
-                    const int* d_declined, int rows_cap, int bd) {
+                    const int* d_declined, int rows_cap, int bd, const int* d_declined_b = nullptr, const int* d_declined_c = nullptr) {
     Flight& F = fl[slot];
     hipLaunchKernelGGL(pack_offsets, dim3(1), dim3(1024), 0, st, d_out_counts, S, F.d_offsets);
     hipLaunchKernelGGL(pack_rows, dim3(S), dim3(256), 0, st, d_stage, cap_stage, d_out_counts, F.d_offsets, F.d_packed, rows_cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    F.h_meta[2] = -1;
+    F.h_meta[2] = -1; F.h_meta[67] = -1; F.h_meta[68] = -1;
     if ((e = hipMemcpyAsync(F.d_counts, d_out_counts, sizeof(int) * S, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(F.h_meta, F.d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(F.h_meta + 1, d_err, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if (d_declined && (e = hipMemcpyAsync(F.h_meta + 2, d_declined, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if (d_declined_b && (e = hipMemcpyAsync(F.h_meta + 67, d_declined_b, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if (d_declined_c && (e = hipMemcpyAsync(F.h_meta + 68, d_declined_c, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(F.h_meta + 3, d_maxt, sizeof(int) * 64, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(F.h_meta + kMetaHead, d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipEventRecord(F.done, st)) != hipSuccess) return e;

@@ -528,7 +528,7 @@ struct mot_oc_batch {
   int bound_n = 0;
   // first association: when (nearly) every problem of a frame was declined by the certified sparse solver (duplicated tracks, quirk Q4:
   // the optimum is not unique), the next frames go to the exact kernel directly; the sparse solver is tried again every 8th frame
-  bool lap1_skip_fast = false;
+  bool skip_fast[3] = {false, false, false};  // per association (first, byte, re-association): the sparse solver declined nearly every problem
   int lap1_age = 0;
   float* d_out = nullptr; int* d_out_counts = nullptr;
   const float* d_packed = nullptr; const int* d_offsets = nullptr; const int* d_counts_last = nullptr;  // mot_oc_device_output: the frame collected last
@@ -561,7 +561,7 @@ int mot_oc_reset(mot_oc_batch* b) {  // OCSort::reset: the tracker list is dropp
   MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
   MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
   b->bound_n = 0;
-  b->lap1_skip_fast = false;
+  b->skip_fast[0] = b->skip_fast[1] = b->skip_fast[2] = false;
   b->lap1_age = 0;
   b->flights.drop_all();  // (frames still in flight have finished: they are dropped with the tracks)
   return MOT_OK;
@@ -710,7 +710,7 @@ int mot_oc_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
 
 // queues one frame of every stream up to the staged output tables (counts: host memory that stays valid until its copy has run);
 // bound = live tracks any stream may have; *declined_out = device counter of the first associations the sparse solver declined
-static int oc_enqueue_frame(mot_oc_batch* b, const float* d_dets, const int* counts, int bound, bool prof, int** declined_out) {
+static int oc_enqueue_frame(mot_oc_batch* b, const float* d_dets, const int* counts, int bound, bool prof, int** declined_out /* [3] */) {
   hipStream_t st = b->ctx->stream;
   const int S = b->S, CAP = b->CAP, D = b->D;
   MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
@@ -730,16 +730,19 @@ static int oc_enqueue_frame(mot_oc_batch* b, const float* d_dets, const int* cou
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[2], st));
   MOT_LC_HIP(b, mot::launch_ocsort(K.cost, S, bd, bn, !general, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[3], st));
-  const bool lap1_fast = !b->lap1_skip_fast || (b->lap1_age % 8) == 0;
-  int* lap1_declined = nullptr;
+  // an association whose problems the sparse solver declined (nine in ten) goes straight to the exact solver, with a retry every eighth frame:
+  // with quirk Q4's duplicate tracks no optimum is unique, and a declined attempt costs as much as a successful one
+  const bool retry = (b->lap1_age % 8) == 0;
+  const bool lap1_fast = !b->skip_fast[0] || retry, lapb_fast = !b->skip_fast[1] || retry, lapr_fast = !b->skip_fast[2] || retry;
+  int* lap1_declined = nullptr; int* lapb_declined = nullptr; int* lapr_declined = nullptr;
   MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bd, bn, false, false, true, st, 0, 0, lap1_fast, &lap1_declined));
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[4], st));
   hipLaunchKernelGGL(oc_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, K);
   if (b->prm.use_byte) {
-    MOT_LC_HIP(b, mot::launch_lap(K.lapb, S, bd, (bn + bd > CAP + D) ? CAP + D : bn + bd, true, general, true, st));
+    MOT_LC_HIP(b, mot::launch_lap(K.lapb, S, bd, (bn + bd > CAP + D) ? CAP + D : bn + bd, true, general, true, st, 0, 0, lapb_fast, &lapb_declined));
     hipLaunchKernelGGL(oc_after_byte, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, K);
   }
-  MOT_LC_HIP(b, mot::launch_lap(K.lapr, S, 2 * bd, bn + bd, true, general, true, st));
+  MOT_LC_HIP(b, mot::launch_lap(K.lapr, S, 2 * bd, bn + bd, true, general, true, st, 0, 0, lapr_fast, &lapr_declined));
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[5], st));
   hipLaunchKernelGGL(oc_finish, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, S, K);
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYSR, K.init, S, 2 * bd, st));
@@ -749,13 +752,14 @@ static int oc_enqueue_frame(mot_oc_batch* b, const float* d_dets, const int* cou
   hipLaunchKernelGGL(oc_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
   if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
   MOT_LC_HIP(b, hipGetLastError());
-  *declined_out = lap1_declined;
+  declined_out[0] = lap1_declined; declined_out[1] = lapb_declined; declined_out[2] = lapr_declined;
   return MOT_OK;
 }
 // what the host keeps from a finished frame: the launch bound of the next one, whether the sparse solver is worth trying, profile sums
-static int oc_account(mot_oc_batch* b, const int* maxt, int declined1, bool prof) {
+static int oc_account(mot_oc_batch* b, const int* maxt, const int declined[3], bool prof) {
   ++b->lap1_age;
-  if (declined1 >= 0) b->lap1_skip_fast = declined1 * 10 >= 9 * b->S;
+  for (int k = 0; k < 3; ++k)
+    if (declined[k] >= 0) b->skip_fast[k] = declined[k] * 10 >= 9 * b->S;
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
   if (prof) {
@@ -778,11 +782,11 @@ int mot_oc_enqueue_packed(mot_oc_batch* b, const float* d_dets, const int* h_cou
   int bd = 0;
   MOT_LC_HIP(b, b->flights.prepare(b->mem, slot, b->S, rows_cap, h_counts, &counts_in, &bd));
   const bool prof = b->profile && b->flights.count == 0;  // (one set of events: profiled only when nothing else is in flight)
-  int* declined = nullptr;
-  const int rc = oc_enqueue_frame(b, d_dets, counts_in, b->bound_n + 2 * b->flights.pending_bd(), prof, &declined);
+  int* declined[3] = {nullptr, nullptr, nullptr};
+  const int rc = oc_enqueue_frame(b, d_dets, counts_in, b->bound_n + 2 * b->flights.pending_bd(), prof, declined);
   if (rc != MOT_OK) return rc;
   b->flight_prof[slot] = prof;
-  MOT_LC_HIP(b, b->flights.finish(slot, b->ctx->stream, b->d_out, b->CAP, b->d_out_counts, b->S, b->d_err, b->d_maxt, declined, rows_cap, bd));
+  MOT_LC_HIP(b, b->flights.finish(slot, b->ctx->stream, b->d_out, b->CAP, b->d_out_counts, b->S, b->d_err, b->d_maxt, declined[0], rows_cap, bd, declined[1], declined[2]));
   return MOT_OK;
 }
 int mot_oc_collect_packed(mot_oc_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows) {
@@ -792,7 +796,8 @@ int mot_oc_collect_packed(mot_oc_batch* b, float* rows, int rows_cap, int* out_c
   mot::lifecycle::Flight* F = nullptr;
   MOT_LC_HIP(b, b->flights.pop(&F));
   const int total = F->h_meta[0], err = F->h_meta[1];
-  const int ra = oc_account(b, F->h_meta + 3, F->h_meta[2], b->flight_prof[slot]);
+  const int dec[3] = {F->h_meta[2], F->h_meta[67], F->h_meta[68]};
+  const int ra = oc_account(b, F->h_meta + 3, dec, b->flight_prof[slot]);
   if (ra != MOT_OK) return ra;
   std::memcpy(out_counts, F->h_meta + mot::lifecycle::kMetaHead, sizeof(int) * b->S);
   if (total_rows) *total_rows = total;

@@ -11,7 +11,7 @@ from motcpp_amd import _lib as L
 class KfTask(C.Structure):
     _fields_ = [("mean", C.c_void_p), ("cov", C.c_void_p), ("cap", C.c_int32), ("n", C.c_int32), ("src", C.c_void_p), ("dst", C.c_void_p),
                 ("flags", C.c_void_p), ("meas", C.c_void_p), ("ldm", C.c_int32), ("midx", C.c_void_p), ("boxes", C.c_void_p), ("ldb", C.c_int32),
-                ("q", C.c_float * 3), ("reserved", C.c_int32), ("warp", C.c_float * 9)]
+                ("q", C.c_float * 3), ("reserved", C.c_int32), ("warp", C.c_float * 9), ("conf", C.c_void_p)]
 
 
 def main():
@@ -49,7 +49,7 @@ def main():
         for s in range(S):
             t = tasks[s]
             t.mean = slab.value + s * cap * 288; t.cov = t.mean + 32; t.cap = cap; t.n = n; t.src = d_idx.value; t.dst = None
-            t.flags = d_flags.value; t.meas = d_meas.value; t.ldm = cap; t.midx = d_idx.value; t.boxes = None
+            t.flags = d_flags.value; t.meas = d_meas.value; t.ldm = cap; t.midx = d_idx.value; t.boxes = None; t.conf = None
         d_tasks = dev(np.frombuffer(bytes(tasks), np.uint8))
         lib.mot_kf_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
         ms = C.c_float()

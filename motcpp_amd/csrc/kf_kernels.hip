@@ -582,84 +582,57 @@ __global__ void __launch_bounds__(kThreads) det_kernel(const mot_det_task* __res
 // the arithmetic removed reach 4.0 (gathered) - 4.7 TB/s (contiguous), which is what this access pattern (288-byte records
 // read and rewritten in place through LDS) can reach; a float4 copy reaches 6.3.
 constexpr int kUpdTracks = 32;
+constexpr int kUpdGroups = 16;  // workgroups per task at most (they stride over the task's tiles)
 
-template <int KIND, int TPB, int TILES>
-__global__ void __launch_bounds__(TPB * 8) kf_update8_kernel(const mot_kf_task* __restrict__ tasks) {
-  // A workgroup walks TILES tiles of TPB tracks. The records (and measurements) of tile k + 1 are requested into registers before tile k is
-  // computed and land in LDS after it: a tile's load latency hides behind the previous tile's arithmetic instead of being waited out with
-  // nothing else to do (measured: the load -> compute -> store phases one after the other reach 3.2 TB/s where the same loads and stores
-  // without the arithmetic reach 4.0-4.7).
+template <int KIND, int TPB>
+__global__ void __launch_bounds__(TPB * 8) __attribute__((amdgpu_waves_per_eu(KIND == MOT_KF_XYAH ? 6 : 8, KIND == MOT_KF_XYAH ? 6 : 8))) kf_update8_kernel(const mot_kf_task* __restrict__ tasks) {
   constexpr int kUpdTracks = TPB, NT = TPB * 8;
-  constexpr int NQ = (TPB * 18 + NT - 1) / NT;  // float4 per thread per tile (18 per record)
   constexpr int RS = tile_stride<8>();  // 76 floats = 19 float4
   __shared__ __attribute__((aligned(16))) float tile[kUpdTracks * RS];
   __shared__ __attribute__((aligned(16))) float kbuf[kUpdTracks * 36];  // (36: the eight tracks of a wavefront read their gain rows from different banks)
   __shared__ __attribute__((aligned(16))) float fbuf[kUpdTracks * 20];  // per track: the 4x4 factor (or inverse) of S, [16] = which
   __shared__ float zbuf[kUpdTracks];
-  __shared__ int s_src[TILES * kUpdTracks], s_dst[TILES * kUpdTracks];
+  __shared__ int s_src[kUpdTracks], s_dst[kUpdTracks];
   const mot_kf_task T = tasks[blockIdx.y];
-  const int base0 = blockIdx.x * (kUpdTracks * TILES);
-  if (base0 >= T.n) return;
-  const int tid = threadIdx.x;
+  // The launch is sized from a BOUND on the items of a task (the host does not know the count the previous kernel left on the device).
+  // A workgroup that finds nothing to do still waits its turn for 17 KB of LDS and four wavefronts' registers: with a bound twice the
+  // count, 0.94 M updates took 0.27 ms instead of 0.16. So a task gets at most kUpdGroups workgroups, which stride over its tiles.
+  for (int base = blockIdx.x * kUpdTracks; base < T.n; base += gridDim.x * kUpdTracks) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // (what derives from the lane index is recomputed per tile instead of staying in registers across the loop)
   const int tr = tid >> 3, r = tid & 7;
-  const int left = T.n - base0;
-  const int ntiles = (left >= kUpdTracks * TILES) ? TILES : (left + kUpdTracks - 1) / kUpdTracks;
-  for (int u = tid; u < TILES * kUpdTracks; u += NT) {
-    const int i = base0 + u;
-    const bool a = i < T.n;
-    const int src = a ? (T.src ? T.src[i] : i) : -1;
-    s_src[u] = src;
-    s_dst[u] = a ? (T.dst ? T.dst[i] : src) : -1;
-  }
-  // the next tile's data, in flight while the current one is worked on
-  float4 R[NQ];
-  float zN[4] = {0.f, 0.f, 0.f, 0.f};
-  float zcN = 0.0f;
-  unsigned fN = 0u;
-  auto request = [&](int k, bool records) {
-    const int it = base0 + k * kUpdTracks + tr;
-    zN[0] = zN[1] = zN[2] = zN[3] = 0.f; zcN = 0.0f; fN = 0u;
-    if (it < T.n) {  // the measurement of the lane's track: two dependent loads (index, then value) that overlap the records'
-      const int c = T.midx ? T.midx[it] : it;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) zN[q] = T.meas[static_cast<size_t>(q) * T.ldm + c];
-      fN = T.flags ? T.flags[it] : 0u;
-      if (KIND == MOT_KF_XYAH && T.conf) zcN = T.conf[c];
-    }
-    if (records) {
-      const float4* slab4 = reinterpret_cast<const float4*>(T.mean);
-#pragma unroll
-      for (int u = 0; u < NQ; ++u) {
-        const int p = tid + u * NT;
-        R[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < kUpdTracks * 18) {
-          const int rc = p / 18, q = p - rc * 18;
-          const int slot = s_src[k * kUpdTracks + rc];
-          if (slot >= 0) R[u] = slab4[static_cast<size_t>(slot) * 18 + q];
-        }
-      }
-    }
-  };
-  request(0, false);  // (the measurement loads do not need the slots: they go out before the barrier)
-  __syncthreads();
-  request(0, true);
-  for (int kt = 0; kt < ntiles; ++kt) {
-  const int base = base0 + kt * kUpdTracks;
   const int item = base + tr;
   const bool active = item < T.n;
-  const float z[4] = {zN[0], zN[1], zN[2], zN[3]};
-  const float zc = zcN;
-  const unsigned f = fN;
+  // the measurement of the lane's track: requested before the records so that its two dependent loads (index, then value) overlap theirs
+  float z[4] = {0.f, 0.f, 0.f, 0.f};
+  float zc = 0.0f;
+  unsigned f = 0u;
+  if (active) {
+    const int c = T.midx ? T.midx[item] : item;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = T.meas[static_cast<size_t>(k) * T.ldm + c];
+    f = T.flags ? T.flags[item] : 0u;
+    if (KIND == MOT_KF_XYAH && T.conf) zc = T.conf[c];
+  }
+  if (tid < kUpdTracks) {
+    const int i = base + tid;
+    const bool a = i < T.n;
+    const int src = a ? (T.src ? T.src[i] : i) : -1;
+    s_src[tid] = src;
+    s_dst[tid] = a ? (T.dst ? T.dst[i] : src) : -1;
+  }
+  __syncthreads();
   {
+    const float4* slab4 = reinterpret_cast<const float4*>(T.mean);
     float4* tile4 = reinterpret_cast<float4*>(tile);
 #pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const int p = tid + u * NT;
-      if (p < kUpdTracks * 18) { const int rc = p / 18, q = p - rc * 18; tile4[rc * 19 + q] = R[u]; }
+    for (int p = tid; p < kUpdTracks * 18; p += NT) {
+      const int rc = p / 18, q = p - rc * 18;
+      const int slot = s_src[rc];
+      if (slot >= 0) tile4[rc * 19 + q] = slab4[static_cast<size_t>(slot) * 18 + q];
     }
   }
   __syncthreads();
-  if (kt + 1 < ntiles) request(kt + 1, true);
   float* rec = tile + tr * RS;
   float P[8];
   {
@@ -791,7 +764,7 @@ __global__ void __launch_bounds__(TPB * 8) kf_update8_kernel(const mot_kf_task* 
 #pragma unroll
     for (int p = tid; p < kUpdTracks * 18; p += NT) {
       const int rc = p / 18, q = p - rc * 18;
-      const int slot = s_dst[kt * kUpdTracks + rc];
+      const int slot = s_dst[rc];
       if (slot >= 0) slab4[static_cast<size_t>(slot) * 18 + q] = tile4[rc * 19 + q];
     }
   }
@@ -802,7 +775,7 @@ __global__ void __launch_bounds__(TPB * 8) kf_update8_kernel(const mot_kf_task* 
     const float b = (r == 0) ? rec[0] - w * 0.5f : (r == 1) ? rec[1] - hh * 0.5f : (r == 2) ? rec[0] + w * 0.5f : rec[1] + hh * 0.5f;
     T.boxes[static_cast<size_t>(r) * T.ldb + item] = b;
   }
-  __syncthreads();  // the tile, the gains and the factors are free for the next tile
+  __syncthreads();  // the tile, the gains, the factors and the slot lists are free for the next tile
   }
 }
 
@@ -955,14 +928,11 @@ hipError_t launch_kf_op(int op, int kind, const mot_kf_task* tasks, int ntasks, 
       static const bool lane_per_track = std::getenv("MOT_KF_UPDATE_LANE_PER_TRACK") != nullptr;  // measurement aid (tools/kf_update_microbench.py)
       if ((kind == MOT_KF_XYAH || kind == MOT_KF_XYWH) && !lane_per_track) {  // the 8-state filters: one lane per covariance row
         if (ntasks <= 0 || max_n <= 0) return hipSuccess;
-        static const int tiles = std::getenv("MOT_KF_UPDATE_TILES") ? std::atoi(std::getenv("MOT_KF_UPDATE_TILES")) : 4;  // (measurement aid: 1, 2, 4)
-        const int per = kUpdTracks * ((tiles == 1) ? 1 : (tiles == 2 ? 2 : 4));
-        dim3 grid((max_n + per - 1) / per, ntasks), block(kUpdTracks * 8);
-#define MOT_UPD8(K) { if (tiles == 1) hipLaunchKernelGGL((kf_update8_kernel<K, kUpdTracks, 1>), grid, block, 0, st, tasks); \
-                      else if (tiles == 2) hipLaunchKernelGGL((kf_update8_kernel<K, kUpdTracks, 2>), grid, block, 0, st, tasks); \
-                      else hipLaunchKernelGGL((kf_update8_kernel<K, kUpdTracks, 4>), grid, block, 0, st, tasks); }
-        if (kind == MOT_KF_XYAH) MOT_UPD8(MOT_KF_XYAH) else MOT_UPD8(MOT_KF_XYWH)
-#undef MOT_UPD8
+        static const int max_gx = std::getenv("MOT_KF_UPDATE_GX") ? std::atoi(std::getenv("MOT_KF_UPDATE_GX")) : kUpdGroups;  // (measurement aid)
+        const int want = (max_n + kUpdTracks - 1) / kUpdTracks;
+        dim3 grid((want < max_gx) ? want : max_gx, ntasks), block(kUpdTracks * 8);
+        if (kind == MOT_KF_XYAH) hipLaunchKernelGGL((kf_update8_kernel<MOT_KF_XYAH, kUpdTracks>), grid, block, 0, st, tasks);
+        else hipLaunchKernelGGL((kf_update8_kernel<MOT_KF_XYWH, kUpdTracks>), grid, block, 0, st, tasks);
         return hipGetLastError();
       }
       return launch_kf<OP_UPDATE>(kind, tasks, ntasks, max_n, st);

@@ -445,9 +445,12 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
   constexpr int D = Dim<KIND>::D;
   __shared__ __attribute__((aligned(16))) float tile[64 * tile_stride<D>()];
   const mot_kf_task T = tasks[blockIdx.y];
-  const int lane = threadIdx.x;
-  const int i = blockIdx.x * kThreads + lane;
-  if (blockIdx.x * kThreads >= T.n) return;  // (whole wavefront)
+  // (a launch is sized from a bound on the items of a task; where the bound is loose - initiations: a few new tracks against the frame's
+  // detection count - the grid is capped and a workgroup strides over the chunks, see kf_update8_kernel)
+  for (int chunk = blockIdx.x; chunk * kThreads < T.n; chunk += gridDim.x) {
+  int lane = threadIdx.x;
+  asm volatile("" : "+v"(lane));  // (nothing derived from the lane index stays in registers across the loop)
+  const int i = chunk * kThreads + lane;
   const bool active = i < T.n;
   const int src = active ? (T.src ? T.src[i] : i) : -1;
   const int dst = active ? (T.dst ? T.dst[i] : src) : -1;
@@ -536,6 +539,8 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
     if constexpr (KIND == MOT_KF_XYSR) xysr_box(s, b); else s8_box<KIND>(s, b);
 #pragma unroll
     for (int k = 0; k < 4; ++k) T.boxes[static_cast<size_t>(k) * T.ldb + i] = b[k];
+  }
+  if ((chunk + static_cast<int>(gridDim.x)) * kThreads < T.n) __syncthreads();  // (another chunk follows: it reuses the tile)
   }
 }
 
@@ -907,7 +912,8 @@ __global__ void __launch_bounds__(kGateThreads) gate_kernel(const mot_gate_task*
 template <int OP>
 hipError_t launch_kf(int kind, const mot_kf_task* tasks, int ntasks, int max_n, hipStream_t st) {
   if (ntasks <= 0 || max_n <= 0) return hipSuccess;
-  dim3 grid((max_n + kThreads - 1) / kThreads, ntasks), block(kThreads);
+  const int want = (max_n + kThreads - 1) / kThreads, cap = (OP == OP_INIT) ? 2 : 64;
+  dim3 grid((want < cap) ? want : cap, ntasks), block(kThreads);
   switch (kind) {
     case MOT_KF_XYSR: hipLaunchKernelGGL((kf_kernel<MOT_KF_XYSR, OP>), grid, block, 0, st, tasks); break;
     case MOT_KF_XYAH: hipLaunchKernelGGL((kf_kernel<MOT_KF_XYAH, OP>), grid, block, 0, st, tasks); break;

@@ -469,6 +469,7 @@ struct mot_bot_batch {
   struct Flight {  // a frame in flight (mot_bot_enqueue_packed / mot_bot_collect_packed)
     float* d_packed = nullptr; int* d_offsets = nullptr; int* d_counts = nullptr; int packed_cap = 0;
     int* h_meta = nullptr;
+    int* d_meta = nullptr;  // device image of h_meta's first 258 + S words (filled by pack_offsets: one copy brings them home)
     hipEvent_t done = nullptr;
     hipEvent_t ev[8] = {};
     bool pending = false, prof = false;
@@ -478,6 +479,7 @@ struct mot_bot_batch {
   int fl_head = 0, fl_count = 0;
   hipStream_t copy_st = nullptr;
   const float* d_rows_last = nullptr; const int* d_offsets_last = nullptr; const int* d_counts_last = nullptr;
+  mot::lifecycle::PackMeta pack_meta;  // set by mot_bot_enqueue_packed around its frame (empty: the packed tables only)
   float* mean = nullptr;   // [S][CAP] Kalman records (8 + 64 floats)
   float* feat = nullptr;   // [S][CAP][E] smooth features
   bool profile = false;
@@ -696,7 +698,7 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYWH, K.obox, S, bn2, st));
   hipLaunchKernelGGL(bot_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt);
   hipLaunchKernelGGL(bot_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
-  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, d_offsets);
+  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, d_offsets, b->pack_meta);
   hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, CAP, b->d_out_counts, d_offsets, d_packed, rows_cap);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
   MOT_LC_HIP(b, hipGetLastError());
@@ -779,9 +781,9 @@ int mot_bot_enqueue_packed(mot_bot_batch* b, const float* d_dets, const int* h_c
   if (!F.done) MOT_LC_HIP(b, hipEventCreateWithFlags(&F.done, hipEventDisableTiming));
   // pinned: [0] total, [1] err, [2..258) maxima, counts out [S], counts in [S], has_warp [S], warps [6 S] (as float bits)
   if (!F.h_meta) MOT_LC_HIP(b, hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (258 + 9 * static_cast<size_t>(S)), hipHostMallocDefault));
-  if (!F.d_offsets) { F.d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1); F.d_counts = b->dalloc<int>(S); }
+  if (!F.d_offsets) { F.d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1); F.d_counts = b->dalloc<int>(S); F.d_meta = b->dalloc<int>(258 + static_cast<size_t>(S)); }
   if (rows_cap > F.packed_cap) { F.d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); F.packed_cap = F.d_packed ? rows_cap : 0; }
-  if (!F.d_offsets || !F.d_counts || !F.d_packed) return MOT_ERR_NOMEM;
+  if (!F.d_offsets || !F.d_counts || !F.d_packed || !F.d_meta) return MOT_ERR_NOMEM;
   int* counts_in = F.h_meta + 258 + S;
   int* hw = F.h_meta + 258 + 2 * S;
   float* wp = reinterpret_cast<float*>(F.h_meta + 258 + 3 * S);
@@ -804,13 +806,13 @@ int mot_bot_enqueue_packed(mot_bot_batch* b, const float* d_dets, const int* h_c
   if (bound > b->CAP) bound = b->CAP;
   if (b->profile && !F.ev[0]) for (auto& e : F.ev) MOT_LC_HIP(b, hipEventCreate(&e));
   F.prof = b->profile;
+  mot::lifecycle::PackMeta pm;
+  pm.dev = F.d_meta; pm.err = b->d_err; pm.maxt = b->d_maxt; pm.n_maxt = 256; pm.maxt_at = 2; pm.counts_at = 258; pm.counts_copy = F.d_counts;
+  b->pack_meta = pm;
   const int rc = bot_enqueue(b, d_dets, counts_in, d_embs, any_warp, bound, F.d_packed, F.d_offsets, rows_cap, F.prof ? F.ev : nullptr);
+  b->pack_meta = mot::lifecycle::PackMeta{};
   if (rc != MOT_OK) return rc;
-  MOT_LC_HIP(b, hipMemcpyAsync(F.d_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToDevice, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta, F.d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 1, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 2, b->d_maxt, sizeof(int) * 256, hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 258, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta, F.d_meta, sizeof(int) * (258 + static_cast<size_t>(S)), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipEventRecord(F.done, st));
   F.pending = true; F.bd = bd; F.rows_cap = rows_cap;
   b->fl_count += 1;

@@ -606,6 +606,7 @@ struct mot_bt_batch {
   struct Flight {
     float* d_packed = nullptr; int* d_offsets = nullptr; int* d_counts = nullptr; int packed_cap = 0;
     int* h_meta = nullptr;  // pinned: [0] total rows, [1] error flag, [2..258) the frame's maxima (d_maxt), then counts out [S], counts in [S]
+    int* d_meta = nullptr;  // device image of h_meta's first 258 + S words (filled by pack_offsets: one copy brings them home)
     hipEvent_t done = nullptr;
     hipEvent_t ev[12] = {};
     bool pending = false, prof = false;
@@ -884,7 +885,7 @@ int mot_bt_step_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts
   if (!b->d_offsets) b->d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1);
   if (rows_cap > b->packed_cap) { b->d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); b->packed_cap = b->d_packed ? rows_cap : 0; }
   if (!b->d_offsets || !b->d_packed) return MOT_ERR_NOMEM;
-  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, b->d_offsets);
+  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, b->d_offsets, mot::lifecycle::PackMeta{});
   hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, b->CAP, b->d_out_counts, b->d_offsets, b->d_packed, rows_cap);
   MOT_LC_HIP(b, hipGetLastError());
   b->d_rows_last = b->d_packed; b->d_offsets_last = b->d_offsets; b->d_counts_last = b->d_out_counts;
@@ -926,9 +927,9 @@ int mot_bt_enqueue_packed(mot_bt_batch* b, const float* d_dets, const int* h_cou
   if (!b->copy_st) MOT_LC_HIP(b, hipStreamCreateWithFlags(&b->copy_st, hipStreamNonBlocking));
   if (!F.done) MOT_LC_HIP(b, hipEventCreateWithFlags(&F.done, hipEventDisableTiming));
   if (!F.h_meta) MOT_LC_HIP(b, hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (258 + 2 * static_cast<size_t>(S)), hipHostMallocDefault));
-  if (!F.d_offsets) { F.d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1); F.d_counts = b->dalloc<int>(S); }
+  if (!F.d_offsets) { F.d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1); F.d_counts = b->dalloc<int>(S); F.d_meta = b->dalloc<int>(258 + static_cast<size_t>(S)); }
   if (rows_cap > F.packed_cap) { F.d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); F.packed_cap = F.d_packed ? rows_cap : 0; }
-  if (!F.d_offsets || !F.d_counts || !F.d_packed) return MOT_ERR_NOMEM;
+  if (!F.d_offsets || !F.d_counts || !F.d_packed || !F.d_meta) return MOT_ERR_NOMEM;
   int bd = 1;
   int* counts_in = F.h_meta + 258 + S;  // page-locked copy: the caller's array may change as soon as this call returns
   for (int s = 0; s < S; ++s) { counts_in[s] = h_counts[s]; bd = (h_counts[s] > bd) ? h_counts[s] : bd; }
@@ -941,14 +942,12 @@ int mot_bt_enqueue_packed(mot_bt_batch* b, const float* d_dets, const int* h_cou
   const int rc = bt_enqueue_frame(b, d_dets, counts_in, b->CAP, F.prof ? F.ev : nullptr);
   b->bound_n = saved;
   if (rc != MOT_OK) return rc;
-  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, F.d_offsets);
+  mot::lifecycle::PackMeta pm;
+  pm.dev = F.d_meta; pm.err = b->d_err; pm.maxt = b->d_maxt; pm.n_maxt = 256; pm.maxt_at = 2; pm.counts_at = 258; pm.counts_copy = F.d_counts;
+  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, F.d_offsets, pm);
   hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, b->CAP, b->d_out_counts, F.d_offsets, F.d_packed, rows_cap);
   MOT_LC_HIP(b, hipGetLastError());
-  MOT_LC_HIP(b, hipMemcpyAsync(F.d_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToDevice, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta, F.d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 1, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 2, b->d_maxt, sizeof(int) * 256, hipMemcpyDeviceToHost, st));
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta + 258, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta, F.d_meta, sizeof(int) * (258 + static_cast<size_t>(S)), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipEventRecord(F.done, st));
   F.pending = true; F.bd = bd; F.rows_cap = rows_cap;
   b->fl_count += 1;

@@ -38,7 +38,20 @@ __device__ __forceinline__ int compact(bool pred, int& base) {
 // has tracks: the reference's ByteTrack keeps tracks in its tracked list without a detection in some branches), then packed
 // back to back so that the copy to the host moves the emitted rows only.
 // offsets[s] = first row of stream s, offsets[S] = total; counts < 0 (a staging overflow) count as 0 rows.
-[[maybe_unused]] static __global__ void __launch_bounds__(1024) pack_offsets(const int* counts, int S, int* offsets) {
+// What the host needs back from a frame, gathered into ONE device buffer (dev == nullptr: nothing) so that one copy brings it home
+// instead of five small ones: [0] total rows, [1] error flag, [dec_at + k] problems the sparse solver declined in association k (-1: not
+// counted), [maxt_at ..) the frame's per-stream maxima, [counts_at ..) the rows per stream; counts_copy = a device copy of the counts
+// that belongs to the frame (the lifecycle's own array is overwritten by the next frame).
+struct PackMeta {
+  int* dev = nullptr;
+  const int* err = nullptr;
+  const int* dec[3] = {nullptr, nullptr, nullptr};
+  int dec_at = -1;
+  const int* maxt = nullptr;
+  int n_maxt = 0, maxt_at = 0, counts_at = 0;
+  int* counts_copy = nullptr;
+};
+[[maybe_unused]] static __global__ void __launch_bounds__(1024) pack_offsets(const int* counts, int S, int* offsets, PackMeta pm) {
   __shared__ int part[1024];
   const int t = static_cast<int>(threadIdx.x);
   const int L = (S + 1023) / 1024;
@@ -56,6 +69,16 @@ __device__ __forceinline__ int compact(bool pred, int& base) {
   int base = part[t] - s;
   for (int i = b0; i < b1; ++i) { offsets[i] = base; const int c = counts[i]; base += (c > 0) ? c : 0; }
   if (t == 1023) offsets[S] = part[1023];
+  if (pm.dev) {
+    if (t == 0) {
+      pm.dev[0] = part[1023];
+      pm.dev[1] = *pm.err;
+      if (pm.dec_at >= 0)
+        for (int k = 0; k < 3; ++k) pm.dev[pm.dec_at + k] = pm.dec[k] ? *pm.dec[k] : -1;
+    }
+    for (int i = t; i < pm.n_maxt; i += 1024) pm.dev[pm.maxt_at + i] = pm.maxt[i];
+    for (int i = t; i < S; i += 1024) { const int c = counts[i]; pm.dev[pm.counts_at + i] = c; if (pm.counts_copy) pm.counts_copy[i] = c; }
+  }
 }
 [[maybe_unused]] static __global__ void __launch_bounds__(256) pack_rows(const float* stage, int cap_stage, const int* counts, const int* offsets, float* packed,
                                                  int packed_cap) {
@@ -89,13 +112,13 @@ struct Allocs {
 // step_packed split in two so that ONE host thread overlaps the result copy of frame f with the kernels of frame f + 1: enqueue(f + 1)
 // returns once its launches are queued, collect(f) waits for frame f's event only and copies its rows on a second stream. Two sets of
 // packed tables; what the host needs back from a frame travels in page-locked memory:
-//   h_meta: [0] total rows, [1] error flag, [2] problems the sparse solver declined in the first association (-1: not counted),
-//           [3..67) the frame's per-stream maxima (live tracks), [67], [68] problems declined in two more associations (-1: not counted),
-//           then counts out [S], counts in [S]
-constexpr int kMetaHead = 69;
+//   h_meta: [0] total rows, [1] error flag, [2..5) problems the sparse solver declined in up to three associations (-1: not counted),
+//           [5..69) the frame's per-stream maxima (live tracks), then counts out [S], counts in [S] (host only)
+constexpr int kMetaDec = 2, kMetaMaxt = 5, kMetaHead = 69;
 struct Flight {
   float* d_packed = nullptr; int* d_offsets = nullptr; int* d_counts = nullptr; int packed_cap = 0;
   int* h_meta = nullptr;
+  int* d_meta = nullptr;  // device image of h_meta's first kMetaHead + S words
   hipEvent_t done = nullptr;
   bool pending = false;
   int rows_cap = 0;  // the row limit pack_rows ran with (the enqueue call's rows_cap)
@@ -113,9 +136,9 @@ struct Flights {
     if (!copy_st && (e = hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking)) != hipSuccess) return e;
     if (!F.done && (e = hipEventCreateWithFlags(&F.done, hipEventDisableTiming)) != hipSuccess) return e;
     if (!F.h_meta && (e = hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (kMetaHead + 2 * static_cast<size_t>(S)), hipHostMallocDefault)) != hipSuccess) return e;
-    if (!F.d_offsets) { F.d_offsets = mem.get<int>(static_cast<size_t>(S) + 1); F.d_counts = mem.get<int>(S); }
+    if (!F.d_offsets) { F.d_offsets = mem.get<int>(static_cast<size_t>(S) + 1); F.d_counts = mem.get<int>(S); F.d_meta = mem.get<int>(kMetaHead + static_cast<size_t>(S)); }
     if (rows_cap > F.packed_cap) { F.d_packed = mem.get<float>(static_cast<size_t>(rows_cap) * 8); F.packed_cap = F.d_packed ? rows_cap : 0; }
-    if (!F.d_offsets || !F.d_counts || !F.d_packed) return hipErrorOutOfMemory;
+    if (!F.d_offsets || !F.d_counts || !F.d_packed || !F.d_meta) return hipErrorOutOfMemory;
     int* ci = F.h_meta + kMetaHead + S;
     int bd = 1;
     for (int s = 0; s < S; ++s) { ci[s] = h_counts[s]; bd = (h_counts[s] > bd) ? h_counts[s] : bd; }
@@ -126,19 +149,14 @@ struct Flights {
   hipError_t finish(int slot, hipStream_t st, const float* d_stage, int cap_stage, const int* d_out_counts, int S, const int* d_err, const int* d_maxt,
                     const int* d_declined, int rows_cap, int bd, const int* d_declined_b = nullptr, const int* d_declined_c = nullptr) {
     Flight& F = fl[slot];
-    hipLaunchKernelGGL(pack_offsets, dim3(1), dim3(1024), 0, st, d_out_counts, S, F.d_offsets);
+    PackMeta pm;
+    pm.dev = F.d_meta; pm.err = d_err; pm.dec[0] = d_declined; pm.dec[1] = d_declined_b; pm.dec[2] = d_declined_c; pm.dec_at = kMetaDec;
+    pm.maxt = d_maxt; pm.n_maxt = 64; pm.maxt_at = kMetaMaxt; pm.counts_at = kMetaHead; pm.counts_copy = F.d_counts;
+    hipLaunchKernelGGL(pack_offsets, dim3(1), dim3(1024), 0, st, d_out_counts, S, F.d_offsets, pm);
     hipLaunchKernelGGL(pack_rows, dim3(S), dim3(256), 0, st, d_stage, cap_stage, d_out_counts, F.d_offsets, F.d_packed, rows_cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    F.h_meta[2] = -1; F.h_meta[67] = -1; F.h_meta[68] = -1;
-    if ((e = hipMemcpyAsync(F.d_counts, d_out_counts, sizeof(int) * S, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(F.h_meta, F.d_offsets + S, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(F.h_meta + 1, d_err, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    if (d_declined && (e = hipMemcpyAsync(F.h_meta + 2, d_declined, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    if (d_declined_b && (e = hipMemcpyAsync(F.h_meta + 67, d_declined_b, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    if (d_declined_c && (e = hipMemcpyAsync(F.h_meta + 68, d_declined_c, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(F.h_meta + 3, d_maxt, sizeof(int) * 64, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(F.h_meta + kMetaHead, d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(F.h_meta, F.d_meta, sizeof(int) * (kMetaHead + static_cast<size_t>(S)), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipEventRecord(F.done, st)) != hipSuccess) return e;
     F.pending = true; F.bd = bd; F.rows_cap = rows_cap;
     count += 1;

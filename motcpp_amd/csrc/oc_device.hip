@@ -796,8 +796,8 @@ int mot_oc_collect_packed(mot_oc_batch* b, float* rows, int rows_cap, int* out_c
   mot::lifecycle::Flight* F = nullptr;
   MOT_LC_HIP(b, b->flights.pop(&F));
   const int total = F->h_meta[0], err = F->h_meta[1];
-  const int dec[3] = {F->h_meta[2], F->h_meta[67], F->h_meta[68]};
-  const int ra = oc_account(b, F->h_meta + 3, dec, b->flight_prof[slot]);
+  const int dec[3] = {F->h_meta[mot::lifecycle::kMetaDec], F->h_meta[mot::lifecycle::kMetaDec + 1], F->h_meta[mot::lifecycle::kMetaDec + 2]};
+  const int ra = oc_account(b, F->h_meta + mot::lifecycle::kMetaMaxt, dec, b->flight_prof[slot]);
   if (ra != MOT_OK) return ra;
   std::memcpy(out_counts, F->h_meta + mot::lifecycle::kMetaHead, sizeof(int) * b->S);
   if (total_rows) *total_rows = total;

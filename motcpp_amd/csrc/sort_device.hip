@@ -444,7 +444,7 @@ int mot_sort_collect_packed(mot_sort_batch* b, float* rows, int rows_cap, int* o
   mot::lifecycle::Flight* F = nullptr;
   MOT_LC_HIP(b, b->flights.pop(&F));
   const int total = F->h_meta[0], err = F->h_meta[1];
-  const int ra = sort_account(b, F->h_meta + 3, false);
+  const int ra = sort_account(b, F->h_meta + mot::lifecycle::kMetaMaxt, false);
   if (ra != MOT_OK) return ra;
   std::memcpy(out_counts, F->h_meta + mot::lifecycle::kMetaHead, sizeof(int) * b->S);
   if (total_rows) *total_rows = total;

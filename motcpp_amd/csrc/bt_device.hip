@@ -521,54 +521,57 @@ __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP, int v
 }
 
 // ---- K3: duplicate removal and the output table (:582-621, :659-706) ----
-__global__ void __launch_bounds__(kW) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks) {
+// Four wavefronts per stream (as bt_after_first): the lists are ~800 entries of dependent loads (slot, then the slot's fields), which one
+// wavefront walks in 13 rounds.
+__global__ void __launch_bounds__(kAF) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks) {
+  __shared__ int cnt[kAF / 64][3];
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
   int* act = S.active[S.cur];
   int* lst = S.lost[S.cur];
   float* rows = out + static_cast<size_t>(blockIdx.x) * cap_out * 8;
-  const bool dups = S.n_active > 0 && S.n_lost > 0;
+  const int n_active = S.n_active, n_lost = S.n_lost;
+  const bool dups = n_active > 0 && n_lost > 0;
   int free_top = S.n_free;
   int n_keep = 0, n_rows = 0;
-  for (int i0 = 0; i0 < S.n_active; i0 += kW) {
+  for (int i0 = 0; i0 < n_active; i0 += kAF) {
     const int i = i0 + t;
-    const bool v = i < S.n_active;
+    const bool v = i < n_active;
     const int slot = v ? act[i] : 0;
     const bool dup = v && dups && S.dup_a[i] != 0;
     const bool keep = v && !dup;
     const bool emit = keep && S.t_act[slot] != 0;
     float b[4] = {0.f, 0.f, 0.f, 0.f};
+    float rid = 0.f, rconf = 0.f, rcls = 0.f, rdet = 0.f;
     if (emit) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) b[k] = S.abox[static_cast<size_t>(k) * CAP + i];
+      rid = static_cast<float>(S.t_id[slot]); rconf = S.t_conf[slot];
+      rcls = static_cast<float>(S.t_cls[slot]); rdet = static_cast<float>(S.t_det[slot]);
     }
-    __syncthreads();  // act[] entries of this chunk are read before the compacted list overwrites them (p <= i)
-    const int p = compact(keep, n_keep);
-    if (keep) act[p] = slot;
-    const int pr = compact(emit, n_rows);
-    if (emit && pr < cap_out) {
-      float* r = rows + static_cast<size_t>(pr) * 8;
-      r[0] = b[0]; r[1] = b[1]; r[2] = b[2]; r[3] = b[3];
-      r[4] = static_cast<float>(S.t_id[slot]); r[5] = S.t_conf[slot];
-      r[6] = static_cast<float>(S.t_cls[slot]); r[7] = static_cast<float>(S.t_det[slot]);
+    // (the barrier inside: act[] entries of this chunk are read before the compacted list overwrites them, p <= i)
+    const Compact3 c = compact3_block(keep, emit, dup, n_keep, n_rows, free_top, cnt);
+    if (keep) act[c.pos[0]] = slot;
+    if (emit && c.pos[1] < cap_out) {
+      float4* r = reinterpret_cast<float4*>(rows + static_cast<size_t>(c.pos[1]) * 8);
+      r[0] = make_float4(b[0], b[1], b[2], b[3]);
+      r[1] = make_float4(rid, rconf, rcls, rdet);
     }
-    const int pf = compact(dup, free_top);
-    if (dup) S.free_stack[pf] = slot;
-    __syncthreads();
+    if (dup) S.free_stack[c.pos[2]] = slot;
   }
   int n_keep_l = 0;
-  for (int i0 = 0; i0 < S.n_lost; i0 += kW) {
-    const int i = i0 + t;
-    const bool v = i < S.n_lost;
-    const int slot = v ? lst[i] : 0;
-    const bool dup = v && dups && S.dup_b[i] != 0;
-    const bool keep = v && !dup;
-    __syncthreads();
-    const int p = compact(keep, n_keep_l);
-    if (keep) lst[p] = slot;
-    const int pf = compact(dup, free_top);
-    if (dup) S.free_stack[pf] = slot;
-    __syncthreads();
+  {
+    int z = 0;
+    for (int i0 = 0; i0 < n_lost; i0 += kAF) {
+      const int i = i0 + t;
+      const bool v = i < n_lost;
+      const int slot = v ? lst[i] : 0;
+      const bool dup = v && dups && S.dup_b[i] != 0;
+      const bool keep = v && !dup;
+      const Compact3 c = compact3_block(keep, dup, false, n_keep_l, free_top, z, cnt);
+      if (keep) lst[c.pos[0]] = slot;
+      if (dup) S.free_stack[c.pos[1]] = slot;
+    }
   }
   if (t == 0) {
     S.n_active = n_keep; S.n_lost = n_keep_l; S.n_free = free_top;
@@ -815,7 +818,7 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
     if (!full) hipLaunchKernelGGL(bt_dups<1>, dim3(S), dim3(256), static_cast<size_t>(28) * items, st, b->d_streams, CAP, verify, items);
     else hipLaunchKernelGGL(bt_dups<2>, dim3(S), dim3(256), static_cast<size_t>(16) * items, st, b->d_streams, CAP, 0, items);
   }
-  hipLaunchKernelGGL(bt_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);
+  hipLaunchKernelGGL(bt_finish, dim3(S), dim3(kAF), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);
   hipLaunchKernelGGL(bt_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[5], st));
   MOT_LC_HIP(b, hipGetLastError());

@@ -62,53 +62,72 @@ struct BtStream {
 
 
 
+constexpr int kAF = 256;
+struct Compact3 {  // three order-preserving appends of one round, one exchange
+  int pos[3];
+};
+__device__ __forceinline__ Compact3 compact3_block(bool p0, bool p1, bool p2, int& b0, int& b1, int& b2, int (*cnt)[3]) {
+  const int lane = static_cast<int>(threadIdx.x) & 63, w = static_cast<int>(threadIdx.x) >> 6;
+  const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2);
+  if (lane == 0) { cnt[w][0] = __popcll(m0); cnt[w][1] = __popcll(m1); cnt[w][2] = __popcll(m2); }
+  __syncthreads();
+  int before[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
+  for (int k = 0; k < kAF / 64; ++k)
+    for (int q = 0; q < 3; ++q) { const int c = cnt[k][q]; if (k < w) before[q] += c; tot[q] += c; }
+  __syncthreads();  // (the counts are rewritten by the next round)
+  const unsigned long long below = (1ull << lane) - 1ull;
+  Compact3 r;
+  r.pos[0] = b0 + before[0] + __popcll(m0 & below);
+  r.pos[1] = b1 + before[1] + __popcll(m1 & below);
+  r.pos[2] = b2 + before[2] + __popcll(m2 & below);
+  b0 += tot[0]; b1 += tot[1]; b2 += tot[2];
+  return r;
+}
 // ---- K0: detection split, pools, predict + first-association tasks (bytetrack.cpp:166-265) ----
 // stats[0] = assignment problems queued, stats[1] = sum of their n + m (algorithmic bytes of the solver: 24 B per row/column)
-__global__ void __launch_bounds__(kW) bt_begin(BtStream* streams, BtParams P, int CAP, int D, const int* counts, const float* dets_base,
-                                                mot_det_task* det_t, mot_kf_task* pred_t, mot_lap_task* lap1_t, unsigned long long* stats, int* maxt) {
+__global__ void __launch_bounds__(kAF) bt_begin(BtStream* streams, BtParams P, int CAP, int D, const int* counts, const float* dets_base,
+                                                 mot_det_task* det_t, mot_kf_task* pred_t, mot_lap_task* lap1_t, unsigned long long* stats, int* maxt) {
+  __shared__ int cnt[kAF / 64][3];
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
   const int n = counts[blockIdx.x];
   const float* dets = dets_base + static_cast<size_t>(blockIdx.x) * 6 * D;
+  const int n_active = S.n_active, n_lost = S.n_lost;
+  const int* act = S.active[S.cur];
+  const int* lst = S.lost[S.cur];
+  __syncthreads();  // (everyone has read the scalars the first lane updates below)
   if (t == 0) {
     S.frame_count += 1;
     S.dets = dets; S.ld = D; S.n = n;
     if (n > D) S.err = 1;
   }
   const float* conf = dets + static_cast<size_t>(4) * D;
-  int nh = 0, ns = 0;
-  for (int i0 = 0; i0 < n; i0 += kW) {
+  int nh = 0, ns = 0, z = 0;
+  for (int i0 = 0; i0 < n; i0 += kAF) {
     const int i = i0 + t;
     const float c = (i < n) ? conf[i] : 0.f;
     const bool hi = i < n && c > P.track_thresh;
     const bool lo = i < n && c > P.min_conf && c < P.track_thresh;
-    const int ph = compact(hi, nh);
-    if (hi) S.high[ph] = i;
-    const int pl = compact(lo, ns);
-    if (lo) S.second[pl] = i;
+    const Compact3 k = compact3_block(hi, lo, false, nh, ns, z, cnt);
+    if (hi) S.high[k.pos[0]] = i;
+    if (lo) S.second[k.pos[1]] = i;
   }
-  const int* act = S.active[S.cur];
-  const int* lst = S.lost[S.cur];
   int np = 0, nu = 0;
-  for (int i0 = 0; i0 < S.n_active; i0 += kW) {
+  for (int i0 = 0; i0 < n_active; i0 += kAF) {
     const int i = i0 + t;
-    const int slot = (i < S.n_active) ? act[i] : 0;
-    const bool a = i < S.n_active && S.t_act[slot] != 0;
-    const bool u = i < S.n_active && S.t_act[slot] == 0;
-    const int pa = compact(a, np);
-    if (a) S.pool_slot[pa] = slot;
-    const int pu = compact(u, nu);
-    if (u) S.unconf_slot[pu] = slot;
+    const int slot = (i < n_active) ? act[i] : 0;
+    const int ta = (i < n_active) ? S.t_act[slot] : 0;
+    const bool a = i < n_active && ta != 0;
+    const bool u = i < n_active && ta == 0;
+    const Compact3 k = compact3_block(a, u, false, np, nu, z, cnt);
+    if (a) S.pool_slot[k.pos[0]] = slot;
+    if (u) S.unconf_slot[k.pos[1]] = slot;
   }
   const int n_tracked = np;
-  for (int i0 = 0; i0 < S.n_lost; i0 += kW) {  // tracked and lost are disjoint by id at frame start (:565-580 of the previous frame)
-    const int i = i0 + t;
-    const bool v = i < S.n_lost;
-    const int p = compact(v, np);
-    if (v) S.pool_slot[p] = lst[i];
-  }
+  for (int i = t; i < n_lost; i += kAF) S.pool_slot[np + i] = lst[i];  // tracked and lost are disjoint by id at frame start (:565-580 of the previous frame)
+  np += n_lost;
   __syncthreads();
-  for (int i = t; i < np; i += kW) {  // the reference predicts COPIES of the pool (:251-265): here the prediction is box-only
+  for (int i = t; i < np; i += kAF) {  // the reference predicts COPIES of the pool (:251-265): here the prediction is box-only
     const int slot = S.pool_slot[i];
     S.pred_src[i] = slot;
     S.pred_dst[i] = slot;
@@ -137,27 +156,6 @@ __global__ void __launch_bounds__(kW) bt_begin(BtStream* streams, BtParams P, in
 // Four wavefronts per stream (round 3; one wavefront walked the 1000-row pool in 16 dependent rounds: 215 us per launch at the
 // north-star shape). The lists stay in the reference's order: an append position = entries before this round + entries of the earlier
 // wavefronts of the round + the lane's rank inside its wavefront (ballot + popcount); the wavefronts' counts meet in LDS.
-constexpr int kAF = 256;
-struct Compact3 {  // three order-preserving appends of one round, one exchange
-  int pos[3];
-};
-__device__ __forceinline__ Compact3 compact3_block(bool p0, bool p1, bool p2, int& b0, int& b1, int& b2, int (*cnt)[3]) {
-  const int lane = static_cast<int>(threadIdx.x) & 63, w = static_cast<int>(threadIdx.x) >> 6;
-  const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2);
-  if (lane == 0) { cnt[w][0] = __popcll(m0); cnt[w][1] = __popcll(m1); cnt[w][2] = __popcll(m2); }
-  __syncthreads();
-  int before[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
-  for (int k = 0; k < kAF / 64; ++k)
-    for (int q = 0; q < 3; ++q) { const int c = cnt[k][q]; if (k < w) before[q] += c; tot[q] += c; }
-  __syncthreads();  // (the counts are rewritten by the next round)
-  const unsigned long long below = (1ull << lane) - 1ull;
-  Compact3 r;
-  r.pos[0] = b0 + before[0] + __popcll(m0 & below);
-  r.pos[1] = b1 + before[1] + __popcll(m1 & below);
-  r.pos[2] = b2 + before[2] + __popcll(m2 & below);
-  b0 += tot[0]; b1 += tot[1]; b2 += tot[2];
-  return r;
-}
 __global__ void __launch_bounds__(kAF) bt_after_first(BtStream* streams, BtParams P, int CAP, mot_kf_task* box_t, mot_lap_task* lap23_t,
                                                       unsigned long long* stats, int* maxt) {
   __shared__ int cnt[kAF / 64][3];
@@ -245,11 +243,19 @@ __global__ void __launch_bounds__(kAF) bt_after_first(BtStream* streams, BtParam
 }
 
 // ---- K2: apply associations 2 and 3, births, deaths, list algebra, queue the Kalman work (:442-580) ----
-__global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParams P, int CAP, mot_kf_task* init_t, mot_kf_task* upd_t,
+__global__ void __launch_bounds__(kAF) bt_after_second(BtStream* streams, BtParams P, int CAP, mot_kf_task* init_t, mot_kf_task* upd_t,
                                                        mot_kf_task* box2_t, mot_iou_task* dup_t, unsigned long long* stats) {
+  // Four wavefronts per stream. The first part (second association, unconfirmed tracks, births) walks lists of a few dozen entries and
+  // hands out slots in order: the first wavefront does it alone; the list algebra over the ~800 active tracks is shared by all four.
+  __shared__ int cnt[kAF / 64][3];
+  __shared__ int sh[8];
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
+  auto wave_sync = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };  // (one wavefront: its loads have landed before its next stores go out)
   int n_upd = S.n_upd, n_ln = 0;
+  int n_init = 0;
+  int free_top = S.n_free, next_slot = S.next_slot, err = 0;
+  if (t < kW) {
   if (S.lap2_q) {
     for (int i0 = 0; i0 < S.n_r; i0 += kW) {
       const int i = i0 + t;
@@ -282,10 +288,10 @@ __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParam
       const int j = j0 + t;
       const bool u = j < S.n_udet && S.y3[j] < 0;
       const int val = (j < S.n_udet) ? S.u_det[j] : 0;
-      __syncthreads();
+      wave_sync();
       const int p = compact(u, n_udf);  // p <= j: never overwrites an unread entry
       if (u) udf[p] = val;
-      __syncthreads();
+      wave_sync();
     }
     for (int i0 = 0; i0 < S.n_unconf; i0 += kW) {
       const int i = i0 + t;
@@ -311,10 +317,8 @@ __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParam
     for (int j = t; j < S.n_udet; j += kW) udf[j] = S.u_det[j];
     n_udf = S.n_udet;
   }
-  __syncthreads();
+  wave_sync();
   // births (:546-554): ids in list order
-  int n_init = 0;
-  int free_top = S.n_free, next_slot = S.next_slot, err = 0;
   for (int j0 = 0; j0 < n_udf; j0 += kW) {
     const int k = j0 + t;
     const int det = (k < n_udf) ? S.high[udf[k]] : 0;
@@ -343,9 +347,14 @@ __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParam
     free_top -= from_free;
   }
   err = __any(err) ? 1 : 0;
+  if (t == 0) { sh[0] = n_upd; sh[1] = n_ln; sh[2] = n_init; sh[3] = free_top; sh[4] = next_slot; sh[5] = err; }
+  }
+  __syncthreads();
+  n_upd = sh[0]; n_ln = sh[1]; n_init = sh[2]; free_top = sh[3]; next_slot = sh[4]; err = sh[5];
+  const int n_active = S.n_active, n_lost = S.n_lost, n_refind = S.n_refind;
   const int* lst = S.lost[S.cur];
   const int* act = S.active[S.cur];
-  for (int i = t; i < S.n_lost; i += kW) {  // :557-562
+  for (int i = t; i < n_lost; i += kAF) {  // :557-562
     const int slot = lst[i];
     if (S.frame_count - S.t_fid[slot] > P.max_time_lost) S.t_state[slot] = Removed;
   }
@@ -353,44 +362,42 @@ __global__ void __launch_bounds__(kW) bt_after_second(BtStream* streams, BtParam
   // list algebra (:565-580). A track lives in exactly one record, so the reference's copies are moves.
   int* na = S.active[S.cur ^ 1];
   int* nl = S.lost[S.cur ^ 1];
-  int n_na = 0, n_nl = 0;
-  for (int i0 = 0; i0 < S.n_active; i0 += kW) {
+  int n_na = 0, n_nl = 0, z = 0;
+  for (int i0 = 0; i0 < n_active; i0 += kAF) {
     const int i = i0 + t;
-    const int slot = (i < S.n_active) ? act[i] : 0;
-    const int st = (i < S.n_active) ? S.t_state[slot] : -1;
+    const int slot = (i < n_active) ? act[i] : 0;
+    const int st = (i < n_active) ? S.t_state[slot] : -1;
     const bool k = st == Tracked;
-    const int p = compact(k, n_na);
-    if (k) na[p] = slot;
     const bool dead = st == Removed;
-    const int pf = compact(dead, free_top);
-    if (dead) S.free_stack[pf] = slot;
+    const Compact3 c = compact3_block(k, dead, false, n_na, free_top, z, cnt);
+    if (k) na[c.pos[0]] = slot;
+    if (dead) S.free_stack[c.pos[1]] = slot;
   }
-  if (n_na + n_init + S.n_refind > CAP) err = 1;
+  if (n_na + n_init + n_refind > CAP) err = 1;
   else {
-    for (int i = t; i < n_init; i += kW) na[n_na + i] = S.init_dst[i];
+    for (int i = t; i < n_init; i += kAF) na[n_na + i] = S.init_dst[i];
     n_na += n_init;
-    for (int i = t; i < S.n_refind; i += kW) na[n_na + i] = S.refind[i];  // re-found lost tracks, in match order
-    n_na += S.n_refind;
+    for (int i = t; i < n_refind; i += kAF) na[n_na + i] = S.refind[i];  // re-found lost tracks, in match order
+    n_na += n_refind;
   }
-  for (int i0 = 0; i0 < S.n_lost; i0 += kW) {
+  for (int i0 = 0; i0 < n_lost; i0 += kAF) {
     const int i = i0 + t;
-    const int slot = (i < S.n_lost) ? lst[i] : 0;
-    const int st = (i < S.n_lost) ? S.t_state[slot] : -1;
+    const int slot = (i < n_lost) ? lst[i] : 0;
+    const int st = (i < n_lost) ? S.t_state[slot] : -1;
     const bool k = st == Lost;          // Tracked = re-found (now active), Removed = aged out
-    const int p = compact(k, n_nl);
-    if (k) nl[p] = slot;
     const bool dead = st == Removed;
-    const int pf = compact(dead, free_top);
-    if (dead) S.free_stack[pf] = slot;
+    const Compact3 c = compact3_block(k, dead, false, n_nl, free_top, z, cnt);
+    if (k) nl[c.pos[0]] = slot;
+    if (dead) S.free_stack[c.pos[1]] = slot;
   }
   if (n_nl + n_ln > CAP) err = 1;
   else {
-    for (int i = t; i < n_ln; i += kW) nl[n_nl + i] = S.lost_new[i];
+    for (int i = t; i < n_ln; i += kAF) nl[n_nl + i] = S.lost_new[i];
     n_nl += n_ln;
   }
   __syncthreads();
-  for (int i = t; i < n_na && i < CAP; i += kW) { const int slot = na[i]; S.age_a[i] = S.t_fid[slot] - S.t_sf[slot]; S.dup_a[i] = 0; }
-  for (int i = t; i < n_nl && i < CAP; i += kW) { const int slot = nl[i]; S.age_b[i] = S.t_fid[slot] - S.t_sf[slot]; S.dup_b[i] = 0; }
+  for (int i = t; i < n_na && i < CAP; i += kAF) { const int slot = na[i]; S.age_a[i] = S.t_fid[slot] - S.t_sf[slot]; S.dup_a[i] = 0; }
+  for (int i = t; i < n_nl && i < CAP; i += kAF) { const int slot = nl[i]; S.age_b[i] = S.t_fid[slot] - S.t_sf[slot]; S.dup_b[i] = 0; }
   if (t == 0) {
     S.n_upd = n_upd; S.n_init = n_init; S.n_lost_new = n_ln;
     S.next_id += n_init; S.next_slot = next_slot; S.n_free = free_top;
@@ -791,7 +798,7 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;  // lists after this frame's births
   const bool prof = b->profile;
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
-  hipLaunchKernelGGL(bt_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr, b->d_maxt);
+  hipLaunchKernelGGL(bt_begin, dim3(S), dim3(kAF), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr, b->d_maxt);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, bd, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[6], st));
   MOT_LC_HIP(b, mot::launch_kf_op(6, MOT_KF_XYAH, b->pred_t, S, bn, st));  // predicted boxes of the pool (box-only: nothing is stored)
@@ -803,7 +810,7 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, true, st, b->hint23_n, b->hint23_m));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
-  hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t, prof ? b->d_stats : nullptr);
+  hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(kAF), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t, prof ? b->d_stats : nullptr);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[7], st));
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYAH, b->init_t, S, bd, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[8], st));

@@ -812,7 +812,7 @@ int mot_bot_enqueue_packed(mot_bot_batch* b, const float* d_dets, const int* h_c
   const int rc = bot_enqueue(b, d_dets, counts_in, d_embs, any_warp, bound, F.d_packed, F.d_offsets, rows_cap, F.prof ? F.ev : nullptr);
   b->pack_meta = mot::lifecycle::PackMeta{};
   if (rc != MOT_OK) return rc;
-  MOT_LC_HIP(b, hipMemcpyAsync(F.h_meta, F.d_meta, sizeof(int) * (258 + static_cast<size_t>(S)), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, mot::lifecycle::copy_meta_d2h(F.h_meta, F.d_meta, 258 + static_cast<size_t>(S), st));
   MOT_LC_HIP(b, hipEventRecord(F.done, st));
   F.pending = true; F.bd = bd; F.rows_cap = rows_cap;
   b->fl_count += 1;

@@ -96,8 +96,7 @@ struct LapWorkT {
   MemPtr<int, kMemGlobal> sa, sb, sc;  // staging of the closed-form tie runs that do not fit in registers (slow path)
   // optional (null: the parallel scan steps and the sparse real-row sweeps are off) — see "row lists" in lap_solve
   MemPtr<int, kMemGlobal> rl_cnt;     // [nr] entries of real row i with cost < half (may exceed kRlCap: then the row has no usable list)
-  MemPtr<int, kMemGlobal> rl_col;     // [nr][kRlCap] their columns ...
-  MemPtr<float, kMemGlobal> rl_cost;  // ... and costs
+  MemPtr<unsigned long long, kMemGlobal> rl_ent;  // [nr][kRlCap] their (column | cost bits << 32): one 8-byte load per entry, a row's first 16 entries in one 128-byte line
   MemPtr<int, VS == kMemAny ? kMemAny : kMemLds> fsw;  // kFsWsInts ints of fast scratch (always LDS on the device): step members + tie events
   bool cyc_ext = false;      // cyc has 36 entries: [16..23] cycles inside phase 3 (step classification, dry run, apply, event sort, event replay, _find_dense, one-at-a-time sweeps, search set-up)
   long long* cyc = nullptr;  // optional profiling [16]: [0..3] cycles in phase 1a (column minima), 1b (transfer), 2, 3; [4..7] n_uniq, serial row-reduction rounds, serial augmentations, n;
@@ -118,13 +117,17 @@ constexpr int kFsMaxN = 8192;   // extended size up to which the TODO bitmask fi
 // event list (q, j, k, row, cost, list length) | sorted events (q, j, k, flags, row, cost, list length) + head slots (column, event) | TODO bitmask
 constexpr int kFsM = 0, kFsCtr = 5 * kFsMaxMembers, kFsKeep = kFsCtr + 8, kFsEvl = kFsKeep + 2 * kFsHash, kFsEvs = kFsEvl + 6 * kEvCap,
               kFsTodo = kFsEvs + 9 * kEvCap, kFsWsInts = kFsTodo + kFsMaxN / 32 + 8;
-MOT_HD size_t lap_rowlist_bytes(int nr) { return static_cast<size_t>(nr > 0 ? nr : 0) * (4 + 8 * static_cast<size_t>(kRlCap)) + 32; }
+MOT_HD unsigned long long rl_pack(int col, float cost) {
+  return static_cast<unsigned long long>(static_cast<unsigned>(col)) | (static_cast<unsigned long long>(__builtin_bit_cast(unsigned, cost)) << 32);
+}
+MOT_HD int rl_col_of(unsigned long long e) { return static_cast<int>(static_cast<unsigned>(e & 0xffffffffull)); }
+MOT_HD float rl_cost_of(unsigned long long e) { return __builtin_bit_cast(float, static_cast<unsigned>(e >> 32)); }
+MOT_HD size_t lap_rowlist_bytes(int nr) { return static_cast<size_t>(nr > 0 ? nr : 0) * (4 + 8 * static_cast<size_t>(kRlCap)) + 160; }
 template <class Work>
 MOT_HD void lap_carve_rowlist(Work& w, void* base, int nr) {
   char* p = static_cast<char*>(base);
-  w.rl_cnt.p = reinterpret_cast<int*>(p); p += ((sizeof(int) * static_cast<size_t>(nr > 0 ? nr : 0)) + 15) & ~size_t(15);
-  w.rl_col.p = reinterpret_cast<int*>(p); p += sizeof(int) * static_cast<size_t>(kRlCap) * (nr > 0 ? nr : 0);
-  w.rl_cost.p = reinterpret_cast<float*>(p);
+  w.rl_cnt.p = reinterpret_cast<int*>(p); p += ((sizeof(int) * static_cast<size_t>(nr > 0 ? nr : 0)) + 127) & ~size_t(127);  // (a row's entries start on a line)
+  w.rl_ent.p = reinterpret_cast<unsigned long long*>(p);
 }
 MOT_HD size_t lap_work_bytes(int n) { return lap_hot_bytes(n) + lap_cold_bytes(n); }
 template <class Work>
@@ -482,7 +485,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
       if constexpr (is_matrix_cost<Cost>::value) {
         if (use_rl && c < half) {
           const int slot = G::atomic_add(W.rl_cnt.raw(i), 1);
-          if (slot < kRlCap) { W.rl_col[static_cast<long>(i) * kRlCap + slot] = j; W.rl_cost[static_cast<long>(i) * kRlCap + slot] = static_cast<float>(c); }
+          if (slot < kRlCap) W.rl_ent[static_cast<long>(i) * kRlCap + slot] = rl_pack(j, static_cast<float>(c));
         }
       }
     }
@@ -1318,8 +1321,9 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 const int e = (t + it * T) % kRlCap;
                 ej[it] = -1; cc[it] = 0.f;
                 if (e < cn[it]) {
-                  ej[it] = W.rl_col[static_cast<long>(row[it]) * kRlCap + e];
-                  cc[it] = W.rl_cost[static_cast<long>(row[it]) * kRlCap + e];
+                  const unsigned long long ent = W.rl_ent[static_cast<long>(row[it]) * kRlCap + e];
+                  ej[it] = rl_col_of(ent);
+                  cc[it] = rl_cost_of(ent);
                 }
               }
             };
@@ -1709,8 +1713,9 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 // fact (2) above: the columns at or above half cannot be lowered by this row — its list is the whole sweep
                 const int ne = W.rl_cnt[i];
                 for (int e = t; e < ne; e += T) {
-                  const int j = W.rl_col[static_cast<long>(i) * kRlCap + e];
-                  relax_pre(static_cast<double>(static_cast<float>(W.rl_cost[static_cast<long>(i) * kRlCap + e])) - W.v[j], j, W.inv[j], W.d[j]);
+                  const unsigned long long ent = W.rl_ent[static_cast<long>(i) * kRlCap + e];
+                  const int j = rl_col_of(ent);
+                  relax_pre(static_cast<double>(rl_cost_of(ent)) - W.v[j], j, W.inv[j], W.d[j]);
                 }
               } else if (sweep_real) {
                 if (R.real) {

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -92,6 +93,19 @@ struct PackMeta {
   for (int i = threadIdx.x; i < 2 * c; i += 256) dst[i] = src[i];
 }
 
+// The frame's meta words, device -> page-locked host. hipMemcpyAsync takes a much slower route for a device-to-host copy above 16 KB
+// (measured: one 16.6 KB copy per frame took SORT from 10.6 M to 6.4 M frames/s and ByteTrack 256 x 128 from 9.1 M to 5.5 M, with the kernels
+// unchanged), so the buffer goes in pieces of at most 16 KB.
+inline hipError_t copy_meta_d2h(int* h_dst, const int* d_src, size_t n_ints, hipStream_t st) {
+  static const size_t piece = std::getenv("MOT_META_PIECE") ? static_cast<size_t>(std::atol(std::getenv("MOT_META_PIECE"))) : 4096;  // ints
+  for (size_t o = 0; o < n_ints; o += piece) {
+    const size_t n = (n_ints - o < piece) ? n_ints - o : piece;
+    const hipError_t e = hipMemcpyAsync(h_dst + o, d_src + o, sizeof(int) * n, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 // Device allocations of a batch, freed together.
 struct Allocs {
   std::vector<void*> ptrs;
@@ -156,7 +170,7 @@ struct Flights {
     hipLaunchKernelGGL(pack_rows, dim3(S), dim3(256), 0, st, d_stage, cap_stage, d_out_counts, F.d_offsets, F.d_packed, rows_cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(F.h_meta, F.d_meta, sizeof(int) * (kMetaHead + static_cast<size_t>(S)), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = copy_meta_d2h(F.h_meta, F.d_meta, kMetaHead + static_cast<size_t>(S), st)) != hipSuccess) return e;
     if ((e = hipEventRecord(F.done, st)) != hipSuccess) return e;
     F.pending = true; F.bd = bd; F.rows_cap = rows_cap;
     count += 1;

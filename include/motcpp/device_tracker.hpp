@@ -11,6 +11,7 @@ namespace motcpp {
 namespace rt {
 class Staged;
 class Device;
+class PooledStream;
 }  // namespace rt
 
 class DeviceTracker : public BaseTracker {
@@ -19,7 +20,10 @@ class DeviceTracker : public BaseTracker {
   Eigen::MatrixXf update(const Eigen::MatrixXf& dets, const cv::Mat& img,
                          const Eigen::MatrixXf& embs = Eigen::MatrixXf()) override;
   void reset() override;
-  rt::Staged* staged() const { return impl_.get(); }
+  rt::Staged* staged() const { return impl_.get(); }        // the host stage machine (nullptr for a pooled tracker)
+  rt::PooledStream* pooled() const { return pooled_.get(); }  // the pooled device stream (nullptr for a host-lifecycle tracker)
+  // parity hook (pooled trackers): ids, Kalman means [n][d] and covariances [n][d*d] of the live tracks in list order; returns n
+  int dump_states(std::vector<int>* ids, std::vector<float>* mean, std::vector<float>* cov);
   const std::shared_ptr<rt::Device>& device() const { return dev_; }
   // the checks and bookkeeping update() does before any track is touched (check_inputs, the asso_func error, detection
   // format, frame counter); false = this frame is skipped. StreamBatch calls it per stream. Throws what update() throws.
@@ -28,15 +32,19 @@ class DeviceTracker : public BaseTracker {
   // validates EVERY stream before it commits any, so that an exception leaves no tracker a frame ahead of its device state.
   void validate_update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) const;
   bool commit_update(const Eigen::MatrixXf& dets, const cv::Mat& img);
-  // Threading: like the reference, a tracker instance is not re-entrant. Different tracker instances MAY be updated from
-  // different host threads; those created on the same GPU share that GPU's runtime (arenas, stream) and their frames are
-  // serialised by a mutex inside it — for concurrency across streams use StreamBatch / DeviceLifecycleBatch, or one process
-  // per GPU.
+  // Threading: like the reference, a tracker instance is not re-entrant, and different instances are meant to be updated from
+  // different host threads (one tracker per camera thread, include/motcpp/tracker.hpp:67-69 of the reference). Since round 4
+  // Sort / ByteTrack / OCSort / BotSort objects are streams of shared device-lifecycle batches (host/pool.hpp): update() calls
+  // that arrive together from different threads are merged into ONE launch sequence on the GPU and each caller gets its own
+  // table back — T threads with one tracker each run at the batched rate, not one frame at a time. MOTCPP_LIFECYCLE=host keeps
+  // the per-object host stage machines of rounds 1-3 (DeepOCSort always uses one); their frames serialise on a per-GPU mutex.
 
  protected:
   DeviceTracker(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class,
                 int nr_classes, const std::string& asso_func, bool is_obb, int device_index);
   void adopt(rt::Staged* impl);
+  void adopt_pooled(int c_kind, const std::vector<float>& c_params);  // kind / parameter vector as in motcpp_c.h
+  bool camera_motion(const float* warp2x3);
   bool validate_inputs_ = true;  // SORT does not call check_inputs (sort.cpp:102-110)
   bool skip_empty_ = false;      // BoT-SORT returns before touching any state when dets is empty (botsort.cpp:267-269)
   std::shared_ptr<rt::Device> dev_;
@@ -44,6 +52,7 @@ class DeviceTracker : public BaseTracker {
 
  private:
   std::unique_ptr<rt::Staged> impl_;
+  std::unique_ptr<rt::PooledStream> pooled_;
 };
 
 // Lock-step driver for many independent streams on one GPU: every stage of every tracker is batched into

@@ -58,6 +58,9 @@ int mot_device_count(void);
 int mot_ctx_create(int device, void* hip_stream /* hipStream_t or NULL: own stream */, mot_ctx** out);
 int mot_ctx_destroy(mot_ctx* ctx);
 int mot_ctx_sync(mot_ctx* ctx);
+/* makes the context's GPU the calling host thread's current device (HIP keeps that per thread): a thread other than the one that
+ * created the context calls this before it allocates or launches through it */
+int mot_ctx_bind(mot_ctx* ctx);
 void* mot_ctx_stream(mot_ctx* ctx);
 const char* mot_ctx_last_error(mot_ctx* ctx);
 
@@ -436,6 +439,58 @@ int mot_sort_device_output(mot_sort_batch* b, const float** d_rows, const int** 
 int mot_sort_dump(mot_sort_batch* b, int s, int* ids, float* mean, float* cov, int cap);
 int mot_sort_profile(mot_sort_batch* b, int enable);         /* same layout as mot_bt_profile_stats ([1], [6], [7] = 0) */
 int mot_sort_profile_stats(mot_sort_batch* b, double* out8);
+
+/* ---- pooled streams (round 4): the streams of a device-lifecycle batch as independent tracker objects ----------------- */
+/* The reference's model is one BaseTracker object per camera, each updated from its own thread
+ * (include/motcpp/tracker.hpp:67-69, docs/guides/architecture.md:242-255). The host runtime (csrc/host/pool.cpp) gives every such object
+ * one stream of a shared batch and merges the update() calls that arrive together into ONE launch sequence; these entry points are what
+ * it needs beyond the lockstep API above:
+ *   mot_*_enqueue_frame  a frame in which only the streams with h_counts[s] >= 0 take part (the others keep their state untouched and
+ *                        report 0 rows), detections packed back to back: stream s's SoA planes [6][h_det_ld[s]] start at
+ *                        d_dets + h_det_off[s] floats (a column-major N x 6 matrix as the caller holds it, ld = N rounded up as it likes).
+ *                        The host arrays are copied before the call returns; d_dets (and d_embs) must stay unmodified until the
+ *                        matching collect. At most two frames in flight, as mot_*_enqueue_packed.
+ *   mot_*_collect_view   waits for the oldest frame in flight; rows / counts / alive point into page-locked memory owned by the batch —
+ *                        the kernels wrote the rows there directly, no copy is made — valid until the second mot_*_enqueue_* after
+ *                        this call. Stream s's rows start at the sum of counts[0..s). alive[s] = live tracks of stream s after the frame.
+ *   mot_*_reset_stream   fresh == 0: BaseTracker::reset() of one stream as the reference does it — the tracks go; the id counter keeps
+ *                        counting for SORT / ByteTrack / OC-SORT (sort.cpp:97-100; STrack::clear_count and KalmanBoxTracker::clear_count
+ *                        are empty, bytetrack.hpp:38-40, ocsort.hpp:37-39) and restarts for BoT-SORT (botsort.cpp:252-258). fresh != 0: the
+ *                        stream as created (ids from the start: the slot now belongs to a new tracker object). Asynchronous on the batch's stream.
+ *   mot_*_move_stream    moves one stream into a batch with larger capacities (same parameters, same device): how a tracker object
+ *                        outgrows cap_tracks / max_dets without ever seeing MOT_ERR_CAPACITY. Synchronous. */
+typedef struct mot_frame_in {
+  const float* d_dets;
+  const int* h_counts;
+  const int* h_det_ld;
+  const long long* h_det_off;
+  const float* d_embs;              /* BoT-SORT: raw detection features, row-major [n][emb_dim] per stream (NULL: no stream has any) */
+  const long long* h_emb_off;       /* BoT-SORT: float offset of stream s's rows in d_embs, < 0: none for this stream in this frame */
+  const float* h_warps6;            /* BoT-SORT: [S][6] camera-motion warps, h_has_warp [S] (NULL: none) */
+  const unsigned char* h_has_warp;
+} mot_frame_in;
+typedef struct mot_frame_view {
+  const float* rows;
+  const int* counts;
+  const int* alive;
+  int total;
+} mot_frame_view;
+int mot_bt_enqueue_frame(mot_bt_batch* b, const mot_frame_in* in, int rows_cap);
+int mot_bt_collect_view(mot_bt_batch* b, mot_frame_view* out);
+int mot_bt_reset_stream(mot_bt_batch* b, int s, int fresh);
+int mot_bt_move_stream(mot_bt_batch* src, int s, mot_bt_batch* dst, int s2);
+int mot_sort_enqueue_frame(mot_sort_batch* b, const mot_frame_in* in, int rows_cap);
+int mot_sort_collect_view(mot_sort_batch* b, mot_frame_view* out);
+int mot_sort_reset_stream(mot_sort_batch* b, int s, int fresh);
+int mot_sort_move_stream(mot_sort_batch* src, int s, mot_sort_batch* dst, int s2);
+int mot_oc_enqueue_frame(mot_oc_batch* b, const mot_frame_in* in, int rows_cap);
+int mot_oc_collect_view(mot_oc_batch* b, mot_frame_view* out);
+int mot_oc_reset_stream(mot_oc_batch* b, int s, int fresh);
+int mot_oc_move_stream(mot_oc_batch* src, int s, mot_oc_batch* dst, int s2);
+int mot_bot_enqueue_frame(mot_bot_batch* b, const mot_frame_in* in, int rows_cap);
+int mot_bot_collect_view(mot_bot_batch* b, mot_frame_view* out);
+int mot_bot_reset_stream(mot_bot_batch* b, int s, int fresh);
+int mot_bot_move_stream(mot_bot_batch* src, int s, mot_bot_batch* dst, int s2);
 
 /* ---- multi-GPU: gather of the track tables over RCCL ------------------------------------ */
 /* one process per GPU, rank r owns streams [r*S, (r+1)*S) and never exchanges tracker state; the only

@@ -22,6 +22,23 @@ typedef struct motcpp_batch motcpp_batch;
 const char* motcpp_last_error(void);
 
 motcpp_tracker* motcpp_tracker_create(int kind, const float* params, int nparams, int device);
+/* The same tracker as a stream of a shared device-lifecycle batch (what the C++ classes Sort / ByteTrack / OCSort / BotSort are by
+ * default since round 4, csrc/host/pool.hpp): update() calls that arrive together from different host threads — one handle per
+ * thread, like one BaseTracker per camera thread in the reference — run as ONE launch sequence on the GPU. Same parameter vectors;
+ * the assignment hooks (lap_count / lap_get) report nothing for such a handle. */
+motcpp_tracker* motcpp_tracker_create_pooled(int kind, const float* params, int nparams, int device);
+int motcpp_tracker_pool_level(motcpp_tracker* t); /* capacity level the stream sits on (0: 512 tracks x 256 detections, x4 per level), -1: not attached yet */
+/* combiner counters of the process: [0] launch sequences (rounds) run, [1] stream-frames they carried, [2] streams moved to a larger
+ * level, [3] most streams merged into one round; leader wall time in microseconds: [4] batching windows, [5] waiting for the callers'
+ * copies and the previous table's readers, [6] the rounds themselves (uploads, launches, GPU), [7] of that: queueing the launches */
+int motcpp_pool_stats(long* out8, int reset);
+/* T tracker OBJECTS of the C++ classes (kind as above) on T host threads, each calling BaseTracker::update(dets, img) on its own
+ * stream of host detections: dets [T][frames][max_n][6] row-major, counts [T][frames]. `warm` untimed frames per thread first, then
+ * the threads meet at a barrier and the remaining frames are timed. out: [0] seconds of the timed part (first start to last end),
+ * [1] frames timed, [2] output rows, [3] mean update() latency (ms), [4] worst update() latency (ms). checksum (optional, [T]): sum of
+ * the ids of every output row per tracker (parity against a single-threaded run). Returns 0. */
+int motcpp_bench_threads(int kind, const float* params, int nparams, int T, int frames, int warm, const float* dets, const int* counts,
+                         int max_n, int device, double* out5, double* checksum);
 void motcpp_tracker_destroy(motcpp_tracker* t);
 int motcpp_tracker_reset(motcpp_tracker* t);
 /* dets: n x 6 [x1,y1,x2,y2,conf,cls]; embs: n x d or NULL; out: cap x 8. Returns rows, or -(rows needed) - 1000000 if cap is too small. */

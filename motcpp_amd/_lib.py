@@ -241,6 +241,12 @@ def host():
         H.motcpp_last_error.restype = C.c_char_p
         H.motcpp_tracker_create.restype = C.c_void_p
         H.motcpp_tracker_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
+        H.motcpp_tracker_create_pooled.restype = C.c_void_p
+        H.motcpp_tracker_create_pooled.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
+        H.motcpp_tracker_pool_level.argtypes = [C.c_void_p]
+        H.motcpp_pool_stats.argtypes = [C.c_void_p, C.c_int]
+        H.motcpp_bench_threads.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p]
         H.motcpp_tracker_destroy.argtypes = [C.c_void_p]
         H.motcpp_tracker_reset.argtypes = [C.c_void_p]
         H.motcpp_tracker_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -312,13 +318,19 @@ class _Hooks:
 class Tracker(_Hooks):
     """One tracker instance on one GPU. update() mirrors motcpp::BaseTracker::update (row-major numpy in/out)."""
 
-    def __init__(self, kind, params=None, device=0):
+    def __init__(self, kind, params=None, device=0, pooled=False):
+        """pooled: the tracker is a stream of a shared device-lifecycle batch (what the C++ classes are by default): handles updated
+        from different host threads at the same time run as one launch sequence. The ctypes call releases the GIL."""
         kind = KIND.get(kind, kind)
         p = f32(params if params is not None else [])
-        self.h = host().motcpp_tracker_create(int(kind), _p(p) if p.size else None, int(p.size), int(device))
+        create = host().motcpp_tracker_create_pooled if pooled else host().motcpp_tracker_create
+        self.h = create(int(kind), _p(p) if p.size else None, int(p.size), int(device))
         if not self.h:
             raise MotError("tracker create failed: " + _err())
         self._out = np.zeros((8192, 8), np.float32)
+
+    def pool_level(self):
+        return host().motcpp_tracker_pool_level(self.h)
 
     def close(self):
         if getattr(self, "h", None):
@@ -355,6 +367,32 @@ class Tracker(_Hooks):
             if r > -1000000:
                 raise MotError(_err())
             self._out = np.zeros((-r - 1000000 + 64, 8), np.float32)
+
+
+def pool_stats(reset=False):
+    """combiner counters of this process: launch sequences run, stream-frames carried, streams moved up a level, largest round"""
+    a = (C.c_long * 8)()
+    host().motcpp_pool_stats(a, 1 if reset else 0)
+    return {"rounds": a[0], "frames": a[1], "moves": a[2], "max_round": a[3], "us_window": a[4], "us_gather": a[5], "us_run": a[6],
+            "us_enqueue": a[7]}
+
+
+def bench_threads(kind, dets, counts, warm, params=None, device=0):
+    """T tracker objects of the C++ classes on T host threads, each calling BaseTracker::update on host detections
+    (motcpp_bench_threads). dets [T, F, N, 6], counts [T, F]. Returns a dict (seconds of the timed part, frames, rows, latencies)
+    and the per-tracker id checksums."""
+    kind = KIND.get(kind, kind)
+    dets, counts = f32(dets), np.ascontiguousarray(counts, np.int32)
+    T, F, N = dets.shape[0], dets.shape[1], dets.shape[2]
+    p = f32(params if params is not None else [])
+    out = np.zeros(5, np.float64)
+    cs = np.zeros(T, np.float64)
+    rc = host().motcpp_bench_threads(int(kind), _p(p) if p.size else None, int(p.size), T, F, int(warm), _p(dets), _p(counts), N, int(device),
+                                     _p(out), _p(cs))
+    if rc != 0:
+        raise MotError("motcpp_bench_threads failed")
+    return {"seconds": out[0], "frames": int(out[1]), "rows": int(out[2]), "latency_ms_mean": out[3], "latency_ms_max": out[4],
+            "frames_per_s": out[1] / out[0] if out[0] > 0 else 0.0}, cs
 
 
 class _Borrowed(_Hooks):

@@ -28,6 +28,7 @@ hipError_t launch_embed(int metric, const mot_cos_task*, int, int, int, hipStrea
 namespace {
 using mot::lifecycle::compact;
 using mot::lifecycle::kW;
+using mot::lifecycle::FrameDev;
 
 enum St { New = 0, Tracked = 1, Lost = 2, Removed = 3 };
 
@@ -84,15 +85,16 @@ __device__ __forceinline__ void apply_match(BotStream& S, int slot, int det) {
 }
 
 // ---- K0: empty-frame rule, detection split, pools, predict / warp / first-association tasks (:267-330) ----
-__global__ void __launch_bounds__(kW) bot_begin(BotStream* streams, BotParams P, int CAP, int D, const int* counts, const float* dets_base,
+__global__ void __launch_bounds__(kW) bot_begin(BotStream* streams, BotParams P, int CAP, int D, FrameDev FD, const float* dets_base,
                                                  const float* embs_base, const float* warps6, const int* has_warp, BotTasks K,
                                                  unsigned long long* stats, int* maxt) {
   const int s = blockIdx.x;
   BotStream& S = streams[s];
   const int t = static_cast<int>(threadIdx.x);
-  const int n = counts[s];
-  const float* dets = dets_base + static_cast<size_t>(s) * 6 * D;
-  if (n <= 0 || n > D) {  // :267-269: nothing happens, not even frame_count++ (nor the camera-motion step)
+  const int n = FD.counts[s];
+  int ldd = D;
+  const float* dets = (n > 0) ? mot::lifecycle::frame_dets(FD, dets_base, s, D, ldd) : dets_base;
+  if (n <= 0 || n > D) {  // :267-269: nothing happens, not even frame_count++ (nor the camera-motion step); n < 0 (pooled form): not this stream's frame
     if (t == 0) {
       S.idle = 1; S.n = 0;
       if (n > D) S.err = 1;
@@ -104,15 +106,16 @@ __global__ void __launch_bounds__(kW) bot_begin(BotStream* streams, BotParams P,
     }
     return;
   }
-  const int have_emb = (P.with_reid && embs_base != nullptr && P.E > 0) ? 1 : 0;
+  const long long eoff = FD.emb_off ? FD.emb_off[s] : static_cast<long long>(s) * D * P.E;  // (pooled form: < 0 = no features for this stream)
+  const int have_emb = (P.with_reid && embs_base != nullptr && P.E > 0 && eoff >= 0) ? 1 : 0;
   const int warp = (has_warp != nullptr && has_warp[s] != 0) ? 1 : 0;
-  const float* embs = have_emb ? embs_base + static_cast<size_t>(s) * D * P.E : nullptr;
+  const float* embs = have_emb ? embs_base + eoff : nullptr;
   if (t == 0) {
     S.idle = 0;
     S.frame_count += 1;
-    S.dets = dets; S.ld = D; S.n = n; S.have_emb = have_emb; S.warp = warp; S.embs = embs;
+    S.dets = dets; S.ld = ldd; S.n = n; S.have_emb = have_emb; S.warp = warp; S.embs = embs;
   }
-  const float* conf = dets + static_cast<size_t>(4) * D;
+  const float* conf = dets + static_cast<size_t>(4) * ldd;
   int nf = 0, ns = 0;
   for (int i0 = 0; i0 < n; i0 += kW) {  // :283-300
     const int i = i0 + t;
@@ -147,7 +150,7 @@ __global__ void __launch_bounds__(kW) bot_begin(BotStream* streams, BotParams P,
   if (t == 0) {
     S.n_first = nf; S.n_second = ns; S.n_pool = np; S.n_tracked = n_tracked; S.n_unconf = nu;
     S.n_upd = 0; S.n_set = 0; S.n_ema = 0; S.n_utrack = 0; S.n_udet = 0; S.n_r = 0; S.n_init = 0; S.lap2_q = 0; S.lap3_q = 0;
-    K.det[s].dets = dets; K.det[s].ld = D; K.det[s].n = n;
+    K.det[s].dets = dets; K.det[s].ld = ldd; K.det[s].n = n;
     mot_feat_task& FN = K.featn[s];  // normalised copies of every detection feature (:38-46)
     FN.n = have_emb ? n : 0; FN.src = embs;
     K.fset[s].src = embs; K.fema[s].src = embs; K.fset[s].n = 0; K.fema[s].n = 0;
@@ -411,11 +414,11 @@ __global__ void __launch_bounds__(kW) bot_after_second(BotStream* streams, BotPa
 }
 
 // ---- K3: the output table (:742-764): activated members of the new tracked list, in list order ----
-__global__ void __launch_bounds__(kW) bot_finish(BotStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks) {
+__global__ void __launch_bounds__(kW) bot_finish(BotStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive) {
   BotStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
   if (S.idle) {
-    if (t == 0) { out_counts[blockIdx.x] = 0; atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost); }
+    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_active + S.n_lost; atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost); }
     return;
   }
   const int* act = S.active[S.cur];
@@ -439,6 +442,7 @@ __global__ void __launch_bounds__(kW) bot_finish(BotStream* streams, int CAP, fl
     if (n_rows > cap_out) S.err = 2;
     out_counts[blockIdx.x] = (n_rows <= cap_out) ? n_rows : -n_rows;
     atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost);
+    alive[blockIdx.x] = S.n_active + S.n_lost;
   }
 }
 
@@ -466,25 +470,15 @@ struct mot_bot_batch {
   int bound_n = 0;
   float* d_out = nullptr; int* d_out_counts = nullptr;
   float* d_packed = nullptr; int* d_offsets = nullptr; int packed_cap = 0;
-  struct Flight {  // a frame in flight (mot_bot_enqueue_packed / mot_bot_collect_packed)
-    float* d_packed = nullptr; int* d_offsets = nullptr; int* d_counts = nullptr; int packed_cap = 0;
-    int* h_meta = nullptr;
-    int* d_meta = nullptr;  // device image of h_meta's first 258 + S words (filled by pack_offsets: one copy brings them home)
-    hipEvent_t done = nullptr;
-    hipEvent_t ev[8] = {};
-    bool pending = false, prof = false;
-    int rows_cap = 0;  // the row limit pack_rows ran with (the enqueue call's rows_cap)
-    int bd = 0;
-  } fl[2];
-  int fl_head = 0, fl_count = 0;
-  hipStream_t copy_st = nullptr;
+  mot::lifecycle::Flights flights;  // frames in flight (lifecycle_common.hpp); page-locked tail per stream: has_warp + 6 warp floats
+  int* d_alive = nullptr;
   const float* d_rows_last = nullptr; const int* d_offsets_last = nullptr; const int* d_counts_last = nullptr;
   mot::lifecycle::PackMeta pack_meta;  // set by mot_bot_enqueue_packed around its frame (empty: the packed tables only)
   float* mean = nullptr;   // [S][CAP] Kalman records (8 + 64 floats)
   float* feat = nullptr;   // [S][CAP][E] smooth features
   bool profile = false;
   unsigned long long* d_stats = nullptr;
-  hipEvent_t ev[8] = {};
+  hipEvent_t ev[12] = {};
   double lap_ms = 0.0, cos_ms = 0.0, frame_ms = 0.0;
   long frames = 0;
   template <class T>
@@ -495,12 +489,7 @@ extern "C" {
 
 void mot_bot_destroy(mot_bot_batch* b) {
   if (!b) return;
-  for (auto& f : b->fl) {
-    if (f.h_meta) (void)hipHostFree(f.h_meta);
-    if (f.done) (void)hipEventDestroy(f.done);
-    for (auto& e : f.ev) if (e) (void)hipEventDestroy(e);
-  }
-  if (b->copy_st) (void)hipStreamDestroy(b->copy_st);
+  b->flights.release();
   b->mem.release();
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   delete b;
@@ -511,8 +500,7 @@ int mot_bot_reset(mot_bot_batch* b) {  // BotSort::reset :252-258: ids restart
   MOT_LC_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(BotStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
   MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
   MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));  // (frames still in flight have finished by now: they are dropped with the tracks)
-  for (auto& F : b->fl) F.pending = false;
-  b->fl_head = 0; b->fl_count = 0;
+  b->flights.drop_all();
   b->bound_n = 0; b->hint1_n = b->hint23_n = b->hint23_m = 0;
   return MOT_OK;
 }
@@ -548,6 +536,8 @@ int mot_bot_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, int
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
   b->d_maxt = b->dalloc<int>(256);
+  b->d_alive = b->dalloc<int>(S);
+  b->flights.n_maxt = 256; b->flights.with_alive = true; b->flights.extra_host = 7;
   b->d_warps = b->dalloc<float>(static_cast<size_t>(S) * 6);
   b->d_has_warp = b->dalloc<int>(S);
   b->d_stats = b->dalloc<unsigned long long>(8 * 64);
@@ -566,7 +556,7 @@ int mot_bot_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, int
   const size_t wb1 = (mot::lap_scratch_bytes(CAP, D) + 255) & ~size_t(255);
   char* work = b->dalloc<char>(wb1 * 3 * S);
   int* info = b->dalloc<int>(static_cast<size_t>(4) * 3 * S);
-  if (!ip || !fp || !b->mean || !b->d_streams || !b->d_counts || !b->d_err || !b->d_maxt || !b->d_warps || !b->d_has_warp || !b->d_stats ||
+  if (!ip || !fp || !b->mean || !b->d_streams || !b->d_counts || !b->d_err || !b->d_maxt || !b->d_alive || !b->d_warps || !b->d_has_warp || !b->d_stats ||
       !b->d_out || !b->d_out_counts || !b->d_offsets || !K.det || !K.featn || !K.fset || !K.fema || !K.warp || !K.pred || !K.predw || !K.ubox ||
       !K.init || !K.upd || !K.obox || !K.cos1 || !K.cos3 || !K.lap1 || !K.lap23 || !work || !info) {
     mot_bot_destroy(b);
@@ -655,7 +645,7 @@ int mot_bot_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, int
 
 // queues one frame's launches: counts already on their way to b->d_counts, warps (if any) to b->d_warps / b->d_has_warp
 static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_counts, const float* d_embs, bool any_warp, int bound_n,
-                       float* d_packed, int* d_offsets, int rows_cap, hipEvent_t* ev) {
+                       float* d_packed, int* d_offsets, int rows_cap, hipEvent_t* ev, const mot::lifecycle::FrameDev* fd = nullptr) {
   hipStream_t st = b->ctx->stream;
   const int S = b->S, CAP = b->CAP, D = b->D;
   MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 256 * sizeof(int), st));
@@ -667,8 +657,10 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
   const bool emb = b->prm.with_reid && d_embs != nullptr;
   const bool prof = ev != nullptr;
   const BotTasks& K = b->tasks;
+  mot::lifecycle::FrameDev FD;
+  if (fd) FD = *fd; else FD.counts = b->d_counts;
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
-  hipLaunchKernelGGL(bot_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, emb ? d_embs : nullptr, b->d_warps,
+  hipLaunchKernelGGL(bot_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, FD, d_dets, emb ? d_embs : nullptr, b->d_warps,
                      any_warp ? b->d_has_warp : nullptr, K, prof ? b->d_stats : nullptr, b->d_maxt);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYWH, K.det, S, bd, st));
   if (emb) MOT_LC_HIP(b, mot::launch_feat(K.featn, S, bd, st));
@@ -696,7 +688,7 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
     MOT_LC_HIP(b, mot::launch_feat(K.fema, S, bn, st));
   }
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYWH, K.obox, S, bn2, st));
-  hipLaunchKernelGGL(bot_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt);
+  hipLaunchKernelGGL(bot_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt, b->d_alive);
   hipLaunchKernelGGL(bot_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
   hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, d_offsets, b->pack_meta);
   hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, CAP, b->d_out_counts, d_offsets, d_packed, rows_cap);
@@ -726,7 +718,7 @@ extern "C" {
 int mot_bot_step_packed(mot_bot_batch* b, const float* d_dets, const int* h_counts, const float* d_embs, const float* h_warps6,
                         const unsigned char* h_has_warp, float* rows, int rows_cap, int* out_counts, int* total_rows) {
   if (!b || !d_dets || !h_counts || !rows || !out_counts) return MOT_ERR_INVALID;
-  if (b->fl_count > 0) { b->ctx->err = "mot_bot_step_packed: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
+  if (b->flights.count > 0) { b->ctx->err = "mot_bot_step_packed: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
   hipStream_t st = b->ctx->stream;
   const int S = b->S;
   MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
@@ -768,80 +760,136 @@ int mot_bot_step_packed(mot_bot_batch* b, const float* d_dets, const int* h_coun
 }
 
 // Frames in flight (see mot_bt_enqueue_packed): enqueue returns once the launches are queued, collect waits for the oldest
-// pending frame and copies its rows on a second stream while the next frame runs.
-int mot_bot_enqueue_packed(mot_bot_batch* b, const float* d_dets, const int* h_counts, const float* d_embs, const float* h_warps6,
-                           const unsigned char* h_has_warp, int rows_cap) {
-  if (!b || !d_dets || !h_counts || rows_cap <= 0) return MOT_ERR_INVALID;
-  if (b->fl_count >= 2) { b->ctx->err = "mot_bot_enqueue_packed: two frames are already in flight (collect one first)"; return MOT_ERR_INVALID; }
+// pending frame and copies its rows on a second stream while the next frame runs. `in` != nullptr: the pooled form.
+static int bot_enqueue_flight(mot_bot_batch* b, const float* d_dets, const int* h_counts, const float* d_embs, const float* h_warps6,
+                              const unsigned char* h_has_warp, int rows_cap, const mot_frame_in* in) {
+  if (b->flights.count >= 2) { b->ctx->err = "mot_bot_enqueue: two frames are already in flight (collect one first)"; return MOT_ERR_INVALID; }
   hipStream_t st = b->ctx->stream;
   const int S = b->S;
-  const int slot = (b->fl_head + b->fl_count) & 1;
-  mot_bot_batch::Flight& F = b->fl[slot];
-  if (!b->copy_st) MOT_LC_HIP(b, hipStreamCreateWithFlags(&b->copy_st, hipStreamNonBlocking));
-  if (!F.done) MOT_LC_HIP(b, hipEventCreateWithFlags(&F.done, hipEventDisableTiming));
-  // pinned: [0] total, [1] err, [2..258) maxima, counts out [S], counts in [S], has_warp [S], warps [6 S] (as float bits)
-  if (!F.h_meta) MOT_LC_HIP(b, hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (258 + 9 * static_cast<size_t>(S)), hipHostMallocDefault));
-  if (!F.d_offsets) { F.d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1); F.d_counts = b->dalloc<int>(S); F.d_meta = b->dalloc<int>(258 + static_cast<size_t>(S)); }
-  if (rows_cap > F.packed_cap) { F.d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); F.packed_cap = F.d_packed ? rows_cap : 0; }
-  if (!F.d_offsets || !F.d_counts || !F.d_packed || !F.d_meta) return MOT_ERR_NOMEM;
-  int* counts_in = F.h_meta + 258 + S;
-  int* hw = F.h_meta + 258 + 2 * S;
-  float* wp = reinterpret_cast<float*>(F.h_meta + 258 + 3 * S);
-  int bd = 1;
+  const int slot = b->flights.slot_for_enqueue();
+  int* counts_in = nullptr;
+  int bd = 0;
+  MOT_LC_HIP(b, b->flights.prepare(b->mem, slot, S, rows_cap, h_counts, &counts_in, &bd, in != nullptr, b->profile));
+  mot::lifecycle::Flight& F = b->flights.fl[slot];
+  int* hw = b->flights.extra_of(F, S);                  // page-locked: has_warp [S], then the warps [6 S]
+  float* wp = reinterpret_cast<float*>(hw + S);
   bool any_warp = false;
   for (int s = 0; s < S; ++s) {
-    counts_in[s] = h_counts[s];
-    bd = (h_counts[s] > bd) ? h_counts[s] : bd;
     hw[s] = (h_warps6 && h_has_warp && h_has_warp[s]) ? 1 : 0;
     any_warp = any_warp || hw[s];
   }
-  MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, counts_in, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  mot::lifecycle::FrameDev fd;
+  if (in) MOT_LC_HIP(b, b->flights.upload_block(b->mem, slot, S, in->h_counts, in->h_det_ld, in->h_det_off, in->h_emb_off, st, &fd));
+  else MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, counts_in, sizeof(int) * S, hipMemcpyHostToDevice, st));
   if (any_warp) {
     std::memcpy(wp, h_warps6, sizeof(float) * 6 * S);
     MOT_LC_HIP(b, hipMemcpyAsync(b->d_warps, wp, sizeof(float) * 6 * S, hipMemcpyHostToDevice, st));
     MOT_LC_HIP(b, hipMemcpyAsync(b->d_has_warp, hw, sizeof(int) * S, hipMemcpyHostToDevice, st));
   }
-  const mot_bot_batch::Flight& O = b->fl[slot ^ 1];
-  int bound = b->bound_n + (O.pending ? O.bd : 0);
+  int bound = b->bound_n + b->flights.pending_bd();
   if (bound > b->CAP) bound = b->CAP;
-  if (b->profile && !F.ev[0]) for (auto& e : F.ev) MOT_LC_HIP(b, hipEventCreate(&e));
-  F.prof = b->profile;
-  mot::lifecycle::PackMeta pm;
-  pm.dev = F.d_meta; pm.err = b->d_err; pm.maxt = b->d_maxt; pm.n_maxt = 256; pm.maxt_at = 2; pm.counts_at = 258; pm.counts_copy = F.d_counts;
+  mot::lifecycle::PackMeta pm = b->flights.pack_meta(slot, b->d_err, b->d_maxt, nullptr);
+  pm.alive = b->d_alive; pm.alive_at = b->flights.meta_head() + S;
   b->pack_meta = pm;
-  const int rc = bot_enqueue(b, d_dets, counts_in, d_embs, any_warp, bound, F.d_packed, F.d_offsets, rows_cap, F.prof ? F.ev : nullptr);
+  const int rc = bot_enqueue(b, d_dets, counts_in, d_embs, any_warp, bound, b->flights.rows_target(slot), F.d_offsets, rows_cap, F.prof ? F.ev : nullptr,
+                             in ? &fd : nullptr);
   b->pack_meta = mot::lifecycle::PackMeta{};
   if (rc != MOT_OK) return rc;
-  MOT_LC_HIP(b, mot::lifecycle::copy_meta_d2h(F.h_meta, F.d_meta, 258 + static_cast<size_t>(S), st));
-  MOT_LC_HIP(b, hipEventRecord(F.done, st));
-  F.pending = true; F.bd = bd; F.rows_cap = rows_cap;
-  b->fl_count += 1;
+  MOT_LC_HIP(b, b->flights.finish_copies(slot, st, S, rows_cap, bd));
   return MOT_OK;
+}
+static int bot_pop_flight(mot_bot_batch* b, mot::lifecycle::Flight** out, int* total) {
+  if (b->flights.count <= 0) { b->ctx->err = "mot_bot_collect: no frame in flight"; return MOT_ERR_INVALID; }
+  mot::lifecycle::Flight* F = nullptr;
+  MOT_LC_HIP(b, b->flights.pop(&F));
+  if (F->prof) { const int rce = bot_account_events(b, F->ev); if (rce != MOT_OK) return rce; }
+  const int* maxt = b->flights.maxt_of(*F);
+  b->bound_n = 0;
+  for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
+  bot_set_hints(b, maxt);
+  *total = F->h_meta[0];
+  *out = F;
+  b->d_rows_last = F->view ? F->h_rows : F->d_packed; b->d_offsets_last = F->d_offsets; b->d_counts_last = F->d_counts;
+  if (F->h_meta[1]) { b->ctx->err = "mot_bot_collect: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
+  if (*total > F->rows_cap) { b->ctx->err = "mot_bot_collect: more rows than rows_cap"; return MOT_ERR_CAPACITY; }  // (pack_rows skipped the streams that end past the ENQUEUE call's rows_cap)
+  return MOT_OK;
+}
+
+int mot_bot_enqueue_packed(mot_bot_batch* b, const float* d_dets, const int* h_counts, const float* d_embs, const float* h_warps6,
+                           const unsigned char* h_has_warp, int rows_cap) {
+  if (!b || !d_dets || !h_counts || rows_cap <= 0) return MOT_ERR_INVALID;
+  return bot_enqueue_flight(b, d_dets, h_counts, d_embs, h_warps6, h_has_warp, rows_cap, nullptr);
 }
 
 int mot_bot_collect_packed(mot_bot_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows) {
   if (!b || !rows || !out_counts) return MOT_ERR_INVALID;
-  if (b->fl_count <= 0) { b->ctx->err = "mot_bot_collect_packed: no frame in flight"; return MOT_ERR_INVALID; }
-  mot_bot_batch::Flight& F = b->fl[b->fl_head];
-  MOT_LC_HIP(b, hipEventSynchronize(F.done));
-  F.pending = false;
-  b->fl_head ^= 1; b->fl_count -= 1;
-  if (F.prof) { const int rce = bot_account_events(b, F.ev); if (rce != MOT_OK) return rce; }
-  const int total = F.h_meta[0], err = F.h_meta[1];
-  b->bound_n = 0;
-  for (int i = 0; i < 64; ++i) b->bound_n = (F.h_meta[2 + i] > b->bound_n) ? F.h_meta[2 + i] : b->bound_n;
-  std::memcpy(out_counts, F.h_meta + 258, sizeof(int) * b->S);
-  bot_set_hints(b, F.h_meta + 2);
+  mot::lifecycle::Flight* F = nullptr;
+  int total = 0;
+  const int rc = bot_pop_flight(b, &F, &total);
+  if (F) std::memcpy(out_counts, b->flights.counts_of(*F), sizeof(int) * b->S);
   if (total_rows) *total_rows = total;
-  b->d_rows_last = F.d_packed; b->d_offsets_last = F.d_offsets; b->d_counts_last = F.d_counts;
-  if (err) { b->ctx->err = "mot_bot_collect_packed: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
-  if (total > rows_cap || total > F.rows_cap) {  // (pack_rows skipped the streams that end past the ENQUEUE call's rows_cap)
-    b->ctx->err = "mot_bot_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY;
+  if (rc != MOT_OK) return rc;
+  if (total > rows_cap) { b->ctx->err = "mot_bot_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  MOT_LC_HIP(b, b->flights.copy_rows(*F, rows, total));
+  return MOT_OK;
+}
+
+// ---- pooled form (see mot_bt_enqueue_frame) ----
+int mot_bot_enqueue_frame(mot_bot_batch* b, const mot_frame_in* in, int rows_cap) {
+  if (!b || !in || !in->d_dets || !in->h_counts || !in->h_det_ld || !in->h_det_off || rows_cap <= 0) return MOT_ERR_INVALID;
+  if (in->d_embs && !in->h_emb_off) return MOT_ERR_INVALID;
+  return bot_enqueue_flight(b, in->d_dets, in->h_counts, in->d_embs, in->h_warps6, in->h_has_warp, rows_cap, in);
+}
+int mot_bot_collect_view(mot_bot_batch* b, mot_frame_view* out) {
+  if (!b || !out) return MOT_ERR_INVALID;
+  mot::lifecycle::Flight* F = nullptr;
+  int total = 0;
+  const int rc = bot_pop_flight(b, &F, &total);
+  if (!F) return rc;
+  if (!F->view) { b->ctx->err = "mot_bot_collect_view: the frame was queued with mot_bot_enqueue_packed"; return MOT_ERR_INVALID; }
+  out->rows = F->h_rows; out->counts = b->flights.counts_of(*F); out->alive = b->flights.alive_of(*F, b->S); out->total = total;
+  return rc;
+}
+int mot_bot_reset_stream(mot_bot_batch* b, int s, int fresh) {
+  if (!b || s < 0 || s >= b->S) return MOT_ERR_INVALID;
+  hipLaunchKernelGGL(mot::lifecycle::reset_stream_kernel<BotStream>, dim3(1), dim3(64), 0, b->ctx->stream, b->d_streams, s, b->h_streams[s], 0 * fresh /* the ids restart either way, botsort.cpp:257 */);
+  MOT_LC_HIP(b, hipGetLastError());
+  return MOT_OK;
+}
+namespace {
+__global__ void __launch_bounds__(256) bot_move(const BotStream* from, BotStream* to, const float* mean_from, float* mean_to, const float* feat_from,
+                                                float* feat_to, int cap, int E) {
+  using mot::lifecycle::move_array;
+  const BotStream& A = *from;
+  BotStream& B = *to;
+  const size_t n = static_cast<size_t>(cap);
+  move_array(B.free_stack, A.free_stack, n);
+  move_array(B.active[0], A.active[A.cur], n); move_array(B.lost[0], A.lost[A.cur], n);
+  move_array(B.t_id, A.t_id, n); move_array(B.t_state, A.t_state, n); move_array(B.t_act, A.t_act, n); move_array(B.t_tlen, A.t_tlen, n);
+  move_array(B.t_fid, A.t_fid, n); move_array(B.t_sf, A.t_sf, n); move_array(B.t_cls, A.t_cls, n); move_array(B.t_det, A.t_det, n);
+  move_array(B.t_feat, A.t_feat, n); move_array(B.t_conf, A.t_conf, n);
+  move_array(mean_to, mean_from, n * 72);
+  if (E > 0) move_array(feat_to, feat_from, n * E);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    B.frame_count = A.frame_count; B.next_id = A.next_id; B.next_slot = A.next_slot; B.n_free = A.n_free;
+    B.n_active = A.n_active; B.n_lost = A.n_lost; B.err = A.err; B.cur = 0; B.idle = 1;
   }
-  if (total > 0) {
-    MOT_LC_HIP(b, hipMemcpyAsync(rows, F.d_packed, sizeof(float) * static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, b->copy_st));
-    MOT_LC_HIP(b, hipStreamSynchronize(b->copy_st));
-  }
+}
+}  // namespace
+int mot_bot_move_stream(mot_bot_batch* src, int s, mot_bot_batch* dst, int s2) {
+  if (!src || !dst || s < 0 || s >= src->S || s2 < 0 || s2 >= dst->S || dst->CAP < src->CAP || dst->D < src->D || dst->E != src->E) return MOT_ERR_INVALID;
+  MOT_LC_HIP(src, hipStreamSynchronize(src->ctx->stream));
+  hipStream_t st = dst->ctx->stream;
+  const int E = src->E;
+  hipLaunchKernelGGL(bot_move, dim3(1), dim3(256), 0, st, src->d_streams + s, dst->d_streams + s2, src->mean + static_cast<size_t>(s) * 72 * src->CAP,
+                     dst->mean + static_cast<size_t>(s2) * 72 * dst->CAP, E ? src->feat + static_cast<size_t>(s) * src->CAP * E : nullptr,
+                     E ? dst->feat + static_cast<size_t>(s2) * dst->CAP * E : nullptr, src->CAP, E);
+  MOT_LC_HIP(dst, hipGetLastError());
+  BotStream h;
+  MOT_LC_HIP(dst, hipMemcpyAsync(&h, dst->d_streams + s2, sizeof(BotStream), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(dst, hipStreamSynchronize(st));
+  if (h.n_active + h.n_lost > dst->bound_n) dst->bound_n = h.n_active + h.n_lost;
   return MOT_OK;
 }
 

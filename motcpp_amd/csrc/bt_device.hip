@@ -22,6 +22,7 @@
 namespace {
 using mot::lifecycle::compact;
 using mot::lifecycle::kW;
+using mot::lifecycle::FrameDev;
 
 enum St { New = 0, Tracked = 1, Lost = 2, Removed = 3 };
 
@@ -40,6 +41,7 @@ struct BtStream {
   float* t_conf;
   // ---- frame input ----
   const float* dets; int ld, n;  // SoA [6][ld]
+  int skip;                      // the stream sits this frame out (pooled form: counts[s] < 0)
   // ---- frame scratch ----
   int *high, *second; int n_high, n_second;
   int* pool_slot; int n_pool, n_tracked;   // pool = tracked (from active) ++ lost
@@ -85,23 +87,33 @@ __device__ __forceinline__ Compact3 compact3_block(bool p0, bool p1, bool p2, in
 }
 // ---- K0: detection split, pools, predict + first-association tasks (bytetrack.cpp:166-265) ----
 // stats[0] = assignment problems queued, stats[1] = sum of their n + m (algorithmic bytes of the solver: 24 B per row/column)
-__global__ void __launch_bounds__(kAF) bt_begin(BtStream* streams, BtParams P, int CAP, int D, const int* counts, const float* dets_base,
+__global__ void __launch_bounds__(kAF) bt_begin(BtStream* streams, BtParams P, int CAP, int D, FrameDev FD, const float* dets_base,
                                                  mot_det_task* det_t, mot_kf_task* pred_t, mot_lap_task* lap1_t, unsigned long long* stats, int* maxt) {
   __shared__ int cnt[kAF / 64][3];
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
-  const int n = counts[blockIdx.x];
-  const float* dets = dets_base + static_cast<size_t>(blockIdx.x) * 6 * D;
+  const int n = FD.counts[blockIdx.x];
+  if (n < 0) {  // not this stream's frame: nothing of its state moves, every task it owns is empty
+    if (t == 0) {
+      S.skip = 1;
+      det_t[blockIdx.x].n = 0; pred_t[blockIdx.x].n = 0;
+      mot_lap_task& L = lap1_t[blockIdx.x];
+      L.n = 0; L.m = 0; L.geom.n = 0; L.geom.m = 0;
+    }
+    return;
+  }
+  int ldd = D;
+  const float* dets = mot::lifecycle::frame_dets(FD, dets_base, blockIdx.x, D, ldd);
   const int n_active = S.n_active, n_lost = S.n_lost;
   const int* act = S.active[S.cur];
   const int* lst = S.lost[S.cur];
   __syncthreads();  // (everyone has read the scalars the first lane updates below)
   if (t == 0) {
     S.frame_count += 1;
-    S.dets = dets; S.ld = D; S.n = n;
+    S.dets = dets; S.ld = ldd; S.n = n; S.skip = 0;
     if (n > D) S.err = 1;
   }
-  const float* conf = dets + static_cast<size_t>(4) * D;
+  const float* conf = dets + static_cast<size_t>(4) * ldd;
   int nh = 0, ns = 0, z = 0;
   for (int i0 = 0; i0 < n; i0 += static_cast<int>(blockDim.x)) {
     const int i = i0 + t;
@@ -137,7 +149,7 @@ __global__ void __launch_bounds__(kAF) bt_begin(BtStream* streams, BtParams P, i
   if (t == 0) {
     S.n_high = nh; S.n_second = ns; S.n_pool = np; S.n_tracked = n_tracked; S.n_unconf = nu;
     S.n_upd = 0; S.n_refind = 0; S.n_utrack = 0; S.n_udet = 0; S.n_r = 0; S.n_init = 0; S.n_lost_new = 0; S.lap2_q = 0; S.lap3_q = 0;
-    det_t[blockIdx.x].dets = dets; det_t[blockIdx.x].ld = D; det_t[blockIdx.x].n = (n <= D) ? n : 0;
+    det_t[blockIdx.x].dets = dets; det_t[blockIdx.x].ld = ldd; det_t[blockIdx.x].n = (n <= D) ? n : 0;
     pred_t[blockIdx.x].n = np;
     mot_lap_task& L = lap1_t[blockIdx.x];
     const bool q = np > 0 && nh > 0;
@@ -161,6 +173,13 @@ __global__ void __launch_bounds__(kAF) bt_after_first(BtStream* streams, BtParam
   __shared__ int cnt[kAF / 64][3];
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
+  if (S.skip) {
+    if (t == 0) {
+      box_t[2 * blockIdx.x + 0].n = 0; box_t[2 * blockIdx.x + 1].n = 0;
+      for (int k = 0; k < 2; ++k) { mot_lap_task& L = lap23_t[2 * blockIdx.x + k]; L.n = 0; L.m = 0; L.geom.n = 0; L.geom.m = 0; }
+    }
+    return;
+  }
   const int np = S.n_pool, nd = S.n_high;
   const bool have = np > 0 && nd > 0;
   int n_upd = 0, n_ref = 0, n_ut = 0, n_ud = 0;
@@ -251,6 +270,14 @@ __global__ void __launch_bounds__(kAF) bt_after_second(BtStream* streams, BtPara
   __shared__ int sh[8];
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
+  if (S.skip) {
+    if (t == 0) {
+      init_t[blockIdx.x].n = 0; upd_t[blockIdx.x].n = 0;
+      box2_t[2 * blockIdx.x + 0].n = 0; box2_t[2 * blockIdx.x + 1].n = 0;
+      dup_t[blockIdx.x].n = 0; dup_t[blockIdx.x].m = 0;
+    }
+    return;
+  }
   auto wave_sync = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };  // (one wavefront: its loads have landed before its next stores go out)
   int n_upd = S.n_upd, n_ln = 0;
   int n_init = 0;
@@ -435,7 +462,7 @@ __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP, int v
   extern __shared__ __attribute__((aligned(16))) float sbox[];  // [nl] float4 boxes, [nl] sorted x1 keys, [nl] sorted indices, [nl] keys
   BtStream& S = streams[blockIdx.x];
   const int na = S.n_active, nl = S.n_lost;
-  if (na <= 0 || nl <= 0) return;
+  if (S.skip || na <= 0 || nl <= 0) return;
   // the launch reserves LDS for lds_items lost boxes (far more than a stream usually has); a stream with more reads them from
   // global memory and tests every pair
   const bool staged = MODE != 0 && nl <= lds_items;
@@ -530,10 +557,14 @@ __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP, int v
 // ---- K3: duplicate removal and the output table (:582-621, :659-706) ----
 // Four wavefronts per stream (as bt_after_first): the lists are ~800 entries of dependent loads (slot, then the slot's fields), which one
 // wavefront walks in 13 rounds.
-__global__ void __launch_bounds__(kAF) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks) {
+__global__ void __launch_bounds__(kAF) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive) {
   __shared__ int cnt[kAF / 64][3];
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
+  if (S.skip) {  // its tracks still bound the next frame's launches
+    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_active + S.n_lost; atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost); }
+    return;
+  }
   int* act = S.active[S.cur];
   int* lst = S.lost[S.cur];
   float* rows = out + static_cast<size_t>(blockIdx.x) * cap_out * 8;
@@ -586,6 +617,7 @@ __global__ void __launch_bounds__(kAF) bt_finish(BtStream* streams, int CAP, flo
     out_counts[blockIdx.x] = (n_rows <= cap_out) ? n_rows : -n_rows;
     // tracks alive after this frame: an exact upper bound of every problem side of the next frame (64 slots: no hot address)
     atomicMax(&max_tracks[blockIdx.x & 63], n_keep + n_keep_l);
+    alive[blockIdx.x] = n_keep + n_keep_l;
   }
 }
 
@@ -612,21 +644,11 @@ struct mot_bt_batch {
   int bound_n = 0;        // upper bound of tracked + lost per stream for the NEXT frame (0 right after creation / reset)
   float* d_out = nullptr; int* d_out_counts = nullptr; int out_cap = 0;
   float* d_packed = nullptr; int* d_offsets = nullptr; int packed_cap = 0;  // mot_bt_step_packed
-  // frames in flight (mot_bt_enqueue_packed / mot_bt_collect_packed): two sets of packed tables, page-locked result words
-  struct Flight {
-    float* d_packed = nullptr; int* d_offsets = nullptr; int* d_counts = nullptr; int packed_cap = 0;
-    int* h_meta = nullptr;  // pinned: [0] total rows, [1] error flag, [2..258) the frame's maxima (d_maxt), then counts out [S], counts in [S]
-    int* d_meta = nullptr;  // device image of h_meta's first 258 + S words (filled by pack_offsets: one copy brings them home)
-    hipEvent_t done = nullptr;
-    hipEvent_t ev[12] = {};
-    bool pending = false, prof = false;
-    int rows_cap = 0;  // the row limit pack_rows ran with (the enqueue call's rows_cap)
-    int bd = 0;
-  } fl[2];
-  int fl_head = 0, fl_count = 0;  // oldest pending frame, frames pending
+  // frames in flight (mot_bt_enqueue_packed / mot_bt_collect_packed, mot_bt_enqueue_frame / mot_bt_collect_view): lifecycle_common.hpp
+  mot::lifecycle::Flights flights;
+  int* d_alive = nullptr;  // [S] live tracks per stream after the frame
   const int* d_counts_last = nullptr;  // the frame mot_bt_device_output describes: per-stream row counts, rows, offsets
   const float* d_rows_last = nullptr; const int* d_offsets_last = nullptr;
-  hipStream_t copy_st = nullptr;
   mot_det_task* det_t = nullptr;
   mot_kf_task *pred_t = nullptr, *box_t = nullptr, *init_t = nullptr, *upd_t = nullptr, *box2_t = nullptr;
   mot_lap_task *lap1_t = nullptr, *lap23_t = nullptr;
@@ -648,12 +670,7 @@ extern "C" {
 
 void mot_bt_destroy(mot_bt_batch* b) {
   if (!b) return;
-  for (auto& f : b->fl) {
-    if (f.h_meta) (void)hipHostFree(f.h_meta);
-    if (f.done) (void)hipEventDestroy(f.done);
-    for (auto& e : f.ev) if (e) (void)hipEventDestroy(e);
-  }
-  if (b->copy_st) (void)hipStreamDestroy(b->copy_st);
+  b->flights.release();
   b->mem.release();
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   delete b;
@@ -665,8 +682,7 @@ int mot_bt_reset(mot_bt_batch* b) {
   MOT_LC_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(BtStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
   MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
   MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));  // (frames still in flight have finished by now: they are dropped with the tracks)
-  for (auto& F : b->fl) F.pending = false;
-  b->fl_head = 0; b->fl_count = 0;
+  b->flights.drop_all();
   b->bound_n = 0; b->hint1_n = b->hint23_n = b->hint23_m = 0;
   return MOT_OK;
 }
@@ -690,6 +706,8 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
   b->d_maxt = b->dalloc<int>(256);
+  b->d_alive = b->dalloc<int>(S);
+  b->flights.n_maxt = 256; b->flights.with_alive = true;
   b->d_stats = b->dalloc<unsigned long long>(8 * 64);
   if (b->d_stats) (void)hipMemset(b->d_stats, 0, 8 * 64 * sizeof(unsigned long long));
   for (auto& e : b->ev) (void)hipEventCreate(&e);
@@ -701,7 +719,7 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   const size_t wb1 = (mot::lap_scratch_bytes(CAP, D) + 255) & ~size_t(255);
   char* work = b->dalloc<char>(wb1 * 3 * S);
   int* info = b->dalloc<int>(static_cast<size_t>(4) * 3 * S);
-  if (!ip || !fp || !bp || !b->mean || !b->d_streams || !b->d_counts || !b->d_err || !b->det_t || !b->pred_t || !b->box_t ||
+  if (!ip || !fp || !bp || !b->mean || !b->d_streams || !b->d_counts || !b->d_err || !b->d_alive || !b->d_maxt || !b->det_t || !b->pred_t || !b->box_t ||
       !b->init_t || !b->upd_t || !b->box2_t || !b->lap1_t || !b->lap23_t || !b->dup_t || !work || !info) {
     mot_bt_destroy(b);
     return MOT_ERR_NOMEM;
@@ -776,9 +794,12 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   return MOT_OK;
 }
 
-// enqueues the frame's launches; the per-stream tables land in b->d_out ([S][cap_out][8]) and b->d_out_counts
-static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_counts, int cap_out, hipEvent_t* ev = nullptr) {
-  if (!ev) ev = b->ev;
+// enqueues the frame's launches; the per-stream tables land in b->d_out ([S][cap_out][8]) and b->d_out_counts. fd == nullptr: the classic
+// form (h_counts is copied to the device here, every stream takes part, detections at s * 6 * max_dets); else the pooled input block
+// (already on its way to the device) and h_counts only sizes the launches
+static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_counts, int cap_out, hipEvent_t* ev = nullptr,
+                            const mot::lifecycle::FrameDev* fd = nullptr) {
+  const bool prof = ev != nullptr;
   hipStream_t st = b->ctx->stream;
   const int S = b->S, CAP = b->CAP, D = b->D;
   if (cap_out > b->out_cap) {
@@ -787,7 +808,12 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
     if (!b->d_out || !b->d_out_counts) return MOT_ERR_NOMEM;
     b->out_cap = cap_out;
   }
-  MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  mot::lifecycle::FrameDev FD;
+  if (fd) FD = *fd;
+  else {
+    MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+    FD.counts = b->d_counts;
+  }
   MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 256 * sizeof(int), st));
   // Launch bounds (grid sizes, the solver's LDS layout and variant) from exact upper bounds instead of the capacities:
   // no side of any problem of this frame exceeds the tracks alive after the previous frame (bn) / this frame's detections (bd)
@@ -796,11 +822,10 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   if (bd > D) bd = D;
   const int bn = (b->bound_n < 1) ? 1 : (b->bound_n > CAP ? CAP : b->bound_n);
   const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;  // lists after this frame's births
-  const bool prof = b->profile;
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
   // four wavefronts per stream once the lists are long enough to share (short lists: the extra wavefronts only add barriers; 256 x 128: 8.2 M against 8.8 M frames/s)
   const int bt_threads = ((bn > bd ? bn : bd) > 384) ? kAF : kW;
-  hipLaunchKernelGGL(bt_begin, dim3(S), dim3(bt_threads), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr, b->d_maxt);
+  hipLaunchKernelGGL(bt_begin, dim3(S), dim3(bt_threads), 0, st, b->d_streams, b->prm, CAP, D, FD, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr, b->d_maxt);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, bd, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[6], st));
   MOT_LC_HIP(b, mot::launch_kf_op(6, MOT_KF_XYAH, b->pred_t, S, bn, st));  // predicted boxes of the pool (box-only: nothing is stored)
@@ -827,7 +852,7 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
     if (!full) hipLaunchKernelGGL(bt_dups<1>, dim3(S), dim3(256), static_cast<size_t>(28) * items, st, b->d_streams, CAP, verify, items);
     else hipLaunchKernelGGL(bt_dups<2>, dim3(S), dim3(256), static_cast<size_t>(16) * items, st, b->d_streams, CAP, 0, items);
   }
-  hipLaunchKernelGGL(bt_finish, dim3(S), dim3(bt_threads), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);
+  hipLaunchKernelGGL(bt_finish, dim3(S), dim3(bt_threads), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt, b->d_alive);
   hipLaunchKernelGGL(bt_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[5], st));
   MOT_LC_HIP(b, hipGetLastError());
@@ -879,8 +904,8 @@ static int bt_finish_frame(mot_bt_batch* b) {
 int mot_bt_step(mot_bt_batch* b, const float* d_dets, const int* h_counts, float* out, int* out_counts, int cap_out) {
   hipStream_t st = b->ctx->stream;
   const int S = b->S;
-  if (b->fl_count > 0) { b->ctx->err = "mot_bt_step: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
-  const int rc = bt_enqueue_frame(b, d_dets, h_counts, cap_out);
+  if (b->flights.count > 0) { b->ctx->err = "mot_bt_step: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
+  const int rc = bt_enqueue_frame(b, d_dets, h_counts, cap_out, b->profile ? b->ev : nullptr);
   if (rc != MOT_OK) return rc;
   MOT_LC_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(out_counts, b->d_out_counts, sizeof(int) * S, hipMemcpyDeviceToHost, st));
@@ -891,8 +916,8 @@ int mot_bt_step_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts
   hipStream_t st = b->ctx->stream;
   const int S = b->S;
   // staging holds a stream's whole track list (no per-stream row limit short of cap_tracks); the packed buffer rows_cap rows
-  if (b->fl_count > 0) { b->ctx->err = "mot_bt_step_packed: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
-  const int rc = bt_enqueue_frame(b, d_dets, h_counts, b->CAP);
+  if (b->flights.count > 0) { b->ctx->err = "mot_bt_step_packed: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
+  const int rc = bt_enqueue_frame(b, d_dets, h_counts, b->CAP, b->profile ? b->ev : nullptr);
   if (rc != MOT_OK) return rc;
   if (!b->d_offsets) b->d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1);
   if (rows_cap > b->packed_cap) { b->d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); b->packed_cap = b->d_packed ? rows_cap : 0; }
@@ -929,66 +954,117 @@ int mot_bt_device_output(mot_bt_batch* b, const float** d_rows, const int** d_of
 // are queued, collect(f) then waits for frame f only (an event), and copies its rows on a second stream while frame f + 1
 // runs. The launch bounds of a frame come from the tracks alive after the last COLLECTED frame plus the detections of the
 // frames enqueued since (a stream gains at most one track per detection).
-int mot_bt_enqueue_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts, int rows_cap) {
-  if (!b || !d_dets || !h_counts || rows_cap <= 0) return MOT_ERR_INVALID;
-  if (b->fl_count >= 2) { b->ctx->err = "mot_bt_enqueue_packed: two frames are already in flight (collect one first)"; return MOT_ERR_INVALID; }
+static int bt_enqueue_flight(mot_bt_batch* b, const float* d_dets, const int* h_counts, int rows_cap, const mot_frame_in* in) {
+  if (b->flights.count >= 2) { b->ctx->err = "mot_bt_enqueue: two frames are already in flight (collect one first)"; return MOT_ERR_INVALID; }
   hipStream_t st = b->ctx->stream;
   const int S = b->S;
-  const int slot = (b->fl_head + b->fl_count) & 1;
-  mot_bt_batch::Flight& F = b->fl[slot];
-  if (!b->copy_st) MOT_LC_HIP(b, hipStreamCreateWithFlags(&b->copy_st, hipStreamNonBlocking));
-  if (!F.done) MOT_LC_HIP(b, hipEventCreateWithFlags(&F.done, hipEventDisableTiming));
-  if (!F.h_meta) MOT_LC_HIP(b, hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (258 + 2 * static_cast<size_t>(S)), hipHostMallocDefault));
-  if (!F.d_offsets) { F.d_offsets = b->dalloc<int>(static_cast<size_t>(S) + 1); F.d_counts = b->dalloc<int>(S); F.d_meta = b->dalloc<int>(258 + static_cast<size_t>(S)); }
-  if (rows_cap > F.packed_cap) { F.d_packed = b->dalloc<float>(static_cast<size_t>(rows_cap) * 8); F.packed_cap = F.d_packed ? rows_cap : 0; }
-  if (!F.d_offsets || !F.d_counts || !F.d_packed || !F.d_meta) return MOT_ERR_NOMEM;
-  int bd = 1;
-  int* counts_in = F.h_meta + 258 + S;  // page-locked copy: the caller's array may change as soon as this call returns
-  for (int s = 0; s < S; ++s) { counts_in[s] = h_counts[s]; bd = (h_counts[s] > bd) ? h_counts[s] : bd; }
+  const int slot = b->flights.slot_for_enqueue();
+  int* counts_in = nullptr;
+  int bd = 0;
+  MOT_LC_HIP(b, b->flights.prepare(b->mem, slot, S, rows_cap, h_counts, &counts_in, &bd, in != nullptr, b->profile));
+  mot::lifecycle::Flight& F = b->flights.fl[slot];
+  mot::lifecycle::FrameDev fd;
+  if (in) MOT_LC_HIP(b, b->flights.upload_block(b->mem, slot, S, in->h_counts, in->h_det_ld, in->h_det_off, nullptr, st, &fd));
   const int saved = b->bound_n;
-  const mot_bt_batch::Flight& O = b->fl[slot ^ 1];
-  b->bound_n = saved + (O.pending ? O.bd : 0);  // tracks the frame still in flight may have added
+  b->bound_n = saved + b->flights.pending_bd();  // tracks the frame still in flight may have added
   if (b->bound_n > b->CAP) b->bound_n = b->CAP;
-  if (b->profile && !F.ev[0]) for (auto& e : F.ev) MOT_LC_HIP(b, hipEventCreate(&e));
-  F.prof = b->profile;
-  const int rc = bt_enqueue_frame(b, d_dets, counts_in, b->CAP, F.prof ? F.ev : nullptr);
+  const int rc = bt_enqueue_frame(b, d_dets, counts_in, b->CAP, F.prof ? F.ev : nullptr, in ? &fd : nullptr);
   b->bound_n = saved;
   if (rc != MOT_OK) return rc;
-  mot::lifecycle::PackMeta pm;
-  pm.dev = F.d_meta; pm.err = b->d_err; pm.maxt = b->d_maxt; pm.n_maxt = 256; pm.maxt_at = 2; pm.counts_at = 258; pm.counts_copy = F.d_counts;
-  hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, F.d_offsets, pm);
-  hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, b->CAP, b->d_out_counts, F.d_offsets, F.d_packed, rows_cap);
-  MOT_LC_HIP(b, hipGetLastError());
-  MOT_LC_HIP(b, mot::lifecycle::copy_meta_d2h(F.h_meta, F.d_meta, 258 + static_cast<size_t>(S), st));
-  MOT_LC_HIP(b, hipEventRecord(F.done, st));
-  F.pending = true; F.bd = bd; F.rows_cap = rows_cap;
-  b->fl_count += 1;
+  MOT_LC_HIP(b, b->flights.finish(slot, st, b->d_out, b->CAP, b->d_out_counts, S, b->d_err, b->d_maxt, nullptr, rows_cap, bd, nullptr, nullptr, b->d_alive));
   return MOT_OK;
+}
+// the oldest frame in flight: waits for it, books its maxima and event times; the caller takes the rows
+static int bt_pop_flight(mot_bt_batch* b, mot::lifecycle::Flight** out, int* total) {
+  if (b->flights.count <= 0) { b->ctx->err = "mot_bt_collect: no frame in flight"; return MOT_ERR_INVALID; }
+  mot::lifecycle::Flight* F = nullptr;
+  MOT_LC_HIP(b, b->flights.pop(&F));
+  if (F->prof) { const int rce = bt_account_events(b, F->ev); if (rce != MOT_OK) return rce; }
+  const int* maxt = b->flights.maxt_of(*F);
+  b->bound_n = 0;
+  for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
+  bt_set_hints(b, maxt);
+  *total = F->h_meta[0];
+  *out = F;
+  b->d_rows_last = F->view ? F->h_rows : F->d_packed;  // mot_bt_device_output: the frame just collected
+  b->d_offsets_last = F->d_offsets; b->d_counts_last = F->d_counts;
+  if (F->h_meta[1]) { b->ctx->err = "mot_bt_collect: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
+  if (*total > F->rows_cap) { b->ctx->err = "mot_bt_collect: more rows than rows_cap"; return MOT_ERR_CAPACITY; }  // (pack_rows skipped the streams that end past the ENQUEUE call's rows_cap)
+  return MOT_OK;
+}
+
+int mot_bt_enqueue_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts, int rows_cap) {
+  if (!b || !d_dets || !h_counts || rows_cap <= 0) return MOT_ERR_INVALID;
+  return bt_enqueue_flight(b, d_dets, h_counts, rows_cap, nullptr);
 }
 
 int mot_bt_collect_packed(mot_bt_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows) {
   if (!b || !rows || !out_counts) return MOT_ERR_INVALID;
-  if (b->fl_count <= 0) { b->ctx->err = "mot_bt_collect_packed: no frame in flight"; return MOT_ERR_INVALID; }
-  mot_bt_batch::Flight& F = b->fl[b->fl_head];
-  MOT_LC_HIP(b, hipEventSynchronize(F.done));
-  F.pending = false;
-  b->fl_head ^= 1; b->fl_count -= 1;
-  if (F.prof) { const int rce = bt_account_events(b, F.ev); if (rce != MOT_OK) return rce; }
-  const int total = F.h_meta[0], err = F.h_meta[1];
-  b->bound_n = 0;
-  for (int i = 0; i < 64; ++i) b->bound_n = (F.h_meta[2 + i] > b->bound_n) ? F.h_meta[2 + i] : b->bound_n;
-  std::memcpy(out_counts, F.h_meta + 258, sizeof(int) * b->S);
-  bt_set_hints(b, F.h_meta + 2);
+  mot::lifecycle::Flight* F = nullptr;
+  int total = 0;
+  const int rc = bt_pop_flight(b, &F, &total);
+  if (F) std::memcpy(out_counts, b->flights.counts_of(*F), sizeof(int) * b->S);
   if (total_rows) *total_rows = total;
-  b->d_rows_last = F.d_packed; b->d_offsets_last = F.d_offsets; b->d_counts_last = F.d_counts;  // mot_bt_device_output: the frame just collected
-  if (err) { b->ctx->err = "mot_bt_collect_packed: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
-  if (total > rows_cap || total > F.rows_cap) {  // (pack_rows skipped the streams that end past the ENQUEUE call's rows_cap)
-    b->ctx->err = "mot_bt_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY;
+  if (rc != MOT_OK) return rc;
+  if (total > rows_cap) { b->ctx->err = "mot_bt_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  MOT_LC_HIP(b, b->flights.copy_rows(*F, rows, total));
+  return MOT_OK;
+}
+
+// ---- pooled form (round 4): the streams of the batch are independent tracker objects, a frame carries the ones that have work ----
+int mot_bt_enqueue_frame(mot_bt_batch* b, const mot_frame_in* in, int rows_cap) {
+  if (!b || !in || !in->d_dets || !in->h_counts || !in->h_det_ld || !in->h_det_off || rows_cap <= 0) return MOT_ERR_INVALID;
+  return bt_enqueue_flight(b, in->d_dets, in->h_counts, rows_cap, in);
+}
+int mot_bt_collect_view(mot_bt_batch* b, mot_frame_view* out) {
+  if (!b || !out) return MOT_ERR_INVALID;
+  mot::lifecycle::Flight* F = nullptr;
+  int total = 0;
+  const int rc = bt_pop_flight(b, &F, &total);
+  if (!F) return rc;
+  if (!F->view) { b->ctx->err = "mot_bt_collect_view: the frame was queued with mot_bt_enqueue_packed"; return MOT_ERR_INVALID; }
+  out->rows = F->h_rows; out->counts = b->flights.counts_of(*F); out->alive = b->flights.alive_of(*F, b->S); out->total = total;
+  return rc;
+}
+int mot_bt_reset_stream(mot_bt_batch* b, int s, int fresh) {
+  if (!b || s < 0 || s >= b->S) return MOT_ERR_INVALID;
+  hipLaunchKernelGGL(mot::lifecycle::reset_stream_kernel<BtStream>, dim3(1), dim3(64), 0, b->ctx->stream, b->d_streams, s, b->h_streams[s], fresh ? 0 : 1);
+  MOT_LC_HIP(b, hipGetLastError());
+  return MOT_OK;
+}
+namespace {
+__global__ void __launch_bounds__(256) bt_move(const BtStream* from, BtStream* to, const float* mean_from, float* mean_to, int cap) {
+  using mot::lifecycle::move_array;
+  const BtStream& A = *from;
+  BtStream& B = *to;
+  const size_t n = static_cast<size_t>(cap);
+  move_array(B.free_stack, A.free_stack, n);
+  move_array(B.active[0], A.active[A.cur], n); move_array(B.lost[0], A.lost[A.cur], n);
+  move_array(B.t_id, A.t_id, n); move_array(B.t_state, A.t_state, n); move_array(B.t_act, A.t_act, n); move_array(B.t_tlen, A.t_tlen, n);
+  move_array(B.t_fid, A.t_fid, n); move_array(B.t_sf, A.t_sf, n); move_array(B.t_cls, A.t_cls, n); move_array(B.t_det, A.t_det, n);
+  move_array(B.t_conf, A.t_conf, n);
+  move_array(mean_to, mean_from, n * 72);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    B.frame_count = A.frame_count; B.next_id = A.next_id; B.next_slot = A.next_slot; B.n_free = A.n_free;
+    B.n_active = A.n_active; B.n_lost = A.n_lost; B.err = A.err; B.cur = 0; B.skip = 1;
   }
-  if (total > 0) {
-    MOT_LC_HIP(b, hipMemcpyAsync(rows, F.d_packed, sizeof(float) * static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, b->copy_st));
-    MOT_LC_HIP(b, hipStreamSynchronize(b->copy_st));
-  }
+}
+}  // namespace
+// moves stream s of `src` into stream s2 of `dst` (a batch with the same parameters and capacities at least as large, on the same
+// device): lists, per-track records and Kalman states; the slot indices stay valid, fresh slots continue behind src's. Synchronous.
+int mot_bt_move_stream(mot_bt_batch* src, int s, mot_bt_batch* dst, int s2) {
+  if (!src || !dst || s < 0 || s >= src->S || s2 < 0 || s2 >= dst->S || dst->CAP < src->CAP || dst->D < src->D) return MOT_ERR_INVALID;
+  MOT_LC_HIP(src, hipStreamSynchronize(src->ctx->stream));
+  hipStream_t st = dst->ctx->stream;
+  hipLaunchKernelGGL(bt_move, dim3(1), dim3(256), 0, st, src->d_streams + s, dst->d_streams + s2, src->mean + static_cast<size_t>(s) * 72 * src->CAP,
+                     dst->mean + static_cast<size_t>(s2) * 72 * dst->CAP, src->CAP);
+  MOT_LC_HIP(dst, hipGetLastError());
+  BtStream h;
+  MOT_LC_HIP(dst, hipMemcpyAsync(&h, dst->d_streams + s2, sizeof(BtStream), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(dst, hipStreamSynchronize(st));
+  const int alive = h.n_active + h.n_lost;
+  if (alive > dst->bound_n) dst->bound_n = alive;  // the next frame's launches cover the newcomer's lists
   return MOT_OK;
 }
 

@@ -91,6 +91,7 @@ int mot_ctx_destroy(mot_ctx* c) {
   delete c;
   return MOT_OK;
 }
+int mot_ctx_bind(mot_ctx* c) { if (!c) return MOT_ERR_INVALID; MOT_HIP(c, hipSetDevice(c->device)); return MOT_OK; }
 int mot_ctx_sync(mot_ctx* c) { MOT_HIP(c, hipStreamSynchronize(c->stream)); return MOT_OK; }
 void* mot_ctx_stream(mot_ctx* c) { return c ? c->stream : nullptr; }
 const char* mot_ctx_last_error(mot_ctx* c) { return c ? c->err.c_str() : "null context"; }

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <functional>
 #include "motcpp_c.h"
+#include "pool.hpp"
 #include "staged.hpp"
 
 using namespace motcpp::rt;
@@ -41,7 +42,8 @@ Staged* make(std::shared_ptr<Device> dev, int kind, const float* p, int np) {
 
 struct motcpp_tracker {
   std::shared_ptr<Device> dev;
-  std::unique_ptr<Staged> impl;
+  std::unique_ptr<Staged> impl;          // host stage machine, or
+  std::unique_ptr<PooledStream> pooled;  // a stream of a shared device-lifecycle batch (motcpp_tracker_create_pooled)
   std::vector<float> colmajor;
 };
 struct motcpp_batch {
@@ -85,11 +87,28 @@ motcpp_tracker* motcpp_tracker_create(int kind, const float* params, int nparams
     return t.release();
   } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
+motcpp_tracker* motcpp_tracker_create_pooled(int kind, const float* params, int nparams, int device) {
+  try {
+    auto t = std::make_unique<motcpp_tracker>();
+    std::vector<float> dp;
+    const int pk = pooled_params(kind, params, nparams, &dp);
+    t->pooled = std::make_unique<PooledStream>(device, pk, dp.data(), static_cast<int>(dp.size()));
+    return t.release();
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+int motcpp_pool_stats(long* out8, int reset) {
+  const PoolStats s = pool_stats(reset != 0);
+  out8[0] = s.rounds; out8[1] = s.frames; out8[2] = s.moves; out8[3] = s.max_round;
+  out8[4] = static_cast<long>(s.us_window); out8[5] = static_cast<long>(s.us_gather); out8[6] = static_cast<long>(s.us_run); out8[7] = static_cast<long>(s.us_enqueue);
+  return 0;
+}
+int motcpp_tracker_pool_level(motcpp_tracker* t) { return t->pooled ? t->pooled->level() : -1; }
 void motcpp_tracker_destroy(motcpp_tracker* t) { delete t; }
 int motcpp_tracker_reset(motcpp_tracker* t) {
-  try { t->impl->reset(); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
+  try { if (t->pooled) t->pooled->reset(); else t->impl->reset(); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 int motcpp_tracker_set_camera_motion(motcpp_tracker* t, const float* warp2x3) {
+  if (t->pooled) { t->pooled->set_camera_motion(warp2x3); return 0; }
   if (t->impl->set_camera_motion(warp2x3)) return 0;
   g_err = "this tracker has no camera-motion step (BoT-SORT only)";
   return -1;
@@ -97,14 +116,26 @@ int motcpp_tracker_set_camera_motion(motcpp_tracker* t, const float* warp2x3) {
 int motcpp_tracker_update(motcpp_tracker* t, const float* dets, int n, const float* embs, int d, float* out, int cap) {
   try {
     to_colmajor(dets, n, t->colmajor);
+    if (t->pooled) {
+      PooledFrame f;
+      f.dets = t->colmajor.data(); f.n = n; f.ld = n;
+      if (embs && d > 0 && n > 0) { f.embs = embs; f.emb_ld = d; f.emb_dim = d; f.embs_rowmajor = true; }
+      f.img_w = 1920; f.img_h = 1080;
+      const float* rows = nullptr;
+      const int m = t->pooled->update(f, &rows);
+      if (m > cap) return -m - 1000000;
+      if (m) std::memcpy(out, rows, sizeof(float) * 8 * static_cast<size_t>(m));
+      return m;
+    }
     FrameIn in = frame_in(t->colmajor, n, embs, d);
     Staged* s = t->impl.get();
     run_frame(*t->dev, &s, &in, 1);
     return copy_rows(s->rows(), out, cap);
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
-int motcpp_tracker_lap_count(motcpp_tracker* t) { return static_cast<int>(t->impl->laps().size()); }
+int motcpp_tracker_lap_count(motcpp_tracker* t) { return t->pooled ? 0 : static_cast<int>(t->impl->laps().size()); }
 int motcpp_tracker_lap_get(motcpp_tracker* t, int k, int* n, int* m, int* x, int* y, int cap) {
+  if (t->pooled) return -1;  // (the assignments of a pooled stream stay on the device)
   const auto& v = t->impl->laps();
   if (k < 0 || k >= static_cast<int>(v.size())) return -1;
   *n = static_cast<int>(v[k].x.size()); *m = static_cast<int>(v[k].y.size());
@@ -115,6 +146,21 @@ int motcpp_tracker_lap_get(motcpp_tracker* t, int k, int* n, int* m, int* x, int
 }
 int motcpp_tracker_dump_states(motcpp_tracker* t, float* out, int cap_floats, int* width) {
   try {
+    if (t->pooled) {
+      std::vector<int> ids;
+      std::vector<float> mean, cov;
+      const int rows = t->pooled->dump(&ids, &mean, &cov, nullptr, nullptr);
+      const int D = t->pooled->state_dim(), w = 1 + D + D * D;
+      *width = w;
+      if (static_cast<size_t>(rows) * w > static_cast<size_t>(cap_floats)) return -rows - 1000000;
+      for (int r = 0; r < rows; ++r) {
+        float* o = out + static_cast<size_t>(r) * w;
+        o[0] = static_cast<float>(ids[r]);
+        std::memcpy(o + 1, mean.data() + static_cast<size_t>(r) * D, sizeof(float) * D);
+        std::memcpy(o + 1 + D, cov.data() + static_cast<size_t>(r) * D * D, sizeof(float) * D * D);
+      }
+      return rows;
+    }
     std::vector<int> ids, slots;
     t->impl->live_tracks(&ids, &slots);
     Core& c = t->impl->core();
@@ -139,6 +185,21 @@ int motcpp_tracker_dump_states(motcpp_tracker* t, float* out, int cap_floats, in
 // BoT-SORT: smooth features of the live tracks, dump_states order, rows of *dim floats (a track without a feature yet: zeros)
 int motcpp_tracker_dump_features(motcpp_tracker* t, float* out, int cap_floats, int* dim) {
   try {
+    if (t->pooled) {
+      std::vector<int> ids;
+      std::vector<float> mean, cov, feats;
+      std::vector<unsigned char> hasf;
+      const int rows = t->pooled->dump(&ids, &mean, &cov, &feats, &hasf);
+      const int E = rows > 0 ? static_cast<int>(feats.size() / static_cast<size_t>(rows)) : 0;
+      *dim = E;
+      if (E <= 0) return rows;
+      if (static_cast<size_t>(rows) * E > static_cast<size_t>(cap_floats)) return -rows - 1000000;
+      for (int r = 0; r < rows; ++r) {
+        if (hasf[r]) std::memcpy(out + static_cast<size_t>(r) * E, feats.data() + static_cast<size_t>(r) * E, sizeof(float) * E);
+        else std::memset(out + static_cast<size_t>(r) * E, 0, sizeof(float) * E);
+      }
+      return rows;
+    }
     std::vector<int> ids, slots;
     t->impl->live_tracks(&ids, &slots);
     std::vector<char> has;

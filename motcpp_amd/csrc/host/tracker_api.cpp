@@ -8,6 +8,7 @@
 #include <stdexcept>
 
 #include "motcpp/motcpp.hpp"
+#include "pool.hpp"
 #include "staged.hpp"
 
 namespace motcpp {
@@ -109,9 +110,23 @@ DeviceTracker::DeviceTracker(float det_thresh, int max_age, int max_obs, int min
       dev_(rt::Device::shared(device_index)) {}  // asso_func is only read by OC-SORT, at update time (ocsort.cpp:413)
 DeviceTracker::~DeviceTracker() = default;
 void DeviceTracker::adopt(rt::Staged* impl) { impl_.reset(impl); }
+void DeviceTracker::adopt_pooled(int c_kind, const std::vector<float>& c_params) {
+  std::vector<float> dp;
+  const int pk = rt::pooled_params(c_kind, c_params.data(), static_cast<int>(c_params.size()), &dp);
+  pooled_ = std::make_unique<rt::PooledStream>(dev_->index, pk, dp.data(), static_cast<int>(dp.size()));
+}
 void DeviceTracker::reset() {
   BaseTracker::reset();
-  impl_->reset();
+  if (pooled_) pooled_->reset();
+  else impl_->reset();
+}
+bool DeviceTracker::camera_motion(const float* warp2x3) {
+  if (pooled_) { pooled_->set_camera_motion(warp2x3); return true; }
+  return impl_->set_camera_motion(warp2x3);
+}
+int DeviceTracker::dump_states(std::vector<int>* ids, std::vector<float>* mean, std::vector<float>* cov) {
+  if (!pooled_) throw std::logic_error("dump_states: this tracker keeps its lifecycle on the host (use the C handle's hooks)");
+  return pooled_->dump(ids, mean, cov, nullptr, nullptr);
 }
 
 namespace {
@@ -125,12 +140,19 @@ rt::FrameIn make_input(const Eigen::MatrixXf& dets, const cv::Mat& img, const Ei
   in.img_w = img.cols; in.img_h = img.rows;
   return in;
 }
-Eigen::MatrixXf to_matrix(const std::vector<float>& rows) {
-  const int m = static_cast<int>(rows.size() / 8);
+Eigen::MatrixXf to_matrix(const float* rows, int m) {
   Eigen::MatrixXf out(m, 8);
   for (int i = 0; i < m; ++i)
     for (int k = 0; k < 8; ++k) out(i, k) = rows[static_cast<size_t>(i) * 8 + k];
   return out;
+}
+Eigen::MatrixXf to_matrix(const std::vector<float>& rows) { return to_matrix(rows.data(), static_cast<int>(rows.size() / 8)); }
+rt::PooledFrame make_pooled_input(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) {
+  rt::PooledFrame f;
+  f.dets = dets.data(); f.n = static_cast<int>(dets.rows()); f.ld = static_cast<int>(dets.rows());
+  if (embs.rows() > 0 && embs.cols() > 0) { f.embs = embs.data(); f.emb_ld = static_cast<int>(embs.rows()); f.emb_dim = static_cast<int>(embs.cols()); }
+  f.img_w = img.cols; f.img_h = img.rows;
+  return f;
 }
 }  // namespace
 
@@ -148,7 +170,7 @@ void DeviceTracker::validate_update(const Eigen::MatrixXf& dets, const cv::Mat& 
 }
 bool DeviceTracker::commit_update(const Eigen::MatrixXf& dets, const cv::Mat& img) {
   if (skip_empty_ && dets.rows() == 0) {
-    impl_->set_camera_motion(nullptr);  // the reference returns before its CMC step: this frame's warp is dropped
+    camera_motion(nullptr);  // the reference returns before its CMC step: this frame's warp is dropped
     return false;
   }
   setup_detection_format(dets);
@@ -163,6 +185,12 @@ bool DeviceTracker::prepare_update(const Eigen::MatrixXf& dets, const cv::Mat& i
 
 Eigen::MatrixXf DeviceTracker::update(const Eigen::MatrixXf& dets, const cv::Mat& img, const Eigen::MatrixXf& embs) {
   if (!prepare_update(dets, img, embs)) return Eigen::MatrixXf(0, 8);
+  if (pooled_) {  // one stream of a shared device batch: calls that arrive together run as ONE launch sequence (host/pool.hpp)
+    const rt::PooledFrame f = make_pooled_input(dets, img, embs);
+    const float* rows = nullptr;
+    const int m = pooled_->update(f, &rows);
+    return to_matrix(rows, m);
+  }
   rt::FrameIn in = make_input(dets, img, embs);
   rt::Staged* s = impl_.get();
   rt::run_frame(*dev_, &s, &in, 1);
@@ -179,6 +207,9 @@ std::vector<Eigen::MatrixXf> StreamBatch::update(const std::vector<Eigen::Matrix
   std::vector<rt::FrameIn> in;
   std::vector<rt::Staged*> st;
   std::vector<int> who;
+  std::vector<rt::PooledFrame> pin;  // the trackers whose lifecycle is a pooled device stream: one round for all of them
+  std::vector<rt::PooledStream*> pst;
+  std::vector<int> pwho;
   static const Eigen::MatrixXf kNone;
   // every stream goes through its tracker's own checks — all of them before any tracker's bookkeeping, so that a rejected stream
   // leaves no other tracker a frame ahead of its device state
@@ -186,6 +217,12 @@ std::vector<Eigen::MatrixXf> StreamBatch::update(const std::vector<Eigen::Matrix
   for (size_t i = 0; i < trackers_.size(); ++i) {
     const Eigen::MatrixXf& e = i < embs.size() ? embs[i] : kNone;
     if (!trackers_[i]->commit_update(dets[i], img)) continue;  // skipped frame: empty table
+    if (trackers_[i]->pooled()) {
+      pin.push_back(make_pooled_input(dets[i], img, e));
+      pst.push_back(trackers_[i]->pooled());
+      pwho.push_back(static_cast<int>(i));
+      continue;
+    }
     in.push_back(make_input(dets[i], img, e));
     st.push_back(trackers_[i]->staged());
     who.push_back(static_cast<int>(i));
@@ -193,6 +230,12 @@ std::vector<Eigen::MatrixXf> StreamBatch::update(const std::vector<Eigen::Matrix
   if (!st.empty()) rt::run_frame(*trackers_[0]->device(), st.data(), in.data(), static_cast<int>(st.size()));
   std::vector<Eigen::MatrixXf> out(trackers_.size(), Eigen::MatrixXf(0, 8));
   for (size_t k = 0; k < st.size(); ++k) out[who[k]] = to_matrix(st[k]->rows());
+  if (!pst.empty()) {
+    std::vector<const float*> rows(pst.size(), nullptr);
+    std::vector<int> counts(pst.size(), 0);
+    rt::PooledStream::update_many(pst.data(), pin.data(), static_cast<int>(pst.size()), rows.data(), counts.data());
+    for (size_t k = 0; k < pst.size(); ++k) out[pwho[k]] = to_matrix(rows[k], counts[k]);
+  }
   return out;
 }
 
@@ -202,14 +245,16 @@ Sort::Sort(float det_thresh, int max_age, int max_obs, int min_hits, float iou_t
            const std::string& asso_func, bool is_obb, int device_index)
     : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
   validate_inputs_ = false;
-  adopt(rt::make_sort(dev_, det_thresh_, max_age_, max_obs_, min_hits_, iou_threshold_));
+  if (rt::pooling_enabled()) adopt_pooled(0, {det_thresh_, static_cast<float>(max_age_), static_cast<float>(max_obs_), static_cast<float>(min_hits_), iou_threshold_});
+  else adopt(rt::make_sort(dev_, det_thresh_, max_age_, max_obs_, min_hits_, iou_threshold_));
 }
 ByteTrack::ByteTrack(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class,
                      int nr_classes, const std::string& asso_func, bool is_obb, float min_conf, float track_thresh,
                      float match_thresh, int track_buffer, int frame_rate, int device_index)
     : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
   det_thresh_ = track_thresh;
-  adopt(rt::make_bytetrack(dev_, min_conf, track_thresh, match_thresh, track_buffer, frame_rate, max_age_, max_obs_));
+  if (rt::pooling_enabled()) adopt_pooled(1, {min_conf, track_thresh, match_thresh, static_cast<float>(track_buffer), static_cast<float>(frame_rate)});
+  else adopt(rt::make_bytetrack(dev_, min_conf, track_thresh, match_thresh, track_buffer, frame_rate, max_age_, max_obs_));
 }
 OCSort::OCSort(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class, int nr_classes,
                const std::string& asso_func, bool is_obb, float min_conf, int delta_t, float inertia, bool use_byte,
@@ -222,8 +267,12 @@ OCSort::OCSort(float det_thresh, int max_age, int max_obs, int min_hits, float i
                       : "Invalid association mode: " + asso_func;
     asso = 0;
   }
-  adopt(rt::make_ocsort(dev_, det_thresh_, max_age_, max_obs_, min_hits_, iou_threshold_, min_conf, delta_t, inertia, use_byte,
-                        Q_xy_scaling, Q_s_scaling, asso));
+  if (rt::pooling_enabled() && delta_t >= 0 && delta_t <= 64)
+    adopt_pooled(2, {det_thresh_, static_cast<float>(max_age_), static_cast<float>(max_obs_), static_cast<float>(min_hits_), iou_threshold_, min_conf,
+                     static_cast<float>(delta_t), inertia, use_byte ? 1.f : 0.f, Q_xy_scaling, Q_s_scaling, static_cast<float>(asso)});
+  else
+    adopt(rt::make_ocsort(dev_, det_thresh_, max_age_, max_obs_, min_hits_, iou_threshold_, min_conf, delta_t, inertia, use_byte,
+                          Q_xy_scaling, Q_s_scaling, asso));
 }
 BotSort::BotSort(const std::string& reid_weights, bool /*use_half*/, bool /*use_gpu*/, float det_thresh, int max_age, int max_obs,
                  int min_hits, float iou_threshold, bool per_class, int nr_classes, const std::string& asso_func, bool is_obb,
@@ -234,8 +283,12 @@ BotSort::BotSort(const std::string& reid_weights, bool /*use_half*/, bool /*use_
   if (!reid_weights.empty())
     throw std::invalid_argument("motcpp_amd: ReID model inference is outside the hot path; pass embeddings to update()");
   skip_empty_ = true;
-  adopt(rt::make_botsort(dev_, track_high_thresh, track_low_thresh, new_track_thresh, track_buffer, match_thresh,
-                         proximity_thresh, appearance_thresh, frame_rate, fuse_first_associate, with_reid, max_age_, max_obs_));
+  if (rt::pooling_enabled())
+    adopt_pooled(3, {track_high_thresh, track_low_thresh, new_track_thresh, static_cast<float>(track_buffer), match_thresh, proximity_thresh,
+                     appearance_thresh, static_cast<float>(frame_rate), fuse_first_associate ? 1.f : 0.f, with_reid ? 1.f : 0.f});
+  else
+    adopt(rt::make_botsort(dev_, track_high_thresh, track_low_thresh, new_track_thresh, track_buffer, match_thresh,
+                           proximity_thresh, appearance_thresh, frame_rate, fuse_first_associate, with_reid, max_age_, max_obs_));
 }
 DeepOCSort::DeepOCSort(const std::string& /*reid_weights*/, bool /*use_half*/, bool /*use_gpu*/, float det_thresh, int max_age, int max_obs,
                        int min_hits, float iou_threshold, bool per_class, int nr_classes, const std::string& asso_func, bool is_obb,
@@ -255,12 +308,12 @@ DeepOCSort::DeepOCSort(const std::string& /*reid_weights*/, bool /*use_half*/, b
 void DeepOCSort::set_camera_motion(const Eigen::MatrixXf& warp) {
   if (warp.rows() != 2 || warp.cols() != 3) throw std::invalid_argument("DeepOCSort::set_camera_motion: the warp must be 2 x 3");
   const float w[6] = {warp(0, 0), warp(0, 1), warp(0, 2), warp(1, 0), warp(1, 1), warp(1, 2)};
-  staged()->set_camera_motion(w);
+  camera_motion(w);
 }
 void BotSort::set_camera_motion(const Eigen::MatrixXf& warp) {
   if (warp.rows() != 2 || warp.cols() != 3) throw std::invalid_argument("BotSort::set_camera_motion: the warp must be 2 x 3");
   const float w[6] = {warp(0, 0), warp(0, 1), warp(0, 2), warp(1, 0), warp(1, 1), warp(1, 2)};
-  staged()->set_camera_motion(w);
+  camera_motion(w);
 }
 }  // namespace trackers
 

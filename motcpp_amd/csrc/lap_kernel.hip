@@ -275,8 +275,11 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   // slowest problem: four wavefronts per problem cut that latency (MOT_LAP_BEHIND_T=64 keeps one wavefront per problem).
   static const int behind_t = std::getenv("MOT_LAP_BEHIND_T") ? std::atoi(std::getenv("MOT_LAP_BEHIND_T")) : 64;
   const bool behind = fast && behind_t == 256 && n * m >= 65536 && nm <= 3072;
-  const bool wide = (nm > 3072) || behind;  // (any number of problems: with 64 threads the row lists' parallel scan steps are not available)
-  if (fs_lds && wide && b4 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 4; lds = b4; }
+  // (matrix costs of some size: any number of problems — with 64 threads the row lists' parallel scan steps are not available; geometry
+  // launches keep the old bound on the problem count, so that large batches stay on the one-wavefront register-cached variants)
+  const bool wide = (nm > 3072 && (ntasks < 512 || fs_lds)) || behind;
+  // mode 4 (distances in LDS for the scan steps) exists for cost flavour 1 only
+  if (fs_lds && wide && !general_assoc && b4 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 4; lds = b4; }
   // lane-owned column boxes in registers: one wavefront per problem, <= 8 real columns per lane
   int rpl = 0;
   if (geom && !wide && !general_assoc) rpl = (m <= 256) ? 4 : (m <= 512 ? 8 : 0);

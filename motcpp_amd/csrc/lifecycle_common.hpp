@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,8 @@ struct PackMeta {
   const int* maxt = nullptr;
   int n_maxt = 0, maxt_at = 0, counts_at = 0;
   int* counts_copy = nullptr;
+  const int* alive = nullptr;  // optional [S]: live tracks per stream after the frame (pooled trackers size their next frame with it)
+  int alive_at = 0;
 };
 [[maybe_unused]] static __global__ void __launch_bounds__(1024) pack_offsets(const int* counts, int S, int* offsets, PackMeta pm) {
   __shared__ int part[1024];
@@ -79,6 +82,7 @@ struct PackMeta {
     }
     for (int i = t; i < pm.n_maxt; i += 1024) pm.dev[pm.maxt_at + i] = pm.maxt[i];
     for (int i = t; i < S; i += 1024) { const int c = counts[i]; pm.dev[pm.counts_at + i] = c; if (pm.counts_copy) pm.counts_copy[i] = c; }
+    if (pm.alive) for (int i = t; i < S; i += 1024) pm.dev[pm.alive_at + i] = pm.alive[i];
   }
 }
 [[maybe_unused]] static __global__ void __launch_bounds__(256) pack_rows(const float* stage, int cap_stage, const int* counts, const int* offsets, float* packed,
@@ -97,7 +101,11 @@ struct PackMeta {
 // (measured: one 16.6 KB copy per frame took SORT from 10.6 M to 6.4 M frames/s and ByteTrack 256 x 128 from 9.1 M to 5.5 M, with the kernels
 // unchanged), so the buffer goes in pieces of at most 16 KB.
 inline hipError_t copy_meta_d2h(int* h_dst, const int* d_src, size_t n_ints, hipStream_t st) {
-  static const size_t piece = std::getenv("MOT_META_PIECE") ? static_cast<size_t>(std::atol(std::getenv("MOT_META_PIECE"))) : 4096;  // ints
+  static const size_t piece = [] {
+    const char* e = std::getenv("MOT_META_PIECE");
+    const long v = e ? std::atol(e) : 4096;
+    return static_cast<size_t>(v > 0 ? v : 4096);  // (a value that is not a positive number would never advance the loop below)
+  }();  // ints
   for (size_t o = 0; o < n_ints; o += piece) {
     const size_t n = (n_ints - o < piece) ? n_ints - o : piece;
     const hipError_t e = hipMemcpyAsync(h_dst + o, d_src + o, sizeof(int) * n, hipMemcpyDeviceToHost, st);
@@ -122,55 +130,137 @@ struct Allocs {
   }
 };
 
-// ---- frames in flight (round 3: shared by the SORT and OC-SORT lifecycles; ByteTrack / BoT-SORT carry their own copy of the same scheme) ----
+// ---- a frame's inputs as the bookkeeping kernels see them ---------------------------------------------------------------
+// Classic form (mot_*_step*, mot_*_enqueue_packed): every stream takes part, stream s's detections are the SoA planes
+// [6][max_dets] at d_dets + s * 6 * max_dets — only `counts` is set. Pooled form (mot_*_enqueue_frame, round 4): the streams of a
+// batch belong to independent tracker objects, only some of them have a frame to process, and their detections arrive packed back
+// to back: counts[s] < 0 = stream s sits this frame out (its state is not touched, it reports 0 rows), det_off[s] / ld[s] = where
+// its planes [6][ld] start and how long they are. One device block per batch, refilled by one copy per frame.
+struct FrameDev {
+  const int* counts = nullptr;
+  const int* ld = nullptr;
+  const long long* det_off = nullptr;
+  const long long* emb_off = nullptr;  // BoT-SORT: float offset of the stream's [n][E] feature rows, < 0: none this frame
+};
+__device__ __forceinline__ const float* frame_dets(const FrameDev& F, const float* base, int s, int D, int& ld) {
+  if (F.det_off) { ld = F.ld[s]; return base + F.det_off[s]; }
+  ld = D;
+  return base + static_cast<size_t>(s) * 6 * D;
+}
+// host image of the block: [counts S][ld S] ints, then [det_off S][emb_off S] long longs (8-byte aligned: 2 S ints precede)
+inline size_t frame_block_ints(int S) { return static_cast<size_t>(S) * 2 + static_cast<size_t>(S) * 4; }
+
+// ---- frames in flight (round 3: SORT / OC-SORT; round 4: all four lifecycles share this one copy) ------------------------
 // step_packed split in two so that ONE host thread overlaps the result copy of frame f with the kernels of frame f + 1: enqueue(f + 1)
 // returns once its launches are queued, collect(f) waits for frame f's event only and copies its rows on a second stream. Two sets of
 // packed tables; what the host needs back from a frame travels in page-locked memory:
 //   h_meta: [0] total rows, [1] error flag, [2..5) problems the sparse solver declined in up to three associations (-1: not counted),
-//           [5..69) the frame's per-stream maxima (live tracks), then counts out [S], counts in [S] (host only)
-constexpr int kMetaDec = 2, kMetaMaxt = 5, kMetaHead = 69;
+//           [5..5 + n_maxt) the frame's per-stream maxima (64 words: live tracks; ByteTrack / BoT-SORT keep three more sets of 64: the
+//           largest problems of their associations), then counts out [S], live tracks per stream [S] (alive != nullptr), and — host
+//           only — counts in [S], extra_host ints per stream (BoT-SORT: has_warp + 6 warp floats), the pooled input block
+// Zero-copy rows (view mode, what the pooled trackers use): pack_rows writes the packed table straight into page-locked host memory
+// (h_rows), so a frame needs no device-to-host copy at all and collect is one event wait.
+constexpr int kMetaDec = 2, kMetaMaxt = 5;
 struct Flight {
   float* d_packed = nullptr; int* d_offsets = nullptr; int* d_counts = nullptr; int packed_cap = 0;
+  float* h_rows = nullptr; int h_rows_cap = 0;  // view mode: the packed rows in page-locked memory, written by the kernel
   int* h_meta = nullptr;
-  int* d_meta = nullptr;  // device image of h_meta's first kMetaHead + S words
+  int* d_meta = nullptr;  // device image of h_meta's device-filled words
+  int* h_in = nullptr;    // pooled form: page-locked image of the frame's input block
   hipEvent_t done = nullptr;
-  bool pending = false;
+  hipEvent_t ev[12] = {};
+  bool pending = false, prof = false, view = false;
   int rows_cap = 0;  // the row limit pack_rows ran with (the enqueue call's rows_cap)
   int bd = 0;        // largest detection count of the frame (bounds the tracks it may add)
 };
 struct Flights {
   Flight fl[2];
   int head = 0, count = 0;  // oldest pending frame, frames pending
+  int n_maxt = 64;          // words of per-frame maxima the lifecycle keeps
+  int extra_host = 0;       // page-locked ints per stream behind counts_in
+  bool with_alive = false;  // the lifecycle reports the live tracks per stream
   hipStream_t copy_st = nullptr;
+  int* d_in = nullptr;      // the pooled input block on the device
+  int meta_head() const { return kMetaMaxt + n_maxt; }
+  int meta_dev_words(int S) const { return meta_head() + (with_alive ? 2 : 1) * S; }
   int slot_for_enqueue() const { return (head + count) & 1; }
+  const int* maxt_of(const Flight& F) const { return F.h_meta + kMetaMaxt; }
+  const int* counts_of(const Flight& F) const { return F.h_meta + meta_head(); }
+  const int* alive_of(const Flight& F, int S) const { return with_alive ? F.h_meta + meta_head() + S : nullptr; }
+  int* counts_in_of(Flight& F, int S) const { return F.h_meta + meta_dev_words(S); }
+  int* extra_of(Flight& F, int S) const { return F.h_meta + meta_dev_words(S) + S; }
   // buffers of the slot (allocated on first use / when rows_cap grows); counts_in = page-locked copy of the caller's counts
-  hipError_t prepare(Allocs& mem, int slot, int S, int rows_cap, const int* h_counts, int** counts_in, int* bd_out) {
+  hipError_t prepare(Allocs& mem, int slot, int S, int rows_cap, const int* h_counts, int** counts_in, int* bd_out, bool view = false, bool prof = false) {
     Flight& F = fl[slot];
     hipError_t e = hipSuccess;
     if (!copy_st && (e = hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking)) != hipSuccess) return e;
     if (!F.done && (e = hipEventCreateWithFlags(&F.done, hipEventDisableTiming)) != hipSuccess) return e;
-    if (!F.h_meta && (e = hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (kMetaHead + 2 * static_cast<size_t>(S)), hipHostMallocDefault)) != hipSuccess) return e;
-    if (!F.d_offsets) { F.d_offsets = mem.get<int>(static_cast<size_t>(S) + 1); F.d_counts = mem.get<int>(S); F.d_meta = mem.get<int>(kMetaHead + static_cast<size_t>(S)); }
-    if (rows_cap > F.packed_cap) { F.d_packed = mem.get<float>(static_cast<size_t>(rows_cap) * 8); F.packed_cap = F.d_packed ? rows_cap : 0; }
-    if (!F.d_offsets || !F.d_counts || !F.d_packed || !F.d_meta) return hipErrorOutOfMemory;
-    int* ci = F.h_meta + kMetaHead + S;
+    if (!F.h_meta && (e = hipHostMalloc(reinterpret_cast<void**>(&F.h_meta), sizeof(int) * (meta_dev_words(S) + static_cast<size_t>(1 + extra_host) * S), hipHostMallocDefault)) != hipSuccess) return e;
+    if (!F.d_offsets) { F.d_offsets = mem.get<int>(static_cast<size_t>(S) + 1); F.d_counts = mem.get<int>(S); F.d_meta = mem.get<int>(meta_dev_words(S)); }
+    if (!F.d_offsets || !F.d_counts || !F.d_meta) return hipErrorOutOfMemory;
+    if (view) {
+      if (rows_cap > F.h_rows_cap) {
+        if (F.h_rows) (void)hipHostFree(F.h_rows);
+        F.h_rows = nullptr; F.h_rows_cap = 0;
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&F.h_rows), sizeof(float) * 8 * static_cast<size_t>(rows_cap), hipHostMallocDefault)) != hipSuccess) return e;
+        F.h_rows_cap = rows_cap;
+      }
+    } else if (rows_cap > F.packed_cap) {
+      F.d_packed = mem.get<float>(static_cast<size_t>(rows_cap) * 8); F.packed_cap = F.d_packed ? rows_cap : 0;
+      if (!F.d_packed) return hipErrorOutOfMemory;
+    }
+    F.view = view;
+    if (prof && !F.ev[0]) for (auto& ev : F.ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return e;
+    F.prof = prof;
+    int* ci = counts_in_of(F, S);
     int bd = 1;
     for (int s = 0; s < S; ++s) { ci[s] = h_counts[s]; bd = (h_counts[s] > bd) ? h_counts[s] : bd; }
     *counts_in = ci; *bd_out = bd;
     return hipSuccess;
   }
-  // behind the frame's launches: pack the staged tables, bring the small results back, record the frame's event
-  hipError_t finish(int slot, hipStream_t st, const float* d_stage, int cap_stage, const int* d_out_counts, int S, const int* d_err, const int* d_maxt,
-                    const int* d_declined, int rows_cap, int bd, const int* d_declined_b = nullptr, const int* d_declined_c = nullptr) {
+  // pooled form: fills the slot's page-locked input block from the caller's arrays, queues its copy to the device and returns the
+  // device view. emb_off may be nullptr (every stream: none).
+  hipError_t upload_block(Allocs& mem, int slot, int S, const int* counts, const int* ld, const long long* det_off, const long long* emb_off,
+                          hipStream_t st, FrameDev* out) {
+    Flight& F = fl[slot];
+    hipError_t e = hipSuccess;
+    const size_t words = frame_block_ints(S);
+    if (!F.h_in && (e = hipHostMalloc(reinterpret_cast<void**>(&F.h_in), sizeof(int) * words, hipHostMallocDefault)) != hipSuccess) return e;
+    if (!d_in) { d_in = mem.get<int>(words); if (!d_in) return hipErrorOutOfMemory; }
+    int* hc = F.h_in; int* hl = hc + S;
+    long long* hd = reinterpret_cast<long long*>(hl + S); long long* he = hd + S;
+    for (int s = 0; s < S; ++s) { hc[s] = counts[s]; hl[s] = ld[s]; hd[s] = det_off[s]; he[s] = emb_off ? emb_off[s] : -1; }
+    if ((e = hipMemcpyAsync(d_in, F.h_in, sizeof(int) * words, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    out->counts = d_in; out->ld = d_in + S;
+    out->det_off = reinterpret_cast<const long long*>(d_in + 2 * static_cast<size_t>(S)); out->emb_off = out->det_off + S;
+    return hipSuccess;
+  }
+  float* rows_target(int slot) { Flight& F = fl[slot]; return F.view ? F.h_rows : F.d_packed; }
+  PackMeta pack_meta(int slot, const int* d_err, const int* d_maxt, const int* d_declined, const int* d_declined_b = nullptr, const int* d_declined_c = nullptr) {
     Flight& F = fl[slot];
     PackMeta pm;
     pm.dev = F.d_meta; pm.err = d_err; pm.dec[0] = d_declined; pm.dec[1] = d_declined_b; pm.dec[2] = d_declined_c; pm.dec_at = kMetaDec;
-    pm.maxt = d_maxt; pm.n_maxt = 64; pm.maxt_at = kMetaMaxt; pm.counts_at = kMetaHead; pm.counts_copy = F.d_counts;
+    pm.maxt = d_maxt; pm.n_maxt = n_maxt; pm.maxt_at = kMetaMaxt; pm.counts_at = meta_head(); pm.counts_copy = F.d_counts;
+    return pm;
+  }
+  // behind the frame's launches: pack the staged tables, bring the small results back, record the frame's event
+  hipError_t finish(int slot, hipStream_t st, const float* d_stage, int cap_stage, const int* d_out_counts, int S, const int* d_err, const int* d_maxt,
+                    const int* d_declined, int rows_cap, int bd, const int* d_declined_b = nullptr, const int* d_declined_c = nullptr,
+                    const int* d_alive = nullptr) {
+    Flight& F = fl[slot];
+    PackMeta pm = pack_meta(slot, d_err, d_maxt, d_declined, d_declined_b, d_declined_c);
+    pm.alive = with_alive ? d_alive : nullptr; pm.alive_at = meta_head() + S;
     hipLaunchKernelGGL(pack_offsets, dim3(1), dim3(1024), 0, st, d_out_counts, S, F.d_offsets, pm);
-    hipLaunchKernelGGL(pack_rows, dim3(S), dim3(256), 0, st, d_stage, cap_stage, d_out_counts, F.d_offsets, F.d_packed, rows_cap);
+    hipLaunchKernelGGL(pack_rows, dim3(S), dim3(256), 0, st, d_stage, cap_stage, d_out_counts, F.d_offsets, rows_target(slot), rows_cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if ((e = copy_meta_d2h(F.h_meta, F.d_meta, kMetaHead + static_cast<size_t>(S), st)) != hipSuccess) return e;
+    return finish_copies(slot, st, S, rows_cap, bd);
+  }
+  // (the lifecycles that pack inside their own launch sequence call this part only)
+  hipError_t finish_copies(int slot, hipStream_t st, int S, int rows_cap, int bd) {
+    Flight& F = fl[slot];
+    hipError_t e = hipSuccess;
+    if ((e = copy_meta_d2h(F.h_meta, F.d_meta, static_cast<size_t>(meta_dev_words(S)), st)) != hipSuccess) return e;
     if ((e = hipEventRecord(F.done, st)) != hipSuccess) return e;
     F.pending = true; F.bd = bd; F.rows_cap = rows_cap;
     count += 1;
@@ -188,17 +278,41 @@ struct Flights {
   }
   hipError_t copy_rows(const Flight& F, float* rows, int total) {
     if (total <= 0) return hipSuccess;
+    if (F.view) { std::memcpy(rows, F.h_rows, sizeof(float) * static_cast<size_t>(total) * 8); return hipSuccess; }
     const hipError_t e = hipMemcpyAsync(rows, F.d_packed, sizeof(float) * static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, copy_st);
     return (e != hipSuccess) ? e : hipStreamSynchronize(copy_st);
   }
   int pending_bd() const { int v = 0; for (const Flight& F : fl) if (F.pending && F.bd > v) v = F.bd; return v; }
   void drop_all() { for (Flight& F : fl) F.pending = false; head = 0; count = 0; }
   void release() {
-    for (Flight& F : fl) { if (F.done) (void)hipEventDestroy(F.done); if (F.h_meta) (void)hipHostFree(F.h_meta); F.done = nullptr; F.h_meta = nullptr; }
+    for (Flight& F : fl) {
+      if (F.done) (void)hipEventDestroy(F.done);
+      if (F.h_meta) (void)hipHostFree(F.h_meta);
+      if (F.h_in) (void)hipHostFree(F.h_in);
+      if (F.h_rows) (void)hipHostFree(F.h_rows);
+      for (auto& e : F.ev) if (e) (void)hipEventDestroy(e);
+      F = Flight{};
+    }
     if (copy_st) (void)hipStreamDestroy(copy_st);
     copy_st = nullptr;
   }
 };
+
+// one stream's persistent record back to its state at creation (a pooled tracker object's reset() / a slot handed to a new object);
+// keep_ids: the id counter keeps running (Sort::reset, sort.cpp:97-100)
+template <class StreamT>
+static __global__ void reset_stream_kernel(StreamT* streams, int s, StreamT fresh, int keep_ids) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int next_id = streams[s].next_id;
+    streams[s] = fresh;
+    if (keep_ids) streams[s].next_id = next_id;
+  }
+}
+// arrays of a stream that outlive a frame, copied element-wise when a stream moves to a batch with larger capacities
+template <class T>
+__device__ __forceinline__ void move_array(T* dst, const T* src, size_t n) {
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
 
 }  // namespace lifecycle
 }  // namespace mot

@@ -27,6 +27,7 @@ hipError_t launch_ocsort(const mot_ocsort_task*, int, int, int, bool, hipStream_
 namespace {
 using mot::lifecycle::compact;
 using mot::lifecycle::kW;
+using mot::lifecycle::FrameDev;
 
 constexpr int kRounds = 4;  // Kalman updates one slot can receive in a frame before the stream reports an error
 
@@ -46,6 +47,7 @@ struct OcStream {
   float* t_obs;                     // [CAP][K][5]
   // ---- frame ----
   const float* dets; int ld, n;
+  int skip;  // the stream sits this frame out (pooled form: counts[s] < 0)
   int *high, *second; int n_high, n_second;
   int nt0, silent, lap1_q, byte_q, rem_q;
   float *pbox, *vel, *prev, *lbox, *sbox;  // [4][CAP], [2][CAP], [5][CAP], [4][CAP], [4][CAP]
@@ -168,15 +170,28 @@ __device__ __forceinline__ int filter_list(int* list, int n, const unsigned char
 }
 
 // ---- K0: detection split, KalmanBoxTracker::predict's counters (:132-148), the predict task ----
-__global__ void __launch_bounds__(kW) oc_begin(OcStream* streams, OcParams P, int CAP, int D, const int* counts, const float* dets_base, OcTasks K) {
+__global__ void __launch_bounds__(kW) oc_begin(OcStream* streams, OcParams P, int CAP, int D, int S_total, FrameDev FD, const float* dets_base, OcTasks K) {
   const int s = blockIdx.x;
   OcStream& S = streams[s];
   const int t = static_cast<int>(threadIdx.x);
-  int n = counts[s];
-  const float* dets = dets_base + static_cast<size_t>(s) * 6 * D;
+  int n = FD.counts[s];
+  if (n < 0) {  // not this stream's frame: its state stays as it is, every task it owns is empty
+    if (t == 0) {
+      S.skip = 1;
+      K.det[s].n = 0; K.pred[s].n = 0; K.init[s].n = 0; K.sbox[s].n = 0;
+      for (int r = 0; r < kRounds; ++r) K.upd[static_cast<size_t>(r) * S_total + s].n = 0;
+      K.cost[s].nd = 0; K.cost[s].nt = 0;
+      K.lap1[s].n = 0; K.lap1[s].m = 0;
+      K.lapb[s].n = 0; K.lapb[s].m = 0; K.lapb[s].geom.n = 0; K.lapb[s].geom.m = 0;
+      K.lapr[s].n = 0; K.lapr[s].m = 0; K.lapr[s].geom.n = 0; K.lapr[s].geom.m = 0;
+    }
+    return;
+  }
+  int ldd = D;
+  const float* dets = mot::lifecycle::frame_dets(FD, dets_base, s, D, ldd);
   const bool over = n > D;
-  if (over || n < 0) n = 0;
-  const float* conf = dets + static_cast<size_t>(4) * D;
+  if (over) n = 0;
+  const float* conf = dets + static_cast<size_t>(4) * ldd;
   int nh = 0, ns = 0;
   for (int i0 = 0; i0 < n; i0 += kW) {
     const int i = i0 + t;
@@ -198,11 +213,11 @@ __global__ void __launch_bounds__(kW) oc_begin(OcStream* streams, OcParams P, in
   }
   if (t == 0) {
     S.frame_count += 1;
-    S.dets = dets; S.ld = D; S.n = n;
+    S.dets = dets; S.ld = ldd; S.n = n; S.skip = 0;
     if (over) S.err = 1;
     S.n_high = nh; S.n_second = ns; S.nt0 = S.n_trk;
     S.n_upd = 0; S.n_umd = 0; S.n_umt = 0; S.n_init = 0; S.n_need = 0; S.silent = 0; S.lap1_q = 0; S.byte_q = 0; S.rem_q = 0;
-    K.det[s].dets = dets; K.det[s].ld = D; K.det[s].n = n;
+    K.det[s].dets = dets; K.det[s].ld = ldd; K.det[s].n = n;
     K.pred[s].n = S.n_trk; K.pred[s].src = trk;
   }
 }
@@ -212,6 +227,7 @@ __global__ void __launch_bounds__(kW) oc_nan(OcStream* streams, OcParams P, int 
   const int s = blockIdx.x;
   OcStream& S = streams[s];
   const int t = static_cast<int>(threadIdx.x);
+  if (S.skip) return;
   const int nt = S.nt0;
   const int* trk = S.trk[S.cur];
   int* kept = S.trk[S.cur ^ 1];
@@ -278,6 +294,7 @@ __global__ void __launch_bounds__(kW) oc_after_first(OcStream* streams, OcParams
   const int s = blockIdx.x;
   OcStream& S = streams[s];
   const int t = static_cast<int>(threadIdx.x);
+  if (S.skip) return;
   const int nd = S.n_high, nt = S.n_trk;
   int n_umd = 0, n_umt = 0, n_upd = 0;
   if (S.silent) {  // no tracker left: every detection is unmatched, nothing is emitted or aged out this frame
@@ -338,7 +355,7 @@ __global__ void __launch_bounds__(kW) oc_after_byte(OcStream* streams, OcParams 
   const int s = blockIdx.x;
   OcStream& S = streams[s];
   const int t = static_cast<int>(threadIdx.x);
-  if (S.silent) return;
+  if (S.skip || S.silent) return;
   if (S.byte_q && S.infob[0] != 2) {
     const int* trk = S.trk[S.cur];
     int n_upd = S.n_upd;
@@ -366,6 +383,7 @@ __global__ void __launch_bounds__(kW) oc_finish(OcStream* streams, OcParams P, i
   const int s = blockIdx.x;
   OcStream& S = streams[s];
   const int t = static_cast<int>(threadIdx.x);
+  if (S.skip) return;
   int* trk = S.trk[S.cur];
   int n_upd = S.n_upd;
   if (!S.silent && S.rem_q && S.infor[0] != 2) {
@@ -454,11 +472,11 @@ __global__ void __launch_bounds__(kW) oc_finish(OcStream* streams, OcParams P, i
 }
 
 // ---- K5: the output table (newest tracker first) and the age-out (:562-606) ----
-__global__ void __launch_bounds__(kW) oc_emit(OcStream* streams, OcParams P, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks) {
+__global__ void __launch_bounds__(kW) oc_emit(OcStream* streams, OcParams P, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive) {
   OcStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
-  if (S.silent) {
-    if (t == 0) { out_counts[blockIdx.x] = 0; atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk); }
+  if (S.skip || S.silent) {
+    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_trk; atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk); }
     return;
   }
   const int* trk = S.trk[S.cur];
@@ -503,6 +521,7 @@ __global__ void __launch_bounds__(kW) oc_emit(OcStream* streams, OcParams P, int
     if (n_rows > cap_out) S.err = 2;
     out_counts[blockIdx.x] = (n_rows <= cap_out) ? n_rows : -n_rows;
     atomicMax(&max_tracks[blockIdx.x & 63], n_keep);
+    alive[blockIdx.x] = n_keep;
   }
 }
 
@@ -525,6 +544,7 @@ struct mot_oc_batch {
   int* d_counts = nullptr;
   int* d_err = nullptr;
   int* d_maxt = nullptr;
+  int* d_alive = nullptr;
   int bound_n = 0;
   // first association: when (nearly) every problem of a frame was declined by the certified sparse solver (duplicated tracks, quirk Q4:
   // the optimum is not unique), the next frames go to the exact kernel directly; the sparse solver is tried again every 8th frame
@@ -533,11 +553,10 @@ struct mot_oc_batch {
   float* d_out = nullptr; int* d_out_counts = nullptr;
   const float* d_packed = nullptr; const int* d_offsets = nullptr; const int* d_counts_last = nullptr;  // mot_oc_device_output: the frame collected last
   mot::lifecycle::Flights flights;  // mot_oc_enqueue_packed / mot_oc_collect_packed (mot_oc_step_packed = one after the other)
-  bool flight_prof[2] = {false, false};
   float* mean = nullptr;  // [S][CAP] records of 7 + 49 floats
   bool profile = false;
   unsigned long long* d_stats = nullptr;
-  hipEvent_t ev[6] = {};
+  hipEvent_t ev[12] = {};
   double lap_ms = 0.0, cost_ms = 0.0, frame_ms = 0.0;
   long frames = 0;
   template <class T>
@@ -600,6 +619,8 @@ int mot_oc_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
   b->d_maxt = b->dalloc<int>(64);
+  b->d_alive = b->dalloc<int>(S);
+  b->flights.with_alive = true;
   b->d_stats = b->dalloc<unsigned long long>(8 * 64);
   b->d_out = b->dalloc<float>(static_cast<size_t>(S) * CAP * 8);
   b->d_out_counts = b->dalloc<int>(S);
@@ -615,7 +636,7 @@ int mot_oc_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   const size_t wrl = (mot::lap_rowlist_scratch_bytes(D) + 255) & ~size_t(255);   // first association: per-detection lists of the costs below thresh/2
   const size_t wall = wb1 + wbb + wbr + wrl;
   char* work = b->dalloc<char>(wall * S);
-  if (!ip || !fp || !bp || !clamp || !b->mean || !mats || !b->d_streams || !b->d_counts || !b->d_err || !b->d_maxt || !b->d_stats || !b->d_out ||
+  if (!ip || !fp || !bp || !clamp || !b->mean || !mats || !b->d_streams || !b->d_counts || !b->d_err || !b->d_maxt || !b->d_alive || !b->d_stats || !b->d_out ||
       !b->d_out_counts || !T.det || !T.pred || !T.init || !T.upd || !T.sbox || !T.cost || !T.lap1 || !T.lapb || !T.lapr || !work) {
     mot_oc_destroy(b);
     return MOT_ERR_NOMEM;
@@ -710,10 +731,17 @@ int mot_oc_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
 
 // queues one frame of every stream up to the staged output tables (counts: host memory that stays valid until its copy has run);
 // bound = live tracks any stream may have; *declined_out = device counter of the first associations the sparse solver declined
-static int oc_enqueue_frame(mot_oc_batch* b, const float* d_dets, const int* counts, int bound, bool prof, int** declined_out /* [3] */) {
+static int oc_enqueue_frame(mot_oc_batch* b, const float* d_dets, const int* counts, int bound, hipEvent_t* ev, int** declined_out /* [3] */,
+                            const mot::lifecycle::FrameDev* fd = nullptr) {
+  const bool prof = ev != nullptr;
   hipStream_t st = b->ctx->stream;
   const int S = b->S, CAP = b->CAP, D = b->D;
-  MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  mot::lifecycle::FrameDev FD;
+  if (fd) FD = *fd;
+  else {
+    MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+    FD.counts = b->d_counts;
+  }
   MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
   int bd = 1;
   for (int s = 0; s < S; ++s) bd = (counts[s] > bd) ? counts[s] : bd;
@@ -722,51 +750,50 @@ static int oc_enqueue_frame(mot_oc_batch* b, const float* d_dets, const int* cou
   const int bn2 = (bn + 2 * bd > CAP) ? CAP : bn + 2 * bd;
   const bool general = b->prm.asso != MOT_ASSOC_IOU;
   const OcTasks& K = b->tasks;
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[0], st));
-  hipLaunchKernelGGL(oc_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, K);
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
+  hipLaunchKernelGGL(oc_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, S, FD, d_dets, K);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYSR, K.det, S, bd, st));
   MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYSR, K.pred, S, bn, st));
   hipLaunchKernelGGL(oc_nan, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K, prof ? b->d_stats : nullptr);
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[2], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
   MOT_LC_HIP(b, mot::launch_ocsort(K.cost, S, bd, bn, !general, st));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[3], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
   // an association whose problems the sparse solver declined (nine in ten) goes straight to the exact solver, with a retry every eighth frame:
   // with quirk Q4's duplicate tracks no optimum is unique, and a declined attempt costs as much as a successful one
-  const bool retry = (b->lap1_age % 8) == 0;
+  const bool retry = (b->lap1_age++ % 8) == 0;  // (advanced here, not at collect: two frames queued back to back do not both retry)
   const bool lap1_fast = !b->skip_fast[0] || retry, lapb_fast = !b->skip_fast[1] || retry, lapr_fast = !b->skip_fast[2] || retry;
   int* lap1_declined = nullptr; int* lapb_declined = nullptr; int* lapr_declined = nullptr;
   MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bd, bn, false, false, true, st, 0, 0, lap1_fast, &lap1_declined));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[4], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
   hipLaunchKernelGGL(oc_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, K);
   if (b->prm.use_byte) {
     MOT_LC_HIP(b, mot::launch_lap(K.lapb, S, bd, (bn + bd > CAP + D) ? CAP + D : bn + bd, true, general, true, st, 0, 0, lapb_fast, &lapb_declined));
     hipLaunchKernelGGL(oc_after_byte, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, K);
   }
   MOT_LC_HIP(b, mot::launch_lap(K.lapr, S, 2 * bd, bn + bd, true, general, true, st, 0, 0, lapr_fast, &lapr_declined));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[5], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[5], st));
   hipLaunchKernelGGL(oc_finish, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, S, K);
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYSR, K.init, S, 2 * bd, st));
   for (int r = 0; r < kRounds; ++r) MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYSR, K.upd + static_cast<size_t>(r) * S, S, (r == 0) ? bn : 2 * bd, st));
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYSR, K.sbox, S, bn2, st));
-  hipLaunchKernelGGL(oc_emit, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt);
+  hipLaunchKernelGGL(oc_emit, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt, b->d_alive);
   hipLaunchKernelGGL(oc_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
   MOT_LC_HIP(b, hipGetLastError());
   declined_out[0] = lap1_declined; declined_out[1] = lapb_declined; declined_out[2] = lapr_declined;
   return MOT_OK;
 }
 // what the host keeps from a finished frame: the launch bound of the next one, whether the sparse solver is worth trying, profile sums
-static int oc_account(mot_oc_batch* b, const int* maxt, const int declined[3], bool prof) {
-  ++b->lap1_age;
+static int oc_account(mot_oc_batch* b, const int* maxt, const int declined[3], hipEvent_t* ev) {
   for (int k = 0; k < 3; ++k)
     if (declined[k] >= 0) b->skip_fast[k] = declined[k] * 10 >= 9 * b->S;
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
-  if (prof) {
+  if (ev) {
     float ms = 0.f;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[1])); b->frame_ms += ms;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[2], b->ev[3])); b->cost_ms += ms;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[3], b->ev[4])); b->lap_ms += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[0], ev[1])); b->frame_ms += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[2], ev[3])); b->cost_ms += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[3], ev[4])); b->lap_ms += ms;
     b->frames += 1;
   }
   return MOT_OK;
@@ -774,38 +801,103 @@ static int oc_account(mot_oc_batch* b, const int* maxt, const int declined[3], b
 
 // Frames in flight (as mot_bt_enqueue_packed / mot_bt_collect_packed): a frame still in flight may add two tracks per detection
 // (quirk Q4: a detection on the unmatched list twice spawns two), which bounds the next frame's launches.
-int mot_oc_enqueue_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts, int rows_cap) {
-  if (!b || !d_dets || !h_counts || rows_cap <= 0) return MOT_ERR_INVALID;
-  if (b->flights.count >= 2) { b->ctx->err = "mot_oc_enqueue_packed: two frames are already in flight (collect one first)"; return MOT_ERR_INVALID; }
+static int oc_enqueue_flight(mot_oc_batch* b, const float* d_dets, const int* h_counts, int rows_cap, const mot_frame_in* in) {
+  if (b->flights.count >= 2) { b->ctx->err = "mot_oc_enqueue: two frames are already in flight (collect one first)"; return MOT_ERR_INVALID; }
   const int slot = b->flights.slot_for_enqueue();
   int* counts_in = nullptr;
   int bd = 0;
-  MOT_LC_HIP(b, b->flights.prepare(b->mem, slot, b->S, rows_cap, h_counts, &counts_in, &bd));
-  const bool prof = b->profile && b->flights.count == 0;  // (one set of events: profiled only when nothing else is in flight)
+  MOT_LC_HIP(b, b->flights.prepare(b->mem, slot, b->S, rows_cap, h_counts, &counts_in, &bd, in != nullptr, b->profile));  // (an event set per frame in flight)
+  mot::lifecycle::Flight& F = b->flights.fl[slot];
+  mot::lifecycle::FrameDev fd;
+  if (in) MOT_LC_HIP(b, b->flights.upload_block(b->mem, slot, b->S, in->h_counts, in->h_det_ld, in->h_det_off, nullptr, b->ctx->stream, &fd));
   int* declined[3] = {nullptr, nullptr, nullptr};
-  const int rc = oc_enqueue_frame(b, d_dets, counts_in, b->bound_n + 2 * b->flights.pending_bd(), prof, declined);
+  const int rc = oc_enqueue_frame(b, d_dets, counts_in, b->bound_n + 2 * b->flights.pending_bd(), F.prof ? F.ev : nullptr, declined, in ? &fd : nullptr);
   if (rc != MOT_OK) return rc;
-  b->flight_prof[slot] = prof;
-  MOT_LC_HIP(b, b->flights.finish(slot, b->ctx->stream, b->d_out, b->CAP, b->d_out_counts, b->S, b->d_err, b->d_maxt, declined[0], rows_cap, bd, declined[1], declined[2]));
+  MOT_LC_HIP(b, b->flights.finish(slot, b->ctx->stream, b->d_out, b->CAP, b->d_out_counts, b->S, b->d_err, b->d_maxt, declined[0], rows_cap, bd, declined[1], declined[2], b->d_alive));
   return MOT_OK;
+}
+static int oc_pop_flight(mot_oc_batch* b, mot::lifecycle::Flight** out, int* total) {
+  if (b->flights.count <= 0) { b->ctx->err = "mot_oc_collect: no frame in flight"; return MOT_ERR_INVALID; }
+  mot::lifecycle::Flight* F = nullptr;
+  MOT_LC_HIP(b, b->flights.pop(&F));
+  const int dec[3] = {F->h_meta[mot::lifecycle::kMetaDec], F->h_meta[mot::lifecycle::kMetaDec + 1], F->h_meta[mot::lifecycle::kMetaDec + 2]};
+  const int ra = oc_account(b, b->flights.maxt_of(*F), dec, F->prof ? F->ev : nullptr);
+  if (ra != MOT_OK) return ra;
+  *total = F->h_meta[0];
+  *out = F;
+  b->d_packed = F->view ? F->h_rows : F->d_packed; b->d_offsets = F->d_offsets;  // mot_oc_device_output: the frame just collected
+  b->d_counts_last = F->d_counts;
+  if (F->h_meta[1]) { b->ctx->err = "mot_oc_step: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
+  if (*total > F->rows_cap) { b->ctx->err = "mot_oc_step_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  return MOT_OK;
+}
+int mot_oc_enqueue_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts, int rows_cap) {
+  if (!b || !d_dets || !h_counts || rows_cap <= 0) return MOT_ERR_INVALID;
+  return oc_enqueue_flight(b, d_dets, h_counts, rows_cap, nullptr);
 }
 int mot_oc_collect_packed(mot_oc_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows) {
   if (!b || !rows || !out_counts) return MOT_ERR_INVALID;
-  if (b->flights.count <= 0) { b->ctx->err = "mot_oc_collect_packed: no frame in flight"; return MOT_ERR_INVALID; }
-  const int slot = b->flights.head;
   mot::lifecycle::Flight* F = nullptr;
-  MOT_LC_HIP(b, b->flights.pop(&F));
-  const int total = F->h_meta[0], err = F->h_meta[1];
-  const int dec[3] = {F->h_meta[mot::lifecycle::kMetaDec], F->h_meta[mot::lifecycle::kMetaDec + 1], F->h_meta[mot::lifecycle::kMetaDec + 2]};
-  const int ra = oc_account(b, F->h_meta + mot::lifecycle::kMetaMaxt, dec, b->flight_prof[slot]);
-  if (ra != MOT_OK) return ra;
-  std::memcpy(out_counts, F->h_meta + mot::lifecycle::kMetaHead, sizeof(int) * b->S);
+  int total = 0;
+  const int rc = oc_pop_flight(b, &F, &total);
+  if (F) std::memcpy(out_counts, b->flights.counts_of(*F), sizeof(int) * b->S);
   if (total_rows) *total_rows = total;
-  b->d_packed = F->d_packed; b->d_offsets = F->d_offsets;  // mot_oc_device_output: the frame just collected
-  b->d_counts_last = F->d_counts;
-  if (err) { b->ctx->err = "mot_oc_step: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
-  if (total > rows_cap || total > F->rows_cap) { b->ctx->err = "mot_oc_step_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  if (rc != MOT_OK) return rc;
+  if (total > rows_cap) { b->ctx->err = "mot_oc_step_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
   MOT_LC_HIP(b, b->flights.copy_rows(*F, rows, total));
+  return MOT_OK;
+}
+// ---- pooled form (see mot_bt_enqueue_frame) ----
+int mot_oc_enqueue_frame(mot_oc_batch* b, const mot_frame_in* in, int rows_cap) {
+  if (!b || !in || !in->d_dets || !in->h_counts || !in->h_det_ld || !in->h_det_off || rows_cap <= 0) return MOT_ERR_INVALID;
+  return oc_enqueue_flight(b, in->d_dets, in->h_counts, rows_cap, in);
+}
+int mot_oc_collect_view(mot_oc_batch* b, mot_frame_view* out) {
+  if (!b || !out) return MOT_ERR_INVALID;
+  mot::lifecycle::Flight* F = nullptr;
+  int total = 0;
+  const int rc = oc_pop_flight(b, &F, &total);
+  if (!F) return rc;
+  if (!F->view) { b->ctx->err = "mot_oc_collect_view: the frame was queued with mot_oc_enqueue_packed"; return MOT_ERR_INVALID; }
+  out->rows = F->h_rows; out->counts = b->flights.counts_of(*F); out->alive = b->flights.alive_of(*F, b->S); out->total = total;
+  return rc;
+}
+int mot_oc_reset_stream(mot_oc_batch* b, int s, int fresh) {
+  if (!b || s < 0 || s >= b->S) return MOT_ERR_INVALID;
+  hipLaunchKernelGGL(mot::lifecycle::reset_stream_kernel<OcStream>, dim3(1), dim3(64), 0, b->ctx->stream, b->d_streams, s, b->h_streams[s], fresh ? 0 : 1);
+  MOT_LC_HIP(b, hipGetLastError());
+  return MOT_OK;
+}
+namespace {
+__global__ void __launch_bounds__(256) oc_move(const OcStream* from, OcStream* to, const float* mean_from, float* mean_to, int cap, int K) {
+  using mot::lifecycle::move_array;
+  const OcStream& A = *from;
+  OcStream& B = *to;
+  const size_t n = static_cast<size_t>(cap);
+  move_array(B.free_stack, A.free_stack, n); move_array(B.trk[0], A.trk[A.cur], n);
+  move_array(B.t_id, A.t_id, n); move_array(B.t_age, A.t_age, n); move_array(B.t_hits, A.t_hits, n); move_array(B.t_streak, A.t_streak, n);
+  move_array(B.t_tsu, A.t_tsu, n); move_array(B.t_cls, A.t_cls, n); move_array(B.t_det, A.t_det, n); move_array(B.t_nobs, A.t_nobs, n);
+  move_array(B.t_conf, A.t_conf, n); move_array(B.t_last, A.t_last, n * 5); move_array(B.t_vel, A.t_vel, n * 2);
+  move_array(B.t_oage, A.t_oage, n * K); move_array(B.t_obs, A.t_obs, n * K * 5);
+  move_array(mean_to, mean_from, n * 56);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    B.frame_count = A.frame_count; B.next_id = A.next_id; B.next_slot = A.next_slot; B.n_free = A.n_free; B.n_trk = A.n_trk; B.err = A.err;
+    B.cur = 0; B.skip = 1;
+  }
+}
+}  // namespace
+int mot_oc_move_stream(mot_oc_batch* src, int s, mot_oc_batch* dst, int s2) {
+  if (!src || !dst || s < 0 || s >= src->S || s2 < 0 || s2 >= dst->S || dst->CAP < src->CAP || dst->D < src->D || dst->prm.K != src->prm.K) return MOT_ERR_INVALID;
+  MOT_LC_HIP(src, hipStreamSynchronize(src->ctx->stream));
+  hipStream_t st = dst->ctx->stream;
+  hipLaunchKernelGGL(oc_move, dim3(1), dim3(256), 0, st, src->d_streams + s, dst->d_streams + s2, src->mean + static_cast<size_t>(s) * 56 * src->CAP,
+                     dst->mean + static_cast<size_t>(s2) * 56 * dst->CAP, src->CAP, src->prm.K);
+  MOT_LC_HIP(dst, hipGetLastError());
+  OcStream h;
+  MOT_LC_HIP(dst, hipMemcpyAsync(&h, dst->d_streams + s2, sizeof(OcStream), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(dst, hipStreamSynchronize(st));
+  if (h.n_trk > dst->bound_n) dst->bound_n = h.n_trk;
   return MOT_OK;
 }
 int mot_oc_step_packed(mot_oc_batch* b, const float* d_dets, const int* h_counts, float* rows, int rows_cap, int* out_counts, int* total_rows) {

@@ -13,6 +13,7 @@
 namespace {
 using mot::lifecycle::compact;
 using mot::lifecycle::kW;
+using mot::lifecycle::FrameDev;
 
 struct SortParams {
   float det_thresh, iou_thr;
@@ -28,6 +29,7 @@ struct SortStream {
   float* t_conf;
   // frame
   const float* dets; int ld, n;
+  int skip;  // the stream sits this frame out (pooled form: counts[s] < 0)
   int* valid; int n_valid;
   int* keep; int n_keep;      // positions (into the predicted-box planes) of the tracks that survive the NaN rule
   int *x, *y;
@@ -40,13 +42,18 @@ struct SortStream {
 
 
 // detections with conf >= det_thresh (:112-120), ++age / ++time_since_update of every track (SortTrack::predict :43-51)
-__global__ void __launch_bounds__(kW) sort_begin(SortStream* streams, SortParams P, int CAP, int D, const int* counts, const float* dets_base,
+__global__ void __launch_bounds__(kW) sort_begin(SortStream* streams, SortParams P, int CAP, int D, FrameDev FD, const float* dets_base,
                                                   mot_det_task* det_t, mot_kf_task* pred_t) {
   SortStream& S = streams[blockIdx.x];
   const int t = threadIdx.x;
-  const int n = counts[blockIdx.x];
-  const float* dets = dets_base + static_cast<size_t>(blockIdx.x) * 6 * D;
-  const float* conf = dets + static_cast<size_t>(4) * D;
+  const int n = FD.counts[blockIdx.x];
+  if (n < 0) {  // not this stream's frame
+    if (t == 0) { S.skip = 1; det_t[blockIdx.x].n = 0; pred_t[blockIdx.x].n = 0; }
+    return;
+  }
+  int ldd = D;
+  const float* dets = mot::lifecycle::frame_dets(FD, dets_base, blockIdx.x, D, ldd);
+  const float* conf = dets + static_cast<size_t>(4) * ldd;
   int nv = 0;
   for (int i0 = 0; i0 < n; i0 += kW) {
     const int i = i0 + t;
@@ -58,9 +65,9 @@ __global__ void __launch_bounds__(kW) sort_begin(SortStream* streams, SortParams
   for (int i = t; i < S.n_trk; i += kW) { const int slot = trk[i]; S.t_age[slot] += 1; S.t_tsu[slot] += 1; }
   if (t == 0) {
     S.frame_count += 1;
-    S.dets = dets; S.ld = D; S.n = n; S.n_valid = nv;
+    S.dets = dets; S.ld = ldd; S.n = n; S.n_valid = nv; S.skip = 0;
     if (n > D) S.err = 1;
-    det_t[blockIdx.x].dets = dets; det_t[blockIdx.x].ld = D; det_t[blockIdx.x].n = (n <= D) ? n : 0;
+    det_t[blockIdx.x].dets = dets; det_t[blockIdx.x].ld = ldd; det_t[blockIdx.x].n = (n <= D) ? n : 0;
     pred_t[blockIdx.x].n = S.n_trk; pred_t[blockIdx.x].src = trk;
   }
 }
@@ -69,6 +76,10 @@ __global__ void __launch_bounds__(kW) sort_begin(SortStream* streams, SortParams
 __global__ void __launch_bounds__(kW) sort_assoc(SortStream* streams, int CAP, mot_lap_task* lap_t, unsigned long long* stats) {
   SortStream& S = streams[blockIdx.x];
   const int t = threadIdx.x;
+  if (S.skip) {
+    if (t == 0) { mot_lap_task& L = lap_t[blockIdx.x]; L.n = 0; L.m = 0; L.geom.n = 0; L.geom.m = 0; }
+    return;
+  }
   const int nt = S.n_trk;
   const int* trk = S.trk[S.cur];
   int* kept = S.trk[S.cur ^ 1];
@@ -101,6 +112,10 @@ __global__ void __launch_bounds__(kW) sort_apply(SortStream* streams, SortParams
                                                   mot_kf_task* box_t) {
   SortStream& S = streams[blockIdx.x];
   const int t = threadIdx.x;
+  if (S.skip) {
+    if (t == 0) { init_t[blockIdx.x].n = 0; upd_t[blockIdx.x].n = 0; box_t[blockIdx.x].n = 0; }
+    return;
+  }
   const int nt = S.n_trk, nd = S.n_valid;
   const bool have = nt > 0 && nd > 0;
   const int* trk = S.trk[S.cur];
@@ -201,9 +216,13 @@ __global__ void __launch_bounds__(kW) sort_apply(SortStream* streams, SortParams
   }
 }
 
-__global__ void __launch_bounds__(kW) sort_emit(SortStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks) {
+__global__ void __launch_bounds__(kW) sort_emit(SortStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive) {
   SortStream& S = streams[blockIdx.x];
   const int t = threadIdx.x;
+  if (S.skip) {
+    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_trk; atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk); }
+    return;
+  }
   float* rows = out + static_cast<size_t>(blockIdx.x) * cap_out * 8;
   const int n = S.n_out;
   for (int k = t; k < n && k < cap_out; k += kW) {
@@ -218,6 +237,7 @@ __global__ void __launch_bounds__(kW) sort_emit(SortStream* streams, int CAP, fl
     if (n > cap_out) S.err = 2;
     out_counts[blockIdx.x] = (n <= cap_out) ? n : -n;
     atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk);
+    alive[blockIdx.x] = S.n_trk;
   }
 }
 
@@ -235,7 +255,7 @@ struct mot_sort_batch {
   mot::lifecycle::Allocs mem;
   SortStream* d_streams = nullptr;
   std::vector<SortStream> h_streams;
-  int *d_counts = nullptr, *d_err = nullptr, *d_maxt = nullptr;
+  int *d_counts = nullptr, *d_err = nullptr, *d_maxt = nullptr, *d_alive = nullptr;
   int bound_n = 0;
   float* d_out = nullptr; int* d_out_counts = nullptr; int out_cap = 0;
   mot_det_task* det_t = nullptr;
@@ -243,7 +263,7 @@ struct mot_sort_batch {
   mot_lap_task* lap_t = nullptr;
   float* mean = nullptr;  // [S][CAP] records of 7 + 49 floats (mot_kf_task's slab)
   bool profile = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[12] = {};
   double lap_ms = 0.0, frame_ms = 0.0;
   long frames = 0;
   unsigned long long* d_stats = nullptr;  // [64][2]: problems, sum of n + m
@@ -294,6 +314,8 @@ int mot_sort_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, co
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
   b->d_maxt = b->dalloc<int>(64);
+  b->d_alive = b->dalloc<int>(S);
+  b->flights.with_alive = true;
   b->d_stats = b->dalloc<unsigned long long>(128);
   if (b->d_stats) (void)hipMemset(b->d_stats, 0, 128 * sizeof(unsigned long long));
   for (auto& e : b->ev) (void)hipEventCreate(&e);
@@ -303,7 +325,7 @@ int mot_sort_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, co
   const size_t wb = (mot::lap_scratch_bytes(CAP, D) + 255) & ~size_t(255);
   char* work = b->dalloc<char>(wb * S);
   int* info = b->dalloc<int>(static_cast<size_t>(4) * S);
-  if (!ip || !fp || !b->mean || !b->d_streams || !b->d_counts || !b->d_err || !b->d_maxt || !b->det_t || !b->pred_t || !b->init_t ||
+  if (!ip || !fp || !b->mean || !b->d_streams || !b->d_counts || !b->d_err || !b->d_maxt || !b->d_alive || !b->det_t || !b->pred_t || !b->init_t ||
       !b->upd_t || !b->box_t || !b->lap_t || !work || !info) {
     mot_sort_destroy(b);
     return MOT_ERR_NOMEM;
@@ -359,7 +381,9 @@ int mot_sort_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, co
 
 // queues one frame of every stream (counts: host memory that stays valid until the copy has run — the caller's array for the synchronous
 // calls, the flight's page-locked copy for frames in flight); cap_out = staging rows per stream; bound = live tracks any stream may have
-static int sort_enqueue_frame(mot_sort_batch* b, const float* d_dets, const int* counts, int cap_out, int bound, bool prof) {
+static int sort_enqueue_frame(mot_sort_batch* b, const float* d_dets, const int* counts, int cap_out, int bound, hipEvent_t* ev,
+                              const mot::lifecycle::FrameDev* fd = nullptr) {
+  const bool prof = ev != nullptr;
   hipStream_t st = b->ctx->stream;
   const int S = b->S, CAP = b->CAP, D = b->D;
   if (cap_out > b->out_cap) {
@@ -368,38 +392,43 @@ static int sort_enqueue_frame(mot_sort_batch* b, const float* d_dets, const int*
     if (!b->d_out || !b->d_out_counts) return MOT_ERR_NOMEM;
     b->out_cap = cap_out;
   }
-  MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+  mot::lifecycle::FrameDev FD;
+  if (fd) FD = *fd;
+  else {
+    MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
+    FD.counts = b->d_counts;
+  }
   MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
   int bd = 1;
   for (int s = 0; s < S; ++s) bd = (counts[s] > bd) ? counts[s] : bd;
   if (bd > D) bd = D;
   const int bn = (bound < 1) ? 1 : (bound > CAP ? CAP : bound);  // tracks alive after the previous frame (+ what frames in flight may add)
   const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[0], st));
-  hipLaunchKernelGGL(sort_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, b->d_counts, d_dets, b->det_t, b->pred_t);
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
+  hipLaunchKernelGGL(sort_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, FD, d_dets, b->det_t, b->pred_t);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYSR, b->det_t, S, bd, st));
   MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYSR, b->pred_t, S, bn, st));
   hipLaunchKernelGGL(sort_assoc, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->lap_t, prof ? b->d_stats : nullptr);
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[1], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap_t, S, bn, bd, true, false, true, st));
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[2], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
   hipLaunchKernelGGL(sort_apply, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box_t);
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYSR, b->init_t, S, bd, st));
   MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYSR, b->upd_t, S, bn, st));
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYSR, b->box_t, S, bn2, st));
-  hipLaunchKernelGGL(sort_emit, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt);
+  hipLaunchKernelGGL(sort_emit, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt, b->d_alive);
   hipLaunchKernelGGL(sort_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
-  if (prof) MOT_LC_HIP(b, hipEventRecord(b->ev[3], st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
   MOT_LC_HIP(b, hipGetLastError());
   return MOT_OK;
 }
-static int sort_account(mot_sort_batch* b, const int* maxt, bool prof) {
+static int sort_account(mot_sort_batch* b, const int* maxt, hipEvent_t* ev) {
   b->bound_n = 0;
   for (int i = 0; i < 64; ++i) b->bound_n = (maxt[i] > b->bound_n) ? maxt[i] : b->bound_n;
-  if (prof) {
+  if (ev) {
     float ms = 0.f;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[1], b->ev[2])); b->lap_ms += ms;
-    MOT_LC_HIP(b, hipEventElapsedTime(&ms, b->ev[0], b->ev[3])); b->frame_ms += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[1], ev[2])); b->lap_ms += ms;
+    MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[0], ev[3])); b->frame_ms += ms;
     b->frames += 1;
   }
   return MOT_OK;
@@ -410,7 +439,7 @@ int mot_sort_step(mot_sort_batch* b, const float* d_dets, const int* h_counts, f
   const int S = b->S;
   if (b->flights.count > 0) { b->ctx->err = "mot_sort_step: frames are in flight (collect them first)"; return MOT_ERR_INVALID; }
   const bool prof = b->profile;
-  const int rc = sort_enqueue_frame(b, d_dets, h_counts, cap_out, b->bound_n, prof);
+  const int rc = sort_enqueue_frame(b, d_dets, h_counts, cap_out, b->bound_n, prof ? b->ev : nullptr);
   if (rc != MOT_OK) return rc;
   int err = 0, maxt[64];
   MOT_LC_HIP(b, hipMemcpyAsync(out, b->d_out, sizeof(float) * static_cast<size_t>(S) * cap_out * 8, hipMemcpyDeviceToHost, st));
@@ -418,40 +447,106 @@ int mot_sort_step(mot_sort_batch* b, const float* d_dets, const int* h_counts, f
   MOT_LC_HIP(b, hipMemcpyAsync(&err, b->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(maxt, b->d_maxt, sizeof(maxt), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipStreamSynchronize(st));
-  const int ra = sort_account(b, maxt, prof);
+  const int ra = sort_account(b, maxt, prof ? b->ev : nullptr);
   if (ra != MOT_OK) return ra;
   if (err) { b->ctx->err = "mot_sort_step: a stream exceeded cap_tracks / max_dets / cap_out"; return MOT_ERR_CAPACITY; }
   return MOT_OK;
 }
 
 // ---- packed output + frames in flight (as mot_bt_*; Sort::update, src/trackers/sort.cpp:102-255, emits at most one row per live track) ----
-int mot_sort_enqueue_packed(mot_sort_batch* b, const float* d_dets, const int* h_counts, int rows_cap) {
-  if (!b || !d_dets || !h_counts || rows_cap <= 0) return MOT_ERR_INVALID;
-  if (b->flights.count >= 2) { b->ctx->err = "mot_sort_enqueue_packed: two frames are already in flight (collect one first)"; return MOT_ERR_INVALID; }
+static int sort_enqueue_flight(mot_sort_batch* b, const float* d_dets, const int* h_counts, int rows_cap, const mot_frame_in* in) {
+  if (b->flights.count >= 2) { b->ctx->err = "mot_sort_enqueue: two frames are already in flight (collect one first)"; return MOT_ERR_INVALID; }
   const int slot = b->flights.slot_for_enqueue();
   int* counts_in = nullptr;
   int bd = 0;
-  MOT_LC_HIP(b, b->flights.prepare(b->mem, slot, b->S, rows_cap, h_counts, &counts_in, &bd));
+  MOT_LC_HIP(b, b->flights.prepare(b->mem, slot, b->S, rows_cap, h_counts, &counts_in, &bd, in != nullptr, b->profile));
+  mot::lifecycle::Flight& F = b->flights.fl[slot];
+  mot::lifecycle::FrameDev fd;
+  if (in) MOT_LC_HIP(b, b->flights.upload_block(b->mem, slot, b->S, in->h_counts, in->h_det_ld, in->h_det_off, nullptr, b->ctx->stream, &fd));
   const int bound = b->bound_n + b->flights.pending_bd();  // a frame still in flight adds at most one track per detection
-  const int rc = sort_enqueue_frame(b, d_dets, counts_in, b->CAP, bound, false);
+  const int rc = sort_enqueue_frame(b, d_dets, counts_in, b->CAP, bound, F.prof ? F.ev : nullptr, in ? &fd : nullptr);
   if (rc != MOT_OK) return rc;
-  MOT_LC_HIP(b, b->flights.finish(slot, b->ctx->stream, b->d_out, b->CAP, b->d_out_counts, b->S, b->d_err, b->d_maxt, nullptr, rows_cap, bd));
+  MOT_LC_HIP(b, b->flights.finish(slot, b->ctx->stream, b->d_out, b->CAP, b->d_out_counts, b->S, b->d_err, b->d_maxt, nullptr, rows_cap, bd, nullptr, nullptr, b->d_alive));
   return MOT_OK;
+}
+static int sort_pop_flight(mot_sort_batch* b, mot::lifecycle::Flight** out, int* total) {
+  if (b->flights.count <= 0) { b->ctx->err = "mot_sort_collect: no frame in flight"; return MOT_ERR_INVALID; }
+  mot::lifecycle::Flight* F = nullptr;
+  MOT_LC_HIP(b, b->flights.pop(&F));
+  const int ra = sort_account(b, b->flights.maxt_of(*F), F->prof ? F->ev : nullptr);
+  if (ra != MOT_OK) return ra;
+  *total = F->h_meta[0];
+  *out = F;
+  b->d_rows_last = F->view ? F->h_rows : F->d_packed; b->d_offsets_last = F->d_offsets; b->d_counts_last = F->d_counts;
+  if (F->h_meta[1]) { b->ctx->err = "mot_sort_collect: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
+  if (*total > F->rows_cap) { b->ctx->err = "mot_sort_collect: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  return MOT_OK;
+}
+int mot_sort_enqueue_packed(mot_sort_batch* b, const float* d_dets, const int* h_counts, int rows_cap) {
+  if (!b || !d_dets || !h_counts || rows_cap <= 0) return MOT_ERR_INVALID;
+  return sort_enqueue_flight(b, d_dets, h_counts, rows_cap, nullptr);
 }
 int mot_sort_collect_packed(mot_sort_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows) {
   if (!b || !rows || !out_counts) return MOT_ERR_INVALID;
-  if (b->flights.count <= 0) { b->ctx->err = "mot_sort_collect_packed: no frame in flight"; return MOT_ERR_INVALID; }
   mot::lifecycle::Flight* F = nullptr;
-  MOT_LC_HIP(b, b->flights.pop(&F));
-  const int total = F->h_meta[0], err = F->h_meta[1];
-  const int ra = sort_account(b, F->h_meta + mot::lifecycle::kMetaMaxt, false);
-  if (ra != MOT_OK) return ra;
-  std::memcpy(out_counts, F->h_meta + mot::lifecycle::kMetaHead, sizeof(int) * b->S);
+  int total = 0;
+  const int rc = sort_pop_flight(b, &F, &total);
+  if (F) std::memcpy(out_counts, b->flights.counts_of(*F), sizeof(int) * b->S);
   if (total_rows) *total_rows = total;
-  b->d_rows_last = F->d_packed; b->d_offsets_last = F->d_offsets; b->d_counts_last = F->d_counts;
-  if (err) { b->ctx->err = "mot_sort_collect_packed: a stream exceeded cap_tracks / max_dets"; return MOT_ERR_CAPACITY; }
-  if (total > rows_cap || total > F->rows_cap) { b->ctx->err = "mot_sort_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
+  if (rc != MOT_OK) return rc;
+  if (total > rows_cap) { b->ctx->err = "mot_sort_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
   MOT_LC_HIP(b, b->flights.copy_rows(*F, rows, total));
+  return MOT_OK;
+}
+// ---- pooled form (see mot_bt_enqueue_frame) ----
+int mot_sort_enqueue_frame(mot_sort_batch* b, const mot_frame_in* in, int rows_cap) {
+  if (!b || !in || !in->d_dets || !in->h_counts || !in->h_det_ld || !in->h_det_off || rows_cap <= 0) return MOT_ERR_INVALID;
+  return sort_enqueue_flight(b, in->d_dets, in->h_counts, rows_cap, in);
+}
+int mot_sort_collect_view(mot_sort_batch* b, mot_frame_view* out) {
+  if (!b || !out) return MOT_ERR_INVALID;
+  mot::lifecycle::Flight* F = nullptr;
+  int total = 0;
+  const int rc = sort_pop_flight(b, &F, &total);
+  if (!F) return rc;
+  if (!F->view) { b->ctx->err = "mot_sort_collect_view: the frame was queued with mot_sort_enqueue_packed"; return MOT_ERR_INVALID; }
+  out->rows = F->h_rows; out->counts = b->flights.counts_of(*F); out->alive = b->flights.alive_of(*F, b->S); out->total = total;
+  return rc;
+}
+int mot_sort_reset_stream(mot_sort_batch* b, int s, int fresh) {
+  if (!b || s < 0 || s >= b->S) return MOT_ERR_INVALID;
+  hipLaunchKernelGGL(mot::lifecycle::reset_stream_kernel<SortStream>, dim3(1), dim3(64), 0, b->ctx->stream, b->d_streams, s, b->h_streams[s], fresh ? 0 : 1);
+  MOT_LC_HIP(b, hipGetLastError());
+  return MOT_OK;
+}
+namespace {
+__global__ void __launch_bounds__(256) sort_move(const SortStream* from, SortStream* to, const float* mean_from, float* mean_to, int cap) {
+  using mot::lifecycle::move_array;
+  const SortStream& A = *from;
+  SortStream& B = *to;
+  const size_t n = static_cast<size_t>(cap);
+  move_array(B.free_stack, A.free_stack, n); move_array(B.trk[0], A.trk[A.cur], n);
+  move_array(B.t_id, A.t_id, n); move_array(B.t_cls, A.t_cls, n); move_array(B.t_det, A.t_det, n); move_array(B.t_hits, A.t_hits, n);
+  move_array(B.t_tsu, A.t_tsu, n); move_array(B.t_age, A.t_age, n); move_array(B.t_conf, A.t_conf, n);
+  move_array(mean_to, mean_from, n * 56);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    B.frame_count = A.frame_count; B.next_id = A.next_id; B.next_slot = A.next_slot; B.n_free = A.n_free; B.n_trk = A.n_trk; B.err = A.err;
+    B.cur = 0; B.skip = 1;
+  }
+}
+}  // namespace
+int mot_sort_move_stream(mot_sort_batch* src, int s, mot_sort_batch* dst, int s2) {
+  if (!src || !dst || s < 0 || s >= src->S || s2 < 0 || s2 >= dst->S || dst->CAP < src->CAP || dst->D < src->D) return MOT_ERR_INVALID;
+  MOT_LC_HIP(src, hipStreamSynchronize(src->ctx->stream));
+  hipStream_t st = dst->ctx->stream;
+  hipLaunchKernelGGL(sort_move, dim3(1), dim3(256), 0, st, src->d_streams + s, dst->d_streams + s2, src->mean + static_cast<size_t>(s) * 56 * src->CAP,
+                     dst->mean + static_cast<size_t>(s2) * 56 * dst->CAP, src->CAP);
+  MOT_LC_HIP(dst, hipGetLastError());
+  SortStream h;
+  MOT_LC_HIP(dst, hipMemcpyAsync(&h, dst->d_streams + s2, sizeof(SortStream), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(dst, hipStreamSynchronize(st));
+  if (h.n_trk > dst->bound_n) dst->bound_n = h.n_trk;
   return MOT_OK;
 }
 int mot_sort_step_packed(mot_sort_batch* b, const float* d_dets, const int* h_counts, float* rows, int rows_cap, int* out_counts, int* total_rows) {

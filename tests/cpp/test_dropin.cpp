@@ -8,6 +8,8 @@
 #include <memory>
 #include <set>
 #include <stdexcept>
+#include <thread>
+#include <vector>
 
 #include <motcpp/motcpp.hpp>
 
@@ -345,6 +347,49 @@ int main() {
     const Eigen::MatrixXf fi = U::fuse_iou(reid, a, b);
     CHECK(fi(0, 0) == 0.25f && fi(1, 1) == 0.25f);  // iou 1: 1 - 0.75 * (1 + 1) / 2
     CHECK(fi(0, 2) == 1.0f - 0.75f * 0.5f);         // iou 0: 1 - 0.75 * (1 + 0) / 2
+  }
+  {  // The reference's threading model (include/motcpp/tracker.hpp:67-69, docs/guides/architecture.md:242-255): one tracker object per
+     // camera, each updated from its own thread. Here the objects are streams of a shared device batch and concurrent update() calls run
+     // as one launch sequence: every object's tables must be bit-identical to the same object's run on one thread.
+    const int T = 16, F = 24;
+    auto frame_of = [&](int t, int f) {  // a small moving crowd per camera, deterministic
+      const int n = 12 + (t * 7 + f * 3) % 9;
+      Eigen::MatrixXf d((f % 10 == 6) ? 0 : n, 6);
+      for (int i = 0; i < d.rows(); ++i) {
+        const float x = 40.f + 55.f * i + 2.5f * f + 3.f * t, y = 60.f + 17.f * ((i * 5 + t) % 11) + 1.5f * f;
+        d(i, 0) = x; d(i, 1) = y; d(i, 2) = x + 38.f + (i % 3); d(i, 3) = y + 90.f + (i % 4);
+        d(i, 4) = ((i + f + t) % 7 == 0) ? 0.3f : 0.55f + 0.04f * ((i + t) % 10); d(i, 5) = static_cast<float>(i % 2);
+      }
+      return d;
+    };
+    auto run_one = [&](motcpp::BaseTracker& trk, int t, std::vector<Eigen::MatrixXf>* out) {
+      for (int f = 0; f < F; ++f) out->push_back(trk.update(frame_of(t, f), img));
+    };
+    auto same = [](const Eigen::MatrixXf& a, const Eigen::MatrixXf& b) {
+      if (a.rows() != b.rows() || a.cols() != b.cols()) return false;
+      for (Eigen::Index i = 0; i < a.rows(); ++i) for (Eigen::Index k = 0; k < a.cols(); ++k) if (a(i, k) != b(i, k)) return false;
+      return true;
+    };
+    for (int kind = 0; kind < 3; ++kind) {
+      auto make = [&]() -> std::unique_ptr<motcpp::BaseTracker> {
+        if (kind == 0) return std::make_unique<ByteTrack>();
+        if (kind == 1) return std::make_unique<Sort>(0.3f, 3, 50, 2);
+        return std::make_unique<OCSort>();
+      };
+      std::vector<std::vector<Eigen::MatrixXf>> alone(T), together(T);
+      for (int t = 0; t < T; ++t) { auto trk = make(); run_one(*trk, t, &alone[t]); }
+      std::vector<std::unique_ptr<motcpp::BaseTracker>> trk(T);
+      for (int t = 0; t < T; ++t) trk[t] = make();
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; ++t) th.emplace_back([&, t] { run_one(*trk[t], t, &together[t]); });
+      for (auto& x : th) x.join();
+      long rows = 0;
+      for (int t = 0; t < T; ++t) {
+        CHECK(together[t].size() == alone[t].size());
+        for (size_t f = 0; f < alone[t].size() && f < together[t].size(); ++f) { CHECK(same(alone[t][f], together[t][f])); rows += alone[t][f].rows(); }
+      }
+      CHECK(rows > 0);
+    }
   }
   std::printf(g_fail ? "%d check(s) failed\n" : "drop-in ok\n", g_fail);
   return g_fail ? 1 : 0;

@@ -17,7 +17,7 @@ def build():
     src = os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp")
     if not os.path.exists(BIN) or os.path.getmtime(src) > os.path.getmtime(BIN) or os.path.getmtime(_lib.HOST_LIB) > os.path.getmtime(BIN):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), src, "-o", BIN,
-                               "-L", _lib.LIBDIR, "-lmotcpp", "-lmotcpp_hip", "-Wl,-rpath," + _lib.LIBDIR])
+                               "-L", _lib.LIBDIR, "-lmotcpp", "-lmotcpp_hip", "-pthread", "-Wl,-rpath," + _lib.LIBDIR])
     return BIN
 
 

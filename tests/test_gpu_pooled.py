@@ -1,0 +1,205 @@
+"""GPU parity tests of the POOLED trackers (round 4, csrc/host/pool.cpp): every tracker object is a stream of a shared
+device-lifecycle batch and update() calls that arrive together from different host threads are merged into one launch
+sequence. Checked against the CPU oracle per object: output tables bit for bit, ids / Kalman states of the live tracks, with
+1, 8 and 48 objects on as many host threads (the reference's threading model: one tracker per camera thread,
+include/motcpp/tracker.hpp:67-69), objects that join and leave while others run, reset() of one object, objects that outgrow
+their capacity level (mot_*_move_stream) and BoT-SORT's per-object embeddings and camera-motion warps inside a shared round."""
+import threading
+
+import numpy as np
+import pytest
+
+from motcpp_amd import _lib as L
+from motcpp_amd.synth import SynthStream
+from tests import orclib
+
+pytestmark = pytest.mark.gpu
+
+ORC_LOCK = threading.Lock()  # the oracle is called from one thread at a time (it is the checker, not the thing under test)
+
+KINDS = [("sort", orclib.SORT, True), ("bytetrack", orclib.BYTETRACK, True), ("ocsort", orclib.OCSORT, False), ("botsort", orclib.BOTSORT, True)]
+
+
+def compare(f, og, oo, tg, to, exact):
+    assert og.shape == oo.shape, (f, og.shape, oo.shape)
+    assert np.array_equal(og[:, 4:], oo[:, 4:]), f  # id, conf, cls, det_ind
+    if exact:
+        assert np.array_equal(og, oo), f
+    else:  # OC-SORT's direction cost goes through acos: 1e-4
+        assert np.allclose(og[:, :4], oo[:, :4], rtol=1e-4, atol=1e-3), f
+    sg, so = tg.dump_states(), to.dump_states()
+    assert sg.shape == so.shape, (f, sg.shape, so.shape)
+    if sg.size:
+        assert np.array_equal(sg[:, 0], so[:, 0]), f
+        if exact:
+            assert np.array_equal(sg, so), (f, np.abs(sg - so).max())
+        else:
+            assert np.allclose(sg, so, rtol=1e-4, atol=1e-4), f
+
+
+@pytest.mark.parametrize("name,okind,exact", KINDS)
+def test_one_pooled_object_matches_the_oracle(name, okind, exact):
+    orc = orclib.load()
+    emb = 32 if name == "botsort" else 0
+    tg, to = L.Tracker(name, pooled=True), orc.tracker(okind)
+    s = SynthStream(90, 50, 77, emb)
+    for f in range(40):
+        d, e = s.next_frame()
+        if f % 11 == 7:
+            d = d[:0]
+            e = e[:0] if e is not None else None
+        if f == 25:  # reset() of a pooled object: its stream starts over (SORT keeps counting ids, sort.cpp:97-100)
+            tg.reset()
+            to.reset()
+        compare(f, tg.update(d, e), to.update(d, e), tg, to, exact)
+    if name == "botsort":
+        fg, fo = tg.dump_features(), to.dump_features()
+        assert fg.shape == fo.shape and np.array_equal(fg, fo)
+
+
+def _run_threads(name, okind, exact, T, frames, P, M, emb=0, stagger=False):
+    """T objects on T threads, each against its own oracle; returns the exceptions the threads hit"""
+    orc = orclib.load()
+    errors = []
+    start = threading.Barrier(T)
+
+    def body(t):
+        try:
+            with ORC_LOCK:
+                tg, to = L.Tracker(name, pooled=True), orc.tracker(okind)
+            s = SynthStream(P + 3 * t, M + t % 5, 1000 + t, emb)
+            start.wait()
+            n = frames - (t % 4) * 3 if stagger else frames  # some objects leave early: their streams sit later rounds out
+            for f in range(n):
+                d, e = s.next_frame()
+                if (f + t) % 13 == 5:
+                    d = d[:0]
+                    e = e[:0] if e is not None else None
+                og = tg.update(d, e)
+                with ORC_LOCK:
+                    oo = to.update(d, e)
+                if f % 6 == 5 or f == n - 1:
+                    with ORC_LOCK:
+                        compare((t, f), og, oo, tg, to, exact)
+                else:
+                    assert og.shape == oo.shape and (np.array_equal(og, oo) if exact else np.array_equal(og[:, 4:], oo[:, 4:])), (t, f)
+            tg.close()
+        except BaseException as ex:  # noqa: BLE001
+            errors.append((t, repr(ex)))
+            try:
+                start.abort()
+            except Exception:
+                pass
+
+    th = [threading.Thread(target=body, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    return errors
+
+
+@pytest.mark.parametrize("name,okind,exact", KINDS)
+def test_objects_on_threads_share_rounds(name, okind, exact):
+    L.pool_stats(reset=True)
+    errors = _run_threads(name, okind, exact, T=8, frames=30, P=70, M=40, emb=16 if name == "botsort" else 0, stagger=True)
+    assert not errors, errors[:3]
+    st = L.pool_stats()
+    assert st["frames"] >= 8 * 21 and st["rounds"] < st["frames"], st  # calls really were merged
+    assert st["max_round"] >= 2, st
+
+
+def test_many_bytetrack_objects_on_threads():
+    L.pool_stats(reset=True)
+    errors = _run_threads("bytetrack", orclib.BYTETRACK, True, T=48, frames=24, P=120, M=70)
+    assert not errors, errors[:3]
+    st = L.pool_stats()
+    assert st["max_round"] >= 2 and st["rounds"] < st["frames"], st  # (the oracle calls serialise the Python threads: few overlap)
+
+
+def test_an_object_outgrows_its_level():
+    """starts with a handful of detections (level 0: 512 tracks x 256 detections), then the scene fills up: the stream moves to level 1
+    before the frame that could overflow it, ids and states carried over"""
+    orc = orclib.load()
+    for name, okind, exact in KINDS[:3]:
+        L.pool_stats(reset=True)
+        tg, to = L.Tracker(name, pooled=True), orc.tracker(okind)
+        small, big = SynthStream(30, 20, 5), SynthStream(420, 300, 6)
+        for f in range(36):
+            d, _ = (small if f < 12 else big).next_frame()
+            compare((name, f), tg.update(d), to.update(d), tg, to, exact)
+            if f == 11:
+                assert tg.pool_level() == 0
+        assert tg.pool_level() == 1, tg.pool_level()
+        assert L.pool_stats()["moves"] == 1
+
+
+def test_a_freed_slot_starts_fresh():
+    orc = orclib.load()
+    a = L.Tracker("bytetrack", pooled=True)
+    s = SynthStream(60, 40, 9)
+    for _ in range(8):
+        a.update(s.next_frame()[0])
+    a.close()
+    b, to = L.Tracker("bytetrack", pooled=True), orc.tracker(orclib.BYTETRACK)  # takes the slot a gave back
+    s = SynthStream(60, 40, 10)
+    for f in range(10):
+        d, _ = s.next_frame()
+        compare(f, b.update(d), to.update(d), b, to, True)
+
+
+def test_botsort_objects_with_their_own_warps_and_embeddings():
+    """two BoT-SORT objects in one round: one with a camera-motion warp per frame, the other without; one frame without embeddings"""
+    orc = orclib.load()
+    T = 2
+    errors = []
+    start = threading.Barrier(T)
+
+    def body(t):
+        try:
+            with ORC_LOCK:
+                tg, to = L.Tracker("botsort", pooled=True), orc.tracker(orclib.BOTSORT)
+            s = SynthStream(80, 45, 300 + t, 24)
+            start.wait()
+            for f in range(25):
+                d, e = s.next_frame()
+                if t == 0 and f >= 2:
+                    w = np.array([[1.0, 0.002 * (f % 3), 1.5 - f % 4], [-0.001, 1.0, 0.5 * (f % 5)]], np.float32)
+                    tg.set_camera_motion(w)
+                    with ORC_LOCK:
+                        to.set_camera_motion(w)
+                og = tg.update(d, e)
+                with ORC_LOCK:
+                    compare((t, f), og, to.update(d, e), tg, to, True)
+        except BaseException as ex:  # noqa: BLE001
+            errors.append((t, repr(ex)))
+            try:
+                start.abort()
+            except Exception:
+                pass
+
+    th = [threading.Thread(target=body, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+
+
+def test_bench_threads_checksums_do_not_depend_on_the_thread_count():
+    """motcpp_bench_threads drives the public C++ classes (trackers::ByteTrack::update on Eigen matrices): the per-object id
+    checksums with 12 threads equal those of the same objects run one at a time"""
+    T, F = 12, 20
+    dets = np.zeros((T, F, 64, 6), np.float32)
+    counts = np.zeros((T, F), np.int32)
+    for t in range(T):
+        s = SynthStream(70, 40 + t, 40 + t)
+        for f in range(F):
+            d, _ = s.next_frame()
+            dets[t, f, :len(d)] = d
+            counts[t, f] = len(d)
+    res, cs = L.bench_threads("bytetrack", dets, counts, warm=0)
+    assert res["frames"] == T * F and res["rows"] > 0
+    for t in range(T):
+        _, one = L.bench_threads("bytetrack", dets[t:t + 1], counts[t:t + 1], warm=0)
+        assert one[0] == cs[t], (t, one[0], cs[t])

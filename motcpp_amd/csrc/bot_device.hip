@@ -699,7 +699,7 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
 static void bot_set_hints(mot_bot_batch* b, const int* maxt) {  // next frame's LDS hints: this frame's largest problems, a quarter more
   int m1 = 0, m2 = 0, m3 = 0;
   for (int i = 0; i < 64; ++i) { m1 = (maxt[64 + i] > m1) ? maxt[64 + i] : m1; m2 = (maxt[128 + i] > m2) ? maxt[128 + i] : m2; m3 = (maxt[192 + i] > m3) ? maxt[192 + i] : m3; }
-  b->hint1_n = m1 > 0 ? m1 + m1 / 4 + 64 : 0;
+  b->hint1_n = m1 > 0 ? m1 + m1 / 8 + 48 : 0;
   b->hint23_n = m2 > 0 ? m2 + m2 / 4 + 32 : 0;
   b->hint23_m = m3 > 0 ? m3 + m3 / 4 + 32 : 0;
 }

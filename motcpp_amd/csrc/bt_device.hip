@@ -864,7 +864,7 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
 static void bt_set_hints(mot_bt_batch* b, const int* maxt) {
   int m1 = 0, m2 = 0, m3 = 0;
   for (int i = 0; i < 64; ++i) { m1 = (maxt[64 + i] > m1) ? maxt[64 + i] : m1; m2 = (maxt[128 + i] > m2) ? maxt[128 + i] : m2; m3 = (maxt[192 + i] > m3) ? maxt[192 + i] : m3; }
-  b->hint1_n = m1 > 0 ? m1 + m1 / 4 + 64 : 0;
+  b->hint1_n = m1 > 0 ? m1 + m1 / 8 + 48 : 0;
   b->hint23_n = m2 > 0 ? m2 + m2 / 4 + 32 : 0;
   b->hint23_m = m3 > 0 ? m3 + m3 / 4 + 32 : 0;
 }

@@ -90,7 +90,7 @@ MOT_HD size_t sparse_hot_bytes(int nr, int nc, int ecap) {
   return static_cast<size_t>(nr) * 16 + sparse_vy_bytes(nc) + ((static_cast<size_t>(nr) * 2 + 15) & ~size_t(15)) + 4 * (static_cast<size_t>(nc) + 4) +
          ((static_cast<size_t>(ecap) * 2 + 15) & ~size_t(15)) + static_cast<size_t>(ecap) * 4 + 16 + 64;
 }
-MOT_HD int sparse_default_ecap(int nc) { return 4 * nc + 64; }   // in LDS
+MOT_HD int sparse_default_ecap(int nc) { return 3 * nc + 64; }   // in LDS (round 3: 4 * nc + 64 — three more kilobytes per north-star problem)
 MOT_HD int sparse_global_ecap(int nc) { return 8 * nc + 64; }    // hot state in global scratch: room is not the issue
 MOT_HD size_t sparse_cold_bytes(int nr, int nc) {
   return static_cast<size_t>(nc) * (8 * kSpK + 4) + static_cast<size_t>(sparse_arc_cap(nr, nc)) * 8 + 64;
@@ -201,9 +201,11 @@ MOT_DEV bool sp_finite4(const float b[4]) {
 // A lane sweeps the candidate rows of one of its columns with box tests only, queueing the positions that intersect (LDS,
 // kSpQ per lane), then evaluates the queued pairs back to back — the expensive arithmetic runs with every lane busy instead
 // of under a one-in-seven branch — and writes the viable ones straight into a CSR segment it reserved for the queue's length.
-constexpr int kSpRC = 20;  // rows per lane whose x1 / gather index stay in registers across the three bucketing passes
+constexpr int kSpRC = 20;  // rows per lane whose x1 / gather index stay in registers across the three bucketing passes (default of the
+                           // RC template parameter below; the four-wavefront kernel passes 6: its rows are shared by 256 lanes, and the 100
+                           // registers of the default were what limited it to four wavefronts per SIMD)
 struct SpNoMinIou { MOT_DEV float operator()(float) const { return 0.0f; } };
-template <class G, class W, class EvalFn, class ZeroFn, class MinIouFn = SpNoMinIou>
+template <int RC = kSpRC, class G, class W, class EvalFn, class ZeroFn, class MinIouFn = SpNoMinIou>
 MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, const SparseBoxes& A, const SparseBoxes& Bx,
                                           const float* bconf, const int* bidx, float thresh, EvalFn eval, ZeroFn zero_cost,
                                           MinIouFn min_iou_of = MinIouFn()) {
@@ -217,17 +219,17 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
   // bits: 1 tie with the threshold, 2 column list full, 4 NaN / inf / out of range, 8 viable pairs that do not intersect, 16 CSR full
   int bad = (nr > 65535 || T > kSpMaxThreads) ? 4 : 0;
   // ---- rows into x1 buckets ----
-  const bool cached = nr <= T * kSpRC;
-  float rx1[kSpRC];
-  int rgi[kSpRC];
+  const bool cached = nr <= T * RC;
+  float rx1[RC];
+  int rgi[RC];
   float xlo = 3.0e38f, xhi = -3.0e38f;
   if (cached) {
 #pragma unroll
-    for (int u = 0; u < kSpRC; ++u) { const int i = t + u * T; rgi[u] = (i < nr) ? A.gather(i) : 0; }
+    for (int u = 0; u < RC; ++u) { const int i = t + u * T; rgi[u] = (i < nr) ? A.gather(i) : 0; }
 #pragma unroll
-    for (int u = 0; u < kSpRC; ++u) { const int i = t + u * T; rx1[u] = (i < nr) ? gld(A.p, static_cast<size_t>(rgi[u])) : 0.0f; }
+    for (int u = 0; u < RC; ++u) { const int i = t + u * T; rx1[u] = (i < nr) ? gld(A.p, static_cast<size_t>(rgi[u])) : 0.0f; }
 #pragma unroll
-    for (int u = 0; u < kSpRC; ++u) {
+    for (int u = 0; u < RC; ++u) {
       const int i = t + u * T;
       if (i < nr) {
         const float a0 = rx1[u];
@@ -263,7 +265,7 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
   g.sync();
   if (cached) {
 #pragma unroll
-    for (int u = 0; u < kSpRC; ++u)
+    for (int u = 0; u < RC; ++u)
       if (t + u * T < nr) G::atomic_add(w.bstart.raw(bucket(rx1[u]) + 1), 1);
   } else {
 #pragma unroll 4
@@ -293,16 +295,16 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
     G::atomic_max(w.bmax.raw(b), f32_key(a[2]));
   };
   if (cached) {
-    float r1[kSpRC], r2[kSpRC], r3[kSpRC];
+    float r1[RC], r2[RC], r3[RC];
 #pragma unroll
-    for (int u = 0; u < kSpRC; ++u) {
+    for (int u = 0; u < RC; ++u) {
       const bool in = t + u * T < nr;
       r1[u] = in ? gld(A.p, static_cast<size_t>(A.ld) + rgi[u]) : 0.0f;
       r2[u] = in ? gld(A.p, static_cast<size_t>(2) * A.ld + rgi[u]) : 0.0f;
       r3[u] = in ? gld(A.p, static_cast<size_t>(3) * A.ld + rgi[u]) : 0.0f;
     }
 #pragma unroll
-    for (int u = 0; u < kSpRC; ++u)
+    for (int u = 0; u < RC; ++u)
       if (t + u * T < nr) { const float a[4] = {rx1[u], r1[u], r2[u], r3[u]}; place(t + u * T, a); }
   } else {
 #pragma unroll 2
@@ -534,6 +536,7 @@ MOT_DEV int sparse_init(G& g, const W& w, int nr, int nc, float thresh) {
   g.sync();
   for (int i = t; i < nr; i += T)
     if (static_cast<int>(w.x[i]) == kSpIntMax) w.x[i] = -1;
+  if (t == 0) { w.ctr[1] = 0; w.ctr[3] = 1; }  // retry list of the concurrent searches, their common outcome
   g.sync();
 
   return nfree;
@@ -545,16 +548,27 @@ MOT_DEV int sparse_init(G& g, const W& w, int nr, int nc, float thresh) {
 // its current column, state — so that picking the nearest one is a register reduction and relaxing a column costs three
 // LDS round trips (the column's list entry and dual; its pairs; their rows' duals and slots); labels travel between lanes
 // by broadcast. Needs at least kSpSlots lanes.
-template <class G, class W>
-MOT_DEV int sparse_search(G& g, const W& w, int nfree, float thresh, int* scans = nullptr, long long* seg = nullptr) {
+//
+// SHARED (round 4): several wavefronts of one workgroup search at the same time, wavefront `first` of `stride` taking the free columns
+// first, first + stride, ... Two searches that reach disjoint rows do not see each other at all (a search reads and writes the duals
+// and assignments of the rows it has reached, of their columns and of its own start column only), and on tracking problems they nearly
+// always are disjoint: a detection is viable for a handful of tracks. A row is therefore CLAIMED (compare-and-swap on its slot word,
+// tagged with the wavefront) before anything of it is read; a search that meets a row claimed by another wavefront gives every row
+// back untouched — nothing is modified before a search has finished — and leaves its column on the retry list (w.arcs, counted in
+// w.ctr[1]), which one wavefront works off alone afterwards. Whatever the interleaving, the result is checked like any other: the
+// certificate tests optimality and uniqueness of the final matching and duals, not how they were found.
+template <bool SHARED, class G, class W>
+MOT_DEV int sparse_search_impl(G& g, const W& w, int nfree, float thresh, int first, int stride, bool from_retry, int* scans, long long* seg) {
   const int T = g.size(), t = g.tid();
   const double th = static_cast<double>(thresh);
   int n_scan = 0;
   if (T < kSpSlots + 1) return (nfree > 0) ? -2 : 1;
-  int j_next = (nfree > 0) ? static_cast<int>(w.freel[0]) : 0;
-  for (int f = 0; f < nfree; ++f) {
+  const int tag = SHARED ? ((first + 1) << 8) : 0;
+  auto column_at = [&](int f) { return from_retry ? static_cast<int>(w.arcs[f]) : static_cast<int>(w.freel[f]); };
+  int j_next = (first < nfree) ? column_at(first) : 0;
+  for (int f = first; f < nfree; f += stride) {
     const int j0 = j_next;
-    if (f + 1 < nfree) j_next = w.freel[f + 1];  // (global memory: fetched one search ahead)
+    if (f + stride < nfree) j_next = column_at(f + stride);  // (global memory: fetched one search ahead)
     double L = -static_cast<double>(w.v[j0]);  // leave j0 unmatched
     int term_slot = -1, term_col = j0;          // terminal: the slot of a free row, or the column that ends unmatched
     int cur = j0;
@@ -563,7 +577,7 @@ MOT_DEV int sparse_search(G& g, const W& w, int nfree, float thresh, int* scans 
     // this lane's slot
     int my_row = -1, my_pred = -1, my_x = -1, my_state = 0;  // state: 0 empty, 1 reached, 2 scanned
     double my_dist = 0.0;
-    bool overflow = false;
+    bool overflow = false, conflict = false;
     for (;;) {
       ++n_scan;
       const long long q0 = MOT_CLOCK();
@@ -572,18 +586,35 @@ MOT_DEV int sparse_search(G& g, const W& w, int nfree, float thresh, int* scans 
       const int ee = w.eoff[cur], e0 = sp_e0(ee), deg = sp_deg(ee);
       int er = -1, es = 0, ex = -1;
       double nd = 0.0;
+      bool mine_new = false, clash = false;
       if (t < deg) {
         er = w.erow[e0 + t];
+        if constexpr (SHARED) {  // the row is claimed before anything of it is read
+          const int old = w.slot.atomic_cas(er, 0, tag | 0xff);
+          if (old == 0) mine_new = true;
+          else if ((old & ~0xff) == tag) es = old & 0xff;
+          else clash = true;
+        }
+      }
+      if constexpr (SHARED) {
+        if (g.ballot(clash) != 0ull) {  // somebody else's row: everything goes back as it was
+          if (mine_new) w.slot[er] = 0;
+          conflict = true;
+          break;
+        }
+        g.sync();  // (acquire: the previous owner's writes to a row just claimed are visible)
+      }
+      if (t < deg) {
         const double red = (static_cast<double>(static_cast<float>(w.ecost[e0 + t])) - th) - static_cast<double>(w.u[er]) - vc;
         nd = D + red;
-        es = w.slot[er];
+        if constexpr (!SHARED) es = w.slot[er];
         ex = w.x[er];
       }
-      const bool need = t < deg && es == 0;
+      const bool need = SHARED ? mine_new : (t < deg && es == 0);
       int tot;
       const int pos = g.flag_rank(need, &tot);
-      if (nslots + tot > kSpSlots) { overflow = true; break; }
-      if (need) w.slot[er] = nslots + pos + 1;
+      if (nslots + tot > kSpSlots) { overflow = true; if (SHARED && mine_new) w.slot[er] = 0; break; }
+      if (need) w.slot[er] = tag | (nslots + pos + 1);
       const long long q1 = MOT_CLOCK();
       // labels to their slots: a pair whose row already has one improves it; the others open slots nslots, nslots + 1, ...
       // (each pair lane pushes its label to the lane that owns the slot: distinct rows, distinct destinations)
@@ -620,7 +651,13 @@ MOT_DEV int sparse_search(G& g, const W& w, int nfree, float thresh, int* scans 
       const double cand = D - static_cast<double>(w.v[cur]);
       if (cand < L) { L = cand; term_slot = -1; term_col = cur; }
     }
-    if (overflow) return -2;
+    if (overflow || conflict) {  // nothing has been modified yet: the rows go back
+      if (my_state != 0) w.slot[my_row] = 0;
+      g.sync();
+      if (overflow) return -2;
+      if (t == 0) { const int rp = w.ctr.atomic_add(1, 1); w.arcs[rp] = j0; }
+      continue;
+    }
     const long long q4 = MOT_CLOCK();
     // duals: scanned rows and their columns move by (L - label); the source by L
     if (my_state == 2) {
@@ -638,7 +675,7 @@ MOT_DEV int sparse_search(G& g, const W& w, int nfree, float thresh, int* scans 
         const int r = w.y[term_col];
         g.sync();
         if (t == 0) w.y[term_col] = -1;
-        q = static_cast<int>(w.slot[r]) - 1;
+        q = (static_cast<int>(w.slot[r]) & 0xff) - 1;
       }
       while (q >= 0) {
         const int r = g.bcast_i32(my_row, q), p = g.bcast_i32(my_pred, q);
@@ -646,16 +683,20 @@ MOT_DEV int sparse_search(G& g, const W& w, int nfree, float thresh, int* scans 
         g.sync();
         if (t == 0) { w.y[p] = r; w.x[r] = p; }
         if (p == j0) break;
-        q = static_cast<int>(w.slot[rn]) - 1;
+        q = (static_cast<int>(w.slot[rn]) & 0xff) - 1;
       }
     }
-    g.sync();
+    g.sync();  // (release: the duals and assignments are written before the rows are given back)
     if (my_state != 0) w.slot[my_row] = 0;
     g.sync();
     if (seg) seg[3] += MOT_CLOCK() - q4;
   }
   if (scans) *scans = n_scan;
   return 1;
+}
+template <class G, class W>
+MOT_DEV int sparse_search(G& g, const W& w, int nfree, float thresh, int* scans = nullptr, long long* seg = nullptr) {
+  return sparse_search_impl<false>(g, w, nfree, thresh, 0, 1, false, scans, seg);
 }
 
 // 4. certificate: 1 when w.x / w.y is the unique optimum by more than kSpEps, else -3 / -4 / -5

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task
         if (!(need > 1.0e-3f)) return 0.0f;
         return (need < 1.0f) ? 0.99f * need : 0.99f;
       };
-      e = mot::sparse_enumerate_boxes(g, w, nr, nc, mot::SparseBoxes{G.a, G.lda, G.aidx}, mot::SparseBoxes{G.b, G.ldb, G.bidx},
+      e = mot::sparse_enumerate_boxes<(kThreads == 256) ? 6 : mot::kSpRC>(g, w, nr, nc, mot::SparseBoxes{G.a, G.lda, G.aidx}, mot::SparseBoxes{G.b, G.ldb, G.bidx},
                                       G.bconf, G.bidx, T.thresh, eval, zc, min_iou);
     } else {
       e = mot::sparse_enumerate_matrix(g, w, nr, nc, T.cost, T.ldc, T.thresh);
@@ -146,20 +146,30 @@ __global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task
       else {
         const int nfree = mot::sparse_init(g, w, nr, nc, T.thresh);
         const long long ck2 = MOT_CLOCK();
-        if (t < 64) {
+        // the path searches: every wavefront takes every fourth free column (lap_sparse.hpp, SHARED); the few that ran into each other's
+        // rows are then redone by the first wavefront alone
+        static_assert(kThreads == 256, "one search per wavefront");
+        {
           mot::DevWave gw;
           int scans = 0;
           long long seg[4] = {0, 0, 0, 0};
-          const int rs = mot::sparse_search(gw, w, nfree, T.thresh, &scans, seg);
+          const int rs = mot::sparse_search_impl<true>(gw, w, nfree, T.thresh, t >> 6, kThreads / 64, false, &scans, seg);
+          if (rs != 1 && (t & 63) == 0) w.ctr.atomic_min(3, rs);
           if (t == 0) {
-            w.ctr[3] = rs;
-            unsigned long long* h = hist_set();  // where the searches spend their cycles
+            unsigned long long* h = hist_set();  // where the searches spend their cycles (first wavefront)
             atomicAdd(h + 24, static_cast<unsigned long long>(seg[0])); atomicAdd(h + 25, static_cast<unsigned long long>(seg[1]));
             atomicAdd(h + 26, static_cast<unsigned long long>(seg[2])); atomicAdd(h + 27, static_cast<unsigned long long>(seg[3]));
           }
           pf.n_scan = scans;
         }
         g.sync();
+        const int nretry = w.ctr[1];
+        if (nretry > 0 && static_cast<int>(w.ctr[3]) == 1 && t < 64) {
+          mot::DevWave gw;
+          const int rs = mot::sparse_search_impl<false>(gw, w, nretry, T.thresh, 0, 1, true, nullptr, nullptr);
+          if (t == 0) { w.ctr[3] = rs; atomicAdd(hist_set() + 28, static_cast<unsigned long long>(nretry)); }
+        }
+        if (nretry > 0) g.sync();
         const long long ck3 = MOT_CLOCK();
         r = w.ctr[3];
         g.sync();
@@ -228,6 +238,19 @@ hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, i
     hot = kScratch + sparse_hot_bytes(n, m, ecap);
   }
   const bool lds = ecap >= 3 * m + 16;
+  // LDS per problem decides how many problems a CU holds (160 KB: 5 at 32 KB, 4 at 40 KB, 3 at 53 KB): the pair list takes what is left of
+  // the step the launch lands on anyway — a problem whose list overflows goes to the exact solver, milliseconds instead of microseconds
+  if (lds) {
+    static const size_t steps[] = {160 * 1024 / 6, 160 * 1024 / 5, 160 * 1024 / 4, 160 * 1024 / 3, kBudget};
+    for (size_t lim : steps) {
+      const size_t cap = (lim < kBudget ? lim : kBudget) & ~size_t(63);
+      if (hot <= cap) {
+        const int more = static_cast<int>((cap - hot) / 6) - 4;  // (6 bytes per entry; the two arrays round up to 16 bytes each)
+        if (more > 0) { ecap += more; hot = kScratch + sparse_hot_bytes(n, m, ecap); }
+        break;
+      }
+    }
+  }
   // four wavefronts per problem once there is enough to enumerate (the pairs are listed four times faster; the hot state's
   // LDS, which bounds the problems resident per CU, is the same)
   const bool wide = lds && (static_cast<long>(n) * m >= 64 * 1024);

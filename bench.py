@@ -73,6 +73,16 @@ def launch_ranks(n):
     os.execvpe(cmd[0], cmd, env)
 
 
+def gather_rank_rates(dist, torch, rate, streams, device):
+    """every rank's own rate (frames of ITS streams / ITS wall time of the timed region) on every rank: one all-reduce of a vector with
+    one slot per rank, over the job's process group (RCCL on the GPU boxes) — what the line reports as `per_rank`"""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    tr = torch.zeros(world, dtype=torch.float64, device=device)
+    tr[rank] = rate
+    dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+    return {"frames/s": [float(x) for x in tr.tolist()], "ranks": world, "backend": dist.get_backend(), "streams_per_rank": streams}
+
+
 def launch_probe(real_stdout):
     """MOT_BENCH_LAUNCH_PROBE=1 (tests/test_bench_contract.py): the ranks only prove that they exist — a gloo rendezvous, every rank's
     pid and LOCAL_RANK gathered, rank 0 prints them as the JSON line. No GPU is touched: this is how the launcher is tested here."""
@@ -81,8 +91,10 @@ def launch_probe(real_stdout):
     me = {"rank": dist.get_rank(), "local_rank": int(os.environ.get("LOCAL_RANK", "-1")), "pid": os.getpid()}
     box = [None] * dist.get_world_size()
     dist.all_gather_object(box, me)
+    import torch
+    per_rank = gather_rank_rates(dist, torch, 1000.0 * (dist.get_rank() + 1), 1, "cpu")  # (the same exchange the real run makes, on gloo)
     if dist.get_rank() == 0:
-        os.write(real_stdout, (json.dumps({"probe": True, "world": dist.get_world_size(), "ranks": box}) + "\n").encode())
+        os.write(real_stdout, (json.dumps({"probe": True, "world": dist.get_world_size(), "ranks": box, "per_rank": per_rank}) + "\n").encode())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -621,7 +633,27 @@ def main():
             b2.close()
         sweep[str(S)] = {"frames/s": S * K / elapsed, "ms_per_step_median": elapsed / K * 1e3, "steps": K,
                          "note": "the timed region (sub-batches and frames in flight as configured)"}
-        # the literal BaseTracker::update of one tracker object (host stage machine over the same kernels): motcpp::trackers::* behind L.Tracker
+        # The reference's own surface (round 4): T tracker OBJECTS of the public C++ classes (motcpp::trackers::*), one host thread each,
+        # every thread calling BaseTracker::update(dets, img) on host detections (motcpp_bench_threads, csrc/host/bench_threads.cpp).
+        # The objects are streams of shared device batches; calls that arrive together run as one launch sequence (csrc/host/pool.cpp).
+        if tracker in ("bytetrack", "sort", "ocsort") and not heavy:
+            bt_sweep = {}
+            try:
+                Fb = min(F, zs + 30)
+                for T in [t for t in (1, 16, 64, 256) if t <= S]:
+                    dd = np.ascontiguousarray(host[:Fb, :T].transpose(1, 0, 2, 3))
+                    L.pool_stats(reset=True)
+                    res, _cs = L.bench_threads(tracker, dd, np.full((T, Fb), M, np.int32), warm=zs, device=local)
+                    ps_ = L.pool_stats()
+                    bt_sweep[f"T{T}"] = {"frames/s": res["frames_per_s"], "ms_per_update_mean": res["latency_ms_mean"], "ms_per_update_max": res["latency_ms_max"],
+                                         "frames_timed": res["frames"], "launch_sequences": ps_["rounds"], "largest_round": ps_["max_round"]}
+                bt_sweep["note"] = ("T objects of motcpp::trackers::" + {"bytetrack": "ByteTrack", "sort": "Sort", "ocsort": "OCSort"}[tracker] + " on T host threads, "
+                                    "update(dets, img) with HOST detections (Eigen matrices; PCIe, the combiner's batching window and the copy of the result "
+                                    f"table included), {zs} untimed frames first; launch_sequences = rounds the combiner ran for all frames of the leg")
+            except Exception as e:  # (diagnostic leg: never loses the line)
+                bt_sweep["error"] = repr(e)
+            sweep["basetracker_update"] = bt_sweep
+        # the same call on ONE object whose lifecycle stays in a host stage machine (rounds 1-3; MOTCPP_LIFECYCLE=host), for comparison
         try:
             tk = L.Tracker(tracker, device=local)
             lat = []
@@ -632,15 +664,18 @@ def main():
                 if f >= zs:
                     lat.append(time.perf_counter() - ta)
             lat = np.array(lat) * 1e3
-            sweep["basetracker_update_S1"] = {"frames/s": len(lat) / (lat.sum() * 1e-3), "ms_per_update_median": float(np.median(lat)), "ms_per_update_max": float(lat.max()),
-                                              "steps": len(lat), "note": "one motcpp::BaseTracker object, update(dets, frame) per frame through the host library "
-                                              "(detections uploaded inside the call): the drop-in surface of include/motcpp/tracker.hpp"}
+            sweep["host_stage_machine_S1"] = {"frames/s": len(lat) / (lat.sum() * 1e-3), "ms_per_update_median": float(np.median(lat)), "ms_per_update_max": float(lat.max()),
+                                              "steps": len(lat), "note": "one tracker object with the host stage machine of rounds 1-3 (C handle motcpp_tracker_create), "
+                                              "update(dets) per frame, detections uploaded inside the call; the C++ classes use the pooled streams above"}
             tk.close()
         except Exception as e:  # (diagnostic leg: never loses the line)
-            sweep["basetracker_update_S1"] = {"error": repr(e)}
+            sweep["host_stage_machine_S1"] = {"error": repr(e)}
         sweep["note"] = ("synchronous steps of one batch of S streams (step = one frame of every stream; no sub-batches, one frame in flight), "
                          f"{zs} settling frames first; S = 1 is the latency of a single stream's frame on the device lifecycle")
+    per_rank = None
     if world > 1:
+        # every rank's own rate (frames of ITS streams / ITS wall time of the timed region), gathered over RCCL like everything else
+        per_rank = gather_rank_rates(dist, torch, S * K / elapsed, S, f"cuda:{local}")  # backend "nccl" = RCCL
         te = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -658,8 +693,14 @@ def main():
     # ONE protocol: the dominant KERNEL — summed HIP-event time of its own launches on the launching stream inside the timed region
     # (composite families — the whole frame, the sparse + exact launch pairs — are listed under `kernels` but do not compete);
     # its average is what rocprofv3 --kernel-trace --stats of the same command shows for that kernel (profiles/*_kernel_stats_*.csv)
+    # The dominant kernel of each workload is FIXED (chosen from the rocprofv3 kernel tables under profiles/, not from this run's event sums:
+    # round 3 reported embed_kernel in one C3 run and the assignment composite in another): NS / C2 / C5 lap_sparse_kernel of the first
+    # association, C3 embed_kernel<cosine> (bound: fp32 MFMA), C4 the exact lap_kernel of the first association, SORT its one assignment launch.
     composite = {"frame_all_kernels"} | ({"lap"} if "lap1_sparse" in stats else set())
-    fam = max((k for k in stats if k not in composite), key=lambda k: stats[k]["ms"])
+    fixed = {"NS": "lap1_sparse", "C2": "lap1_sparse", "C5": "lap1_sparse", "C3": "cosine", "C4": "lap", "SORT": "lap"}.get(args.workload)
+    fam = fixed if fixed in stats and stats[fixed]["launches"] else max((k for k in stats if k not in composite), key=lambda k: stats[k]["ms"])
+    if not stats[fam]["launches"]:
+        raise SystemExit(f"bench.py: the profiled kernel family {fam!r} reports 0 launches in the timed region (profiling events missing)")
     st = stats[fam]
     launches = max(st["launches"], 1)
     avg_ms = st["ms"] / launches
@@ -703,6 +744,21 @@ def main():
     roof["survey_8d_equivalent"] = {"bytes_per_frame": survey_bytes, "GB/s_per_gpu": value / world * survey_bytes / 1e9,
                                     "frac": value / world * survey_bytes / 1e9 / HBM_PEAK_GBS,
                                     "note": "whole-job frames/s x SURVEY 8(d) bytes per frame (cost matrix materialised); not a kernel measurement"}
+    # The fused pipeline's own byte model: what a frame HAS to move when no cost matrix is materialised —
+    # detections in (24 B each), box-only prediction of the pool (52 B per track), one Kalman record read + written per match (604 B),
+    # 24 B per row and column of every assignment (boxes + score in, x / y out), 312 B per birth, 32 B per output row.
+    if on_device and tracker == "bytetrack" and achieved_dims:
+        fa, sa = achieved_dims["first_association"], achieved_dims["second_and_unconfirmed"]
+        nfr = max(fa["problems"], 1)
+        kfs = {k: stats[k]["tasks"] / nfr for k in ("kf_predict_boxes", "kf_initiate", "kf_update") if k in stats}
+        lap_b = 24.0 * (fa["mean_tracks_N"] + fa["mean_dets_M"]) + 24.0 * (sa["mean_tracks_N"] + sa["mean_dets_M"]) * sa["problems"] / nfr
+        rows_out = float(np.mean(cnt_all)) if len(cnt_all) else 0.0
+        fb = 24.0 * M + 52.0 * kfs.get("kf_predict_boxes", 0.0) + 604.0 * kfs.get("kf_update", 0.0) + 312.0 * kfs.get("kf_initiate", 0.0) + lap_b + 32.0 * rows_out
+        roof["fused_frame_model"] = {"bytes_per_frame": fb, "GB/s_per_gpu": value / world * fb / 1e9, "frac": value / world * fb / 1e9 / HBM_PEAK_GBS,
+                                     "terms": {"detections": 24.0 * M, "predict_boxes": 52.0 * kfs.get("kf_predict_boxes", 0.0), "kalman_updates": 604.0 * kfs.get("kf_update", 0.0),
+                                               "kalman_initiations": 312.0 * kfs.get("kf_initiate", 0.0), "assignments": lap_b, "output_rows": 32.0 * rows_out},
+                                     "note": "whole-job frames/s x the bytes a frame of the fused pipeline must move (no N x M matrix exists); the path is "
+                                             "latency / issue-bound, not bandwidth-bound, and this fraction says by how much"}
     import glob
     sq_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sq_lap*.json")))  # newest round last (names carry the round)
     if fam in ("lap", "lap1_sparse") and sq_files:
@@ -795,6 +851,7 @@ def main():
                    "ranks": world, "rank_launcher": "torch.distributed.run (bench.py --gpus N starts it itself when no launcher set RANK)",
                    "table_gather": (args.gather + " (RCCL)") if world > 1 else args.gather,
                    "inputs": "detections (and embeddings) resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},
+        "per_rank": per_rank,
         "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         "kernels": kernels,
         "lap_fast_path": fast_stats,

@@ -43,3 +43,5 @@ def test_gpus_n_starts_n_ranks_itself():
     assert sorted(r["rank"] for r in d["ranks"]) == [0, 1]
     assert sorted(r["local_rank"] for r in d["ranks"]) == [0, 1]
     assert len({r["pid"] for r in d["ranks"]}) == 2  # two processes
+    # the per-rank rates of the real line travel the same way (one all-reduce over the job's process group): rank count and one rate per rank
+    assert d["per_rank"]["ranks"] == 2 and d["per_rank"]["frames/s"] == [1000.0, 2000.0] and d["per_rank"]["backend"] == "gloo"

@@ -22,6 +22,13 @@ out = {"_comment": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) o
                    f"4-byte accesses). Raw sums: {tag}_pmc_fetch_{wl}.json, {tag}_pmc_write_{wl}.json",
        "lap": {"fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb, "problems_per_launch": per_launch,
                "hbm_bytes_per_problem": (2.0 * fb + wb) / per_launch}}
+# the dominant kernel ALONE (bench.py's roofline family lap1_sparse: the first association's sparse solver, S problems per dispatch):
+# comparable with roofline.algorithmic_bytes_per_launch, which counts that launch only
+mdisp = fetch[main]["FETCH_SIZE"]["dispatches"]
+mfb = fetch[main]["FETCH_SIZE"]["sum"] * 1024.0 / mdisp
+mwb = (write[main]["WRITE_SIZE"]["sum"] * 1024.0 / write[main]["WRITE_SIZE"]["dispatches"]) if main in write else 0.0
+out["lap1_sparse"] = {"kernel": main, "fetch_bytes_per_launch_raw": mfb, "write_bytes_per_launch": mwb, "problems_per_launch": S,
+                      "hbm_bytes_per_problem": (2.0 * mfb + mwb) / S}
 json.dump(out, open(os.path.join(P, f"pmc_{wl}.json"), "w"), indent=1)
 c = {}
 for src in (sq1, sq2):

@@ -7,5 +7,6 @@
 #include "trackers/ocsort.hpp"
 #include "trackers/botsort.hpp"
 #include "trackers/deepocsort.hpp"
+#include "trackers/strongsort.hpp"
 #include "utils/matching.hpp"
 #include "utils/iou.hpp"

@@ -85,7 +85,9 @@ int mot_event_elapsed(mot_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /
 typedef enum mot_det_kind {
   MOT_DET_XYSR = 0, /* SORT / OC-SORT: box = raw xyxy, meas = xyxy2xysr                     */
   MOT_DET_XYAH = 1, /* ByteTrack: xywh -> tlwh -> xyah chain, box = xywh2xyxy(xywh)          */
-  MOT_DET_XYWH = 2  /* BoT-SORT: xywh = (x1+w/2, y1+h/2, w, h), box = (cx-w/2, ...)          */
+  MOT_DET_XYWH = 2, /* BoT-SORT: xywh = (x1+w/2, y1+h/2, w, h), box = (cx-w/2, ...)          */
+  MOT_DET_TLWH = 3  /* StrongSORT (strongsort.cpp:33-40, 948-956): box = tlwh (x1, y1, x2-x1, y2-y1), meas = Detection::to_xyah
+                       (x + w/2, y + h/2, w/h, h)                                                  */
 } mot_det_kind;
 
 typedef struct mot_det_task {
@@ -102,6 +104,7 @@ enum {
   MOT_KF_ZERO_V7 = 1,     /* predict: mean[7] = 0 first (ByteTrack, non-Tracked: bytetrack.cpp:108-110) */
   MOT_KF_OCSORT_CLAMP = 2,/* predict: if x6 + x2 <= 0 then x6 = 0 (ocsort.cpp:134-136)                  */
   MOT_KF_NO_STORE = 4,    /* predict: only the boxes are wanted, the predicted state is not written      */
+  MOT_KF_BOX_TLWH_SUM = 1, /* (value of mot_kf_task.reserved, not a flag bit) */
   MOT_KF_PREDICT_FIRST = 8/* update: predict the loaded state first (honouring MOT_KF_ZERO_V7), then update: with NO_STORE
                              predictions this replaces "predict into a scratch slot, update from it" without the round trip */
 };
@@ -118,7 +121,8 @@ typedef struct mot_kf_task {
   const int32_t* midx;       /* [n] measurement column per item (NULL: item index)            */
   float* boxes; int32_t ldb; /* optional out [4][ldb]: xyxy of the written state, column = item */
   float q[3];                /* XYSR only: Q(4,4), Q(5,5), Q(6,6)                             */
-  int32_t reserved;
+  int32_t reserved;          /* box style of `boxes`: 0 the tracker family's own (centre +- half size), MOT_KF_BOX_TLWH_SUM (XYAH, mot_kf_boxes /
+                                mot_kf_predict): x2 = x1 + w, y2 = y1 + h — StrongSORT's Track::to_tlbr, src/trackers/strongsort.cpp:94-111 */
   float warp[9];             /* camera-motion warp, 3x3 row-major (mot_kf_warp, mot_kf_predict_warp) */
   const float* conf;         /* optional, MOT_KF_XYAH update: detection confidences, indexed like `meas` — the NSA Kalman rule of
                                 BaseKalmanFilter::project, R = ((1 - conf) * std)^2 (src/motion/kalman_filter.cpp:60-75; StrongSORT's
@@ -157,7 +161,7 @@ int mot_kf_predict_warp(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int
  *   MOT_GATE_STRONGSORT   gate_cost_matrix (src/trackers/strongsort.cpp:449-492): cost replaced by gated_cost above 9.4877,
  *                         then EVERY entry blended lambda * cost + (1 - lambda) * distance
  * dim = 2 (only_position) or 4. meas: SoA [4][ldm] (xyah for XYAH, xywh for XYWH), what mot_det_prepare writes. */
-typedef enum mot_gate_mode { MOT_GATE_DISTANCE = 0, MOT_GATE_FUSE_MOTION = 1, MOT_GATE_STRONGSORT = 2 } mot_gate_mode;
+typedef enum mot_gate_mode { MOT_GATE_DISTANCE = 0, MOT_GATE_FUSE_MOTION = 1, MOT_GATE_STRONGSORT = 2, MOT_GATE_CLAMP = 0x100 /* flag, OR'ed in */ } mot_gate_mode;
 typedef struct mot_gate_task {
   int32_t n, m;                        /* tracks x measurements                                              */
   const float* mean; const int32_t* src; /* Kalman records (see mot_kf_task) and the slot of each row, NULL = identity */
@@ -166,6 +170,7 @@ typedef struct mot_gate_task {
   float* out; int32_t ldo;             /* n x m row-major                                                    */
   int32_t mode, only_position, metric; /* metric 0 = "maha", 1 = "gaussian" (XYAH only)                      */
   float lambda, gated_cost;
+  float clamp_above; /* with MOT_GATE_CLAMP in `mode`: a result above this becomes clamp_above + 1e-5 (min_cost_matching, strongsort.cpp:376-379) */
 } mot_gate_task;
 int mot_gate_cost(mot_ctx* ctx, int kf_kind, const mot_gate_task* tasks, int ntasks, int max_n, int max_m);
 /* host-pointer form: mean8 [n][8], cov [n][64], meas row-major [m][4], cost/out row-major n x m (cost NULL for mode 0) */
@@ -261,10 +266,37 @@ typedef struct mot_feat_task {
                                                              2: src/|src| only where |src| > 1e-6 (ReIDBackend::normalize_features,
                                                                 src/appearance/reid_backend.cpp:72-88; DeepOCSortKalmanBoxTracker
                                                                 ctor deepocsort.cpp:73-79), 3: EMA then normalise where the norm
-                                                                exceeds 1e-6 (update_emb, deepocsort.cpp:132-150) */
+                                                                exceeds 1e-6 (update_emb, deepocsort.cpp:132-150),
+                                                             4: StrongSORT's Track::update (strongsort.cpp:165-182): EMA of the stored feature with an already
+                                                                normalised src, renormalised when the norm exceeds 1e-10 — else the stored feature stays,
+                                                             5: src/|src| where |src| > 1e-10, else src (cosine_distance's row normalisation :317-331; a new
+                                                                track's feature :84-91), 6: plain copy */
   float alpha;                                            /* EMA weight of the old feature (0.9)     */
 } mot_feat_task;
 int mot_feat_update(mot_ctx* ctx, const mot_feat_task* tasks, int ntasks, int max_n);
+
+/* ---- StrongSORT's cost matrices (src/trackers/strongsort.cpp) ------------------------------ */
+/* mot_ss_nn_cost: NearestNeighborDistanceMetric::distance (:239-275) — cost[i][j] = min over the samples s of track i of 1 - dots[s][j],
+ * dots = inner products of the re-normalised sample rows with the re-normalised detection features (mot_embedding_cost, MOT_EMB_DOT);
+ * soff [n + 1]: track i's samples are the rows soff[i] .. soff[i+1]-1 of dots; no sample: 1e5.
+ * mot_ss_iou_cost: iou_matching::iou_cost (:500-583) + min_cost_matching's clamp (:376-379): 1 - IoU between the tlwh box of track i's
+ * Kalman state (record `src[i]` of `mean`, Track::to_tlwh :94-100) and detection didx[j] of the tlwh planes dtlwh [4][ldd]
+ * (mot_det_prepare, MOT_DET_TLWH); stale[i] != 0 (time_since_update > 1): 1e5; results above max_dist become max_dist + 1e-5. */
+typedef struct mot_ss_nn_task {
+  int32_t n, m;
+  const float* dots; int32_t ldd;
+  const int32_t* soff;
+  float* cost; int32_t ldc;
+} mot_ss_nn_task;
+int mot_ss_nn_cost(mot_ctx* ctx, const mot_ss_nn_task* tasks, int ntasks, int max_n, int max_m);
+typedef struct mot_ss_iou_task {
+  int32_t n, m;
+  const float* mean; const int32_t* src; const uint8_t* stale;
+  const float* dtlwh; int32_t ldd; const int32_t* didx;
+  float* cost; int32_t ldc;
+  float max_dist;
+} mot_ss_iou_task;
+int mot_ss_iou_cost(mot_ctx* ctx, const mot_ss_iou_task* tasks, int ntasks, int max_n, int max_m);
 
 /* ---- linear assignment ---------------------------------------------------------------- */
 typedef enum mot_lap_mode {

@@ -1,13 +1,14 @@
 /* motcpp_c.h — flat C handles over the C++ tracker classes of libmotcpp.so (for ctypes / cgo / JNI style
  * bindings and for this repository's tests and bench.py). Matrices are ROW-major here.
  *
- * kind: 0 SORT, 1 ByteTrack, 2 OC-SORT, 3 BoT-SORT. Parameter vectors (missing tail = reference defaults):
+ * kind: 0 SORT, 1 ByteTrack, 2 OC-SORT, 3 BoT-SORT, 4 DeepOC-SORT, 5 StrongSORT. Parameter vectors (missing tail = reference defaults):
  *  SORT      [det_thresh, max_age, max_obs, min_hits, iou_threshold]
  *  ByteTrack [min_conf, track_thresh, match_thresh, track_buffer, frame_rate, max_age, max_obs]
  *  OC-SORT   [det_thresh, max_age, max_obs, min_hits, iou_threshold, min_conf, delta_t, inertia, use_byte, Q_xy, Q_s,
  *             asso (mot_assoc: 0 iou, 1 hmiou, 2 giou, 3 ciou, 4 diou, 5 centroid)]
  *  BoT-SORT  [track_high, track_low, new_track, track_buffer, match_thresh, proximity, appearance,
  *             frame_rate, fuse_first_associate, with_reid, max_age, max_obs]
+ *  StrongSORT [min_conf, max_cos_dist, max_iou_dist, n_init, nn_budget, mc_lambda, ema_alpha, max_age]
  * Functions return >= 0 on success and a negative value on error (motcpp_last_error() has the message).
  */
 #ifndef MOTCPP_C_H_

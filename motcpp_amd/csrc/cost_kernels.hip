@@ -211,7 +211,9 @@ __global__ void __launch_bounds__(kThreads) ocsort_kernel(const mot_ocsort_task*
 // ---- appearance rows: normalise / exponential moving average ------------------------------------------------------------
 // mode 0: feat = src / |src| (BotSTrack ctor, botsort.cpp:38-46); 1: feat = alpha*feat + (1-alpha)*src, renormalised
 // (update_features, botsort.cpp:158-169); 2: feat = src / |src| if |src| > 1e-6 else src (ReIDBackend::normalize_features,
-// reid_backend.cpp:72-88); 3: the EMA with that 1e-6 rule (update_emb, deepocsort.cpp:132-150).
+// reid_backend.cpp:72-88); 3: the EMA with that 1e-6 rule (update_emb, deepocsort.cpp:132-150); 4: StrongSORT's EMA (Track::update,
+// strongsort.cpp:165-182: blend with an already normalised src, renormalise when the norm exceeds 1e-10, else the stored row stays);
+// 5: src / |src| where |src| > 1e-10 (cosine_distance :317-331); 6: plain copy.
 // The squared norm is a k-ordered fmaf chain — that order IS the result, so one lane walks one row for it — but everything
 // else is parallel: a 256-thread workgroup owns 32 rows, its four wavefronts stream the rows into an LDS tile with 256-byte
 // coalesced runs and blend them on the way (the EMA is elementwise), lanes 0..31 run the 32 chains out of LDS (odd row
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(256) feat_kernel(const mot_feat_task* __restri
     s_alpha[tid] = T.alpha_i ? T.alpha_i[i] : T.alpha;
   }
   __syncthreads();
-  const bool ema = T.mode == 1 || T.mode == 3;
+  const bool ema = T.mode == 1 || T.mode == 3 || T.mode == 4;
   const bool single = T.d <= kFeatCols;
   constexpr int RS = kFeatCols + 1;
   float nn = 0.0f;
@@ -259,14 +261,15 @@ __global__ void __launch_bounds__(256) feat_kernel(const mot_feat_task* __restri
       for (int k = 0; k < cols; ++k) nn = __builtin_fmaf(row[k], row[k], nn);
       if (c0 + cols >= T.d) {
         const float nrm = sqrtf(nn);
-        const bool go = (T.mode >= 2) ? (nrm > 1e-6f) : (nrm > 0.0f);
-        s_nrm[tid] = go ? nrm : 0.0f;  // 0 = leave the row as it is
+        const bool go = (T.mode == 6) ? false : ((T.mode >= 4) ? (nrm > 1e-10f) : ((T.mode >= 2) ? (nrm > 1e-6f) : (nrm > 0.0f)));
+        s_nrm[tid] = go ? nrm : 0.0f;  // 0 = the row is stored as it is (mode 4: the stored row stays as it was)
       }
     }
     __syncthreads();
     for (int r = wave; r < rows; r += 4) {
       float* fp = T.feat + s_f[r] + c0;
       const float nrm = single ? s_nrm[r] : 0.0f;
+      if (T.mode == 4 && single && nrm == 0.0f) continue;  // strongsort.cpp:176-179: the smoothed feature is only taken when it can be normalised
 #pragma unroll 4
       for (int k = lane; k < cols; k += 64) {
         const float v = tile[r * RS + k];

@@ -35,6 +35,9 @@ Staged* make(std::shared_ptr<Device> dev, int kind, const float* p, int np) {
                              (int)P(p, np, 5, 3), P(p, np, 6, 0.2f), P(p, np, 7, 0.5f), P(p, np, 8, 0.95f), P(p, np, 9, 0.5f),
                              P(p, np, 10, 0.f) != 0.f, P(p, np, 11, 0.f) != 0.f, P(p, np, 12, 0.f) != 0.f, P(p, np, 13, 0.01f),
                              P(p, np, 14, 0.0001f), (int)P(p, np, 15, 0.f));
+    case 5:  // min_conf, max_cos_dist, max_iou_dist, n_init, nn_budget, mc_lambda, ema_alpha, max_age
+      return make_strongsort(dev, P(p, np, 0, 0.1f), P(p, np, 1, 0.2f), P(p, np, 2, 0.7f), (int)P(p, np, 3, 3), (int)P(p, np, 4, 100), P(p, np, 5, 0.98f),
+                             P(p, np, 6, 0.9f), (int)P(p, np, 7, 30));
   }
   throw Error("unknown tracker kind");
 }

@@ -160,10 +160,11 @@ void Device::begin_frame() {
 bool Device::TaskLists::empty() const {
   for (int k = 0; k < 3; ++k)
     if (!det[k].empty() || !kf_init[k].empty() || !kf_upd[k].empty() || !kf_pred[k].empty() || !kf_box[k].empty() || !kf_warp[k].empty() || !kf_predw[k].empty()) return false;
-  return feat_set.empty() && feat_ema.empty() && cos.empty() && dot.empty() && deep.empty() && iou.empty() && oc.empty() && lap.empty();
+  return det[3].empty() && feat_set.empty() && feat_ema.empty() && feat_late.empty() && ss_nn.empty() && gate.empty() && ss_iou.empty() && cos.empty() && dot.empty() && deep.empty() && iou.empty() && oc.empty() && lap.empty();
 }
 void Device::TaskLists::clear() {
   for (int k = 0; k < 3; ++k) { det[k].clear(); kf_init[k].clear(); kf_upd[k].clear(); kf_pred[k].clear(); kf_box[k].clear(); kf_warp[k].clear(); kf_predw[k].clear(); }
+  det[3].clear(); feat_late.clear(); ss_nn.clear(); gate.clear(); ss_iou.clear();
   feat_set.clear(); feat_ema.clear(); cos.clear(); dot.clear(); deep.clear(); iou.clear(); oc.clear(); lap.clear();
   lap_geom = false;
   lap_assoc = false;
@@ -181,7 +182,8 @@ void Device::TaskLists::append(TaskLists& o) {
     move_back(det[k], o.det[k]); move_back(kf_init[k], o.kf_init[k]); move_back(kf_upd[k], o.kf_upd[k]);
     move_back(kf_pred[k], o.kf_pred[k]); move_back(kf_box[k], o.kf_box[k]); move_back(kf_warp[k], o.kf_warp[k]); move_back(kf_predw[k], o.kf_predw[k]);
   }
-  move_back(feat_set, o.feat_set); move_back(feat_ema, o.feat_ema); move_back(cos, o.cos); move_back(dot, o.dot); move_back(deep, o.deep); move_back(iou, o.iou);
+  move_back(det[3], o.det[3]);
+  move_back(feat_set, o.feat_set); move_back(feat_ema, o.feat_ema); move_back(feat_late, o.feat_late); move_back(ss_nn, o.ss_nn); move_back(gate, o.gate); move_back(ss_iou, o.ss_iou); move_back(cos, o.cos); move_back(dot, o.dot); move_back(deep, o.deep); move_back(iou, o.iou);
   move_back(oc, o.oc); move_back(lap, o.lap);
   lap_geom = lap_geom || o.lap_geom;
   o.lap_geom = false;
@@ -248,7 +250,8 @@ void Device::flush() {
   auto &oc = L.oc;
   auto &lap = L.lap;
   const bool lap_geom = L.lap_geom, lap_assoc = L.lap_assoc, lap_appearance = L.lap_appearance;
-  const mot_det_task* d_det[3];
+  const mot_det_task* d_det[4];
+  d_det[3] = stage_tasks(*up, L.det[3]);
   const mot_kf_task *d_init[3], *d_upd[3], *d_pred[3], *d_box[3], *d_warp[3], *d_predw[3];
   for (int k = 0; k < 3; ++k) {
     d_det[k] = stage_tasks(*up, det[k]);
@@ -261,6 +264,10 @@ void Device::flush() {
   }
   const mot_feat_task* d_fset = stage_tasks(*up, feat_set);
   const mot_feat_task* d_fema = stage_tasks(*up, feat_ema);
+  const mot_feat_task* d_flate = stage_tasks(*up, L.feat_late);
+  const mot_ss_nn_task* d_ssnn = stage_tasks(*up, L.ss_nn);
+  const mot_gate_task* d_gate = stage_tasks(*up, L.gate);
+  const mot_ss_iou_task* d_ssiou = stage_tasks(*up, L.ss_iou);
   const mot_cos_task* d_cos = stage_tasks(*up, cos);
   const mot_cos_task* d_dot = stage_tasks(*up, L.dot);
   const mot_deep_task* d_deep = stage_tasks(*up, L.deep);
@@ -288,7 +295,7 @@ void Device::flush() {
     for (const mot_kf_task& t : v) b += t.n * (4.0 * (D + D * D) * per_state_rw + 16.0 + 8.0);
     return b;
   };
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < 4; ++k) {
     double b = 0;
     for (const mot_det_task& t : det[k]) b += t.n * (16.0 + 32.0);
     run(F_DET, det[k].size(), b, 0, [&] { check(mot_det_prepare(ctx, k, d_det[k], (int)det[k].size(), maxn(det[k], [](const mot_det_task& t) { return t.n; })), "mot_det_prepare"); });
@@ -306,6 +313,12 @@ void Device::flush() {
     double b = 0;
     for (const mot_feat_task& t : feat_ema) b += 4.0 * t.n * t.d * 3;
     run(F_FEAT, feat_ema.size(), b, 0, [&] { check(mot_feat_update(ctx, d_fema, (int)feat_ema.size(), maxn(feat_ema, [](const mot_feat_task& t) { return t.n; })), "mot_feat_update"); });
+  }
+  {
+    auto& fl = L.feat_late;
+    double b = 0;
+    for (const mot_feat_task& t : fl) b += 4.0 * t.n * t.d * 2;
+    run(F_FEAT, fl.size(), b, 0, [&] { check(mot_feat_update(ctx, d_flate, (int)fl.size(), maxn(fl, [](const mot_feat_task& t) { return t.n; })), "mot_feat_update"); });
   }
   for (int k = 0; k < 3; ++k)
     run(F_KF_PREDICT, kf_pred[k].size(), kf_bytes(kf_pred[k], k, 2.0), 0, [&] { check(mot_kf_predict(ctx, k, d_pred[k], (int)kf_pred[k].size(), maxn(kf_pred[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_predict"); });
@@ -333,6 +346,20 @@ void Device::flush() {
     run(F_COSINE, dot.size(), b, fl, [&] {
       check(mot_embedding_cost(ctx, MOT_EMB_DOT, d_dot, (int)dot.size(), maxn(dot, [](const mot_cos_task& t) { return t.n; }), maxn(dot, [](const mot_cos_task& t) { return t.m; })), "mot_embedding_cost");
     });
+  }
+  {  // StrongSORT: nearest-sample distances, then the motion gate on them, and its IoU cost (strongsort.cpp:239-275, 449-492, 500-583)
+    auto& nn = L.ss_nn;
+    double b = 0;
+    for (const mot_ss_nn_task& t : nn) b += 4.0 * ((double)(t.soff ? 1 : 0) + 1.0) * t.n * (double)t.m;
+    run(F_COSINE, nn.size(), b, 0, [&] { check(mot_ss_nn_cost(ctx, d_ssnn, (int)nn.size(), maxn(nn, [](const mot_ss_nn_task& t) { return t.n; }), maxn(nn, [](const mot_ss_nn_task& t) { return t.m; })), "mot_ss_nn_cost"); });
+    auto& gt = L.gate;
+    b = 0;
+    for (const mot_gate_task& t : gt) b += 8.0 * t.n * (double)t.m;
+    run(F_IOU, gt.size(), b, 0, [&] { check(mot_gate_cost(ctx, MOT_KF_XYAH, d_gate, (int)gt.size(), maxn(gt, [](const mot_gate_task& t) { return t.n; }), maxn(gt, [](const mot_gate_task& t) { return t.m; })), "mot_gate_cost"); });
+    auto& si = L.ss_iou;
+    b = 0;
+    for (const mot_ss_iou_task& t : si) b += 4.0 * t.n * (double)t.m + 16.0 * (t.n + t.m);
+    run(F_IOU, si.size(), b, 0, [&] { check(mot_ss_iou_cost(ctx, d_ssiou, (int)si.size(), maxn(si, [](const mot_ss_iou_task& t) { return t.n; }), maxn(si, [](const mot_ss_iou_task& t) { return t.m; })), "mot_ss_iou_cost"); });
   }
   {
     double b = 0;
@@ -486,6 +513,7 @@ float* Core::boxes(const std::vector<int>& slots, Span<float>* boxes_dl) {
   else bx = dev_->tmp->alloc<float>(static_cast<size_t>(4) * n).d;
   mot_kf_task t{};
   t.mean = mean_; t.cov = cov_; t.cap = cap_; t.n = n; t.src = s.d; t.boxes = bx; t.ldb = n;
+  t.reserved = box_style;
   dev_->q().kf_box[kind_].push_back(t);
   return bx;
 }

@@ -109,9 +109,13 @@ class Device {
   // Task lists of the current stage (host copies; flush() concatenates them and moves them to the device). One set
   // per host thread: a stage machine appends to the set of the thread it runs on, without locking.
   struct TaskLists {
-    std::vector<mot_det_task> det[3];
+    std::vector<mot_det_task> det[4];  // by mot_det_kind
     std::vector<mot_kf_task> kf_init[3], kf_upd[3], kf_pred[3], kf_box[3], kf_warp[3], kf_predw[3];
     std::vector<mot_feat_task> feat_set, feat_ema;
+    std::vector<mot_feat_task> feat_late;  // after feat_ema: rows that read what the two lists before wrote (StrongSORT's sample library)
+    std::vector<mot_ss_nn_task> ss_nn;     // StrongSORT: minimum over a track's samples (after the raw inner products, before the gate)
+    std::vector<mot_gate_task> gate;       // XYAH motion gate + blend (+ clamp) on a cost matrix
+    std::vector<mot_ss_iou_task> ss_iou;   // StrongSORT's IoU cost on tlwh boxes
     std::vector<mot_cos_task> cos;
     std::vector<mot_cos_task> dot;    // raw inner products (DeepOC-SORT's embedding similarity)
     std::vector<mot_deep_task> deep;  // ... and its weighting into the association cost (after the OC-SORT cost, before the LAP)
@@ -161,6 +165,7 @@ class Core {
   int scratch_slot(int i) const { return pcap_ + i; }
   void clear_slots();
   float q[3] = {0.01f, 0.01f, 0.0001f};  // XYSR process noise tail
+  int box_style = 0;                      // mot_kf_task.reserved of the boxes() tasks (StrongSORT: MOT_KF_BOX_TLWH_SUM)
 
   // ---- detections of the current frame ----
   struct Dets {

@@ -96,6 +96,9 @@ int asso_kind(const std::string& name);
 Staged* make_deepocsort(std::shared_ptr<Device>, float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold,
                         int delta_t, float inertia, float w_emb, float alpha_fixed, float aw_param, bool emb_off, bool cmc_off,
                         bool aw_off, float q_xy, float q_s, int asso);
+// StrongSORT (src/trackers/strongsort.cpp); nn_budget > 0
+Staged* make_strongsort(std::shared_ptr<Device>, float min_conf, float max_cos_dist, float max_iou_dist, int n_init, int nn_budget,
+                        float mc_lambda, float ema_alpha, int max_age);
 Staged* make_botsort(std::shared_ptr<Device>, float track_high, float track_low, float new_track, int track_buffer,
                      float match_thresh, float proximity, float appearance, int frame_rate, bool fuse_first, bool with_reid,
                      int max_age, int max_obs);

@@ -305,6 +305,15 @@ DeepOCSort::DeepOCSort(const std::string& /*reid_weights*/, bool /*use_half*/, b
   adopt(rt::make_deepocsort(dev_, det_thresh_, max_age_, max_obs_, min_hits_, iou_threshold_, delta_t, inertia, w_association_emb,
                             alpha_fixed_emb, aw_param, embedding_off, cmc_off, aw_off, Q_xy_scaling, Q_s_scaling, asso));
 }
+StrongSORT::StrongSORT(const std::string& reid_weights, bool /*use_half*/, bool /*use_gpu*/, float det_thresh, int max_age, int max_obs, int min_hits,
+                       float iou_threshold, bool per_class, int nr_classes, const std::string& asso_func, bool is_obb, float min_conf,
+                       float max_cos_dist, float max_iou_dist, int n_init, int nn_budget, float mc_lambda, float ema_alpha, int device_index)
+    : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
+  if (!reid_weights.empty())
+    throw std::invalid_argument("motcpp_amd: ReID model inference is outside the hot path; pass embeddings to update()");
+  // (the tracker gets the constructor's max_age, strongsort.cpp:841-842; BaseTracker only adjusts max_obs)
+  adopt(rt::make_strongsort(dev_, min_conf, max_cos_dist, max_iou_dist, n_init, nn_budget, mc_lambda, ema_alpha, max_age));
+}
 void DeepOCSort::set_camera_motion(const Eigen::MatrixXf& warp) {
   if (warp.rows() != 2 || warp.cols() != 3) throw std::invalid_argument("DeepOCSort::set_camera_motion: the warp must be 2 x 3");
   const float w[6] = {warp(0, 0), warp(0, 1), warp(0, 2), warp(1, 0), warp(1, 1), warp(1, 2)};

@@ -537,6 +537,12 @@ __global__ void __launch_bounds__(kThreads) kf_kernel(const mot_kf_task* __restr
   if (T.boxes && active) {
     float b[4];
     if constexpr (KIND == MOT_KF_XYSR) xysr_box(s, b); else s8_box<KIND>(s, b);
+    if constexpr (KIND == MOT_KF_XYAH) {
+      if (T.reserved == MOT_KF_BOX_TLWH_SUM) {  // StrongSORT's Track::to_tlbr (strongsort.cpp:94-111): the far corner is top-left + size
+        const float w = s.m[2] * s.m[3];
+        b[2] = b[0] + w; b[3] = b[1] + s.m[3];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) T.boxes[static_cast<size_t>(k) * T.ldb + i] = b[k];
   }
@@ -563,6 +569,10 @@ __global__ void __launch_bounds__(kThreads) det_kernel(const mot_det_task* __res
     const float tl = xc - w * 0.5f, tt = yc - h * 0.5f;
     z[0] = tl + w * 0.5f; z[1] = tt + h * 0.5f; z[2] = (h > 0.0f) ? (w / h) : 0.0f; z[3] = h;
     box[0] = xc - w * 0.5f; box[1] = yc - h * 0.5f; box[2] = xc + w * 0.5f; box[3] = yc + h * 0.5f;  // xywh2xyxy
+  } else if (KIND == MOT_DET_TLWH) {  // strongsort.cpp:948-956 (tlwh), Detection::to_xyah :33-40
+    const float w = x2 - x1, h = y2 - y1;
+    box[0] = x1; box[1] = y1; box[2] = w; box[3] = h;
+    z[0] = x1 + w / 2.0f; z[1] = y1 + h / 2.0f; z[2] = w / h; z[3] = h;
   } else {  // botsort.cpp:23-36, 171-181
     const float w = x2 - x1, h = y2 - y1;
     const float cx = x1 + w / 2.0f, cy = y1 + h / 2.0f;
@@ -897,15 +907,17 @@ __global__ void __launch_bounds__(kGateThreads) gate_kernel(const mot_gate_task*
     }
   }
   float out = g;
-  if (T.mode == MOT_GATE_FUSE_MOTION) {
+  const int gmode = T.mode & 0xff;
+  if (gmode == MOT_GATE_FUSE_MOTION) {
     const float thr = pos ? 5.9915f : 9.4877f;  // chi2inv95[dim - 1] (matching.hpp:16-26)
     const float c = T.cost[static_cast<size_t>(row) * T.ldc + j];
     out = (g > thr) ? __builtin_inff() : (T.lambda * c + (1.0f - T.lambda) * g);
-  } else if (T.mode == MOT_GATE_STRONGSORT) {
+  } else if (gmode == MOT_GATE_STRONGSORT) {
     float c = T.cost[static_cast<size_t>(row) * T.ldc + j];
     if (g > 9.4877f) c = T.gated_cost;  // the 4-dof quantile whatever only_position is (strongsort.cpp:461)
     out = T.lambda * c + (1.0f - T.lambda) * g;
   }
+  if ((T.mode & MOT_GATE_CLAMP) && out > T.clamp_above) out = T.clamp_above + 1e-5f;  // min_cost_matching, strongsort.cpp:376-379
   T.out[static_cast<size_t>(row) * T.ldo + j] = out;
 }
 
@@ -967,6 +979,7 @@ hipError_t launch_det(int kind, const mot_det_task* tasks, int ntasks, int max_n
     case MOT_DET_XYSR: hipLaunchKernelGGL((det_kernel<MOT_DET_XYSR>), grid, block, 0, st, tasks); break;
     case MOT_DET_XYAH: hipLaunchKernelGGL((det_kernel<MOT_DET_XYAH>), grid, block, 0, st, tasks); break;
     case MOT_DET_XYWH: hipLaunchKernelGGL((det_kernel<MOT_DET_XYWH>), grid, block, 0, st, tasks); break;
+    case MOT_DET_TLWH: hipLaunchKernelGGL((det_kernel<MOT_DET_TLWH>), grid, block, 0, st, tasks); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

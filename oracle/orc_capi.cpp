@@ -18,12 +18,14 @@ struct Handle {
   std::unique_ptr<OCSort> oc;
   std::unique_ptr<BotSort> bot;
   std::unique_ptr<DeepOCSort> deep;
+  std::unique_ptr<StrongSort> strong;
   const std::vector<LapResult>* laps() const {
     switch (kind) {
       case 1: return &byte->laps;
       case 2: return &oc->laps;
       case 3: return &bot->laps;
       case 4: return &deep->laps;
+      case 5: return &strong->laps;
       default: return nullptr;
     }
   }
@@ -78,6 +80,10 @@ void* orc_tracker_create(int kind, const float* p, int np) {
                                              P(p, np, 12, 0.f) != 0.f, P(p, np, 13, 0.01f), P(p, np, 14, 0.0001f));
       h->deep->set_asso((int)P(p, np, 15, 0.f), (int)P(p, np, 16, 1920.f), (int)P(p, np, 17, 1080.f));
       break;
+    case 5:  // min_conf, max_cos_dist, max_iou_dist, n_init, nn_budget, mc_lambda, ema_alpha, max_age
+      h->strong = std::make_unique<StrongSort>(P(p, np, 0, 0.1f), P(p, np, 1, 0.2f), P(p, np, 2, 0.7f), (int)P(p, np, 3, 3), (int)P(p, np, 4, 100),
+                                               P(p, np, 5, 0.98f), P(p, np, 6, 0.9f), (int)P(p, np, 7, 30));
+      break;
     default:
       delete h;
       return nullptr;
@@ -92,6 +98,7 @@ void orc_tracker_reset(void* hv) {
   if (h->oc) h->oc->reset();
   if (h->bot) h->bot->reset();
   if (h->deep) h->deep->reset();
+  if (h->strong) h->strong->reset();
 }
 
 // BoT-SORT only: the 2x3 camera-motion warp of the next update() (returns 0, or -1 for the other trackers)
@@ -118,6 +125,7 @@ int orc_tracker_update(void* hv, const float* dets, int n, const float* embs, in
     case 2: t = h->oc->update(dets, n); break;
     case 3: t = h->bot->update(dets, n, embs, d); break;
     case 4: t = h->deep->update(dets, n, embs, d); break;
+    case 5: t = h->strong->update(dets, n, embs, d); break;
   }
   const int rows = static_cast<int>(t.size());
   if (rows > cap) return -rows;
@@ -151,6 +159,7 @@ int orc_tracker_dump_states(void* hv, float* out, int cap_floats, int* w) {
     case 2: s = h->oc->dump_states(); break;
     case 3: s = h->bot->dump_states(); break;
     case 4: s = h->deep->dump_states(); break;
+    case 5: s = h->strong->dump_states(); break;
   }
   *w = s.empty() ? 0 : static_cast<int>(s[0].size());
   size_t need = s.size() * static_cast<size_t>(*w);
@@ -263,8 +272,8 @@ void orc_feat_update(int mode, float alpha, int n, int d, float* feat, const flo
 int orc_tracker_dump_features(void* hv, float* out, int cap_floats, int* d) {
   auto* h = static_cast<Handle*>(hv);
   *d = 0;
-  if (h->kind != 3 && h->kind != 4) return 0;
-  const std::vector<std::vector<float>> f = (h->kind == 3) ? h->bot->dump_features() : h->deep->dump_features();
+  if (h->kind != 3 && h->kind != 4 && h->kind != 5) return 0;
+  const std::vector<std::vector<float>> f = (h->kind == 3) ? h->bot->dump_features() : ((h->kind == 4) ? h->deep->dump_features() : h->strong->dump_features());
   for (const auto& r : f) if (!r.empty()) *d = static_cast<int>(r.size());
   if (*d == 0) return static_cast<int>(f.size());
   if (f.size() * static_cast<size_t>(*d) > static_cast<size_t>(cap_floats)) return -static_cast<int>(f.size());

@@ -12,10 +12,12 @@
 // [x1,y1,x2,y2,id,conf,cls,det_ind] like the reference's M x 8 matrix.
 #pragma once
 #include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <set>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -1266,6 +1268,282 @@ class BotSort {
   float warp_[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
   bool has_warp_ = false;
   std::vector<BTrack> active_, lost_;
+};
+
+// =======================================================================================
+// StrongSORT — src/trackers/strongsort.cpp (round 4; "parity unpinned": the reference's tests hold no vector for it)
+// =======================================================================================
+// update() :847-1012 over Tracker::predict / update / match :595-816, Track :45-197, NearestNeighborDistanceMetric :203-335,
+// min_cost_matching / matching_cascade :343-447, gate_cost_matrix :449-492, iou_matching :500-583. Restated as written, quirks
+// included:
+//  * matching_cascade and min_cost_matching replace an EMPTY index list by "all of them" (:358-368, :440-447): with no confirmed
+//    track the appearance stage runs over every track; with no candidate for the IoU stage every track takes part in it; and when
+//    the appearance stage left no detection unmatched the IoU stage sees ALL detections again — its own unmatched detections
+//    (detections the first stage had matched among them) are then what new tracks are started from (:765-776, :608-611).
+//  * the distance metric keeps, per confirmed track, the last nn_budget smoothed features (one appended per frame, matched or
+//    not, :627-650) and the cost is the minimum cosine distance over them, with both sides re-normalised (:306-334).
+//  * the camera-motion step (:900-906, ECC image registration) is outside this path: update() runs without it.
+//  * Track's test switch (:61-76) is kept: under GITHUB_ACTIONS=true (and GITHUB_JOB != mot-metrics-benchmark) a new track is Confirmed
+//    at birth — how the reference's own CI sees confirmed tracks from the second frame on. Read at every birth, as there.
+// Eigen's reduction orders (norm(), the GEMM of the cosine term) are unspecified: dot_chain's canonical order, as elsewhere.
+class StrongSort {
+ public:
+  explicit StrongSort(float min_conf = 0.1f, float max_cos_dist = 0.2f, float max_iou_dist = 0.7f, int n_init = 3, int nn_budget = 100,
+                      float mc_lambda = 0.98f, float ema_alpha = 0.9f, int max_age = 30)
+      : min_conf_(min_conf), max_cos_(max_cos_dist), max_iou_(max_iou_dist), n_init_(n_init), budget_(nn_budget), lambda_(mc_lambda),
+        alpha_(ema_alpha), max_age_(max_age) {}
+  void reset() { tracks_.clear(); next_id_ = 1; samples_.clear(); }  // :812-816
+
+  enum State { Tentative = 1, Confirmed = 2, Deleted = 3 };
+  struct Det {  // Detection :23-40
+    float tlwh[4];
+    float conf;
+    int cls, det_ind;
+    std::vector<float> feat;
+    void to_xyah(float o[4]) const {
+      o[0] = tlwh[0] + tlwh[2] / 2.0f; o[1] = tlwh[1] + tlwh[3] / 2.0f; o[2] = tlwh[2] / tlwh[3]; o[3] = tlwh[3];
+    }
+  };
+  struct Track {  // :45-197
+    int id = 0;
+    State8 kf;
+    std::vector<float> feature;  // the smoothed feature (features.back()); empty: none yet
+    float conf = 0.f;
+    int cls = 0, det_ind = -1, hits = 1, age = 1, tsu = 0;
+    State state = Tentative;
+    void to_tlwh(float o[4]) const {  // :94-100
+      o[2] = kf.mean[2] * kf.mean[3]; o[3] = kf.mean[3];
+      o[0] = kf.mean[0] - o[2] / 2.0f; o[1] = kf.mean[1] - o[3] / 2.0f;
+    }
+  };
+  std::vector<LapResult> laps;
+
+  OutTable update(const float* dets, int n, const float* embs, int emb_dim) {  // :847-1012
+    laps.clear();
+    std::vector<Det> D;
+    const bool use_emb = embs != nullptr && emb_dim > 0;  // (embs.rows() == dets.rows() is the caller's contract here)
+    for (int i = 0; i < n; ++i) {
+      const float* r = dets + static_cast<size_t>(i) * 6;
+      if (!(r[4] >= min_conf_)) continue;  // :873-877
+      Det d;
+      d.tlwh[0] = r[0]; d.tlwh[1] = r[1]; d.tlwh[2] = r[2] - r[0]; d.tlwh[3] = r[3] - r[1];  // :948-956
+      d.conf = r[4]; d.cls = static_cast<int>(r[5]); d.det_ind = i;
+      if (use_emb) d.feat.assign(embs + static_cast<size_t>(i) * emb_dim, embs + static_cast<size_t>(i + 1) * emb_dim);
+      D.push_back(std::move(d));
+    }
+    for (Track& t : tracks_) { KfXYAH::predict(t.kf); ++t.age; ++t.tsu; }  // :595-599, :139-145
+    tracker_update(D);
+    OutTable out;
+    for (const Track& t : tracks_) {  // :976-994
+      if (t.state != Confirmed || t.tsu >= 1) continue;
+      float b[4];
+      t.to_tlwh(b);
+      out.push_back({b[0], b[1], b[0] + b[2], b[1] + b[3], static_cast<float>(t.id), t.conf, static_cast<float>(t.cls), static_cast<float>(t.det_ind)});
+    }
+    return out;
+  }
+
+  std::vector<std::vector<float>> dump_states() const {
+    std::vector<std::vector<float>> v;
+    for (const Track& t : tracks_) {
+      std::vector<float> r;
+      r.push_back(static_cast<float>(t.id));
+      for (int k = 0; k < 8; ++k) r.push_back(t.kf.mean[k]);
+      for (int a = 0; a < 8; ++a) for (int b = 0; b < 8; ++b) r.push_back(t.kf.cov[a][b]);
+      v.push_back(std::move(r));
+    }
+    return v;
+  }
+  std::vector<std::vector<float>> dump_features() const {
+    std::vector<std::vector<float>> v;
+    for (const Track& t : tracks_) v.push_back(t.feature);
+    return v;
+  }
+
+ private:
+  static float norm_of(const std::vector<float>& a) { return std::sqrt(dot_chain(a.data(), a.data(), static_cast<int>(a.size()))); }
+  static std::vector<float> renormed(const std::vector<float>& a) {  // cosine_distance :317-331: row /= norm when norm > 1e-10
+    std::vector<float> r = a;
+    const float nn = norm_of(a);
+    if (nn > 1e-10f) for (float& x : r) x /= nn;
+    return r;
+  }
+  using Matches = std::vector<std::array<int, 2>>;
+  struct MatchOut { Matches m; std::vector<int> ut, ud; };
+
+  // min_cost_matching :343-420 with the cost matrix supplied by `metric(track_idx, det_idx)`
+  template <class Fn>
+  MatchOut min_cost_matching(Fn metric, float max_distance, const std::vector<Det>& dets, std::vector<int> track_idx, std::vector<int> det_idx) {
+    if (track_idx.empty()) { track_idx.resize(tracks_.size()); for (size_t i = 0; i < track_idx.size(); ++i) track_idx[i] = static_cast<int>(i); }
+    if (det_idx.empty()) { det_idx.resize(dets.size()); for (size_t i = 0; i < det_idx.size(); ++i) det_idx[i] = static_cast<int>(i); }
+    MatchOut o;
+    if (track_idx.empty() || det_idx.empty()) { o.ut = track_idx; o.ud = det_idx; return o; }
+    Mat cost = metric(track_idx, det_idx);
+    for (float& c : cost.a) if (c > max_distance) c = max_distance + 1e-5f;  // :376-379
+    LapResult r = linear_assignment(cost, max_distance);
+    laps.push_back(r);
+    std::vector<char> mt(track_idx.size(), 0), md(det_idx.size(), 0);
+    for (const auto& p : r.matches)
+      if (cost(p[0], p[1]) <= max_distance) { o.m.push_back({track_idx[p[0]], det_idx[p[1]]}); mt[p[0]] = 1; md[p[1]] = 1; }
+    for (size_t i = 0; i < track_idx.size(); ++i) if (!mt[i]) o.ut.push_back(track_idx[i]);
+    for (size_t j = 0; j < det_idx.size(); ++j) if (!md[j]) o.ud.push_back(det_idx[j]);
+    return o;
+  }
+
+  Mat gated_metric(const std::vector<Det>& dets, const std::vector<int>& ti, const std::vector<int>& di) {  // :666-718
+    const int n = static_cast<int>(ti.size()), m = static_cast<int>(di.size());
+    int dim = 0;
+    for (int j : di) if (!dets[j].feat.empty()) { dim = static_cast<int>(dets[j].feat.size()); break; }
+    Mat cost(n, m, 1e5f);
+    if (dim == 0) return cost;  // :688-690: no features at all — not even gated
+    std::vector<std::vector<float>> yn(m);
+    for (int j = 0; j < m; ++j) {
+      std::vector<float> f(dim, 0.0f);
+      if (static_cast<int>(dets[di[j]].feat.size()) == dim) f = dets[di[j]].feat;
+      yn[j] = renormed(f);
+    }
+    for (int i = 0; i < n; ++i) {  // NearestNeighborDistanceMetric::distance :239-275
+      auto it = samples_.find(tracks_[ti[i]].id);
+      if (it == samples_.end() || it->second.empty()) continue;  // 1e5
+      for (int j = 0; j < m; ++j) cost(i, j) = 0.0f;
+      bool first = true;
+      for (const std::vector<float>& xs : it->second) {
+        if (static_cast<int>(xs.size()) != dim) { for (int j = 0; j < m; ++j) cost(i, j) = first ? 1.0f : std::min(cost(i, j), 1.0f); first = false; continue; }  // :313-315
+        const std::vector<float> xn = renormed(xs);
+        for (int j = 0; j < m; ++j) {
+          const float d = 1.0f - dot_chain(xn.data(), yn[j].data(), dim);
+          cost(i, j) = first ? d : std::min(cost(i, j), d);
+        }
+        first = false;
+      }
+    }
+    // gate_cost_matrix :449-492
+    std::vector<float> meas(static_cast<size_t>(4) * m), g(m);
+    for (int j = 0; j < m; ++j) dets[di[j]].to_xyah(&meas[static_cast<size_t>(4) * j]);
+    for (int i = 0; i < n; ++i) {
+      gating_xyah(tracks_[ti[i]].kf, meas.data(), m, false, 0, g.data());
+      for (int j = 0; j < m; ++j) {
+        float c = cost(i, j);
+        if (g[j] > 9.4877f) c = 1e5f;
+        cost(i, j) = lambda_ * c + (1.0f - lambda_) * g[j];
+      }
+    }
+    return cost;
+  }
+
+  Mat iou_cost(const std::vector<Det>& dets, const std::vector<int>& ti, const std::vector<int>& di) {  // :500-583
+    const int n = static_cast<int>(ti.size()), m = static_cast<int>(di.size());
+    Mat cost(n, m, 0.0f);
+    for (int i = 0; i < n; ++i) {
+      const Track& t = tracks_[ti[i]];
+      if (t.tsu > 1) { for (int j = 0; j < m; ++j) cost(i, j) = 1e5f; continue; }
+      float b[4];
+      t.to_tlwh(b);
+      const float bx2 = b[0] + b[2], by2 = b[1] + b[3], ab = b[2] * b[3];
+      for (int j = 0; j < m; ++j) {
+        const float* c = dets[di[j]].tlwh;
+        const float cx2 = c[0] + c[2], cy2 = c[1] + c[3];
+        const float tlx = std::max(b[0], c[0]), tly = std::max(b[1], c[1]);
+        const float brx = std::min(bx2, cx2), bry = std::min(by2, cy2);
+        const float w = std::max(0.0f, brx - tlx), h = std::max(0.0f, bry - tly);
+        const float ai = w * h, ac = c[2] * c[3];
+        const float au = ab + ac - ai;
+        const float iou = (au > 1e-6f) ? (ai / au) : 0.0f;
+        cost(i, j) = 1.0f - iou;
+      }
+    }
+    return cost;
+  }
+
+  void track_update(Track& t, const Det& d) {  // Track::update :147-187
+    float z[4];
+    d.to_xyah(z);
+    t.conf = d.conf; t.cls = d.cls; t.det_ind = d.det_ind;
+    KfXYAH::update(t.kf, z, d.conf);
+    if (!d.feat.empty()) {
+      const float fn = norm_of(d.feat);
+      if (!(fn < 1e-10f)) {
+        std::vector<float> f = d.feat;
+        for (float& x : f) x /= fn;
+        if (!t.feature.empty()) {
+          std::vector<float> s(f.size());
+          for (size_t k = 0; k < f.size(); ++k) s[k] = alpha_ * t.feature[k] + (1.0f - alpha_) * f[k];
+          const float sn = norm_of(s);
+          if (sn > 1e-10f) { for (float& x : s) x /= sn; t.feature = std::move(s); }
+        } else {
+          t.feature = std::move(f);
+        }
+      }
+    }
+    ++t.hits; t.tsu = 0;
+    if (t.state == Tentative && t.hits >= n_init_) t.state = Confirmed;
+  }
+
+  void tracker_update(const std::vector<Det>& dets) {  // Tracker::update :601-651 + match :653-806
+    std::vector<int> confirmed, unconfirmed;
+    for (size_t i = 0; i < tracks_.size(); ++i) (tracks_[i].state == Confirmed ? confirmed : unconfirmed).push_back(static_cast<int>(i));
+    MatchOut A = min_cost_matching([&](const std::vector<int>& ti, const std::vector<int>& di) { return gated_metric(dets, ti, di); }, max_cos_, dets,
+                                   confirmed, {});  // matching_cascade :422-447 = one min_cost_matching
+    std::vector<int> cand = unconfirmed, ua_rest;
+    for (int k : A.ut) (tracks_[k].tsu == 1 ? cand : ua_rest).push_back(k);
+    MatchOut B = min_cost_matching([&](const std::vector<int>& ti, const std::vector<int>& di) { return iou_cost(dets, ti, di); }, max_iou_, dets, cand, A.ud);
+    Matches matches = A.m;
+    std::set<int> mt, md;
+    for (const auto& p : A.m) { mt.insert(p[0]); md.insert(p[1]); }
+    for (const auto& p : B.m)
+      if (!mt.count(p[0]) && !md.count(p[1])) { matches.push_back(p); mt.insert(p[0]); md.insert(p[1]); }
+    std::set<int> um(ua_rest.begin(), ua_rest.end());
+    um.insert(B.ut.begin(), B.ut.end());
+    for (const auto& p : matches) track_update(tracks_[p[0]], dets[p[1]]);
+    for (int k : um) {  // mark_missed :189-197
+      Track& t = tracks_[k];
+      if (t.state == Tentative) t.state = Deleted;
+      else if (t.tsu > max_age_) t.state = Deleted;
+    }
+    for (int j : B.ud) {  // initiate_track :808-810, Track::Track :45-92
+      const Det& d = dets[j];
+      Track t;
+      t.id = next_id_++;
+      {
+        const char* ga = std::getenv("GITHUB_ACTIONS");
+        const char* gj = std::getenv("GITHUB_JOB");
+        if (ga && std::string(ga) == "true" && (!gj || std::string(gj) != "mot-metrics-benchmark")) t.state = Confirmed;
+      }
+      float z[4];
+      d.to_xyah(z);
+      t.kf = KfXYAH::initiate(z);
+      t.conf = d.conf; t.cls = d.cls; t.det_ind = d.det_ind;
+      if (!d.feat.empty()) {
+        const float fn = norm_of(d.feat);
+        if (fn > 1e-10f) { t.feature = d.feat; for (float& x : t.feature) x /= fn; }
+      }
+      tracks_.push_back(std::move(t));
+    }
+    tracks_.erase(std::remove_if(tracks_.begin(), tracks_.end(), [](const Track& t) { return t.state == Deleted; }), tracks_.end());
+    // partial_fit :203-237 with the confirmed tracks' features (:627-650)
+    std::vector<int> active;
+    bool any = false;
+    for (const Track& t : tracks_) if (t.state == Confirmed) { active.push_back(t.id); any = any || !t.feature.empty(); }
+    if (any) {
+      for (const Track& t : tracks_) {
+        if (t.state != Confirmed || t.feature.empty()) continue;
+        std::vector<std::vector<float>>& v = samples_[t.id];
+        v.push_back(t.feature);
+        if (budget_ > 0 && static_cast<int>(v.size()) > budget_) v.erase(v.begin(), v.end() - budget_);
+      }
+      std::unordered_map<int, std::vector<std::vector<float>>> kept;
+      for (int id : active) { auto it = samples_.find(id); if (it != samples_.end()) kept[id] = std::move(it->second); }
+      samples_ = std::move(kept);
+    }
+  }
+
+  float min_conf_, max_cos_, max_iou_;
+  int n_init_, budget_;
+  float lambda_, alpha_;
+  int max_age_;
+  int next_id_ = 1;
+  std::vector<Track> tracks_;
+  std::unordered_map<int, std::vector<std::vector<float>>> samples_;
 };
 
 }  // namespace orc

@@ -21,6 +21,7 @@ using motcpp::trackers::ByteTrack;
 using motcpp::trackers::DeepOCSort;
 using motcpp::trackers::OCSort;
 using motcpp::trackers::Sort;
+using motcpp::trackers::StrongSORT;
 
 static Eigen::MatrixXf dets1(float x1, float y1, float x2, float y2, float c, float cls) {
   Eigen::MatrixXf d(1, 6);
@@ -294,6 +295,22 @@ int main() {
     threw = false;
     try { Eigen::MatrixXf w(3, 3); off.set_camera_motion(w); } catch (const std::invalid_argument&) { threw = true; }
     CHECK(threw);
+  }
+  {  // StrongSORT (strongsort.hpp:294-312): the reference's constructor signature; embeddings come with update(). From a cold start the
+     // tracks stay tentative (the reference's matching as written, see csrc/host/strongsort.cpp): tables have 8 columns and may be empty.
+    StrongSORT t;
+    Eigen::MatrixXf e(3, 8);
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 8; ++k) e(i, k) = (i == k % 3) ? 1.0f : 0.1f;
+    for (int f = 0; f < 4; ++f) CHECK(t.update(multi, img, e).cols() == 8);
+    CHECK(t.update(empty, img).rows() == 0);
+    t.reset();
+    CHECK(t.update(multi, img).cols() == 8);  // without embeddings the IoU stage decides (strongsort.cpp:688-690)
+    bool threw = false;
+    try { t.update(single, cv::Mat()); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);  // check_inputs (:853)
+    threw = false;
+    try { StrongSORT w("osnet.onnx"); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);  // ReID inference is outside the hot path
   }
   {  // an embedding matrix with the wrong number of rows is rejected, alone and inside a StreamBatch
     BotSort t;

@@ -493,3 +493,63 @@ def test_botsort_warp_is_one_shot_and_dropped_with_an_empty_frame(orc):
     assert np.array_equal(a.update(frames[2])[:, 4:], b.update(frames[2])[:, 4:])
     with pytest.raises(ValueError):
         orc.tracker(orclib.SORT).set_camera_motion(W)
+
+
+# ---- StrongSORT (round 4): what src/trackers/strongsort.cpp does from a cold start, derived by hand from the code ----------------
+def _ss_frame(shift=0.0):
+    return np.array([[100 + shift, 100, 150, 220, 0.9, 0], [400 + shift, 300, 460, 430, 0.8, 0], [900 + shift, 500, 960, 640, 0.7, 1]], np.float32)
+
+
+def test_strongsort_cold_start_as_written(orc):
+    """Frame 1: three tentative tracks (ids 1-3, nothing emitted: none is confirmed). Frame 2: no confirmed track, so matching_cascade's
+    empty index list means ALL tracks (strongsort.cpp:358-361, 440-447); nothing matches without samples; the IoU stage's candidates are the
+    unconfirmed tracks PLUS stage A's unmatched tracks with time_since_update == 1 (:745-757) — every track twice. One copy of each track
+    matches its detection (hits 2 < n_init 3), the other copy stays unmatched and puts the track on the unmatched list, where a tentative
+    track is deleted (:189-197, :608-611). No detection is left over: the frame ends with NO track. Frame 3 starts over with ids 4-6."""
+    import os
+    old = os.environ.pop("GITHUB_ACTIONS", None)
+    try:
+        t = orc.tracker(orclib.STRONGSORT)
+        assert t.update(_ss_frame()).shape == (0, 8)
+        assert list(t.dump_states()[:, 0]) == [1, 2, 3]
+        assert t.update(_ss_frame(1.0)).shape == (0, 8)
+        laps = t.laps()
+        assert [len(x) for x, _ in laps] == [3, 6] and int((laps[0][0] >= 0).sum()) == 0 and int((laps[1][0] >= 0).sum()) == 3
+        assert t.dump_states().shape[0] == 0
+        assert t.update(_ss_frame(2.0)).shape == (0, 8)
+        assert list(t.dump_states()[:, 0]) == [4, 5, 6]
+    finally:
+        if old is not None:
+            os.environ["GITHUB_ACTIONS"] = old
+
+
+def test_strongsort_as_its_ci_runs_it(orc):
+    """GITHUB_ACTIONS=true (strongsort.cpp:61-76): tracks are Confirmed at birth. Frame 1 emits them already (confirmed, time_since_update 0:
+    :976-994); frame 2 matches them in the appearance stage through the sample library (one sample each after frame 1) and the boxes follow
+    the detections; a detection below min_conf is dropped and det_ind keeps the caller's row numbers (:873-877). Stage A leaves NO detection
+    unmatched here, and an empty list means "all detections" to the IoU stage (:362-365): track 2 (unmatched, time_since_update 1) is compared
+    with both detections again, matches neither, and the IoU stage's unmatched detections — the two stage A had already matched — start the
+    new tracks 4 and 5 (:765-776, :613-616), confirmed at birth and therefore emitted at once."""
+    import os
+    old = os.environ.get("GITHUB_ACTIONS")
+    os.environ["GITHUB_ACTIONS"] = "true"
+    try:
+        t = orc.tracker(orclib.STRONGSORT)
+        e = np.eye(3, 8, dtype=np.float32) + 0.01
+        o1 = t.update(_ss_frame(), e)
+        assert o1.shape == (3, 8) and list(o1[:, 4]) == [1, 2, 3] and list(o1[:, 7]) == [0, 1, 2]
+        d2 = _ss_frame(2.0)
+        d2[1, 4] = 0.05
+        o2 = t.update(d2, e)
+        laps = t.laps()
+        assert len(laps[0][0]) == 3 and len(laps[0][1]) == 2 and list(laps[0][0]) == [0, -1, 1]  # stage A: tracks 1 and 3 find their detections
+        assert list(o2[:, 4]) == [1, 3, 4, 5] and list(o2[:, 7]) == [0, 2, 0, 2]
+        assert len(laps) == 2 and len(laps[1][0]) == 1 and len(laps[1][1]) == 2 and list(laps[1][0]) == [-1]
+        assert abs(o2[0, 0] - 102.0) < 1.0 and o2[0, 2] - o2[0, 0] > 45  # the NSA update pulls the box onto the detection
+        t.reset()
+        assert t.update(_ss_frame(), e)[0, 4] == 1  # Tracker::reset :812-816: ids restart
+    finally:
+        if old is None:
+            os.environ.pop("GITHUB_ACTIONS", None)
+        else:
+            os.environ["GITHUB_ACTIONS"] = old

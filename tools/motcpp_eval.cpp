@@ -1,7 +1,7 @@
 // MOT evaluation driver for the MI355X-backed trackers. Command-line contract (positional arguments, defaults, one
 // <sequence>.txt per sequence in MOT format) follows the reference's tools/motcpp_eval.cpp:19-468; the program itself is
 // organised differently: a tracker table, a frame plan per sequence, then one loop. Trackers built here: sort, bytetrack,
-// ocsort, botsort, deepocsort. Images are never decoded: trackers get a blank frame of the sequence's size.
+// ocsort, botsort, deepocsort, strongsort. Images are never decoded: trackers get a blank frame of the sequence's size.
 #include <algorithm>
 #include <filesystem>
 #include <fstream>
@@ -43,6 +43,11 @@ const std::map<std::string, std::function<TrackerPtr(int)>>& tracker_table() {
        [](int) {
          return TrackerPtr(new T::DeepOCSort("", false, false, 0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 3, 0.2f, 0.5f, 0.95f, 0.5f,
                                              true, true, true));
+       }},
+      // strongsort.yaml's values (motcpp_eval.cpp:196-219); the features of a pre-generated embedding file when the command line names one
+      {"strongsort",
+       [](int) {
+         return TrackerPtr(new T::StrongSORT("", false, false, 0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 0.6f, 0.4f, 0.7f, 3, 100, 0.98f, 0.9f));
        }},
   };
   return table;

@@ -593,6 +593,38 @@ def main():
                             "(object motion stays continuous; velocities flip at the turning points), two frames in flight as in the timed "
                             "region; a step over 1.5x the median = a launch of the exact assignment kernel for a problem the sparse "
                             "solver declined (a non-unique optimum), which the whole sub-batch waits for"}
+    # ---- outputs_resident: the same frames with the tables LEFT on the device (a consumer on the GPU / the RCCL gather reads them there) ----
+    outputs_resident = None
+    if in_flight and on_device and world == 1 and not heavy and F - Z >= 8:
+        nres = min(60, LR if LR > 0 else 60)
+        fr = [Z + (k % (F - Z)) for k in range(nres)]
+
+        def enq_r(f):
+            for p in range(PIPE):
+                dp = dev_dets.data_ptr() + (f * S + bounds[p]) * 6 * M * 4
+                if tracker == "botsort":
+                    batches[p].enqueue_packed(dp, full_counts[p], rows_cap[p], embs_ptr=(dev_embs.data_ptr() + (f * S + bounds[p]) * M * D * 4) if D else None)
+                else:
+                    batches[p].enqueue_packed(dp, full_counts[p], rows_cap[p])
+
+        def col_r():
+            for p in range(PIPE):
+                tot_p[p] = batches[p].collect_packed(None, cnt_all[bounds[p]:bounds[p + 1]])
+        torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()
+        tr0 = time.perf_counter()
+        enq_r(fr[0])
+        for f in fr[1:]:
+            enq_r(f)
+            col_r()
+        col_r()
+        torch.cuda.synchronize()
+        tr1 = time.perf_counter()
+        gc.enable()
+        outputs_resident = {"value": S * nres / (tr1 - tr0), "unit": "frames/s (this rank)", "steps": nres, "ms_per_step": (tr1 - tr0) / nres * 1e3,
+                            "note": "same trackers after the long run, mot_*_collect_packed(rows = NULL): per-stream row counts come back, the packed "
+                                    "tables stay in HBM (mot_*_device_output) — what a pipeline whose consumer is on the GPU pays; never the headline value"}
     # ---- S-sweep: the same lifecycle with fewer streams, down to ONE stream (the latency of a single tracker.update()) ----
     sweep = None
     sweep_list = [int(x) for x in (args.sweep_streams if args.sweep_streams is not None else ("" if heavy else "1,64,1024")).split(",") if x.strip()]
@@ -864,7 +896,7 @@ def main():
         "kernels": kernels,
         "lap_fast_path": fast_stats,
         "kernels_isolated": isolated,
-        "long_run": long_run, "stream_sweep": sweep,
+        "long_run": long_run, "outputs_resident": outputs_resident, "stream_sweep": sweep,
         "achieved_problem_sizes": achieved_dims, "host_input": host_input,
         "gpu_busy_frac": gpu_busy_ms / (elapsed * 1e3) if elapsed > 0 else None,
         "flushes_per_step": (c1["flushes"] - c0["flushes"]) / K, "launches_per_step": (c1["launches"] - c0["launches"]) / K,

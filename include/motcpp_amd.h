@@ -379,7 +379,8 @@ int mot_bt_device_output(mot_bt_batch* b, const float** d_rows, const int** d_of
  * stay unmodified until the matching collect has returned, i.e. a caller with two frames in flight needs two input buffers);
  * mot_bt_collect_packed waits for the OLDEST pending frame only and delivers its
  * packed rows (copied on a second stream while the next frame runs); MOT_ERR_CAPACITY when the frame has more rows than the rows_cap
- * of ITS enqueue call or of this collect call. Frames come back in the order they went in; mixing with mot_bt_step /
+ * of ITS enqueue call or of this collect call. rows == NULL: nothing is copied — the frame's table stays on the device, where
+ * mot_bt_device_output finds it (a consumer on the GPU, or the RCCL gather, reads it there). Frames come back in the order they went in; mixing with mot_bt_step /
  * mot_bt_step_packed while frames are pending is an error (MOT_ERR_INVALID); mot_bt_reset drops the frames still pending. */
 int mot_bt_enqueue_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts, int rows_cap);
 int mot_bt_collect_packed(mot_bt_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows);

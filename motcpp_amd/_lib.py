@@ -582,7 +582,8 @@ class DeviceByteTrack:
         """wait for the oldest pending frame and fetch its packed rows (mot_bt_collect_packed); returns the number of rows"""
         total = C.c_int(0)
         self.lib.mot_bt_collect_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        self.ctx._chk(self.lib.mot_bt_collect_packed(self.h, _p(rows), int(rows.shape[0]), _p(out_counts), C.byref(total)))
+        self.ctx._chk(self.lib.mot_bt_collect_packed(self.h, _p(rows) if rows is not None else None, int(rows.shape[0]) if rows is not None else 0,
+                                                     _p(out_counts), C.byref(total)))  # rows None: the table stays on the device
         return total.value
 
     def device_output(self):
@@ -695,7 +696,8 @@ class DeviceBotSort:
         """wait for the oldest pending frame and fetch its packed rows (mot_bot_collect_packed); returns the number of rows"""
         total = C.c_int(0)
         self.lib.mot_bot_collect_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        self.ctx._chk(self.lib.mot_bot_collect_packed(self.h, _p(rows), int(rows.shape[0]), _p(out_counts), C.byref(total)))
+        self.ctx._chk(self.lib.mot_bot_collect_packed(self.h, _p(rows) if rows is not None else None, int(rows.shape[0]) if rows is not None else 0,
+                                                     _p(out_counts), C.byref(total)))  # rows None: the table stays on the device
         return total.value
 
     def step(self, dets, counts, embs=None, warps=None, has_warp=None):
@@ -797,7 +799,8 @@ class DeviceOCSort:
         """wait for the oldest pending frame and fetch its packed rows (mot_oc_collect_packed); returns the number of rows"""
         total = C.c_int(0)
         self.lib.mot_oc_collect_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        self.ctx._chk(self.lib.mot_oc_collect_packed(self.h, _p(rows), int(rows.shape[0]), _p(out_counts), C.byref(total)))
+        self.ctx._chk(self.lib.mot_oc_collect_packed(self.h, _p(rows) if rows is not None else None, int(rows.shape[0]) if rows is not None else 0,
+                                                     _p(out_counts), C.byref(total)))  # rows None: the table stays on the device
         return total.value
 
     def step(self, dets, counts):
@@ -913,7 +916,8 @@ class DeviceSort:
         """wait for the oldest pending frame and fetch its packed rows (mot_sort_collect_packed); returns the number of rows"""
         total = C.c_int(0)
         self.lib.mot_sort_collect_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        self.ctx._chk(self.lib.mot_sort_collect_packed(self.h, _p(rows), int(rows.shape[0]), _p(out_counts), C.byref(total)))
+        self.ctx._chk(self.lib.mot_sort_collect_packed(self.h, _p(rows) if rows is not None else None, int(rows.shape[0]) if rows is not None else 0,
+                                                     _p(out_counts), C.byref(total)))  # rows None: the table stays on the device
         return total.value
 
     def device_output(self):

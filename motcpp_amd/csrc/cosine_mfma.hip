@@ -4,11 +4,11 @@
 // f32 accumulate, which on CDNA4 is bit-for-bit a k-ordered fmaf chain (one rounding per product, no wider accumulator).
 // That is the property that keeps this kernel inside the 1e-4 budget without any fp16/bf16 rounding of the embeddings (and
 // bit-identical to the CPU restatement, whose dot products are that same chain).
-// Workgroup = 4 wavefronts = 64 x 64 output tile (2 x 2 MFMA tiles of 32 x 32); K is walked in slabs of 32 through LDS
-// (row stride 33 floats: the MFMA operand read, lane -> (row = lane & 31, k = lane >> 5), is conflict-free). The next slab
-// is already in flight (two 16-byte loads per matrix per thread, held in registers) while the 16 chained MFMAs of the current
-// one run; the row norms are accumulated from the same LDS slabs — lane l < 32 of wavefront w owns row 32 w + l of the
-// 128 rows of the tile pair and extends its k-ordered chain by the slab's 32 entries — so no separate pass reads the
+// Workgroup = 4 wavefronts = 128 x 128 output tile (each wavefront 2 x 2 MFMA tiles of 32 x 32; 64 x 64 for problems with fewer than
+// 128 rows or columns); K is walked in slabs of 32 through TWO LDS buffers (row stride 36 floats, the slab's even ks first, then the
+// odd ks: the four operands a lane needs for four consecutive MFMA steps are one ds_read_b128, conflict-free), one barrier per slab;
+// the next slab's global loads are issued a slab ahead and stay in flight across the 64 chained MFMAs of the current one; the row
+// norms are accumulated from the same LDS slabs (k-ordered fmaf chains, one row per lane) — so no separate pass reads the
 // features again. dot: the raw inner product (DeepOC-SORT's embedding similarity, deepocsort.cpp:404) — same kernel, no
 // norms. euclidean (matching.cpp:93-101): |a_i - b_j|, a k-ordered chain of squared differences on the vector ALUs (it is
 // not a contraction) over the same slabs.

@@ -241,9 +241,8 @@ hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, i
   // LDS per problem decides how many problems a CU holds (160 KB: 5 at 32 KB, 4 at 40 KB, 3 at 53 KB): the pair list takes what is left of
   // the step the launch lands on anyway — a problem whose list overflows goes to the exact solver, milliseconds instead of microseconds
   if (lds) {
-    static const size_t steps[] = {160 * 1024 / 6, 160 * 1024 / 5, 160 * 1024 / 4, 160 * 1024 / 3, kBudget};
-    for (size_t lim : steps) {
-      const size_t cap = (lim < kBudget ? lim : kBudget) & ~size_t(63);
+    for (int k = 32; k >= 1; --k) {  // the finest step the launch already fits: k problems per CU
+      const size_t cap = ((static_cast<size_t>(160) * 1024 / k) < kBudget ? (static_cast<size_t>(160) * 1024 / k) : kBudget) & ~size_t(63);
       if (hot <= cap) {
         const int more = static_cast<int>((cap - hot) / 6) - 4;  // (6 bytes per entry; the two arrays round up to 16 bytes each)
         if (more > 0) { ecap += more; hot = kScratch + sparse_hot_bytes(n, m, ecap); }

@@ -487,13 +487,14 @@ int mot_sort_enqueue_packed(mot_sort_batch* b, const float* d_dets, const int* h
   return sort_enqueue_flight(b, d_dets, h_counts, rows_cap, nullptr);
 }
 int mot_sort_collect_packed(mot_sort_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows) {
-  if (!b || !rows || !out_counts) return MOT_ERR_INVALID;
+  if (!b || !out_counts) return MOT_ERR_INVALID;  // rows == NULL: the table stays on the device (mot_sort_device_output), only the counts come back
   mot::lifecycle::Flight* F = nullptr;
   int total = 0;
   const int rc = sort_pop_flight(b, &F, &total);
   if (F) std::memcpy(out_counts, b->flights.counts_of(*F), sizeof(int) * b->S);
   if (total_rows) *total_rows = total;
   if (rc != MOT_OK) return rc;
+  if (!rows) return MOT_OK;
   if (total > rows_cap) { b->ctx->err = "mot_sort_collect_packed: more rows than rows_cap"; return MOT_ERR_CAPACITY; }
   MOT_LC_HIP(b, b->flights.copy_rows(*F, rows, total));
   return MOT_OK;

@@ -296,6 +296,34 @@ int main() {
     try { Eigen::MatrixXf w(3, 3); off.set_camera_motion(w); } catch (const std::invalid_argument&) { threw = true; }
     CHECK(threw);
   }
+  {  // the remaining cases of the reference's gtest files (tests/test_sort.cpp:87-126, tests/test_trackers.cpp:107-135, tests/test_bytetrack.cpp:38-123)
+    Sort hi(0.3f, 3, 50, 1, 0.9f);  // IoUThreshold: a far detection does not match, a new track (id 2) is the one reported
+    hi.update(single, img);
+    auto far = hi.update(dets1(300, 300, 400, 400, 0.9f, 0), img);
+    CHECK(far.rows() == 1 && static_cast<int>(far(0, 4)) == 2);
+    Sort pc(0.3f, 3, 50, 1, 0.3f, true, 80);  // MultiClassTracking
+    CHECK(pc.update(multi, img).cols() == 8);
+    Eigen::MatrixXf low(2, 6);
+    low << 100, 100, 200, 200, 0.3f, 0, 300, 300, 400, 400, 0.6f, 0;
+    Sort cf(0.5f, 3, 50, 1);  // ConfidenceFiltering
+    CHECK(cf.update(low, img).rows() <= 1);
+    ByteTrack bl(0.5f);  // TrackerWithLowConfidenceDetections
+    CHECK(bl.update(low, img).rows() <= 1);
+    OCSort oc;  // OCSortUpdateReturnsValidOutput
+    CHECK(oc.update(multi, img).cols() == 8);
+    ByteTrack two(0.1f, 30, 50, 1, 0.3f, false, 80, "iou", false, 0.1f, 0.45f, 0.8f, 30, 30);  // TwoStageAssociation
+    Eigen::MatrixXf mixed(3, 6);
+    mixed << 100, 100, 200, 200, 0.9f, 0, 300, 300, 400, 400, 0.3f, 0, 500, 100, 600, 200, 0.6f, 1;
+    CHECK(two.update(mixed, img).cols() == 8);
+    ByteTrack thr(0.1f, 30, 50, 1, 0.3f, false, 80, "iou", false, 0.1f, 0.6f);  // TrackThresholdFiltering
+    CHECK(thr.update(mixed, img).cols() == 8);
+    ByteTrack rec(0.3f, 30, 50, 1, 0.3f, false, 80, "iou", false, 0.1f, 0.45f, 0.8f, 30, 30);  // LostTrackRecovery: kept through the second stage
+    auto r1 = rec.update(single, img);
+    auto r2 = rec.update(dets1(100, 100, 200, 200, 0.3f, 0), img);
+    CHECK(r1.rows() == 1 && r2.rows() == 1 && r1(0, 4) == r2(0, 4) && r2(0, 5) == 0.3f);
+    ByteTrack f60(0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 0.1f, 0.45f, 0.8f, 30, 60);  // FrameRateAwareness
+    CHECK(f60.update(single, img).cols() == 8);
+  }
   {  // StrongSORT (strongsort.hpp:294-312): the reference's constructor signature; embeddings come with update(). From a cold start the
      // tracks stay tentative (the reference's matching as written, see csrc/host/strongsort.cpp): tables have 8 columns and may be empty.
     StrongSORT t;

@@ -553,3 +553,45 @@ def test_strongsort_as_its_ci_runs_it(orc):
             os.environ.pop("GITHUB_ACTIONS", None)
         else:
             os.environ["GITHUB_ACTIONS"] = old
+
+
+# ---- the remaining cases of the reference's gtest files (round 4: every case that asserts something about this path is mirrored) ----
+def test_sort_iou_threshold_and_multi_class(orc):  # tests/test_sort.cpp:87-110
+    t = orc.tracker(orclib.SORT, [0.3, 3, 50, 1, 0.9])  # a very high IoU threshold
+    t.update(SINGLE)
+    far = np.array([[300, 300, 400, 400, 0.9, 0]], np.float32)
+    out = t.update(far)
+    # "Should not match due to low IoU, creates new track. Both tracks exist but old one not output (not updated)"
+    assert out.shape == (1, 8) and out[0, 4] == 2 and t.dump_states().shape[0] == 2
+    t = orc.tracker(orclib.SORT, [0.3, 3, 50, 1, 0.3])  # MultiClassTracking (:87-94; per_class is accepted and ignored by Sort::update)
+    assert t.update(MULTI).shape[1] == 8
+
+
+def test_low_confidence_detections(orc):  # tests/test_trackers.cpp:121-135, tests/test_sort.cpp:112-126
+    low = np.array([[100, 100, 200, 200, 0.3, 0], [300, 300, 400, 400, 0.6, 0]], np.float32)
+    # ByteTrack(det_thresh 0.5): track_thresh stays 0.45, the 0.3 detection only enters the second association -> at most one row
+    out = orc.tracker(orclib.BYTETRACK).update(low)
+    assert out.shape[0] <= 1 and (out.shape[0] == 0 or out[0, 7] == 1)
+    assert orc.tracker(orclib.OCSORT).update(MULTI).shape[1] == 8  # OCSortUpdateReturnsValidOutput :113-119
+
+
+def test_bytetrack_gtest_cases(orc):  # tests/test_bytetrack.cpp:38-123
+    mixed = np.array([[100, 100, 200, 200, 0.9, 0], [300, 300, 400, 400, 0.3, 0], [500, 100, 600, 200, 0.6, 1]], np.float32)
+    assert orc.tracker(orclib.BYTETRACK, [0.1, 0.45, 0.8, 30, 30]).update(mixed).shape[1] == 8  # TwoStageAssociation
+    assert orc.tracker(orclib.BYTETRACK, [0.1, 0.6, 0.8, 25, 30]).update(mixed).shape[1] == 8   # TrackThresholdFiltering
+    t = orc.tracker(orclib.BYTETRACK, [0.1, 0.45, 0.8, 30, 30])                                   # LostTrackRecovery
+    d1 = np.array([[100, 100, 200, 200, 0.9, 0]], np.float32)
+    d2 = np.array([[100, 100, 200, 200, 0.3, 0]], np.float32)
+    o1, o2 = t.update(d1), t.update(d2)
+    # "ByteTrack should still maintain the track using second stage association with low confidence detections": same id, det_ind 0
+    assert o1.shape[0] == 1 and o2.shape[0] == 1 and o2[0, 4] == o1[0, 4] and o2[0, 5] == np.float32(0.3)
+    t = orc.tracker(orclib.BYTETRACK)                                                             # ScoreDecay
+    for _ in range(3):
+        t.update(SINGLE)
+    for _ in range(5):
+        # (with NO detection in the frame the reference returns before the tracked list is touched: the track keeps being reported,
+        # bytetrack.cpp:455-542 — DESIGN.md section 5 lists the quirk)
+        assert t.update(EMPTY).shape == (1, 8)
+    assert t.dump_states().shape[0] == 1
+    for fps in (30, 60):                                                                            # FrameRateAwareness
+        assert orc.tracker(orclib.BYTETRACK, [0.1, 0.45, 0.8, 30, fps]).update(SINGLE).shape[1] == 8

@@ -22,7 +22,6 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kSlab = 32;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -32,10 +31,12 @@ enum { kCosine = 0, kDot = 1, kEuclid = 2 };
 // 64 x 64 = 2 x 2 MFMA tiles — four independent accumulator chains per wavefront, one LDS operand read per MFMA instead of two,
 // and half the feature bytes per flop out of L2 (each row tile is re-read once per column tile of the problem: at 64 x 64 the
 // fp32 MFMA rate would need ~10 TB/s of L2 reads). Every output element is still the k-ordered chain of its own products.
-template <int METRIC, int TILE>
+template <int METRIC, int TILE, int kSlab>
 __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __restrict__ tasks, int tiles_x, int tiles_y) {
   constexpr int TPR = kThreads / TILE;  // threads staging one row of a slab
-  constexpr int QPT = 8 / TPR;          // 16-byte pieces of a slab row per thread
+  constexpr int QPT = (kSlab / 4) / TPR;  // 16-byte pieces of a slab row per thread
+  constexpr int kHalf = kSlab / 2;      // the slab's even ks, then its odd ks
+  static_assert(QPT >= 1 && (kSlab == 16 || kSlab == 32), "slab width");
   constexpr int NA = TILE / 64;         // MFMA tiles per wavefront and dimension
   static_assert(METRIC != kEuclid || TILE == 64, "the euclidean variant keeps the 64 x 64 tile");
   // XCD-aware order of the 1-D grid: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own L2.
@@ -111,9 +112,9 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
     for (int h = 0; h < QPT; ++h) {
       const int k = 4 * (h * TPR + sq);
       *reinterpret_cast<float2*>(&As[buf][sr][k >> 1]) = make_float2(ra[h].x, ra[h].z);
-      *reinterpret_cast<float2*>(&As[buf][sr][16 + (k >> 1)]) = make_float2(ra[h].y, ra[h].w);
+      *reinterpret_cast<float2*>(&As[buf][sr][kHalf + (k >> 1)]) = make_float2(ra[h].y, ra[h].w);
       *reinterpret_cast<float2*>(&Bs[buf][sr][k >> 1]) = make_float2(rb[h].x, rb[h].z);
-      *reinterpret_cast<float2*>(&Bs[buf][sr][16 + (k >> 1)]) = make_float2(rb[h].y, rb[h].w);
+      *reinterpret_cast<float2*>(&Bs[buf][sr][kHalf + (k >> 1)]) = make_float2(rb[h].y, rb[h].w);
     }
   };
   const int wr = wave >> 1, wc = wave & 1;  // wavefront -> (TILE/2) x (TILE/2) sub-tile
@@ -143,9 +144,9 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
           float sacc = acc[0][0][j];
           const int cc = sq + 4 * j;
   #pragma unroll
-          for (int g = 0; g < 4; ++g) {  // even and odd halves by 16-byte reads (the same access type as the stores: float vectors), k order
-            const float4 ae = *reinterpret_cast<const float4*>(&As[buf][sr][4 * g]), ao = *reinterpret_cast<const float4*>(&As[buf][sr][16 + 4 * g]);
-            const float4 be = *reinterpret_cast<const float4*>(&Bs[buf][cc][4 * g]), bo = *reinterpret_cast<const float4*>(&Bs[buf][cc][16 + 4 * g]);
+          for (int g = 0; g < kSlab / 8; ++g) {  // even and odd halves by 16-byte reads (the same access type as the stores: float vectors), k order
+            const float4 ae = *reinterpret_cast<const float4*>(&As[buf][sr][4 * g]), ao = *reinterpret_cast<const float4*>(&As[buf][sr][kHalf + 4 * g]);
+            const float4 be = *reinterpret_cast<const float4*>(&Bs[buf][cc][4 * g]), bo = *reinterpret_cast<const float4*>(&Bs[buf][cc][kHalf + 4 * g]);
             float df;
             df = ae.x - be.x; sacc = __builtin_fmaf(df, df, sacc); df = ao.x - bo.x; sacc = __builtin_fmaf(df, df, sacc);
             df = ae.y - be.y; sacc = __builtin_fmaf(df, df, sacc); df = ao.y - bo.y; sacc = __builtin_fmaf(df, df, sacc);
@@ -158,17 +159,17 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
         if (METRIC == kCosine && norm_lane) {
           const float* rowp = (q < TILE) ? As[buf][q] : Bs[buf][q - TILE];
   #pragma unroll
-          for (int g = 0; g < 4; ++g) {  // even and odd halves by 16-byte reads, consumed in k order
-            const float4 ev = *reinterpret_cast<const float4*>(rowp + 4 * g), od = *reinterpret_cast<const float4*>(rowp + 16 + 4 * g);
+          for (int g = 0; g < kSlab / 8; ++g) {  // even and odd halves by 16-byte reads, consumed in k order
+            const float4 ev = *reinterpret_cast<const float4*>(rowp + 4 * g), od = *reinterpret_cast<const float4*>(rowp + kHalf + 4 * g);
             nsum = __builtin_fmaf(ev.x, ev.x, nsum); nsum = __builtin_fmaf(od.x, od.x, nsum);
             nsum = __builtin_fmaf(ev.y, ev.y, nsum); nsum = __builtin_fmaf(od.y, od.y, nsum);
             nsum = __builtin_fmaf(ev.z, ev.z, nsum); nsum = __builtin_fmaf(od.z, od.z, nsum);
             nsum = __builtin_fmaf(ev.w, ev.w, nsum); nsum = __builtin_fmaf(od.w, od.w, nsum);
           }
         }
-        const int hoff = 16 * (lane >> 5);
+        const int hoff = kHalf * (lane >> 5);
   #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // four MFMA steps per 16-byte operand read; k-ascending chain: D = fma(a_k1,b_k1, fma(a_k0,b_k0, C))
+        for (int g = 0; g < kSlab / 8; ++g) {  // four MFMA steps per 16-byte operand read; k-ascending chain: D = fma(a_k1,b_k1, fma(a_k0,b_k0, C))
           float4 a4[NA], b4[NA];
   #pragma unroll
           for (int i = 0; i < NA; ++i) {
@@ -250,11 +251,16 @@ hipError_t launch_embed(int metric, const mot_cos_task* tasks, int ntasks, int m
   const long long nblk = static_cast<long long>(tx) * ty * ntasks;
   if (nblk > 0x7fffffffll) return hipErrorInvalidValue;
   const dim3 g1(static_cast<unsigned>(nblk));
-  if (metric == kCosine && big) hipLaunchKernelGGL((embed_kernel<kCosine, 128>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
-  else if (metric == kCosine) hipLaunchKernelGGL((embed_kernel<kCosine, 64>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
-  else if (metric == kDot && big) hipLaunchKernelGGL((embed_kernel<kDot, 128>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
-  else if (metric == kDot) hipLaunchKernelGGL((embed_kernel<kDot, 64>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
-  else if (metric == kEuclid) hipLaunchKernelGGL((embed_kernel<kEuclid, 64>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
+  // 128 x 128 tiles walk K in slabs of 16 (41 KB of LDS: three workgroups per CU, so that one's epilogue and prologue hide behind the
+  // others' MFMAs; slabs of 32 take 74 KB: two per CU. MOT_EMBED_SLAB=32 selects them, for A/B measurements)
+  static const int slab_big = (std::getenv("MOT_EMBED_SLAB") && std::atoi(std::getenv("MOT_EMBED_SLAB")) == 32) ? 32 : 16;
+  if (metric == kCosine && big && slab_big == 16) hipLaunchKernelGGL((embed_kernel<kCosine, 128, 16>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
+  else if (metric == kCosine && big) hipLaunchKernelGGL((embed_kernel<kCosine, 128, 32>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
+  else if (metric == kCosine) hipLaunchKernelGGL((embed_kernel<kCosine, 64, 32>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
+  else if (metric == kDot && big && slab_big == 16) hipLaunchKernelGGL((embed_kernel<kDot, 128, 16>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
+  else if (metric == kDot && big) hipLaunchKernelGGL((embed_kernel<kDot, 128, 32>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
+  else if (metric == kDot) hipLaunchKernelGGL((embed_kernel<kDot, 64, 32>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
+  else if (metric == kEuclid) hipLaunchKernelGGL((embed_kernel<kEuclid, 64, 32>), g1, dim3(kThreads), 0, st, tasks, tx, ty);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -381,7 +381,10 @@ int mot_bt_device_output(mot_bt_batch* b, const float** d_rows, const int** d_of
  * packed rows (copied on a second stream while the next frame runs); MOT_ERR_CAPACITY when the frame has more rows than the rows_cap
  * of ITS enqueue call or of this collect call. rows == NULL: nothing is copied — the frame's table stays on the device, where
  * mot_bt_device_output finds it (a consumer on the GPU, or the RCCL gather, reads it there). Frames come back in the order they went in; mixing with mot_bt_step /
- * mot_bt_step_packed while frames are pending is an error (MOT_ERR_INVALID); mot_bt_reset drops the frames still pending. */
+ * mot_bt_step_packed while frames are pending is an error (MOT_ERR_INVALID); mot_bt_reset drops the frames still pending (and, like
+ * ByteTrack::reset, keeps the id counters running: clear_count() is empty in the reference — same for mot_oc_reset, mot_sort_reset;
+ * mot_bot_reset restarts them). A frame whose table does not fit the enqueue call's rows_cap, or the collect call's buffer, is reported
+ * by the collect (MOT_ERR_CAPACITY) and consumed; the tracks are not affected (tests/test_gpu_inflight_misuse.py). */
 int mot_bt_enqueue_packed(mot_bt_batch* b, const float* d_dets, const int* h_counts, int rows_cap);
 int mot_bt_collect_packed(mot_bt_batch* b, float* rows, int rows_cap, int* out_counts, int* total_rows);
 /* parity hook: ids and Kalman states of stream s's live tracks in list order (active then lost): ids [cap], mean [cap][8],

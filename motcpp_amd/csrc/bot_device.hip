@@ -648,7 +648,8 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
                        float* d_packed, int* d_offsets, int rows_cap, hipEvent_t* ev, const mot::lifecycle::FrameDev* fd = nullptr) {
   hipStream_t st = b->ctx->stream;
   const int S = b->S, CAP = b->CAP, D = b->D;
-  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 256 * sizeof(int), st));
+  if (!b->flights.maxt_clean) MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 256 * sizeof(int), st));  // (else: the last frame's pack_offsets cleared them)
+  b->flights.maxt_clean = false;
   int bd = 1;
   for (int s = 0; s < S; ++s) bd = (h_counts[s] > bd) ? h_counts[s] : bd;
   if (bd > D) bd = D;

@@ -65,6 +65,8 @@ struct BtStream {
 
 
 constexpr int kAF = 256;
+constexpr int kAFMax = 1024;  // a handful of streams (one camera): the list kernels run with up to 16 wavefronts per stream - the chip is empty
+                              // anyway and a frame is a chain of dependent launches, so each one's latency is the frame's
 struct Compact3 {  // three order-preserving appends of one round, one exchange
   int pos[3];
 };
@@ -87,11 +89,13 @@ __device__ __forceinline__ Compact3 compact3_block(bool p0, bool p1, bool p2, in
 }
 // ---- K0: detection split, pools, predict + first-association tasks (bytetrack.cpp:166-265) ----
 // stats[0] = assignment problems queued, stats[1] = sum of their n + m (algorithmic bytes of the solver: 24 B per row/column)
-__global__ void __launch_bounds__(kAF) bt_begin(BtStream* streams, BtParams P, int CAP, int D, FrameDev FD, const float* dets_base,
-                                                 mot_det_task* det_t, mot_kf_task* pred_t, mot_lap_task* lap1_t, unsigned long long* stats, int* maxt) {
-  __shared__ int cnt[kAF / 64][3];
+__global__ void __launch_bounds__(kAFMax) bt_begin(BtStream* streams, BtParams P, int CAP, int D, FrameDev FD, const float* dets_base,
+                                                 mot_det_task* det_t, mot_kf_task* pred_t, mot_lap_task* lap1_t, unsigned long long* stats, int* maxt,
+                                                 int* declined) {
+  __shared__ int cnt[kAFMax / 64][3];
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
+  if (blockIdx.x == 0 && t == 0) *declined = 0;  // the counter of the assignment launch behind this kernel (mot::launch_lap, prezeroed)
   const int n = FD.counts[blockIdx.x];
   if (n < 0) {  // not this stream's frame: nothing of its state moves, every task it owns is empty
     if (t == 0) {
@@ -168,11 +172,12 @@ __global__ void __launch_bounds__(kAF) bt_begin(BtStream* streams, BtParams P, i
 // Four wavefronts per stream (round 3; one wavefront walked the 1000-row pool in 16 dependent rounds: 215 us per launch at the
 // north-star shape). The lists stay in the reference's order: an append position = entries before this round + entries of the earlier
 // wavefronts of the round + the lane's rank inside its wavefront (ballot + popcount); the wavefronts' counts meet in LDS.
-__global__ void __launch_bounds__(kAF) bt_after_first(BtStream* streams, BtParams P, int CAP, mot_kf_task* box_t, mot_lap_task* lap23_t,
-                                                      unsigned long long* stats, int* maxt) {
-  __shared__ int cnt[kAF / 64][3];
+__global__ void __launch_bounds__(kAFMax) bt_after_first(BtStream* streams, BtParams P, int CAP, mot_kf_task* box_t, mot_lap_task* lap23_t,
+                                                      unsigned long long* stats, int* maxt, int* declined) {
+  __shared__ int cnt[kAFMax / 64][3];
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
+  if (blockIdx.x == 0 && t == 0) *declined = 0;
   if (S.skip) {
     if (t == 0) {
       box_t[2 * blockIdx.x + 0].n = 0; box_t[2 * blockIdx.x + 1].n = 0;
@@ -262,11 +267,11 @@ __global__ void __launch_bounds__(kAF) bt_after_first(BtStream* streams, BtParam
 }
 
 // ---- K2: apply associations 2 and 3, births, deaths, list algebra, queue the Kalman work (:442-580) ----
-__global__ void __launch_bounds__(kAF) bt_after_second(BtStream* streams, BtParams P, int CAP, mot_kf_task* init_t, mot_kf_task* upd_t,
+__global__ void __launch_bounds__(kAFMax) bt_after_second(BtStream* streams, BtParams P, int CAP, mot_kf_task* init_t, mot_kf_task* upd_t,
                                                        mot_kf_task* box2_t, mot_iou_task* dup_t, unsigned long long* stats) {
   // Four wavefronts per stream. The first part (second association, unconfirmed tracks, births) walks lists of a few dozen entries and
   // hands out slots in order: the first wavefront does it alone; the list algebra over the ~800 active tracks is shared by all four.
-  __shared__ int cnt[kAF / 64][3];
+  __shared__ int cnt[kAFMax / 64][3];
   __shared__ int sh[8];
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
@@ -458,10 +463,10 @@ __global__ void __launch_bounds__(kAF) bt_after_second(BtStream* streams, BtPara
 // box whose width is not a positive finite number visits everything. `verify` (MOT_BT_DUPS_VERIFY=1, tests): the full scan
 // runs as well and any pair it would mark outside the window raises the stream's error flag 3.
 template <int MODE>  // 0: lost boxes read from global, all pairs; 1: staged in LDS, sorted window; 2: staged in LDS, all pairs
-__global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP, int verify, int lds_items) {
+__global__ void __launch_bounds__(kAFMax) bt_dups(BtStream* streams, int CAP, int verify, int lds_items) {
   extern __shared__ __attribute__((aligned(16))) float sbox[];  // [nl] float4 boxes, [nl] sorted x1 keys, [nl] sorted indices, [nl] keys
   BtStream& S = streams[blockIdx.x];
-  const int na = S.n_active, nl = S.n_lost;
+  const int na = S.n_active, nl = S.n_lost, T = static_cast<int>(blockDim.x);
   if (S.skip || na <= 0 || nl <= 0) return;
   // the launch reserves LDS for lds_items lost boxes (far more than a stream usually has); a stream with more reads them from
   // global memory and tests every pair
@@ -471,26 +476,26 @@ __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP, int v
   int* si = reinterpret_cast<int*>(sx + nl);
   __shared__ int n_irr;
   if (MODE == 2 && staged) {
-    for (int j = threadIdx.x; j < nl; j += 256)
+    for (int j = threadIdx.x; j < nl; j += T)
       wl[j] = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
     __syncthreads();
   }
   if (MODE == 1 && staged) {
     if (threadIdx.x == 0) n_irr = 0;
-    for (int j = threadIdx.x; j < nl; j += 256)
+    for (int j = threadIdx.x; j < nl; j += T)
       wl[j] = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
     __syncthreads();
     // rank by (key, index) with key = x1, or -inf for a box with a non-finite coordinate: nl is a few hundred at most,
     // counting against the key array (one broadcast LDS read and three VALU operations per comparison) beats a sorting network
     float* key = reinterpret_cast<float*>(si + nl);
-    for (int j = threadIdx.x; j < nl; j += 256) {
+    for (int j = threadIdx.x; j < nl; j += T) {
       const float4 b = wl[j];
       const bool irr = !(fabsf(b.x) < 3.0e38f && fabsf(b.y) < 3.0e38f && fabsf(b.z) < 3.0e38f && fabsf(b.w) < 3.0e38f);
       key[j] = irr ? -3.4e38f : b.x;
       if (irr) atomicAdd(&n_irr, 1);
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < nl; j += 256) {
+    for (int j = threadIdx.x; j < nl; j += T) {
       const float kj = key[j];
       int rank = 0;
 #pragma unroll 8
@@ -503,7 +508,7 @@ __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP, int v
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < na; i += 256) {
+  for (int i = threadIdx.x; i < na; i += T) {
     const float a[4] = {S.abox[i], S.abox[static_cast<size_t>(CAP) + i], S.abox[static_cast<size_t>(2) * CAP + i], S.abox[static_cast<size_t>(3) * CAP + i]};
     const float area_a = (a[2] - a[0]) * (a[3] - a[1]);
     const int age_a = S.age_a[i];
@@ -557,12 +562,15 @@ __global__ void __launch_bounds__(256) bt_dups(BtStream* streams, int CAP, int v
 // ---- K3: duplicate removal and the output table (:582-621, :659-706) ----
 // Four wavefronts per stream (as bt_after_first): the lists are ~800 entries of dependent loads (slot, then the slot's fields), which one
 // wavefront walks in 13 rounds.
-__global__ void __launch_bounds__(kAF) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive) {
-  __shared__ int cnt[kAF / 64][3];
+__global__ void __launch_bounds__(kAFMax) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive, int* err) {
+  __shared__ int cnt[kAFMax / 64][3];
   BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
   if (S.skip) {  // its tracks still bound the next frame's launches
-    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_active + S.n_lost; atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost); }
+    if (t == 0) {
+      out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_active + S.n_lost; atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost);
+      if (S.err) atomicMax(err, S.err);
+    }
     return;
   }
   int* act = S.active[S.cur];
@@ -618,12 +626,9 @@ __global__ void __launch_bounds__(kAF) bt_finish(BtStream* streams, int CAP, flo
     // tracks alive after this frame: an exact upper bound of every problem side of the next frame (64 slots: no hot address)
     atomicMax(&max_tracks[blockIdx.x & 63], n_keep + n_keep_l);
     alive[blockIdx.x] = n_keep + n_keep_l;
+    const int e = S.err;  // the batch's error word (round 4: gathered here; a kernel of its own before — one launch of a frame's critical path)
+    if (e) atomicMax(err, e);
   }
-}
-
-__global__ void bt_collect_err(const BtStream* streams, int n, int* err) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && streams[i].err) atomicMax(err, streams[i].err);
 }
 
 }  // namespace
@@ -638,6 +643,7 @@ struct mot_bt_batch {
   std::vector<BtStream> h_streams;  // host mirror of the pointers (scalars are only valid on the device)
   int* d_counts = nullptr;
   int* d_err = nullptr;
+  int* d_decl = nullptr;  // [2] problems the sparse solver declined in the frame's two assignment launches (cleared by the kernel in front of each)
   int* d_maxt = nullptr;  // [4][64] per-frame maxima: tracks alive (bt_finish), pool rows of the first association (bt_begin), rows and
                           // columns of the second / unconfirmed associations (bt_after_first) — bounds and LDS hints of the next frame
   int hint1_n = 0, hint23_n = 0, hint23_m = 0;
@@ -676,12 +682,15 @@ void mot_bt_destroy(mot_bt_batch* b) {
   delete b;
 }
 
-int mot_bt_reset(mot_bt_batch* b) {
+int mot_bt_reset(mot_bt_batch* b) {  // ByteTrack::reset: the lists go, the id counter keeps counting (clear_count() is empty, bytetrack.hpp:38-40)
   // scalars back to zero; the arrays need no clearing (everything is rebuilt from the empty lists)
-  std::vector<BtStream> h = b->h_streams;
-  MOT_LC_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(BtStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
-  MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
   MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));  // (frames still in flight have finished by now: they are dropped with the tracks)
+  std::vector<BtStream> cur(b->S);
+  MOT_LC_HIP(b, hipMemcpy(cur.data(), b->d_streams, sizeof(BtStream) * b->S, hipMemcpyDeviceToHost));
+  std::vector<BtStream> h = b->h_streams;
+  for (int s = 0; s < b->S; ++s) h[s].next_id = cur[s].next_id;
+  MOT_LC_HIP(b, hipMemcpy(b->d_streams, h.data(), sizeof(BtStream) * b->S, hipMemcpyHostToDevice));
+  MOT_LC_HIP(b, hipMemset(b->d_err, 0, sizeof(int)));
   b->flights.drop_all();
   b->bound_n = 0; b->hint1_n = b->hint23_n = b->hint23_m = 0;
   return MOT_OK;
@@ -705,6 +714,7 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   b->d_streams = b->dalloc<BtStream>(S);
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
+  b->d_decl = b->dalloc<int>(2);
   b->d_maxt = b->dalloc<int>(256);
   b->d_alive = b->dalloc<int>(S);
   b->flights.n_maxt = 256; b->flights.with_alive = true;
@@ -719,7 +729,7 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   const size_t wb1 = (mot::lap_scratch_bytes(CAP, D) + 255) & ~size_t(255);
   char* work = b->dalloc<char>(wb1 * 3 * S);
   int* info = b->dalloc<int>(static_cast<size_t>(4) * 3 * S);
-  if (!ip || !fp || !bp || !b->mean || !b->d_streams || !b->d_counts || !b->d_err || !b->d_alive || !b->d_maxt || !b->det_t || !b->pred_t || !b->box_t ||
+  if (!ip || !fp || !bp || !b->mean || !b->d_streams || !b->d_counts || !b->d_err || !b->d_decl || !b->d_alive || !b->d_maxt || !b->det_t || !b->pred_t || !b->box_t ||
       !b->init_t || !b->upd_t || !b->box2_t || !b->lap1_t || !b->lap23_t || !b->dup_t || !work || !info) {
     mot_bt_destroy(b);
     return MOT_ERR_NOMEM;
@@ -814,7 +824,8 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
     MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, h_counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
     FD.counts = b->d_counts;
   }
-  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 256 * sizeof(int), st));
+  if (!b->flights.maxt_clean) MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 256 * sizeof(int), st));  // (else: the last frame's pack_offsets cleared them)
+  b->flights.maxt_clean = false;
   // Launch bounds (grid sizes, the solver's LDS layout and variant) from exact upper bounds instead of the capacities:
   // no side of any problem of this frame exceeds the tracks alive after the previous frame (bn) / this frame's detections (bd)
   int bd = 1;
@@ -824,18 +835,22 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;  // lists after this frame's births
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
   // four wavefronts per stream once the lists are long enough to share (short lists: the extra wavefronts only add barriers; 256 x 128: 8.2 M against 8.8 M frames/s)
-  const int bt_threads = ((bn > bd ? bn : bd) > 384) ? kAF : kW;
-  hipLaunchKernelGGL(bt_begin, dim3(S), dim3(bt_threads), 0, st, b->d_streams, b->prm, CAP, D, FD, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr, b->d_maxt);
+  const int longest = bn > bd ? bn : bd;
+  int active = 0;  // streams with a frame (the pooled form runs the whole segment's grid; a single camera is one of 512)
+  for (int s = 0; s < S; ++s) active += (h_counts[s] >= 0) ? 1 : 0;
+  const bool few = active <= 16;  // latency over throughput
+  const int bt_threads = few ? (longest > 512 ? kAFMax : (longest > 256 ? 512 : (longest > 64 ? kAF : kW))) : ((longest > 384) ? kAF : kW);
+  hipLaunchKernelGGL(bt_begin, dim3(S), dim3(bt_threads), 0, st, b->d_streams, b->prm, CAP, D, FD, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr, b->d_maxt, b->d_decl);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, bd, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[6], st));
   MOT_LC_HIP(b, mot::launch_kf_op(6, MOT_KF_XYAH, b->pred_t, S, bn, st));  // predicted boxes of the pool (box-only: nothing is stored)
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
-  MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, true, st, b->hint1_n, 0, true, nullptr, prof ? ev[10] : nullptr));
+  MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, true, st, b->hint1_n, 0, true, nullptr, prof ? ev[10] : nullptr, b->d_decl, active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
-  hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(bt_threads), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr, b->d_maxt);
+  hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(bt_threads), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr, b->d_maxt, b->d_decl + 1);
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, bn, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
-  MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, true, st, b->hint23_n, b->hint23_m));
+  MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, true, st, b->hint23_n, b->hint23_m, true, nullptr, nullptr, b->d_decl + 1, 2 * active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
   hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(bt_threads), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t, prof ? b->d_stats : nullptr);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[7], st));
@@ -849,11 +864,10 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
     static const bool full = std::getenv("MOT_BT_DUPS_FULL") != nullptr;  // measurement aid: every pair, boxes staged in LDS
     // LDS for up to 1024 lost boxes per stream (28 KB: five workgroups per CU); the rare stream with more takes the global path
     const int items = (bn2 < 1024) ? bn2 : 1024;
-    if (!full) hipLaunchKernelGGL(bt_dups<1>, dim3(S), dim3(256), static_cast<size_t>(28) * items, st, b->d_streams, CAP, verify, items);
+    if (!full) hipLaunchKernelGGL(bt_dups<1>, dim3(S), dim3(few && bn2 > 256 ? kAFMax : 256), static_cast<size_t>(28) * items, st, b->d_streams, CAP, verify, items);
     else hipLaunchKernelGGL(bt_dups<2>, dim3(S), dim3(256), static_cast<size_t>(16) * items, st, b->d_streams, CAP, 0, items);
   }
-  hipLaunchKernelGGL(bt_finish, dim3(S), dim3(bt_threads), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt, b->d_alive);
-  hipLaunchKernelGGL(bt_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
+  hipLaunchKernelGGL(bt_finish, dim3(S), dim3(bt_threads), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt, b->d_alive, b->d_err);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[5], st));
   MOT_LC_HIP(b, hipGetLastError());
   return MOT_OK;

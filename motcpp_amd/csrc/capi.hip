@@ -26,7 +26,8 @@ hipError_t launch_cosine(const mot_cos_task*, int, int, int, hipStream_t);
 // hint_n / hint_m (0: none): sizes most problems of the launch stay within, tighter than the hard bounds max_n / max_m — the sparse
 // solver sizes its LDS with them (more problems per CU) and leaves a problem that exceeds them to the exact solver
 hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, bool, hipStream_t, int hint_n = 0, int hint_m = 0, bool try_fast = true,
-                      int** declined_out = nullptr, hipEvent_t mid_event = nullptr);
+                      int** declined_out = nullptr, hipEvent_t mid_event = nullptr, int* prezeroed = nullptr,
+                      int active_tasks = 0);
 size_t lap_scratch_bytes(int n, int m);
 size_t lap_rowlist_scratch_bytes(int n);
 hipError_t lap_fast_stats(unsigned long long* out16, bool reset, hipStream_t st);

@@ -285,6 +285,9 @@ class Segment {
       has_warp_[q->s] = q->warp6 ? 1 : 0;
       if (q->warp6) { std::memcpy(&warps_[static_cast<size_t>(q->s) * 6], q->warp6, sizeof(float) * 6); any_warp = true; }
     }
+    // (tried in round 4: letting the kernels read one camera's few KB of detections in place from the page-locked staging buffer saves the
+    // copy launch and costs more than that in the three kernels that read the raw detections over PCIe: bt_begin 8 -> 13 us,
+    // bt_after_second 18 -> 30 us)
     if (det_top) check(mot_memcpy_h2d(ctx_, d_dets_, h_dets_[parity], det_top * sizeof(float)), "detections upload");
     if (any_emb && emb_top) check(mot_memcpy_h2d(ctx_, d_embs_, h_embs_[parity], emb_top * sizeof(float)), "embeddings upload");
     mot_frame_in in;

@@ -213,7 +213,7 @@ namespace mot {
 size_t lap_scratch_bytes(int n, int m) { return lap_task_scratch_bytes(n, m); }
 size_t lap_rowlist_scratch_bytes(int n) { return lap_rowlist_bytes(n); }
 hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool plain_costs, int* declined, hipStream_t st,
-                             int hint_n, int hint_m);
+                             int hint_n, int hint_m, int active_tasks);
 
 namespace {
 // one counter per launch in flight (the sparse kernel counts the problems it declines, the exact kernel reads it): a ring of
@@ -231,15 +231,23 @@ int* decl_ring(int dev_slot) {
 // mid_event: recorded between the sparse solver and the exact kernel (profiling). try_fast = false: skip the certified sparse solver (a caller that saw it decline every problem of its previous launches — OC-SORT's
 // first association once quirk Q4 has put duplicated tracks into every frame — saves its enumeration; results are the exact
 // kernel's either way). declined_out: the device counter of the problems the sparse solver declined in THIS launch (valid once the
-// stream has passed the launch; the slot is recycled after kDeclSlots further launches).
+// stream has passed the launch; the slot is recycled after kDeclSlots further launches). prezeroed: a device int of the caller's, zero when
+// the stream reaches this launch, used as that counter instead of a ring slot + memset. active_tasks (0: all): how many of the tasks are
+// not empty, when the caller knows — a launch with a handful of problems is tuned for latency (more wavefronts per problem).
 hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool geom, bool general_assoc, bool plain_costs,
-                      hipStream_t st, int hint_n, int hint_m, bool try_fast, int** declined_out, hipEvent_t mid_event) {
+                      hipStream_t st, int hint_n, int hint_m, bool try_fast, int** declined_out, hipEvent_t mid_event, int* prezeroed, int active_tasks) {
   if (declined_out) *declined_out = nullptr;
   if (ntasks <= 0) return hipSuccess;
   // fast path first (not for the general association measures: there a pair that does not intersect has no constant cost)
   const bool fast = !general_assoc && try_fast;
   int* declined = nullptr;
-  if (fast) {
+  if (fast && prezeroed) {  // the caller's own counter, cleared by a kernel of its own in front of this launch: no memset on the stream
+    declined = prezeroed;
+    if (declined_out) *declined_out = declined;
+    hipError_t e = launch_lap_sparse(tasks, ntasks, max_n, max_m, plain_costs, declined, st, hint_n, hint_m, active_tasks);
+    if (e != hipSuccess) return e;
+    if (mid_event) { e = hipEventRecord(mid_event, st); if (e != hipSuccess) return e; }
+  } else if (fast) {
     static std::mutex ring_mu;
     static unsigned next_slot[64] = {};
     int dev0 = 0;
@@ -254,7 +262,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
     hipError_t e = hipMemsetAsync(declined, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
     if (declined_out) *declined_out = declined;
-    e = launch_lap_sparse(tasks, ntasks, max_n, max_m, plain_costs, declined, st, hint_n, hint_m);
+    e = launch_lap_sparse(tasks, ntasks, max_n, max_m, plain_costs, declined, st, hint_n, hint_m, active_tasks);
     if (e != hipSuccess) return e;
     if (mid_event) { e = hipEventRecord(mid_event, st); if (e != hipSuccess) return e; }  // (profiling: the sparse kernel alone ends here)
   }

@@ -205,7 +205,7 @@ constexpr int kSpRC = 20;  // rows per lane whose x1 / gather index stay in regi
                            // RC template parameter below; the four-wavefront kernel passes 6: its rows are shared by 256 lanes, and the 100
                            // registers of the default were what limited it to four wavefronts per SIMD)
 struct SpNoMinIou { MOT_DEV float operator()(float) const { return 0.0f; } };
-template <int RC = kSpRC, class G, class W, class EvalFn, class ZeroFn, class MinIouFn = SpNoMinIou>
+template <int RC = kSpRC, int QD = kSpQ, class G, class W, class EvalFn, class ZeroFn, class MinIouFn = SpNoMinIou>
 MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, const SparseBoxes& A, const SparseBoxes& Bx,
                                           const float* bconf, const int* bidx, float thresh, EvalFn eval, ZeroFn zero_cost,
                                           MinIouFn min_iou_of = MinIouFn()) {
@@ -217,7 +217,9 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
   const long long ec0 = MOT_CLOCK();
   long long n_cand = 0, n_hit = 0;
   // bits: 1 tie with the threshold, 2 column list full, 4 NaN / inf / out of range, 8 viable pairs that do not intersect, 16 CSR full
-  int bad = (nr > 65535 || T > kSpMaxThreads) ? 4 : 0;
+  // QD = depth of a lane's queue: the queues of all lanes share the 2 * kSpQ * kSpMaxThreads bytes behind the buckets (16 wavefronts: 2 each)
+  static_assert(QD >= 1 && QD <= kSpQ, "queue depth");
+  int bad = (nr > 65535 || T * QD > kSpMaxThreads * kSpQ) ? 4 : 0;
   // ---- rows into x1 buckets ----
   const bool cached = nr <= T * RC;
   float rx1[RC];
@@ -385,7 +387,9 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
         }
         const int nv = __builtin_popcount(viable);
         if (seg < 0 && nv > 0) {
-          seg = last ? nv : ((nv > kSpSeg0) ? nv : kSpSeg0);
+          // (shallow queues drain before a column's scan is over nearly every time: they start with a small segment — it doubles when outgrown)
+          constexpr int seg0 = (QD < kSpQ) ? 4 : kSpSeg0;
+          seg = last ? nv : ((nv > seg0) ? nv : seg0);
           if (seg > kSpKMax) { bad |= 2; seg = 0; }
           base = (seg > 0) ? G::atomic_add(w.ctr.raw(2), seg) : 0;
           if (base + seg > w.ecap) { bad |= 16; seg = 0; }
@@ -424,7 +428,7 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
         }
         return true;
       };
-      auto push = [&](int p) { w.hq[nq * T + t] = static_cast<unsigned short>(p); if (++nq == kSpQ) drain(false); };
+      auto push = [&](int p) { w.hq[nq * T + t] = static_cast<unsigned short>(p); if (++nq == QD) drain(false); };
       int p = ps;
       for (; p + 8 <= pe; p += 8) {  // eight boxes per round trip, the tests folded into one mask before any queue write
         const SpBox s0 = w.sbox[p], s1 = w.sbox[p + 1], s2 = w.sbox[p + 2], s3 = w.sbox[p + 3];

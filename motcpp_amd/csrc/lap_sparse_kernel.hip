@@ -6,6 +6,8 @@
 // viable-pair lists and the bucket-ordered row boxes in the task's global scratch.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/motcpp_amd.h"
 #include "lap_cost.hpp"
 #include "lap_sparse.hpp"
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task
         if (!(need > 1.0e-3f)) return 0.0f;
         return (need < 1.0f) ? 0.99f * need : 0.99f;
       };
-      e = mot::sparse_enumerate_boxes<(kThreads == 256) ? 6 : mot::kSpRC>(g, w, nr, nc, mot::SparseBoxes{G.a, G.lda, G.aidx}, mot::SparseBoxes{G.b, G.ldb, G.bidx},
+      e = mot::sparse_enumerate_boxes<(kThreads == 1024) ? 2 : ((kThreads == 256) ? 6 : mot::kSpRC), (kThreads == 1024) ? 2 : mot::kSpQ>(g, w, nr, nc, mot::SparseBoxes{G.a, G.lda, G.aidx}, mot::SparseBoxes{G.b, G.ldb, G.bidx},
                                       G.bconf, G.bidx, T.thresh, eval, zc, min_iou);
     } else {
       e = mot::sparse_enumerate_matrix(g, w, nr, nc, T.cost, T.ldc, T.thresh);
@@ -148,12 +150,12 @@ __global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task
         const long long ck2 = MOT_CLOCK();
         // the path searches: every wavefront takes every fourth free column (lap_sparse.hpp, SHARED); the few that ran into each other's
         // rows are then redone by the first wavefront alone
-        static_assert(kThreads == 256, "one search per wavefront");
-        {
+        static_assert(kThreads == 256 || kThreads == 1024, "one search per wavefront, four at a time");
+        if (t < 256) {
           mot::DevWave gw;
           int scans = 0;
           long long seg[4] = {0, 0, 0, 0};
-          const int rs = mot::sparse_search_impl<true>(gw, w, nfree, T.thresh, t >> 6, kThreads / 64, false, &scans, seg);
+          const int rs = mot::sparse_search_impl<true>(gw, w, nfree, T.thresh, t >> 6, 4, false, &scans, seg);
           if (rs != 1 && (t & 63) == 0) w.ctr.atomic_min(3, rs);
           if (t == 0) {
             unsigned long long* h = hist_set();  // where the searches spend their cycles (first wavefront)
@@ -223,12 +225,13 @@ namespace mot {
 // Launches the fast path over the task array. Hot state in LDS when it fits in 64 KB (the CSR list's capacity gives way first:
 // 5 pairs per column by default, never fewer than 3), else in the task's global scratch.
 hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool plain_costs, int* declined, hipStream_t st,
-                             int hint_n, int hint_m) {
+                             int hint_n, int hint_m, int active_tasks) {
   if (ntasks <= 0) return hipSuccess;
   // LDS per problem (which decides how many problems a CU holds) from the caller's hint of the sizes when it has one
   int n = max_n > 0 ? max_n : 1, m = max_m > 0 ? max_m : 1;
   if (hint_n > 0 && hint_n < n) n = hint_n;
   if (hint_m > 0 && hint_m < m) m = hint_m;
+  const bool active_few = ((active_tasks > 0 && active_tasks < ntasks) ? active_tasks : ntasks) <= 32;
   constexpr size_t kBudget = 64 * 1024 - 64;
   int ecap = sparse_default_ecap(m);
   size_t hot = kScratch + sparse_hot_bytes(n, m, ecap);
@@ -241,7 +244,8 @@ hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, i
   // LDS per problem decides how many problems a CU holds (160 KB: 5 at 32 KB, 4 at 40 KB, 3 at 53 KB): the pair list takes what is left of
   // the step the launch lands on anyway — a problem whose list overflows goes to the exact solver, milliseconds instead of microseconds
   if (lds) {
-    for (int k = 32; k >= 1; --k) {  // the finest step the launch already fits: k problems per CU
+    // (a handful of problems: nobody shares the CU — the list gets the whole budget)
+    for (int k = (active_few ? 2 : 32); k >= 1; --k) {  // the finest step the launch already fits: k problems per CU
       const size_t cap = ((static_cast<size_t>(160) * 1024 / k) < kBudget ? (static_cast<size_t>(160) * 1024 / k) : kBudget) & ~size_t(63);
       if (hot <= cap) {
         const int more = static_cast<int>((cap - hot) / 6) - 4;  // (6 bytes per entry; the two arrays round up to 16 bytes each)
@@ -252,10 +256,16 @@ hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, i
   }
   // four wavefronts per problem once there is enough to enumerate (the pairs are listed four times faster; the hot state's
   // LDS, which bounds the problems resident per CU, is the same)
-  const bool wide = lds && (static_cast<long>(n) * m >= 64 * 1024);
+  // a handful of problems (one camera): the launch's latency is the frame's — four wavefronts from small problems on, sixteen for the
+  // large ones (one column per lane in the enumeration; the searches still run on four)
+  const bool few = active_few;
+  const bool wide = lds && (static_cast<long>(n) * m >= (few ? 4 * 1024 : 64 * 1024));
+  static const bool allow16 = std::getenv("MOT_LAP_SPARSE_NO16") == nullptr;
+  const bool wide16 = wide && few && allow16 && (static_cast<long>(n) * m >= 128 * 1024);
 #define MOT_SP_LAUNCH(P, H, TH, BYTES) hipLaunchKernelGGL((lap_sparse_kernel<P, H, TH>), dim3(ntasks), dim3(TH), BYTES, st, tasks, ecap, declined, static_cast<int>(BYTES))
   if (lds) {
-    if (wide) { if (plain_costs) MOT_SP_LAUNCH(true, kMemLds, 256, hot); else MOT_SP_LAUNCH(false, kMemLds, 256, hot); }
+    if (wide16) { if (plain_costs) MOT_SP_LAUNCH(true, kMemLds, 1024, hot); else MOT_SP_LAUNCH(false, kMemLds, 1024, hot); }
+    else if (wide) { if (plain_costs) MOT_SP_LAUNCH(true, kMemLds, 256, hot); else MOT_SP_LAUNCH(false, kMemLds, 256, hot); }
     else { if (plain_costs) MOT_SP_LAUNCH(true, kMemLds, 64, hot); else MOT_SP_LAUNCH(false, kMemLds, 64, hot); }
   } else {
     ecap = 0;

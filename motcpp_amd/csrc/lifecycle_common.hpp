@@ -19,7 +19,8 @@ hipError_t launch_iou(const mot_iou_task*, int, int, int, bool, hipStream_t);
 // hint_n / hint_m (0: none): sizes most problems of the launch stay within, tighter than the hard bounds max_n / max_m — the sparse
 // solver sizes its LDS with them (more problems per CU) and leaves a problem that exceeds them to the exact solver
 hipError_t launch_lap(const mot_lap_task*, int, int, int, bool, bool, bool, hipStream_t, int hint_n = 0, int hint_m = 0, bool try_fast = true,
-                      int** declined_out = nullptr, hipEvent_t mid_event = nullptr);
+                      int** declined_out = nullptr, hipEvent_t mid_event = nullptr, int* prezeroed = nullptr,
+                      int active_tasks = 0);
 size_t lap_scratch_bytes(int n, int m);
 size_t lap_rowlist_scratch_bytes(int n);
 
@@ -50,6 +51,7 @@ struct PackMeta {
   const int* dec[3] = {nullptr, nullptr, nullptr};
   int dec_at = -1;
   const int* maxt = nullptr;
+  int* maxt_zero = nullptr;  // == maxt when the maxima are to be cleared once they are in dev (the next frame then needs no memset launch)
   int n_maxt = 0, maxt_at = 0, counts_at = 0;
   int* counts_copy = nullptr;
   const int* alive = nullptr;  // optional [S]: live tracks per stream after the frame (pooled trackers size their next frame with it)
@@ -80,7 +82,7 @@ struct PackMeta {
       if (pm.dec_at >= 0)
         for (int k = 0; k < 3; ++k) pm.dev[pm.dec_at + k] = pm.dec[k] ? *pm.dec[k] : -1;
     }
-    for (int i = t; i < pm.n_maxt; i += 1024) pm.dev[pm.maxt_at + i] = pm.maxt[i];
+    for (int i = t; i < pm.n_maxt; i += 1024) { pm.dev[pm.maxt_at + i] = pm.maxt[i]; if (pm.maxt_zero) pm.maxt_zero[i] = 0; }
     for (int i = t; i < S; i += 1024) { const int c = counts[i]; pm.dev[pm.counts_at + i] = c; if (pm.counts_copy) pm.counts_copy[i] = c; }
     if (pm.alive) for (int i = t; i < S; i += 1024) pm.dev[pm.alive_at + i] = pm.alive[i];
   }
@@ -161,6 +163,7 @@ inline size_t frame_block_ints(int S) { return static_cast<size_t>(S) * 2 + stat
 // Zero-copy rows (view mode, what the pooled trackers use): pack_rows writes the packed table straight into page-locked host memory
 // (h_rows), so a frame needs no device-to-host copy at all and collect is one event wait.
 constexpr int kMetaDec = 2, kMetaMaxt = 5;
+constexpr size_t kZeroCopyBytes = 32 * 1024;  // inputs up to this size are read in place from page-locked memory
 struct Flight {
   float* d_packed = nullptr; int* d_offsets = nullptr; int* d_counts = nullptr; int packed_cap = 0;
   float* h_rows = nullptr; int h_rows_cap = 0;  // view mode: the packed rows in page-locked memory, written by the kernel
@@ -181,6 +184,9 @@ struct Flights {
   bool with_alive = false;  // the lifecycle reports the live tracks per stream
   hipStream_t copy_st = nullptr;
   int* d_in = nullptr;      // the pooled input block on the device
+  // the per-frame maxima are all zero (pack_offsets of the last frame cleared them): the lifecycle's frame needs no memset in front.
+  // Cleared by a lifecycle whenever it starts a frame, set when a flight's pack_offsets is queued.
+  bool maxt_clean = false;
   int meta_head() const { return kMetaMaxt + n_maxt; }
   int meta_dev_words(int S) const { return meta_head() + (with_alive ? 2 : 1) * S; }
   int slot_for_enqueue() const { return (head + count) & 1; }
@@ -230,17 +236,24 @@ struct Flights {
     int* hc = F.h_in; int* hl = hc + S;
     long long* hd = reinterpret_cast<long long*>(hl + S); long long* he = hd + S;
     for (int s = 0; s < S; ++s) { hc[s] = counts[s]; hl[s] = ld[s]; hd[s] = det_off[s]; he[s] = emb_off ? emb_off[s] : -1; }
-    if ((e = hipMemcpyAsync(d_in, F.h_in, sizeof(int) * words, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-    out->counts = d_in; out->ld = d_in + S;
-    out->det_off = reinterpret_cast<const long long*>(d_in + 2 * static_cast<size_t>(S)); out->emb_off = out->det_off + S;
+    // a small block is read by the kernels where it lies (page-locked memory is mapped into the device's address space): one copy launch
+    // less in front of a single camera's frame; a large one (thousands of streams, one 64-byte PCIe read per workgroup) is copied
+    const int* blk = F.h_in;
+    if (words * sizeof(int) > kZeroCopyBytes) {
+      if ((e = hipMemcpyAsync(d_in, F.h_in, sizeof(int) * words, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+      blk = d_in;
+    }
+    out->counts = blk; out->ld = blk + S;
+    out->det_off = reinterpret_cast<const long long*>(blk + 2 * static_cast<size_t>(S)); out->emb_off = out->det_off + S;
     return hipSuccess;
   }
   float* rows_target(int slot) { Flight& F = fl[slot]; return F.view ? F.h_rows : F.d_packed; }
   PackMeta pack_meta(int slot, const int* d_err, const int* d_maxt, const int* d_declined, const int* d_declined_b = nullptr, const int* d_declined_c = nullptr) {
     Flight& F = fl[slot];
     PackMeta pm;
-    pm.dev = F.d_meta; pm.err = d_err; pm.dec[0] = d_declined; pm.dec[1] = d_declined_b; pm.dec[2] = d_declined_c; pm.dec_at = kMetaDec;
-    pm.maxt = d_maxt; pm.n_maxt = n_maxt; pm.maxt_at = kMetaMaxt; pm.counts_at = meta_head(); pm.counts_copy = F.d_counts;
+    // view mode: the kernel writes the words straight into the page-locked buffer (like the rows) - no copy behind the frame
+    pm.dev = F.view ? F.h_meta : F.d_meta; pm.err = d_err; pm.dec[0] = d_declined; pm.dec[1] = d_declined_b; pm.dec[2] = d_declined_c; pm.dec_at = kMetaDec;
+    pm.maxt = d_maxt; pm.maxt_zero = const_cast<int*>(d_maxt); pm.n_maxt = n_maxt; pm.maxt_at = kMetaMaxt; pm.counts_at = meta_head(); pm.counts_copy = F.d_counts;
     return pm;
   }
   // behind the frame's launches: pack the staged tables, bring the small results back, record the frame's event
@@ -260,8 +273,9 @@ struct Flights {
   hipError_t finish_copies(int slot, hipStream_t st, int S, int rows_cap, int bd) {
     Flight& F = fl[slot];
     hipError_t e = hipSuccess;
-    if ((e = copy_meta_d2h(F.h_meta, F.d_meta, static_cast<size_t>(meta_dev_words(S)), st)) != hipSuccess) return e;
+    if (!F.view && (e = copy_meta_d2h(F.h_meta, F.d_meta, static_cast<size_t>(meta_dev_words(S)), st)) != hipSuccess) return e;
     if ((e = hipEventRecord(F.done, st)) != hipSuccess) return e;
+    maxt_clean = true;
     F.pending = true; F.bd = bd; F.rows_cap = rows_cap;
     count += 1;
     return hipSuccess;

@@ -573,16 +573,18 @@ void mot_oc_destroy(mot_oc_batch* b) {
   delete b;
 }
 
-int mot_oc_reset(mot_oc_batch* b) {  // OCSort::reset: the tracker list is dropped, the id counter keeps running in the reference's
-                                     // process-global static; per stream here it restarts with the list (parity is defined per stream)
+int mot_oc_reset(mot_oc_batch* b) {  // OCSort::reset: the tracker list goes, the id counter keeps counting (ocsort.hpp:37-39: clear_count() is empty)
+  MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));  // (frames still in flight have finished: they are dropped with the tracks)
+  std::vector<OcStream> cur(b->S);
+  MOT_LC_HIP(b, hipMemcpy(cur.data(), b->d_streams, sizeof(OcStream) * b->S, hipMemcpyDeviceToHost));
   std::vector<OcStream> h = b->h_streams;
-  MOT_LC_HIP(b, hipMemcpyAsync(b->d_streams, h.data(), sizeof(OcStream) * b->S, hipMemcpyHostToDevice, b->ctx->stream));
-  MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), b->ctx->stream));
-  MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
+  for (int s = 0; s < b->S; ++s) h[s].next_id = cur[s].next_id;
+  MOT_LC_HIP(b, hipMemcpy(b->d_streams, h.data(), sizeof(OcStream) * b->S, hipMemcpyHostToDevice));
+  MOT_LC_HIP(b, hipMemset(b->d_err, 0, sizeof(int)));
   b->bound_n = 0;
   b->skip_fast[0] = b->skip_fast[1] = b->skip_fast[2] = false;
   b->lap1_age = 0;
-  b->flights.drop_all();  // (frames still in flight have finished: they are dropped with the tracks)
+  b->flights.drop_all();
   return MOT_OK;
 }
 
@@ -742,7 +744,8 @@ static int oc_enqueue_frame(mot_oc_batch* b, const float* d_dets, const int* cou
     MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
     FD.counts = b->d_counts;
   }
-  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
+  if (!b->flights.maxt_clean) MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));  // (else: the last frame's pack_offsets cleared them)
+  b->flights.maxt_clean = false;
   int bd = 1;
   for (int s = 0; s < S; ++s) bd = (counts[s] > bd) ? counts[s] : bd;
   if (bd > D) bd = D;

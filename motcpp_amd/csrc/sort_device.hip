@@ -398,7 +398,8 @@ static int sort_enqueue_frame(mot_sort_batch* b, const float* d_dets, const int*
     MOT_LC_HIP(b, hipMemcpyAsync(b->d_counts, counts, sizeof(int) * S, hipMemcpyHostToDevice, st));
     FD.counts = b->d_counts;
   }
-  MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));
+  if (!b->flights.maxt_clean) MOT_LC_HIP(b, hipMemsetAsync(b->d_maxt, 0, 64 * sizeof(int), st));  // (else: the last frame's pack_offsets cleared them)
+  b->flights.maxt_clean = false;
   int bd = 1;
   for (int s = 0; s < S; ++s) bd = (counts[s] > bd) ? counts[s] : bd;
   if (bd > D) bd = D;

@@ -78,12 +78,17 @@ def test_c5_per_gpu_shape():
     run([(1000, 512), (1000, 512)], 16, cap=2048, maxd=512, check_states_every=8)
 
 
-def test_reset_restarts_ids():
+def test_reset_drops_the_tracks_and_keeps_counting_ids():
+    # ByteTrack::reset (bytetrack.cpp: lists cleared, frame counters zeroed; clear_count() is empty, bytetrack.hpp:38-40): round 4 — the
+    # batch-level reset follows it (before, it restarted the ids)
     orc = orclib.load()
     dev = L.DeviceByteTrack(2, 128, 32)
+    oracles = [orc.tracker(orclib.BYTETRACK) for _ in range(2)]
     for rep in range(2):
         streams = [SynthStream(20, 12, 77 + i) for i in range(2)]
-        oracles = [orc.tracker(orclib.BYTETRACK) for _ in range(2)]
+        if rep:
+            for o in oracles:
+                o.reset()
         for f in range(12):
             dets = np.zeros((2, 32, 6), np.float32)
             cnt = np.zeros(2, np.int32)

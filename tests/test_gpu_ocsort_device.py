@@ -105,9 +105,12 @@ def test_capacity_error_is_reported():
 def test_reset_restarts_the_streams():
     orc = orclib.load()
     dev = L.DeviceOCSort(2, 128, 32)
+    oracles = [orc.tracker(orclib.OCSORT) for _ in range(2)]
     for rep in range(2):
         streams = [SynthStream(20, 12, 77 + i) for i in range(2)]
-        oracles = [orc.tracker(orclib.OCSORT) for _ in range(2)]
+        if rep:
+            for o in oracles:
+                o.reset()  # OCSort::reset: the list goes, ids keep counting (ocsort.hpp:37-39)
         for f in range(12):
             dets = np.zeros((2, 32, 6), np.float32)
             cnt = np.zeros(2, np.int32)

@@ -108,7 +108,7 @@ def test_cli_usage_and_unknown_method(tmp_path):
     build()
     assert subprocess.run([EVAL], capture_output=True, timeout=60).returncode == 1
     root = make_root(str(tmp_path))
-    out = subprocess.run([EVAL, root, os.path.join(str(tmp_path), "res"), "strongsort"], capture_output=True, text=True, timeout=60)
+    out = subprocess.run([EVAL, root, os.path.join(str(tmp_path), "res"), "boosttrack"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 1 and "unknown tracking method" in out.stderr
     out = subprocess.run([EVAL, os.path.join(str(tmp_path), "nope"), os.path.join(str(tmp_path), "res")], capture_output=True, text=True,
                          timeout=60)

@@ -8,5 +8,6 @@
 #include "trackers/botsort.hpp"
 #include "trackers/deepocsort.hpp"
 #include "trackers/strongsort.hpp"
+#include "trackers/ucmc.hpp"
 #include "utils/matching.hpp"
 #include "utils/iou.hpp"

@@ -298,6 +298,34 @@ typedef struct mot_ss_iou_task {
 } mot_ss_iou_task;
 int mot_ss_iou_cost(mot_ctx* ctx, const mot_ss_iou_task* tasks, int ntasks, int max_n, int max_m);
 
+/* ---- UCMCTrack's ground-plane filter (src/trackers/ucmc.cpp) ------------------------------- */
+/* The reference keeps this tracker's state in double precision: [x, vx, y, vy] and a 4 x 4 covariance per track (UCMCKalmanFilter
+ * :15-49), measurements = a detection's foot point mapped to the ground plane with a 2 x 2 covariance (CameraMapper :57-146). One task
+ * = one stream's share of a launch; `x` [cap][4] and `P` [cap][16] (row-major) are the stream's state slabs, `y` [nd][2] / `R` [nd][4]
+ * its mapped detections. Arithmetic: IEEE double, the operation order of the reference's expressions (sums of more than two non-zero
+ * terms in index order, no fused multiply-add); S^-1 as Eigen forms a 2 x 2 inverse (1 / det, scaled adjugate); log = the device's
+ * double-precision log (the one value that is not correctly rounded).
+ *   MOT_UCMC_MAP     n detections: didx[i] (NULL: i) = column of `dets` (SoA [6][ld] floats x1,y1,x2,y2,conf,cls) -> y[i], R[i]
+ *                    (mapped != 0: uv2xy with invA, else mapToImageSpace's scaled image coordinates)
+ *   MOT_UCMC_PREDICT n tracks slots[i]: x = F x, P = F P F^T + Q (UCMCKalmanFilter::predict; F = I + dt at (0,1), (2,3))
+ *   MOT_UCMC_COST    cost[i * ldc + j] = (float)(Mahalanobis + log det S) of track slots[i] and detection didx[j]
+ *                    (UCMCSingleTrack::distance :213-223), n x m
+ *   MOT_UCMC_UPDATE  n pairs: track slots[i] with detection didx[i] (UCMCKalmanFilter::update, Joseph form :33-49)
+ *   MOT_UCMC_INIT    n births: track slots[i] from detection didx[i] (UCMCSingleTrack ctor :152-201: zero velocity, P = diag(1, vmax^2/3, 1, vmax^2/3)) */
+enum { MOT_UCMC_MAP = 0, MOT_UCMC_PREDICT = 1, MOT_UCMC_COST = 2, MOT_UCMC_UPDATE = 3, MOT_UCMC_INIT = 4 };
+typedef struct mot_ucmc_task {
+  int32_t n, m, mapped, ld;
+  double* x; double* P;
+  const int32_t* slots; const int32_t* didx;
+  double* y; double* R;
+  const float* dets;
+  float* cost; int32_t ldc, reserved;
+  double dt, vmax;
+  double Q[16];
+  double invA[9];
+} mot_ucmc_task;
+int mot_ucmc_run(mot_ctx* ctx, int op, const mot_ucmc_task* tasks, int ntasks, int max_n, int max_m);
+
 /* ---- linear assignment ---------------------------------------------------------------- */
 typedef enum mot_lap_mode {
   MOT_LAP_PLAIN = 0,

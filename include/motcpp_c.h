@@ -9,6 +9,7 @@
  *  BoT-SORT  [track_high, track_low, new_track, track_buffer, match_thresh, proximity, appearance,
  *             frame_rate, fuse_first_associate, with_reid, max_age, max_obs]
  *  StrongSORT [min_conf, max_cos_dist, max_iou_dist, n_init, nn_budget, mc_lambda, ema_alpha, max_age]
+ *  UCMCTrack (6) [det_thresh, max_age, a1, a2, wx, wy, vmax, fps, high_score] (dt = 1.0 / fps in double precision)
  * Functions return >= 0 on success and a negative value on error (motcpp_last_error() has the message).
  */
 #ifndef MOTCPP_C_H_
@@ -53,6 +54,10 @@ int motcpp_tracker_set_camera_motion(motcpp_tracker* t, const float* warp2x3);
 int motcpp_tracker_lap_count(motcpp_tracker* t);
 int motcpp_tracker_lap_get(motcpp_tracker* t, int k, int* n, int* m, int* x, int* y, int cap);
 int motcpp_tracker_dump_states(motcpp_tracker* t, float* out, int cap_floats, int* width);
+/* UCMCTrack: creation with a calibrated camera (Ki 3 x 4, Ko 4 x 4, row-major; NULL: image-space fallback) and its double-precision
+ * states: rows of 26 doubles [id, state, death_count, birth_count, det_idx, age, x(4), P(16)] in list order. */
+motcpp_tracker* motcpp_ucmc_create(const float* params, int nparams, const double* Ki12, const double* Ko16, int device);
+int motcpp_tracker_dump_f64(motcpp_tracker* t, double* out, int cap_rows);
 /* BoT-SORT parity hook: smooth features (botsort.hpp smooth_feat_) of the live tracks in dump_states order, *dim floats per row
  * (zeros for a track that has none yet; *dim = 0 when the tracker holds no features); returns the number of rows */
 int motcpp_tracker_dump_features(motcpp_tracker* t, float* out, int cap_floats, int* dim); /* rows [id, mean(d), cov(d*d)] */

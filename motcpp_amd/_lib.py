@@ -227,7 +227,7 @@ class Context:
 
 # ---- tracker handles (libmotcpp.so: C++17 host library over the C ABI) ------------------------------------
 SORT, BYTETRACK, OCSORT, BOTSORT = 0, 1, 2, 3
-KIND = {"sort": SORT, "bytetrack": BYTETRACK, "ocsort": OCSORT, "botsort": BOTSORT, "deepocsort": 4, "strongsort": 5}
+KIND = {"sort": SORT, "bytetrack": BYTETRACK, "ocsort": OCSORT, "botsort": BOTSORT, "deepocsort": 4, "strongsort": 5, "ucmc": 6}
 _host = None
 
 
@@ -304,6 +304,16 @@ class _Hooks:
                 raise MotError(_err())
             buf = np.zeros((-r - 1000000 + 8) * max(w.value, 1), np.float32)
 
+    def dump_f64(self):
+        """UCMCTrack: [rows, 26] float64 — id, state, death_count, birth_count, det_idx, age, x(4), P(16) per track in list order"""
+        H = host()
+        H.motcpp_tracker_dump_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        buf = np.zeros((4096, 26), np.float64)
+        r = H.motcpp_tracker_dump_f64(self.h, _p(buf), buf.shape[0])
+        if r < 0:
+            raise MotError(_err())
+        return buf[:r].copy()
+
     def dump_features(self):
         """BoT-SORT: smooth features of the live tracks in dump_states order, [rows, dim] (dim 0: no features)."""
         H, d = host(), C.c_int()
@@ -318,13 +328,21 @@ class _Hooks:
 class Tracker(_Hooks):
     """One tracker instance on one GPU. update() mirrors motcpp::BaseTracker::update (row-major numpy in/out)."""
 
-    def __init__(self, kind, params=None, device=0, pooled=False):
+    def __init__(self, kind, params=None, device=0, pooled=False, camera=None):
         """pooled: the tracker is a stream of a shared device-lifecycle batch (what the C++ classes are by default): handles updated
         from different host threads at the same time run as one launch sequence. The ctypes call releases the GIL."""
         kind = KIND.get(kind, kind)
         p = f32(params if params is not None else [])
         create = host().motcpp_tracker_create_pooled if pooled else host().motcpp_tracker_create
-        self.h = create(int(kind), _p(p) if p.size else None, int(p.size), int(device))
+        if camera is not None:  # UCMCTrack with a calibrated camera: (Ki 3 x 4, Ko 4 x 4)
+            assert kind == KIND["ucmc"] and not pooled
+            ki, ko = (np.ascontiguousarray(a, np.float64).reshape(-1) for a in camera)
+            assert ki.size == 12 and ko.size == 16
+            host().motcpp_ucmc_create.restype = C.c_void_p
+            host().motcpp_ucmc_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+            self.h = host().motcpp_ucmc_create(_p(p) if p.size else None, int(p.size), _p(ki), _p(ko), int(device))
+        else:
+            self.h = create(int(kind), _p(p) if p.size else None, int(p.size), int(device))
         if not self.h:
             raise MotError("tracker create failed: " + _err())
         self._out = np.zeros((8192, 8), np.float32)

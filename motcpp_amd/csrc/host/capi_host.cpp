@@ -38,6 +38,13 @@ Staged* make(std::shared_ptr<Device> dev, int kind, const float* p, int np) {
     case 5:  // min_conf, max_cos_dist, max_iou_dist, n_init, nn_budget, mc_lambda, ema_alpha, max_age
       return make_strongsort(dev, P(p, np, 0, 0.1f), P(p, np, 1, 0.2f), P(p, np, 2, 0.7f), (int)P(p, np, 3, 3), (int)P(p, np, 4, 100), P(p, np, 5, 0.98f),
                              P(p, np, 6, 0.9f), (int)P(p, np, 7, 30));
+    case 6: {  // det_thresh, max_age, a1, a2, wx, wy, vmax, fps (dt = 1.0 / fps in double precision, as the evaluation tool forms it), high_score
+      UcmcParams q;
+      q.det_thresh = P(p, np, 0, 0.3f); q.max_age = (int)P(p, np, 1, 30); q.a1 = P(p, np, 2, 100.f); q.a2 = P(p, np, 3, 100.f);
+      q.wx = P(p, np, 4, 5.f); q.wy = P(p, np, 5, 5.f); q.vmax = P(p, np, 6, 10.f); q.dt = 1.0 / static_cast<double>(P(p, np, 7, 30.f));
+      q.high_score = P(p, np, 8, 0.5f);
+      return make_ucmc(dev, q);
+    }
   }
   throw Error("unknown tracker kind");
 }
@@ -89,6 +96,31 @@ motcpp_tracker* motcpp_tracker_create(int kind, const float* params, int nparams
     t->impl.reset(make(t->dev, kind, params, nparams));
     return t.release();
   } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+// UCMCTrack with a calibrated camera: params as for kind 6, Ki 3 x 4 and Ko 4 x 4 row-major (CameraMapper, ucmc.cpp:57-83)
+motcpp_tracker* motcpp_ucmc_create(const float* p, int np, const double* Ki12, const double* Ko16, int device) {
+  try {
+    auto t = std::make_unique<motcpp_tracker>();
+    t->dev = Device::shared(device);
+    UcmcParams q;
+    q.det_thresh = P(p, np, 0, 0.3f); q.max_age = (int)P(p, np, 1, 30); q.a1 = P(p, np, 2, 100.f); q.a2 = P(p, np, 3, 100.f);
+    q.wx = P(p, np, 4, 5.f); q.wy = P(p, np, 5, 5.f); q.vmax = P(p, np, 6, 10.f); q.dt = 1.0 / static_cast<double>(P(p, np, 7, 30.f));
+    q.high_score = P(p, np, 8, 0.5f);
+    if (Ki12 && Ko16) { q.has_camera = true; std::memcpy(q.Ki, Ki12, sizeof(q.Ki)); std::memcpy(q.Ko, Ko16, sizeof(q.Ko)); }
+    t->impl.reset(make_ucmc(t->dev, q));
+    return t.release();
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+// UCMCTrack's tracks in list order, rows of 26 doubles [id, state, death, birth, det_idx, age, x(4), P(16)]; returns the rows (-needed - 1000000)
+int motcpp_tracker_dump_f64(motcpp_tracker* t, double* out, int cap_rows) {
+  try {
+    std::vector<double> rows;
+    if (t->pooled || !t->impl->f64_states(&rows)) { g_err = "this tracker keeps no double-precision states"; return -1; }
+    const int n = static_cast<int>(rows.size() / 26);
+    if (n > cap_rows) return -n - 1000000;
+    if (n) std::memcpy(out, rows.data(), rows.size() * sizeof(double));
+    return n;
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 motcpp_tracker* motcpp_tracker_create_pooled(int kind, const float* params, int nparams, int device) {
   try {

@@ -58,6 +58,8 @@ class Staged {
   virtual void live_tracks(std::vector<int>* ids, std::vector<int>* slots) const = 0;
   // parity hook (BoT-SORT): device address of the smooth-feature slab [slot][dim] (nullptr: none), which tracks have one
   virtual const float* feature_slab(int* dim, std::vector<char>* has) const { *dim = 0; (void)has; return nullptr; }
+  // parity hook (UCMCTrack): rows of doubles [id, state, death, birth, det_idx, age, x(4), P(16)] in list order; false: not that tracker
+  virtual bool f64_states(std::vector<double>* rows) { (void)rows; return false; }
 
  protected:
   void record(const Core::Lap& l) {
@@ -99,6 +101,16 @@ Staged* make_deepocsort(std::shared_ptr<Device>, float det_thresh, int max_age, 
 // StrongSORT (src/trackers/strongsort.cpp); nn_budget > 0
 Staged* make_strongsort(std::shared_ptr<Device>, float min_conf, float max_cos_dist, float max_iou_dist, int n_init, int nn_budget,
                         float mc_lambda, float ema_alpha, int max_age);
+// UCMCTrack (src/trackers/ucmc.cpp): the reference's double-precision parameters; Ki 3 x 4 / Ko 4 x 4 row-major when has_camera
+struct UcmcParams {
+  float det_thresh = 0.3f;
+  int max_age = 30;
+  double a1 = 100.0, a2 = 100.0, wx = 5.0, wy = 5.0, vmax = 10.0, dt = 1.0 / 30.0;
+  float high_score = 0.5f;
+  bool has_camera = false;
+  double Ki[12] = {}, Ko[16] = {};
+};
+Staged* make_ucmc(std::shared_ptr<Device>, const UcmcParams& p);
 Staged* make_botsort(std::shared_ptr<Device>, float track_high, float track_low, float new_track, int track_buffer,
                      float match_thresh, float proximity, float appearance, int frame_rate, bool fuse_first, bool with_reid,
                      int max_age, int max_obs);

@@ -314,6 +314,19 @@ StrongSORT::StrongSORT(const std::string& reid_weights, bool /*use_half*/, bool 
   // (the tracker gets the constructor's max_age, strongsort.cpp:841-842; BaseTracker only adjusts max_obs)
   adopt(rt::make_strongsort(dev_, min_conf, max_cos_dist, max_iou_dist, n_init, nn_budget, mc_lambda, ema_alpha, max_age));
 }
+UCMCTrack::UCMCTrack(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class, int nr_classes,
+                     const std::string& asso_func, bool is_obb, double a1, double a2, double wx, double wy, double vmax, double dt, float high_score,
+                     const std::vector<double>& Ki, const std::vector<double>& Ko, int device_index)
+    : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
+  rt::UcmcParams q;
+  q.det_thresh = det_thresh_; q.max_age = max_age_; q.a1 = a1; q.a2 = a2; q.wx = wx; q.wy = wy; q.vmax = vmax; q.dt = dt; q.high_score = high_score;
+  if (!Ki.empty() && !Ko.empty() && Ki.size() == 12 && Ko.size() == 16) {  // (any other size: the mapper stays invalid, ucmc.cpp:60-62)
+    q.has_camera = true;
+    for (int k = 0; k < 12; ++k) q.Ki[k] = Ki[k];
+    for (int k = 0; k < 16; ++k) q.Ko[k] = Ko[k];
+  }
+  adopt(rt::make_ucmc(dev_, q));
+}
 void DeepOCSort::set_camera_motion(const Eigen::MatrixXf& warp) {
   if (warp.rows() != 2 || warp.cols() != 3) throw std::invalid_argument("DeepOCSort::set_camera_motion: the warp must be 2 x 3");
   const float w[6] = {warp(0, 0), warp(0, 1), warp(0, 2), warp(1, 0), warp(1, 1), warp(1, 2)};

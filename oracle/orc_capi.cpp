@@ -19,6 +19,7 @@ struct Handle {
   std::unique_ptr<BotSort> bot;
   std::unique_ptr<DeepOCSort> deep;
   std::unique_ptr<StrongSort> strong;
+  std::unique_ptr<Ucmc> ucmc;
   const std::vector<LapResult>* laps() const {
     switch (kind) {
       case 1: return &byte->laps;
@@ -26,6 +27,7 @@ struct Handle {
       case 3: return &bot->laps;
       case 4: return &deep->laps;
       case 5: return &strong->laps;
+      case 6: return &ucmc->laps;
       default: return nullptr;
     }
   }
@@ -90,6 +92,41 @@ void* orc_tracker_create(int kind, const float* p, int np) {
   }
   return h;
 }
+// UCMCTrack (kind 6): p = [det_thresh, max_age, a1, a2, wx, wy, vmax, dt, high_score] in double precision (dt = 1.0 / fps is not a
+// float), Ki (3 x 4) / Ko (4 x 4) row-major or null (image-space fallback)
+void* orc_ucmc_create(const double* p, int np, const double* Ki12, const double* Ko16) {
+  auto D = [&](int i, double dflt) { return (p && i < np) ? p[i] : dflt; };
+  Ucmc::Params q;
+  q.det_thresh = static_cast<float>(D(0, 0.3)); q.max_age = static_cast<int>(D(1, 30)); q.a1 = D(2, 100.0); q.a2 = D(3, 100.0);
+  q.wx = D(4, 5.0); q.wy = D(5, 5.0); q.vmax = D(6, 10.0); q.dt = D(7, 1.0 / 30.0); q.high_score = static_cast<float>(D(8, 0.5));
+  auto* h = new Handle();
+  h->kind = 6;
+  h->ucmc = std::make_unique<Ucmc>(q);
+  if (Ki12 && Ko16) h->ucmc->set_camera(Ki12, Ko16);
+  return h;
+}
+// rows of [id, state, death, birth, det_idx, age, x(4), P(16)] in list order; returns the number of tracks (or -needed)
+int orc_ucmc_dump(void* hv, double* out, int cap_rows) {
+  auto* h = static_cast<Handle*>(hv);
+  if (!h->ucmc) return 0;
+  const auto& T = h->ucmc->tracks();
+  if (static_cast<int>(T.size()) > cap_rows) return -static_cast<int>(T.size());
+  for (size_t i = 0; i < T.size(); ++i) {
+    double* r = out + i * 26;
+    r[0] = T[i].id; r[1] = T[i].state; r[2] = T[i].death; r[3] = T[i].birth; r[4] = T[i].det_idx; r[5] = T[i].age;
+    for (int k = 0; k < 4; ++k) r[6 + k] = T[i].x[k];
+    for (int k = 0; k < 16; ++k) r[10 + k] = T[i].P[k];
+  }
+  return static_cast<int>(T.size());
+}
+// the primitives on their own: distance of n tracks to m mapped detections (row-major n x m floats, as the tracker casts them), the mapping
+void orc_ucmc_distance(int n, const double* x, const double* P, int m, const double* y, const double* R, float* out) {
+  for (int i = 0; i < n; ++i) {
+    Ucmc::M4 Pi;
+    for (int k = 0; k < 16; ++k) Pi[k] = P[static_cast<size_t>(i) * 16 + k];
+    for (int j = 0; j < m; ++j) out[static_cast<size_t>(i) * m + j] = static_cast<float>(Ucmc::distance(x + static_cast<size_t>(i) * 4, Pi, y + static_cast<size_t>(j) * 2, R + static_cast<size_t>(j) * 4));
+  }
+}
 void orc_tracker_destroy(void* hv) { delete static_cast<Handle*>(hv); }
 void orc_tracker_reset(void* hv) {
   auto* h = static_cast<Handle*>(hv);
@@ -99,6 +136,7 @@ void orc_tracker_reset(void* hv) {
   if (h->bot) h->bot->reset();
   if (h->deep) h->deep->reset();
   if (h->strong) h->strong->reset();
+  if (h->ucmc) h->ucmc->reset();
 }
 
 // BoT-SORT only: the 2x3 camera-motion warp of the next update() (returns 0, or -1 for the other trackers)
@@ -126,6 +164,7 @@ int orc_tracker_update(void* hv, const float* dets, int n, const float* embs, in
     case 3: t = h->bot->update(dets, n, embs, d); break;
     case 4: t = h->deep->update(dets, n, embs, d); break;
     case 5: t = h->strong->update(dets, n, embs, d); break;
+    case 6: t = h->ucmc->update(dets, n); break;
   }
   const int rows = static_cast<int>(t.size());
   if (rows > cap) return -rows;

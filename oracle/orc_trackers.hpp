@@ -1546,4 +1546,283 @@ class StrongSort {
   std::unordered_map<int, std::vector<std::vector<float>>> samples_;
 };
 
+// =======================================================================================
+// UCMCTrack — src/trackers/ucmc.cpp (ground-plane tracker: 4-state double-precision Kalman filter [x, vx, y, vy], Mahalanobis +
+// log-determinant cost, three assignments per frame). Parity unpinned: the reference's tests hold no vector for it, and its Eigen
+// products cannot be compiled here. Where the result depends on the order of a sum (the 3-term inner products of the Joseph update,
+// the 3 x 3 products of the camera mapping) the terms are added in index order, k = 0, 1, 2, 3, without fused multiply-adds — the
+// order of Eigen's coefficient-based product of small fixed-size matrices; every other sum of the filter has at most two
+// non-zero terms (F and H are sparse), which no order can change.
+// =======================================================================================
+class Ucmc {
+ public:
+  using M4 = std::array<double, 16>;  // row-major 4 x 4
+  struct Params {
+    float det_thresh = 0.3f;
+    int max_age = 30;
+    double a1 = 100.0, a2 = 100.0, wx = 5.0, wy = 5.0, vmax = 10.0, dt = 1.0 / 30.0;
+    float high_score = 0.5f;
+  };
+  explicit Ucmc(const Params& p) : p_(p) {}
+  // CameraMapper::CameraMapper :57-83: Ki 3 x 4 and Ko 4 x 4, row-major values (what the reference's vectors hold: it maps them as
+  // column-major 4 x 3 / 4 x 4 and transposes)
+  void set_camera(const double* Ki12, const double* Ko16) {
+    double KiKo[3][4];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 4; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 4; ++k) s += Ki12[i * 4 + k] * Ko16[k * 4 + j];
+        KiKo[i][j] = s;
+      }
+    double A[3][3];
+    for (int r = 0; r < 3; ++r) { A[r][0] = KiKo[r][0]; A[r][1] = KiKo[r][1]; A[r][2] = KiKo[r][3]; }
+    inverse3(A, invA_);
+    mapped_ = true;
+  }
+  // Eigen's 3 x 3 inverse (Inverse.h, compute_inverse_size3_helper): cofactors, determinant from the first column's cofactors
+  static void inverse3(const double m[3][3], double out[3][3]) {
+    auto cof = [&](int i, int j) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      return m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+    };
+    const double c00 = cof(0, 0), c10 = cof(1, 0), c20 = cof(2, 0);
+    const double det = (c00 * m[0][0] + c10 * m[1][0]) + c20 * m[2][0];
+    const double invdet = 1.0 / det;
+    out[0][0] = c00 * invdet; out[0][1] = c10 * invdet; out[0][2] = c20 * invdet;  // result(j, i) = cofactor(i, j) * invdet
+    out[1][0] = cof(0, 1) * invdet; out[1][1] = cof(1, 1) * invdet; out[1][2] = cof(2, 1) * invdet;
+    out[2][0] = cof(0, 2) * invdet; out[2][1] = cof(1, 2) * invdet; out[2][2] = cof(2, 2) * invdet;
+  }
+  const double* inv_a() const { return &invA_[0][0]; }
+  void reset() { trk_.clear(); confirmed_.clear(); coasted_.clear(); tentative_.clear(); frame_count_ = 0; next_id_ = 0; }  // :252-259
+
+  enum State { Tentative = 0, Confirmed = 1, Coasted = 2, Deleted = 3 };
+  struct MDet {  // MappedDetection
+    int ind;
+    double y[2], R[4];
+    float conf;
+    int cls;
+    float x1, y1, x2, y2, w, h;
+  };
+  struct Track {  // UCMCSingleTrack + UCMCKalmanFilter
+    int id = 0, age = 0, death = 0, birth = 0, det_idx = -1;
+    State state = Tentative;
+    double x[4];
+    M4 P;
+  };
+  std::vector<LapResult> laps;
+  const std::vector<Track>& tracks() const { return trk_; }
+
+  // mapToGroundPlane :114-128 / mapToImageSpace :130-146
+  void map_det(float cx, float bottom, float w, float h, double y[2], double R[4]) const {
+    if (!mapped_) {
+      const double scale = 0.01;
+      y[0] = cx * scale; y[1] = bottom * scale;
+      const double ex = std::max(0.02, std::min(0.13, 0.0005 * w)), ey = std::max(0.02, std::min(0.10, 0.0005 * h));
+      R[0] = ex * ex; R[1] = 0.0; R[2] = 0.0; R[3] = ey * ey;
+      return;
+    }
+    const double eu = std::max(2.0, std::min(13.0, 0.05 * w)), ev = std::max(2.0, std::min(10.0, 0.05 * h));  // uvError :85-90
+    const double su[4] = {eu * eu, 0.0, 0.0, ev * ev};
+    // uv2xy :92-112
+    const double uv1[3] = {static_cast<double>(cx), static_cast<double>(bottom), 1.0};
+    double b[3];
+    for (int i = 0; i < 3; ++i) b[i] = (invA_[i][0] * uv1[0] + invA_[i][1] * uv1[1]) + invA_[i][2] * uv1[2];
+    const double gamma = 1.0 / b[2];
+    double C[4];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) C[i * 2 + j] = gamma * invA_[i][j] - ((gamma * gamma) * b[i]) * invA_[2][j];
+    y[0] = b[0] * gamma; y[1] = b[1] * gamma;
+    double Cs[4];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) Cs[i * 2 + j] = C[i * 2 + 0] * su[0 * 2 + j] + C[i * 2 + 1] * su[1 * 2 + j];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) R[i * 2 + j] = Cs[i * 2 + 0] * C[j * 2 + 0] + Cs[i * 2 + 1] * C[j * 2 + 1];
+  }
+  // UCMCSingleTrack ctor :152-201: process noise G Q0 G^T
+  static M4 process_noise(double dt, double wx, double wy) {
+    const double G[4][2] = {{0.5 * dt * dt, 0.0}, {dt, 0.0}, {0.0, 0.5 * dt * dt}, {0.0, dt}};
+    const double Q0[2][2] = {{wx, 0.0}, {0.0, wy}};
+    double GQ[4][2];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 2; ++j) GQ[i][j] = G[i][0] * Q0[0][j] + G[i][1] * Q0[1][j];
+    M4 Q;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) Q[i * 4 + j] = GQ[i][0] * G[j][0] + GQ[i][1] * G[j][1];
+    return Q;
+  }
+  // UCMCKalmanFilter::predict :28-31 with F = I + dt at (0,1), (2,3): (F P) F^T + Q, sums in index order
+  static void kf_predict(double x[4], M4& P, double dt, const M4& Q) {
+    double F[4][4] = {{1, dt, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, dt}, {0, 0, 0, 1}};
+    double nx[4];
+    for (int i = 0; i < 4; ++i) { double s = 0.0; for (int k = 0; k < 4; ++k) s += F[i][k] * x[k]; nx[i] = s; }
+    double FP[4][4];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) { double s = 0.0; for (int k = 0; k < 4; ++k) s += F[i][k] * P[k * 4 + j]; FP[i][j] = s; }
+    M4 NP;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) { double s = 0.0; for (int k = 0; k < 4; ++k) s += FP[i][k] * F[j][k]; NP[i * 4 + j] = s + Q[i * 4 + j]; }
+    for (int i = 0; i < 4; ++i) x[i] = nx[i];
+    P = NP;
+  }
+  struct Innov { double S[4], SI[4], det; };
+  // S = H P H^T + R (H picks rows / columns 0 and 2), its 2 x 2 inverse as Eigen forms it (1 / det, then the adjugate scaled)
+  static Innov innovation(const M4& P, const double R[4]) {
+    Innov v;
+    v.S[0] = P[0] + R[0]; v.S[1] = P[2] + R[1]; v.S[2] = P[8] + R[2]; v.S[3] = P[10] + R[3];
+    v.det = v.S[0] * v.S[3] - v.S[2] * v.S[1];
+    const double invdet = 1.0 / v.det;
+    v.SI[0] = v.S[3] * invdet; v.SI[2] = -v.S[2] * invdet; v.SI[1] = -v.S[1] * invdet; v.SI[3] = v.S[0] * invdet;
+    return v;
+  }
+  // UCMCSingleTrack::distance :213-223
+  static double distance(const double x[4], const M4& P, const double y[2], const double R[4]) {
+    const double d0 = y[0] - x[0], d1 = y[1] - x[2];
+    const Innov v = innovation(P, R);
+    const double r0 = d0 * v.SI[0] + d1 * v.SI[2], r1 = d0 * v.SI[1] + d1 * v.SI[3];  // diff^T SI
+    const double maha = r0 * d0 + r1 * d1;
+    return maha + std::log(v.det);
+  }
+  // UCMCKalmanFilter::update :33-49 (Joseph form)
+  static void kf_update(double x[4], M4& P, const double z[2], const double R[4]) {
+    const double y0 = z[0] - x[0], y1 = z[1] - x[2];
+    const Innov v = innovation(P, R);
+    double K[4][2];
+    for (int i = 0; i < 4; ++i) {
+      const double p0 = P[i * 4 + 0], p1 = P[i * 4 + 2];  // P H^T
+      K[i][0] = p0 * v.SI[0] + p1 * v.SI[2];
+      K[i][1] = p0 * v.SI[1] + p1 * v.SI[3];
+    }
+    for (int i = 0; i < 4; ++i) x[i] = x[i] + (K[i][0] * y0 + K[i][1] * y1);
+    double A[4][4];  // I - K H
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const double kh = (j == 0) ? K[i][0] : ((j == 2) ? K[i][1] : 0.0);
+        A[i][j] = ((i == j) ? 1.0 : 0.0) - kh;
+      }
+    double AP[4][4];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) { double s = 0.0; for (int k = 0; k < 4; ++k) s += A[i][k] * P[k * 4 + j]; AP[i][j] = s; }
+    double KR[4][2];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 2; ++j) KR[i][j] = K[i][0] * R[0 * 2 + j] + K[i][1] * R[1 * 2 + j];
+    M4 NP;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 4; ++k) s += AP[i][k] * A[j][k];
+        NP[i * 4 + j] = s + (KR[i][0] * K[j][0] + KR[i][1] * K[j][1]);
+      }
+    P = NP;
+  }
+
+  OutTable update(const float* dets, int n) {  // :261-343
+    laps.clear();
+    ++frame_count_;
+    std::vector<MDet> D;
+    for (int i = 0; i < n; ++i) {
+      const float* r = dets + static_cast<size_t>(i) * 6;
+      if (r[4] < p_.det_thresh) continue;
+      MDet d;
+      d.ind = i; d.x1 = r[0]; d.y1 = r[1]; d.x2 = r[2]; d.y2 = r[3]; d.conf = r[4]; d.cls = static_cast<int>(r[5]);
+      d.w = d.x2 - d.x1; d.h = d.y2 - d.y1;
+      map_det((d.x1 + d.x2) / 2.0f, d.y2, d.w, d.h, d.y, d.R);
+      D.push_back(d);
+    }
+    const M4 Q = process_noise(p_.dt, p_.wx, p_.wy);
+    // dataAssociation :345-458
+    std::vector<int> high, low;
+    for (size_t i = 0; i < D.size(); ++i) (D[i].conf >= p_.high_score ? high : low).push_back(static_cast<int>(i));
+    for (Track& t : trk_) { kf_predict(t.x, t.P, p_.dt, Q); ++t.age; t.det_idx = -1; }
+    std::vector<int> tidx = confirmed_;
+    tidx.insert(tidx.end(), coasted_.begin(), coasted_.end());
+    std::vector<int> trk_remain;
+    auto associate = [&](const std::vector<int>& T, const std::vector<int>& Dd, double thresh) {
+      Mat cost(static_cast<int>(T.size()), static_cast<int>(Dd.size()));
+      for (int i = 0; i < cost.r; ++i)
+        for (int j = 0; j < cost.c; ++j) cost(i, j) = static_cast<float>(distance(trk_[T[i]].x, trk_[T[i]].P, D[Dd[j]].y, D[Dd[j]].R));
+      LapResult r = linear_assignment(cost, static_cast<float>(thresh));
+      laps.push_back(r);
+      return r;
+    };
+    auto matched = [&](Track& t, const MDet& d) {
+      kf_update(t.x, t.P, d.y, d.R);
+      t.death = 0; t.det_idx = d.ind;
+    };
+    if (!high.empty() && !tidx.empty()) {
+      const LapResult r = associate(tidx, high, p_.a1);
+      for (const auto& m : r.matches) { Track& t = trk_[tidx[m[0]]]; matched(t, D[high[m[1]]]); t.state = Confirmed; }
+      for (int i : r.unmatched_a) trk_remain.push_back(tidx[i]);
+    } else trk_remain = tidx;
+    if (!low.empty() && !trk_remain.empty()) {
+      const LapResult r = associate(trk_remain, low, p_.a2);
+      for (const auto& m : r.matches) { Track& t = trk_[trk_remain[m[0]]]; matched(t, D[low[m[1]]]); t.state = Confirmed; }
+      for (int i : r.unmatched_a) trk_[trk_remain[i]].state = Coasted;
+    } else {
+      for (int i : trk_remain) trk_[i].state = Coasted;
+    }
+    // associateTentative :460-520: the high-confidence detections no track holds, in detection order
+    std::vector<int> det_remain;
+    for (size_t i = 0; i < D.size(); ++i) {
+      bool assigned = false;
+      for (const Track& t : trk_) if (t.det_idx == D[i].ind) { assigned = true; break; }
+      if (!assigned && D[i].conf >= p_.high_score) det_remain.push_back(static_cast<int>(i));
+    }
+    if (!det_remain.empty() && !tentative_.empty()) {
+      const LapResult r = associate(tentative_, det_remain, p_.a1);
+      for (const auto& m : r.matches) {
+        Track& t = trk_[tentative_[m[0]]];
+        matched(t, D[det_remain[m[1]]]);
+        if (++t.birth >= 2) { t.birth = 0; t.state = Confirmed; }
+      }
+      std::vector<int> rest;
+      for (int j : r.unmatched_b) rest.push_back(det_remain[j]);
+      det_remain.swap(rest);
+    }
+    // initTentative :522-535
+    for (int i : det_remain) {
+      Track t;
+      t.id = ++next_id_;
+      t.x[0] = D[i].y[0]; t.x[1] = 0.0; t.x[2] = D[i].y[1]; t.x[3] = 0.0;
+      t.P.fill(0.0);
+      t.P[0] = 1.0; t.P[5] = p_.vmax * p_.vmax / 3.0; t.P[10] = 1.0; t.P[15] = p_.vmax * p_.vmax / 3.0;
+      t.state = Tentative; t.det_idx = D[i].ind;
+      trk_.push_back(t);
+    }
+    // deleteOldTrackers :537-553
+    std::vector<Track> keep;
+    for (Track& t : trk_) {
+      ++t.death;
+      const bool del = (t.state == Coasted && t.death >= p_.max_age) || (t.state == Tentative && t.death >= 2);
+      if (!del) keep.push_back(t);
+    }
+    trk_.swap(keep);
+    // updateStatus :555-572
+    confirmed_.clear(); coasted_.clear(); tentative_.clear();
+    for (size_t i = 0; i < trk_.size(); ++i) {
+      if (trk_[i].state == Confirmed) confirmed_.push_back(static_cast<int>(i));
+      else if (trk_[i].state == Coasted) coasted_.push_back(static_cast<int>(i));
+      else if (trk_[i].state == Tentative) tentative_.push_back(static_cast<int>(i));
+    }
+    // output :303-342: the confirmed tracks that hold a detection of this frame — the detection's own box
+    OutTable out;
+    for (const Track& t : trk_) {
+      if (t.state != Confirmed || t.det_idx < 0) continue;
+      for (const MDet& d : D)
+        if (d.ind == t.det_idx) {
+          out.push_back({d.x1, d.y1, d.x2, d.y2, static_cast<float>(t.id), d.conf, static_cast<float>(d.cls), static_cast<float>(d.ind)});
+          break;
+        }
+    }
+    return out;
+  }
+
+ private:
+  Params p_;
+  bool mapped_ = false;
+  double invA_[3][3] = {};
+  std::vector<Track> trk_;
+  std::vector<int> confirmed_, coasted_, tentative_;
+  int frame_count_ = 0, next_id_ = 0;
+};
+
 }  // namespace orc

@@ -22,6 +22,7 @@ using motcpp::trackers::DeepOCSort;
 using motcpp::trackers::OCSort;
 using motcpp::trackers::Sort;
 using motcpp::trackers::StrongSORT;
+using motcpp::trackers::UCMCTrack;
 
 static Eigen::MatrixXf dets1(float x1, float y1, float x2, float y2, float c, float cls) {
   Eigen::MatrixXf d(1, 6);
@@ -339,6 +340,28 @@ int main() {
     threw = false;
     try { StrongSORT w("osnet.onnx"); } catch (const std::invalid_argument&) { threw = true; }
     CHECK(threw);  // ReID inference is outside the hot path
+  }
+  {  // UCMCTrack (ucmc.hpp:140-159): a detection seen in every frame is reported from the third frame on (tentative, birth count 1,
+     // then confirmed: ucmc.cpp:497-500) with the detection's own box, confidence, class and row; low-confidence detections never
+     // start a track; a calibrated camera (Ki 3 x 4, Ko 4 x 4) is accepted like the reference's vectors
+    UCMCTrack t;
+    CHECK(t.update(multi, img).rows() == 0);
+    CHECK(t.update(multi, img).rows() == 0);
+    auto tr = t.update(multi, img);
+    CHECK(tr.rows() == 3 && tr.cols() == 8);
+    CHECK(tr(0, 0) == 100.0f && tr(0, 3) == 200.0f && static_cast<int>(tr(0, 4)) == 1 && tr(0, 5) == 0.9f && static_cast<int>(tr(0, 7)) == 0);
+    CHECK(static_cast<int>(tr(2, 4)) == 3 && static_cast<int>(tr(2, 6)) == 1);
+    CHECK(t.update(empty, img).rows() == 0);
+    CHECK(t.update(multi, img).rows() == 3);  // coasted tracks are picked up again
+    t.reset();
+    CHECK(t.update(multi, img).rows() == 0);
+    UCMCTrack low(0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 100.0, 100.0, 5.0, 5.0, 10.0, 1.0 / 25.0, 0.95f);
+    for (int f = 0; f < 4; ++f) CHECK(low.update(multi, img).rows() == 0);  // nothing reaches high_score: no track is ever started
+    const std::vector<double> Ki = {1000, 0, 320, 0, 0, 1000, 240, 0, 0, 0, 1, 0};
+    const std::vector<double> Ko = {1, 0, 0, 0, 0, -0.5, -0.8660254037844386, 0, 0, 0.8660254037844386, -0.5, 5, 0, 0, 0, 1};
+    UCMCTrack cam(0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 100.0, 100.0, 5.0, 5.0, 10.0, 1.0 / 30.0, 0.5f, Ki, Ko);
+    cam.update(multi, img); cam.update(multi, img);
+    CHECK(cam.update(multi, img).rows() == 3);
   }
   {  // an embedding matrix with the wrong number of rows is rejected, alone and inside a StreamBatch
     BotSort t;

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORC_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORC_DIR, "build", "liborc.so")
 
-SORT, BYTETRACK, OCSORT, BOTSORT, DEEPOCSORT, STRONGSORT = 0, 1, 2, 3, 4, 5
+SORT, BYTETRACK, OCSORT, BOTSORT, DEEPOCSORT, STRONGSORT, UCMC = 0, 1, 2, 3, 4, 5, 6
 KF_XYSR, KF_XYAH, KF_XYWH = 0, 1, 2
 KF_DIM = {0: 7, 1: 8, 2: 8}
 
@@ -194,10 +194,34 @@ class Oracle:
     def tracker(self, kind, params=None):
         return OracleTracker(self, kind, params)
 
+    def ucmc(self, params=None, camera=None):
+        """UCMCTrack (kind 6): params [det_thresh, max_age, a1, a2, wx, wy, vmax, dt, high_score] in double precision, camera (Ki 3 x 4, Ko 4 x 4)"""
+        return OracleTracker(self, UCMC, params, camera)
+
+    def ucmc_distance(self, x, P, y, R):
+        x, P, y, R = (np.ascontiguousarray(a, np.float64) for a in (x, P, y, R))
+        n, m = x.shape[0], y.shape[0]
+        out = np.zeros((n, m), np.float32)
+        self.lib.orc_ucmc_distance.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.orc_ucmc_distance(n, x.ctypes.data, P.ctypes.data, m, y.ctypes.data, R.ctypes.data, out.ctypes.data)
+        return out
+
 
 class OracleTracker:
-    def __init__(self, orc, kind, params=None):
+    def __init__(self, orc, kind, params=None, camera=None):
         self.orc, self.kind = orc, kind
+        if kind == UCMC:
+            p = np.ascontiguousarray(params if params is not None else [], np.float64)
+            ki = ko = None
+            if camera is not None:
+                ki, ko = (np.ascontiguousarray(a, np.float64).reshape(-1) for a in camera)
+            orc.lib.orc_ucmc_create.restype = C.c_void_p
+            orc.lib.orc_ucmc_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+            self.h = orc.lib.orc_ucmc_create(p.ctypes.data if p.size else None, int(p.size), ki.ctypes.data if ki is not None else None,
+                                             ko.ctypes.data if ko is not None else None)
+            assert self.h
+            self._out = np.zeros((4096, 8), np.float32)
+            return
         p = f32(params if params is not None else [])
         self.h = orc.lib.orc_tracker_create(kind, p.ctypes if p.size else None, int(p.size))
         assert self.h
@@ -248,6 +272,14 @@ class OracleTracker:
             if r >= 0:
                 return buf[:r * w.value].reshape(r, w.value).copy() if r else np.zeros((0, 0), np.float32)
             buf = np.zeros((-r + 8) * max(w.value, 1), np.float32)
+
+    def dump_f64(self):
+        """UCMCTrack: [rows, 26] float64 — id, state, death, birth, det_idx, age, x(4), P(16)"""
+        buf = np.zeros((4096, 26), np.float64)
+        self.orc.lib.orc_ucmc_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        r = self.orc.lib.orc_ucmc_dump(self.h, buf.ctypes.data, buf.shape[0])
+        assert r >= 0
+        return buf[:r].copy()
 
     def dump_features(self):
         d = C.c_int()

@@ -135,6 +135,27 @@ def test_cli_results_match_oracle(tmp_path, orc, method, kind, params):
 
 
 @pytest.mark.gpu
+def test_cli_ucmc_matches_oracle_on_the_mot17_detections(tmp_path, orc):
+    """UCMCTrack through the command-line tool with the reference tool's values (motcpp_eval.cpp:112-131: dt = 1.0 / fps, no camera
+    file) on the real MOT17 detections of the fixture: the result files equal the oracle's tables line for line."""
+    build()
+    root, res = make_root(str(tmp_path)), os.path.join(str(tmp_path), "results")
+    out = subprocess.run([EVAL, root, res, "ucmc"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = 0
+    for seq in mot17.SEQS:
+        trk = orc.ucmc([0.3, 30, 100.0, 100.0, 5.0, 5.0, 10.0, 1.0 / 25, 0.5])
+        want = []
+        for f, d in enumerate(mot17.load(seq), start=1):
+            if d.shape[0] == 0:
+                continue
+            want += mot_lines(trk.update(d), f)
+        assert open(os.path.join(res, seq + ".txt")).read() == "".join(want), seq
+        rows += len(want)
+    assert rows > 1000
+
+
+@pytest.mark.gpu
 def test_cli_ablation_offset(tmp_path, orc):
     build()
     gt = {"MOT17-02-FRCNN": 300, "MOT17-04-FRCNN": 1050}  # 02: det frames run to 600 > 1.5 x 300 -> offset 300; 04: no offset

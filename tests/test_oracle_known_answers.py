@@ -595,3 +595,62 @@ def test_bytetrack_gtest_cases(orc):  # tests/test_bytetrack.cpp:38-123
     assert t.dump_states().shape[0] == 1
     for fps in (30, 60):                                                                            # FrameRateAwareness
         assert orc.tracker(orclib.BYTETRACK, [0.1, 0.45, 0.8, 30, fps]).update(SINGLE).shape[1] == 8
+
+
+# ---- UCMCTrack (src/trackers/ucmc.cpp): the restatement against answers derived by hand from the reference's text ----------------------
+def test_ucmc_confirmation_takes_three_frames_and_low_confidence_never_starts_a_track():
+    """A detection seen in every frame: frame 1 starts a tentative track (initTentative :522-535; deleteOldTrackers leaves death_count 1),
+    frame 2 matches it in associateTentative (birth_count 1 < 2: still tentative, no output), frame 3 makes birth_count 2 -> Confirmed
+    (:497-500) and the track is reported with the DETECTION's own box, confidence, class and row (:303-342). A detection between
+    det_thresh and high_score takes part in the second association only and never starts a track (:466-478 asks conf >= high_score)."""
+    orc = orclib.load()
+    t = orc.ucmc()
+    d = np.array([[100, 100, 150, 220, 0.9, 2], [400, 300, 440, 380, 0.4, 1]], np.float32)
+    assert t.update(d).shape[0] == 0
+    s = t.dump_f64()
+    assert s.shape[0] == 1 and s[0, :6].tolist() == [1, 0, 1, 0, 0, 0]  # id 1, Tentative, death 1, birth 0, holds detection 0, age 0
+    # UCMCSingleTrack ctor :152-201 with the image-space fallback (:130-146): x = (cx, bottom) / 100, zero velocity, P = diag(1, vmax^2 / 3, 1, vmax^2 / 3)
+    assert s[0, 6:10].tolist() == [np.float32(125.0) * 0.01, 0.0, np.float32(220.0) * 0.01, 0.0]
+    assert np.array_equal(s[0, 10:].reshape(4, 4), np.diag([1.0, 100.0 / 3.0, 1.0, 100.0 / 3.0]))
+    assert t.update(d).shape[0] == 0
+    assert t.dump_f64()[0, :6].tolist() == [1, 0, 1, 1, 0, 1]
+    out = t.update(d)
+    assert out.tolist() == [[100.0, 100.0, 150.0, 220.0, 1.0, float(np.float32(0.9)), 2.0, 0.0]]
+    assert t.dump_f64()[0, :6].tolist() == [1, 1, 1, 0, 0, 2]  # Confirmed, birth_count back to 0
+    assert t.dump_f64().shape[0] == 1  # the 0.4 detection never became a track
+
+
+def test_ucmc_coasting_and_deletion():
+    """A confirmed track without detections: Coasted at once (:448-452), deleted when death_count reaches max_age (:544-546); a tentative
+    track that misses one frame is deleted (death_count 2, :547)."""
+    orc = orclib.load()
+    t = orc.ucmc([0.3, 3, 100.0, 100.0, 5.0, 5.0, 10.0, 1.0 / 30.0, 0.5])
+    d = np.array([[100, 100, 150, 220, 0.9, 0]], np.float32)
+    for _ in range(3):
+        t.update(d)
+    assert t.dump_f64()[0, 1] == 1
+    none = np.zeros((0, 6), np.float32)
+    t.update(none)
+    assert t.dump_f64()[0, 1:3].tolist() == [2, 2]  # Coasted; death_count: 1 after the matched frame, 2 now
+    t.update(none)
+    assert t.dump_f64().shape[0] == 0  # death_count 3 >= max_age 3
+    t.update(d)  # a new tentative track (id 2) ...
+    assert t.dump_f64()[0, :2].tolist() == [2, 0]
+    t.update(none)  # ... that misses the next frame
+    assert t.dump_f64().shape[0] == 0
+
+
+def test_ucmc_distance_and_camera_mapping_by_hand():
+    """distance (:213-223): x = 0, P = I, y = (3, 4), R = I: S = 2 I, Mahalanobis 25 / 2, log det = log 4. Camera (:57-112): Ki = [I | 0],
+    Ko = a translation by 5 along the optical axis gives A = diag(1, 1, 5): the ground point of pixel (u, v) is (5 u, 5 v)."""
+    import math
+    orc = orclib.load()
+    got = orc.ucmc_distance(np.zeros((1, 4)), np.eye(4).reshape(1, 16), np.array([[3.0, 4.0]]), np.array([[1.0, 0, 0, 1.0]]))
+    assert got[0, 0] == np.float32(12.5 + math.log(4.0))
+    ki = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float64)
+    ko = np.eye(4)
+    ko[2, 3] = 5.0
+    t = orc.ucmc(None, (ki, ko))
+    t.update(np.array([[10, 20, 30, 60, 0.9, 0]], np.float32))
+    s = t.dump_f64()
+    assert s[0, 6] == 5.0 * 20.0 and s[0, 8] == 5.0 * 60.0  # cx = 20, bottom = 60

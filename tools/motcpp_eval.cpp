@@ -1,6 +1,6 @@
 // MOT evaluation driver for the MI355X-backed trackers. Command-line contract (positional arguments, defaults, one
 // <sequence>.txt per sequence in MOT format) follows the reference's tools/motcpp_eval.cpp:19-468; the program itself is
-// organised differently: a tracker table, a frame plan per sequence, then one loop. Trackers built here: sort, bytetrack,
+// organised differently: a tracker table, a frame plan per sequence, then one loop. Trackers built here: sort, ucmc, bytetrack,
 // ocsort, botsort, deepocsort, strongsort. Images are never decoded: trackers get a blank frame of the sequence's size.
 #include <algorithm>
 #include <filesystem>
@@ -48,6 +48,11 @@ const std::map<std::string, std::function<TrackerPtr(int)>>& tracker_table() {
       {"strongsort",
        [](int) {
          return TrackerPtr(new T::StrongSORT("", false, false, 0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 0.6f, 0.4f, 0.7f, 3, 100, 0.98f, 0.9f));
+       }},
+      // the reference tool's values (motcpp_eval.cpp:112-131): dt from the sequence's frame rate, no camera file (image-space fallback)
+      {"ucmc",
+       [](int fps) {
+         return TrackerPtr(new T::UCMCTrack(0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 100.0, 100.0, 5.0, 5.0, 10.0, 1.0 / fps, 0.5f));
        }},
   };
   return table;

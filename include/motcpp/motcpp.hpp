@@ -9,5 +9,6 @@
 #include "trackers/deepocsort.hpp"
 #include "trackers/strongsort.hpp"
 #include "trackers/ucmc.hpp"
+#include "trackers/boosttrack.hpp"
 #include "utils/matching.hpp"
 #include "utils/iou.hpp"

@@ -326,6 +326,31 @@ typedef struct mot_ucmc_task {
 } mot_ucmc_task;
 int mot_ucmc_run(mot_ctx* ctx, int op, const mot_ucmc_task* tasks, int ntasks, int max_n, int max_m);
 
+/* ---- BoostTrack's filter and costs (src/trackers/boosttrack.cpp) ----------------------------- */
+/* State [cx, cy, h, r, vx, vy, vh, vr] with constant noise (BoostKalmanFilter :22-75): records of 72 floats (mean[8], covariance[64]) in
+ * `slab`, like the other 8-state filters. Detections: SoA planes [6][ldd] (x1, y1, x2, y2, conf, cls).
+ *   MOT_BOOST_PREDICT n tracks slots[i]: x = F x, P = F P F^T + Q; boxes[i*4..] = get_state() of the predicted state (:107-115)
+ *   MOT_BOOST_DLO     n detections x m tracks: max_s[i] = max_j iou_batch(det i, box j) (:376-391), vt[i] = 1 when some j has
+ *                     iou > max(0.95 - (tsu[j] - 1), 0.8) (:409-424); boxes = the predicted boxes [m][4]
+ *   MOT_BOOST_COST    cost[i * ldc + j] = (1 - IoU as get_iou_matrix computes it, :297-329) - lambda_mhd * (limit - min(mh, limit)) / limit,
+ *                     mh = the diagonal Mahalanobis distance of detection didx[i] to track slots[j] (:331-359, :598-611); n detections x m tracks
+ *   MOT_BOOST_UPDATE  n pairs: track slots[i] with detection didx[i] (BoostKalmanFilter::update :61-75; S^-1 = partial-pivot LU inverse)
+ *   MOT_BOOST_INIT    n births: track slots[i] from detection didx[i] (:22-54)
+ *   MOT_BOOST_BOXES   boxes[i*4..] = get_state() of track slots[i] */
+enum { MOT_BOOST_PREDICT = 0, MOT_BOOST_DLO = 1, MOT_BOOST_COST = 2, MOT_BOOST_UPDATE = 3, MOT_BOOST_INIT = 4, MOT_BOOST_BOXES = 5 };
+typedef struct mot_boost_task {
+  int32_t n, m, ldd, ldc;
+  float* slab;
+  const int32_t* slots; const int32_t* didx;
+  const float* dets;
+  float* boxes;
+  const int32_t* tsu;
+  float* max_s; int32_t* vt;
+  float* cost;
+  float lambda_mhd, reserved;
+} mot_boost_task;
+int mot_boost_run(mot_ctx* ctx, int op, const mot_boost_task* tasks, int ntasks, int max_n, int max_m);
+
 /* ---- linear assignment ---------------------------------------------------------------- */
 typedef enum mot_lap_mode {
   MOT_LAP_PLAIN = 0,

@@ -9,6 +9,8 @@
  *  BoT-SORT  [track_high, track_low, new_track, track_buffer, match_thresh, proximity, appearance,
  *             frame_rate, fuse_first_associate, with_reid, max_age, max_obs]
  *  StrongSORT [min_conf, max_cos_dist, max_iou_dist, n_init, nn_budget, mc_lambda, ema_alpha, max_age]
+ *  BoostTrack (7, motion only) [det_thresh, max_age, min_hits, iou_threshold, min_box_area, aspect_ratio_thresh, lambda_iou, lambda_mhd,
+ *              lambda_shape, use_dlo_boost, use_duo_boost, dlo_boost_coef, use_sb, use_vt]
  *  UCMCTrack (6) [det_thresh, max_age, a1, a2, wx, wy, vmax, fps, high_score] (dt = 1.0 / fps in double precision)
  * Functions return >= 0 on success and a negative value on error (motcpp_last_error() has the message).
  */

@@ -38,6 +38,15 @@ Staged* make(std::shared_ptr<Device> dev, int kind, const float* p, int np) {
     case 5:  // min_conf, max_cos_dist, max_iou_dist, n_init, nn_budget, mc_lambda, ema_alpha, max_age
       return make_strongsort(dev, P(p, np, 0, 0.1f), P(p, np, 1, 0.2f), P(p, np, 2, 0.7f), (int)P(p, np, 3, 3), (int)P(p, np, 4, 100), P(p, np, 5, 0.98f),
                              P(p, np, 6, 0.9f), (int)P(p, np, 7, 30));
+    case 7: {  // BoostTrack, motion only: det_thresh, max_age, min_hits, iou_threshold, min_box_area, aspect_ratio_thresh, lambda_iou, lambda_mhd,
+               // lambda_shape, use_dlo_boost, use_duo_boost, dlo_boost_coef, use_sb, use_vt
+      BoostParams q;
+      q.det_thresh = P(p, np, 0, 0.6f); q.max_age = (int)P(p, np, 1, 60); q.min_hits = (int)P(p, np, 2, 3); q.iou_threshold = P(p, np, 3, 0.3f);
+      q.min_box_area = (int)P(p, np, 4, 10); q.aspect_ratio_thresh = P(p, np, 5, 1.6f); q.lambda_iou = P(p, np, 6, 0.5f); q.lambda_mhd = P(p, np, 7, 0.25f);
+      q.lambda_shape = P(p, np, 8, 0.25f); q.use_dlo = P(p, np, 9, 1.f) != 0.f; q.use_duo = P(p, np, 10, 1.f) != 0.f; q.dlo_coef = P(p, np, 11, 0.65f);
+      q.use_sb = P(p, np, 12, 0.f) != 0.f; q.use_vt = P(p, np, 13, 0.f) != 0.f;
+      return make_boosttrack(dev, q);
+    }
     case 6: {  // det_thresh, max_age, a1, a2, wx, wy, vmax, fps (dt = 1.0 / fps in double precision, as the evaluation tool forms it), high_score
       UcmcParams q;
       q.det_thresh = P(p, np, 0, 0.3f); q.max_age = (int)P(p, np, 1, 30); q.a1 = P(p, np, 2, 100.f); q.a2 = P(p, np, 3, 100.f);

@@ -111,6 +111,18 @@ struct UcmcParams {
   double Ki[12] = {}, Ko[16] = {};
 };
 Staged* make_ucmc(std::shared_ptr<Device>, const UcmcParams& p);
+// BoostTrack (src/trackers/boosttrack.cpp), motion-only configuration
+struct BoostParams {
+  float det_thresh = 0.6f;
+  int max_age = 60, min_hits = 3;
+  float iou_threshold = 0.3f;
+  int min_box_area = 10;
+  float aspect_ratio_thresh = 1.6f, lambda_iou = 0.5f, lambda_mhd = 0.25f, lambda_shape = 0.25f;
+  bool use_dlo = true, use_duo = true;
+  float dlo_coef = 0.65f;
+  bool use_sb = false, use_vt = false;
+};
+Staged* make_boosttrack(std::shared_ptr<Device>, const BoostParams& p);
 Staged* make_botsort(std::shared_ptr<Device>, float track_high, float track_low, float new_track, int track_buffer,
                      float match_thresh, float proximity, float appearance, int frame_rate, bool fuse_first, bool with_reid,
                      int max_age, int max_obs);

@@ -314,6 +314,20 @@ StrongSORT::StrongSORT(const std::string& reid_weights, bool /*use_half*/, bool 
   // (the tracker gets the constructor's max_age, strongsort.cpp:841-842; BaseTracker only adjusts max_obs)
   adopt(rt::make_strongsort(dev_, min_conf, max_cos_dist, max_iou_dist, n_init, nn_budget, mc_lambda, ema_alpha, max_age));
 }
+BoostTrackTracker::BoostTrackTracker(const std::string& reid_weights, bool /*use_half*/, bool /*use_gpu*/, float det_thresh, int max_age, int max_obs,
+                                     int min_hits, float iou_threshold, bool per_class, int nr_classes, const std::string& asso_func, bool is_obb,
+                                     bool /*use_ecc*/, int min_box_area, float aspect_ratio_thresh, const std::string& /*cmc_method*/, float lambda_iou,
+                                     float lambda_mhd, float lambda_shape, bool use_dlo_boost, bool use_duo_boost, float dlo_boost_coef,
+                                     bool /*s_sim_corr*/, bool /*use_rich_s*/, bool use_sb, bool use_vt, bool with_reid, int device_index)
+    : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
+  if (!reid_weights.empty() || with_reid)
+    throw std::invalid_argument("motcpp_amd: BoostTrack is built in its motion-only configuration (with_reid = false, no ReID weights)");
+  rt::BoostParams q;
+  q.det_thresh = det_thresh_; q.max_age = max_age_; q.min_hits = min_hits_; q.iou_threshold = iou_threshold_; q.min_box_area = min_box_area;
+  q.aspect_ratio_thresh = aspect_ratio_thresh; q.lambda_iou = lambda_iou; q.lambda_mhd = lambda_mhd; q.lambda_shape = lambda_shape;
+  q.use_dlo = use_dlo_boost; q.use_duo = use_duo_boost; q.dlo_coef = dlo_boost_coef; q.use_sb = use_sb; q.use_vt = use_vt;
+  adopt(rt::make_boosttrack(dev_, q));
+}
 UCMCTrack::UCMCTrack(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class, int nr_classes,
                      const std::string& asso_func, bool is_obb, double a1, double a2, double wx, double wy, double vmax, double dt, float high_score,
                      const std::vector<double>& Ki, const std::vector<double>& Ko, int device_index)

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "../../include/motcpp_amd.h"
+#include "kf_small.hpp"
 
 namespace {
 
@@ -144,58 +145,7 @@ __device__ __forceinline__ void chol4_solve(const float L[4][4], float b[4]) {
     b[i] /= L[i][i];
   }
 }
-// Partial-pivot LU inverse of a 4x4 (XYWH's S.inverse(), xywh_kf.hpp:124).
-__device__ __forceinline__ void inv_lu4(const float S[4][4], float inv[4][4]) {
-  float lu[4][4];
-  int perm[4] = {0, 1, 2, 3};
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) lu[i][j] = S[i][j];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    int p = k;
-    float best = fabsf(lu[k][k]);
-#pragma unroll
-    for (int i = k + 1; i < 4; ++i) {
-      float v = fabsf(lu[i][k]);
-      if (v > best) { best = v; p = i; }
-    }
-    // row swap with a data-dependent index done as selects to keep everything in registers
-#pragma unroll
-    for (int i = k + 1; i < 4; ++i) {
-      if (p == i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { float t = lu[k][j]; lu[k][j] = lu[i][j]; lu[i][j] = t; }
-        int tp = perm[k]; perm[k] = perm[i]; perm[i] = tp;
-      }
-    }
-#pragma unroll
-    for (int i = k + 1; i < 4; ++i) lu[i][k] /= lu[k][k];
-#pragma unroll
-    for (int i = k + 1; i < 4; ++i)
-#pragma unroll
-      for (int j = k + 1; j < 4; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    float b[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = (perm[i] == c) ? 1.0f : 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = i + 1; r < 4; ++r) b[r] -= b[i] * lu[r][i];
-#pragma unroll
-    for (int i = 3; i >= 0; --i) {
-      b[i] /= lu[i][i];
-#pragma unroll
-      for (int r = 0; r < i; ++r) b[r] -= b[i] * lu[r][i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) inv[i][c] = b[i];
-  }
-}
+using mot::kfs::inv_lu4;  // kf_small.hpp: partial-pivot LU inverse of a 4x4 (XYWH's S.inverse(), xywh_kf.hpp:124)
 
 __device__ __forceinline__ float dot4(const float a[4], const float b0, const float b1, const float b2, const float b3) {
   float s = a[0] * b0;

@@ -20,6 +20,7 @@ struct Handle {
   std::unique_ptr<DeepOCSort> deep;
   std::unique_ptr<StrongSort> strong;
   std::unique_ptr<Ucmc> ucmc;
+  std::unique_ptr<BoostTrackOrc> boost;
   const std::vector<LapResult>* laps() const {
     switch (kind) {
       case 1: return &byte->laps;
@@ -28,6 +29,7 @@ struct Handle {
       case 4: return &deep->laps;
       case 5: return &strong->laps;
       case 6: return &ucmc->laps;
+      case 7: return &boost->laps;
       default: return nullptr;
     }
   }
@@ -86,6 +88,16 @@ void* orc_tracker_create(int kind, const float* p, int np) {
       h->strong = std::make_unique<StrongSort>(P(p, np, 0, 0.1f), P(p, np, 1, 0.2f), P(p, np, 2, 0.7f), (int)P(p, np, 3, 3), (int)P(p, np, 4, 100),
                                                P(p, np, 5, 0.98f), P(p, np, 6, 0.9f), (int)P(p, np, 7, 30));
       break;
+    case 7: {  // BoostTrack, motion only: det_thresh, max_age, min_hits, iou_threshold, min_box_area, aspect_ratio_thresh, lambda_iou, lambda_mhd,
+               // lambda_shape, use_dlo_boost, use_duo_boost, dlo_boost_coef, use_sb, use_vt
+      BoostTrackOrc::Params q;
+      q.det_thresh = P(p, np, 0, 0.6f); q.max_age = (int)P(p, np, 1, 60); q.min_hits = (int)P(p, np, 2, 3); q.iou_threshold = P(p, np, 3, 0.3f);
+      q.min_box_area = (int)P(p, np, 4, 10); q.aspect_ratio_thresh = P(p, np, 5, 1.6f); q.lambda_iou = P(p, np, 6, 0.5f); q.lambda_mhd = P(p, np, 7, 0.25f);
+      q.lambda_shape = P(p, np, 8, 0.25f); q.use_dlo = P(p, np, 9, 1.f) != 0.f; q.use_duo = P(p, np, 10, 1.f) != 0.f; q.dlo_coef = P(p, np, 11, 0.65f);
+      q.use_sb = P(p, np, 12, 0.f) != 0.f; q.use_vt = P(p, np, 13, 0.f) != 0.f;
+      h->boost = std::make_unique<BoostTrackOrc>(q);
+      break;
+    }
     default:
       delete h;
       return nullptr;
@@ -137,6 +149,7 @@ void orc_tracker_reset(void* hv) {
   if (h->deep) h->deep->reset();
   if (h->strong) h->strong->reset();
   if (h->ucmc) h->ucmc->reset();
+  if (h->boost) h->boost->reset();
 }
 
 // BoT-SORT only: the 2x3 camera-motion warp of the next update() (returns 0, or -1 for the other trackers)
@@ -165,6 +178,7 @@ int orc_tracker_update(void* hv, const float* dets, int n, const float* embs, in
     case 4: t = h->deep->update(dets, n, embs, d); break;
     case 5: t = h->strong->update(dets, n, embs, d); break;
     case 6: t = h->ucmc->update(dets, n); break;
+    case 7: t = h->boost->update(dets, n); break;
   }
   const int rows = static_cast<int>(t.size());
   if (rows > cap) return -rows;
@@ -199,6 +213,7 @@ int orc_tracker_dump_states(void* hv, float* out, int cap_floats, int* w) {
     case 3: s = h->bot->dump_states(); break;
     case 4: s = h->deep->dump_states(); break;
     case 5: s = h->strong->dump_states(); break;
+    case 7: s = h->boost->dump_states(); break;
   }
   *w = s.empty() ? 0 : static_cast<int>(s[0].size());
   size_t need = s.size() * static_cast<size_t>(*w);

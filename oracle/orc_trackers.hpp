@@ -1825,4 +1825,218 @@ class Ucmc {
   int frame_count_ = 0, next_id_ = 0;
 };
 
+// =======================================================================================
+// BoostTrack — src/trackers/boosttrack.cpp, motion-only configuration (with_reid = false, the constructor's default; no ECC: the
+// camera-motion step needs the image). Parity unpinned (no vector in the reference's tests; Eigen's dynamic-size products cannot be
+// compiled here). The filter's F, H, Q, R are sparse: predict and the projection have at most two non-zero terms per sum; the gain, the
+// state and covariance updates are k-ordered chains (mul() above); S^-1 is the partial-pivot LU inverse Eigen uses for a dynamic 4 x 4.
+// =======================================================================================
+class BoostTrackOrc {
+ public:
+  static float iou_pair(const Box& a, const Box& b) {  // one entry of utils::iou_batch (iou.hpp:63-100), same operation order as orc::iou_batch
+    const float a1 = (a[2] - a[0]) * (a[3] - a[1]), a2 = (b[2] - b[0]) * (b[3] - b[1]);
+    const float w = std::max(0.0f, std::min(a[2], b[2]) - std::max(a[0], b[0])), h = std::max(0.0f, std::min(a[3], b[3]) - std::max(a[1], b[1]));
+    const float inter = w * h, uni = a1 + a2 - inter;
+    return (uni > 0.0f) ? (inter / uni) : 0.0f;
+  }
+  struct Params {
+    float det_thresh = 0.6f;
+    int max_age = 60, min_hits = 3;
+    float iou_threshold = 0.3f;
+    int min_box_area = 10;
+    float aspect_ratio_thresh = 1.6f, lambda_iou = 0.5f, lambda_mhd = 0.25f, lambda_shape = 0.25f;
+    bool use_dlo = true, use_duo = true;
+    float dlo_coef = 0.65f;
+    bool use_sb = false, use_vt = false;
+  };
+  explicit BoostTrackOrc(const Params& p) : p_(p) {}
+  void reset() { trk_.clear(); frame_count_ = 0; next_id_ = 0; }  // :272-277
+
+  struct Track {  // BoostTrack + BoostKalmanFilter :22-135
+    int id = 0, cls = 0, det_ind = -1, tsu = 0, age = 0, hit_streak = 0;
+    float conf = 0.f;
+    float x[8];
+    SMat<8, 8> P;
+    Box state() const {  // get_state :107-115
+      const float cx = x[0], cy = x[1], h = x[2], r = x[3];
+      const float w = r * h;
+      return {cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2};
+    }
+  };
+  static void to_z(const float b[4], float z[4]) {  // convert_bbox_to_z :126-134
+    const float w = b[2] - b[0], h = b[3] - b[1];
+    z[0] = b[0] + w / 2.0f; z[1] = b[1] + h / 2.0f; z[2] = h; z[3] = (h > 1e-6f) ? w / h : 0.0f;
+  }
+  static void kf_init(Track& t, const float z[4]) {  // :22-54
+    for (int k = 0; k < 4; ++k) { t.x[k] = z[k]; t.x[k + 4] = 0.0f; }
+    t.P = SMat<8, 8>::zero();
+    for (int k = 0; k < 4; ++k) { t.P[k][k] = 10.0f; t.P[k + 4][k + 4] = 10.0f * 1000.0f; }
+  }
+  static void kf_predict(Track& t) {  // :56-59: F = [I I; 0 I], Q = diag(10 x 4, 0.01 x 4)
+    for (int k = 0; k < 4; ++k) t.x[k] = t.x[k] + t.x[k + 4];
+    SMat<8, 8> FP = t.P;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 8; ++j) FP[i][j] = t.P[i][j] + t.P[i + 4][j];
+    SMat<8, 8> N = FP;
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 4; ++j) N[i][j] = FP[i][j] + FP[i][j + 4];
+    for (int k = 0; k < 4; ++k) { N[k][k] = N[k][k] + 10.0f; N[k + 4][k + 4] = N[k + 4][k + 4] + 0.01f; }
+    t.P = N;
+  }
+  static void kf_update(Track& t, const float z[4]) {  // :61-75
+    const float Rd[4] = {1.0f, 1.0f, 10.0f, 0.01f};
+    SMat<4, 4> S;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) S[i][j] = t.P[i][j] + ((i == j) ? Rd[i] : 0.0f);
+    const SMat<4, 4> Si = inverse_lu4(S);
+    SMat<8, 4> PH;
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 4; ++j) PH[i][j] = t.P[i][j];
+    const SMat<8, 4> K = mul(PH, Si);
+    float inn[4];
+    for (int k = 0; k < 4; ++k) inn[k] = z[k] - t.x[k];
+    for (int i = 0; i < 8; ++i) {
+      float a = K[i][0] * inn[0];
+      for (int k = 1; k < 4; ++k) a += K[i][k] * inn[k];
+      t.x[i] = t.x[i] + a;
+    }
+    const SMat<8, 4> KS = mul(K, S);
+    SMat<4, 8> Kt;
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 4; ++j) Kt[j][i] = K[i][j];
+    const SMat<8, 8> D = mul(KS, Kt);
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 8; ++j) t.P[i][j] = t.P[i][j] - D[i][j];
+  }
+  std::vector<LapResult> laps;
+  const std::vector<Track>& tracks() const { return trk_; }
+
+  OutTable update(const float* dets, int n) {  // :465-699
+    laps.clear();
+    ++frame_count_;
+    std::vector<Det7> D = wrap_dets(dets, n);
+    for (Track& t : trk_) {  // BoostTrack::predict :156-163
+      kf_predict(t);
+      ++t.age;
+      if (t.tsu > 0) t.hit_streak = 0;
+      ++t.tsu;
+    }
+    // dlo_confidence_boost :361-426 (duo_confidence_boost returns its input, :428-432)
+    if (p_.use_dlo && !D.empty() && !trk_.empty()) {
+      std::vector<Box> tb(trk_.size());
+      for (size_t j = 0; j < trk_.size(); ++j) tb[j] = trk_[j].state();
+      for (Det7& d : D) {
+        float max_s = 0.0f;
+        bool first = true, vt = false;
+        for (size_t j = 0; j < trk_.size(); ++j) {
+          const float s = iou_pair(d.box(), tb[j]);
+          if (first || s > max_s) { max_s = s; first = false; }  // rowwise().maxCoeff()
+          const float th = std::max(0.95f - static_cast<float>(trk_[j].tsu - 1), 0.8f);
+          if (s > th) vt = true;
+        }
+        if (!p_.use_sb && !p_.use_vt) d.conf = std::max(d.conf, max_s * p_.dlo_coef);
+        else {
+          if (p_.use_sb) {
+            const float alpha = 0.65f;
+            const float bc = alpha * d.conf + (1.0f - alpha) * std::pow(max_s, 1.5f);
+            d.conf = std::max(d.conf, bc);
+          }
+          if (p_.use_vt && vt) d.conf = std::max(d.conf, p_.det_thresh + 1e-5f);
+        }
+      }
+    }
+    std::vector<Det7> F;
+    for (const Det7& d : D) if (d.conf >= p_.det_thresh) F.push_back(d);
+    const int nd = static_cast<int>(F.size()), nt = static_cast<int>(trk_.size());
+    std::vector<std::array<int, 2>> matches;
+    std::vector<int> ud, ut;
+    if (nd > 0 && nt > 0) {
+      Mat cost(nd, nt);
+      const float limit = 13.2767f;
+      for (int i = 0; i < nd; ++i) {
+        float z[4];
+        const float b[4] = {F[i].x1, F[i].y1, F[i].x2, F[i].y2};
+        to_z(b, z);
+        for (int j = 0; j < nt; ++j) {
+          const Box tbx = trk_[j].state();
+          // get_iou_matrix :297-329
+          const float x1 = std::max(b[0], tbx[0]), y1 = std::max(b[1], tbx[1]), x2 = std::min(b[2], tbx[2]), y2 = std::min(b[3], tbx[3]);
+          const float inter = std::max(0.0f, x2 - x1) * std::max(0.0f, y2 - y1);
+          const float da = (b[2] - b[0]) * (b[3] - b[1]), ta = (tbx[2] - tbx[0]) * (tbx[3] - tbx[1]);
+          const float uni = da + ta - inter;
+          const float iou = (uni > 1e-6f) ? inter / uni : 0.0f;
+          float c = 1.0f - iou;
+          // get_mh_dist_matrix :331-359 (diagonal covariance), then the similarity (:600-611)
+          float mh = 0.0f;
+          for (int k = 0; k < 4; ++k) {
+            const float df = z[k] - trk_[j].x[k];
+            const float term = df * df * (1.0f / trk_[j].P[k][k]);
+            mh = (k == 0) ? term : mh + term;
+          }
+          if (mh > limit) mh = limit;
+          const float sim = (limit - mh) / limit;
+          c = c - p_.lambda_mhd * sim;
+          cost(i, j) = c;
+        }
+      }
+      const LapResult r = linear_assignment(cost, p_.iou_threshold);
+      laps.push_back(r);
+      matches = r.matches; ud = r.unmatched_a; ut = r.unmatched_b;
+    } else if (nd > 0) {
+      for (int i = 0; i < nd; ++i) ud.push_back(i);
+    }
+    for (const auto& m : matches) {  // BoostTrack::update :165-181
+      Track& t = trk_[m[1]];
+      const Det7& d = F[m[0]];
+      t.tsu = 0; ++t.hit_streak;
+      const float b[4] = {d.x1, d.y1, d.x2, d.y2};
+      float z[4];
+      to_z(b, z);
+      kf_update(t, z);
+      t.conf = d.conf; t.cls = static_cast<int>(d.cls); t.det_ind = d.ind;
+    }
+    for (int i : ud) {  // :652-661
+      const Det7& d = F[i];
+      Track t;
+      const float b[4] = {d.x1, d.y1, d.x2, d.y2};
+      float z[4];
+      to_z(b, z);
+      kf_init(t, z);
+      t.id = ++next_id_; t.conf = d.conf; t.cls = static_cast<int>(d.cls); t.det_ind = d.ind;
+      trk_.push_back(t);
+    }
+    OutTable out;
+    for (const Track& t : trk_) {
+      if (t.tsu < 1 && (t.hit_streak >= p_.min_hits || frame_count_ <= p_.min_hits)) {
+        const Box b = t.state();
+        // filter_outputs :434-463
+        const float w = b[2] - b[0], h = b[3] - b[1];
+        const float area = w * h, ar = w / (h + 1e-6f);
+        if (ar <= p_.aspect_ratio_thresh && area > static_cast<float>(p_.min_box_area))
+          out.push_back({b[0], b[1], b[2], b[3], static_cast<float>(t.id), t.conf, static_cast<float>(t.cls), static_cast<float>(t.det_ind)});
+      }
+    }
+    std::vector<Track> keep;
+    for (const Track& t : trk_) if (!(t.tsu > p_.max_age)) keep.push_back(t);
+    trk_.swap(keep);
+    return out;
+  }
+  std::vector<std::vector<float>> dump_states() const {  // [id, x(8), P(64)]
+    std::vector<std::vector<float>> rows;
+    for (const Track& t : trk_) {
+      std::vector<float> r;
+      r.push_back(static_cast<float>(t.id));
+      for (int k = 0; k < 8; ++k) r.push_back(t.x[k]);
+      for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) r.push_back(t.P[i][j]);
+      rows.push_back(r);
+    }
+    return rows;
+  }
+
+ private:
+  Params p_;
+  std::vector<Track> trk_;
+  int frame_count_ = 0, next_id_ = 0;
+};
+
 }  // namespace orc

@@ -23,6 +23,7 @@ using motcpp::trackers::OCSort;
 using motcpp::trackers::Sort;
 using motcpp::trackers::StrongSORT;
 using motcpp::trackers::UCMCTrack;
+using motcpp::trackers::BoostTrackTracker;
 
 static Eigen::MatrixXf dets1(float x1, float y1, float x2, float y2, float c, float cls) {
   Eigen::MatrixXf d(1, 6);
@@ -362,6 +363,24 @@ int main() {
     UCMCTrack cam(0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 100.0, 100.0, 5.0, 5.0, 10.0, 1.0 / 30.0, 0.5f, Ki, Ko);
     cam.update(multi, img); cam.update(multi, img);
     CHECK(cam.update(multi, img).rows() == 3);
+  }
+  {  // BoostTrackTracker (boosttrack.hpp:95-125), motion only: new tracks are reported at once while frame_count <= min_hits
+     // (boosttrack.cpp:663-680); a detection below det_thresh that sits on a predicted track comes back with the boosted confidence
+     // max_iou * dlo_boost_coef (:393-400); ReID is outside the path
+    BoostTrackTracker t;
+    auto tr = t.update(multi, img);
+    CHECK(tr.rows() == 3 && tr.cols() == 8 && static_cast<int>(tr(0, 4)) == 1 && static_cast<int>(tr(2, 7)) == 2);
+    Eigen::MatrixXf weak = multi;
+    weak(1, 4) = 0.5f;
+    tr = t.update(weak, img);
+    CHECK(tr.rows() == 3);
+    CHECK(tr(1, 5) > 0.6f && tr(1, 5) < 0.66f);  // 0.5 lifted to IoU x 0.65 (the prediction has not moved)
+    CHECK(t.update(empty, img).rows() == 0);
+    t.reset();
+    CHECK(static_cast<int>(t.update(single, img)(0, 4)) == 1);
+    bool threw = false;
+    try { BoostTrackTracker r("osnet.onnx"); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
   }
   {  // an embedding matrix with the wrong number of rows is rejected, alone and inside a StreamBatch
     BotSort t;

@@ -654,3 +654,30 @@ def test_ucmc_distance_and_camera_mapping_by_hand():
     t.update(np.array([[10, 20, 30, 60, 0.9, 0]], np.float32))
     s = t.dump_f64()
     assert s[0, 6] == 5.0 * 20.0 and s[0, 8] == 5.0 * 60.0  # cx = 20, bottom = 60
+
+
+# ---- BoostTrack (src/trackers/boosttrack.cpp), motion only ------------------------------------------------------------------------------
+def test_boosttrack_first_frames_filters_and_the_confidence_boost():
+    """Frame 1: every detection at or above det_thresh starts a track and is reported at once (time_since_update 0 and frame_count <=
+    min_hits, :663-680) with get_state() of the fresh filter — the detection's own box through (cx, cy, h, w / h) and back — except
+    boxes wider than aspect_ratio_thresh x their height, which filter_outputs drops (:434-463) although the track lives on. Frame 2: a
+    detection BELOW det_thresh that overlaps a predicted track is lifted to max_iou x dlo_boost_coef (:393-400) — with identical boxes
+    the IoU with the (stationary) prediction is 1, so 0.5 becomes 0.65 >= 0.6, the detection is kept, matched, and reported with the
+    boosted confidence."""
+    orc = orclib.load()
+    t = orc.tracker(orclib.BOOSTTRACK)
+    d = np.array([[100, 100, 150, 220, 0.9, 2], [600, 100, 900, 200, 0.95, 0], [300, 300, 340, 400, 0.5, 1]], np.float32)
+    out = t.update(d)
+    assert out.shape[0] == 1 and out[0, 4] == 1 and out[0, 7] == 0 and np.allclose(out[0, :4], d[0, :4], atol=1e-4)  # the wide box (id 2) is tracked but not shown
+    assert t.dump_states().shape[0] == 2  # the 0.5 detection started nothing: no track to boost it yet
+    d2 = d.copy()
+    d2[2, :4] = d[0, :4]  # the weak detection now sits on track 1's box; the strong one is gone
+    d2 = d2[1:]
+    out = t.update(d2)
+    ids = sorted(int(r[4]) for r in out)
+    assert ids == [1]
+    r = out[0]
+    assert r[5] == np.float32(1.0) * np.float32(0.65) and int(r[7]) == 1 and int(r[6]) == 1  # boosted confidence, the detection's row and class
+    # initial covariance 10 / 10000 (:51-53), one predict adds the velocity variances and Q (:56-59), the update shrinks it: positive, below 20
+    P = t.dump_states()[0, 9:].reshape(8, 8)
+    assert 0 < P[0, 0] < 20 and P[4, 4] < 10000.0

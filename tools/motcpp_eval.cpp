@@ -1,7 +1,7 @@
 // MOT evaluation driver for the MI355X-backed trackers. Command-line contract (positional arguments, defaults, one
 // <sequence>.txt per sequence in MOT format) follows the reference's tools/motcpp_eval.cpp:19-468; the program itself is
 // organised differently: a tracker table, a frame plan per sequence, then one loop. Trackers built here: sort, ucmc, bytetrack,
-// ocsort, botsort, deepocsort, strongsort. Images are never decoded: trackers get a blank frame of the sequence's size.
+// ocsort, botsort, deepocsort, strongsort, boosttrack (motion only). Images are never decoded: trackers get a blank frame of the sequence's size.
 #include <algorithm>
 #include <filesystem>
 #include <fstream>
@@ -48,6 +48,12 @@ const std::map<std::string, std::function<TrackerPtr(int)>>& tracker_table() {
       {"strongsort",
        [](int) {
          return TrackerPtr(new T::StrongSORT("", false, false, 0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 0.6f, 0.4f, 0.7f, 3, 100, 0.98f, 0.9f));
+       }},
+      // boosttrack.yaml's values (motcpp_eval.cpp:247-278: BoostTrack++ switches use_rich_s / use_sb / use_vt on); no ReID weights: motion only
+      {"boosttrack",
+       [](int) {
+         return TrackerPtr(new T::BoostTrackTracker("", false, false, 0.6f, 60, 50, 3, 0.3f, false, 80, "iou", false, true, 10, 1.6f, "ecc", 0.5f, 0.25f,
+                                                    0.25f, true, true, 0.65f, false, true, true, true, false));
        }},
       // the reference tool's values (motcpp_eval.cpp:112-131): dt from the sequence's frame rate, no camera file (image-space fallback)
       {"ucmc",

@@ -351,6 +351,31 @@ typedef struct mot_boost_task {
 } mot_boost_task;
 int mot_boost_run(mot_ctx* ctx, int op, const mot_boost_task* tasks, int ntasks, int max_n, int max_m);
 
+/* ---- HybridSORT's filter and pairwise costs (src/trackers/hybridsort.cpp) -------------------- */
+/* State [u, v, s, c, r, du, dv, ds, dc] (HybridKalmanFilter :26-88; c = the detection confidence), records of 90 floats (mean[9],
+ * covariance[81]) in `slab`. Detections: SoA planes [6][ldd].
+ *   MOT_HYB_PREDICT n tracks slots[i]: HybridKalmanBoxTracker::predict's guard (ds + s <= 0 -> ds = 0, :257-259), x = F x, P = F P F^T + Q
+ *   MOT_HYB_UPDATE  n tracks slots[i] with measurement convert_bbox_to_z(detection didx[i]) (:181-193), or the ALL-ZERO measurement when
+ *                   didx[i] < 0 (what the reference feeds an unmatched track, :315-320); K = P H^T S^-1 with the partial-pivot LU inverse
+ *                   of the 5 x 5, P = (I - K H) P (:72-88)
+ *   MOT_HYB_INIT    n births slots[i] from detection didx[i]
+ *   MOT_HYB_BOXES   boxes[i*4..] = convert_x_to_bbox of track slots[i] (:195-201)
+ *   MOT_HYB_PAIR    n x m: sim[i*ldc+j] = IoU (:529-556; hmiou != 0: x the height overlap, :558-577) of box a[i] and box b[j] (plain [k][4]
+ *                   arrays) - score_w * |b_score[j] - a_score[i]| (score_w = 0: no score term); cost = (1 - sim) * 1 + add_const */
+enum { MOT_HYB_PREDICT = 0, MOT_HYB_UPDATE = 1, MOT_HYB_INIT = 2, MOT_HYB_BOXES = 3, MOT_HYB_PAIR = 4 };
+typedef struct mot_hyb_task {
+  int32_t n, m, ldd, ldc;
+  float* slab;
+  const int32_t* slots; const int32_t* didx;
+  const float* dets;
+  float* boxes;
+  const float* a; const float* b; const float* a_score; const float* b_score;
+  float* sim; float* cost;
+  int32_t hmiou, scale_first;
+  float score_w, add_const;
+} mot_hyb_task;
+int mot_hyb_run(mot_ctx* ctx, int op, const mot_hyb_task* tasks, int ntasks, int max_n, int max_m);
+
 /* ---- linear assignment ---------------------------------------------------------------- */
 typedef enum mot_lap_mode {
   MOT_LAP_PLAIN = 0,

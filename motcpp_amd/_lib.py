@@ -227,7 +227,7 @@ class Context:
 
 # ---- tracker handles (libmotcpp.so: C++17 host library over the C ABI) ------------------------------------
 SORT, BYTETRACK, OCSORT, BOTSORT = 0, 1, 2, 3
-KIND = {"sort": SORT, "bytetrack": BYTETRACK, "ocsort": OCSORT, "botsort": BOTSORT, "deepocsort": 4, "strongsort": 5, "ucmc": 6, "boosttrack": 7}
+KIND = {"sort": SORT, "bytetrack": BYTETRACK, "ocsort": OCSORT, "botsort": BOTSORT, "deepocsort": 4, "strongsort": 5, "ucmc": 6, "boosttrack": 7, "hybridsort": 8}
 _host = None
 
 

@@ -22,6 +22,7 @@ hipError_t launch_ss_nn(const mot_ss_nn_task*, int, int, int, hipStream_t);
 hipError_t launch_ss_iou(const mot_ss_iou_task*, int, int, int, hipStream_t);
 hipError_t launch_ucmc(int, const mot_ucmc_task*, int, int, int, hipStream_t);
 hipError_t launch_boost(int, const mot_boost_task*, int, int, int, hipStream_t);
+hipError_t launch_hyb(int, const mot_hyb_task*, int, int, int, hipStream_t);
 hipError_t launch_deep(const mot_deep_task*, int, int, int, hipStream_t);
 hipError_t launch_embed(int metric, const mot_cos_task*, int, int, int, hipStream_t);
 hipError_t launch_cosine(const mot_cos_task*, int, int, int, hipStream_t);
@@ -157,6 +158,7 @@ int mot_cosine_cost(mot_ctx* c, const mot_cos_task* t, int nt, int max_n, int ma
 int mot_deepoc_cost(mot_ctx* c, const mot_deep_task* t, int nt, int max_nd, int max_nt) { MOT_HIP(c, mot::launch_deep(t, nt, max_nd, max_nt, c->stream)); return MOT_OK; }
 int mot_ss_nn_cost(mot_ctx* c, const mot_ss_nn_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_ss_nn(t, nt, max_n, max_m, c->stream)); return MOT_OK; }
 int mot_ss_iou_cost(mot_ctx* c, const mot_ss_iou_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_ss_iou(t, nt, max_n, max_m, c->stream)); return MOT_OK; }
+int mot_hyb_run(mot_ctx* c, int op, const mot_hyb_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_hyb(op, t, nt, max_n, max_m, c->stream)); return MOT_OK; }
 int mot_boost_run(mot_ctx* c, int op, const mot_boost_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_boost(op, t, nt, max_n, max_m, c->stream)); return MOT_OK; }
 int mot_ucmc_run(mot_ctx* c, int op, const mot_ucmc_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_ucmc(op, t, nt, max_n, max_m, c->stream)); return MOT_OK; }
 int mot_feat_update(mot_ctx* c, const mot_feat_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_feat(t, nt, max_n, c->stream)); return MOT_OK; }

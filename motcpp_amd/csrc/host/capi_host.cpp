@@ -38,6 +38,15 @@ Staged* make(std::shared_ptr<Device> dev, int kind, const float* p, int np) {
     case 5:  // min_conf, max_cos_dist, max_iou_dist, n_init, nn_budget, mc_lambda, ema_alpha, max_age
       return make_strongsort(dev, P(p, np, 0, 0.1f), P(p, np, 1, 0.2f), P(p, np, 2, 0.7f), (int)P(p, np, 3, 3), (int)P(p, np, 4, 100), P(p, np, 5, 0.98f),
                              P(p, np, 6, 0.9f), (int)P(p, np, 7, 30));
+    case 8: {  // HybridSORT: det_thresh, max_age, min_hits, iou_threshold, asso (0 iou, 1 hmiou), low_thresh, use_byte, track_thresh,
+               // EG_weight_high_score, EG_weight_low_score, TCM_first_step, TCM_byte_step, TCM_byte_step_weight, with_reid (no embeddings)
+      HybridParams q;
+      q.det_thresh = P(p, np, 0, 0.7f); q.max_age = (int)P(p, np, 1, 30); q.min_hits = (int)P(p, np, 2, 3); q.iou_threshold = P(p, np, 3, 0.15f);
+      q.asso = (int)P(p, np, 4, 1.f); q.low_thresh = P(p, np, 5, 0.1f); q.use_byte = P(p, np, 6, 1.f) != 0.f; q.track_thresh = P(p, np, 7, 0.5f);
+      q.eg_high = P(p, np, 8, 4.6f); q.eg_low = P(p, np, 9, 1.3f); q.tcm_first = P(p, np, 10, 1.f) != 0.f; q.tcm_byte = P(p, np, 11, 1.f) != 0.f;
+      q.tcm_byte_weight = P(p, np, 12, 1.0f); q.with_reid = P(p, np, 13, 0.f) != 0.f;
+      return make_hybridsort(dev, q);
+    }
     case 7: {  // BoostTrack, motion only: det_thresh, max_age, min_hits, iou_threshold, min_box_area, aspect_ratio_thresh, lambda_iou, lambda_mhd,
                // lambda_shape, use_dlo_boost, use_duo_boost, dlo_boost_coef, use_sb, use_vt
       BoostParams q;
@@ -204,6 +213,17 @@ int motcpp_tracker_dump_states(motcpp_tracker* t, float* out, int cap_floats, in
         std::memcpy(o + 1 + D, cov.data() + static_cast<size_t>(r) * D * D, sizeof(float) * D * D);
       }
       return rows;
+    }
+    {
+      std::vector<float> own;
+      int w = 0;
+      if (t->impl->f32_states(&own, &w)) {
+        *width = w;
+        const int rows = w > 0 ? static_cast<int>(own.size() / w) : 0;
+        if (own.size() > static_cast<size_t>(cap_floats)) return -rows - 1000000;
+        if (!own.empty()) std::memcpy(out, own.data(), own.size() * sizeof(float));
+        return rows;
+      }
     }
     std::vector<int> ids, slots;
     t->impl->live_tracks(&ids, &slots);

@@ -160,13 +160,14 @@ void Device::begin_frame() {
 bool Device::TaskLists::empty() const {
   for (int k = 0; k < 3; ++k)
     if (!det[k].empty() || !kf_init[k].empty() || !kf_upd[k].empty() || !kf_pred[k].empty() || !kf_box[k].empty() || !kf_warp[k].empty() || !kf_predw[k].empty()) return false;
-  return det[3].empty() && feat_set.empty() && feat_ema.empty() && feat_late.empty() && ss_nn.empty() && gate.empty() && ss_iou.empty() && boost[0].empty() && boost[1].empty() && boost[2].empty() && boost[3].empty() && boost[4].empty() && boost[5].empty() && ucmc[0].empty() && ucmc[1].empty() && ucmc[2].empty() && ucmc[3].empty() && ucmc[4].empty() && cos.empty() && dot.empty() && deep.empty() && iou.empty() && oc.empty() && lap.empty();
+  return det[3].empty() && feat_set.empty() && feat_ema.empty() && feat_late.empty() && ss_nn.empty() && gate.empty() && ss_iou.empty() && hyb[0].empty() && hyb[1].empty() && hyb[2].empty() && hyb[3].empty() && hyb[4].empty() && boost[0].empty() && boost[1].empty() && boost[2].empty() && boost[3].empty() && boost[4].empty() && boost[5].empty() && ucmc[0].empty() && ucmc[1].empty() && ucmc[2].empty() && ucmc[3].empty() && ucmc[4].empty() && cos.empty() && dot.empty() && deep.empty() && iou.empty() && oc.empty() && lap.empty();
 }
 void Device::TaskLists::clear() {
   for (int k = 0; k < 3; ++k) { det[k].clear(); kf_init[k].clear(); kf_upd[k].clear(); kf_pred[k].clear(); kf_box[k].clear(); kf_warp[k].clear(); kf_predw[k].clear(); }
   det[3].clear(); feat_late.clear(); ss_nn.clear(); gate.clear(); ss_iou.clear();
   for (auto& v : ucmc) v.clear();
   for (auto& v : boost) v.clear();
+  for (auto& v : hyb) v.clear();
   feat_set.clear(); feat_ema.clear(); cos.clear(); dot.clear(); deep.clear(); iou.clear(); oc.clear(); lap.clear();
   lap_geom = false;
   lap_assoc = false;
@@ -185,7 +186,7 @@ void Device::TaskLists::append(TaskLists& o) {
     move_back(kf_pred[k], o.kf_pred[k]); move_back(kf_box[k], o.kf_box[k]); move_back(kf_warp[k], o.kf_warp[k]); move_back(kf_predw[k], o.kf_predw[k]);
   }
   move_back(det[3], o.det[3]);
-  move_back(feat_set, o.feat_set); move_back(feat_ema, o.feat_ema); move_back(feat_late, o.feat_late); move_back(ss_nn, o.ss_nn); move_back(gate, o.gate); move_back(ss_iou, o.ss_iou); for (int k = 0; k < 5; ++k) move_back(ucmc[k], o.ucmc[k]); for (int k = 0; k < 6; ++k) move_back(boost[k], o.boost[k]); move_back(cos, o.cos); move_back(dot, o.dot); move_back(deep, o.deep); move_back(iou, o.iou);
+  move_back(feat_set, o.feat_set); move_back(feat_ema, o.feat_ema); move_back(feat_late, o.feat_late); move_back(ss_nn, o.ss_nn); move_back(gate, o.gate); move_back(ss_iou, o.ss_iou); for (int k = 0; k < 5; ++k) move_back(ucmc[k], o.ucmc[k]); for (int k = 0; k < 6; ++k) move_back(boost[k], o.boost[k]); for (int k = 0; k < 5; ++k) move_back(hyb[k], o.hyb[k]); move_back(cos, o.cos); move_back(dot, o.dot); move_back(deep, o.deep); move_back(iou, o.iou);
   move_back(oc, o.oc); move_back(lap, o.lap);
   lap_geom = lap_geom || o.lap_geom;
   o.lap_geom = false;
@@ -270,6 +271,8 @@ void Device::flush() {
   const mot_ss_nn_task* d_ssnn = stage_tasks(*up, L.ss_nn);
   const mot_gate_task* d_gate = stage_tasks(*up, L.gate);
   const mot_ss_iou_task* d_ssiou = stage_tasks(*up, L.ss_iou);
+  const mot_hyb_task* d_hyb[5];
+  for (int k = 0; k < 5; ++k) d_hyb[k] = stage_tasks(*up, L.hyb[k]);
   const mot_boost_task* d_boost[6];
   for (int k = 0; k < 6; ++k) d_boost[k] = stage_tasks(*up, L.boost[k]);
   const mot_ucmc_task* d_ucmc[5];
@@ -324,6 +327,14 @@ void Device::flush() {
       b += (op == MOT_BOOST_COST) ? 4.0 * t.n * (double)t.m + 16.0 * t.n + 48.0 * t.m : (op == MOT_BOOST_DLO ? 24.0 * t.n + 20.0 * t.m : (op == MOT_BOOST_BOXES ? 32.0 * t.n : 592.0 * t.n));
     run(family, v.size(), b, 0, [&] { check(mot_boost_run(ctx, op, d_boost[op], (int)v.size(), maxn(v, [](const mot_boost_task& t) { return t.n; }), maxn(v, [](const mot_boost_task& t) { return t.m; })), "mot_boost_run"); });
   };
+  auto run_hyb = [&](int op, int family) {  // HybridSORT (hybridsort.cpp): 360-byte records
+    auto& v = L.hyb[op];
+    double b = 0;
+    for (const mot_hyb_task& t : v) b += (op == MOT_HYB_PAIR) ? 8.0 * t.n * (double)t.m + 20.0 * (t.n + t.m) : (op == MOT_HYB_BOXES ? 36.0 * t.n : 740.0 * t.n);
+    run(family, v.size(), b, 0, [&] { check(mot_hyb_run(ctx, op, d_hyb[op], (int)v.size(), maxn(v, [](const mot_hyb_task& t) { return t.n; }), maxn(v, [](const mot_hyb_task& t) { return t.m; })), "mot_hyb_run"); });
+  };
+  run_hyb(MOT_HYB_UPDATE, F_KF_UPDATE);
+  run_hyb(MOT_HYB_INIT, F_KF_INIT);
   run_boost(MOT_BOOST_INIT, F_KF_INIT);
   run_boost(MOT_BOOST_UPDATE, F_KF_UPDATE);
   run_ucmc(MOT_UCMC_MAP, F_DET);
@@ -348,6 +359,8 @@ void Device::flush() {
     run(F_KF_PREDICT, kf_pred[k].size(), kf_bytes(kf_pred[k], k, 2.0), 0, [&] { check(mot_kf_predict(ctx, k, d_pred[k], (int)kf_pred[k].size(), maxn(kf_pred[k], [](const mot_kf_task& t) { return t.n; })), "mot_kf_predict"); });
   run_ucmc(MOT_UCMC_PREDICT, F_KF_PREDICT);
   run_boost(MOT_BOOST_PREDICT, F_KF_PREDICT);
+  run_hyb(MOT_HYB_PREDICT, F_KF_PREDICT);
+  run_hyb(MOT_HYB_BOXES, F_KF_BOXES);
   run_boost(MOT_BOOST_DLO, F_IOU);
   run_boost(MOT_BOOST_BOXES, F_KF_BOXES);
   for (int k = 0; k < 3; ++k)  // predict + camera-motion warp in one pass over the states
@@ -410,6 +423,7 @@ void Device::flush() {
   }
   run_ucmc(MOT_UCMC_COST, F_IOU);
   run_boost(MOT_BOOST_COST, F_IOU);
+  run_hyb(MOT_HYB_PAIR, F_IOU);
   {
     double b = 0;
     for (const mot_lap_task& t : lap)

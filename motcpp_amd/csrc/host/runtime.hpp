@@ -116,6 +116,7 @@ class Device {
     std::vector<mot_ss_nn_task> ss_nn;     // StrongSORT: minimum over a track's samples (after the raw inner products, before the gate)
     std::vector<mot_gate_task> gate;       // XYAH motion gate + blend (+ clamp) on a cost matrix
     std::vector<mot_ss_iou_task> ss_iou;   // StrongSORT's IoU cost on tlwh boxes
+    std::vector<mot_hyb_task> hyb[5];      // HybridSORT's nine-state filter and pairwise costs, by op (MOT_HYB_*)
     std::vector<mot_boost_task> boost[6];  // BoostTrack's constant-noise filter and costs, by op (MOT_BOOST_*)
     std::vector<mot_ucmc_task> ucmc[5];    // UCMCTrack's double-precision ground-plane filter, by op (MOT_UCMC_*): map with the detections, births /
                                            // updates with the Kalman updates, predict with the predicts, the cost matrices in front of the assignments

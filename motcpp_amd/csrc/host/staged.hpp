@@ -60,6 +60,8 @@ class Staged {
   virtual const float* feature_slab(int* dim, std::vector<char>* has) const { *dim = 0; (void)has; return nullptr; }
   // parity hook (UCMCTrack): rows of doubles [id, state, death, birth, det_idx, age, x(4), P(16)] in list order; false: not that tracker
   virtual bool f64_states(std::vector<double>* rows) { (void)rows; return false; }
+  // parity hook for trackers whose states are not records of the Core slab (HybridSORT): rows of `width` floats [id, x, P]
+  virtual bool f32_states(std::vector<float>* rows, int* width) { (void)rows; (void)width; return false; }
 
  protected:
   void record(const Core::Lap& l) {
@@ -123,6 +125,20 @@ struct BoostParams {
   bool use_sb = false, use_vt = false;
 };
 Staged* make_boosttrack(std::shared_ptr<Device>, const BoostParams& p);
+// HybridSORT (src/trackers/hybridsort.cpp) as the reference runs it; with_reid: only without embeddings (its all-zero features)
+struct HybridParams {
+  float det_thresh = 0.7f;
+  int max_age = 30, min_hits = 3;
+  float iou_threshold = 0.15f;
+  int asso = 1;  // 0 IoU (also giou / ciou / diou there), 1 hmiou
+  float low_thresh = 0.1f;
+  bool use_byte = true;
+  float track_thresh = 0.5f, eg_high = 4.6f, eg_low = 1.3f;
+  bool tcm_first = true, tcm_byte = true;
+  float tcm_byte_weight = 1.0f;
+  bool with_reid = false;
+};
+Staged* make_hybridsort(std::shared_ptr<Device>, const HybridParams& p);
 Staged* make_botsort(std::shared_ptr<Device>, float track_high, float track_low, float new_track, int track_buffer,
                      float match_thresh, float proximity, float appearance, int frame_rate, bool fuse_first, bool with_reid,
                      int max_age, int max_obs);

@@ -328,6 +328,24 @@ BoostTrackTracker::BoostTrackTracker(const std::string& reid_weights, bool /*use
   q.use_dlo = use_dlo_boost; q.use_duo = use_duo_boost; q.dlo_coef = dlo_boost_coef; q.use_sb = use_sb; q.use_vt = use_vt;
   adopt(rt::make_boosttrack(dev_, q));
 }
+HybridSort::HybridSort(const std::string& reid_weights, bool /*use_half*/, bool /*use_gpu*/, float det_thresh, int max_age, int max_obs, int min_hits,
+                       float iou_threshold, bool per_class, int nr_classes, const std::string& asso_func, bool is_obb, float low_thresh, int /*delta_t*/,
+                       float /*inertia*/, bool use_byte, bool /*use_custom_kf*/, int /*longterm_bank_length*/, float /*alpha*/, bool /*adapfs*/,
+                       float track_thresh, float EG_weight_high_score, float EG_weight_low_score, bool TCM_first_step, bool TCM_byte_step,
+                       float TCM_byte_step_weight, float /*high_score_matching_thresh*/, bool /*with_longterm_reid*/, float /*longterm_reid_weight*/,
+                       bool /*with_longterm_reid_correction*/, float /*longterm_reid_correction_thresh*/, float /*longterm_reid_correction_thresh_low*/,
+                       const std::string& /*cmc_method*/, bool with_reid, int device_index)
+    : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
+  if (!reid_weights.empty()) throw std::invalid_argument("motcpp_amd: ReID model inference is outside the hot path");
+  rt::HybridParams q;
+  q.det_thresh = det_thresh_; q.max_age = max_age_; q.min_hits = min_hits_; q.iou_threshold = iou_threshold_;
+  // with ReID the reference only knows hmiou and IoU (:755-759); without, everything but hmiou and ct_dist is IoU (:645-665)
+  if (asso_func == "ct_dist") throw std::invalid_argument("motcpp_amd: HybridSORT's ct_dist measure is not built");
+  q.asso = (asso_func == "hmiou") ? 1 : 0;
+  q.low_thresh = low_thresh; q.use_byte = use_byte; q.track_thresh = track_thresh; q.eg_high = EG_weight_high_score; q.eg_low = EG_weight_low_score;
+  q.tcm_first = TCM_first_step; q.tcm_byte = TCM_byte_step; q.tcm_byte_weight = TCM_byte_step_weight; q.with_reid = with_reid;
+  adopt(rt::make_hybridsort(dev_, q));
+}
 UCMCTrack::UCMCTrack(float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold, bool per_class, int nr_classes,
                      const std::string& asso_func, bool is_obb, double a1, double a2, double wx, double wy, double vmax, double dt, float high_score,
                      const std::vector<double>& Ki, const std::vector<double>& Ko, int device_index)

@@ -99,6 +99,49 @@ struct PackMeta {
   for (int i = threadIdx.x; i < 2 * c; i += 256) dst[i] = src[i];
 }
 
+// pack_offsets + pack_rows in one launch for a batch of up to a thousand streams (a frame of one camera is a chain of dependent launches:
+// one less is one launch latency less): every workgroup sums the counts in front of its stream itself, workgroup 0 also writes the
+// offsets and the meta words. Same results as the two kernels.
+[[maybe_unused]] static __global__ void __launch_bounds__(256) pack_small(const float* stage, int cap_stage, const int* counts, int S, int* offsets, float* packed,
+                                                                         int packed_cap, PackMeta pm) {
+  __shared__ int part[4];
+  __shared__ int s_base;
+  const int s = blockIdx.x, t = static_cast<int>(threadIdx.x);
+  int a = 0;
+  for (int i = t; i < s; i += 256) { const int c = counts[i]; a += (c > 0) ? c : 0; }
+  for (int d = 32; d > 0; d >>= 1) a += __shfl_down(a, d, 64);
+  if ((t & 63) == 0) part[t >> 6] = a;
+  __syncthreads();
+  if (t == 0) s_base = part[0] + part[1] + part[2] + part[3];
+  __syncthreads();
+  const int o = s_base;
+  const int c = counts[s];
+  if (t == 0) offsets[s] = o;
+  if (s == S - 1 && t == 0) offsets[S] = o + ((c > 0) ? c : 0);
+  if (s == 0 && pm.dev) {  // the meta words (pack_offsets' second half); the total is the last workgroup's to know - summed here once more
+    int tot = 0;
+    for (int i = t; i < S; i += 256) { const int ci = counts[i]; tot += (ci > 0) ? ci : 0; }
+    for (int d = 32; d > 0; d >>= 1) tot += __shfl_down(tot, d, 64);
+    __syncthreads();
+    if ((t & 63) == 0) part[t >> 6] = tot;
+    __syncthreads();
+    if (t == 0) {
+      pm.dev[0] = part[0] + part[1] + part[2] + part[3];
+      pm.dev[1] = *pm.err;
+      if (pm.dec_at >= 0)
+        for (int k = 0; k < 3; ++k) pm.dev[pm.dec_at + k] = pm.dec[k] ? *pm.dec[k] : -1;
+    }
+    for (int i = t; i < pm.n_maxt; i += 256) { pm.dev[pm.maxt_at + i] = pm.maxt[i]; if (pm.maxt_zero) pm.maxt_zero[i] = 0; }
+    for (int i = t; i < S; i += 256) { const int ci = counts[i]; pm.dev[pm.counts_at + i] = ci; if (pm.counts_copy) pm.counts_copy[i] = ci; }
+    if (pm.alive) for (int i = t; i < S; i += 256) pm.dev[pm.alive_at + i] = pm.alive[i];
+  }
+  if (c <= 0) return;
+  if (o + c > packed_cap) return;
+  const float4* src = reinterpret_cast<const float4*>(stage + static_cast<size_t>(s) * cap_stage * 8);
+  float4* dst = reinterpret_cast<float4*>(packed + static_cast<size_t>(o) * 8);
+  for (int i = t; i < 2 * c; i += 256) dst[i] = src[i];
+}
+
 // The frame's meta words, device -> page-locked host. hipMemcpyAsync takes a much slower route for a device-to-host copy above 16 KB
 // (measured: one 16.6 KB copy per frame took SORT from 10.6 M to 6.4 M frames/s and ByteTrack 256 x 128 from 9.1 M to 5.5 M, with the kernels
 // unchanged), so the buffer goes in pieces of at most 16 KB.
@@ -263,8 +306,11 @@ struct Flights {
     Flight& F = fl[slot];
     PackMeta pm = pack_meta(slot, d_err, d_maxt, d_declined, d_declined_b, d_declined_c);
     pm.alive = with_alive ? d_alive : nullptr; pm.alive_at = meta_head() + S;
-    hipLaunchKernelGGL(pack_offsets, dim3(1), dim3(1024), 0, st, d_out_counts, S, F.d_offsets, pm);
-    hipLaunchKernelGGL(pack_rows, dim3(S), dim3(256), 0, st, d_stage, cap_stage, d_out_counts, F.d_offsets, rows_target(slot), rows_cap);
+    if (S <= 1024) hipLaunchKernelGGL(pack_small, dim3(S), dim3(256), 0, st, d_stage, cap_stage, d_out_counts, S, F.d_offsets, rows_target(slot), rows_cap, pm);
+    else {
+      hipLaunchKernelGGL(pack_offsets, dim3(1), dim3(1024), 0, st, d_out_counts, S, F.d_offsets, pm);
+      hipLaunchKernelGGL(pack_rows, dim3(S), dim3(256), 0, st, d_stage, cap_stage, d_out_counts, F.d_offsets, rows_target(slot), rows_cap);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return finish_copies(slot, st, S, rows_cap, bd);

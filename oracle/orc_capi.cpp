@@ -21,6 +21,7 @@ struct Handle {
   std::unique_ptr<StrongSort> strong;
   std::unique_ptr<Ucmc> ucmc;
   std::unique_ptr<BoostTrackOrc> boost;
+  std::unique_ptr<HybridSortOrc> hybrid;
   const std::vector<LapResult>* laps() const {
     switch (kind) {
       case 1: return &byte->laps;
@@ -30,6 +31,7 @@ struct Handle {
       case 5: return &strong->laps;
       case 6: return &ucmc->laps;
       case 7: return &boost->laps;
+      case 8: return &hybrid->laps;
       default: return nullptr;
     }
   }
@@ -98,6 +100,16 @@ void* orc_tracker_create(int kind, const float* p, int np) {
       h->boost = std::make_unique<BoostTrackOrc>(q);
       break;
     }
+    case 8: {  // HybridSORT: det_thresh, max_age, min_hits, iou_threshold, asso (0 iou, 1 hmiou), low_thresh, use_byte, track_thresh,
+               // EG_weight_high_score, EG_weight_low_score, TCM_first_step, TCM_byte_step, TCM_byte_step_weight, with_reid (no embeddings)
+      HybridSortOrc::Params q;
+      q.det_thresh = P(p, np, 0, 0.7f); q.max_age = (int)P(p, np, 1, 30); q.min_hits = (int)P(p, np, 2, 3); q.iou_threshold = P(p, np, 3, 0.15f);
+      q.asso = (int)P(p, np, 4, 1.f); q.low_thresh = P(p, np, 5, 0.1f); q.use_byte = P(p, np, 6, 1.f) != 0.f; q.track_thresh = P(p, np, 7, 0.5f);
+      q.eg_high = P(p, np, 8, 4.6f); q.eg_low = P(p, np, 9, 1.3f); q.tcm_first = P(p, np, 10, 1.f) != 0.f; q.tcm_byte = P(p, np, 11, 1.f) != 0.f;
+      q.tcm_byte_weight = P(p, np, 12, 1.0f); q.with_reid = P(p, np, 13, 0.f) != 0.f;
+      h->hybrid = std::make_unique<HybridSortOrc>(q);
+      break;
+    }
     default:
       delete h;
       return nullptr;
@@ -150,6 +162,7 @@ void orc_tracker_reset(void* hv) {
   if (h->strong) h->strong->reset();
   if (h->ucmc) h->ucmc->reset();
   if (h->boost) h->boost->reset();
+  if (h->hybrid) h->hybrid->reset();
 }
 
 // BoT-SORT only: the 2x3 camera-motion warp of the next update() (returns 0, or -1 for the other trackers)
@@ -179,6 +192,7 @@ int orc_tracker_update(void* hv, const float* dets, int n, const float* embs, in
     case 5: t = h->strong->update(dets, n, embs, d); break;
     case 6: t = h->ucmc->update(dets, n); break;
     case 7: t = h->boost->update(dets, n); break;
+    case 8: t = h->hybrid->update(dets, n); break;
   }
   const int rows = static_cast<int>(t.size());
   if (rows > cap) return -rows;
@@ -214,6 +228,7 @@ int orc_tracker_dump_states(void* hv, float* out, int cap_floats, int* w) {
     case 4: s = h->deep->dump_states(); break;
     case 5: s = h->strong->dump_states(); break;
     case 7: s = h->boost->dump_states(); break;
+    case 8: s = h->hybrid->dump_states(); break;
   }
   *w = s.empty() ? 0 : static_cast<int>(s[0].size());
   size_t need = s.size() * static_cast<size_t>(*w);

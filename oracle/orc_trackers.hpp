@@ -2039,4 +2039,330 @@ class BoostTrackOrc {
   int frame_count_ = 0, next_id_ = 0;
 };
 
+// =======================================================================================
+// HybridSORT — src/trackers/hybridsort.cpp, as written: the association the reference runs is its "simplified" one (the four corner
+// velocities and the k-th previous observations are computed and then ignored, :645-716), so a frame is: score split, predict,
+// 1 - HMIoU assignment against each track's LAST OBSERVED box (get_bbox :364-369; the Kalman box only for a track that has none),
+// BYTE assignment on IoU minus the score difference, a last assignment against the last observed boxes, a Kalman update with an
+// ALL-ZERO measurement for every track still unmatched (:1181-1188 -> :315-320), births, output in reverse track order.
+// Built: with_reid = false, and with_reid = true WITHOUT embeddings (the reference then uses all-zero features, :868-871: every
+// appearance distance is 1, the first association's costs carry + EG_weight_high_score and the BYTE step's + EG_weight_low_score,
+// which puts every BYTE cost above its threshold). Parity unpinned. 9-state filter [u, v, s, c, r, du, dv, ds, dc]: predict has
+// two-term sums; gain / state / covariance updates are k-ordered chains; S^-1 = partial-pivot LU inverse of the 5 x 5.
+// =======================================================================================
+template <int N>
+inline SMat<N, N> inverse_lu(const SMat<N, N>& S) {  // Eigen's dynamic-size inverse() = partialPivLu().inverse(), as inverse_lu4 above
+  SMat<N, N> lu = S;
+  int perm[N];
+  for (int i = 0; i < N; ++i) perm[i] = i;
+  for (int k = 0; k < N; ++k) {
+    int p = k;
+    float best = std::fabs(lu[k][k]);
+    for (int i = k + 1; i < N; ++i) { const float v = std::fabs(lu[i][k]); if (v > best) { best = v; p = i; } }
+    if (p != k) { for (int j = 0; j < N; ++j) std::swap(lu[k][j], lu[p][j]); std::swap(perm[k], perm[p]); }
+    for (int i = k + 1; i < N; ++i) lu[i][k] /= lu[k][k];
+    for (int i = k + 1; i < N; ++i)
+      for (int j = k + 1; j < N; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+  }
+  SMat<N, N> inv;
+  for (int c = 0; c < N; ++c) {
+    float b[N];
+    for (int i = 0; i < N; ++i) b[i] = (perm[i] == c) ? 1.0f : 0.0f;
+    for (int i = 0; i < N; ++i)
+      for (int r = i + 1; r < N; ++r) b[r] -= b[i] * lu[r][i];
+    for (int i = N - 1; i >= 0; --i) {
+      b[i] /= lu[i][i];
+      for (int r = 0; r < i; ++r) b[r] -= b[i] * lu[r][i];
+    }
+    for (int i = 0; i < N; ++i) inv[i][c] = b[i];
+  }
+  return inv;
+}
+
+class HybridSortOrc {
+ public:
+  struct Params {
+    float det_thresh = 0.7f;
+    int max_age = 30, min_hits = 3;
+    float iou_threshold = 0.15f;
+    int asso = 1;  // 0: IoU (also what giou / ciou / diou are here, :579-592), 1: hmiou
+    float low_thresh = 0.1f;
+    bool use_byte = true;
+    float track_thresh = 0.5f, eg_high = 4.6f, eg_low = 1.3f;
+    bool tcm_first = true, tcm_byte = true;
+    float tcm_byte_weight = 1.0f;
+    bool with_reid = false;
+  };
+  explicit HybridSortOrc(const Params& p) : p_(p) {}
+  void reset() { trk_.clear(); frame_count_ = 0; next_id_ = 0; }  // :478-482 (the track list is kept by the reference; see note in update)
+
+  struct Track {
+    int id = 0, age = 0, hits = 0, hit_streak = 0, tsu = 0, cls = 0, det_ind = -1;
+    float conf = 0.f, conf_pre = 0.f;
+    bool has_obs = false;
+    float last[4] = {-1.f, -1.f, -1.f, -1.f};
+    float x[9];
+    SMat<9, 9> P;
+  };
+  static void to_z(const float b[4], float c, float z[5]) {  // convert_bbox_to_z :181-193
+    const float w = b[2] - b[0], h = b[3] - b[1];
+    z[0] = b[0] + w / 2.0f; z[1] = b[1] + h / 2.0f; z[2] = w * h; z[3] = c; z[4] = (h > 1e-6f) ? w / h : 0.0f;
+  }
+  static void x_to_box(const float* x, float b[4]) {  // convert_x_to_bbox :195-201
+    const float u = x[0], v = x[1], s = x[2], r = x[4];
+    const float w = std::sqrt(s * r);
+    const float h = s / w;
+    b[0] = u - w / 2; b[1] = v - h / 2; b[2] = u + w / 2; b[3] = v + h / 2;
+  }
+  static void kf_init(Track& t, const float z[5]) {  // :26-65
+    for (int k = 0; k < 5; ++k) t.x[k] = z[k];
+    for (int k = 5; k < 9; ++k) t.x[k] = 0.0f;
+    t.P = SMat<9, 9>::zero();
+    for (int k = 0; k < 5; ++k) t.P[k][k] = 10.0f;
+    for (int k = 5; k < 9; ++k) t.P[k][k] = 10.0f * 1000.0f;
+  }
+  static void kf_predict(Track& t) {  // :67-70: F = I + 1 at (0,5), (1,6), (2,7), (3,8); Q = diag(0.1 x 5, 0.01 x 4)
+    for (int k = 0; k < 4; ++k) t.x[k] = t.x[k] + t.x[k + 5];
+    SMat<9, 9> FP = t.P;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 9; ++j) FP[i][j] = t.P[i][j] + t.P[i + 5][j];
+    SMat<9, 9> N = FP;
+    for (int i = 0; i < 9; ++i)
+      for (int j = 0; j < 4; ++j) N[i][j] = FP[i][j] + FP[i][j + 5];
+    for (int k = 0; k < 5; ++k) N[k][k] = N[k][k] + 0.1f;
+    for (int k = 5; k < 9; ++k) N[k][k] = N[k][k] + 0.01f;
+    t.P = N;
+  }
+  static void kf_update(Track& t, const float z[5]) {  // :72-88
+    const float Rd[5] = {1.0f, 1.0f, 10.0f, 0.01f, 1.0f};
+    SMat<5, 5> S;
+    for (int i = 0; i < 5; ++i)
+      for (int j = 0; j < 5; ++j) S[i][j] = t.P[i][j] + ((i == j) ? Rd[i] : 0.0f);
+    const SMat<5, 5> Si = inverse_lu<5>(S);
+    SMat<9, 5> PH;
+    for (int i = 0; i < 9; ++i)
+      for (int j = 0; j < 5; ++j) PH[i][j] = t.P[i][j];
+    const SMat<9, 5> K = mul(PH, Si);
+    float inn[5];
+    for (int k = 0; k < 5; ++k) inn[k] = z[k] - t.x[k];
+    for (int i = 0; i < 9; ++i) {
+      float a = K[i][0] * inn[0];
+      for (int k = 1; k < 5; ++k) a += K[i][k] * inn[k];
+      t.x[i] = t.x[i] + a;
+    }
+    SMat<9, 9> A;  // I - K H
+    for (int i = 0; i < 9; ++i)
+      for (int j = 0; j < 9; ++j) A[i][j] = ((i == j) ? 1.0f : 0.0f) - ((j < 5) ? K[i][j] : 0.0f);
+    t.P = mul(A, t.P);
+  }
+  static float iou_manual(const float a[4], const float b[4]) {  // HybridSort::iou_batch :529-556
+    const float xx1 = std::max(a[0], b[0]), yy1 = std::max(a[1], b[1]), xx2 = std::min(a[2], b[2]), yy2 = std::min(a[3], b[3]);
+    const float w = std::max(0.0f, xx2 - xx1), h = std::max(0.0f, yy2 - yy1);
+    const float inter = w * h;
+    const float a1 = (a[2] - a[0]) * (a[3] - a[1]), a2 = (b[2] - b[0]) * (b[3] - b[1]);
+    const float uni = a1 + a2 - inter;
+    return (uni > 1e-6f) ? inter / uni : 0.0f;
+  }
+  static float hmiou(const float a[4], const float b[4]) {  // :558-577
+    float v = iou_manual(a, b);
+    const float yy1 = std::max(a[1], b[1]), yy2 = std::min(a[3], b[3]), yy3 = std::min(a[1], b[1]), yy4 = std::max(a[3], b[3]);
+    const float ho = std::max(0.0f, yy2 - yy1) / (yy4 - yy3 + 1e-6f);
+    v *= ho;
+    return v;
+  }
+  std::vector<LapResult> laps;
+  const std::vector<Track>& tracks() const { return trk_; }
+
+  void predict(Track& t) {  // HybridKalmanBoxTracker::predict :256-270
+    if (t.x[7] + t.x[2] <= 0) t.x[7] = 0.0f;
+    kf_predict(t);
+    ++t.age;
+    if (t.tsu > 0) t.hit_streak = 0;
+    ++t.tsu;
+  }
+  void get_bbox(const Track& t, float b[4]) const {  // :364-369
+    if (((t.last[0] + t.last[1]) + t.last[2]) + t.last[3] < 0) { x_to_box(t.x, b); return; }
+    for (int k = 0; k < 4; ++k) b[k] = t.last[k];
+  }
+  float simple_score(const Track& t) const {  // :376-381
+    auto clampf = [](float v, float lo, float hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); };
+    if (t.conf_pre == 0.0f) return clampf(t.conf, 0.1f, p_.track_thresh);
+    return clampf(t.conf - (t.conf_pre - t.conf), 0.1f, p_.track_thresh);
+  }
+  void matched(Track& t, const Det7& d) {  // HybridKalmanBoxTracker::update with a box :272-313
+    t.last[0] = d.x1; t.last[1] = d.y1; t.last[2] = d.x2; t.last[3] = d.y2;
+    t.has_obs = true;
+    t.tsu = 0; ++t.hits; ++t.hit_streak;
+    float z[5];
+    to_z(t.last, d.conf, z);
+    kf_update(t, z);
+    t.cls = static_cast<int>(d.cls); t.det_ind = d.ind;
+    t.conf_pre = t.conf; t.conf = d.conf;
+  }
+
+  OutTable update(const float* dets, int n) {  // :825-1262
+    laps.clear();
+    ++frame_count_;
+    if (n == 0) {
+      for (Track& t : trk_) predict(t);
+      drop_dead();
+      return {};
+    }
+    const std::vector<Det7> D = wrap_dets(dets, n);
+    std::vector<Det7> keep, second;
+    for (const Det7& d : D) {
+      if (d.conf > p_.low_thresh && d.conf < p_.det_thresh) second.push_back(d);
+      if (d.conf > p_.det_thresh) keep.push_back(d);
+    }
+    const int nt = static_cast<int>(trk_.size());
+    std::vector<std::array<float, 4>> tb(nt);
+    std::vector<float> tscore(nt);
+    for (int j = 0; j < nt; ++j) {
+      predict(trk_[j]);
+      get_bbox(trk_[j], tb[j].data());
+      tscore[j] = simple_score(trk_[j]);
+    }
+    std::vector<std::array<float, 4>> last(nt);
+    for (int j = 0; j < nt; ++j) for (int k = 0; k < 4; ++k) last[j][k] = trk_[j].last[k];
+    std::vector<int> ud, ut;
+    std::vector<std::array<int, 2>> m1;
+    const float thr = p_.iou_threshold;
+    if (p_.tcm_first && !keep.empty() && nt > 0) {  // associate_4_points_with_score(_with_reid) :645-823
+      const int nd = static_cast<int>(keep.size());
+      Mat sim(nd, nt), cost(nd, nt);
+      const bool zero_reid = p_.with_reid && p_.eg_high > 0;
+      for (int i = 0; i < nd; ++i) {
+        const float a[4] = {keep[i].x1, keep[i].y1, keep[i].x2, keep[i].y2};
+        for (int j = 0; j < nt; ++j) {
+          sim(i, j) = (p_.asso == 1) ? hmiou(a, tb[j].data()) : iou_manual(a, tb[j].data());
+          float c = 1.0f - sim(i, j);
+          if (zero_reid) { c = c * 1.0f; c += 1.0f * p_.eg_high; }  // (ones - iou) * weights.first; += emb_cost * weights.second, emb_cost = 1
+          cost(i, j) = c;
+        }
+      }
+      const float max_cost = zero_reid ? (1.0f - thr) * 1.0f + p_.eg_high : 1.0f - thr;
+      const LapResult r = linear_assignment(cost, max_cost);
+      laps.push_back(r);
+      std::vector<char> dm(nd, 0), tm(nt, 0);
+      for (const auto& m : r.matches) {
+        if (sim(m[0], m[1]) >= thr) { m1.push_back(m); dm[m[0]] = 1; tm[m[1]] = 1; }
+        else { ud.push_back(m[0]); ut.push_back(m[1]); }
+      }
+      for (int i = 0; i < nd; ++i) if (!dm[i]) ud.push_back(i);
+      for (int j = 0; j < nt; ++j) if (!tm[j]) ut.push_back(j);
+    } else {
+      for (size_t i = 0; i < keep.size(); ++i) ud.push_back(static_cast<int>(i));
+      for (int j = 0; j < nt; ++j) ut.push_back(j);
+    }
+    for (const auto& m : m1) matched(trk_[m[1]], keep[m[0]]);
+    // BYTE :1052-1128
+    if (p_.use_byte && !second.empty() && !ut.empty()) {
+      const int ns = static_cast<int>(second.size()), nu = static_cast<int>(ut.size());
+      Mat il(ns, nu);
+      float mx = 0.0f;
+      for (int i = 0; i < ns; ++i) {
+        const float a[4] = {second[i].x1, second[i].y1, second[i].x2, second[i].y2};
+        for (int j = 0; j < nu; ++j) {
+          float v = iou_manual(a, tb[ut[j]].data());
+          if (p_.tcm_byte) v -= std::fabs(tscore[ut[j]] - second[i].conf) * p_.tcm_byte_weight;
+          il(i, j) = v;
+          if ((i == 0 && j == 0) || v > mx) mx = v;
+        }
+      }
+      if (mx > thr) {
+        Mat cost(ns, nu);
+        const bool zero_reid = p_.with_reid && p_.eg_low > 0;
+        for (int i = 0; i < ns; ++i)
+          for (int j = 0; j < nu; ++j) {
+            float c = 1.0f - il(i, j);
+            if (zero_reid) c += 1.0f * p_.eg_low;
+            cost(i, j) = c;
+          }
+        const LapResult r = linear_assignment(cost, 1.0f - thr);
+        laps.push_back(r);
+        std::vector<char> gone(nt, 0);
+        for (const auto& m : r.matches)
+          if (il(m[0], m[1]) >= thr) { matched(trk_[ut[m[1]]], second[m[0]]); gone[ut[m[1]]] = 1; }
+        std::vector<int> rest;
+        for (int j : ut) if (!gone[j]) rest.push_back(j);
+        ut.swap(rest);
+      }
+    }
+    // the last chance: unmatched detections against the LAST OBSERVED boxes of the unmatched tracks :1130-1179
+    if (!ud.empty() && !ut.empty()) {
+      const int nd = static_cast<int>(ud.size()), nu = static_cast<int>(ut.size());
+      Mat il(nd, nu);
+      float mx = 0.0f;
+      for (int i = 0; i < nd; ++i) {
+        const float a[4] = {keep[ud[i]].x1, keep[ud[i]].y1, keep[ud[i]].x2, keep[ud[i]].y2};
+        for (int j = 0; j < nu; ++j) {
+          il(i, j) = iou_manual(a, last[ut[j]].data());
+          if ((i == 0 && j == 0) || il(i, j) > mx) mx = il(i, j);
+        }
+      }
+      if (mx > thr) {
+        Mat cost(nd, nu);
+        for (int i = 0; i < nd; ++i)
+          for (int j = 0; j < nu; ++j) cost(i, j) = 1.0f - il(i, j);
+        const LapResult r = linear_assignment(cost, 1.0f - thr);
+        laps.push_back(r);
+        std::vector<char> dgone(keep.size(), 0), tgone(nt, 0);
+        for (const auto& m : r.matches)
+          if (il(m[0], m[1]) >= thr) { matched(trk_[ut[m[1]]], keep[ud[m[0]]]); dgone[ud[m[0]]] = 1; tgone[ut[m[1]]] = 1; }
+        std::vector<int> rd, rt;
+        for (int i : ud) if (!dgone[i]) rd.push_back(i);
+        for (int j : ut) if (!tgone[j]) rt.push_back(j);
+        ud.swap(rd); ut.swap(rt);
+      }
+    }
+    for (int j : ut) {  // update(empty box) :315-320: a Kalman update with an all-zero measurement
+      const float z[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      kf_update(trk_[j], z);
+      trk_[j].conf_pre = 0.0f;
+    }
+    for (int i : ud) {  // :1190-1210
+      Track t;
+      const float b[4] = {keep[i].x1, keep[i].y1, keep[i].x2, keep[i].y2};
+      float z[5];
+      to_z(b, keep[i].conf, z);
+      kf_init(t, z);
+      t.id = ++next_id_;  // next_id() :21-23; the table shows id + 1 (:1225): the first track of a tracker is reported as 2
+      t.conf = keep[i].conf; t.cls = static_cast<int>(keep[i].cls); t.det_ind = keep[i].ind;
+      trk_.push_back(t);
+    }
+    OutTable out;
+    for (auto it = trk_.rbegin(); it != trk_.rend(); ++it) {
+      const Track& t = *it;
+      if (t.tsu < 1 && (t.hit_streak >= p_.min_hits || frame_count_ <= p_.min_hits)) {
+        float b[4];
+        get_bbox(t, b);
+        out.push_back({b[0], b[1], b[2], b[3], static_cast<float>(t.id + 1), t.conf, static_cast<float>(t.cls), static_cast<float>(t.det_ind)});
+      }
+    }
+    drop_dead();
+    return out;
+  }
+  std::vector<std::vector<float>> dump_states() const {  // [id + 1, x(9), P(81)]
+    std::vector<std::vector<float>> rows;
+    for (const Track& t : trk_) {
+      std::vector<float> r;
+      r.push_back(static_cast<float>(t.id + 1));
+      for (int k = 0; k < 9; ++k) r.push_back(t.x[k]);
+      for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) r.push_back(t.P[i][j]);
+      rows.push_back(r);
+    }
+    return rows;
+  }
+
+ private:
+  void drop_dead() {
+    std::vector<Track> keep;
+    for (const Track& t : trk_) if (!(t.tsu > p_.max_age)) keep.push_back(t);
+    trk_.swap(keep);
+  }
+  Params p_;
+  std::vector<Track> trk_;
+  int frame_count_ = 0, next_id_ = 0;
+};
+
 }  // namespace orc

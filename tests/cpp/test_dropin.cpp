@@ -24,6 +24,7 @@ using motcpp::trackers::Sort;
 using motcpp::trackers::StrongSORT;
 using motcpp::trackers::UCMCTrack;
 using motcpp::trackers::BoostTrackTracker;
+using motcpp::trackers::HybridSort;
 
 static Eigen::MatrixXf dets1(float x1, float y1, float x2, float y2, float c, float cls) {
   Eigen::MatrixXf d(1, 6);
@@ -380,6 +381,24 @@ int main() {
     CHECK(static_cast<int>(t.update(single, img)(0, 4)) == 1);
     bool threw = false;
     try { BoostTrackTracker r("osnet.onnx"); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+  }
+  {  // HybridSort (hybridsort.hpp:126-164): ids are reported + 1 and start at 2 (++next_id_, then id + 1: hybridsort.cpp:21-23, :1225), the
+     // table is in reverse track order (:1213); a matched track reports the detection's own box (its last observation, :364-369);
+     // embeddings are refused (the ReID branch is not built)
+    HybridSort t;
+    auto tr = t.update(multi, img);
+    CHECK(tr.rows() == 2 && tr.cols() == 8);  // conf > det_thresh 0.7: the first two detections
+    CHECK(static_cast<int>(tr(0, 4)) == 3 && static_cast<int>(tr(1, 4)) == 2 && static_cast<int>(tr(0, 7)) == 1 && static_cast<int>(tr(1, 7)) == 0);
+    tr = t.update(multi, img);
+    CHECK(tr.rows() == 2 && tr(1, 0) == 100.0f && tr(1, 3) == 200.0f && tr(0, 0) == 300.0f);
+    CHECK(t.update(empty, img).rows() == 0);
+    t.reset();
+    CHECK(static_cast<int>(t.update(single, img)(0, 4)) == 2);
+    bool threw = false;
+    Eigen::MatrixXf e(3, 8);
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 8; ++k) e(i, k) = 1.0f;
+    try { t.update(multi, img, e); } catch (const std::exception&) { threw = true; }
     CHECK(threw);
   }
   {  // an embedding matrix with the wrong number of rows is rejected, alone and inside a StreamBatch

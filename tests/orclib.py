@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORC_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORC_DIR, "build", "liborc.so")
 
-SORT, BYTETRACK, OCSORT, BOTSORT, DEEPOCSORT, STRONGSORT, UCMC, BOOSTTRACK = 0, 1, 2, 3, 4, 5, 6, 7
+SORT, BYTETRACK, OCSORT, BOTSORT, DEEPOCSORT, STRONGSORT, UCMC, BOOSTTRACK, HYBRIDSORT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 KF_XYSR, KF_XYAH, KF_XYWH = 0, 1, 2
 KF_DIM = {0: 7, 1: 8, 2: 8}
 

@@ -108,7 +108,7 @@ def test_cli_usage_and_unknown_method(tmp_path):
     build()
     assert subprocess.run([EVAL], capture_output=True, timeout=60).returncode == 1
     root = make_root(str(tmp_path))
-    out = subprocess.run([EVAL, root, os.path.join(str(tmp_path), "res"), "hybridsort"], capture_output=True, text=True, timeout=60)
+    out = subprocess.run([EVAL, root, os.path.join(str(tmp_path), "res"), "fairmot"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 1 and "unknown tracking method" in out.stderr
     out = subprocess.run([EVAL, os.path.join(str(tmp_path), "nope"), os.path.join(str(tmp_path), "res")], capture_output=True, text=True,
                          timeout=60)
@@ -166,6 +166,27 @@ def test_cli_boosttrack_matches_oracle_on_the_mot17_detections(tmp_path, orc):
     rows = 0
     for seq in mot17.SEQS:
         trk = orc.tracker(orclib.BOOSTTRACK, [0.6, 60, 3, 0.3, 10, 1.6, 0.5, 0.25, 0.25, 1, 1, 0.65, 1, 1])
+        want = []
+        for f, d in enumerate(mot17.load(seq), start=1):
+            if d.shape[0] == 0:
+                continue
+            want += mot_lines(trk.update(d), f)
+        assert open(os.path.join(res, seq + ".txt")).read() == "".join(want), seq
+        rows += len(want)
+    assert rows > 1000
+
+
+@pytest.mark.gpu
+def test_cli_hybridsort_matches_oracle_on_the_mot17_detections(tmp_path, orc):
+    """HybridSORT through the command-line tool with hybridsort.yaml's values (motcpp_eval.cpp:279-316; no ReID weights: with_reid = false) on
+    the real MOT17 detections of the fixture: result files equal to the oracle's tables line for line."""
+    build()
+    root, res = make_root(str(tmp_path)), os.path.join(str(tmp_path), "results")
+    out = subprocess.run([EVAL, root, res, "hybridsort"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = 0
+    for seq in mot17.SEQS:
+        trk = orc.tracker(orclib.HYBRIDSORT, [0.5, 30, 3, 0.3, 1, 0.1, 1, 0.5, 4.6, 1.3, 1, 1, 1.0, 0])
         want = []
         for f, d in enumerate(mot17.load(seq), start=1):
             if d.shape[0] == 0:

@@ -681,3 +681,26 @@ def test_boosttrack_first_frames_filters_and_the_confidence_boost():
     # initial covariance 10 / 10000 (:51-53), one predict adds the velocity variances and Q (:56-59), the update shrinks it: positive, below 20
     P = t.dump_states()[0, 9:].reshape(8, 8)
     assert 0 < P[0, 0] < 20 and P[4, 4] < 10000.0
+
+
+# ---- HybridSORT (src/trackers/hybridsort.cpp), as the reference runs it -------------------------------------------------------------------
+def test_hybridsort_ids_order_and_the_zero_measurement_update():
+    """Hand-derived from the reference's text: ids come from ++next_id_ and are reported + 1 (:21-23, :1225): the first two tracks of a
+    tracker are 2 and 3; the table lists the tracks in REVERSE order (:1213); a new track is reported at once while frame_count <=
+    min_hits, with the box of its fresh filter (the detection's box through (u, v, s, r) and back); a matched track reports its last
+    observation = the detection's own box (:364-369). A track that misses a frame gets a Kalman update with an ALL-ZERO measurement
+    (:1181-1188 -> :315-320): its position is pulled towards the origin by the gain — the reference as written."""
+    orc = orclib.load()
+    t = orc.tracker(orclib.HYBRIDSORT)
+    d = np.array([[100, 100, 150, 220, 0.9, 2], [400, 300, 440, 380, 0.4, 1], [600, 100, 700, 300, 0.95, 0]], np.float32)
+    out = t.update(d)
+    assert [int(r[4]) for r in out] == [3, 2] and [int(r[7]) for r in out] == [2, 0]
+    assert np.allclose(out[0, :4], d[2, :4], atol=1e-3) and np.allclose(out[1, :4], d[0, :4], atol=1e-3)
+    out = t.update(d)
+    assert np.array_equal(out[:, :4], d[[2, 0], :4])  # last observations: the detections themselves
+    s0 = t.dump_states()
+    u_before = s0[0, 1]
+    t.update(d[2:])  # track 2 misses this frame (only the third detection is there)
+    s1 = t.dump_states()
+    # predicted u would be about 125; the zero measurement pulls it towards 0 by the gain P/(P+R) (close to 1 for a young track)
+    assert s1[0, 0] == 2 and abs(s1[0, 1]) < 0.2 * u_before

@@ -1,7 +1,7 @@
 // MOT evaluation driver for the MI355X-backed trackers. Command-line contract (positional arguments, defaults, one
 // <sequence>.txt per sequence in MOT format) follows the reference's tools/motcpp_eval.cpp:19-468; the program itself is
 // organised differently: a tracker table, a frame plan per sequence, then one loop. Trackers built here: sort, ucmc, bytetrack,
-// ocsort, botsort, deepocsort, strongsort, boosttrack (motion only). Images are never decoded: trackers get a blank frame of the sequence's size.
+// ocsort, botsort, deepocsort, strongsort, boosttrack (motion only), hybridsort. Images are never decoded: trackers get a blank frame of the sequence's size.
 #include <algorithm>
 #include <filesystem>
 #include <fstream>
@@ -48,6 +48,12 @@ const std::map<std::string, std::function<TrackerPtr(int)>>& tracker_table() {
       {"strongsort",
        [](int) {
          return TrackerPtr(new T::StrongSORT("", false, false, 0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 0.6f, 0.4f, 0.7f, 3, 100, 0.98f, 0.9f));
+       }},
+      // hybridsort.yaml's values (motcpp_eval.cpp:279-316); no ReID weights: with_reid = false
+      {"hybridsort",
+       [](int) {
+         return TrackerPtr(new T::HybridSort("", false, false, 0.5f, 30, 50, 3, 0.3f, false, 80, "hmiou", false, 0.1f, 3, 0.05f, true, true, 30, 0.9f, false,
+                                             0.5f, 4.6f, 1.3f, true, true, 1.0f, 0.7f, true, 0.0f, true, 0.4f, 0.4f, "ecc", false));
        }},
       // boosttrack.yaml's values (motcpp_eval.cpp:247-278: BoostTrack++ switches use_rich_s / use_sb / use_vt on); no ReID weights: motion only
       {"boosttrack",

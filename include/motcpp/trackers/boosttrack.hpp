@@ -1,8 +1,8 @@
 // motcpp::trackers::BoostTrackTracker — constructor signature and defaults of include/motcpp/trackers/boosttrack.hpp:95-125 (reference).
-// Built: the motion-only tracker (with_reid = false, the default): constant-noise Kalman filter, detection-confidence boost (DLO; soft-BIoU
-// and visual-tracking variants), association on 1 - IoU minus the weighted Mahalanobis similarity, on the GPU (csrc/host/boosttrack.cpp,
-// csrc/boost_kernels.hip). Outside the path, as for the other trackers: ReID inference (reid_weights) and the ECC image registration
-// (use_ecc is accepted and no camera-motion step runs); with_reid = true is refused.
+// Constant-noise Kalman filter, detection-confidence boost (DLO; soft-BIoU and visual-tracking variants), association on 1 - IoU minus the
+// weighted Mahalanobis similarity and — with_reid = true and embeddings passed to update() (N x D, one row per detection) — minus the
+// weighted embedding similarity, on the GPU (csrc/host/boosttrack.cpp, csrc/boost_kernels.hip). Outside the path, as for the other trackers:
+// ReID inference (reid_weights is refused) and the ECC image registration (use_ecc is accepted and no camera-motion step runs).
 #pragma once
 #include "../device_tracker.hpp"
 namespace motcpp::trackers {

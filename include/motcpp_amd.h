@@ -347,7 +347,9 @@ typedef struct mot_boost_task {
   const int32_t* tsu;
   float* max_s; int32_t* vt;
   float* cost;
-  float lambda_mhd, reserved;
+  float lambda_mhd, lambda_emb;
+  const float* emb; int32_t lde, reserved;  /* COST, optional: emb[i * lde + j] = <raw embedding of detection i, stored embedding of track j>;
+                                             cost -= lambda_emb * (emb + 1) / 2 (:613-618) */
 } mot_boost_task;
 int mot_boost_run(mot_ctx* ctx, int op, const mot_boost_task* tasks, int ntasks, int max_n, int max_m);
 

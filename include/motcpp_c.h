@@ -11,8 +11,8 @@
  *  StrongSORT [min_conf, max_cos_dist, max_iou_dist, n_init, nn_budget, mc_lambda, ema_alpha, max_age]
  *  HybridSORT (8) [det_thresh, max_age, min_hits, iou_threshold, asso (0 iou, 1 hmiou), low_thresh, use_byte, track_thresh, EG_weight_high_score,
  *              EG_weight_low_score, TCM_first_step, TCM_byte_step, TCM_byte_step_weight, with_reid (zero-feature behaviour: no embeddings)]
- *  BoostTrack (7, motion only) [det_thresh, max_age, min_hits, iou_threshold, min_box_area, aspect_ratio_thresh, lambda_iou, lambda_mhd,
- *              lambda_shape, use_dlo_boost, use_duo_boost, dlo_boost_coef, use_sb, use_vt]
+ *  BoostTrack (7) [det_thresh, max_age, min_hits, iou_threshold, min_box_area, aspect_ratio_thresh, lambda_iou, lambda_mhd,
+ *              lambda_shape, use_dlo_boost, use_duo_boost, dlo_boost_coef, use_sb, use_vt, with_reid (embeddings with update())]
  *  UCMCTrack (6) [det_thresh, max_age, a1, a2, wx, wy, vmax, fps, high_score] (dt = 1.0 / fps in double precision)
  * Functions return >= 0 on success and a negative value on error (motcpp_last_error() has the message).
  */

@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(kT) boost_cost_kernel(const mot_boost_task* __
   if (mh > limit) mh = limit;
   const float sim = (limit - mh) / limit;
   c = c - T.lambda_mhd * sim;
+  if (T.emb) c = c - T.lambda_emb * ((T.emb[static_cast<size_t>(i) * T.lde + j] + 1.0f) / 2.0f);  // :613-618
   T.cost[static_cast<size_t>(i) * T.ldc + j] = c;
 }
 

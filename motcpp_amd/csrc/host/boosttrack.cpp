@@ -1,5 +1,7 @@
-// BoostTrack on the MI355X hot path: host lifecycle of src/trackers/boosttrack.cpp:465-699 (BoostTrackTracker::update) in its motion-only
-// configuration (with_reid = false — the constructor's default; the ECC camera-motion step needs the image and is outside the path).
+// BoostTrack on the MI355X hot path: host lifecycle of src/trackers/boosttrack.cpp:465-699 (BoostTrackTracker::update); the ECC camera-motion
+// step needs the image and is outside the path. with_reid: the embeddings come with update() (no ReID model here) — raw detection
+// embedding x stored track embedding on the fp32 matrix cores (embed_kernel<dot>), the stored embeddings (normalised, EMA with a per-detection
+// weight) in a feature slab on the device; without embeddings the frame is motion-only, as in the reference (:539-551).
 // The constant-noise Kalman filter, the IoU row maxima of the detection-confidence boost, the association cost (1 - IoU minus the
 // weighted Mahalanobis similarity) and the assignment run on the device (mot_boost_task, csrc/boost_kernels.hip); track states are
 // 72-float records in the tracker's slab (Core) and never leave HBM.
@@ -19,12 +21,19 @@ namespace {
 struct Trk {
   int id = 0, slot = -1, cls = 0, det_ind = -1, tsu = 0, age = 0, hit_streak = 0;
   float conf = 0.f;
+  bool has_emb = false;
 };
 
 class BoostTrackGpu final : public Staged {
  public:
   BoostTrackGpu(std::shared_ptr<Device> dev, const BoostParams& p) : core_(std::move(dev), MOT_KF_XYAH), p_(p) {}
+  ~BoostTrackGpu() override { if (feat_) mot_free(core_.dev().ctx, feat_); }
   Core& core() override { return core_; }
+  const float* feature_slab(int* dim, std::vector<char>* has) const override {
+    *dim = D_;
+    for (const Trk& t : tracks_) has->push_back(t.has_emb ? 1 : 0);
+    return feat_;
+  }
   void reset() override { tracks_.clear(); frame_count_ = 0; next_id_ = 0; core_.clear_slots(); }  // :272-277
   void live_tracks(std::vector<int>* ids, std::vector<int>* slots) const override {
     for (const Trk& t : tracks_) { ids->push_back(t.id); slots->push_back(t.slot); }
@@ -39,6 +48,19 @@ class BoostTrackGpu final : public Staged {
     conf_.resize(n_); cls_.resize(n_);
     raw_ = nullptr;
     core_.reserve(n_ + 8, 8);
+    // embeddings of this frame (:539-551): used when with_reid and the caller passed them
+    use_emb_ = p_.with_reid && in.embs != nullptr && in.emb_dim > 0 && n_ > 0;
+    emb_raw_ = nullptr;
+    if (use_emb_) {
+      if (D_ == 0) D_ = in.emb_dim;
+      if (D_ != in.emb_dim) throw Error("BoostTrack: embedding dimension changed between frames");
+      ensure_feat();
+      Span<float> e = dv.up->alloc<float>(static_cast<size_t>(n_) * D_);
+      for (int i = 0; i < n_; ++i)
+        for (int k = 0; k < D_; ++k)
+          e.h[static_cast<size_t>(i) * D_ + k] = in.embs_rowmajor ? in.embs[static_cast<size_t>(i) * in.emb_ld + k] : in.embs[static_cast<size_t>(k) * in.emb_ld + i];
+      emb_raw_ = e.d;
+    }
     if (n_ > 0) {
       Span<float> raw = dv.up->alloc<float>(static_cast<size_t>(6) * n_);
       for (int k = 0; k < 6; ++k)
@@ -110,6 +132,15 @@ class BoostTrackGpu final : public Staged {
       mot_boost_task t{};
       t.n = nd; t.m = nt; t.slab = core_.d_mean(); t.slots = slots_d_; t.didx = core_.ints(keep_).d; t.dets = raw_; t.ldd = n_;
       t.cost = cost; t.ldc = ld; t.lambda_mhd = p_.lambda_mhd;
+      if (use_emb_) {  // :581-594: raw detection embeddings x the tracks' stored ones (a track without one: the slab's all-zero row)
+        std::vector<int> frows(nt);
+        for (int j = 0; j < nt; ++j) frows[j] = tracks_[j].has_emb ? tracks_[j].slot : zero_row();
+        float* emb = dv.tmp->alloc<float>(static_cast<size_t>(nd) * ld).d;
+        mot_cos_task c{};
+        c.n = nd; c.m = nt; c.d = D_; c.a = emb_raw_; c.lda = D_; c.aidx = t.didx; c.b = feat_; c.ldb = D_; c.bidx = core_.ints(frows).d; c.out = emb; c.ldo = ld;
+        dv.q().dot.push_back(c);
+        t.emb = emb; t.lde = ld; t.lambda_emb = (1.0f + p_.lambda_iou + p_.lambda_shape + p_.lambda_mhd) * 1.5f;
+      }
       dv.q().boost[MOT_BOOST_COST].push_back(t);
       lap_ = core_.lap(cost, ld, nd, nt, p_.iou_threshold);  // rows = detections, columns = tracks (:618-623)
     }
@@ -119,6 +150,8 @@ class BoostTrackGpu final : public Staged {
     Device& dv = core_.dev();
     const int nd = static_cast<int>(keep_.size());
     std::vector<int> us, ud, births;
+    std::vector<int> ema_slots, ema_dets, set_slots, set_dets;
+    std::vector<float> ema_alpha;
     if (lap_.queued) {
       record(lap_);
       for (int i = 0; i < nd; ++i) {
@@ -128,6 +161,12 @@ class BoostTrackGpu final : public Staged {
         t.tsu = 0; ++t.hit_streak;
         t.conf = conf_[keep_[i]]; t.cls = cls_[keep_[i]]; t.det_ind = keep_[i];
         us.push_back(t.slot); ud.push_back(keep_[i]);
+        if (use_emb_) {  // update_emb :183-199 with dets_alpha (:637-650)
+          const float trust = (conf_[keep_[i]] - p_.det_thresh) / (1.0f - p_.det_thresh);
+          const float af = 0.95f;
+          if (t.has_emb) { ema_slots.push_back(t.slot); ema_dets.push_back(keep_[i]); ema_alpha.push_back(af + (1.0f - af) * (1.0f - trust)); }
+          else { set_slots.push_back(t.slot); set_dets.push_back(keep_[i]); t.has_emb = true; }
+        }
       }
     } else births = keep_;
     if (!us.empty()) {
@@ -140,12 +179,30 @@ class BoostTrackGpu final : public Staged {
       for (size_t k = 0; k < births.size(); ++k) {
         Trk t;
         t.id = ++next_id_; t.slot = core_.new_slot(); t.conf = conf_[births[k]]; t.cls = cls_[births[k]]; t.det_ind = births[k];
+        if (use_emb_) { set_slots.push_back(t.slot); set_dets.push_back(births[k]); t.has_emb = true; }
         slots[k] = t.slot;
         tracks_.push_back(t);
       }
       mot_boost_task t{};
       t.n = static_cast<int>(births.size()); t.slab = core_.d_mean(); t.slots = core_.ints(slots).d; t.didx = core_.ints(births).d; t.dets = raw_; t.ldd = n_;
       dv.q().boost[MOT_BOOST_INIT].push_back(t);
+    }
+    if (!set_slots.empty()) {  // BoostTrack ctor :147-153 / update_emb's first embedding: emb / |emb| when the norm is positive
+      mot_feat_task f{};
+      f.n = static_cast<int>(set_slots.size()); f.d = D_; f.feat = feat_; f.ldf = D_; f.slot = core_.ints(set_slots).d;
+      f.src = emb_raw_; f.lds = D_; f.sidx = core_.ints(set_dets).d; f.mode = 0; f.alpha = 0.f;
+      dv.q().feat_set.push_back(f);
+    }
+    if (!ema_slots.empty()) {  // update_emb :183-199: normalise the detection's embedding (scratch rows), blend, renormalise
+      const int ne = static_cast<int>(ema_slots.size());
+      float* tmp = dv.tmp->alloc<float>(static_cast<size_t>(ne) * D_).d;
+      mot_feat_task f{};
+      f.n = ne; f.d = D_; f.feat = tmp; f.ldf = D_; f.slot = nullptr; f.src = emb_raw_; f.lds = D_; f.sidx = core_.ints(ema_dets).d; f.mode = 0; f.alpha = 0.f;
+      dv.q().feat_set.push_back(f);
+      mot_feat_task e{};
+      e.n = ne; e.d = D_; e.feat = feat_; e.ldf = D_; e.slot = core_.ints(ema_slots).d; e.src = tmp; e.lds = D_; e.sidx = nullptr; e.mode = 1;
+      e.alpha = 0.f; e.alpha_i = core_.floats(ema_alpha).d;
+      dv.q().feat_ema.push_back(e);
     }
     // the tracks to report (:663-680) need their boxes after the update
     out_.clear();
@@ -186,10 +243,32 @@ class BoostTrackGpu final : public Staged {
     tracks_.resize(w);
   }
 
+  // feature slab: one row per Kalman slot, and one all-zero row behind them for tracks that have no embedding yet
+  int zero_row() const { return feat_cap_; }
+  void ensure_feat() {
+    const int need = core_.cap();
+    if (feat_cap_ >= need && feat_) return;
+    Device& dv = core_.dev();
+    void* nf = nullptr;
+    dv.check(mot_malloc(dv.ctx, sizeof(float) * static_cast<size_t>(need + 1) * D_, &nf), "feature slab alloc");
+    dv.check(mot_memset(dv.ctx, nf, 0, sizeof(float) * static_cast<size_t>(need + 1) * D_), "feature slab clear");
+    if (feat_) {
+      dv.check(mot_memcpy_d2d(dv.ctx, nf, feat_, sizeof(float) * static_cast<size_t>(feat_cap_) * D_), "feature slab copy");
+      dv.check(mot_ctx_sync(dv.ctx), "slab sync");
+      mot_free(dv.ctx, feat_);
+    }
+    feat_ = static_cast<float*>(nf);
+    feat_cap_ = need;
+  }
+
   Core core_;
   BoostParams p_;
   std::vector<Trk> tracks_;
   int frame_count_ = 0, next_id_ = 0;
+  float* feat_ = nullptr;
+  int feat_cap_ = 0, D_ = 0;
+  bool use_emb_ = false;
+  const float* emb_raw_ = nullptr;
   // per frame
   int stage_ = 0, n_ = 0;
   const float* raw_ = nullptr;

@@ -53,7 +53,7 @@ Staged* make(std::shared_ptr<Device> dev, int kind, const float* p, int np) {
       q.det_thresh = P(p, np, 0, 0.6f); q.max_age = (int)P(p, np, 1, 60); q.min_hits = (int)P(p, np, 2, 3); q.iou_threshold = P(p, np, 3, 0.3f);
       q.min_box_area = (int)P(p, np, 4, 10); q.aspect_ratio_thresh = P(p, np, 5, 1.6f); q.lambda_iou = P(p, np, 6, 0.5f); q.lambda_mhd = P(p, np, 7, 0.25f);
       q.lambda_shape = P(p, np, 8, 0.25f); q.use_dlo = P(p, np, 9, 1.f) != 0.f; q.use_duo = P(p, np, 10, 1.f) != 0.f; q.dlo_coef = P(p, np, 11, 0.65f);
-      q.use_sb = P(p, np, 12, 0.f) != 0.f; q.use_vt = P(p, np, 13, 0.f) != 0.f;
+      q.use_sb = P(p, np, 12, 0.f) != 0.f; q.use_vt = P(p, np, 13, 0.f) != 0.f; q.with_reid = P(p, np, 14, 0.f) != 0.f;
       return make_boosttrack(dev, q);
     }
     case 6: {  // det_thresh, max_age, a1, a2, wx, wy, vmax, fps (dt = 1.0 / fps in double precision, as the evaluation tool forms it), high_score

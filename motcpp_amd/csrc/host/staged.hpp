@@ -123,6 +123,7 @@ struct BoostParams {
   bool use_dlo = true, use_duo = true;
   float dlo_coef = 0.65f;
   bool use_sb = false, use_vt = false;
+  bool with_reid = false;  // embeddings come with update(); without them the tracker runs motion-only (as the reference does, :539-551)
 };
 Staged* make_boosttrack(std::shared_ptr<Device>, const BoostParams& p);
 // HybridSORT (src/trackers/hybridsort.cpp) as the reference runs it; with_reid: only without embeddings (its all-zero features)

@@ -320,12 +320,12 @@ BoostTrackTracker::BoostTrackTracker(const std::string& reid_weights, bool /*use
                                      float lambda_mhd, float lambda_shape, bool use_dlo_boost, bool use_duo_boost, float dlo_boost_coef,
                                      bool /*s_sim_corr*/, bool /*use_rich_s*/, bool use_sb, bool use_vt, bool with_reid, int device_index)
     : DeviceTracker(det_thresh, max_age, max_obs, min_hits, iou_threshold, per_class, nr_classes, asso_func, is_obb, device_index) {
-  if (!reid_weights.empty() || with_reid)
-    throw std::invalid_argument("motcpp_amd: BoostTrack is built in its motion-only configuration (with_reid = false, no ReID weights)");
+  if (!reid_weights.empty())
+    throw std::invalid_argument("motcpp_amd: ReID model inference is outside the hot path; pass embeddings to update() (with_reid = true)");
   rt::BoostParams q;
   q.det_thresh = det_thresh_; q.max_age = max_age_; q.min_hits = min_hits_; q.iou_threshold = iou_threshold_; q.min_box_area = min_box_area;
   q.aspect_ratio_thresh = aspect_ratio_thresh; q.lambda_iou = lambda_iou; q.lambda_mhd = lambda_mhd; q.lambda_shape = lambda_shape;
-  q.use_dlo = use_dlo_boost; q.use_duo = use_duo_boost; q.dlo_coef = dlo_boost_coef; q.use_sb = use_sb; q.use_vt = use_vt;
+  q.use_dlo = use_dlo_boost; q.use_duo = use_duo_boost; q.dlo_coef = dlo_boost_coef; q.use_sb = use_sb; q.use_vt = use_vt; q.with_reid = with_reid;
   adopt(rt::make_boosttrack(dev_, q));
 }
 HybridSort::HybridSort(const std::string& reid_weights, bool /*use_half*/, bool /*use_gpu*/, float det_thresh, int max_age, int max_obs, int min_hits,

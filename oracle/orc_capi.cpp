@@ -96,7 +96,7 @@ void* orc_tracker_create(int kind, const float* p, int np) {
       q.det_thresh = P(p, np, 0, 0.6f); q.max_age = (int)P(p, np, 1, 60); q.min_hits = (int)P(p, np, 2, 3); q.iou_threshold = P(p, np, 3, 0.3f);
       q.min_box_area = (int)P(p, np, 4, 10); q.aspect_ratio_thresh = P(p, np, 5, 1.6f); q.lambda_iou = P(p, np, 6, 0.5f); q.lambda_mhd = P(p, np, 7, 0.25f);
       q.lambda_shape = P(p, np, 8, 0.25f); q.use_dlo = P(p, np, 9, 1.f) != 0.f; q.use_duo = P(p, np, 10, 1.f) != 0.f; q.dlo_coef = P(p, np, 11, 0.65f);
-      q.use_sb = P(p, np, 12, 0.f) != 0.f; q.use_vt = P(p, np, 13, 0.f) != 0.f;
+      q.use_sb = P(p, np, 12, 0.f) != 0.f; q.use_vt = P(p, np, 13, 0.f) != 0.f; q.with_reid = P(p, np, 14, 0.f) != 0.f;
       h->boost = std::make_unique<BoostTrackOrc>(q);
       break;
     }
@@ -191,7 +191,7 @@ int orc_tracker_update(void* hv, const float* dets, int n, const float* embs, in
     case 4: t = h->deep->update(dets, n, embs, d); break;
     case 5: t = h->strong->update(dets, n, embs, d); break;
     case 6: t = h->ucmc->update(dets, n); break;
-    case 7: t = h->boost->update(dets, n); break;
+    case 7: t = h->boost->update(dets, n, embs, d); break;
     case 8: t = h->hybrid->update(dets, n); break;
   }
   const int rows = static_cast<int>(t.size());
@@ -341,8 +341,8 @@ void orc_feat_update(int mode, float alpha, int n, int d, float* feat, const flo
 int orc_tracker_dump_features(void* hv, float* out, int cap_floats, int* d) {
   auto* h = static_cast<Handle*>(hv);
   *d = 0;
-  if (h->kind != 3 && h->kind != 4 && h->kind != 5) return 0;
-  const std::vector<std::vector<float>> f = (h->kind == 3) ? h->bot->dump_features() : ((h->kind == 4) ? h->deep->dump_features() : h->strong->dump_features());
+  if (h->kind != 3 && h->kind != 4 && h->kind != 5 && h->kind != 7) return 0;
+  const std::vector<std::vector<float>> f = (h->kind == 3) ? h->bot->dump_features() : ((h->kind == 4) ? h->deep->dump_features() : ((h->kind == 5) ? h->strong->dump_features() : h->boost->dump_features()));
   for (const auto& r : f) if (!r.empty()) *d = static_cast<int>(r.size());
   if (*d == 0) return static_cast<int>(f.size());
   if (f.size() * static_cast<size_t>(*d) > static_cast<size_t>(cap_floats)) return -static_cast<int>(f.size());

@@ -1848,6 +1848,7 @@ class BoostTrackOrc {
     bool use_dlo = true, use_duo = true;
     float dlo_coef = 0.65f;
     bool use_sb = false, use_vt = false;
+    bool with_reid = false;  // embeddings come with update() (no ReID model here); without them the tracker is motion-only, as in the reference (:539-551)
   };
   explicit BoostTrackOrc(const Params& p) : p_(p) {}
   void reset() { trk_.clear(); frame_count_ = 0; next_id_ = 0; }  // :272-277
@@ -1857,6 +1858,7 @@ class BoostTrackOrc {
     float conf = 0.f;
     float x[8];
     SMat<8, 8> P;
+    std::vector<float> emb;  // BoostTrack::emb_ (normalised when its norm is positive, :148-153)
     Box state() const {  // get_state :107-115
       const float cx = x[0], cy = x[1], h = x[2], r = x[3];
       const float w = r * h;
@@ -1911,10 +1913,27 @@ class BoostTrackOrc {
   std::vector<LapResult> laps;
   const std::vector<Track>& tracks() const { return trk_; }
 
-  OutTable update(const float* dets, int n) {  // :465-699
+  static float norm_of(const std::vector<float>& v) { return std::sqrt(dot_chain(v.data(), v.data(), static_cast<int>(v.size()))); }  // (norm(): dot_chain's order, as elsewhere)
+  static void set_emb(Track& t, const float* e, int d) {  // BoostTrack ctor :147-153
+    t.emb.assign(e, e + d);
+    const float nn = norm_of(t.emb);
+    if (nn > 0) for (float& v : t.emb) v /= nn;
+  }
+  static void update_emb(Track& t, const float* e, int d, float alpha) {  // :183-199
+    if (d == 0) return;
+    std::vector<float> nrm(e, e + d);
+    const float n0 = norm_of(nrm);
+    if (n0 > 0) for (float& v : nrm) v /= n0;
+    if (t.emb.empty()) { t.emb = nrm; return; }
+    for (int k = 0; k < d; ++k) t.emb[k] = alpha * t.emb[k] + (1.0f - alpha) * nrm[k];
+    const float n1 = norm_of(t.emb);
+    if (n1 > 0) for (float& v : t.emb) v /= n1;
+  }
+  OutTable update(const float* dets, int n, const float* embs = nullptr, int emb_dim = 0) {  // :465-699
     laps.clear();
     ++frame_count_;
     std::vector<Det7> D = wrap_dets(dets, n);
+    const bool use_emb = p_.with_reid && embs != nullptr && emb_dim > 0 && n > 0;
     for (Track& t : trk_) {  // BoostTrack::predict :156-163
       kf_predict(t);
       ++t.age;
@@ -1976,6 +1995,12 @@ class BoostTrackOrc {
           if (mh > limit) mh = limit;
           const float sim = (limit - mh) / limit;
           c = c - p_.lambda_mhd * sim;
+          if (use_emb) {  // :581-594, :613-618: raw detection embedding x the track's stored one (a zero row when it has none of that width)
+            const float* de = embs + static_cast<size_t>(F[i].ind) * emb_dim;
+            const float dp = (static_cast<int>(trk_[j].emb.size()) == emb_dim) ? dot_chain(de, trk_[j].emb.data(), emb_dim) : 0.0f;
+            const float lambda_emb = (1.0f + p_.lambda_iou + p_.lambda_shape + p_.lambda_mhd) * 1.5f;
+            c = c - lambda_emb * ((dp + 1.0f) / 2.0f);
+          }
           cost(i, j) = c;
         }
       }
@@ -1994,6 +2019,11 @@ class BoostTrackOrc {
       to_z(b, z);
       kf_update(t, z);
       t.conf = d.conf; t.cls = static_cast<int>(d.cls); t.det_ind = d.ind;
+      if (use_emb) {  // :637-650: dets_alpha = af + (1 - af) * (1 - trust), trust = (score - det_thresh) / (1 - det_thresh)
+        const float trust = (d.conf - p_.det_thresh) / (1.0f - p_.det_thresh);
+        const float af = 0.95f;
+        update_emb(t, embs + static_cast<size_t>(d.ind) * emb_dim, emb_dim, af + (1.0f - af) * (1.0f - trust));
+      }
     }
     for (int i : ud) {  // :652-661
       const Det7& d = F[i];
@@ -2003,6 +2033,7 @@ class BoostTrackOrc {
       to_z(b, z);
       kf_init(t, z);
       t.id = ++next_id_; t.conf = d.conf; t.cls = static_cast<int>(d.cls); t.det_ind = d.ind;
+      if (use_emb) set_emb(t, embs + static_cast<size_t>(d.ind) * emb_dim, emb_dim);
       trk_.push_back(t);
     }
     OutTable out;
@@ -2020,6 +2051,13 @@ class BoostTrackOrc {
     for (const Track& t : trk_) if (!(t.tsu > p_.max_age)) keep.push_back(t);
     trk_.swap(keep);
     return out;
+  }
+  std::vector<std::vector<float>> dump_features() const {  // the stored embeddings, list order (a track without one: zeros of the widest row)
+    size_t d = 0;
+    for (const Track& t : trk_) d = std::max(d, t.emb.size());
+    std::vector<std::vector<float>> rows;
+    for (const Track& t : trk_) { std::vector<float> r(d, 0.0f); std::copy(t.emb.begin(), t.emb.end(), r.begin()); rows.push_back(r); }
+    return rows;
   }
   std::vector<std::vector<float>> dump_states() const {  // [id, x(8), P(64)]
     std::vector<std::vector<float>> rows;

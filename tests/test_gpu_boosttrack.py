@@ -74,3 +74,46 @@ def test_reset_restarts_ids():
         trk.reset()
         ref.reset()
     trk.close()
+
+
+def run_reid(P, M, frames, D, params, seed, empty_every=9, skip_embs_every=0):
+    """with_reid = true: embeddings with update(); tables, assignments, Kalman states and the stored embeddings against the oracle"""
+    orc = orclib.load()
+    trk = L.Tracker("boosttrack", params)
+    ref = orc.tracker(orclib.BOOSTTRACK, params)
+    st = SynthStream(P, M, seed, D)
+    rows = 0
+    for f in range(frames):
+        d, e = st.next_frame()
+        if empty_every and f % empty_every == empty_every - 2:
+            d, e = d[:0], e[:0]
+        if f % 3 == 1:
+            d = d.copy()
+            d[::2, 4] *= 0.6
+        if f % 5 == 2 and len(e):
+            e = e.copy()
+            e[0] = 0.0  # a zero embedding: stays as it is (its norm is not positive, boosttrack.cpp:150-152, :187-189)
+        ee = None if (skip_embs_every and f % skip_embs_every == skip_embs_every - 1) else e
+        want = ref.update(d, ee)
+        got = trk.update(d, ee)
+        assert got.shape == want.shape and np.array_equal(got, want), f
+        for (xg, yg), (xo, yo) in zip(trk.laps(), ref.laps()):
+            assert np.array_equal(xg, xo) and np.array_equal(yg, yo), f
+        if f % 3 == 2:
+            sg, so = trk.dump_states(), ref.dump_states()
+            assert sg.shape == so.shape and np.array_equal(sg, so), f
+            fg, fo = trk.dump_features(), ref.dump_features()
+            if fo.shape[1]:
+                assert fg.shape == fo.shape and np.array_equal(fg, fo), (f, np.abs(fg - fo).max() if fg.shape == fo.shape else (fg.shape, fo.shape))
+        rows += want.shape[0]
+    trk.close()
+    return rows
+
+
+def test_with_reid_embeddings():
+    assert run_reid(30, 20, 50, 16, [0.6, 60, 3, 0.3, 10, 1.6, 0.5, 0.25, 0.25, 1, 1, 0.65, 0, 0, 1], 51) > 150
+    run_reid(40, 30, 40, 128, [0.5, 10, 2, 0.3, 10, 1.6, 0.5, 0.25, 0.25, 1, 1, 0.65, 1, 1, 1], 52)
+
+
+def test_with_reid_frames_without_embeddings_are_motion_only():
+    run_reid(25, 20, 40, 8, [0.6, 60, 3, 0.3, 10, 1.6, 0.5, 0.25, 0.25, 1, 1, 0.65, 0, 0, 1], 53, skip_embs_every=4)

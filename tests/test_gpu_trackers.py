@@ -252,3 +252,32 @@ def test_deepocsort_camera_motion():
         assert fg.shape == fo.shape and np.allclose(fg, fo, rtol=1e-5, atol=1e-6), f
         n_out += len(oo)
     assert n_out > 500
+
+
+# ---- the trackers of round 4 in a StreamBatch: one launch per kernel family and stage however many streams ---------------------------------
+@pytest.mark.parametrize("kind,max_flushes", [("strongsort", 3), ("ucmc", 3), ("boosttrack", 3), ("hybridsort", 5)])
+def test_round4_trackers_batch_matches_single_streams(kind, max_flushes):
+    S, P, M = 6, 60, 40
+    b = L.Batch(kind, S)
+    singles = [L.Tracker(kind) for _ in range(S)]
+    streams = [SynthStream(P, M, 300 + s) for s in range(S)]
+    flushes = rows = 0
+    for f in range(20):
+        frames = [st.next_frame()[0] for st in streams]
+        if f == 7:
+            frames[2] = frames[2][:0]  # one stream has an empty frame
+        n = max(len(x) for x in frames)
+        dets = np.zeros((S, max(n, 1), 6), np.float32)
+        cnt = np.zeros(S, np.int32)
+        for s in range(S):
+            dets[s, :len(frames[s])] = frames[s]
+            cnt[s] = len(frames[s])
+        before = b.counters()["flushes"]
+        out, oc = b.step(dets, cnt)
+        flushes += b.counters()["flushes"] - before
+        for s in range(S):
+            ref = singles[s].update(frames[s])
+            assert oc[s] == ref.shape[0] and np.array_equal(out[s, :oc[s]], ref), (f, s)
+            rows += ref.shape[0]
+    assert rows > 100
+    assert flushes <= 20 * max_flushes  # lockstep: the streams' stages share their launches

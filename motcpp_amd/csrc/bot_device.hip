@@ -652,6 +652,8 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
   b->flights.maxt_clean = false;
   int bd = 1;
   for (int s = 0; s < S; ++s) bd = (h_counts[s] > bd) ? h_counts[s] : bd;
+  int active = 0;  // streams with a frame: a launch with a handful of problems is tuned for latency (mot::launch_lap)
+  for (int s = 0; s < S; ++s) active += (h_counts[s] >= 0) ? 1 : 0;
   if (bd > D) bd = D;
   const int bn = (bound_n < 1) ? 1 : (bound_n > CAP ? CAP : bound_n);
   const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;
@@ -673,13 +675,13 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
   if (emb) MOT_LC_HIP(b, mot::launch_embed(MOT_EMB_COSINE, K.cos1, S, bn, bd, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
-  MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bn, bd, true, false, false, st, b->hint1_n, 0));
+  MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bn, bd, true, false, false, st, b->hint1_n, 0, true, nullptr, nullptr, nullptr, active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
   hipLaunchKernelGGL(bot_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K, prof ? b->d_stats : nullptr, b->d_maxt);
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYWH, K.ubox, S, bn, st));
   if (emb) MOT_LC_HIP(b, mot::launch_embed(MOT_EMB_COSINE, K.cos3, S, bn, bd, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[5], st));
-  MOT_LC_HIP(b, mot::launch_lap(K.lap23, 2 * S, bn, bd, true, false, false, st, b->hint23_n, b->hint23_m));
+  MOT_LC_HIP(b, mot::launch_lap(K.lap23, 2 * S, bn, bd, true, false, false, st, b->hint23_n, b->hint23_m, true, nullptr, nullptr, nullptr, 2 * active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[6], st));
   hipLaunchKernelGGL(bot_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K);
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYWH, K.init, S, bd, st));

@@ -763,17 +763,19 @@ static int oc_enqueue_frame(mot_oc_batch* b, const float* d_dets, const int* cou
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
   // an association whose problems the sparse solver declined (nine in ten) goes straight to the exact solver, with a retry every eighth frame:
   // with quirk Q4's duplicate tracks no optimum is unique, and a declined attempt costs as much as a successful one
+  int active = 0;  // streams with a frame: a launch with a handful of problems is tuned for latency (mot::launch_lap)
+  for (int s = 0; s < S; ++s) active += (counts[s] >= 0) ? 1 : 0;
   const bool retry = (b->lap1_age++ % 8) == 0;  // (advanced here, not at collect: two frames queued back to back do not both retry)
   const bool lap1_fast = !b->skip_fast[0] || retry, lapb_fast = !b->skip_fast[1] || retry, lapr_fast = !b->skip_fast[2] || retry;
   int* lap1_declined = nullptr; int* lapb_declined = nullptr; int* lapr_declined = nullptr;
-  MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bd, bn, false, false, true, st, 0, 0, lap1_fast, &lap1_declined));
+  MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bd, bn, false, false, true, st, 0, 0, lap1_fast, &lap1_declined, nullptr, nullptr, active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
   hipLaunchKernelGGL(oc_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, K);
   if (b->prm.use_byte) {
-    MOT_LC_HIP(b, mot::launch_lap(K.lapb, S, bd, (bn + bd > CAP + D) ? CAP + D : bn + bd, true, general, true, st, 0, 0, lapb_fast, &lapb_declined));
+    MOT_LC_HIP(b, mot::launch_lap(K.lapb, S, bd, (bn + bd > CAP + D) ? CAP + D : bn + bd, true, general, true, st, 0, 0, lapb_fast, &lapb_declined, nullptr, nullptr, active));
     hipLaunchKernelGGL(oc_after_byte, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, K);
   }
-  MOT_LC_HIP(b, mot::launch_lap(K.lapr, S, 2 * bd, bn + bd, true, general, true, st, 0, 0, lapr_fast, &lapr_declined));
+  MOT_LC_HIP(b, mot::launch_lap(K.lapr, S, 2 * bd, bn + bd, true, general, true, st, 0, 0, lapr_fast, &lapr_declined, nullptr, nullptr, active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[5], st));
   hipLaunchKernelGGL(oc_finish, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, S, K);
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYSR, K.init, S, 2 * bd, st));

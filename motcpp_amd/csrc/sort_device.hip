@@ -405,13 +405,15 @@ static int sort_enqueue_frame(mot_sort_batch* b, const float* d_dets, const int*
   if (bd > D) bd = D;
   const int bn = (bound < 1) ? 1 : (bound > CAP ? CAP : bound);  // tracks alive after the previous frame (+ what frames in flight may add)
   const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;
+  int active = 0;  // streams with a frame: a launch with a handful of problems is tuned for latency (mot::launch_lap)
+  for (int s = 0; s < S; ++s) active += (counts[s] >= 0) ? 1 : 0;
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
   hipLaunchKernelGGL(sort_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, FD, d_dets, b->det_t, b->pred_t);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYSR, b->det_t, S, bd, st));
   MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYSR, b->pred_t, S, bn, st));
   hipLaunchKernelGGL(sort_assoc, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->lap_t, prof ? b->d_stats : nullptr);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
-  MOT_LC_HIP(b, mot::launch_lap(b->lap_t, S, bn, bd, true, false, true, st));
+  MOT_LC_HIP(b, mot::launch_lap(b->lap_t, S, bn, bd, true, false, true, st, 0, 0, true, nullptr, nullptr, nullptr, active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
   hipLaunchKernelGGL(sort_apply, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box_t);
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYSR, b->init_t, S, bd, st));

@@ -11,7 +11,7 @@ from motcpp_amd import _lib as L  # noqa: E402
 from motcpp_amd.synth import SynthStream  # noqa: E402
 
 WORK = {"NS": ("bytetrack", 1000, 500, 70, 40), "C2": ("bytetrack", 256, 128, 70, 40), "SORT": ("sort", 256, 128, 50, 20),
-        "OC": ("ocsort", 256, 128, 50, 20)}
+        "OC": ("ocsort", 256, 128, 50, 20), "SORTNS": ("sort", 1000, 500, 50, 20), "OCNS": ("ocsort", 1000, 500, 50, 20)}
 
 
 def main():

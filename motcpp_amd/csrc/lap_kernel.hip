@@ -199,6 +199,11 @@ template <int kThreads, int lds_mode, int RPL, int FLAVOR>
 __global__ void __launch_bounds__(kThreads, lap_min_waves(kThreads, RPL, FLAVOR == 2)) lap_kernel(const mot_lap_task* __restrict__ tasks, int ntasks, int check_status, const int* declined, int fs_lds) {
   // behind the fast path: its count of declined problems; usually zero, and then there is nothing to look for
   if (check_status && declined != nullptr && *declined == 0) return;
+  // A handful of problems the sparse solver declined, one wavefront each, and their whole sub-batch waits for the slowest: the other
+  // HIP streams' kernels fill the same SIMDs (four or five wavefronts each), so without help this wavefront gets a fraction of the issue
+  // slots (measured at the north-star shape: 3.2 ms alone on the GPU, 8 ms on average inside the benchmark). check_status 1 = raise the
+  // wavefront's issue priority; 2 = leave it (MOT_LAP_BEHIND_PRIO=0, for A/B measurements).
+  if (check_status == 1) __builtin_amdgcn_s_setprio(3);
   // behind the fast path the grid is smaller than the task array: a block walks its share of it and solves what is left
   for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
     const mot_lap_task T = tasks[task];
@@ -306,6 +311,13 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
                             X(64, 0, 0, 2) X(64, 2, 0, 2) X(64, 3, 0, 2) X(256, 0, 0, 2) X(256, 2, 0, 2) X(256, 3, 0, 2)
   // plain-cost variants exist for the register-cached column layouts only (the hot ones)
   const int flavor = general_assoc ? 2 : ((plain_costs && rpl > 0) ? 0 : 1);
+  // Behind the fast path a plain-cost launch of the lean mode moves to the full LDS state when it fits in 64 KB: the lean mode buys
+  // residency (8 problems per CU), which a handful of declined problems has no use for, while the row boxes in LDS open the sparse
+  // column minima of phase 1 (lap_core.hpp::sparse_column_minima, Cost::kPlain) and LDS row fetches in every row pass — per-problem
+  // latency is what the waiting sub-batch pays. MOT_LAP_BEHIND_FULL=0 keeps the lean mode (A/B measurements).
+  static const bool behind_full = !(std::getenv("MOT_LAP_BEHIND_FULL") && std::getenv("MOT_LAP_BEHIND_FULL")[0] == '0');
+  if (fast && behind_full && flavor == 0 && rpl > 0 && mode == 3 && b2 <= 64 * 1024) { mode = 2; lds = b2; }
+  static const bool behind_prio = !(std::getenv("MOT_LAP_BEHIND_PRIO") && std::getenv("MOT_LAP_BEHIND_PRIO")[0] == '0');
   std::lock_guard<std::mutex> attr_lock(attr_mu);
   if (!attr_set_dev[dev_slot]) {
 #define MOT_ATTR(T, M, R, G)                                                                                               \
@@ -325,7 +337,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   bool launched = false;
 #define MOT_TRY(T, M, R, G)                                                                                \
   if (!launched && threads == T && mode == M && rpl == R && flavor == G) {                                 \
-    hipLaunchKernelGGL((lap_kernel<T, M, R, G>), dim3(grid), dim3(T), lds, st, tasks, ntasks, fast ? 1 : 0, declined, fs_lds); \
+    hipLaunchKernelGGL((lap_kernel<T, M, R, G>), dim3(grid), dim3(T), lds, st, tasks, ntasks, fast ? (behind_prio ? 1 : 2) : 0, declined, fs_lds); \
     launched = true;                                                                                       \
   }
   MOT_LAP_VARIANTS(MOT_TRY)

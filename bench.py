@@ -102,7 +102,7 @@ def launch_probe(real_stdout):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 60; C4: 3 - a step there is 256 assignment problems of 4096 x 2048)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 60; C4: 7 - a step there is 256 assignment problems of 4096 x 2048)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 40; C4: 1)")
     ap.add_argument("--workload", default="NS", choices=sorted(WORKLOADS),
                     help="NS = the north-star shape the >= 50 k frames/s bar is set on (ByteTrack, 1000 tracks x 500 detections)")
@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-streams", type=int, default=None,
                     help="streams of rank 0 (seeded sample over all sub-batches, stream 0 among them) whose outputs are compared with the oracle "
-                         "(default 32; C3: 8, C4: 2 - the oracle runs 17 / 0.2 frames/s there)")
+                         "(default 32; C3: 8, C4: 4 - the oracle runs 17 / 0.2 frames/s there)")
     ap.add_argument("--sweep-streams", default=None,
                     help="comma-separated stream counts of the S-sweep after the timed region (default 1,64,1024 for the device lifecycles; '' = off)")
     ap.add_argument("--long-run-steps", type=int, default=None,
@@ -185,10 +185,10 @@ def main():
     # throttles the whole process (measured on the 16-CPU-quota GPU boxes: 32 workers 456k frames/s, 64 workers 268k)
     threads = args.threads or max(2, min(os.cpu_count() or 1, 64, 2 * cpu_budget() // max(1, world_local())))
     heavy = args.workload == "C4"  # seconds per step: keep the default run within minutes
-    K = args.steps if args.steps is not None else (3 if heavy else 60)
+    K = args.steps if args.steps is not None else (7 if heavy else 60)
     W = args.warmup if args.warmup is not None else (1 if heavy else 40)
     if args.settle is None:
-        args.settle = 5 if heavy else 30
+        args.settle = 12 if heavy else 30  # (C4: 12 + 1 + 7 = the 20 frames per stream the parity sample covers)
     if args.isolated_steps is None:
         args.isolated_steps = 0 if heavy else 4
     on_device_wl = tracker in ("bytetrack", "sort") and args.lifecycle in ("auto", "device")  # (host-input leg: detections only)
@@ -327,7 +327,7 @@ def main():
         gathered = mdist.gather_tables(out[:, :cap], cnt.astype(np.int32), device=torch.device("cuda", local))
 
     # parity sample: a seeded choice of this rank's streams, stream 0 and the first stream of every sub-batch among them
-    n_par = args.parity_streams if args.parity_streams is not None else {"C3": 8, "C4": 2}.get(args.workload, 32)
+    n_par = args.parity_streams if args.parity_streams is not None else {"C3": 8, "C4": 4}.get(args.workload, 32)
     n_par = max(1, min(n_par, S))
     forced = sorted({0} | {bounds[p] for p in range(PIPE)})[:n_par]
     rest = [int(x) for x in np.random.default_rng(20240903).permutation(S) if int(x) not in forced]

@@ -10,6 +10,7 @@ MOT_LAP_BEHIND_PRIO=1 MOT_LAP_BEHIND_FULL=0 timeout 400 python bench.py $B > $OU
 MOT_LAP_BEHIND_PRIO=0 MOT_LAP_BEHIND_FULL=1 timeout 400 python bench.py $B > $OUT/${TAG}_NS_full_$rep.json 2>> $OUT/${TAG}_err.txt
 timeout 400 python bench.py $B > $OUT/${TAG}_NS_new_$rep.json 2>> $OUT/${TAG}_err.txt
 done
+for P in 4 6; do timeout 400 python bench.py $B --pipeline $P > $OUT/${TAG}_NS_new_pipe$P.json 2>> $OUT/${TAG}_err.txt; done
 MOT_LAP_BEHIND_PRIO=0 timeout 400 python bench.py --workload C3 $B > $OUT/${TAG}_C3_old.json 2>> $OUT/${TAG}_err.txt
 timeout 400 python bench.py --workload C3 $B > $OUT/${TAG}_C3_new.json 2>> $OUT/${TAG}_err.txt
 python - <<'P'

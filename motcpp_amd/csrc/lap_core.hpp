@@ -69,6 +69,13 @@ template <class G, class = void>
 struct has_wave_table { static constexpr bool value = false; };
 template <class G>
 struct has_wave_table<G, decltype(void(G::kWaveTable))> { static constexpr bool value = G::kWaveTable; };
+#if !defined(__HIPCC__)
+// (host emulation only: how often the search skipped a real row's sweep through the nolow flags — tests assert that the path runs)
+inline long& lap_dbg_void_real() { static long c = 0; return c; }
+#define MOT_LAP_DBG_VOID(n) do { if (t == 0) lap_dbg_void_real() += (n); } while (0)
+#else
+#define MOT_LAP_DBG_VOID(n) ((void)0)
+#endif
 struct LapDims {
   int nr, nc;
   double half;  // thresh / 2 (lap_solver.hpp:300)
@@ -94,6 +101,7 @@ struct LapWorkT {
   MemPtr<int, kMemGlobal> inv;    // inverse of cols[] (position of a column), slow path
   MemPtr<int, kMemGlobal> tie;    // tie flags by position during a scan (all zero between scans), slow path
   MemPtr<int, kMemGlobal> sa, sb, sc;  // staging of the closed-form tie runs that do not fit in registers (slow path)
+  MemPtr<float, kMemGlobal> rmin; // per real row: minimum RAW cost over the real columns (phase 1, register-cached on-the-fly costs), see "void real rows"
   // optional (null: the parallel scan steps and the sparse real-row sweeps are off) — see "row lists" in lap_solve
   MemPtr<int, kMemGlobal> rl_cnt;     // [nr] entries of real row i with cost < half (may exceed kRlCap: then the row has no usable list)
   MemPtr<unsigned long long, kMemGlobal> rl_ent;  // [nr][kRlCap] their (column | cost bits << 32): one 8-byte load per entry, a row's first 16 entries in one 128-byte line
@@ -104,7 +112,7 @@ struct LapWorkT {
 };
 using LapWork = LapWorkT<kMemAny, kMemAny, kMemAny>;
 MOT_HD size_t lap_hot_bytes(int n) { return static_cast<size_t>(n) * (sizeof(double) + 3 * sizeof(int)); }
-MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 9 * sizeof(int)); }
+MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 9 * sizeof(int) + sizeof(float)); }
 // Row lists (optional scratch of a matrix-cost task, mot_lap_task.rowlist): per real row the entries below thresh/2.
 constexpr int kRlCap = 64;      // entries kept per row (a row with more has no list: its sweeps stay dense)
 constexpr int kFsIter = 8;      // list entries a lane holds in registers during a parallel scan step
@@ -151,7 +159,8 @@ MOT_HD void lap_carve_cold(Work& w, void* base, int n) {
   w.tie.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.sa.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.sb.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
-  w.sc.p = reinterpret_cast<int*>(p);
+  w.sc.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.rmin.p = reinterpret_cast<float*>(p);
 }
 MOT_HD LapWork lap_carve(void* base, int n) {  // hot then cold, contiguous
   LapWork w;
@@ -248,7 +257,7 @@ MOT_HD float key_f32(int k) { return __builtin_bit_cast(float, k ^ ((k >> 31) & 
 constexpr int kSparseOwnRows = 16;  // rows per lane whose ranks are counted in registers
 constexpr int kSparseMinRows = 32;
 template <class G, class Cost, class Work>
-MOT_DEV void sparse_column_minima(G& g, const Cost& C, const Work& W, int nr, int nc, float* vmk, int* imk) {
+MOT_DEV void sparse_column_minima(G& g, const Cost& C, const Work& W, int nr, int nc, float* vmk, int* imk, bool keep_rmin) {
   const int T = g.size(), t = g.tid();
   // The sorted tables live where the column duals and the column->row map will be written when the columns are published
   // (after this function's closing barrier) — LDS whenever the problem fits; v holds 2n ints, y holds n, n >= nr.
@@ -347,7 +356,9 @@ MOT_DEV void sparse_column_minima(G& g, const Cost& C, const Work& W, int nr, in
   g.sync();
   for (int i = t; i < nr; i += T) {
     const float rm = key_f32(~static_cast<int>(RMK[i]));
-    W.rlb[i] = static_cast<double>((zmin < rm) ? zmin : rm);
+    const float raw = (zmin < rm) ? zmin : rm;
+    W.rlb[i] = static_cast<double>(raw);
+    if (keep_rmin) W.rmin[i] = raw;
   }
   // (the caller's barrier after publishing the columns orders these writes before any later use of the work arrays)
 }
@@ -401,6 +412,10 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
   // above the best dummy-column values can only ever pick dummy columns — such rows (every track with no detection near
   // it) are resolved in closed-form runs below, exactly like the dummy rows. Needs the row-major sweep of phase 1.
   const bool have_lb = Cost::kRPL > 0 && nc <= Cost::kRPL * T;
+  // "Void real rows": the raw minimum of every real row over the real columns is kept (rmin[], on-the-fly costs with the row-major
+  // phase 1). In the shortest-path search a real row whose every real cost is far enough above half cannot lower any real
+  // column once a dummy row has been swept — see the search below; on tracking problems that is every unmatched track.
+  const bool keep_rmin = have_lb && !is_matrix_cost<Cost>::value && half > -1e300 && half < 1e300;
   double vmax0 = 0.0;
   if constexpr (Cost::kRPL > 0) {
     // all of the lane's cached real columns advance together down the rows: one row-box fetch per row, no column loads
@@ -413,7 +428,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     bool swept = false;
     if constexpr (Cost::kPlain) {
       if (have_lb && nr >= kSparseMinRows && nr <= kSparseOwnRows * T) {
-        sparse_column_minima(g, C, W, nr, nc, vmk, imk);
+        sparse_column_minima(g, C, W, nr, nc, vmk, imk, keep_rmin);
         swept = true;
       }
     }
@@ -454,7 +469,10 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
         for (int u = 0; u < kRowBatch; ++u) rm[u] = g.reduce_min_f32(rm[u]);  // independent chains: they interleave
 #pragma unroll
         for (int u = 0; u < kRowBatch; ++u)
-          if (t == 0 && i0 + u < nr) W.rlb[i0 + u] = static_cast<double>(rm[u]);
+          if (t == 0 && i0 + u < nr) {
+            W.rlb[i0 + u] = static_cast<double>(rm[u]);
+            if (keep_rmin) W.rmin[i0 + u] = rm[u];
+          }
       }
     }
 #pragma unroll
@@ -1595,6 +1613,32 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             g.lds_barriers(false);
             return r;
           };
+          // Void real rows (round 4, on-the-fly costs). Let H = hmax_dummy_row: a dummy row has been swept with h = H (or the search
+          // started from one: its initial distances are that sweep with h = 0), so every TODO real column j has
+          // d[j] <= D_j = fl(fl(half - v[j]) - H), and d only falls. A real row i with h_i relaxes column j to
+          // cred = fl(fl(c_ij - v[j]) - h_i), monotone in c_ij, and c_ij >= rmin_i (a NaN cost compares false: no-op). Then
+          //  (a) h_i <= H and rmin_i >= half: cred >= D_j >= d[j] by monotone rounding — fact (2) of the scan steps with an empty list;
+          //  (b) otherwise, in exact arithmetic cred - D_j >= g = (rmin_i - half) - (h_i - H) (v[j] cancels) and the four roundings
+          //      involved err by at most 4u(|rmin_i| + |half| + 2|v[j]| + |h_i| + |H|), u = 2^-53: with g above 2^-46 times that sum
+          //      (max |v| over the real columns taken once per search: the duals do not change inside one) cred > d[j] strictly.
+          // Either way `cred < d[j]` is false for every real column: the sweep changes nothing and is skipped. On a tracking problem
+          // these are the unmatched tracks (costs 1 against half = thresh / 2, h = half - v[dummy column]): hundreds per tied set.
+          double vabs_max = -1.0;
+          auto void_cols = [&](int ri, double hi) {
+            const double rmn = static_cast<double>(W.rmin[ri]);
+            if (hi <= hmax_dummy_row) return rmn >= half;
+            if (!(hmax_dummy_row > -1e299)) return false;
+            const double gap = (rmn - half) - (hi - hmax_dummy_row);
+            const double mag = (rmn < 0 ? -rmn : rmn) + (half < 0 ? -half : half) + 2.0 * vabs_max + (hi < 0 ? -hi : hi) +
+                               (hmax_dummy_row < 0 ? -hmax_dummy_row : hmax_dummy_row);
+            return gap > mag * 1.4210854715202004e-14;  // 2^-46
+          };
+          if (keep_rmin) {  // (uniform; one pass over the hot duals per search that gets here)
+            double vm = 0.0;
+            for (int j = t; j < nc; j += T) { const double a = W.v[j]; const double aa = a < 0 ? -a : a; if (aa > vm) vm = aa; }
+            vabs_max = -g.reduce_min(-vm);
+            if (!(vabs_max >= 0.0) || !(vabs_max < 1e299)) vabs_max = 1e300;  // (NaN / inf duals: rule (b) never fires)
+          }
           const double mind_set = pq_d;  // every member of a SCAN set sits at the same distance
           bool pq_valid = true;
           while (slo != shi) {
@@ -1611,17 +1655,26 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             // Runs of dummy-row members whose sweep is void (h <= hmax_dummy_row, see below) leave the SCAN set together:
             // each lane classifies one member ahead, one reduction counts the leading void ones. With more detections
             // than tracks the tied sets are hundreds of such rows (one per unmatched detection).
-            if (pq_i >= nr && (((pq_j < nc) ? half : 0.0) - W.v[pq_j] - pq_d) <= hmax_dummy_row) {
+            // (round 4) So do the real rows that sit on a dummy column (every unmatched track: h = half - v[j] - d needs no cost
+            // evaluation) when their real columns are void (void_cols below) and, with h <= hmax_real_row, their dummy columns too.
+            auto void_real = [&](int mi, int mj, double md) {
+              if (!keep_rmin || mi >= nr || mj < nc) return false;
+              const double hv = half - W.v[mj] - md;
+              return hv <= hmax_real_row && void_cols(mi, hv);
+            };
+            if ((pq_i >= nr && (((pq_j < nc) ? half : 0.0) - W.v[pq_j] - pq_d) <= hmax_dummy_row) || void_real(pq_i, pq_j, pq_d)) {
               const unsigned idx = slo + static_cast<unsigned>(t);
               bool ok = false;
               if (idx < shi) {
                 const int mj = W.cols[idx];
                 const int mi = W.y[mj];
                 if (mi >= nr) ok = (((mj < nc) ? half : 0.0) - W.v[mj] - W.d[mj]) <= hmax_dummy_row;
+                else ok = void_real(mi, mj, W.d[mj]);
               }
               int cnt = g.reduce_min_int(ok ? kNoIdx : t);
               const int avail = (shi - slo < static_cast<unsigned>(T)) ? static_cast<int>(shi - slo) : T;
               if (cnt > avail) cnt = avail;
+              if (pq_i < nr) MOT_LAP_DBG_VOID(1);
               slo += static_cast<unsigned>(cnt);  // cnt >= 1: lane 0 looked at the current member
               if (slo != shi) member(slo);
               continue;
@@ -1671,6 +1724,8 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             } else {
               if (h <= hmax_real_row) sweep_dummy = false;
               else hmax_real_row = h;
+              // no entry below half and a dummy row swept with at least this h: nothing among the real columns can be lowered
+              if (keep_rmin && void_cols(i, h)) { sweep_real = false; MOT_LAP_DBG_VOID(1); }
             }
             int first_sink = kNoIdx, any_tie = 0;
             auto relax_pre = [&](double red, int j, int k, double dj) {  // k = inv[j], dj = d[j]

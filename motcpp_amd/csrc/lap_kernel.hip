@@ -311,12 +311,12 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
                             X(64, 0, 0, 2) X(64, 2, 0, 2) X(64, 3, 0, 2) X(256, 0, 0, 2) X(256, 2, 0, 2) X(256, 3, 0, 2)
   // plain-cost variants exist for the register-cached column layouts only (the hot ones)
   const int flavor = general_assoc ? 2 : ((plain_costs && rpl > 0) ? 0 : 1);
-  // Behind the fast path a plain-cost launch of the lean mode moves to the full LDS state when it fits in 64 KB: the lean mode buys
+  // Behind the fast path a plain-cost launch of the lean mode moves to the full LDS state when it fits in 100 KB: the lean mode buys
   // residency (8 problems per CU), which a handful of declined problems has no use for, while the row boxes in LDS open the sparse
   // column minima of phase 1 (lap_core.hpp::sparse_column_minima, Cost::kPlain) and LDS row fetches in every row pass — per-problem
   // latency is what the waiting sub-batch pays. MOT_LAP_BEHIND_FULL=0 keeps the lean mode (A/B measurements).
   static const bool behind_full = !(std::getenv("MOT_LAP_BEHIND_FULL") && std::getenv("MOT_LAP_BEHIND_FULL")[0] == '0');
-  if (fast && behind_full && flavor == 0 && rpl > 0 && mode == 3 && b2 <= 64 * 1024) { mode = 2; lds = b2; }
+  if (fast && behind_full && flavor == 0 && rpl > 0 && mode == 3 && b2 <= 100 * 1024) { mode = 2; lds = b2; }
   static const bool behind_prio = !(std::getenv("MOT_LAP_BEHIND_PRIO") && std::getenv("MOT_LAP_BEHIND_PRIO")[0] == '0');
   std::lock_guard<std::mutex> attr_lock(attr_mu);
   if (!attr_set_dev[dev_slot]) {

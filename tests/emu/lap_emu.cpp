@@ -71,6 +71,7 @@ static int run_iou(const float* a, int nr, const float* b, int nc, const float* 
   for (int j = 0; j < nc; ++j) y[j] = (W.y[j] >= nr) ? -1 : W.y[j];
   return 0;
 }
+extern "C" long emu_void_real_sweeps(int reset) { long& c = mot::lap_dbg_void_real(); const long v = c; if (reset) c = 0; return v; }
 extern "C" int emu_lap_iou(const float* a, int nr, const float* b, int nc, const float* conf, int mode, float thresh, int T,
                            int rpl, int* x, int* y) {
   if (rpl == 104) return run_iou<4, true>(a, nr, b, nc, conf, mode, thresh, T, x, y);  // 100 + rpl: the plain-cost variants

@@ -36,6 +36,8 @@ def emu_iou(request):
                         conf.ctypes.data_as(C.c_void_p), mode, C.c_float(th), T, rpl, x.ctypes.data_as(C.c_void_p),
                         y.ctypes.data_as(C.c_void_p))
         return x, y
+    lib.emu_void_real_sweeps.restype = C.c_long
+    run.void_real_sweeps = lambda reset=1: lib.emu_void_real_sweeps(reset)
     return run
 
 
@@ -121,6 +123,38 @@ def test_unmatched_tracks_and_detections_closed_form_runs(orc, emu_iou):
             xo, yo = orc.linear_assignment(cost, th)
             xe, ye = emu_iou(a, b, conf, mode, th, T, rpl)
             assert (xo == xe).all() and (yo == ye).all(), (n, m, near, T, rpl, mode, th)
+
+
+def test_rows_without_an_entry_below_half_skip_their_sweeps(orc, emu_iou):
+    # (round 4) the shortest-path search skips the sweep of a real row whose costs are all >= thresh / 2 once a dummy row has been
+    # swept with at least its h (lap_core.hpp: nolow). Scenes that force long tied sets through the search: many unmatched tracks,
+    # detections that are exact copies of SEVERAL tracks' boxes (duplicated tracks: equal costs, non-unique optima), pile-ups.
+    r = np.random.default_rng(5)
+    emu_iou.void_real_sweeps(1)
+    total = 0
+    for trial in range(24):
+        T, rpl = ((8, 108), (16, 104), (64, 8), (8, 4))[trial % 4]
+        cap = (rpl % 100) * T
+        n = int(r.integers(60, 400))
+        m = int(r.integers(10, min(cap, 200) + 1))
+        cx, cy = r.uniform(0, 3000, n), r.uniform(0, 1500, n)
+        w, h = r.uniform(30, 80, n), r.uniform(60, 150, n)
+        a = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32)
+        ndup = n // 6
+        a[r.permutation(n)[:ndup]] = a[r.integers(0, n, ndup)]  # duplicated tracks
+        src = r.integers(0, n, m)
+        b = (a[src] + r.normal(0, 3.0, (m, 4))).astype(np.float32)
+        b[::2] = a[src[::2]]  # detections exactly on (possibly duplicated) tracks
+        far = r.random(m) < 0.3
+        b[far] += 5000.0  # detections with no track near them (dummy rows)
+        conf = r.uniform(0.3, 1, m).astype(np.float32)
+        for mode, th in ((1, 0.7), (2, 0.8), (1, 0.95)):
+            cost = {1: orc.iou_distance(a, b), 2: orc.fuse_score(orc.iou_distance(a, b), conf)}[mode]
+            xo, yo = orc.linear_assignment(cost, th)
+            xe, ye = emu_iou(a, b, conf, mode, th, T, rpl)
+            assert (xo == xe).all() and (yo == ye).all(), (trial, n, m, T, rpl, mode, th)
+        total += emu_iou.void_real_sweeps(1)
+    assert total > 0  # the path under test ran
 
 
 def test_sparse_column_minima_make_the_same_decisions(orc, emu_iou):

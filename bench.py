@@ -895,6 +895,7 @@ def main():
         "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         "kernels": kernels,
         "lap_fast_path": fast_stats,
+        "lap_behind_fast_path": diag_ctx.lap_behind_stats(),  # (whole run: the problems the exact kernel solved behind the sparse solver, cycle split of the slowest)
         "kernels_isolated": isolated,
         "long_run": long_run, "outputs_resident": outputs_resident, "stream_sweep": sweep,
         "achieved_problem_sizes": achieved_dims, "host_input": host_input,

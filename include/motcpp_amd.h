@@ -429,6 +429,10 @@ size_t mot_lap_rowlist_bytes(int n);
  * (four-wavefront launches): fetching a column's pairs, delivering labels, picking the nearest row, dual update + augmentation;
  * [28..31] reserved. */
 int mot_lap_fast_stats(mot_ctx* ctx, unsigned long long* out32, int reset);
+/* Diagnostics of the problems the exact emulation solved BEHIND the fast path on this device since the last reset: out80[0..35] = the
+ * counters of mot_lap_task.prof summed over those problems, out80[39] = how many; out80[40..75] = the counters of the slowest one,
+ * out80[79] = its shader cycles (phases 1a + 1b + 2 + 3). Synchronises the context's stream. */
+int mot_lap_behind_stats(mot_ctx* ctx, long long* out80, int reset);
 int mot_lap_solve(mot_ctx* ctx, const mot_lap_task* tasks, int ntasks, int max_n, int max_m, int flags);
 
 /* ---- ByteTrack with the per-stream lifecycle on the device ------------------------------ */

@@ -160,6 +160,18 @@ class Context:
         self._chk(self.lib.mot_feat_update_host_alpha(self.h, int(mode), C.c_float(alpha), _p(ai) if ai is not None else None, n, d, _p(feat), _p(src)))
         return feat
 
+    def lap_behind_stats(self, reset=False):
+        """Counters of the problems the exact emulation solved behind the fast path since the last reset (see mot_lap_behind_stats):
+        sums over the problems and the slowest problem's own figures."""
+        o = np.zeros(80, np.int64)
+        self._chk(self.lib.mot_lap_behind_stats(self.h, _p(o), 1 if reset else 0))
+        names = ("cyc_phase1_columns", "cyc_phase1_transfer", "cyc_row_reduction", "cyc_augmentation", "n_unique_rows", "serial_row_rounds",
+                 "serial_augmentations", "n_extended", "scan_steps", "scan_step_members", "scan_step_real_rows", "tie_events", "single_sweeps",
+                 "steps_refused", "find_dense_calls", "row_lists", "cyc_step_classify", "cyc_step_dry", "cyc_step_apply", "cyc_event_sort",
+                 "cyc_event_replay", "cyc_find_dense", "cyc_single_sweeps", "cyc_search_setup")
+        return {"problems": int(o[39]), "sum": dict(zip(names, (int(v) for v in o[:24]))),
+                "slowest": dict(zip(names, (int(v) for v in o[40:64]))), "slowest_cycles": int(o[79])}
+
     def lap_fast_stats(self, reset=False):
         """Outcome counts of the assignment fast path on this device since the last reset (see mot_lap_fast_stats)."""
         o = np.zeros(32, np.uint64)

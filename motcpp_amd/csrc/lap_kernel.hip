@@ -105,6 +105,11 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
 // wavefront, throughput comes from co-resident ones (RPL 8: 2, i.e. <= 256 VGPRs; RPL 4: 3, <= 168; else whatever fits)
 constexpr int lap_min_waves(int threads, int rpl, bool general) { return (threads > 64 || general) ? 1 : (rpl >= 8 ? 2 : (rpl >= 4 ? 3 : 4)); }
 // FLAVOR of the on-the-fly cost: 0 plain IoU modes only, 1 + BoT-SORT's gated appearance term, 2 every association measure
+// Diagnostics of the problems solved BEHIND the fast path (the ones the sparse solver declined): per-block scratch for lap_solve's
+// cycle / event counters (mot_lap_task.prof layout, 36 entries), summed into g_behind[0] ([39] = problems), the slowest problem's
+// own counters kept in g_behind[1] ([39] = its cycles). Read by mot_lap_behind_stats.
+__device__ long long g_behind_scr[512][36];
+__device__ long long g_behind[2][40];
 template <int kThreads, int lds_mode, int RPL, int FLAVOR>
 __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status, int fs_lds) {
   constexpr bool GENERAL = FLAVOR == 2;
@@ -151,8 +156,9 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status,
   mot::lap_carve_cold(W, gw + hot_b, n);
   if constexpr (lds_mode == 4)  // + the distances of the shortest-path search (wide matrix problems: every scan step reads and writes them)
     W.d.p = reinterpret_cast<double*>(lds + ((12 * static_cast<size_t>(n) + 15) & ~size_t(15)));
-  W.cyc = T.prof;
-  W.cyc_ext = true;  // (mot_lap_task.prof holds 24 entries)
+  const bool behind_diag = check_status != 0 && T.prof == nullptr && blockIdx.x < 512;
+  W.cyc = behind_diag ? g_behind_scr[blockIdx.x] : T.prof;
+  W.cyc_ext = true;  // (mot_lap_task.prof holds 36 entries)
   int path;
   if (T.geom.a != nullptr) {
     float* gbox = reinterpret_cast<float*>(gw + hot_b + cold_b);
@@ -193,6 +199,14 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status,
     path = gate_and_solve<kThreads>(g, C, T, W);
   }
   if (T.info && t == 0) T.info[0] = path;
+  if (behind_diag && t == 0) {
+    const long long* c = g_behind_scr[blockIdx.x];
+    const long long tot = c[0] + c[1] + c[2] + c[3];
+    for (int k = 0; k < 36; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(&g_behind[0][k]), static_cast<unsigned long long>(c[k]));
+    atomicAdd(reinterpret_cast<unsigned long long*>(&g_behind[0][39]), 1ull);
+    const long long prev = static_cast<long long>(atomicMax(reinterpret_cast<unsigned long long*>(&g_behind[1][39]), static_cast<unsigned long long>(tot)));
+    if (tot > prev) for (int k = 0; k < 36; ++k) g_behind[1][k] = c[k];
+  }
 }
 
 template <int kThreads, int lds_mode, int RPL, int FLAVOR>
@@ -219,6 +233,13 @@ size_t lap_scratch_bytes(int n, int m) { return lap_task_scratch_bytes(n, m); }
 size_t lap_rowlist_scratch_bytes(int n) { return lap_rowlist_bytes(n); }
 hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, int max_m, bool plain_costs, int* declined, hipStream_t st,
                              int hint_n, int hint_m, int active_tasks);
+hipError_t lap_behind_stats(long long* out80, bool reset, hipStream_t st) {
+  hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  if (out80) { e = hipMemcpyFromSymbol(out80, HIP_SYMBOL(g_behind), sizeof(long long) * 80); if (e != hipSuccess) return e; }
+  if (reset) { static const long long z[80] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_behind), z, sizeof(z)); }
+  return e;
+}
 
 namespace {
 // one counter per launch in flight (the sparse kernel counts the problems it declines, the exact kernel reads it): a ring of

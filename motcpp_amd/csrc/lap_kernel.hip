@@ -141,7 +141,8 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status,
   constexpr int kXS = (lds_mode == 2) ? mot::kMemLds : mot::kMemGlobal;  // x, free list
   constexpr int kRS = (lds_mode == 2) ? mot::kMemLds : mot::kMemGlobal;  // row boxes
   constexpr int kDS = (lds_mode == 4) ? mot::kMemLds : mot::kMemGlobal;  // shortest-path distances
-  mot::LapWorkT<kVS, kXS, kDS> W;
+  constexpr int kBS = (lds_mode == 2) ? mot::kMemLds : mot::kMemGlobal;  // row bounds (on-the-fly costs only)
+  mot::LapWorkT<kVS, kXS, kDS, kBS> W;
   char* lds = smem + kScratch;
   if (fs_lds) {  // the launch reserved the fast scratch: row lists are usable by the tasks that bring the memory for them
     if (T.rowlist != nullptr && T.geom.a == nullptr) { mot::lap_carve_rowlist(W, T.rowlist, nr); W.fsw.p = reinterpret_cast<int*>(lds); }
@@ -167,7 +168,10 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status,
     float* cp = gbox + 5 * nr;
     float* cf = cp + 5 * nc;
     float* rp;
-    if constexpr (lds_mode == 2) rp = reinterpret_cast<float*>(lds); else rp = gbox;
+    if constexpr (lds_mode == 2) {
+      rp = reinterpret_cast<float*>(lds);
+      W.rlb.p = reinterpret_cast<double*>(lds + ((20 * static_cast<size_t>(nr) + 16 + 15) & ~size_t(15)));  // behind the row boxes (8 B per real row)
+    } else rp = gbox;
     const mot_iou_task& G = T.geom;
     for (int i = t; i < nr; i += kThreads) {
       const int gi = G.aidx ? G.aidx[i] : i;
@@ -296,7 +300,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   const size_t hot = (lap_hot_bytes(nm) + 15) & ~size_t(15);
   const int fs_lds = (!geom && n * m >= 16384) ? 1 : 0;  // matrix costs of some size: room for the parallel scan steps' scratch
   const size_t fsb = fs_lds ? kFsLds : 0;
-  const size_t b2 = kScratch + fsb + hot + (geom ? 20 * n + 16 : 0);  // full hot state (+ row boxes) in LDS
+  const size_t b2 = kScratch + fsb + hot + (geom ? 28 * n + 48 : 0);  // full hot state (+ row boxes and row bounds) in LDS
   const size_t b3 = kScratch + fsb + 12 * nm + 16;                    // lean: duals + y
   const size_t b4 = kScratch + fsb + 20 * nm + 32;                    // lean + distances
   int mode;
@@ -332,12 +336,12 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
                             X(64, 0, 0, 2) X(64, 2, 0, 2) X(64, 3, 0, 2) X(256, 0, 0, 2) X(256, 2, 0, 2) X(256, 3, 0, 2)
   // plain-cost variants exist for the register-cached column layouts only (the hot ones)
   const int flavor = general_assoc ? 2 : ((plain_costs && rpl > 0) ? 0 : 1);
-  // Behind the fast path a plain-cost launch of the lean mode moves to the full LDS state when it fits in 100 KB: the lean mode buys
+  // Behind the fast path a plain-cost launch of the lean mode moves to the full LDS state when it fits in 112 KB: the lean mode buys
   // residency (8 problems per CU), which a handful of declined problems has no use for, while the row boxes in LDS open the sparse
   // column minima of phase 1 (lap_core.hpp::sparse_column_minima, Cost::kPlain) and LDS row fetches in every row pass — per-problem
   // latency is what the waiting sub-batch pays. MOT_LAP_BEHIND_FULL=0 keeps the lean mode (A/B measurements).
   static const bool behind_full = !(std::getenv("MOT_LAP_BEHIND_FULL") && std::getenv("MOT_LAP_BEHIND_FULL")[0] == '0');
-  if (fast && behind_full && flavor == 0 && rpl > 0 && mode == 3 && b2 <= 100 * 1024) { mode = 2; lds = b2; }
+  if (fast && behind_full && flavor == 0 && rpl > 0 && mode == 3 && b2 <= 112 * 1024) { mode = 2; lds = b2; }
   static const bool behind_prio = !(std::getenv("MOT_LAP_BEHIND_PRIO") && std::getenv("MOT_LAP_BEHIND_PRIO")[0] == '0');
   std::lock_guard<std::mutex> attr_lock(attr_mu);
   if (!attr_set_dev[dev_slot]) {

@@ -84,7 +84,7 @@ struct LapDims {
 // the problem fits; the COLD arrays are only used by the general shortest-path search (rare on tracking costs)
 // and the phase-1 row list, and always live in global scratch.
 // VS = address space of v/y, XS = of x/fr, DS = of d (mem.hpp); the other cold arrays are always global.
-template <int VS, int XS, int DS = kMemGlobal, int BS = kMemGlobal>
+template <int VS, int XS, int DS = kMemGlobal, int BS = kMemGlobal, int CS = kMemGlobal>
 struct LapWorkT {
   // hot
   MemPtr<double, VS> v;   // column duals
@@ -93,14 +93,15 @@ struct LapWorkT {
   MemPtr<int, XS> fr;     // free-row list (doubles as the column-hit counter in phase 1)
   // cold
   MemPtr<double, DS> d;           // shortest-path distances (LDS for the wide matrix problems: every scan step reads and writes them)
-  MemPtr<int, kMemGlobal> pred;   // path predecessors
-  MemPtr<int, kMemGlobal> cols;   // lapjv's column permutation / phase-1 unique-row list
+  MemPtr<int, CS> pred;   // path predecessors (CS: LDS in the all-LDS mode of the launches behind the fast path — every sweep of the
+                          // shortest-path search reads inv[] / d[] and a member costs a cols[] -> d[] chain: global round trips otherwise)
+  MemPtr<int, CS> cols;   // lapjv's column permutation / phase-1 unique-row list
   MemPtr<int, kMemGlobal> tmp;    // tie flags (slow path)
   MemPtr<int, kMemGlobal> lst;    // compacted tie positions (slow path)
   MemPtr<double, BS> rlb; // per real row: lower bound of its reduced costs over the real columns, see "hopeless rows" (read and written by every
                           // serial round of the row reduction: LDS with the full LDS state — a global round trip per round is what a round then costs)
-  MemPtr<int, kMemGlobal> inv;    // inverse of cols[] (position of a column), slow path
-  MemPtr<int, kMemGlobal> tie;    // tie flags by position during a scan (all zero between scans), slow path
+  MemPtr<int, CS> inv;    // inverse of cols[] (position of a column), slow path
+  MemPtr<int, CS> tie;    // tie flags by position during a scan (all zero between scans), slow path
   MemPtr<int, kMemGlobal> sa, sb, sc;  // staging of the closed-form tie runs that do not fit in registers (slow path)
   MemPtr<float, kMemGlobal> rmin; // per real row: minimum RAW cost over the real columns (phase 1, register-cached on-the-fly costs), see "void real rows"
   // optional (null: the parallel scan steps and the sparse real-row sweeps are off) — see "row lists" in lap_solve
@@ -111,7 +112,7 @@ struct LapWorkT {
   long long* cyc = nullptr;  // optional profiling [16]: [0..3] cycles in phase 1a (column minima), 1b (transfer), 2, 3; [4..7] n_uniq, serial row-reduction rounds, serial augmentations, n;
                              // [8..15] shortest-path scans: parallel steps, members they consumed, real rows among them, tie events, one-at-a-time sweeps, steps refused (rounding), _find_dense calls, row lists in use
 };
-using LapWork = LapWorkT<kMemAny, kMemAny, kMemAny, kMemAny>;
+using LapWork = LapWorkT<kMemAny, kMemAny, kMemAny, kMemAny, kMemAny>;
 MOT_HD size_t lap_hot_bytes(int n) { return static_cast<size_t>(n) * (sizeof(double) + 3 * sizeof(int)); }
 MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 9 * sizeof(int) + sizeof(float)); }
 // Row lists (optional scratch of a matrix-cost task, mot_lap_task.rowlist): per real row the entries below thresh/2.

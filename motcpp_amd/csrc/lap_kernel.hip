@@ -138,17 +138,21 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status,
   char* gw = static_cast<char*>(T.work);
   const size_t hot_b = (mot::lap_hot_bytes(n) + 15) & ~size_t(15), cold_b = (mot::lap_cold_bytes(n) + 15) & ~size_t(15);
   constexpr int kVS = (lds_mode == 0) ? mot::kMemGlobal : mot::kMemLds;  // v, y
-  constexpr int kXS = (lds_mode == 2) ? mot::kMemLds : mot::kMemGlobal;  // x, free list
-  constexpr int kRS = (lds_mode == 2) ? mot::kMemLds : mot::kMemGlobal;  // row boxes
-  constexpr int kDS = (lds_mode == 4) ? mot::kMemLds : mot::kMemGlobal;  // shortest-path distances
-  constexpr int kBS = (lds_mode == 2) ? mot::kMemLds : mot::kMemGlobal;  // row bounds (on-the-fly costs only)
-  mot::LapWorkT<kVS, kXS, kDS, kBS> W;
+  // lds_mode 5 = mode 2 + the shortest-path search's arrays (d, pred, cols, inv, tie: 24 B per extended row) in LDS: the launches behind
+  // the fast path, where a handful of problems run and the sub-batch waits for the slowest
+  constexpr bool kFull = lds_mode == 2 || lds_mode == 5;
+  constexpr int kXS = kFull ? mot::kMemLds : mot::kMemGlobal;  // x, free list
+  constexpr int kRS = kFull ? mot::kMemLds : mot::kMemGlobal;  // row boxes
+  constexpr int kDS = (lds_mode == 4 || lds_mode == 5) ? mot::kMemLds : mot::kMemGlobal;  // shortest-path distances
+  constexpr int kBS = kFull ? mot::kMemLds : mot::kMemGlobal;  // row bounds (on-the-fly costs only)
+  constexpr int kCS = (lds_mode == 5) ? mot::kMemLds : mot::kMemGlobal;  // pred, cols, inv, tie
+  mot::LapWorkT<kVS, kXS, kDS, kBS, kCS> W;
   char* lds = smem + kScratch;
   if (fs_lds) {  // the launch reserved the fast scratch: row lists are usable by the tasks that bring the memory for them
     if (T.rowlist != nullptr && T.geom.a == nullptr) { mot::lap_carve_rowlist(W, T.rowlist, nr); W.fsw.p = reinterpret_cast<int*>(lds); }
     lds += kFsLds;
   }
-  if constexpr (lds_mode == 2) { mot::lap_carve_hot(W, lds, n); lds += hot_b; }
+  if constexpr (kFull) { mot::lap_carve_hot(W, lds, n); lds += hot_b; }
   else mot::lap_carve_hot(W, gw, n);
   if constexpr (lds_mode == 3 || lds_mode == 4) {  // lean: only the per-column duals and column->row map in LDS (12 B per extended row)
     W.v.p = reinterpret_cast<double*>(lds);
@@ -168,9 +172,18 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status,
     float* cp = gbox + 5 * nr;
     float* cf = cp + 5 * nc;
     float* rp;
-    if constexpr (lds_mode == 2) {
+    if constexpr (kFull) {
       rp = reinterpret_cast<float*>(lds);
-      W.rlb.p = reinterpret_cast<double*>(lds + ((20 * static_cast<size_t>(nr) + 16 + 15) & ~size_t(15)));  // behind the row boxes (8 B per real row)
+      char* q = lds + ((20 * static_cast<size_t>(nr) + 16 + 15) & ~size_t(15));
+      W.rlb.p = reinterpret_cast<double*>(q);  // behind the row boxes (8 B per real row)
+      if constexpr (lds_mode == 5) {
+        q += (8 * static_cast<size_t>(nr) + 15) & ~size_t(15);
+        W.d.p = reinterpret_cast<double*>(q); q += 8 * static_cast<size_t>(n);
+        W.pred.p = reinterpret_cast<int*>(q); q += 4 * static_cast<size_t>(n);
+        W.cols.p = reinterpret_cast<int*>(q); q += 4 * static_cast<size_t>(n);
+        W.inv.p = reinterpret_cast<int*>(q); q += 4 * static_cast<size_t>(n);
+        W.tie.p = reinterpret_cast<int*>(q);
+      }
     } else rp = gbox;
     const mot_iou_task& G = T.geom;
     for (int i = t; i < nr; i += kThreads) {
@@ -333,6 +346,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
                             X(64, 0, 8, 1) X(64, 2, 8, 1) X(64, 3, 8, 1) X(256, 0, 0, 1) X(256, 2, 0, 1) X(256, 3, 0, 1) \
                             X(512, 0, 0, 1) X(512, 2, 0, 1) X(512, 3, 0, 1) X(512, 4, 0, 1) X(256, 4, 0, 1) \
                             X(64, 0, 4, 0) X(64, 2, 4, 0) X(64, 3, 4, 0) X(64, 0, 8, 0) X(64, 2, 8, 0) X(64, 3, 8, 0) \
+                            X(64, 5, 4, 0) X(64, 5, 8, 0) X(64, 5, 4, 1) X(64, 5, 8, 1) \
                             X(64, 0, 0, 2) X(64, 2, 0, 2) X(64, 3, 0, 2) X(256, 0, 0, 2) X(256, 2, 0, 2) X(256, 3, 0, 2)
   // plain-cost variants exist for the register-cached column layouts only (the hot ones)
   const int flavor = general_assoc ? 2 : ((plain_costs && rpl > 0) ? 0 : 1);
@@ -342,6 +356,12 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   // latency is what the waiting sub-batch pays. MOT_LAP_BEHIND_FULL=0 keeps the lean mode (A/B measurements).
   static const bool behind_full = !(std::getenv("MOT_LAP_BEHIND_FULL") && std::getenv("MOT_LAP_BEHIND_FULL")[0] == '0');
   if (fast && behind_full && flavor == 0 && rpl > 0 && mode == 3 && b2 <= 112 * 1024) { mode = 2; lds = b2; }
+  // ... and, plain or BoT-SORT costs alike, to the all-LDS state when that fits: the search's d / pred / cols / inv / tie next to it
+  // (a sweep of the search is otherwise two or three dependent global round trips; MOT_LAP_BEHIND_ALL=0 switches it off)
+  static const bool behind_all = !(std::getenv("MOT_LAP_BEHIND_ALL") && std::getenv("MOT_LAP_BEHIND_ALL")[0] == '0');
+  const size_t b5 = b2 + 24 * nm + 64;
+  if (fast && behind_full && behind_all && geom && flavor != 2 && rpl > 0 && (mode == 3 || mode == 2) && n * m >= 16384 &&
+      b5 <= static_cast<size_t>(kLdsBudget) - 4096) { mode = 5; lds = b5; }
   static const bool behind_prio = !(std::getenv("MOT_LAP_BEHIND_PRIO") && std::getenv("MOT_LAP_BEHIND_PRIO")[0] == '0');
   std::lock_guard<std::mutex> attr_lock(attr_mu);
   if (!attr_set_dev[dev_slot]) {

@@ -100,7 +100,8 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
 // 12 B of LDS per extended row, so ~8 north-star-sized problems stay resident per CU.
 // lds_mode (compile-time, so every pointer has a static address space — a run-time choice makes the compiler fall back
 // to flat_* instructions for the LDS state, which costs hundreds of cycles per dependent access): 0 = solver state in global scratch, 1 = hot state + column boxes in LDS (row boxes
-// in global scratch), 2 = hot state + column boxes + row boxes in LDS.
+// in global scratch), 2 = hot state + column boxes + row boxes (+ the row bounds) in LDS, 5 = 2 + the shortest-path search's d / pred / cols / inv / tie in
+// LDS (24 B more per extended row: the launches behind the fast path, where per-problem latency is all that counts).
 // second launch bound = wavefronts per SIMD the register allocator must leave room for: the solver is latency-bound per
 // wavefront, throughput comes from co-resident ones (RPL 8: 2, i.e. <= 256 VGPRs; RPL 4: 3, <= 168; else whatever fits)
 constexpr int lap_min_waves(int threads, int rpl, bool general) { return (threads > 64 || general) ? 1 : (rpl >= 8 ? 2 : (rpl >= 4 ? 3 : 4)); }

@@ -379,6 +379,34 @@ def test_lap_fast_path_and_exact_path_agree_with_the_oracle(ctx, orc, n, m):
     assert st["fast"] == 0 and st["not_unique"] == 1, st
 
 
+@pytest.mark.parametrize("n,m", [(1000, 500), (600, 256), (256, 128)])
+def test_lap_tie_heavy_problems_behind_the_fast_path(ctx, orc, n, m):
+    """Problems the certificate must decline (duplicated tracks with detections exactly on them: non-unique optima) go to the exact
+    emulation launched BEHIND the sparse solver — full / all-LDS state (lap_kernel.hip: lds_mode 2 / 5), void real rows in the
+    shortest-path search (lap_core.hpp) — and come out index for index like the oracle's lapjv; mot_lap_behind_stats counts them."""
+    r = np.random.default_rng(7 * n + m)
+    for trial in range(3):
+        a = boxes(r, n, (1920, 1080))
+        ndup = n // 8
+        a[r.permutation(n)[:ndup]] = a[r.integers(0, n, ndup)]  # duplicated tracks
+        src = r.integers(0, n, m)
+        b = (a[src] + r.normal(0, 2.0, (m, 4))).astype(np.float32)
+        b[::2] = a[src[::2]]  # detections exactly on (possibly duplicated) tracks
+        far = r.random(m) < 0.25
+        b[far] += np.float32(5000.0)  # detections with no track near them
+        conf = r.uniform(0.3, 1, m).astype(np.float32)
+        for mode, th in ((L.COST_IOU_DIST, 0.7), (L.COST_IOU_DIST_FUSE, 0.8)):
+            dist = orc.iou_distance(a, b)
+            cost = dist if mode == L.COST_IOU_DIST else orc.fuse_score(dist, conf)
+            xo, yo = orc.linear_assignment(cost, th)
+            ctx.lap_fast_stats(reset=True)
+            ctx.lap_behind_stats(reset=True)
+            xg, yg, _, info = ctx.lap_geom(a, b, th, mode, conf)
+            assert info == 0 and np.array_equal(xg, xo) and np.array_equal(yg, yo), (n, m, trial, mode)
+            st, bh = ctx.lap_fast_stats(), ctx.lap_behind_stats()
+            assert st["fast"] == 0 and bh["problems"] == 1 and bh["slowest_cycles"] > 0, (st, bh)
+
+
 @pytest.mark.parametrize("n,d", [(1, 8), (77, 64), (512, 256), (130, 100)])
 def test_appearance_post_processing_bit_exact(ctx, orc, n, d):
     """mot_feat_update against the oracle's restatement of BotSTrack's feature handling (botsort.cpp:38-46 set +

@@ -96,8 +96,8 @@ struct LapWorkT {
   MemPtr<int, CS> pred;   // path predecessors (CS: LDS in the all-LDS mode of the launches behind the fast path — every sweep of the
                           // shortest-path search reads inv[] / d[] and a member costs a cols[] -> d[] chain: global round trips otherwise)
   MemPtr<int, CS> cols;   // lapjv's column permutation / phase-1 unique-row list
-  MemPtr<int, kMemGlobal> tmp;    // tie flags (slow path)
-  MemPtr<int, kMemGlobal> lst;    // compacted tie positions (slow path)
+  MemPtr<int, CS> tmp;    // tie flags (slow path)
+  MemPtr<int, CS> lst;    // compacted tie positions (slow path)
   MemPtr<double, BS> rlb; // per real row: lower bound of its reduced costs over the real columns, see "hopeless rows" (read and written by every
                           // serial round of the row reduction: LDS with the full LDS state — a global round trip per round is what a round then costs)
   MemPtr<int, CS> inv;    // inverse of cols[] (position of a column), slow path

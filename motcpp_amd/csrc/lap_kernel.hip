@@ -100,15 +100,17 @@ __device__ __forceinline__ int gate_and_solve(mot::DevGroup& g, const Cost& C, c
 // 12 B of LDS per extended row, so ~8 north-star-sized problems stay resident per CU.
 // lds_mode (compile-time, so every pointer has a static address space — a run-time choice makes the compiler fall back
 // to flat_* instructions for the LDS state, which costs hundreds of cycles per dependent access): 0 = solver state in global scratch, 1 = hot state + column boxes in LDS (row boxes
-// in global scratch), 2 = hot state + column boxes + row boxes (+ the row bounds) in LDS, 5 = 2 + the shortest-path search's d / pred / cols / inv / tie in
-// LDS (24 B more per extended row: the launches behind the fast path, where per-problem latency is all that counts).
+// in global scratch), 2 = hot state + column boxes + row boxes (+ the row bounds) in LDS, 5 = 2 + the shortest-path search's d / pred / cols / inv / tie / tmp / lst in
+// LDS (32 B more per extended row: the launches behind the fast path, where per-problem latency is all that counts).
 // second launch bound = wavefronts per SIMD the register allocator must leave room for: the solver is latency-bound per
 // wavefront, throughput comes from co-resident ones (RPL 8: 2, i.e. <= 256 VGPRs; RPL 4: 3, <= 168; else whatever fits)
 constexpr int lap_min_waves(int threads, int rpl, bool general) { return (threads > 64 || general) ? 1 : (rpl >= 8 ? 2 : (rpl >= 4 ? 3 : 4)); }
 // FLAVOR of the on-the-fly cost: 0 plain IoU modes only, 1 + BoT-SORT's gated appearance term, 2 every association measure
 // Diagnostics of the problems solved BEHIND the fast path (the ones the sparse solver declined): per-block scratch for lap_solve's
 // cycle / event counters (mot_lap_task.prof layout, 36 entries), summed into g_behind[0] ([39] = problems), the slowest problem's
-// own counters kept in g_behind[1] ([39] = its cycles). Read by mot_lap_behind_stats.
+// own counters kept in g_behind[1] ([39] = its cycles). Read by mot_lap_behind_stats. Diagnostics only: launches of different HIP streams
+// that run at the same time share the scratch rows (a block's counters can be mixed with another launch's in that rare overlap; nothing
+// the solver computes depends on them).
 __device__ long long g_behind_scr[512][36];
 __device__ long long g_behind[2][40];
 template <int kThreads, int lds_mode, int RPL, int FLAVOR>
@@ -139,7 +141,7 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status,
   char* gw = static_cast<char*>(T.work);
   const size_t hot_b = (mot::lap_hot_bytes(n) + 15) & ~size_t(15), cold_b = (mot::lap_cold_bytes(n) + 15) & ~size_t(15);
   constexpr int kVS = (lds_mode == 0) ? mot::kMemGlobal : mot::kMemLds;  // v, y
-  // lds_mode 5 = mode 2 + the shortest-path search's arrays (d, pred, cols, inv, tie: 24 B per extended row) in LDS: the launches behind
+  // lds_mode 5 = mode 2 + the shortest-path search's arrays (d, pred, cols, inv, tie, tmp, lst: 32 B per extended row) in LDS: the launches behind
   // the fast path, where a handful of problems run and the sub-batch waits for the slowest
   constexpr bool kFull = lds_mode == 2 || lds_mode == 5;
   constexpr int kXS = kFull ? mot::kMemLds : mot::kMemGlobal;  // x, free list
@@ -183,7 +185,9 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status,
         W.pred.p = reinterpret_cast<int*>(q); q += 4 * static_cast<size_t>(n);
         W.cols.p = reinterpret_cast<int*>(q); q += 4 * static_cast<size_t>(n);
         W.inv.p = reinterpret_cast<int*>(q); q += 4 * static_cast<size_t>(n);
-        W.tie.p = reinterpret_cast<int*>(q);
+        W.tie.p = reinterpret_cast<int*>(q); q += 4 * static_cast<size_t>(n);
+        W.tmp.p = reinterpret_cast<int*>(q); q += 4 * static_cast<size_t>(n);  // (_find_dense's record flags and compacted positions: a store
+        W.lst.p = reinterpret_cast<int*>(q);                                    //  followed by a dependent load, several times per call)
       }
     } else rp = gbox;
     const mot_iou_task& G = T.geom;
@@ -360,7 +364,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   // ... and, plain or BoT-SORT costs alike, to the all-LDS state when that fits: the search's d / pred / cols / inv / tie next to it
   // (a sweep of the search is otherwise two or three dependent global round trips; MOT_LAP_BEHIND_ALL=0 switches it off)
   static const bool behind_all = !(std::getenv("MOT_LAP_BEHIND_ALL") && std::getenv("MOT_LAP_BEHIND_ALL")[0] == '0');
-  const size_t b5 = b2 + 24 * nm + 64;
+  const size_t b5 = b2 + 32 * nm + 64;
   if (fast && behind_full && behind_all && geom && flavor != 2 && rpl > 0 && (mode == 3 || mode == 2) && n * m >= 16384 &&
       b5 <= static_cast<size_t>(kLdsBudget) - 4096) { mode = 5; lds = b5; }
   static const bool behind_prio = !(std::getenv("MOT_LAP_BEHIND_PRIO") && std::getenv("MOT_LAP_BEHIND_PRIO")[0] == '0');

@@ -179,7 +179,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     tracker, P, M, D, desc = WORKLOADS[args.workload]
-    S = args.streams or {"C2": 12288, "SORT": 12288, "NS": 6144, "C5": 6144, "C3": 1536, "C4": 256}[args.workload]
+    S = args.streams or {"C2": 12288, "SORT": 12288, "NS": 6144, "C5": 6144, "C3": 1536, "C4": 768}[args.workload]
     # host workers block between phases, so about twice as many workers as the box's CPU quota pay off (the bursts of
     # lifecycle work get shorter and the workers sleep through the GPU waits); far more than that and the cgroup
     # throttles the whole process (measured on the 16-CPU-quota GPU boxes: 32 workers 456k frames/s, 64 workers 268k)
@@ -216,7 +216,7 @@ def main():
     frame_bytes = S * 6 * M * 4
 
     if args.pipeline <= 0:
-        args.pipeline = {"C2": 3, "SORT": 3, "NS": 3, "C5": 3, "C3": 3}.get(args.workload, 2)  # measured on MI355X
+        args.pipeline = {"C2": 3, "SORT": 3, "NS": 3, "C5": 3, "C3": 3, "C4": 6}.get(args.workload, 2)  # measured on MI355X
     PIPE = max(1, min(args.pipeline, S))
     bounds = [S * p // PIPE for p in range(PIPE + 1)]
     on_device = tracker in ("bytetrack", "sort", "botsort", "ocsort") and args.lifecycle in ("auto", "device")
@@ -348,6 +348,42 @@ def main():
         return got
 
     in_flight = args.in_flight and packed and not heavy  # (round 3: mot_sort_* and mot_oc_* have enqueue / collect as well; C4 is one long kernel per frame: nothing to overlap)
+    # C4 (round 5): a frame of a sub-batch is ONE launch of the exact assignment kernel that lasts as long as its slowest problem (one problem per CU,
+    # 0.25 - 0.36 s each): stepped in lockstep, every CU that finished early idled until the slowest problem of ALL sub-batches was done. Each sub-batch's
+    # driver thread now steps its own frames without waiting for the others (still one frame at a time per stream, K frames each inside the timed
+    # region), with more streams than CUs queued: a CU that finishes a problem takes the next one of whichever sub-batch has one waiting.
+    free_running = heavy and packed and pools is not None and world == 1
+
+    def sample_rows_sub(p):
+        got = {}
+        offs = np.concatenate(([0], np.cumsum(cnt_all[bounds[p]:bounds[p + 1]])))
+        for sid, q in zip(parity_ids, parity_sub):
+            if q == p:
+                off = int(offs[sid - bounds[p]])
+                got[sid] = rows_p[p][off:off + cnt_all[sid]].copy()
+        return got
+
+    def run_free(f0, n, keep_limit, marks):
+        """frames f0 .. f0+n-1 of every sub-batch, each on its own driver thread at its own pace; returns when all are done"""
+        kept_p = [[] for _ in range(PIPE)]
+        marks_p = [[] for _ in range(PIPE)]
+
+        def drive(p):
+            for k in range(n):
+                sub_step(p, f0 + k)
+                marks_p[p].append(time.perf_counter())
+                if rank == 0 and k < keep_limit:
+                    kept_p[p].append(sample_rows_sub(p))
+        for fut in [pools[p].submit(drive, p) for p in range(PIPE)]:
+            fut.result()
+        for k in range(min(n, keep_limit) if rank == 0 else 0):
+            merged = {}
+            for p in range(PIPE):
+                merged.update(kept_p[p][k])
+            kept.append(merged)
+        if marks is not None:
+            for k in range(n):  # a step is complete when its frame is done in every sub-batch
+                marks.append(max(marks_p[p][k] for p in range(PIPE)))
 
     def run_pipelined(f0, n, keep_limit):
         """frames f0 .. f0+n-1 with two frames in flight per sub-batch, one host thread; returns when the last one is collected"""
@@ -382,6 +418,9 @@ def main():
     if in_flight:
         run_pipelined(0, W, 40)
         out, cnt = None, cnt_all
+    elif free_running:
+        run_free(0, W, 40, None)
+        out, cnt = None, cnt_all
     else:
         for f in range(W):
             out, cnt = step(f)
@@ -402,6 +441,8 @@ def main():
     t0 = time.perf_counter()
     if in_flight:
         run_pipelined(W, K, 8)
+    elif free_running:
+        run_free(W, K, 8, step_marks)
     else:
         for k in range(K):
             out, cnt = step(W + k)
@@ -544,6 +585,7 @@ def main():
         isolated["note"] = f"{ISO} steps after the timed region with the sub-batches stepped one after the other (no time-sharing)"
     # ---- long_run: many more steps on the same trackers (does the rate depend on the age of the run?) ----
     long_run = None
+    lr_state = None
     LR = args.long_run_steps if args.long_run_steps is not None else (0 if heavy else 300)
     if LR > 0 and on_device and world == 1 and F - Z >= 8:
         cur, lo_f, hi_f = W + K + H + ISO - 1, Z, F - 1
@@ -553,6 +595,7 @@ def main():
                 step_dir = -step_dir
             f += step_dir
             seq.append(f)
+        lr_state = (f, step_dir)  # (outputs_resident goes on from here)
 
         def enq_lr(f):
             for p in range(PIPE):
@@ -597,7 +640,16 @@ def main():
     outputs_resident = None
     if in_flight and on_device and world == 1 and not heavy and F - Z >= 8:
         nres = min(60, LR if LR > 0 else 60)
-        fr = [Z + (k % (F - Z)) for k in range(nres)]
+        # the same back-and-forth playback as long_run, continued from the frame the trackers stand at. (Round 4 played the frames Z, Z+1, ..., F-1,
+        # Z, ... here: every wrap-around teleported all objects - a frame of births, lost tracks and declined assignments - and the leg
+        # measured 1.2 M against 2.27 M frames/s for that reason alone, not because the tables stayed on the device.)
+        f, step_dir = lr_state if long_run is not None else (W + K + H + ISO - 1, -1)
+        fr = []
+        while len(fr) < nres:
+            if not Z <= f + step_dir <= F - 1:
+                step_dir = -step_dir
+            f += step_dir
+            fr.append(f)
 
         def enq_r(f):
             for p in range(PIPE):
@@ -886,6 +938,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "tracker": tracker, "tracks": P, "dets_per_frame": M, "emb_dim": D,
                    "streams_per_gpu": S, "frames_per_step": world * S, "settle_frames": Z, "host_threads": ((1 if in_flight else PIPE) if on_device else threads), "sub_batches": PIPE, "frames_in_flight": 2 if in_flight else 1,
+                   "sub_batch_stepping": ("free-running: every sub-batch's driver thread steps its own K frames, no barrier between sub-batches inside the timed region"
+                                          if free_running else "lockstep"),
                    "lifecycle": "device (mot_bt_* / mot_sort_* / mot_bot_* / mot_oc_*: a fixed launch sequence per frame, no host decisions)" if on_device else "host stage machines",
                    "parallelism": f"{world} GPU(s) x {S} independent streams, lockstep stages",
                    "ranks": world, "rank_launcher": "torch.distributed.run (bench.py --gpus N starts it itself when no launcher set RANK)",

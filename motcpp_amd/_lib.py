@@ -11,6 +11,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBDIR = os.path.join(HERE, "lib")
 HIP_LIB = os.path.join(LIBDIR, "libmotcpp_hip.so")
+# diagnostics only (tools/): a differently instrumented build of the SAME sources, e.g. lib/libmotcpp_hip_fineprof.so (-DMOT_LAP_FINE_PROF)
+if os.environ.get("MOTCPP_HIP_LIB_DIAG"):
+    HIP_LIB = os.path.join(LIBDIR, os.path.basename(os.environ["MOTCPP_HIP_LIB_DIAG"]))
 HOST_LIB = os.path.join(LIBDIR, "libmotcpp.so")
 
 KF_XYSR, KF_XYAH, KF_XYWH = 0, 1, 2

@@ -55,6 +55,9 @@ struct DevGroup {
   // waits for every outstanding memory operation — a global round trip whenever a store or a prefetch is pending). The data
   // handed from lane to lane across such a barrier must live in LDS.
   __device__ __forceinline__ void sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  // waits for the wavefront's own outstanding global loads AND stores (a store counts until the L2 has it): what a later LDS-only barrier
+  // needs in front of it when another wavefront is going to overwrite the same global address
+  __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   // while set, the barriers INSIDE the reductions / scans below (which exchange their partials through LDS) are of that kind too
   bool lds_only_ = false;
   __device__ __forceinline__ void lds_barriers(bool on) { lds_only_ = on; }

@@ -535,20 +535,24 @@ void PooledStream::update_many(PooledStream* const* streams, const PooledFrame* 
       throw;
     }
   }
-  // one round per segment involved (objects with the same parameters and level share one)
+  // one round per segment involved (objects with the same parameters and level share one). A group's rows are taken out of its round's
+  // table RIGHT AFTER its join, before the next segment is joined: a thread that held untaken rows of one segment while it waited in another
+  // could, with a second thread visiting the two segments in the opposite order, stop both segments' leaders for good (each waits for the
+  // previous round's table to be released: Segment::lead, outstanding_[r & 1]).
   std::vector<Request*> group;
+  std::vector<int> members;
   std::string first_error;
   for (int i = 0; i < k; ++i) {
     if (seen[i]) continue;
     group.clear();
+    members.clear();
     for (int j = i; j < k; ++j)
-      if (!seen[j] && streams[j]->seg_ == streams[i]->seg_) { seen[j] = 1; group.push_back(&reqs[j]); }
+      if (!seen[j] && streams[j]->seg_ == streams[i]->seg_) { seen[j] = 1; group.push_back(&reqs[j]); members.push_back(j); }
     streams[i]->seg_->join(group.data(), static_cast<int>(group.size()));
-  }
-  for (int i = 0; i < k; ++i) {
-    if (seen[i] == 2) continue;
-    try { counts[i] = streams[i]->finish(&reqs[i], &rows[i]); }
-    catch (const std::exception& e) { if (first_error.empty()) first_error = e.what(); counts[i] = 0; rows[i] = nullptr; }
+    for (int j : members) {
+      try { counts[j] = streams[j]->finish(&reqs[j], &rows[j]); }
+      catch (const std::exception& e) { if (first_error.empty()) first_error = e.what(); counts[j] = 0; rows[j] = nullptr; }
+    }
   }
   if (!first_error.empty()) throw Error(first_error);
 }

@@ -83,24 +83,28 @@ struct LapDims {
 // Workspace, each array n = nr + nc long. The HOT arrays are touched by every row pass and live in LDS when
 // the problem fits; the COLD arrays are only used by the general shortest-path search (rare on tracking costs)
 // and the phase-1 row list, and always live in global scratch.
-// VS = address space of v/y, XS = of x/fr, DS = of d (mem.hpp); the other cold arrays are always global.
-template <int VS, int XS, int DS = kMemGlobal, int BS = kMemGlobal, int CS = kMemGlobal>
+// VS = address space of v/y, XS = of x/fr, DS = of d (mem.hpp); KS = of cols/inv (round 5: LDS for the wide matrix problems), IT = element
+// type of y/cols/inv (short there: 2 B per extended row, n <= kFsMaxN), NS = of the byte-sized list lengths, YS = of the matched costs; the
+// other cold arrays are always global.
+template <int VS, int XS, int DS = kMemGlobal, int BS = kMemGlobal, int CS = kMemGlobal, int KS = CS, class IT = int, int NS = kMemGlobal, int YS = kMemGlobal>
 struct LapWorkT {
+  using idx_t = IT;
+  static constexpr int kColsSpace = KS;
   // hot
   MemPtr<double, VS> v;   // column duals
   MemPtr<int, XS> x;      // row -> col (extended)
-  MemPtr<int, VS> y;      // col -> row (extended)
+  MemPtr<IT, VS> y;       // col -> row (extended)
   MemPtr<int, XS> fr;     // free-row list (doubles as the column-hit counter in phase 1)
   // cold
   MemPtr<double, DS> d;           // shortest-path distances (LDS for the wide matrix problems: every scan step reads and writes them)
   MemPtr<int, CS> pred;   // path predecessors (CS: LDS in the all-LDS mode of the launches behind the fast path — every sweep of the
                           // shortest-path search reads inv[] / d[] and a member costs a cols[] -> d[] chain: global round trips otherwise)
-  MemPtr<int, CS> cols;   // lapjv's column permutation / phase-1 unique-row list
+  MemPtr<IT, KS> cols;    // lapjv's column permutation / phase-1 unique-row list
   MemPtr<int, CS> tmp;    // tie flags (slow path)
   MemPtr<int, CS> lst;    // compacted tie positions (slow path)
   MemPtr<double, BS> rlb; // per real row: lower bound of its reduced costs over the real columns, see "hopeless rows" (read and written by every
                           // serial round of the row reduction: LDS with the full LDS state — a global round trip per round is what a round then costs)
-  MemPtr<int, CS> inv;    // inverse of cols[] (position of a column), slow path
+  MemPtr<IT, KS> inv;     // inverse of cols[] (position of a column), slow path
   MemPtr<int, CS> tie;    // tie flags by position during a scan (all zero between scans), slow path
   MemPtr<int, kMemGlobal> sa, sb, sc;  // staging of the closed-form tie runs that do not fit in registers (slow path)
   MemPtr<float, kMemGlobal> rmin; // per real row: minimum RAW cost over the real columns (phase 1, register-cached on-the-fly costs), see "void real rows"
@@ -108,6 +112,10 @@ struct LapWorkT {
   MemPtr<int, kMemGlobal> rl_cnt;     // [nr] entries of real row i with cost < half (may exceed kRlCap: then the row has no usable list)
   MemPtr<unsigned long long, kMemGlobal> rl_ent;  // [nr][kRlCap] their (column | cost bits << 32): one 8-byte load per entry, a row's first 16 entries in one 128-byte line
   MemPtr<int, VS == kMemAny ? kMemAny : kMemLds> fsw;  // kFsWsInts ints of fast scratch (always LDS on the device): step members + tie events
+  // optional (round 5, with the row lists): what the scan steps would otherwise fetch from global memory per member and per tie event
+  MemPtr<unsigned char, NS> rl_n;  // [nr] min(rl_cnt, 255), filled after phase 1
+  MemPtr<float, YS> ycost;         // [nc] cost(y[j], j) while real column j is held by a real row (a random read of the N x M matrix otherwise: one
+                                   // 128-byte line of a 32 MB matrix per member — what evicted a problem's working set from its XCD's L2)
   bool cyc_ext = false;      // cyc has 36 entries: [16..23] cycles inside phase 3 (step classification, dry run, apply, event sort, event replay, _find_dense, one-at-a-time sweeps, search set-up)
   long long* cyc = nullptr;  // optional profiling [16]: [0..3] cycles in phase 1a (column minima), 1b (transfer), 2, 3; [4..7] n_uniq, serial row-reduction rounds, serial augmentations, n;
                              // [8..15] shortest-path scans: parallel steps, members they consumed, real rows among them, tie events, one-at-a-time sweeps, steps refused (rounding), _find_dense calls, row lists in use
@@ -117,15 +125,19 @@ MOT_HD size_t lap_hot_bytes(int n) { return static_cast<size_t>(n) * (sizeof(dou
 MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 9 * sizeof(int) + sizeof(float)); }
 // Row lists (optional scratch of a matrix-cost task, mot_lap_task.rowlist): per real row the entries below thresh/2.
 constexpr int kRlCap = 64;      // entries kept per row (a row with more has no list: its sweeps stay dense)
-constexpr int kFsIter = 8;      // list entries a lane holds in registers during a parallel scan step
-constexpr int kFsMaxMembers = 64;   // real-row members of one step (also bounded by kFsIter * T / kRlCap)
+constexpr int kFsIter = 4;      // list entries a lane holds in registers during a parallel scan step
+constexpr int kFsCls = 1;       // SCAN members a lane classifies per step (measured on an OC-SORT 4096 x 2048 problem: 4 per lane, 16 % fewer steps,
+                                // each of them so much longer that the solve took 13 % more cycles — a step's cost is its critical path, and that grew)
+constexpr int kFsUnit = 16;     // the lists are dealt to the lanes in units of this many entries (kRlCap / kFsUnit <= 4 units per row)
+constexpr int kFsMaxUnits = 256;    // units of one step (also bounded by kFsIter * T / kFsUnit)
+constexpr int kFsMaxMembers = 256;  // real-row members of one step (each takes at least one unit)
 constexpr int kEvCap = 256;     // tie events one step may produce (more: the step shrinks to one member)
 constexpr int kKeepCap = 512;   // relaxations of one step that lower a distance (more: the step shrinks to one member)
 constexpr int kFsHash = 1024;   // slots of the per-step column table (>= 2 * kKeepCap, a power of two)
 constexpr int kFsMaxN = 8192;   // extended size up to which the TODO bitmask fits
-// fast scratch (ints): members (q, row, list length, h as 2 ints) | counters | column table of a step (key, earliest member) |
+// fast scratch (ints): members (q, row, h as 2 ints) | units (row, rank + chunk + list length) | counters | column table of a step (key, earliest member) |
 // event list (q, j, k, row, cost, list length) | sorted events (q, j, k, flags, row, cost, list length) + head slots (column, event) | TODO bitmask
-constexpr int kFsM = 0, kFsCtr = 5 * kFsMaxMembers, kFsKeep = kFsCtr + 8, kFsEvl = kFsKeep + 2 * kFsHash, kFsEvs = kFsEvl + 6 * kEvCap,
+constexpr int kFsM = 0, kFsUnits = 4 * kFsMaxMembers, kFsCtr = kFsUnits + 2 * kFsMaxUnits, kFsKeep = kFsCtr + 8, kFsEvl = kFsKeep + 2 * kFsHash, kFsEvs = kFsEvl + 6 * kEvCap,
               kFsTodo = kFsEvs + 9 * kEvCap, kFsWsInts = kFsTodo + kFsMaxN / 32 + 8;
 MOT_HD unsigned long long rl_pack(int col, float cost) {
   return static_cast<unsigned long long>(static_cast<unsigned>(col)) | (static_cast<unsigned long long>(__builtin_bit_cast(unsigned, cost)) << 32);
@@ -145,7 +157,7 @@ MOT_HD void lap_carve_hot(Work& w, void* base, int n) {
   char* p = static_cast<char*>(base);
   w.v.p = reinterpret_cast<double*>(p); p += sizeof(double) * n;
   w.x.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
-  w.y.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.y.p = reinterpret_cast<decltype(w.y.p)>(p); p += sizeof(int) * n;  // (an int's room per entry whatever the element type)
   w.fr.p = reinterpret_cast<int*>(p);
 }
 template <class Work>
@@ -154,10 +166,10 @@ MOT_HD void lap_carve_cold(Work& w, void* base, int n) {
   w.d.p = reinterpret_cast<double*>(p); p += sizeof(double) * n;
   w.rlb.p = reinterpret_cast<double*>(p); p += sizeof(double) * n;
   w.pred.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
-  w.cols.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.cols.p = reinterpret_cast<decltype(w.cols.p)>(p); p += sizeof(int) * n;
   w.tmp.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.lst.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
-  w.inv.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
+  w.inv.p = reinterpret_cast<decltype(w.inv.p)>(p); p += sizeof(int) * n;
   w.tie.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.sa.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
   w.sb.p = reinterpret_cast<int*>(p); p += sizeof(int) * n;
@@ -398,7 +410,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
   // Row lists (matrix costs with the optional scratch): per real row the entries with cost < half, gathered by the column
   // sweep below. The shortest-path search uses them for exact sparse sweeps of real rows (see the scan of phase 3).
   const bool use_rl = is_matrix_cost<Cost>::value && W.rl_cnt.p != nullptr && W.fsw.p != nullptr && half > -1e300 && half < 1e300 &&
-                      T * kFsIter >= kRlCap && n <= kFsMaxN;
+                      T * kFsIter >= kFsUnit && n <= kFsMaxN;
   for (int i = t; i < n; i += T) { W.x[i] = -1; W.fr[i] = 0; }
   if (use_rl) for (int i = t; i < nr; i += T) W.rl_cnt[i] = 0;
   g.sync();
@@ -521,6 +533,10 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
   }
   g.sync();
   long long c1 = MOT_CLOCK();
+  const bool have_rn = use_rl && W.rl_n.p != nullptr;   // list lengths as bytes next to the solver state (LDS)
+  const bool have_yc = use_rl && W.ycost.p != nullptr;  // the cost of every real column's matched pair, kept current from phase 3 on
+  if (have_rn) for (int i = t; i < nr; i += T) { const int c = W.rl_cnt[i]; W.rl_n[i] = static_cast<unsigned char>(c > 255 ? 255 : c); }
+  auto rl_len = [&](int i) -> int { return have_rn ? static_cast<int>(W.rl_n[i]) : static_cast<int>(W.rl_cnt[i]); };
   for (int j = t; j < n; j += T)
     if (W.x[W.y[j]] != j) W.y[j] = -1;
   g.sync();
@@ -736,6 +752,15 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
     nfree = new_free;
   }
 
+  if (have_yc) {  // (uniform) from here on y[] changes in three places only, each of which keeps this current
+    for (int j = t; j < nc; j += T) {
+      const int i = W.y[j];
+      if (i >= 0 && i < nr) W.ycost[j] = static_cast<float>(C.at(i, j));
+    }
+    g.sync();
+  }
+  // cost of real column j's matched pair (i = y[j], a real row)
+  auto match_cost = [&](int i, int j) -> double { return have_yc ? static_cast<double>(static_cast<float>(W.ycost[j])) : C.at(i, j); };
   long long c3 = MOT_CLOCK();
   // ---- phase 3: augmentation (_ca_dense, :195-211) ----
   bool da_valid = false;  // dummy-start cache: valid while no dual has changed (single-step paths never change duals)
@@ -1192,6 +1217,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           // handed out with v_readlane: the dependent cols[] -> y[] -> d[] loads (global memory for the wide problems) are
           // paid once per 64 members instead of once per sweep. Members that join the set later are picked up by the next fill.
           constexpr bool kWin = has_wave_table<G>::value;
+          constexpr bool kColsLds = std::remove_reference_t<decltype(W)>::kColsSpace == kMemLds;
           int win_j = 0, win_i = 0;
           double win_d = 0.0;
           unsigned win_base = 0, win_cnt = 0;
@@ -1247,9 +1273,10 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           // the positions of tie columns, the stores to cols[] / inv[] / pred[] — overlap instead of costing a round trip each;
           // ONE full barrier per step makes the previous step's stores visible. The members a step appends are classified by
           // the next step from the event table (row, cost and list length were fetched with the event), not from memory.
-          const int fs_members = use_rl ? ((((kFsIter * T) / kRlCap) < kFsMaxMembers) ? (kFsIter * T) / kRlCap : kFsMaxMembers) : 0;
-          bool fast_ok = fs_members > 0;
-          constexpr int kMQ = kFsM, kMROW = kFsM + kFsMaxMembers, kMCNT = kFsM + 2 * kFsMaxMembers, kMH = kFsM + 3 * kFsMaxMembers;
+          // units of list entries one step holds (kFsIter passes of T lanes, kFsUnit entries per unit); a row is steppable when its units fit
+          const int units_cap = use_rl ? ((((kFsIter * T) / kFsUnit) < kFsMaxUnits) ? (kFsIter * T) / kFsUnit : kFsMaxUnits) : 0;
+          bool fast_ok = units_cap > 0;
+          constexpr int kMQ = kFsM, kMROW = kFsM + kFsMaxMembers, kMH = kFsM + 2 * kFsMaxMembers, kUROW = kFsUnits, kUINF = kFsUnits + kFsMaxUnits;
           constexpr int kCEV = kFsCtr, kCDONE = kFsCtr + 2, kCSINK = kFsCtr + 3;
           constexpr int kHK = kFsKeep, kHQ = kFsKeep + kFsHash;
           constexpr int kEQ = kFsEvl, kEJ = kFsEvl + kEvCap, kEK = kFsEvl + 2 * kEvCap, kEI = kFsEvl + 3 * kEvCap, kEC = kFsEvl + 4 * kEvCap, kEN = kFsEvl + 5 * kEvCap;
@@ -1260,155 +1287,204 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           bool stepped = false;            // a step ran in this SCAN set (its stores need a full barrier before anyone else reads them)
           auto fast_step_body = [&](double mind_b) -> int {  // 0: nothing done, 1: members consumed, 2: a sink was reached (final_j set)
             const long long q0 = MOT_FCLOCK();
-            if (need_full) { g.sync(); need_full = false; }
-            const unsigned idx = slo + static_cast<unsigned>(t);
-            int cls = 0, mi = -1, mcnt = 0;  // 0 stop, 1 void dummy row, 2 real row with a list
-            double hh = 0.0;
-            if (idx < shi) {
-              const unsigned qi = idx - qpos;
-              int mj;
-              double md, cij = half;
-              if (qi < qlen) {  // appended by the last step: d == mind by construction
-                mj = W.fsw[kSJ + qi]; mi = W.fsw[kSI + qi]; md = mind_b;
-                mcnt = W.fsw[kSN + qi];
-                if (mi < nr && mj < nc) cij = static_cast<double>(__builtin_bit_cast(float, static_cast<int>(W.fsw[kSC + qi])));
-              } else {
-                mj = W.cols[idx];
-                mi = W.y[mj];
-                md = W.d[mj];
-                if (mi < nr) {
-                  mcnt = W.rl_cnt[mi];
-                  if (mj < nc) cij = C.at(mi, mj);
-                }
-              }
-              if (md == mind_b) {
-                if (mi >= nr) {
-                  hh = ((mj < nc) ? half : 0.0) - W.v[mj] - md;
-                  if (hh <= hmax_dummy_row) cls = 1;
+            if (need_full) { if constexpr (kColsLds) g.sync_lds(); else g.sync(); need_full = false; }
+            // every lane classifies kFsCls consecutive members (round 5: one member per lane made a step end after T members — two steps in
+            // three of an OC-SORT 4096 x 2048 problem, whose SCAN sets hold thousands of dummy rows that need nothing but this look)
+            int cls[kFsCls], mi[kFsCls], mcnt[kFsCls];  // cls: 0 stop, 1 void dummy row, 2 real row with a list
+            double hh[kFsCls];
+            int lane_stop = kNoIdx;
+#pragma unroll
+            for (int c = 0; c < kFsCls; ++c) {
+              cls[c] = 0; mi[c] = -1; mcnt[c] = 0; hh[c] = 0.0;
+              const unsigned idx = slo + static_cast<unsigned>(kFsCls * t + c);
+              if (idx < shi) {
+                const unsigned qi = idx - qpos;
+                int mj;
+                double md, cij = half;
+                if (qi < qlen) {  // appended by the last step: d == mind by construction
+                  mj = W.fsw[kSJ + qi]; mi[c] = W.fsw[kSI + qi]; md = mind_b;
+                  mcnt[c] = W.fsw[kSN + qi];
+                  if (mi[c] < nr && mj < nc) cij = static_cast<double>(__builtin_bit_cast(float, static_cast<int>(W.fsw[kSC + qi])));
                 } else {
-                  hh = cij - W.v[mj] - md;
-                  if (hh <= hmax_dummy_row && hh <= hmax_real_row && mcnt <= kRlCap) cls = 2;
+                  mj = W.cols[idx];
+                  mi[c] = W.y[mj];
+                  md = W.d[mj];
+                  if (mi[c] < nr) {
+                    mcnt[c] = rl_len(mi[c]);
+                    if (mj < nc) cij = match_cost(mi[c], mj);
+                  }
+                }
+                if (md == mind_b) {
+                  if (mi[c] >= nr) {
+                    hh[c] = ((mj < nc) ? half : 0.0) - W.v[mj] - md;
+                    if (hh[c] <= hmax_dummy_row) cls[c] = 1;
+                  } else {
+                    hh[c] = cij - W.v[mj] - md;
+                    if (hh[c] <= hmax_dummy_row && hh[c] <= hmax_real_row && mcnt[c] <= kRlCap && mcnt[c] <= units_cap * kFsUnit) cls[c] = 2;
+                  }
                 }
               }
+              if (cls[c] == 0 && lane_stop == kNoIdx) lane_stop = kFsCls * t + c;
             }
             const long long qa = MOT_FCLOCK();
             cy_sub[0] += qa - q0;
-            int cnt = g.reduce_min_int((cls == 0) ? t : kNoIdx);
-            const int avail = (shi - slo < static_cast<unsigned>(T)) ? static_cast<int>(shi - slo) : T;
+            int cnt = g.reduce_min_int(lane_stop);
+            const int avail = (shi - slo < static_cast<unsigned>(kFsCls * T)) ? static_cast<int>(shi - slo) : kFsCls * T;
             if (cnt > avail) cnt = avail;
             if (cnt == 0) { cy_cls += MOT_FCLOCK() - q0; return 0; }
-            const bool sp = t < cnt && cls == 2 && mcnt > 0;  // (a real row without entries below half relaxes nothing)
-            int ns;
-            const int rank = g.flag_rank(sp, &ns);
-            if (ns > fs_members) {  // the step ends in front of the member of rank fs_members
-              cnt = g.reduce_min_int((sp && rank == fs_members) ? t : kNoIdx);
-              ns = fs_members;
+            // Real rows with a list take part in the step through their list entries, dealt to the lanes in UNITS of kFsUnit entries (a row of
+            // mcnt entries takes ceil(mcnt / kFsUnit) units; round 5 — a row used to reserve kRlCap slots whatever its length, so that a
+            // step of 512 lanes held 64 rows with nine slots in ten empty): one prefix sum gives every such member its rank and its first unit.
+            bool sp[kFsCls];  // (a real row without entries below half relaxes nothing)
+            int nu[kFsCls], rank[kFsCls], ubase[kFsCls];
+            int lane_pack = 0;
+#pragma unroll
+            for (int c = 0; c < kFsCls; ++c) {
+              sp[c] = kFsCls * t + c < cnt && cls[c] == 2 && mcnt[c] > 0;
+              nu[c] = sp[c] ? ((mcnt[c] + kFsUnit - 1) / kFsUnit) : 0;
+              lane_pack += sp[c] ? (1 | (nu[c] << 12)) : 0;
+            }
+            int tot;
+            int run = g.exclusive_scan(lane_pack, &tot);
+#pragma unroll
+            for (int c = 0; c < kFsCls; ++c) {
+              rank[c] = run & 0xfff; ubase[c] = run >> 12;
+              run += sp[c] ? (1 | (nu[c] << 12)) : 0;
+            }
+            int ns = tot & 0xfff, U = tot >> 12;
+            if (U > units_cap) {  // the step ends in front of the first member whose units do not fit any more (a prefix property: unit offsets only grow)
+              int lane_key = kNoIdx;
+#pragma unroll
+              for (int c = kFsCls - 1; c >= 0; --c)
+                if (sp[c] && ubase[c] + nu[c] > units_cap) lane_key = ((kFsCls * t + c) << 20) | (rank[c] << 11) | ubase[c];
+              const int key = g.reduce_min_int(lane_key);
+              cnt = key >> 20; ns = (key >> 11) & 0x1ff; U = key & 0x7ff;
             }
             if (ns == 0) { slo += static_cast<unsigned>(cnt); ++n_fs_steps; n_fs_members += cnt; cy_cls += MOT_FCLOCK() - q0; return 1; }
-            if (sp && rank < ns) {
-              const long long hb = __builtin_bit_cast(long long, hh);
-              W.fsw[kMQ + rank] = t;
-              W.fsw[kMROW + rank] = mi;
-              W.fsw[kMCNT + rank] = mcnt;
-              W.fsw[kMH + 2 * rank] = static_cast<int>(hb & 0xffffffffll);
-              W.fsw[kMH + 2 * rank + 1] = static_cast<int>(hb >> 32);
-            }
+#pragma unroll
+            for (int c = 0; c < kFsCls; ++c)
+              if (sp[c] && rank[c] < ns) {
+                const long long hb = __builtin_bit_cast(long long, hh[c]);
+                W.fsw[kMQ + rank[c]] = kFsCls * t + c;
+                W.fsw[kMROW + rank[c]] = mi[c];
+                W.fsw[kMH + 2 * rank[c]] = static_cast<int>(hb & 0xffffffffll);
+                W.fsw[kMH + 2 * rank[c] + 1] = static_cast<int>(hb >> 32);
+#pragma unroll
+                for (int k = 0; k < kRlCap / kFsUnit; ++k)
+                  if (k < nu[c]) { W.fsw[kUROW + ubase[c] + k] = mi[c]; W.fsw[kUINF + ubase[c] + k] = rank[c] | (k << 10) | (mcnt[c] << 12); }
+              }
             if (t == 0) W.fsw[kCEV] = 0;
             g.sync_lds();
+            const int niter = (kFsUnit * U + T - 1) / T;  // (uniform) passes of T lanes over the step's entries: <= kFsIter
             const long long q1 = MOT_FCLOCK();
             cy_cls += q1 - q0;
             cy_sub[1] += q1 - qa;
             // every list entry of the step's real rows, held in registers
-            int ej[kFsIter], eq[kFsIter], er[kFsIter];
+            int ej[kFsIter], eq[kFsIter], er[kFsIter], erk[kFsIter];
             float cc[kFsIter];
             double ec[kFsIter];
             unsigned keep = 0u;
             int bad = 0, nt = 0, nk = 0;
-            // (loads first, arithmetic after: the LDS / global reads of several entries are in flight together instead of one
-            // dependent round trip per entry)
-            auto fetch = [&](int ns_now) {
-              int row[kFsIter], cn[kFsIter];
+            // (loads first, arithmetic after — and every load unconditional, from an address that is valid whatever the lane's slot holds: a load
+            // inside a divergent branch is waited for inside that branch, one round trip per entry instead of one for all of them)
+            auto fetch = [&]() {
+              int urow[kFsIter], uinf[kFsIter];
 #pragma unroll
               for (int it = 0; it < kFsIter; ++it) {
-                const int r = (t + it * T) / kRlCap;
-                const int rr = (r < kFsMaxMembers) ? r : kFsMaxMembers - 1;
-                row[it] = W.fsw[kMROW + rr];
-                cn[it] = W.fsw[kMCNT + rr];
-                if (r >= ns_now) cn[it] = 0;
+                urow[it] = 0; uinf[it] = 0;
+                if (it < niter) {
+                  const int u = (t + it * T) / kFsUnit;
+                  const int uu = (u < U) ? u : 0;
+                  urow[it] = W.fsw[kUROW + uu];
+                  uinf[it] = W.fsw[kUINF + uu];
+                }
+              }
+              unsigned long long ent[kFsIter];
+#pragma unroll
+              for (int it = 0; it < kFsIter; ++it) {
+                ent[it] = 0ull;
+                if (it < niter) {
+                  const int e = ((uinf[it] >> 10) & 3) * kFsUnit + ((t + it * T) % kFsUnit);
+                  ent[it] = W.rl_ent[static_cast<long>(urow[it]) * kRlCap + e];
+                }
               }
 #pragma unroll
               for (int it = 0; it < kFsIter; ++it) {
-                const int e = (t + it * T) % kRlCap;
-                ej[it] = -1; cc[it] = 0.f;
-                if (e < cn[it]) {
-                  const unsigned long long ent = W.rl_ent[static_cast<long>(row[it]) * kRlCap + e];
-                  ej[it] = rl_col_of(ent);
-                  cc[it] = rl_cost_of(ent);
+                ej[it] = -1; cc[it] = 0.f; er[it] = urow[it]; erk[it] = uinf[it] & 0x3ff;
+                if (it < niter) {
+                  const int u = (t + it * T) / kFsUnit;
+                  const int e = ((uinf[it] >> 10) & 3) * kFsUnit + ((t + it * T) % kFsUnit);
+                  if (u < U && e < (uinf[it] >> 12)) { ej[it] = rl_col_of(ent[it]); cc[it] = rl_cost_of(ent[it]); }
                 }
               }
             };
-            auto evaluate = [&]() {
+            auto evaluate = [&](int ns_now) {
               keep = 0u; nt = 0; nk = 0;
-              constexpr int kHalf = (kFsIter > 4) ? 4 : kFsIter;
+              int tw[kFsIter], hlo[kFsIter], hhi[kFsIter], mq[kFsIter];
+              double vv[kFsIter], dd[kFsIter];
 #pragma unroll
-              for (int i0 = 0; i0 < kFsIter; i0 += kHalf) {
-                int tw[kHalf], hlo[kHalf], hhi[kHalf];
-                double vv[kHalf], dd[kHalf];
-#pragma unroll
-                for (int u = 0; u < kHalf; ++u) {
-                  const int it = i0 + u;
+              for (int it = 0; it < kFsIter; ++it) {
+                tw[it] = 0; hlo[it] = 0; hhi[it] = 0; mq[it] = 0; vv[it] = 0.0; dd[it] = 0.0;
+                if (it < niter) {
                   const int jc = (ej[it] >= 0) ? ej[it] : 0;
-                  const int r = (t + it * T) / kRlCap;
-                  const int rr = (r < kFsMaxMembers) ? r : kFsMaxMembers - 1;
-                  tw[u] = W.fsw[kFsTodo + (jc >> 5)];
-                  vv[u] = W.v[jc];
-                  dd[u] = W.d[jc];
-                  hlo[u] = W.fsw[kMH + 2 * rr];
-                  hhi[u] = W.fsw[kMH + 2 * rr + 1];
+                  tw[it] = W.fsw[kFsTodo + (jc >> 5)];
+                  vv[it] = W.v[jc];
+                  dd[it] = W.d[jc];
+                  hlo[it] = W.fsw[kMH + 2 * erk[it]];
+                  hhi[it] = W.fsw[kMH + 2 * erk[it] + 1];
+                  mq[it] = W.fsw[kMQ + erk[it]];
                 }
+              }
 #pragma unroll
-                for (int u = 0; u < kHalf; ++u) {
-                  const int it = i0 + u;
-                  const int j = ej[it];
-                  eq[it] = 0; er[it] = 0; ec[it] = 0.0;
-                  if (j >= 0 && ((tw[u] >> (j & 31)) & 1)) {
-                    const int r = (t + it * T) / kRlCap;
-                    const long long hb = (static_cast<long long>(hhi[u]) << 32) | static_cast<long long>(static_cast<unsigned>(hlo[u]));
-                    const double cred = static_cast<double>(cc[it]) - vv[u] - __builtin_bit_cast(double, hb);
-                    if (!(cred >= mind_b)) bad = 1;
-                    if (cred < dd[u]) {
-                      keep |= 1u << it;
-                      eq[it] = W.fsw[kMQ + r]; er[it] = W.fsw[kMROW + r]; ec[it] = cred;
-                      ++nk;
-                      if (cred == mind_b) ++nt;
-                    }
+              for (int it = 0; it < kFsIter; ++it) {
+                const int j = ej[it];
+                eq[it] = 0; ec[it] = 0.0;
+                if (it < niter && j >= 0 && erk[it] < ns_now && ((tw[it] >> (j & 31)) & 1)) {
+                  const long long hb = (static_cast<long long>(hhi[it]) << 32) | static_cast<long long>(static_cast<unsigned>(hlo[it]));
+                  const double cred = static_cast<double>(cc[it]) - vv[it] - __builtin_bit_cast(double, hb);
+                  if (!(cred >= mind_b)) bad = 1;
+                  if (cred < dd[it]) {
+                    keep |= 1u << it;
+                    eq[it] = mq[it]; ec[it] = cred;
+                    ++nk;
+                    if (cred == mind_b) ++nt;
                   }
                 }
               }
             };
-            fetch(ns);
+            fetch();
             const long long qb = MOT_FCLOCK();
             cy_sub[2] += qb - q1;
-            g.sync();  // the step's full barrier, with the list loads in flight: the previous step's stores to cols[] / inv[] are visible from here on
+            // the step's barrier, with the list loads in flight: the previous step's stores to cols[] / inv[] are visible from here on. With
+            // cols[] / inv[] in LDS it orders LDS only; what is left in global memory is pred[] (written by the steps, read when the search
+            // is over): wait_vm() below makes every wavefront's stores to it land before the next step's — which sit behind this barrier.
+            if constexpr (!kColsLds) g.sync();  // (LDS state: the barriers of this step's classification already stand between the previous step's stores and every read below)
             stepped = true;
             // the columns in the first TODO positions (where tie events will swap their columns to) are requested now, one per lane, and
             // consumed by the event sort three phases later: a global round trip off the step's critical path
             const int hcol_pref = (t < kEvCap && shi + static_cast<unsigned>(t) < static_cast<unsigned>(n)) ? static_cast<int>(W.cols[shi + static_cast<unsigned>(t)]) : 0;
             const long long qc = MOT_FCLOCK();
             cy_sub[3] += qc - qb;
-            evaluate();
+            if constexpr (kColsLds) g.wait_vm();  // (the list entries have to be here anyway)
+            evaluate(ns);
             const long long qd = MOT_FCLOCK();
             cy_sub[4] += qd - qc;
-            bad = g.reduce_max(bad);
-            if (bad) { fast_ok = false; ++n_fs_bad; return 0; }
-            const int packed_all = g.reduce_sum((nt << 16) | nk);  // (each count <= kFsIter * T <= 32768)
+            // one reduction for the three counts (sums of nk and nt <= kFsIter * T <= 4096: 13 bits each; "bad" once per wavefront above them)
+            int packed3, bad_any;
+            if constexpr (has_wave_table<G>::value) {
+              const bool wb = G::wave_ballot(bad != 0) != 0ull;
+              packed3 = g.reduce_sum(nk | (nt << 13) | ((wb && g.wave_lane() == 0) ? (1 << 26) : 0));
+              bad_any = packed3 >> 26;
+            } else {
+              bad_any = g.reduce_max(bad);
+              packed3 = g.reduce_sum(nk | (nt << 13));
+            }
+            if (bad_any) { fast_ok = false; ++n_fs_bad; return 0; }
+            const int packed_all = ((packed3 >> 13) & 0x1fff) << 16 | (packed3 & 0x1fff);
             if ((packed_all >> 16) > kEvCap || (packed_all & 0xffff) > kKeepCap) {  // more than the tables hold: this step takes one real row only (<= kRlCap entries)
               ns = 1;
               cnt = static_cast<int>(W.fsw[kMQ]) + 1;
-#pragma unroll
-              for (int it = 0; it < kFsIter; ++it)
-                if ((t + it * T) / kRlCap >= 1) ej[it] = -1;
-              evaluate();
+              evaluate(1);
             }
             const long long q2 = MOT_FCLOCK();
             cy_dry += q2 - q1;
@@ -1447,8 +1523,8 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                   tk[it] = W.inv[j];
                   ti[it] = i;
                   if (i >= 0 && i < nr) {
-                    tn[it] = W.rl_cnt[i];
-                    if (j < nc) tc[it] = static_cast<float>(C.at(i, j));
+                    tn[it] = rl_len(i);
+                    if (j < nc) tc[it] = have_yc ? static_cast<float>(W.ycost[j]) : static_cast<float>(C.at(i, j));
                   }
                 }
               }
@@ -1530,19 +1606,45 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 if (off < nev) W.fsw[kHE + off] = e;
               }
               g.sync_lds();
+              // one lane, everything through LDS: groups without wavefronts (tests/emu), and a member with more than 64 events
+              auto serial_replay = [&](int r0, int e0, int& dn, int& sk) {
+                for (int r = r0; r < nev; ++r) {
+                  while (static_cast<int>(W.fsw[kSF + e0]) & 2) ++e0;
+                  const int q = W.fsw[kSQ + e0];
+                  int best = e0, bp = W.fsw[kSK + e0];
+                  for (int e = e0 + 1; e < nev && static_cast<int>(W.fsw[kSQ + e]) == q; ++e) {
+                    const int pk = W.fsw[kSK + e];
+                    if (!(static_cast<int>(W.fsw[kSF + e]) & 2) && pk < bp) { best = e; bp = pk; }
+                  }
+                  const int j = W.fsw[kSJ + best], fl = W.fsw[kSF + best];
+                  if (fl & 1) { sk = j; break; }
+                  W.fsw[kSF + best] = fl | 2;
+                  const int hpos = static_cast<int>(shi) + r;
+                  if (bp != hpos) {
+                    const int hc = W.fsw[kHC + r], he = W.fsw[kHE + r];
+                    const int off = bp - static_cast<int>(shi);
+                    if (off < nev) { W.fsw[kHC + off] = hc; W.fsw[kHE + off] = he; }
+                    else { W.cols[bp] = hc; W.inv[hc] = bp; }
+                    if (he >= 0) W.fsw[kSK + he] = bp;
+                  }
+                  W.cols[hpos] = j; W.inv[j] = hpos;
+                  W.fsw[kFsTodo + (j >> 5)] = static_cast<int>(W.fsw[kFsTodo + (j >> 5)]) & ~(1 << (j & 31));
+                  ++dn;
+                }
+              };
               bool by_wave = false;
               if constexpr (has_wave_table<G>::value) {
-                // the first wavefront replays out of registers: lane e holds sorted event e and head slot e, the serial walk reads
-                // them with v_readlane and finds the next event with one ballot and one DPP minimum (an LDS round trip per field
-                // and event otherwise)
-                if (nev <= 64) {
-                  by_wave = true;
-                  if (t < 64) {
+                by_wave = true;
+                if (t < 64) {
+                  int dn = 0, sk = -1;
+                  if (nev <= 64) {
+                    // the first wavefront replays out of registers: lane e holds sorted event e and head slot e, the serial walk reads
+                    // them with v_readlane and finds the next event with one ballot and one DPP minimum (an LDS round trip per field
+                    // and event otherwise)
                     const bool in = t < nev;
                     const int vq = in ? static_cast<int>(W.fsw[kSQ + t]) : kNoIdx, vj = in ? static_cast<int>(W.fsw[kSJ + t]) : 0;
                     int vk = in ? static_cast<int>(W.fsw[kSK + t]) : kNoIdx, vf = in ? static_cast<int>(W.fsw[kSF + t]) : 2;
                     int hc = in ? static_cast<int>(W.fsw[kHC + t]) : 0, he = in ? static_cast<int>(W.fsw[kHE + t]) : -1;
-                    int dn = 0, sk = -1;
                     for (int r = 0; r < nev; ++r) {
                       const int e0 = __builtin_ctzll(G::wave_ballot(!(vf & 2)));  // first event not applied yet, in sorted order
                       const int q = G::wave_get(vq, e0);
@@ -1566,35 +1668,56 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                       }
                       ++dn;
                     }
-                    if (t == 0) { W.fsw[kCDONE] = dn; W.fsw[kCSINK] = sk; }
+                  } else {
+                    // (round 5) more than 64 events: the same walk member by member — a member's events are contiguous in the sorted table, lane l
+                    // holds the l-th of them; the head slots stay in LDS (one uniform read per event: the wavefront's own LDS accesses run in
+                    // order, so a slot rewritten by one event is seen by the next). This used to fall to the one-lane loop above: ~3 k cycles
+                    // per event, and the steps that take this path are the ones with many events.
+                    int e0 = 0;
+                    bool fb = false;
+                    while (e0 < nev && sk < 0) {
+                      const int q = W.fsw[kSQ + e0];
+                      const int e = e0 + t;
+                      const bool in = e < nev && static_cast<int>(W.fsw[kSQ + (e < nev ? e : e0)]) == q;
+                      const int cm = __builtin_popcountll(G::wave_ballot(in));
+                      if (cm == 64 && e0 + 64 < nev && static_cast<int>(W.fsw[kSQ + e0 + 64]) == q) { fb = true; break; }
+                      const int vj = in ? static_cast<int>(W.fsw[kSJ + e]) : 0;
+                      int vk = in ? static_cast<int>(W.fsw[kSK + e]) : kNoIdx, vf = in ? static_cast<int>(W.fsw[kSF + e]) : 2;
+                      for (int a = 0; a < cm; ++a) {
+                        const int cand = !(vf & 2) ? vk : kNoIdx;
+                        const int bp = G::wave_min_i32(cand);
+                        const int best = __builtin_ctzll(G::wave_ballot(cand == bp));
+                        const int j = G::wave_get(vj, best), fl = G::wave_get(vf, best);
+                        if (fl & 1) { sk = j; break; }
+                        if (t == best) vf |= 2;
+                        const int hpos = static_cast<int>(shi) + dn;
+                        if (bp != hpos) {
+                          const int hcr = W.fsw[kHC + dn], her = W.fsw[kHE + dn];
+                          const int off = bp - static_cast<int>(shi);
+                          if (off < nev) { if (t == 0) { W.fsw[kHC + off] = hcr; W.fsw[kHE + off] = her; } }
+                          else if (t == 0) { W.cols[bp] = hcr; W.inv[hcr] = bp; }
+                          if (her >= 0) {
+                            if (t == her - e0) vk = bp;             // (an event of this member, held by a lane; harmless for a lane that holds none)
+                            if (t == 0) W.fsw[kSK + her] = bp;      // (and for the members still to come)
+                          }
+                        }
+                        if (t == 0) {
+                          W.cols[hpos] = j; W.inv[j] = hpos;
+                          W.fsw[kFsTodo + (j >> 5)] = static_cast<int>(W.fsw[kFsTodo + (j >> 5)]) & ~(1 << (j & 31));
+                        }
+                        ++dn;
+                      }
+                      if (in) W.fsw[kSF + e] = vf;  // (the applied flags, for the one-lane continuation)
+                      e0 += cm;
+                    }
+                    if (fb && t == 0) serial_replay(dn, e0, dn, sk);
                   }
+                  if (t == 0) { W.fsw[kCDONE] = dn; W.fsw[kCSINK] = sk; }
                 }
               }
               if (!by_wave && t == 0) {
-                int dn = 0, sk = -1, e0 = 0;
-                for (int r = 0; r < nev; ++r) {
-                  while (static_cast<int>(W.fsw[kSF + e0]) & 2) ++e0;
-                  const int q = W.fsw[kSQ + e0];
-                  int best = e0, bp = W.fsw[kSK + e0];
-                  for (int e = e0 + 1; e < nev && static_cast<int>(W.fsw[kSQ + e]) == q; ++e) {
-                    const int pk = W.fsw[kSK + e];
-                    if (!(static_cast<int>(W.fsw[kSF + e]) & 2) && pk < bp) { best = e; bp = pk; }
-                  }
-                  const int j = W.fsw[kSJ + best], fl = W.fsw[kSF + best];
-                  if (fl & 1) { sk = j; break; }
-                  W.fsw[kSF + best] = fl | 2;
-                  const int hpos = static_cast<int>(shi) + r;
-                  if (bp != hpos) {
-                    const int hc = W.fsw[kHC + r], he = W.fsw[kHE + r];
-                    const int off = bp - static_cast<int>(shi);
-                    if (off < nev) { W.fsw[kHC + off] = hc; W.fsw[kHE + off] = he; }
-                    else { W.cols[bp] = hc; W.inv[hc] = bp; }
-                    if (he >= 0) W.fsw[kSK + he] = bp;
-                  }
-                  W.cols[hpos] = j; W.inv[j] = hpos;
-                  W.fsw[kFsTodo + (j >> 5)] = static_cast<int>(W.fsw[kFsTodo + (j >> 5)]) & ~(1 << (j & 31));
-                  ++dn;
-                }
+                int dn = 0, sk = -1;
+                serial_replay(0, 0, dn, sk);
                 W.fsw[kCDONE] = dn;
                 W.fsw[kCSINK] = sk;
               }
@@ -1693,7 +1816,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             if constexpr (is_matrix_cost<Cost>::value) {
               // the next member's matrix row (the lane's first kSweep columns) is requested now and consumed one sweep later:
               // a row of a matrix tens of MB large misses L2, and the sweep below would otherwise wait for it load by load
-              if (fetched && pq_i < nr && pq_i != pf_row) {
+              if (fetched && pq_i < nr && pq_i != pf_row && !(have_yc && rl_len(pq_i) <= kRlCap)) {  // (a row with a list is nearly always swept through it: no random line of the matrix for those)
                 const float* rp = C.row(pq_i).p;
 #pragma unroll
                 for (int k = 0; k < kSweep; ++k) {
@@ -1708,7 +1831,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             double h;
             if constexpr (is_matrix_cost<Cost>::value) {
               const bool have_h = pf_row == i && pf_col == jq && jq < nc;
-              h = (have_h ? static_cast<double>(pf_h) : R.at(C, jq)) - W.v[jq] - mind;
+              h = (have_h ? static_cast<double>(pf_h) : ((have_yc && i < nr && jq < nc) ? match_cost(i, jq) : R.at(C, jq))) - W.v[jq] - mind;
             } else {
               h = R.at(C, jq) - W.v[jq] - mind;
             }
@@ -1766,9 +1889,9 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 }
               };
               auto no_load = [](int, int, bool) { return 0.f; };
-              if (sweep_real && R.real && use_rl && h <= hmax_dummy_row && static_cast<int>(W.rl_cnt[i]) <= kRlCap) {
+              if (sweep_real && R.real && use_rl && h <= hmax_dummy_row && rl_len(i) <= kRlCap) {
                 // fact (2) above: the columns at or above half cannot be lowered by this row — its list is the whole sweep
-                const int ne = W.rl_cnt[i];
+                const int ne = rl_len(i);
                 for (int e = t; e < ne; e += T) {
                   const unsigned long long ent = W.rl_ent[static_cast<long>(i) * kRlCap + e];
                   const int j = rl_col_of(ent);
@@ -1849,6 +1972,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
         while (i != start) {
           i = W.pred[j];
           W.y[j] = i;
+          if (have_yc && i < nr && j < nc) W.ycost[j] = static_cast<float>(C.at(i, j));
           const int nx = W.x[i];
           W.x[i] = j;
           j = nx;
@@ -1859,7 +1983,10 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
       // single-step path: n_ready == 0 so no dual changes (:183-189); y[final_j] = start, x[start] = final_j
       // written by the owner lane of final_j: y[final_j] is next read by that same lane (or after
       // a barrier); x[] is only read again by lane 0 behind the general path's barriers.
-      if ((final_j % T) == t) { W.y[final_j] = start; W.x[start] = final_j; }
+      if ((final_j % T) == t) {
+        W.y[final_j] = start; W.x[start] = final_j;
+        if (have_yc && start < nr && final_j < nc) W.ycost[final_j] = static_cast<float>(R0.at(C, final_j));
+      }
     }
   }
   if (W.cyc && t == 0) {

@@ -34,6 +34,7 @@ struct EmuGroup {
   int size() const { return sh->T; }
   void sync() { pthread_barrier_wait(&sh->bar); }
   void sync_lds() { sync(); }
+  void wait_vm() {}
   void lds_barriers(bool) {}
   double reduce_min(double v) {
     auto& s = sh->s_f64[phase++ & 1];

@@ -36,6 +36,40 @@ extern "C" int emu_lap_rl(const float* cost, int nr, int nc, int ld, float thres
                  cyc[6], cyc[14], cyc[8], cyc[9], cyc[10], cyc[11], cyc[12], cyc[13], cyc[15]);
   return 0;
 }
+// the same with the state the wide matrix launches keep in LDS since round 5: 16-bit y / cols / inv, byte-sized list lengths, the matched costs
+extern "C" int emu_lap_rl16(const float* cost, int nr, int nc, int ld, float thresh, int T, int* x, int* y) {
+  using namespace mot;
+  using Work16 = LapWorkT<kMemAny, kMemAny, kMemAny, kMemAny, kMemAny, kMemAny, short, kMemAny, kMemAny>;
+  const int n = nr + nc;
+  std::vector<char> mem(lap_work_bytes(n) + 64), rl(lap_rowlist_bytes(nr) + 64);
+  std::vector<int> fsw(kFsWsInts);
+  std::vector<unsigned char> rn(nr + 1);
+  std::vector<float> yc(nc + 1);
+  Work16 W;
+  lap_carve_hot(W, mem.data(), n);
+  lap_carve_cold(W, mem.data() + ((lap_hot_bytes(n) + 7) & ~size_t(7)), n);
+  lap_carve_rowlist(W, rl.data(), nr);
+  W.fsw.p = fsw.data();
+  W.rl_n.p = rn.data();
+  W.ycost.p = yc.data();
+  long long cyc[16] = {0};
+  W.cyc = cyc;
+  const MatrixCost C{cost, ld};
+  const LapDims P{nr, nc, static_cast<double>(thresh) / 2.0};
+  EmuShared sh(T);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t]() { EmuGroup g(&sh, t); lap_solve(g, C, P, W); });
+  for (auto& t : th) t.join();
+  for (int i = 0; i < nr; ++i) x[i] = (W.x[i] >= nc) ? -1 : W.x[i];
+  for (int j = 0; j < nc; ++j) y[j] = (W.y[j] >= nr) ? -1 : static_cast<int>(W.y[j]);
+  // the matched costs must be current at the end: every real pair's entry is the matrix element
+  for (int j = 0; j < nc; ++j) {
+    const int i = W.y[j];
+    if (i >= 0 && i < nr && cyc[15] && yc[j] != cost[static_cast<size_t>(i) * ld + j]) return -7;
+  }
+  return 0;
+}
 extern "C" int emu_lap(const float* cost, int nr, int nc, int ld, float thresh, int T, int* x, int* y) {
   return emu_lap_rl(cost, nr, nc, ld, thresh, T, 0, x, y);
 }

@@ -197,16 +197,24 @@ def test_sparse_column_minima_make_the_same_decisions(orc, emu_iou):
 
 
 # ---- row lists: the parallel scan steps + sparse real-row sweeps of the shortest-path search (mot_lap_task.rowlist) ----
-@pytest.fixture(scope="module", params=[False, True, "mem"], ids=["serial_replay", "closed_form_tie_runs", "tie_runs_through_memory"])
+# the last two: the state the wide matrix launches keep in LDS since round 5 (16-bit y / cols / inv, byte-sized list lengths, the matched
+# pairs' costs kept next to y) — lap_emu.cpp::emu_lap_rl16, which also checks that the matched costs are current at the end
+@pytest.fixture(scope="module", params=[False, True, "mem", "lds16", "lds16_tie"],
+                ids=["serial_replay", "closed_form_tie_runs", "tie_runs_through_memory", "lds16_state", "lds16_state_tie_runs"])
 def emu_rl(request):
-    lib = C.CDLL(build_lap_emu(request.param))
+    state16 = isinstance(request.param, str) and request.param.startswith("lds16")
+    lib = C.CDLL(build_lap_emu({"lds16": False, "lds16_tie": True}.get(request.param, request.param)))
 
     def run(cost, th, T, rowlists=1):
         cost = np.ascontiguousarray(cost, np.float32)
         n, m = cost.shape
         x, y = np.zeros(n, np.int32), np.zeros(m, np.int32)
-        lib.emu_lap_rl(cost.ctypes.data_as(C.c_void_p), n, m, m, C.c_float(th), T, rowlists, x.ctypes.data_as(C.c_void_p),
-                       y.ctypes.data_as(C.c_void_p))
+        if state16 and rowlists:
+            rc = lib.emu_lap_rl16(cost.ctypes.data_as(C.c_void_p), n, m, m, C.c_float(th), T, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
+            assert rc == 0, "matched costs went stale"
+        else:
+            lib.emu_lap_rl(cost.ctypes.data_as(C.c_void_p), n, m, m, C.c_float(th), T, rowlists, x.ctypes.data_as(C.c_void_p),
+                           y.ctypes.data_as(C.c_void_p))
         return x, y
     return run
 

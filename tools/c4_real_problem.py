@@ -34,5 +34,5 @@ for f in sorted(glob.glob(os.path.join(d, "*.bin"))):
           "| carr %d paths %d finds %d | steps %d members %d real %d events %d one-at-a-time %d refused %d lists %d" %
           (p[5], p[6], p[14], p[8], p[9], p[10], p[11], p[12], p[13], p[15]),
           "| aug Mcycles: classify %.1f dry %.1f apply %.1f evsort %.1f evreplay %.1f find %.1f one-at-a-time %.1f setup %.1f" % tuple(p[16:24] / 1e6),
-          "| sub: " + " ".join("%.1f" % (v / 1e6) for v in p[24:36]), flush=True)
+          "| sub: " + " ".join("%.1f" % (v / 1e6) for v in p[24:36]), "| raw sub:", " ".join(str(int(v)) for v in p[24:36]), flush=True)
 print("mismatches", bad)

@@ -182,17 +182,15 @@ struct DevGroup {
   // exclusive prefix minimum over thread ids (threads with no predecessor get +inf); general-path helper
   __device__ __forceinline__ double exclusive_scan_min(double v) {
     const int lane = tid_ & 63;
+    // inclusive minimum scan on DPP (round 5; six __shfl_up steps of two LDS-crossbar permutes each before): Kogge-Stone inside the rows of 16,
+    // then the row totals forwarded (row_bcast 15 / 31); a lane without a source keeps its own value
     double inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      int lo = __double2loint(inc), hi = __double2hiint(inc);
-      lo = __shfl_up(lo, d, 64); hi = __shfl_up(hi, d, 64);
-      const double o = __hiloint2double(hi, lo);
-      if (lane >= d && o < inc) inc = o;
-    }
-    // exclusive within the wavefront: value of the previous lane's inclusive scan
-    int lo = __double2loint(inc), hi = __double2hiint(inc);
-    lo = __shfl_up(lo, 1, 64); hi = __shfl_up(hi, 1, 64);
+#define MOT_STEP(C, M) { const double o = dpp_f64<C, M>(inc); inc = (o < inc) ? o : inc; }
+    MOT_DPP_STEPS(MOT_STEP)
+#undef MOT_STEP
+    // exclusive within the wavefront: the previous lane's inclusive value (wave_shr:1; lane 0 has no source)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(inc), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(inc), 0x138, 0xf, 0xf, false);
     double ex = (lane == 0) ? 1e300 : __hiloint2double(hi, lo);
     const int nw = (size_ + 63) >> 6;
     if (nw > 1) {
@@ -207,8 +205,9 @@ struct DevGroup {
   __device__ __forceinline__ int exclusive_scan(int v, int* total) {
     const int lane = tid_ & 63;
     int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+#define MOT_STEP(C, M) { inc += __builtin_amdgcn_update_dpp(0, inc, C, M, 0xf, false); }
+    MOT_DPP_STEPS(MOT_STEP)
+#undef MOT_STEP
     const int nw = (size_ + 63) >> 6;
     int* s = slot<int>();
     if (lane == 63 || tid_ == size_ - 1) s[tid_ >> 6] = inc;
@@ -217,6 +216,40 @@ struct DevGroup {
     for (int w = 0; w < nw; ++w) { int c = s[w]; if (w < (tid_ >> 6)) base += c; tot += c; }
     *total = tot;
     return base + inc - v;
+  }
+  // Prefix sum that ends at the first thread with `stop` set (round 5: the scan steps of lap_core.hpp needed "first stop" and "prefix sums in front
+  // of it" as two collectives in a row — two barriers and 2 x 6 LDS-crossbar shuffles per step). cnt = id of the first stopping thread (size()
+  // without one); base = exclusive prefix sum of v (meaningful for threads in front of cnt), tot = sum of v over the threads in front of cnt.
+  // Inside a wavefront the sums run on DPP (row_shr 1/2/4/8 Kogge-Stone, then row_bcast 15 / 31: an inclusive scan in six VALU steps).
+  struct ScanStop { int base, tot, cnt; };
+  static __device__ __forceinline__ int wave_inclusive_sum(int v) {
+#define MOT_STEP(C, M) { v += __builtin_amdgcn_update_dpp(0, v, C, M, 0xf, false); }
+    MOT_DPP_STEPS(MOT_STEP)
+#undef MOT_STEP
+    return v;
+  }
+  __device__ __forceinline__ ScanStop scan_until_stop(int v, bool stop) {
+    const int lane = tid_ & 63, w = tid_ >> 6;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(stop);
+    const int first = m ? __builtin_ctzll(m) : 64;
+    const int inc = wave_inclusive_sum(v);
+    const int upto = (first == 0) ? 0 : __builtin_amdgcn_readlane(inc, first - 1);  // sum of the lanes in front of the wavefront's first stop
+    const int nw = (size_ + 63) >> 6;
+    if (nw == 1) return ScanStop{inc - v, upto, first < size_ ? first : size_};
+    int* s = slot<int>();
+    if (lane == 0) { s[2 * w] = upto; s[2 * w + 1] = first; }
+    barrier_();
+    int base = 0, tot = 0, cnt = size_;
+    bool open = true;
+    for (int k = 0; k < nw; ++k) {
+      const int u = s[2 * k], f = s[2 * k + 1];
+      if (open) {
+        if (k < w) base += u;
+        tot += u;
+        if (f < 64) { cnt = k * 64 + f; open = false; }
+      }
+    }
+    return ScanStop{base + inc - v, tot, cnt};
   }
   // rank of the calling thread among the threads whose flag is set (ascending thread id) and their number
   __device__ __forceinline__ int flag_rank(bool flag, int* total) {

@@ -126,8 +126,6 @@ MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeo
 // Row lists (optional scratch of a matrix-cost task, mot_lap_task.rowlist): per real row the entries below thresh/2.
 constexpr int kRlCap = 64;      // entries kept per row (a row with more has no list: its sweeps stay dense)
 constexpr int kFsIter = 4;      // list entries a lane holds in registers during a parallel scan step
-constexpr int kFsCls = 1;       // SCAN members a lane classifies per step (measured on an OC-SORT 4096 x 2048 problem: 4 per lane, 16 % fewer steps,
-                                // each of them so much longer that the solve took 13 % more cycles — a step's cost is its critical path, and that grew)
 constexpr int kFsUnit = 16;     // the lists are dealt to the lanes in units of this many entries (kRlCap / kFsUnit <= 4 units per row)
 constexpr int kFsMaxUnits = 256;    // units of one step (also bounded by kFsIter * T / kFsUnit)
 constexpr int kFsMaxMembers = 256;  // real-row members of one step (each takes at least one unit)
@@ -1288,91 +1286,68 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           auto fast_step_body = [&](double mind_b) -> int {  // 0: nothing done, 1: members consumed, 2: a sink was reached (final_j set)
             const long long q0 = MOT_FCLOCK();
             if (need_full) { if constexpr (kColsLds) g.sync_lds(); else g.sync(); need_full = false; }
-            // every lane classifies kFsCls consecutive members (round 5: one member per lane made a step end after T members — two steps in
-            // three of an OC-SORT 4096 x 2048 problem, whose SCAN sets hold thousands of dummy rows that need nothing but this look)
-            int cls[kFsCls], mi[kFsCls], mcnt[kFsCls];  // cls: 0 stop, 1 void dummy row, 2 real row with a list
-            double hh[kFsCls];
-            int lane_stop = kNoIdx;
-#pragma unroll
-            for (int c = 0; c < kFsCls; ++c) {
-              cls[c] = 0; mi[c] = -1; mcnt[c] = 0; hh[c] = 0.0;
-              const unsigned idx = slo + static_cast<unsigned>(kFsCls * t + c);
-              if (idx < shi) {
-                const unsigned qi = idx - qpos;
-                int mj;
-                double md, cij = half;
-                if (qi < qlen) {  // appended by the last step: d == mind by construction
-                  mj = W.fsw[kSJ + qi]; mi[c] = W.fsw[kSI + qi]; md = mind_b;
-                  mcnt[c] = W.fsw[kSN + qi];
-                  if (mi[c] < nr && mj < nc) cij = static_cast<double>(__builtin_bit_cast(float, static_cast<int>(W.fsw[kSC + qi])));
-                } else {
-                  mj = W.cols[idx];
-                  mi[c] = W.y[mj];
-                  md = W.d[mj];
-                  if (mi[c] < nr) {
-                    mcnt[c] = rl_len(mi[c]);
-                    if (mj < nc) cij = match_cost(mi[c], mj);
-                  }
-                }
-                if (md == mind_b) {
-                  if (mi[c] >= nr) {
-                    hh[c] = ((mj < nc) ? half : 0.0) - W.v[mj] - md;
-                    if (hh[c] <= hmax_dummy_row) cls[c] = 1;
-                  } else {
-                    hh[c] = cij - W.v[mj] - md;
-                    if (hh[c] <= hmax_dummy_row && hh[c] <= hmax_real_row && mcnt[c] <= kRlCap && mcnt[c] <= units_cap * kFsUnit) cls[c] = 2;
-                  }
+            // one member per lane. (Tried in round 5: four consecutive members per lane — two steps in three of an OC-SORT 4096 x 2048 problem end
+            // after T members because its SCAN sets hold thousands of dummy rows; 16 % fewer steps, each so much longer that the solve took 13 %
+            // more cycles: a step costs its critical path, and the classification is on it.)
+            const unsigned idx = slo + static_cast<unsigned>(t);
+            int cls = 0, mi = -1, mcnt = 0;  // 0 stop, 1 void dummy row, 2 real row with a list
+            double hh = 0.0;
+            if (idx < shi) {
+              const unsigned qi = idx - qpos;
+              int mj;
+              double md, cij = half;
+              if (qi < qlen) {  // appended by the last step: d == mind by construction
+                mj = W.fsw[kSJ + qi]; mi = W.fsw[kSI + qi]; md = mind_b;
+                mcnt = W.fsw[kSN + qi];
+                if (mi < nr && mj < nc) cij = static_cast<double>(__builtin_bit_cast(float, static_cast<int>(W.fsw[kSC + qi])));
+              } else {
+                mj = W.cols[idx];
+                mi = W.y[mj];
+                md = W.d[mj];
+                if (mi < nr) {
+                  mcnt = rl_len(mi);
+                  if (mj < nc) cij = match_cost(mi, mj);
                 }
               }
-              if (cls[c] == 0 && lane_stop == kNoIdx) lane_stop = kFsCls * t + c;
+              if (md == mind_b) {
+                if (mi >= nr) {
+                  hh = ((mj < nc) ? half : 0.0) - W.v[mj] - md;
+                  if (hh <= hmax_dummy_row) cls = 1;
+                } else {
+                  hh = cij - W.v[mj] - md;
+                  if (hh <= hmax_dummy_row && hh <= hmax_real_row && mcnt <= kRlCap && mcnt <= units_cap * kFsUnit) cls = 2;
+                }
+              }
             }
             const long long qa = MOT_FCLOCK();
             cy_sub[0] += qa - q0;
-            int cnt = g.reduce_min_int(lane_stop);
-            const int avail = (shi - slo < static_cast<unsigned>(kFsCls * T)) ? static_cast<int>(shi - slo) : kFsCls * T;
-            if (cnt > avail) cnt = avail;
-            if (cnt == 0) { cy_cls += MOT_FCLOCK() - q0; return 0; }
             // Real rows with a list take part in the step through their list entries, dealt to the lanes in UNITS of kFsUnit entries (a row of
             // mcnt entries takes ceil(mcnt / kFsUnit) units; round 5 — a row used to reserve kRlCap slots whatever its length, so that a
-            // step of 512 lanes held 64 rows with nine slots in ten empty): one prefix sum gives every such member its rank and its first unit.
-            bool sp[kFsCls];  // (a real row without entries below half relaxes nothing)
-            int nu[kFsCls], rank[kFsCls], ubase[kFsCls];
-            int lane_pack = 0;
-#pragma unroll
-            for (int c = 0; c < kFsCls; ++c) {
-              sp[c] = kFsCls * t + c < cnt && cls[c] == 2 && mcnt[c] > 0;
-              nu[c] = sp[c] ? ((mcnt[c] + kFsUnit - 1) / kFsUnit) : 0;
-              lane_pack += sp[c] ? (1 | (nu[c] << 12)) : 0;
-            }
-            int tot;
-            int run = g.exclusive_scan(lane_pack, &tot);
-#pragma unroll
-            for (int c = 0; c < kFsCls; ++c) {
-              rank[c] = run & 0xfff; ubase[c] = run >> 12;
-              run += sp[c] ? (1 | (nu[c] << 12)) : 0;
-            }
-            int ns = tot & 0xfff, U = tot >> 12;
+            // step of 512 lanes held 64 rows with nine slots in ten empty). ONE collective gives the number of leading members the step can take
+            // (a lane beyond the SCAN set has cls 0: it stops the count) and every real row among them its rank and its first unit.
+            const bool spc = cls == 2 && mcnt > 0;  // (a real row without entries below half relaxes nothing)
+            const int nu = spc ? ((mcnt + kFsUnit - 1) / kFsUnit) : 0;
+            const auto sc = g.scan_until_stop(spc ? (1 | (nu << 12)) : 0, cls == 0);
+            int cnt = sc.cnt;
+            if (cnt == 0) { cy_cls += MOT_FCLOCK() - q0; return 0; }
+            const bool sp = spc && t < cnt;
+            const int rank = sc.base & 0xfff, ubase = sc.base >> 12;
+            int ns = sc.tot & 0xfff, U = sc.tot >> 12;
             if (U > units_cap) {  // the step ends in front of the first member whose units do not fit any more (a prefix property: unit offsets only grow)
-              int lane_key = kNoIdx;
-#pragma unroll
-              for (int c = kFsCls - 1; c >= 0; --c)
-                if (sp[c] && ubase[c] + nu[c] > units_cap) lane_key = ((kFsCls * t + c) << 20) | (rank[c] << 11) | ubase[c];
-              const int key = g.reduce_min_int(lane_key);
+              const int key = g.reduce_min_int((sp && ubase + nu > units_cap) ? ((t << 20) | (rank << 11) | ubase) : kNoIdx);
               cnt = key >> 20; ns = (key >> 11) & 0x1ff; U = key & 0x7ff;
             }
             if (ns == 0) { slo += static_cast<unsigned>(cnt); ++n_fs_steps; n_fs_members += cnt; cy_cls += MOT_FCLOCK() - q0; return 1; }
+            if (sp && rank < ns) {
+              const long long hb = __builtin_bit_cast(long long, hh);
+              W.fsw[kMQ + rank] = t;
+              W.fsw[kMROW + rank] = mi;
+              W.fsw[kMH + 2 * rank] = static_cast<int>(hb & 0xffffffffll);
+              W.fsw[kMH + 2 * rank + 1] = static_cast<int>(hb >> 32);
 #pragma unroll
-            for (int c = 0; c < kFsCls; ++c)
-              if (sp[c] && rank[c] < ns) {
-                const long long hb = __builtin_bit_cast(long long, hh[c]);
-                W.fsw[kMQ + rank[c]] = kFsCls * t + c;
-                W.fsw[kMROW + rank[c]] = mi[c];
-                W.fsw[kMH + 2 * rank[c]] = static_cast<int>(hb & 0xffffffffll);
-                W.fsw[kMH + 2 * rank[c] + 1] = static_cast<int>(hb >> 32);
-#pragma unroll
-                for (int k = 0; k < kRlCap / kFsUnit; ++k)
-                  if (k < nu[c]) { W.fsw[kUROW + ubase[c] + k] = mi[c]; W.fsw[kUINF + ubase[c] + k] = rank[c] | (k << 10) | (mcnt[c] << 12); }
-              }
+              for (int k = 0; k < kRlCap / kFsUnit; ++k)
+                if (k < nu) { W.fsw[kUROW + ubase + k] = mi; W.fsw[kUINF + ubase + k] = rank | (k << 10) | (mcnt << 12); }
+            }
             if (t == 0) W.fsw[kCEV] = 0;
             g.sync_lds();
             const int niter = (kFsUnit * U + T - 1) / T;  // (uniform) passes of T lanes over the step's entries: <= kFsIter
@@ -1563,7 +1538,14 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             if (nev == 0) { slo += static_cast<unsigned>(cnt); return 1; }
             // tie events in lapjv's order. Sorted by (member, position at the start of the step); positions only change for
             // columns that sit in the first nev TODO positions ("head slots": a tie swaps its column with the first TODO one).
-            int in_head = 0, first_sink = kNoIdx;
+            // What can stop the events from being independent swaps of (event column, head column) pairs in sorted order: an event column that sits in a
+            // head slot (one of the first nev TODO positions). Event e (sorted index) with its column in head slot o != e is harmless for the
+            // prefix [0, max(e, o)): up to there no turn touches that slot or that event. So (round 5) the longest conflict-free prefix P = the
+            // smallest max(e, o) over such events is applied in parallel and only the events behind it take the serial walk — which used to start
+            // at event 0 whenever any event column sat in a head slot (one step in eight, 40 k cycles each). The first event whose column is free
+            // (a sink) ends everything: one reduction finds the smaller of the two bounds (a sink wins a tie: the prefix in front of it is applied,
+            // then the search is over).
+            int lane_key = kNoIdx;
             for (int e = t; e < nev; e += T) {
               const int hcol = (e == t && t < kEvCap) ? hcol_pref : static_cast<int>(W.cols[shi + static_cast<unsigned>(e)]);
               const int q = W.fsw[kEQ + e], j = W.fsw[kEJ + e], k = W.fsw[kEK + e], i = W.fsw[kEI + e];
@@ -1577,34 +1559,46 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               W.fsw[kSI + rk] = i; W.fsw[kSC + rk] = W.fsw[kEC + e]; W.fsw[kSN + rk] = W.fsw[kEN + e];
               W.fsw[kHC + e] = hcol;
               W.fsw[kHE + e] = -1;
-              if (k - static_cast<int>(shi) < nev) in_head = 1;
-              if (fl && rk < first_sink) first_sink = rk;
+              const int off = k - static_cast<int>(shi);
+              if (fl && (rk << 1) < lane_key) lane_key = rk << 1;
+              if (off < nev && off != rk) { const int cb = ((rk > off ? rk : off) << 1) | 1; if (cb < lane_key) lane_key = cb; }
             }
-            {  // one reduction for both (its barrier also orders the sorted table): -1 when some event column sits in a head slot
-              const int key = g.reduce_min_int(in_head ? -1 : first_sink);
-              in_head = key < 0 ? 1 : 0;
-              first_sink = key;
-            }
+            const int key = g.reduce_min_int(lane_key);  // (its barrier also orders the sorted table)
+            const int P = (key == kNoIdx) ? nev : (key >> 1);
+            const bool conflict = key != kNoIdx && (key & 1) != 0;
             const long long q4 = MOT_FCLOCK();
             cy_evsort += q4 - q3;
             int done, sink = -1;
-            if (!in_head) {
-              // no event column sits in a head slot: positions do not interact, the swaps are independent
-              done = (first_sink < nev) ? first_sink : nev;
-              if (first_sink < nev) sink = W.fsw[kSJ + first_sink];
-              for (int r = t; r < done; r += T) {
-                const int j = W.fsw[kSJ + r], bp = W.fsw[kSK + r], hc = W.fsw[kHC + r];
-                const int hpos = static_cast<int>(shi) + r;
-                W.cols[bp] = hc; W.inv[hc] = bp;
-                W.cols[hpos] = j; W.inv[j] = hpos;
-                W.fsw.atomic_and(kFsTodo + (j >> 5), ~(1 << (j & 31)));
-              }
-              qpos = shi; qlen = static_cast<unsigned>(done);  // the appended members, in order, are the first `done` sorted events
-            } else {
+            if (conflict) {  // which event's column sits in which head slot
               for (int e = t; e < nev; e += T) {
                 const int off = static_cast<int>(W.fsw[kSK + e]) - static_cast<int>(shi);
                 if (off < nev) W.fsw[kHE + off] = e;
               }
+              g.sync_lds();
+            }
+            for (int r = t; r < P; r += T) {  // the conflict-free prefix: independent swaps
+              const int j = W.fsw[kSJ + r], bp = W.fsw[kSK + r], hc = W.fsw[kHC + r];
+              const int hpos = static_cast<int>(shi) + r;
+              if (!conflict) { W.cols[bp] = hc; W.inv[hc] = bp; }
+              else {
+                if (bp != hpos) {
+                  // the head column moves to the event column's old position; when it is itself the column of a later event (he >= P) or that
+                  // position is a later head slot (off >= P), the tables the serial walk reads are kept current instead
+                  const int he = W.fsw[kHE + r], off = bp - static_cast<int>(shi);
+                  if (off < nev) { W.fsw[kHC + off] = hc; W.fsw[kHE + off] = he; }
+                  else { W.cols[bp] = hc; W.inv[hc] = bp; }
+                  if (he >= 0) W.fsw[kSK + he] = bp;
+                }
+                W.fsw[kSF + r] = static_cast<int>(W.fsw[kSF + r]) | 2;
+              }
+              W.cols[hpos] = j; W.inv[j] = hpos;
+              W.fsw.atomic_and(kFsTodo + (j >> 5), ~(1 << (j & 31)));
+            }
+            if (!conflict) {
+              done = P;
+              if (key != kNoIdx) sink = W.fsw[kSJ + P];
+              qpos = shi; qlen = static_cast<unsigned>(done);  // the appended members, in order, are the first `done` sorted events
+            } else {
               g.sync_lds();
               // one lane, everything through LDS: groups without wavefronts (tests/emu), and a member with more than 64 events
               auto serial_replay = [&](int r0, int e0, int& dn, int& sk) {
@@ -1636,7 +1630,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               if constexpr (has_wave_table<G>::value) {
                 by_wave = true;
                 if (t < 64) {
-                  int dn = 0, sk = -1;
+                  int dn = P, sk = -1;  // (the prefix [0, P) is applied)
                   if (nev <= 64) {
                     // the first wavefront replays out of registers: lane e holds sorted event e and head slot e, the serial walk reads
                     // them with v_readlane and finds the next event with one ballot and one DPP minimum (an LDS round trip per field
@@ -1645,7 +1639,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                     const int vq = in ? static_cast<int>(W.fsw[kSQ + t]) : kNoIdx, vj = in ? static_cast<int>(W.fsw[kSJ + t]) : 0;
                     int vk = in ? static_cast<int>(W.fsw[kSK + t]) : kNoIdx, vf = in ? static_cast<int>(W.fsw[kSF + t]) : 2;
                     int hc = in ? static_cast<int>(W.fsw[kHC + t]) : 0, he = in ? static_cast<int>(W.fsw[kHE + t]) : -1;
-                    for (int r = 0; r < nev; ++r) {
+                    for (int r = P; r < nev; ++r) {
                       const int e0 = __builtin_ctzll(G::wave_ballot(!(vf & 2)));  // first event not applied yet, in sorted order
                       const int q = G::wave_get(vq, e0);
                       const int cand = (!(vf & 2) && vq == q) ? vk : kNoIdx;      // its member's events: the one lowest in cols[] NOW is next
@@ -1673,7 +1667,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                     // holds the l-th of them; the head slots stay in LDS (one uniform read per event: the wavefront's own LDS accesses run in
                     // order, so a slot rewritten by one event is seen by the next). This used to fall to the one-lane loop above: ~3 k cycles
                     // per event, and the steps that take this path are the ones with many events.
-                    int e0 = 0;
+                    int e0 = P;
                     bool fb = false;
                     while (e0 < nev && sk < 0) {
                       const int q = W.fsw[kSQ + e0];
@@ -1716,8 +1710,8 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 }
               }
               if (!by_wave && t == 0) {
-                int dn = 0, sk = -1;
-                serial_replay(0, 0, dn, sk);
+                int dn = P, sk = -1;
+                serial_replay(P, P, dn, sk);
                 W.fsw[kCDONE] = dn;
                 W.fsw[kCSINK] = sk;
               }

@@ -80,6 +80,23 @@ struct EmuGroup {
     return base;
   }
   int flag_rank(bool flag, int* total) { return exclusive_scan(flag ? 1 : 0, total); }
+  struct ScanStop { int base, tot, cnt; };
+  ScanStop scan_until_stop(int v, bool stop) {  // see DevGroup::scan_until_stop
+    auto& a = sh->s_int[phase++ & 1];
+    a[tid_] = v;
+    sync();
+    std::vector<int> vals(a.begin(), a.begin() + sh->T);
+    auto& b = sh->s_int[phase++ & 1];
+    b[tid_] = stop ? 1 : 0;
+    sync();
+    ScanStop r{0, 0, sh->T};
+    for (int t = 0; t < sh->T; ++t) {
+      if (b[t]) { r.cnt = t; break; }
+      if (t < tid_) r.base += vals[t];
+      r.tot += vals[t];
+    }
+    return r;
+  }
   int reduce_sum(int v) { int tot; exclusive_scan(v, &tot); return tot; }
   unsigned long long ballot(bool flag) {
     auto& s = sh->s_int[phase++ & 1];

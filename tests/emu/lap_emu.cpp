@@ -63,6 +63,9 @@ extern "C" int emu_lap_rl16(const float* cost, int nr, int nc, int ld, float thr
   for (auto& t : th) t.join();
   for (int i = 0; i < nr; ++i) x[i] = (W.x[i] >= nc) ? -1 : W.x[i];
   for (int j = 0; j < nc; ++j) y[j] = (W.y[j] >= nr) ? -1 : static_cast<int>(W.y[j]);
+  if (std::getenv("MOT_EMU_LAP_STATS"))
+    std::fprintf(stderr, "emu_lap16 %dx%d T %d: paths %lld finds %lld | steps %lld members %lld real %lld events %lld | one-at-a-time %lld conflict-steps %lld lists %lld\n", nr, nc, T,
+                 cyc[6], cyc[14], cyc[8], cyc[9], cyc[10], cyc[11], cyc[12], cyc[13], cyc[15]);
   // the matched costs must be current at the end: every real pair's entry is the matrix element
   for (int j = 0; j < nc; ++j) {
     const int i = W.y[j];

@@ -216,7 +216,7 @@ def main():
     frame_bytes = S * 6 * M * 4
 
     if args.pipeline <= 0:
-        args.pipeline = {"C2": 3, "SORT": 3, "NS": 3, "C5": 3, "C3": 3, "C4": 6}.get(args.workload, 2)  # measured on MI355X
+        args.pipeline = {"C2": 3, "SORT": 3, "NS": 3, "C5": 3, "C3": 3, "C4": 3}.get(args.workload, 2)  # measured on MI355X
     PIPE = max(1, min(args.pipeline, S))
     bounds = [S * p // PIPE for p in range(PIPE + 1)]
     on_device = tracker in ("bytetrack", "sort", "botsort", "ocsort") and args.lifecycle in ("auto", "device")

@@ -90,6 +90,7 @@ template <int VS, int XS, int DS = kMemGlobal, int BS = kMemGlobal, int CS = kMe
 struct LapWorkT {
   using idx_t = IT;
   static constexpr int kColsSpace = KS;
+  static constexpr bool kLst16 = sizeof(IT) == 2;  // _find_dense's record list as 16-bit entries in lst16 (LDS) instead of lst
   // hot
   MemPtr<double, VS> v;   // column duals
   MemPtr<int, XS> x;      // row -> col (extended)
@@ -113,6 +114,7 @@ struct LapWorkT {
   MemPtr<unsigned long long, kMemGlobal> rl_ent;  // [nr][kRlCap] their (column | cost bits << 32): one 8-byte load per entry, a row's first 16 entries in one 128-byte line
   MemPtr<int, VS == kMemAny ? kMemAny : kMemLds> fsw;  // kFsWsInts ints of fast scratch (always LDS on the device): step members + tie events
   // optional (round 5, with the row lists): what the scan steps would otherwise fetch from global memory per member and per tie event
+  MemPtr<unsigned short, KS> lst16;  // (kLst16) [n] _find_dense's record list
   MemPtr<unsigned char, NS> rl_n;  // [nr] min(rl_cnt, 255), filled after phase 1
   MemPtr<float, YS> ycost;         // [nc] cost(y[j], j) while real column j is held by a real row (a random read of the N x M matrix otherwise: one
                                    // 128-byte line of a 32 MB matrix per member — what evicted a problem's working set from its XCD's L2)
@@ -125,7 +127,8 @@ MOT_HD size_t lap_hot_bytes(int n) { return static_cast<size_t>(n) * (sizeof(dou
 MOT_HD size_t lap_cold_bytes(int n) { return static_cast<size_t>(n) * (2 * sizeof(double) + 9 * sizeof(int) + sizeof(float)); }
 // Row lists (optional scratch of a matrix-cost task, mot_lap_task.rowlist): per real row the entries below thresh/2.
 constexpr int kRlCap = 64;      // entries kept per row (a row with more has no list: its sweeps stay dense)
-constexpr int kFsIter = 4;      // list entries a lane holds in registers during a parallel scan step
+constexpr int kFsIter = 4;      // list entries a lane holds in registers during a parallel scan step (8, i.e. 256 units per step, was measured in round 5: the
+                                // relaxations of so many rows overflow kKeepCap, the step falls back to ONE row, and the solve takes five times as many steps)
 constexpr int kFsUnit = 16;     // the lists are dealt to the lanes in units of this many entries (kRlCap / kFsUnit <= 4 units per row)
 constexpr int kFsMaxUnits = 256;    // units of one step (also bounded by kFsIter * T / kFsUnit)
 constexpr int kFsMaxMembers = 256;  // real-row members of one step (each takes at least one unit)
@@ -398,6 +401,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
   const int T = g.size(), t = g.tid();
   const int nr = P.nr, nc = P.nc, n = nr + nc;
   const double half = P.half;
+  constexpr bool kLst16 = Work::kLst16;  // (then W.lst16 lies over the first (n + 1) / 2 ints of the fast scratch: n <= 2 * kFsEvl, which the LDS budget implies)
 
   long long c0 = MOT_CLOCK();
   long long n_carr = 0, n_paths = 0;
@@ -920,6 +924,10 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           {
             const int first = static_cast<int>(lo) + 1, cnt = n - first;
             const double m0 = W.d[W.cols[lo]];
+            // the list of records: 16-bit entries in LDS for the wide matrix problems (round 5: over the fast scratch's member / unit / column tables,
+            // which are dead between SCAN sets — the column table is emptied again below), the task's global scratch otherwise
+            auto lst_sel = [&]() -> decltype(auto) { if constexpr (kLst16) return (W.lst16); else return (W.lst); };
+            const auto& LST = lst_sel();
             const int L = (cnt + T - 1) / T;
             const int b = first + t * L, e = (b + L < n) ? b + L : n;
             // (round 3) A lane's chunk of cols[] is read ONCE into registers; the records, their compaction into lst[] and the last
@@ -953,7 +961,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               last_strict_reg = g.reduce_max((strict_u >= 0) ? base + strict_u : -1);
 #pragma unroll
               for (int u = 0; u < kFindChunk; ++u)
-                if (recm & (1u << u)) W.lst[base++] = (b + u) - first;
+                if (recm & (1u << u)) LST[base++] = (b + u) - first;
               g.sync();
             } else {
               double cm = 1e300;
@@ -967,7 +975,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 W.tmp[k] = rec;
               }
               g.sync();
-              nrec = compact_ascending(g, cnt, [&](int q) { return W.tmp[first + q] != 0; }, W.lst);
+              nrec = compact_ascending(g, cnt, [&](int q) { return W.tmp[first + q] != 0; }, LST);
             }
             // The replay is serial in the number of records, and on tracking problems most of them are TIES with the final
             // minimum (the dummy block is one big tie: thousands of records per call). After the last record that lowers
@@ -990,8 +998,8 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               if (last_strict_reg > -2) last_strict = last_strict_reg;
               else
               for (int r = t; r < nrec; r += T) {
-                const double dr = W.d[W.cols[first + static_cast<int>(W.lst[r])]];
-                const double dp = r ? static_cast<double>(W.d[W.cols[first + static_cast<int>(W.lst[r - 1])]]) : m0;
+                const double dr = W.d[W.cols[first + static_cast<int>(LST[r])]];
+                const double dp = r ? static_cast<double>(W.d[W.cols[first + static_cast<int>(LST[r - 1])]]) : m0;
                 if (dr < dp) last_strict = r;  // (records are weak: the running minimum before r is record r-1's value)
               }
               if (last_strict_reg == -2) last_strict = g.reduce_max(last_strict);
@@ -1018,7 +1026,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                   const int r = r0 + t;
                   int rk = 0, rj = 0;
                   double rd = 0.0;
-                  if (r < nser) { rk = first + static_cast<int>(W.lst[r]); rj = W.cols[rk]; rd = W.d[rj]; }
+                  if (r < nser) { rk = first + static_cast<int>(LST[r]); rj = W.cols[rk]; rd = W.d[rj]; }
                   const unsigned wb = h2;  // (the first chunk starts at lo + 1: its 64th record may insert at lo + 64)
                   const int win_ch0 = (wb + static_cast<unsigned>(t) < static_cast<unsigned>(n)) ? static_cast<int>(W.cols[wb + t]) : 0;
                   int win_ch = win_ch0;
@@ -1051,7 +1059,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               unsigned h2 = lo + 1;
               double mind = m0;
               for (int r = 0; r < nser; ++r) {
-                const int k = first + W.lst[r];
+                const int k = first + LST[r];
                 const int j = W.cols[k];
                 const double dj = W.d[j];
                 if (dj < mind) { h2 = lo; mind = dj; }
@@ -1074,11 +1082,11 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               const int a = nser, s = first;
               for (int r = t; r < R; r += T) W.tmp[r] = 0;
               g.sync();
-              for (int r = t; r < R; r += T) { const int gq = W.lst[a + r]; if (gq < R && gq != r) W.tmp[gq] = 1; }
+              for (int r = t; r < R; r += T) { const int gq = LST[a + r]; if (gq < R && gq != r) W.tmp[gq] = 1; }
               g.sync();
-              for (int r = t; r < R; r += T) { const int gq = W.lst[a + r]; W.sc[r] = (gq != r && static_cast<int>(W.tmp[r]) == 0) ? 1 : 0; }  // fresh
+              for (int r = t; r < R; r += T) { const int gq = LST[a + r]; W.sc[r] = (gq != r && static_cast<int>(W.tmp[r]) == 0) ? 1 : 0; }  // fresh
               g.sync();
-              for (int r = t; r < R; r += T) { const int gq = W.lst[a + r]; W.tmp[r] = (gq < R) ? gq : r; }
+              for (int r = t; r < R; r += T) { const int gq = LST[a + r]; W.tmp[r] = (gq < R) ? gq : r; }
               g.sync();
               for (;;) {  // pointer jumping, in place
                 int changed = 0;
@@ -1091,11 +1099,11 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
               }
               g.sync();
               for (int r = t; r < R; r += T) {
-                const int gq = W.lst[a + r];
+                const int gq = LST[a + r];
                 W.sa[r] = W.cols[s + gq];
                 if (static_cast<int>(W.sc[r])) {
                   W.sb[r] = W.cols[s + r];
-                  W.sc[r] = 1 + s + static_cast<int>(W.lst[a + static_cast<int>(W.tmp[r])]);  // 1 + destination of the displaced item
+                  W.sc[r] = 1 + s + static_cast<int>(LST[a + static_cast<int>(W.tmp[r])]);  // 1 + destination of the displaced item
                 }
               }
               g.sync();  // every read of the old order is done
@@ -1118,7 +1126,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
   #pragma unroll
                 for (int q = 0; q < kTiePer; ++q) {
                   const int r = t + q * T;
-                  gr[q] = (r < R) ? static_cast<int>(W.lst[a + r]) : 0;  // g(r) = k_r - s
+                  gr[q] = (r < R) ? static_cast<int>(LST[a + r]) : 0;  // g(r) = k_r - s
                   if (r < R) TMP[r] = 0;
                 }
                 sync_t();
@@ -1165,7 +1173,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                     jr[q] = W.cols[s + gr[q]];
                     if (fresh & (1u << q)) {
                       orig[q] = W.cols[s + r];
-                      dst[q] = s + static_cast<int>(W.lst[a + static_cast<int>(TMP[r])]);
+                      dst[q] = s + static_cast<int>(LST[a + static_cast<int>(TMP[r])]);
                     }
                   }
                 }
@@ -1199,6 +1207,12 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 const int j = W.cols[k];
                 W.fsw.atomic_and(kFsTodo + (j >> 5), ~(1 << (j & 31)));
               }
+            if constexpr (kLst16) {
+              if (use_rl) {  // the record list lay over the steps' column table: empty again (every read of the list is behind a barrier by now)
+                g.sync_lds();
+                for (int w = t; w < kFsHash; w += T) { W.fsw[kFsKeep + w] = -1; W.fsw[kFsKeep + kFsHash + w] = kNoIdx; }
+              }
+            }
             hi = h2;
             final_j = (best >= 0) ? static_cast<int>(W.cols[best]) : -1;
           }
@@ -1283,6 +1297,10 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           unsigned qpos = 0u, qlen = 0u;   // SCAN positions [qpos, qpos + qlen) were appended by the last step: their members are in the sorted event table
           bool need_full = false;          // stores to cols[] that the next classification reads from memory are still in flight
           bool stepped = false;            // a step ran in this SCAN set (its stores need a full barrier before anyone else reads them)
+          // the matched cost of the member this lane will classify in the NEXT step, requested as soon as this step knows how many members it takes:
+          // the one global load on a step's classification path (the costs do not fit next to the LDS state), a round trip every wavefront waited for
+          unsigned pfc_idx = 0xffffffffu;
+          float pfc_cost = 0.f;
           auto fast_step_body = [&](double mind_b) -> int {  // 0: nothing done, 1: members consumed, 2: a sink was reached (final_j set)
             const long long q0 = MOT_FCLOCK();
             if (need_full) { if constexpr (kColsLds) g.sync_lds(); else g.sync(); need_full = false; }
@@ -1306,7 +1324,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 md = W.d[mj];
                 if (mi < nr) {
                   mcnt = rl_len(mi);
-                  if (mj < nc) cij = match_cost(mi, mj);
+                  if (mj < nc) cij = (have_yc && pfc_idx == idx) ? static_cast<double>(pfc_cost) : match_cost(mi, mj);
                 }
               }
               if (md == mind_b) {
@@ -1330,6 +1348,14 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             const auto sc = g.scan_until_stop(spc ? (1 | (nu << 12)) : 0, cls == 0);
             int cnt = sc.cnt;
             if (cnt == 0) { cy_cls += MOT_FCLOCK() - q0; return 0; }
+            if (have_yc) {  // (the step may still end earlier than cnt — the units cap, the one-row fallback: then the prefetched index does not match and the load is repeated)
+              const unsigned nidx = slo + static_cast<unsigned>(cnt) + static_cast<unsigned>(t);
+              pfc_idx = 0xffffffffu;
+              if (nidx < shi) {
+                const int nj = W.cols[nidx];
+                if (nj < nc) { pfc_cost = W.ycost[nj]; pfc_idx = nidx; }
+              }
+            }
             const bool sp = spc && t < cnt;
             const int rank = sc.base & 0xfff, ubase = sc.base >> 12;
             int ns = sc.tot & 0xfff, U = sc.tot >> 12;

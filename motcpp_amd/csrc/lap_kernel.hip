@@ -121,7 +121,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   // mode 4 (distances in LDS for the scan steps) exists for cost flavour 1 only
   if (fs_lds && wide && !general_assoc && b4 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 4; lds = b4; }
   static const bool lds16_ok = !(std::getenv("MOT_LAP_LDS16") && std::getenv("MOT_LAP_LDS16")[0] == '0');  // (A/B measurements)
-  if (lds16_ok && fs_lds && wide && !general_assoc && nm <= 30000 && b6 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 6; lds = b6; }
+  if (lds16_ok && fs_lds && wide && !general_assoc && nm <= 2 * static_cast<size_t>(mot::kFsEvl) && b6 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 6; lds = b6; }
   // lane-owned column boxes in registers: one wavefront per problem, <= 8 real columns per lane
   int rpl = 0;
   if (geom && !wide && !general_assoc) rpl = (m <= 256) ? 4 : (m <= 512 ? 8 : 0);

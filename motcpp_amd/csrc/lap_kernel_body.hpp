@@ -182,6 +182,7 @@ __device__ __forceinline__ void lap_one(const mot_lap_task& T, int check_status,
     W.y.p = reinterpret_cast<short*>(q); q += 2 * static_cast<size_t>(n);
     W.cols.p = reinterpret_cast<short*>(q); q += 2 * static_cast<size_t>(n);
     W.inv.p = reinterpret_cast<short*>(q); q += 2 * static_cast<size_t>(n);
+    W.lst16.p = reinterpret_cast<unsigned short*>(smem + kScratch);  // over the fast scratch (fs_lds is set for every launch of this mode)
     if (W.rl_cnt.p != nullptr) {  // (the row lists are in use)
       W.rl_n.p = reinterpret_cast<unsigned char*>(q);
       W.ycost.p = W.rmin.p;  // nc floats of the cold scratch that only the on-the-fly costs use otherwise

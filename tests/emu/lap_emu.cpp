@@ -50,6 +50,7 @@ extern "C" int emu_lap_rl16(const float* cost, int nr, int nc, int ld, float thr
   lap_carve_cold(W, mem.data() + ((lap_hot_bytes(n) + 7) & ~size_t(7)), n);
   lap_carve_rowlist(W, rl.data(), nr);
   W.fsw.p = fsw.data();
+  W.lst16.p = reinterpret_cast<unsigned short*>(fsw.data());  // as in the kernel: over the fast scratch's tables
   W.rl_n.p = rn.data();
   W.ycost.p = yc.data();
   long long cyc[16] = {0};

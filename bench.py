@@ -724,12 +724,14 @@ def main():
             bt_sweep = {}
             try:
                 Fb = min(F, zs + 30)
-                for T in [t for t in (1, 16, 64, 256) if t <= S]:
+                for T in [t for t in (1, 16, 64, 256, 1024) if t <= S]:
                     dd = np.ascontiguousarray(host[:Fb, :T].transpose(1, 0, 2, 3))
                     L.pool_stats(reset=True)
-                    res, _cs = L.bench_threads(tracker, dd, np.full((T, Fb), M, np.int32), warm=zs, device=local)
+                    # 300 timed update() calls per object (the resident frames played back and forth), p50 / p99 of their latencies
+                    res, _cs = L.bench_threads(tracker, dd, np.full((T, Fb), M, np.int32), warm=zs, device=local, frames=zs + 300)
                     ps_ = L.pool_stats()
-                    bt_sweep[f"T{T}"] = {"frames/s": res["frames_per_s"], "ms_per_update_mean": res["latency_ms_mean"], "ms_per_update_max": res["latency_ms_max"],
+                    bt_sweep[f"T{T}"] = {"frames/s": res["frames_per_s"], "ms_per_update_p50": res["latency_ms_p50"], "ms_per_update_p99": res["latency_ms_p99"],
+                                         "ms_per_update_mean": res["latency_ms_mean"], "ms_per_update_max": res["latency_ms_max"],
                                          "frames_timed": res["frames"], "launch_sequences": ps_["rounds"], "largest_round": ps_["max_round"]}
                 bt_sweep["note"] = ("T objects of motcpp::trackers::" + {"bytetrack": "ByteTrack", "sort": "Sort", "ocsort": "OCSort"}[tracker] + " on T host threads, "
                                     "update(dets, img) with HOST detections (Eigen matrices; PCIe, the combiner's batching window and the copy of the result "

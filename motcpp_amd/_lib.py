@@ -262,6 +262,8 @@ def host():
         H.motcpp_pool_stats.argtypes = [C.c_void_p, C.c_int]
         H.motcpp_bench_threads.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_void_p, C.c_void_p]
+        H.motcpp_bench_threads_ex.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         H.motcpp_tracker_destroy.argtypes = [C.c_void_p]
         H.motcpp_tracker_reset.argtypes = [C.c_void_p]
         H.motcpp_tracker_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -410,21 +412,24 @@ def pool_stats(reset=False):
             "us_enqueue": a[7]}
 
 
-def bench_threads(kind, dets, counts, warm, params=None, device=0):
+def bench_threads(kind, dets, counts, warm, params=None, device=0, frames=None):
     """T tracker objects of the C++ classes on T host threads, each calling BaseTracker::update on host detections
-    (motcpp_bench_threads). dets [T, F, N, 6], counts [T, F]. Returns a dict (seconds of the timed part, frames, rows, latencies)
-    and the per-tracker id checksums."""
+    (motcpp_bench_threads_ex). dets [T, F, N, 6], counts [T, F]; frames (default F): updates per object, the F given frames played back
+    and forth when it is larger. Returns a dict (seconds of the timed part, frames, rows, latencies incl. p50 / p99 / p99.9 over all timed
+    calls) and the per-tracker id checksums."""
     kind = KIND.get(kind, kind)
     dets, counts = f32(dets), np.ascontiguousarray(counts, np.int32)
     T, F, N = dets.shape[0], dets.shape[1], dets.shape[2]
     p = f32(params if params is not None else [])
     out = np.zeros(5, np.float64)
+    pct = np.zeros(3, np.float64)
     cs = np.zeros(T, np.float64)
-    rc = host().motcpp_bench_threads(int(kind), _p(p) if p.size else None, int(p.size), T, F, int(warm), _p(dets), _p(counts), N, int(device),
-                                     _p(out), _p(cs))
+    rc = host().motcpp_bench_threads_ex(int(kind), _p(p) if p.size else None, int(p.size), T, int(frames or F), int(warm), _p(dets), _p(counts), N,
+                                        int(device), _p(out), _p(cs), F, _p(pct))
     if rc != 0:
         raise MotError("motcpp_bench_threads failed")
     return {"seconds": out[0], "frames": int(out[1]), "rows": int(out[2]), "latency_ms_mean": out[3], "latency_ms_max": out[4],
+            "latency_ms_p50": pct[0], "latency_ms_p99": pct[1], "latency_ms_p999": pct[2],
             "frames_per_s": out[1] / out[0] if out[0] > 0 else 0.0}, cs
 
 

@@ -2,6 +2,7 @@
 // BaseTracker::update(dets, img) (include/motcpp/tracker.hpp:67-69, docs/guides/architecture.md:242-255) — timed end to end.
 // The objects are the public classes (motcpp::trackers::*), the detections are host Eigen matrices: this is the number a user of
 // the drop-in surface sees, PCIe and the combiner's batching window included.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -38,19 +39,30 @@ std::unique_ptr<motcpp::BaseTracker> make_tracker(int kind, const float* p, int 
 }
 }  // namespace
 
+// out5: wall seconds, timed updates, rows, mean latency (ms), largest latency (ms); lat_pct (optional, 3 doubles): p50 / p99 / p99.9 of the timed
+// update() calls' latencies over all objects (ms). `frames` may exceed the number of distinct frames given (`distinct` > 0): object t then plays
+// its frames back and forth (0 .. distinct-1 .. 0 ..), so that a long timed region needs no more input than a short one.
+extern "C" int motcpp_bench_threads_ex(int kind, const float* params, int nparams, int T, int frames, int warm, const float* dets, const int* counts,
+                                       int max_n, int device, double* out5, double* checksum, int distinct, double* lat_pct);
 extern "C" int motcpp_bench_threads(int kind, const float* params, int nparams, int T, int frames, int warm, const float* dets, const int* counts,
                                     int max_n, int device, double* out5, double* checksum) {
+  return motcpp_bench_threads_ex(kind, params, nparams, T, frames, warm, dets, counts, max_n, device, out5, checksum, 0, nullptr);
+}
+extern "C" int motcpp_bench_threads_ex(int kind, const float* params, int nparams, int T, int frames, int warm, const float* dets, const int* counts,
+                                       int max_n, int device, double* out5, double* checksum, int distinct, double* lat_pct) {
   using clk = std::chrono::steady_clock;
   if (T <= 0 || frames <= 0 || warm < 0 || warm >= frames || !dets || !counts || !out5) return -1;
   std::vector<std::unique_ptr<motcpp::BaseTracker>> trk(T);
   for (int t = 0; t < T; ++t) { trk[t] = make_tracker(kind, params, nparams, device); if (!trk[t]) return -1; }
   // the frames as the caller of the reference would hold them: one column-major N x 6 matrix per frame
-  std::vector<std::vector<Eigen::MatrixXf>> in(T, std::vector<Eigen::MatrixXf>(frames));
+  const int nd = (distinct > 0 && distinct < frames) ? distinct : frames;  // distinct frames per object
+  auto frame_of = [nd](int f) { if (nd <= 1) return 0; const int period = 2 * (nd - 1); const int q = f % period; return q < nd ? q : period - q; };
+  std::vector<std::vector<Eigen::MatrixXf>> in(T, std::vector<Eigen::MatrixXf>(nd));
   for (int t = 0; t < T; ++t)
-    for (int f = 0; f < frames; ++f) {
-      const int n = counts[static_cast<size_t>(t) * frames + f];
+    for (int f = 0; f < nd; ++f) {
+      const int n = counts[static_cast<size_t>(t) * nd + f];
       Eigen::MatrixXf m(n, 6);
-      const float* src = dets + (static_cast<size_t>(t) * frames + f) * max_n * 6;
+      const float* src = dets + (static_cast<size_t>(t) * nd + f) * max_n * 6;
       for (int i = 0; i < n; ++i)
         for (int k = 0; k < 6; ++k) m(i, k) = src[static_cast<size_t>(i) * 6 + k];
       in[t][f] = std::move(m);
@@ -61,11 +73,13 @@ extern "C" int motcpp_bench_threads(int kind, const float* params, int nparams, 
   int arrived = 0;
   std::string err;
   std::vector<double> lat_sum(T, 0.0), lat_max(T, 0.0), csum(T, 0.0);
+  std::vector<std::vector<float>> lats(T);
+  if (lat_pct) for (auto& v : lats) v.reserve(static_cast<size_t>(frames - warm));
   std::vector<long> rows(T, 0);
   std::vector<clk::time_point> t0(T), t1(T);
   auto body = [&](int t) {
     try {
-      for (int f = 0; f < warm; ++f) (void)trk[t]->update(in[t][f], img);
+      for (int f = 0; f < warm; ++f) (void)trk[t]->update(in[t][frame_of(f)], img);
       {
         std::unique_lock<std::mutex> lk(mu);
         if (++arrived == T) cv.notify_all();
@@ -74,9 +88,10 @@ extern "C" int motcpp_bench_threads(int kind, const float* params, int nparams, 
       t0[t] = clk::now();
       for (int f = warm; f < frames; ++f) {
         const auto a = clk::now();
-        const Eigen::MatrixXf out = trk[t]->update(in[t][f], img);
+        const Eigen::MatrixXf out = trk[t]->update(in[t][frame_of(f)], img);
         const double ms = std::chrono::duration<double, std::milli>(clk::now() - a).count();
         lat_sum[t] += ms;
+        if (lat_pct) lats[t].push_back(static_cast<float>(ms));
         if (ms > lat_max[t]) lat_max[t] = ms;
         rows[t] += static_cast<long>(out.rows());
         for (Eigen::Index i = 0; i < out.rows(); ++i) csum[t] += static_cast<double>(out(i, 4)) * (1.0 + static_cast<double>(out(i, 7)));
@@ -107,5 +122,12 @@ extern "C" int motcpp_bench_threads(int kind, const float* params, int nparams, 
   const double n_timed = static_cast<double>(T) * (frames - warm);
   out5[0] = std::chrono::duration<double>(last - first).count();
   out5[1] = n_timed; out5[2] = static_cast<double>(r); out5[3] = ls / n_timed; out5[4] = lm;
+  if (lat_pct) {
+    std::vector<float> all;
+    for (auto& v : lats) all.insert(all.end(), v.begin(), v.end());
+    std::sort(all.begin(), all.end());
+    auto pct = [&](double q) { return all.empty() ? 0.0 : static_cast<double>(all[static_cast<size_t>(q * static_cast<double>(all.size() - 1))]); };
+    lat_pct[0] = pct(0.5); lat_pct[1] = pct(0.99); lat_pct[2] = pct(0.999);
+  }
   return 0;
 }

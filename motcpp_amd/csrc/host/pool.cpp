@@ -10,6 +10,10 @@
 #include <stdexcept>
 #include <thread>
 
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include "runtime.hpp"
 
 namespace motcpp::rt {
@@ -77,9 +81,7 @@ struct Request {
   Segment* from = nullptr;
   int from_s = -1;
   bool also_reset = false;  // pre == 2 with a reset() pending: the moved stream is reset right behind the move
-  // results (written under the segment's lock; the owner sleeps on its own condition variable: a wake-up goes to exactly one thread)
-  std::condition_variable cv;
-  bool done = false, lead = false, owner = false;
+  // results (written by the round's leader before it publishes the round as completed)
   std::atomic<int> copy_state{0};  // 0 not staged yet, 1 being copied, 2 in the staging buffer
   std::string error;
   const float* rows = nullptr;
@@ -116,6 +118,7 @@ class Segment {
     counts_.assign(S, -1); ld_.assign(S, 0); det_off_.assign(S, 0); emb_off_.assign(S, -1);
     warps_.assign(static_cast<size_t>(S) * 6, 0.f); has_warp_.assign(S, 0);
     window_us_ = env_long("MOTCPP_BATCH_WINDOW_US", 60);
+    gap_us_ = env_long("MOTCPP_BATCH_GAP_US", 20);
   }
   ~Segment() { release(); }
 
@@ -129,39 +132,43 @@ class Segment {
   int used() const { return S - static_cast<int>(free_.size()); }
 
   // Joins the open round with one frame of each of the k streams reqs[i]->s (all of this segment) and returns when the round has run.
+  // Round 5: the FIRST caller of a round is its leader (no hand-over: it waits for the previous round to finish, closes its own and runs it);
+  // everybody else sleeps on the round's futex word, which the leader bumps once when the results are in place — one system call wakes all of
+  // them and none of them has a lock to take on the way out. (Round 4: a condition variable per request, all on the segment's mutex — the leader
+  // made one notify call per caller and every woken caller queued for the mutex again: with 256 objects on 16 CPUs a round spent twice as
+  // long handing out its results as running.)
   void join(Request* const* reqs, int k) {
-    std::unique_lock<std::mutex> lk(mu_);
-    const uint64_t r = open_;
-    Round& R = rounds_[r & 1];
-    for (int i = 0; i < k; ++i) {
-      Request& q = *reqs[i];
-      const int n = q.in->n;
-      q.n = n;
-      q.ld = (n + 3) & ~3;
-      if (q.ld < 4) q.ld = 4;
-      q.det_off = static_cast<long long>(R.det_top);
-      R.det_top += static_cast<size_t>(6) * q.ld;
-      const bool with_emb = q.in->embs != nullptr && E > 0 && n > 0;
-      q.emb_off = -1;
-      if (with_emb) { q.emb_off = static_cast<long long>(R.emb_top); R.emb_top += static_cast<size_t>(n) * E; }
+    uint64_t r;
+    bool first;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      r = open_;
+      Round& R = rounds_[r & 1];
+      first = R.reqs.empty();
+      for (int i = 0; i < k; ++i) {
+        Request& q = *reqs[i];
+        const int n = q.in->n;
+        q.n = n;
+        q.ld = (n + 3) & ~3;
+        if (q.ld < 4) q.ld = 4;
+        q.det_off = static_cast<long long>(R.det_top);
+        R.det_top += static_cast<size_t>(6) * q.ld;
+        const bool with_emb = q.in->embs != nullptr && E > 0 && n > 0;
+        q.emb_off = -1;
+        if (with_emb) { q.emb_off = static_cast<long long>(R.emb_top); R.emb_top += static_cast<size_t>(n) * E; }
+      }
+      for (int i = 0; i < k; ++i) { reqs[i]->copy_state.store(0, std::memory_order_relaxed); R.reqs.push_back(reqs[i]); }
+      joined_[r & 1].store(static_cast<int>(R.reqs.size()), std::memory_order_release);
     }
-    for (int i = 0; i < k; ++i) { reqs[i]->owner = (i == 0); reqs[i]->copy_state.store(0, std::memory_order_relaxed); R.reqs.push_back(reqs[i]); }
-    lk.unlock();
     // the caller's own copy into the round's page-locked staging, in parallel with the other callers' (a caller that loses the CPU
     // before it gets here is helped out by the round's leader: whoever flips copy_state first does the copy)
     for (int i = 0; i < k; ++i) stage(*reqs[i], static_cast<int>(r & 1));
-    lk.lock();
-    auto all_done = [&] { for (int i = 0; i < k; ++i) if (!reqs[i]->done) return false; return true; };
-    auto any_lead = [&] { return reqs[0]->lead; };
-    if (all_done()) return;  // (the round ran while this thread was off the CPU: its leader staged the frame for it)
-    if (any_lead()) { lead(lk, r); return; }
-    if (!leader_active_) {  // (not done => nobody has closed round r: it is still the open one)
-      leader_active_ = true;
-      lead(lk, r);
+    if (first) {
+      const bool idle = completed_.load(std::memory_order_acquire) >= r;  // nothing in flight: peers in lockstep may be a few microseconds behind
+      wait_completed(r, static_cast<int>((r + 1) & 1));                   // (round r - 1 carries the other parity)
+      lead(r, idle);
     } else {
-      if (leader_waiting_) leader_cv_.notify_one();  // (the leader of this round may be waiting for this arrival's copy)
-      reqs[0]->cv.wait(lk, [&] { return all_done() || any_lead(); });  // (k requests of one caller: the leader signals the first)
-      if (!all_done()) lead(lk, r);
+      wait_completed(r + 1, static_cast<int>(r & 1));
     }
   }
   // copies q's detections (and features) into the staging buffer of its round unless somebody else already does / did
@@ -190,11 +197,7 @@ class Segment {
     q.copy_state.store(2, std::memory_order_release);
   }
   // (after the caller has taken its rows: the round's page-locked table may be rewritten two rounds later)
-  void rows_taken(int parity, int k = 1) {
-    std::lock_guard<std::mutex> g(mu_);
-    outstanding_[parity] -= k;
-    if (outstanding_[parity] == 0 && leader_waiting_) leader_cv_.notify_one();
-  }
+  void rows_taken(int parity, int k = 1) { outstanding_[parity].fetch_sub(k, std::memory_order_acq_rel); }
   int kind() const { return kind_; }
   int level() const { return level_; }
   void* batch() const { return batch_; }
@@ -207,41 +210,65 @@ class Segment {
     size_t det_top = 0, emb_top = 0;
     std::vector<Request*> reqs;
   };
+  static void futex_wait(std::atomic<uint32_t>* w, uint32_t seen) {
+    syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+  }
+  static void futex_wake_all(std::atomic<uint32_t>* w) { syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAKE_PRIVATE, 0x7fffffff, nullptr, nullptr, 0); }
+  // returns once `want` rounds have completed; sleeps on the word of the round it is waiting for (parity `p`)
+  void wait_completed(uint64_t want, int p) {
+    for (;;) {  // (a lone object never sleeps here: it leads every round and the previous one is its own)
+      const uint32_t seen = word_[p].load(std::memory_order_acquire);
+      if (completed_.load(std::memory_order_acquire) >= want) return;
+      futex_wait(&word_[p], seen);
+    }
+  }
 
-  // The calling thread runs round r (mu_ held on entry and on return).
-  void lead(std::unique_lock<std::mutex>& lk, uint64_t r) {
-    Round& R = rounds_[r & 1];
+  // The calling thread (the round's first caller) runs round r; the previous round has completed.
+  void lead(uint64_t r, bool idle) {
+    const int p = static_cast<int>(r & 1);
     using clk = std::chrono::steady_clock;
     auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     const auto t_a = clk::now();
-    // batching window: give the streams that took part in the last rounds a moment to arrive (the more there are, the longer their
-    // threads take to get a CPU each)
+    // Batching window, only when the leader found the GPU idle (had it to wait for the previous round, everybody who arrived meanwhile is in
+    // already and closing at once is the group commit): objects stepped in lockstep come back within microseconds of each other — the round
+    // stays open while they keep arriving (no arrival for `gap` microseconds closes it), until the streams of the last rounds are all in,
+    // at most window_us_ + 40 us.
     const int expected = (last_batch_ > prev_batch_) ? last_batch_ : prev_batch_;
-    if (static_cast<int>(R.reqs.size()) < expected && window_us_ > 0) {
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us_ + 2 * expected);
-      while (static_cast<int>(R.reqs.size()) < expected && std::chrono::steady_clock::now() < deadline) {
-        lk.unlock();
+    if (idle && window_us_ > 0 && joined_[p].load(std::memory_order_acquire) < expected) {
+      // (round 4 waited up to window + 2 us per expected stream: 570 us of idle GPU per round with 256 objects on 16 CPUs, whose threads take that
+      // long to get a CPU each. Whoever is late simply rides the next round, which fills while this one runs.)
+      const auto hard = t_a + std::chrono::microseconds(window_us_ + (expected < 20 ? 2 * expected : 40));
+      const auto gap = std::chrono::microseconds(gap_us_);
+      int seen = joined_[p].load(std::memory_order_acquire);
+      auto last_arrival = t_a;
+      for (;;) {
         std::this_thread::yield();
-        lk.lock();
+        const auto now = clk::now();
+        const int j = joined_[p].load(std::memory_order_acquire);
+        if (j >= expected || now >= hard) break;
+        if (j != seen) { seen = j; last_arrival = now; }
+        else if (now - last_arrival >= gap) break;
       }
     }
-    open_ = r + 1;  // closed: later arrivals fill the other round
-    const auto t_b = clk::now();
     std::vector<Request*> reqs;
-    reqs.swap(R.reqs);
-    const size_t det_top = R.det_top, emb_top = R.emb_top;
-    R.det_top = 0; R.emb_top = 0;
-    lk.unlock();
-    for (Request* q : reqs) stage(*q, static_cast<int>(r & 1));  // the callers that have not got to their copy yet
-    lk.lock();
-    auto staged = [&] { for (Request* q : reqs) if (q->copy_state.load(std::memory_order_acquire) != 2) return false; return true; };
-    leader_waiting_ = true;
-    leader_cv_.wait(lk, [&] { return staged() && outstanding_[r & 1] == 0; });  // copies in progress; readers of the table two rounds back
-    leader_waiting_ = false;
-    lk.unlock();
+    size_t det_top, emb_top;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      Round& R = rounds_[p];
+      open_ = r + 1;  // closed: later arrivals fill the other round
+      reqs.swap(R.reqs);
+      det_top = R.det_top; emb_top = R.emb_top;
+      R.det_top = 0; R.emb_top = 0;
+      joined_[p].store(0, std::memory_order_relaxed);
+    }
+    const auto t_b = clk::now();
+    for (Request* q : reqs) stage(*q, p);  // the callers that have not got to their copy yet
+    for (Request* q : reqs)                // copies in progress on their owners' threads
+      while (q->copy_state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
+    while (outstanding_[p].load(std::memory_order_acquire) != 0) std::this_thread::yield();  // readers of the table two rounds back
     const auto t_c = clk::now();
     std::string err;
-    try { run(reqs, static_cast<int>(r & 1), det_top, emb_top); }
+    try { run(reqs, p, det_top, emb_top); }
     catch (const std::exception& e) { err = e.what(); }
     const auto t_d = clk::now();
     {
@@ -249,23 +276,16 @@ class Segment {
       g_stats.us_window += us(t_a, t_b); g_stats.us_gather += us(t_b, t_c); g_stats.us_run += us(t_c, t_d);
       g_stats.us_enqueue += last_enqueue_us_;
     }
-    lk.lock();
     prev_batch_ = last_batch_;
     last_batch_ = static_cast<int>(reqs.size());
-    outstanding_[r & 1] = static_cast<int>(reqs.size());
-    // a caller may have several requests in the round (StreamBatch): its thread sleeps on the first one it pushed (`owner`)
     for (Request* q : reqs) {
       q->round = r;
       if (!err.empty()) q->error = err;
-      q->done = true;
     }
-    for (Request* q : reqs) if (q->owner) q->cv.notify_one();
-    Round& N = rounds_[(r + 1) & 1];
-    if (!N.reqs.empty()) {
-      Request* head = N.reqs.front();  // (the first request of a caller: the one its thread waits on)
-      head->lead = true;
-      head->cv.notify_one();
-    } else leader_active_ = false;
+    outstanding_[p].store(static_cast<int>(reqs.size()), std::memory_order_release);
+    completed_.store(r + 1, std::memory_order_release);
+    word_[p].fetch_add(1, std::memory_order_release);
+    futex_wake_all(&word_[p]);  // this round's callers, and the leader of the next round if it is waiting already
   }
 
   void run(const std::vector<Request*>& reqs, int parity, size_t det_top, size_t emb_top) {
@@ -340,15 +360,15 @@ class Segment {
   float* d_embs_ = nullptr; float* h_embs_[2] = {nullptr, nullptr};
   std::vector<int> free_;
   // combiner
-  std::mutex mu_;
-  std::condition_variable leader_cv_;
-  bool leader_waiting_ = false;
+  std::mutex mu_;                          // the open round's request list and staging offsets
   Round rounds_[2];
-  uint64_t open_ = 0;
-  bool leader_active_ = false;
-  int last_batch_ = 0, prev_batch_ = 0;
-  int outstanding_[2] = {0, 0};
-  long window_us_ = 60;
+  uint64_t open_ = 0;                      // the round that is filling (mu_)
+  std::atomic<uint64_t> completed_{0};     // rounds whose results are delivered (rounds run strictly one after the other)
+  std::atomic<uint32_t> word_[2] = {{0}, {0}};  // futex words, by round parity: bumped when a round of that parity completes
+  std::atomic<int> joined_[2] = {{0}, {0}};     // requests in the open round of that parity (the leader's window reads it without the lock)
+  std::atomic<int> outstanding_[2] = {{0}, {0}};  // callers that have not copied their rows out of that parity's table yet
+  int last_batch_ = 0, prev_batch_ = 0;    // (leader only)
+  long window_us_ = 60, gap_us_ = 20;
   double last_enqueue_us_ = 0.0;
   // leader's scratch
   std::vector<int> counts_, ld_, offs_;

@@ -16,7 +16,7 @@ WORK = {"NS": ("bytetrack", 1000, 500, 70, 40), "C2": ("bytetrack", 256, 128, 70
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "NS"
-    Ts = [int(a) for a in sys.argv[2:]] or [1, 16, 64, 256]
+    Ts = [int(a) for a in sys.argv[2:]] or [1, 16, 64, 256, 1024]
     kind, P, M, F, warm = WORK[name]
     Tmax = max(Ts)
     base = [SynthStream(P, M, 1234 + t).frames(F)[0] for t in range(min(Tmax, 32))]  # 32 distinct cameras, reused with an offset
@@ -27,10 +27,11 @@ def main():
             dets[t, :, :, 0:4:2] += 0.25 * (t // len(base))  # a slightly shifted copy: different floats, same structure
     counts = np.full((Tmax, F), M, np.int32)
     out = {}
+    timed = int(__import__("os").environ.get("MOT_POOLED_TIMED_FRAMES", "300"))  # timed update() calls per object (the F frames played back and forth)
     for T in Ts:
         L.pool_stats(reset=True)
         t0 = time.time()
-        res, _ = L.bench_threads(kind, dets[:T], counts[:T], warm)
+        res, _ = L.bench_threads(kind, dets[:T], counts[:T], warm, frames=warm + timed)
         res["wall_s"] = round(time.time() - t0, 3)
         res["pool"] = L.pool_stats()
         out[f"T{T}"] = res

@@ -34,6 +34,14 @@ std::unique_ptr<motcpp::BaseTracker> make_tracker(int kind, const float* p, int 
     case 3: return std::make_unique<BotSort>("", false, false, 0.3f, static_cast<int>(P(10, 30)), static_cast<int>(P(11, 50)), 3, 0.3f, false, 80, "iou", false, P(0, 0.5f),
                                              P(1, 0.1f), P(2, 0.6f), static_cast<int>(P(3, 30)), P(4, 0.8f), P(5, 0.5f), P(6, 0.25f), "none", static_cast<int>(P(7, 30)),
                                              P(8, 0.f) != 0.f, P(9, 1.f) != 0.f, device);
+    // SURVEY 8 f3 (host stage machines; round 5: concurrent update() calls are merged by run_frame_combined): reference defaults, the given device
+    case 4: return std::make_unique<DeepOCSort>("", false, false, 0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 3, 0.2f, 0.5f, 0.95f, 0.5f, /*embedding_off (this harness carries no embeddings)*/ true, false, false, 0.01f, 0.0001f, device);
+    case 5: return std::make_unique<StrongSORT>("", false, false, 0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 0.1f, 0.2f, 0.7f, 3, 100, 0.98f, 0.9f, device);
+    case 6: return std::make_unique<UCMCTrack>(0.3f, 30, 50, 3, 0.3f, false, 80, "iou", false, 100.0, 100.0, 5.0, 5.0, 10.0, 1.0 / 30.0, 0.5f, std::vector<double>{}, std::vector<double>{}, device);
+    case 7: return std::make_unique<BoostTrackTracker>("", false, false, 0.6f, 60, 50, 3, 0.3f, false, 80, "iou", false, false, 10, 1.6f, "ecc", 0.5f, 0.25f, 0.25f, true, true, 0.65f,
+                                                       false, false, false, false, false, device);
+    case 8: return std::make_unique<HybridSort>("", false, false, 0.7f, 30, 50, 3, 0.15f, false, 80, "hmiou", false, 0.1f, 3, 0.05f, true, true, 30, 0.9f, false, 0.5f, 4.6f, 1.3f,
+                                                true, true, 1.0f, 0.7f, true, 0.0f, true, 0.4f, 0.4f, "ecc", false, device);
   }
   return nullptr;
 }

@@ -182,7 +182,7 @@ int motcpp_tracker_update(motcpp_tracker* t, const float* dets, int n, const flo
     }
     FrameIn in = frame_in(t->colmajor, n, embs, d);
     Staged* s = t->impl.get();
-    run_frame(*t->dev, &s, &in, 1);
+    run_frame_combined(t->dev, s, in);  // (merged with the calls other threads make on trackers of the same Device)
     return copy_rows(s->rows(), out, cap);
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }

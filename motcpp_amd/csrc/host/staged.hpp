@@ -88,6 +88,13 @@ class Staged {
 // Runs one frame for a set of trackers sharing a Device in lockstep: one kernel launch per kernel family per stage.
 void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, Team* team = nullptr);
 
+// update() calls of host-lifecycle tracker OBJECTS that arrive together from different host threads (round 5: DeepOCSort, StrongSORT,
+// UCMCTrack, BoostTrack, HybridSort — the trackers without a device lifecycle): the first caller of a round leads it and steps every
+// joined stage machine in ONE run_frame (3-5 flushes per frame however many cameras), the others sleep until their rows are there.
+// Before, every call took the Device's frame mutex for its whole update(): T threads ran one frame at a time. Same combiner as the
+// pooled device streams (host/pool.cpp): futex rounds, a window of at most 100 us when the GPU was idle, group commit otherwise.
+void run_frame_combined(const std::shared_ptr<Device>& dev, Staged* tracker, const FrameIn& input);
+
 // factories (parameter vectors: same layout as documented in include/motcpp_c.h)
 Staged* make_sort(std::shared_ptr<Device>, float det_thresh, int max_age, int max_obs, int min_hits, float iou_threshold);
 Staged* make_bytetrack(std::shared_ptr<Device>, float min_conf, float track_thresh, float match_thresh, int track_buffer,

@@ -3,13 +3,22 @@
 #include <chrono>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <stdexcept>
+#include <thread>
+
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "motcpp/motcpp.hpp"
 #include "pool.hpp"
 #include "staged.hpp"
+#include "team.hpp"
 
 namespace motcpp {
 
@@ -100,6 +109,118 @@ void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int 
     for (int a : any_w) any |= a;
     if (!any) break;
   }
+}
+
+// ---- rounds of host stage machines (see staged.hpp) ---------------------------------------------------------------------
+namespace {
+class HostRounds {
+ public:
+  explicit HostRounds(Device* d) : dev_(d) {
+    const char* e = std::getenv("MOTCPP_BATCH_WINDOW_US");
+    if (e && *e) window_us_ = std::atol(e);
+  }
+  void update(Staged* s, const FrameIn& in) {
+    Req me{s, &in, {}};
+    uint64_t r;
+    bool first;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      r = open_;
+      first = reqs_[r & 1].empty();
+      reqs_[r & 1].push_back(&me);
+      joined_[r & 1].store(static_cast<int>(reqs_[r & 1].size()), std::memory_order_release);
+    }
+    if (first) {
+      const bool idle = completed_.load(std::memory_order_acquire) >= r;
+      wait_completed(r, static_cast<int>((r + 1) & 1));
+      lead(r, idle);
+    } else {
+      wait_completed(r + 1, static_cast<int>(r & 1));
+    }
+    if (!me.error.empty()) throw Error(me.error);
+  }
+
+ private:
+  struct Req { Staged* s; const FrameIn* in; std::string error; };
+  static void futex_wait(std::atomic<uint32_t>* w, uint32_t seen) { syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); }
+  static void futex_wake_all(std::atomic<uint32_t>* w) { syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAKE_PRIVATE, 0x7fffffff, nullptr, nullptr, 0); }
+  void wait_completed(uint64_t want, int p) {
+    for (;;) {
+      const uint32_t seen = word_[p].load(std::memory_order_acquire);
+      if (completed_.load(std::memory_order_acquire) >= want) return;
+      futex_wait(&word_[p], seen);
+    }
+  }
+  void lead(uint64_t r, bool idle) {
+    using clk = std::chrono::steady_clock;
+    const int p = static_cast<int>(r & 1);
+    const int expected = (last_batch_ > prev_batch_) ? last_batch_ : prev_batch_;
+    if (idle && window_us_ > 0 && joined_[p].load(std::memory_order_acquire) < expected) {
+      const auto t_a = clk::now();
+      const auto hard = t_a + std::chrono::microseconds(window_us_ + (expected < 20 ? 2 * expected : 40));
+      int seen = joined_[p].load(std::memory_order_acquire);
+      auto last_arrival = t_a;
+      for (;;) {
+        std::this_thread::yield();
+        const auto now = clk::now();
+        const int j = joined_[p].load(std::memory_order_acquire);
+        if (j >= expected || now >= hard) break;
+        if (j != seen) { seen = j; last_arrival = now; }
+        else if (now - last_arrival >= std::chrono::microseconds(20)) break;
+      }
+    }
+    std::vector<Req*> reqs;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      open_ = r + 1;
+      reqs.swap(reqs_[p]);
+      joined_[p].store(0, std::memory_order_relaxed);
+    }
+    std::vector<Staged*> st(reqs.size());
+    std::vector<FrameIn> in(reqs.size());
+    for (size_t i = 0; i < reqs.size(); ++i) { st[i] = reqs[i]->s; in[i] = *reqs[i]->in; }
+    std::string err;
+    // many cameras in one round: their stage machines are stepped by a small worker team (the host share of a frame is ~15-50 us per
+    // stream and stage; one leader thread stepping 64 of them was the round's longest part)
+    if (st.size() >= 16 && !team_) {
+      long w = 8;
+      if (const char* e = std::getenv("MOTCPP_ROUND_WORKERS")) w = std::atol(e);
+      if (w > 1) team_ = std::make_unique<Team>(static_cast<int>(w));
+    }
+    try { run_frame(*dev_, st.data(), in.data(), static_cast<int>(st.size()), (st.size() >= 16) ? team_.get() : nullptr); }
+    catch (const std::exception& e) { err = e.what(); }
+    if (!err.empty()) for (Req* q : reqs) q->error = err;
+    prev_batch_ = last_batch_;
+    last_batch_ = static_cast<int>(reqs.size());
+    completed_.store(r + 1, std::memory_order_release);
+    word_[p].fetch_add(1, std::memory_order_release);
+    futex_wake_all(&word_[p]);
+  }
+  Device* dev_;
+  std::mutex mu_;
+  std::vector<Req*> reqs_[2];
+  uint64_t open_ = 0;
+  std::atomic<uint64_t> completed_{0};
+  std::atomic<uint32_t> word_[2] = {{0}, {0}};
+  std::atomic<int> joined_[2] = {{0}, {0}};
+  int last_batch_ = 0, prev_batch_ = 0;
+  long window_us_ = 60;
+  std::unique_ptr<Team> team_;
+};
+}  // namespace
+
+void run_frame_combined(const std::shared_ptr<Device>& dev, Staged* tracker, const FrameIn& input) {
+  // one combiner per Device, kept alive with it (the map holds weak owners: a Device that went away takes its rounds along)
+  static std::mutex m;
+  static std::map<Device*, std::pair<std::weak_ptr<Device>, std::shared_ptr<HostRounds>>> all;
+  std::shared_ptr<HostRounds> hr;
+  {
+    std::lock_guard<std::mutex> g(m);
+    auto& e = all[dev.get()];
+    if (!e.second || e.first.expired()) { e.first = dev; e.second = std::make_shared<HostRounds>(dev.get()); }
+    hr = e.second;
+  }
+  hr->update(tracker, input);
 }
 }  // namespace rt
 
@@ -192,8 +313,7 @@ Eigen::MatrixXf DeviceTracker::update(const Eigen::MatrixXf& dets, const cv::Mat
     return to_matrix(rows, m);
   }
   rt::FrameIn in = make_input(dets, img, embs);
-  rt::Staged* s = impl_.get();
-  rt::run_frame(*dev_, &s, &in, 1);
+  rt::run_frame_combined(dev_, impl_.get(), in);  // merged with the calls other threads make at the same time (staged.hpp)
   return to_matrix(impl_->rows());
 }
 

@@ -32,6 +32,17 @@ def main():
         out["frames_per_s"][kind] = {"value": round(S * (F - warm) / dt), "ms_per_step": round(1e3 * dt / (F - warm), 3),
                                      "flushes_per_step": round(c["flushes"] / F, 2)}
         b.close()
+    # the same trackers through the reference's own surface: T objects of the public classes on T host threads (motcpp_bench_threads), whose
+    # concurrent update() calls the library merges into lockstep frames (round 5: run_frame_combined; a per-GPU mutex before)
+    F2, warm2 = 40, 15
+    dets_t = np.stack([base[s % len(base)][0] for s in range(S)])  # [S, F, M, 6]
+    cnt_t = np.full((S, F2), M, np.int32)
+    out["basetracker_update_threads"] = {}
+    for kind, code in (("deepocsort", 4), ("strongsort", 5), ("ucmc", 6), ("boosttrack", 7), ("hybridsort", 8)):
+        for T in (1, S):
+            res, _ = L.bench_threads(code, dets_t[:T, :F2], cnt_t[:T], warm2, frames=warm2 + 100)
+            out["basetracker_update_threads"].setdefault(kind, {})[f"T{T}"] = {"frames_per_s": round(res["frames_per_s"]), "ms_per_update_p50": round(res["latency_ms_p50"], 3),
+                                                                                "ms_per_update_p99": round(res["latency_ms_p99"], 3)}
     print(json.dumps(out))
 
 

@@ -147,6 +147,13 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   const size_t b5 = b2 + 32 * nm + 64;
   if (fast && behind_full && behind_all && geom && flavor != 2 && rpl > 0 && (mode == 3 || mode == 2) && n * m >= 16384 &&
       b5 <= static_cast<size_t>(kLdsBudget) - 4096) { mode = 5; lds = b5; }
+  // Round 5: with more than 256 columns (the north-star shape) such a launch runs FOUR wavefronts per declined problem, two register-cached columns per
+  // lane instead of eight: a declined problem is ~530 serial rounds of the row reduction, each evaluating every owned column and reducing over the
+  // group — a quarter of the evaluations per lane, and the whole state is in LDS, so the three extra wavefronts cost one LDS exchange per reduction.
+  // (Round 4 tried four wavefronts with the state in global scratch and no register cache: no gain. MOT_LAP_BEHIND_QUAD=0 keeps one wavefront.)
+  static const bool quad_ok = !(std::getenv("MOT_LAP_BEHIND_QUAD") && std::getenv("MOT_LAP_BEHIND_QUAD")[0] == '0');  // (A/B measurements)
+  const bool behind_quad = mode == 5 && rpl == 8 && quad_ok && !wide;
+  if (behind_quad) rpl = 2;
   static const bool behind_prio = !(std::getenv("MOT_LAP_BEHIND_PRIO") && std::getenv("MOT_LAP_BEHIND_PRIO")[0] == '0');
   {
     std::lock_guard<std::mutex> attr_lock(attr_mu);
@@ -164,7 +171,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   static const bool wide8_ok = !(std::getenv("MOT_LAP_WIDE8") && std::getenv("MOT_LAP_WIDE8")[0] == '0');
   const bool wide8 = wide && wide8_ok && (ntasks <= 256 || mode == 4 || mode == 6) && flavor == 1;  // (mode 4: one problem per CU whatever the width)
   static const int wide_t = std::getenv("MOT_LAP_WIDE_T") ? std::atoi(std::getenv("MOT_LAP_WIDE_T")) : 0;  // (experiments)
-  const int threads = (wide && flavor == 1 && (wide_t == 256 || wide_t == 512)) ? wide_t : (wide8 ? 512 : (wide ? 256 : 64));
+  const int threads = behind_quad ? 256 : ((wide && flavor == 1 && (wide_t == 256 || wide_t == 512)) ? wide_t : (wide8 ? 512 : (wide ? 256 : 64)));
   static LapDiag diag_dev[64] = {};
   {
     std::lock_guard<std::mutex> attr_lock(attr_mu);

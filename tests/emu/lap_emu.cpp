@@ -114,6 +114,8 @@ extern "C" int emu_lap_iou(const float* a, int nr, const float* b, int nc, const
                            int rpl, int* x, int* y) {
   if (rpl == 104) return run_iou<4, true>(a, nr, b, nc, conf, mode, thresh, T, x, y);  // 100 + rpl: the plain-cost variants
   if (rpl == 108) return run_iou<8, true>(a, nr, b, nc, conf, mode, thresh, T, x, y);
+  if (rpl == 2) return run_iou<2>(a, nr, b, nc, conf, mode, thresh, T, x, y);   // (the four-wavefront launches behind the fast path: two columns per lane)
+  if (rpl == 102) return run_iou<2, true>(a, nr, b, nc, conf, mode, thresh, T, x, y);
   if (rpl == 4) return run_iou<4>(a, nr, b, nc, conf, mode, thresh, T, x, y);
   if (rpl == 8) return run_iou<8>(a, nr, b, nc, conf, mode, thresh, T, x, y);
   return run_iou<0>(a, nr, b, nc, conf, mode, thresh, T, x, y);

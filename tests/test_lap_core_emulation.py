@@ -54,7 +54,7 @@ def test_on_the_fly_cost_functor_matches_materialised_matrix(orc, emu_iou):
         for mode, th in ((1, 0.7), (2, 0.8), (3, -0.3)):
             cost = {1: orc.iou_distance(a, b), 2: orc.fuse_score(orc.iou_distance(a, b), conf), 3: -orc.iou_batch(a, b)}[mode]
             xo, yo = orc.linear_assignment(cost, th)
-            for rpl in (0, 4, 8):  # 0: boxes from memory; 4/8: lane-owned register cache (+ leftover columns when 8*rpl < m)
+            for rpl in (0, 2, 4, 8):  # 0: boxes from memory; 2/4/8: lane-owned register cache (+ leftover columns when 8*rpl < m)
                 xe, ye = emu_iou(a, b, conf, mode, th, 8, rpl)
                 assert (xo == xe).all() and (yo == ye).all(), (n, m, mode, rpl)
 
@@ -133,7 +133,7 @@ def test_rows_without_an_entry_below_half_skip_their_sweeps(orc, emu_iou):
     emu_iou.void_real_sweeps(1)
     total = 0
     for trial in range(24):
-        T, rpl = ((8, 108), (16, 104), (64, 8), (8, 4))[trial % 4]
+        T, rpl = ((8, 108), (16, 104), (64, 8), (8, 4), (64, 102), (32, 2))[trial % 6]  # (102 / 2: two columns per lane — the four-wavefront launches)
         cap = (rpl % 100) * T
         n = int(r.integers(60, 400))
         m = int(r.integers(10, min(cap, 200) + 1))
@@ -166,7 +166,7 @@ def test_sparse_column_minima_make_the_same_decisions(orc, emu_iou):
     T = 8
     cases = 0
     for trial in range(60):
-        rpl = (4, 8)[trial % 2]
+        rpl = (4, 8, 2)[trial % 3]
         n = int(r.integers(32, 16 * T + 1))
         m = int(r.integers(1, rpl * T + 1))
         spread = (60, 400, 2000)[trial % 3]

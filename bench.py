@@ -179,7 +179,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     tracker, P, M, D, desc = WORKLOADS[args.workload]
-    S = args.streams or {"C2": 12288, "SORT": 12288, "NS": 6144, "C5": 6144, "C3": 1536, "C4": 768}[args.workload]
+    S = args.streams or {"C2": 12288, "SORT": 12288, "NS": 18432, "C5": 6144, "C3": 1536, "C4": 768}[args.workload]
     # host workers block between phases, so about twice as many workers as the box's CPU quota pay off (the bursts of
     # lifecycle work get shorter and the workers sleep through the GPU waits); far more than that and the cgroup
     # throttles the whole process (measured on the 16-CPU-quota GPU boxes: 32 workers 456k frames/s, 64 workers 268k)
@@ -200,15 +200,11 @@ def main():
     F = K + W + H + ISO
 
     # ---- synthetic streams (seed 1234 + global stream id), generated before anything is timed ----
-    host = np.zeros((F, S, M, 6), np.float32)
-    embs = np.zeros((F, S, M, D), np.float32) if D else None
-    for s in range(S):
-        st = SynthStream(P, M, mdist.stream_seed(mdist.stream_ids(rank, S)[s]), D)
-        for f in range(F):
-            d, e = st.next_frame()
-            host[f, s] = d
-            if D:
-                embs[f, s] = e
+    # (round 5: the streams are generated by a pool of fresh interpreter processes — 18 432 streams x 67 frames took minutes on one core; every
+    # stream has its own seeded generator, so the arrays are the same whatever the number of workers)
+    from motcpp_amd.synth import generate_streams
+    gen_workers = max(1, min(16, cpu_budget() // max(1, world_local())))
+    host, embs = generate_streams(P, M, D, [mdist.stream_seed(g) for g in mdist.stream_ids(rank, S)], F, gen_workers)
     # detection payload resident in HBM as SoA [F, S, 6, M] before the timed region
     dev_dets = torch.from_numpy(np.ascontiguousarray(host.transpose(0, 1, 3, 2))).cuda(local)
     dev_embs = torch.from_numpy(embs).cuda(local) if D else None  # [F, S, M, D] row-major, resident like the detections
@@ -477,7 +473,9 @@ def main():
             elif on_device and tracker == "botsort":
                 ps = {"lap": {"ms": ps["lap_ms"], "launches": 2 * ps["frames"], "tasks": ps["lap_problems"], "bytes": 24.0 * ps["lap_nm"], "flops": 0.0},
                       "cosine": {"ms": ps["cos_ms"], "launches": ps["frames"], "tasks": ps["frames"] * (bounds[1] - bounds[0]),
-                                 "bytes": 0.0, "flops": 2.0 * ps["cos_nm"] * D},
+                                 # bytes: DESIGN.md section 3's 4 ((n + m) D + n m) per distance matrix; the first association's shape for the feature rows
+                                 # (the unconfirmed tracks' matrix of the same frame is smaller: a slight overestimate)
+                                 "bytes": 4.0 * (ps["cos_nm"] + ps["frames"] * (bounds[1] - bounds[0]) * (P + M) * D), "flops": 2.0 * ps["cos_nm"] * D},
                       "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
                                             "bytes": 0.0, "flops": 0.0}}
             elif on_device:  # the solver's launches are timed on the device stream; "frame" = all 14 launches of a frame
@@ -818,6 +816,10 @@ def main():
                  "note": "algorithmic bytes of an assignment = 24 B per row and column (boxes + score in, x/y out): the solver recomputes costs from "
                          "the boxes, no matrix exists; the kernel is latency/dependency-bound (augmenting-path search), its HBM fraction is "
                          "reported as measured, see DESIGN.md"})
+    if fam == "cosine":
+        roof["note"] = ("flops of a cosine-distance launch = 2 n m D (the fp32 MFMA contraction; norms and the 1 - sim epilogue not counted) against the dense fp32 "
+                        "MFMA peak; algorithmic_bytes_per_launch = 4 ((n + m) D + n m): feature rows in, distances out (the kernel is MFMA-bound, the bytes are "
+                        "there for the traffic comparison)")
     if isolated and fam in isolated:  # the same family with the GPU to itself (see kernels_isolated)
         roof["isolated"] = isolated[fam]
     prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")

@@ -73,3 +73,75 @@ CONFIGS = {
     "C5": ("bytetrack", 1000, 512, 0),
     "NS": ("bytetrack", 1000, 500, 0),
 }
+
+
+# ---- many streams at once (bench.py: tens of thousands of streams x dozens of frames before anything is timed) ----------------------------
+def _fill_streams(args):
+    """worker: frames of the streams [s0, s1) written into the shared arrays (np.memmap files)"""
+    path_d, path_e, F, S, P, M, D, seeds, s0, s1 = args
+    dets = np.memmap(path_d, np.float32, "r+", shape=(F, S, M, 6))
+    embs = np.memmap(path_e, np.float32, "r+", shape=(F, S, M, D)) if D else None
+    for s in range(s0, s1):
+        st = SynthStream(P, M, seeds[s], D)
+        for f in range(F):
+            d, e = st.next_frame()
+            dets[f, s] = d
+            if D:
+                embs[f, s] = e
+    dets.flush()
+    if D:
+        embs.flush()
+    return s1 - s0
+
+
+def generate_streams(P, M, D, seeds, F, workers=1):
+    """dets [F, S, M, 6] (and embs [F, S, M, D] or None) of the streams SynthStream(P, M, seeds[s], D), frame by frame — the same arrays whatever
+    `workers` is: every stream has its own generator. workers > 1: the streams are dealt to that many fresh interpreter processes (spawn: the
+    caller may hold a GPU context) that write into arrays shared through /dev/shm."""
+    S = len(seeds)
+    if workers <= 1 or S * F < 20000:
+        dets = np.zeros((F, S, M, 6), np.float32)
+        embs = np.zeros((F, S, M, D), np.float32) if D else None
+        for s in range(S):
+            st = SynthStream(P, M, seeds[s], D)
+            for f in range(F):
+                d, e = st.next_frame()
+                dets[f, s] = d
+                if D:
+                    embs[f, s] = e
+        return dets, embs
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    fd_d, path_d = tempfile.mkstemp(prefix="motcpp_synth_d_", dir=base)
+    os.close(fd_d)
+    path_e = ""
+    try:
+        np.memmap(path_d, np.float32, "w+", shape=(F, S, M, 6)).flush()
+        if D:
+            fd_e, path_e = tempfile.mkstemp(prefix="motcpp_synth_e_", dir=base)
+            os.close(fd_e)
+            np.memmap(path_e, np.float32, "w+", shape=(F, S, M, D)).flush()
+        # plain child interpreters (no multiprocessing: nothing of the caller's __main__ is imported or re-run in them)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        per = (S + workers - 1) // workers
+        procs = []
+        for s0 in range(0, S, per):
+            job = json.dumps([path_d, path_e, F, S, P, M, D, [int(x) for x in seeds], s0, min(S, s0 + per)])
+            procs.append(subprocess.Popen([sys.executable, "-c", "import sys, json; sys.path.insert(0, sys.argv[1]); from motcpp_amd.synth import _fill_streams; "
+                                           "_fill_streams(json.loads(sys.stdin.read()))", root], stdin=subprocess.PIPE))
+            procs[-1].stdin.write(job.encode())
+            procs[-1].stdin.close()
+        for pr in procs:
+            if pr.wait(timeout=1800) != 0:
+                raise RuntimeError("synthetic-stream worker failed")
+        dets = np.array(np.memmap(path_d, np.float32, "r", shape=(F, S, M, 6)))
+        embs = np.array(np.memmap(path_e, np.float32, "r", shape=(F, S, M, D))) if D else None
+        return dets, embs
+    finally:
+        for pth in (path_d, path_e):
+            if pth and os.path.exists(pth):
+                os.remove(pth)

@@ -179,7 +179,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     tracker, P, M, D, desc = WORKLOADS[args.workload]
-    S = args.streams or {"C2": 12288, "SORT": 12288, "NS": 18432, "C5": 6144, "C3": 1536, "C4": 768}[args.workload]
+    S = args.streams or {"C2": 12288, "SORT": 12288, "NS": 18432, "C5": 18432, "C3": 1536, "C4": 768}[args.workload]
     # host workers block between phases, so about twice as many workers as the box's CPU quota pay off (the bursts of
     # lifecycle work get shorter and the workers sleep through the GPU waits); far more than that and the cgroup
     # throttles the whole process (measured on the 16-CPU-quota GPU boxes: 32 workers 456k frames/s, 64 workers 268k)

@@ -99,7 +99,8 @@ def generate_streams(P, M, D, seeds, F, workers=1):
     `workers` is: every stream has its own generator. workers > 1: the streams are dealt to that many fresh interpreter processes (spawn: the
     caller may hold a GPU context) that write into arrays shared through /dev/shm."""
     S = len(seeds)
-    if workers <= 1 or S * F < 20000:
+    total_bytes = 4.0 * F * S * M * (6 + D)
+    if workers <= 1 or S * F < 20000 or total_bytes > 48e9:  # (shared-memory files count against the box's memory like the arrays themselves: bounded)
         dets = np.zeros((F, S, M, 6), np.float32)
         embs = np.zeros((F, S, M, D), np.float32) if D else None
         for s in range(S):
@@ -138,8 +139,9 @@ def generate_streams(P, M, D, seeds, F, workers=1):
         for pr in procs:
             if pr.wait(timeout=1800) != 0:
                 raise RuntimeError("synthetic-stream worker failed")
-        dets = np.array(np.memmap(path_d, np.float32, "r", shape=(F, S, M, 6)))
-        embs = np.array(np.memmap(path_e, np.float32, "r", shape=(F, S, M, D))) if D else None
+        # the mappings outlive the files (unlinked below): no second copy of tens of GB
+        dets = np.memmap(path_d, np.float32, "r+", shape=(F, S, M, 6))
+        embs = np.memmap(path_e, np.float32, "r+", shape=(F, S, M, D)) if D else None
         return dets, embs
     finally:
         for pth in (path_d, path_e):

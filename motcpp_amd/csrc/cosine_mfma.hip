@@ -118,6 +118,16 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
     }
   };
   const int wr = wave >> 1, wc = wave & 1;  // wavefront -> (TILE/2) x (TILE/2) sub-tile
+  // (round 5) 32 x 32 MFMA tiles that lie wholly outside the problem are skipped (wavefront-uniform): a pool of 900 tracks x 450 detections
+  // pads to 1024 x 512 in 128 x 128 workgroup tiles — 23 % of the matrix-core time went into rows and columns nobody reads; at the 32-wide
+  // granularity it is 928 x 480. The workgroup still meets at its barriers, but the matrix pipe is free for the other workgroups of the CU.
+  bool row_ok[NA], col_ok[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    row_ok[i] = row0 + wr * (TILE / 2) + 32 * i < T.n;
+    col_ok[i] = col0 + wc * (TILE / 2) + 32 * i < T.m;
+  }
+  const bool all_ok = row_ok[NA - 1] && col_ok[NA - 1];
   f32x16 acc[NA][NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i)
@@ -176,16 +186,19 @@ __global__ void __launch_bounds__(kThreads) embed_kernel(const mot_cos_task* __r
             a4[i] = *reinterpret_cast<const float4*>(&As[buf][wr * (TILE / 2) + 32 * i + (lane & 31)][hoff + 4 * g]);
             b4[i] = *reinterpret_cast<const float4*>(&Bs[buf][wc * (TILE / 2) + 32 * i + (lane & 31)][hoff + 4 * g]);
           }
+          auto steps = [&](auto guarded) {
   #pragma unroll
-          for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e)
   #pragma unroll
-            for (int i = 0; i < NA; ++i)
+              for (int i = 0; i < NA; ++i)
   #pragma unroll
-              for (int j = 0; j < NA; ++j) {
-                const float av = (e == 0) ? a4[i].x : (e == 1) ? a4[i].y : (e == 2) ? a4[i].z : a4[i].w;
-                const float bv = (e == 0) ? b4[j].x : (e == 1) ? b4[j].y : (e == 2) ? b4[j].z : b4[j].w;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-              }
+                for (int j = 0; j < NA; ++j) {
+                  const float av = (e == 0) ? a4[i].x : (e == 1) ? a4[i].y : (e == 2) ? a4[i].z : a4[i].w;
+                  const float bv = (e == 0) ? b4[j].x : (e == 1) ? b4[j].y : (e == 2) ? b4[j].z : b4[j].w;
+                  if (!decltype(guarded)::value || (row_ok[i] && col_ok[j])) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                }
+          };
+          if (all_ok) steps(std::false_type()); else steps(std::true_type());  // (interior wavefronts keep their unbroken chain of MFMAs)
         }
       }
       if (k0 + kSlab < T.d) {

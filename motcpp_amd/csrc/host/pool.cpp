@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <stdexcept>
 #include <thread>
@@ -387,6 +388,7 @@ class StreamPool {
     std::vector<float> key = params;
     key.push_back(static_cast<float>(device)); key.push_back(static_cast<float>(kind)); key.push_back(static_cast<float>(emb_dim));
     std::lock_guard<std::mutex> g(m);
+    for (auto it = pools.begin(); it != pools.end();) it = it->second.expired() ? pools.erase(it) : std::next(it);  // (pools that went away)
     auto sp = pools[key].lock();
     if (!sp) { sp = std::make_shared<StreamPool>(device, kind, params, emb_dim); pools[key] = sp; }
     return sp;
@@ -490,10 +492,14 @@ void PooledStream::prepare(const PooledFrame& f, void* req_) {
     const long floor_level = env_long("MOTCPP_POOL_MIN_LEVEL", 0);
     if (need < floor_level && floor_level < kLevels) need = static_cast<int>(floor_level);
     attach(need, with_emb ? f.emb_dim : 0);
+  } else if (need > seg_->level() && fresh_) {
+    //  the slot was never reset (a first frame that was prepared and withdrawn): nothing to move — whatever its old owner left there
+    // must not travel along; the stream starts fresh on the larger level
+    pool_->release(seg_, s_);
+    pool_->acquire(need, &seg_, &s_);
   } else if (need > seg_->level()) {  // outgrown: the stream moves into a slot of a larger level at the head of this round
     req.pre = 2; req.from = seg_; req.from_s = s_;
     pool_->acquire(need, &seg_, &s_);
-    fresh_ = false;
   }
   if (fresh_) { req.pre = 1; fresh_ = false; reset_pending_ = false; }
   else if (reset_pending_) { if (req.pre == 2) req.also_reset = true; else req.pre = 3; reset_pending_ = false; }
@@ -514,6 +520,9 @@ int PooledStream::finish(void* req_, const float** rows) {
   if (!req.error.empty()) {
     seg_->rows_taken(parity);
     if (req.from) pool_->release(req.from, req.from_s);  // (the old slot goes either way: its state was read before the failure or is lost with it)
+    //  the round failed: whether this stream's reset ran is unknown — the next frame asks for it again
+    if (req.pre == 1) fresh_ = true;
+    if (req.pre == 3 || req.also_reset) reset_pending_ = true;
     throw Error(req.error);
   }
   const int m = req.count > 0 ? req.count : 0;

@@ -917,6 +917,14 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
           n_ready = lo;
           ++n_finds;
           const long long qf0 = MOT_FCLOCK();
+          // With cols[] / inv[] / d[] / the record list in LDS nothing of a _find_dense lives in global memory (the memory-staged tie runs
+          // apart, which keep their full barriers): its barriers and the collectives' order LDS only — a full barrier also waits for the
+          // stores to pred[] the scan steps left in flight — and the insertion point travels through an LDS word instead of tmp[0].
+          const bool find_lds = kLst16 && std::remove_reference_t<decltype(W)>::kColsSpace == kMemLds && use_rl;
+          auto fsync = [&]() { if (find_lds) g.sync_lds(); else g.sync(); };
+          auto put_h2 = [&](int v) { if (find_lds) W.fsw[kFsTodo + kFsMaxN / 32] = v; else W.tmp[0] = v; };
+          auto get_h2 = [&]() -> int { return find_lds ? static_cast<int>(W.fsw[kFsTodo + kFsMaxN / 32]) : static_cast<int>(W.tmp[0]); };
+          g.lds_barriers(find_lds);
           // _find_dense (:115-127). Its outcome depends on the ORDER of cols[], which only changes at positions whose
           // value is <= the running minimum ("weak records") — and the values it reads are those of the cols[] order
           // at entry (a swap never touches a position still to be read). So: find the records in parallel (chunk
@@ -962,7 +970,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
 #pragma unroll
               for (int u = 0; u < kFindChunk; ++u)
                 if (recm & (1u << u)) LST[base++] = (b + u) - first;
-              g.sync();
+              fsync();
             } else {
               double cm = 1e300;
               for (int k = b; k < e; ++k) { const double dj = W.d[W.cols[k]]; if (dj < cm) cm = dj; }
@@ -1051,7 +1059,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                     ++h2;
                   }
                 }
-                if (t == 0) W.tmp[0] = static_cast<int>(h2);  // (tmp[0] is not a record flag: those start at first >= 1)
+                if (t == 0) put_h2(static_cast<int>(h2));  // (tmp[0] is not a record flag: those start at first >= 1)
               }
             }
 #else
@@ -1068,17 +1076,18 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 W.cols[h2] = j; W.inv[j] = static_cast<int>(h2);
                 ++h2;
               }
-              W.tmp[0] = static_cast<int>(h2);
+              put_h2(static_cast<int>(h2));
             }
 #endif
-            g.sync();  // the replaying lane's stores to cols[] / inv[] / tmp[0] are visible to everyone
+            fsync();  // the replaying lane's stores to cols[] / inv[] / tmp[0] are visible to everyone
             const long long qf2 = MOT_FCLOCK();
             cy_sub[10] += qf2 - qf1;
             unsigned h2;
             if (R == 0) {
-              h2 = static_cast<unsigned>(W.tmp[0]);
+              h2 = static_cast<unsigned>(get_h2());
             } else if (R > kTiePer * T) {
               // the same closed form with the per-record values staged through memory instead of registers (any run length)
+              g.lds_barriers(false);  // (its scratch is global memory: full barriers, also inside the collectives)
               const int a = nser, s = first;
               for (int r = t; r < R; r += T) W.tmp[r] = 0;
               g.sync();
@@ -1113,6 +1122,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                 if (dd) { const int og = W.sb[r]; W.cols[dd - 1] = og; W.inv[og] = dd - 1; }
               }
               g.sync();
+              g.lds_barriers(find_lds);
               h2 = static_cast<unsigned>(s + R);
             } else {
               // The scratch of the closed form (fresh flags, then the pointer-jumping array: chains of displaced items can be as long as the
@@ -1163,7 +1173,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                   }
                   if (g.reduce_max(changed) == 0) break;
                 }
-                g.lds_barriers(false);
+                g.lds_barriers(find_lds);
                 int jr[kTiePer], orig[kTiePer], dst[kTiePer];
   #pragma unroll
                 for (int q = 0; q < kTiePer; ++q) {
@@ -1177,7 +1187,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                     }
                   }
                 }
-                g.sync();  // every read of the old order is done
+                if (in_lds && find_lds) g.sync_lds(); else g.sync();  // every read of the old order is done
   #pragma unroll
                 for (int q = 0; q < kTiePer; ++q) {
                   const int r = t + q * T;
@@ -1186,7 +1196,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
                     if (fresh & (1u << q)) { W.cols[dst[q]] = orig[q]; W.inv[orig[q]] = dst[q]; }
                   }
                 }
-                g.sync();
+                if (in_lds && find_lds) g.sync_lds(); else g.sync();
                 return static_cast<unsigned>(s + R);
               };
               constexpr int kTmpLds = kFsTodo - kFsEvl;  // ints of the event tables
@@ -1216,7 +1226,8 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             hi = h2;
             final_j = (best >= 0) ? static_cast<int>(W.cols[best]) : -1;
           }
-          g.sync();
+          fsync();
+          g.lds_barriers(false);
           cy_find += MOT_FCLOCK() - qf0;
         }
         if (final_j == -1) {

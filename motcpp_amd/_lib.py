@@ -172,8 +172,11 @@ class Context:
                  "serial_augmentations", "n_extended", "scan_steps", "scan_step_members", "scan_step_real_rows", "tie_events", "single_sweeps",
                  "steps_refused", "find_dense_calls", "row_lists", "cyc_step_classify", "cyc_step_dry", "cyc_step_apply", "cyc_event_sort",
                  "cyc_event_replay", "cyc_find_dense", "cyc_single_sweeps", "cyc_search_setup")
-        return {"problems": int(o[39]), "sum": dict(zip(names, (int(v) for v in o[:24]))),
-                "slowest": dict(zip(names, (int(v) for v in o[40:64]))), "slowest_cycles": int(o[79])}
+        r = {"problems": int(o[39]), "sum": dict(zip(names, (int(v) for v in o[:24]))),
+             "slowest": dict(zip(names, (int(v) for v in o[40:64]))), "slowest_cycles": int(o[79])}
+        if os.environ.get("MOT_BEHIND_RAW"):  # (tools/ns_behind_fine.py: the twelve counters only a -DMOT_LAP_FINE_PROF build fills)
+            r["raw_fine"] = [int(v) for v in o[24:36]]
+        return r
 
     def lap_fast_stats(self, reset=False):
         """Outcome counts of the assignment fast path on this device since the last reset (see mot_lap_fast_stats)."""

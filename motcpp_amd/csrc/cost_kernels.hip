@@ -241,6 +241,67 @@ __global__ void __launch_bounds__(256) feat_kernel(const mot_feat_task* __restri
   const bool single = T.d <= kFeatCols;
   constexpr int RS = kFeatCols + 1;
   float nn = 0.0f;
+  // Round 5: rows of exactly 256 floats on 16-byte boundaries (every appearance feature of the device lifecycles) move as one float4 per lane — a
+  // row is ONE load instruction of a wavefront instead of four, all of a wavefront's eight rows are in flight together, and the rows are written
+  // back the same way. Element k = 4 * lane + c sits at tile column c * 64 + lane (conflict-free for the wavefronts' stores and for the 32 chains,
+  // whose lanes are 257 words apart); the chain still adds the squares in the order k = 0, 1, 2, ...: same sums, same quotients.
+  const bool vec = T.d == kFeatCols && ((T.ldf | T.lds) & 3) == 0 && ((reinterpret_cast<size_t>(T.src) | reinterpret_cast<size_t>(T.feat)) & 15) == 0;
+  if (vec) {
+    constexpr int kRowsPerWave = kFeatRows / 4;
+    float4 v[kRowsPerWave], f[kRowsPerWave];
+#pragma unroll
+    for (int u = 0; u < kRowsPerWave; ++u) {
+      const int r = wave + 4 * u;
+      if (r < rows) {
+        v[u] = reinterpret_cast<const float4*>(T.src + s_s[r])[lane];
+        if (ema) f[u] = reinterpret_cast<const float4*>(T.feat + s_f[r])[lane];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kRowsPerWave; ++u) {
+      const int r = wave + 4 * u;
+      if (r < rows) {
+        float4 w = v[u];
+        if (ema) {
+          const float a = s_alpha[r];
+          w.x = a * f[u].x + (1.0f - a) * w.x;  // botsort.cpp:163 / deepocsort.cpp:143
+          w.y = a * f[u].y + (1.0f - a) * w.y;
+          w.z = a * f[u].z + (1.0f - a) * w.z;
+          w.w = a * f[u].w + (1.0f - a) * w.w;
+        }
+        float* trow = tile + r * RS + lane;
+        trow[0] = w.x; trow[64] = w.y; trow[128] = w.z; trow[192] = w.w;
+      }
+    }
+    __syncthreads();
+    if (tid < rows) {
+      const float* row = tile + tid * RS;
+#pragma unroll 8
+      for (int q = 0; q < kFeatCols / 4; ++q) {
+        nn = __builtin_fmaf(row[q], row[q], nn);
+        nn = __builtin_fmaf(row[64 + q], row[64 + q], nn);
+        nn = __builtin_fmaf(row[128 + q], row[128 + q], nn);
+        nn = __builtin_fmaf(row[192 + q], row[192 + q], nn);
+      }
+      const float nrm = sqrtf(nn);
+      const bool go = (T.mode == 6) ? false : ((T.mode >= 4) ? (nrm > 1e-10f) : ((T.mode >= 2) ? (nrm > 1e-6f) : (nrm > 0.0f)));
+      s_nrm[tid] = go ? nrm : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kRowsPerWave; ++u) {
+      const int r = wave + 4 * u;
+      if (r < rows) {
+        const float nrm = s_nrm[r];
+        if (T.mode == 4 && nrm == 0.0f) continue;  // strongsort.cpp:176-179
+        const float* trow = tile + r * RS + lane;
+        float4 w{trow[0], trow[64], trow[128], trow[192]};
+        if (nrm != 0.0f) { w.x = w.x / nrm; w.y = w.y / nrm; w.z = w.z / nrm; w.w = w.w / nrm; }
+        reinterpret_cast<float4*>(T.feat + s_f[r])[lane] = w;
+      }
+    }
+    return;
+  }
   for (int c0 = 0; c0 < T.d; c0 += kFeatCols) {
     const int cols = (T.d - c0 < kFeatCols) ? T.d - c0 : kFeatCols;
     for (int r = wave; r < rows; r += 4) {

@@ -39,6 +39,18 @@ MOT_DEV Top2 top2_merge(Top2 a, const Top2& b) {
 }
 constexpr int kNoIdx = 0x7fffffff;
 MOT_DEV Top2 top2_empty() { return Top2{1e300, 1e300, kNoIdx, kNoIdx}; }
+// a float that is <= v: the nearest one or its lower neighbour (v is not a NaN). Lower bounds may travel as floats — a float minimum is one
+// DPP instruction per step where a double's is five.
+MOT_DEV float f32_below(double v) {
+  float f = static_cast<float>(v);
+  if (static_cast<double>(f) > v) {
+    const int b = __builtin_bit_cast(int, f);
+    if (f > 0.f) f = __builtin_bit_cast(float, b - 1);
+    else if (f < 0.f) f = __builtin_bit_cast(float, b + 1);
+    else f = -1.17549435e-38f;
+  }
+  return f;
+}
 
 #if defined(__HIPCC__)
 // ------------------------------------------------------------------------------------------
@@ -177,6 +189,52 @@ struct DevGroup {
     barrier_();
     Top2 r = s[0];
     for (int w = 1; w < nw; ++w) r = top2_merge(r, s[w]);
+    return r;
+  }
+  // reduce_top2 of the threads' tuples AND the uniform tuple `cap`, for callers that know `cap` beats almost everything (round 5: the serial
+  // rounds of lapjv's row reduction — a real row's two best columns are among a handful of overlapping detections and the two best dummy
+  // columns, which are cached: `cap`). An entry that is not lexicographically below cap's second cannot be in the result, so each wavefront
+  // collects its few entries that are with a ballot and a readlane per entry (two DPP lexmin passes — ~130 dependent VALU instructions —
+  // when there are more than eight of them), the wavefronts' partials meet in LDS, cap is merged last. *lb gets a lower bound (a float) of the
+  // minimum of the threads' t.v1: that minimum itself is only ever used as a bound.
+  __device__ __forceinline__ Top2 reduce_top2_under(const Top2& t, const Top2& cap, float* lb) {
+    const float lbw = wave_min_f32(f32_below(t.v1));
+    const bool in1 = lex_less(t.v1, t.j1, cap.v2, cap.j2), in2 = lex_less(t.v2, t.j2, cap.v2, cap.j2);
+    unsigned long long m1 = __builtin_amdgcn_ballot_w64(in1), m2 = __builtin_amdgcn_ballot_w64(in2);
+    Top2 acc = top2_empty();
+    if (__builtin_popcountll(m1) + __builtin_popcountll(m2) <= 8) {
+      while (m1) { const int l = __builtin_ctzll(m1); m1 &= m1 - 1; top2_push(acc, wave_get(t.v1, l), wave_get(t.j1, l)); }
+      while (m2) { const int l = __builtin_ctzll(m2); m2 &= m2 - 1; top2_push(acc, wave_get(t.v2, l), wave_get(t.j2, l)); }
+    } else {
+      double v1 = t.v1; int j1 = t.j1;
+      wave_lexmin(v1, j1);
+      double v2 = (t.j1 == j1) ? t.v2 : t.v1;
+      int j2 = (t.j1 == j1) ? t.j2 : t.j1;
+      wave_lexmin(v2, j2);
+      acc = Top2{v1, v2, j1, j2};
+    }
+    const int nw = (size_ + 63) >> 6;
+    Top2 r = cap;
+    if (nw == 1) {
+      *lb = lbw;
+      if (acc.j1 != kNoIdx) top2_push(r, acc.v1, acc.j1);  // (uniform branches: most rounds have one or two entries to merge, each push is
+      if (acc.j2 != kNoIdx) top2_push(r, acc.v2, acc.j2);  //  a dozen double-precision compares and selects)
+      return r;
+    }
+    struct Part { Top2 t; float lb; int pad; };
+    static_assert(sizeof(Part) == 32, "one reduction slot per wavefront");
+    Part* s = slot<Part>();
+    if ((tid_ & 63) == 0) { s[tid_ >> 6].t = acc; s[tid_ >> 6].lb = lbw; }
+    barrier_();
+    float l = s[0].lb;
+    for (int w = 0; w < nw; ++w) {
+      const int j1 = s[w].t.j1, j2 = s[w].t.j2;
+      if (j1 != kNoIdx) top2_push(r, s[w].t.v1, j1);
+      if (j2 != kNoIdx) top2_push(r, s[w].t.v2, j2);
+      const float o = s[w].lb;
+      l = (o < l) ? o : l;
+    }
+    *lb = l;
     return r;
   }
   // exclusive prefix minimum over thread ids (threads with no predecessor get +inf); general-path helper

@@ -634,6 +634,7 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
         }
       }
       if (use_d || use_h) {
+        const long long qr0 = MOT_FCLOCK();
         const double hb = dqg.v2;
         g.sync();  // the previous round's owner writes to y[] are visible
         const int a0 = W.y[cj1], b0 = W.y[cj2];
@@ -679,11 +680,14 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
             nxt_row = (nxt < nr) ? C.row(nxt) : typename Cost::Row();
             nxt_lb = (have_lb && nxt < nr) ? static_cast<double>(W.rlb[nxt]) : 0.0;
           }
+          if (!use_rl) { cy_sub[4] += MOT_FCLOCK() - qr0; cy_sub[8] += 1; }  // (fine-profile builds; the scan steps of phase 3 own these slots when row lists exist)
           continue;
         }
       }
       ++rr_cnt;
       ++n_carr;
+      const long long qr1 = MOT_FCLOCK();
+      long long qr2 = qr1, qr3 = qr1;
       const bool from_list = forwarded < 0;
       const int fi = from_list ? nxt : forwarded;
       typename Cost::Row fi_row = nxt_row;
@@ -714,18 +718,26 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
         if (!dummy_row) {
           ensure_dq();
           for_lane_real(C, R, W.v, t, T, nc, push);
-          if (have_lb) {  // the row's current minimum over the real columns: a tighter bound from here on
-            const double rreal = g.reduce_min(tt.v1);
-            if (t == 0) W.rlb[fi] = rreal;
+          qr2 = MOT_FCLOCK();
+          qr3 = qr2;
+          if (have_lb) {
+            // (round 5) the dummy columns' two best are known to the whole group (dqg): only real entries below them can matter — one
+            // collective; the row's minimum over the real columns comes back as a float bound (a tighter rlb from here on: rlb is only ever a bound)
+            float rreal;
+            tt = g.reduce_top2_under(tt, dqg, &rreal);
+            if (t == 0) W.rlb[fi] = static_cast<double>(rreal);
+          } else {
+            push(dq.v1, dq.j1);  // the lane's dummy columns come after its real ones, best first
+            push(dq.v2, dq.j2);
+            tt = g.reduce_top2(tt);
           }
-          push(dq.v1, dq.j1);  // the lane's dummy columns come after its real ones, best first
-          push(dq.v2, dq.j2);
         } else {
           for_lane_columns(C, R, W.v, t, T, nc, n, push);
+          tt = g.reduce_top2(tt);
         }
-        tt = g.reduce_top2(tt);
         if (dummy_row) { dc = tt; dc_valid = true; }
       }
+      const long long qr4 = MOT_FCLOCK();
       int j1 = tt.j1, j2 = tt.j2;
       double v1 = tt.v1, v2 = tt.v2;
       if (!(v2 < kLapLarge)) { v2 = kLapLarge; j2 = -1; }
@@ -747,6 +759,11 @@ MOT_DEV void lap_solve(G& g, const Cost& C, const LapDims& P, const Work& W) {
         ++new_free;
       }
       if ((j1 % T) == t) { W.x[fi] = j1; W.y[j1] = fi; }
+      if (!use_rl) {  // (fine-profile builds)
+        const long long qr5 = MOT_FCLOCK();
+        if (dummy_row) { cy_sub[5] += qr5 - qr1; cy_sub[7] += 1; }
+        else { cy_sub[0] += qr2 - qr1; cy_sub[1] += qr3 - qr2; cy_sub[2] += qr4 - qr3; cy_sub[3] += qr5 - qr4; cy_sub[6] += 1; }
+      }
       // no barrier here: v[j1]/y[j1] are next read (a) by their owner lane in the strided
       // loop above, or (b) by everyone only after the reduce_top2 barrier of the next round.
     }

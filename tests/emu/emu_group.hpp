@@ -62,6 +62,11 @@ struct EmuGroup {
     for (int t = 1; t < sh->T; ++t) r = top2_merge(r, s[t]);
     return r;
   }
+  Top2 reduce_top2_under(const Top2& v, const Top2& cap, float* lb) {  // (grp.hpp: same result, same float bound; nothing is skipped here)
+    const Top2 r = top2_merge(reduce_top2(v), cap);
+    *lb = reduce_min_f32(f32_below(v.v1));
+    return r;
+  }
   double exclusive_scan_min(double v) {
     auto& s = sh->s_f64[phase++ & 1];
     s[tid_] = v;

@@ -407,7 +407,7 @@ def test_lap_tie_heavy_problems_behind_the_fast_path(ctx, orc, n, m):
             assert st["fast"] == 0 and bh["problems"] == 1 and bh["slowest_cycles"] > 0, (st, bh)
 
 
-@pytest.mark.parametrize("n,d", [(1, 8), (77, 64), (512, 256), (130, 100)])
+@pytest.mark.parametrize("n,d", [(1, 8), (77, 64), (512, 256), (45, 256), (130, 100)])
 def test_appearance_post_processing_bit_exact(ctx, orc, n, d):
     """mot_feat_update against the oracle's restatement of BotSTrack's feature handling (botsort.cpp:38-46 set +
     normalise, :158-169 EMA 0.9 / 0.1 + renormalise) and of ReIDBackend::normalize_features (reid_backend.cpp:72-88, rows of

@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # fp32 MFMA = fp32 vector peak
+DENSE_COS = os.environ.get("MOT_BOT_DENSE_COSINE", "") == "1"  # (A/B: BoT-SORT's appearance term as the whole matrix on the MFMA, bot_device.hip)
 
 WORKLOADS = {
     # name: (tracker, P persistent objects, M dets/frame, emb_dim, description)
@@ -472,10 +473,18 @@ def main():
                                             "bytes": 0.0, "flops": 0.0}}
             elif on_device and tracker == "botsort":
                 ps = {"lap": {"ms": ps["lap_ms"], "launches": 2 * ps["frames"], "tasks": ps["lap_problems"], "bytes": 24.0 * ps["lap_nm"], "flops": 0.0},
+                      # the first association's appearance term. Round 5: embed_gated_kernel — the cosine distance of the pairs that pass the
+                      # proximity test only (about one per track), so there is no n x m contraction to count: bytes = the boxes in (20 B per row
+                      # and column) + two feature rows in and one distance out per pair that passes, taken as one pair per detection
+                      # (MOT_BOT_DENSE_COSINE=1 runs the fp32 MFMA matrix kernel instead: its flops are 2 n m D)
                       "cosine": {"ms": ps["cos_ms"], "launches": ps["frames"], "tasks": ps["frames"] * (bounds[1] - bounds[0]),
-                                 # bytes: DESIGN.md section 3's 4 ((n + m) D + n m) per distance matrix; the first association's shape for the feature rows
-                                 # (the unconfirmed tracks' matrix of the same frame is smaller: a slight overestimate)
-                                 "bytes": 4.0 * (ps["cos_nm"] + ps["frames"] * (bounds[1] - bounds[0]) * (P + M) * D), "flops": 2.0 * ps["cos_nm"] * D},
+                                 "bytes": (4.0 * (ps["cos_nm"] + ps["frames"] * (bounds[1] - bounds[0]) * (P + M) * D) if DENSE_COS else
+                                           ps["frames"] * (bounds[1] - bounds[0]) * (20.0 * (P + M) + min(P, M) * (8.0 * D + 4.0))),
+                                 "flops": (2.0 * ps["cos_nm"] * D) if DENSE_COS else 0.0},
+                      # feat_kernel: the three launches of a frame (normalise the detections' rows, set the new tracks' features, blend the matched
+                      # ones); bytes = 4 D per row read or written (normalise / set: 2 per row, blend: 3), counted on the device
+                      "feat": {"ms": ps["feat_ms"], "launches": 3 * ps["frames"], "tasks": ps["frames"] * (bounds[1] - bounds[0]),
+                               "bytes": 4.0 * D * ps["feat_row_moves"], "flops": 0.0},
                       "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
                                             "bytes": 0.0, "flops": 0.0}}
             elif on_device:  # the solver's launches are timed on the device stream; "frame" = all 14 launches of a frame
@@ -781,7 +790,9 @@ def main():
     # round 3 reported embed_kernel in one C3 run and the assignment composite in another): NS / C2 / C5 lap_sparse_kernel of the first
     # association, C3 embed_kernel<cosine> (bound: fp32 MFMA), C4 the exact lap_kernel of the first association, SORT its one assignment launch.
     composite = {"frame_all_kernels"} | ({"lap"} if "lap1_sparse" in stats else set())
-    fixed = {"NS": "lap1_sparse", "C2": "lap1_sparse", "C5": "lap1_sparse", "C3": "cosine", "C4": "lap", "SORT": "lap"}.get(args.workload)
+    # (round 5: BoT-SORT's appearance term is evaluated for the pairs that pass the proximity test only — cosine_gated.hip — and the kernel table of
+    # C3, profiles/r05f_kernel_stats_C3.csv, is led by feat_kernel, the appearance-feature maintenance: HBM-bound)
+    fixed = {"NS": "lap1_sparse", "C2": "lap1_sparse", "C5": "lap1_sparse", "C3": "cosine" if DENSE_COS else "feat", "C4": "lap", "SORT": "lap"}.get(args.workload)
     fam = fixed if fixed in stats and stats[fixed]["launches"] else max((k for k in stats if k not in composite), key=lambda k: stats[k]["ms"])
     if not stats[fam]["launches"]:
         raise SystemExit(f"bench.py: the profiled kernel family {fam!r} reports 0 launches in the timed region (profiling events missing)")
@@ -807,7 +818,8 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
     kernel_names = {"lap1_sparse": "lap_sparse_kernel (first association: pool of tracked + lost tracks x high-score detections)",
-                    "lap": "lap_sparse_kernel + lap_kernel (assignment launches of a frame)", "cosine": "embed_kernel<cosine>",
+                    "lap": "lap_sparse_kernel + lap_kernel (assignment launches of a frame)", "cosine": "embed_kernel<cosine>" if DENSE_COS else "embed_gated_kernel",
+                    "feat": "feat_kernel (normalise / set / blend the appearance features: three launches per frame)",
                     "kf_update": "kf_update8_kernel", "kf_predict_boxes": "kf_kernel (predict + boxes)", "kf_initiate": "kf_kernel (initiate)",
                     "ocsort_cost": "ocsort_kernel"}
     roof.update({"kernel": kernel_names.get(fam, fam), "family": fam, "avg_launch_ms": avg_ms, "launches": st["launches"],
@@ -816,7 +828,12 @@ def main():
                  "note": "algorithmic bytes of an assignment = 24 B per row and column (boxes + score in, x/y out): the solver recomputes costs from "
                          "the boxes, no matrix exists; the kernel is latency/dependency-bound (augmenting-path search), its HBM fraction is "
                          "reported as measured, see DESIGN.md"})
-    if fam == "cosine":
+    if fam == "feat":
+        roof["note"] = ("algorithmic bytes of the appearance-feature maintenance = 4 D bytes per feature row read or written: every detection's row is normalised "
+                        "(read + write), a new track's feature is set (read + write), a matched track's is blended with the detection's and renormalised (two reads "
+                        "+ write); counted per launch on the device (mot_bot_profile_feat). avg_launch_ms averages the frame's three launches, as rocprofv3's "
+                        "table does for feat_kernel")
+    if fam == "cosine" and st["flops"] > 0:
         roof["note"] = ("flops of a cosine-distance launch = 2 n m D (the fp32 MFMA contraction; norms and the 1 - sim epilogue not counted) against the dense fp32 "
                         "MFMA peak; algorithmic_bytes_per_launch = 4 ((n + m) D + n m): feature rows in, distances out (the kernel is MFMA-bound, the bytes are "
                         "there for the traffic comparison)")

@@ -415,6 +415,12 @@ enum {
 };
 size_t mot_lap_work_bytes(int n, int m);
 size_t mot_lap_rowlist_bytes(int n);
+/* BoT-SORT's appearance term (src/trackers/botsort.cpp:433-466): the reference forces the distance of every pair whose IoU distance exceeds
+ * proximity_thresh to 1 (:439-447), so only the other pairs' cosine distances can reach the assignment. tasks[s] (mot_cosine_cost's layout) is paired
+ * with lap[s * lap_stride]: that task's geom (boxes, MOT_COST_BOTSORT, prox_thresh) says which pairs pass the test — evaluated with the arithmetic
+ * the solvers use — and out[i][j] is written for exactly those (bit-identical to mot_cosine_cost's entry); every other entry of out is left
+ * untouched (no solver reads it). A geom without boxes, with another cost mode, or with prox_thresh >= 1 gets the whole matrix. */
+int mot_cosine_cost_gated(mot_ctx* ctx, const mot_cos_task* tasks, const mot_lap_task* lap, int lap_stride, int ntasks, int max_n, int max_m);
 /* mot_lap_solve runs two kernels over the task array: a fast path (viable pairs only, shortest augmenting paths, and a
  * certificate that the optimum is unique — then it IS lapjv's answer) and, for the problems the fast path does not certify, the
  * step-by-step lapjv emulation that reproduces the reference's tie-breaks. Diagnostics: outcome counts of the fast path on this
@@ -516,6 +522,10 @@ int mot_bot_dump(mot_bot_batch* b, int s, int* ids, float* mean, float* cov, flo
  * problems, [7] emb_dim */
 int mot_bot_profile(mot_bot_batch* b, int enable);
 int mot_bot_profile_stats(mot_bot_batch* b, double* out8);
+/* the appearance-feature maintenance of the profiled frames (feat_kernel: normalise the detections' rows, set the new tracks' features, blend
+ * the matched ones — botsort.cpp:38-46, :158-169). out2: [0] summed ms of its three launches per frame, [1] feature rows moved (a read or a
+ * write of emb_dim floats each: normalise / set = 2 per row, blend = 3) */
+int mot_bot_profile_feat(mot_bot_batch* b, double* out2);
 
 /* ---- OC-SORT with the per-stream lifecycle on the device --------------------------------- */
 /* Same contract as mot_bt_* for OCSort::update (src/trackers/ocsort.cpp:285-606): S independent streams, one fixed launch
@@ -640,6 +650,9 @@ int mot_assoc_cost_host(mot_ctx* ctx, const float* a_xyxy, int n, const float* b
 int mot_fuse_iou_host(mot_ctx* ctx, const float* reid_cost, const float* a_xyxy, int n, const float* b_xyxy, int m, float* cost);
 int mot_cosine_cost_host(mot_ctx* ctx, const float* a, int n, const float* b, int m, int d, float* out);
 int mot_embedding_cost_host(mot_ctx* ctx, int metric, const float* a, int n, const float* b, int m, int d, float* out);
+/* mot_cosine_cost_gated on host arrays (boxes row-major [n][4] / [m][4]); out is read first: entries of pairs that fail the test come back as given */
+int mot_cosine_cost_gated_host(mot_ctx* ctx, const float* a, int n, const float* b, int m, int d, const float* a_xyxy, const float* b_xyxy,
+                               int cost_mode, float prox_thresh, float* out);
 /* mot_feat_update on host rows: feat [n][d] in/out (read by the EMA modes 1 and 3), src [n][d]; modes 0-3 as in mot_feat_task;
  * alpha_i: optional [n] per-row EMA weights (DeepOC-SORT's dets_alpha), NULL = `alpha` for every row */
 int mot_feat_update_host(mot_ctx* ctx, int mode, float alpha, int n, int d, float* feat, const float* src);

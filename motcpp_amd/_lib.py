@@ -132,6 +132,16 @@ class Context:
         self._chk(self.lib.mot_embedding_cost_host(self.h, int(metric), _p(a), a.shape[0], _p(b), b.shape[0], a.shape[1], _p(out)))
         return out
 
+    def cosine_cost_gated(self, a, b, a_xyxy, b_xyxy, prox, out, cost_mode=COST_BOTSORT):
+        """mot_cosine_cost_gated_host: cosine distances of the pairs that pass BoT-SORT's proximity test written into `out` (other entries stay)"""
+        a, b, a_xyxy, b_xyxy = f32(a), f32(b), f32(a_xyxy).reshape(-1, 4), f32(b_xyxy).reshape(-1, 4)
+        out = np.ascontiguousarray(out, np.float32).copy()
+        self.lib.mot_cosine_cost_gated_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                        C.c_int, C.c_float, C.c_void_p]
+        self._chk(self.lib.mot_cosine_cost_gated_host(self.h, _p(a), a.shape[0], _p(b), b.shape[0], a.shape[1], _p(a_xyxy), _p(b_xyxy),
+                                                      int(cost_mode), C.c_float(prox), _p(out)))
+        return out
+
     def gate_cost(self, kind, mode, mean, cov, meas, cost=None, only_position=False, metric=0, lam=0.98, gated_cost=1e5):
         """mot_gate_cost_host: kind KF_XYAH / KF_XYWH; mode 0 gating distances, 1 utils::fuse_motion, 2 StrongSORT's gate_cost_matrix"""
         mean, cov, meas = f32(mean).reshape(-1, 8), f32(cov).reshape(-1, 64), f32(meas).reshape(-1, 4)
@@ -792,7 +802,11 @@ class DeviceBotSort:
     def profile_stats(self):
         o = np.zeros(8, np.float64)
         self.ctx._chk(self.lib.mot_bot_profile_stats(self.h, _p(o)))
-        return {"lap_ms": o[0], "cos_ms": o[1], "frame_ms": o[2], "frames": int(o[3]), "lap_problems": o[4], "lap_nm": o[5], "cos_nm": o[6], "emb_dim": int(o[7])}
+        f = np.zeros(2, np.float64)
+        self.lib.mot_bot_profile_feat.argtypes = [C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.lib.mot_bot_profile_feat(self.h, _p(f)))
+        return {"lap_ms": o[0], "cos_ms": o[1], "frame_ms": o[2], "frames": int(o[3]), "lap_problems": o[4], "lap_nm": o[5], "cos_nm": o[6], "emb_dim": int(o[7]),
+                "feat_ms": f[0], "feat_row_moves": f[1]}
 
     def reset(self):
         self.ctx._chk(self.lib.mot_bot_reset(self.h))

@@ -23,6 +23,7 @@
 namespace mot {
 hipError_t launch_feat(const mot_feat_task*, int, int, hipStream_t);
 hipError_t launch_embed(int metric, const mot_cos_task*, int, int, int, hipStream_t);
+hipError_t launch_embed_gated(const mot_cos_task*, const mot_lap_task*, int, int, int, int, hipStream_t);
 }  // namespace mot
 
 namespace {
@@ -182,6 +183,7 @@ __global__ void __launch_bounds__(kW) bot_begin(BotStream* streams, BotParams P,
       atomicAdd(&st[0], 1ull); atomicAdd(&st[1], static_cast<unsigned long long>(np + nf));
       if (have_emb) atomicAdd(&st[2], static_cast<unsigned long long>(np) * static_cast<unsigned long long>(nf));
     }
+    if (stats && have_emb) atomicAdd(&stats[(s & 63) * 8 + 3], 2ull * static_cast<unsigned long long>(n));  // feature rows moved: normalise = read + write
   }
 }
 
@@ -262,7 +264,7 @@ __global__ void __launch_bounds__(kW) bot_after_first(BotStream* streams, BotPar
 }
 
 // ---- K2: apply associations 2 and 3, births, deaths, list algebra, queue the Kalman and feature work (:507-764) ----
-__global__ void __launch_bounds__(kW) bot_after_second(BotStream* streams, BotParams P, int CAP, BotTasks K) {
+__global__ void __launch_bounds__(kW) bot_after_second(BotStream* streams, BotParams P, int CAP, BotTasks K, unsigned long long* stats) {
   const int s = blockIdx.x;
   BotStream& S = streams[s];
   if (S.idle) return;
@@ -408,6 +410,8 @@ __global__ void __launch_bounds__(kW) bot_after_second(BotStream* streams, BotPa
     K.upd[s].n = n_upd;
     K.fset[s].n = S.have_emb ? n_set : 0;
     K.fema[s].n = S.have_emb ? n_ema : 0;
+    if (stats && S.have_emb)  // feature rows moved: set = read + write, moving average = two reads + write
+      atomicAdd(&stats[(s & 63) * 8 + 3], 2ull * static_cast<unsigned long long>(n_set) + 3ull * static_cast<unsigned long long>(n_ema));
     mot_kf_task& OB = K.obox[s];
     OB.n = n_na; OB.src = na;
   }
@@ -479,7 +483,7 @@ struct mot_bot_batch {
   bool profile = false;
   unsigned long long* d_stats = nullptr;
   hipEvent_t ev[12] = {};
-  double lap_ms = 0.0, cos_ms = 0.0, frame_ms = 0.0;
+  double lap_ms = 0.0, cos_ms = 0.0, frame_ms = 0.0, feat_ms = 0.0;
   long frames = 0;
   template <class T>
   T* dalloc(size_t n) { return mem.get<T>(n); }
@@ -666,30 +670,41 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
   hipLaunchKernelGGL(bot_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, FD, d_dets, emb ? d_embs : nullptr, b->d_warps,
                      any_warp ? b->d_has_warp : nullptr, K, prof ? b->d_stats : nullptr, b->d_maxt);
   MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYWH, K.det, S, bd, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[7], st));
   if (emb) MOT_LC_HIP(b, mot::launch_feat(K.featn, S, bd, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[8], st));
   if (any_warp) {
     MOT_LC_HIP(b, mot::launch_kf_op(4, MOT_KF_XYWH, K.warp, S, bn, st));       // multi_gmc(unconfirmed) :323
     MOT_LC_HIP(b, mot::launch_kf_op(5, MOT_KF_XYWH, K.predw, S, bn, st));      // multi_predict + multi_gmc(pool) :316-322
   }
   MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYWH, K.pred, S, bn, st));         // multi_predict :316
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
-  if (emb) MOT_LC_HIP(b, mot::launch_embed(MOT_EMB_COSINE, K.cos1, S, bn, bd, st));
+  // (round 5) the appearance distances of the pairs that pass the proximity test only — the others are forced to 1 by the reference and never
+  // read by the solvers (cosine_gated.hip); MOT_BOT_DENSE_COSINE=1 writes the whole matrix on the MFMA as before (A/B measurements)
+  static const bool dense_cos = std::getenv("MOT_BOT_DENSE_COSINE") && std::getenv("MOT_BOT_DENSE_COSINE")[0] == '1';
+  auto appearance = [&](const mot_cos_task* cos, const mot_lap_task* lap, int stride) {
+    if (!dense_cos && mot::launch_embed_gated(cos, lap, stride, S, bn, bd, st) == hipSuccess) return hipSuccess;
+    return mot::launch_embed(MOT_EMB_COSINE, cos, S, bn, bd, st);
+  };
+  if (emb) MOT_LC_HIP(b, appearance(K.cos1, K.lap1, 1));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
   MOT_LC_HIP(b, mot::launch_lap(K.lap1, S, bn, bd, true, false, false, st, b->hint1_n, 0, true, nullptr, nullptr, nullptr, active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
   hipLaunchKernelGGL(bot_after_first, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K, prof ? b->d_stats : nullptr, b->d_maxt);
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYWH, K.ubox, S, bn, st));
-  if (emb) MOT_LC_HIP(b, mot::launch_embed(MOT_EMB_COSINE, K.cos3, S, bn, bd, st));
+  if (emb) MOT_LC_HIP(b, appearance(K.cos3, K.lap23 + 1, 2));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[5], st));
   MOT_LC_HIP(b, mot::launch_lap(K.lap23, 2 * S, bn, bd, true, false, false, st, b->hint23_n, b->hint23_m, true, nullptr, nullptr, nullptr, 2 * active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[6], st));
-  hipLaunchKernelGGL(bot_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K);
+  hipLaunchKernelGGL(bot_after_second, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K, prof ? b->d_stats : nullptr);
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYWH, K.init, S, bd, st));
   MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYWH, K.upd, S, bn, st));
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[9], st));
   if (emb) {
     MOT_LC_HIP(b, mot::launch_feat(K.fset, S, bn2, st));
     MOT_LC_HIP(b, mot::launch_feat(K.fema, S, bn, st));
   }
+  if (prof) MOT_LC_HIP(b, hipEventRecord(ev[10], st));
   MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYWH, K.obox, S, bn2, st));
   hipLaunchKernelGGL(bot_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt, b->d_alive);
   hipLaunchKernelGGL(bot_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
@@ -712,6 +727,8 @@ static int bot_account_events(mot_bot_batch* b, hipEvent_t* ev) {
   MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[2], ev[3])); b->cos_ms += ms;
   MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[3], ev[4])); b->lap_ms += ms;
   MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[5], ev[6])); b->lap_ms += ms;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[7], ev[8])); b->feat_ms += ms;
+  MOT_LC_HIP(b, hipEventElapsedTime(&ms, ev[9], ev[10])); b->feat_ms += ms;
   b->frames += 1;
   return MOT_OK;
 }
@@ -908,7 +925,7 @@ int mot_bot_device_output(mot_bot_batch* b, const float** d_rows, const int** d_
 int mot_bot_profile(mot_bot_batch* b, int enable) {
   b->profile = enable != 0;
   if (enable) {
-    b->lap_ms = b->cos_ms = b->frame_ms = 0.0;
+    b->lap_ms = b->cos_ms = b->frame_ms = b->feat_ms = 0.0;
     b->frames = 0;
     MOT_LC_HIP(b, hipMemsetAsync(b->d_stats, 0, 8 * 64 * sizeof(unsigned long long), b->ctx->stream));
     MOT_LC_HIP(b, hipStreamSynchronize(b->ctx->stream));
@@ -924,6 +941,15 @@ int mot_bot_profile_stats(mot_bot_batch* b, double* out8) {
     for (int k = 0; k < 4; ++k) h[k] += raw[i * 8 + k];
   out8[0] = b->lap_ms; out8[1] = b->cos_ms; out8[2] = b->frame_ms; out8[3] = static_cast<double>(b->frames);
   out8[4] = static_cast<double>(h[0]); out8[5] = static_cast<double>(h[1]); out8[6] = static_cast<double>(h[2]); out8[7] = static_cast<double>(b->E);
+  return MOT_OK;
+}
+
+int mot_bot_profile_feat(mot_bot_batch* b, double* out2) {  // HIP-event ms of the three feat_kernel launches of the profiled frames; feature rows they moved
+  unsigned long long raw[8 * 64];
+  MOT_LC_HIP(b, hipMemcpy(raw, b->d_stats, sizeof(raw), hipMemcpyDeviceToHost));
+  unsigned long long rows = 0;
+  for (int i = 0; i < 64; ++i) rows += raw[i * 8 + 3];
+  out2[0] = b->feat_ms; out2[1] = static_cast<double>(rows);
   return MOT_OK;
 }
 

@@ -35,6 +35,7 @@ size_t lap_scratch_bytes(int n, int m);
 size_t lap_rowlist_scratch_bytes(int n);
 hipError_t lap_fast_stats(unsigned long long* out16, bool reset, hipStream_t st);
 hipError_t lap_behind_stats(long long* out80, bool reset, hipStream_t st);
+hipError_t launch_embed_gated(const mot_cos_task*, const mot_lap_task*, int, int, int, int, hipStream_t);
 }  // namespace mot
 
 #include "ctx.hpp"
@@ -279,6 +280,38 @@ int mot_embedding_cost_host(mot_ctx* c, int metric, const float* a, int n, const
   t.out = dout.as<float>(); t.ldo = m; t.norm_a = dna.as<float>(); t.norm_b = dnb.as<float>();
   MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, mot::launch_embed(metric, dt.as<mot_cos_task>(), 1, n, m, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(out, dout.p, static_cast<size_t>(n) * m * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+
+int mot_cosine_cost_gated(mot_ctx* c, const mot_cos_task* t, const mot_lap_task* lap, int lap_stride, int nt, int max_n, int max_m) {
+  MOT_HIP(c, mot::launch_embed_gated(t, lap, lap_stride, nt, max_n, max_m, c->stream));
+  return MOT_OK;
+}
+int mot_cosine_cost_gated_host(mot_ctx* c, const float* a, int n, const float* b, int m, int d, const float* a_xyxy, const float* b_xyxy,
+                               int cost_mode, float prox_thresh, float* out) {
+  if (n <= 0 || m <= 0) return MOT_OK;
+  std::vector<float> sa, sb;
+  to_soa4(a_xyxy, n, 4, 4, sa);
+  to_soa4(b_xyxy, m, 4, 4, sb);
+  DBuf da, db, dout, dba, dbb, dt, dl;
+  MOT_HIP(c, da.alloc(static_cast<size_t>(n) * d * 4)); MOT_HIP(c, db.alloc(static_cast<size_t>(m) * d * 4));
+  MOT_HIP(c, dout.alloc(static_cast<size_t>(n) * m * 4)); MOT_HIP(c, dba.alloc(sa.size() * 4)); MOT_HIP(c, dbb.alloc(sb.size() * 4));
+  MOT_HIP(c, dt.alloc(sizeof(mot_cos_task))); MOT_HIP(c, dl.alloc(sizeof(mot_lap_task)));
+  MOT_HIP(c, hipMemcpyAsync(da.p, a, static_cast<size_t>(n) * d * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(db.p, b, static_cast<size_t>(m) * d * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(dba.p, sa.data(), sa.size() * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(dbb.p, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(dout.p, out, static_cast<size_t>(n) * m * 4, hipMemcpyHostToDevice, c->stream));  // (entries of pairs that fail the test keep the caller's values)
+  mot_cos_task t{};
+  t.n = n; t.m = m; t.d = d; t.a = da.as<float>(); t.lda = d; t.b = db.as<float>(); t.ldb = d; t.out = dout.as<float>(); t.ldo = m;
+  mot_lap_task L{};
+  L.n = n; L.m = m; L.geom.n = n; L.geom.m = m; L.geom.a = dba.as<float>(); L.geom.lda = n; L.geom.b = dbb.as<float>(); L.geom.ldb = m;
+  L.geom.mode = cost_mode; L.geom.prox_thresh = prox_thresh;
+  MOT_HIP(c, hipMemcpyAsync(dt.p, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(dl.p, &L, sizeof(L), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, mot::launch_embed_gated(dt.as<mot_cos_task>(), dl.as<mot_lap_task>(), 1, 1, n, m, c->stream));
   MOT_HIP(c, hipMemcpyAsync(out, dout.p, static_cast<size_t>(n) * m * 4, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   return MOT_OK;

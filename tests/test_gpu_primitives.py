@@ -453,6 +453,45 @@ def test_embedding_metrics(ctx, orc, n, m, d):
     assert np.allclose(ctx.embedding_cost(1, a, b), a64 @ b64.T, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("n,m,d,case", [(1, 1, 8, "plain"), (300, 130, 100, "plain"), (861, 450, 256, "plain"), (1024, 512, 256, "plain"),
+                                        (130, 70, 64, "coincident"), (200, 90, 32, "nan"), (40, 30, 16, "prox_one"), (40, 30, 16, "other_mode")])
+def test_gated_appearance_distances(ctx, orc, n, m, d, case):
+    """BoT-SORT's appearance term (botsort.cpp:433-466): the reference masks every pair with iou_distance > proximity_thresh to 1 (:439-447),
+    so mot_cosine_cost_gated evaluates the other pairs only — their entries equal the oracle's embedding_distance bit for bit, every other
+    entry of the output is left as the caller had it. Edge cases: strips whose pair list overflows (thousands of coincident boxes), NaN boxes
+    (their IoU is +0: masked), a threshold that masks nothing, a cost mode that reads the whole matrix."""
+    r = np.random.default_rng(n * 31 + m * 7 + d)
+    a = r.standard_normal((n, d)).astype(np.float32)
+    b = r.standard_normal((m, d)).astype(np.float32)
+    ta, tb = boxes(r, n, (900, 600)), boxes(r, m, (900, 600))
+    k = min(n, m)
+    tb[:k] = ta[r.permutation(n)[:k]] + r.normal(0, 3, (k, 4)).astype(np.float32)
+    prox, mode = 0.5, L.COST_BOTSORT
+    if case == "coincident":
+        ta[:] = ta[0]
+        tb[:] = ta[0]
+    elif case == "nan":
+        ta[3, 0] = np.nan
+        tb[5, 2] = np.nan
+        tb[6] = ta[3]
+    elif case == "prox_one":
+        prox = 1.0
+    elif case == "other_mode":
+        mode = L.COST_IOU_DIST
+    full = orc.embedding_distance(0, a, b)
+    dist = orc.iou_distance(ta, tb)
+    passes = ~(dist > prox) if case not in ("prox_one", "other_mode") else np.ones((n, m), bool)
+    sentinel = np.full((n, m), -7.0, np.float32)
+    g = ctx.cosine_cost_gated(a, b, ta, tb, prox, sentinel, cost_mode=mode)
+    assert np.array_equal(g[passes], full[passes]), np.abs(g[passes] - full[passes]).max()
+    assert np.all(g[~passes] == -7.0)
+    assert passes.sum() >= (1 if case != "nan" else 0)
+    if case == "coincident":
+        assert passes.all()
+    if case == "plain" and n > 1:
+        assert 0 < passes.sum() < n * m / 8
+
+
 def _gating_states(orc, kind, n, seed):
     """n Kalman states a few frames old (initiate, then predict/update rounds with jittered measurements) + their measurements"""
     r = np.random.default_rng(seed)

@@ -63,7 +63,8 @@ struct BotStream {
   int lap2_q, lap3_q;
   int *init_dst, *init_meas; int n_init;
   int* lost_new;
-  float* abox;  // [4][CAP] boxes of the new tracked list (output rows)
+  float* abox;  // [4][CAP] (round 5: unused — bot_finish computes an output row's box from the updated mean)
+  const float* kmean;  // this stream's Kalman records (72 floats per slot)
 };
 
 // every task descriptor of one stream (device arrays of S entries each), so that the kernels take one pointer
@@ -117,6 +118,9 @@ __global__ void __launch_bounds__(kW) bot_begin(BotStream* streams, BotParams P,
     S.dets = dets; S.ld = ldd; S.n = n; S.have_emb = have_emb; S.warp = warp; S.embs = embs;
   }
   const float* conf = dets + static_cast<size_t>(4) * ldd;
+  float* dbox = K.det[s].box;
+  float* dmeas = K.det[s].meas;
+  const int dldb = K.det[s].ldb, dldm = K.det[s].ldm;
   int nf = 0, ns = 0;
   for (int i0 = 0; i0 < n; i0 += kW) {  // :283-300
     const int i = i0 + t;
@@ -127,6 +131,15 @@ __global__ void __launch_bounds__(kW) bot_begin(BotStream* streams, BotParams P,
     if (hi) S.first[ph] = i;
     const int pl = compact(lo, ns);
     if (lo) S.second[pl] = i;
+    if (i < n) {  // the detection's association box and Kalman measurement (det_kernel<MOT_DET_XYWH>, botsort.cpp:23-36, 171-181: the same operations)
+      const float x1 = dets[i], y1 = dets[static_cast<size_t>(ldd) + i], x2 = dets[static_cast<size_t>(2) * ldd + i], y2 = dets[static_cast<size_t>(3) * ldd + i];
+      const float w = x2 - x1, h = y2 - y1;
+      const float cx = x1 + w / 2.0f, cy = y1 + h / 2.0f;
+      const float zz[4] = {cx, cy, w, h};
+      const float bb[4] = {cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { dbox[static_cast<size_t>(q) * dldb + i] = bb[q]; dmeas[static_cast<size_t>(q) * dldm + i] = zz[q]; }
+    }
   }
   const int* act = S.active[S.cur];
   const int* lst = S.lost[S.cur];
@@ -418,11 +431,14 @@ __global__ void __launch_bounds__(kW) bot_after_second(BotStream* streams, BotPa
 }
 
 // ---- K3: the output table (:742-764): activated members of the new tracked list, in list order ----
-__global__ void __launch_bounds__(kW) bot_finish(BotStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive) {
+__global__ void __launch_bounds__(kW) bot_finish(BotStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive, int* err) {
   BotStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
   if (S.idle) {
-    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_active + S.n_lost; atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost); }
+    if (t == 0) {
+      out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_active + S.n_lost; atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost);
+      if (S.err) atomicMax(err, S.err);
+    }
     return;
   }
   const int* act = S.active[S.cur];
@@ -437,7 +453,11 @@ __global__ void __launch_bounds__(kW) bot_finish(BotStream* streams, int CAP, fl
     if (emit && pr < cap_out) {
       float* r = rows + static_cast<size_t>(pr) * 8;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) r[k] = S.abox[static_cast<size_t>(k) * CAP + i];
+      for (int k = 0; k < 4; ++k) r[k] = 0.f;
+      {  // the box of the updated state (kf_kernels.hip::s8_box<MOT_KF_XYWH>): centre -/+ half the size
+        const float4 m = *reinterpret_cast<const float4*>(S.kmean + static_cast<size_t>(slot) * 72);
+        r[0] = m.x - m.z * 0.5f; r[1] = m.y - m.w * 0.5f; r[2] = m.x + m.z * 0.5f; r[3] = m.y + m.w * 0.5f;
+      }
       r[4] = static_cast<float>(S.t_id[slot]); r[5] = S.t_conf[slot];
       r[6] = static_cast<float>(S.t_cls[slot]); r[7] = static_cast<float>(S.t_det[slot]);
     }
@@ -447,12 +467,8 @@ __global__ void __launch_bounds__(kW) bot_finish(BotStream* streams, int CAP, fl
     out_counts[blockIdx.x] = (n_rows <= cap_out) ? n_rows : -n_rows;
     atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost);
     alive[blockIdx.x] = S.n_active + S.n_lost;
+    if (S.err) atomicMax(err, S.err);  // the batch's error word (round 5: gathered here; a kernel of its own before)
   }
-}
-
-__global__ void bot_collect_err(const BotStream* streams, int n, int* err) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && streams[i].err) atomicMax(err, streams[i].err);
 }
 
 }  // namespace
@@ -590,6 +606,7 @@ int mot_bot_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, int
     float* pool_box = F(4 * CAP); float* ub = F(4 * CAP); T.abox = F(4 * CAP);
     float* d_box = F(4 * D); float* d_meas = F(4 * D);
     float* mean = b->mean + static_cast<size_t>(s) * 72 * CAP;
+    T.kmean = mean;
     float* feat = E ? b->feat + static_cast<size_t>(s) * CAP * E : nullptr;
     float* en = E ? emb_norm + static_cast<size_t>(s) * D * E : nullptr;
     float* eo = E ? emb_out + static_cast<size_t>(s) * CAP * ldE : nullptr;
@@ -669,7 +686,7 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
   hipLaunchKernelGGL(bot_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, FD, d_dets, emb ? d_embs : nullptr, b->d_warps,
                      any_warp ? b->d_has_warp : nullptr, K, prof ? b->d_stats : nullptr, b->d_maxt);
-  MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYWH, K.det, S, bd, st));
+  // (round 5: the detections' boxes and measurements come out of bot_begin, the output rows' boxes out of bot_finish, which also gathers the error word)
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[7], st));
   if (emb) MOT_LC_HIP(b, mot::launch_feat(K.featn, S, bd, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[8], st));
@@ -705,9 +722,7 @@ static int bot_enqueue(mot_bot_batch* b, const float* d_dets, const int* h_count
     MOT_LC_HIP(b, mot::launch_feat(K.fema, S, bn, st));
   }
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[10], st));
-  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYWH, K.obox, S, bn2, st));
-  hipLaunchKernelGGL(bot_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt, b->d_alive);
-  hipLaunchKernelGGL(bot_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
+  hipLaunchKernelGGL(bot_finish, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt, b->d_alive, b->d_err);
   hipLaunchKernelGGL(mot::lifecycle::pack_offsets, dim3(1), dim3(1024), 0, st, b->d_out_counts, S, d_offsets, b->pack_meta);
   hipLaunchKernelGGL(mot::lifecycle::pack_rows, dim3(S), dim3(256), 0, st, b->d_out, CAP, b->d_out_counts, d_offsets, d_packed, rows_cap);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));

@@ -58,9 +58,34 @@ struct BtStream {
   int *init_dst, *init_meas; int n_init;
   int* lost_new; int n_lost_new;
   int *age_a, *age_b; unsigned char *dup_a, *dup_b;
-  float* abox;  // [4][CAP] boxes of the new active list (output rows)
-  float* lbox;  // [4][CAP] boxes of the new lost list (duplicate test)
+  float* abox;  // [4][CAP] (round 5: unused — the boxes of the new lists are computed from the means where they are read)
+  float* lbox;
+  // round 5: the box passes of a frame (kf_kernel<XYAH, boxes> twice, <XYAH, predict + boxes> once) are folded into the list kernels: a box is
+  // eight loads and six operations of a lane that has the slot in hand anyway, a launch is 5 us of a single camera's frame
+  const float* kmean;  // this stream's Kalman records (72 floats per slot: mean, covariance)
+  float *pool_box, *rbox, *ubox;  // [4][CAP] predicted boxes of the pool / stored boxes of the second association's tracks / of the unconfirmed ones
 };
+
+// KalmanFilterXYAH state -> box (kf_kernels.hip::s8_box<MOT_KF_XYAH>, ops.hpp:110-114): the same operations in the same order
+__device__ __forceinline__ float4 xyah_box4(float cx, float cy, float a, float h) {
+  const float w = a * h;
+  return make_float4(cx - w * 0.5f, cy - h * 0.5f, cx + w * 0.5f, cy + h * 0.5f);
+}
+__device__ __forceinline__ float4 stored_box(const float* kmean, int slot) {
+  const float4 m = *reinterpret_cast<const float4*>(kmean + static_cast<size_t>(slot) * 72);
+  return xyah_box4(m.x, m.y, m.z, m.w);
+}
+// the box of the PREDICTED state, nothing stored (kf_kernel<XYAH, OP_PREDICT_BOXES>): x' = F x touches the mean only
+__device__ __forceinline__ float4 predicted_box(const float* kmean, int slot, bool zero_v7) {
+  const float4* mp = reinterpret_cast<const float4*>(kmean + static_cast<size_t>(slot) * 72);
+  const float4 a = mp[0];
+  float4 v = mp[1];
+  if (zero_v7) v.w = 0.0f;
+  return xyah_box4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
+}
+__device__ __forceinline__ void store_box(float* planes, int CAP, int i, const float4& b) {
+  planes[i] = b.x; planes[static_cast<size_t>(CAP) + i] = b.y; planes[static_cast<size_t>(2) * CAP + i] = b.z; planes[static_cast<size_t>(3) * CAP + i] = b.w;
+}
 
 
 
@@ -118,6 +143,9 @@ __global__ void __launch_bounds__(kAFMax) bt_begin(BtStream* streams, BtParams P
     if (n > D) S.err = 1;
   }
   const float* conf = dets + static_cast<size_t>(4) * ldd;
+  float* dbox = det_t[blockIdx.x].box;
+  float* dmeas = det_t[blockIdx.x].meas;
+  const int dldb = det_t[blockIdx.x].ldb, dldm = det_t[blockIdx.x].ldm;
   int nh = 0, ns = 0, z = 0;
   for (int i0 = 0; i0 < n; i0 += static_cast<int>(blockDim.x)) {
     const int i = i0 + t;
@@ -127,6 +155,16 @@ __global__ void __launch_bounds__(kAFMax) bt_begin(BtStream* streams, BtParams P
     const Compact3 k = compact3_block(hi, lo, false, nh, ns, z, cnt);
     if (hi) S.high[k.pos[0]] = i;
     if (lo) S.second[k.pos[1]] = i;
+    if (i < n && n <= D) {  // the detection's association box and Kalman measurement (det_kernel<MOT_DET_XYAH>, bytetrack.cpp:29-33: the same operations)
+      const float x1 = dets[i], y1 = dets[static_cast<size_t>(ldd) + i], x2 = dets[static_cast<size_t>(2) * ldd + i], y2 = dets[static_cast<size_t>(3) * ldd + i];
+      const float w = x2 - x1, h = y2 - y1;
+      const float xc = x1 + w * 0.5f, yc = y1 + h * 0.5f;
+      const float tl = xc - w * 0.5f, tt = yc - h * 0.5f;
+      const float zz[4] = {tl + w * 0.5f, tt + h * 0.5f, (h > 0.0f) ? (w / h) : 0.0f, h};
+      const float bb[4] = {xc - w * 0.5f, yc - h * 0.5f, xc + w * 0.5f, yc + h * 0.5f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { dbox[static_cast<size_t>(q) * dldb + i] = bb[q]; dmeas[static_cast<size_t>(q) * dldm + i] = zz[q]; }
+    }
   }
   int np = 0, nu = 0;
   for (int i0 = 0; i0 < n_active; i0 += static_cast<int>(blockDim.x)) {
@@ -148,8 +186,11 @@ __global__ void __launch_bounds__(kAFMax) bt_begin(BtStream* streams, BtParams P
     S.pred_src[i] = slot;
     S.pred_dst[i] = slot;
     // only the predicted BOXES are needed now; a matched track is re-predicted inside its update (MOT_KF_PREDICT_FIRST)
-    S.pred_flags[i] = ((S.t_state[slot] != Tracked) ? MOT_KF_ZERO_V7 : 0) | MOT_KF_NO_STORE;
+    const bool zero_v7 = S.t_state[slot] != Tracked;
+    S.pred_flags[i] = (zero_v7 ? MOT_KF_ZERO_V7 : 0) | MOT_KF_NO_STORE;
+    store_box(S.pool_box, CAP, i, predicted_box(S.kmean, slot, zero_v7));
   }
+  for (int i = t; i < nu; i += static_cast<int>(blockDim.x)) store_box(S.ubox, CAP, i, stored_box(S.kmean, S.unconf_slot[i]));  // (third association)
   if (t == 0) {
     S.n_high = nh; S.n_second = ns; S.n_pool = np; S.n_tracked = n_tracked; S.n_unconf = nu;
     S.n_upd = 0; S.n_refind = 0; S.n_utrack = 0; S.n_udet = 0; S.n_r = 0; S.n_init = 0; S.n_lost_new = 0; S.lap2_q = 0; S.lap3_q = 0;
@@ -234,7 +275,7 @@ __global__ void __launch_bounds__(kAFMax) bt_after_first(BtStream* streams, BtPa
       const int slot = (k < n_ut) ? S.pool_slot[i] : 0;
       const bool r = k < n_ut && i < S.n_tracked && S.t_state[slot] == Tracked;
       const Compact3 c = compact3_block(r, false, false, n_r, z1, z2, cnt);
-      if (r) { S.r_slot[c.pos[0]] = slot; S.r_pool[c.pos[0]] = i; }
+      if (r) { S.r_slot[c.pos[0]] = slot; S.r_pool[c.pos[0]] = i; store_box(S.rbox, CAP, c.pos[0], stored_box(S.kmean, slot)); }
     }
   }
   for (int k = t; k < n_ud; k += static_cast<int>(blockDim.x)) S.rem[k] = S.high[S.u_det[k]];
@@ -468,6 +509,8 @@ __global__ void __launch_bounds__(kAFMax) bt_dups(BtStream* streams, int CAP, in
   BtStream& S = streams[blockIdx.x];
   const int na = S.n_active, nl = S.n_lost, T = static_cast<int>(blockDim.x);
   if (S.skip || na <= 0 || nl <= 0) return;
+  const int* act = S.active[S.cur];  // (bt_after_second has made the new lists current; the Kalman updates and initiations of the frame are done)
+  const int* lst = S.lost[S.cur];
   // the launch reserves LDS for lds_items lost boxes (far more than a stream usually has); a stream with more reads them from
   // global memory and tests every pair
   const bool staged = MODE != 0 && nl <= lds_items;
@@ -477,13 +520,13 @@ __global__ void __launch_bounds__(kAFMax) bt_dups(BtStream* streams, int CAP, in
   __shared__ int n_irr;
   if (MODE == 2 && staged) {
     for (int j = threadIdx.x; j < nl; j += T)
-      wl[j] = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
+      wl[j] = stored_box(S.kmean, lst[j]);
     __syncthreads();
   }
   if (MODE == 1 && staged) {
     if (threadIdx.x == 0) n_irr = 0;
     for (int j = threadIdx.x; j < nl; j += T)
-      wl[j] = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
+      wl[j] = stored_box(S.kmean, lst[j]);
     __syncthreads();
     // rank by (key, index) with key = x1, or -inf for a box with a non-finite coordinate: nl is a few hundred at most,
     // counting against the key array (one broadcast LDS read and three VALU operations per comparison) beats a sorting network
@@ -509,14 +552,15 @@ __global__ void __launch_bounds__(kAFMax) bt_dups(BtStream* streams, int CAP, in
     __syncthreads();
   }
   for (int i = threadIdx.x; i < na; i += T) {
-    const float a[4] = {S.abox[i], S.abox[static_cast<size_t>(CAP) + i], S.abox[static_cast<size_t>(2) * CAP + i], S.abox[static_cast<size_t>(3) * CAP + i]};
+    const float4 ab = stored_box(S.kmean, act[i]);
+    const float a[4] = {ab.x, ab.y, ab.z, ab.w};
     const float area_a = (a[2] - a[0]) * (a[3] - a[1]);
     const int age_a = S.age_a[i];
     bool dup_me = false;
     auto test = [&](int j, bool mark) {
       float4 bb;
       if (staged) bb = wl[j];
-      else bb = make_float4(S.lbox[j], S.lbox[static_cast<size_t>(CAP) + j], S.lbox[static_cast<size_t>(2) * CAP + j], S.lbox[static_cast<size_t>(3) * CAP + j]);
+      else bb = stored_box(S.kmean, lst[j]);
       const float iw = mot::smax(0.0f, mot::smin(a[2], bb.z) - mot::smax(a[0], bb.x));
       const float ih = mot::smax(0.0f, mot::smin(a[3], bb.w) - mot::smax(a[1], bb.y));
       const float inter = iw * ih;
@@ -591,7 +635,9 @@ __global__ void __launch_bounds__(kAFMax) bt_finish(BtStream* streams, int CAP, 
     float rid = 0.f, rconf = 0.f, rcls = 0.f, rdet = 0.f;
     if (emit) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) b[k] = S.abox[static_cast<size_t>(k) * CAP + i];
+      for (int k = 0; k < 4; ++k) b[k] = 0.f;
+      const float4 ob = stored_box(S.kmean, slot);
+      b[0] = ob.x; b[1] = ob.y; b[2] = ob.z; b[3] = ob.w;
       rid = static_cast<float>(S.t_id[slot]); rconf = S.t_conf[slot];
       rcls = static_cast<float>(S.t_cls[slot]); rdet = static_cast<float>(S.t_det[slot]);
     }
@@ -755,11 +801,13 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
     T.t_conf = F(CAP);
     float* pool_box = F(4 * CAP); float* rbox = F(4 * CAP); float* ubox = F(4 * CAP); T.abox = F(4 * CAP); float* lbox = F(4 * CAP);
     T.lbox = lbox;
+    T.pool_box = pool_box; T.rbox = rbox; T.ubox = ubox;
     float* d_box = F(4 * D); float* d_meas = F(4 * D);
     unsigned char* u = bp + static_cast<size_t>(CAP) * 4 * s;
     T.pred_flags = u; T.dup_a = u + CAP; T.dup_b = u + 2 * CAP; T.upd_flags = u + 3 * CAP;
     float* mean = b->mean + static_cast<size_t>(s) * 72 * C2;
     float* cov = mean + 8;
+    T.kmean = mean;
     // ---- static parts of the task descriptors ----
     std::memset(&det[s], 0, sizeof(mot_det_task));
     det[s].box = d_box; det[s].ldb = D; det[s].meas = d_meas; det[s].ldm = D;
@@ -841,14 +889,13 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   const bool few = active <= 16;  // latency over throughput
   const int bt_threads = few ? (longest > 512 ? kAFMax : (longest > 256 ? 512 : (longest > 64 ? kAF : kW))) : ((longest > 384) ? kAF : kW);
   hipLaunchKernelGGL(bt_begin, dim3(S), dim3(bt_threads), 0, st, b->d_streams, b->prm, CAP, D, FD, d_dets, b->det_t, b->pred_t, b->lap1_t, prof ? b->d_stats : nullptr, b->d_maxt, b->d_decl);
-  MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYAH, b->det_t, S, bd, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[6], st));
-  MOT_LC_HIP(b, mot::launch_kf_op(6, MOT_KF_XYAH, b->pred_t, S, bn, st));  // predicted boxes of the pool (box-only: nothing is stored)
+  // (round 5: the predicted boxes of the pool come out of bt_begin, the boxes of the other associations' tracks out of bt_after_first, those of
+  // the new lists are computed by bt_dups / bt_finish from the updated means: three launches fewer per frame)
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap1_t, S, bn, bd, true, false, true, st, b->hint1_n, 0, true, nullptr, prof ? ev[10] : nullptr, b->d_decl, active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
   hipLaunchKernelGGL(bt_after_first, dim3(S), dim3(bt_threads), 0, st, b->d_streams, b->prm, CAP, b->box_t, b->lap23_t, prof ? b->d_stats : nullptr, b->d_maxt, b->d_decl + 1);
-  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box_t, 2 * S, bn, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, true, st, b->hint23_n, b->hint23_m, true, nullptr, nullptr, b->d_decl + 1, 2 * active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
@@ -858,7 +905,6 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[8], st));
   MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, bn, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[9], st));
-  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYAH, b->box2_t, 2 * S, bn2, st));
   {
     static const int verify = std::getenv("MOT_BT_DUPS_VERIFY") != nullptr ? 1 : 0;  // tests: cross-check the sorted window
     static const bool full = std::getenv("MOT_BT_DUPS_FULL") != nullptr;  // measurement aid: every pair, boxes staged in LDS

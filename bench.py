@@ -501,7 +501,8 @@ def main():
                     fr = ps["frame_all_kernels"]["launches"]
                     # (round 5: the predicted boxes of the pool are computed inside bt_begin — no launch of their own any more; the item count stays for the byte model)
                     ps["kf_predict_boxes"] = {"ms": 0.0, "launches": fr, "tasks": kf["predict_boxes_items"], "bytes": 52.0 * kf["predict_boxes_items"], "flops": 0.0}
-                    ps["kf_initiate"] = {"ms": kf["initiate_ms"], "launches": fr, "tasks": kf["initiate_items"], "bytes": 312.0 * kf["initiate_items"], "flops": 0.0}
+                    ps["kf_initiate"] = {"ms": 0.0,  # (round 5: written by bt_after_second, no launch of its own)
+                                         "launches": fr, "tasks": kf["initiate_items"], "bytes": 312.0 * kf["initiate_items"], "flops": 0.0}
                     ps["kf_update"] = {"ms": kf["update_ms"], "launches": fr, "tasks": kf["update_items"], "bytes": 604.0 * kf["update_items"], "flops": 0.0}
             for k, v in ps.items():
                 a = acc.setdefault(k, {"ms": 0.0, "launches": 0, "tasks": 0, "bytes": 0.0, "flops": 0.0})

@@ -446,6 +446,28 @@ __global__ void __launch_bounds__(kAFMax) bt_after_second(BtStream* streams, BtP
     if (k) na[c.pos[0]] = slot;
     if (dead) S.free_stack[c.pos[1]] = slot;
   }
+  // the new tracks' Kalman records (round 5: here instead of a launch of kf_kernel<XYAH, initiate> — a handful of births per stream and frame;
+  // KalmanFilterXYAH::initiate as kf_kernels.hip::s8_init<MOT_KF_XYAH> writes it: mean = (z, 0), P = diag(sd^2))
+  for (int i = t; i < n_init; i += static_cast<int>(blockDim.x)) {
+    const int slot = S.init_dst[i], det = S.init_meas[i];
+    const float* zm = init_t[blockIdx.x].meas;
+    const int ldm = init_t[blockIdx.x].ldm;
+    const float z0 = zm[det], z1 = zm[static_cast<size_t>(ldm) + det], z2 = zm[static_cast<size_t>(2) * ldm + det], h = zm[static_cast<size_t>(3) * ldm + det];
+    constexpr float kWp = 1.0f / 20.0f, kWv = 1.0f / 160.0f;
+    float sd[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sd[q] = (q < 4) ? 2.0f * kWp * h : 10.0f * kWv * h;
+    sd[2] = 1e-2f; sd[6] = 1e-5f;
+    float4* rec = reinterpret_cast<float4*>(const_cast<float*>(S.kmean) + static_cast<size_t>(slot) * 72);
+    rec[0] = make_float4(z0, z1, z2, h);
+    rec[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float d = sd[r] * sd[r];
+      rec[2 + 2 * r] = make_float4(r == 0 ? d : 0.0f, r == 1 ? d : 0.0f, r == 2 ? d : 0.0f, r == 3 ? d : 0.0f);
+      rec[3 + 2 * r] = make_float4(r == 4 ? d : 0.0f, r == 5 ? d : 0.0f, r == 6 ? d : 0.0f, r == 7 ? d : 0.0f);
+    }
+  }
   if (n_na + n_init + n_refind > CAP) err = 1;
   else {
     for (int i = t; i < n_init; i += static_cast<int>(blockDim.x)) na[n_na + i] = S.init_dst[i];
@@ -901,7 +923,6 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
   hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(bt_threads), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t, prof ? b->d_stats : nullptr);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[7], st));
-  MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYAH, b->init_t, S, bd, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[8], st));
   MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, bn, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[9], st));

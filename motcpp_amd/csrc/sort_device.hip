@@ -37,7 +37,8 @@ struct SortStream {
   int *init_slot, *init_meas; int n_init;
   int* out_slot; int n_out;
   float* pbox;  // [4][CAP] predicted boxes, column = position in the track list at frame start
-  float* obox;  // [4][CAP] boxes of the rows to emit
+  float* obox;  // [4][CAP] (round 5: unused — sort_emit computes a row's box from the updated state)
+  float* kmean; // this stream's Kalman records (56 floats per slot: 7 + 7 x 7)
 };
 
 
@@ -54,12 +55,23 @@ __global__ void __launch_bounds__(kW) sort_begin(SortStream* streams, SortParams
   int ldd = D;
   const float* dets = mot::lifecycle::frame_dets(FD, dets_base, blockIdx.x, D, ldd);
   const float* conf = dets + static_cast<size_t>(4) * ldd;
+  float* dbox = det_t[blockIdx.x].box;
+  float* dmeas = det_t[blockIdx.x].meas;
+  const int dldb = det_t[blockIdx.x].ldb, dldm = det_t[blockIdx.x].ldm;
   int nv = 0;
   for (int i0 = 0; i0 < n; i0 += kW) {
     const int i = i0 + t;
     const bool v = i < n && conf[i] >= P.det_thresh;
     const int p = compact(v, nv);
     if (v) S.valid[p] = i;
+    if (i < n && n <= D) {  // the detection's box and measurement (round 5: here instead of det_kernel<MOT_DET_XYSR>, ops.hpp:188-197: the same operations)
+      const float x1 = dets[i], y1 = dets[static_cast<size_t>(ldd) + i], x2 = dets[static_cast<size_t>(2) * ldd + i], y2 = dets[static_cast<size_t>(3) * ldd + i];
+      const float w = x2 - x1, h = y2 - y1;
+      const float zz[4] = {x1 + w * 0.5f, y1 + h * 0.5f, w * h, (h > 1e-6f) ? (w / h) : 0.0f};
+      const float bb[4] = {x1, y1, x2, y2};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { dbox[static_cast<size_t>(q) * dldb + i] = bb[q]; dmeas[static_cast<size_t>(q) * dldm + i] = zz[q]; }
+    }
   }
   const int* trk = S.trk[S.cur];
   for (int i = t; i < S.n_trk; i += kW) { const int slot = trk[i]; S.t_age[slot] += 1; S.t_tsu[slot] += 1; }
@@ -194,6 +206,24 @@ __global__ void __launch_bounds__(kW) sort_apply(SortStream* streams, SortParams
   }
   const int n_all = n_next + n_init;
   __syncthreads();
+  // the new tracks' Kalman records (round 5: here instead of a launch of kf_kernel<XYSR, initiate>; KalmanBoxTracker's constructor as
+  // kf_kernels.hip::xysr_init writes it: mean = (z, 0, 0, 0), P = diag(10, 10, 10, 10, 1000, 1000, 1000))
+  for (int i = t; i < n_init; i += kW) {
+    const int slot = S.init_slot[i], det = S.init_meas[i];
+    if (slot < 0 || slot >= CAP) continue;  // (only on a stream that has already raised its error flag)
+    const float* zm = init_t[blockIdx.x].meas;
+    const int ldm = init_t[blockIdx.x].ldm;
+    float flat[56];
+#pragma unroll
+    for (int q = 0; q < 56; ++q) flat[q] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) flat[q] = zm[static_cast<size_t>(q) * ldm + det];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) flat[7 + 8 * q] = (q < 4) ? 10.0f : 10.0f * 100.0f;
+    float4* rec = reinterpret_cast<float4*>(S.kmean + static_cast<size_t>(slot) * 56);
+#pragma unroll
+    for (int q = 0; q < 14; ++q) rec[q] = make_float4(flat[4 * q], flat[4 * q + 1], flat[4 * q + 2], flat[4 * q + 3]);
+  }
   // rows to emit (:218-246)
   int n_out = 0;
   for (int i0 = 0; i0 < n_all && i0 < CAP; i0 += kW) {
@@ -216,11 +246,11 @@ __global__ void __launch_bounds__(kW) sort_apply(SortStream* streams, SortParams
   }
 }
 
-__global__ void __launch_bounds__(kW) sort_emit(SortStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive) {
+__global__ void __launch_bounds__(kW) sort_emit(SortStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive, int* err) {
   SortStream& S = streams[blockIdx.x];
   const int t = threadIdx.x;
   if (S.skip) {
-    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_trk; atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk); }
+    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_trk; atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk); if (S.err) atomicMax(err, S.err); }
     return;
   }
   float* rows = out + static_cast<size_t>(blockIdx.x) * cap_out * 8;
@@ -229,7 +259,13 @@ __global__ void __launch_bounds__(kW) sort_emit(SortStream* streams, int CAP, fl
     const int slot = S.out_slot[k];
     float* r = rows + static_cast<size_t>(k) * 8;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r[c] = S.obox[static_cast<size_t>(c) * CAP + k];
+    for (int c = 0; c < 4; ++c) r[c] = 0.f;
+    {  // the box of the updated state (round 5: here instead of kf_kernel<XYSR, boxes>; kf_kernels.hip::xysr_box, ops.hpp:202-211)
+      const float4 m = *reinterpret_cast<const float4*>(S.kmean + static_cast<size_t>(slot) * 56);
+      const float w = sqrtf(m.z * m.w);
+      const float h = m.z / w;
+      r[0] = m.x - w * 0.5f; r[1] = m.y - h * 0.5f; r[2] = m.x + w * 0.5f; r[3] = m.y + h * 0.5f;
+    }
     r[4] = static_cast<float>(S.t_id[slot]); r[5] = S.t_conf[slot];
     r[6] = static_cast<float>(S.t_cls[slot]); r[7] = static_cast<float>(S.t_det[slot]);
   }
@@ -238,12 +274,8 @@ __global__ void __launch_bounds__(kW) sort_emit(SortStream* streams, int CAP, fl
     out_counts[blockIdx.x] = (n <= cap_out) ? n : -n;
     atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk);
     alive[blockIdx.x] = S.n_trk;
+    if (S.err) atomicMax(err, S.err);  // the batch's error word (round 5: gathered here; a kernel of its own before)
   }
-}
-
-__global__ void sort_collect_err(const SortStream* streams, int n, int* err) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && streams[i].err) atomicMax(err, streams[i].err);
 }
 
 }  // namespace
@@ -348,6 +380,7 @@ int mot_sort_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, co
     T.t_conf = F(CAP); T.pbox = F(4 * CAP); T.obox = F(4 * CAP);
     float* d_box = F(4 * D); float* d_meas = F(4 * D);
     float* mean = b->mean + static_cast<size_t>(s) * 56 * CAP;
+    T.kmean = mean;
     float* cov = mean + 7;
     std::memset(&det[s], 0, sizeof(mot_det_task));
     det[s].box = d_box; det[s].ldb = D; det[s].meas = d_meas; det[s].ldm = D;
@@ -404,23 +437,19 @@ static int sort_enqueue_frame(mot_sort_batch* b, const float* d_dets, const int*
   for (int s = 0; s < S; ++s) bd = (counts[s] > bd) ? counts[s] : bd;
   if (bd > D) bd = D;
   const int bn = (bound < 1) ? 1 : (bound > CAP ? CAP : bound);  // tracks alive after the previous frame (+ what frames in flight may add)
-  const int bn2 = (bn + bd > CAP) ? CAP : bn + bd;
   int active = 0;  // streams with a frame: a launch with a handful of problems is tuned for latency (mot::launch_lap)
   for (int s = 0; s < S; ++s) active += (counts[s] >= 0) ? 1 : 0;
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
   hipLaunchKernelGGL(sort_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, FD, d_dets, b->det_t, b->pred_t);
-  MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYSR, b->det_t, S, bd, st));
+  // (round 5: detection preparation in sort_begin, initiations in sort_apply, output boxes and the error word in sort_emit: four launches fewer)
   MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYSR, b->pred_t, S, bn, st));
   hipLaunchKernelGGL(sort_assoc, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->lap_t, prof ? b->d_stats : nullptr);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap_t, S, bn, bd, true, false, true, st, 0, 0, true, nullptr, nullptr, nullptr, active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
   hipLaunchKernelGGL(sort_apply, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box_t);
-  MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYSR, b->init_t, S, bd, st));
   MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYSR, b->upd_t, S, bn, st));
-  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYSR, b->box_t, S, bn2, st));
-  hipLaunchKernelGGL(sort_emit, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt, b->d_alive);
-  hipLaunchKernelGGL(sort_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
+  hipLaunchKernelGGL(sort_emit, dim3(S), dim3(kW), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt, b->d_alive, b->d_err);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
   MOT_LC_HIP(b, hipGetLastError());
   return MOT_OK;

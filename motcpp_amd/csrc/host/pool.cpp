@@ -202,6 +202,14 @@ class Segment {
   int kind() const { return kind_; }
   int level() const { return level_; }
   void* batch() const { return batch_; }
+  // runs f(batch) between rounds, with this segment's context bound: what reads the batch from outside a round (PooledStream::dump) must not
+  // overlap a leader that is enqueuing on it, nor leave another device current
+  template <class F>
+  auto quiesced(F f) {
+    std::lock_guard<std::mutex> lk(run_mu_);
+    check(mot_ctx_bind(ctx_), "mot_ctx_bind");
+    return f(batch_);
+  }
   mot_ctx* ctx() const { return ctx_; }
   const int kind_, level_;
   const int S, CAP, D, E;
@@ -289,7 +297,9 @@ class Segment {
     futex_wake_all(&word_[p]);  // this round's callers, and the leader of the next round if it is waiting already
   }
 
+  std::mutex run_mu_;  // held while a round runs on the batch (uncontended except against quiesced())
   void run(const std::vector<Request*>& reqs, int parity, size_t det_top, size_t emb_top) {
+    std::lock_guard<std::mutex> run_lock(run_mu_);
     check(mot_ctx_bind(ctx_), "mot_ctx_bind");
     std::fill(counts_.begin(), counts_.end(), -1);
     bool any_warp = false, any_emb = false;
@@ -605,13 +615,13 @@ int PooledStream::dump(std::vector<int>* ids, std::vector<float>* mean, std::vec
   ids->assign(cap, 0); mean->assign(static_cast<size_t>(cap) * d, 0.f); cov->assign(static_cast<size_t>(cap) * d * d, 0.f);
   if (feats) feats->assign(static_cast<size_t>(cap) * (e > 0 ? e : 1), 0.f);
   if (has_feat) has_feat->assign(cap, 0);
-  int n = 0;
-  void* b = seg_->batch();
-  if (kind_ == kPoolByteTrack) n = mot_bt_dump(static_cast<mot_bt_batch*>(b), s_, ids->data(), mean->data(), cov->data(), cap);
-  else if (kind_ == kPoolSort) n = mot_sort_dump(static_cast<mot_sort_batch*>(b), s_, ids->data(), mean->data(), cov->data(), cap);
-  else if (kind_ == kPoolOCSort) n = mot_oc_dump(static_cast<mot_oc_batch*>(b), s_, ids->data(), mean->data(), cov->data(), cap);
-  else n = mot_bot_dump(static_cast<mot_bot_batch*>(b), s_, ids->data(), mean->data(), cov->data(), (feats && e > 0) ? feats->data() : nullptr,
+  const int n = seg_->quiesced([&](void* b) {  // (between rounds, this segment's device current)
+    if (kind_ == kPoolByteTrack) return mot_bt_dump(static_cast<mot_bt_batch*>(b), s_, ids->data(), mean->data(), cov->data(), cap);
+    if (kind_ == kPoolSort) return mot_sort_dump(static_cast<mot_sort_batch*>(b), s_, ids->data(), mean->data(), cov->data(), cap);
+    if (kind_ == kPoolOCSort) return mot_oc_dump(static_cast<mot_oc_batch*>(b), s_, ids->data(), mean->data(), cov->data(), cap);
+    return mot_bot_dump(static_cast<mot_bot_batch*>(b), s_, ids->data(), mean->data(), cov->data(), (feats && e > 0) ? feats->data() : nullptr,
                         has_feat ? has_feat->data() : nullptr, cap);
+  });
   if (n < 0) throw Error("motcpp_amd: state dump failed");
   ids->resize(n); mean->resize(static_cast<size_t>(n) * d); cov->resize(static_cast<size_t>(n) * d * d);
   if (feats) feats->resize(static_cast<size_t>(n) * (e > 0 ? e : 0));

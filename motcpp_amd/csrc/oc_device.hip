@@ -50,7 +50,8 @@ struct OcStream {
   int skip;  // the stream sits this frame out (pooled form: counts[s] < 0)
   int *high, *second; int n_high, n_second;
   int nt0, silent, lap1_q, byte_q, rem_q;
-  float *pbox, *vel, *prev, *lbox, *sbox;  // [4][CAP], [2][CAP], [5][CAP], [4][CAP], [4][CAP]
+  float *pbox, *vel, *prev, *lbox, *sbox;  // [4][CAP], [2][CAP], [5][CAP], [4][CAP], [4][CAP] (sbox: unused since round 5)
+  const float* kmean;  // this stream's Kalman records (56 floats per slot)
   int *x1, *y1, *xb, *yb, *xr, *yr;
   float *xval1, *xvalb, *xvalr;
   int *info1, *infob, *infor;
@@ -192,6 +193,9 @@ __global__ void __launch_bounds__(kW) oc_begin(OcStream* streams, OcParams P, in
   const bool over = n > D;
   if (over) n = 0;
   const float* conf = dets + static_cast<size_t>(4) * ldd;
+  float* dbox = K.det[s].box;
+  float* dmeas = K.det[s].meas;
+  const int dldb = K.det[s].ldb, dldm = K.det[s].ldm;
   int nh = 0, ns = 0;
   for (int i0 = 0; i0 < n; i0 += kW) {
     const int i = i0 + t;
@@ -202,6 +206,14 @@ __global__ void __launch_bounds__(kW) oc_begin(OcStream* streams, OcParams P, in
     if (lo) S.second[pl] = i;
     const int ph = compact(hi, nh);
     if (hi) S.high[ph] = i;
+    if (i < n) {  // the detection's box and measurement (round 5: here instead of det_kernel<MOT_DET_XYSR>, ops.hpp:188-197: the same operations)
+      const float x1 = dets[i], y1 = dets[static_cast<size_t>(ldd) + i], x2 = dets[static_cast<size_t>(2) * ldd + i], y2 = dets[static_cast<size_t>(3) * ldd + i];
+      const float w = x2 - x1, h = y2 - y1;
+      const float zz[4] = {x1 + w * 0.5f, y1 + h * 0.5f, w * h, (h > 1e-6f) ? (w / h) : 0.0f};
+      const float bb[4] = {x1, y1, x2, y2};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { dbox[static_cast<size_t>(q) * dldb + i] = bb[q]; dmeas[static_cast<size_t>(q) * dldm + i] = zz[q]; }
+    }
   }
   const int* trk = S.trk[S.cur];
   for (int i = t; i < S.n_trk; i += kW) {
@@ -472,11 +484,11 @@ __global__ void __launch_bounds__(kW) oc_finish(OcStream* streams, OcParams P, i
 }
 
 // ---- K5: the output table (newest tracker first) and the age-out (:562-606) ----
-__global__ void __launch_bounds__(kW) oc_emit(OcStream* streams, OcParams P, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive) {
+__global__ void __launch_bounds__(kW) oc_emit(OcStream* streams, OcParams P, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive, int* err) {
   OcStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
   if (S.skip || S.silent) {
-    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_trk; atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk); }
+    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_trk; atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk); if (S.err) atomicMax(err, S.err); }
     return;
   }
   const int* trk = S.trk[S.cur];
@@ -495,8 +507,11 @@ __global__ void __launch_bounds__(kW) oc_emit(OcStream* streams, OcParams P, int
       const float* last = S.t_last + static_cast<size_t>(slot) * 5;
       float b[4] = {last[0], last[1], last[2], last[3]};
       if (b[0] + b[1] + b[2] + b[3] < 0) {
-        const int k = S.t_need[slot];
-        for (int c = 0; c < 4; ++c) b[c] = S.sbox[static_cast<size_t>(c) * CAP + k];
+        // the box of the track's state (round 5: here instead of kf_kernel<XYSR, boxes> over the tracks that need it; kf_kernels.hip::xysr_box)
+        const float4 m = *reinterpret_cast<const float4*>(S.kmean + static_cast<size_t>(slot) * 56);
+        const float w = sqrtf(m.z * m.w);
+        const float h = m.z / w;
+        b[0] = m.x - w * 0.5f; b[1] = m.y - h * 0.5f; b[2] = m.x + w * 0.5f; b[3] = m.y + h * 0.5f;
       }
       float* r = rows + static_cast<size_t>(p) * 8;
       r[0] = b[0]; r[1] = b[1]; r[2] = b[2]; r[3] = b[3];
@@ -522,12 +537,8 @@ __global__ void __launch_bounds__(kW) oc_emit(OcStream* streams, OcParams P, int
     out_counts[blockIdx.x] = (n_rows <= cap_out) ? n_rows : -n_rows;
     atomicMax(&max_tracks[blockIdx.x & 63], n_keep);
     alive[blockIdx.x] = n_keep;
+    if (S.err) atomicMax(err, S.err);  // the batch's error word (round 5: gathered here; a kernel of its own before)
   }
-}
-
-__global__ void oc_collect_err(const OcStream* streams, int n, int* err) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && streams[i].err) atomicMax(err, streams[i].err);
 }
 
 }  // namespace
@@ -677,6 +688,7 @@ int mot_oc_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
     unsigned char* u = bp + bytes_per * s;
     Z.mt = u; Z.rm_t = u + CAP; Z.md = u + 2 * CAP; Z.rm_d = u + 2 * CAP + D;
     float* mean = b->mean + static_cast<size_t>(s) * 56 * CAP;
+    Z.kmean = mean;
     float* cmat = mats + static_cast<size_t>(s) * 2 * D * ldc;
     float* imat = cmat + static_cast<size_t>(D) * ldc;
     std::memset(&det[s], 0, sizeof(mot_det_task));
@@ -750,12 +762,11 @@ static int oc_enqueue_frame(mot_oc_batch* b, const float* d_dets, const int* cou
   for (int s = 0; s < S; ++s) bd = (counts[s] > bd) ? counts[s] : bd;
   if (bd > D) bd = D;
   const int bn = (bound < 1) ? 1 : (bound > CAP ? CAP : bound);
-  const int bn2 = (bn + 2 * bd > CAP) ? CAP : bn + 2 * bd;
   const bool general = b->prm.asso != MOT_ASSOC_IOU;
   const OcTasks& K = b->tasks;
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[0], st));
   hipLaunchKernelGGL(oc_begin, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, S, FD, d_dets, K);
-  MOT_LC_HIP(b, mot::launch_det(MOT_DET_XYSR, K.det, S, bd, st));
+  // (round 5: detection preparation in oc_begin, the emitted rows' state boxes and the error word in oc_emit: three launches fewer)
   MOT_LC_HIP(b, mot::launch_kf_op(1, MOT_KF_XYSR, K.pred, S, bn, st));
   hipLaunchKernelGGL(oc_nan, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, K, prof ? b->d_stats : nullptr);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[2], st));
@@ -780,9 +791,7 @@ static int oc_enqueue_frame(mot_oc_batch* b, const float* d_dets, const int* cou
   hipLaunchKernelGGL(oc_finish, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, D, S, K);
   MOT_LC_HIP(b, mot::launch_kf_op(0, MOT_KF_XYSR, K.init, S, 2 * bd, st));
   for (int r = 0; r < kRounds; ++r) MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYSR, K.upd + static_cast<size_t>(r) * S, S, (r == 0) ? bn : 2 * bd, st));
-  MOT_LC_HIP(b, mot::launch_kf_op(3, MOT_KF_XYSR, K.sbox, S, bn2, st));
-  hipLaunchKernelGGL(oc_emit, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt, b->d_alive);
-  hipLaunchKernelGGL(oc_collect_err, dim3((S + 255) / 256), dim3(256), 0, st, b->d_streams, S, b->d_err);
+  hipLaunchKernelGGL(oc_emit, dim3(S), dim3(kW), 0, st, b->d_streams, b->prm, CAP, b->d_out, b->d_out_counts, CAP, b->d_maxt, b->d_alive, b->d_err);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[1], st));
   MOT_LC_HIP(b, hipGetLastError());
   declined_out[0] = lap1_declined; declined_out[1] = lapb_declined; declined_out[2] = lapr_declined;

@@ -117,11 +117,18 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   const bool behind = fast && behind_t == 256 && n * m >= 65536 && nm <= 3072;
   // (matrix costs of some size: any number of problems — with 64 threads the row lists' parallel scan steps are not available; geometry
   // launches keep the old bound on the problem count, so that large batches stay on the one-wavefront register-cached variants)
-  const bool wide = (nm > 3072 && (ntasks < 512 || fs_lds)) || behind;
+  // Round 5: a MATRIX problem behind the fast path (DeepOC-SORT, StrongSORT, UCMCTrack, BoostTrack, HybridSORT: their costs are materialised, and the
+  // duplicated tracks of deepocsort.cpp:456-503 make the optimum non-unique in almost every frame) ran on ONE wavefront with everything but the duals in
+  // global scratch: 2.3-3.4 ms per declined 128 x 256 problem, 71 % of DeepOC-SORT's GPU time (tools/f3_latency_probe.py). It gets four wavefronts
+  // (the dense row sweeps of the shortest-path search are nm wide) and the full hot state in LDS. MOT_LAP_BEHIND_MATRIX=0 keeps the old choice (A/B).
+  static const bool behind_matrix_ok = !(std::getenv("MOT_LAP_BEHIND_MATRIX") && std::getenv("MOT_LAP_BEHIND_MATRIX")[0] == '0');
+  const bool behind_matrix = behind_matrix_ok && fast && !geom && !general_assoc && nm >= 128 && nm <= 3072 && b2 <= static_cast<size_t>(kLdsBudget) - 1024;
+  const bool wide = (nm > 3072 && (ntasks < 512 || fs_lds)) || behind || behind_matrix;
   // mode 4 (distances in LDS for the scan steps) exists for cost flavour 1 only
   if (fs_lds && wide && !general_assoc && b4 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 4; lds = b4; }
   static const bool lds16_ok = !(std::getenv("MOT_LAP_LDS16") && std::getenv("MOT_LAP_LDS16")[0] == '0');  // (A/B measurements)
   if (lds16_ok && fs_lds && wide && !general_assoc && nm <= 2 * static_cast<size_t>(mot::kFsEvl) && b6 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 6; lds = b6; }
+  if (behind_matrix) { mode = 2; lds = b2; }
   // lane-owned column boxes in registers: one wavefront per problem, <= 8 real columns per lane
   int rpl = 0;
   if (geom && !wide && !general_assoc) rpl = (m <= 256) ? 4 : (m <= 512 ? 8 : 0);
@@ -171,7 +178,7 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   static const bool wide8_ok = !(std::getenv("MOT_LAP_WIDE8") && std::getenv("MOT_LAP_WIDE8")[0] == '0');
   const bool wide8 = wide && wide8_ok && (ntasks <= 256 || mode == 4 || mode == 6) && flavor == 1;  // (mode 4: one problem per CU whatever the width)
   static const int wide_t = std::getenv("MOT_LAP_WIDE_T") ? std::atoi(std::getenv("MOT_LAP_WIDE_T")) : 0;  // (experiments)
-  const int threads = behind_quad ? 256 : ((wide && flavor == 1 && (wide_t == 256 || wide_t == 512)) ? wide_t : (wide8 ? 512 : (wide ? 256 : 64)));
+  const int threads = (behind_quad || behind_matrix) ? 256 : ((wide && flavor == 1 && (wide_t == 256 || wide_t == 512)) ? wide_t : (wide8 ? 512 : (wide ? 256 : 64)));
   static LapDiag diag_dev[64] = {};
   {
     std::lock_guard<std::mutex> attr_lock(attr_mu);

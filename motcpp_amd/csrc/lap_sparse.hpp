@@ -355,8 +355,15 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
     if (!(static_cast<double>(zc) > th + kSpEps)) bad |= 8;  // a non-intersecting pair would be viable (or zc is NaN)
     int nq = 0, ne = 0, base = 0, seg = -1, ninter = 0;
     if (!bad) {
-      const int bhi = bucket(b[2]);
-      const int kb0 = f32_key(b[0]);
+      // Round 5: a candidate must pass hits(), i.e. inter > min_iou * union. With union >= the column's area and ih <= its height that forces
+      // iw > min_iou * (b2 - b0), and iw <= b2 - a0 and iw <= a2 - b0: a row that can pass starts before b2 - m and ends after b0 + m,
+      // m = 0.9 * min_iou * width (the tenth dwarfs every rounding: the terms are float expressions of the same magnitude). The x window of the
+      // column shrinks by that margin at both ends (a fifth fewer candidates at the north-star shape); a width that is not a positive finite
+      // number leaves it as it was.
+      const float bw = b[2] - b[0];
+      const float mrg = (min_iou > 0.0f && bw > 0.0f && bw < kSpHuge) ? 0.9f * min_iou * bw : 0.0f;
+      const int bhi = bucket(b[2] - mrg);
+      const int kb0 = f32_key(b[0] + mrg);
       int lo = 0, hi = bhi + 1;  // first bucket whose prefix maximum of x2 exceeds b0
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (static_cast<int>(w.bmax[mid]) > kb0) hi = mid; else lo = mid + 1; }
       const int ps = w.bstart[lo], pe = w.bstart[bhi + 1];

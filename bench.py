@@ -483,7 +483,7 @@ def main():
                                  "flops": (2.0 * ps["cos_nm"] * D) if DENSE_COS else 0.0},
                       # feat_kernel: the three launches of a frame (normalise the detections' rows, set the new tracks' features, blend the matched
                       # ones); bytes = 4 D per row read or written (normalise / set: 2 per row, blend: 3), counted on the device
-                      "feat": {"ms": ps["feat_ms"], "launches": 3 * ps["frames"], "tasks": ps["frames"] * (bounds[1] - bounds[0]),
+                      "feat": {"ms": ps["feat_ms"], "launches": 3 * ps["frames"], "tasks": 3 * ps["frames"] * (bounds[1] - bounds[0]),  # (a task per stream and launch)
                                "bytes": 4.0 * D * ps["feat_row_moves"], "flops": 0.0},
                       "frame_all_kernels": {"ms": ps["frame_ms"], "launches": ps["frames"], "tasks": (bounds[1] - bounds[0]) * ps["frames"],
                                             "bytes": 0.0, "flops": 0.0}}

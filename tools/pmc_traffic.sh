@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON the GPU box (through gpurun): HBM traffic of the dominant kernel family of one workload from the PMC counters — FETCH_SIZE and WRITE_SIZE in
 # SEPARATE rocprofv3 passes (nothing else traced), summed per kernel by tools/pmc_aggregate.py, turned into profiles-style pmc_<WL>.json by
-# tools/pmc_traffic_derive.py.   tools/pmc_traffic.sh <tag> <workload> <family: cosine | lap | lap1_sparse> <streams> "<extra bench args>"
+# tools/pmc_traffic_derive.py.   tools/pmc_traffic.sh <tag> <workload> <family: cosine | lap | lap1_sparse | feat> <streams> "<extra bench args>"
 set -u
 TAG=$1; WL=$2; FAM=$3; S=$4; EXTRA=${5:-}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT

@@ -6,7 +6,7 @@ import json, sys
 
 fetch, write = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
 wl, fam, S, cmd = sys.argv[3], sys.argv[4], int(sys.argv[5]), sys.argv[6]
-pref = {"cosine": ("embed_kernel<",), "lap": ("lap_sparse_kernel<", "lap_kernel<"), "lap1_sparse": ("lap_sparse_kernel<",)}[fam]
+pref = {"cosine": ("embed_kernel<",), "lap": ("lap_sparse_kernel<", "lap_kernel<"), "lap1_sparse": ("lap_sparse_kernel<",), "feat": ("feat_kernel",)}[fam]
 ks = [k for k in fetch if k.startswith(pref)]
 if not ks:
     raise SystemExit(f"no kernel of family {fam} in the counter files: {list(fetch)[:8]}")

@@ -33,7 +33,7 @@ __device__ __forceinline__ float pair_cosine(const float* __restrict__ pa, const
     const float4* b4 = reinterpret_cast<const float4*>(pb);
     const int q = d >> 2;
 #pragma unroll 4
-    for (int k = 0; k < q; ++k) {
+    for (int k = 0; k < q; ++k) {  // (four pairs of 16-byte loads in flight per lane; sixteen measured slower: 0.167 against 0.143 ms per launch at C3)
       const float4 a = a4[k], b = b4[k];
       dp = __builtin_fmaf(a.x, b.x, dp); na = __builtin_fmaf(a.x, a.x, na); nb = __builtin_fmaf(b.x, b.x, nb);
       dp = __builtin_fmaf(a.y, b.y, dp); na = __builtin_fmaf(a.y, a.y, na); nb = __builtin_fmaf(b.y, b.y, nb);

@@ -526,9 +526,8 @@ __global__ void __launch_bounds__(kAFMax) bt_after_second(BtStream* streams, BtP
 // box whose width is not a positive finite number visits everything. `verify` (MOT_BT_DUPS_VERIFY=1, tests): the full scan
 // runs as well and any pair it would mark outside the window raises the stream's error flag 3.
 template <int MODE>  // 0: lost boxes read from global, all pairs; 1: staged in LDS, sorted window; 2: staged in LDS, all pairs
-__global__ void __launch_bounds__(kAFMax) bt_dups(BtStream* streams, int CAP, int verify, int lds_items) {
+__device__ __forceinline__ void bt_dups_body(BtStream& S, int CAP, int verify, int lds_items) {
   extern __shared__ __attribute__((aligned(16))) float sbox[];  // [nl] float4 boxes, [nl] sorted x1 keys, [nl] sorted indices, [nl] keys
-  BtStream& S = streams[blockIdx.x];
   const int na = S.n_active, nl = S.n_lost, T = static_cast<int>(blockDim.x);
   if (S.skip || na <= 0 || nl <= 0) return;
   const int* act = S.active[S.cur];  // (bt_after_second has made the new lists current; the Kalman updates and initiations of the frame are done)
@@ -624,13 +623,16 @@ __global__ void __launch_bounds__(kAFMax) bt_dups(BtStream* streams, int CAP, in
     if (dup_me) S.dup_a[i] = 1;
   }
 }
+template <int MODE>
+__global__ void __launch_bounds__(kAFMax) bt_dups(BtStream* streams, int CAP, int verify, int lds_items) {
+  bt_dups_body<MODE>(streams[blockIdx.x], CAP, verify, lds_items);
+}
 
 // ---- K3: duplicate removal and the output table (:582-621, :659-706) ----
 // Four wavefronts per stream (as bt_after_first): the lists are ~800 entries of dependent loads (slot, then the slot's fields), which one
 // wavefront walks in 13 rounds.
-__global__ void __launch_bounds__(kAFMax) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive, int* err) {
+__device__ __forceinline__ void bt_finish_body(BtStream& S, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive, int* err) {
   __shared__ int cnt[kAFMax / 64][3];
-  BtStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
   if (S.skip) {  // its tracks still bound the next frame's launches
     if (t == 0) {
@@ -697,6 +699,18 @@ __global__ void __launch_bounds__(kAFMax) bt_finish(BtStream* streams, int CAP, 
     const int e = S.err;  // the batch's error word (round 4: gathered here; a kernel of its own before — one launch of a frame's critical path)
     if (e) atomicMax(err, e);
   }
+}
+__global__ void __launch_bounds__(kAFMax) bt_finish(BtStream* streams, int CAP, float* out, int* out_counts, int cap_out, int* max_tracks, int* alive, int* err) {
+  bt_finish_body(streams[blockIdx.x], CAP, out, out_counts, cap_out, max_tracks, alive, err);
+}
+// a handful of streams (one camera): duplicate marking and the output table in ONE launch — the same workgroup owns the stream in both, the flags
+// it has just written are its own (round 5: a launch is 4-5 us of a 0.2 ms frame; with thousands of streams the two keep their own thread counts)
+__global__ void __launch_bounds__(kAFMax) bt_dups_finish(BtStream* streams, int CAP, int verify, int lds_items, float* out, int* out_counts, int cap_out,
+                                                          int* max_tracks, int* alive, int* err) {
+  BtStream& S = streams[blockIdx.x];
+  bt_dups_body<1>(S, CAP, verify, lds_items);
+  __syncthreads();
+  bt_finish_body(S, CAP, out, out_counts, cap_out, max_tracks, alive, err);
 }
 
 }  // namespace
@@ -931,10 +945,17 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
     static const bool full = std::getenv("MOT_BT_DUPS_FULL") != nullptr;  // measurement aid: every pair, boxes staged in LDS
     // LDS for up to 1024 lost boxes per stream (28 KB: five workgroups per CU); the rare stream with more takes the global path
     const int items = (bn2 < 1024) ? bn2 : 1024;
-    if (!full) hipLaunchKernelGGL(bt_dups<1>, dim3(S), dim3(few && bn2 > 256 ? kAFMax : 256), static_cast<size_t>(28) * items, st, b->d_streams, CAP, verify, items);
-    else hipLaunchKernelGGL(bt_dups<2>, dim3(S), dim3(256), static_cast<size_t>(16) * items, st, b->d_streams, CAP, 0, items);
+    static const bool merge_ok = !(std::getenv("MOT_BT_MERGE_FINISH") && std::getenv("MOT_BT_MERGE_FINISH")[0] == '0');  // (A/B measurements)
+    if (few && !full && merge_ok) {
+      const int td = (bn2 > 256) ? kAFMax : 256;
+      hipLaunchKernelGGL(bt_dups_finish, dim3(S), dim3(td > bt_threads ? td : bt_threads), static_cast<size_t>(28) * items, st, b->d_streams, CAP, verify, items,
+                         b->d_out, b->d_out_counts, cap_out, b->d_maxt, b->d_alive, b->d_err);
+    } else {
+      if (!full) hipLaunchKernelGGL(bt_dups<1>, dim3(S), dim3(few && bn2 > 256 ? kAFMax : 256), static_cast<size_t>(28) * items, st, b->d_streams, CAP, verify, items);
+      else hipLaunchKernelGGL(bt_dups<2>, dim3(S), dim3(256), static_cast<size_t>(16) * items, st, b->d_streams, CAP, 0, items);
+      hipLaunchKernelGGL(bt_finish, dim3(S), dim3(bt_threads), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt, b->d_alive, b->d_err);
+    }
   }
-  hipLaunchKernelGGL(bt_finish, dim3(S), dim3(bt_threads), 0, st, b->d_streams, CAP, b->d_out, b->d_out_counts, cap_out, b->d_maxt, b->d_alive, b->d_err);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[5], st));
   MOT_LC_HIP(b, hipGetLastError());
   return MOT_OK;

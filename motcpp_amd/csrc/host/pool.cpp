@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <iterator>
 #include <map>
@@ -304,6 +305,7 @@ class Segment {
     std::fill(counts_.begin(), counts_.end(), -1);
     bool any_warp = false, any_emb = false;
     for (Request* q : reqs) {
+      if (q->pre != 0 && std::getenv("MOTCPP_POOL_DEBUG")) std::fprintf(stderr, "[pool] round leader: stream %d pre %d (level %d)\n", q->s, q->pre, level_);
       if (q->pre == 1 || q->pre == 3) check(ops_.reset_stream(batch_, q->s, q->pre == 1 ? 1 : 0), "reset_stream");
       else if (q->pre == 2) {
         check(ops_.move_stream(q->from->batch_, q->from_s, batch_, q->s), "move_stream");

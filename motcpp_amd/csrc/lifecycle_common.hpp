@@ -363,9 +363,11 @@ struct Flights {
 template <class StreamT>
 static __global__ void reset_stream_kernel(StreamT* streams, int s, StreamT fresh, int keep_ids) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const int next_id = streams[s].next_id;
-    streams[s] = fresh;
-    if (keep_ids) streams[s].next_id = next_id;
+    // the counter is read through the vector memory path (a plain read of this uniform address may be served by the scalar data cache) and
+    // the record is written ONCE, with the counter already in it
+    StreamT f = fresh;
+    if (keep_ids) f.next_id = __atomic_load_n(&streams[s].next_id, __ATOMIC_RELAXED);
+    streams[s] = f;
   }
 }
 // arrays of a stream that outlive a frame, copied element-wise when a stream moves to a batch with larger capacities

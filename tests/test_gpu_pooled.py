@@ -114,7 +114,17 @@ def test_many_bytetrack_objects_on_threads():
     errors = _run_threads("bytetrack", orclib.BYTETRACK, True, T=48, frames=24, P=120, M=70)
     assert not errors, errors[:3]
     st = L.pool_stats()
-    assert st["max_round"] >= 2 and st["rounds"] < st["frames"], st  # (the oracle calls serialise the Python threads: few overlap)
+    assert st["frames"] >= 48 * 24 and st["rounds"] <= st["frames"], st
+    # That calls arriving together share a round is checked with C++ threads (motcpp_bench_threads): the oracle calls above serialise the Python
+    # threads, and since a frame takes ~0.1 ms on the GPU two of them rarely meet — whether any did is a matter of timing, not of the library.
+    F, M = 30, 70
+    base = [SynthStream(120, M, 500 + t).frames(F)[0] for t in range(16)]
+    dets = np.stack(base).astype(np.float32)
+    counts = np.full((16, F), M, np.int32)
+    L.pool_stats(reset=True)
+    res, _ = L.bench_threads("bytetrack", dets, counts, 5, frames=60)
+    st = L.pool_stats()
+    assert res["frames"] > 0 and st["max_round"] >= 2 and st["rounds"] < st["frames"], st
 
 
 def test_an_object_outgrows_its_level():
@@ -203,3 +213,18 @@ def test_bench_threads_checksums_do_not_depend_on_the_thread_count():
     for t in range(T):
         _, one = L.bench_threads("bytetrack", dets[t:t + 1], counts[t:t + 1], warm=0)
         assert one[0] == cs[t], (t, one[0], cs[t])
+
+
+@pytest.mark.parametrize("kind", ["bytetrack", "sort"])
+def test_reset_keeps_the_id_counter_in_a_fresh_process(kind):
+    """ByteTrack::reset / Sort::reset keep counting ids (bytetrack.cpp:157-165, sort.cpp:97-100). Round 5: the FIRST pooled objects of a process lost
+    the counter in two runs of three (the stream-reset kernel wrote the record and then patched the counter back in, reading it through a path that
+    could return a stale value): the check runs in new interpreters, where it showed."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for _ in range(3):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "pooled_reset_stress.py"), "3", kind], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.strip().splitlines()[-1].endswith("lost counters 0"), out.stdout[-2000:]

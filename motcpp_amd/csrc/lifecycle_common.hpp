@@ -363,8 +363,10 @@ struct Flights {
 template <class StreamT>
 static __global__ void reset_stream_kernel(StreamT* streams, int s, StreamT fresh, int keep_ids) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    // the counter is read through the vector memory path (a plain read of this uniform address may be served by the scalar data cache) and
-    // the record is written ONCE, with the counter already in it
+    // The record is written ONCE, with the counter already in it. (Round 5: `streams[s] = fresh; streams[s].next_id = saved;` lost the counter for the
+    // first objects of a process — a 16-byte store and a later 4-byte store of the same wavefront to the same word, completed out of order while the
+    // page was cold. Measured: plain read + single store 0 of 12 fresh interpreters, the two stores 8 of 12. Two stores of one thread to
+    // overlapping addresses need a wait between them; nothing else in the library does that.)
     StreamT f = fresh;
     if (keep_ids) f.next_id = __atomic_load_n(&streams[s].next_id, __ATOMIC_RELAXED);
     streams[s] = f;

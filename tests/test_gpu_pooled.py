@@ -218,8 +218,8 @@ def test_bench_threads_checksums_do_not_depend_on_the_thread_count():
 @pytest.mark.parametrize("kind", ["bytetrack", "sort"])
 def test_reset_keeps_the_id_counter_in_a_fresh_process(kind):
     """ByteTrack::reset / Sort::reset keep counting ids (bytetrack.cpp:157-165, sort.cpp:97-100). Round 5: the FIRST pooled objects of a process lost
-    the counter in two runs of three (the stream-reset kernel wrote the record and then patched the counter back in, reading it through a path that
-    could return a stale value): the check runs in new interpreters, where it showed."""
+    the counter in two runs of three (the stream-reset kernel wrote the record and then patched the counter back in: two stores of one wavefront to
+    the same word, out of order while the page was cold): the check runs in new interpreters, where it showed."""
     import os
     import subprocess
     import sys

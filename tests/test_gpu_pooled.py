@@ -105,8 +105,21 @@ def test_objects_on_threads_share_rounds(name, okind, exact):
     errors = _run_threads(name, okind, exact, T=8, frames=30, P=70, M=40, emb=16 if name == "botsort" else 0, stagger=True)
     assert not errors, errors[:3]
     st = L.pool_stats()
-    assert st["frames"] >= 8 * 21 and st["rounds"] < st["frames"], st  # calls really were merged
-    assert st["max_round"] >= 2, st
+    assert st["frames"] >= 8 * 21 and st["rounds"] <= st["frames"], st
+    # (whether two Python threads met in a round is a matter of timing — a frame takes ~0.1 ms on the GPU and the oracle calls serialise the threads;
+    # that concurrent calls DO share rounds is checked with C++ threads below)
+
+
+@pytest.mark.parametrize("kind", ["sort", "bytetrack", "ocsort"])
+def test_concurrent_updates_share_rounds(kind):
+    """16 tracker objects of the public C++ classes on 16 host threads (motcpp_bench_threads): their update() calls run as merged launch sequences"""
+    F, M = 30, 70
+    dets = np.stack([SynthStream(120, M, 500 + t).frames(F)[0] for t in range(16)]).astype(np.float32)
+    counts = np.full((16, F), M, np.int32)
+    L.pool_stats(reset=True)
+    res, _ = L.bench_threads(kind, dets, counts, 5, frames=60)
+    st = L.pool_stats()
+    assert res["frames"] > 0 and st["max_round"] >= 2 and st["rounds"] < st["frames"], st
 
 
 def test_many_bytetrack_objects_on_threads():
@@ -115,16 +128,7 @@ def test_many_bytetrack_objects_on_threads():
     assert not errors, errors[:3]
     st = L.pool_stats()
     assert st["frames"] >= 48 * 24 and st["rounds"] <= st["frames"], st
-    # That calls arriving together share a round is checked with C++ threads (motcpp_bench_threads): the oracle calls above serialise the Python
-    # threads, and since a frame takes ~0.1 ms on the GPU two of them rarely meet — whether any did is a matter of timing, not of the library.
-    F, M = 30, 70
-    base = [SynthStream(120, M, 500 + t).frames(F)[0] for t in range(16)]
-    dets = np.stack(base).astype(np.float32)
-    counts = np.full((16, F), M, np.int32)
-    L.pool_stats(reset=True)
-    res, _ = L.bench_threads("bytetrack", dets, counts, 5, frames=60)
-    st = L.pool_stats()
-    assert res["frames"] > 0 and st["max_round"] >= 2 and st["rounds"] < st["frames"], st
+    # (that calls arriving together share a round: test_concurrent_updates_share_rounds, with C++ threads)
 
 
 def test_an_object_outgrows_its_level():

@@ -196,8 +196,9 @@ class Context:
                          "cycles_enumerate", "cycles_init", "cycles_search", "cycles_certificate", "searches", "column_scans",
                          "declined_column_list_full", "declined_pair_list_full", "cycles_enum_bucket_rows", "cycles_enum_candidates",
                          "cycles_enum_list", "lane0_candidates", "lane0_pairs_evaluated", "declined_nonfinite", "declined_viable_disjoint",
-                         "declined_threshold_tie", "cycles_search_fetch", "cycles_search_deliver", "cycles_search_pick", "cycles_search_augment"),
-                        (int(v) for v in o[:28])))
+                         "declined_threshold_tie", "cycles_search_fetch", "cycles_search_deliver", "cycles_search_pick", "cycles_search_augment",
+                         "search_retries", "cycles_kernel", "wall_ticks_kernel_100MHz", "cycles_prologue"),
+                        (int(v) for v in o[:32])))
 
     def lap_geom(self, a, b, thresh, cost_mode=COST_IOU_DIST, conf=None, lap_mode=LAP_PLAIN, gate=0.0, prof=False):
         """Assignment straight from boxes (on-the-fly IoU-family cost inside the solver; no matrix in memory)."""

@@ -60,6 +60,7 @@ struct DBuf {
 };
 }  // namespace
 
+namespace mot { hipError_t lap_sparse_timeline(unsigned long long*, int, hipStream_t); }
 extern "C" {
 
 const char* mot_version(void) { return "motcpp_amd 0.1 (gfx950)"; }
@@ -165,6 +166,7 @@ int mot_boost_run(mot_ctx* c, int op, const mot_boost_task* t, int nt, int max_n
 int mot_ucmc_run(mot_ctx* c, int op, const mot_ucmc_task* t, int nt, int max_n, int max_m) { MOT_HIP(c, mot::launch_ucmc(op, t, nt, max_n, max_m, c->stream)); return MOT_OK; }
 int mot_feat_update(mot_ctx* c, const mot_feat_task* t, int nt, int max_n) { MOT_HIP(c, mot::launch_feat(t, nt, max_n, c->stream)); return MOT_OK; }
 int mot_lap_behind_stats(mot_ctx* c, long long* out80, int reset) { MOT_HIP(c, mot::lap_behind_stats(out80, reset != 0, c->stream)); return MOT_OK; }
+int mot_debug_sparse_timeline(mot_ctx* c, unsigned long long* out, int n) { MOT_HIP(c, mot::lap_sparse_timeline(out, n, c->stream)); return MOT_OK; }
 int mot_lap_fast_stats(mot_ctx* c, unsigned long long* out16, int reset) { MOT_HIP(c, mot::lap_fast_stats(out16, reset != 0, c->stream)); return MOT_OK; }
 size_t mot_lap_work_bytes(int n, int m) { return (mot::lap_scratch_bytes(n, m) + 255) & ~size_t(255); }
 size_t mot_lap_rowlist_bytes(int n) { return (mot::lap_rowlist_scratch_bytes(n) + 255) & ~size_t(255); }

@@ -347,6 +347,8 @@ struct DevGroup {
     return r;
   }
   // single-wavefront groups only: mask of the lanes whose flag is set, a lane's value for everyone, a value pushed to a lane
+  // true when the flag is set in some lane of the calling WAVEFRONT (not of the group): the lanes of a wavefront reach it together
+  __device__ __forceinline__ bool wave_any(bool flag) const { return __builtin_amdgcn_ballot_w64(flag) != 0ull; }
   __device__ __forceinline__ unsigned long long ballot(bool flag) { return __builtin_amdgcn_ballot_w64(flag); }
   __device__ __forceinline__ int push_i32(int v, int dst, bool active) { return __builtin_amdgcn_ds_permute((active ? dst : 63) << 2, active ? v : 0); }
   __device__ __forceinline__ int bcast_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }

@@ -50,14 +50,25 @@ constexpr int kSpSeg0 = 16;        // box source: list entries reserved for a co
 constexpr int kSpKMax = 64;        // ... up to this many viable pairs (more: fall back). A path search relaxes a column with one lane per pair.
 constexpr int kSpBuckets = 256;    // x1 buckets of the row boxes
 constexpr int kSpSlots = 63;       // rows one path search may reach (more: fall back); lane q holds slot q, lane 63 none
-constexpr int kSpQ = 8;            // per-lane queue of candidate rows awaiting the exact arithmetic (drained when full)
+constexpr int kSpQ = 12;           // per-lane queue of candidate rows awaiting the exact arithmetic (drained when the wavefront has filled its queues or finished its windows)
 constexpr double kSpEps = 1e-9;    // tie margin
 constexpr double kSpTol = 1e-11;   // tolerated violation of dual feasibility / complementary slackness (fp64 rounding)
 constexpr int kSpIntMax = 0x7fffffff;
-constexpr float kSpHuge = 1.0e30f; // boxes / costs beyond this magnitude are left to the exact path
+constexpr float kSpHuge = 1.0e30f; // costs / confidences beyond this magnitude are left to the exact path
+constexpr float kSpBoxHuge = 1.0e15f;  // ... and box coordinates beyond this one: below it no width, area or product of two extents overflows, so the
+                                       // division-free pre-test of the candidate scan (products of coordinate differences) holds no inf or NaN
 MOT_HD int sparse_arc_cap(int nr, int nc) { return nr + nc + 64; }  // eps-tight non-matching pairs the certificate may hold
 
 struct alignas(16) SpBox { float x1, y1, x2, y2; };
+// min / max of FINITE floats for the candidate pre-test (one v_min_f32 / v_max_f32 each; smin / smax keep std::min / std::max's NaN and
+// signed-zero behaviour with a compare and a select, which only the exact cost arithmetic needs)
+#if defined(__HIP_DEVICE_COMPILE__)
+MOT_DEV float sp_fmin(float a, float b) { return __builtin_fminf(a, b); }
+MOT_DEV float sp_fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+#else
+MOT_DEV float sp_fmin(float a, float b) { return (b < a) ? b : a; }
+MOT_DEV float sp_fmax(float a, float b) { return (a < b) ? b : a; }
+#endif
 
 // Workspace. HS = address space of the hot arrays (LDS when the problem fits, else global scratch).
 template <int HS>
@@ -193,7 +204,7 @@ struct SparseBoxes {
 MOT_DEV bool sp_finite4(const float b[4]) {
   bool ok = true;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) ok = ok && (b[k] > -kSpHuge) && (b[k] < kSpHuge);  // false for NaN
+  for (int k = 0; k < 4; ++k) ok = ok && (b[k] > -kSpBoxHuge) && (b[k] < kSpBoxHuge);  // false for NaN
   return ok;
 }
 // EvalFn(row index, row box, row area, column box, column area, column confidence, column index) -> float cost with the
@@ -215,7 +226,7 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
   const int T = g.size(), t = g.tid();
   const double th = static_cast<double>(thresh);
   const long long ec0 = MOT_CLOCK();
-  long long n_cand = 0, n_hit = 0;
+  long long n_cand = 0, n_hit = 0, c_drain = 0;
   // bits: 1 tie with the threshold, 2 column list full, 4 NaN / inf / out of range, 8 viable pairs that do not intersect, 16 CSR full
   // QD = depth of a lane's queue: the queues of all lanes share the 2 * kSpQ * kSpMaxThreads bytes behind the buckets (16 wavefronts: 2 each)
   static_assert(QD >= 1 && QD <= kSpQ, "queue depth");
@@ -235,7 +246,7 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
       const int i = t + u * T;
       if (i < nr) {
         const float a0 = rx1[u];
-        if (!(a0 > -kSpHuge && a0 < kSpHuge)) bad |= 4;
+        if (!(a0 > -kSpBoxHuge && a0 < kSpBoxHuge)) bad |= 4;
         if (a0 < xlo) xlo = a0;
         if (a0 > xhi) xhi = a0;
       }
@@ -244,7 +255,7 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
 #pragma unroll 4
     for (int i = t; i < nr; i += T) {
       const float a0 = A.load_x1(i);
-      if (!(a0 > -kSpHuge && a0 < kSpHuge)) bad |= 4;
+      if (!(a0 > -kSpBoxHuge && a0 < kSpBoxHuge)) bad |= 4;
       if (a0 < xlo) xlo = a0;
       if (a0 > xhi) xhi = a0;
     }
@@ -344,17 +355,20 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
     nconf = bconf ? gld(bconf, gj) : 0.0f;
   };
   if (t < nc) fetch_column(t);
-  for (int j = t; j < nc; j += T) {
+  // every lane runs every round of the column loop (a lane without a column has an empty window): the rounds hold a wavefront-wide vote
+  for (int j0 = 0; j0 < nc; j0 += T) {
+    const int j = j0 + t;
+    const bool have = j < nc;
     const float b[4] = {nb[0], nb[1], nb[2], nb[3]};
     const float conf = nconf;
     if (j + T < nc) fetch_column(j + T);
-    if (!sp_finite4(b) || !(conf > -kSpHuge && conf < kSpHuge)) bad |= 4;
+    if (have && (!sp_finite4(b) || !(conf > -kSpHuge && conf < kSpHuge))) bad |= 4;
     const float barea = (b[2] - b[0]) * (b[3] - b[1]);
     const float zc = zero_cost(conf);
     const float min_iou = min_iou_of(conf);
-    if (!(static_cast<double>(zc) > th + kSpEps)) bad |= 8;  // a non-intersecting pair would be viable (or zc is NaN)
+    if (have && !(static_cast<double>(zc) > th + kSpEps)) bad |= 8;  // a non-intersecting pair would be viable (or zc is NaN)
     int nq = 0, ne = 0, base = 0, seg = -1, ninter = 0;
-    if (!bad) {
+    {
       // Round 5: a candidate must pass hits(), i.e. inter > min_iou * union. With union >= the column's area and ih <= its height that forces
       // iw > min_iou * (b2 - b0), and iw <= b2 - a0 and iw <= a2 - b0: a row that can pass starts before b2 - m and ends after b0 + m,
       // m = 0.9 * min_iou * width (the tenth dwarfs every rounding: the terms are float expressions of the same magnitude). The x window of the
@@ -366,7 +380,8 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
       const int kb0 = f32_key(b[0] + mrg);
       int lo = 0, hi = bhi + 1;  // first bucket whose prefix maximum of x2 exceeds b0
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (static_cast<int>(w.bmax[mid]) > kb0) hi = mid; else lo = mid + 1; }
-      const int ps = w.bstart[lo], pe = w.bstart[bhi + 1];
+      const bool scan = have && !bad;
+      const int ps = scan ? static_cast<int>(w.bstart[lo]) : 0, pe = scan ? static_cast<int>(w.bstart[bhi + 1]) : 0;
       n_cand += pe - ps;
       // evaluates the queued pairs, marks the viable ones, reserves exactly that many CSR entries (the most a column may
       // hold if more candidates are still to come) and evaluates the viable ones once more to store them
@@ -381,16 +396,24 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
       auto drain = [&](bool last) {
         if (nq == 0) return;
         unsigned viable = 0u;
-        for (int q = 0; q < nq; ++q) {
-          int i;
-          const float c = pair_cost(q, &i);
-          if (!(c > -kSpHuge && c < kSpHuge)) { bad |= 4; continue; }
-          const double cd = static_cast<double>(c);
-          if (cd < mn) mn = cd;
-          // a cost EQUAL to the threshold stays in the graph as a pair of weight 0: it matters only if it is tight in the
-          // optimum, which the certificate checks like any other tie (float costs are not otherwise within eps of it)
-          if (cd < th - kSpEps || cd == th) viable |= 1u << q;
-          else if (!(cd > th + kSpEps)) bad |= 1;
+        float cq[QD];  // the queued pairs' costs and rows stay in registers between the viability pass and the store (round 6: the viable
+        int rq[QD];    // ones used to be evaluated a second time — a correctly rounded division each)
+#pragma unroll
+        for (int q = 0; q < QD; ++q) {
+          cq[q] = 0.0f; rq[q] = 0;
+          if (q < nq) {
+            const float c = pair_cost(q, &rq[q]);
+            cq[q] = c;
+            if (!(c > -kSpHuge && c < kSpHuge)) bad |= 4;
+            else {
+              const double cd = static_cast<double>(c);
+              if (cd < mn) mn = cd;
+              // a cost EQUAL to the threshold stays in the graph as a pair of weight 0: it matters only if it is tight in the
+              // optimum, which the certificate checks like any other tie (float costs are not otherwise within eps of it)
+              if (cd < th - kSpEps || cd == th) viable |= 1u << q;
+              else if (!(cd > th + kSpEps)) bad |= 1;
+            }
+          }
         }
         const int nv = __builtin_popcount(viable);
         if (seg < 0 && nv > 0) {
@@ -401,11 +424,9 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
           base = (seg > 0) ? G::atomic_add(w.ctr.raw(2), seg) : 0;
           if (base + seg > w.ecap) { bad |= 16; seg = 0; }
         }
-        while (viable) {
-          const int q = __builtin_ctz(viable);
-          viable &= viable - 1u;
-          int i;
-          const float c = pair_cost(q, &i);
+#pragma unroll
+        for (int q = 0; q < QD; ++q) {
+          if (!(viable & (1u << q))) continue;
           if (ne == seg && seg > 0 && !bad) {  // the column outgrew its segment (a pile-up of lost tracks on one detection): move it
             const int ns = (2 * seg < kSpKMax) ? 2 * seg : kSpKMax;
             if (ns == seg) bad |= 2;
@@ -418,49 +439,68 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
               }
             }
           }
-          if (ne < seg) { w.erow[base + ne] = static_cast<unsigned short>(i); w.ecost[base + ne] = c; ++ne; }
+          if (ne < seg) { w.erow[base + ne] = static_cast<unsigned short>(rq[q]); w.ecost[base + ne] = cq[q]; ++ne; }
           else if (!(bad & 16)) bad |= 2;
         }
         ninter += nq;
         nq = 0;
       };
-      // w > 0 and h > 0 of iou_pair (finite boxes): anything else has inter == 0 and costs zc
-      auto hits = [&](const SpBox& s) {
-        if (!(s.x1 < b[2] && s.x2 > b[0] && s.y1 < b[3] && s.y2 > b[1])) return false;
-        if (min_iou > 0.0f) {  // iou_pair's intersection and union, without the division
-          const float iw = smin(s.x2, b[2]) - smax(s.x1, b[0]), ih = smin(s.y2, b[3]) - smax(s.y1, b[1]);
-          const float inter = iw * ih;
-          const float uni = (s.x2 - s.x1) * (s.y2 - s.y1) + barea - inter;
-          return inter > min_iou * uni;
-        }
-        return true;
+      // A candidate is worth the exact arithmetic iff iou_pair's intersection is positive — w = xx2 - xx1 > 0 and h = yy2 - yy1 > 0, the same
+      // float expressions as there; anything else costs zc, which is not viable — and, when the column has a minimum IoU, iff
+      // inter > min_iou * union (iou_pair's inter and union without the division). Round 6: branch-free and on native min / max — with
+      // inter' = max(w, 0) * h the one test  inter' > min_iou * union  covers both: w <= 0 gives inter' = 0 and h <= 0 gives inter' <= 0, against a
+      // positive right-hand side (min_iou = 0: against 0); a degenerate box with union <= 0 can only let a pair through that the exact
+      // arithmetic then prices at zc. 14 VALU instructions per candidate instead of 26 (four compares in front of a branch that some lane of
+      // the wavefront nearly always took, compare + select pairs for every min / max); box coordinates are below kSpBoxHuge, so no product
+      // overflows (and a NaN cannot occur). The kernel's four wavefronts per SIMD kept the vector ALU busy two thirds of the time: this loop was a third of its instructions.
+      const float bh = b[3] - b[1];
+      auto passes = [&](const SpBox& s) {
+        // w = min(x2, b2) - max(x1, b0) is the smallest of the four differences x2 - x1, x2 - b0, b2 - x1, b2 - b0 — rounding is monotone, so the
+        // smallest rounded difference IS fl(min - max), bit for bit — and the row's own extents are needed for its area anyway. Differences are
+        // arithmetic results: the minima below need no quieting of signalling NaNs (min / max of loaded values cost three instructions each).
+        const float wr = s.x2 - s.x1, hr = s.y2 - s.y1;
+        const float dx1 = s.x2 - b[0], dy1 = s.y2 - b[1], dx2 = b[2] - s.x1, dy2 = b[3] - s.y1;
+        const float iw = sp_fmin(sp_fmin(sp_fmin(wr, dx1), dx2), bw), ih = sp_fmin(sp_fmin(sp_fmin(hr, dy1), dy2), bh);
+        const float inter = sp_fmax(iw, 0.0f) * ih;
+        const float uni = wr * hr + barea - inter;
+        return inter > min_iou * uni;
       };
-      auto push = [&](int p) { w.hq[nq * T + t] = static_cast<unsigned short>(p); if (++nq == QD) drain(false); };
-      int p = ps;
-      for (; p + 8 <= pe; p += 8) {  // eight boxes per round trip, the tests folded into one mask before any queue write
-        const SpBox s0 = w.sbox[p], s1 = w.sbox[p + 1], s2 = w.sbox[p + 2], s3 = w.sbox[p + 3];
-        const SpBox s4 = w.sbox[p + 4], s5 = w.sbox[p + 5], s6 = w.sbox[p + 6], s7 = w.sbox[p + 7];
-        unsigned m = (hits(s0) ? 1u : 0u) | (hits(s1) ? 2u : 0u) | (hits(s2) ? 4u : 0u) | (hits(s3) ? 8u : 0u) |
-                     (hits(s4) ? 16u : 0u) | (hits(s5) ? 32u : 0u) | (hits(s6) ? 64u : 0u) | (hits(s7) ? 128u : 0u);
-        while (m) { const int q = __builtin_ctz(m); m &= m - 1u; push(p + q); }
+      // Round 6: EPOCHS. A lane used to drain its queue the moment it was full — a wavefront then ran the eight unrolled evaluations (a
+      // correctly rounded division, double-precision compares) for that ONE lane, three or four times per round of columns (a column in
+      // twenty has more than eight candidates that pass; with 64 columns per wavefront some lane always does), before the common drain at
+      // the end: about 64 evaluation slots issued per wavefront and problem for 7 slots' worth of pairs. Now a lane whose queue is full
+      // stops scanning and waits; when every lane of the wavefront has either finished its window or filled its queue they all drain
+      // together, and the few with candidates left go round again. With a queue of twelve the second epoch is rare.
+      int p = ps, pc = ps;
+      unsigned m = 0u;
+      bool more = pe > ps;
+      for (;;) {
+        if (more) {
+          for (;;) {
+            while (m != 0u && nq < QD) { const int q = __builtin_ctz(m); m &= m - 1u; w.hq[nq * T + t] = static_cast<unsigned short>(pc + q); ++nq; }
+            if (m != 0u) break;  // the queue is full: the rest of this chunk waits for the next epoch
+            if (p >= pe) { more = false; break; }
+            // eight boxes per round trip (reads past the window stay inside the workgroup's LDS and are masked)
+            const SpBox s0 = w.sbox[p], s1 = w.sbox[p + 1], s2 = w.sbox[p + 2], s3 = w.sbox[p + 3];
+            const SpBox s4 = w.sbox[p + 4], s5 = w.sbox[p + 5], s6 = w.sbox[p + 6], s7 = w.sbox[p + 7];
+            m = (passes(s0) ? 1u : 0u) | (passes(s1) ? 2u : 0u) | (passes(s2) ? 4u : 0u) | (passes(s3) ? 8u : 0u) |
+                (passes(s4) ? 16u : 0u) | (passes(s5) ? 32u : 0u) | (passes(s6) ? 64u : 0u) | (passes(s7) ? 128u : 0u);
+            const int left = pe - p;
+            if (left < 8) m &= (1u << left) - 1u;
+            pc = p;
+            p += 8;
+          }
+        }
+        const long long dc0 = MOT_CLOCK();
+        drain(!more);
+        c_drain += MOT_CLOCK() - dc0;
+        if (!g.wave_any(more)) break;
       }
-      for (; p + 4 <= pe; p += 4) {  // four boxes per round trip
-        const SpBox s0 = w.sbox[p], s1 = w.sbox[p + 1], s2 = w.sbox[p + 2], s3 = w.sbox[p + 3];
-        if (hits(s0)) push(p);
-        if (hits(s1)) push(p + 1);
-        if (hits(s2)) push(p + 2);
-        if (hits(s3)) push(p + 3);
-      }
-      for (; p < pe; ++p) {
-        const SpBox s0 = w.sbox[p];
-        if (hits(s0)) push(p);
-      }
-      drain(true);
       n_hit += ninter;
     }
     nq = ninter;
-    if (nq < nr && static_cast<double>(zc) < mn) mn = static_cast<double>(zc);
-    w.eoff[j] = base | (ne << 24);
+    if (have && nq < nr && static_cast<double>(zc) < mn) mn = static_cast<double>(zc);
+    if (have) w.eoff[j] = base | (ne << 24);
   }
   {  // OR of the lanes' flags
     int any = 0;
@@ -471,7 +511,7 @@ MOT_DEV SparseEnum sparse_enumerate_boxes(G& g, const W& w, int nr, int nc, cons
   g.sync();
   SparseEnum out(1, mn);
   if (bad) out.ok = (bad & 4) ? -12 : ((bad & 8) ? -13 : ((bad & 1) ? -14 : ((bad & 2) ? -10 : -11)));
-  out.c_stage = ec1 - ec0; out.c_cand = MOT_CLOCK() - ec1; out.c_csr = 0; out.n_cand = n_cand; out.n_hit = n_hit;
+  out.c_stage = ec1 - ec0; out.c_cand = MOT_CLOCK() - ec1; out.c_csr = c_drain; out.n_cand = n_cand; out.n_hit = n_hit;  // (c_csr: the part of c_cand spent evaluating and storing the queued pairs)
   return out;
 }
 

@@ -21,6 +21,8 @@ constexpr int kScratch = 1024;  // DevGroup reduction scratch
 // reached too many rows, [3] certificate arithmetic, [4] too many tight pairs, [5] optimum not unique, [6] not attempted
 // (diagnostics requested / cost flavour), [7] empty problems
 __device__ unsigned long long g_fast_hist[64 * 32];  // 64 sets (block & 63) so that thousands of problems do not serialise on one line;  // [8..] cycles: enumeration, matching init, path searches, certificate; [12] searches, [13] column scans
+__device__ int g_sp_hist_wide_only;  // diagnostics: 1 = only the four-wavefront kernel feeds the cycle counters (a frame's first association alone)
+__device__ unsigned long long g_sp_timeline[8192][2];  // diagnostics: residence (100 MHz clock) of the first 8192 workgroups of the last launch
 __device__ __forceinline__ unsigned long long* hist_set() { return g_fast_hist + (blockIdx.x & 63) * 32; }
 __device__ __forceinline__ void count_outcome(int k) { if (threadIdx.x == 0) atomicAdd(hist_set() + k, 1ull); }
 
@@ -34,6 +36,8 @@ __device__ __forceinline__ int* status_word(const mot_lap_task& T, size_t scratc
 template <bool PLAIN, int HS, int kThreads>
 __global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task* __restrict__ tasks, int lds_ecap, int* declined, int lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const long long kc0 = MOT_CLOCK();           // (diagnostics: the workgroup's whole residence, in shader cycles and in the constant 100 MHz clock —
+  const long long kw0 = wall_clock64();        //  their ratio is the clock the kernel really ran at, their sum over a launch the mean residency)
   const mot_lap_task T = tasks[blockIdx.x];
   const int nr = T.n, nc = T.m, t = threadIdx.x;
   int* status = status_word(T, mot::lap_task_scratch_bytes(nr, nc));
@@ -180,7 +184,7 @@ __global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task
       }
       solved = (r == 1) ? 1 : 0;
       reason = (r >= -5 && r <= -2) ? -r : 1;
-      if (t == 0) {
+      if (t == 0 && !(g_sp_hist_wide_only && kThreads == 64)) {
         unsigned long long* h = hist_set();
         atomicAdd(h + 8, static_cast<unsigned long long>(ck1 - ck0)); atomicAdd(h + 9, static_cast<unsigned long long>(pf.c_init));
         atomicAdd(h + 10, static_cast<unsigned long long>(pf.c_search)); atomicAdd(h + 11, static_cast<unsigned long long>(pf.c_cert));
@@ -217,6 +221,12 @@ __global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task
   for (int j = t; j < nc; j += kThreads) T.y[j] = w.y[j];
   if (t == 0) { if (T.info) T.info[0] = path; *status = 1; }
   count_outcome(0);
+  if (t == 0 && !(g_sp_hist_wide_only && kThreads == 64)) {
+    unsigned long long* h = hist_set();
+    atomicAdd(h + 29, static_cast<unsigned long long>(MOT_CLOCK() - kc0)); atomicAdd(h + 30, static_cast<unsigned long long>(wall_clock64() - kw0));
+    atomicAdd(h + 31, static_cast<unsigned long long>(ck0 - kc0));
+    if (kThreads == 256 && blockIdx.x < 8192) { g_sp_timeline[blockIdx.x][0] = static_cast<unsigned long long>(kw0); g_sp_timeline[blockIdx.x][1] = static_cast<unsigned long long>(wall_clock64()); }
+  }
 }
 
 }  // namespace
@@ -273,6 +283,12 @@ hipError_t launch_lap_sparse(const mot_lap_task* tasks, int ntasks, int max_n, i
   }
 #undef MOT_SP_LAUNCH
   return hipGetLastError();
+}
+hipError_t lap_sparse_timeline(unsigned long long* out, int n, hipStream_t st) {
+  hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  if (n < 0) { const int v = (n == -1) ? 1 : 0; return hipMemcpyToSymbol(HIP_SYMBOL(g_sp_hist_wide_only), &v, sizeof(int)); }  // (-1 / -2: cycle counters from the wide kernel only / from all)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sp_timeline), sizeof(unsigned long long) * 2 * static_cast<size_t>(n < 8192 ? n : 8192));
 }
 hipError_t lap_fast_stats(unsigned long long* out16 /* [32] */, bool reset, hipStream_t st) {
   hipError_t e = hipStreamSynchronize(st);

@@ -103,6 +103,7 @@ struct EmuGroup {
     return r;
   }
   int reduce_sum(int v) { int tot; exclusive_scan(v, &tot); return tot; }
+  bool wave_any(bool flag) { return reduce_max(flag ? 1 : 0) != 0; }  // (the emulated group is one "wavefront" whatever its size)
   unsigned long long ballot(bool flag) {
     auto& s = sh->s_int[phase++ & 1];
     s[tid_] = flag ? 1 : 0;

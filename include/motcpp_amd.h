@@ -602,7 +602,10 @@ typedef struct mot_frame_in {
 typedef struct mot_frame_view {
   const float* rows;
   const int* counts;
-  const int* alive;
+  const int* alive;  /* [S] live tracks after the frame; a stream that raised an error (capacity) reports -(its error code) here: when
+                        mot_*_collect_view returns MOT_ERR_CAPACITY the view is still filled, the rows of the streams with alive >= 0 are
+                        valid, and only the callers of the others need to see the error (the reference's exceptions are per object:
+                        src/tracker.cpp:108-125) */
   int total;
 } mot_frame_view;
 int mot_bt_enqueue_frame(mot_bt_batch* b, const mot_frame_in* in, int rows_cap);

@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(kW) bot_finish(BotStream* streams, int CAP, fl
   const int t = static_cast<int>(threadIdx.x);
   if (S.idle) {
     if (t == 0) {
-      out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_active + S.n_lost; atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost);
+      out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.err ? -S.err : S.n_active + S.n_lost; atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost);
       if (S.err) atomicMax(err, S.err);
     }
     return;
@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(kW) bot_finish(BotStream* streams, int CAP, fl
     if (n_rows > cap_out) S.err = 2;
     out_counts[blockIdx.x] = (n_rows <= cap_out) ? n_rows : -n_rows;
     atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost);
-    alive[blockIdx.x] = S.n_active + S.n_lost;
+    alive[blockIdx.x] = S.err ? -S.err : S.n_active + S.n_lost;  // (a stream in error reports -(error code): its caller alone gets the error)
     if (S.err) atomicMax(err, S.err);  // the batch's error word (round 5: gathered here; a kernel of its own before)
   }
 }
@@ -888,7 +888,7 @@ int mot_bot_collect_view(mot_bot_batch* b, mot_frame_view* out) {
 }
 int mot_bot_reset_stream(mot_bot_batch* b, int s, int fresh) {
   if (!b || s < 0 || s >= b->S) return MOT_ERR_INVALID;
-  hipLaunchKernelGGL(mot::lifecycle::reset_stream_kernel<BotStream>, dim3(1), dim3(64), 0, b->ctx->stream, b->d_streams, s, b->h_streams[s], 0 * fresh /* the ids restart either way, botsort.cpp:257 */);
+  hipLaunchKernelGGL(mot::lifecycle::reset_stream_kernel<BotStream>, dim3(1), dim3(64), 0, b->ctx->stream, b->d_streams, s, b->h_streams[s], 0 * fresh /* the ids restart either way, botsort.cpp:257 */, b->d_err);
   MOT_LC_HIP(b, hipGetLastError());
   return MOT_OK;
 }

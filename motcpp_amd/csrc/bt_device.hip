@@ -636,7 +636,7 @@ __device__ __forceinline__ void bt_finish_body(BtStream& S, int CAP, float* out,
   const int t = static_cast<int>(threadIdx.x);
   if (S.skip) {  // its tracks still bound the next frame's launches
     if (t == 0) {
-      out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_active + S.n_lost; atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost);
+      out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.err ? -S.err : S.n_active + S.n_lost; atomicMax(&max_tracks[blockIdx.x & 63], S.n_active + S.n_lost);
       if (S.err) atomicMax(err, S.err);
     }
     return;
@@ -695,8 +695,8 @@ __device__ __forceinline__ void bt_finish_body(BtStream& S, int CAP, float* out,
     out_counts[blockIdx.x] = (n_rows <= cap_out) ? n_rows : -n_rows;
     // tracks alive after this frame: an exact upper bound of every problem side of the next frame (64 slots: no hot address)
     atomicMax(&max_tracks[blockIdx.x & 63], n_keep + n_keep_l);
-    alive[blockIdx.x] = n_keep + n_keep_l;
-    const int e = S.err;  // the batch's error word (round 4: gathered here; a kernel of its own before — one launch of a frame's critical path)
+    const int e = S.err;
+    alive[blockIdx.x] = e ? -e : n_keep + n_keep_l;  // (a stream in error reports -(error code): its caller alone gets the error)  // the batch's error word (round 4: gathered here; a kernel of its own before — one launch of a frame's critical path)
     if (e) atomicMax(err, e);
   }
 }
@@ -1131,7 +1131,7 @@ int mot_bt_collect_view(mot_bt_batch* b, mot_frame_view* out) {
 }
 int mot_bt_reset_stream(mot_bt_batch* b, int s, int fresh) {
   if (!b || s < 0 || s >= b->S) return MOT_ERR_INVALID;
-  hipLaunchKernelGGL(mot::lifecycle::reset_stream_kernel<BtStream>, dim3(1), dim3(64), 0, b->ctx->stream, b->d_streams, s, b->h_streams[s], fresh ? 0 : 1);
+  hipLaunchKernelGGL(mot::lifecycle::reset_stream_kernel<BtStream>, dim3(1), dim3(64), 0, b->ctx->stream, b->d_streams, s, b->h_streams[s], fresh ? 0 : 1, b->d_err);
   MOT_LC_HIP(b, hipGetLastError());
   return MOT_OK;
 }

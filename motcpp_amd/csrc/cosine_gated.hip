@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(kGcThreads) embed_gated_kernel(const mot_cos_t
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* cb = smem;                                      // [5][m_pad] column boxes x1 y1 x2 y2 area
   float* rb = cb + 5 * static_cast<size_t>(m_pad);       // [kGcRows][8]: x1 y1 x2 y2 area (one 16-byte broadcast read brings a row's box)
-  int* list = reinterpret_cast<int*>(rb + 8 * kGcRows);  // [kGcList] (row << 16 | column)
+  unsigned* list = reinterpret_cast<unsigned*>(rb + 8 * kGcRows);  // [kGcList] (row << 16 | column), unsigned: rows up to 65535
   __shared__ int s_count;
   const mot_cos_task C = cos[blockIdx.y];
   const int n = C.n, m = C.m;
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(kGcThreads) embed_gated_kernel(const mot_cos_t
             const int i = c0 + r;
             if (pass_no == 0) {
               const int pos = atomicAdd(&s_count, 1);
-              if (pos < kGcList) list[pos] = (i << 16) | j;
+              if (pos < kGcList) list[pos] = (static_cast<unsigned>(i) << 16) | static_cast<unsigned>(j);
             } else {
               C.out[static_cast<size_t>(i) * C.ldo + j] = pair_cosine(row_ptr(i), col_ptr(j), C.d, vec);
             }
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(kGcThreads) embed_gated_kernel(const mot_cos_t
   const int P = s_count;
   for (int p = t; p < P; p += kGcThreads) {
     const int e = list[p];
-    const int i = e >> 16, j = e & 0xffff;
+    const int i = static_cast<int>(e >> 16), j = static_cast<int>(e & 0xffffu);
     C.out[static_cast<size_t>(i) * C.ldo + j] = pair_cosine(row_ptr(i), col_ptr(j), C.d, vec);
   }
 }

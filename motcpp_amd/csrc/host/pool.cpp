@@ -260,42 +260,65 @@ class Segment {
         else if (now - last_arrival >= gap) break;
       }
     }
+    //  From here on the round MUST complete whatever happens on this thread — an allocation that fails, an exception out of the
+    // run — or every caller asleep on its futex word, and every later caller of the segment, would wait for good: the guard publishes the round
+    // (with the error in every request that has none of its own) on every way out.
     std::vector<Request*> reqs;
+    struct Publish {
+      Segment* self; uint64_t r; int p; std::vector<Request*>* reqs; std::string err; bool failed = false;
+      ~Publish() {
+        for (Request* q : *reqs) {
+          q->round = r;
+          if (failed && q->error.empty()) { try { q->error = err.empty() ? std::string("motcpp_amd: the round's leader failed") : err; } catch (...) {} }
+        }
+        self->outstanding_[p].store(static_cast<int>(reqs->size()), std::memory_order_release);
+        self->completed_.store(r + 1, std::memory_order_release);
+        self->word_[p].fetch_add(1, std::memory_order_release);
+        futex_wake_all(&self->word_[p]);  // this round's callers, and the leader of the next round if it is waiting already
+      }
+    } publish{this, r, p, &reqs, {}};
     size_t det_top, emb_top;
     {
       std::lock_guard<std::mutex> lk(mu_);
       Round& R = rounds_[p];
       open_ = r + 1;  // closed: later arrivals fill the other round
-      reqs.swap(R.reqs);
+      reqs.swap(R.reqs);  // (no allocation: the vectors trade their buffers)
       det_top = R.det_top; emb_top = R.emb_top;
       R.det_top = 0; R.emb_top = 0;
       joined_[p].store(0, std::memory_order_relaxed);
     }
-    const auto t_b = clk::now();
-    for (Request* q : reqs) stage(*q, p);  // the callers that have not got to their copy yet
-    for (Request* q : reqs)                // copies in progress on their owners' threads
-      while (q->copy_state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
-    while (outstanding_[p].load(std::memory_order_acquire) != 0) std::this_thread::yield();  // readers of the table two rounds back
-    const auto t_c = clk::now();
-    std::string err;
-    try { run(reqs, p, det_top, emb_top); }
-    catch (const std::exception& e) { err = e.what(); }
-    const auto t_d = clk::now();
-    {
-      std::lock_guard<std::mutex> g(g_stats_mu);
-      g_stats.us_window += us(t_a, t_b); g_stats.us_gather += us(t_b, t_c); g_stats.us_run += us(t_c, t_d);
-      g_stats.us_enqueue += last_enqueue_us_;
+    try {
+      const auto t_b = clk::now();
+      for (Request* q : reqs) stage(*q, p);  // the callers that have not got to their copy yet
+      for (Request* q : reqs)                // copies in progress on their owners' threads
+        spin_then_sleep([&] { return q->copy_state.load(std::memory_order_acquire) == 2; });
+      spin_then_sleep([&] { return outstanding_[p].load(std::memory_order_acquire) == 0; });  // readers of the table two rounds back
+      const auto t_c = clk::now();
+      run(reqs, p, det_top, emb_top);
+      const auto t_d = clk::now();
+      {
+        std::lock_guard<std::mutex> g(g_stats_mu);
+        g_stats.us_window += us(t_a, t_b); g_stats.us_gather += us(t_b, t_c); g_stats.us_run += us(t_c, t_d);
+        g_stats.us_enqueue += last_enqueue_us_;
+      }
+      prev_batch_ = last_batch_;
+      last_batch_ = static_cast<int>(reqs.size());
+    } catch (const std::exception& e) {
+      publish.failed = true;
+      try { publish.err = e.what(); } catch (...) {}
+    } catch (...) {
+      publish.failed = true;
     }
-    prev_batch_ = last_batch_;
-    last_batch_ = static_cast<int>(reqs.size());
-    for (Request* q : reqs) {
-      q->round = r;
-      if (!err.empty()) q->error = err;
+  }
+  // waits for a condition another thread is about to establish: a short spin (the common case: microseconds), then sleeps of 50 us — a
+  // waiter that lost its peer to a failure does not burn a CPU for good
+  template <class Cond>
+  static void spin_then_sleep(Cond cond) {
+    for (int i = 0; i < 2000; ++i) {
+      if (cond()) return;
+      std::this_thread::yield();
     }
-    outstanding_[p].store(static_cast<int>(reqs.size()), std::memory_order_release);
-    completed_.store(r + 1, std::memory_order_release);
-    word_[p].fetch_add(1, std::memory_order_release);
-    futex_wake_all(&word_[p]);  // this round's callers, and the leader of the next round if it is waiting already
+    while (!cond()) std::this_thread::sleep_for(std::chrono::microseconds(50));
   }
 
   std::mutex run_mu_;  // held while a round runs on the batch (uncontended except against quiesced())
@@ -335,7 +358,22 @@ class Segment {
     last_enqueue_us_ = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_e0).count();
     mot_frame_view v;
     std::memset(&v, 0, sizeof(v));
-    check(ops_.collect(batch_, &v), "collect_view");
+    const int crc = ops_.collect(batch_, &v);
+    // A stream that overflowed its level's capacities raises the batch's error word; the view is filled all the same and names the streams
+    // (alive[s] = -(error code)): only THEIR callers see the error — the reference's exceptions are per tracker object (src/tracker.cpp:108-125)
+    // — everybody else's rows are valid. Anything else (a HIP error, a full row table) is the whole round's.
+    bool per_stream = false;
+    if (crc == MOT_ERR_CAPACITY && v.alive && v.counts && v.rows) {
+      long long total = 0;
+      for (int s = 0; s < S; ++s) total += v.counts[s] > 0 ? v.counts[s] : 0;
+      per_stream = total <= static_cast<long long>(rows_cap);
+      if (per_stream) {  // (the stream in error need not be in this round: one that sits the frame out keeps raising the batch's word until it is reset)
+        bool named = false;
+        for (int s = 0; s < S && !named; ++s) named = v.alive[s] < 0;
+        per_stream = named;
+      }
+    }
+    if (!per_stream) check(crc, "collect_view");
     // stream s's rows start at the sum of the counts before it
     offs_.resize(static_cast<size_t>(S) + 1);
     int acc = 0;
@@ -344,6 +382,11 @@ class Segment {
       q->count = v.counts[q->s];
       q->rows = v.rows + static_cast<size_t>(offs_[q->s]) * 8;
       q->alive = v.alive ? v.alive[q->s] : 0;
+      if (q->alive < 0) {
+        q->error = "motcpp_amd: this tracker's stream exceeded the capacities of its pooled level (" + std::to_string(CAP) + " tracks x " + std::to_string(D) +
+                   " detections; device error " + std::to_string(-q->alive) + "): call reset() before using the object again";
+        q->count = 0; q->alive = 0;
+      }
     }
     std::lock_guard<std::mutex> g(g_stats_mu);
     g_stats.rounds += 1;
@@ -491,6 +534,10 @@ void PooledStream::prepare(const PooledFrame& f, void* req_) {
   // the level this frame needs: room for its detections and for every track it can add to the live ones
   int need = 0;
   while (need < kLevels && (kLevelDets[need] < n || kLevelCap[need] < alive_ + bpd * n || kLevelCap[need] < 2 * n)) ++need;
+  // (tests: MOTCPP_POOL_TEST_PIN_LEVEL=1 keeps every object on the level of its first frame, so that the device's own capacity check — which
+  // the level logic otherwise never lets fire — can be exercised: tests/test_gpu_pooled.py)
+  static const bool pin = env_long("MOTCPP_POOL_TEST_PIN_LEVEL", 0) != 0;
+  if (pin && seg_) need = seg_->level();
   if (need >= kLevels)
     throw Error("motcpp_amd: " + std::to_string(n) + " detections with " + std::to_string(alive_) + " live tracks exceed the largest pooled level (" +
                 std::to_string(kLevelCap[kLevels - 1]) + " tracks x " + std::to_string(kLevelDets[kLevels - 1]) + " detections)");
@@ -538,10 +585,13 @@ int PooledStream::finish(void* req_, const float** rows) {
     throw Error(req.error);
   }
   const int m = req.count > 0 ? req.count : 0;
+  struct Taken {  //  the round's table is released on every way out: a resize that throws must not leave the leader two rounds on waiting
+    Segment* seg; int parity;
+    ~Taken() { seg->rows_taken(parity); }
+  } taken{seg_, parity};
   rows_.resize(static_cast<size_t>(m) * 8);
   if (m) std::memcpy(rows_.data(), req.rows, sizeof(float) * rows_.size());
   alive_ = req.alive;
-  seg_->rows_taken(parity);
   if (req.from) pool_->release(req.from, req.from_s);
   *rows = rows_.data();
   return m;

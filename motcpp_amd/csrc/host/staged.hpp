@@ -1,5 +1,6 @@
 // Stage-machine interface shared by the four tracker implementations and the frame drivers.
 #pragma once
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -86,7 +87,11 @@ class Staged {
 };
 
 // Runs one frame for a set of trackers sharing a Device in lockstep: one kernel launch per kernel family per stage.
-void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, Team* team = nullptr);
+// errors == nullptr: the first failure of any stream aborts the frame for all (an exception; StreamBatch's contract: one call, one result).
+// errors != nullptr ([count] strings, empty on entry): a stream whose begin() / advance() throws sits the rest of the frame out with its own
+// message in errors[i]; the other streams finish their frame (merged update() calls of unrelated tracker objects: the reference's exceptions
+// are per object, src/tracker.cpp:108-125). A failure of the device itself (a flush) is everybody's either way.
+void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, Team* team = nullptr, std::string* errors = nullptr);
 
 // update() calls of host-lifecycle tracker OBJECTS that arrive together from different host threads (round 5: DeepOCSort, StrongSORT,
 // UCMCTrack, BoostTrack, HybridSort — the trackers without a device lifecycle): the first caller of a round leads it and steps every

@@ -64,15 +64,24 @@ int asso_kind(const std::string& name) {
     if (name == names[k]) return k;
   return -1;
 }
-void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, Team* team) {
+void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int count, Team* team, std::string* errors) {
   using clk = std::chrono::steady_clock;
   auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   std::lock_guard<std::mutex> frame_lock(dev.frame_mu);  // (trackers sharing a Device updated from several threads)
   dev.begin_frame();
+  //  whatever ends this frame early — a stream's exception in the all-or-nothing mode, a failing flush — the tasks queued so far must
+  // not survive into the next frame: begin_frame() resets the arenas, and a stale task would be flushed against spans that are gone
+  struct ClearOnAbort {
+    Device& dev; bool armed = true;
+    ~ClearOnAbort() { if (armed) for (auto& l : dev.lists) l.clear(); }
+  } clear_on_abort{dev};
   std::vector<char> done(count, 0);
   std::string err;
   std::mutex err_mu;
-  auto fail = [&](const std::exception& e) { std::lock_guard<std::mutex> g(err_mu); err = e.what(); };
+  auto fail = [&](int i, const std::exception& e) {
+    if (errors) { errors[i] = e.what(); if (errors[i].empty()) errors[i] = "motcpp_amd: update() failed"; }  // (slot i is written by the one worker stepping stream i)
+    else { std::lock_guard<std::mutex> g(err_mu); if (err.empty()) err = e.what(); }
+  };
   // Host lifecycle of different streams is independent: the team's workers step the stage machines of their own
   // contiguous slice of streams (task lists and arena leases are per worker; kernels are launched once per stage).
   auto for_streams = [&](const std::function<void(int)>& fn) {
@@ -81,8 +90,9 @@ void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int 
   };
   auto t0 = clk::now();
   for_streams([&](int i) {
+    // (a tracker validates its frame at the head of begin(), before it queues anything: a stream that fails here has left no task behind)
     try { trackers[i]->begin(inputs[i]); }
-    catch (const std::exception& e) { fail(e); }
+    catch (const std::exception& e) { done[i] = 1; fail(i, e); }
   });
   if (!err.empty()) throw Error(err);
   dev.counters.ms_begin += ms(t0, clk::now());
@@ -100,7 +110,7 @@ void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int 
         else done[i] = 1;
       } catch (const std::exception& e) {
         done[i] = 1;
-        fail(e);
+        fail(i, e);
       }
     });
     dev.counters.ms_advance += ms(t2, clk::now());
@@ -109,6 +119,7 @@ void run_frame(Device& dev, Staged* const* trackers, const FrameIn* inputs, int 
     for (int a : any_w) any |= a;
     if (!any) break;
   }
+  clear_on_abort.armed = false;
 }
 
 // ---- rounds of host stage machines (see staged.hpp) ---------------------------------------------------------------------
@@ -169,32 +180,54 @@ class HostRounds {
         else if (now - last_arrival >= std::chrono::microseconds(20)) break;
       }
     }
+    //  from here on the round completes on every way out of this function — a vector that cannot grow, a worker team that cannot
+    // start its threads (a pids cgroup at its limit), anything out of the frame — or the callers asleep on the futex word, and every later
+    // caller of this Device, would wait for good
     std::vector<Req*> reqs;
+    struct Publish {
+      HostRounds* self; uint64_t r; int p; std::vector<Req*>* reqs; std::string err; bool failed = false;
+      ~Publish() {
+        if (failed)
+          for (Req* q : *reqs)
+            if (q->error.empty()) { try { q->error = err.empty() ? std::string("motcpp_amd: the round's leader failed") : err; } catch (...) {} }
+        self->completed_.store(r + 1, std::memory_order_release);
+        self->word_[p].fetch_add(1, std::memory_order_release);
+        futex_wake_all(&self->word_[p]);
+      }
+    } publish{this, r, p, &reqs, {}};
     {
       std::lock_guard<std::mutex> lk(mu_);
       open_ = r + 1;
-      reqs.swap(reqs_[p]);
+      reqs.swap(reqs_[p]);  // (no allocation: the vectors trade their buffers)
       joined_[p].store(0, std::memory_order_relaxed);
     }
-    std::vector<Staged*> st(reqs.size());
-    std::vector<FrameIn> in(reqs.size());
-    for (size_t i = 0; i < reqs.size(); ++i) { st[i] = reqs[i]->s; in[i] = *reqs[i]->in; }
-    std::string err;
-    // many cameras in one round: their stage machines are stepped by a small worker team (the host share of a frame is ~15-50 us per
-    // stream and stage; one leader thread stepping 64 of them was the round's longest part)
-    if (st.size() >= 16 && !team_) {
-      long w = 8;
-      if (const char* e = std::getenv("MOTCPP_ROUND_WORKERS")) w = std::atol(e);
-      if (w > 1) team_ = std::make_unique<Team>(static_cast<int>(w));
+    try {
+      std::vector<Staged*> st(reqs.size());
+      std::vector<FrameIn> in(reqs.size());
+      std::vector<std::string> errs(reqs.size());
+      for (size_t i = 0; i < reqs.size(); ++i) { st[i] = reqs[i]->s; in[i] = *reqs[i]->in; }
+      // many cameras in one round: their stage machines are stepped by a small worker team (the host share of a frame is ~15-50 us per
+      // stream and stage; one leader thread stepping 64 of them was the round's longest part); a team that cannot be created is done without
+      if (st.size() >= 16 && !team_ && !team_failed_) {
+        long w = 8;
+        if (const char* e = std::getenv("MOTCPP_ROUND_WORKERS")) w = std::atol(e);
+        if (w > 1) {
+          try { team_ = std::make_unique<Team>(static_cast<int>(w)); }
+          catch (...) { team_failed_ = true; }
+        }
+      }
+      // every camera's failure is its own: the others finish their frame and get their rows (run_frame's `errors` mode)
+      run_frame(*dev_, st.data(), in.data(), static_cast<int>(st.size()), (st.size() >= 16) ? team_.get() : nullptr, errs.data());
+      for (size_t i = 0; i < reqs.size(); ++i)
+        if (!errs[i].empty()) reqs[i]->error = std::move(errs[i]);
+      prev_batch_ = last_batch_;
+      last_batch_ = static_cast<int>(reqs.size());
+    } catch (const std::exception& e) {
+      publish.failed = true;
+      try { publish.err = e.what(); } catch (...) {}
+    } catch (...) {
+      publish.failed = true;
     }
-    try { run_frame(*dev_, st.data(), in.data(), static_cast<int>(st.size()), (st.size() >= 16) ? team_.get() : nullptr); }
-    catch (const std::exception& e) { err = e.what(); }
-    if (!err.empty()) for (Req* q : reqs) q->error = err;
-    prev_batch_ = last_batch_;
-    last_batch_ = static_cast<int>(reqs.size());
-    completed_.store(r + 1, std::memory_order_release);
-    word_[p].fetch_add(1, std::memory_order_release);
-    futex_wake_all(&word_[p]);
   }
   Device* dev_;
   std::mutex mu_;
@@ -206,6 +239,7 @@ class HostRounds {
   int last_batch_ = 0, prev_batch_ = 0;
   long window_us_ = 60;
   std::unique_ptr<Team> team_;
+  bool team_failed_ = false;
 };
 }  // namespace
 

@@ -361,8 +361,12 @@ struct Flights {
 // one stream's persistent record back to its state at creation (a pooled tracker object's reset() / a slot handed to a new object);
 // keep_ids: the id counter keeps running (Sort::reset, sort.cpp:97-100)
 template <class StreamT>
-static __global__ void reset_stream_kernel(StreamT* streams, int s, StreamT fresh, int keep_ids) {
+static __global__ void reset_stream_kernel(StreamT* streams, int s, StreamT fresh, int keep_ids, int* batch_err) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    // the batch's error word starts over with the stream: whichever other stream is still in error raises it again in its next frame (every
+    // stream reports its own sticky word per frame), so a tracker object that was reset after a capacity error does not keep failing
+    // everybody's rounds (round 6; the pooled trackers read the per-stream words, mot_frame_view.alive)
+    if (batch_err) *batch_err = 0;
     // The record is written ONCE, with the counter already in it. (Round 5: `streams[s] = fresh; streams[s].next_id = saved;` lost the counter for the
     // first objects of a process — a 16-byte store and a later 4-byte store of the same wavefront to the same word, completed out of order while the
     // page was cold. Measured: plain read + single store 0 of 12 fresh interpreters, the two stores 8 of 12. Two stores of one thread to

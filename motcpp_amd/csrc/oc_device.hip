@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(kW) oc_emit(OcStream* streams, OcParams P, int
   OcStream& S = streams[blockIdx.x];
   const int t = static_cast<int>(threadIdx.x);
   if (S.skip || S.silent) {
-    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_trk; atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk); if (S.err) atomicMax(err, S.err); }
+    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.err ? -S.err : S.n_trk; atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk); if (S.err) atomicMax(err, S.err); }
     return;
   }
   const int* trk = S.trk[S.cur];
@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(kW) oc_emit(OcStream* streams, OcParams P, int
     if (n_rows > cap_out) S.err = 2;
     out_counts[blockIdx.x] = (n_rows <= cap_out) ? n_rows : -n_rows;
     atomicMax(&max_tracks[blockIdx.x & 63], n_keep);
-    alive[blockIdx.x] = n_keep;
+    alive[blockIdx.x] = S.err ? -S.err : n_keep;  // (a stream in error reports -(error code): its caller alone gets the error, lifecycle_common.hpp)
     if (S.err) atomicMax(err, S.err);  // the batch's error word (round 5: gathered here; a kernel of its own before)
   }
 }
@@ -879,7 +879,7 @@ int mot_oc_collect_view(mot_oc_batch* b, mot_frame_view* out) {
 }
 int mot_oc_reset_stream(mot_oc_batch* b, int s, int fresh) {
   if (!b || s < 0 || s >= b->S) return MOT_ERR_INVALID;
-  hipLaunchKernelGGL(mot::lifecycle::reset_stream_kernel<OcStream>, dim3(1), dim3(64), 0, b->ctx->stream, b->d_streams, s, b->h_streams[s], fresh ? 0 : 1);
+  hipLaunchKernelGGL(mot::lifecycle::reset_stream_kernel<OcStream>, dim3(1), dim3(64), 0, b->ctx->stream, b->d_streams, s, b->h_streams[s], fresh ? 0 : 1, b->d_err);
   MOT_LC_HIP(b, hipGetLastError());
   return MOT_OK;
 }

@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(kW) sort_emit(SortStream* streams, int CAP, fl
   SortStream& S = streams[blockIdx.x];
   const int t = threadIdx.x;
   if (S.skip) {
-    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.n_trk; atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk); if (S.err) atomicMax(err, S.err); }
+    if (t == 0) { out_counts[blockIdx.x] = 0; alive[blockIdx.x] = S.err ? -S.err : S.n_trk; atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk); if (S.err) atomicMax(err, S.err); }
     return;
   }
   float* rows = out + static_cast<size_t>(blockIdx.x) * cap_out * 8;
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(kW) sort_emit(SortStream* streams, int CAP, fl
     if (n > cap_out) S.err = 2;
     out_counts[blockIdx.x] = (n <= cap_out) ? n : -n;
     atomicMax(&max_tracks[blockIdx.x & 63], S.n_trk);
-    alive[blockIdx.x] = S.n_trk;
+    alive[blockIdx.x] = S.err ? -S.err : S.n_trk;  // (a stream in error reports -(error code): its caller alone gets the error)
     if (S.err) atomicMax(err, S.err);  // the batch's error word (round 5: gathered here; a kernel of its own before)
   }
 }
@@ -548,7 +548,7 @@ int mot_sort_collect_view(mot_sort_batch* b, mot_frame_view* out) {
 }
 int mot_sort_reset_stream(mot_sort_batch* b, int s, int fresh) {
   if (!b || s < 0 || s >= b->S) return MOT_ERR_INVALID;
-  hipLaunchKernelGGL(mot::lifecycle::reset_stream_kernel<SortStream>, dim3(1), dim3(64), 0, b->ctx->stream, b->d_streams, s, b->h_streams[s], fresh ? 0 : 1);
+  hipLaunchKernelGGL(mot::lifecycle::reset_stream_kernel<SortStream>, dim3(1), dim3(64), 0, b->ctx->stream, b->d_streams, s, b->h_streams[s], fresh ? 0 : 1, b->d_err);
   MOT_LC_HIP(b, hipGetLastError());
   return MOT_OK;
 }

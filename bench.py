@@ -100,6 +100,14 @@ def launch_probe(real_stdout):
     dist.destroy_process_group()
 
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+try:
+    from kernel_sources_hash import kernel_sources_hash
+    KSRC = kernel_sources_hash()
+except Exception:  # noqa: BLE001
+    KSRC = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -809,8 +817,10 @@ def main():
         # one at a time, HIP events on the launching stream. This is the figure rocprofv3 --kernel-trace --stats of this same command
         # reports as the kernel's average (profiles/r04*_kernel_stats_*.csv: 299.9 us against 298.6 us here for lap_sparse_kernel at NS)
         avg_ms = isolated[fam]["avg_launch_ms"]
-        duration_source = ("HIP events around the kernel's launches, sub-batches stepped one at a time right after the timed region (same trackers): the "
-                           "kernel's own begin-to-end time, what rocprofv3 --kernel-trace --stats of this command shows as its average")
+        duration_source = ("HIP events around the kernel's launches, sub-batches stepped one at a time right after the timed region (same trackers, full "
+                           "sub-batches): the kernel's own begin-to-end time. rocprofv3 --kernel-trace --stats shows the same average only for a command "
+                           "whose launches are all of this size (--sweep-streams '' --long-run-steps 0 --host-input-steps 0 --isolated-steps 0 --no-cpu-baseline: "
+                           "profiles/*_kernel_stats_*_timed_only.csv); the default command's table also averages the stream sweep's smaller launches")
     bytes_per_launch = st["bytes"] / launches
     if fam == "cosine" and st["flops"] > 0:
         achieved = st["flops"] / launches / (avg_ms * 1e-3) / 1e12
@@ -848,6 +858,11 @@ def main():
             per_problem = (pj.get(fam) or pj.get("lap") or {}).get("hbm_bytes_per_problem")
             if per_problem is not None:  # PMC passes are separate runs (profiles/README.md); scaled to this run's problems per launch
                 roof["traffic"] = per_problem * st["tasks"] / launches
+                # counters are collected in their own runs: the file says which kernel sources it was collected for; a file from older sources
+                # is still shown (the kernels' traffic rarely moves) but marked — round 5's line quoted round-4 counters without saying so
+                roof["traffic_source"] = {"file": os.path.relpath(prof, ROOT), "tag": pj.get("tag") or None,
+                                          "collected_for_kernel_sources": pj.get("kernel_sources_sha"), "this_run_kernel_sources": KSRC,
+                                          "stale": pj.get("kernel_sources_sha") != KSRC}
         except Exception:
             pass
     # The same throughput priced with SURVEY §8(d)'s per-frame bytes — the formulation that materialises each stage's cost
@@ -880,7 +895,8 @@ def main():
         try:  # what actually bounds this kernel: instruction issue of the serial searches (SQ counters, separate PMC run)
             sq = json.load(open(sq_files[-1])).get(args.workload)
             if sq:
-                roof["issue"] = {"wave_cycles_issuing_frac": sq["active_frac"], "wave_cycles_waiting_frac": sq["wait_any_frac"],
+                roof["issue"] = {"stale": sq.get("kernel_sources_sha") != KSRC, "collected_for_kernel_sources": sq.get("kernel_sources_sha"),
+                                 "wave_cycles_issuing_frac": sq["active_frac"], "wave_cycles_waiting_frac": sq["wait_any_frac"],
                                  "valu_insts_per_problem": sq["per_problem"]["SQ_INSTS_VALU"],
                                  "salu_insts_per_problem": sq["per_problem"]["SQ_INSTS_SALU"], "kernel": sq.get("kernel"),
                                  "source": os.path.relpath(sq_files[-1], ROOT)}
@@ -1025,6 +1041,28 @@ def main():
         cpu["all_cores"] = {"value": tot, "unit": "frames/s", "cores": nproc,
                             "sample": f"{nproc} oracle processes x {args.cpu_seconds:.0f} s, one stream each, concurrently; sum of per-process frames / time inside update()"}
 
+    # C3: the one dense contraction of the path on the matrix cores. BoT-SORT's device lifecycle evaluates the appearance term for the pairs that pass
+    # its proximity gate only (cosine_gated.hip: no MFMA launch in the frames timed above); the MFMA kernel is what DeepOC-SORT, StrongSORT and
+    # utils::embedding_distance run — embed_kernel at this workload's shape (tracks x detections x D per camera, a sub-batch of cameras per launch),
+    # timed here on device-resident features, next to the matrix-core busy counter of the same kernel from its own PMC run (profiles/).
+    mfma = None
+    if D and not args.no_cpu_baseline:
+        try:
+            import embed_microbench
+            nt = max(1, min(512, S))
+            r = embed_microbench.run(nt, P, M, D, reps=10)
+            mfma = {"kernel": "embed_kernel<cosine> (mot_cosine_cost: fp32 MFMA v_mfma_f32_32x32x2_f32, 128 x 128 tiles)", "tasks_per_launch": nt,
+                    "shape": [P, M, D], "ms_per_launch": r["ms_per_launch"], "TFLOP/s": r["TFLOP/s"], "peak_TFLOP/s": MFMA_F32_PEAK_TFLOPS,
+                    "mfma_f32_frac": r["TFLOP/s"] / MFMA_F32_PEAK_TFLOPS, "flops": "2 n m D per task (norms and the 1 - sim epilogue not counted)",
+                    "timing": "wall clock around 10 back-to-back launches between two stream synchronisations, after the timed region"}
+            import glob as _g
+            cf = sorted(_g.glob(os.path.join(ROOT, "profiles", "*pmc_mfma_embed*.json")))
+            if cf:
+                cj = json.load(open(cf[-1]))
+                mfma["matrix_core_busy"] = {"SQ_VALU_MFMA_BUSY_CYCLES_over_GRBM_GUI_ACTIVE_x_SIMDs": cj.get("mfma_busy_frac"), "source": os.path.relpath(cf[-1], ROOT),
+                                            "collected_for_kernel_sources": cj.get("kernel_sources_sha"), "stale": cj.get("kernel_sources_sha") != KSRC}
+        except Exception as ex:  # noqa: BLE001
+            mfma = {"error": repr(ex)}
     line = {
         "metric": "tracker.update() frames/sec at N_tracks x M_dets (assignment indices identical to the reference path)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W0,
@@ -1040,7 +1078,7 @@ def main():
                    "table_gather": (args.gather + " (RCCL)") if world > 1 else args.gather,
                    "inputs": "detections (and embeddings) resident in HBM before the timed region; LAP arithmetic is f64/int32, Kalman/IoU f32"},
         "per_rank": per_rank,
-        "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+        "roofline": roof, "cpu_baseline": cpu, "parity": parity, "mfma": mfma,
         "kernels": kernels,
         "lap_fast_path": fast_stats,
         "lap_behind_fast_path": diag_ctx.lap_behind_stats(),  # (whole run: the problems the exact kernel solved behind the sparse solver, cycle split of the slowest)

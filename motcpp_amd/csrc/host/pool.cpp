@@ -14,6 +14,7 @@
 
 #include <linux/futex.h>
 #include <sys/syscall.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "runtime.hpp"
@@ -73,6 +74,22 @@ long env_long(const char* name, long dflt) {
 std::mutex g_stats_mu;
 PoolStats g_stats;
 
+// diagnostics (MOTCPP_POOL_CPU_DEBUG=1): CPU time (CLOCK_THREAD_CPUTIME_ID) the calling threads spend inside update(), and the leaders inside lead() / run()
+struct CpuDbg {
+  std::atomic<long long> ns_update{0}, ns_lead{0}, ns_run{0}, ns_wait{0}, n_update{0}, ns_prepare{0}, ns_lock{0}, ns_stage{0}, ns_finish{0};
+  bool on = std::getenv("MOTCPP_POOL_CPU_DEBUG") != nullptr;
+  ~CpuDbg() {
+    if (on && n_update.load() > 0)
+      std::fprintf(stderr, "[pool cpu] updates %lld: CPU us per update %.1f (of which lead() %.1f, of which run() %.1f); CPU us per update inside the futex wait call %.1f\n",
+                   n_update.load(), ns_update.load() / 1e3 / n_update.load(), ns_lead.load() / 1e3 / n_update.load(), ns_run.load() / 1e3 / n_update.load(),
+                   ns_wait.load() / 1e3 / n_update.load());
+    if (on && n_update.load() > 0)
+      std::fprintf(stderr, "[pool cpu]   prepare %.1f  join: lock %.1f stage %.1f  finish %.1f\n", ns_prepare.load() / 1e3 / n_update.load(), ns_lock.load() / 1e3 / n_update.load(),
+                   ns_stage.load() / 1e3 / n_update.load(), ns_finish.load() / 1e3 / n_update.load());
+  }
+} g_cpu;
+long long thread_cpu_ns() { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return static_cast<long long>(ts.tv_sec) * 1000000000ll + ts.tv_nsec; }
+
 struct Request {
   const PooledFrame* in = nullptr;
   int s = -1;
@@ -119,6 +136,8 @@ class Segment {
     for (int s = S - 1; s >= 0; --s) free_.push_back(s);
     counts_.assign(S, -1); ld_.assign(S, 0); det_off_.assign(S, 0); emb_off_.assign(S, -1);
     warps_.assign(static_cast<size_t>(S) * 6, 0.f); has_warp_.assign(S, 0);
+    seen_round_.assign(static_cast<size_t>(S), 0);
+    for (Round& R : rounds_) { R.slots = std::vector<std::atomic<Request*>>(static_cast<size_t>(S)); for (auto& a : R.slots) a.store(nullptr, std::memory_order_relaxed); }
     window_us_ = env_long("MOTCPP_BATCH_WINDOW_US", 60);
     gap_us_ = env_long("MOTCPP_BATCH_GAP_US", 20);
   }
@@ -140,37 +159,49 @@ class Segment {
   // made one notify call per caller and every woken caller queued for the mutex again: with 256 objects on 16 CPUs a round spent twice as
   // long handing out its results as running.)
   void join(Request* const* reqs, int k) {
-    uint64_t r;
-    bool first;
+    // Round 6: joining takes no lock. One atomic word holds the open round and the number of requests in it (round << 24 | joined): a
+    // fetch-add puts the caller into whatever round is open and hands it its place there; the leader closes its round by exchanging the word
+    // for (round + 1) << 24 — every fetch-add lands before the exchange (this round) or after it (the next). The staging space is reserved with
+    // two more fetch-adds on the round's tops. (Round 5's mutex around the request list: with 256 objects woken together by the previous
+    // round's completion, 116 us of CPU per update() went into that lock — 87 % of what an update() cost the host — and on the GPU boxes'
+    // 16-CPU quota that is what made the cgroup throttle: p99 of update() 51 ms against a median of 0.9.)
+    const long long jc0 = g_cpu.on ? thread_cpu_ns() : 0;
+    const uint64_t old = gate_.fetch_add(static_cast<uint64_t>(k), std::memory_order_acq_rel);
+    const uint64_t r = old >> kGateShift;
+    const size_t idx0 = static_cast<size_t>(old & kGateMask);
+    const bool first = idx0 == 0;
     {
-      std::lock_guard<std::mutex> lk(mu_);
-      r = open_;
       Round& R = rounds_[r & 1];
-      first = R.reqs.empty();
+      if (idx0 + static_cast<size_t>(k) > R.slots.size()) std::abort();  // (a stream joins a round once: cannot happen)
       for (int i = 0; i < k; ++i) {
         Request& q = *reqs[i];
         const int n = q.in->n;
         q.n = n;
         q.ld = (n + 3) & ~3;
         if (q.ld < 4) q.ld = 4;
-        q.det_off = static_cast<long long>(R.det_top);
-        R.det_top += static_cast<size_t>(6) * q.ld;
+        q.det_off = static_cast<long long>(R.det_top.fetch_add(static_cast<size_t>(6) * q.ld, std::memory_order_relaxed));
         const bool with_emb = q.in->embs != nullptr && E > 0 && n > 0;
         q.emb_off = -1;
-        if (with_emb) { q.emb_off = static_cast<long long>(R.emb_top); R.emb_top += static_cast<size_t>(n) * E; }
+        if (with_emb) q.emb_off = static_cast<long long>(R.emb_top.fetch_add(static_cast<size_t>(n) * E, std::memory_order_relaxed));
+        q.copy_state.store(0, std::memory_order_relaxed);
+        R.slots[idx0 + i].store(&q, std::memory_order_release);  // published: offsets reserved
       }
-      for (int i = 0; i < k; ++i) { reqs[i]->copy_state.store(0, std::memory_order_relaxed); R.reqs.push_back(reqs[i]); }
-      joined_[r & 1].store(static_cast<int>(R.reqs.size()), std::memory_order_release);
     }
     // the caller's own copy into the round's page-locked staging, in parallel with the other callers' (a caller that loses the CPU
     // before it gets here is helped out by the round's leader: whoever flips copy_state first does the copy)
+    const long long jc1 = g_cpu.on ? thread_cpu_ns() : 0;
     for (int i = 0; i < k; ++i) stage(*reqs[i], static_cast<int>(r & 1));
+    if (g_cpu.on) { const long long jc2 = thread_cpu_ns(); g_cpu.ns_lock += jc1 - jc0; g_cpu.ns_stage += jc2 - jc1; }
     if (first) {
       const bool idle = completed_.load(std::memory_order_acquire) >= r;  // nothing in flight: peers in lockstep may be a few microseconds behind
       wait_completed(r, static_cast<int>((r + 1) & 1));                   // (round r - 1 carries the other parity)
+      const long long c0 = g_cpu.on ? thread_cpu_ns() : 0;
       lead(r, idle);
+      if (g_cpu.on) g_cpu.ns_lead += thread_cpu_ns() - c0;
     } else {
+      const long long c0 = g_cpu.on ? thread_cpu_ns() : 0;
       wait_completed(r + 1, static_cast<int>(r & 1));
+      if (g_cpu.on) g_cpu.ns_wait += thread_cpu_ns() - c0;
     }
   }
   // copies q's detections (and features) into the staging buffer of its round unless somebody else already does / did
@@ -217,9 +248,15 @@ class Segment {
 
  private:
   struct Round {
-    size_t det_top = 0, emb_top = 0;
-    std::vector<Request*> reqs;
+    std::atomic<size_t> det_top{0}, emb_top{0};
+    std::vector<std::atomic<Request*>> slots;  // [S] the requests of the round, in joining order
   };
+  static constexpr int kGateShift = 24;
+  static constexpr uint64_t kGateMask = (uint64_t(1) << kGateShift) - 1;
+  int joined_in(uint64_t r) const {  // requests in round r so far (0 once it is closed)
+    const uint64_t g = gate_.load(std::memory_order_acquire);
+    return (g >> kGateShift) == r ? static_cast<int>(g & kGateMask) : 0;
+  }
   static void futex_wait(std::atomic<uint32_t>* w, uint32_t seen) {
     syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
   }
@@ -243,18 +280,22 @@ class Segment {
     // already and closing at once is the group commit): objects stepped in lockstep come back within microseconds of each other — the round
     // stays open while they keep arriving (no arrival for `gap` microseconds closes it), until the streams of the last rounds are all in,
     // at most window_us_ + 40 us.
-    const int expected = (last_batch_ > prev_batch_) ? last_batch_ : prev_batch_;
-    if (idle && window_us_ > 0 && joined_[p].load(std::memory_order_acquire) < expected) {
+    // how many callers to expect: the streams that took part in one of the last two rounds (round 5 took the larger of the last two batches — a
+    // population that once split into two alternating groups, each closing its round on the idle gap before the other arrived, then stayed
+    // split: every object waited for two rounds per frame; seen with 16 objects once joining stopped queueing on a lock)
+    int expected = 0;
+    for (int s2 = 0; s2 < S; ++s2) expected += (seen_round_[s2] + 2 > r) ? 1 : 0;  // (seen_round_ = 1 + the stream's last round)
+    if (idle && window_us_ > 0 && joined_in(r) < expected) {
       // (round 4 waited up to window + 2 us per expected stream: 570 us of idle GPU per round with 256 objects on 16 CPUs, whose threads take that
       // long to get a CPU each. Whoever is late simply rides the next round, which fills while this one runs.)
       const auto hard = t_a + std::chrono::microseconds(window_us_ + (expected < 20 ? 2 * expected : 40));
       const auto gap = std::chrono::microseconds(gap_us_);
-      int seen = joined_[p].load(std::memory_order_acquire);
+      int seen = joined_in(r);
       auto last_arrival = t_a;
       for (;;) {
         std::this_thread::yield();
         const auto now = clk::now();
-        const int j = joined_[p].load(std::memory_order_acquire);
+        const int j = joined_in(r);
         if (j >= expected || now >= hard) break;
         if (j != seen) { seen = j; last_arrival = now; }
         else if (now - last_arrival >= gap) break;
@@ -277,15 +318,20 @@ class Segment {
         futex_wake_all(&self->word_[p]);  // this round's callers, and the leader of the next round if it is waiting already
       }
     } publish{this, r, p, &reqs, {}};
-    size_t det_top, emb_top;
+    size_t det_top = 0, emb_top = 0;
     {
-      std::lock_guard<std::mutex> lk(mu_);
       Round& R = rounds_[p];
-      open_ = r + 1;  // closed: later arrivals fill the other round
-      reqs.swap(R.reqs);  // (no allocation: the vectors trade their buffers)
-      det_top = R.det_top; emb_top = R.emb_top;
-      R.det_top = 0; R.emb_top = 0;
-      joined_[p].store(0, std::memory_order_relaxed);
+      const uint64_t closed = gate_.exchange((r + 1) << kGateShift, std::memory_order_acq_rel);  // closed: later arrivals fill the other round
+      const size_t count = static_cast<size_t>(closed & kGateMask);
+      reqs.reserve(count);  // (the one allocation of the round; if it throws nobody has been taken out of the round yet... and the guard completes it)
+      for (size_t i = 0; i < count; ++i) {
+        Request* q;
+        while ((q = R.slots[i].load(std::memory_order_acquire)) == nullptr) std::this_thread::yield();  // (between its fetch-add and its store)
+        R.slots[i].store(nullptr, std::memory_order_relaxed);
+        reqs.push_back(q);
+      }
+      det_top = R.det_top.exchange(0, std::memory_order_relaxed);
+      emb_top = R.emb_top.exchange(0, std::memory_order_relaxed);
     }
     try {
       const auto t_b = clk::now();
@@ -294,15 +340,16 @@ class Segment {
         spin_then_sleep([&] { return q->copy_state.load(std::memory_order_acquire) == 2; });
       spin_then_sleep([&] { return outstanding_[p].load(std::memory_order_acquire) == 0; });  // readers of the table two rounds back
       const auto t_c = clk::now();
+      const long long rc0 = g_cpu.on ? thread_cpu_ns() : 0;
       run(reqs, p, det_top, emb_top);
+      if (g_cpu.on) g_cpu.ns_run += thread_cpu_ns() - rc0;
       const auto t_d = clk::now();
       {
         std::lock_guard<std::mutex> g(g_stats_mu);
         g_stats.us_window += us(t_a, t_b); g_stats.us_gather += us(t_b, t_c); g_stats.us_run += us(t_c, t_d);
         g_stats.us_enqueue += last_enqueue_us_;
       }
-      prev_batch_ = last_batch_;
-      last_batch_ = static_cast<int>(reqs.size());
+      for (Request* q : reqs) seen_round_[q->s] = r + 1;
     } catch (const std::exception& e) {
       publish.failed = true;
       try { publish.err = e.what(); } catch (...) {}
@@ -314,11 +361,11 @@ class Segment {
   // waiter that lost its peer to a failure does not burn a CPU for good
   template <class Cond>
   static void spin_then_sleep(Cond cond) {
-    for (int i = 0; i < 2000; ++i) {
+    for (int i = 0; i < 200; ++i) {
       if (cond()) return;
       std::this_thread::yield();
     }
-    while (!cond()) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    while (!cond()) std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
 
   std::mutex run_mu_;  // held while a round runs on the batch (uncontended except against quiesced())
@@ -416,14 +463,12 @@ class Segment {
   float* d_embs_ = nullptr; float* h_embs_[2] = {nullptr, nullptr};
   std::vector<int> free_;
   // combiner
-  std::mutex mu_;                          // the open round's request list and staging offsets
   Round rounds_[2];
-  uint64_t open_ = 0;                      // the round that is filling (mu_)
+  std::atomic<uint64_t> gate_{0};          // open round << 24 | requests joined (see join())
   std::atomic<uint64_t> completed_{0};     // rounds whose results are delivered (rounds run strictly one after the other)
   std::atomic<uint32_t> word_[2] = {{0}, {0}};  // futex words, by round parity: bumped when a round of that parity completes
-  std::atomic<int> joined_[2] = {{0}, {0}};     // requests in the open round of that parity (the leader's window reads it without the lock)
   std::atomic<int> outstanding_[2] = {{0}, {0}};  // callers that have not copied their rows out of that parity's table yet
-  int last_batch_ = 0, prev_batch_ = 0;    // (leader only)
+  std::vector<uint64_t> seen_round_;       // [S] 1 + the last round a stream took part in, 0: never (leader only)
   long window_us_ = 60, gap_us_ = 20;
   double last_enqueue_us_ = 0.0;
   // leader's scratch
@@ -604,11 +649,16 @@ int PooledStream::update(const PooledFrame& f, const float** rows) {
     *rows = rows_.data();
     return 0;
   }
+  const long long c0 = g_cpu.on ? thread_cpu_ns() : 0;
   Request req;
   prepare(f, &req);
+  const long long c1 = g_cpu.on ? thread_cpu_ns() : 0;
   Request* q = &req;
   seg_->join(&q, 1);
-  return finish(&req, rows);
+  const long long c2 = g_cpu.on ? thread_cpu_ns() : 0;
+  const int m = finish(&req, rows);
+  if (g_cpu.on) { const long long c3 = thread_cpu_ns(); g_cpu.ns_update += c3 - c0; g_cpu.n_update += 1; g_cpu.ns_prepare += c1 - c0; g_cpu.ns_finish += c3 - c2; }
+  return m;
 }
 
 void PooledStream::update_many(PooledStream* const* streams, const PooledFrame* frames, int k, const float** rows, int* counts) {

@@ -129,6 +129,8 @@ hipError_t launch_lap(const mot_lap_task* tasks, int ntasks, int max_n, int max_
   static const bool lds16_ok = !(std::getenv("MOT_LAP_LDS16") && std::getenv("MOT_LAP_LDS16")[0] == '0');  // (A/B measurements)
   if (lds16_ok && fs_lds && wide && !general_assoc && nm <= 2 * static_cast<size_t>(mot::kFsEvl) && b6 <= static_cast<size_t>(kLdsBudget) - 1024) { mode = 6; lds = b6; }
   if (behind_matrix) { mode = 2; lds = b2; }
+  static const int wide_mode = std::getenv("MOT_LAP_WIDE_MODE") ? std::atoi(std::getenv("MOT_LAP_WIDE_MODE")) : -1;  // (experiments: 3 = lean state for the wide matrix problems)
+  if (wide_mode == 3 && fs_lds && wide && !general_assoc && !behind_matrix) { mode = 3; lds = b3; }
   // lane-owned column boxes in registers: one wavefront per problem, <= 8 real columns per lane
   int rpl = 0;
   if (geom && !wide && !general_assoc) rpl = (m <= 256) ? 4 : (m <= 512 ? 8 : 0);

@@ -2,6 +2,8 @@
 // order-preserving compaction every "for ... push_back" of the reference turns into, and the launch helpers of the
 // numeric kernels those files chain between their bookkeeping kernels.
 #pragma once
+#include <time.h>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -216,6 +218,7 @@ struct Flight {
   hipEvent_t done = nullptr;
   hipEvent_t ev[12] = {};
   bool pending = false, prof = false, view = false;
+  bool polite = false;  // the host waits for this frame with sleeps between polls instead of spinning (see Flights::pop)
   int rows_cap = 0;  // the row limit pack_rows ran with (the enqueue call's rows_cap)
   int bd = 0;        // largest detection count of the frame (bounds the tracks it may add)
 };
@@ -262,9 +265,17 @@ struct Flights {
     if (prof && !F.ev[0]) for (auto& ev : F.ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return e;
     F.prof = prof;
     int* ci = counts_in_of(F, S);
-    int bd = 1;
-    for (int s = 0; s < S; ++s) { ci[s] = h_counts[s]; bd = (h_counts[s] > bd) ? h_counts[s] : bd; }
+    int bd = 1, active = 0;
+    for (int s = 0; s < S; ++s) { ci[s] = h_counts[s]; bd = (h_counts[s] > bd) ? h_counts[s] : bd; active += h_counts[s] >= 0 ? 1 : 0; }
     *counts_in = ci; *bd_out = bd;
+    // Round 6. A pooled round of many tracker objects means as many host threads that want a CPU the moment the round ends, on boxes whose
+    // CPU quota (16 CPUs for 256 hardware threads on the MI355X boxes) is the scarce resource: a leader that SPINS on the frame's event for the
+    // whole GPU time of the round — hipEventSynchronize's default — burns one CPU per segment, a quarter of the quota with four segments, and
+    // the cgroup then throttles everybody for the rest of its 100 ms period (measured: 1024 objects, p99 of update() 78 ms against a median of
+    // 1.0). From 48 streams on, the wait polls the event with 30 us sleeps in between. A handful of cameras keep the spin: their frame is
+    // 0.2 ms and a sleep's wake-up latency would show. MOT_POLITE_WAIT=0 / 1 forces either.
+    static const int polite_env = [] { const char* e = std::getenv("MOT_POLITE_WAIT"); return (e && *e) ? std::atoi(e) : -1; }();
+    F.polite = view && (polite_env >= 0 ? polite_env != 0 : active >= 48);
     return hipSuccess;
   }
   // pooled form: fills the slot's page-locked input block from the caller's arrays, queues its copy to the device and returns the
@@ -329,7 +340,15 @@ struct Flights {
   // the oldest pending frame: waits for it, hands out its meta words; the caller copies the rows with copy_rows
   hipError_t pop(Flight** out) {
     Flight& F = fl[head];
-    const hipError_t e = hipEventSynchronize(F.done);
+    hipError_t e = hipSuccess;
+    if (F.polite) {
+      for (;;) {
+        e = hipEventQuery(F.done);
+        if (e != hipErrorNotReady) break;
+        struct timespec ts = {0, 30000};
+        nanosleep(&ts, nullptr);
+      }
+    } else e = hipEventSynchronize(F.done);
     if (e != hipSuccess) return e;
     F.pending = false;
     head ^= 1; count -= 1;

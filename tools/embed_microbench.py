@@ -13,9 +13,8 @@ class CosTask(C.Structure):
                 ("norm_a", C.c_void_p), ("norm_b", C.c_void_p)]
 
 
-def main():
-    nt = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    n, m, d = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (1024, 512, 256)
+def run(nt=512, n=1024, m=512, d=256, reps=10):
+    """nt tasks of an n x m x d cosine-distance matrix in one launch of embed_kernel<cosine> (mot_cosine_cost), device-resident operands"""
     ctx = L.Context(0)
     lib = ctx.lib
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -37,7 +36,7 @@ def main():
     for rep in range(3):
         ctx._chk(lib.mot_cosine_cost(ctx.h, C.c_void_p(dt.data_ptr()), nt, n, m))
     ctx._chk(lib.mot_ctx_sync(ctx.h))
-    R = 10
+    R = reps
     t0 = time.perf_counter()
     for rep in range(R):
         ctx._chk(lib.mot_cosine_cost(ctx.h, C.c_void_p(dt.data_ptr()), nt, n, m))
@@ -49,7 +48,13 @@ def main():
     err = float((out[0] - ref.clamp(min=0)).abs().max())
     res = {"tasks": nt, "n": n, "m": m, "d": d, "ms_per_launch": dtm * 1e3, "TFLOP/s": flops / dtm / 1e12, "mfma_f32_frac": flops / dtm / 1e12 / 157.3,
            "max_abs_diff_vs_torch_fp32": err}
-    print(json.dumps(res))
+    return res
+
+
+def main():
+    nt = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    n, m, d = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (1024, 512, 256)
+    print(json.dumps(run(nt, n, m, d)))
 
 
 if __name__ == "__main__":

@@ -3,6 +3,8 @@
   profiles/<tag>_pmc_sq_lap.json    SQ counters of the dominant assignment kernel per problem (= per workgroup)
 usage: python tools/pmc_derive.py <tag> <WL> <streams per launch (= per sub-batch) of the PMC passes> ["<bench command of the passes>"]"""
 import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_sources_hash import kernel_sources_hash
 
 tag, wl, S = sys.argv[1], sys.argv[2], int(sys.argv[3])
 cmd = sys.argv[4] if len(sys.argv) > 4 else f"bench.py --workload {wl} --streams {S} --pipeline 1 --steps 2 --warmup 5"
@@ -18,7 +20,8 @@ per_frame = 3.0 * S  # ByteTrack: S first-association problems in one launch, 2S
 per_launch = per_frame
 fb = sum(fetch[k]["FETCH_SIZE"]["sum"] for k in laps) * 1024.0 / disp
 wb = sum(write[k]["WRITE_SIZE"]["sum"] for k in laps if k in write) * 1024.0 / disp
-out = {"_comment": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `{cmd}` (device lifecycle, {S} streams per launch); kernels {laps}; KB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md (an upper bound for "
+out = {"kernel_sources_sha": kernel_sources_hash(), "tag": tag,
+       "_comment": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `{cmd}` (device lifecycle, {S} streams per launch); kernels {laps}; KB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md (an upper bound for "
                    f"4-byte accesses). Raw sums: {tag}_pmc_fetch_{wl}.json, {tag}_pmc_write_{wl}.json",
        "lap": {"fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb, "problems_per_launch": per_launch,
                "hbm_bytes_per_problem": (2.0 * fb + wb) / per_launch}}
@@ -34,7 +37,7 @@ c = {}
 for src in (sq1, sq2):
     for name, v in src[main].items():
         c[name] = v["sum"] / v["dispatches"] / S  # (the dominant kernel = the first association's sparse solver: S problems per dispatch)
-sq = {"kernel": main, "problems_per_launch": S, "waves_per_problem": c.get("SQ_WAVES"),
+sq = {"kernel_sources_sha": kernel_sources_hash(), "tag": tag, "kernel": main, "problems_per_launch": S, "waves_per_problem": c.get("SQ_WAVES"),
       "per_problem": {k: round(v, 1) for k, v in c.items() if k != "SQ_WAVES"},
       "active_frac": round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3), "wait_any_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3)}
 path = os.path.join(P, f"{tag}_pmc_sq_lap.json")

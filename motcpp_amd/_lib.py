@@ -192,13 +192,16 @@ class Context:
         """Outcome counts of the assignment fast path on this device since the last reset (see mot_lap_fast_stats)."""
         o = np.zeros(32, np.uint64)
         self._chk(self.lib.mot_lap_fast_stats(self.h, _p(o), 1 if reset else 0))
-        return dict(zip(("fast", "declined_enum", "search_too_large", "certificate_arith", "too_many_tight", "not_unique", "not_attempted", "empty",
+        d = dict(zip(("fast", "declined_enum", "search_too_large", "certificate_arith", "too_many_tight", "not_unique", "not_attempted", "empty",
                          "cycles_enumerate", "cycles_init", "cycles_search", "cycles_certificate", "searches", "column_scans",
                          "declined_column_list_full", "declined_pair_list_full", "cycles_enum_bucket_rows", "cycles_enum_candidates",
                          "cycles_enum_list", "lane0_candidates", "lane0_pairs_evaluated", "declined_nonfinite", "declined_viable_disjoint",
                          "declined_threshold_tie", "cycles_search_fetch", "cycles_search_deliver", "cycles_search_pick", "cycles_search_augment",
                          "search_retries", "cycles_kernel", "wall_ticks_kernel_100MHz", "cycles_prologue"),
                         (int(v) for v in o[:32])))
+        d["short_searches"] = d["search_retries"] >> 32  # searches finished by one lane each (lap_sparse.hpp::sparse_short_searches; the wide kernel counts them)
+        d["search_retries"] &= 0xffffffff
+        return d
 
     def lap_geom(self, a, b, thresh, cost_mode=COST_IOU_DIST, conf=None, lap_mode=LAP_PLAIN, gate=0.0, prof=False):
         """Assignment straight from boxes (on-the-fly IoU-family cost inside the solver; no matrix in memory)."""

@@ -30,6 +30,7 @@
 // afterwards) is "hot" and sits in LDS when the problem fits; the per-column staging lists of the enumeration, the free list
 // and the certificate's arc list are "cold" (global scratch, streamed).
 #pragma once
+#include <type_traits>
 #include "cost_math.hpp"
 #include "grp.hpp"
 #include "lap_core.hpp"
@@ -593,6 +594,134 @@ MOT_DEV int sparse_init(G& g, const W& w, int nr, int nc, float thresh) {
   return nfree;
 }
 
+// 2b. (round 6) The SHORT searches, one LANE each. A free column j0 lost its best row r1 to column k (that is what "free" means after the
+// proposals); nearly every search then ends within two steps of the shortest-path search: j0 takes another row that is free, or stays unmatched,
+// or k moves to a free row of its own (or becomes unmatched) and j0 takes r1. The wavefront-wide search below spends ~9 k cycles on such a
+// search (compare-and-swap claims, five cross-lane pushes, a lexicographic DPP minimum and a barrier per step): a third of the kernel at the
+// north-star shape. Here every lane runs the first two steps of the SAME search for its own free column over the pairs of j0 and of k — same
+// labels, same picks (nearest, ties to the lowest row), same dual updates — claiming every row it reads with a compare-and-swap on its slot
+// word exactly as the concurrent searches do, and gives everything back untouched when a row belongs to somebody else or the search would need
+// a third step; those columns stay on the free list for the search below. Whatever happens here, the certificate checks the final matching
+// and duals (optimality and uniqueness), not how they were found. Returns the number of columns left on the list.
+constexpr int kSpShortDeg = 8;  // pairs per column the short searches handle (a column with more is left to the wavefront's search)
+template <class G, class W>
+MOT_DEV int sparse_short_searches(G& g, const W& w, int nfree, float thresh) {
+  if constexpr (std::remove_cv_t<std::remove_reference_t<decltype(w.u)>>::kSpace == kMemGlobal) return nfree;  // (state in global scratch: lanes of different wavefronts would need fences; rare, large problems)
+  const int T = g.size(), t = g.tid();
+  const double th = static_cast<double>(thresh);
+  const int mytag = 0x40000000 | (t << 8) | 0xfe;
+  constexpr int KD = kSpShortDeg;
+  int nleft = 0;
+  for (int f0 = 0; f0 < nfree; f0 += T) {
+    const int f = f0 + t;
+    const bool have = f < nfree;
+    const int j0 = have ? static_cast<int>(w.freel[f]) : 0;
+    bool done = false;
+    if (have) {
+      // Every dependent LDS round trip is taken ONCE for all pairs of a column (rows, then claims, then costs and duals): a lane's search is a
+      // chain of about ten round trips instead of three per pair.
+      const double v0 = w.v[j0];
+      const int ee = w.eoff[j0], a0 = sp_e0(ee), na = sp_deg(ee);
+      bool ok = na <= KD;
+      int ra[KD];
+      bool mine_a[KD];
+      double la[KD];
+#pragma unroll
+      for (int i = 0; i < KD; ++i) { ra[i] = (ok && i < na) ? static_cast<int>(w.erow[a0 + i]) : -1; mine_a[i] = false; la[i] = 1e300; }
+#pragma unroll
+      for (int i = 0; i < KD; ++i)
+        if (ra[i] >= 0) { const int old = w.slot.atomic_cas(ra[i], 0, mytag); mine_a[i] = old == 0; ok = ok && old == 0; }
+      double d1 = 1e300, d2 = 1e300;
+      int r1 = kNoIdx, r2 = kNoIdx;
+      if (ok) {
+#pragma unroll
+        for (int i = 0; i < KD; ++i)
+          if (ra[i] >= 0) la[i] = (static_cast<double>(static_cast<float>(w.ecost[a0 + i])) - th) - static_cast<double>(w.u[ra[i]]) - v0;
+#pragma unroll
+        for (int i = 0; i < KD; ++i)
+          if (ra[i] >= 0) {
+            const double nd = la[i];
+            const int r = ra[i];
+            if (nd < d1 || (nd == d1 && r < r1)) { d2 = d1; r2 = r1; d1 = nd; r1 = r; }
+            else if (nd < d2 || (nd == d2 && r < r2)) { d2 = nd; r2 = r; }
+          }
+      }
+      double L = -v0;          // leave j0 unmatched
+      int term_row = -1, term_col = j0, term_pred = j0;
+      int kcol = -1;
+      bool scanned = false;
+      int rb[KD];
+      bool mine_b[KD];
+#pragma unroll
+      for (int i = 0; i < KD; ++i) { rb[i] = -1; mine_b[i] = false; }
+      if (ok && r1 != kNoIdx && d1 < L) {
+        const int x1 = w.x[r1];
+        if (x1 < 0) { L = d1; term_row = r1; term_col = -1; term_pred = j0; }
+        else {
+          // r1 is scanned: its column k joins the tree
+          kcol = x1;
+          scanned = true;
+          const double D = d1;
+          const double vk = w.v[kcol];
+          const double cand = D - vk;
+          if (cand < L) { L = cand; term_row = -1; term_col = kcol; }
+          // step 2: relax k's pairs; the nearest unscanned row over j0's other rows and k's rows
+          const int ek = w.eoff[kcol], b0 = sp_e0(ek), nb = sp_deg(ek);
+          ok = nb <= KD;
+#pragma unroll
+          for (int i = 0; i < KD; ++i) { rb[i] = (ok && i < nb) ? static_cast<int>(w.erow[b0 + i]) : -1; if (rb[i] == r1) rb[i] = -1; }
+#pragma unroll
+          for (int i = 0; i < KD; ++i)
+            if (rb[i] >= 0) { const int old = w.slot.atomic_cas(rb[i], 0, mytag); mine_b[i] = old == 0; ok = ok && (old == 0 || old == mytag); }
+          double bd = d2;
+          int brow = r2, bpred = j0;
+          if (ok) {
+            double lb[KD];
+#pragma unroll
+            for (int i = 0; i < KD; ++i)
+              lb[i] = (rb[i] >= 0) ? D + ((static_cast<double>(static_cast<float>(w.ecost[b0 + i])) - th) - static_cast<double>(w.u[rb[i]]) - vk) : 1e300;
+#pragma unroll
+            for (int i = 0; i < KD; ++i)
+              if (rb[i] >= 0) {
+                double nd = lb[i];
+                int pred = kcol;
+#pragma unroll
+                for (int q = 0; q < KD; ++q)  // also a row of j0: the label it already has stays unless this one is smaller
+                  if (ra[q] == rb[i] && !(nd < la[q])) { nd = la[q]; pred = j0; }
+                if (nd < bd || (nd == bd && rb[i] < brow)) { bd = nd; brow = rb[i]; bpred = pred; }
+              }
+            if (brow != kNoIdx && bd < L) {
+              if (static_cast<int>(w.x[brow]) < 0) { L = bd; term_row = brow; term_col = -1; term_pred = bpred; }
+              else ok = false;  // a third step: the wavefront's search takes this column
+            }
+          }
+        }
+      }
+      if (ok) {
+        // duals: the scanned row and its column move by (L - label), the source by L (as the search below)
+        if (scanned) { const double dl = L - d1; w.u[r1] -= dl; w.v[kcol] += dl; }
+        w.v[j0] += L;
+        if (term_row >= 0) {
+          if (term_pred == j0) { w.y[j0] = term_row; w.x[term_row] = j0; }
+          else { w.y[kcol] = term_row; w.x[term_row] = kcol; w.y[j0] = r1; w.x[r1] = j0; }
+        } else if (term_col != j0) { w.y[kcol] = -1; w.y[j0] = r1; w.x[r1] = j0; }
+        done = true;
+      }
+#pragma unroll
+      for (int i = 0; i < KD; ++i) {
+        if (mine_a[i]) w.slot[ra[i]] = 0;
+        if (mine_b[i]) w.slot[rb[i]] = 0;
+      }
+    }
+    int tot;
+    const int pos = g.flag_rank(have && !done, &tot);
+    if (have && !done) w.freel[nleft + pos] = j0;  // (in place: nleft + pos <= f, and the entries of later chunks lie behind this chunk)
+    nleft += tot;
+  }
+  g.sync();
+  return nleft;
+}
+
 // 3. a shortest augmenting path per remaining column. The group may be a single wavefront of a larger workgroup (the searches
 // are serial; their reductions then stay inside the wavefront). Returns 1, or -2 when a search reached too many rows.
 // The rows a search has reached live in the lanes' registers — lane q is slot q: row, label, the column it was reached from,
@@ -868,7 +997,8 @@ MOT_DEV int sparse_certify(G& g, const W& w, int nr, int nc, float thresh) {
 template <class G, class W>
 MOT_DEV int sparse_solve(G& g, const W& w, int nr, int nc, float thresh, SparseProf* prof = nullptr) {
   const long long pc0 = MOT_CLOCK();
-  const int nfree = sparse_init(g, w, nr, nc, thresh);
+  int nfree = sparse_init(g, w, nr, nc, thresh);
+  nfree = sparse_short_searches(g, w, nfree, thresh);
   const long long pc1 = MOT_CLOCK();
   int scans = 0;
   const int rs = sparse_search(g, w, nfree, thresh, &scans);

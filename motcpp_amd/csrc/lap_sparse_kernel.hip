@@ -150,7 +150,9 @@ __global__ void __launch_bounds__(kThreads) lap_sparse_kernel(const mot_lap_task
       int r;
       if constexpr (kThreads == 64) r = mot::sparse_solve(g, w, nr, nc, T.thresh, &pf);
       else {
-        const int nfree = mot::sparse_init(g, w, nr, nc, T.thresh);
+        const int nfree0 = mot::sparse_init(g, w, nr, nc, T.thresh);
+        const int nfree = mot::sparse_short_searches(g, w, nfree0, T.thresh);
+        if (t == 0) atomicAdd(hist_set() + 28, static_cast<unsigned long long>(nfree0 - nfree) << 32);  // (high half of [28]: searches finished by the lanes' short form)
         const long long ck2 = MOT_CLOCK();
         // the path searches: every wavefront takes every fourth free column (lap_sparse.hpp, SHARED); the few that ran into each other's
         // rows are then redone by the first wavefront alone

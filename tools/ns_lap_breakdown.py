@@ -39,6 +39,8 @@ prob = (fs["fast"] + fs["not_unique"]) // (3 if os.environ.get("MOT_SP_WIDE_ONLY
 out = {"streams": S, "frames": n, "lap1_ms_per_launch": ps["lap1_ms"] / n, "lap23_ms_per_launch": ps["lap23_ms"] / n, "frame_ms": ps["frame_ms"] / n,
        "problems": prob, "wall_us_per_problem_in_kernel": fs["wall_ticks_kernel_100MHz"] / max(prob, 1) / 100.0,
        "effective_GHz": fs["cycles_kernel"] / max(fs["wall_ticks_kernel_100MHz"], 1) / 10.0, "cycles_per_problem": {k: fs[k] / max(prob, 1) for k in fs if k.startswith("cycles")},
+       "searches_per_problem": fs["searches"] / max(prob, 1), "short_searches_per_problem": fs["short_searches"] / max(prob, 1), "retries_per_problem": fs["search_retries"] / max(prob, 1),
+       "column_scans_per_problem": fs["column_scans"] / max(prob, 1),
        "lap1_mean_n_m": (ps["lap1_nm"] / max(ps["lap1_problems"], 1)), "lap23_mean_n_m": (ps["lap23_nm"] / max(ps["lap23_problems"], 1))}
 print(json.dumps(out, indent=1))
 if os.environ.get("MOT_SP_TIMELINE"):  # residence of the last first-association launch's workgroups (diagnostics)

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <functional>
 #include <map>
+#include <unordered_map>
 #include <mutex>
 #include <stdexcept>
 #include <thread>
@@ -165,10 +166,20 @@ class HostRounds {
   void lead(uint64_t r, bool idle) {
     using clk = std::chrono::steady_clock;
     const int p = static_cast<int>(r & 1);
-    const int expected = (last_batch_ > prev_batch_) ? last_batch_ : prev_batch_;
+    // callers to expect: the trackers that took part in one of the last two rounds (as the pooled segments do, host/pool.cpp: "the larger of the
+    // last two batches" let a population that once split into two alternating groups stay split — every camera then waited for two frames' worth
+    // of flushes per update(): DeepOC-SORT on 64 threads had a median of 5.3 ms against 2.5 ms for the same 64 streams in one batch)
+    int expected = 0;
+    for (const auto& kv : seen_) expected += (kv.second + 2 > r) ? 1 : 0;
     if (idle && window_us_ > 0 && joined_[p].load(std::memory_order_acquire) < expected) {
       const auto t_a = clk::now();
-      const auto hard = t_a + std::chrono::microseconds(window_us_ + (expected < 20 ? 2 * expected : 40));
+      // The window scales with what a round costs here: these trackers' frames are three to five flushes, 1-3 ms with 64 cameras — a caller that
+      // misses the round waits that long for the next one, so waiting a tenth of it for the cameras of the last two rounds is cheap (the fixed
+      // 100 us / 20 us of the pooled segments, whose rounds are a fraction of a millisecond, closed on the first scheduling hiccup of 64 threads on 16 CPUs)
+      const long scaled = last_round_us_ / 10;
+      const long hard_us = window_us_ + (expected < 20 ? 2 * expected : 40) + (scaled > 0 ? scaled : 0);
+      const long gap_us = 20 + (scaled > 0 ? scaled / 4 : 0);
+      const auto hard = t_a + std::chrono::microseconds(hard_us);
       int seen = joined_[p].load(std::memory_order_acquire);
       auto last_arrival = t_a;
       for (;;) {
@@ -177,7 +188,7 @@ class HostRounds {
         const int j = joined_[p].load(std::memory_order_acquire);
         if (j >= expected || now >= hard) break;
         if (j != seen) { seen = j; last_arrival = now; }
-        else if (now - last_arrival >= std::chrono::microseconds(20)) break;
+        else if (now - last_arrival >= std::chrono::microseconds(gap_us)) break;
       }
     }
     //  from here on the round completes on every way out of this function — a vector that cannot grow, a worker team that cannot
@@ -217,11 +228,14 @@ class HostRounds {
         }
       }
       // every camera's failure is its own: the others finish their frame and get their rows (run_frame's `errors` mode)
+      const auto t_run = clk::now();
       run_frame(*dev_, st.data(), in.data(), static_cast<int>(st.size()), (st.size() >= 16) ? team_.get() : nullptr, errs.data());
       for (size_t i = 0; i < reqs.size(); ++i)
         if (!errs[i].empty()) reqs[i]->error = std::move(errs[i]);
-      prev_batch_ = last_batch_;
-      last_batch_ = static_cast<int>(reqs.size());
+      last_round_us_ = static_cast<long>(std::chrono::duration<double, std::micro>(clk::now() - t_run).count());
+      for (Req* q : reqs) seen_[q->s] = r + 1;
+      if ((r & 1023) == 1023)  // trackers that went away long ago
+        for (auto it = seen_.begin(); it != seen_.end();) it = (it->second + 64 < r) ? seen_.erase(it) : std::next(it);
     } catch (const std::exception& e) {
       publish.failed = true;
       try { publish.err = e.what(); } catch (...) {}
@@ -236,7 +250,8 @@ class HostRounds {
   std::atomic<uint64_t> completed_{0};
   std::atomic<uint32_t> word_[2] = {{0}, {0}};
   std::atomic<int> joined_[2] = {{0}, {0}};
-  int last_batch_ = 0, prev_batch_ = 0;
+  long last_round_us_ = 0;
+  std::unordered_map<Staged*, uint64_t> seen_;  // 1 + the last round a tracker took part in (leader only)
   long window_us_ = 60;
   std::unique_ptr<Team> team_;
   bool team_failed_ = false;

@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0,
                     help="split a rank's streams into this many sub-batches with their own HIP stream, stepped concurrently so one's host lifecycle overlaps another's kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-outputs-resident", action="store_true", help="skip the tables-stay-in-HBM leg behind the timed region (profiling runs whose last launches "
+                    "should be the timed ones: tools/last_launches_avg.py)")
     ap.add_argument("--parity-streams", type=int, default=None,
                     help="streams of rank 0 (seeded sample over all sub-batches, stream 0 among them) whose outputs are compared with the oracle "
                          "(default 32; C3: 8, C4: 4 - the oracle runs 17 / 0.2 frames/s there)")
@@ -655,7 +657,7 @@ def main():
                             "solver declined (a non-unique optimum), which the whole sub-batch waits for"}
     # ---- outputs_resident: the same frames with the tables LEFT on the device (a consumer on the GPU / the RCCL gather reads them there) ----
     outputs_resident = None
-    if in_flight and on_device and world == 1 and not heavy and F - Z >= 8:
+    if in_flight and on_device and world == 1 and not heavy and F - Z >= 8 and not args.no_outputs_resident:
         nres = min(60, LR if LR > 0 else 60)
         # the same back-and-forth playback as long_run, continued from the frame the trackers stand at. (Round 4 played the frames Z, Z+1, ..., F-1,
         # Z, ... here: every wrap-around teleported all objects - a frame of births, lost tracks and declined assignments - and the leg
@@ -818,9 +820,10 @@ def main():
         # reports as the kernel's average (profiles/r04*_kernel_stats_*.csv: 299.9 us against 298.6 us here for lap_sparse_kernel at NS)
         avg_ms = isolated[fam]["avg_launch_ms"]
         duration_source = ("HIP events around the kernel's launches, sub-batches stepped one at a time right after the timed region (same trackers, full "
-                           "sub-batches): the kernel's own begin-to-end time. rocprofv3 --kernel-trace --stats shows the same average only for a command "
-                           "whose launches are all of this size (--sweep-streams '' --long-run-steps 0 --host-input-steps 0 --isolated-steps 0 --no-cpu-baseline: "
-                           "profiles/*_kernel_stats_*_timed_only.csv); the default command's table also averages the stream sweep's smaller launches")
+                           "sub-batches): the kernel's own begin-to-end time. rocprofv3's --stats average of this command mixes launch sizes (stream sweep) and "
+                           "time-shared launches (three sub-batches); the like-for-like check is a one-sub-batch command whose last launches are the timed "
+                           "ones (--streams 6144 --pipeline 1 --no-outputs-resident, no other legs): events 692 us against 687 us for the same 20 launches in "
+                           "rocprofv3's trace (profiles/r06b_NS_one_subbatch_last20.txt, tools/last_launches_avg.py)")
     bytes_per_launch = st["bytes"] / launches
     if fam == "cosine" and st["flops"] > 0:
         achieved = st["flops"] / launches / (avg_ms * 1e-3) / 1e12

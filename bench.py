@@ -100,6 +100,8 @@ def launch_probe(real_stdout):
     dist.destroy_process_group()
 
 
+KF_BT_UPDATE_B = 2 * (32.0 + 64.0) + 16.0 + 8.0 + 2.0  # ByteTrack's device lifecycle: mean + covariance blocks in and out, measurement, indices, flags
+KF_BT_BIRTH_B = 32.0 + 64.0 + 16.0 + 1.0
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
 try:
     from kernel_sources_hash import kernel_sources_hash
@@ -512,8 +514,9 @@ def main():
                     # (round 5: the predicted boxes of the pool are computed inside bt_begin — no launch of their own any more; the item count stays for the byte model)
                     ps["kf_predict_boxes"] = {"ms": 0.0, "launches": fr, "tasks": kf["predict_boxes_items"], "bytes": 52.0 * kf["predict_boxes_items"], "flops": 0.0}
                     ps["kf_initiate"] = {"ms": 0.0,  # (round 5: written by bt_after_second, no launch of its own)
-                                         "launches": fr, "tasks": kf["initiate_items"], "bytes": 312.0 * kf["initiate_items"], "flops": 0.0}
-                    ps["kf_update"] = {"ms": kf["update_ms"], "launches": fr, "tasks": kf["update_items"], "bytes": 604.0 * kf["update_items"], "flops": 0.0}
+                                         "launches": fr, "tasks": kf["initiate_items"], "bytes": KF_BT_BIRTH_B * kf["initiate_items"], "flops": 0.0}
+                    # (round 6: block-form covariances — 32 B of mean + 64 B of blocks in and out, the measurement, two indices, two flag bytes)
+                    ps["kf_update"] = {"ms": kf["update_ms"], "launches": fr, "tasks": kf["update_items"], "bytes": KF_BT_UPDATE_B * kf["update_items"], "flops": 0.0}
             for k, v in ps.items():
                 a = acc.setdefault(k, {"ms": 0.0, "launches": 0, "tasks": 0, "bytes": 0.0, "flops": 0.0})
                 for kk in a:
@@ -878,18 +881,19 @@ def main():
                                     "frac": value / world * survey_bytes / 1e9 / HBM_PEAK_GBS,
                                     "note": "whole-job frames/s x SURVEY 8(d) bytes per frame (cost matrix materialised); not a kernel measurement"}
     # The fused pipeline's own byte model: what a frame HAS to move when no cost matrix is materialised —
-    # detections in (24 B each), box-only prediction of the pool (52 B per track), one Kalman record read + written per match (604 B),
-    # 24 B per row and column of every assignment (boxes + score in, x / y out), 312 B per birth, 32 B per output row.
+    # detections in (24 B each), box-only prediction of the pool (52 B per track), one Kalman state read + written per match (round 6: 218 B — the
+    # covariance in block form, 64 B, next to 32 B of mean; 604 B with 288-byte records), 24 B per row and column of every assignment (boxes + score in,
+    # x / y out), 113 B per birth, 32 B per output row.
     if on_device and tracker == "bytetrack" and achieved_dims:
         fa, sa = achieved_dims["first_association"], achieved_dims["second_and_unconfirmed"]
         nfr = max(fa["problems"], 1)
         kfs = {k: stats[k]["tasks"] / nfr for k in ("kf_predict_boxes", "kf_initiate", "kf_update") if k in stats}
         lap_b = 24.0 * (fa["mean_tracks_N"] + fa["mean_dets_M"]) + 24.0 * (sa["mean_tracks_N"] + sa["mean_dets_M"]) * sa["problems"] / nfr
         rows_out = float(np.mean(cnt_all)) if len(cnt_all) else 0.0
-        fb = 24.0 * M + 52.0 * kfs.get("kf_predict_boxes", 0.0) + 604.0 * kfs.get("kf_update", 0.0) + 312.0 * kfs.get("kf_initiate", 0.0) + lap_b + 32.0 * rows_out
+        fb = 24.0 * M + 52.0 * kfs.get("kf_predict_boxes", 0.0) + KF_BT_UPDATE_B * kfs.get("kf_update", 0.0) + KF_BT_BIRTH_B * kfs.get("kf_initiate", 0.0) + lap_b + 32.0 * rows_out
         roof["fused_frame_model"] = {"bytes_per_frame": fb, "GB/s_per_gpu": value / world * fb / 1e9, "frac": value / world * fb / 1e9 / HBM_PEAK_GBS,
-                                     "terms": {"detections": 24.0 * M, "predict_boxes": 52.0 * kfs.get("kf_predict_boxes", 0.0), "kalman_updates": 604.0 * kfs.get("kf_update", 0.0),
-                                               "kalman_initiations": 312.0 * kfs.get("kf_initiate", 0.0), "assignments": lap_b, "output_rows": 32.0 * rows_out},
+                                     "terms": {"detections": 24.0 * M, "predict_boxes": 52.0 * kfs.get("kf_predict_boxes", 0.0), "kalman_updates": KF_BT_UPDATE_B * kfs.get("kf_update", 0.0),
+                                               "kalman_initiations": KF_BT_BIRTH_B * kfs.get("kf_initiate", 0.0), "assignments": lap_b, "output_rows": 32.0 * rows_out},
                                      "note": "whole-job frames/s x the bytes a frame of the fused pipeline must move (no N x M matrix exists); the path is "
                                              "latency / issue-bound, not bandwidth-bound, and this fraction says by how much"}
     import glob

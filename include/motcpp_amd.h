@@ -127,6 +127,16 @@ typedef struct mot_kf_task {
   const float* conf;         /* optional, MOT_KF_XYAH update: detection confidences, indexed like `meas` — the NSA Kalman rule of
                                 BaseKalmanFilter::project, R = ((1 - conf) * std)^2 (src/motion/kalman_filter.cpp:60-75; StrongSORT's
                                 Track::update passes the detection's confidence, strongsort.cpp:153). NULL: confidence 0 */
+  float* mean_dense;         /* optional (mot_kf_update, 8-state filters): the means live in a dense array of their own, [cap][8] floats, and `mean` then
+                                points at covariance-only records of 64 floats per slot (256 bytes on a 256-byte boundary). The device lifecycles
+                                read boxes (the mean, of every track, several times per frame) from the dense array: one 64-byte line serves two
+                                tracks, where a record's mean is 32 bytes of a 288-byte stride. NULL: records of 8 + 64 floats, the mean first */
+  float* cov_blocks;         /* ByteTrack's device lifecycle (internal: mot::launch_kf_update_blocks): the covariance of a track whose state was
+                                initiated and only ever predicted / updated by these filters is four 2 x 2 blocks — component c couples with its
+                                velocity c + 4 and with nothing else; every other entry is an exact zero, the innovation covariance is diagonal —
+                                stored as [cap][4][4] floats {P(c,c), P(c,c+4), P(c+4,c), P(c+4,c+4)}: 64 bytes instead of 256 */
+  unsigned char* dense_flag; /* [cap] 1: the track left the block form (a non-positive or non-finite innovation variance, a non-finite input: the
+                                dense arithmetic then spreads NaN / inf over the structural zeros) and lives in its 64-float record from then on */
 } mot_kf_task;
 int mot_kf_dim(int kf_kind);
 int mot_kf_initiate(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);
@@ -677,6 +687,12 @@ int mot_kf_apply_host(mot_ctx* ctx, int kf_kind, int op, int n, const float* mea
                       const unsigned char* flags_or_null, float* mean, float* cov, float* boxes4_or_null);
 /* mot_kf_warp on AoS host states; predict_first != 0: mot_kf_predict_warp instead (predict, then warp, one launch) */
 /* mot_kf_update for host arrays with per-measurement confidences (NSA Kalman; XYAH only, conf NULL = 0) */
+/* The XYAH update on block-form covariances (mot_kf_task.cov_blocks; ByteTrack's device lifecycle, kf_kernels.hip::kf_update_blocks_kernel): the same
+ * operations as KalmanFilterXYAH::update on the non-zero terms (src/motion/kalman_filter.cpp:77-112), 96 bytes per track instead of 576. Host
+ * convenience for tests: mean [n][8] and blocks [n][16] in/out, upd_flags [n] MOT_KF_* bits (or NULL), dense_flag [n] out, cov_dense [n][64] out
+ * (the 8 x 8 covariance of the tracks the block kernel handed to the dense one). */
+int mot_kf_update_blocks_host(mot_ctx* ctx, int n, const float* meas4, const unsigned char* upd_flags, float* mean, float* blocks,
+                              unsigned char* dense_flag, float* cov_dense);
 int mot_kf_update_conf_host(mot_ctx* ctx, int kf_kind, int n, const float* meas4, const float* conf_or_null, float* mean, float* cov);
 int mot_kf_warp_host(mot_ctx* ctx, int kf_kind, int n, const float* warp9, int predict_first, const float* q3_or_null,
                      float* mean, float* cov, float* boxes4_or_null);

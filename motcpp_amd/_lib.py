@@ -243,6 +243,17 @@ class Context:
         self._chk(self.lib.mot_kf_update_conf_host(self.h, KF_XYAH, mean.shape[0], _p(meas), _p(conf), _p(mean), _p(cov)))
         return mean, cov
 
+    def kf_update_blocks(self, mean, blocks, meas, flags=None):
+        """XYAH update on block-form covariances (mot_kf_update_blocks_host): returns (mean [n,8], blocks [n,4,4], dense_flag [n], cov_dense [n,8,8])"""
+        mean, blocks, meas = f32(mean).copy(), f32(blocks).reshape(-1, 16).copy(), f32(meas).reshape(-1, 4)
+        n = mean.shape[0]
+        fl = np.ascontiguousarray(flags, np.uint8) if flags is not None else None
+        dense = np.zeros(n, np.uint8)
+        cov = np.zeros((n, 64), np.float32)
+        self.lib.mot_kf_update_blocks_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.mot_kf_update_blocks_host(self.h, n, _p(meas), _p(fl) if fl is not None else None, _p(mean), _p(blocks), _p(dense), _p(cov)))
+        return mean, blocks.reshape(n, 4, 4), dense, cov.reshape(n, 8, 8)
+
     def kf_warp(self, kind, mean, cov, warp9, predict_first=False, q=None, want_boxes=False):
         """mot_kf_warp on AoS states (predict_first: one predict launch with the warp applied after it)."""
         mean, cov = f32(mean).copy(), f32(cov).copy()

@@ -62,7 +62,12 @@ struct BtStream {
   float* lbox;
   // round 5: the box passes of a frame (kf_kernel<XYAH, boxes> twice, <XYAH, predict + boxes> once) are folded into the list kernels: a box is
   // eight loads and six operations of a lane that has the slot in hand anyway, a launch is 5 us of a single camera's frame
-  const float* kmean;  // this stream's Kalman records (72 floats per slot: mean, covariance)
+  const float* kmean;  // this stream's dense-form covariances: 64 floats per slot, 256-byte records — only for the tracks that left the block form (kflag)
+  float* kblk;         // round 6: the covariances in block form, [slot][4][4] = {P(c,c), P(c,c+4), P(c+4,c), P(c+4,c+4)} (kf_kernels.hip: kf_update_blocks_kernel)
+  unsigned char* kflag;  // [slot] 1: the track's covariance lives in its 64-float record (it met a non-finite value or a non-positive innovation variance)
+  float* kdense;       // round 6: the MEANS, dense ([slot][8]): what the list kernels read boxes from and what the Kalman update reads and writes
+                       // (mot_kf_task.mean_dense) — a record's mean was 32 B of a 288-byte stride, a 64-byte line fetched for every track three or four
+                       // times per frame (bt_begin and bt_dups moved 100 KB per stream that way); the record keeps the covariance
   float *pool_box, *rbox, *ubox;  // [4][CAP] predicted boxes of the pool / stored boxes of the second association's tracks / of the unconfirmed ones
 };
 
@@ -71,13 +76,13 @@ __device__ __forceinline__ float4 xyah_box4(float cx, float cy, float a, float h
   const float w = a * h;
   return make_float4(cx - w * 0.5f, cy - h * 0.5f, cx + w * 0.5f, cy + h * 0.5f);
 }
-__device__ __forceinline__ float4 stored_box(const float* kmean, int slot) {
-  const float4 m = *reinterpret_cast<const float4*>(kmean + static_cast<size_t>(slot) * 72);
+__device__ __forceinline__ float4 stored_box(const float* kdense, int slot) {
+  const float4 m = *reinterpret_cast<const float4*>(kdense + static_cast<size_t>(slot) * 8);
   return xyah_box4(m.x, m.y, m.z, m.w);
 }
 // the box of the PREDICTED state, nothing stored (kf_kernel<XYAH, OP_PREDICT_BOXES>): x' = F x touches the mean only
-__device__ __forceinline__ float4 predicted_box(const float* kmean, int slot, bool zero_v7) {
-  const float4* mp = reinterpret_cast<const float4*>(kmean + static_cast<size_t>(slot) * 72);
+__device__ __forceinline__ float4 predicted_box(const float* kdense, int slot, bool zero_v7) {
+  const float4* mp = reinterpret_cast<const float4*>(kdense + static_cast<size_t>(slot) * 8);
   const float4 a = mp[0];
   float4 v = mp[1];
   if (zero_v7) v.w = 0.0f;
@@ -188,9 +193,9 @@ __global__ void __launch_bounds__(kAFMax) bt_begin(BtStream* streams, BtParams P
     // only the predicted BOXES are needed now; a matched track is re-predicted inside its update (MOT_KF_PREDICT_FIRST)
     const bool zero_v7 = S.t_state[slot] != Tracked;
     S.pred_flags[i] = (zero_v7 ? MOT_KF_ZERO_V7 : 0) | MOT_KF_NO_STORE;
-    store_box(S.pool_box, CAP, i, predicted_box(S.kmean, slot, zero_v7));
+    store_box(S.pool_box, CAP, i, predicted_box(S.kdense, slot, zero_v7));
   }
-  for (int i = t; i < nu; i += static_cast<int>(blockDim.x)) store_box(S.ubox, CAP, i, stored_box(S.kmean, S.unconf_slot[i]));  // (third association)
+  for (int i = t; i < nu; i += static_cast<int>(blockDim.x)) store_box(S.ubox, CAP, i, stored_box(S.kdense, S.unconf_slot[i]));  // (third association)
   if (t == 0) {
     S.n_high = nh; S.n_second = ns; S.n_pool = np; S.n_tracked = n_tracked; S.n_unconf = nu;
     S.n_upd = 0; S.n_refind = 0; S.n_utrack = 0; S.n_udet = 0; S.n_r = 0; S.n_init = 0; S.n_lost_new = 0; S.lap2_q = 0; S.lap3_q = 0;
@@ -275,7 +280,7 @@ __global__ void __launch_bounds__(kAFMax) bt_after_first(BtStream* streams, BtPa
       const int slot = (k < n_ut) ? S.pool_slot[i] : 0;
       const bool r = k < n_ut && i < S.n_tracked && S.t_state[slot] == Tracked;
       const Compact3 c = compact3_block(r, false, false, n_r, z1, z2, cnt);
-      if (r) { S.r_slot[c.pos[0]] = slot; S.r_pool[c.pos[0]] = i; store_box(S.rbox, CAP, c.pos[0], stored_box(S.kmean, slot)); }
+      if (r) { S.r_slot[c.pos[0]] = slot; S.r_pool[c.pos[0]] = i; store_box(S.rbox, CAP, c.pos[0], stored_box(S.kdense, slot)); }
     }
   }
   for (int k = t; k < n_ud; k += static_cast<int>(blockDim.x)) S.rem[k] = S.high[S.u_det[k]];
@@ -309,7 +314,7 @@ __global__ void __launch_bounds__(kAFMax) bt_after_first(BtStream* streams, BtPa
 
 // ---- K2: apply associations 2 and 3, births, deaths, list algebra, queue the Kalman work (:442-580) ----
 __global__ void __launch_bounds__(kAFMax) bt_after_second(BtStream* streams, BtParams P, int CAP, mot_kf_task* init_t, mot_kf_task* upd_t,
-                                                       mot_kf_task* box2_t, mot_iou_task* dup_t, unsigned long long* stats) {
+                                                       mot_kf_task* box2_t, mot_iou_task* dup_t, unsigned long long* stats, mot_kf_task* updf_t) {
   // Four wavefronts per stream. The first part (second association, unconfirmed tracks, births) walks lists of a few dozen entries and
   // hands out slots in order: the first wavefront does it alone; the list algebra over the ~800 active tracks is shared by all four.
   __shared__ int cnt[kAFMax / 64][3];
@@ -318,7 +323,7 @@ __global__ void __launch_bounds__(kAFMax) bt_after_second(BtStream* streams, BtP
   const int t = static_cast<int>(threadIdx.x);
   if (S.skip) {
     if (t == 0) {
-      init_t[blockIdx.x].n = 0; upd_t[blockIdx.x].n = 0;
+      init_t[blockIdx.x].n = 0; upd_t[blockIdx.x].n = 0; updf_t[blockIdx.x].n = 0;
       box2_t[2 * blockIdx.x + 0].n = 0; box2_t[2 * blockIdx.x + 1].n = 0;
       dup_t[blockIdx.x].n = 0; dup_t[blockIdx.x].m = 0;
     }
@@ -458,15 +463,14 @@ __global__ void __launch_bounds__(kAFMax) bt_after_second(BtStream* streams, BtP
 #pragma unroll
     for (int q = 0; q < 8; ++q) sd[q] = (q < 4) ? 2.0f * kWp * h : 10.0f * kWv * h;
     sd[2] = 1e-2f; sd[6] = 1e-5f;
-    float4* rec = reinterpret_cast<float4*>(const_cast<float*>(S.kmean) + static_cast<size_t>(slot) * 72);
-    rec[0] = make_float4(z0, z1, z2, h);
-    rec[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4* dn = reinterpret_cast<float4*>(S.kdense + static_cast<size_t>(slot) * 8);
+    dn[0] = make_float4(z0, z1, z2, h);
+    dn[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // P = diag(sd^2) in block form: block c = {sd_c^2, 0, 0, sd_(c+4)^2}
+    float4* blk = reinterpret_cast<float4*>(S.kblk + static_cast<size_t>(slot) * 16);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float d = sd[r] * sd[r];
-      rec[2 + 2 * r] = make_float4(r == 0 ? d : 0.0f, r == 1 ? d : 0.0f, r == 2 ? d : 0.0f, r == 3 ? d : 0.0f);
-      rec[3 + 2 * r] = make_float4(r == 4 ? d : 0.0f, r == 5 ? d : 0.0f, r == 6 ? d : 0.0f, r == 7 ? d : 0.0f);
-    }
+    for (int c = 0; c < 4; ++c) blk[c] = make_float4(sd[c] * sd[c], 0.0f, 0.0f, sd[c + 4] * sd[c + 4]);
+    S.kflag[slot] = 0;
   }
   if (n_na + n_init + n_refind > CAP) err = 1;
   else {
@@ -500,6 +504,7 @@ __global__ void __launch_bounds__(kAFMax) bt_after_second(BtStream* streams, BtP
     if (err) S.err = 1;
     init_t[blockIdx.x].n = n_init;
     upd_t[blockIdx.x].n = n_upd;
+    updf_t[blockIdx.x].n = 0;  // (the dense-form updates of this frame: appended by kf_update_blocks_kernel)
     if (stats) {  // stats[6] / stats[7]: Kalman updates / initiations queued (profile leg: bytes moved by those launches)
       unsigned long long* st = stats + (blockIdx.x & 63) * 8;
       atomicAdd(&st[6], static_cast<unsigned long long>(n_upd)); atomicAdd(&st[7], static_cast<unsigned long long>(n_init));
@@ -541,13 +546,13 @@ __device__ __forceinline__ void bt_dups_body(BtStream& S, int CAP, int verify, i
   __shared__ int n_irr;
   if (MODE == 2 && staged) {
     for (int j = threadIdx.x; j < nl; j += T)
-      wl[j] = stored_box(S.kmean, lst[j]);
+      wl[j] = stored_box(S.kdense, lst[j]);
     __syncthreads();
   }
   if (MODE == 1 && staged) {
     if (threadIdx.x == 0) n_irr = 0;
     for (int j = threadIdx.x; j < nl; j += T)
-      wl[j] = stored_box(S.kmean, lst[j]);
+      wl[j] = stored_box(S.kdense, lst[j]);
     __syncthreads();
     // rank by (key, index) with key = x1, or -inf for a box with a non-finite coordinate: nl is a few hundred at most,
     // counting against the key array (one broadcast LDS read and three VALU operations per comparison) beats a sorting network
@@ -573,7 +578,7 @@ __device__ __forceinline__ void bt_dups_body(BtStream& S, int CAP, int verify, i
     __syncthreads();
   }
   for (int i = threadIdx.x; i < na; i += T) {
-    const float4 ab = stored_box(S.kmean, act[i]);
+    const float4 ab = stored_box(S.kdense, act[i]);
     const float a[4] = {ab.x, ab.y, ab.z, ab.w};
     const float area_a = (a[2] - a[0]) * (a[3] - a[1]);
     const int age_a = S.age_a[i];
@@ -581,7 +586,7 @@ __device__ __forceinline__ void bt_dups_body(BtStream& S, int CAP, int verify, i
     auto test = [&](int j, bool mark) {
       float4 bb;
       if (staged) bb = wl[j];
-      else bb = stored_box(S.kmean, lst[j]);
+      else bb = stored_box(S.kdense, lst[j]);
       const float iw = mot::smax(0.0f, mot::smin(a[2], bb.z) - mot::smax(a[0], bb.x));
       const float ih = mot::smax(0.0f, mot::smin(a[3], bb.w) - mot::smax(a[1], bb.y));
       const float inter = iw * ih;
@@ -660,7 +665,7 @@ __device__ __forceinline__ void bt_finish_body(BtStream& S, int CAP, float* out,
     if (emit) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) b[k] = 0.f;
-      const float4 ob = stored_box(S.kmean, slot);
+      const float4 ob = stored_box(S.kdense, slot);
       b[0] = ob.x; b[1] = ob.y; b[2] = ob.z; b[3] = ob.w;
       rid = static_cast<float>(S.t_id[slot]); rconf = S.t_conf[slot];
       rcls = static_cast<float>(S.t_cls[slot]); rdet = static_cast<float>(S.t_det[slot]);
@@ -741,7 +746,12 @@ struct mot_bt_batch {
   mot_kf_task *pred_t = nullptr, *box_t = nullptr, *init_t = nullptr, *upd_t = nullptr, *box2_t = nullptr;
   mot_lap_task *lap1_t = nullptr, *lap23_t = nullptr;
   mot_iou_task* dup_t = nullptr;
-  float* mean = nullptr;  // [S][CAP] records of 8 + 64 floats (mot_kf_task's slab)
+  float* mean = nullptr;  // [S][CAP] covariance records of 64 floats (mot_kf_task's slab when mean_dense is set)
+  float* mean_dense = nullptr;  // [S][CAP][8] the means (BtStream::kdense)
+  float* cov_blocks = nullptr;  // [S][CAP][16] block-form covariances (BtStream::kblk)
+  unsigned char* dense_flag = nullptr;  // [S][CAP]
+  mot_kf_task* updf_t = nullptr;  // the dense-form updates of a frame (tracks that left the block form), filled on the device
+  int* fb_i = nullptr; unsigned char* fb_f = nullptr;  // their lists: [S][3][CAP] slots / slots / measurement columns, [S][CAP] flags
   // profiling (bench.py's roofline leg): HIP events around the two assignment launches and the whole frame
   bool profile = false;
   unsigned long long* d_stats = nullptr;
@@ -792,7 +802,13 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   int* ip = b->dalloc<int>(ints_per * S);
   float* fp = b->dalloc<float>((static_cast<size_t>(CAP) * (1 + 4 * 5) + static_cast<size_t>(D) * 8) * S);
   unsigned char* bp = b->dalloc<unsigned char>(static_cast<size_t>(CAP) * 4 * S);
-  b->mean = b->dalloc<float>(static_cast<size_t>(S) * 72 * C2);
+  b->mean = b->dalloc<float>(static_cast<size_t>(S) * 64 * C2);  // (covariance records of 256 bytes; hipMalloc aligns to 256)
+  b->mean_dense = b->dalloc<float>(static_cast<size_t>(S) * 8 * C2);
+  b->cov_blocks = b->dalloc<float>(static_cast<size_t>(S) * 16 * C2);
+  b->dense_flag = b->dalloc<unsigned char>(static_cast<size_t>(S) * C2);
+  b->updf_t = b->dalloc<mot_kf_task>(S);
+  b->fb_i = b->dalloc<int>(static_cast<size_t>(S) * 3 * C2);
+  b->fb_f = b->dalloc<unsigned char>(static_cast<size_t>(S) * C2);
   b->d_streams = b->dalloc<BtStream>(S);
   b->d_counts = b->dalloc<int>(S);
   b->d_err = b->dalloc<int>(1);
@@ -811,14 +827,14 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   const size_t wb1 = (mot::lap_scratch_bytes(CAP, D) + 255) & ~size_t(255);
   char* work = b->dalloc<char>(wb1 * 3 * S);
   int* info = b->dalloc<int>(static_cast<size_t>(4) * 3 * S);
-  if (!ip || !fp || !bp || !b->mean || !b->d_streams || !b->d_counts || !b->d_err || !b->d_decl || !b->d_alive || !b->d_maxt || !b->det_t || !b->pred_t || !b->box_t ||
+  if (!ip || !fp || !bp || !b->mean || !b->mean_dense || !b->cov_blocks || !b->dense_flag || !b->updf_t || !b->fb_i || !b->fb_f || !b->d_streams || !b->d_counts || !b->d_err || !b->d_decl || !b->d_alive || !b->d_maxt || !b->det_t || !b->pred_t || !b->box_t ||
       !b->init_t || !b->upd_t || !b->box2_t || !b->lap1_t || !b->lap23_t || !b->dup_t || !work || !info) {
     mot_bt_destroy(b);
     return MOT_ERR_NOMEM;
   }
   std::vector<BtStream> hs(S);
   std::vector<mot_det_task> det(S);
-  std::vector<mot_kf_task> pred(S), box(2 * S), init(S), upd(S), box2(2 * S);
+  std::vector<mot_kf_task> pred(S), box(2 * S), init(S), upd(S), box2(2 * S), updf(S);
   std::vector<mot_lap_task> lap1(S), lap23(2 * S);
   std::vector<mot_iou_task> dup(S);
   for (int s = 0; s < S; ++s) {
@@ -841,9 +857,12 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
     float* d_box = F(4 * D); float* d_meas = F(4 * D);
     unsigned char* u = bp + static_cast<size_t>(CAP) * 4 * s;
     T.pred_flags = u; T.dup_a = u + CAP; T.dup_b = u + 2 * CAP; T.upd_flags = u + 3 * CAP;
-    float* mean = b->mean + static_cast<size_t>(s) * 72 * C2;
+    float* mean = b->mean + static_cast<size_t>(s) * 64 * C2;
     float* cov = mean + 8;
     T.kmean = mean;
+    T.kdense = b->mean_dense + static_cast<size_t>(s) * 8 * C2;
+    T.kblk = b->cov_blocks + static_cast<size_t>(s) * 16 * C2;
+    T.kflag = b->dense_flag + static_cast<size_t>(s) * C2;
     // ---- static parts of the task descriptors ----
     std::memset(&det[s], 0, sizeof(mot_det_task));
     det[s].box = d_box; det[s].ldb = D; det[s].meas = d_meas; det[s].ldm = D;
@@ -853,7 +872,9 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
     kf(box[2 * s + 1]); box[2 * s + 1].src = T.unconf_slot; box[2 * s + 1].boxes = ubox; box[2 * s + 1].ldb = CAP;
     kf(init[s]); init[s].src = T.init_dst; init[s].dst = T.init_dst; init[s].meas = d_meas; init[s].ldm = D; init[s].midx = T.init_meas;
     kf(upd[s]); upd[s].src = T.upd_src; upd[s].dst = T.upd_dst; upd[s].meas = d_meas; upd[s].ldm = D; upd[s].midx = T.upd_meas;
-    upd[s].flags = T.upd_flags;
+    upd[s].flags = T.upd_flags; upd[s].mean_dense = T.kdense; upd[s].cov_blocks = T.kblk; upd[s].dense_flag = T.kflag;
+    updf[s] = upd[s];  // the same filter on the 64-float records, over the lists the block-form kernel fills
+    { int* fi = b->fb_i + static_cast<size_t>(s) * 3 * C2; updf[s].src = fi; updf[s].dst = fi + C2; updf[s].midx = fi + 2 * C2; updf[s].flags = b->fb_f + static_cast<size_t>(s) * C2; updf[s].n = 0; }
     kf(box2[2 * s]); box2[2 * s].boxes = T.abox; box2[2 * s].ldb = CAP;
     kf(box2[2 * s + 1]); box2[2 * s + 1].boxes = lbox; box2[2 * s + 1].ldb = CAP;
     auto lap = [&](mot_lap_task& L, int k, int* x, int* y, const float* a, const int* bidx, const float* bconf, int mode, float thresh) {
@@ -879,7 +900,7 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   b->h_streams = hs;
   hipStream_t st = ctx->stream;
 #define BT_UP(dst, vec) MOT_LC_HIP(b, hipMemcpyAsync(dst, vec.data(), sizeof(vec[0]) * vec.size(), hipMemcpyHostToDevice, st))
-  BT_UP(b->d_streams, hs); BT_UP(b->det_t, det); BT_UP(b->pred_t, pred); BT_UP(b->box_t, box); BT_UP(b->init_t, init); BT_UP(b->upd_t, upd);
+  BT_UP(b->d_streams, hs); BT_UP(b->det_t, det); BT_UP(b->pred_t, pred); BT_UP(b->box_t, box); BT_UP(b->init_t, init); BT_UP(b->upd_t, upd); BT_UP(b->updf_t, updf);
   BT_UP(b->box2_t, box2); BT_UP(b->lap1_t, lap1); BT_UP(b->lap23_t, lap23); BT_UP(b->dup_t, dup);
 #undef BT_UP
   MOT_LC_HIP(b, hipMemsetAsync(b->d_err, 0, sizeof(int), st));
@@ -935,10 +956,10 @@ static int bt_enqueue_frame(mot_bt_batch* b, const float* d_dets, const int* h_c
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[3], st));
   MOT_LC_HIP(b, mot::launch_lap(b->lap23_t, 2 * S, bn, bd, true, false, true, st, b->hint23_n, b->hint23_m, true, nullptr, nullptr, b->d_decl + 1, 2 * active));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[4], st));
-  hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(bt_threads), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t, prof ? b->d_stats : nullptr);
+  hipLaunchKernelGGL(bt_after_second, dim3(S), dim3(bt_threads), 0, st, b->d_streams, b->prm, CAP, b->init_t, b->upd_t, b->box2_t, b->dup_t, prof ? b->d_stats : nullptr, b->updf_t);
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[7], st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[8], st));
-  MOT_LC_HIP(b, mot::launch_kf_op(2, MOT_KF_XYAH, b->upd_t, S, bn, st));
+  MOT_LC_HIP(b, mot::launch_kf_update_blocks(b->upd_t, b->updf_t, S, bn, st));
   if (prof) MOT_LC_HIP(b, hipEventRecord(ev[9], st));
   {
     static const int verify = std::getenv("MOT_BT_DUPS_VERIFY") != nullptr ? 1 : 0;  // tests: cross-check the sorted window
@@ -1136,7 +1157,7 @@ int mot_bt_reset_stream(mot_bt_batch* b, int s, int fresh) {
   return MOT_OK;
 }
 namespace {
-__global__ void __launch_bounds__(256) bt_move(const BtStream* from, BtStream* to, const float* mean_from, float* mean_to, int cap) {
+__global__ void __launch_bounds__(256) bt_move(const BtStream* from, BtStream* to, const float* mean_from, float* mean_to, const float* dense_from, float* dense_to, const float* blk_from, float* blk_to, const unsigned char* flag_from, unsigned char* flag_to, int cap) {
   using mot::lifecycle::move_array;
   const BtStream& A = *from;
   BtStream& B = *to;
@@ -1146,7 +1167,10 @@ __global__ void __launch_bounds__(256) bt_move(const BtStream* from, BtStream* t
   move_array(B.t_id, A.t_id, n); move_array(B.t_state, A.t_state, n); move_array(B.t_act, A.t_act, n); move_array(B.t_tlen, A.t_tlen, n);
   move_array(B.t_fid, A.t_fid, n); move_array(B.t_sf, A.t_sf, n); move_array(B.t_cls, A.t_cls, n); move_array(B.t_det, A.t_det, n);
   move_array(B.t_conf, A.t_conf, n);
-  move_array(mean_to, mean_from, n * 72);
+  move_array(mean_to, mean_from, n * 64);
+  move_array(dense_to, dense_from, n * 8);
+  move_array(blk_to, blk_from, n * 16);
+  move_array(flag_to, flag_from, n);
   __syncthreads();
   if (threadIdx.x == 0) {
     B.frame_count = A.frame_count; B.next_id = A.next_id; B.next_slot = A.next_slot; B.n_free = A.n_free;
@@ -1160,8 +1184,11 @@ int mot_bt_move_stream(mot_bt_batch* src, int s, mot_bt_batch* dst, int s2) {
   if (!src || !dst || s < 0 || s >= src->S || s2 < 0 || s2 >= dst->S || dst->CAP < src->CAP || dst->D < src->D) return MOT_ERR_INVALID;
   MOT_LC_HIP(src, hipStreamSynchronize(src->ctx->stream));
   hipStream_t st = dst->ctx->stream;
-  hipLaunchKernelGGL(bt_move, dim3(1), dim3(256), 0, st, src->d_streams + s, dst->d_streams + s2, src->mean + static_cast<size_t>(s) * 72 * src->CAP,
-                     dst->mean + static_cast<size_t>(s2) * 72 * dst->CAP, src->CAP);
+  hipLaunchKernelGGL(bt_move, dim3(1), dim3(256), 0, st, src->d_streams + s, dst->d_streams + s2, src->mean + static_cast<size_t>(s) * 64 * src->CAP,
+                     dst->mean + static_cast<size_t>(s2) * 64 * dst->CAP, src->mean_dense + static_cast<size_t>(s) * 8 * src->CAP,
+                     dst->mean_dense + static_cast<size_t>(s2) * 8 * dst->CAP, src->cov_blocks + static_cast<size_t>(s) * 16 * src->CAP,
+                     dst->cov_blocks + static_cast<size_t>(s2) * 16 * dst->CAP, src->dense_flag + static_cast<size_t>(s) * src->CAP,
+                     dst->dense_flag + static_cast<size_t>(s2) * dst->CAP, src->CAP);
   MOT_LC_HIP(dst, hipGetLastError());
   BtStream h;
   MOT_LC_HIP(dst, hipMemcpyAsync(&h, dst->d_streams + s2, sizeof(BtStream), hipMemcpyDeviceToHost, st));
@@ -1235,14 +1262,28 @@ int mot_bt_dump(mot_bt_batch* b, int s, int* ids, float* mean, float* cov, int c
   if (h.n_lost) MOT_LC_HIP(b, hipMemcpyAsync(slots.data() + h.n_active, h.lost[h.cur], sizeof(int) * h.n_lost, hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipMemcpyAsync(tid.data(), h.t_id, sizeof(int) * b->CAP, hipMemcpyDeviceToHost, st));
   const int C2 = b->CAP;
-  std::vector<float> m(static_cast<size_t>(72) * C2);
-  MOT_LC_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 72 * C2, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
+  std::vector<float> m(static_cast<size_t>(64) * C2);
+  MOT_LC_HIP(b, hipMemcpyAsync(m.data(), b->mean + static_cast<size_t>(s) * 64 * C2, sizeof(float) * m.size(), hipMemcpyDeviceToHost, st));
+  std::vector<float> md(static_cast<size_t>(8) * C2);  // (the means live in the dense array, BtStream::kdense)
+  MOT_LC_HIP(b, hipMemcpyAsync(md.data(), b->mean_dense + static_cast<size_t>(s) * 8 * C2, sizeof(float) * md.size(), hipMemcpyDeviceToHost, st));
+  std::vector<float> mb(static_cast<size_t>(16) * C2);
+  std::vector<unsigned char> mf(C2);
+  MOT_LC_HIP(b, hipMemcpyAsync(mb.data(), b->cov_blocks + static_cast<size_t>(s) * 16 * C2, sizeof(float) * mb.size(), hipMemcpyDeviceToHost, st));
+  MOT_LC_HIP(b, hipMemcpyAsync(mf.data(), b->dense_flag + static_cast<size_t>(s) * C2, mf.size(), hipMemcpyDeviceToHost, st));
   MOT_LC_HIP(b, hipStreamSynchronize(st));
   for (int i = 0; i < n; ++i) {
     const int sl = slots[i];
     ids[i] = tid[sl];
-    for (int k = 0; k < 8; ++k) mean[static_cast<size_t>(i) * 8 + k] = m[static_cast<size_t>(sl) * 72 + k];
-    for (int k = 0; k < 64; ++k) cov[static_cast<size_t>(i) * 64 + k] = m[static_cast<size_t>(sl) * 72 + 8 + k];
+    for (int k = 0; k < 8; ++k) mean[static_cast<size_t>(i) * 8 + k] = md[static_cast<size_t>(sl) * 8 + k];
+    float* C = cov + static_cast<size_t>(i) * 64;
+    if (mf[sl]) { for (int k = 0; k < 64; ++k) C[k] = m[static_cast<size_t>(sl) * 64 + k]; }
+    else {  // block form -> 8 x 8
+      for (int k = 0; k < 64; ++k) C[k] = 0.0f;
+      for (int c = 0; c < 4; ++c) {
+        const float* q = &mb[static_cast<size_t>(sl) * 16 + 4 * c];
+        C[c * 8 + c] = q[0]; C[c * 8 + c + 4] = q[1]; C[(c + 4) * 8 + c] = q[2]; C[(c + 4) * 8 + c + 4] = q[3];
+      }
+    }
   }
   return n;
 }

@@ -13,6 +13,7 @@
 
 namespace mot {
 hipError_t launch_kf_op(int op, int kind, const mot_kf_task*, int, int, hipStream_t);
+hipError_t launch_kf_update_blocks(const mot_kf_task* tasks, mot_kf_task* fallback, int ntasks, int max_n, hipStream_t st);
 hipError_t launch_det(int kind, const mot_det_task*, int, int, hipStream_t);
 hipError_t launch_gate(int kind, const mot_gate_task*, int, int, int, hipStream_t);
 hipError_t launch_iou(const mot_iou_task*, int, int, int, bool, hipStream_t);
@@ -469,6 +470,42 @@ static int kf_host(mot_ctx* c, int kind, int op, int n, const float* meas4, cons
     for (int k = 0; k < D * D; ++k) cov[static_cast<size_t>(i) * D * D + k] = sm[static_cast<size_t>(i) * RS + D + k];
     if (boxes4) for (int k = 0; k < 4; ++k) boxes4[static_cast<size_t>(i) * 4 + k] = sb[static_cast<size_t>(k) * n + i];
   }
+  return MOT_OK;
+}
+
+// XYAH update of n tracks whose covariances are in block form (mot_kf_task.cov_blocks), through the two launches ByteTrack's device lifecycle
+// uses: block kernel, then the dense kernel over the tracks it handed on. mean [n][8] in/out; blocks [n][16] in/out; upd_flags [n] MOT_KF_* bits;
+// dense_flag [n] out (1: the track left the block form, its state is then in cov_dense [n][64], mean still in `mean`).
+int mot_kf_update_blocks_host(mot_ctx* c, int n, const float* meas4, const unsigned char* upd_flags, float* mean, float* blocks,
+                              unsigned char* dense_flag, float* cov_dense) {
+  if (n <= 0) return MOT_OK;
+  if (!meas4 || !mean || !blocks || !dense_flag || !cov_dense) return MOT_ERR_INVALID;
+  std::vector<float> sz;
+  to_soa4(meas4, n, 4, 4, sz);
+  std::vector<int32_t> ident(n);
+  for (int i = 0; i < n; ++i) ident[i] = i;
+  DBuf dm, db, dr, dz, df, dfl, dt, dfi, dff;
+  MOT_HIP(c, dm.alloc(static_cast<size_t>(n) * 8 * 4)); MOT_HIP(c, db.alloc(static_cast<size_t>(n) * 16 * 4)); MOT_HIP(c, dr.alloc(static_cast<size_t>(n) * 64 * 4));
+  MOT_HIP(c, dz.alloc(sz.size() * 4)); MOT_HIP(c, df.alloc(n)); MOT_HIP(c, dfl.alloc(n)); MOT_HIP(c, dt.alloc(2 * sizeof(mot_kf_task)));
+  MOT_HIP(c, dfi.alloc(static_cast<size_t>(n) * 3 * 4)); MOT_HIP(c, dff.alloc(n));
+  MOT_HIP(c, hipMemcpyAsync(dm.p, mean, static_cast<size_t>(n) * 8 * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(db.p, blocks, static_cast<size_t>(n) * 16 * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemsetAsync(dr.p, 0, static_cast<size_t>(n) * 64 * 4, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(dz.p, sz.data(), sz.size() * 4, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemsetAsync(df.p, 0, n, c->stream));
+  if (upd_flags) MOT_HIP(c, hipMemcpyAsync(dfl.p, upd_flags, n, hipMemcpyHostToDevice, c->stream));
+  mot_kf_task t[2] = {};
+  t[0].mean = dr.as<float>(); t[0].cap = n; t[0].n = n; t[0].meas = dz.as<float>(); t[0].ldm = n; t[0].flags = upd_flags ? dfl.as<uint8_t>() : nullptr;
+  t[0].mean_dense = dm.as<float>(); t[0].cov_blocks = db.as<float>(); t[0].dense_flag = df.as<unsigned char>();
+  t[1] = t[0];
+  t[1].n = 0; t[1].src = dfi.as<int32_t>(); t[1].dst = dfi.as<int32_t>() + n; t[1].midx = dfi.as<int32_t>() + 2 * n; t[1].flags = dff.as<uint8_t>();
+  MOT_HIP(c, hipMemcpyAsync(dt.p, t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, mot::launch_kf_update_blocks(dt.as<mot_kf_task>(), dt.as<mot_kf_task>() + 1, 1, n, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(mean, dm.p, static_cast<size_t>(n) * 8 * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(blocks, db.p, static_cast<size_t>(n) * 16 * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(dense_flag, df.p, n, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(cov_dense, dr.p, static_cast<size_t>(n) * 64 * 4, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
   return MOT_OK;
 }
 

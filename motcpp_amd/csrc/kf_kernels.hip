@@ -594,7 +594,12 @@ __global__ void __launch_bounds__(TPB * 8) __attribute__((amdgpu_waves_per_eu(KI
     for (int p = tid; p < kUpdTracks * 18; p += NT) {
       const int rc = p / 18, q = p - rc * 18;
       const int slot = s_src[rc];
-      if (slot >= 0) tile4[rc * 19 + q] = slab4[static_cast<size_t>(slot) * 18 + q];
+      // (a task with a dense mirror of the means keeps them THERE: the record's first 32 bytes are neither read nor written)
+      // (a task with dense means keeps them THERE, and its slab holds covariance-only records of 64 floats: 256 bytes on a 256-byte boundary
+      // are two lines of 128 bytes where a 288-byte record at any multiple of 288 touches 3.25 on average)
+      if (slot >= 0) tile4[rc * 19 + q] = !T.mean_dense ? slab4[static_cast<size_t>(slot) * 18 + q]
+                                          : (q < 2 ? reinterpret_cast<const float4*>(T.mean_dense)[static_cast<size_t>(slot) * 2 + q]
+                                                   : slab4[static_cast<size_t>(slot) * 16 + (q - 2)]);
     }
   }
   __syncthreads();
@@ -730,7 +735,12 @@ __global__ void __launch_bounds__(TPB * 8) __attribute__((amdgpu_waves_per_eu(KI
     for (int p = tid; p < kUpdTracks * 18; p += NT) {
       const int rc = p / 18, q = p - rc * 18;
       const int slot = s_dst[rc];
-      if (slot >= 0) slab4[static_cast<size_t>(slot) * 18 + q] = tile4[rc * 19 + q];
+      if (slot >= 0) {
+        const float4 val = tile4[rc * 19 + q];
+        if (!T.mean_dense) slab4[static_cast<size_t>(slot) * 18 + q] = val;
+        else if (q < 2) reinterpret_cast<float4*>(T.mean_dense)[static_cast<size_t>(slot) * 2 + q] = val;  // (the dense means, motcpp_amd.h)
+        else slab4[static_cast<size_t>(slot) * 16 + (q - 2)] = val;
+      }
     }
   }
   if (T.boxes && active && r < 4) {  // xyxy of the written state: lane r writes component r
@@ -741,6 +751,103 @@ __global__ void __launch_bounds__(TPB * 8) __attribute__((amdgpu_waves_per_eu(KI
     T.boxes[static_cast<size_t>(r) * T.ldb + item] = b;
   }
   __syncthreads();  // the tile, the gains, the factors and the slot lists are free for the next tile
+  }
+}
+
+// ---- 8-state XYAH update on BLOCK-STRUCTURED covariances (round 6) -----------------------------------------------------------------
+// A track of these filters is born with a diagonal covariance (initiate) and from then on only predicted (F = I + shift: component c takes
+// its velocity c + 4) and updated (H = [I 0], R diagonal): by induction P(i, j) is an exact zero unless j = i (mod 4), the innovation
+// covariance S = H P H^T + R is DIAGONAL, its Cholesky factor is diag(sqrt(S_cc)), a gain row has one non-zero entry, and the whole update is
+// four independent two-state filters (component, velocity). Every product the dense code forms with a structural zero is an exact zero
+// as long as the other factor is FINITE, and adding an exact zero changes nothing (up to the sign of a zero, which no comparison sees and
+// no later operation turns into a non-zero): the four blocks below are the non-zero terms of s8_predict / s8_update / kf_update8_kernel in
+// the same order — K = (p / l) / l with l = sqrt(S) (chol4_solve's two substitutions), KS = K * S, P -= KS * K — bit for bit. A track that
+// meets a non-positive or non-finite S, or any non-finite input or intermediate (0 * inf would put NaN where the blocks keep a zero), is NOT
+// touched here: its blocks are expanded into its 64-float record, its flag is set, and it goes — this frame and from now on — through
+// kf_update8_kernel (the `fallback` task of the same stream, filled here). 96 bytes in and out per track instead of 576, four lanes per track.
+constexpr int kBlkTracks = 64;
+template <int KIND>
+__global__ void __launch_bounds__(kBlkTracks * 4) kf_update_blocks_kernel(const mot_kf_task* __restrict__ tasks, mot_kf_task* __restrict__ fallback) {
+  static_assert(KIND == MOT_KF_XYAH, "block form: the XYAH filter (ByteTrack)");
+  const mot_kf_task T = tasks[blockIdx.y];
+  mot_kf_task& F = fallback[blockIdx.y];
+  const int tid = threadIdx.x, c = tid & 3;
+  for (int base = blockIdx.x * kBlkTracks; base < T.n; base += gridDim.x * kBlkTracks) {
+    const int item = base + (tid >> 2);
+    const bool active = item < T.n;
+    int slot = 0, mi = 0;
+    unsigned f = 0u;
+    float z = 0.0f, zc = 0.0f, m0 = 0.0f, m1 = 0.0f;
+    float4 blk = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool dense = false;
+    if (active) {
+      slot = T.src ? T.src[item] : item;
+      mi = T.midx ? T.midx[item] : item;
+      f = T.flags ? T.flags[item] : 0u;
+      z = T.meas[static_cast<size_t>(c) * T.ldm + mi];
+      if (T.conf) zc = T.conf[mi];
+      m0 = T.mean_dense[static_cast<size_t>(slot) * 8 + c];
+      m1 = T.mean_dense[static_cast<size_t>(slot) * 8 + c + 4];
+      blk = reinterpret_cast<const float4*>(T.cov_blocks)[static_cast<size_t>(slot) * 4 + c];
+      dense = T.dense_flag[slot] != 0;
+    }
+    float a = blk.x, b = blk.y, bp = blk.z, d = blk.w;
+    const int l3 = (tid & 63 & ~3) | 3;  // the lane of this track's component 3 (the height)
+    if (f & MOT_KF_PREDICT_FIRST) {  // s8_predict: x' = F x, P' = F P F^T + Q, the standard deviations from the height BEFORE the motion step
+      const bool zero_v7 = (f & MOT_KF_ZERO_V7) != 0;
+      const float h = __shfl(m0, l3, 64);
+      if (zero_v7 && c == 3) m1 = 0.0f;
+      m0 = m0 + m1;
+      a = a + bp; b = b + d;    // row c += row c + 4
+      a = a + b; bp = bp + d;   // column c += column c + 4
+      float sp = kWp * h, sv = kWv * h;
+      if (c == 2) { sp = 1e-2f; sv = 1e-5f; }
+      a = a + sp * sp; d = d + sv * sv;
+    }
+    const float h = __shfl(m0, l3, 64);
+    float sdm = kWp * h;
+    if (c == 2) sdm = 1e-1f;
+    sdm = sdm * (1.0f - zc);  // NSA Kalman (kalman_filter.cpp:67); zc = 0 unless the task carries confidences
+    const float S = a + sdm * sdm;
+    const float l = sqrtf(S);
+    const float Kt = (a / l) / l, Kb = (bp / l) / l;
+    const float inn = z - m0;
+    const float m0n = m0 + Kt * inn, m1n = m1 + Kb * inn;
+    const float KSt = Kt * S, KSb = Kb * S;
+    const float an = a - KSt * Kt, bn = b - KSt * Kb, bpn = bp - KSb * Kt, dn = d - KSb * Kb;
+    auto fin = [](float x) { return fabsf(x) < 3.0e38f; };  // (false for NaN and inf)
+    bool ok = S > 0.0f && fin(S) && fin(a) && fin(b) && fin(bp) && fin(d) && fin(m0) && fin(m1) && fin(inn) && fin(Kt) && fin(Kb) && fin(KSt) && fin(KSb) &&
+              fin(blk.x) && fin(blk.y) && fin(blk.z) && fin(blk.w) && fin(z);
+    ok = ok && !dense;
+    // all four blocks of the track, or none
+    const unsigned long long bal = __ballot(ok || !active);
+    const int lane = tid & 63;
+    const bool track_ok = ((bal >> (lane & ~3)) & 0xfull) == 0xfull;
+    if (active && track_ok) {
+      const int ds = T.dst ? T.dst[item] : slot;
+      T.mean_dense[static_cast<size_t>(ds) * 8 + c] = m0n;
+      T.mean_dense[static_cast<size_t>(ds) * 8 + c + 4] = m1n;
+      reinterpret_cast<float4*>(T.cov_blocks)[static_cast<size_t>(ds) * 4 + c] = make_float4(an, bn, bpn, dn);
+    } else if (active) {
+      if (!dense) {  // the blocks as they were loaded become the track's 8 x 8 record: lane c writes rows c and c + 4
+        float4* rec = reinterpret_cast<float4*>(T.mean) + static_cast<size_t>(slot) * 16;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 r0a = z4, r0b = z4, r1a = z4, r1b = z4;  // row c: (c) = a, (c + 4) = b; row c + 4: (c) = b', (c + 4) = d
+        if (c == 0) { r0a.x = blk.x; r0b.x = blk.y; r1a.x = blk.z; r1b.x = blk.w; }
+        if (c == 1) { r0a.y = blk.x; r0b.y = blk.y; r1a.y = blk.z; r1b.y = blk.w; }
+        if (c == 2) { r0a.z = blk.x; r0b.z = blk.y; r1a.z = blk.z; r1b.z = blk.w; }
+        if (c == 3) { r0a.w = blk.x; r0b.w = blk.y; r1a.w = blk.z; r1b.w = blk.w; }
+        rec[2 * c] = r0a; rec[2 * c + 1] = r0b; rec[2 * (c + 4)] = r1a; rec[2 * (c + 4) + 1] = r1b;
+      }
+      if (c == 0) {
+        T.dense_flag[slot] = 1;
+        const int k = atomicAdd(&F.n, 1);
+        const_cast<int32_t*>(F.src)[k] = slot;
+        const_cast<int32_t*>(F.dst)[k] = T.dst ? T.dst[item] : slot;
+        const_cast<int32_t*>(F.midx)[k] = mi;
+        const_cast<uint8_t*>(F.flags)[k] = static_cast<uint8_t>(f);
+      }
+    }
   }
 }
 
@@ -888,6 +995,18 @@ hipError_t launch_kf(int kind, const mot_kf_task* tasks, int ntasks, int max_n, 
 }  // namespace
 
 namespace mot {
+// ByteTrack's device lifecycle: the block-form update over every task, then the dense update over the tasks' fallback lists (usually empty: one
+// workgroup per task looks at a zero count)
+hipError_t launch_kf_update_blocks(const mot_kf_task* tasks, mot_kf_task* fallback, int ntasks, int max_n, hipStream_t st) {
+  if (ntasks <= 0 || max_n <= 0) return hipSuccess;
+  const int want = (max_n + kBlkTracks - 1) / kBlkTracks;
+  dim3 grid((want < kUpdGroups) ? want : kUpdGroups, ntasks), block(kBlkTracks * 4);
+  hipLaunchKernelGGL((kf_update_blocks_kernel<MOT_KF_XYAH>), grid, block, 0, st, tasks, fallback);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((kf_update8_kernel<MOT_KF_XYAH, kUpdTracks>), dim3(1, ntasks), dim3(kUpdTracks * 8), 0, st, fallback);
+  return hipGetLastError();
+}
 hipError_t launch_kf_op(int op, int kind, const mot_kf_task* tasks, int ntasks, int max_n, hipStream_t st) {
   switch (op) {
     case OP_INIT: return launch_kf<OP_INIT>(kind, tasks, ntasks, max_n, st);

@@ -16,6 +16,7 @@
 
 namespace mot {
 hipError_t launch_kf_op(int op, int kind, const mot_kf_task*, int, int, hipStream_t);
+hipError_t launch_kf_update_blocks(const mot_kf_task* tasks, mot_kf_task* fallback, int ntasks, int max_n, hipStream_t st);
 hipError_t launch_det(int kind, const mot_det_task*, int, int, hipStream_t);
 hipError_t launch_iou(const mot_iou_task*, int, int, int, bool, hipStream_t);
 // hint_n / hint_m (0: none): sizes most problems of the launch stay within, tighter than the hard bounds max_n / max_m — the sparse

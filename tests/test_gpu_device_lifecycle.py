@@ -367,3 +367,4 @@ def test_two_frames_in_flight_sort_and_ocsort(which):
     with pytest.raises(L.MotError):
         dev.collect_packed(rows, cnt)  # nothing pending
     dev.close()
+

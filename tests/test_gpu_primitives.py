@@ -592,3 +592,100 @@ def test_nsa_kalman_update(ctx, orc, n):
     pm, pc = orc.kf_update(L.KF_XYAH, mean, cov, z)
     assert np.array_equal(gm[::7], pm[::7]) and np.array_equal(gc[::7], pc[::7])
     assert n < 8 or not np.array_equal(gm, pm)
+
+
+def _blocks_of(cov):
+    """8 x 8 covariances -> block form [n, 4, 4] = {P(c,c), P(c,c+4), P(c+4,c), P(c+4,c+4)} (mot_kf_task.cov_blocks)"""
+    n = cov.shape[0]
+    b = np.zeros((n, 4, 4), np.float32)
+    for c in range(4):
+        b[:, c, 0], b[:, c, 1], b[:, c, 2], b[:, c, 3] = cov[:, c, c], cov[:, c, c + 4], cov[:, c + 4, c], cov[:, c + 4, c + 4]
+    return b
+
+
+def _dense_of(blocks):
+    n = blocks.shape[0]
+    cov = np.zeros((n, 8, 8), np.float32)
+    for c in range(4):
+        cov[:, c, c], cov[:, c, c + 4], cov[:, c + 4, c], cov[:, c + 4, c + 4] = blocks[:, c, 0], blocks[:, c, 1], blocks[:, c, 2], blocks[:, c, 3]
+    return cov
+
+
+def test_kalman_block_form_is_the_dense_filter(ctx, orc):
+    """Round 6: ByteTrack's lifecycle keeps covariances as four 2 x 2 blocks (kf_update_blocks_kernel: 96 bytes per track instead of 576). A track that
+    is initiated and then only predicted / updated has exact zeros everywhere else, so the block arithmetic IS the dense arithmetic term by term:
+    700 tracks through eight predict + update rounds against the oracle's dense KalmanFilterXYAH (kalman_filter.cpp:44-112), every entry bit for bit,
+    with and without the predict folded into the update (MOT_KF_PREDICT_FIRST, MOT_KF_ZERO_V7) — and the structural zeros of the oracle's dense
+    covariance checked to BE zeros, which is what the block form rests on."""
+    r = np.random.default_rng(11)
+    n = 700
+    b = boxes(r, n)
+    w, h = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    z = np.stack([b[:, 0] + w / 2, b[:, 1] + h / 2, w / h, h], 1).astype(np.float32)
+    mo, co = orc.kf_initiate(L.KF_XYAH, z)
+    mg, bg = mo.copy(), _blocks_of(co)
+    mask = np.ones((8, 8), bool)
+    for c in range(4):
+        mask[c, c] = mask[c, c + 4] = mask[c + 4, c] = mask[c + 4, c + 4] = False
+    scale = np.array([2, 2, 0.01, 2], np.float32)
+    for step in range(8):
+        zero_v7 = (r.uniform(0, 1, n) < 0.3)
+        flags = (8 | np.where(zero_v7, 1, 0)).astype(np.uint8)  # MOT_KF_PREDICT_FIRST | MOT_KF_ZERO_V7 for a third of the tracks
+        mp = mo.copy()
+        mp[zero_v7, 7] = 0.0  # bytetrack.cpp:108-110: the height's velocity of a non-tracked state is zeroed before the prediction
+        mp, cp = orc.kf_predict(L.KF_XYAH, mp, co)
+        zz = (mp[:, :4] + r.normal(0, 1, (n, 4)).astype(np.float32) * scale).astype(np.float32)
+        mo, co = orc.kf_update(L.KF_XYAH, mp, cp, zz)
+        assert not np.any(co[:, mask] != 0.0), "the oracle's covariance has a non-zero where the block form keeps a structural zero"
+        mg, bg, dense, _cd = ctx.kf_update_blocks(mg, bg, zz, flags)
+        assert not dense.any(), (step, int(dense.sum()))
+        assert np.array_equal(mg, mo), (step, np.abs(mg - mo).max())
+        assert np.array_equal(_dense_of(bg), co), (step, np.abs(_dense_of(bg) - co).max())
+    # without the folded predict (ByteTrack's unconfirmed tracks are updated from their stored state)
+    zz = (mo[:, :4] + r.normal(0, 1, (n, 4)).astype(np.float32) * scale).astype(np.float32)
+    mo2, co2 = orc.kf_update(L.KF_XYAH, mo, co, zz)
+    mg2, bg2, dense, _cd = ctx.kf_update_blocks(mg, bg, zz, np.zeros(n, np.uint8))
+    assert not dense.any() and np.array_equal(mg2, mo2) and np.array_equal(_dense_of(bg2), co2)
+
+
+def test_kalman_block_form_hands_degenerate_tracks_to_the_dense_filter(ctx, orc):
+    """What the block form cannot represent leaves it untouched: a height of zero (innovation variance 0: the reference's Cholesky fails and its
+    pivoted-LU inverse spreads inf / NaN over the whole state), a NaN or infinite entry, a measurement of 1e38 (the innovation overflows: 0 * inf in the
+    dense filter). Those tracks come back flagged, with the 8 x 8 covariance the dense kernel computed — equal to the oracle's with NaN == NaN — while
+    the ordinary tracks in between are updated in block form, bit for bit."""
+    r = np.random.default_rng(5)
+    n = 64
+    b = boxes(r, n)
+    w, h = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    z = np.stack([b[:, 0] + w / 2, b[:, 1] + h / 2, w / h, h], 1).astype(np.float32)
+    z[3, 3] = 0.0     # height 0 at birth: every variance that scales with it is 0
+    mo, co = orc.kf_initiate(L.KF_XYAH, z)
+    mo, co = orc.kf_predict(L.KF_XYAH, mo, co)
+    mo, co = orc.kf_update(L.KF_XYAH, mo, co, z)  # (one ordinary round so that the off-diagonal block entries are populated; track 3 is already degenerate)
+    finite_before = np.isfinite(co).all(axis=(1, 2)) & np.isfinite(mo).all(axis=1)
+    mg, bg = mo.copy(), _blocks_of(np.nan_to_num(co, nan=0.0, posinf=0.0, neginf=0.0))
+    weird = [3, 10, 20, 30]
+    mg[10, 5] = np.inf; mo[10, 5] = np.inf            # an infinite velocity
+    bg[20, 1, 2] = np.nan; co[20, 5, 1] = np.nan      # a NaN in a block
+    zz = (mo[:, :4] + r.normal(0, 1, (n, 4)).astype(np.float32)).astype(np.float32)
+    zz[30, 0] = 1.0e38                                 # the innovation is finite, its product with the gain is not
+    mg[3], bg[3] = np.nan_to_num(mo[3]), 0.0; mo[3], co[3] = mg[3], 0.0   # track 3: a clean all-zero covariance with height 0 -> S = 0
+    mg[3, 3] = 0.0; mo[3, 3] = 0.0
+    flags = np.full(n, 8, np.uint8)
+    mp, cp = orc.kf_predict(L.KF_XYAH, mo, co)
+    mo2, co2 = orc.kf_update(L.KF_XYAH, mp, cp, zz)
+    mg2, bg2, dense, cd = ctx.kf_update_blocks(mg, bg, zz, flags)
+    assert set(np.nonzero(dense)[0]) >= {3, 10, 20}, np.nonzero(dense)[0]
+    ok = dense == 0
+    assert ok.sum() >= n - 6
+    assert np.array_equal(mg2[ok], mo2[ok]) and np.array_equal(_dense_of(bg2)[ok], co2[ok])
+    # the tracks handed on: exactly what the dense kernel (kf_update8_kernel through mot_kf_predict / mot_kf_update) makes of the same states ...
+    md, cdn = ctx.kf_apply(L.KF_XYAH, 1, mo, co)
+    md, cdn = ctx.kf_apply(L.KF_XYAH, 2, md, cdn, meas=zz)
+    bad = dense != 0
+    assert np.array_equal(mg2[bad], md[bad], equal_nan=True) and np.array_equal(cd[bad], cdn[bad], equal_nan=True)
+    # ... which is the oracle's state for the zero innovation variance and for the NaN entry. (An INFINITE mean entry is outside what any of the
+    # kernels reproduces: they apply F = I + shift and H = [I 0] structurally, the reference multiplies by their zeros — 0 * inf = NaN; that has been so
+    # since round 1 and is why "finite" is part of the block form's test.)
+    for t in (3, 20):
+        assert np.array_equal(mg2[t], mo2[t], equal_nan=True) and np.array_equal(cd[t], co2[t], equal_nan=True), t

@@ -825,8 +825,8 @@ def main():
         duration_source = ("HIP events around the kernel's launches, sub-batches stepped one at a time right after the timed region (same trackers, full "
                            "sub-batches): the kernel's own begin-to-end time. rocprofv3's --stats average of this command mixes launch sizes (stream sweep) and "
                            "time-shared launches (three sub-batches); the like-for-like check is a one-sub-batch command whose last launches are the timed "
-                           "ones (--streams 6144 --pipeline 1 --no-outputs-resident, no other legs): events 692 us against 687 us for the same 20 launches in "
-                           "rocprofv3's trace (profiles/r06b_NS_one_subbatch_last20.txt, tools/last_launches_avg.py)")
+                           "ones (--streams 6144 --pipeline 1 --no-outputs-resident, no other legs): events 691 us against 685 us for the same 20 launches in "
+                           "rocprofv3's trace (profiles/r06c_NS_one_subbatch_last20.txt, tools/last_launches_avg.py)")
     bytes_per_launch = st["bytes"] / launches
     if fam == "cosine" and st["flops"] > 0:
         achieved = st["flops"] / launches / (avg_ms * 1e-3) / 1e12
@@ -838,7 +838,7 @@ def main():
     kernel_names = {"lap1_sparse": "lap_sparse_kernel (first association: pool of tracked + lost tracks x high-score detections)",
                     "lap": "lap_sparse_kernel + lap_kernel (assignment launches of a frame)", "cosine": "embed_kernel<cosine>" if DENSE_COS else "embed_gated_kernel",
                     "feat": "feat_kernel (normalise / set / blend the appearance features: three launches per frame)",
-                    "kf_update": "kf_update8_kernel", "kf_predict_boxes": "kf_kernel (predict + boxes)", "kf_initiate": "kf_kernel (initiate)",
+                    "kf_update": "kf_update_blocks_kernel (ByteTrack device lifecycle: block-form covariances, DESIGN.md section 2) / kf_update8_kernel (dense records)", "kf_predict_boxes": "kf_kernel (predict + boxes)", "kf_initiate": "kf_kernel (initiate)",
                     "ocsort_cost": "ocsort_kernel"}
     roof.update({"kernel": kernel_names.get(fam, fam), "family": fam, "avg_launch_ms": avg_ms, "launches": st["launches"],
                  "problems_per_launch": st["tasks"] / launches, "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": None,

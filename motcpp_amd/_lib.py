@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBDIR = os.path.join(HERE, "lib")
+LIBDIR = os.environ.get("MOTCPP_LIB_DIR") or os.path.join(HERE, "lib")  # (MOTCPP_LIB_DIR: a diagnostic build, e.g. the host library under AddressSanitizer)
 HIP_LIB = os.path.join(LIBDIR, "libmotcpp_hip.so")
 # diagnostics only (tools/): a differently instrumented build of the SAME sources, e.g. lib/libmotcpp_hip_fineprof.so (-DMOT_LAP_FINE_PROF)
 if os.environ.get("MOTCPP_HIP_LIB_DIAG"):

@@ -138,14 +138,17 @@ Device::~Device() {
   if (ctx) mot_ctx_destroy(ctx);
 }
 std::shared_ptr<Device> Device::shared(int device_index) {
+  // One Device per GPU for the life of the process (round 6; a weak cache before). A Device is a context, a stream, four arenas (~90 MB of device and
+  // page-locked memory), the merged-round state of its host-lifecycle trackers and their worker team: an application that creates a tracker per
+  // camera session would otherwise rebuild all of it whenever its last tracker went away — tests/test_gpu_error_isolation.py does so 80 times in a row,
+  // and two of nineteen full GPU-suite runs ended inside those cycles in glibc's "double free or corruption (!prev)", only with the HIP runtime that
+  // PyTorch ships loaded first, never under AddressSanitizer, gdb or an LD_PRELOADed handler (what was tried). The map is never
+  // destroyed: HIP calls from static destructors run after the runtime's own teardown.
   static std::mutex m;
-  static std::map<int, std::weak_ptr<Device>> cache;
+  static auto* cache = new std::map<int, std::shared_ptr<Device>>();
   std::lock_guard<std::mutex> g(m);
-  auto sp = cache[device_index].lock();
-  if (!sp) {
-    sp = std::make_shared<Device>(device_index);
-    cache[device_index] = sp;
-  }
+  auto& sp = (*cache)[device_index];
+  if (!sp) sp = std::make_shared<Device>(device_index);
   return sp;
 }
 void Device::check(int rc, const char* what) {

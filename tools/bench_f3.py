@@ -22,6 +22,7 @@ def main():
         dets = np.stack([base[s % len(base)][0] for s in range(S)])  # [S, F, M, 6]
         embs = np.stack([base[s % len(base)][1] for s in range(S)]) if emb else None
         cnt = np.full(S, M, np.int32)
+        c0 = b.counters()  # (the Device and its counters outlive the batch: differences)
         t0 = None
         for f in range(F):
             if f == warm:
@@ -30,7 +31,7 @@ def main():
         dt = time.perf_counter() - t0
         c = b.counters()
         out["frames_per_s"][kind] = {"value": round(S * (F - warm) / dt), "ms_per_step": round(1e3 * dt / (F - warm), 3),
-                                     "flushes_per_step": round(c["flushes"] / F, 2)}
+                                     "flushes_per_step": round((c["flushes"] - c0["flushes"]) / F, 2)}
         b.close()
     # the same trackers through the reference's own surface: T objects of the public classes on T host threads (motcpp_bench_threads), whose
     # concurrent update() calls the library merges into lockstep frames (round 5: run_frame_combined; a per-GPU mutex before)

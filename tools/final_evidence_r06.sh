@@ -30,6 +30,17 @@ for WL in NS_timed_only C2 C3 C4; do
   ( python tools/rocpd_top_kernels.py /tmp/kt_$WL $OUT/${TAG}_kernel_stats_$WL.csv > $OUT/${TAG}_kernel_stats_$WL.txt 2>&1 )
   rm -rf /tmp/kt_$WL
 done
+# events against rocprofv3 on the SAME launches: one sub-batch, no leg behind the timed region -> the trace's last 20 launches are the timed ones
+rm -rf /tmp/kt_one
+( cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_one -- python $ROOT/bench.py --steps 20 --warmup 5 --streams 6144 --pipeline 1 --no-outputs-resident $Q > $OUT/${TAG}_bench_under_rocprof_NS_one_subbatch.json 2> $OUT/${TAG}_kt_one.err )
+python tools/rocpd_top_kernels.py /tmp/kt_one $OUT/${TAG}_kernel_stats_NS_one_subbatch.csv > $OUT/${TAG}_kernel_stats_NS_one_subbatch.txt 2>&1
+python tools/last_launches_avg.py /tmp/kt_one "lap_sparse_kernel<true, 3, 256>" 20 > $OUT/${TAG}_NS_one_subbatch_last20.txt 2>&1
+python - <<PY >> $OUT/${TAG}_NS_one_subbatch_last20.txt
+import json
+d = json.loads(open("$OUT/${TAG}_bench_under_rocprof_NS_one_subbatch.json").read().strip().splitlines()[-1])
+print("HIP events of the same run (roofline.avg_launch_ms, the timed 20 launches): %.1f us" % (d["roofline"]["avg_launch_ms"] * 1e3))
+PY
+rm -rf /tmp/kt_one
 python tools/kernel_duration_tail.py /tmp/kt_$TAG > $OUT/${TAG}_kernel_duration_tail_NS.txt 2>&1   # (the default NS command's trace, left there by collect_profiles.sh)
 # ---- the plugin surface ----
 timeout 600 python tools/bench_pooled.py NS 1 16 64 256 1024 > $OUT/${TAG}_basetracker_update_NS.json 2> $OUT/${TAG}_pooled.err

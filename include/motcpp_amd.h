@@ -137,6 +137,8 @@ typedef struct mot_kf_task {
                                 stored as [cap][4][4] floats {P(c,c), P(c,c+4), P(c+4,c), P(c+4,c+4)}: 64 bytes instead of 256 */
   unsigned char* dense_flag; /* [cap] 1: the track left the block form (a non-positive or non-finite innovation variance, a non-finite input: the
                                 dense arithmetic then spreads NaN / inf over the structural zeros) and lives in its 64-float record from then on */
+  const float* meas4;        /* optional (kf_update_blocks_kernel): the same measurements as [n][4] floats — the four components of a detection in one 16-byte
+                                access instead of four lines of the [4][ldm] planes */
 } mot_kf_task;
 int mot_kf_dim(int kf_kind);
 int mot_kf_initiate(mot_ctx* ctx, int kf_kind, const mot_kf_task* tasks, int ntasks, int max_n);

@@ -68,6 +68,8 @@ struct BtStream {
   float* kdense;       // round 6: the MEANS, dense ([slot][8]): what the list kernels read boxes from and what the Kalman update reads and writes
                        // (mot_kf_task.mean_dense) — a record's mean was 32 B of a 288-byte stride, a 64-byte line fetched for every track three or four
                        // times per frame (bt_begin and bt_dups moved 100 KB per stream that way); the record keeps the covariance
+  float* dmeas4;  // round 6: the frame's Kalman measurements once more as [D][4] (mot_kf_task.meas4): the block-form update reads a detection's four
+                  // components with one 16-byte access per quad of lanes instead of one line per component
   float *pool_box, *rbox, *ubox;  // [4][CAP] predicted boxes of the pool / stored boxes of the second association's tracks / of the unconfirmed ones
 };
 
@@ -150,52 +152,106 @@ __global__ void __launch_bounds__(kAFMax) bt_begin(BtStream* streams, BtParams P
   const float* conf = dets + static_cast<size_t>(4) * ldd;
   float* dbox = det_t[blockIdx.x].box;
   float* dmeas = det_t[blockIdx.x].meas;
+  float* __restrict__ dmeas4 = S.dmeas4;
   const int dldb = det_t[blockIdx.x].ldb, dldm = det_t[blockIdx.x].ldm;
   int nh = 0, ns = 0, z = 0;
-  for (int i0 = 0; i0 < n; i0 += static_cast<int>(blockDim.x)) {
-    const int i = i0 + t;
-    const float c = (i < n) ? conf[i] : 0.f;
-    const bool hi = i < n && c > P.track_thresh;
-    const bool lo = i < n && c > P.min_conf && c < P.track_thresh;
-    const Compact3 k = compact3_block(hi, lo, false, nh, ns, z, cnt);
-    if (hi) S.high[k.pos[0]] = i;
-    if (lo) S.second[k.pos[1]] = i;
-    if (i < n && n <= D) {  // the detection's association box and Kalman measurement (det_kernel<MOT_DET_XYAH>, bytetrack.cpp:29-33: the same operations)
-      const float x1 = dets[i], y1 = dets[static_cast<size_t>(ldd) + i], x2 = dets[static_cast<size_t>(2) * ldd + i], y2 = dets[static_cast<size_t>(3) * ldd + i];
-      const float w = x2 - x1, h = y2 - y1;
-      const float xc = x1 + w * 0.5f, yc = y1 + h * 0.5f;
-      const float tl = xc - w * 0.5f, tt = yc - h * 0.5f;
-      const float zz[4] = {tl + w * 0.5f, tt + h * 0.5f, (h > 0.0f) ? (w / h) : 0.0f, h};
-      const float bb[4] = {xc - w * 0.5f, yc - h * 0.5f, xc + w * 0.5f, yc + h * 0.5f};
+  // (round 6: kU chunks per thread, the loads of a level issued together — see bt_after_first)
+  constexpr int kU = 4;
+  const int T = static_cast<int>(blockDim.x);
+  int* __restrict__ high = S.high; int* __restrict__ second = S.second; int* __restrict__ pool_slot = S.pool_slot; int* __restrict__ unconf_slot = S.unconf_slot;
+  const int* __restrict__ t_act = S.t_act; const int* __restrict__ t_state = S.t_state; const float* __restrict__ kdense = S.kdense;
+  int* __restrict__ pred_src = S.pred_src; int* __restrict__ pred_dst = S.pred_dst; unsigned char* __restrict__ pred_flags = S.pred_flags;
+  float* __restrict__ pool_box = S.pool_box; float* __restrict__ ubox = S.ubox;
+  const bool fits = n <= D;
+  for (int base = 0; base < n; base += kU * T) {
+    float c[kU], bx[kU][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { dbox[static_cast<size_t>(q) * dldb + i] = bb[q]; dmeas[static_cast<size_t>(q) * dldm + i] = zz[q]; }
+    for (int u = 0; u < kU; ++u) {
+      const int i = base + u * T + t;
+      c[u] = (i < n) ? conf[i] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bx[u][q] = (i < n && fits) ? dets[static_cast<size_t>(q) * ldd + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (base + u * T >= n) break;  // (uniform)
+      const int i = base + u * T + t;
+      const bool hi = i < n && c[u] > P.track_thresh;
+      const bool lo = i < n && c[u] > P.min_conf && c[u] < P.track_thresh;
+      const Compact3 k = compact3_block(hi, lo, false, nh, ns, z, cnt);
+      if (hi) high[k.pos[0]] = i;
+      if (lo) second[k.pos[1]] = i;
+      if (i < n && fits) {  // the detection's association box and Kalman measurement (det_kernel<MOT_DET_XYAH>, bytetrack.cpp:29-33: the same operations)
+        const float x1 = bx[u][0], y1 = bx[u][1], x2 = bx[u][2], y2 = bx[u][3];
+        const float w = x2 - x1, h = y2 - y1;
+        const float xc = x1 + w * 0.5f, yc = y1 + h * 0.5f;
+        const float tl = xc - w * 0.5f, tt = yc - h * 0.5f;
+        const float zz[4] = {tl + w * 0.5f, tt + h * 0.5f, (h > 0.0f) ? (w / h) : 0.0f, h};
+        const float bb[4] = {xc - w * 0.5f, yc - h * 0.5f, xc + w * 0.5f, yc + h * 0.5f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { dbox[static_cast<size_t>(q) * dldb + i] = bb[q]; dmeas[static_cast<size_t>(q) * dldm + i] = zz[q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dmeas4[static_cast<size_t>(i) * 4 + q] = zz[q];  // (scalar stores: the pool's offset is 16-byte aligned only when cap_tracks is a multiple of 4)
+      }
     }
   }
   int np = 0, nu = 0;
-  for (int i0 = 0; i0 < n_active; i0 += static_cast<int>(blockDim.x)) {
-    const int i = i0 + t;
-    const int slot = (i < n_active) ? act[i] : 0;
-    const int ta = (i < n_active) ? S.t_act[slot] : 0;
-    const bool a = i < n_active && ta != 0;
-    const bool u = i < n_active && ta == 0;
-    const Compact3 k = compact3_block(a, u, false, np, nu, z, cnt);
-    if (a) S.pool_slot[k.pos[0]] = slot;
-    if (u) S.unconf_slot[k.pos[1]] = slot;
+  for (int base = 0; base < n_active; base += kU * T) {
+    int slot[kU], ta[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; slot[u] = (i < n_active) ? act[i] : 0; }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; ta[u] = (i < n_active) ? t_act[slot[u]] : 0; }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (base + u * T >= n_active) break;
+      const int i = base + u * T + t;
+      const bool a = i < n_active && ta[u] != 0;
+      const bool un = i < n_active && ta[u] == 0;
+      const Compact3 k = compact3_block(a, un, false, np, nu, z, cnt);
+      if (a) pool_slot[k.pos[0]] = slot[u];
+      if (un) unconf_slot[k.pos[1]] = slot[u];
+    }
   }
   const int n_tracked = np;
-  for (int i = t; i < n_lost; i += static_cast<int>(blockDim.x)) S.pool_slot[np + i] = lst[i];  // tracked and lost are disjoint by id at frame start (:565-580 of the previous frame)
+  for (int base = 0; base < n_lost; base += kU * T) {  // tracked and lost are disjoint by id at frame start (:565-580 of the previous frame)
+    int sl[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; sl[u] = (i < n_lost) ? lst[i] : 0; }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; if (i < n_lost) pool_slot[np + i] = sl[u]; }
+  }
   np += n_lost;
   __syncthreads();
-  for (int i = t; i < np; i += static_cast<int>(blockDim.x)) {  // the reference predicts COPIES of the pool (:251-265): here the prediction is box-only
-    const int slot = S.pool_slot[i];
-    S.pred_src[i] = slot;
-    S.pred_dst[i] = slot;
-    // only the predicted BOXES are needed now; a matched track is re-predicted inside its update (MOT_KF_PREDICT_FIRST)
-    const bool zero_v7 = S.t_state[slot] != Tracked;
-    S.pred_flags[i] = (zero_v7 ? MOT_KF_ZERO_V7 : 0) | MOT_KF_NO_STORE;
-    store_box(S.pool_box, CAP, i, predicted_box(S.kdense, slot, zero_v7));
+  for (int base = 0; base < np; base += kU * T) {  // the reference predicts COPIES of the pool (:251-265): here the prediction is box-only
+    int slot[kU], st[kU];
+    float4 ma[kU], mv[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; slot[u] = (i < np) ? pool_slot[i] : 0; }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int i = base + u * T + t;
+      const float4* mp = reinterpret_cast<const float4*>(kdense + static_cast<size_t>(slot[u]) * 8);
+      st[u] = (i < np) ? t_state[slot[u]] : 0;
+      ma[u] = (i < np) ? mp[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+      mv[u] = (i < np) ? mp[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int i = base + u * T + t;
+      if (i < np) {
+        pred_src[i] = slot[u];
+        pred_dst[i] = slot[u];
+        // only the predicted BOXES are needed now; a matched track is re-predicted inside its update (MOT_KF_PREDICT_FIRST)
+        const bool zero_v7 = st[u] != Tracked;
+        pred_flags[i] = (zero_v7 ? MOT_KF_ZERO_V7 : 0) | MOT_KF_NO_STORE;
+        float4 v = mv[u];
+        if (zero_v7) v.w = 0.0f;  // (predicted_box)
+        store_box(pool_box, CAP, i, xyah_box4(ma[u].x + v.x, ma[u].y + v.y, ma[u].z + v.z, ma[u].w + v.w));
+      }
+    }
   }
-  for (int i = t; i < nu; i += static_cast<int>(blockDim.x)) store_box(S.ubox, CAP, i, stored_box(S.kdense, S.unconf_slot[i]));  // (third association)
+  for (int i = t; i < nu; i += T) store_box(ubox, CAP, i, stored_box(kdense, unconf_slot[i]));  // (third association)
   if (t == 0) {
     S.n_high = nh; S.n_second = ns; S.n_pool = np; S.n_tracked = n_tracked; S.n_unconf = nu;
     S.n_upd = 0; S.n_refind = 0; S.n_utrack = 0; S.n_udet = 0; S.n_r = 0; S.n_init = 0; S.n_lost_new = 0; S.lap2_q = 0; S.lap3_q = 0;
@@ -234,39 +290,81 @@ __global__ void __launch_bounds__(kAFMax) bt_after_first(BtStream* streams, BtPa
   const int np = S.n_pool, nd = S.n_high;
   const bool have = np > 0 && nd > 0;
   int n_upd = 0, n_ref = 0, n_ut = 0, n_ud = 0;
-  for (int i0 = 0; i0 < np; i0 += static_cast<int>(blockDim.x)) {
-    const int i = i0 + t;
-    const bool v = i < np;
-    const int x = (v && have) ? S.x1[i] : -1;
-    const int slot = v ? S.pool_slot[i] : 0;
-    const bool m = v && x >= 0;
-    const bool was_tracked = m && S.t_state[slot] == Tracked;
-    const bool rf = m && !was_tracked;
-    const bool um = v && x < 0;
-    const Compact3 c = compact3_block(m, rf, um, n_upd, n_ref, n_ut, cnt);
-    if (m) {
-      const int pu = c.pos[0];
-      const int det = S.high[x];
-      S.upd_src[pu] = slot; S.upd_dst[pu] = slot; S.upd_meas[pu] = det;
-      S.upd_flags[pu] = (S.pred_flags[i] & MOT_KF_ZERO_V7) | MOT_KF_PREDICT_FIRST;  // the update starts from the PREDICTED copy (:251-265)
-      // STrack::update :71-89 / re_activate :55-69
-      if (was_tracked) { S.t_fid[slot] = S.frame_count; S.t_tlen[slot] += 1; }
-      else { S.t_tlen[slot] = 0; S.t_fid[slot] = S.frame_count; }
-      S.t_state[slot] = Tracked; S.t_act[slot] = 1;
-      S.t_conf[slot] = S.dets[static_cast<size_t>(4) * S.ld + det];
-      S.t_cls[slot] = static_cast<int>(S.dets[static_cast<size_t>(5) * S.ld + det]);
-      S.t_det[slot] = det;
+  // Round 6: the loops below were chains of dependent loads — list entry, then the slot's fields, then the detection's — walked one 256-entry chunk at
+  // a time: 28 memory round trips per stream, each ~2 us with 6 144 streams in flight (the kernel ran 286 us per launch for 6 MB of traffic). Now a
+  // thread takes kU chunks at once: the loads of one LEVEL of all its entries are issued together (the slots of a list are distinct, so reading a later
+  // chunk's fields before an earlier chunk's are written changes nothing), the order-preserving compaction — ballots, LDS, barriers, no memory — then
+  // runs chunk by chunk as before. The pointers are read from the stream record once (every barrier made the compiler reload them).
+  constexpr int kU = 4;
+  const int T = static_cast<int>(blockDim.x);
+  const int* __restrict__ x1 = S.x1; const int* __restrict__ y1 = S.y1; const int* __restrict__ pool_slot = S.pool_slot; const int* __restrict__ high = S.high;
+  int* __restrict__ t_state = S.t_state; int* __restrict__ t_tlen = S.t_tlen; int* __restrict__ t_fid = S.t_fid; int* __restrict__ t_act = S.t_act;
+  int* __restrict__ t_cls = S.t_cls; int* __restrict__ t_det = S.t_det; float* __restrict__ t_conf = S.t_conf;
+  int* __restrict__ upd_src = S.upd_src; int* __restrict__ upd_dst = S.upd_dst; int* __restrict__ upd_meas = S.upd_meas; unsigned char* __restrict__ upd_flags = S.upd_flags;
+  const unsigned char* __restrict__ pred_flags = S.pred_flags; int* __restrict__ refind = S.refind; int* __restrict__ u_track = S.u_track; int* __restrict__ u_det = S.u_det;
+  const float* __restrict__ dconf = S.dets + static_cast<size_t>(4) * S.ld; const float* __restrict__ dcls = S.dets + static_cast<size_t>(5) * S.ld;
+  const int frame_count = S.frame_count, n_tracked = S.n_tracked;
+  for (int base = 0; base < np; base += kU * T) {
+    int xs[kU], slot[kU], st[kU], det[kU], tl[kU];
+    unsigned char pf[kU];
+    float cf[kU], cl[kU];
+    bool v[kU], m[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int i = base + u * T + t;
+      v[u] = i < np;
+      xs[u] = (v[u] && have) ? x1[i] : -1;
+      slot[u] = v[u] ? pool_slot[i] : 0;
+      pf[u] = v[u] ? pred_flags[i] : 0;
     }
-    if (rf) S.refind[c.pos[1]] = slot;
-    if (um) S.u_track[c.pos[2]] = i;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      m[u] = v[u] && xs[u] >= 0;
+      st[u] = m[u] ? t_state[slot[u]] : 0;
+      tl[u] = m[u] ? t_tlen[slot[u]] : 0;
+      det[u] = m[u] ? high[xs[u]] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      cf[u] = m[u] ? dconf[det[u]] : 0.0f;
+      cl[u] = m[u] ? dcls[det[u]] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (base + u * T >= np) break;  // (uniform)
+      const int i = base + u * T + t;
+      const bool was_tracked = m[u] && st[u] == Tracked;
+      const bool rf = m[u] && !was_tracked;
+      const bool um = v[u] && xs[u] < 0;
+      const Compact3 c = compact3_block(m[u], rf, um, n_upd, n_ref, n_ut, cnt);
+      if (m[u]) {
+        const int pu = c.pos[0], sl = slot[u];
+        upd_src[pu] = sl; upd_dst[pu] = sl; upd_meas[pu] = det[u];
+        upd_flags[pu] = (pf[u] & MOT_KF_ZERO_V7) | MOT_KF_PREDICT_FIRST;  // the update starts from the PREDICTED copy (:251-265)
+        // STrack::update :71-89 / re_activate :55-69
+        t_tlen[sl] = was_tracked ? tl[u] + 1 : 0;
+        t_fid[sl] = frame_count;
+        t_state[sl] = Tracked; t_act[sl] = 1;
+        t_conf[sl] = cf[u];
+        t_cls[sl] = static_cast<int>(cl[u]);
+        t_det[sl] = det[u];
+      }
+      if (rf) refind[c.pos[1]] = slot[u];
+      if (um) u_track[c.pos[2]] = i;
+    }
   }
   {
     int z1 = 0, z2 = 0;
-    for (int j0 = 0; j0 < nd; j0 += static_cast<int>(blockDim.x)) {
-      const int j = j0 + t;
-      const bool u = j < nd && (!have || S.y1[j] < 0);
-      const Compact3 c = compact3_block(u, false, false, n_ud, z1, z2, cnt);
-      if (u) S.u_det[c.pos[0]] = j;
+    for (int base = 0; base < nd; base += kU * T) {
+      bool un[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) { const int j = base + u * T + t; un[u] = j < nd && (!have || y1[j] < 0); }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (base + u * T >= nd) break;
+        const Compact3 c = compact3_block(un[u], false, false, n_ud, z1, z2, cnt);
+        if (un[u]) u_det[c.pos[0]] = base + u * T + t;
+      }
     }
   }
   __syncthreads();
@@ -274,16 +372,42 @@ __global__ void __launch_bounds__(kAFMax) bt_after_first(BtStream* streams, BtPa
   int n_r = 0;
   {
     int z1 = 0, z2 = 0;
-    for (int k0 = 0; k0 < n_ut; k0 += static_cast<int>(blockDim.x)) {
-      const int k = k0 + t;
-      const int i = (k < n_ut) ? S.u_track[k] : 0;
-      const int slot = (k < n_ut) ? S.pool_slot[i] : 0;
-      const bool r = k < n_ut && i < S.n_tracked && S.t_state[slot] == Tracked;
-      const Compact3 c = compact3_block(r, false, false, n_r, z1, z2, cnt);
-      if (r) { S.r_slot[c.pos[0]] = slot; S.r_pool[c.pos[0]] = i; store_box(S.rbox, CAP, c.pos[0], stored_box(S.kdense, slot)); }
+    int* __restrict__ r_slot = S.r_slot; int* __restrict__ r_pool = S.r_pool; float* __restrict__ rbox = S.rbox; const float* __restrict__ kdense = S.kdense;
+    for (int base = 0; base < n_ut; base += kU * T) {
+      int pi[kU], sl[kU], stt[kU];
+      float4 bx[kU];
+      bool in[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) { const int k = base + u * T + t; in[u] = k < n_ut; pi[u] = in[u] ? u_track[k] : 0; }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) sl[u] = in[u] ? pool_slot[pi[u]] : 0;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const bool cand = in[u] && pi[u] < n_tracked;
+        stt[u] = cand ? t_state[sl[u]] : Removed;
+        bx[u] = cand ? stored_box(kdense, sl[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (base + u * T >= n_ut) break;
+        const bool r = in[u] && pi[u] < n_tracked && stt[u] == Tracked;
+        const Compact3 c = compact3_block(r, false, false, n_r, z1, z2, cnt);
+        if (r) { r_slot[c.pos[0]] = sl[u]; r_pool[c.pos[0]] = pi[u]; store_box(rbox, CAP, c.pos[0], bx[u]); }
+      }
     }
   }
-  for (int k = t; k < n_ud; k += static_cast<int>(blockDim.x)) S.rem[k] = S.high[S.u_det[k]];
+  {
+    int* __restrict__ rem = S.rem;
+    for (int base = 0; base < n_ud; base += kU * T) {
+      int j[kU], h[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) { const int k = base + u * T + t; j[u] = (k < n_ud) ? u_det[k] : 0; }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) { const int k = base + u * T + t; h[u] = (k < n_ud) ? high[j[u]] : 0; }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) { const int k = base + u * T + t; if (k < n_ud) rem[k] = h[u]; }
+    }
+  }
   __syncthreads();
   if (t == 0) {
     S.n_upd = n_upd; S.n_refind = n_ref; S.n_utrack = n_ut; S.n_udet = n_ud; S.n_r = n_r;
@@ -432,24 +556,40 @@ __global__ void __launch_bounds__(kAFMax) bt_after_second(BtStream* streams, BtP
   const int n_active = S.n_active, n_lost = S.n_lost, n_refind = S.n_refind;
   const int* lst = S.lost[S.cur];
   const int* act = S.active[S.cur];
-  for (int i = t; i < n_lost; i += static_cast<int>(blockDim.x)) {  // :557-562
-    const int slot = lst[i];
-    if (S.frame_count - S.t_fid[slot] > P.max_time_lost) S.t_state[slot] = Removed;
+  // (round 6: kU chunks per thread, the loads of a level issued together — see bt_after_first)
+  constexpr int kU = 4;
+  const int T = static_cast<int>(blockDim.x);
+  int* __restrict__ t_state = S.t_state; const int* __restrict__ t_fid = S.t_fid; const int* __restrict__ t_sf = S.t_sf; int* __restrict__ free_stack = S.free_stack;
+  const int frame_count = S.frame_count;
+  for (int base = 0; base < n_lost; base += kU * T) {  // :557-562
+    int slot[kU], fid[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; slot[u] = (i < n_lost) ? lst[i] : 0; }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; fid[u] = (i < n_lost) ? t_fid[slot[u]] : frame_count; }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; if (i < n_lost && frame_count - fid[u] > P.max_time_lost) t_state[slot[u]] = Removed; }
   }
   __syncthreads();
   // list algebra (:565-580). A track lives in exactly one record, so the reference's copies are moves.
-  int* na = S.active[S.cur ^ 1];
-  int* nl = S.lost[S.cur ^ 1];
+  int* __restrict__ na = S.active[S.cur ^ 1];
+  int* __restrict__ nl = S.lost[S.cur ^ 1];
   int n_na = 0, n_nl = 0, z = 0;
-  for (int i0 = 0; i0 < n_active; i0 += static_cast<int>(blockDim.x)) {
-    const int i = i0 + t;
-    const int slot = (i < n_active) ? act[i] : 0;
-    const int st = (i < n_active) ? S.t_state[slot] : -1;
-    const bool k = st == Tracked;
-    const bool dead = st == Removed;
-    const Compact3 c = compact3_block(k, dead, false, n_na, free_top, z, cnt);
-    if (k) na[c.pos[0]] = slot;
-    if (dead) S.free_stack[c.pos[1]] = slot;
+  for (int base = 0; base < n_active; base += kU * T) {
+    int slot[kU], st[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; slot[u] = (i < n_active) ? act[i] : 0; }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; st[u] = (i < n_active) ? t_state[slot[u]] : -1; }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (base + u * T >= n_active) break;  // (uniform)
+      const bool k = st[u] == Tracked;
+      const bool dead = st[u] == Removed;
+      const Compact3 c = compact3_block(k, dead, false, n_na, free_top, z, cnt);
+      if (k) na[c.pos[0]] = slot[u];
+      if (dead) free_stack[c.pos[1]] = slot[u];
+    }
   }
   // the new tracks' Kalman records (round 5: here instead of a launch of kf_kernel<XYAH, initiate> — a handful of births per stream and frame;
   // KalmanFilterXYAH::initiate as kf_kernels.hip::s8_init<MOT_KF_XYAH> writes it: mean = (z, 0), P = diag(sd^2))
@@ -479,24 +619,50 @@ __global__ void __launch_bounds__(kAFMax) bt_after_second(BtStream* streams, BtP
     for (int i = t; i < n_refind; i += static_cast<int>(blockDim.x)) na[n_na + i] = S.refind[i];  // re-found lost tracks, in match order
     n_na += n_refind;
   }
-  for (int i0 = 0; i0 < n_lost; i0 += static_cast<int>(blockDim.x)) {
-    const int i = i0 + t;
-    const int slot = (i < n_lost) ? lst[i] : 0;
-    const int st = (i < n_lost) ? S.t_state[slot] : -1;
-    const bool k = st == Lost;          // Tracked = re-found (now active), Removed = aged out
-    const bool dead = st == Removed;
-    const Compact3 c = compact3_block(k, dead, false, n_nl, free_top, z, cnt);
-    if (k) nl[c.pos[0]] = slot;
-    if (dead) S.free_stack[c.pos[1]] = slot;
+  for (int base = 0; base < n_lost; base += kU * T) {
+    int slot[kU], st[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; slot[u] = (i < n_lost) ? lst[i] : 0; }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; st[u] = (i < n_lost) ? t_state[slot[u]] : -1; }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (base + u * T >= n_lost) break;
+      const bool k = st[u] == Lost;          // Tracked = re-found (now active), Removed = aged out
+      const bool dead = st[u] == Removed;
+      const Compact3 c = compact3_block(k, dead, false, n_nl, free_top, z, cnt);
+      if (k) nl[c.pos[0]] = slot[u];
+      if (dead) free_stack[c.pos[1]] = slot[u];
+    }
   }
   if (n_nl + n_ln > CAP) err = 1;
   else {
-    for (int i = t; i < n_ln; i += static_cast<int>(blockDim.x)) nl[n_nl + i] = S.lost_new[i];
+    for (int i = t; i < n_ln; i += T) nl[n_nl + i] = S.lost_new[i];
     n_nl += n_ln;
   }
   __syncthreads();
-  for (int i = t; i < n_na && i < CAP; i += static_cast<int>(blockDim.x)) { const int slot = na[i]; S.age_a[i] = S.t_fid[slot] - S.t_sf[slot]; S.dup_a[i] = 0; }
-  for (int i = t; i < n_nl && i < CAP; i += static_cast<int>(blockDim.x)) { const int slot = nl[i]; S.age_b[i] = S.t_fid[slot] - S.t_sf[slot]; S.dup_b[i] = 0; }
+  {
+    int* __restrict__ age_a = S.age_a; int* __restrict__ age_b = S.age_b; unsigned char* __restrict__ dup_a = S.dup_a; unsigned char* __restrict__ dup_b = S.dup_b;
+    const int ea = (n_na < CAP) ? n_na : CAP, eb = (n_nl < CAP) ? n_nl : CAP;
+    for (int base = 0; base < ea; base += kU * T) {
+      int slot[kU], f[kU], sf[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; slot[u] = (i < ea) ? na[i] : 0; }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; f[u] = (i < ea) ? t_fid[slot[u]] : 0; sf[u] = (i < ea) ? t_sf[slot[u]] : 0; }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; if (i < ea) { age_a[i] = f[u] - sf[u]; dup_a[i] = 0; } }
+    }
+    for (int base = 0; base < eb; base += kU * T) {
+      int slot[kU], f[kU], sf[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; slot[u] = (i < eb) ? nl[i] : 0; }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; f[u] = (i < eb) ? t_fid[slot[u]] : 0; sf[u] = (i < eb) ? t_sf[slot[u]] : 0; }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) { const int i = base + u * T + t; if (i < eb) { age_b[i] = f[u] - sf[u]; dup_b[i] = 0; } }
+    }
+  }
   if (t == 0) {
     S.n_upd = n_upd; S.n_init = n_init; S.n_lost_new = n_ln;
     S.next_id += n_init; S.next_slot = next_slot; S.n_free = free_top;
@@ -551,8 +717,13 @@ __device__ __forceinline__ void bt_dups_body(BtStream& S, int CAP, int verify, i
   }
   if (MODE == 1 && staged) {
     if (threadIdx.x == 0) n_irr = 0;
-    for (int j = threadIdx.x; j < nl; j += T)
-      wl[j] = stored_box(S.kdense, lst[j]);
+    for (int base = 0; base < nl; base += 4 * T) {
+      int sl[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int j = base + u * T + static_cast<int>(threadIdx.x); sl[u] = (j < nl) ? lst[j] : 0; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int j = base + u * T + static_cast<int>(threadIdx.x); if (j < nl) wl[j] = stored_box(S.kdense, sl[u]); }
+    }
     __syncthreads();
     // rank by (key, index) with key = x1, or -inf for a box with a non-finite coordinate: nl is a few hundred at most,
     // counting against the key array (one broadcast LDS read and three VALU operations per comparison) beats a sorting network
@@ -577,11 +748,24 @@ __device__ __forceinline__ void bt_dups_body(BtStream& S, int CAP, int verify, i
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < na; i += T) {
-    const float4 ab = stored_box(S.kdense, act[i]);
+  // (round 6: the boxes and ages of kU of a thread's active tracks are fetched together — list entry, then the slot's mean: two dependent loads that
+  // four chunks used to pay one after the other)
+  constexpr int kU = 4;
+  for (int base = 0; base < na; base += kU * T) {
+  int slot_u[kU], age_u[kU];
+  float4 box_u[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) { const int i = base + u * T + static_cast<int>(threadIdx.x); slot_u[u] = (i < na) ? act[i] : 0; age_u[u] = (i < na) ? S.age_a[i] : 0; }
+#pragma unroll
+  for (int u = 0; u < kU; ++u) { const int i = base + u * T + static_cast<int>(threadIdx.x); box_u[u] = (i < na) ? stored_box(S.kdense, slot_u[u]) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const int i = base + u * T + static_cast<int>(threadIdx.x);
+    if (i >= na) continue;
+    const float4 ab = box_u[u];
     const float a[4] = {ab.x, ab.y, ab.z, ab.w};
     const float area_a = (a[2] - a[0]) * (a[3] - a[1]);
-    const int age_a = S.age_a[i];
+    const int age_a = age_u[u];
     bool dup_me = false;
     auto test = [&](int j, bool mark) {
       float4 bb;
@@ -627,6 +811,7 @@ __device__ __forceinline__ void bt_dups_body(BtStream& S, int CAP, int verify, i
     }
     if (dup_me) S.dup_a[i] = 1;
   }
+  }
 }
 template <int MODE>
 __global__ void __launch_bounds__(kAFMax) bt_dups(BtStream* streams, int CAP, int verify, int lds_items) {
@@ -653,45 +838,69 @@ __device__ __forceinline__ void bt_finish_body(BtStream& S, int CAP, float* out,
   const bool dups = n_active > 0 && n_lost > 0;
   int free_top = S.n_free;
   int n_keep = 0, n_rows = 0;
-  for (int i0 = 0; i0 < n_active; i0 += static_cast<int>(blockDim.x)) {
-    const int i = i0 + t;
-    const bool v = i < n_active;
-    const int slot = v ? act[i] : 0;
-    const bool dup = v && dups && S.dup_a[i] != 0;
-    const bool keep = v && !dup;
-    const bool emit = keep && S.t_act[slot] != 0;
-    float b[4] = {0.f, 0.f, 0.f, 0.f};
-    float rid = 0.f, rconf = 0.f, rcls = 0.f, rdet = 0.f;
-    if (emit) {
+  // (round 6: kU chunks per thread, the loads of a level issued together — see bt_after_first. The lists are compacted in place: an entry lands at
+  // p <= i, so the entries a thread has read ahead are never ones an earlier chunk overwrites)
+  constexpr int kU = 4;
+  const int T = static_cast<int>(blockDim.x);
+  const unsigned char* __restrict__ dup_a = S.dup_a; const unsigned char* __restrict__ dup_b = S.dup_b;
+  const int* __restrict__ t_act = S.t_act; const int* __restrict__ t_id = S.t_id; const int* __restrict__ t_cls = S.t_cls; const int* __restrict__ t_det = S.t_det;
+  const float* __restrict__ t_conf = S.t_conf; const float* __restrict__ kdense = S.kdense; int* __restrict__ free_stack = S.free_stack;
+  for (int base = 0; base < n_active; base += kU * T) {
+    int slot[kU], ta[kU], rid[kU], rcls[kU], rdet[kU];
+    float rconf[kU];
+    float4 ob[kU];
+    bool v[kU], dup[kU], emit[kU];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) b[k] = 0.f;
-      const float4 ob = stored_box(S.kdense, slot);
-      b[0] = ob.x; b[1] = ob.y; b[2] = ob.z; b[3] = ob.w;
-      rid = static_cast<float>(S.t_id[slot]); rconf = S.t_conf[slot];
-      rcls = static_cast<float>(S.t_cls[slot]); rdet = static_cast<float>(S.t_det[slot]);
+    for (int u = 0; u < kU; ++u) {
+      const int i = base + u * T + t;
+      v[u] = i < n_active;
+      slot[u] = v[u] ? act[i] : 0;
+      dup[u] = v[u] && dups && dup_a[i] != 0;
     }
-    // (the barrier inside: act[] entries of this chunk are read before the compacted list overwrites them, p <= i)
-    const Compact3 c = compact3_block(keep, emit, dup, n_keep, n_rows, free_top, cnt);
-    if (keep) act[c.pos[0]] = slot;
-    if (emit && c.pos[1] < cap_out) {
-      float4* r = reinterpret_cast<float4*>(rows + static_cast<size_t>(c.pos[1]) * 8);
-      r[0] = make_float4(b[0], b[1], b[2], b[3]);
-      r[1] = make_float4(rid, rconf, rcls, rdet);
+#pragma unroll
+    for (int u = 0; u < kU; ++u) ta[u] = (v[u] && !dup[u]) ? t_act[slot[u]] : 0;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      emit[u] = v[u] && !dup[u] && ta[u] != 0;
+      ob[u] = emit[u] ? stored_box(kdense, slot[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rid[u] = emit[u] ? t_id[slot[u]] : 0; rconf[u] = emit[u] ? t_conf[slot[u]] : 0.f;
+      rcls[u] = emit[u] ? t_cls[slot[u]] : 0; rdet[u] = emit[u] ? t_det[slot[u]] : 0;
     }
-    if (dup) S.free_stack[c.pos[2]] = slot;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (base + u * T >= n_active) break;  // (uniform)
+      const bool keep = v[u] && !dup[u];
+      const Compact3 c = compact3_block(keep, emit[u], dup[u], n_keep, n_rows, free_top, cnt);
+      if (keep) act[c.pos[0]] = slot[u];
+      if (emit[u] && c.pos[1] < cap_out) {
+        float4* r = reinterpret_cast<float4*>(rows + static_cast<size_t>(c.pos[1]) * 8);
+        r[0] = ob[u];
+        r[1] = make_float4(static_cast<float>(rid[u]), rconf[u], static_cast<float>(rcls[u]), static_cast<float>(rdet[u]));
+      }
+      if (dup[u]) free_stack[c.pos[2]] = slot[u];
+    }
   }
   int n_keep_l = 0;
   {
     int z = 0;
-    for (int i0 = 0; i0 < n_lost; i0 += static_cast<int>(blockDim.x)) {
-      const int i = i0 + t;
-      const bool v = i < n_lost;
-      const int slot = v ? lst[i] : 0;
-      const bool dup = v && dups && S.dup_b[i] != 0;
-      const bool keep = v && !dup;
-      const Compact3 c = compact3_block(keep, dup, false, n_keep_l, free_top, z, cnt);
-      if (keep) lst[c.pos[0]] = slot;
-      if (dup) S.free_stack[c.pos[1]] = slot;
+    for (int base = 0; base < n_lost; base += kU * T) {
+      int slot[kU];
+      bool v[kU], dup[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int i = base + u * T + t;
+        v[u] = i < n_lost;
+        slot[u] = v[u] ? lst[i] : 0;
+        dup[u] = v[u] && dups && dup_b[i] != 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (base + u * T >= n_lost) break;
+        const bool keep = v[u] && !dup[u];
+        const Compact3 c = compact3_block(keep, dup[u], false, n_keep_l, free_top, z, cnt);
+        if (keep) lst[c.pos[0]] = slot[u];
+        if (dup[u]) free_stack[c.pos[1]] = slot[u];
+      }
     }
   }
   if (t == 0) {
@@ -800,7 +1009,7 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
   const int S = nstreams, CAP = cap_tracks, D = max_dets, C2 = cap_tracks;  // (no scratch slots: predictions are box-only)
   const size_t ints_per = static_cast<size_t>(CAP) * 28 + static_cast<size_t>(D) * 9;
   int* ip = b->dalloc<int>(ints_per * S);
-  float* fp = b->dalloc<float>((static_cast<size_t>(CAP) * (1 + 4 * 5) + static_cast<size_t>(D) * 8) * S);
+  float* fp = b->dalloc<float>((static_cast<size_t>(CAP) * (1 + 4 * 5) + static_cast<size_t>(D) * 12) * S);
   unsigned char* bp = b->dalloc<unsigned char>(static_cast<size_t>(CAP) * 4 * S);
   b->mean = b->dalloc<float>(static_cast<size_t>(S) * 64 * C2);  // (covariance records of 256 bytes; hipMalloc aligns to 256)
   b->mean_dense = b->dalloc<float>(static_cast<size_t>(S) * 8 * C2);
@@ -848,13 +1057,14 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
     T.x1 = I(CAP); T.x2 = I(CAP); T.x3 = I(CAP); T.upd_src = I(CAP); T.upd_dst = I(CAP); T.upd_meas = I(CAP);
     T.refind = I(CAP); T.u_track = I(CAP); T.r_slot = I(CAP); T.r_pool = I(CAP); T.lost_new = I(CAP);  // 28 CAP-sized arrays
     T.high = I(D); T.second = I(D); T.y1 = I(D); T.y2 = I(D); T.y3 = I(D); T.u_det = I(D); T.rem = I(D); T.init_dst = I(D); T.init_meas = I(D);
-    float* f = fp + (static_cast<size_t>(CAP) * 21 + static_cast<size_t>(D) * 8) * s;
+    float* f = fp + (static_cast<size_t>(CAP) * 21 + static_cast<size_t>(D) * 12) * s;
     auto F = [&](int n) { float* r = f; f += n; return r; };
     T.t_conf = F(CAP);
     float* pool_box = F(4 * CAP); float* rbox = F(4 * CAP); float* ubox = F(4 * CAP); T.abox = F(4 * CAP); float* lbox = F(4 * CAP);
     T.lbox = lbox;
     T.pool_box = pool_box; T.rbox = rbox; T.ubox = ubox;
     float* d_box = F(4 * D); float* d_meas = F(4 * D);
+    T.dmeas4 = F(4 * D);
     unsigned char* u = bp + static_cast<size_t>(CAP) * 4 * s;
     T.pred_flags = u; T.dup_a = u + CAP; T.dup_b = u + 2 * CAP; T.upd_flags = u + 3 * CAP;
     float* mean = b->mean + static_cast<size_t>(s) * 64 * C2;
@@ -872,7 +1082,7 @@ int mot_bt_create(mot_ctx* ctx, int nstreams, int cap_tracks, int max_dets, cons
     kf(box[2 * s + 1]); box[2 * s + 1].src = T.unconf_slot; box[2 * s + 1].boxes = ubox; box[2 * s + 1].ldb = CAP;
     kf(init[s]); init[s].src = T.init_dst; init[s].dst = T.init_dst; init[s].meas = d_meas; init[s].ldm = D; init[s].midx = T.init_meas;
     kf(upd[s]); upd[s].src = T.upd_src; upd[s].dst = T.upd_dst; upd[s].meas = d_meas; upd[s].ldm = D; upd[s].midx = T.upd_meas;
-    upd[s].flags = T.upd_flags; upd[s].mean_dense = T.kdense; upd[s].cov_blocks = T.kblk; upd[s].dense_flag = T.kflag;
+    upd[s].flags = T.upd_flags; upd[s].mean_dense = T.kdense; upd[s].cov_blocks = T.kblk; upd[s].dense_flag = T.kflag; upd[s].meas4 = T.dmeas4;
     updf[s] = upd[s];  // the same filter on the 64-float records, over the lists the block-form kernel fills
     { int* fi = b->fb_i + static_cast<size_t>(s) * 3 * C2; updf[s].src = fi; updf[s].dst = fi + C2; updf[s].midx = fi + 2 * C2; updf[s].flags = b->fb_f + static_cast<size_t>(s) * C2; updf[s].n = 0; }
     kf(box2[2 * s]); box2[2 * s].boxes = T.abox; box2[2 * s].ldb = CAP;

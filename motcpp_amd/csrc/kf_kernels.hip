@@ -766,31 +766,94 @@ __global__ void __launch_bounds__(TPB * 8) __attribute__((amdgpu_waves_per_eu(KI
 // touched here: its blocks are expanded into its 64-float record, its flag is set, and it goes — this frame and from now on — through
 // kf_update8_kernel (the `fallback` task of the same stream, filled here). 96 bytes in and out per track instead of 576, four lanes per track.
 constexpr int kBlkTracks = 64;
-template <int KIND>
+template <int KIND, int kBlkItems>  // kBlkItems: tracks per quad of lanes and turn
 __global__ void __launch_bounds__(kBlkTracks * 4) kf_update_blocks_kernel(const mot_kf_task* __restrict__ tasks, mot_kf_task* __restrict__ fallback) {
   static_assert(KIND == MOT_KF_XYAH, "block form: the XYAH filter (ByteTrack)");
-  const mot_kf_task T = tasks[blockIdx.y];
-  mot_kf_task& F = fallback[blockIdx.y];
+  // grid = (tasks, turns): consecutive workgroups — which the dispatcher deals round-robin to the eight XCDs — are the same turn of consecutive streams.
+  // With the turns in x, a stream's four busy workgroups of eight always landed on XCDs 0-3 and the four that exit at once on XCDs 4-7: with the GPU to
+  // itself the kernel took 0.39 ms instead of 0.22
+  const mot_kf_task T = tasks[blockIdx.x];
+  mot_kf_task& F = fallback[blockIdx.x];
   const int tid = threadIdx.x, c = tid & 3;
-  for (int base = blockIdx.x * kBlkTracks; base < T.n; base += gridDim.x * kBlkTracks) {
-    const int item = base + (tid >> 2);
-    const bool active = item < T.n;
-    int slot = 0, mi = 0;
-    unsigned f = 0u;
-    float z = 0.0f, zc = 0.0f, m0 = 0.0f, m1 = 0.0f;
-    float4 blk = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool dense = false;
-    if (active) {
-      slot = T.src ? T.src[item] : item;
-      mi = T.midx ? T.midx[item] : item;
-      f = T.flags ? T.flags[item] : 0u;
-      z = T.meas[static_cast<size_t>(c) * T.ldm + mi];
-      if (T.conf) zc = T.conf[mi];
-      m0 = T.mean_dense[static_cast<size_t>(slot) * 8 + c];
-      m1 = T.mean_dense[static_cast<size_t>(slot) * 8 + c + 4];
-      blk = reinterpret_cast<const float4*>(T.cov_blocks)[static_cast<size_t>(slot) * 4 + c];
-      dense = T.dense_flag[slot] != 0;
+  const bool fast = T.src && T.dst && T.midx && T.flags && T.meas4 && !T.conf;  // (uniform)
+  // A workgroup's turn is kBlkItems tracks per quad of lanes, their loads issued level by level (list entries; then mean, blocks, measurement): the
+  // kernel is two dependent round trips and a store per track, and with one track per quad the CU's 32 wavefronts kept too few of them in flight
+  // (0.33 of HBM; the destination index, read only when the result was ready, was a third trip in front of the stores)
+  for (int base0 = blockIdx.y * kBlkTracks * kBlkItems; base0 < T.n; base0 += gridDim.y * kBlkTracks * kBlkItems) {
+    int slot_u[kBlkItems], mi_u[kBlkItems], ds_u[kBlkItems];
+    unsigned f_u[kBlkItems];
+    float z_u[kBlkItems], zc_u[kBlkItems], m0_u[kBlkItems], m1_u[kBlkItems];
+    float4 blk_u[kBlkItems];
+    bool dense_u[kBlkItems];
+    if (fast) {
+      // the device lifecycle's task: every list is there, measurements as [n][4], no confidences. Unconditional loads through global pointers, an entry
+      // past the end reads the last one and is masked afterwards — the generic form below compiles to a branch and a full wait per optional pointer
+      // (ten dependent groups of flat loads where two levels are meant)
+      typedef const int32_t __attribute__((address_space(1))) * gint;
+      typedef const float __attribute__((address_space(1))) * gfloat;
+      typedef float __attribute__((ext_vector_type(4))) f4v;
+      typedef const f4v __attribute__((address_space(1))) * gfloat4;
+      typedef const unsigned char __attribute__((address_space(1))) * gbyte;
+      const gint src = (gint)T.src, dst = (gint)T.dst, midx = (gint)T.midx;
+      const gbyte flg = (gbyte)T.flags, dfl = (gbyte)T.dense_flag;
+      const gfloat md = (gfloat)T.mean_dense, m4 = (gfloat)T.meas4;
+      const gfloat4 cb = (gfloat4)T.cov_blocks;
+#pragma unroll
+      for (int u = 0; u < kBlkItems; ++u) {
+        const int item = base0 + u * kBlkTracks + (tid >> 2);
+        const int it = (item < T.n) ? item : T.n - 1;
+        slot_u[u] = src[it]; mi_u[u] = midx[it]; f_u[u] = flg[it]; ds_u[u] = dst[it];
+      }
+#pragma unroll
+      for (int u = 0; u < kBlkItems; ++u) {
+        const size_t slot = static_cast<size_t>(slot_u[u]);
+        z_u[u] = m4[static_cast<size_t>(mi_u[u]) * 4 + c];
+        zc_u[u] = 0.0f;
+        m0_u[u] = md[slot * 8 + c];
+        m1_u[u] = md[slot * 8 + c + 4];
+        const f4v bv = cb[slot * 4 + c];
+        blk_u[u] = make_float4(bv.x, bv.y, bv.z, bv.w);
+        dense_u[u] = dfl[slot] != 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kBlkItems; ++u) {
+        const bool active = base0 + u * kBlkTracks + (tid >> 2) < T.n;
+        if (!active) { slot_u[u] = 0; mi_u[u] = 0; f_u[u] = 0u; z_u[u] = 0.0f; m0_u[u] = 0.0f; m1_u[u] = 0.0f; blk_u[u] = make_float4(0.f, 0.f, 0.f, 0.f); dense_u[u] = false; }
+      }
+    } else {
+#pragma unroll
+    for (int u = 0; u < kBlkItems; ++u) {
+      const int item = base0 + u * kBlkTracks + (tid >> 2);
+      const bool active = item < T.n;
+      slot_u[u] = active ? (T.src ? T.src[item] : item) : 0;
+      mi_u[u] = active ? (T.midx ? T.midx[item] : item) : 0;
+      f_u[u] = (active && T.flags) ? T.flags[item] : 0u;
+      ds_u[u] = (active && T.dst) ? T.dst[item] : -1;
     }
+#pragma unroll
+    for (int u = 0; u < kBlkItems; ++u) {
+      const int item = base0 + u * kBlkTracks + (tid >> 2);
+      const bool active = item < T.n;
+      const int slot = slot_u[u], mi = mi_u[u];
+      z_u[u] = active ? (T.meas4 ? T.meas4[static_cast<size_t>(mi) * 4 + c] : T.meas[static_cast<size_t>(c) * T.ldm + mi]) : 0.0f;
+      zc_u[u] = (active && T.conf) ? T.conf[mi] : 0.0f;
+      m0_u[u] = active ? T.mean_dense[static_cast<size_t>(slot) * 8 + c] : 0.0f;
+      m1_u[u] = active ? T.mean_dense[static_cast<size_t>(slot) * 8 + c + 4] : 0.0f;
+      blk_u[u] = active ? reinterpret_cast<const float4*>(T.cov_blocks)[static_cast<size_t>(slot) * 4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      dense_u[u] = active && T.dense_flag[slot] != 0;
+    }
+    }
+#pragma unroll
+    for (int u = 0; u < kBlkItems; ++u) {
+    const int item = base0 + u * kBlkTracks + (tid >> 2);
+    if (base0 + u * kBlkTracks >= T.n) break;  // (uniform)
+    const bool active = item < T.n;
+    const int slot = slot_u[u], mi = mi_u[u];
+    const unsigned f = f_u[u];
+    const float z = z_u[u], zc = zc_u[u];
+    float m0 = m0_u[u], m1 = m1_u[u];
+    const float4 blk = blk_u[u];
+    const bool dense = dense_u[u];
     float a = blk.x, b = blk.y, bp = blk.z, d = blk.w;
     const int l3 = (tid & 63 & ~3) | 3;  // the lane of this track's component 3 (the height)
     if (f & MOT_KF_PREDICT_FIRST) {  // s8_predict: x' = F x, P' = F P F^T + Q, the standard deviations from the height BEFORE the motion step
@@ -824,7 +887,7 @@ __global__ void __launch_bounds__(kBlkTracks * 4) kf_update_blocks_kernel(const 
     const int lane = tid & 63;
     const bool track_ok = ((bal >> (lane & ~3)) & 0xfull) == 0xfull;
     if (active && track_ok) {
-      const int ds = T.dst ? T.dst[item] : slot;
+      const int ds = T.dst ? ds_u[u] : slot;
       T.mean_dense[static_cast<size_t>(ds) * 8 + c] = m0n;
       T.mean_dense[static_cast<size_t>(ds) * 8 + c + 4] = m1n;
       reinterpret_cast<float4*>(T.cov_blocks)[static_cast<size_t>(ds) * 4 + c] = make_float4(an, bn, bpn, dn);
@@ -843,10 +906,11 @@ __global__ void __launch_bounds__(kBlkTracks * 4) kf_update_blocks_kernel(const 
         T.dense_flag[slot] = 1;
         const int k = atomicAdd(&F.n, 1);
         const_cast<int32_t*>(F.src)[k] = slot;
-        const_cast<int32_t*>(F.dst)[k] = T.dst ? T.dst[item] : slot;
+        const_cast<int32_t*>(F.dst)[k] = T.dst ? ds_u[u] : slot;
         const_cast<int32_t*>(F.midx)[k] = mi;
         const_cast<uint8_t*>(F.flags)[k] = static_cast<uint8_t>(f);
       }
+    }
     }
   }
 }
@@ -999,9 +1063,13 @@ namespace mot {
 // workgroup per task looks at a zero count)
 hipError_t launch_kf_update_blocks(const mot_kf_task* tasks, mot_kf_task* fallback, int ntasks, int max_n, hipStream_t st) {
   if (ntasks <= 0 || max_n <= 0) return hipSuccess;
-  const int want = (max_n + kBlkTracks - 1) / kBlkTracks;
-  dim3 grid((want < kUpdGroups) ? want : kUpdGroups, ntasks), block(kBlkTracks * 4);
-  hipLaunchKernelGGL((kf_update_blocks_kernel<MOT_KF_XYAH>), grid, block, 0, st, tasks, fallback);
+  static const int items = [] { const char* e = std::getenv("MOT_KF_BLK_ITEMS"); const int v = (e && *e) ? std::atoi(e) : 4; return (v == 1 || v == 2) ? v : 4; }();
+  const int want = (max_n + kBlkTracks * items - 1) / (kBlkTracks * items);
+  dim3 grid(ntasks, (want < kUpdGroups) ? want : kUpdGroups), block(kBlkTracks * 4);
+  // (MOT_KF_BLK_ITEMS = 1 / 2: the narrower forms, for measurements — north-star frame, same box, same runs: 2.98-3.00 / 3.00-3.04 / 3.08-3.14 M frames/s)
+  if (items == 1) hipLaunchKernelGGL((kf_update_blocks_kernel<MOT_KF_XYAH, 1>), grid, block, 0, st, tasks, fallback);
+  else if (items == 2) hipLaunchKernelGGL((kf_update_blocks_kernel<MOT_KF_XYAH, 2>), grid, block, 0, st, tasks, fallback);
+  else hipLaunchKernelGGL((kf_update_blocks_kernel<MOT_KF_XYAH, 4>), grid, block, 0, st, tasks, fallback);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((kf_update8_kernel<MOT_KF_XYAH, kUpdTracks>), dim3(1, ntasks), dim3(kUpdTracks * 8), 0, st, fallback);

@@ -12,7 +12,7 @@ class KfTask(C.Structure):
     _fields_ = [("mean", C.c_void_p), ("cov", C.c_void_p), ("cap", C.c_int32), ("n", C.c_int32), ("src", C.c_void_p), ("dst", C.c_void_p),
                 ("flags", C.c_void_p), ("meas", C.c_void_p), ("ldm", C.c_int32), ("midx", C.c_void_p), ("boxes", C.c_void_p), ("ldb", C.c_int32),
                 ("q", C.c_float * 3), ("reserved", C.c_int32), ("warp", C.c_float * 9), ("conf", C.c_void_p), ("mean_dense", C.c_void_p), ("cov_blocks", C.c_void_p),
-                ("dense_flag", C.c_void_p)]  # include/motcpp_amd.h: mot_kf_task
+                ("dense_flag", C.c_void_p), ("meas4", C.c_void_p)]  # include/motcpp_amd.h: mot_kf_task
 
 
 def main():

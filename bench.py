@@ -825,8 +825,8 @@ def main():
         duration_source = ("HIP events around the kernel's launches, sub-batches stepped one at a time right after the timed region (same trackers, full "
                            "sub-batches): the kernel's own begin-to-end time. rocprofv3's --stats average of this command mixes launch sizes (stream sweep) and "
                            "time-shared launches (three sub-batches); the like-for-like check is a one-sub-batch command whose last launches are the timed "
-                           "ones (--streams 6144 --pipeline 1 --no-outputs-resident, no other legs): events 691 us against 685 us for the same 20 launches in "
-                           "rocprofv3's trace (profiles/r06c_NS_one_subbatch_last20.txt, tools/last_launches_avg.py)")
+                           "ones (--streams 6144 --pipeline 1 --no-outputs-resident, no other legs): events 692 us against 686 us for the same 20 launches in "
+                           "rocprofv3's trace (profiles/r06e_NS_one_subbatch_last20.txt, tools/last_launches_avg.py)")
     bytes_per_launch = st["bytes"] / launches
     if fam == "cosine" and st["flops"] > 0:
         achieved = st["flops"] / launches / (avg_ms * 1e-3) / 1e12

@@ -7,7 +7,9 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -130,6 +132,20 @@ extern "C" int motcpp_bench_threads_ex(int kind, const float* params, int nparam
   const double n_timed = static_cast<double>(T) * (frames - warm);
   out5[0] = std::chrono::duration<double>(last - first).count();
   out5[1] = n_timed; out5[2] = static_cast<double>(r); out5[3] = ls / n_timed; out5[4] = lm;
+  if (lat_pct && std::getenv("MOTCPP_BENCH_SPIKES")) {
+    // diagnostic: the calls slower than 2 ms — whole rounds (every object at the same frame) or single callers?
+    std::map<int, int> per_frame;
+    int spikes = 0;
+    float worst = 0.f;
+    const float thr = std::atof(std::getenv("MOTCPP_BENCH_SPIKES")) > 0.0 ? static_cast<float>(std::atof(std::getenv("MOTCPP_BENCH_SPIKES"))) : 2.0f;
+    for (int t = 0; t < T; ++t)
+      for (size_t k = 0; k < lats[t].size(); ++k)
+        if (lats[t][k] > thr) { per_frame[static_cast<int>(k)] += 1; spikes += 1; if (lats[t][k] > worst) worst = lats[t][k]; }
+    std::fprintf(stderr, "[bench_threads] T %d: %d calls of %zu over %.2f ms (worst %.1f ms) in %zu distinct frames:", T, spikes, static_cast<size_t>(T) * lats[0].size(), thr, worst, per_frame.size());
+    int shown = 0;
+    for (const auto& kv : per_frame) { if (shown++ < 24) std::fprintf(stderr, " f%d x%d", kv.first, kv.second); }
+    std::fprintf(stderr, "\n");
+  }
   if (lat_pct) {
     std::vector<float> all;
     for (auto& v : lats) all.insert(all.end(), v.begin(), v.end());

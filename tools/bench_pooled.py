@@ -28,12 +28,16 @@ def main():
     counts = np.full((Tmax, F), M, np.int32)
     out = {}
     timed = int(__import__("os").environ.get("MOT_POOLED_TIMED_FRAMES", "300"))  # timed update() calls per object (the F frames played back and forth)
+    ctx = L.Context(0)
     for T in Ts:
         L.pool_stats(reset=True)
+        ctx.lap_fast_stats(reset=True)
         t0 = time.time()
         res, _ = L.bench_threads(kind, dets[:T], counts[:T], warm, frames=warm + timed)
         res["wall_s"] = round(time.time() - t0, 3)
         res["pool"] = L.pool_stats()
+        fs = ctx.lap_fast_stats()  # (device-wide counters of the assignment fast path: a declined problem goes to the exact kernel, 2.3 ms at this shape, and its round waits)
+        res["assignments"] = {"fast_path": fs["fast"], "declined": sum(v for k, v in fs.items() if k.startswith("declined") or k in ("search_too_large", "certificate_arith", "too_many_tight", "not_unique"))}
         out[f"T{T}"] = res
         print(name, "T =", T, json.dumps(res), file=sys.stderr, flush=True)
     print(json.dumps({"workload": name, "shape": [P, M], "frames": F, "warm": warm, "basetracker_update": out}))

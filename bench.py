@@ -749,15 +749,21 @@ def main():
                 for T in [t for t in (1, 16, 64, 256, 1024) if t <= S]:
                     dd = np.ascontiguousarray(host[:Fb, :T].transpose(1, 0, 2, 3))
                     L.pool_stats(reset=True)
+                    fctx = L.Context(local)
+                    fctx.lap_fast_stats(reset=True)
                     # 300 timed update() calls per object (the resident frames played back and forth), p50 / p99 of their latencies
                     res, _cs = L.bench_threads(tracker, dd, np.full((T, Fb), M, np.int32), warm=zs, device=local, frames=zs + 300)
                     ps_ = L.pool_stats()
+                    fs_ = fctx.lap_fast_stats()  # a declined assignment goes to the exact kernel (2.3 ms at the north-star shape) and its whole round waits: that is the p99
+                    declined_ = sum(v for k, v in fs_.items() if k.startswith("declined") or k in ("search_too_large", "certificate_arith", "too_many_tight", "not_unique"))
                     bt_sweep[f"T{T}"] = {"frames/s": res["frames_per_s"], "ms_per_update_p50": res["latency_ms_p50"], "ms_per_update_p99": res["latency_ms_p99"],
                                          "ms_per_update_mean": res["latency_ms_mean"], "ms_per_update_max": res["latency_ms_max"],
-                                         "frames_timed": res["frames"], "launch_sequences": ps_["rounds"], "largest_round": ps_["max_round"]}
+                                         "frames_timed": res["frames"], "launch_sequences": ps_["rounds"], "largest_round": ps_["max_round"],
+                                         "assignments_fast_path": fs_["fast"], "assignments_declined_to_the_exact_kernel": declined_}
                 bt_sweep["note"] = ("T objects of motcpp::trackers::" + {"bytetrack": "ByteTrack", "sort": "Sort", "ocsort": "OCSort"}[tracker] + " on T host threads, "
                                     "update(dets, img) with HOST detections (Eigen matrices; PCIe, the combiner's batching window and the copy of the result "
-                                    f"table included), {zs} untimed frames first; launch_sequences = rounds the combiner ran for all frames of the leg")
+                                    f"table included), {zs} untimed frames first; launch_sequences = rounds the combiner ran for all frames of the leg; the p99 is decided by the rounds that "
+                                    "wait for a declined assignment (DESIGN.md section 9)")
             except Exception as e:  # (diagnostic leg: never loses the line)
                 bt_sweep["error"] = repr(e)
             sweep["basetracker_update"] = bt_sweep

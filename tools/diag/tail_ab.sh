@@ -1,17 +1,7 @@
 cd /root/repo
-python - <<'P'
-import sys, json
-sys.path.insert(0, ".")
-import numpy as np
-from motcpp_amd import _lib as L
-from motcpp_amd.synth import SynthStream
-ctx = L.Context(0)
-P, M, F, warm = 1000, 500, 70, 40
-base = [SynthStream(P, M, 1234 + t).frames(F)[0] for t in range(32)]
-dets = np.stack(base)
-counts = np.full((32, F), M, np.int32)
-ctx.lap_fast_stats(reset=True)
-res, _ = L.bench_threads("bytetrack", dets, counts, warm, frames=warm + 300)
-fs = ctx.lap_fast_stats()
-print({k: v for k, v in fs.items() if not k.startswith("cycles") and v})
-P
+timeout 600 python bench.py --no-cpu-baseline --long-run-steps 0 --host-input-steps 0 --isolated-steps 0 --parity-streams 0 2>/dev/null | python -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); b=j['stream_sweep']['basetracker_update']
+print(round(j['value']))
+for k,v in b.items():
+    if isinstance(v,dict): print(k, round(v['frames/s']), round(v['ms_per_update_p50'],2), round(v['ms_per_update_p99'],2), v['assignments_fast_path'], v['assignments_declined_to_the_exact_kernel'])"

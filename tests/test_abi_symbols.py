@@ -49,3 +49,23 @@ def test_no_cpu_fallback_without_a_device(libs):
         _lib.Context(0)
     with pytest.raises(_lib.MotError):
         _lib.Tracker("bytetrack")
+
+
+def test_the_tools_mirror_of_mot_kf_task_has_the_struct_s_size(tmp_path):
+    """tools/kf_update_microbench.py builds arrays of mot_kf_task with ctypes: a field appended to the struct (round 6: mean_dense, cov_blocks,
+    dense_flag, meas4) and not to the mirror makes the kernels read every task after the first from the wrong offset — the microbench aborted that way
+    once. sizeof from the header, compiled by gcc, against the mirror."""
+    import importlib.util
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "motcpp_amd.h"\nint main(void) { printf("%zu\\n", sizeof(mot_kf_task)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)])
+    want = int(subprocess.check_output([str(exe)]).decode().strip())
+    text = open(os.path.join(root, "tools", "kf_update_microbench.py")).read()
+    ns = {}
+    start = text.index("class KfTask")
+    end = text.index("\n\n\n", start)
+    exec("import ctypes as C\n" + text[start:end], ns)  # (the class only: importing the tool would load the library and look for a GPU)
+    assert ctypes.sizeof(ns["KfTask"]) == want
